@@ -1,0 +1,78 @@
+"""Helpers to load the golden fixtures written by oracle/gen_golden.py."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle.mol_oracle import MoLConfig, hash_item_table
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PER_CONFIG = ["c1_ml1m", "c2_ml20m", "c3_books", "c4_16x16x64"]
+
+
+class Fixture:
+    def __init__(self, name: str):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        d = json.loads(str(self.z["cfg_json"]))
+        d["uid_embedding_hash_sizes"] = tuple(d["uid_embedding_hash_sizes"])
+        self.cfg = MoLConfig(**d)
+        self.weights = self._weights()
+
+    def _weights(self):
+        w = {k[2:]: torch.from_numpy(self.z[k]) for k in self.z.files if k.startswith("w/")}
+        # uid tables are stored sliced to the rows used; expand back to (hash_size + 1, d)
+        for i, hs in enumerate(self.cfg.uid_embedding_hash_sizes):
+            key = f"_query_embeddings_fn._uid_embeddings_{i}.weight"
+            rows = w.pop(key + ".rows")
+            full = torch.zeros((hs + 1, self.cfg.dot_product_dimension), dtype=torch.float32)
+            full[rows] = w[key]
+            w[key] = full
+        return w
+
+    def t(self, key: str) -> torch.Tensor:
+        return torch.from_numpy(np.asarray(self.z[key]))
+
+    def has(self, key: str) -> bool:
+        return key in self.z.files
+
+    @property
+    def kw(self):
+        return {"user_ids": self.t("user_ids")} if self.has("user_ids") else {}
+
+    @property
+    def user_ids(self):
+        return self.t("user_ids") if self.has("user_ids") else None
+
+
+def full_size_inputs(fx: Fixture):
+    """Rebuild the by-recipe inputs of the F7 fixtures (oracle/gen_golden.py:full_size_fixture)."""
+    n = int(fx.z["N"])
+    X = torch.from_numpy(hash_item_table(int(fx.z["table_seed"]), 0, n, fx.cfg.item_embedding_dim)).unsqueeze(0)
+    g = torch.Generator().manual_seed(int(fx.z["item_ids_seed"]))
+    ids = torch.cumsum(torch.randint(1, 4, (n,), generator=g), 0).to(torch.int64).unsqueeze(0)
+    return X, ids
+
+
+def assert_topk_matches(scores, ids, ref_scores, ref_ids, atol=1e-4, tie_tol=2e-5):
+    """Tie-aware comparison: scores within `atol`; ids identical except inside groups of
+    reference scores closer than `tie_tol` (torch.topk's order among ties is unspecified)."""
+    scores, ids, ref_scores, ref_ids = (torch.as_tensor(x).cpu() for x in (scores, ids, ref_scores, ref_ids))
+    assert scores.shape == ref_scores.shape and ids.shape == ref_ids.shape
+    assert torch.allclose(scores, ref_scores, atol=atol, rtol=0), float((scores - ref_scores).abs().max())
+    B, k = ids.shape
+    for b in range(B):
+        if torch.equal(ids[b], ref_ids[b]):
+            continue
+        # split the row into runs of near-equal reference scores and compare each run as a set;
+        # the boundary run may exchange members with items just outside the top-k
+        rs = ref_scores[b]
+        start = 0
+        for j in range(1, k + 1):
+            if j == k or (rs[j - 1] - rs[j]) > tie_tol:
+                a, r = set(ids[b, start:j].tolist()), set(ref_ids[b, start:j].tolist())
+                if a != r:
+                    assert j == k, f"row {b}: ids differ outside a tie group at [{start},{j})"
+                    assert (rs[start] - rs[k - 1]) <= tie_tol
+                start = j
