@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Headline benchmark: queries/sec of exact MoL top-k (BASELINE.json metric) on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (config.workload): amzn-books HSTU+MoL 8x8x32, N = 695 762 items, B = 32 queries per batch --
+the configuration BASELINE.json's target is quoted on (">=10x the reference CPU queries/sec on amzn-books
+8x8x32 MoL exact top-k at 1 GPU") and the largest of the real-dataset shapes; it fits one GPU.
+One step = one pass of the hot path over one batch, the reference's timing protocol
+(data/eval.py:128-170): CandidateIndex.get_top_k_outputs(k=120, truncate_k_prime_to=200) with the
+seen-id filter on = query prologue -> fused MoL scoring of all N items -> exact top-200 -> id map ->
+seen-id filter.  Inputs (item index, weights, queries, seen ids) are resident in HBM before the timed
+region.  For N > 1 the corpus is sharded by item id (strong scaling: total N fixed) and the per-shard
+top-k are merged after one RCCL all-gather.
+
+Synthetic data: random-init weights with the reference's initialisers, counter-hash item table, LayerNorm'd
+Gaussian queries; trained checkpoints / datasets are git-LFS pointers in the reference.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import rails_amd  # noqa: E402
+from rails_amd import engine as E  # noqa: E402
+from rails_amd.sharded import ShardedMoLBruteForceTopK, shard_bounds  # noqa: E402
+
+WORKLOADS = {
+    # name: (oracle config key, N, seen-id width)
+    "amzn-books": ("amzn-books", 695762, 61),
+    "ml-20m": ("ml-20m", 27278, 211),
+    "ml-1m": ("ml-1m", 3883, 211),
+}
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBPS = 8000.0
+
+
+def flops_per_pair(cfg) -> int:
+    """2*L*d (sub-embedding contraction) + 4*L*H (pair-gate MLP) + 12*L (combine/softmax/mix)."""
+    L = cfg.query_dot_product_groups * cfg.item_dot_product_groups
+    return 2 * L * cfg.dot_product_dimension + 4 * L * cfg.gating_qi_hidden_dim + 12 * L
+
+
+def bytes_per_item_fp32(cfg) -> int:
+    """fp32 index: (P_X*d + L) * 4 bytes per item, streamed once per batch."""
+    L = cfg.query_dot_product_groups * cfg.item_dot_product_groups
+    return (cfg.item_dot_product_groups * cfg.dot_product_dimension + L) * 4
+
+
+def cpu_baseline(cfg, weights, q, user_ids, n_total: int, sample_items: int, k_prime: int):
+    """The oracle (CPU restatement of the reference path, torch-CPU fp32, all host threads) on a bounded
+    sample: all B queries against the first `sample_items` items, scaled linearly to N (the path is linear
+    in N; top-k is <0.1 % of CPU time)."""
+    from oracle import mol_oracle as O
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    X = torch.from_numpy(O.hash_item_table(1, 0, sample_items, cfg.item_embedding_dim)).unsqueeze(0)
+    ids = torch.arange(1, sample_items + 1, dtype=torch.int64).unsqueeze(0)
+    B = q.shape[0]
+    O.brute_force_topk(cfg, weights, q[:2], X[:, :2048], ids[:, :2048], 10, None if user_ids is None else user_ids[:2])  # warm-up
+    t0 = time.perf_counter()
+    O.brute_force_topk(cfg, weights, q, X, ids, min(k_prime, sample_items), user_ids, chunk=4096)
+    dt = time.perf_counter() - t0
+    qps = B / (dt * (n_total / sample_items))
+    return {
+        "value": qps,
+        "unit": "queries/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"B={B} queries x first {sample_items} of {n_total} items, 1 timed pass ({dt:.1f} s), scaled linearly in N",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="amzn-books", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--k", type=int, default=120)
+    ap.add_argument("--k-prime", type=int, default=200)
+    ap.add_argument("--cpu-sample-items", type=int, default=20000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from oracle import mol_oracle as O  # inputs generator + cpu_baseline checker only
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg_key, N, width = WORKLOADS[args.workload]
+    cfg = O.CONFIGS[cfg_key]
+    B, k, kp = args.batch, args.k, args.k_prime
+    weights = O.synthetic_weights(cfg, seed=0)
+    mol, _ = rails_amd.create_mol_interaction_module(
+        cfg.query_embedding_dim, cfg.item_embedding_dim, cfg.dot_product_dimension, cfg.query_dot_product_groups,
+        cfg.item_dot_product_groups, cfg.temperature, 0.0, cfg.query_hidden_dim, 0.1, cfg.item_hidden_dim,
+        cfg.gating_query_hidden_dim, cfg.gating_qi_hidden_dim, cfg.gating_item_hidden_dim, cfg.softmax_dropout_rate, False,
+        query_nonlinearity=cfg.query_nonlinearity, uid_embedding_hash_sizes=list(cfg.uid_embedding_hash_sizes) or None)
+    mol.load_state_dict(weights, strict=True)
+    mol = mol.to(dev).eval()
+
+    lo, hi = shard_bounds(N, world, rank)
+    X = torch.from_numpy(O.hash_item_table(1, lo, hi - lo, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = torch.arange(lo + 1, hi + 1, dtype=torch.int64, device=dev).unsqueeze(0)  # 1-based item ids
+    q_cpu = O.synthetic_queries(cfg, B)
+    q = q_cpu.to(dev)
+    uid_cpu = None
+    kw = {}
+    if len(cfg.uid_embedding_hash_sizes) > 0:
+        g = torch.Generator().manual_seed(3)
+        uid_cpu = torch.randint(0, cfg.uid_embedding_hash_sizes[0], (B,), generator=g, dtype=torch.int64)
+        kw["user_ids"] = uid_cpu.to(dev)
+
+    with torch.inference_mode():
+        t0 = time.perf_counter()
+        topk_mod = ShardedMoLBruteForceTopK(mol, X, ids, N)
+        torch.cuda.synchronize()
+        index_build_s = time.perf_counter() - t0
+        local = topk_mod._local_module
+        eng = local._bind()
+        # seen ids: half of each row's own top-k' (so the filter has work) + zero padding
+        _, top_ids = topk_mod(q, k=min(kp, N), **kw)
+        inv = torch.zeros((B, width), dtype=torch.int64, device=dev)
+        g = torch.Generator().manual_seed(4)
+        for b in range(B):
+            sel = torch.randperm(top_ids.shape[1], generator=g)[: width // 2].to(dev)
+            inv[b, : width // 2] = top_ids[b, sel]
+        cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)
+
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+        logits = torch.empty((B, hi - lo), dtype=torch.float32, device=dev)
+
+        def step(i=None):
+            """get_top_k_outputs with the scoring launch bracketed by events on the launch stream."""
+            qpack, _, _ = eng.query_pack(q, kw.get("user_ids"))
+            if i is not None:
+                ev0[i].record()
+            eng.score_dense(qpack, B, local._index, out=logits)
+            if i is not None:
+                ev1[i].record()
+            k_local = min(kp, hi - lo)
+            s, top = E.topk(logits, k_local, ids=local._ids_flat)
+            if world > 1:
+                from rails_amd.sharded import pack_candidates, unpack_candidates
+                import torch.distributed as dist
+
+                msg = pack_candidates(s, top, kp)
+                gathered = torch.empty((world,) + tuple(msg.shape), dtype=msg.dtype, device=dev)
+                dist.all_gather_into_tensor(gathered, msg)
+                all_s, all_i = unpack_candidates(gathered, kp)
+                s, top = E.topk(all_s, kp, ids=all_i)
+            return E.filter_seen_ids(top, s, inv, k)
+
+        # sanity: the decomposed step equals the module API
+        ref_ids, ref_scores, _ = cand.get_top_k_outputs(q, k, kw, topk_mod, inv, truncate_k_prime_to=kp)
+        got_ids, got_scores = step()
+        assert torch.equal(ref_ids, got_ids) and torch.equal(ref_scores, got_scores)
+
+        for _ in range(args.warmup):
+            step()
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    score_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+    n_shard = hi - lo
+    flops_alg = B * n_shard * flops_per_pair(cfg)
+    achieved = flops_alg / (score_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            try:
+                rec = json.load(open(pmc)).get(f"{args.workload}:B{B}:gpus{world}")
+                traffic = rec and rec.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "queries/sec, MoL exact top-k over N items (get_top_k_outputs: score + top-k' + id map + seen-id filter)",
+            "value": B * args.steps / elapsed,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload} HSTU+MoL {cfg.query_dot_product_groups}x{cfg.item_dot_product_groups}x{cfg.dot_product_dimension}, N={N} items, exact brute-force top-k",
+                "global_batch": B, "k": k, "k_prime": kp, "seen_id_width": width, "n_items": N,
+                "parallelism": f"item-shard x{world}" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "kernel": "mol_score_kernel",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": PEAK_F32_MFMA_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
+                "traffic": traffic,
+                "kernel_ms": score_ms,
+                "flops_per_launch": flops_alg,
+                "hbm_bytes_alg_per_launch": n_shard * bytes_per_item_fp32(cfg),
+                "hbm_frac": n_shard * bytes_per_item_fp32(cfg) / (score_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+            },
+            "index_build_s": index_build_s,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, weights, q_cpu, uid_cpu, N, min(args.cpu_sample_items, N), kp)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

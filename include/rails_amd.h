@@ -1,0 +1,163 @@
+/* rails_amd — C ABI of the MI355X-native Mixture-of-Logits (MoL) retrieval path.
+ *
+ * The reference (bailuding/rails) is pure Python/PyTorch and has no FFI of its own; the "interface
+ * each entry point replaces" is therefore a Python call site of the reference, cited per function as
+ * `path:line` inside the reference repository.  INTEGRATION.md shows the ctypes binding a maintainer
+ * adds on the reference side.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM of the current HIP device) unless stated otherwise;
+ *     matrices are dense row-major exactly as the reference's state_dict() / tensors hold them;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     every call only enqueues work on it: no allocation, no synchronisation, no host copies;
+ *   - return value 0 on success, a negative RAILS_E* code otherwise; rails_last_error() returns
+ *     a thread-local human-readable message for the last failure;
+ *   - packed buffers (`gate pack`, `item index`, `query pack`) are opaque fp32 blobs whose sizes
+ *     come from the *_floats() helpers; they are only valid for the shape they were built for.
+ */
+#ifndef RAILS_AMD_H_
+#define RAILS_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RAILS_OK 0
+#define RAILS_EINVAL (-22)       /* bad argument (null pointer, non-positive size, k > n ...) */
+#define RAILS_ENOTSUP (-95)      /* shape / option outside what the HIP kernels implement */
+#define RAILS_ENOMEM (-12)       /* caller-provided workspace too small */
+#define RAILS_ELAUNCH (-5)       /* HIP launch failure (message carries hipGetErrorString) */
+
+#define RAILS_GEGLU 0
+#define RAILS_SWIGLU 1
+#define RAILS_MAX_UID_TABLES 4
+
+/* Hyper-parameters of one MoL module; field names follow create_mol_interaction_module
+ * (modeling/similarity_utils.py:42-70). */
+typedef struct rails_mol_shape {
+  int32_t query_embedding_dim;
+  int32_t item_embedding_dim;
+  int32_t dot_product_dimension;      /* d */
+  int32_t query_dot_product_groups;   /* P_Q */
+  int32_t item_dot_product_groups;    /* P_X */
+  int32_t query_hidden_dim;           /* GLU width of the query projection (512); must be > 0 */
+  int32_t gating_query_hidden_dim;    /* 128 */
+  int32_t gating_item_hidden_dim;     /* 128 */
+  int32_t gating_qi_hidden_dim;       /* 128 */
+  int32_t query_nonlinearity;         /* RAILS_GEGLU | RAILS_SWIGLU */
+  int32_t num_uid_tables;             /* len(uid_embedding_hash_sizes) */
+  int32_t dot_product_l2_norm;        /* 0 | 1 */
+  float temperature;                  /* 0.05 */
+  float eps;                          /* 1e-6 */
+} rails_mol_shape;
+
+/* Raw module weights, one pointer per state_dict() tensor (SURVEY.md section 8b lists the keys). */
+typedef struct rails_mol_weights {
+  const float* q_glu_w;   /* _query_embeddings_fn._query_emb_proj_module.1._w   (D_q, 2*query_hidden) */
+  const float* q_glu_b;   /* ...1._b                                            (2*query_hidden)      */
+  const float* q_proj_w;  /* ...2.weight                            (d*(P_Q-u), query_hidden)         */
+  const float* q_proj_b;  /* ...2.bias                                                                */
+  const float* uid_table[RAILS_MAX_UID_TABLES];  /* _uid_embeddings_{i}.weight   (hash_i + 1, d)       */
+  int64_t uid_hash_size[RAILS_MAX_UID_TABLES];
+  const float* i_proj_w;  /* _item_embeddings_fn._item_emb_proj_module.1.weight  (P_X*d, D_i)         */
+  const float* i_proj_b;
+  const float* gq_w1;     /* _gating_fn._query_only_partial_module.0.weight      (H_q, D_q)           */
+  const float* gq_b1;
+  const float* gq_w2;     /* ...2.weight                                          (L, H_q)            */
+  const float* gi_w1;     /* _gating_fn._item_only_partial_module.1.weight       (H_i, D_i)           */
+  const float* gi_b1;
+  const float* gi_w2;     /* ...3.weight                                          (L, H_i)            */
+  const float* gqi_w1;    /* _gating_fn._qi_partial_module.1.weight              (H, L)               */
+  const float* gqi_b1;
+  const float* gqi_w2;    /* ...3.weight                                          (L, H)              */
+  const float* gqi_b2;
+} rails_mol_weights;
+
+/* Thread-local message of the last failed call ("" if none). */
+const char* rails_last_error(void);
+
+/* Library / device probe: number of compute units of the current device (256 on MI355X), or < 0. */
+int rails_device_compute_units(void);
+
+/* 1 if the fused scoring kernel is compiled for this shape, else 0 (rails_last_error() says why). */
+int rails_mol_shape_supported(const rails_mol_shape* shape);
+
+/* ---- index build -----------------------------------------------------------------------------
+ * Replaces what MoLTopKModule.__init__ (rails/indexing/mol_top_k.py:29-81) keeps per corpus, plus the
+ * item-side work the reference redoes on every forward: RecoMoLItemEmbeddingsFn.forward
+ * (rails/similarities/mol/item_embeddings_fns.py:149-183) and the item-only gate
+ * (rails/similarities/mol/similarity_fn.py:170-171). */
+
+/* fp32 count of the packed pair-gate weights. */
+size_t rails_mol_gate_pack_floats(const rails_mol_shape* shape);
+/* Permute the pair-gate MLP (gqi_*) into MFMA fragment order. */
+int rails_mol_pack_gate_weights(const rails_mol_shape* shape, const rails_mol_weights* w, float* gate_pack,
+                                void* stream);
+
+/* fp32 count of the item index for n_items items (tiles of 32 items, last tile zero padded). */
+size_t rails_mol_index_floats(const rails_mol_shape* shape, int64_t n_items);
+/* items: (n_items, D_i) row-major.  Writes component embeddings Ex (l2-normalised) and the item gate gi
+ * of every item into `index` in tile/fragment order. */
+int rails_mol_index_build(const rails_mol_shape* shape, const rails_mol_weights* w, const float* items,
+                          int64_t n_items, float* index, void* stream);
+/* Inverse view for accessors/tests: plain Ex (n_items, P_X, d) and/or gi (n_items, L); either may be NULL.
+ * Mirrors MoLSimilarity.get_item_component_embeddings (similarity_fn.py:294-339). */
+int rails_mol_index_unpack(const rails_mol_shape* shape, const float* index, int64_t n_items, float* ex_out,
+                           float* gi_out, void* stream);
+/* Gather rows of an index into a new tile-packed index: out tile layout over `n_rows * n_cand` items
+ * taken at cand_idx[r * n_cand + j] (positions in `index`, int64).  n_cand must be a multiple of 32.
+ * Replaces self._item_embeddings[idx] (mol_top_k.py:361-363) for the rerank pass. */
+int rails_mol_index_gather(const rails_mol_shape* shape, const float* index, int64_t n_items,
+                           const int64_t* cand_idx, int64_t n_rows, int64_t n_cand, float* out_index,
+                           void* stream);
+
+/* ---- query side ------------------------------------------------------------------------------
+ * Replaces RecoMoLQueryEmbeddingsFn.forward (rails/similarities/mol/query_embeddings_fns.py:175-254,
+ * GLU at rails/similarities/layers.py:19-74) and the query-only gate (similarity_fn.py:166-169). */
+size_t rails_mol_query_pack_floats(const rails_mol_shape* shape, int32_t batch);
+/* queries: (batch, D_q); user_ids: (batch) int64 or NULL when num_uid_tables == 0.
+ * eq_out (batch, P_Q, d) and gq_out (batch, L) are optional plain copies (NULL to skip). */
+int rails_mol_query_prologue(const rails_mol_shape* shape, const rails_mol_weights* w, const float* queries,
+                             const int64_t* user_ids, int32_t batch, float* query_pack, float* eq_out,
+                             float* gq_out, void* stream);
+
+/* ---- scoring ---------------------------------------------------------------------------------
+ * Replaces MoLSimilarity.forward for the shared-corpus case (similarity_fn.py:341-413, B' == 1):
+ * logits[b * ld + x] for b < batch, x < n_items. */
+int rails_mol_score_dense(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack,
+                          int32_t batch, const float* index, int64_t n_items, float* logits, int64_t ld,
+                          void* stream);
+/* Per-row candidates (B' == B branch, similarity_fn.py:397-402): `cand_index` was produced by
+ * rails_mol_index_gather with n_rows == batch; logits[b * ld + j] for j < n_cand. */
+int rails_mol_score_candidates(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack,
+                               int32_t batch, const float* cand_index, int64_t n_cand, float* logits,
+                               int64_t ld, void* stream);
+
+/* ---- exact top-k -----------------------------------------------------------------------------
+ * Replaces torch.topk(all_logits, dim=1, k, sorted, largest=True) + the id gather
+ * (rails/indexing/mol_top_k.py:123-130).  Row b reads scores[b * ld + 0..n).  Ties are broken by
+ * position ascending, so results are deterministic and identical for any sharding of the corpus.
+ * If `ids` is non-NULL, out_ids[b][j] = ids[ids_row_stride * b + pos] (ids_row_stride 0 = one shared
+ * id row, the reference's item_ids.squeeze(0)); else out_ids holds positions.
+ * `sorted` == 0 still returns the exact top-k set (in descending order; unordered is a subset of valid
+ * answers). */
+size_t rails_topk_workspace_bytes(int32_t rows, int64_t n, int32_t k);
+int rails_topk(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t k, int32_t sorted,
+               const int64_t* ids, int64_t ids_row_stride, float* out_scores, int64_t* out_ids,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- seen-id filter --------------------------------------------------------------------------
+ * Replaces the row-wise masking of CandidateIndex.get_top_k_outputs (indexing/candidate_index.py:154-178):
+ * keep the first k ids of each row of (rows, k_prime) that do not occur in invalid_ids (rows, width),
+ * back-filling from the filtered-out ones (in order) when fewer than k survive. */
+int rails_filter_seen_ids(const int64_t* top_ids, const float* top_scores, int32_t rows, int32_t k_prime,
+                          const int64_t* invalid_ids, int32_t width, int32_t k, int64_t* out_ids,
+                          float* out_scores, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAILS_AMD_H_ */

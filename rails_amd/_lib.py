@@ -1,0 +1,153 @@
+"""ctypes binding of librails_amd.so (the C ABI declared in include/rails_amd.h).
+
+There is no fallback: if the shared library is missing or a call fails, this module raises.
+Build it with `python -c "import __graft_entry__ as g; g.build()"` or `make -C rails_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librails_amd.so")
+
+RAILS_OK = 0
+RAILS_EINVAL = -22
+RAILS_ENOTSUP = -95
+RAILS_ENOMEM = -12
+RAILS_ELAUNCH = -5
+RAILS_GEGLU = 0
+RAILS_SWIGLU = 1
+RAILS_MAX_UID_TABLES = 4
+
+_f32p = C.POINTER(C.c_float)
+
+
+class MolShape(C.Structure):
+    _fields_ = [
+        ("query_embedding_dim", C.c_int32),
+        ("item_embedding_dim", C.c_int32),
+        ("dot_product_dimension", C.c_int32),
+        ("query_dot_product_groups", C.c_int32),
+        ("item_dot_product_groups", C.c_int32),
+        ("query_hidden_dim", C.c_int32),
+        ("gating_query_hidden_dim", C.c_int32),
+        ("gating_item_hidden_dim", C.c_int32),
+        ("gating_qi_hidden_dim", C.c_int32),
+        ("query_nonlinearity", C.c_int32),
+        ("num_uid_tables", C.c_int32),
+        ("dot_product_l2_norm", C.c_int32),
+        ("temperature", C.c_float),
+        ("eps", C.c_float),
+    ]
+
+
+class MolWeights(C.Structure):
+    _fields_ = [
+        ("q_glu_w", C.c_void_p),
+        ("q_glu_b", C.c_void_p),
+        ("q_proj_w", C.c_void_p),
+        ("q_proj_b", C.c_void_p),
+        ("uid_table", C.c_void_p * RAILS_MAX_UID_TABLES),
+        ("uid_hash_size", C.c_int64 * RAILS_MAX_UID_TABLES),
+        ("i_proj_w", C.c_void_p),
+        ("i_proj_b", C.c_void_p),
+        ("gq_w1", C.c_void_p),
+        ("gq_b1", C.c_void_p),
+        ("gq_w2", C.c_void_p),
+        ("gi_w1", C.c_void_p),
+        ("gi_b1", C.c_void_p),
+        ("gi_w2", C.c_void_p),
+        ("gqi_w1", C.c_void_p),
+        ("gqi_b1", C.c_void_p),
+        ("gqi_w2", C.c_void_p),
+        ("gqi_b2", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes): one entry per declaration in include/rails_amd.h
+_SHAPE_P = C.POINTER(MolShape)
+_WEIGHTS_P = C.POINTER(MolWeights)
+PROTOTYPES = {
+    "rails_last_error": (C.c_char_p, []),
+    "rails_device_compute_units": (C.c_int, []),
+    "rails_mol_shape_supported": (C.c_int, [_SHAPE_P]),
+    "rails_mol_gate_pack_floats": (C.c_size_t, [_SHAPE_P]),
+    "rails_mol_pack_gate_weights": (C.c_int, [_SHAPE_P, _WEIGHTS_P, C.c_void_p, C.c_void_p]),
+    "rails_mol_index_floats": (C.c_size_t, [_SHAPE_P, C.c_int64]),
+    "rails_mol_index_build": (C.c_int, [_SHAPE_P, _WEIGHTS_P, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "rails_mol_index_unpack": (C.c_int, [_SHAPE_P, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rails_mol_index_gather": (
+        C.c_int,
+        [_SHAPE_P, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p],
+    ),
+    "rails_mol_query_pack_floats": (C.c_size_t, [_SHAPE_P, C.c_int32]),
+    "rails_mol_query_prologue": (
+        C.c_int,
+        [_SHAPE_P, _WEIGHTS_P, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
+    "rails_mol_score_dense": (
+        C.c_int,
+        [_SHAPE_P, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p],
+    ),
+    "rails_mol_score_candidates": (
+        C.c_int,
+        [_SHAPE_P, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p],
+    ),
+    "rails_topk_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int64, C.c_int32]),
+    "rails_topk": (
+        C.c_int,
+        [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
+    ),
+    "rails_filter_seen_ids": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+         C.c_void_p],
+    ),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+class RailsAmdError(RuntimeError):
+    """A call into librails_amd.so failed (message from rails_last_error())."""
+
+
+def load() -> C.CDLL:
+    """Load librails_amd.so once.  Fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is not built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C rails_amd/csrc`). "
+            "rails_amd has no CPU or PyTorch fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return (load().rails_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(code: int, what: str) -> None:
+    """Turn a RAILS_E* code into the exception the reference raises in the same situation."""
+    if code == RAILS_OK:
+        return
+    msg = f"{what}: {last_error()} (code {code})"
+    if code == RAILS_EINVAL:
+        raise ValueError(msg)
+    if code == RAILS_ENOTSUP:
+        raise NotImplementedError(msg)
+    if code == RAILS_ENOMEM:
+        raise MemoryError(msg)
+    raise RailsAmdError(msg)

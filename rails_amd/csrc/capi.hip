@@ -1,0 +1,245 @@
+// extern "C" entry points declared in include/rails_amd.h: argument validation + dispatch.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "mol_kernels.h"
+#include "mol_layout.h"
+
+namespace mol {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static int fail(int code, const char* what) {
+  if (code == kErrLaunch) {
+    const hipError_t e = hipGetLastError();
+    set_error("%s: HIP launch failed (%s)", what, hipGetErrorString(e));
+  } else if (g_err[0] == '\0' || code == kErrInvalid) {
+    if (g_err[0] == '\0') set_error("%s: error %d", what, code);
+  }
+  return code;
+}
+
+static bool shape_ok(const Shape* s) {
+  if (!s) { set_error("shape is NULL"); return false; }
+  if (s->query_embedding_dim <= 0 || s->item_embedding_dim <= 0 || s->dot_product_dimension <= 0 ||
+      s->query_dot_product_groups <= 0 || s->item_dot_product_groups <= 0) {
+    set_error("shape has a non-positive dimension");
+    return false;
+  }
+  if (s->num_uid_tables < 0 || s->num_uid_tables > RAILS_MAX_UID_TABLES ||
+      s->num_uid_tables >= s->query_dot_product_groups) {
+    set_error("num_uid_tables = %d out of range", s->num_uid_tables);
+    return false;
+  }
+  if (!(s->temperature > 0.0f)) { set_error("temperature must be > 0"); return false; }
+  return true;
+}
+
+static bool shape_supported(const Shape* s) {
+  if (!shape_ok(s)) return false;
+  if (s->query_hidden_dim <= 0 || s->gating_query_hidden_dim <= 0 || s->gating_item_hidden_dim <= 0) {
+    set_error("query_hidden_dim / gating hidden dims must be > 0 (plain-Linear variants are not built)");
+    return false;
+  }
+  if (!score_supported(*s)) {
+    set_error("no fused scoring kernel for P_Q x P_X x d = %dx%dx%d with gating_qi_hidden_dim = %d "
+              "(built: 8x4x64, 8x4x128, 8x8x32 with 128)",
+              s->query_dot_product_groups, s->item_dot_product_groups, s->dot_product_dimension,
+              s->gating_qi_hidden_dim);
+    return false;
+  }
+  return true;
+}
+
+static int compute_units() {
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+  return n;
+}
+
+}  // namespace mol
+
+using namespace mol;
+
+extern "C" {
+
+const char* rails_last_error(void) { return g_err; }
+
+int rails_device_compute_units(void) {
+  const int n = compute_units();
+  if (n < 0) { set_error("no HIP device"); return RAILS_ELAUNCH; }
+  return n;
+}
+
+int rails_mol_shape_supported(const rails_mol_shape* shape) { return shape_supported(shape) ? 1 : 0; }
+
+size_t rails_mol_gate_pack_floats(const rails_mol_shape* s) {
+  if (!shape_ok(s)) return 0;
+  const size_t H = (size_t)s->gating_qi_hidden_dim, L = (size_t)num_logits(*s);
+  return 2 * H * L + H + L;
+}
+
+int rails_mol_pack_gate_weights(const rails_mol_shape* s, const rails_mol_weights* w, float* gate_pack, void* stream) {
+  g_err[0] = '\0';
+  if (!shape_supported(s)) return RAILS_ENOTSUP;
+  if (!w || !gate_pack || !w->gqi_w1 || !w->gqi_b1 || !w->gqi_w2 || !w->gqi_b2) {
+    set_error("pack_gate_weights: NULL pointer");
+    return RAILS_EINVAL;
+  }
+  return fail(pack_gate_weights(*s, *w, gate_pack, (hipStream_t)stream), "pack_gate_weights");
+}
+
+size_t rails_mol_index_floats(const rails_mol_shape* s, int64_t n_items) {
+  if (!shape_ok(s) || n_items < 0) return 0;
+  return (size_t)(num_tiles(n_items) * tile_floats(*s));
+}
+
+int rails_mol_index_build(const rails_mol_shape* s, const rails_mol_weights* w, const float* items, int64_t n_items,
+                          float* index, void* stream) {
+  g_err[0] = '\0';
+  if (!shape_supported(s)) return RAILS_ENOTSUP;
+  if (n_items < 0) { set_error("index_build: n_items < 0"); return RAILS_EINVAL; }
+  if (n_items == 0) return RAILS_OK;
+  if (!w || !items || !index || !w->i_proj_w || !w->i_proj_b || !w->gi_w1 || !w->gi_b1 || !w->gi_w2) {
+    set_error("index_build: NULL pointer");
+    return RAILS_EINVAL;
+  }
+  const int r = index_build(*s, *w, items, n_items, index, (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "index_build");
+}
+
+int rails_mol_index_unpack(const rails_mol_shape* s, const float* index, int64_t n_items, float* ex_out, float* gi_out,
+                           void* stream) {
+  g_err[0] = '\0';
+  if (!shape_ok(s)) return RAILS_EINVAL;
+  if (n_items <= 0 || (!ex_out && !gi_out)) return RAILS_OK;
+  if (!index) { set_error("index_unpack: NULL index"); return RAILS_EINVAL; }
+  return fail(index_unpack(*s, index, n_items, ex_out, gi_out, (hipStream_t)stream), "index_unpack");
+}
+
+int rails_mol_index_gather(const rails_mol_shape* s, const float* index, int64_t n_items, const int64_t* cand_idx,
+                           int64_t n_rows, int64_t n_cand, float* out_index, void* stream) {
+  g_err[0] = '\0';
+  if (!shape_ok(s)) return RAILS_EINVAL;
+  if (n_rows < 0 || n_cand < 0) { set_error("index_gather: negative size"); return RAILS_EINVAL; }
+  if (n_rows == 0 || n_cand == 0) return RAILS_OK;
+  if (!index || !cand_idx || !out_index) { set_error("index_gather: NULL pointer"); return RAILS_EINVAL; }
+  const int r = index_gather(*s, index, n_items, cand_idx, n_rows, n_cand, out_index, (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "index_gather");
+}
+
+size_t rails_mol_query_pack_floats(const rails_mol_shape* s, int32_t batch) {
+  if (!shape_ok(s) || batch < 0) return 0;
+  const int QT = queries_per_group(*s);
+  const size_t groups = (size_t)((batch + QT - 1) / QT);
+  return groups * 32 * (size_t)s->dot_product_dimension + (size_t)batch * (size_t)num_logits(*s);
+}
+
+int rails_mol_query_prologue(const rails_mol_shape* s, const rails_mol_weights* w, const float* queries,
+                             const int64_t* user_ids, int32_t batch, float* query_pack, float* eq_out, float* gq_out,
+                             void* stream) {
+  g_err[0] = '\0';
+  if (!shape_supported(s)) return RAILS_ENOTSUP;
+  if (batch < 0) { set_error("query_prologue: batch < 0"); return RAILS_EINVAL; }
+  if (batch == 0) return RAILS_OK;
+  if (!w || !queries || !query_pack || !w->q_glu_w || !w->q_glu_b || !w->q_proj_w || !w->q_proj_b || !w->gq_w1 ||
+      !w->gq_b1 || !w->gq_w2) {
+    set_error("query_prologue: NULL pointer");
+    return RAILS_EINVAL;
+  }
+  if (s->num_uid_tables > 0) {
+    if (!user_ids) { set_error("query_prologue: user_ids is required when num_uid_tables > 0"); return RAILS_EINVAL; }
+    for (int t = 0; t < s->num_uid_tables; ++t)
+      if (!w->uid_table[t] || w->uid_hash_size[t] <= 0) { set_error("query_prologue: uid table %d missing", t); return RAILS_EINVAL; }
+  }
+  return fail(query_prologue(*s, *w, queries, user_ids, batch, query_pack, eq_out, gq_out, (hipStream_t)stream),
+              "query_prologue");
+}
+
+static int score_common(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch,
+                        const float* index, int64_t n_items, float* logits, int64_t ld, int per_row, void* stream,
+                        const char* what) {
+  g_err[0] = '\0';
+  if (!shape_supported(s)) return RAILS_ENOTSUP;
+  if (batch < 0 || n_items < 0) { set_error("%s: negative size", what); return RAILS_EINVAL; }
+  if (batch == 0 || n_items == 0) return RAILS_OK;
+  if (!gate_pack || !query_pack || !index || !logits) { set_error("%s: NULL pointer", what); return RAILS_EINVAL; }
+  if (ld < n_items) { set_error("%s: ld (%lld) < n_items (%lld)", what, (long long)ld, (long long)n_items); return RAILS_EINVAL; }
+  if (per_row && n_items % 32 != 0) { set_error("%s: n_cand must be a multiple of 32", what); return RAILS_EINVAL; }
+  const int cu = compute_units();
+  if (cu <= 0) { set_error("%s: no HIP device", what); return RAILS_ELAUNCH; }
+  ScoreArgs a;
+  const int QT = queries_per_group(*s);
+  a.n_groups = (batch + QT - 1) / QT;
+  a.wpack = gate_pack;
+  a.eqfrag = query_pack;
+  a.gqfrag = query_pack + (int64_t)a.n_groups * 32 * s->dot_product_dimension;
+  a.ipack = index;
+  a.logits = logits;
+  a.ld = ld;
+  a.n_items = n_items;
+  a.n_tiles = num_tiles(n_items);
+  a.B = batch;
+  a.per_row = per_row;
+  a.temperature = s->temperature;
+  a.rcp_temperature = 1.0f / s->temperature;
+  const int r = score_launch(*s, a, cu, (hipStream_t)stream);
+  return r == kOk ? r : fail(r, what);
+}
+
+int rails_mol_score_dense(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch,
+                          const float* index, int64_t n_items, float* logits, int64_t ld, void* stream) {
+  return score_common(s, gate_pack, query_pack, batch, index, n_items, logits, ld, 0, stream, "score_dense");
+}
+
+int rails_mol_score_candidates(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch,
+                               const float* cand_index, int64_t n_cand, float* logits, int64_t ld, void* stream) {
+  return score_common(s, gate_pack, query_pack, batch, cand_index, n_cand, logits, ld, 1, stream, "score_candidates");
+}
+
+size_t rails_topk_workspace_bytes(int32_t rows, int64_t n, int32_t k) {
+  if (rows <= 0 || n <= 0 || k <= 0) return 256;
+  return topk_workspace_bytes(rows, n, k);
+}
+
+int rails_topk(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t k, int32_t sorted, const int64_t* ids,
+               int64_t ids_row_stride, float* out_scores, int64_t* out_ids, void* workspace, size_t workspace_bytes,
+               void* stream) {
+  (void)sorted;  // the descending order returned is also a valid unsorted answer
+  g_err[0] = '\0';
+  if (rows < 0 || n < 0 || k < 0) { set_error("topk: negative size"); return RAILS_EINVAL; }
+  if (k > n) { set_error("topk: selected index k out of range (k = %d > n = %lld)", k, (long long)n); return RAILS_EINVAL; }
+  if (rows == 0 || k == 0) return RAILS_OK;
+  if (!scores || !out_scores || !out_ids) { set_error("topk: NULL pointer"); return RAILS_EINVAL; }
+  if (ld < n) { set_error("topk: ld < n"); return RAILS_EINVAL; }
+  if (n > 16384 && !workspace) { set_error("topk: workspace is required for n > 16384"); return RAILS_ENOMEM; }
+  const int r = topk(scores, ld, rows, n, k, ids, ids_row_stride, out_scores, out_ids, workspace, workspace_bytes,
+                     (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "topk");
+}
+
+int rails_filter_seen_ids(const int64_t* top_ids, const float* top_scores, int32_t rows, int32_t k_prime,
+                          const int64_t* invalid_ids, int32_t width, int32_t k, int64_t* out_ids, float* out_scores,
+                          void* stream) {
+  g_err[0] = '\0';
+  if (rows < 0 || k_prime < 0 || width < 0 || k < 0) { set_error("filter_seen_ids: negative size"); return RAILS_EINVAL; }
+  if (rows == 0 || k == 0) return RAILS_OK;
+  if (!top_ids || !top_scores || !out_ids || !out_scores || (width > 0 && !invalid_ids)) {
+    set_error("filter_seen_ids: NULL pointer");
+    return RAILS_EINVAL;
+  }
+  const int r = filter_seen(top_ids, top_scores, rows, k_prime, invalid_ids, width, k, out_ids, out_scores,
+                            (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "filter_seen_ids");
+}
+
+}  // extern "C"

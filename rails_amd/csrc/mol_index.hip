@@ -1,0 +1,261 @@
+// Index-side kernels: pair-gate weight packing, item index build / unpack / gather.
+//
+// The item index is what the reference's MoLTopKModule keeps per corpus
+// (rails/indexing/mol_top_k.py:29-81) plus the item-only work MoLSimilarity.forward redoes on every
+// call: component embeddings (rails/similarities/mol/item_embeddings_fns.py:149-183) and the item gate
+// (similarity_fn.py:170-171).  It is computed once, in fp32, and laid out in tiles of 32 items in the
+// exact order the scoring kernel's MFMA operands consume it (mol_layout.h), so that every operand
+// fetch of the hot loop is one contiguous 1 KiB per wave.
+#include <hip/hip_runtime.h>
+
+#include "mol_kernels.h"
+#include "mol_layout.h"
+
+namespace mol {
+
+// ---- pair-gate weights -> fragment order --------------------------------------------------------
+__global__ void pack_gate_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
+                                 const float* __restrict__ w2, const float* __restrict__ b2,
+                                 float* __restrict__ out, int PQ, int PX, int H) {
+  const int L = PQ * PX, TH = H / 32, TL = L / 32, E = L / 2;
+  const int total = 2 * H * L + H + L;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    float v;
+    if (i < H * L) {  // W1frag[ec][t][lane][j] = W1[32t + (lane&31)][logit_of(4ec+j, lane>>5)]
+      const int j = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
+      const int t = blk % TH, ec = blk / TH;
+      v = w1[(32 * t + (lane & 31)) * L + logit_of(4 * ec + j, lane >> 5, PQ, PX)];
+    } else if (i < 2 * H * L) {  // W2frag[fc][v][lane][j] = W2[lrow(v, lane&31)][hidden_of(4fc+j, lane>>5)]
+      const int k = i - H * L;
+      const int j = k & 3, lane = (k >> 2) & 63, blk = k >> 8;
+      const int tv = blk % TL, fc = blk / TL;
+      const int row = lane & 31;
+      const int l = logit_of(16 * tv + reg_of_row(row), half_of_row(row), PQ, PX);
+      v = w2[l * H + hidden_of(4 * fc + j, lane >> 5)];
+    } else if (i < 2 * H * L + H) {  // b1frag[t][hi][r]
+      const int k = i - 2 * H * L;
+      const int r = k & 15, hi = (k >> 4) & 1, t = k >> 5;
+      v = b1[32 * t + acc_row(r, hi)];
+    } else {  // b2frag[hi][e]
+      const int k = i - 2 * H * L - H;
+      const int hi = k / E, e = k % E;
+      v = b2[logit_of(e, hi, PQ, PX)];
+    }
+    out[i] = v;
+  }
+}
+
+int pack_gate_weights(const Shape& s, const Weights& w, float* wpack, hipStream_t stream) {
+  const int H = s.gating_qi_hidden_dim, L = num_logits(s);
+  const int total = 2 * H * L + H + L;
+  hipLaunchKernelGGL(pack_gate_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w.gqi_w1, w.gqi_b1,
+                     w.gqi_w2, w.gqi_b2, wpack, s.query_dot_product_groups, s.item_dot_product_groups, H);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+// ---- index build -------------------------------------------------------------------------------
+// One workgroup per tile of 32 items.  Every dense layer is done "column per thread": thread c keeps
+// 32 accumulators (one per item) and walks k in order, reading X / hidden values as LDS broadcasts.
+// fp32 throughout, precise expf and true divisions: this runs once per corpus and has to sit as close
+// to the reference's CPU arithmetic as a different summation order allows.
+constexpr int kBuildThreads = 256;
+
+struct BuildArgs {
+  const float* items;   // (n, D)
+  const float* pw;      // (PX*d, D)
+  const float* pb;      // (PX*d)
+  const float* g1w;     // (Hi, D)
+  const float* g1b;     // (Hi)
+  const float* g2w;     // (L, Hi)
+  float* ipack;
+  int64_t n;
+  int D, PQ, PX, d, Hi;
+  int l2norm;
+  float eps;
+};
+
+__device__ __forceinline__ void dense_cols(const float* __restrict__ W, const float* __restrict__ bias, int col0,
+                                           int ncols, int K, const float* __restrict__ in_s, int in_ld,
+                                           float* __restrict__ out_s, int out_ld, bool silu) {
+  // out_s[x][c - col0] = act(bias[c] + sum_k W[c][k] * in_s[x][k])  for c in [col0, col0 + ncols)
+  for (int c = threadIdx.x; c < ncols; c += kBuildThreads) {
+    const float* wrow = W + (int64_t)(col0 + c) * K;
+    float acc[kTileItems];
+#pragma unroll
+    for (int x = 0; x < kTileItems; ++x) acc[x] = 0.0f;
+    for (int k = 0; k < K; ++k) {
+      const float wv = wrow[k];
+#pragma unroll
+      for (int x = 0; x < kTileItems; ++x) acc[x] = __builtin_fmaf(wv, in_s[x * in_ld + k], acc[x]);
+    }
+    const float bv = bias ? bias[col0 + c] : 0.0f;
+#pragma unroll
+    for (int x = 0; x < kTileItems; ++x) {
+      float v = acc[x] + bv;
+      if (silu) v = v / (1.0f + expf(-v));
+      out_s[x * out_ld + c] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBuildThreads) void index_build_kernel(BuildArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int D = a.D, d = a.d, PX = a.PX, L = a.PQ * a.PX, Hi = a.Hi;
+  const int mpc = (kBuildThreads / d) > 0 ? (kBuildThreads / d) : 1;  // component groups per column chunk
+  const int chunk_cols = mpc * d;
+  const int xs_ld = D + 1, hs_ld = Hi + 1;
+  const int cs_ld = (chunk_cols > L ? chunk_cols : L) + 1;
+  float* xs = smem;                          // [32][D+1]
+  float* hs = xs + kTileItems * xs_ld;       // [32][Hi+1]
+  float* cs = hs + kTileItems * hs_ld;       // [32][max(chunk_cols, L)+1]
+  float* ns = cs + kTileItems * cs_ld;       // [32][mpc] inverse norms
+  const int64_t tile = blockIdx.x;
+  const int64_t item0 = tile * kTileItems;
+  float* tEx = a.ipack + tile * (int64_t)(kTileItems * (PX * d + L));
+  float* tGi = tEx + kTileItems * PX * d;
+
+  for (int i = threadIdx.x; i < kTileItems * D; i += kBuildThreads) {
+    const int x = i / D, k = i - x * D;
+    xs[x * xs_ld + k] = (item0 + x < a.n) ? a.items[(item0 + x) * D + k] : 0.0f;
+  }
+  __syncthreads();
+
+  // component embeddings, one chunk of whole component groups at a time
+  for (int m0 = 0; m0 < PX; m0 += mpc) {
+    const int groups = (PX - m0 < mpc) ? (PX - m0) : mpc;
+    dense_cols(a.pw, a.pb, m0 * d, groups * d, D, xs, xs_ld, cs, cs_ld, false);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kTileItems * groups; i += kBuildThreads) {
+      const int x = i / groups, mg = i - x * groups;
+      float ss = 0.0f;
+      for (int k = 0; k < d; ++k) {
+        const float v = cs[x * cs_ld + mg * d + k];
+        ss = __builtin_fmaf(v, v, ss);
+      }
+      // x / clamp(norm, min=eps)  (item_embeddings_fns.py:173-182)
+      ns[x * mpc + mg] = a.l2norm ? fmaxf(sqrtf(ss), a.eps) : 1.0f;
+    }
+    __syncthreads();
+    // fragment order: Ex slot (m, c8, lane)[j] = Ex[x = lane&31][m][kdim_of(4*c8 + j, lane>>5)]
+    const int slots = groups * (d / 8) * 64;
+    for (int i = threadIdx.x; i < slots; i += kBuildThreads) {
+      const int lane = i & 63, c8 = (i >> 6) % (d / 8), mg = (i >> 6) / (d / 8);
+      const int x = lane & 31, hi = lane >> 5;
+      const float nv = ns[x * mpc + mg];
+      float4 o;
+      float* ov = reinterpret_cast<float*>(&o);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ov[j] = cs[x * cs_ld + mg * d + kdim_of(4 * c8 + j, hi, d)] / nv;
+      if (item0 + x >= a.n) o = make_float4(0.f, 0.f, 0.f, 0.f);
+      reinterpret_cast<float4*>(tEx)[((m0 + mg) * (d / 8) + c8) * 64 + lane] = o;
+    }
+    __syncthreads();
+  }
+
+  // item gate: gi = W2 silu(W1 x + b1)   (modeling/similarity_utils.py:169-185)
+  dense_cols(a.g1w, a.g1b, 0, Hi, D, xs, xs_ld, hs, hs_ld, true);
+  __syncthreads();
+  dense_cols(a.g2w, nullptr, 0, L, Hi, hs, hs_ld, cs, cs_ld, false);
+  __syncthreads();
+  for (int i = threadIdx.x; i < (L / 8) * 64; i += kBuildThreads) {
+    const int lane = i & 63, ec = i >> 6;
+    const int x = lane & 31, hi = lane >> 5;
+    float4 o;
+    float* ov = reinterpret_cast<float*>(&o);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) ov[j] = cs[x * cs_ld + logit_of(4 * ec + j, hi, a.PQ, PX)];
+    if (item0 + x >= a.n) o = make_float4(0.f, 0.f, 0.f, 0.f);
+    reinterpret_cast<float4*>(tGi)[ec * 64 + lane] = o;
+  }
+}
+
+static size_t build_lds_bytes(const Shape& s) {
+  const int d = s.dot_product_dimension, L = num_logits(s);
+  const int mpc = (kBuildThreads / d) > 0 ? (kBuildThreads / d) : 1;
+  const int chunk_cols = mpc * d;
+  const int cs_ld = (chunk_cols > L ? chunk_cols : L) + 1;
+  return sizeof(float) * (size_t)kTileItems *
+         ((s.item_embedding_dim + 1) + (s.gating_item_hidden_dim + 1) + cs_ld + mpc);
+}
+
+int index_build(const Shape& s, const Weights& w, const float* items, int64_t n, float* ipack, hipStream_t stream) {
+  const int64_t tiles = num_tiles(n);
+  if (tiles == 0) return kOk;
+  BuildArgs a;
+  a.items = items; a.pw = w.i_proj_w; a.pb = w.i_proj_b; a.g1w = w.gi_w1; a.g1b = w.gi_b1; a.g2w = w.gi_w2;
+  a.ipack = ipack; a.n = n; a.D = s.item_embedding_dim; a.PQ = s.query_dot_product_groups;
+  a.PX = s.item_dot_product_groups; a.d = s.dot_product_dimension; a.Hi = s.gating_item_hidden_dim;
+  a.l2norm = s.dot_product_l2_norm; a.eps = s.eps;
+  const size_t lds = build_lds_bytes(s);
+  if (lds > 160 * 1024) { set_error("index build needs %zu B of LDS (> 160 KiB) for this shape", lds); return kErrUnsupported; }
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&index_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)lds) != hipSuccess)
+    return kErrLaunch;
+  hipLaunchKernelGGL(index_build_kernel, dim3((unsigned)tiles), dim3(kBuildThreads), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+// ---- unpack: fragment order -> plain (n, PX, d) / (n, L) -----------------------------------------
+__global__ void index_unpack_kernel(const float* __restrict__ ipack, int64_t n, int PQ, int PX, int d,
+                                    float* __restrict__ ex, float* __restrict__ gi) {
+  const int L = PQ * PX;
+  const int64_t tile = blockIdx.x;
+  const float* tEx = ipack + tile * (int64_t)(kTileItems * (PX * d + L));
+  const float* tGi = tEx + kTileItems * PX * d;
+  if (ex) {
+    for (int i = threadIdx.x; i < kTileItems * PX * d; i += blockDim.x) {
+      const int j = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
+      const int c8 = blk % (d / 8), m = blk / (d / 8);
+      const int64_t item = tile * kTileItems + (lane & 31);
+      if (item < n) ex[(item * PX + m) * d + kdim_of(4 * c8 + j, lane >> 5, d)] = tEx[i];
+    }
+  }
+  if (gi) {
+    for (int i = threadIdx.x; i < kTileItems * L; i += blockDim.x) {
+      const int j = i & 3, lane = (i >> 2) & 63, ec = i >> 8;
+      const int64_t item = tile * kTileItems + (lane & 31);
+      if (item < n) gi[item * L + logit_of(4 * ec + j, lane >> 5, PQ, PX)] = tGi[i];
+    }
+  }
+}
+
+int index_unpack(const Shape& s, const float* ipack, int64_t n, float* ex, float* gi, hipStream_t stream) {
+  const int64_t tiles = num_tiles(n);
+  if (tiles == 0) return kOk;
+  hipLaunchKernelGGL(index_unpack_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, ipack, n,
+                     s.query_dot_product_groups, s.item_dot_product_groups, s.dot_product_dimension, ex, gi);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+// ---- gather: rows x n_cand candidate positions -> a tile-packed index of their own -----------------
+__global__ void index_gather_kernel(const float4* __restrict__ ipack, int64_t n, const int64_t* __restrict__ idx,
+                                    int64_t tiles_per_row, int64_t n_cand, int tile_f4, float4* __restrict__ out) {
+  const int64_t otile = blockIdx.x;                 // = row * tiles_per_row + t
+  const int64_t row = otile / tiles_per_row, t = otile - row * tiles_per_row;
+  __shared__ int64_t src[kTileItems];
+  if (threadIdx.x < kTileItems) {
+    int64_t v = idx[row * n_cand + t * kTileItems + threadIdx.x];
+    src[threadIdx.x] = (v >= 0 && v < n) ? v : -1;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < tile_f4; i += blockDim.x) {
+    const int lane = i & 63, slot = i >> 6;
+    const int64_t sidx = src[lane & 31];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sidx >= 0) v = ipack[(sidx >> 5) * tile_f4 + slot * 64 + (lane & 32) + (sidx & 31)];
+    out[otile * tile_f4 + i] = v;
+  }
+}
+
+int index_gather(const Shape& s, const float* ipack, int64_t n, const int64_t* idx, int64_t rows, int64_t n_cand,
+                 float* out, hipStream_t stream) {
+  if (n_cand % kTileItems != 0) { set_error("n_cand (%lld) must be a multiple of 32", (long long)n_cand); return kErrInvalid; }
+  const int64_t tiles_per_row = n_cand / kTileItems;
+  if (rows * tiles_per_row == 0) return kOk;
+  hipLaunchKernelGGL(index_gather_kernel, dim3((unsigned)(rows * tiles_per_row)), dim3(256), 0, stream,
+                     reinterpret_cast<const float4*>(ipack), n, idx, tiles_per_row, n_cand, (int)(tile_floats(s) / 4),
+                     reinterpret_cast<float4*>(out));
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+}  // namespace mol

@@ -1,0 +1,61 @@
+// Internal declarations shared by the HIP translation units behind include/rails_amd.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rails_amd.h"
+
+namespace mol {
+
+using Shape = rails_mol_shape;
+using Weights = rails_mol_weights;
+
+enum : int { kOk = RAILS_OK, kErrInvalid = RAILS_EINVAL, kErrUnsupported = RAILS_ENOTSUP,
+             kErrNoMem = RAILS_ENOMEM, kErrLaunch = RAILS_ELAUNCH };
+
+constexpr int kScoreThreads = 512;  // 8 waves: two per SIMD, so one wave's VALU phases (silu, softmax)
+constexpr int kScoreWaves = 8;      // run under its partner's MFMAs
+
+inline int num_logits(const Shape& s) { return s.query_dot_product_groups * s.item_dot_product_groups; }
+inline int queries_per_group(const Shape& s) { return 32 / s.query_dot_product_groups; }
+inline int64_t num_tiles(int64_t n_items) { return (n_items + 31) / 32; }
+inline int64_t tile_floats(const Shape& s) {
+  return 32LL * (s.item_dot_product_groups * s.dot_product_dimension + num_logits(s));
+}
+
+struct ScoreArgs {
+  const float* wpack;   // packed pair-gate weights (fragment order), Geo::kWpackFloats
+  const float* eqfrag;  // [n_groups][32 * d]
+  const float* gqfrag;  // [B][L] as [hi][e]
+  const float* ipack;   // item tiles
+  float* logits;        // [B][ld]
+  int64_t ld;
+  int64_t n_items;      // shared corpus: items in the index; candidates: items per row
+  int64_t n_tiles;      // shared corpus: tiles in the index; candidates: tiles per row
+  int B;
+  int n_groups;
+  int per_row;          // 1: tile t of row b lives at ipack tile (b * n_tiles + t)
+  float temperature;
+  float rcp_temperature;
+};
+
+void set_error(const char* fmt, ...);
+
+int score_launch(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream);
+bool score_supported(const Shape& s);
+
+int pack_gate_weights(const Shape& s, const Weights& w, float* wpack, hipStream_t stream);
+int index_build(const Shape& s, const Weights& w, const float* items, int64_t n, float* ipack, hipStream_t stream);
+int index_unpack(const Shape& s, const float* ipack, int64_t n, float* ex, float* gi, hipStream_t stream);
+int index_gather(const Shape& s, const float* ipack, int64_t n, const int64_t* idx, int64_t rows, int64_t n_cand,
+                 float* out, hipStream_t stream);
+int query_prologue(const Shape& s, const Weights& w, const float* q, const int64_t* user_ids, int B, float* qpack,
+                   float* eq_out, float* gq_out, hipStream_t stream);
+
+size_t topk_workspace_bytes(int rows, int64_t n, int k);
+int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int64_t* ids, int64_t ids_row_stride,
+         float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, hipStream_t stream);
+int filter_seen(const int64_t* top_ids, const float* top_scores, int rows, int k_prime, const int64_t* invalid,
+                int width, int k, int64_t* out_ids, float* out_scores, hipStream_t stream);
+
+}  // namespace mol

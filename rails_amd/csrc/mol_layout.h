@@ -1,0 +1,66 @@
+// Packed data layouts shared by the MoL kernels (gfx950, wave64, v_mfma_f32_32x32x2_f32).
+//
+// The scoring kernel chains three contractions per (query, item) pair
+//     cl = <Eq, Ex>/tau  ->  hid = silu(W1 cl + b1)  ->  gqi = W2 hid + b2
+// (reference: rails/similarities/mol/similarity_fn.py:389-405 and the Sequential built at
+// modeling/similarity_utils.py:186-207) with ITEMS on the MFMA column axis (lane & 31) and the
+// feature axis on the MFMA row axis.  The accumulator of one MFMA then IS the B operand of the
+// next one: lane (x, hi) holds, in accumulator register r, the feature row
+//     row(r, hi) = (r & 3) + 8 (r >> 2) + 4 hi
+// of item x, and a K=2 MFMA step consumes register r of both lane halves as k = {row(r,0), row(r,1)}.
+// All weight / query / item operands are therefore stored pre-permuted ("fragment order") so that
+// every operand fetch is one contiguous 16 B per lane and no data ever moves between lanes.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(__HIP__)
+#define MOL_HD __host__ __device__ __forceinline__
+#else
+#define MOL_HD inline
+#endif
+
+namespace mol {
+
+constexpr int kTileItems = 32;  // items per tile = MFMA column count
+
+MOL_HD int acc_row(int reg, int hi) { return (reg & 3) + 8 * (reg >> 2) + 4 * hi; }
+
+// geometry derived from (P_Q, P_X, d, H)
+template <int PQ, int PX, int DD, int H>
+struct Geo {
+  static_assert(PQ == 8 || PQ == 16 || PQ == 32, "P_Q must be 8, 16 or 32");
+  static_assert(DD % 8 == 0, "dot_product_dimension must be a multiple of 8");
+  static_assert(H % 32 == 0, "gate hidden dim must be a multiple of 32");
+  static constexpr int L = PQ * PX;
+  static_assert(L % 32 == 0, "P_Q * P_X must be a multiple of 32");
+  static constexpr int QT = 32 / PQ;    // queries per query group (rows of one GEMM1 tile)
+  static constexpr int RPQ = PQ / 2;    // accumulator registers per query inside one GEMM1 tile
+  static constexpr int TH = H / 32;     // row tiles of the hidden layer
+  static constexpr int TL = L / 32;     // row tiles of the gate output
+  static constexpr int E = L / 2;       // K-steps over the logit axis (one per lane half pair)
+  static constexpr int F = H / 2;       // K-steps over the hidden axis
+  static constexpr int KS = DD / 2;     // K-steps of the sub-embedding contraction
+  // floats
+  static constexpr int kTileExFloats = kTileItems * PX * DD;
+  static constexpr int kTileGiFloats = kTileItems * L;
+  static constexpr int kTileFloats = kTileExFloats + kTileGiFloats;
+  static constexpr int kEqGroupFloats = 32 * DD;  // one query group of Eq in fragment order
+  static constexpr int kW1Floats = H * L, kW2Floats = L * H;
+  static constexpr int kWpackFloats = kW1Floats + kW2Floats + H + L;
+};
+
+// logit index l held by K-step e of lane half hi:  e = m * RPQ + r',  p = row(r', hi),  l = p * PX + m
+MOL_HD int logit_of(int e, int hi, int PQ, int PX) {
+  const int rpq = PQ / 2;
+  const int m = e / rpq, r = e % rpq;
+  return acc_row(r, hi) * PX + m;
+}
+// hidden index held by K-step f of lane half hi
+MOL_HD int hidden_of(int f, int hi) { return 32 * (f / 16) + acc_row(f % 16, hi); }
+// sub-embedding index held by K-step s of lane half hi
+MOL_HD int kdim_of(int s, int hi, int DD) { return hi * (DD / 2) + s; }
+// (register, half) that accumulator row i of a 32-row tile lands in
+MOL_HD int reg_of_row(int i) { return (i & 3) + 4 * (i >> 3); }
+MOL_HD int half_of_row(int i) { return (i >> 2) & 1; }
+
+}  // namespace mol

@@ -1,0 +1,324 @@
+// Exact top-k selection and the seen-id filter.
+//
+// Replaces torch.topk(all_logits, dim=1, k, sorted=True, largest=True) and the id gather of
+// MoLBruteForceTopK.forward (rails/indexing/mol_top_k.py:123-130), and the row-wise masking of
+// CandidateIndex.get_top_k_outputs (indexing/candidate_index.py:154-178).
+//
+// Every score becomes a 64-bit key  (orderable(score) << 32) | ~position : all keys of a row are
+// distinct, so "the k largest keys" is a unique set and its descending order is "score descending,
+// then position ascending" -- the deterministic tie rule that makes 1/2/4/8-GPU results identical.
+//
+//   n <= 16384  one workgroup per row bitonic-sorts the whole row in LDS.
+//   larger n    MSB-first radix select (11/11/10 bits of the score, then 11/11/10 of the position if
+//               the k-th score is tied) with LDS histograms finds the k-th largest key T exactly; one
+//               compaction pass gathers the exactly-k keys >= T; the LDS bitonic sort orders them.
+#include <hip/hip_runtime.h>
+
+#include "mol_kernels.h"
+
+namespace mol {
+
+constexpr int kSortCap = 16384;       // 64-bit keys in 128 KiB of LDS
+constexpr int kSortThreads = 1024;
+constexpr int kHistThreads = 512;
+constexpr int kRadixPasses = 6;
+constexpr int kBins = 2048;
+__device__ __constant__ int kPassShift[kRadixPasses] = {53, 42, 32, 21, 10, 0};
+__device__ __constant__ int kPassBits[kRadixPasses] = {11, 11, 10, 11, 11, 10};
+static const int hPassShift[kRadixPasses] = {53, 42, 32, 21, 10, 0};
+static const int hPassBits[kRadixPasses] = {11, 11, 10, 11, 11, 10};
+
+struct SelectState {       // one per row, lives in the workspace
+  unsigned long long prefix;  // resolved high bits of the k-th key (low bits zero)
+  unsigned int need;          // how many keys with that prefix are still wanted
+  unsigned int done;          // 1: every key >= prefix is selected, threshold final
+  unsigned int count;         // compaction cursor
+  unsigned int pad;
+};
+
+__device__ __forceinline__ unsigned int orderable(float f) {
+  const unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unorderable(unsigned int k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+__device__ __forceinline__ unsigned long long make_key(float score, unsigned int pos) {
+  return ((unsigned long long)orderable(score) << 32) | (unsigned int)(~pos);
+}
+
+// ---- LDS bitonic sort (descending) + emit ------------------------------------------------------
+// mode 0: keys come from scores[row*ld + i], i < n.   mode 1: keys come from cand[row*cand_ld + i], i < k.
+__global__ __launch_bounds__(kSortThreads) void sort_emit_kernel(const float* __restrict__ scores, int64_t ld,
+                                                                int64_t n, const unsigned long long* __restrict__ cand,
+                                                                int64_t cand_ld, int k, int npad,
+                                                                const int64_t* __restrict__ ids, int64_t ids_row_stride,
+                                                                float* __restrict__ out_scores,
+                                                                int64_t* __restrict__ out_ids) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  const int row = blockIdx.x;
+  const int count = cand ? k : (int)n;
+  for (int i = threadIdx.x; i < npad; i += kSortThreads) {
+    unsigned long long kv = 0ull;  // below every real key (orderable() never returns 0 for a finite/inf score)
+    if (i < count) kv = cand ? cand[row * cand_ld + i] : make_key(scores[row * ld + i], (unsigned int)i);
+    keys[i] = kv;
+  }
+  __syncthreads();
+  for (int size = 2; size <= npad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < (npad >> 1); t += kSortThreads) {
+        const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+        const int hi2 = lo | stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = keys[lo], b = keys[hi2];
+        if ((a < b) == desc) { keys[lo] = b; keys[hi2] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int j = threadIdx.x; j < k; j += kSortThreads) {
+    const unsigned long long kv = keys[j];
+    const unsigned int pos = ~(unsigned int)(kv & 0xFFFFFFFFull);
+    out_scores[(int64_t)row * k + j] = unorderable((unsigned int)(kv >> 32));
+    out_ids[(int64_t)row * k + j] = ids ? ids[ids_row_stride * row + pos] : (int64_t)pos;
+  }
+}
+
+// ---- radix select ------------------------------------------------------------------------------
+__global__ void select_init_kernel(SelectState* st, int rows, int k) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < rows) { st[r].prefix = 0ull; st[r].need = (unsigned int)k; st[r].done = 0u; st[r].count = 0u; st[r].pad = 0u; }
+}
+
+__global__ __launch_bounds__(kHistThreads) void hist_kernel(const float* __restrict__ scores, int64_t ld, int64_t n,
+                                                           const SelectState* __restrict__ st,
+                                                           unsigned int* __restrict__ hist, int pass,
+                                                           int64_t chunk) {
+  __shared__ unsigned int h[kBins];
+  const int row = blockIdx.y;
+  if (st[row].done) return;
+  const int shift = kPassShift[pass], bits = kPassBits[pass];
+  const unsigned long long prefix = st[row].prefix;
+  const int above = shift + bits;  // bits [above, 64) are resolved
+  for (int i = threadIdx.x; i < kBins; i += kHistThreads) h[i] = 0u;
+  __syncthreads();
+  const int64_t begin = (int64_t)blockIdx.x * chunk;
+  const int64_t end = (begin + chunk < n) ? begin + chunk : n;
+  const float* rowp = scores + (int64_t)row * ld;
+  for (int64_t i = begin + threadIdx.x; i < end; i += kHistThreads) {
+    const unsigned long long key = make_key(rowp[i], (unsigned int)i);
+    const bool match = (above >= 64) || ((key >> above) == (prefix >> above));
+    if (match) atomicAdd(&h[(unsigned int)(key >> shift) & ((1u << bits) - 1u)], 1u);
+  }
+  __syncthreads();
+  unsigned int* gh = hist + ((int64_t)pass * gridDim.y + row) * kBins;
+  for (int i = threadIdx.x; i < kBins; i += kHistThreads)
+    if (h[i]) atomicAdd(&gh[i], h[i]);
+}
+
+// one workgroup per row: walk the histogram from the top bin down to the bin holding the need-th key
+__global__ __launch_bounds__(256) void pick_bin_kernel(SelectState* __restrict__ st,
+                                                       const unsigned int* __restrict__ hist, int pass, int rows) {
+  __shared__ unsigned int part[256];
+  __shared__ unsigned int sel_bin, sel_above;
+  const int row = blockIdx.x;
+  if (st[row].done) return;
+  const int shift = kPassShift[pass], bits = kPassBits[pass];
+  const int nb = 1 << bits, per = nb / 256;  // 8 or 4 bins per thread, top bins first
+  const unsigned int* gh = hist + ((int64_t)pass * rows + row) * kBins;
+  const unsigned int need = st[row].need;
+  unsigned int mine = 0;
+  for (int j = 0; j < per; ++j) mine += gh[nb - 1 - (threadIdx.x * per + j)];
+  part[threadIdx.x] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int cum = 0;
+    int t = 0;
+    for (; t < 256; ++t) { if (cum + part[t] >= need) break; cum += part[t]; }
+    // need <= total by construction (k <= n), so t < 256
+    int bin = nb - 1 - t * per;
+    for (int j = 0; j < per; ++j, --bin) { const unsigned int c = gh[bin]; if (cum + c >= need) break; cum += c; }
+    sel_bin = (unsigned int)bin;
+    sel_above = cum;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int c = gh[sel_bin];
+    const unsigned int still = need - sel_above;
+    st[row].prefix |= ((unsigned long long)sel_bin) << shift;
+    st[row].need = still;
+    // all keys of this bin are wanted -> the threshold is the bin's lower edge; nothing left to resolve
+    if (c == still || pass == kRadixPasses - 1) st[row].done = 1u;
+  }
+}
+
+__global__ __launch_bounds__(kHistThreads) void compact_kernel(const float* __restrict__ scores, int64_t ld, int64_t n,
+                                                              SelectState* __restrict__ st,
+                                                              unsigned long long* __restrict__ cand, int64_t cand_ld,
+                                                              int k, int64_t chunk) {
+  const int row = blockIdx.y;
+  const unsigned long long thr = st[row].prefix;
+  const int64_t begin = (int64_t)blockIdx.x * chunk;
+  const int64_t end = (begin + chunk < n) ? begin + chunk : n;
+  const float* rowp = scores + (int64_t)row * ld;
+  for (int64_t i = begin + threadIdx.x; i < end; i += kHistThreads) {
+    const unsigned long long key = make_key(rowp[i], (unsigned int)i);
+    if (key >= thr) {
+      const unsigned int slot = atomicAdd(&st[row].count, 1u);
+      if (slot < (unsigned int)k) cand[row * cand_ld + slot] = key;
+    }
+  }
+}
+
+static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+size_t topk_workspace_bytes(int rows, int64_t n, int k) {
+  if (n <= kSortCap) return 256;
+  size_t b = align_up(sizeof(SelectState) * (size_t)rows, 256);
+  b += align_up(sizeof(unsigned int) * (size_t)kRadixPasses * rows * kBins, 256);
+  b += align_up(sizeof(unsigned long long) * (size_t)rows * k, 256);
+  return b;
+}
+
+static int ensure_sort_lds() {
+  static bool done = false;
+  if (done) return kOk;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_emit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          kSortCap * (int)sizeof(unsigned long long)) != hipSuccess)
+    return kErrLaunch;
+  done = true;
+  return kOk;
+}
+
+int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int64_t* ids, int64_t ids_row_stride,
+         float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (rows <= 0 || k <= 0) return kOk;
+  if (k > kSortCap) { set_error("k = %d exceeds the in-LDS sort capacity (%d)", k, kSortCap); return kErrUnsupported; }
+  if (n >= (1ll << 32)) { set_error("n = %lld does not fit 32-bit positions; shard the corpus", (long long)n); return kErrUnsupported; }
+  if (ensure_sort_lds() != kOk) return kErrLaunch;
+  if (n <= kSortCap) {
+    const int npad = next_pow2((int)n < 2 ? 2 : (int)n);
+    hipLaunchKernelGGL(sort_emit_kernel, dim3(rows), dim3(kSortThreads), npad * sizeof(unsigned long long), stream,
+                       scores, ld, n, (const unsigned long long*)nullptr, (int64_t)0, k, npad, ids, ids_row_stride,
+                       out_scores, out_ids);
+    return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+  }
+  if (ws_bytes < topk_workspace_bytes(rows, n, k)) { set_error("top-k workspace too small"); return kErrNoMem; }
+  char* base = static_cast<char*>(ws);
+  SelectState* st = reinterpret_cast<SelectState*>(base);
+  base += align_up(sizeof(SelectState) * (size_t)rows, 256);
+  unsigned int* hist = reinterpret_cast<unsigned int*>(base);
+  const size_t hist_bytes = sizeof(unsigned int) * (size_t)kRadixPasses * rows * kBins;
+  base += align_up(hist_bytes, 256);
+  unsigned long long* cand = reinterpret_cast<unsigned long long*>(base);
+
+  if (hipMemsetAsync(hist, 0, hist_bytes, stream) != hipSuccess) return kErrLaunch;
+  hipLaunchKernelGGL(select_init_kernel, dim3((rows + 63) / 64), dim3(64), 0, stream, st, rows, k);
+  // enough workgroups to fill the chip, at least 8K elements each
+  int64_t chunks = (2048 + rows - 1) / rows;
+  const int64_t max_chunks = (n + 8191) / 8192;
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  const int64_t chunk = (n + chunks - 1) / chunks;
+  (void)hPassShift; (void)hPassBits;
+  for (int pass = 0; pass < kRadixPasses; ++pass) {
+    hipLaunchKernelGGL(hist_kernel, dim3((unsigned)chunks, rows), dim3(kHistThreads), 0, stream, scores, ld, n, st, hist,
+                       pass, chunk);
+    hipLaunchKernelGGL(pick_bin_kernel, dim3(rows), dim3(256), 0, stream, st, hist, pass, rows);
+  }
+  hipLaunchKernelGGL(compact_kernel, dim3((unsigned)chunks, rows), dim3(kHistThreads), 0, stream, scores, ld, n, st, cand,
+                     (int64_t)k, k, chunk);
+  const int npad = next_pow2(k < 2 ? 2 : k);
+  hipLaunchKernelGGL(sort_emit_kernel, dim3(rows), dim3(kSortThreads), npad * sizeof(unsigned long long), stream,
+                     scores, ld, n, cand, (int64_t)k, k, npad, ids, ids_row_stride, out_scores, out_ids);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+// ---- seen-id filter ----------------------------------------------------------------------------
+// One workgroup per row.  Literal restatement of indexing/candidate_index.py:156-175:
+//   valid  = not seen, and among the first k such
+//   if fewer than k are valid, back-fill with the first (k - #valid) of the others, in position order
+//   output = the selected positions in ascending position order (exactly k of them)
+constexpr int kFilterThreads = 256;
+
+__global__ __launch_bounds__(kFilterThreads) void filter_seen_kernel(const int64_t* __restrict__ top_ids,
+                                                                    const float* __restrict__ top_scores, int k_prime,
+                                                                    const int64_t* __restrict__ invalid, int width,
+                                                                    int k, int64_t* __restrict__ out_ids,
+                                                                    float* __restrict__ out_scores) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+  int64_t* inv = reinterpret_cast<int64_t*>(fsm);                        // [width]
+  unsigned char* ok = reinterpret_cast<unsigned char*>(inv + width);     // [k_prime]: 1 = not seen
+  __shared__ int seg_ok[kFilterThreads], seg_bad[kFilterThreads];
+  __shared__ int total_ok;
+  const int row = blockIdx.x;
+  const int64_t* ids = top_ids + (int64_t)row * k_prime;
+  for (int i = threadIdx.x; i < width; i += kFilterThreads) inv[i] = invalid[(int64_t)row * width + i];
+  __syncthreads();
+  for (int j = threadIdx.x; j < k_prime; j += kFilterThreads) {
+    const int64_t id = ids[j];
+    bool seen = false;
+    for (int w = 0; w < width; ++w) seen |= (inv[w] == id);
+    ok[j] = seen ? 0 : 1;
+  }
+  __syncthreads();
+  // contiguous segment per thread; exclusive prefix of not-seen counts over segments
+  const int seg = (k_prime + kFilterThreads - 1) / kFilterThreads;
+  const int s0 = threadIdx.x * seg, s1 = (s0 + seg < k_prime) ? s0 + seg : k_prime;
+  int c = 0;
+  for (int j = s0; j < s1; ++j) c += ok[j];
+  seg_ok[threadIdx.x] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int t = 0; t < kFilterThreads; ++t) { const int v = seg_ok[t]; seg_ok[t] = run; run += v; }
+    total_ok = run;
+  }
+  __syncthreads();
+  const int n_valid = total_ok < k ? total_ok : k;   // valid = not seen and cumsum <= k
+  const int gap = k - n_valid;
+  // "invalid" = everything that is not valid: seen ids AND not-seen ids beyond the first k
+  int okc = seg_ok[threadIdx.x];
+  c = 0;
+  for (int j = s0; j < s1; ++j) { const bool valid = ok[j] && (okc + 1 <= k); okc += ok[j]; c += valid ? 0 : 1; }
+  seg_bad[threadIdx.x] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int t = 0; t < kFilterThreads; ++t) { const int v = seg_bad[t]; seg_bad[t] = run; run += v; }
+  }
+  __syncthreads();
+  okc = seg_ok[threadIdx.x];
+  int badc = seg_bad[threadIdx.x];
+  for (int j = s0; j < s1; ++j) {
+    const bool valid = ok[j] && (okc + 1 <= k);
+    okc += ok[j];
+    int out_pos = -1;
+    if (valid) {
+      // selected positions before j: valid ones (= okc_before, all <= k) + back-filled ones (min(badc, gap))
+      out_pos = (okc - 1) + (badc < gap ? badc : gap);
+    } else {
+      if (badc + 1 <= gap) out_pos = (okc < k ? okc : k) + badc;
+      badc += 1;
+    }
+    if (out_pos >= 0 && out_pos < k) {
+      out_ids[(int64_t)row * k + out_pos] = ids[j];
+      out_scores[(int64_t)row * k + out_pos] = top_scores[(int64_t)row * k_prime + j];
+    }
+  }
+}
+
+int filter_seen(const int64_t* top_ids, const float* top_scores, int rows, int k_prime, const int64_t* invalid,
+                int width, int k, int64_t* out_ids, float* out_scores, hipStream_t stream) {
+  if (rows <= 0) return kOk;
+  if (k > k_prime) { set_error("seen-id filter: k (%d) > k' (%d)", k, k_prime); return kErrInvalid; }
+  const size_t lds = sizeof(int64_t) * (size_t)width + (size_t)k_prime + 16;
+  if (lds > 60000) { set_error("seen-id filter: k' or width too large for LDS"); return kErrUnsupported; }
+  hipLaunchKernelGGL(filter_seen_kernel, dim3(rows), dim3(kFilterThreads), lds, stream, top_ids, top_scores, k_prime,
+                     invalid, width, k, out_ids, out_scores);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+}  // namespace mol

@@ -1,0 +1,290 @@
+"""Thin Python driver over the C ABI: owns the packed device buffers, passes raw device pointers.
+
+PyTorch is used for device memory, the current stream and (elsewhere) torch.distributed only; every
+floating-point operation of the path runs in the HIP kernels behind librails_amd.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+TILE_ITEMS = 32
+
+
+@dataclasses.dataclass(frozen=True)
+class MolShapeSpec:
+    """Hyper-parameters of a MoL module (names as in create_mol_interaction_module,
+    reference modeling/similarity_utils.py:42-70)."""
+
+    query_embedding_dim: int
+    item_embedding_dim: int
+    dot_product_dimension: int
+    query_dot_product_groups: int
+    item_dot_product_groups: int
+    query_hidden_dim: int
+    gating_query_hidden_dim: int
+    gating_item_hidden_dim: int
+    gating_qi_hidden_dim: int
+    query_nonlinearity: str = "geglu"
+    uid_embedding_hash_sizes: Tuple[int, ...] = ()
+    dot_product_l2_norm: bool = True
+    temperature: float = 0.05
+    eps: float = 1e-6
+
+    @property
+    def num_logits(self) -> int:
+        return self.query_dot_product_groups * self.item_dot_product_groups
+
+    def to_c(self) -> _lib.MolShape:
+        if self.query_nonlinearity not in ("geglu", "swiglu"):
+            raise ValueError(f"Unknown query_nonlinearity {self.query_nonlinearity}")
+        return _lib.MolShape(
+            self.query_embedding_dim, self.item_embedding_dim, self.dot_product_dimension,
+            self.query_dot_product_groups, self.item_dot_product_groups, self.query_hidden_dim,
+            self.gating_query_hidden_dim, self.gating_item_hidden_dim, self.gating_qi_hidden_dim,
+            _lib.RAILS_GEGLU if self.query_nonlinearity == "geglu" else _lib.RAILS_SWIGLU,
+            len(self.uid_embedding_hash_sizes), 1 if self.dot_product_l2_norm else 0,
+            float(self.temperature), float(self.eps),
+        )
+
+
+# state_dict key -> field of rails_mol_weights
+WEIGHT_FIELDS = {
+    "_query_embeddings_fn._query_emb_proj_module.1._w": "q_glu_w",
+    "_query_embeddings_fn._query_emb_proj_module.1._b": "q_glu_b",
+    "_query_embeddings_fn._query_emb_proj_module.2.weight": "q_proj_w",
+    "_query_embeddings_fn._query_emb_proj_module.2.bias": "q_proj_b",
+    "_item_embeddings_fn._item_emb_proj_module.1.weight": "i_proj_w",
+    "_item_embeddings_fn._item_emb_proj_module.1.bias": "i_proj_b",
+    "_gating_fn._query_only_partial_module.0.weight": "gq_w1",
+    "_gating_fn._query_only_partial_module.0.bias": "gq_b1",
+    "_gating_fn._query_only_partial_module.2.weight": "gq_w2",
+    "_gating_fn._item_only_partial_module.1.weight": "gi_w1",
+    "_gating_fn._item_only_partial_module.1.bias": "gi_b1",
+    "_gating_fn._item_only_partial_module.3.weight": "gi_w2",
+    "_gating_fn._qi_partial_module.1.weight": "gqi_w1",
+    "_gating_fn._qi_partial_module.1.bias": "gqi_b1",
+    "_gating_fn._qi_partial_module.3.weight": "gqi_w2",
+    "_gating_fn._qi_partial_module.3.bias": "gqi_b2",
+}
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _require_device(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what} must live on the GPU: rails_amd runs its path in HIP kernels only and has no CPU fallback "
+            f"(got a tensor on {t.device})"
+        )
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    """fp32 + contiguous view/copy of a device tensor (plumbing: dtype cast, no math)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class MolIndex:
+    """Tile-packed item index: Ex (l2-normalised component embeddings) + gi (item gate) per item."""
+
+    def __init__(self, buf: torch.Tensor, n_items: int):
+        self.buf = buf
+        self.n_items = n_items
+
+
+class MolEngine:
+    """One MoL module's weights bound to the HIP kernels."""
+
+    def __init__(self, spec: MolShapeSpec, weights: Dict[str, torch.Tensor]):
+        self.lib = _lib.load()
+        self.spec = spec
+        self.shape = spec.to_c()
+        if not self.lib.rails_mol_shape_supported(C.byref(self.shape)):
+            raise NotImplementedError(_lib.last_error())
+        self._keep = []  # fp32 contiguous device tensors the weight struct points into
+        w = _lib.MolWeights()
+        for key, field in WEIGHT_FIELDS.items():
+            if key not in weights:
+                raise KeyError(f"MoL weight '{key}' is missing")
+            t = weights[key]
+            _require_device(t, f"weight {key}")
+            t = _f32c(t.detach())
+            self._keep.append(t)
+            setattr(w, field, t.data_ptr())
+        for i, hs in enumerate(spec.uid_embedding_hash_sizes):
+            key = f"_query_embeddings_fn._uid_embeddings_{i}.weight"
+            t = _f32c(weights[key].detach())
+            _require_device(t, f"weight {key}")
+            if t.shape[0] != hs + 1:
+                raise ValueError(f"{key} has {t.shape[0]} rows, expected hash_size + 1 = {hs + 1}")
+            self._keep.append(t)
+            w.uid_table[i] = t.data_ptr()
+            w.uid_hash_size[i] = int(hs)
+        self.weights = w
+        self.device = self._keep[0].device
+        n = self.lib.rails_mol_gate_pack_floats(C.byref(self.shape))
+        self.gate_pack = torch.empty(n, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(
+                self.lib.rails_mol_pack_gate_weights(C.byref(self.shape), C.byref(self.weights), _ptr(self.gate_pack), _stream()),
+                "rails_mol_pack_gate_weights",
+            )
+
+    # ---- item side ----------------------------------------------------------------------------
+    def build_index(self, items: torch.Tensor) -> MolIndex:
+        """items: (N, D_i) on the GPU -> tile-packed index (reference: item-side work of
+        rails/similarities/mol/similarity_fn.py:378-387 + :170-171, done once)."""
+        _require_device(items, "item_embeddings")
+        if items.dim() != 2 or items.shape[1] != self.spec.item_embedding_dim:
+            raise ValueError(f"item_embeddings must be (N, {self.spec.item_embedding_dim}), got {tuple(items.shape)}")
+        items = _f32c(items)
+        n = items.shape[0]
+        floats = self.lib.rails_mol_index_floats(C.byref(self.shape), n)
+        buf = torch.empty(floats, dtype=torch.float32, device=items.device)
+        with torch.cuda.device(items.device):
+            _lib.check(
+                self.lib.rails_mol_index_build(C.byref(self.shape), C.byref(self.weights), _ptr(items), n, _ptr(buf), _stream()),
+                "rails_mol_index_build",
+            )
+        return MolIndex(buf, n)
+
+    def unpack_index(self, index: MolIndex, want_ex: bool = True, want_gi: bool = True):
+        s = self.spec
+        ex = torch.empty((index.n_items, s.item_dot_product_groups, s.dot_product_dimension), dtype=torch.float32, device=index.buf.device) if want_ex else None
+        gi = torch.empty((index.n_items, s.num_logits), dtype=torch.float32, device=index.buf.device) if want_gi else None
+        with torch.cuda.device(index.buf.device):
+            _lib.check(
+                self.lib.rails_mol_index_unpack(C.byref(self.shape), _ptr(index.buf), index.n_items, _ptr(ex), _ptr(gi), _stream()),
+                "rails_mol_index_unpack",
+            )
+        return ex, gi
+
+    def gather_index(self, index: MolIndex, cand_idx: torch.Tensor) -> Tuple[MolIndex, int]:
+        """cand_idx: (rows, K) int64 positions -> per-row tile-packed index, K padded to a multiple of 32."""
+        _require_device(cand_idx, "candidate indices")
+        rows, K = cand_idx.shape
+        Kp = (K + TILE_ITEMS - 1) // TILE_ITEMS * TILE_ITEMS
+        idx = cand_idx.to(torch.int64)
+        if Kp != K:
+            idx = torch.nn.functional.pad(idx, (0, Kp - K), value=-1)
+        idx = idx.contiguous()
+        floats = self.lib.rails_mol_index_floats(C.byref(self.shape), rows * Kp)
+        out = torch.empty(floats, dtype=torch.float32, device=idx.device)
+        with torch.cuda.device(idx.device):
+            _lib.check(
+                self.lib.rails_mol_index_gather(C.byref(self.shape), _ptr(index.buf), index.n_items, _ptr(idx), rows, Kp, _ptr(out), _stream()),
+                "rails_mol_index_gather",
+            )
+        return MolIndex(out, rows * Kp), Kp
+
+    # ---- query side ---------------------------------------------------------------------------
+    def query_pack(self, q: torch.Tensor, user_ids: Optional[torch.Tensor] = None, want_plain: bool = False):
+        _require_device(q, "query_embeddings")
+        if q.dim() != 2 or q.shape[1] != self.spec.query_embedding_dim:
+            raise ValueError(f"query_embeddings must be (B, {self.spec.query_embedding_dim}), got {tuple(q.shape)}")
+        q = _f32c(q)
+        B = q.shape[0]
+        uid = None
+        if len(self.spec.uid_embedding_hash_sizes) > 0:
+            if user_ids is None:
+                raise KeyError("user_ids")  # the reference does kwargs["user_ids"] (query_embeddings_fns.py:206)
+            uid = user_ids.to(device=q.device, dtype=torch.int64).contiguous()
+        n = self.lib.rails_mol_query_pack_floats(C.byref(self.shape), B)
+        pack = torch.empty(n, dtype=torch.float32, device=q.device)
+        s = self.spec
+        eq = torch.empty((B, s.query_dot_product_groups, s.dot_product_dimension), dtype=torch.float32, device=q.device) if want_plain else None
+        gq = torch.empty((B, s.num_logits), dtype=torch.float32, device=q.device) if want_plain else None
+        with torch.cuda.device(q.device):
+            _lib.check(
+                self.lib.rails_mol_query_prologue(C.byref(self.shape), C.byref(self.weights), _ptr(q), _ptr(uid), B, _ptr(pack), _ptr(eq), _ptr(gq), _stream()),
+                "rails_mol_query_prologue",
+            )
+        return pack, eq, gq
+
+    # ---- scoring ------------------------------------------------------------------------------
+    def score_dense(self, qpack: torch.Tensor, batch: int, index: MolIndex, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if out is None:
+            out = torch.empty((batch, index.n_items), dtype=torch.float32, device=index.buf.device)
+        with torch.cuda.device(index.buf.device):
+            _lib.check(
+                self.lib.rails_mol_score_dense(C.byref(self.shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(index.buf), index.n_items, _ptr(out), out.stride(0), _stream()),
+                "rails_mol_score_dense",
+            )
+        return out
+
+    def score_candidates(self, qpack: torch.Tensor, batch: int, cand_index: MolIndex, n_cand_padded: int) -> torch.Tensor:
+        out = torch.empty((batch, n_cand_padded), dtype=torch.float32, device=cand_index.buf.device)
+        with torch.cuda.device(cand_index.buf.device):
+            _lib.check(
+                self.lib.rails_mol_score_candidates(C.byref(self.shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(cand_index.buf), n_cand_padded, _ptr(out), out.stride(0), _stream()),
+                "rails_mol_score_candidates",
+            )
+        return out
+
+
+# ---- shape-independent kernels ----------------------------------------------------------------
+def topk(scores: torch.Tensor, k: int, ids: Optional[torch.Tensor] = None, sorted: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Exact top-k of every row of `scores` (rows, n) fp32 on the GPU; ties by position ascending.
+    ids: None -> positions; (n,) or (1, n) -> shared id row; (rows, n) -> per-row ids.
+    Replaces torch.topk + id gather (reference rails/indexing/mol_top_k.py:123-130)."""
+    lib = _lib.load()
+    _require_device(scores, "scores")
+    if scores.dim() != 2:
+        raise ValueError("scores must be (rows, n)")
+    if scores.dtype != torch.float32 or scores.stride(1) != 1:
+        scores = _f32c(scores)
+    rows, n = scores.shape
+    if k > n:
+        raise RuntimeError(f"selected index k out of range (k={k}, n={n})")  # what torch.topk raises
+    stride = 0
+    if ids is not None:
+        ids = ids.to(device=scores.device, dtype=torch.int64)
+        if ids.dim() == 2 and ids.shape[0] == rows and rows > 1:
+            ids = ids.contiguous()
+            stride = ids.shape[1]
+        else:
+            ids = ids.reshape(-1).contiguous()
+        if ids.shape[-1] < n:
+            raise ValueError("ids has fewer entries than scores has columns")
+    out_s = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((rows, k), dtype=torch.int64, device=scores.device)
+    ws_bytes = lib.rails_topk_workspace_bytes(rows, n, k)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=scores.device)
+    with torch.cuda.device(scores.device):
+        _lib.check(
+            lib.rails_topk(_ptr(scores), scores.stride(0), rows, n, k, 1 if sorted else 0, _ptr(ids), stride, _ptr(out_s), _ptr(out_i), _ptr(ws), ws_bytes, _stream()),
+            "rails_topk",
+        )
+    return out_s, out_i
+
+
+def filter_seen_ids(top_ids: torch.Tensor, top_scores: torch.Tensor, invalid_ids: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Row-wise seen-id filter (reference indexing/candidate_index.py:154-178) -> (ids (rows,k), scores (rows,k))."""
+    lib = _lib.load()
+    _require_device(top_ids, "top_k ids")
+    rows, kp = top_ids.shape
+    top_ids = top_ids.to(torch.int64).contiguous()
+    score_dtype = top_scores.dtype
+    top_scores = _f32c(top_scores)
+    inv = invalid_ids.to(device=top_ids.device, dtype=torch.int64).contiguous()
+    out_i = torch.empty((rows, k), dtype=torch.int64, device=top_ids.device)
+    out_s = torch.empty((rows, k), dtype=torch.float32, device=top_ids.device)
+    with torch.cuda.device(top_ids.device):
+        _lib.check(
+            lib.rails_filter_seen_ids(_ptr(top_ids), _ptr(top_scores), rows, kp, _ptr(inv), inv.shape[1], k, _ptr(out_i), _ptr(out_s), _stream()),
+            "rails_filter_seen_ids",
+        )
+    return out_i, out_s.to(score_dtype)

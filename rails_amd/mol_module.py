@@ -1,0 +1,308 @@
+"""Host-side mirror of the reference's MoL similarity modules (rails/similarities/**), eval only.
+
+The classes keep the reference's constructor signatures, attribute names and therefore
+`state_dict()` keys, so a checkpoint of the reference loads unchanged.  They
+hold parameters; the arithmetic of the path runs in the HIP kernels behind `rails_amd.engine`.
+Training-time branches (dropout, mi_loss, uid l2 aux loss) are out of scope and raise.
+"""
+from __future__ import annotations
+
+import abc
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+
+from .engine import MolEngine, MolIndex, MolShapeSpec
+
+
+def _eval_only(module: torch.nn.Module) -> None:
+    if module.training:
+        raise NotImplementedError(
+            f"{type(module).__name__}: rails_amd implements the eval-mode path only; call .eval() first "
+            "(training branches of the reference -- dropout, mi_loss, uid aux loss -- are out of scope)"
+        )
+
+
+class SimilarityModule(torch.nn.Module):
+    """Type contract of reference rails/similarities/module.py:21-42."""
+
+    @abc.abstractmethod
+    def forward(self, query_embeddings: torch.Tensor, item_embeddings: torch.Tensor, **kwargs) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """(B, D), (1/B, X, D') -> ((B, X) similarities, aux losses)."""
+
+
+class _GLU(torch.nn.Module):
+    """Parameter holder for the query projection's gated unit (reference rails/similarities/layers.py:19-74):
+    `_w` (in, 2*out) ~ N(0, 0.02^2), `_b` (1, 2*out) = 0.  Evaluated inside the fused query-prologue kernel."""
+
+    kind = ""
+
+    def __init__(self, in_features: int, out_features: int) -> None:
+        super().__init__()
+        self._in_features = in_features
+        self._out_features = out_features
+        self._w = torch.nn.Parameter(torch.empty((in_features, out_features * 2)).normal_(mean=0, std=0.02))
+        self._b = torch.nn.Parameter(torch.zeros((1, out_features * 2)))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError(f"{type(self).__name__} is evaluated inside rails_amd's query-prologue HIP kernel")
+
+
+class GeGLU(_GLU):
+    kind = "geglu"
+
+
+class SwiGLU(_GLU):
+    kind = "swiglu"
+
+
+class MoLEmbeddingsFn(torch.nn.Module):
+    """Base of the query/item component-embedding generators (reference mol/embeddings_fn.py:56-78)."""
+
+
+class RecoMoLQueryEmbeddingsFn(MoLEmbeddingsFn):
+    """Parameters of reference rails/similarities/mol/query_embeddings_fns.py:129-254."""
+
+    def __init__(
+        self,
+        query_embedding_dim: int,
+        query_dot_product_groups: int,
+        dot_product_dimension: int,
+        dot_product_l2_norm: bool,
+        proj_fn: Callable[[int, int], torch.nn.Module],
+        eps: float,
+        uid_embedding_hash_sizes: List[int],
+        uid_dropout_rate: float,
+        uid_embedding_level_dropout: bool = False,
+    ) -> None:
+        super().__init__()
+        self._uid_embedding_hash_sizes: List[int] = list(uid_embedding_hash_sizes)
+        self._query_emb_based_dot_product_groups: int = query_dot_product_groups - len(self._uid_embedding_hash_sizes)
+        self._query_emb_proj_module: torch.nn.Module = proj_fn(
+            query_embedding_dim, dot_product_dimension * self._query_emb_based_dot_product_groups
+        )
+        self._dot_product_dimension: int = dot_product_dimension
+        self._dot_product_l2_norm: bool = dot_product_l2_norm
+        for i, hash_size in enumerate(self._uid_embedding_hash_sizes):
+            setattr(self, f"_uid_embeddings_{i}", torch.nn.Embedding(hash_size + 1, dot_product_dimension, padding_idx=0))
+        self._uid_dropout_rate: float = uid_dropout_rate
+        self._uid_embedding_level_dropout: bool = uid_embedding_level_dropout
+        self._eps: float = eps
+
+    def forward(self, input_embeddings: torch.Tensor, **kwargs):
+        raise NotImplementedError("evaluated through MoLSimilarity.get_query_component_embeddings (HIP)")
+
+
+class RecoMoLItemEmbeddingsFn(MoLEmbeddingsFn):
+    """Parameters of reference rails/similarities/mol/item_embeddings_fns.py:122-183."""
+
+    def __init__(
+        self,
+        item_embedding_dim: int,
+        item_dot_product_groups: int,
+        dot_product_dimension: int,
+        dot_product_l2_norm: bool,
+        proj_fn: Callable[[int, int], torch.nn.Module],
+        eps: float,
+    ) -> None:
+        super().__init__()
+        self._item_emb_based_dot_product_groups: int = item_dot_product_groups
+        self._item_emb_proj_module: torch.nn.Module = proj_fn(item_embedding_dim, dot_product_dimension * item_dot_product_groups)
+        self._dot_product_dimension: int = dot_product_dimension
+        self._dot_product_l2_norm: bool = dot_product_l2_norm
+        self._eps: float = eps
+
+    def forward(self, input_embeddings: torch.Tensor, **kwargs):
+        raise NotImplementedError("evaluated through MoLSimilarity.get_item_component_embeddings (HIP)")
+
+
+class SoftmaxDropoutCombiner(torch.nn.Module):
+    """Hyper-parameters of reference similarity_fn.py:66-96.  In eval the combiner is softmax followed by
+    the renormalisation pi / clamp(sum pi, eps) whenever dropout_rate > 0 (similarity_fn.py:42-46); the
+    fused kernel applies it always, which is exact for dropout_rate > 0 and a <=1-ulp rescale otherwise."""
+
+    def __init__(self, dropout_rate: float, eps: float) -> None:
+        super().__init__()
+        self._dropout_rate: float = dropout_rate
+        self._eps: float = eps
+
+    def forward(self, gating_weights: torch.Tensor, x: torch.Tensor):
+        raise NotImplementedError("fused into rails_amd's scoring HIP kernel")
+
+
+class MoLGatingFn(torch.nn.Module):
+    """Parameters of reference similarity_fn.py:99-201 (pi_p(q, x))."""
+
+    def __init__(
+        self,
+        num_logits: int,
+        query_embedding_dim: int,
+        item_embedding_dim: int,
+        query_only_partial_fn: Optional[Callable[[int, int], torch.nn.Module]],
+        item_only_partial_fn: Optional[Callable[[int, int], torch.nn.Module]],
+        qi_partial_fn: Optional[Callable[[int, int], torch.nn.Module]],
+        combination_type: str,
+        normalization_fn: Callable[[int], torch.nn.Module],
+    ) -> None:
+        super().__init__()
+        self._query_only_partial_module = query_only_partial_fn(query_embedding_dim, num_logits) if query_only_partial_fn else None
+        self._item_only_partial_module = item_only_partial_fn(item_embedding_dim, num_logits) if item_only_partial_fn else None
+        self._qi_partial_module = qi_partial_fn(num_logits, num_logits) if qi_partial_fn is not None else None
+        if self._query_only_partial_module is None and self._item_only_partial_module is None and self._qi_partial_module is None:
+            raise ValueError(
+                "At least one of query_only_partial_fn, item_only_partial_fn, and qi_partial_fn must not be None."
+            )
+        self._num_logits: int = num_logits
+        self._combination_type: str = combination_type
+        self._normalization_fn: torch.nn.Module = normalization_fn(num_logits)
+
+    def forward(self, logits, query_embeddings, item_embeddings):
+        raise NotImplementedError("fused into rails_amd's scoring HIP kernel")
+
+
+def _find(seq: torch.nn.Module, kind) -> List[torch.nn.Module]:
+    return [m for m in seq.children() if isinstance(m, kind)] if seq is not None else []
+
+
+class MoLSimilarity(SimilarityModule):
+    """Drop-in for reference rails/similarities/mol/similarity_fn.py:204-413 (eval mode)."""
+
+    def __init__(
+        self,
+        query_embedding_dim: int,
+        item_embedding_dim: int,
+        dot_product_dimension: int,
+        query_dot_product_groups: int,
+        item_dot_product_groups: int,
+        temperature: float,
+        dot_product_l2_norm: bool,
+        query_embeddings_fn: MoLEmbeddingsFn,
+        item_embeddings_fn: Optional[MoLEmbeddingsFn],
+        item_proj_fn: Optional[Callable[[int, int], torch.nn.Module]],
+        gating_query_only_partial_fn: Optional[Callable[[int, int], torch.nn.Module]],
+        gating_item_only_partial_fn: Optional[Callable[[int, int], torch.nn.Module]],
+        gating_qi_partial_fn: Optional[Callable[[int], torch.nn.Module]],
+        gating_combination_type: str,
+        gating_normalization_fn: Callable[[int], torch.nn.Module],
+        eps: float,
+        apply_query_embeddings_fn: bool = True,
+        apply_item_embeddings_fn: bool = True,
+        autocast_bf16: bool = False,
+    ) -> None:
+        super().__init__()
+        self._gating_fn: MoLGatingFn = MoLGatingFn(
+            num_logits=query_dot_product_groups * item_dot_product_groups,
+            query_embedding_dim=query_embedding_dim,
+            item_embedding_dim=item_embedding_dim,
+            query_only_partial_fn=gating_query_only_partial_fn,
+            item_only_partial_fn=gating_item_only_partial_fn,
+            qi_partial_fn=gating_qi_partial_fn,
+            combination_type=gating_combination_type,
+            normalization_fn=gating_normalization_fn,
+        )
+        self._query_embeddings_fn: MoLEmbeddingsFn = query_embeddings_fn
+        self._item_embeddings_fn: Optional[MoLEmbeddingsFn] = item_embeddings_fn
+        self._item_proj_module: Optional[torch.nn.Module] = None
+        if item_embeddings_fn is None:
+            raise NotImplementedError("the legacy item_proj_fn path (similarity_fn.py:252-259) is not supported")
+        self._apply_query_embeddings_fn: bool = apply_query_embeddings_fn
+        self._apply_item_embeddings_fn: bool = apply_item_embeddings_fn
+        self._dot_product_l2_norm: bool = dot_product_l2_norm
+        self._query_embedding_dim: int = query_embedding_dim
+        self._item_embedding_dim: int = item_embedding_dim
+        self._query_dot_product_groups: int = query_dot_product_groups
+        self._item_dot_product_groups: int = item_dot_product_groups
+        self._dot_product_dimension: int = dot_product_dimension
+        self._temperature: float = temperature
+        self._eps: float = eps
+        # the reference autocasts to bf16 on CUDA when set; rails_amd always computes in fp32 (closer to
+        # the fp32 oracle than the reference's own bf16 run), so the flag is accepted and ignored
+        self._autocast_bf16: bool = autocast_bf16
+        self._engine: Optional[MolEngine] = None
+        self._engine_key = None
+
+    # ---- binding the parameters to the HIP engine -----------------------------------------------
+    def shape_spec(self) -> MolShapeSpec:
+        if self._gating_fn._combination_type != "glu_silu":
+            if self._gating_fn._combination_type in ("none", "glu_silu_ln"):
+                raise NotImplementedError(
+                    f"gating_combination_type '{self._gating_fn._combination_type}' has no HIP kernel (every shipped config uses glu_silu)"
+                )
+            raise ValueError(f"Unknown combination_type {self._gating_fn._combination_type}")  # similarity_fn.py:198-199
+        qf, itf, g = self._query_embeddings_fn, self._item_embeddings_fn, self._gating_fn
+        if not isinstance(qf, RecoMoLQueryEmbeddingsFn) or not isinstance(itf, RecoMoLItemEmbeddingsFn):
+            raise NotImplementedError("only RecoMoLQueryEmbeddingsFn / RecoMoLItemEmbeddingsFn are supported (LMMoL* is out of scope)")
+        glus = _find(qf._query_emb_proj_module, _GLU)
+        if len(glus) != 1:
+            raise NotImplementedError("query projection without a GLU hidden layer (query_hidden_dim <= 0) has no HIP kernel")
+        if len(_find(itf._item_emb_proj_module, _GLU)) != 0:
+            raise NotImplementedError("item projection with a GLU hidden layer (item_hidden_dim > 0) has no HIP kernel")
+        if g._query_only_partial_module is None or g._item_only_partial_module is None or g._qi_partial_module is None:
+            raise NotImplementedError("the fused kernel needs all three gate parts (query-only, item-only, pair)")
+        qi_linears = _find(g._qi_partial_module, torch.nn.Linear)
+        if len(qi_linears) != 2:
+            raise NotImplementedError("pair gate without a hidden layer (gating_qi_hidden_dim <= 0) has no HIP kernel")
+        return MolShapeSpec(
+            query_embedding_dim=self._query_embedding_dim,
+            item_embedding_dim=self._item_embedding_dim,
+            dot_product_dimension=self._dot_product_dimension,
+            query_dot_product_groups=self._query_dot_product_groups,
+            item_dot_product_groups=self._item_dot_product_groups,
+            query_hidden_dim=glus[0]._out_features,
+            gating_query_hidden_dim=_find(g._query_only_partial_module, torch.nn.Linear)[0].out_features,
+            gating_item_hidden_dim=_find(g._item_only_partial_module, torch.nn.Linear)[0].out_features,
+            gating_qi_hidden_dim=qi_linears[0].out_features,
+            query_nonlinearity=glus[0].kind,
+            uid_embedding_hash_sizes=tuple(qf._uid_embedding_hash_sizes),
+            dot_product_l2_norm=bool(self._dot_product_l2_norm),
+            temperature=float(self._temperature),
+            eps=float(self._eps),
+        )
+
+    def engine(self) -> MolEngine:
+        """HIP engine bound to the CURRENT parameter values (rebuilt when any parameter changed)."""
+        _eval_only(self)
+        if not self._apply_query_embeddings_fn or not self._apply_item_embeddings_fn:
+            raise NotImplementedError("apply_query_embeddings_fn / apply_item_embeddings_fn = False is not supported")
+        params = dict(self.state_dict(keep_vars=True))
+        key = tuple((k, v.data_ptr(), v._version, v.dtype) for k, v in params.items())
+        if self._engine is None or key != self._engine_key:
+            self._engine = MolEngine(self.shape_spec(), params)
+            self._engine_key = key
+        return self._engine
+
+    # ---- reference API --------------------------------------------------------------------------
+    def get_query_component_embeddings(self, input_embeddings: torch.Tensor, decoupled_inference: bool = False, **kwargs):
+        """(B, D) -> ((B, P_Q, d), {}).  Reference similarity_fn.py:270-292."""
+        if decoupled_inference and not self._apply_query_embeddings_fn:
+            return input_embeddings, {}
+        _, eq, _ = self.engine().query_pack(input_embeddings, kwargs.get("user_ids"), want_plain=True)
+        return eq.to(input_embeddings.dtype), {}
+
+    def get_item_component_embeddings(self, input_embeddings: torch.Tensor, decoupled_inference: bool = False, **kwargs):
+        """(..., D') -> ((..., P_X, d), {}).  Reference similarity_fn.py:294-339."""
+        if decoupled_inference and not self._apply_item_embeddings_fn:
+            return input_embeddings, {}
+        eng = self.engine()
+        lead = input_embeddings.shape[:-1]
+        ex, _ = eng.unpack_index(eng.build_index(input_embeddings.reshape(-1, input_embeddings.shape[-1])), want_gi=False)
+        return ex.reshape(lead + ex.shape[1:]).to(input_embeddings.dtype), {}
+
+    def forward(self, query_embeddings: torch.Tensor, item_embeddings: torch.Tensor, **kwargs) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """(B, D), (1/B, X, D') -> ((B, X), {}).  Reference similarity_fn.py:341-413."""
+        eng = self.engine()
+        B = query_embeddings.size(0)
+        Bp, X = item_embeddings.shape[0], item_embeddings.shape[1]
+        qpack, _, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"))
+        if Bp == 1:
+            logits = eng.score_dense(qpack, B, eng.build_index(item_embeddings[0]))
+        else:
+            if Bp != B:
+                raise RuntimeError(f"item_embeddings.shape[0] must be 1 or B={B}, got {Bp}")
+            Xp = (X + 31) // 32 * 32
+            items = item_embeddings
+            if Xp != X:
+                items = torch.nn.functional.pad(items, (0, 0, 0, Xp - X))
+            cand = eng.build_index(items.reshape(B * Xp, items.shape[-1]))
+            logits = eng.score_candidates(qpack, B, cand, Xp)[:, :X]
+        return logits.to(query_embeddings.dtype), {}

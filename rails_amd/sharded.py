@@ -1,0 +1,96 @@
+"""Item-sharded exact MoL top-k: one process per GPU, one small all-gather per batch.
+
+The reference has no sharded retrieval (eval is asserted single-GPU, eval_from_checkpoint.py:554-555); this
+is the north-star's 8-GPU path.  Its oracle is "equals single-device brute force over the concatenated
+corpus", which holds bit for bit because (a) per-pair arithmetic does not depend on the shard and
+(b) selection uses the total order (score desc, global position asc) at both levels.
+
+  rank r owns items [r * ceil(N/R), min(N, (r+1) * ceil(N/R)))      (contiguous item-id ranges)
+  queries and MoL weights are replicated (KBs); every rank redoes the query prologue
+  per batch: local scoring -> local top-k -> ONE all_gather of B*k*16 bytes -> merge R*k -> k on every rank
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import engine as E
+from .topk_modules import MoLBruteForceTopK, TopKModule
+
+
+def shard_bounds(n_items: int, world_size: int, rank: int) -> Tuple[int, int]:
+    per = (n_items + world_size - 1) // world_size
+    lo = min(n_items, rank * per)
+    return lo, min(n_items, lo + per)
+
+
+def pack_candidates(scores: torch.Tensor, ids: torch.Tensor, k: int) -> torch.Tensor:
+    """(B, k_local) fp32 scores + int64 ids -> one (B, 2k) int64 message (score bits | ids); rows shorter than
+    k are padded with -inf / id -1 so every rank sends the same size."""
+    B, kl = scores.shape
+    if kl < k:
+        scores = torch.cat([scores, scores.new_full((B, k - kl), float("-inf"))], 1)
+        ids = torch.cat([ids, ids.new_full((B, k - kl), -1)], 1)
+    return torch.cat([scores.contiguous().view(torch.int32).to(torch.int64), ids], 1)
+
+
+def unpack_candidates(msg: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(R, B, 2k) gathered messages -> (B, R*k) scores and ids in shard-major order."""
+    R, B, _ = msg.shape
+    scores = msg[:, :, :k].to(torch.int32).view(torch.float32)
+    ids = msg[:, :, k:]
+    return scores.permute(1, 0, 2).reshape(B, R * k).contiguous(), ids.permute(1, 0, 2).reshape(B, R * k).contiguous()
+
+
+def _hip_merge(scores: torch.Tensor, ids: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    return E.topk(scores, k, ids=ids)
+
+
+class ShardedMoLBruteForceTopK(TopKModule):
+    """forward(query_embeddings, k) -> (scores (B, k), ids (B, k)), identical on every rank and identical to
+    MoLBruteForceTopK over the whole corpus.  `local_topk` / `merge` default to the HIP kernels; the CPU tests
+    of the collective logic inject oracle-backed callables instead (gloo, world_size 2)."""
+
+    def __init__(
+        self,
+        mol_module,
+        item_embeddings_shard: Optional[torch.Tensor],
+        item_ids_shard: Optional[torch.Tensor],
+        n_items_total: int,
+        group: Optional[dist.ProcessGroup] = None,
+        local_topk: Optional[Callable[..., Tuple[torch.Tensor, torch.Tensor]]] = None,
+        merge: Optional[Callable[[torch.Tensor, torch.Tensor, int], Tuple[torch.Tensor, torch.Tensor]]] = None,
+    ) -> None:
+        super().__init__()
+        self._group = group
+        self._world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self._n_total = n_items_total
+        if local_topk is None:
+            self._local_module = MoLBruteForceTopK(mol_module, item_embeddings_shard, item_ids_shard)
+            self._n_local = self._local_module.num_items
+            local_topk = lambda q, k, **kw: self._local_module(q, k=k, **kw)  # noqa: E731
+        else:
+            self._n_local = int(item_ids_shard.numel())
+        self._local_topk = local_topk
+        self._merge = merge if merge is not None else _hip_merge
+
+    def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        if k > self._n_total:
+            raise RuntimeError(f"selected index k out of range (k={k}, n={self._n_total})")
+        k_local = min(k, self._n_local)
+        if k_local > 0:
+            s, ids = self._local_topk(query_embeddings, k_local, **kwargs)
+        else:  # an empty shard still takes part in the collective
+            B = query_embeddings.size(0)
+            s = torch.empty((B, 0), dtype=torch.float32, device=query_embeddings.device)
+            ids = torch.empty((B, 0), dtype=torch.int64, device=query_embeddings.device)
+        if self._world == 1:
+            return s, ids
+        msg = pack_candidates(s.float(), ids, k)
+        gathered = torch.empty((self._world,) + tuple(msg.shape), dtype=msg.dtype, device=msg.device)
+        dist.all_gather_into_tensor(gathered, msg, group=self._group)
+        all_s, all_ids = unpack_candidates(gathered, k)
+        ms, mi = self._merge(all_s, all_ids, k)
+        return ms.to(s.dtype), mi

@@ -1,0 +1,148 @@
+"""Host-side mirror of the reference's top-k modules and candidate index.
+
+  TopKModule            reference rails/indexing/candidate_index.py:24-42
+  MoLBruteForceTopK     reference rails/indexing/mol_top_k.py:84-130   (exact)
+  MoLAvgTopK            reference rails/indexing/mol_top_k.py:296-429  (two-pass approximate)
+  CandidateIndex        reference indexing/candidate_index.py:30-185
+  get_top_k_module      reference indexing/utils_rails.py:25-233
+
+Unlike the reference, which keeps the raw (1, N, D) table and re-projects every item on every call
+(mol_top_k.py:118-122), the modules here build the tile-packed item index once at construction
+(rebuilt automatically if the MoL module's parameters change) and per call run: query prologue ->
+fused scoring -> exact top-k -> id gather, all HIP.
+"""
+from __future__ import annotations
+
+import abc
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import engine as E
+from .mol_module import MoLSimilarity
+
+
+class TopKModule(torch.nn.Module):
+    @abc.abstractmethod
+    def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (top_k_scores (B, k), top_k_ids (B, k))."""
+
+
+class MoLTopKModule(TopKModule):
+    """Common state of the MoL top-k modules (reference mol_top_k.py:29-81): borrows `item_embeddings`
+    (1, N, D) and `item_ids` (1, N); owns the packed index."""
+
+    def __init__(self, mol_module: MoLSimilarity, item_embeddings: torch.Tensor, item_ids: torch.Tensor) -> None:
+        super().__init__()
+        self._mol_module: MoLSimilarity = mol_module
+        if item_embeddings.dim() != 3 or item_embeddings.shape[0] != 1:
+            raise ValueError(f"item_embeddings must be (1, N, D), got {tuple(item_embeddings.shape)}")
+        self._item_embeddings: torch.Tensor = item_embeddings
+        self._item_ids: torch.Tensor = item_ids
+        self._ids_flat: torch.Tensor = item_ids.reshape(-1).to(device=item_embeddings.device, dtype=torch.int64).contiguous()
+        self._engine: Optional[E.MolEngine] = None
+        self._index: Optional[E.MolIndex] = None
+        self._bind()
+
+    @property
+    def mol_module(self) -> MoLSimilarity:
+        return self._mol_module
+
+    @property
+    def num_items(self) -> int:
+        return self._item_embeddings.shape[1]
+
+    def _bind(self) -> E.MolEngine:
+        eng = self._mol_module.engine()
+        if eng is not self._engine:  # first use, or the module's parameters changed
+            self._engine = eng
+            self._index = eng.build_index(self._item_embeddings[0])
+        return eng
+
+    def all_logits(self, query_embeddings: torch.Tensor, **kwargs) -> torch.Tensor:
+        """(B, N) fp32 MoL logits against the whole corpus."""
+        eng = self._bind()
+        qpack, _, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"))
+        return eng.score_dense(qpack, query_embeddings.size(0), self._index)
+
+
+class MoLBruteForceTopK(MoLTopKModule):
+    def __init__(self, mol_module: MoLSimilarity, item_embeddings: torch.Tensor, item_ids: torch.Tensor) -> None:
+        super().__init__(mol_module=mol_module, item_embeddings=item_embeddings, item_ids=item_ids)
+
+    def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        logits = self.all_logits(query_embeddings, **kwargs)
+        scores, ids = E.topk(logits, k, ids=self._ids_flat, sorted=sorted)
+        return scores.to(query_embeddings.dtype), ids
+
+
+class CandidateIndex(object):
+    """Reference indexing/candidate_index.py:30-185 (`filter_invalid_ids` / `apply_object_filter` are never
+    called by any entry point of the reference and are not provided)."""
+
+    def __init__(self, ids: torch.Tensor, embeddings: torch.Tensor, invalid_ids: Optional[torch.Tensor] = None, debug_path: Optional[str] = None) -> None:
+        super().__init__()
+        self._ids: torch.Tensor = ids
+        self._embeddings: torch.Tensor = embeddings
+        self._invalid_ids: Optional[torch.Tensor] = invalid_ids
+        self._debug_path: Optional[str] = debug_path
+
+    @property
+    def ids(self) -> torch.Tensor:
+        return self._ids
+
+    @property
+    def num_objects(self) -> int:
+        return self._ids.size(1)
+
+    @property
+    def embeddings(self) -> torch.Tensor:
+        return self._embeddings
+
+    def get_top_k_outputs(
+        self,
+        query_embeddings: torch.Tensor,
+        k: int,
+        aux_payloads: Dict[str, torch.Tensor],
+        top_k_module: TopKModule,
+        invalid_ids: Optional[torch.Tensor],
+        r: int = 1,
+        return_embeddings: bool = False,
+        truncate_k_prime_to: Optional[int] = None,
+    ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+        """-> (top_k_ids (B, k), top_k_scores (B, k), None).  Note: ids first, as in the reference."""
+        if return_embeddings:
+            # the reference's own branch is broken (undefined `top_k_indices`, candidate_index.py:182)
+            raise NotImplementedError("return_embeddings=True is not supported")
+        max_num_invalid_ids = invalid_ids.size(1) if invalid_ids is not None else 0
+        k_prime = min(k + max_num_invalid_ids, self.num_objects)
+        if truncate_k_prime_to is not None:
+            k_prime = min(k_prime, truncate_k_prime_to)
+        top_k_prime_scores, top_k_prime_ids = top_k_module(query_embeddings=query_embeddings, k=k_prime, **aux_payloads)
+        if invalid_ids is not None:
+            if top_k_prime_ids.shape[1] < k:
+                # the reference fails in .view(-1, k) here
+                raise RuntimeError(f"shape '[-1, {k}]' is invalid: only {top_k_prime_ids.shape[1]} candidates per row")
+            top_k_ids, top_k_scores = E.filter_seen_ids(top_k_prime_ids, top_k_prime_scores, invalid_ids, k)
+        else:
+            top_k_scores, top_k_ids = top_k_prime_scores, top_k_prime_ids
+        return top_k_ids, top_k_scores, None
+
+
+_BUILT = {"MoLBruteForceTopK": lambda mol, x, ids: MoLBruteForceTopK(mol_module=mol, item_embeddings=x, item_ids=ids)}
+# names the reference's factory accepts but this build does not implement yet
+_KNOWN_UNBUILT = (
+    ["MIPSBruteForceTopK", "MoLNaiveFaissTopK5"]
+    + [f"MoLNaiveTopK{k}" for k in (5, 10, 25, 50, 75, 100)]
+    + [f"MoLAvgTopK{k}" for k in (100, 200, 500, 1000, 2000, 2500, 3000, 4000)]
+    + [f"MoLCombTopK{a}_{b}" for a, b in ((1, 100), (1, 500), (5, 100), (5, 200), (5, 500), (10, 100), (10, 500), (50, 500), (50, 1000), (100, 1000))]
+)
+
+
+def get_top_k_module(top_k_method: str, model: torch.nn.Module, item_embeddings: torch.Tensor, item_ids: torch.Tensor) -> TopKModule:
+    """String -> module factory; `model._ndp_module` is the MoLSimilarity (reference indexing/utils_rails.py:25-233)."""
+    if top_k_method in _BUILT:
+        return _BUILT[top_k_method](model._ndp_module, item_embeddings, item_ids)
+    if top_k_method in _KNOWN_UNBUILT:
+        raise NotImplementedError(f"top_k_method {top_k_method} is not built yet in rails_amd")
+    raise ValueError(f"Invalid top-k method {top_k_method}")

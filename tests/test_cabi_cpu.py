@@ -1,0 +1,73 @@
+"""CPU: the C-ABI library loads and exports every symbol include/rails_amd.h declares; argument
+validation and the host-side mirror work without a GPU (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+import rails_amd
+from rails_amd import _lib
+from rails_amd import engine as E
+from tests._fixtures import Fixture
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    header = open(os.path.join(ROOT, "include", "rails_amd.h")).read()
+    declared = set(re.findall(r"\b(rails_[a-z0-9_]+)\s*\(", header))
+    declared -= {"rails_mol_shape", "rails_mol_weights"}
+    assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    for name in declared:
+        assert getattr(lib, name) is not None
+
+
+def test_struct_layout_matches_header(lib):
+    assert C.sizeof(_lib.MolShape) == 14 * 4
+    assert C.sizeof(_lib.MolWeights) == 8 * (4 + 4 + 4 + 12)  # 24 pointer-sized fields
+
+
+def test_size_helpers_and_validation(lib):
+    s = E.MolShapeSpec(64, 64, 32, 8, 8, 512, 128, 128, 128).to_c()
+    assert lib.rails_mol_shape_supported(C.byref(s)) == 1
+    assert lib.rails_mol_gate_pack_floats(C.byref(s)) == 2 * 128 * 64 + 128 + 64
+    assert lib.rails_mol_index_floats(C.byref(s), 33) == 2 * 32 * (8 * 32 + 64)     # two tiles
+    assert lib.rails_mol_query_pack_floats(C.byref(s), 5) == 2 * 32 * 32 + 5 * 64   # two query groups of 4
+    bad = E.MolShapeSpec(64, 64, 48, 8, 8, 512, 128, 128, 128).to_c()
+    assert lib.rails_mol_shape_supported(C.byref(bad)) == 0 and "no fused scoring kernel" in _lib.last_error()
+    # k > n is rejected before any launch
+    assert lib.rails_topk(1, 10, 1, 10, 11, 1, None, 0, 1, 1, None, 0, None) == _lib.RAILS_EINVAL
+    with pytest.raises(ValueError):
+        _lib.check(_lib.RAILS_EINVAL, "x")
+    with pytest.raises(NotImplementedError):
+        _lib.check(_lib.RAILS_ENOTSUP, "x")
+
+
+def test_module_mirror_state_dict_and_loud_failure_on_cpu():
+    fx = Fixture("c1_ml1m")
+    cfg = fx.cfg
+    mol, dbg = rails_amd.create_mol_interaction_module(
+        cfg.query_embedding_dim, cfg.item_embedding_dim, cfg.dot_product_dimension, cfg.query_dot_product_groups,
+        cfg.item_dot_product_groups, cfg.temperature, 0.0, cfg.query_hidden_dim, 0.1, cfg.item_hidden_dim,
+        cfg.gating_query_hidden_dim, cfg.gating_qi_hidden_dim, cfg.gating_item_hidden_dim, cfg.softmax_dropout_rate, False,
+        query_nonlinearity=cfg.query_nonlinearity, uid_embedding_hash_sizes=list(cfg.uid_embedding_hash_sizes))
+    assert dbg.startswith("MoL-8x4x64-t0.05-d0.2-l2-q512d0.0swiglu-id0.1-gq128-gi128d0.0-gqi128d0.0-x-glu_silu-uids6040")
+    assert set(mol.state_dict()) == set(fx.weights)          # the reference's keys, exactly
+    mol.load_state_dict(fx.weights, strict=True)
+    with pytest.raises(NotImplementedError):                 # training mode is out of scope
+        mol(fx.t("q"), fx.t("X"), **fx.kw)
+    mol.eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):  # CPU tensors never reach a fallback
+        mol(fx.t("q"), fx.t("X"), **fx.kw)
+    with pytest.raises(ValueError, match="Invalid top-k method"):
+        rails_amd.get_top_k_module("Nope", None, None, None)

@@ -1,0 +1,225 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors and the oracle."""
+import pytest
+import torch
+
+import rails_amd
+from oracle import mol_oracle as O
+from rails_amd import engine as E
+from tests._fixtures import PER_CONFIG, Fixture, assert_topk_matches, full_size_inputs
+
+pytestmark = pytest.mark.gpu
+LOGIT_TOL = 1e-4   # BASELINE.json north_star: "within 1e-4 on MoL logits"
+STAGE_TOL = 2e-6   # unit-norm embeddings / O(1) gates: a few ulp of summation-order noise
+
+SUPPORTED = ["c1_ml1m", "c2_ml20m", "c3_books"]
+
+
+def build_module(cfg, weights, dev):
+    mol, _ = rails_amd.create_mol_interaction_module(
+        cfg.query_embedding_dim, cfg.item_embedding_dim, cfg.dot_product_dimension, cfg.query_dot_product_groups,
+        cfg.item_dot_product_groups, cfg.temperature, 0.0, cfg.query_hidden_dim, 0.1, cfg.item_hidden_dim,
+        cfg.gating_query_hidden_dim, cfg.gating_qi_hidden_dim, cfg.gating_item_hidden_dim, cfg.softmax_dropout_rate, False,
+        query_nonlinearity=cfg.query_nonlinearity, uid_embedding_hash_sizes=list(cfg.uid_embedding_hash_sizes) or None,
+    )
+    mol.load_state_dict(weights, strict=True)
+    return mol.to(dev).eval()
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module", params=SUPPORTED)
+def fx(request):
+    return Fixture(request.param)
+
+
+@pytest.fixture(scope="module")
+def mol(fx, dev):
+    return build_module(fx.cfg, fx.weights, dev)
+
+
+def kw_dev(fx, dev):
+    return {k: v.to(dev) for k, v in fx.kw.items()}
+
+
+def test_f1_stages(fx, mol, dev):
+    n = int(fx.z["F1/n"])
+    q, X = fx.t("q").to(dev), fx.t("X")[:, :n].to(dev)
+    with torch.inference_mode():
+        eq, _ = mol.get_query_component_embeddings(q, **kw_dev(fx, dev))
+        ex, _ = mol.get_item_component_embeddings(X)
+        eng = mol.engine()
+        _, _, gq = eng.query_pack(q, fx.user_ids, want_plain=True) if fx.user_ids is None else eng.query_pack(q, fx.user_ids.to(dev), want_plain=True)
+        _, gi = eng.unpack_index(eng.build_index(X[0]), want_ex=False)
+        logits, aux = mol(q, X, **kw_dev(fx, dev))
+    assert aux == {}
+    for name, got, tol in (("Eq", eq, STAGE_TOL), ("Ex", ex, STAGE_TOL), ("gq", gq, 1e-5), ("gi", gi.unsqueeze(0), 1e-5), ("logits", logits, LOGIT_TOL)):
+        ref = fx.t("F1/" + name)
+        d = float((got.cpu().reshape(ref.shape) - ref).abs().max())
+        assert d <= tol, f"{fx.name}:{name} max|d| = {d}"
+
+
+def test_f2_brute_force_topk(fx, mol, dev):
+    X, ids = fx.t("X").to(dev), fx.t("item_ids").to(dev)
+    N = X.shape[1]
+    with torch.inference_mode():
+        tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
+        logits = tk.all_logits(fx.t("q").to(dev), **kw_dev(fx, dev))
+        d = float((logits.cpu() - fx.t("F2/all_logits")).abs().max())
+        assert d <= LOGIT_TOL, d
+        for k in (10, 200, N):
+            s, i = tk(fx.t("q").to(dev), k=k, **kw_dev(fx, dev))
+            assert s.shape == (fx.t("q").shape[0], k) and i.dtype == torch.int64
+            assert_topk_matches(s, i, fx.t(f"F2/k{k}/scores"), fx.t(f"F2/k{k}/ids"), atol=LOGIT_TOL)
+        with pytest.raises(RuntimeError):
+            tk(fx.t("q").to(dev), k=N + 1, **kw_dev(fx, dev))
+
+
+@pytest.mark.parametrize("case", ["timing", "accuracy", "backfill", "nofilter"])
+def test_f3_candidate_index(fx, mol, dev, case):
+    X, ids = fx.t("X").to(dev), fx.t("item_ids").to(dev)
+    k = int(fx.z[f"F3/{case}/k"])
+    trunc = int(fx.z[f"F3/{case}/truncate"])
+    inv = fx.t(f"F3/{case}/invalid_ids").to(dev) if fx.has(f"F3/{case}/invalid_ids") else None
+    with torch.inference_mode():
+        ci = rails_amd.CandidateIndex(ids=ids, embeddings=X)
+        tk = rails_amd.get_top_k_module("MoLBruteForceTopK", type("M", (), {"_ndp_module": mol})(), X, ids)
+        r_ids, r_scores, r_emb = ci.get_top_k_outputs(
+            query_embeddings=fx.t("q").to(dev), k=k, aux_payloads=kw_dev(fx, dev), top_k_module=tk, invalid_ids=inv,
+            return_embeddings=False, truncate_k_prime_to=None if trunc < 0 else trunc)
+    assert r_emb is None
+    assert_topk_matches(r_scores, r_ids, fx.t(f"F3/{case}/scores"), fx.t(f"F3/{case}/ids"), atol=LOGIT_TOL)
+
+
+def test_f6_per_row_candidates(fx, mol, dev):
+    X = fx.t("X").squeeze(0)
+    cand = X[fx.t("F6/cand_idx")].to(dev)   # (B, 48, D): 48 is not a multiple of 32 -> padded tile
+    with torch.inference_mode():
+        got, _ = mol(fx.t("q").to(dev), cand, **kw_dev(fx, dev))
+    d = float((got.cpu() - fx.t("F6/logits")).abs().max())
+    assert d <= LOGIT_TOL, d
+
+
+def test_f5_harness_metrics(dev):
+    fx = Fixture("harness")
+    mol = build_module(fx.cfg, fx.weights, dev)
+    X, ids, q = fx.t("X").to(dev), fx.t("item_ids").to(dev), fx.t("q").to(dev)
+    past, target = fx.t("past_ids"), fx.t("target_ids")
+    N = X.shape[1]
+    with torch.inference_mode():
+        ci = rails_amd.CandidateIndex(ids=ids, embeddings=X)
+        tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
+        for mode, max_k, trunc in (("accuracy", 2500, None), ("timing", 120, 200)):
+            k = min(max_k, N)
+            top_ids, top_scores, _ = ci.get_top_k_outputs(q, k, {}, tk, past.to(dev), truncate_k_prime_to=trunc)
+            ref_ids = fx.t(f"F5/{mode}/eval_top_k_ids")
+            # ids -> ranks -> HR/NDCG/MRR: identical ids give identical metrics
+            m = O.eval_metrics(top_ids.cpu(), target, max_k)
+            ref_m = O.eval_metrics(ref_ids, target, max_k)
+            assert torch.equal(m["rank"], ref_m["rank"])
+            for key in ("hr@1", "hr@10", "hr@50", "hr@100"):
+                assert torch.equal(m[key], fx.t(f"F5/{mode}/{key}")), key
+            assert torch.allclose(m["mrr"].float(), fx.t(f"F5/{mode}/mrr").float(), atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["full_c1_ml1m", "full_c2_ml20m"])
+def test_f7_full_size(name, dev):
+    fx = Fixture(name)
+    mol = build_module(fx.cfg, fx.weights, dev)
+    X, ids = full_size_inputs(fx)
+    with torch.inference_mode():
+        tk = rails_amd.MoLBruteForceTopK(mol, X.to(dev), ids.to(dev))
+        s, i = tk(fx.t("q").to(dev), k=200, **kw_dev(fx, dev))
+        logits = tk.all_logits(fx.t("q").to(dev), **kw_dev(fx, dev))
+    assert_topk_matches(s, i, fx.t("scores"), fx.t("ids"), atol=LOGIT_TOL)
+    assert float((logits[0].cpu() - fx.t("logits_first_row")).abs().max()) <= LOGIT_TOL
+    assert float((logits.double().sum(1).cpu() - fx.t("logits_rowsum_f64")).abs().max()) <= LOGIT_TOL * logits.shape[1] * 0.05
+
+
+# ---- selection kernels on their own ---------------------------------------------------------------
+@pytest.mark.parametrize("rows,n,k", [(1, 1, 1), (3, 37, 5), (4, 1000, 1000), (2, 16384, 300), (5, 16385, 200),
+                                      (32, 100000, 2711), (1, 3000000, 16384), (7, 70001, 1)])
+def test_topk_matches_deterministic_rule(dev, rows, n, k):
+    g = torch.Generator().manual_seed(rows * 1000003 + n)
+    scores = torch.randn((rows, n), generator=g)
+    s, i = E.topk(scores.to(dev), k)
+    rs, ri = O.select_topk_deterministic(scores, k)
+    assert torch.equal(s.cpu(), rs) and torch.equal(i.cpu(), ri)
+
+
+@pytest.mark.parametrize("n", [5000, 200000])
+def test_topk_with_heavy_ties_is_position_ordered(dev, n):
+    g = torch.Generator().manual_seed(n)
+    scores = torch.randint(0, 7, (6, n), generator=g).float() - 3.0   # only 7 distinct values
+    scores[0] = 0.0                                                     # a constant row
+    scores[1, ::3] = float("-inf")
+    for k in (1, 50, 4096):
+        s, i = E.topk(scores.to(dev), k)
+        rs, ri = O.select_topk_deterministic(scores, k)
+        assert torch.equal(s.cpu(), rs) and torch.equal(i.cpu(), ri)
+
+
+def test_topk_id_lookup_and_strided_rows(dev):
+    g = torch.Generator().manual_seed(5)
+    big = torch.randn((4, 50000), generator=g).to(dev)
+    view = big[:, :40000]                      # ld > n
+    ids = torch.randperm(40000, generator=g).to(dev) + 7
+    s, i = E.topk(view, 100, ids=ids)
+    rs, ri = O.select_topk_deterministic(view.cpu(), 100)
+    assert torch.equal(s.cpu(), rs) and torch.equal(i.cpu(), ids.cpu()[ri])
+    per_row = torch.stack([torch.randperm(40000, generator=g) for _ in range(4)]).to(dev)
+    s, i = E.topk(view, 100, ids=per_row)
+    assert torch.equal(i.cpu(), torch.gather(per_row.cpu(), 1, ri))
+
+
+@pytest.mark.parametrize("rows,kp,width,k", [(4, 200, 61, 120), (8, 2711, 211, 2500), (3, 25, 30, 20), (2, 10, 1, 10)])
+def test_filter_seen_ids_matches_oracle(dev, rows, kp, width, k):
+    g = torch.Generator().manual_seed(kp)
+    ids = torch.stack([torch.randperm(5 * kp, generator=g)[:kp] + 1 for _ in range(rows)])
+    scores = torch.sort(torch.randn((rows, kp), generator=g), dim=1, descending=True)[0]
+    inv = torch.zeros((rows, width), dtype=torch.int64)
+    for r in range(rows):
+        m = min(width, kp - 1) if r % 2 == 0 else width // 2     # even rows: nearly everything is seen -> back-fill
+        inv[r, :m] = ids[r, torch.randperm(kp, generator=g)[:m]]
+    out_i, out_s = E.filter_seen_ids(ids.to(dev), scores.to(dev), inv.to(dev), k)
+    ref_i, ref_s = O.filter_seen_ids(ids, scores, inv, k)
+    assert torch.equal(out_i.cpu(), ref_i) and torch.equal(out_s.cpu(), ref_s)
+
+
+# ---- properties at the full amzn-books size --------------------------------------------------------
+def test_full_size_books_properties(dev):
+    """N = 695 762, B = 32 (BASELINE.json config 3): the oracle cannot score this in seconds, so check
+    (a) a random sample of columns against the oracle, (b) shard-merge == global top-k, (c) idempotence."""
+    cfg = O.CONFIGS["amzn-books"]
+    w = O.synthetic_weights(cfg, seed=0)
+    mol = build_module(cfg, w, dev)
+    N, B, k = 695762, 32, 200
+    X = torch.from_numpy(O.hash_item_table(1, 0, N, cfg.item_embedding_dim))
+    q = O.synthetic_queries(cfg, B)
+    with torch.inference_mode():
+        tk = rails_amd.MoLBruteForceTopK(mol, X.unsqueeze(0).to(dev), torch.arange(1, N + 1).unsqueeze(0).to(dev))
+        logits = tk.all_logits(q.to(dev))
+        s, i = tk(q.to(dev), k=k)
+        s2, i2 = tk(q.to(dev), k=k)
+    assert torch.equal(s, s2) and torch.equal(i, i2)          # deterministic
+    assert bool((s[:, :-1] >= s[:, 1:]).all())                # sorted descending
+    g = torch.Generator().manual_seed(9)
+    cols = torch.cat([torch.randperm(N, generator=g)[:4096], torch.tensor([0, 31, 32, N - 1, N - 2])])
+    ref = O.mol_logits(cfg, w, q, X[cols].unsqueeze(0))
+    d = float((logits[:, cols.to(dev)].cpu() - ref).abs().max())
+    assert d <= LOGIT_TOL, d
+    # the returned scores are the logits at the returned positions, and nothing outside beats the k-th
+    assert torch.equal(torch.gather(logits, 1, i - 1), s)
+    assert bool((logits >= s[:, -1:]).sum(1).ge(k).all()) and bool((logits > s[:, -1:]).sum(1).lt(k).all())
+    # sharded evaluation: per-shard top-k merged == global top-k, bit for bit (2/4/8 shards)
+    for R in (2, 8):
+        bounds = [((N + R - 1) // R) * r for r in range(R)] + [N]
+        parts_s, parts_i = [], []
+        for r in range(R):
+            ps, pi = E.topk(logits[:, bounds[r]:bounds[r + 1]], k)
+            parts_s.append(ps)
+            parts_i.append(pi + bounds[r] + 1)
+        ms, mi = E.topk(torch.cat(parts_s, 1), k, ids=torch.cat(parts_i, 1))
+        assert torch.equal(ms, s) and torch.equal(mi, i)
