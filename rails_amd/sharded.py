@@ -89,8 +89,9 @@ class ShardedMoLBruteForceTopK(TopKModule):
         if self._world == 1:
             return s, ids
         msg = pack_candidates(s.float(), ids, k)
-        gathered = torch.empty((self._world,) + tuple(msg.shape), dtype=msg.dtype, device=msg.device)
+        # concatenated-along-dim-0 output: the layout both RCCL and gloo accept for all_gather_into_tensor
+        gathered = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype, device=msg.device)
         dist.all_gather_into_tensor(gathered, msg, group=self._group)
-        all_s, all_ids = unpack_candidates(gathered, k)
+        all_s, all_ids = unpack_candidates(gathered.view(self._world, msg.shape[0], msg.shape[1]), k)
         ms, mi = self._merge(all_s, all_ids, k)
         return ms.to(s.dtype), mi
