@@ -24,7 +24,7 @@ __global__ void pack_gate_kernel(const float* __restrict__ w1, const float* __re
     if (i < H * L) {  // W1frag[ec][t][lane][j] = W1[32t + (lane&31)][logit_of(4ec+j, lane>>5)]
       const int j = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
       const int t = blk % TH, ec = blk / TH;
-      v = w1[(32 * t + (lane & 31)) * L + logit_of(4 * ec + j, lane >> 5, PQ, PX)];
+      v = -kLog2e * w1[(32 * t + (lane & 31)) * L + logit_of(4 * ec + j, lane >> 5, PQ, PX)];
     } else if (i < 2 * H * L) {  // W2frag[fc][v][lane][j] = W2[lrow(v, lane&31)][hidden_of(4fc+j, lane>>5)]
       const int k = i - H * L;
       const int j = k & 3, lane = (k >> 2) & 63, blk = k >> 8;
@@ -35,11 +35,11 @@ __global__ void pack_gate_kernel(const float* __restrict__ w1, const float* __re
     } else if (i < 2 * H * L + H) {  // b1frag[t][hi][r]
       const int k = i - 2 * H * L;
       const int r = k & 15, hi = (k >> 4) & 1, t = k >> 5;
-      v = b1[32 * t + acc_row(r, hi)];
+      v = -kLog2e * b1[32 * t + acc_row(r, hi)];
     } else {  // b2frag[hi][e]
       const int k = i - 2 * H * L - H;
       const int hi = k / E, e = k % E;
-      v = b2[logit_of(e, hi, PQ, PX)];
+      v = -kLog2e * b2[logit_of(e, hi, PQ, PX)];
     }
     out[i] = v;
   }

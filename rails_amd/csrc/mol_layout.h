@@ -21,6 +21,19 @@
 
 namespace mol {
 
+// Operand pre-scaling (a contract between the packing kernels and the scoring kernel).  On gfx950 the fp32
+// MFMA runs on the same ALUs as the VALU (measured: every v_fma_f32 next to it costs 4 more cycles, every
+// v_exp_f32 8.5, at one or two waves per SIMD -- profiles/r01_ubench_mfma_f32_vs_valu.txt), so every VALU
+// instruction removed from the scoring kernel is time saved.  Constants are therefore folded into operands:
+//   EqFrag  = Eq / tau                      -> GEMM1 yields cl = <Eq,Ex>/tau directly
+//   W1frag, b1frag scaled by -log2(e)       -> GEMM2 yields t = -log2e * pre, and
+//                                              hid' = t * rcp(1 + exp2(t)) = -log2e * silu(pre)
+//   W2frag unscaled, b2frag by -log2(e)     -> GEMM3 on hid' yields -log2e * gqi
+//   gqfrag  = -log2e * gq                   -> t2 = fma(gq', gi, gqi') = -log2e * g, and
+//                                              v = -t2 * rcp(1 + exp2(t2)) = log2e * g*sigmoid(g)
+//   softmax(w) = exp2(v - max v) / sum
+constexpr float kLog2e = 1.4426950408889634f;
+
 constexpr int kTileItems = 32;  // items per tile = MFMA column count
 
 MOL_HD int acc_row(int reg, int hi) { return (reg & 3) + 8 * (reg >> 2) + 4 * hi; }

@@ -28,6 +28,7 @@ struct QueryArgs {
   int B;
   int D, PQ, PX, d, QH, Hq, n_uid, glu, l2norm;
   float eps;
+  float temperature;
 };
 
 // out[c] = bias[c] + sum_k W[c][k] in[k]; one wave per output column, lanes stride k
@@ -119,13 +120,13 @@ __global__ __launch_bounds__(kQueryThreads) void query_prologue_kernel(QueryArgs
     if (a.eq_out) a.eq_out[(int64_t)b * PQ * d + i] = v;
     // EqFrag[g][sc][lane][j] = Eq[g*QT + row/PQ][row%PQ][kdim_of(4sc + j, hi)], lane = hi*32 + row
     const int hi = k / (d / 2), s = k - hi * (d / 2);
-    eqf[((s >> 2) * 64 + hi * 32 + qj * PQ + p) * 4 + (s & 3)] = v;
+    eqf[((s >> 2) * 64 + hi * 32 + qj * PQ + p) * 4 + (s & 3)] = v / a.temperature;  // fragment copy carries 1/tau
   }
   for (int i = threadIdx.x; i < L; i += kQueryThreads) {
     if (a.gq_out) a.gq_out[(int64_t)b * L + i] = gqs[i];
     // gqfrag[b][hi][e] = gq[b][logit_of(e, hi)]
     const int hi = i / (L / 2), e = i - hi * (L / 2);
-    a.gqfrag[(int64_t)b * L + i] = gqs[logit_of(e, hi, PQ, a.PX)];
+    a.gqfrag[(int64_t)b * L + i] = -kLog2e * gqs[logit_of(e, hi, PQ, a.PX)];  // fragment copy carries -log2e
   }
 }
 
@@ -136,7 +137,7 @@ int query_prologue(const Shape& s, const Weights& w, const float* q, const int64
   a.q = q; a.user_ids = user_ids; a.w = w; a.B = B;
   a.D = s.query_embedding_dim; a.PQ = s.query_dot_product_groups; a.PX = s.item_dot_product_groups;
   a.d = s.dot_product_dimension; a.QH = s.query_hidden_dim; a.Hq = s.gating_query_hidden_dim;
-  a.n_uid = s.num_uid_tables; a.glu = s.query_nonlinearity; a.l2norm = s.dot_product_l2_norm; a.eps = s.eps;
+  a.n_uid = s.num_uid_tables; a.glu = s.query_nonlinearity; a.l2norm = s.dot_product_l2_norm; a.eps = s.eps; a.temperature = s.temperature;
   const int QT = queries_per_group(s);
   const int n_groups = (B + QT - 1) / QT;
   a.eqfrag = qpack;

@@ -18,6 +18,9 @@
 // (see mol_layout.h).  Arithmetic is exact fp32 (v_mfma_f32_32x32x2_f32 == an fmaf chain), which is
 // what lets the result sit within 1e-4 of the fp32 CPU path; the bound is the fp32 MFMA rate.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <type_traits>
+#include <utility>
 
 #include "mol_kernels.h"
 #include "mol_layout.h"
@@ -30,209 +33,292 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// x / tau with a compile-time-unknown but launch-constant tau: q = x*r, one Newton correction on the
-// residual.  Correctly rounded except for rare last-bit cases (r = RN(1/tau)).
-__device__ __forceinline__ float div_const(float x, float tau, float rcp_tau) {
-  const float q = x * rcp_tau;
-  const float e = __builtin_fmaf(-q, tau, x);
-  return __builtin_fmaf(e, rcp_tau, q);
-}
-
-// x * sigmoid(x) = x / (1 + exp(-x)); v_exp_f32 / v_rcp_f32 are 1 ulp
-__device__ __forceinline__ float silu_f(float x) {
-  return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));
-}
-
-template <int N>
-__device__ __forceinline__ f32x16 rotate_down(f32x16 v) {
-  f32x16 r;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) r[i] = v[(i + N) & 15];
-  return r;
-}
-
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 
-template <int PQ, int PX, int DD, int H>
-__global__ __launch_bounds__(kScoreThreads, 2) void mol_score_kernel(ScoreArgs p) {
+// ---------------------------------------------------------------------------------------------
+// Building blocks shared by the two kernels below.
+// ---------------------------------------------------------------------------------------------
+
+// GEMM1: D1[m][(qj,p), x] = sum_d Eq[qj,p,d] * Ex[x,m,d].  `eq` is the query group's A operand in fragment
+// order ([sc][lane] float4), `tEx` the tile's B operand ([m][sc][lane] float4) -- in HBM or in LDS.
+template <class G, int PX, int DD>
+__device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float4* __restrict__ eq, const float4* tEx, int lane) {
+#pragma unroll
+  for (int m = 0; m < PX; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) D1[m][r] = 0.0f;
+#pragma unroll
+  for (int sc = 0; sc < DD / 8; ++sc) {
+    const float4 a = eq[sc * 64 + lane];
+#pragma unroll
+    for (int m = 0; m < PX; ++m) {
+      const float4 b = tEx[(m * (DD / 8) + sc) * 64 + lane];
+      D1[m] = mfma32(a.x, b.x, D1[m]);
+      D1[m] = mfma32(a.y, b.y, D1[m]);
+      D1[m] = mfma32(a.z, b.z, D1[m]);
+      D1[m] = mfma32(a.w, b.w, D1[m]);
+    }
+    // keep the operand fetches of later K-chunks below this chunk's MFMAs: left alone, the scheduler hoists
+    // every read of the tile to the top (128 live registers) and spills
+    asm volatile("" ::: "memory");
+  }
+}
+
+// One query of the group: gate MLP (GEMM2 -> silu -> GEMM3), combine, softmax, mixture, on pre-scaled operands
+// (mol_layout.h).  The query's cl values sit in accumulator registers [R0, R0 + RPQ) of every D1 tile.
+template <class G, int PX, int R0>
+__device__ __forceinline__ float query_mlp(f32x16 (&D1)[PX], const float4* sW1, const float4* sW2, const float* sB1,
+                                           const float* sB2, const float4* tGi, const float4* __restrict__ gq4,
+                                           int lane, int hi) {
+  // GEMM2: t[h, x] = -log2e * (b1[h] + sum_l W1[h, l] cl[l, x])
+  f32x16 D2[G::TH];
+#pragma unroll
+  for (int t = 0; t < G::TH; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) D2[t][r] = sB1[t * 32 + hi * 16 + r];
+#pragma unroll
+  for (int ec = 0; ec < G::E / 4; ++ec) {
+#pragma unroll
+    for (int t = 0; t < G::TH; ++t) {
+      const float4 a = sW1[(ec * G::TH + t) * 64 + lane];
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = ec * 4 + j;
+        D2[t] = mfma32(av[j], D1[e / G::RPQ][R0 + e % G::RPQ], D2[t]);
+      }
+    }
+  }
+  // hid' = t / (1 + 2^t) = -log2e * silu(pre): exp2, add, rcp, mul
+#pragma unroll
+  for (int t = 0; t < G::TH; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) D2[t][r] = D2[t][r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(D2[t][r]));
+
+  // GEMM3: gqi'[l, x] = -log2e * (b2[l] + sum_h W2[l, h] hid[h, x])
+  f32x16 D3[G::TL];
+#pragma unroll
+  for (int v = 0; v < G::TL; ++v)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) D3[v][r] = sB2[hi * G::E + v * 16 + r];
+#pragma unroll
+  for (int fc = 0; fc < G::F / 4; ++fc) {
+#pragma unroll
+    for (int v = 0; v < G::TL; ++v) {
+      const float4 a = sW2[(fc * G::TL + v) * 64 + lane];
+      const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int f = fc * 4 + j;
+        D3[v] = mfma32(av[j], D2[f / 16][f % 16], D3[v]);
+      }
+    }
+  }
+
+  // epilogue.  t2 = -log2e * (gq*gi + gqi);  v = -t2 / (1 + 2^t2) = log2e * g*sigmoid(g);  softmax in base 2
+  float mx = -INFINITY;
+#pragma unroll
+  for (int ec = 0; ec < G::E / 4; ++ec) {
+    const float4 gi = tGi[ec * 64 + lane];
+    const float4 gq = gq4[ec];
+    const float giv[4] = {gi.x, gi.y, gi.z, gi.w};
+    const float gqv[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = ec * 4 + j;
+      const float t2 = __builtin_fmaf(gqv[j], giv[j], D3[e / 16][e % 16]);
+      const float v = -t2 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t2));
+      D3[e / 16][e % 16] = v;
+      mx = fmaxf(mx, v);
+    }
+  }
+  mx = fmaxf(mx, xor32(mx));
+  float den = 0.0f, num = 0.0f;
+#pragma unroll
+  for (int e = 0; e < G::E; ++e) {
+    const float ex = __builtin_amdgcn_exp2f(D3[e / 16][e % 16] - mx);
+    den += ex;
+    num = __builtin_fmaf(ex, D1[e / G::RPQ][R0 + e % G::RPQ], num);
+  }
+  den += xor32(den);
+  num += xor32(num);
+  // pi = ex/den, then the eval-time renormalisation pi / clamp(sum pi, 1e-6) (similarity_fn.py:42-46):
+  // sum pi = den * (1/den) up to rounding
+  const float rden = __builtin_amdgcn_rcpf(den);
+  return (num * rden) / fmaxf(den * rden, 1e-6f);
+}
+
+// All queries of one unit, each at its own static register offset (no register rotation).
+// `only` >= 0 restricts the unit to that query (per-row candidates).
+template <class G, int PX>
+__device__ __forceinline__ void unit_queries(f32x16 (&D1)[PX], const ScoreArgs& p, int g, int only, int64_t item0,
+                                             const float4* sW1, const float4* sW2, const float* sB1, const float* sB2,
+                                             const float4* tGi, int lane, int hi, int x) {
+  [&]<int... Q>(std::integer_sequence<int, Q...>) {
+    (
+        [&] {
+          const int q = g * G::QT + Q;
+          if (q < p.B && (only < 0 || q == only)) {
+            const float4* gq4 = reinterpret_cast<const float4*>(p.gqfrag + (int64_t)q * G::L + hi * G::E);
+            const float out = query_mlp<G, PX, Q * G::RPQ>(D1, sW1, sW2, sB1, sB2, tGi, gq4, lane, hi);
+            const int64_t item = item0 + x;
+            if (hi == 0 && item < p.n_items) p.logits[(int64_t)q * p.ld + item] = out;
+          }
+        }(),
+        ...);
+  }(std::make_integer_sequence<int, G::QT>{});
+}
+
+template <class G, int NW>
+__device__ __forceinline__ void stage_weights(const ScoreArgs& p, float* smem) {
+  const float4* src = reinterpret_cast<const float4*>(p.wpack);
+  float4* dst = reinterpret_cast<float4*>(smem);
+  for (int i = threadIdx.x; i < G::kWpackFloats / 4; i += NW * 64) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel A ("direct"): every wave is independent and reads its tile straight from HBM/L2.
+// Used when fewer than 8 query groups exist (B < 8 * 32/P_Q), for per-row candidates, and for shapes whose
+// tile does not fit LDS twice.  unit = (tile, query group), groups fastest.
+// ---------------------------------------------------------------------------------------------
+template <int PQ, int PX, int DD, int H, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(ScoreArgs p) {
   using G = Geo<PQ, PX, DD, H>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const float4* sW1 = reinterpret_cast<const float4*>(smem);
   const float4* sW2 = sW1 + G::kW1Floats / 4;
   const float* sB1 = smem + G::kW1Floats + G::kW2Floats;
-  const float4* sB2 = reinterpret_cast<const float4*>(sB1 + H);
-
-  {  // stage the packed gate weights once per workgroup
-    const float4* src = reinterpret_cast<const float4*>(p.wpack);
-    float4* dst = reinterpret_cast<float4*>(smem);
-    for (int i = threadIdx.x; i < G::kWpackFloats / 4; i += kScoreThreads) dst[i] = src[i];
-  }
+  const float* sB2 = sB1 + H;
+  stage_weights<G, NW>(p, smem);
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int hi = lane >> 5;
-  const int x = lane & 31;
-  // shared corpus: unit = (tile, query group), groups fastest so the waves of one workgroup share a
-  // tile through L1/L2.  per-row candidates: unit = (row b, tile of b's candidates), one query per unit.
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5, x = lane & 31;
   const int inner = p.per_row ? (int)p.n_tiles : p.n_groups;
   const int64_t n_units = p.per_row ? (int64_t)p.B * p.n_tiles : p.n_tiles * p.n_groups;
-  const int64_t stride = (int64_t)gridDim.x * kScoreWaves;
-
-  for (int64_t u = (int64_t)blockIdx.x * kScoreWaves + wave; u < n_units; u += stride) {
+  const int64_t stride = (int64_t)gridDim.x * NW;
+  for (int64_t u = (int64_t)blockIdx.x * NW + wave; u < n_units; u += stride) {
     const int64_t outer = u / inner;
     const int innr = (int)(u - outer * inner);
-    const int64_t tile = p.per_row ? innr : outer;          // tile index inside the row / corpus
-    const int row = p.per_row ? (int)outer : -1;            // per-row mode: the only query of this unit
+    const int64_t tile = p.per_row ? innr : outer;  // tile index inside the row / corpus
+    const int row = p.per_row ? (int)outer : -1;    // per-row mode: the only query of this unit
     const int g = p.per_row ? row / G::QT : innr;
     const int64_t tile_addr = p.per_row ? (int64_t)row * p.n_tiles + tile : tile;
     const float4* tEx = reinterpret_cast<const float4*>(p.ipack + tile_addr * (int64_t)G::kTileFloats);
     const float4* tGi = tEx + G::kTileExFloats / 4;
     const float4* eq = reinterpret_cast<const float4*>(p.eqfrag + (int64_t)g * G::kEqGroupFloats);
-
-    // ---- GEMM1: D1[m][(qj,p), x] = sum_d Eq[qj,p,d] * Ex[x,m,d] -------------------------------
     f32x16 D1[PX];
-#pragma unroll
-    for (int m = 0; m < PX; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) D1[m][r] = 0.0f;
+    gemm1<G, PX, DD>(D1, eq, tEx, lane);
+    unit_queries<G, PX>(D1, p, g, row, tile * kTileItems, sW1, sW2, sB1, sB2, tGi, lane, hi, x);
+  }
+}
 
-#pragma unroll
-    for (int sc = 0; sc < DD / 8; ++sc) {
-      const float4 a = eq[sc * 64 + lane];
-#pragma unroll
-      for (int m = 0; m < PX; ++m) {
-        const float4 b = tEx[(m * (DD / 8) + sc) * 64 + lane];
-        D1[m] = mfma32(a.x, b.x, D1[m]);
-        D1[m] = mfma32(a.y, b.y, D1[m]);
-        D1[m] = mfma32(a.z, b.z, D1[m]);
-        D1[m] = mfma32(a.w, b.w, D1[m]);
-      }
+// ---------------------------------------------------------------------------------------------
+// Kernel B ("staged"): the workgroup's 8 waves share one item tile per step.  The tile is copied
+// HBM -> LDS by LDS-DMA (global_load_lds, 1 KiB per wave-instruction, no registers) one tile ahead of
+// its use, double buffered, so each tile is read from HBM exactly once per batch and its latency is
+// hidden behind a whole tile of MFMA work.  One barrier per tile.
+// ---------------------------------------------------------------------------------------------
+template <class G, int NW>
+__device__ __forceinline__ void dma_tile(const float* __restrict__ src_tile, float* lds_tile, int wave, int lane) {
+  constexpr int kPieces = G::kTileFloats / 256;  // 1 KiB pieces
+  static_assert(G::kTileFloats % 256 == 0, "tile must be a whole number of 1 KiB pieces");
+  for (int piece = wave; piece < kPieces; piece += NW) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(src_tile + piece * 256 + lane * 4),
+        (__attribute__((address_space(3))) void*)(lds_tile + piece * 256), 16, 0, 0);
+  }
+}
+
+template <int PQ, int PX, int DD, int H, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(ScoreArgs p) {
+  using G = Geo<PQ, PX, DD, H>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const float4* sW1 = reinterpret_cast<const float4*>(smem);
+  const float4* sW2 = sW1 + G::kW1Floats / 4;
+  const float* sB1 = smem + G::kW1Floats + G::kW2Floats;
+  const float* sB2 = sB1 + H;
+  float* tiles = smem + G::kWpackFloats;  // two tile buffers
+  stage_weights<G, NW>(p, smem);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5, x = lane & 31;
+  const int64_t first = blockIdx.x;
+  if (first < p.n_tiles) dma_tile<G, NW>(p.ipack + first * (int64_t)G::kTileFloats, tiles, wave, lane);
+  int cur = 0;
+  for (int64_t tile = first; tile < p.n_tiles; tile += gridDim.x, cur ^= 1) {
+    // (1) my pieces of `tile` have landed (vmcnt(0)); (2) barrier: every wave's pieces have, and every wave
+    // is done with the previous tile, so the other buffer may be overwritten
+    __syncthreads();
+    const int64_t next = tile + gridDim.x;
+    if (next < p.n_tiles) dma_tile<G, NW>(p.ipack + next * (int64_t)G::kTileFloats, tiles + (cur ^ 1) * G::kTileFloats, wave, lane);
+    const float4* tEx = reinterpret_cast<const float4*>(tiles + cur * G::kTileFloats);
+    const float4* tGi = tEx + G::kTileExFloats / 4;
+    for (int g = wave; g < p.n_groups; g += NW) {
+      const float4* eq = reinterpret_cast<const float4*>(p.eqfrag + (int64_t)g * G::kEqGroupFloats);
+      f32x16 D1[PX];
+      gemm1<G, PX, DD>(D1, eq, tEx, lane);
+      unit_queries<G, PX>(D1, p, g, -1, tile * kTileItems, sW1, sW2, sB1, sB2, tGi, lane, hi, x);
     }
+  }
+}
 
-    // ---- per query of the group: gate MLP + mixture ----------------------------------------
-#pragma unroll 1
-    for (int qj = 0; qj < G::QT; ++qj) {
-      const int q = g * G::QT + qj;
-      if (q < p.B && (row < 0 || q == row)) {
-        // cl = <.,.> / tau, in place in registers [0, RPQ) of every GEMM1 tile
-#pragma unroll
-        for (int m = 0; m < PX; ++m)
-#pragma unroll
-          for (int r = 0; r < G::RPQ; ++r) D1[m][r] = div_const(D1[m][r], p.temperature, p.rcp_temperature);
+// RAILS_SCORE_VARIANT: 0 = pick automatically; 1 / 2 = force direct / staged with 8 waves (2 per SIMD);
+// 3 / 4 = direct / staged with 4 waves (1 per SIMD, 512 registers)
+static int score_variant() {
+  const char* e = getenv("RAILS_SCORE_VARIANT");
+  return e ? atoi(e) : 0;
+}
 
-        // GEMM2: hid[h, x] = b1[h] + sum_l W1[h, l] cl[l, x]
-        f32x16 D2[G::TH];
-#pragma unroll
-        for (int t = 0; t < G::TH; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) D2[t][r] = sB1[t * 32 + hi * 16 + r];
-#pragma unroll
-        for (int ec = 0; ec < G::E / 4; ++ec) {
-#pragma unroll
-          for (int t = 0; t < G::TH; ++t) {
-            const float4 a = sW1[(ec * G::TH + t) * 64 + lane];
-            const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int e = ec * 4 + j;
-              D2[t] = mfma32(av[j], D1[e / G::RPQ][e % G::RPQ], D2[t]);
-            }
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < G::TH; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) D2[t][r] = silu_f(D2[t][r]);
-
-        // GEMM3: gqi[l, x] = sum_h W2[l, h] hid[h, x]   (b2 joins in the epilogue)
-        f32x16 D3[G::TL];
-#pragma unroll
-        for (int v = 0; v < G::TL; ++v)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) D3[v][r] = 0.0f;
-#pragma unroll
-        for (int fc = 0; fc < G::F / 4; ++fc) {
-#pragma unroll
-          for (int v = 0; v < G::TL; ++v) {
-            const float4 a = sW2[(fc * G::TL + v) * 64 + lane];
-            const float av[4] = {a.x, a.y, a.z, a.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int f = fc * 4 + j;
-              D3[v] = mfma32(av[j], D2[f / 16][f % 16], D3[v]);
-            }
-          }
-        }
-
-        // epilogue: combine, softmax over all L (this lane's E values + the partner half's), mix
-        const float4* gq4 = reinterpret_cast<const float4*>(p.gqfrag + (int64_t)q * G::L + hi * G::E);
-        float mx = -INFINITY;
-#pragma unroll
-        for (int ec = 0; ec < G::E / 4; ++ec) {
-          const float4 gi = tGi[ec * 64 + lane];
-          const float4 gq = gq4[ec];
-          const float4 b2 = sB2[hi * (G::E / 4) + ec];
-          const float giv[4] = {gi.x, gi.y, gi.z, gi.w};
-          const float gqv[4] = {gq.x, gq.y, gq.z, gq.w};
-          const float b2v[4] = {b2.x, b2.y, b2.z, b2.w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int e = ec * 4 + j;
-            const float gqi = D3[e / 16][e % 16] + b2v[j];
-            const float gg = gqv[j] * giv[j] + gqi;
-            const float w = silu_f(gg);
-            D3[e / 16][e % 16] = w;
-            mx = fmaxf(mx, w);
-          }
-        }
-        mx = fmaxf(mx, xor32(mx));
-        float den = 0.0f;
-#pragma unroll
-        for (int e = 0; e < G::E; ++e) {
-          const float ex = __expf(D3[e / 16][e % 16] - mx);
-          D3[e / 16][e % 16] = ex;
-          den += ex;
-        }
-        den += xor32(den);
-        const float rden = __builtin_amdgcn_rcpf(den);
-        float s2 = 0.0f, num = 0.0f;
-#pragma unroll
-        for (int e = 0; e < G::E; ++e) {
-          const float pi = D3[e / 16][e % 16] * rden;
-          s2 += pi;
-          num = __builtin_fmaf(pi, D1[e / G::RPQ][e % G::RPQ], num);
-        }
-        s2 += xor32(s2);
-        num += xor32(num);
-        const float out = num / fmaxf(s2, 1e-6f);
-        const int64_t item = tile * kTileItems + x;
-        if (hi == 0 && item < p.n_items) p.logits[(int64_t)q * p.ld + item] = out;
-      }
-      // bring the next query's rows down to registers [0, RPQ)
-#pragma unroll
-      for (int m = 0; m < PX; ++m) D1[m] = rotate_down<G::RPQ>(D1[m]);
+template <int PQ, int PX, int DD, int H, int NW, bool STAGED>
+static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
+  using G = Geo<PQ, PX, DD, H>;
+  constexpr size_t lds = ((size_t)G::kWpackFloats + (STAGED ? 2 * (size_t)G::kTileFloats : 0)) * sizeof(float);
+  if constexpr (lds > 160 * 1024) {
+    set_error("staged scoring kernel needs %zu B of LDS", lds);
+    return kErrUnsupported;
+  } else {
+    const void* fn = STAGED ? reinterpret_cast<const void*>(&mol_score_staged_kernel<PQ, PX, DD, H, NW>)
+                            : reinterpret_cast<const void*>(&mol_score_direct_kernel<PQ, PX, DD, H, NW>);
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return kErrLaunch;
+      attr_set = true;
     }
+    const int wg_per_cu = (NW == 4 && lds <= 80 * 1024) ? 2 : 1;
+    int64_t grid;
+    if (STAGED) {
+      grid = a.n_tiles;
+    } else {
+      const int64_t n_units = a.per_row ? (int64_t)a.B * a.n_tiles : a.n_tiles * a.n_groups;
+      grid = (n_units + NW - 1) / NW;
+    }
+    if (grid > (int64_t)n_cu * wg_per_cu) grid = (int64_t)n_cu * wg_per_cu;
+    if (grid < 1) return kOk;
+    if (STAGED)
+      hipLaunchKernelGGL((mol_score_staged_kernel<PQ, PX, DD, H, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
+    else
+      hipLaunchKernelGGL((mol_score_direct_kernel<PQ, PX, DD, H, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
   }
 }
 
 template <int PQ, int PX, int DD, int H>
 static int launch_score(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using G = Geo<PQ, PX, DD, H>;
-  const size_t lds = (size_t)G::kWpackFloats * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mol_score_kernel<PQ, PX, DD, H>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return kErrLaunch;
-    attr_set = true;
+  constexpr bool staged_fits = ((size_t)G::kWpackFloats + 2 * (size_t)G::kTileFloats) * sizeof(float) <= 160 * 1024;
+  int variant = score_variant();
+  if (variant == 0) variant = (staged_fits && !a.per_row && a.n_groups >= kScoreWaves) ? 2 : 1;
+  if ((variant == 2 || variant == 4) && a.per_row) { set_error("staged scoring kernel does not do per-row candidates"); return kErrUnsupported; }
+  switch (variant) {
+    case 1: return launch_kernel<PQ, PX, DD, H, 8, false>(a, n_cu, stream);
+    case 2: return launch_kernel<PQ, PX, DD, H, 8, true>(a, n_cu, stream);
+    case 3: return launch_kernel<PQ, PX, DD, H, 4, false>(a, n_cu, stream);
+    case 4: return launch_kernel<PQ, PX, DD, H, 4, true>(a, n_cu, stream);
+    default: set_error("unknown RAILS_SCORE_VARIANT %d", variant); return kErrInvalid;
   }
-  const int64_t n_units = a.per_row ? (int64_t)a.B * a.n_tiles : a.n_tiles * a.n_groups;
-  int64_t grid = (n_units + kScoreWaves - 1) / kScoreWaves;
-  if (grid > n_cu) grid = n_cu;
-  if (grid < 1) return kOk;
-  hipLaunchKernelGGL((mol_score_kernel<PQ, PX, DD, H>), dim3((unsigned)grid), dim3(kScoreThreads), lds, stream, a);
-  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
 bool score_supported(const Shape& s) {
