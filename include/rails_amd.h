@@ -136,6 +136,18 @@ int rails_mol_score_candidates(const rails_mol_shape* shape, const float* gate_p
                                int32_t batch, const float* cand_index, int64_t n_cand, float* logits,
                                int64_t ld, void* stream);
 
+/* ---- coarse pass of the two-pass approximate top-k ---------------------------------------------
+ * Replaces MoLAvgTopK.__init__'s averaged bf16 table (rails/indexing/mol_top_k.py:321-325) and the bf16 `mm`
+ * of MoLAvgTopK.forward / topk_ids (mol_top_k.py:351-354, :418-425).  Every value the reference rounds to bf16
+ * is rounded to bf16 here; scores come back as fp32 holding bf16 values.  The caller selects the K' best with
+ * rails_topk and reranks with rails_mol_index_gather + rails_mol_score_candidates. */
+size_t rails_mol_coarse_table_bytes(const rails_mol_shape* shape, int64_t n_items);   /* 2*d bytes per item */
+int rails_mol_coarse_build(const rails_mol_shape* shape, const float* index, int64_t n_items, void* table, void* stream);
+/* eq: plain (batch, P_Q, d) fp32 from rails_mol_query_prologue's eq_out.  average_queries 0: sum over P_Q
+ * (forward), 1: mean over P_Q (topk_ids).  scores[b * ld + x]. */
+int rails_mol_coarse_score(const rails_mol_shape* shape, const float* eq, int32_t batch, int32_t average_queries,
+                           const void* table, int64_t n_items, float* scores, int64_t ld, void* stream);
+
 /* ---- exact top-k -----------------------------------------------------------------------------
  * Replaces torch.topk(all_logits, dim=1, k, sorted, largest=True) + the id gather
  * (rails/indexing/mol_top_k.py:123-130).  Row b reads scores[b * ld + 0..n).  Ties are broken by

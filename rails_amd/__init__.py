@@ -5,9 +5,9 @@ and fails loudly if librails_amd.so has not been built.
 """
 from .factory import create_mol_interaction_module
 from .mol_module import MoLSimilarity, SimilarityModule
-from .topk_modules import CandidateIndex, MoLBruteForceTopK, TopKModule, get_top_k_module
+from .topk_modules import CandidateIndex, MoLAvgTopK, MoLBruteForceTopK, TopKModule, get_top_k_module
 
 __all__ = [
     "create_mol_interaction_module", "MoLSimilarity", "SimilarityModule", "CandidateIndex",
-    "MoLBruteForceTopK", "TopKModule", "get_top_k_module",
+    "MoLBruteForceTopK", "MoLAvgTopK", "TopKModule", "get_top_k_module",
 ]

@@ -206,6 +206,33 @@ int rails_mol_score_candidates(const rails_mol_shape* s, const float* gate_pack,
   return score_common(s, gate_pack, query_pack, batch, cand_index, n_cand, logits, ld, 1, stream, "score_candidates");
 }
 
+size_t rails_mol_coarse_table_bytes(const rails_mol_shape* s, int64_t n_items) {
+  if (!shape_ok(s) || n_items < 0) return 0;
+  return (size_t)n_items * (size_t)s->dot_product_dimension * 2;
+}
+
+int rails_mol_coarse_build(const rails_mol_shape* s, const float* index, int64_t n_items, void* table, void* stream) {
+  g_err[0] = '\0';
+  if (!shape_ok(s)) return RAILS_EINVAL;
+  if (s->dot_product_dimension % 8 != 0) { set_error("coarse_build: d must be a multiple of 8"); return RAILS_ENOTSUP; }
+  if (n_items < 0) { set_error("coarse_build: n_items < 0"); return RAILS_EINVAL; }
+  if (n_items == 0) return RAILS_OK;
+  if (!index || !table) { set_error("coarse_build: NULL pointer"); return RAILS_EINVAL; }
+  return fail(coarse_build(*s, index, n_items, table, (hipStream_t)stream), "coarse_build");
+}
+
+int rails_mol_coarse_score(const rails_mol_shape* s, const float* eq, int32_t batch, int32_t average_queries,
+                           const void* table, int64_t n_items, float* scores, int64_t ld, void* stream) {
+  g_err[0] = '\0';
+  if (!shape_ok(s)) return RAILS_EINVAL;
+  if (batch < 0 || n_items < 0) { set_error("coarse_score: negative size"); return RAILS_EINVAL; }
+  if (batch == 0 || n_items == 0) return RAILS_OK;
+  if (!eq || !table || !scores) { set_error("coarse_score: NULL pointer"); return RAILS_EINVAL; }
+  if (ld < n_items) { set_error("coarse_score: ld < n_items"); return RAILS_EINVAL; }
+  const int r = coarse_score(*s, eq, batch, average_queries ? 1 : 0, table, n_items, scores, ld, (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "coarse_score");
+}
+
 size_t rails_topk_workspace_bytes(int32_t rows, int64_t n, int32_t k) {
   if (rows <= 0 || n <= 0 || k <= 0) return 256;
   return topk_workspace_bytes(rows, n, k);

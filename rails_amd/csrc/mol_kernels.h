@@ -52,6 +52,10 @@ int index_gather(const Shape& s, const float* ipack, int64_t n, const int64_t* i
 int query_prologue(const Shape& s, const Weights& w, const float* q, const int64_t* user_ids, int B, float* qpack,
                    float* eq_out, float* gq_out, hipStream_t stream);
 
+int coarse_build(const Shape& s, const float* ipack, int64_t n, void* table, hipStream_t stream);
+int coarse_score(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, float* scores, int64_t ld,
+                 hipStream_t stream);
+
 size_t topk_workspace_bytes(int rows, int64_t n, int k);
 int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int64_t* ids, int64_t ids_row_stride,
          float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, hipStream_t stream);

@@ -33,6 +33,15 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// packed fp32 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32): two values per VALU issue slot
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 pk_sigmoid_arg(f32x2 t) {  // 1 / (1 + 2^t)
+  f32x2 e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+  e = e + 1.0f;
+  return f32x2{__builtin_amdgcn_rcpf(e.x), __builtin_amdgcn_rcpf(e.y)};
+}
+
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 
 // ---------------------------------------------------------------------------------------------
@@ -93,7 +102,12 @@ __device__ __forceinline__ float query_mlp(f32x16 (&D1)[PX], const float4* sW1, 
 #pragma unroll
   for (int t = 0; t < G::TH; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) D2[t][r] = D2[t][r] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(D2[t][r]));
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 tv = {D2[t][r], D2[t][r + 1]};
+      const f32x2 h = tv * pk_sigmoid_arg(tv);
+      D2[t][r] = h.x;
+      D2[t][r + 1] = h.y;
+    }
 
   // GEMM3: gqi'[l, x] = -log2e * (b2[l] + sum_h W2[l, h] hid[h, x])
   f32x16 D3[G::TL];
@@ -121,25 +135,29 @@ __device__ __forceinline__ float query_mlp(f32x16 (&D1)[PX], const float4* sW1, 
   for (int ec = 0; ec < G::E / 4; ++ec) {
     const float4 gi = tGi[ec * 64 + lane];
     const float4 gq = gq4[ec];
-    const float giv[4] = {gi.x, gi.y, gi.z, gi.w};
-    const float gqv[4] = {gq.x, gq.y, gq.z, gq.w};
+    const f32x2 giv[2] = {{gi.x, gi.y}, {gi.z, gi.w}};
+    const f32x2 gqv[2] = {{gq.x, gq.y}, {gq.z, gq.w}};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int e = ec * 4 + j;
-      const float t2 = __builtin_fmaf(gqv[j], giv[j], D3[e / 16][e % 16]);
-      const float v = -t2 * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t2));
-      D3[e / 16][e % 16] = v;
-      mx = fmaxf(mx, v);
+    for (int j = 0; j < 2; ++j) {
+      const int e = ec * 4 + 2 * j;
+      const f32x2 t2 = pk_fma(gqv[j], giv[j], f32x2{D3[e / 16][e % 16], D3[e / 16][e % 16 + 1]});
+      const f32x2 v = -t2 * pk_sigmoid_arg(t2);
+      D3[e / 16][e % 16] = v.x;
+      D3[e / 16][e % 16 + 1] = v.y;
+      mx = fmaxf(mx, fmaxf(v.x, v.y));
     }
   }
   mx = fmaxf(mx, xor32(mx));
-  float den = 0.0f, num = 0.0f;
+  f32x2 den2 = {0.0f, 0.0f}, num2 = {0.0f, 0.0f};
 #pragma unroll
-  for (int e = 0; e < G::E; ++e) {
-    const float ex = __builtin_amdgcn_exp2f(D3[e / 16][e % 16] - mx);
-    den += ex;
-    num = __builtin_fmaf(ex, D1[e / G::RPQ][R0 + e % G::RPQ], num);
+  for (int e = 0; e < G::E; e += 2) {
+    const f32x2 d = f32x2{D3[e / 16][e % 16], D3[e / 16][e % 16 + 1]} - mx;
+    const f32x2 ex = {__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};
+    den2 = den2 + ex;
+    // e and e+1 are consecutive registers of one D1 tile (RPQ is even)
+    num2 = pk_fma(ex, f32x2{D1[e / G::RPQ][R0 + e % G::RPQ], D1[e / G::RPQ][R0 + e % G::RPQ + 1]}, num2);
   }
+  float den = den2.x + den2.y, num = num2.x + num2.y;
   den += xor32(den);
   num += xor32(num);
   // pi = ex/den, then the eval-time renormalisation pi / clamp(sum pi, 1e-6) (similarity_fn.py:42-46):

@@ -235,6 +235,31 @@ class MolEngine:
         return out
 
 
+    # ---- coarse pass of the two-pass approximate top-k ------------------------------------------------
+    def build_coarse_table(self, index: MolIndex) -> torch.Tensor:
+        """(N, d) bf16 table of P_X-averaged component embeddings (reference mol_top_k.py:321-325)."""
+        nbytes = self.lib.rails_mol_coarse_table_bytes(C.byref(self.shape), index.n_items)
+        table = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=index.buf.device)
+        with torch.cuda.device(index.buf.device):
+            _lib.check(
+                self.lib.rails_mol_coarse_build(C.byref(self.shape), _ptr(index.buf), index.n_items, _ptr(table), _stream()),
+                "rails_mol_coarse_build",
+            )
+        return table.view(index.n_items, self.spec.dot_product_dimension)
+
+    def coarse_scores(self, eq: torch.Tensor, table: torch.Tensor, average_queries: bool) -> torch.Tensor:
+        """eq (B, P_Q, d) fp32 -> (B, N) fp32 holding bf16-rounded dot products (reference mol_top_k.py:351-354)."""
+        B, n = eq.shape[0], table.shape[0]
+        eq = _f32c(eq)
+        out = torch.empty((B, n), dtype=torch.float32, device=table.device)
+        with torch.cuda.device(table.device):
+            _lib.check(
+                self.lib.rails_mol_coarse_score(C.byref(self.shape), _ptr(eq), B, 1 if average_queries else 0, _ptr(table), n, _ptr(out), out.stride(0), _stream()),
+                "rails_mol_coarse_score",
+            )
+        return out
+
+
 # ---- shape-independent kernels ----------------------------------------------------------------
 def topk(scores: torch.Tensor, k: int, ids: Optional[torch.Tensor] = None, sorted: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """Exact top-k of every row of `scores` (rows, n) fp32 on the GPU; ties by position ascending.

@@ -1,3 +1,3 @@
-from ..topk_modules import MoLBruteForceTopK, MoLTopKModule  # reference: rails/indexing/mol_top_k.py
+from ..topk_modules import MoLAvgTopK, MoLBruteForceTopK, MoLTopKModule  # reference: rails/indexing/mol_top_k.py
 
-__all__ = ["MoLTopKModule", "MoLBruteForceTopK"]
+__all__ = ["MoLTopKModule", "MoLBruteForceTopK", "MoLAvgTopK"]

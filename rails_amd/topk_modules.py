@@ -76,6 +76,55 @@ class MoLBruteForceTopK(MoLTopKModule):
         return scores.to(query_embeddings.dtype), ids
 
 
+class MoLAvgTopK(MoLTopKModule):
+    """Two-pass approximate top-k (reference rails/indexing/mol_top_k.py:296-429): a bf16 dot product of the
+    P_Q-summed query components against the P_X-averaged item components picks `avg_top_k` candidates per query,
+    which are then scored with the full MoL and cut to k.  Spans keep the reference's profiler names."""
+
+    def __init__(self, mol_module: MoLSimilarity, item_embeddings: torch.Tensor, item_ids: torch.Tensor, avg_top_k: int) -> None:
+        super().__init__(mol_module=mol_module, item_embeddings=item_embeddings, item_ids=item_ids)
+        self._avg_top_k: int = avg_top_k
+        self._coarse_engine = None
+        self._coarse_table = None
+
+    def _table(self) -> torch.Tensor:
+        eng = self._bind()
+        if self._coarse_engine is not eng:
+            self._coarse_engine = eng
+            self._coarse_table = eng.build_coarse_table(self._index)
+        return self._coarse_table
+
+    def _coarse_topk(self, query_embeddings: torch.Tensor, average_queries: bool, **kwargs):
+        eng = self._bind()
+        table = self._table()
+        qpack, eq, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"), want_plain=True)
+        coarse = eng.coarse_scores(eq, table, average_queries)
+        if self._avg_top_k > coarse.shape[1]:
+            raise RuntimeError(f"selected index k out of range (k={self._avg_top_k}, n={coarse.shape[1]})")
+        _, idx = E.topk(coarse, self._avg_top_k)
+        return qpack, idx
+
+    def rerank(self, qpack: torch.Tensor, batch: int, cand_idx: torch.Tensor, k: int):
+        """Full MoL on per-row candidates (positions, (B, K')) -> exact top-min(k, K') among them."""
+        eng = self._bind()
+        cand, kp = eng.gather_index(self._index, cand_idx)
+        scores = eng.score_candidates(qpack, batch, cand, kp)[:, : cand_idx.shape[1]]
+        return E.topk(scores, min(k, cand_idx.shape[1]), ids=self._ids_flat[cand_idx])
+
+    def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        if k > self._avg_top_k:  # the reference raises after doing the work (mol_top_k.py:383-386)
+            raise ValueError(f"avg_top_k ({self._avg_top_k}) must be larger than k ({k})")
+        with torch.profiler.record_function("avg_top_k_scoring"):
+            qpack, idx = self._coarse_topk(query_embeddings, average_queries=False, **kwargs)
+        with torch.profiler.record_function("filtered_scoring"):
+            scores, ids = self.rerank(qpack, query_embeddings.size(0), idx, k)
+        return scores.to(query_embeddings.dtype), ids
+
+    def topk_ids(self, query_embeddings: torch.Tensor, sorted: bool = True, **kwargs) -> torch.Tensor:
+        """Coarse candidates only, with the P_Q-averaged query (reference mol_top_k.py:398-429) -> positions."""
+        return self._coarse_topk(query_embeddings, average_queries=True, **kwargs)[1]
+
+
 class CandidateIndex(object):
     """Reference indexing/candidate_index.py:30-185 (`filter_invalid_ids` / `apply_object_filter` are never
     called by any entry point of the reference and are not provided)."""
@@ -130,11 +179,12 @@ class CandidateIndex(object):
 
 
 _BUILT = {"MoLBruteForceTopK": lambda mol, x, ids: MoLBruteForceTopK(mol_module=mol, item_embeddings=x, item_ids=ids)}
+for _k in (100, 200, 500, 1000, 2000, 2500, 3000, 4000):
+    _BUILT[f"MoLAvgTopK{_k}"] = (lambda kk: lambda mol, x, ids: MoLAvgTopK(mol_module=mol, item_embeddings=x, item_ids=ids, avg_top_k=kk))(_k)
 # names the reference's factory accepts but this build does not implement yet
 _KNOWN_UNBUILT = (
     ["MIPSBruteForceTopK", "MoLNaiveFaissTopK5"]
     + [f"MoLNaiveTopK{k}" for k in (5, 10, 25, 50, 75, 100)]
-    + [f"MoLAvgTopK{k}" for k in (100, 200, 500, 1000, 2000, 2500, 3000, 4000)]
     + [f"MoLCombTopK{a}_{b}" for a, b in ((1, 100), (1, 500), (5, 100), (5, 200), (5, 500), (10, 100), (10, 500), (50, 500), (50, 1000), (100, 1000))]
 )
 
