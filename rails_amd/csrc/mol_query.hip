@@ -15,7 +15,7 @@
 
 namespace mol {
 
-constexpr int kQueryThreads = 256;
+constexpr int kQueryThreads = 1024;  // 16 waves: the prologue is a chain of small dense layers, latency-bound
 
 struct QueryArgs {
   const float* q;
@@ -31,21 +31,29 @@ struct QueryArgs {
   float temperature;
 };
 
-// out[c] = bias[c] + sum_k W[c][k] in[k]; one wave per output column, lanes stride k
+// out[c] = bias[c] + sum_k W[c][k] in[k]; a wave owns four output columns at a time (four independent load
+// streams in flight), lanes stride k, then a shuffle reduction per column
 __device__ __forceinline__ void wave_dense(const float* __restrict__ W, const float* __restrict__ bias, int ncols,
                                            int K, const float* __restrict__ in_s, float* __restrict__ out_s,
                                            bool silu) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = kQueryThreads / 64;
-  for (int c = wave; c < ncols; c += nw) {
-    const float* wrow = W + (int64_t)c * K;
-    float acc = 0.0f;
-    for (int k = lane; k < K; k += 64) acc = __builtin_fmaf(wrow[k], in_s[k], acc);
+  for (int c0 = wave * 4; c0 < ncols; c0 += nw * 4) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane; k < K; k += 64) {
+      const float xv = in_s[k];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (lane == 0) {
-      float v = acc + (bias ? bias[c] : 0.0f);
-      if (silu) v = v / (1.0f + expf(-v));
-      out_s[c] = v;
+      for (int j = 0; j < 4; ++j)
+        if (c0 + j < ncols) acc[j] = __builtin_fmaf(W[(int64_t)(c0 + j) * K + k], xv, acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o, 64);
+      if (lane == 0 && c0 + j < ncols) {
+        float v = acc[j] + (bias ? bias[c0 + j] : 0.0f);
+        if (silu) v = v / (1.0f + expf(-v));
+        out_s[c0 + j] = v;
+      }
     }
   }
 }
@@ -79,6 +87,7 @@ __global__ __launch_bounds__(kQueryThreads) void query_prologue_kernel(QueryArgs
   // GLU: h = q W + b (D x 2QH, row-major so lanes stride columns); act(lhs) * rhs
   for (int c = threadIdx.x; c < 2 * QH; c += kQueryThreads) {
     float acc = 0.0f;
+#pragma unroll 8
     for (int k = 0; k < D; ++k) acc = __builtin_fmaf(qs[k], a.w.q_glu_w[(int64_t)k * 2 * QH + c], acc);
     glu[c] = acc + a.w.q_glu_b[c];
   }

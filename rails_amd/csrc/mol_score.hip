@@ -98,7 +98,9 @@ __device__ __forceinline__ float query_mlp(f32x16 (&D1)[PX], const float4* sW1, 
       }
     }
   }
-  // hid' = t / (1 + 2^t) = -log2e * silu(pre): exp2, add, rcp, mul
+  // hid' = t / (1 + 2^t) = -log2e * silu(pre): exp2, add, rcp, mul.  Fenced from the MFMAs on both sides: fp32
+  // MFMA and VALU do not overlap on gfx950, so interleaving them only buys VALU->MFMA hazard nops.
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int t = 0; t < G::TH; ++t)
 #pragma unroll
@@ -108,6 +110,7 @@ __device__ __forceinline__ float query_mlp(f32x16 (&D1)[PX], const float4* sW1, 
       D2[t][r] = h.x;
       D2[t][r + 1] = h.y;
     }
+  __builtin_amdgcn_sched_barrier(0);
 
   // GEMM3: gqi'[l, x] = -log2e * (b2[l] + sum_h W2[l, h] hid[h, x])
   f32x16 D3[G::TL];
@@ -129,8 +132,9 @@ __device__ __forceinline__ float query_mlp(f32x16 (&D1)[PX], const float4* sW1, 
     }
   }
 
-  // epilogue.  t2 = -log2e * (gq*gi + gqi);  v = -t2 / (1 + 2^t2) = log2e * g*sigmoid(g);  softmax in base 2
-  float mx = -INFINITY;
+  // epilogue.  t2 = -log2e * (gq*gi + gqi);  u = t2 / (1 + 2^t2) = -log2e * g*sigmoid(g);  softmax(w) = 2^(min u - u) / sum
+  __builtin_amdgcn_sched_barrier(0);
+  float mn = INFINITY;
 #pragma unroll
   for (int ec = 0; ec < G::E / 4; ++ec) {
     const float4 gi = tGi[ec * 64 + lane];
@@ -141,17 +145,17 @@ __device__ __forceinline__ float query_mlp(f32x16 (&D1)[PX], const float4* sW1, 
     for (int j = 0; j < 2; ++j) {
       const int e = ec * 4 + 2 * j;
       const f32x2 t2 = pk_fma(gqv[j], giv[j], f32x2{D3[e / 16][e % 16], D3[e / 16][e % 16 + 1]});
-      const f32x2 v = -t2 * pk_sigmoid_arg(t2);
-      D3[e / 16][e % 16] = v.x;
-      D3[e / 16][e % 16 + 1] = v.y;
-      mx = fmaxf(mx, fmaxf(v.x, v.y));
+      const f32x2 u = t2 * pk_sigmoid_arg(t2);
+      D3[e / 16][e % 16] = u.x;
+      D3[e / 16][e % 16 + 1] = u.y;
+      mn = fminf(mn, fminf(u.x, u.y));
     }
   }
-  mx = fmaxf(mx, xor32(mx));
+  mn = fminf(mn, xor32(mn));
   f32x2 den2 = {0.0f, 0.0f}, num2 = {0.0f, 0.0f};
 #pragma unroll
   for (int e = 0; e < G::E; e += 2) {
-    const f32x2 d = f32x2{D3[e / 16][e % 16], D3[e / 16][e % 16 + 1]} - mx;
+    const f32x2 d = mn - f32x2{D3[e / 16][e % 16], D3[e / 16][e % 16 + 1]};
     const f32x2 ex = {__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};
     den2 = den2 + ex;
     // e and e+1 are consecutive registers of one D1 tile (RPQ is even)

@@ -9,9 +9,10 @@
 // then position ascending" -- the deterministic tie rule that makes 1/2/4/8-GPU results identical.
 //
 //   n <= 16384  one workgroup per row bitonic-sorts the whole row in LDS.
-//   larger n    MSB-first radix select (11/11/10 bits of the score, then 11/11/10 of the position if
-//               the k-th score is tied) with LDS histograms finds the k-th largest key T exactly; one
-//               compaction pass gathers the exactly-k keys >= T; the LDS bitonic sort orders them.
+//   larger n    MSB-first radix select over the 32 score bits (11/11/10, LDS histograms) finds the k-th largest
+//               score; if that score is tied, one in-order scan of the row finds the position of the last tied
+//               element to take, which completes the 64-bit threshold key T; one compaction pass gathers the
+//               exactly-k keys >= T; the LDS bitonic sort orders them.
 #include <hip/hip_runtime.h>
 
 #include "mol_kernels.h"
@@ -21,12 +22,10 @@ namespace mol {
 constexpr int kSortCap = 16384;       // 64-bit keys in 128 KiB of LDS
 constexpr int kSortThreads = 1024;
 constexpr int kHistThreads = 512;
-constexpr int kRadixPasses = 6;
+constexpr int kRadixPasses = 3;
 constexpr int kBins = 2048;
-__device__ __constant__ int kPassShift[kRadixPasses] = {53, 42, 32, 21, 10, 0};
-__device__ __constant__ int kPassBits[kRadixPasses] = {11, 11, 10, 11, 11, 10};
-static const int hPassShift[kRadixPasses] = {53, 42, 32, 21, 10, 0};
-static const int hPassBits[kRadixPasses] = {11, 11, 10, 11, 11, 10};
+__device__ __constant__ int kPassShift[kRadixPasses] = {53, 42, 32};
+__device__ __constant__ int kPassBits[kRadixPasses] = {11, 11, 10};
 
 struct SelectState {       // one per row, lives in the workspace
   unsigned long long prefix;  // resolved high bits of the k-th key (low bits zero)
@@ -148,7 +147,43 @@ __global__ __launch_bounds__(256) void pick_bin_kernel(SelectState* __restrict__
     st[row].prefix |= ((unsigned long long)sel_bin) << shift;
     st[row].need = still;
     // all keys of this bin are wanted -> the threshold is the bin's lower edge; nothing left to resolve
-    if (c == still || pass == kRadixPasses - 1) st[row].done = 1u;
+    if (c == still) st[row].done = 1u;  // otherwise tie_resolve_kernel finishes the threshold
+  }
+}
+
+// The k-th score is tied: `need` of the elements whose score equals it are wanted, lowest positions first.
+// One workgroup per row scans the row in position order and finds the position of the need-th such element;
+// that completes the threshold key (score bits | ~position).  Rows whose threshold is already final exit at once.
+constexpr int kTieThreads = 1024;
+__global__ __launch_bounds__(kTieThreads) void tie_resolve_kernel(const float* __restrict__ scores, int64_t ld, int64_t n,
+                                                                 SelectState* __restrict__ st) {
+  __shared__ unsigned int wave_cnt[kTieThreads / 64];
+  const int row = blockIdx.x;
+  if (st[row].done) return;
+  const unsigned int target = (unsigned int)(st[row].prefix >> 32);
+  const unsigned int need = st[row].need;
+  const float* rowp = scores + (int64_t)row * ld;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned int running = 0;
+  for (int64_t base = 0; base < n; base += kTieThreads) {
+    const int64_t i = base + threadIdx.x;
+    const bool match = i < n && orderable(rowp[i]) == target;
+    const unsigned long long bal = __ballot(match);
+    if (lane == 0) wave_cnt[wave] = (unsigned int)__popcll(bal);
+    __syncthreads();
+    unsigned int before = running, total = 0;
+    for (int w = 0; w < kTieThreads / 64; ++w) {
+      if (w < wave) before += wave_cnt[w];
+      total += wave_cnt[w];
+    }
+    const unsigned int rank = before + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull));  // 0-based among matches
+    if (match && rank == need - 1) {
+      st[row].prefix = ((unsigned long long)target << 32) | (unsigned int)(~(unsigned int)i);
+      st[row].done = 1u;
+    }
+    running += total;
+    __syncthreads();
+    if (running >= need) break;
   }
 }
 
@@ -222,12 +257,12 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
   if (chunks > max_chunks) chunks = max_chunks;
   if (chunks < 1) chunks = 1;
   const int64_t chunk = (n + chunks - 1) / chunks;
-  (void)hPassShift; (void)hPassBits;
   for (int pass = 0; pass < kRadixPasses; ++pass) {
     hipLaunchKernelGGL(hist_kernel, dim3((unsigned)chunks, rows), dim3(kHistThreads), 0, stream, scores, ld, n, st, hist,
                        pass, chunk);
     hipLaunchKernelGGL(pick_bin_kernel, dim3(rows), dim3(256), 0, stream, st, hist, pass, rows);
   }
+  hipLaunchKernelGGL(tie_resolve_kernel, dim3(rows), dim3(kTieThreads), 0, stream, scores, ld, n, st);
   hipLaunchKernelGGL(compact_kernel, dim3((unsigned)chunks, rows), dim3(kHistThreads), 0, stream, scores, ld, n, st, cand,
                      (int64_t)k, k, chunk);
   const int npad = next_pow2(k < 2 ? 2 : k);
