@@ -38,6 +38,9 @@ WORKLOADS = {
     "amzn-books": ("amzn-books", 695762, 61),
     "ml-20m": ("ml-20m", 27278, 211),
     "ml-1m": ("ml-1m", 3883, 211),
+    # one 8-way shard of the synthetic configs of BASELINE.json (use --items to shrink)
+    "synthetic-16x16x64": ("synthetic-16x16x64", 12_500_000, 0),
+    "synthetic-8x8x32": ("synthetic-8x8x32", 125_000_000, 0),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBPS = 8000.0

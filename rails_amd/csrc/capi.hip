@@ -51,7 +51,7 @@ static bool shape_supported(const Shape* s) {
   }
   if (!score_supported(*s)) {
     set_error("no fused scoring kernel for P_Q x P_X x d = %dx%dx%d with gating_qi_hidden_dim = %d "
-              "(built: 8x4x64, 8x4x128, 8x8x32 with 128)",
+              "(built: 8x4x64, 8x4x128, 8x8x32, 16x16x64 with 128)",
               s->query_dot_product_groups, s->item_dot_product_groups, s->dot_product_dimension,
               s->gating_qi_hidden_dim);
     return false;

@@ -45,6 +45,7 @@ def test_size_helpers_and_validation(lib):
     assert lib.rails_mol_query_pack_floats(C.byref(s), 5) == 2 * 32 * 32 + 5 * 64   # two query groups of 4
     bad = E.MolShapeSpec(64, 64, 48, 8, 8, 512, 128, 128, 128).to_c()
     assert lib.rails_mol_shape_supported(C.byref(bad)) == 0 and "no fused scoring kernel" in _lib.last_error()
+    assert lib.rails_mol_shape_supported(C.byref(E.MolShapeSpec(64, 64, 64, 16, 16, 512, 128, 128, 128).to_c())) == 1
     # k > n is rejected before any launch
     assert lib.rails_topk(1, 10, 1, 10, 11, 1, None, 0, 1, 1, None, 0, None) == _lib.RAILS_EINVAL
     with pytest.raises(ValueError):

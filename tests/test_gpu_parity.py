@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 LOGIT_TOL = 1e-4   # BASELINE.json north_star: "within 1e-4 on MoL logits"
 STAGE_TOL = 2e-6   # unit-norm embeddings / O(1) gates: a few ulp of summation-order noise
 
-SUPPORTED = ["c1_ml1m", "c2_ml20m", "c3_books"]
+SUPPORTED = ["c1_ml1m", "c2_ml20m", "c3_books", "c4_16x16x64"]
 
 
 def build_module(cfg, weights, dev):
