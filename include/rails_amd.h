@@ -136,6 +136,22 @@ int rails_mol_score_candidates(const rails_mol_shape* shape, const float* gate_p
                                int32_t batch, const float* cand_index, int64_t n_cand, float* logits,
                                int64_t ld, void* stream);
 
+/* ---- dot-product (MIPS) scoring ---------------------------------------------------------------
+ * Replaces torch.mm(query_embeddings, item_embeddings_t) of MIPSBruteForceTopK.forward
+ * (rails/indexing/mips_top_k.py:56-81) and of DotProductSimilarity.forward
+ * (rails/similarities/dot_product_similarity_fn.py:48-54).  fp32. */
+size_t rails_mips_index_floats(int32_t dim, int64_t n_items);          /* tile-packed copy of the (n, dim) table */
+int rails_mips_index_build(const float* items, int64_t n_items, int32_t dim, float* index, void* stream);
+size_t rails_mips_query_ws_floats(int32_t dim, int32_t batch);         /* scratch for the packed queries */
+int rails_mips_score(const float* queries, int32_t batch, int32_t dim, const float* index, int64_t n_items,
+                     float* query_ws, float* logits, int64_t ld, void* stream);
+
+/* Per-row candidates: out[bq * n_cand + x] = <queries[bq], items[bq / r][x]> for queries (n_queries, dim) and items
+ * (n_queries / r, n_cand, dim) -- the two bmm branches of DotProductSimilarity.forward
+ * (rails/similarities/dot_product_similarity_fn.py:55-68). */
+int rails_dot_rowwise(const float* queries, const float* items, int64_t n_queries, int32_t n_cand, int32_t dim, int32_t r,
+                      float* out, void* stream);
+
 /* ---- coarse pass of the two-pass approximate top-k ---------------------------------------------
  * Replaces MoLAvgTopK.__init__'s averaged bf16 table (rails/indexing/mol_top_k.py:321-325) and the bf16 `mm`
  * of MoLAvgTopK.forward / topk_ids (mol_top_k.py:351-354, :418-425).  Every value the reference rounds to bf16

@@ -14,6 +14,7 @@ Fixture families:
   F5  eval_metrics_v2_from_tensors (rank, HR@k, NDCG@k, MRR) driven through the reference harness
   F6  per-row candidates branch of MoLSimilarity.forward (B' == B)
   F7  one full-size case for ML-1M (N=3883) and ML-20M (N=27278): B=32, k=200
+  F9  MIPSBruteForceTopK + DotProductSimilarity (all three shape branches)
 """
 import os
 import sys
@@ -308,12 +309,53 @@ def full_size_fixture(name: str, cfg: MoLConfig, N: int, seed: int, B: int = 32,
     print(f"{name}: wrote {len(out)} arrays")
 
 
+def mips_fixture(seed: int = 707):
+    """F9: MIPSBruteForceTopK and the three branches of DotProductSimilarity."""
+    from rails.indexing.mips_top_k import MIPSBruteForceTopK  # reference
+    from rails.similarities.dot_product_similarity_fn import DotProductSimilarity  # reference
+
+    out = {}
+    g = torch.Generator().manual_seed(seed)
+    for tag, D, N, B in (("d50", 50, 1000, 6), ("d64", 64, 20000, 33)):
+        q = torch.randn((B, D), generator=g)
+        X = torch.from_numpy(hash_item_table(seed + D, 0, N, D, sigma=1.0)).unsqueeze(0)
+        ids = sparse_item_ids(N, seed + 3)
+        with torch.inference_mode():
+            tk = MIPSBruteForceTopK(X, ids)
+            dp = DotProductSimilarity()
+            logits, aux = dp(q, X)
+            assert aux == {}
+            # X and ids by recipe (hash_item_table(seed + D, 0, N, D, sigma=1.0), sparse_item_ids(N, seed + 3)); logits: 2 rows
+            out[f"{tag}/q"], out[f"{tag}/N"], out[f"{tag}/table_seed"], out[f"{tag}/ids_seed"] = q.numpy(), np.array(N), np.array(seed + D), np.array(seed + 3)
+            out[f"{tag}/logits_head"] = logits[:2].numpy()
+            for k in (10, 200):
+                s, i = tk(q, k=k)
+                out[f"{tag}/k{k}/scores"], out[f"{tag}/k{k}/ids"] = s.numpy(), i.numpy()
+    # per-row candidates (B, X, D) x (B, D), and the (B*r, D) x (B, X, D) branch
+    with torch.inference_mode():
+        dp = DotProductSimilarity()
+        Xr = torch.randn((4, 37, 24), generator=g)
+        q1 = torch.randn((4, 24), generator=g)
+        q3 = torch.randn((12, 24), generator=g)
+        out["rows/X"], out["rows/q1"], out["rows/q3"] = Xr.numpy(), q1.numpy(), q3.numpy()
+        out["rows/out1"] = dp(q1, Xr)[0].numpy()
+        out["rows/out3"] = dp(q3, Xr)[0].numpy()
+    np.savez_compressed(os.path.join(OUT, "mips.npz"), **out)
+    print(f"mips: wrote {len(out)} arrays")
+
+
+ALL = {
+    "c1_ml1m": lambda: per_config_fixture("c1_ml1m", CONFIGS["ml-1m"], seed=101),
+    "c2_ml20m": lambda: per_config_fixture("c2_ml20m", CONFIGS["ml-20m"], seed=202),
+    "c3_books": lambda: per_config_fixture("c3_books", CONFIGS["amzn-books"], seed=303),
+    "c4_16x16x64": lambda: per_config_fixture("c4_16x16x64", CONFIGS["synthetic-16x16x64"], seed=404, B=5, N=512, n_stage=96),
+    "harness": harness_fixture,
+    "full_c1_ml1m": lambda: full_size_fixture("full_c1_ml1m", CONFIGS["ml-1m"], N=3883, seed=505),
+    "full_c2_ml20m": lambda: full_size_fixture("full_c2_ml20m", CONFIGS["ml-20m"], N=27278, seed=606),
+    "mips": mips_fixture,
+}
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    per_config_fixture("c1_ml1m", CONFIGS["ml-1m"], seed=101)
-    per_config_fixture("c2_ml20m", CONFIGS["ml-20m"], seed=202)
-    per_config_fixture("c3_books", CONFIGS["amzn-books"], seed=303)
-    per_config_fixture("c4_16x16x64", CONFIGS["synthetic-16x16x64"], seed=404, B=5, N=512, n_stage=96)
-    harness_fixture()
-    full_size_fixture("full_c1_ml1m", CONFIGS["ml-1m"], N=3883, seed=505)
-    full_size_fixture("full_c2_ml20m", CONFIGS["ml-20m"], N=27278, seed=606)
+    for name in (sys.argv[1:] or list(ALL)):   # `python oracle/gen_golden.py mips` regenerates one fixture
+        ALL[name]()

@@ -327,6 +327,24 @@ def avg_topk(cfg: MoLConfig, w, q, items, item_ids, k: int, avg_top_k: int, user
     return s, _t(item_ids).reshape(-1)[torch.gather(coarse_idx, 1, idx)], coarse_idx
 
 
+def dot_product_similarity(q: torch.Tensor, items: torch.Tensor) -> torch.Tensor:
+    """DotProductSimilarity.forward (rails/similarities/dot_product_similarity_fn.py:33-68), all three branches."""
+    q, items = _t(q), _t(items)
+    B_I, X, D = items.size()
+    if B_I == 1:
+        return torch.mm(q, items.squeeze(0).t())
+    if q.size(0) != B_I:
+        return torch.bmm(q.view(B_I, -1, D), items.permute(0, 2, 1)).view(-1, X)
+    return torch.bmm(items, q.unsqueeze(2)).squeeze(2)
+
+
+def mips_brute_force_topk(q, items, item_ids, k: int):
+    """MIPSBruteForceTopK.forward (rails/indexing/mips_top_k.py:56-81)."""
+    logits = torch.mm(_t(q), _t(items).permute(2, 1, 0).squeeze(2))
+    s, idx = torch.topk(logits, dim=1, k=k, sorted=True, largest=True)
+    return s, _t(item_ids).reshape(-1)[idx]
+
+
 def eval_ranks(top_k_ids: torch.Tensor, target_ids: torch.Tensor, max_k: int) -> torch.Tensor:
     """data/eval.py:194-201: 1-based rank of the target inside the returned ids, MAX_K+1 if absent."""
     top_k_ids, target_ids = _t(top_k_ids), _t(target_ids)

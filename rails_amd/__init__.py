@@ -4,10 +4,10 @@ Importing the package does not load the HIP library; the first kernel call does 
 and fails loudly if librails_amd.so has not been built.
 """
 from .factory import create_mol_interaction_module
-from .mol_module import MoLSimilarity, SimilarityModule
-from .topk_modules import CandidateIndex, MoLAvgTopK, MoLBruteForceTopK, TopKModule, get_top_k_module
+from .mol_module import DotProductSimilarity, MoLSimilarity, SimilarityModule
+from .topk_modules import CandidateIndex, MIPSBruteForceTopK, MoLAvgTopK, MoLBruteForceTopK, TopKModule, get_top_k_module
 
 __all__ = [
-    "create_mol_interaction_module", "MoLSimilarity", "SimilarityModule", "CandidateIndex",
+    "create_mol_interaction_module", "MoLSimilarity", "DotProductSimilarity", "SimilarityModule", "CandidateIndex", "MIPSBruteForceTopK",
     "MoLBruteForceTopK", "MoLAvgTopK", "TopKModule", "get_top_k_module",
 ]

@@ -95,6 +95,17 @@ PROTOTYPES = {
         C.c_int,
         [_SHAPE_P, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p],
     ),
+    "rails_mips_index_floats": (C.c_size_t, [C.c_int32, C.c_int64]),
+    "rails_mips_index_build": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "rails_mips_query_ws_floats": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "rails_mips_score": (
+        C.c_int,
+        [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p],
+    ),
+    "rails_dot_rowwise": (
+        C.c_int,
+        [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p],
+    ),
     "rails_mol_coarse_table_bytes": (C.c_size_t, [_SHAPE_P, C.c_int64]),
     "rails_mol_coarse_build": (C.c_int, [_SHAPE_P, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "rails_mol_coarse_score": (

@@ -206,6 +206,45 @@ int rails_mol_score_candidates(const rails_mol_shape* s, const float* gate_pack,
   return score_common(s, gate_pack, query_pack, batch, cand_index, n_cand, logits, ld, 1, stream, "score_candidates");
 }
 
+size_t rails_mips_index_floats(int32_t dim, int64_t n_items) {
+  if (dim <= 0 || n_items < 0) return 0;
+  return (size_t)num_tiles(n_items) * 32 * (size_t)((dim + 7) / 8 * 8);
+}
+
+int rails_mips_index_build(const float* items, int64_t n_items, int32_t dim, float* index, void* stream) {
+  g_err[0] = '\0';
+  if (dim <= 0 || n_items < 0) { set_error("mips_index_build: bad size"); return RAILS_EINVAL; }
+  if (n_items == 0) return RAILS_OK;
+  if (!items || !index) { set_error("mips_index_build: NULL pointer"); return RAILS_EINVAL; }
+  return fail(mips_pack_items(items, n_items, dim, index, (hipStream_t)stream), "mips_index_build");
+}
+
+size_t rails_mips_query_ws_floats(int32_t dim, int32_t batch) {
+  if (dim <= 0 || batch < 0) return 0;
+  return (size_t)((batch + 31) / 32) * 32 * (size_t)((dim + 7) / 8 * 8);
+}
+
+int rails_mips_score(const float* queries, int32_t batch, int32_t dim, const float* index, int64_t n_items, float* query_ws,
+                     float* logits, int64_t ld, void* stream) {
+  g_err[0] = '\0';
+  if (dim <= 0 || batch < 0 || n_items < 0) { set_error("mips_score: bad size"); return RAILS_EINVAL; }
+  if (batch == 0 || n_items == 0) return RAILS_OK;
+  if (!queries || !index || !query_ws || !logits) { set_error("mips_score: NULL pointer"); return RAILS_EINVAL; }
+  if (ld < n_items) { set_error("mips_score: ld < n_items"); return RAILS_EINVAL; }
+  const int cu = compute_units();
+  if (cu <= 0) { set_error("mips_score: no HIP device"); return RAILS_ELAUNCH; }
+  return fail(mips_score(queries, batch, dim, index, n_items, query_ws, logits, ld, cu, (hipStream_t)stream), "mips_score");
+}
+
+int rails_dot_rowwise(const float* queries, const float* items, int64_t n_queries, int32_t n_cand, int32_t dim, int32_t r,
+                      float* out, void* stream) {
+  g_err[0] = '\0';
+  if (n_queries < 0 || n_cand < 0 || dim <= 0 || r <= 0 || n_queries % r != 0) { set_error("dot_rowwise: bad size"); return RAILS_EINVAL; }
+  if (n_queries == 0 || n_cand == 0) return RAILS_OK;
+  if (!queries || !items || !out) { set_error("dot_rowwise: NULL pointer"); return RAILS_EINVAL; }
+  return fail(dot_rowwise(queries, items, n_queries, n_cand, dim, r, out, (hipStream_t)stream), "dot_rowwise");
+}
+
 size_t rails_mol_coarse_table_bytes(const rails_mol_shape* s, int64_t n_items) {
   if (!shape_ok(s) || n_items < 0) return 0;
   return (size_t)n_items * (size_t)s->dot_product_dimension * 2;

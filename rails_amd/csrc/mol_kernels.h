@@ -56,6 +56,12 @@ int coarse_build(const Shape& s, const float* ipack, int64_t n, void* table, hip
 int coarse_score(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, float* scores, int64_t ld,
                  hipStream_t stream);
 
+int mips_pack_items(const float* items, int64_t n, int D, float* out, hipStream_t stream);
+int mips_score(const float* q, int B, int D, const float* ifrag, int64_t n, float* qfrag_ws, float* logits, int64_t ld,
+               int n_cu, hipStream_t stream);
+
+int dot_rowwise(const float* q, const float* items, int64_t Bq, int X, int D, int r, float* out, hipStream_t stream);
+
 size_t topk_workspace_bytes(int rows, int64_t n, int k);
 int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int64_t* ids, int64_t ids_row_stride,
          float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, hipStream_t stream);

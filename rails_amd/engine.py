@@ -260,6 +260,47 @@ class MolEngine:
         return out
 
 
+# ---- dot-product (MIPS) scoring ----------------------------------------------------------------
+class MipsIndex:
+    """Tile-packed fp32 copy of an (N, D) item table for the MFMA dot-product scan."""
+
+    def __init__(self, items: torch.Tensor):
+        lib = _lib.load()
+        _require_device(items, "item_embeddings")
+        items = _f32c(items)
+        self.n_items, self.dim = items.shape
+        self.buf = torch.empty(lib.rails_mips_index_floats(self.dim, self.n_items), dtype=torch.float32, device=items.device)
+        with torch.cuda.device(items.device):
+            _lib.check(lib.rails_mips_index_build(_ptr(items), self.n_items, self.dim, _ptr(self.buf), _stream()), "rails_mips_index_build")
+
+    def score(self, q: torch.Tensor) -> torch.Tensor:
+        """(B, D) -> (B, N) fp32 dot products (reference rails/indexing/mips_top_k.py:72)."""
+        lib = _lib.load()
+        _require_device(q, "query_embeddings")
+        if q.dim() != 2 or q.shape[1] != self.dim:
+            raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({tuple(q.shape)} and {self.dim}x{self.n_items})")
+        q = _f32c(q)
+        B = q.shape[0]
+        ws = torch.empty(lib.rails_mips_query_ws_floats(self.dim, B), dtype=torch.float32, device=q.device)
+        out = torch.empty((B, self.n_items), dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            _lib.check(lib.rails_mips_score(_ptr(q), B, self.dim, _ptr(self.buf), self.n_items, _ptr(ws), _ptr(out), out.stride(0), _stream()), "rails_mips_score")
+        return out
+
+
+def dot_rowwise(q: torch.Tensor, items: torch.Tensor) -> torch.Tensor:
+    """q (Bq, D), items (B_I, X, D) with Bq a multiple of B_I -> (Bq, X): <q[bq], items[bq // r][x]>."""
+    lib = _lib.load()
+    _require_device(q, "query_embeddings")
+    q, items = _f32c(q), _f32c(items)
+    Bq, D = q.shape
+    BI, X, _ = items.shape
+    out = torch.empty((Bq, X), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        _lib.check(lib.rails_dot_rowwise(_ptr(q), _ptr(items), Bq, X, D, Bq // BI, _ptr(out), _stream()), "rails_dot_rowwise")
+    return out
+
+
 # ---- shape-independent kernels ----------------------------------------------------------------
 def topk(scores: torch.Tensor, k: int, ids: Optional[torch.Tensor] = None, sorted: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
     """Exact top-k of every row of `scores` (rows, n) fp32 on the GPU; ties by position ascending.

@@ -31,6 +31,28 @@ class SimilarityModule(torch.nn.Module):
         """(B, D), (1/B, X, D') -> ((B, X) similarities, aux losses)."""
 
 
+class DotProductSimilarity(SimilarityModule):
+    """Reference rails/similarities/dot_product_similarity_fn.py:24-68, on the HIP dot-product kernels."""
+
+    def __init__(self) -> None:
+        super().__init__()
+
+    def debug_str(self) -> str:
+        return "dp"
+
+    def forward(self, query_embeddings: torch.Tensor, item_embeddings: torch.Tensor, **kwargs) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        from . import engine as E
+
+        B_I, X, D = item_embeddings.size()
+        if B_I == 1:  # (B, D) x (1, X, D) -> (B, X)
+            out = E.MipsIndex(item_embeddings[0]).score(query_embeddings)
+        else:         # (B * r, D) x (B, X, D) -> (B * r, X); r = 1 is the per-row-candidates case
+            if query_embeddings.size(0) % B_I != 0:
+                raise RuntimeError(f"shape '[{B_I}, -1, {D}]' is invalid for input of size {query_embeddings.numel()}")
+            out = E.dot_rowwise(query_embeddings, item_embeddings)
+        return out.to(query_embeddings.dtype), {}
+
+
 class _GLU(torch.nn.Module):
     """Parameter holder for the query projection's gated unit (reference rails/similarities/layers.py:19-74):
     `_w` (in, 2*out) ~ N(0, 0.02^2), `_b` (1, 2*out) = 0.  Evaluated inside the fused query-prologue kernel."""

@@ -125,6 +125,32 @@ class MoLAvgTopK(MoLTopKModule):
         return self._coarse_topk(query_embeddings, average_queries=True, **kwargs)[1]
 
 
+class MIPSTopKModule(TopKModule):
+    """Reference rails/indexing/mips_top_k.py:23-38."""
+
+    def __init__(self, item_embeddings: torch.Tensor, item_ids: torch.Tensor) -> None:
+        super().__init__()
+        self._item_embeddings: torch.Tensor = item_embeddings
+        self._item_ids: torch.Tensor = item_ids
+
+
+class MIPSBruteForceTopK(MIPSTopKModule):
+    """Dot-product brute force (reference rails/indexing/mips_top_k.py:41-81): MFMA scan + exact top-k, all HIP."""
+
+    def __init__(self, item_embeddings: torch.Tensor, item_ids: torch.Tensor) -> None:
+        super().__init__(item_embeddings=item_embeddings, item_ids=item_ids)
+        if item_embeddings.dim() != 3 or item_embeddings.shape[0] != 1:
+            raise ValueError(f"item_embeddings must be (1, N, D), got {tuple(item_embeddings.shape)}")
+        del self._item_embeddings
+        self._index = E.MipsIndex(item_embeddings[0])
+        self._ids_flat = item_ids.reshape(-1).to(device=item_embeddings.device, dtype=torch.int64).contiguous()
+
+    def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        logits = self._index.score(query_embeddings)
+        scores, ids = E.topk(logits, k, ids=self._ids_flat, sorted=sorted)
+        return scores.to(query_embeddings.dtype), ids
+
+
 class CandidateIndex(object):
     """Reference indexing/candidate_index.py:30-185 (`filter_invalid_ids` / `apply_object_filter` are never
     called by any entry point of the reference and are not provided)."""
@@ -179,11 +205,12 @@ class CandidateIndex(object):
 
 
 _BUILT = {"MoLBruteForceTopK": lambda mol, x, ids: MoLBruteForceTopK(mol_module=mol, item_embeddings=x, item_ids=ids)}
+_NO_MOL = {"MIPSBruteForceTopK": lambda x, ids: MIPSBruteForceTopK(item_embeddings=x, item_ids=ids)}
 for _k in (100, 200, 500, 1000, 2000, 2500, 3000, 4000):
     _BUILT[f"MoLAvgTopK{_k}"] = (lambda kk: lambda mol, x, ids: MoLAvgTopK(mol_module=mol, item_embeddings=x, item_ids=ids, avg_top_k=kk))(_k)
 # names the reference's factory accepts but this build does not implement yet
 _KNOWN_UNBUILT = (
-    ["MIPSBruteForceTopK", "MoLNaiveFaissTopK5"]
+    ["MoLNaiveFaissTopK5"]
     + [f"MoLNaiveTopK{k}" for k in (5, 10, 25, 50, 75, 100)]
     + [f"MoLCombTopK{a}_{b}" for a, b in ((1, 100), (1, 500), (5, 100), (5, 200), (5, 500), (10, 100), (10, 500), (50, 500), (50, 1000), (100, 1000))]
 )
@@ -191,6 +218,8 @@ _KNOWN_UNBUILT = (
 
 def get_top_k_module(top_k_method: str, model: torch.nn.Module, item_embeddings: torch.Tensor, item_ids: torch.Tensor) -> TopKModule:
     """String -> module factory; `model._ndp_module` is the MoLSimilarity (reference indexing/utils_rails.py:25-233)."""
+    if top_k_method in _NO_MOL:
+        return _NO_MOL[top_k_method](item_embeddings, item_ids)
     if top_k_method in _BUILT:
         return _BUILT[top_k_method](model._ndp_module, item_embeddings, item_ids)
     if top_k_method in _KNOWN_UNBUILT:

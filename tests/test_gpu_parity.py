@@ -265,3 +265,32 @@ def test_f4_avg_topk(fx, mol, dev, avg_k):
         assert ov >= 0.9, ov
         with pytest.raises(ValueError, match="must be larger than k"):
             at(q, k=avg_k + 1, **kw)
+
+
+# ---- section 8(f) rank 2: MIPSBruteForceTopK + DotProductSimilarity ------------------------------------
+def test_f9_mips_and_dot_product(dev):
+    import os
+
+    import numpy as np
+
+    from tests._fixtures import GOLDEN
+    from tests.test_oracle_golden import _mips_inputs
+
+    z = np.load(os.path.join(GOLDEN, "mips.npz"))
+    T = lambda k: torch.from_numpy(z[k])
+    dp = rails_amd.DotProductSimilarity()
+    with torch.inference_mode():
+        for tag in ("d50", "d64"):                       # D = 50 exercises the K padding to a multiple of 8
+            q, X, ids = (t.to(dev) for t in _mips_inputs(z, tag))
+            logits, aux = dp(q, X)
+            assert aux == {}
+            ref = O.dot_product_similarity(q.cpu(), X.cpu())
+            assert torch.equal(ref[:2], T(f"{tag}/logits_head"))
+            assert float((logits.cpu() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+            tk = rails_amd.get_top_k_module("MIPSBruteForceTopK", None, X, ids)
+            for k in (10, 200):
+                s, i = tk(q, k=k)
+                assert_topk_matches(s, i, T(f"{tag}/k{k}/scores"), T(f"{tag}/k{k}/ids"), atol=1e-4, tie_tol=1e-4)
+        for qk, ok in (("rows/q1", "rows/out1"), ("rows/q3", "rows/out3")):
+            out, _ = dp(T(qk).to(dev), T("rows/X").to(dev))
+            assert float((out.cpu() - T(ok)).abs().max()) <= 1e-5

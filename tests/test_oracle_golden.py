@@ -111,3 +111,28 @@ def test_hash_item_table_is_shardable():
     b = O.hash_item_table(7, 400, 100, 64)
     assert np.array_equal(a[400:500], b)
     assert abs(float(a.std()) - 0.02) < 5e-4 and float(np.abs(a).max()) <= 0.02 * 3.47
+
+
+def _mips_inputs(z, tag):
+    n, D = int(z[f"{tag}/N"]), z[f"{tag}/q"].shape[1]
+    X = torch.from_numpy(O.hash_item_table(int(z[f"{tag}/table_seed"]), 0, n, D, sigma=1.0)).unsqueeze(0)
+    g = torch.Generator().manual_seed(int(z[f"{tag}/ids_seed"]))
+    ids = torch.cumsum(torch.randint(1, 4, (n,), generator=g), 0).to(torch.int64).unsqueeze(0)
+    return torch.from_numpy(z[f"{tag}/q"]), X, ids
+
+
+def test_f9_mips_and_dot_product():
+    import os
+
+    from tests._fixtures import GOLDEN
+
+    z = np.load(os.path.join(GOLDEN, "mips.npz"))
+    T = lambda k: torch.from_numpy(z[k])
+    for tag in ("d50", "d64"):
+        q, X, ids = _mips_inputs(z, tag)
+        assert torch.equal(O.dot_product_similarity(q, X)[:2], T(f"{tag}/logits_head"))
+        for k in (10, 200):
+            s, i = O.mips_brute_force_topk(q, X, ids, k)
+            assert torch.equal(s, T(f"{tag}/k{k}/scores")) and torch.equal(i, T(f"{tag}/k{k}/ids"))
+    assert torch.equal(O.dot_product_similarity(T("rows/q1"), T("rows/X")), T("rows/out1"))
+    assert torch.equal(O.dot_product_similarity(T("rows/q3"), T("rows/X")), T("rows/out3"))
