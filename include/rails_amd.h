@@ -164,6 +164,21 @@ int rails_mol_coarse_build(const rails_mol_shape* shape, const float* index, int
 int rails_mol_coarse_score(const rails_mol_shape* shape, const float* eq, int32_t batch, int32_t average_queries,
                            const void* table, int64_t n_items, float* scores, int64_t ld, void* stream);
 
+/* ---- per-component candidate generation (MoLNaiveTopK / MoLCombTopK) ------------------------------
+ * Replaces the bf16 component table (rails/indexing/mol_top_k.py:61-73, :172-174) and the per-query-group bf16 `mm`
+ * (mol_top_k.py:247-251, :498-502).  scores has batch * P_Q * P_X rows, row (b * P_Q + i) * P_X + m, n_items columns;
+ * feed it to rails_topk with k = k_per_group and reshape the (rows, k) positions to (batch, P_Q * P_X * k). */
+size_t rails_mol_component_table_bytes(const rails_mol_shape* shape, int64_t n_items);   /* 2 * P_X * d bytes per item */
+int rails_mol_component_build(const rails_mol_shape* shape, const float* index, int64_t n_items, void* table,
+                              void* stream);
+int rails_mol_component_score(const rails_mol_shape* shape, const float* eq, int32_t batch, const void* table,
+                              int64_t n_items, float* scores, int64_t ld, void* stream);
+/* torch.sort(indices, dim=1) on (rows, n) int64, n <= 16384 (mol_top_k.py:257, :515); in == out allowed. */
+int rails_sort_rows_i64(const int64_t* in, int32_t rows, int32_t n, int64_t* out, void* stream);
+/* scores[r][j] = fill where sorted_idx[r][j] == sorted_idx[r][j-1] (mol_top_k.py:277-284, :535-542). */
+int rails_mask_sorted_duplicates(const int64_t* sorted_idx, float* scores, int64_t ld, int32_t rows, int32_t n, float fill,
+                                 void* stream);
+
 /* ---- exact top-k -----------------------------------------------------------------------------
  * Replaces torch.topk(all_logits, dim=1, k, sorted, largest=True) + the id gather
  * (rails/indexing/mol_top_k.py:123-130).  Row b reads scores[b * ld + 0..n).  Ties are broken by

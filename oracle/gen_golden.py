@@ -15,6 +15,7 @@ Fixture families:
   F6  per-row candidates branch of MoLSimilarity.forward (B' == B)
   F7  one full-size case for ML-1M (N=3883) and ML-20M (N=27278): B=32, k=200
   F9  MIPSBruteForceTopK + DotProductSimilarity (all three shape branches)
+  F10 MoLNaiveTopK / MoLCombTopK outputs and the candidate union the reference reranked
 """
 import os
 import sys
@@ -344,6 +345,51 @@ def mips_fixture(seed: int = 707):
     print(f"mips: wrote {len(out)} arrays")
 
 
+def union_fixture(seed: int = 808):
+    """F10: MoLNaiveTopK and MoLCombTopK.  The candidate union the reference built is
+    captured by spying on its torch.sort call, so the rerank half can be checked exactly on the same candidates."""
+    from rails.indexing.mol_top_k import MoLCombTopK, MoLNaiveTopK  # reference
+
+    out = {}
+    for cname, cfg, s0 in (("c1", CONFIGS["ml-1m"], seed), ("c3", CONFIGS["amzn-books"], seed + 50)):
+        mol = build_reference_module(cfg, s0)
+        B, N = 5, 1024
+        q = synthetic_queries(cfg, B, seed=s0 + 2)
+        X = torch.from_numpy(hash_item_table(s0 + 1, 0, N, cfg.item_embedding_dim)).unsqueeze(0)
+        ids = sparse_item_ids(N, s0 + 3)
+        kw = {}
+        if len(cfg.uid_embedding_hash_sizes) > 0:
+            g = torch.Generator().manual_seed(s0 + 4)
+            kw["user_ids"] = torch.randint(0, 200000, (B,), generator=g, dtype=torch.int64)
+            out[f"{cname}/user_ids"] = kw["user_ids"].numpy()
+        out[f"{cname}/cfg_json"] = np.array(__import__("json").dumps(cfg.to_dict()))
+        for k, v in slim_weights(mol, cfg, kw.get("user_ids")).items():
+            out[f"{cname}/w/" + k] = v
+        out[f"{cname}/q"], out[f"{cname}/X"], out[f"{cname}/item_ids"] = q.numpy(), X.numpy(), ids.numpy()
+        mods = {"naive5": lambda: MoLNaiveTopK(mol, X, ids, k_per_group=5),
+                "comb5_100": lambda: MoLCombTopK(mol, X, ids, avg_top_k=100, k_per_group=5)}
+        for mname, make in mods.items():
+            rec = {}
+            orig_sort = torch.sort
+
+            def spy(*a, **k):
+                r = orig_sort(*a, **k)
+                rec["sorted"] = r[0].clone()
+                return r
+
+            with torch.inference_mode():
+                mod = make()
+                torch.sort = spy
+                try:
+                    s, i = mod(q, k=10, sorted=True, **kw)   # k is ignored by the reference: all candidates come back
+                finally:
+                    torch.sort = orig_sort
+            out[f"{cname}/{mname}/scores"], out[f"{cname}/{mname}/ids"] = s.numpy(), i.numpy()
+            out[f"{cname}/{mname}/sorted_all_indices"] = rec["sorted"].numpy()
+    np.savez_compressed(os.path.join(OUT, "union.npz"), **out)
+    print(f"union: wrote {len(out)} arrays")
+
+
 ALL = {
     "c1_ml1m": lambda: per_config_fixture("c1_ml1m", CONFIGS["ml-1m"], seed=101),
     "c2_ml20m": lambda: per_config_fixture("c2_ml20m", CONFIGS["ml-20m"], seed=202),
@@ -353,6 +399,7 @@ ALL = {
     "full_c1_ml1m": lambda: full_size_fixture("full_c1_ml1m", CONFIGS["ml-1m"], N=3883, seed=505),
     "full_c2_ml20m": lambda: full_size_fixture("full_c2_ml20m", CONFIGS["ml-20m"], N=27278, seed=606),
     "mips": mips_fixture,
+    "union": union_fixture,
 }
 
 if __name__ == "__main__":

@@ -327,6 +327,31 @@ def avg_topk(cfg: MoLConfig, w, q, items, item_ids, k: int, avg_top_k: int, user
     return s, _t(item_ids).reshape(-1)[torch.gather(coarse_idx, 1, idx)], coarse_idx
 
 
+def union_rerank(cfg: MoLConfig, w, q, items, item_ids, sorted_all_indices, user_ids=None):
+    """Second half of MoLNaiveTopK / MoLCombTopK.forward (rails/indexing/mol_top_k.py:259-293, :517-551): MoL on the
+    sorted candidate union, duplicates masked with -32767.0, top-k over ALL candidates."""
+    idx = _t(sorted_all_indices)
+    B, k = idx.shape
+    items = _t(items).float().squeeze(0)
+    cand = items[idx.view(-1)].reshape(B, k, -1)
+    scores = mol_stages(cfg, w, q, cand, user_ids)["logits"]
+    valid = torch.cat([torch.ones_like(idx[:, 0:1], dtype=torch.bool), idx[:, 1:] != idx[:, :-1]], dim=1)
+    scores = torch.where(valid, scores, -32767.0)
+    s, ti = torch.topk(scores, k=k, dim=1, largest=True, sorted=True)
+    return s, _t(item_ids).reshape(-1)[torch.gather(idx, 1, ti)]
+
+
+def component_candidate_scores(cfg: MoLConfig, w, q, items, user_ids=None) -> torch.Tensor:
+    """First half (mol_top_k.py:242-251): bf16 mm of every query group against every item group's bf16 components.
+    -> (B, P_Q, P_X, N) bf16."""
+    eq = query_component_embeddings(cfg, w, _t(q).float(), user_ids).to(torch.bfloat16)
+    ex = item_component_embeddings(cfg, w, _t(items).float().squeeze(0)).to(torch.bfloat16)  # (N, P_X, d)
+    N, PX, d = ex.shape
+    table_t = ex.permute(1, 0, 2).reshape(-1, d).transpose(0, 1)  # (d, P_X * N)
+    outs = [torch.mm(eq[:, i, :], table_t).view(eq.size(0), PX, N) for i in range(eq.size(1))]
+    return torch.stack(outs, dim=1)
+
+
 def dot_product_similarity(q: torch.Tensor, items: torch.Tensor) -> torch.Tensor:
     """DotProductSimilarity.forward (rails/similarities/dot_product_similarity_fn.py:33-68), all three branches."""
     q, items = _t(q), _t(items)

@@ -5,9 +5,10 @@ and fails loudly if librails_amd.so has not been built.
 """
 from .factory import create_mol_interaction_module
 from .mol_module import DotProductSimilarity, MoLSimilarity, SimilarityModule
-from .topk_modules import CandidateIndex, MIPSBruteForceTopK, MoLAvgTopK, MoLBruteForceTopK, TopKModule, get_top_k_module
+from .topk_modules import (CandidateIndex, MIPSBruteForceTopK, MoLAvgTopK, MoLBruteForceTopK, MoLCombTopK, MoLNaiveTopK,
+                           TopKModule, get_top_k_module)
 
 __all__ = [
     "create_mol_interaction_module", "MoLSimilarity", "DotProductSimilarity", "SimilarityModule", "CandidateIndex", "MIPSBruteForceTopK",
-    "MoLBruteForceTopK", "MoLAvgTopK", "TopKModule", "get_top_k_module",
+    "MoLBruteForceTopK", "MoLAvgTopK", "MoLNaiveTopK", "MoLCombTopK", "TopKModule", "get_top_k_module",
 ]

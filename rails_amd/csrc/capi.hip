@@ -272,6 +272,51 @@ int rails_mol_coarse_score(const rails_mol_shape* s, const float* eq, int32_t ba
   return r == kOk ? r : fail(r, "coarse_score");
 }
 
+size_t rails_mol_component_table_bytes(const rails_mol_shape* s, int64_t n_items) {
+  if (!shape_ok(s) || n_items < 0) return 0;
+  return (size_t)n_items * (size_t)s->item_dot_product_groups * (size_t)s->dot_product_dimension * 2;
+}
+
+int rails_mol_component_build(const rails_mol_shape* s, const float* index, int64_t n_items, void* table, void* stream) {
+  g_err[0] = '\0';
+  if (!shape_ok(s)) return RAILS_EINVAL;
+  if (s->dot_product_dimension % 8 != 0) { set_error("component_build: d must be a multiple of 8"); return RAILS_ENOTSUP; }
+  if (n_items < 0) { set_error("component_build: n_items < 0"); return RAILS_EINVAL; }
+  if (n_items == 0) return RAILS_OK;
+  if (!index || !table) { set_error("component_build: NULL pointer"); return RAILS_EINVAL; }
+  return fail(component_build(*s, index, n_items, table, (hipStream_t)stream), "component_build");
+}
+
+int rails_mol_component_score(const rails_mol_shape* s, const float* eq, int32_t batch, const void* table, int64_t n_items,
+                              float* scores, int64_t ld, void* stream) {
+  g_err[0] = '\0';
+  if (!shape_ok(s)) return RAILS_EINVAL;
+  if (batch < 0 || n_items < 0) { set_error("component_score: negative size"); return RAILS_EINVAL; }
+  if (batch == 0 || n_items == 0) return RAILS_OK;
+  if (!eq || !table || !scores) { set_error("component_score: NULL pointer"); return RAILS_EINVAL; }
+  if (ld < n_items) { set_error("component_score: ld < n_items"); return RAILS_EINVAL; }
+  const int r = component_score(*s, eq, batch, table, n_items, scores, ld, (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "component_score");
+}
+
+int rails_sort_rows_i64(const int64_t* in, int32_t rows, int32_t n, int64_t* out, void* stream) {
+  g_err[0] = '\0';
+  if (rows < 0 || n < 0) { set_error("sort_rows_i64: negative size"); return RAILS_EINVAL; }
+  if (rows == 0 || n == 0) return RAILS_OK;
+  if (!in || !out) { set_error("sort_rows_i64: NULL pointer"); return RAILS_EINVAL; }
+  const int r = sort_rows_i64(in, rows, n, out, (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "sort_rows_i64");
+}
+
+int rails_mask_sorted_duplicates(const int64_t* sorted_idx, float* scores, int64_t ld, int32_t rows, int32_t n, float fill,
+                                 void* stream) {
+  g_err[0] = '\0';
+  if (rows < 0 || n < 0) { set_error("mask_sorted_duplicates: negative size"); return RAILS_EINVAL; }
+  if (rows == 0 || n == 0) return RAILS_OK;
+  if (!sorted_idx || !scores) { set_error("mask_sorted_duplicates: NULL pointer"); return RAILS_EINVAL; }
+  return fail(mask_sorted_duplicates(sorted_idx, scores, ld, rows, n, fill, (hipStream_t)stream), "mask_sorted_duplicates");
+}
+
 size_t rails_topk_workspace_bytes(int32_t rows, int64_t n, int32_t k) {
   if (rows <= 0 || n <= 0 || k <= 0) return 256;
   return topk_workspace_bytes(rows, n, k);

@@ -97,4 +97,80 @@ int coarse_score(const Shape& s, const float* eq, int B, int avg, const void* ta
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Per-component candidate generation of MoLNaiveTopK / MoLCombTopK (reference rails/indexing/mol_top_k.py:
+// component table :61-73 and :172-174, scoring :242-255 / :495-506).  For every query group i and item group m the
+// reference scores  bf16(Eq[b,i,:]) . bf16(Ex[x,m,:])  with a bf16 mm and takes the top k_per_group per (b, m) row.
+//   table[x][m][:] = bf16(Ex[x,m,:])                                     2*P_X*d bytes per item, item-major
+//   score[(b*P_Q + i)*P_X + m][x] = bf16( sum_d bf16(Eq[b,i,d]) * table[x][m][d] )   fp32 holding bf16 values
+// Row order (b, i, m) makes the top-k output reshape to (B, P_Q*P_X*k_g) directly.
+// ---------------------------------------------------------------------------------------------
+__global__ void component_build_kernel(const float* __restrict__ ipack, int64_t n, int PQ, int PX, int d,
+                                       unsigned short* __restrict__ table) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int row = PX * d;
+  if (i >= n * row) return;
+  const int64_t item = i / row;
+  const int rem = (int)(i - item * row);
+  const int m = rem / d, dd = rem - m * d;
+  const int64_t tile = item >> 5;
+  const int x = (int)(item & 31);
+  const float* tEx = ipack + tile * (int64_t)(kTileItems * (PX * d + PQ * PX));
+  const int hi = dd / (d / 2), s = dd - hi * (d / 2);
+  table[i] = bf16_bits(tEx[((m * (d / 8) + (s >> 2)) * 64 + hi * 32 + x) * 4 + (s & 3)]);
+}
+
+__global__ __launch_bounds__(256) void component_score_kernel(const float* __restrict__ eq, int B, int PQ, int PX, int d,
+                                                             const unsigned short* __restrict__ table, int64_t n,
+                                                             float* __restrict__ scores, int64_t ld) {
+  extern __shared__ __attribute__((aligned(16))) float qs[];  // [B*PQ][d], bf16-rounded
+  for (int i = threadIdx.x; i < B * PQ * d; i += blockDim.x) qs[i] = bf16_rn(eq[i]);
+  __syncthreads();
+  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (int64_t)gridDim.x * blockDim.x) {
+    for (int m = 0; m < PX; ++m) {
+      const uint4* row = reinterpret_cast<const uint4*>(table + (x * PX + m) * d);
+      for (int r0 = 0; r0 < B * PQ; r0 += 8) {  // eight (b, i) rows per pass over the component
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < d / 8; ++c) {
+          const uint4 v = row[c];
+          const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float t = bf16_to_f32((unsigned short)((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu));
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr)
+              if (r0 + rr < B * PQ) acc[rr] = __builtin_fmaf(qs[(r0 + rr) * d + c * 8 + j], t, acc[rr]);
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 8; ++rr)
+          if (r0 + rr < B * PQ) scores[((int64_t)(r0 + rr) * PX + m) * ld + x] = bf16_rn(acc[rr]);
+      }
+    }
+  }
+}
+
+int component_build(const Shape& s, const float* ipack, int64_t n, void* table, hipStream_t stream) {
+  const int64_t total = n * s.item_dot_product_groups * s.dot_product_dimension;
+  if (total == 0) return kOk;
+  hipLaunchKernelGGL(component_build_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ipack, n,
+                     s.query_dot_product_groups, s.item_dot_product_groups, s.dot_product_dimension,
+                     static_cast<unsigned short*>(table));
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+int component_score(const Shape& s, const float* eq, int B, const void* table, int64_t n, float* scores, int64_t ld,
+                    hipStream_t stream) {
+  const int d = s.dot_product_dimension, PQ = s.query_dot_product_groups;
+  if (B <= 0 || n <= 0) return kOk;
+  const size_t lds = sizeof(float) * (size_t)B * PQ * d;
+  if (lds > 64 * 1024) { set_error("component_score: batch %d x P_Q %d x d %d does not fit LDS", B, PQ, d); return kErrUnsupported; }
+  int64_t grid = (n + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(component_score_kernel, dim3((unsigned)grid), dim3(256), lds, stream, eq, B, PQ,
+                     s.item_dot_product_groups, d, static_cast<const unsigned short*>(table), n, scores, ld);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 }  // namespace mol

@@ -345,6 +345,61 @@ __global__ __launch_bounds__(kFilterThreads) void filter_seen_kernel(const int64
   }
 }
 
+// ---- candidate-union helpers of MoLNaiveTopK / MoLCombTopK ------------------------------------------------
+// torch.sort(cat(all_indices), dim=1) (mol_top_k.py:257, :515): ascending LDS bitonic sort of each row of int64.
+__global__ __launch_bounds__(kSortThreads) void sort_rows_i64_kernel(const int64_t* __restrict__ in, int n, int npad,
+                                                                    int64_t* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  const int row = blockIdx.x;
+  for (int i = threadIdx.x; i < npad; i += kSortThreads)
+    keys[i] = i < n ? ((unsigned long long)in[(int64_t)row * n + i] ^ 0x8000000000000000ull) : ~0ull;  // signed order
+  __syncthreads();
+  for (int size = 2; size <= npad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < (npad >> 1); t += kSortThreads) {
+        const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+        const int hi2 = lo | stride;
+        const bool asc = ((lo & size) == 0);
+        const unsigned long long a = keys[lo], b = keys[hi2];
+        if ((a > b) == asc) { keys[lo] = b; keys[hi2] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < n; i += kSortThreads) out[(int64_t)row * n + i] = (int64_t)(keys[i] ^ 0x8000000000000000ull);
+}
+
+// candidate_scores = where(idx[j] != idx[j-1] or j == 0, scores, fill)  (mol_top_k.py:277-284, :535-542)
+__global__ void mask_sorted_duplicates_kernel(const int64_t* __restrict__ idx, float* __restrict__ scores, int64_t ld,
+                                              int rows, int n, float fill) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * n) return;
+  const int row = (int)(i / n), j = (int)(i - (int64_t)row * n);
+  if (j > 0 && idx[i] == idx[i - 1]) scores[(int64_t)row * ld + j] = fill;
+}
+
+int sort_rows_i64(const int64_t* in, int rows, int n, int64_t* out, hipStream_t stream) {
+  if (rows <= 0 || n <= 0) return kOk;
+  if (n > kSortCap) { set_error("sort_rows_i64: n = %d exceeds the in-LDS sort capacity (%d)", n, kSortCap); return kErrUnsupported; }
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_rows_i64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kSortCap * (int)sizeof(unsigned long long)) != hipSuccess)
+      return kErrLaunch;
+    attr = true;
+  }
+  const int npad = next_pow2(n < 2 ? 2 : n);
+  hipLaunchKernelGGL(sort_rows_i64_kernel, dim3(rows), dim3(kSortThreads), npad * sizeof(unsigned long long), stream, in, n, npad, out);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+int mask_sorted_duplicates(const int64_t* idx, float* scores, int64_t ld, int rows, int n, float fill, hipStream_t stream) {
+  const int64_t total = (int64_t)rows * n;
+  if (total <= 0) return kOk;
+  hipLaunchKernelGGL(mask_sorted_duplicates_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, idx, scores, ld, rows, n, fill);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 int filter_seen(const int64_t* top_ids, const float* top_scores, int rows, int k_prime, const int64_t* invalid,
                 int width, int k, int64_t* out_ids, float* out_scores, hipStream_t stream) {
   if (rows <= 0) return kOk;

@@ -260,6 +260,55 @@ class MolEngine:
         return out
 
 
+    # ---- per-component candidates (MoLNaiveTopK / MoLCombTopK) -----------------------------------------
+    def build_component_table(self, index: MolIndex) -> torch.Tensor:
+        """(N, P_X, d) bf16 component embeddings (reference mol_top_k.py:61-73)."""
+        nbytes = self.lib.rails_mol_component_table_bytes(C.byref(self.shape), index.n_items)
+        table = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=index.buf.device)
+        with torch.cuda.device(index.buf.device):
+            _lib.check(
+                self.lib.rails_mol_component_build(C.byref(self.shape), _ptr(index.buf), index.n_items, _ptr(table), _stream()),
+                "rails_mol_component_build",
+            )
+        return table.view(index.n_items, self.spec.item_dot_product_groups, self.spec.dot_product_dimension)
+
+    def component_scores(self, eq: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+        """eq (B, P_Q, d) -> (B * P_Q * P_X, N) fp32 holding bf16 values, row (b * P_Q + i) * P_X + m."""
+        B, n = eq.shape[0], table.shape[0]
+        eq = _f32c(eq)
+        rows = B * self.spec.query_dot_product_groups * self.spec.item_dot_product_groups
+        out = torch.empty((rows, n), dtype=torch.float32, device=table.device)
+        with torch.cuda.device(table.device):
+            _lib.check(
+                self.lib.rails_mol_component_score(C.byref(self.shape), _ptr(eq), B, _ptr(table), n, _ptr(out), out.stride(0), _stream()),
+                "rails_mol_component_score",
+            )
+        return out
+
+
+def sort_rows(idx: torch.Tensor) -> torch.Tensor:
+    """Ascending sort of every row of an int64 (rows, n) tensor, n <= 16384 (torch.sort(dim=1) values)."""
+    lib = _lib.load()
+    _require_device(idx, "indices")
+    idx = idx.to(torch.int64).contiguous()
+    out = torch.empty_like(idx)
+    with torch.cuda.device(idx.device):
+        _lib.check(lib.rails_sort_rows_i64(_ptr(idx), idx.shape[0], idx.shape[1], _ptr(out), _stream()), "rails_sort_rows_i64")
+    return out
+
+
+def mask_sorted_duplicates(sorted_idx: torch.Tensor, scores: torch.Tensor, fill: float) -> None:
+    """In place: scores[r, j] = fill wherever sorted_idx[r, j] == sorted_idx[r, j - 1]."""
+    lib = _lib.load()
+    rows, n = sorted_idx.shape
+    assert scores.dtype == torch.float32 and scores.stride(1) == 1
+    with torch.cuda.device(scores.device):
+        _lib.check(
+            lib.rails_mask_sorted_duplicates(_ptr(sorted_idx), _ptr(scores), scores.stride(0), rows, n, C.c_float(fill), _stream()),
+            "rails_mask_sorted_duplicates",
+        )
+
+
 # ---- dot-product (MIPS) scoring ----------------------------------------------------------------
 class MipsIndex:
     """Tile-packed fp32 copy of an (N, D) item table for the MFMA dot-product scan."""

@@ -1,3 +1,4 @@
-from ..topk_modules import MoLAvgTopK, MoLBruteForceTopK, MoLTopKModule  # reference: rails/indexing/mol_top_k.py
+from ..topk_modules import (MoLAvgTopK, MoLBruteForceTopK, MoLCombTopK, MoLNaiveTopK,  # reference: rails/indexing/mol_top_k.py
+                            MoLTopKModule)
 
-__all__ = ["MoLTopKModule", "MoLBruteForceTopK", "MoLAvgTopK"]
+__all__ = ["MoLTopKModule", "MoLBruteForceTopK", "MoLNaiveTopK", "MoLAvgTopK", "MoLCombTopK"]

@@ -125,6 +125,76 @@ class MoLAvgTopK(MoLTopKModule):
         return self._coarse_topk(query_embeddings, average_queries=True, **kwargs)[1]
 
 
+class _ComponentCandidates:
+    """Per-component candidate generation shared by MoLNaiveTopK and MoLCombTopK."""
+
+    def _component_table(self) -> torch.Tensor:
+        eng = self._bind()
+        if getattr(self, "_comp_engine", None) is not eng:
+            self._comp_engine = eng
+            self._comp_table = eng.build_component_table(self._index)
+        return self._comp_table
+
+    def _component_topk(self, eq: torch.Tensor, k_per_group: int) -> torch.Tensor:
+        """-> (B, P_Q * P_X * k_per_group) positions: top k_per_group items of every (query group, item group) pair."""
+        eng = self._bind()
+        scores = eng.component_scores(eq, self._component_table())
+        if k_per_group > scores.shape[1]:
+            raise RuntimeError(f"selected index k out of range (k={k_per_group}, n={scores.shape[1]})")
+        _, pos = E.topk(scores, k_per_group)
+        return pos.view(eq.shape[0], -1)
+
+    def _rerank_union(self, qpack: torch.Tensor, batch: int, all_indices: torch.Tensor, sorted: bool):
+        """sort -> gather -> full MoL -> mask duplicates with -32767.0 -> top-k over ALL candidates
+        (the reference overwrites k with the candidate count, mol_top_k.py:260 / :518)."""
+        eng = self._bind()
+        sorted_idx = E.sort_rows(all_indices)
+        k = sorted_idx.shape[1]
+        cand, kp = eng.gather_index(self._index, sorted_idx)
+        scores = eng.score_candidates(qpack, batch, cand, kp)[:, :k]
+        E.mask_sorted_duplicates(sorted_idx, scores, -32767.0)
+        return E.topk(scores, k, ids=self._ids_flat[sorted_idx], sorted=sorted)
+
+
+class MoLNaiveTopK(MoLTopKModule, _ComponentCandidates):
+    """Reference rails/indexing/mol_top_k.py:133-293 (the FAISS branch is out of scope).  Returns
+    (B, P_Q * P_X * k_per_group) columns whatever `k` is, as the reference does."""
+
+    def __init__(self, mol_module: MoLSimilarity, item_embeddings: torch.Tensor, item_ids: torch.Tensor, k_per_group: int, use_faiss: bool = False) -> None:
+        if use_faiss:
+            raise NotImplementedError("use_faiss=True (FAISS-GPU IVF index) is out of scope")
+        super().__init__(mol_module=mol_module, item_embeddings=item_embeddings, item_ids=item_ids)
+        self._k_per_group: int = k_per_group
+        self._use_faiss: bool = False
+
+    def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        eng = self._bind()
+        qpack, eq, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"), want_plain=True)
+        all_indices = self._component_topk(eq, self._k_per_group)
+        scores, ids = self._rerank_union(qpack, query_embeddings.size(0), all_indices, sorted)
+        return scores.to(query_embeddings.dtype), ids
+
+
+class MoLCombTopK(MoLAvgTopK, _ComponentCandidates):
+    """Reference rails/indexing/mol_top_k.py:432-551: per-component candidates + the averaged-query coarse
+    candidates, reranked together.  Returns (B, P_Q * P_X * k_per_group + avg_top_k) columns."""
+
+    def __init__(self, mol_module: MoLSimilarity, item_embeddings: torch.Tensor, item_ids: torch.Tensor, avg_top_k: int, k_per_group: int) -> None:
+        super().__init__(mol_module=mol_module, item_embeddings=item_embeddings, item_ids=item_ids, avg_top_k=avg_top_k)
+        self._k_per_group: int = k_per_group
+
+    def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        eng = self._bind()
+        qpack, eq, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"), want_plain=True)
+        comp = self._component_topk(eq, self._k_per_group)
+        coarse = eng.coarse_scores(eq, self._table(), average_queries=True)
+        if self._avg_top_k > coarse.shape[1]:
+            raise RuntimeError(f"selected index k out of range (k={self._avg_top_k}, n={coarse.shape[1]})")
+        _, avg_idx = E.topk(coarse, self._avg_top_k)
+        scores, ids = self._rerank_union(qpack, query_embeddings.size(0), torch.cat([comp, avg_idx], dim=1), sorted)
+        return scores.to(query_embeddings.dtype), ids
+
+
 class MIPSTopKModule(TopKModule):
     """Reference rails/indexing/mips_top_k.py:23-38."""
 
@@ -205,15 +275,15 @@ class CandidateIndex(object):
 
 
 _BUILT = {"MoLBruteForceTopK": lambda mol, x, ids: MoLBruteForceTopK(mol_module=mol, item_embeddings=x, item_ids=ids)}
+for _k in (5, 10, 25, 50, 75, 100):
+    _BUILT[f"MoLNaiveTopK{_k}"] = (lambda kk: lambda mol, x, ids: MoLNaiveTopK(mol_module=mol, item_embeddings=x, item_ids=ids, k_per_group=kk))(_k)
+for _kg, _ka in ((1, 100), (1, 500), (5, 100), (5, 200), (5, 500), (10, 100), (10, 500), (50, 500), (50, 1000), (100, 1000)):
+    _BUILT[f"MoLCombTopK{_kg}_{_ka}"] = (lambda g, a: lambda mol, x, ids: MoLCombTopK(mol_module=mol, item_embeddings=x, item_ids=ids, avg_top_k=a, k_per_group=g))(_kg, _ka)
 _NO_MOL = {"MIPSBruteForceTopK": lambda x, ids: MIPSBruteForceTopK(item_embeddings=x, item_ids=ids)}
 for _k in (100, 200, 500, 1000, 2000, 2500, 3000, 4000):
     _BUILT[f"MoLAvgTopK{_k}"] = (lambda kk: lambda mol, x, ids: MoLAvgTopK(mol_module=mol, item_embeddings=x, item_ids=ids, avg_top_k=kk))(_k)
-# names the reference's factory accepts but this build does not implement yet
-_KNOWN_UNBUILT = (
-    ["MoLNaiveFaissTopK5"]
-    + [f"MoLNaiveTopK{k}" for k in (5, 10, 25, 50, 75, 100)]
-    + [f"MoLCombTopK{a}_{b}" for a, b in ((1, 100), (1, 500), (5, 100), (5, 200), (5, 500), (10, 100), (10, 500), (50, 500), (50, 1000), (100, 1000))]
-)
+# accepted by the reference's factory but out of scope here: FAISS-GPU IVF candidate generation
+_KNOWN_UNBUILT = ["MoLNaiveFaissTopK5"]
 
 
 def get_top_k_module(top_k_method: str, model: torch.nn.Module, item_embeddings: torch.Tensor, item_ids: torch.Tensor) -> TopKModule:
@@ -223,5 +293,5 @@ def get_top_k_module(top_k_method: str, model: torch.nn.Module, item_embeddings:
     if top_k_method in _BUILT:
         return _BUILT[top_k_method](model._ndp_module, item_embeddings, item_ids)
     if top_k_method in _KNOWN_UNBUILT:
-        raise NotImplementedError(f"top_k_method {top_k_method} is not built yet in rails_amd")
+        raise NotImplementedError(f"top_k_method {top_k_method} needs faiss-gpu and is out of scope for rails_amd")
     raise ValueError(f"Invalid top-k method {top_k_method}")

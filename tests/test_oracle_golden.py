@@ -136,3 +136,43 @@ def test_f9_mips_and_dot_product():
             assert torch.equal(s, T(f"{tag}/k{k}/scores")) and torch.equal(i, T(f"{tag}/k{k}/ids"))
     assert torch.equal(O.dot_product_similarity(T("rows/q1"), T("rows/X")), T("rows/out1"))
     assert torch.equal(O.dot_product_similarity(T("rows/q3"), T("rows/X")), T("rows/out3"))
+
+
+def _union_case(z, cname):
+    import json
+
+    d = json.loads(str(z[f"{cname}/cfg_json"]))
+    d["uid_embedding_hash_sizes"] = tuple(d["uid_embedding_hash_sizes"])
+    cfg = O.MoLConfig(**d)
+    w = {k[len(cname) + 3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(f"{cname}/w/")}
+    for i, hs in enumerate(cfg.uid_embedding_hash_sizes):
+        key = f"_query_embeddings_fn._uid_embeddings_{i}.weight"
+        rows = w.pop(key + ".rows")
+        full = torch.zeros((hs + 1, cfg.dot_product_dimension))
+        full[rows] = w[key]
+        w[key] = full
+    T = lambda k: torch.from_numpy(z[f"{cname}/{k}"])
+    uid = T("user_ids") if f"{cname}/user_ids" in z.files else None
+    return cfg, w, T, uid
+
+
+@pytest.mark.parametrize("cname", ["c1", "c3"])
+def test_f10_naive_and_comb_rerank(cname):
+    import os
+
+    from tests._fixtures import GOLDEN
+
+    z = np.load(os.path.join(GOLDEN, "union.npz"))
+    cfg, w, T, uid = _union_case(z, cname)
+    for mname, width in (("naive5", cfg.num_logits * 5), ("comb5_100", cfg.num_logits * 5 + 100)):
+        idx = T(f"{mname}/sorted_all_indices")
+        assert idx.shape[1] == width                          # the reference returns ALL candidates, not k
+        s, i = O.union_rerank(cfg, w, T("q"), T("X"), T("item_ids"), idx, uid)
+        assert_topk_matches(s, i, T(f"{mname}/scores"), T(f"{mname}/ids"), atol=2e-6)
+        assert bool((T(f"{mname}/scores")[:, -1] == -32767.0).all())   # duplicates exist and sink to the end
+    # the candidate generator: every index of the naive union is among the per-pair top-5 of the bf16 component scores
+    cs = O.component_candidate_scores(cfg, w, T("q"), T("X"), uid).float()      # (B, P_Q, P_X, N)
+    kth = torch.topk(cs, 5, dim=-1).values[..., -1:]                             # 5th best per (b, i, m)
+    allowed = (cs >= kth).any(1).any(1)                                          # (B, N): item reachable by some pair
+    idx = T("naive5/sorted_all_indices")
+    assert bool(torch.gather(allowed, 1, idx).all())
