@@ -346,3 +346,87 @@ def test_sort_rows_and_duplicate_mask(dev):
     E.mask_sorted_duplicates(out.to(dev), dev_scores, -32767.0)
     valid = torch.cat([torch.ones((7, 1), dtype=torch.bool), out[:, 1:] != out[:, :-1]], 1)
     assert torch.equal(dev_scores.cpu(), torch.where(valid, scores, torch.tensor(-32767.0)))
+
+
+# ---- robustness -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B", [1, 3, 33, 100])
+def test_batch_sizes_cover_padding_and_both_kernels(dev, B):
+    """B = 1, 3: partial query group on the direct kernel; B = 33, 100: >= 8 groups -> staged kernel with the group
+    loop wrapping (g += 8) and a padded last group."""
+    cfg = O.CONFIGS["amzn-books"]
+    w = O.synthetic_weights(cfg, seed=5)
+    mol = build_module(cfg, w, dev)
+    N = 2000 + B
+    X = torch.from_numpy(O.hash_item_table(3, 0, N, cfg.item_embedding_dim)).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B, seed=B)
+    with torch.inference_mode():
+        got, _ = mol(q.to(dev), X.to(dev))
+    ref = O.mol_logits(cfg, w, q, X)
+    assert got.shape == (B, N)
+    assert float((got.cpu() - ref).abs().max()) <= LOGIT_TOL
+
+
+def test_bf16_module_and_inputs_round_trip(dev):
+    """eval_batch.py runs --eval_dtype=bf16 (model and item table cast to bf16): parameters and inputs are
+    up-cast, arithmetic stays fp32, outputs come back in the query dtype."""
+    fx = Fixture("c3_books")
+    mol = build_module(fx.cfg, fx.weights, dev).to(torch.bfloat16)
+    q, X, ids = fx.t("q").to(dev).bfloat16(), fx.t("X").to(dev).bfloat16(), fx.t("item_ids").to(dev)
+    with torch.inference_mode():
+        tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
+        s, i = tk(q, k=20)
+        logits = tk.all_logits(q)
+    assert s.dtype == torch.bfloat16 and i.dtype == torch.int64 and logits.dtype == torch.float32
+    w16 = {k: v.bfloat16().float() for k, v in fx.weights.items()}
+    ref = O.mol_logits(fx.cfg, w16, q.float().cpu(), X.float().cpu())
+    assert float((logits.cpu() - ref).abs().max()) <= LOGIT_TOL
+
+
+def test_index_follows_parameter_updates(dev):
+    fx = Fixture("c3_books")
+    mol = build_module(fx.cfg, fx.weights, dev)
+    q, X, ids = fx.t("q").to(dev), fx.t("X").to(dev), fx.t("item_ids").to(dev)
+    with torch.inference_mode():
+        tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
+        before = tk.all_logits(q).clone()
+    w2 = {k: v.clone() for k, v in fx.weights.items()}
+    w2["_item_embeddings_fn._item_emb_proj_module.1.weight"] *= 0.5
+    w2["_gating_fn._qi_partial_module.3.bias"] += 0.25
+    mol.load_state_dict(w2)                       # in-place update, as train-time eval does between epochs
+    with torch.inference_mode():
+        after = tk.all_logits(q)
+    ref = O.mol_logits(fx.cfg, w2, fx.t("q"), fx.t("X"))
+    assert float((after.cpu() - ref).abs().max()) <= LOGIT_TOL
+    assert float((after - before).abs().max()) > 1e-3
+
+
+def test_multi_million_item_corpus(dev):
+    """3 M items (3.8 GB index): 64-bit addressing of tiles / logits, radix top-k over a long row."""
+    cfg = O.CONFIGS["amzn-books"]
+    w = O.synthetic_weights(cfg, seed=6)
+    mol = build_module(cfg, w, dev)
+    N, B, k = 3_000_001, 4, 500
+    X = torch.cat([torch.from_numpy(O.hash_item_table(8, s, min(500_000, N - s), cfg.item_embedding_dim)) for s in range(0, N, 500_000)])
+    q = O.synthetic_queries(cfg, B, seed=11)
+    with torch.inference_mode():
+        tk = rails_amd.MoLBruteForceTopK(mol, X.unsqueeze(0).to(dev), torch.arange(N, dtype=torch.int64).unsqueeze(0).to(dev))
+        logits = tk.all_logits(q.to(dev))
+        s, i = tk(q.to(dev), k=k)
+    cols = torch.tensor([0, 1, 31, 32, 1_048_575, 1_048_576, 2_147_483 , N - 2, N - 1])
+    g = torch.Generator().manual_seed(2)
+    cols = torch.cat([cols, torch.randint(0, N, (2048,), generator=g)])
+    ref = O.mol_logits(cfg, w, q, X[cols].unsqueeze(0))
+    assert float((logits[:, cols.to(dev)].cpu() - ref).abs().max()) <= LOGIT_TOL
+    rs, ri = O.select_topk_deterministic(logits.cpu(), k)
+    assert torch.equal(s.cpu(), rs) and torch.equal(i.cpu(), ri)
+
+
+def test_degenerate_sizes(dev):
+    fx = Fixture("c3_books")
+    mol = build_module(fx.cfg, fx.weights, dev)
+    X, ids = fx.t("X")[:, :1].to(dev), fx.t("item_ids")[:, :1].to(dev)     # a corpus of one item
+    with torch.inference_mode():
+        tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
+        s, i = tk(fx.t("q")[:1].to(dev), k=1)
+    ref = O.mol_logits(fx.cfg, fx.weights, fx.t("q")[:1], fx.t("X")[:, :1])
+    assert abs(float(s) - float(ref)) <= LOGIT_TOL and int(i) == int(fx.t("item_ids")[0, 0])
