@@ -116,12 +116,30 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # RAILS_BENCH_TEST_BACKEND=gloo is a TEST hook: several ranks share GPU 0 and the (tiny) all-gather message is
+    # staged through the host, so the sharded code path can be exercised on a one-GPU box.  Never set by the driver.
+    test_backend = os.environ.get("RAILS_BENCH_TEST_BACKEND")
+    if test_backend:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if test_backend:
+            dist.init_process_group(test_backend)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def all_gather_rows(msg):
+        """(B, W) -> (world * B, W), rank-major.  RCCL over xGMI; host-staged only under the test hook."""
+        if test_backend:
+            buf = torch.empty((world * msg.shape[0], msg.shape[1]), dtype=msg.dtype)
+            dist.all_gather_into_tensor(buf, msg.cpu())
+            return buf.to(dev)
+        buf = torch.empty((world * msg.shape[0], msg.shape[1]), dtype=msg.dtype, device=dev)
+        dist.all_gather_into_tensor(buf, msg)
+        return buf
 
     cfg_key, N, width = WORKLOADS[args.workload]
     cfg = O.CONFIGS[cfg_key]
@@ -179,11 +197,9 @@ def main() -> None:
             s, top = E.topk(logits, k_local, ids=local._ids_flat)
             if world > 1:
                 from rails_amd.sharded import pack_candidates, unpack_candidates
-                import torch.distributed as dist
 
                 msg = pack_candidates(s, top, kp)
-                gathered = torch.empty((world * msg.shape[0], msg.shape[1]), dtype=msg.dtype, device=dev)
-                dist.all_gather_into_tensor(gathered, msg)
+                gathered = all_gather_rows(msg)
                 all_s, all_i = unpack_candidates(gathered.view(world, msg.shape[0], msg.shape[1]), kp)
                 s, top = E.topk(all_s, kp, ids=all_i)
             return E.filter_seen_ids(top, s, inv, k)
@@ -209,7 +225,7 @@ def main() -> None:
         elapsed = time.perf_counter() - t0
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if test_backend else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     score_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps

@@ -90,8 +90,13 @@ class ShardedMoLBruteForceTopK(TopKModule):
             return s, ids
         msg = pack_candidates(s.float(), ids, k)
         # concatenated-along-dim-0 output: the layout both RCCL and gloo accept for all_gather_into_tensor
-        gathered = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype, device=msg.device)
-        dist.all_gather_into_tensor(gathered, msg, group=self._group)
+        if msg.is_cuda and dist.get_backend(self._group) == "gloo":   # test setups only: stage through the host
+            host = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype)
+            dist.all_gather_into_tensor(host, msg.cpu(), group=self._group)
+            gathered = host.to(msg.device)
+        else:
+            gathered = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype, device=msg.device)
+            dist.all_gather_into_tensor(gathered, msg, group=self._group)
         all_s, all_ids = unpack_candidates(gathered.view(self._world, msg.shape[0], msg.shape[1]), k)
         ms, mi = self._merge(all_s, all_ids, k)
         return ms.to(s.dtype), mi
