@@ -85,14 +85,14 @@ def cpu_baseline(cfg, weights, q, user_ids, n_total: int, sample_items: int, k_p
             best = (dt, threads)
     torch.set_num_threads(best[1])
     run(2048, 2048)
-    dt = run(sample_items, 4096)
+    dt = min(run(sample_items, 4096), run(sample_items, 4096))  # best of two passes: shared hosts are noisy
     qps = B / (dt * (n_total / sample_items))
     return {
         "value": qps,
         "unit": "queries/s",
         "cores": torch.get_num_threads(),
         "kind": "port",
-        "sample": f"B={B} queries x first {sample_items} of {n_total} items, 1 timed pass ({dt:.1f} s) at the best of 8..{ncpu} threads, scaled linearly in N",
+        "sample": f"B={B} queries x first {sample_items} of {n_total} items, best of 2 timed passes ({dt:.1f} s) at the best of 8..{ncpu} threads, scaled linearly in N",
     }
 
 
