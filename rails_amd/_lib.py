@@ -66,6 +66,10 @@ class MolWeights(C.Structure):
     ]
 
 
+class MolSplitScales(C.Structure):
+    _fields_ = [("cl_scale", C.c_float), ("w1_scale", C.c_float), ("w2_scale", C.c_float)]
+
+
 # name -> (restype, argtypes): one entry per declaration in include/rails_amd.h
 _SHAPE_P = C.POINTER(MolShape)
 _WEIGHTS_P = C.POINTER(MolWeights)
@@ -94,6 +98,15 @@ PROTOTYPES = {
     "rails_mol_score_candidates": (
         C.c_int,
         [_SHAPE_P, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p],
+    ),
+    "rails_mol_pack_gate_weights_split": (C.c_int, [_SHAPE_P, _WEIGHTS_P, C.POINTER(MolSplitScales), C.c_void_p, C.c_void_p]),
+    "rails_mol_score_dense_split": (
+        C.c_int,
+        [_SHAPE_P, C.c_void_p, C.POINTER(MolSplitScales), C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p],
+    ),
+    "rails_mol_score_candidates_split": (
+        C.c_int,
+        [_SHAPE_P, C.c_void_p, C.POINTER(MolSplitScales), C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p],
     ),
     "rails_mips_index_floats": (C.c_size_t, [C.c_int32, C.c_int64]),
     "rails_mips_index_build": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),

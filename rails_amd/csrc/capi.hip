@@ -167,7 +167,7 @@ int rails_mol_query_prologue(const rails_mol_shape* s, const rails_mol_weights* 
 
 static int score_common(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch,
                         const float* index, int64_t n_items, float* logits, int64_t ld, int per_row, void* stream,
-                        const char* what) {
+                        const char* what, const rails_mol_split_scales* split = nullptr) {
   g_err[0] = '\0';
   if (!shape_supported(s)) return RAILS_ENOTSUP;
   if (batch < 0 || n_items < 0) { set_error("%s: negative size", what); return RAILS_EINVAL; }
@@ -192,6 +192,17 @@ static int score_common(const rails_mol_shape* s, const float* gate_pack, const 
   a.per_row = per_row;
   a.temperature = s->temperature;
   a.rcp_temperature = 1.0f / s->temperature;
+  a.split = split ? 1 : 0;
+  a.cl_scale = a.inv_c = a.c2 = a.inv_c2 = a.inv_cl_scale = 1.0f;
+  if (split) {
+    if (!(split->cl_scale > 0.0f && split->w1_scale > 0.0f && split->w2_scale > 0.0f)) { set_error("%s: scales must be > 0", what); return RAILS_EINVAL; }
+    const float c = split->cl_scale * split->w1_scale;
+    a.cl_scale = split->cl_scale;
+    a.inv_cl_scale = 1.0f / split->cl_scale;
+    a.inv_c = 1.0f / c;
+    a.c2 = c * split->w2_scale;
+    a.inv_c2 = 1.0f / a.c2;
+  }
   const int r = score_launch(*s, a, cu, (hipStream_t)stream);
   return r == kOk ? r : fail(r, what);
 }
@@ -204,6 +215,32 @@ int rails_mol_score_dense(const rails_mol_shape* s, const float* gate_pack, cons
 int rails_mol_score_candidates(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch,
                                const float* cand_index, int64_t n_cand, float* logits, int64_t ld, void* stream) {
   return score_common(s, gate_pack, query_pack, batch, cand_index, n_cand, logits, ld, 1, stream, "score_candidates");
+}
+
+int rails_mol_pack_gate_weights_split(const rails_mol_shape* s, const rails_mol_weights* w,
+                                      const rails_mol_split_scales* scales, float* gate_pack, void* stream) {
+  g_err[0] = '\0';
+  if (!shape_supported(s)) return RAILS_ENOTSUP;
+  if (!w || !scales || !gate_pack || !w->gqi_w1 || !w->gqi_b1 || !w->gqi_w2 || !w->gqi_b2) {
+    set_error("pack_gate_weights_split: NULL pointer");
+    return RAILS_EINVAL;
+  }
+  const SplitScales sc = {scales->cl_scale, scales->w1_scale, scales->w2_scale};
+  return fail(pack_gate_weights_split(*s, *w, sc, gate_pack, (hipStream_t)stream), "pack_gate_weights_split");
+}
+
+int rails_mol_score_dense_split(const rails_mol_shape* s, const float* gate_pack, const rails_mol_split_scales* scales,
+                                const float* query_pack, int32_t batch, const float* index, int64_t n_items, float* logits,
+                                int64_t ld, void* stream) {
+  if (!scales) { set_error("score_dense_split: NULL scales"); return RAILS_EINVAL; }
+  return score_common(s, gate_pack, query_pack, batch, index, n_items, logits, ld, 0, stream, "score_dense_split", scales);
+}
+
+int rails_mol_score_candidates_split(const rails_mol_shape* s, const float* gate_pack, const rails_mol_split_scales* scales,
+                                     const float* query_pack, int32_t batch, const float* cand_index, int64_t n_cand,
+                                     float* logits, int64_t ld, void* stream) {
+  if (!scales) { set_error("score_candidates_split: NULL scales"); return RAILS_EINVAL; }
+  return score_common(s, gate_pack, query_pack, batch, cand_index, n_cand, logits, ld, 1, stream, "score_candidates_split", scales);
 }
 
 size_t rails_mips_index_floats(int32_t dim, int64_t n_items) {

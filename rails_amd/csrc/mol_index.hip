@@ -53,6 +53,63 @@ int pack_gate_weights(const Shape& s, const Weights& w, float* wpack, hipStream_
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
+// ---- pair-gate weights -> f16 hi/lo fragments for the f16x3 precision mode (mol_layout.h) -------------------
+__device__ __forceinline__ void split_f16(float x, unsigned short& hi, unsigned short& lo) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 h = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(x, 0.0f));   // round toward zero
+  const _Float16 l = (_Float16)(x - (float)h.x);                              // remainder is exact in fp32; RNE to f16
+  hi = __builtin_bit_cast(unsigned short, h.x);
+  lo = __builtin_bit_cast(unsigned short, l);
+}
+
+__global__ void pack_gate_split_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
+                                       const float* __restrict__ w2, const float* __restrict__ b2,
+                                       float* __restrict__ out, int PQ, int PX, int H, float s_w1, float s_w2, float c,
+                                       float c2) {
+  const int L = PQ * PX, TH = H / 32, TL = L / 32, E = L / 2;
+  unsigned short* w1hi = reinterpret_cast<unsigned short*>(out);
+  unsigned short* w1lo = w1hi + H * L;
+  unsigned short* w2hi = w1lo + H * L;
+  unsigned short* w2lo = w2hi + H * L;
+  float* b1f = out + 2 * H * L;
+  float* b2f = b1f + H;
+  const int total = 2 * H * L + H + L;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    if (i < H * L) {  // W1 fragment [s][t][lane][jj]: row 32t + (lane&31), logit logit_of(8s + jj, lane>>5)
+      const int jj = i & 7, lane = (i >> 3) & 63, blk = i >> 9;
+      const int t = blk % TH, ks = blk / TH;
+      const float v = s_w1 * (-kLog2e * w1[(32 * t + (lane & 31)) * L + logit_of(8 * ks + jj, lane >> 5, PQ, PX)]);
+      split_f16(v, w1hi[i], w1lo[i]);
+    } else if (i < 2 * H * L) {  // W2 fragment [s][v][lane][jj]: row lrow(v, lane&31), hidden hidden_of(8s + jj, lane>>5)
+      const int k = i - H * L;
+      const int jj = k & 7, lane = (k >> 3) & 63, blk = k >> 9;
+      const int tv = blk % TL, ks = blk / TL;
+      const int row = lane & 31;
+      const int l = logit_of(16 * tv + reg_of_row(row), half_of_row(row), PQ, PX);
+      const float v = s_w2 * w2[l * H + hidden_of(8 * ks + jj, lane >> 5)];
+      split_f16(v, w2hi[k], w2lo[k]);
+    } else if (i < 2 * H * L + H) {  // b1frag[t][hi][r], carries c * (-log2e)
+      const int k = i - 2 * H * L;
+      const int r = k & 15, hi = (k >> 4) & 1, t = k >> 5;
+      b1f[k] = c * (-kLog2e * b1[32 * t + acc_row(r, hi)]);
+    } else {  // b2frag[hi][e], carries c2 * (-log2e)
+      const int k = i - 2 * H * L - H;
+      const int hi = k / E, e = k % E;
+      b2f[k] = c2 * (-kLog2e * b2[logit_of(e, hi, PQ, PX)]);
+    }
+  }
+}
+
+int pack_gate_weights_split(const Shape& s, const Weights& w, const SplitScales& sc, float* wpack, hipStream_t stream) {
+  const int H = s.gating_qi_hidden_dim, L = num_logits(s);
+  const int total = 2 * H * L + H + L;
+  const float c = sc.cl_scale * sc.w1_scale;
+  hipLaunchKernelGGL(pack_gate_split_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w.gqi_w1, w.gqi_b1,
+                     w.gqi_w2, w.gqi_b2, wpack, s.query_dot_product_groups, s.item_dot_product_groups, H, sc.w1_scale,
+                     sc.w2_scale, c, c * sc.w2_scale);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 // ---- index build -------------------------------------------------------------------------------
 // One workgroup per tile of 32 items.  Every dense layer is done "column per thread": thread c keeps
 // 32 accumulators (one per item) and walks k in order, reading X / hidden values as LDS broadcasts.

@@ -37,7 +37,17 @@ struct ScoreArgs {
   int per_row;          // 1: tile t of row b lives at ipack tile (b * n_tiles + t)
   float temperature;
   float rcp_temperature;
+  // split-f16 gate MLP (precision mode "f16x3", mol_layout.h): power-of-two operand scales; 0 -> exact fp32 kernels
+  int split;
+  float cl_scale;       // s_a: GEMM1 output is s_a * cl
+  float inv_c;          // 1 / (s_a * s_w1): D2 holds c * t
+  float c2;             // s_a * s_w1 * s_w2: D3 holds c2 * gqi'
+  float inv_c2;
+  float inv_cl_scale;
 };
+
+struct SplitScales { float cl_scale, w1_scale, w2_scale; };
+int pack_gate_weights_split(const Shape& s, const Weights& w, const SplitScales& sc, float* wpack, hipStream_t stream);
 
 void set_error(const char* fmt, ...);
 

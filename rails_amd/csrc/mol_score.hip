@@ -51,14 +51,16 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 // GEMM1: D1[m][(qj,p), x] = sum_d Eq[qj,p,d] * Ex[x,m,d].  `eq` is the query group's A operand in fragment
 // order ([sc][lane] float4), `tEx` the tile's B operand ([m][sc][lane] float4) -- in HBM or in LDS.
 template <class G, int PX, int DD>
-__device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float4* __restrict__ eq, const float4* tEx, int lane) {
+__device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float4* __restrict__ eq, const float4* tEx, int lane,
+                                      float a_scale = 1.0f) {
 #pragma unroll
   for (int m = 0; m < PX; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) D1[m][r] = 0.0f;
 #pragma unroll
   for (int sc = 0; sc < DD / 8; ++sc) {
-    const float4 a = eq[sc * 64 + lane];
+    float4 a = eq[sc * 64 + lane];
+    a.x *= a_scale; a.y *= a_scale; a.z *= a_scale; a.w *= a_scale;  // 1 (fp32 mode) or the power-of-two s_a (f16x3)
 #pragma unroll
     for (int m = 0; m < PX; ++m) {
       const float4 b = tEx[(m * (DD / 8) + sc) * 64 + lane];
@@ -170,19 +172,144 @@ __device__ __forceinline__ float query_mlp(f32x16 (&D1)[PX], const float4* sW1, 
   return (num * rden) / fmaxf(den * rden, 1e-6f);
 }
 
+// ---- precision mode "f16x3": the gate GEMMs on f16 MFMA with hi/lo-split operands (mol_layout.h) ---------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+
+// two fp32 values -> packed f16 hi (round toward zero) and packed f16 lo (the exact fp32 remainder, RTZ to f16)
+__device__ __forceinline__ void split_pair(float x0, float x1, h2v& hi, h2v& lo) {
+  hi = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+  lo = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(x0 - (float)hi.x, x1 - (float)hi.y));
+}
+
+template <class G, int PX, int R0>
+__device__ __forceinline__ float query_mlp_split(f32x16 (&D1)[PX], const float* smem, const float4* tGi,
+                                                 const float4* __restrict__ gq4, int lane, int hi, const ScoreArgs& p) {
+  constexpr int HL8 = G::kW1Floats / 8;  // h8 fragments per weight matrix half
+  const h8* sW1hi = reinterpret_cast<const h8*>(smem);
+  const h8* sW1lo = sW1hi + HL8;
+  const h8* sW2hi = sW1lo + HL8;
+  const h8* sW2lo = sW2hi + HL8;
+  const float* sB1 = smem + G::kW1Floats + G::kW2Floats;
+  const float* sB2 = sB1 + G::TH * 32;
+
+  // GEMM2: D2 = c * t,  t = -log2e * (b1 + W1 cl);  K-step ks covers cl registers e in [8 ks, 8 ks + 8)
+  f32x16 D2[G::TH];
+#pragma unroll
+  for (int t = 0; t < G::TH; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) D2[t][r] = sB1[t * 32 + hi * 16 + r];
+#pragma unroll
+  for (int ks = 0; ks < G::E / 8; ++ks) {
+    h8 bh, bl;
+#pragma unroll
+    for (int jj = 0; jj < 8; jj += 2) {
+      const int e = ks * 8 + jj;
+      h2v ph, pl;
+      split_pair(D1[e / G::RPQ][R0 + e % G::RPQ], D1[(e + 1) / G::RPQ][R0 + (e + 1) % G::RPQ], ph, pl);
+      bh[jj] = ph.x; bh[jj + 1] = ph.y; bl[jj] = pl.x; bl[jj + 1] = pl.y;
+    }
+#pragma unroll
+    for (int t = 0; t < G::TH; ++t) {
+      const h8 ah = sW1hi[(ks * G::TH + t) * 64 + lane];
+      const h8 al = sW1lo[(ks * G::TH + t) * 64 + lane];
+      D2[t] = mfma16(al, bh, D2[t]);
+      D2[t] = mfma16(ah, bl, D2[t]);
+      D2[t] = mfma16(ah, bh, D2[t]);
+    }
+  }
+  // hid'' = D2 * rcp(1 + exp2(D2 / c)) = c * hid'
+  const f32x2 inv_c = {p.inv_c, p.inv_c};
+#pragma unroll
+  for (int t = 0; t < G::TH; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const f32x2 tv = {D2[t][r], D2[t][r + 1]};
+      const f32x2 h = tv * pk_sigmoid_arg(tv * inv_c);
+      D2[t][r] = h.x;
+      D2[t][r + 1] = h.y;
+    }
+
+  // GEMM3: D3 = c2 * gqi';  K-step ks covers hidden registers f in [8 ks, 8 ks + 8)
+  f32x16 D3[G::TL];
+#pragma unroll
+  for (int v = 0; v < G::TL; ++v)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) D3[v][r] = sB2[hi * G::E + v * 16 + r];
+#pragma unroll
+  for (int ks = 0; ks < G::F / 8; ++ks) {
+    h8 bh, bl;
+#pragma unroll
+    for (int jj = 0; jj < 8; jj += 2) {
+      const int f = ks * 8 + jj;
+      h2v ph, pl;
+      split_pair(D2[f / 16][f % 16], D2[f / 16][f % 16 + 1], ph, pl);
+      bh[jj] = ph.x; bh[jj + 1] = ph.y; bl[jj] = pl.x; bl[jj + 1] = pl.y;
+    }
+#pragma unroll
+    for (int v = 0; v < G::TL; ++v) {
+      const h8 ah = sW2hi[(ks * G::TL + v) * 64 + lane];
+      const h8 al = sW2lo[(ks * G::TL + v) * 64 + lane];
+      D3[v] = mfma16(al, bh, D3[v]);
+      D3[v] = mfma16(ah, bl, D3[v]);
+      D3[v] = mfma16(ah, bh, D3[v]);
+    }
+  }
+
+  // epilogue: T2 = c2 * t2 = fma(c2 * gq', gi, D3);  u = t2 / (1 + 2^t2)
+  const f32x2 c2 = {p.c2, p.c2}, inv_c2 = {p.inv_c2, p.inv_c2};
+  float mn = INFINITY;
+#pragma unroll
+  for (int ec = 0; ec < G::E / 4; ++ec) {
+    const float4 gi = tGi[ec * 64 + lane];
+    const float4 gq = gq4[ec];
+    const f32x2 giv[2] = {{gi.x, gi.y}, {gi.z, gi.w}};
+    const f32x2 gqv[2] = {{gq.x, gq.y}, {gq.z, gq.w}};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int e = ec * 4 + 2 * j;
+      const f32x2 t2 = pk_fma(gqv[j] * c2, giv[j], f32x2{D3[e / 16][e % 16], D3[e / 16][e % 16 + 1]}) * inv_c2;
+      const f32x2 u = t2 * pk_sigmoid_arg(t2);
+      D3[e / 16][e % 16] = u.x;
+      D3[e / 16][e % 16 + 1] = u.y;
+      mn = fminf(mn, fminf(u.x, u.y));
+    }
+  }
+  mn = fminf(mn, xor32(mn));
+  f32x2 den2 = {0.0f, 0.0f}, num2 = {0.0f, 0.0f};
+#pragma unroll
+  for (int e = 0; e < G::E; e += 2) {
+    const f32x2 d = mn - f32x2{D3[e / 16][e % 16], D3[e / 16][e % 16 + 1]};
+    const f32x2 ex = {__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};
+    den2 = den2 + ex;
+    num2 = pk_fma(ex, f32x2{D1[e / G::RPQ][R0 + e % G::RPQ], D1[e / G::RPQ][R0 + e % G::RPQ + 1]}, num2);
+  }
+  float den = den2.x + den2.y, num = num2.x + num2.y;
+  den += xor32(den);
+  num += xor32(num);
+  const float rden = __builtin_amdgcn_rcpf(den);
+  return (num * rden * p.inv_cl_scale) / fmaxf(den * rden, 1e-6f);   // D1 holds s_a * cl
+}
+
 // All queries of one unit, each at its own static register offset (no register rotation).
 // `only` >= 0 restricts the unit to that query (per-row candidates).
-template <class G, int PX>
+template <class G, int PX, bool SPLIT>
 __device__ __forceinline__ void unit_queries(f32x16 (&D1)[PX], const ScoreArgs& p, int g, int only, int64_t item0,
-                                             const float4* sW1, const float4* sW2, const float* sB1, const float* sB2,
-                                             const float4* tGi, int lane, int hi, int x) {
+                                             const float* smem, const float4* sW1, const float4* sW2, const float* sB1,
+                                             const float* sB2, const float4* tGi, int lane, int hi, int x) {
   [&]<int... Q>(std::integer_sequence<int, Q...>) {
     (
         [&] {
           const int q = g * G::QT + Q;
           if (q < p.B && (only < 0 || q == only)) {
             const float4* gq4 = reinterpret_cast<const float4*>(p.gqfrag + (int64_t)q * G::L + hi * G::E);
-            const float out = query_mlp<G, PX, Q * G::RPQ>(D1, sW1, sW2, sB1, sB2, tGi, gq4, lane, hi);
+            float out;
+            if constexpr (SPLIT) out = query_mlp_split<G, PX, Q * G::RPQ>(D1, smem, tGi, gq4, lane, hi, p);
+            else out = query_mlp<G, PX, Q * G::RPQ>(D1, sW1, sW2, sB1, sB2, tGi, gq4, lane, hi);
             const int64_t item = item0 + x;
             if (hi == 0 && item < p.n_items) p.logits[(int64_t)q * p.ld + item] = out;
           }
@@ -203,7 +330,7 @@ __device__ __forceinline__ void stage_weights(const ScoreArgs& p, float* smem) {
 // Used when fewer than 8 query groups exist (B < 8 * 32/P_Q), for per-row candidates, and for shapes whose
 // tile does not fit LDS twice.  unit = (tile, query group), groups fastest.
 // ---------------------------------------------------------------------------------------------
-template <int PQ, int PX, int DD, int H, int NW>
+template <int PQ, int PX, int DD, int H, int NW, bool SPLIT>
 __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(ScoreArgs p) {
   using G = Geo<PQ, PX, DD, H>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -231,8 +358,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(Score
     const float4* tGi = tEx + G::kTileExFloats / 4;
     const float4* eq = reinterpret_cast<const float4*>(p.eqfrag + (int64_t)g * G::kEqGroupFloats);
     f32x16 D1[PX];
-    gemm1<G, PX, DD>(D1, eq, tEx, lane);
-    unit_queries<G, PX>(D1, p, g, row, tile * kTileItems, sW1, sW2, sB1, sB2, tGi, lane, hi, x);
+    gemm1<G, PX, DD>(D1, eq, tEx, lane, SPLIT ? p.cl_scale : 1.0f);
+    unit_queries<G, PX, SPLIT>(D1, p, g, row, tile * kTileItems, smem, sW1, sW2, sB1, sB2, tGi, lane, hi, x);
   }
 }
 
@@ -253,7 +380,7 @@ __device__ __forceinline__ void dma_tile(const float* __restrict__ src_tile, flo
   }
 }
 
-template <int PQ, int PX, int DD, int H, int NW>
+template <int PQ, int PX, int DD, int H, int NW, bool SPLIT>
 __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(ScoreArgs p) {
   using G = Geo<PQ, PX, DD, H>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -281,8 +408,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(Score
     for (int g = wave; g < p.n_groups; g += NW) {
       const float4* eq = reinterpret_cast<const float4*>(p.eqfrag + (int64_t)g * G::kEqGroupFloats);
       f32x16 D1[PX];
-      gemm1<G, PX, DD>(D1, eq, tEx, lane);
-      unit_queries<G, PX>(D1, p, g, -1, tile * kTileItems, sW1, sW2, sB1, sB2, tGi, lane, hi, x);
+      gemm1<G, PX, DD>(D1, eq, tEx, lane, SPLIT ? p.cl_scale : 1.0f);
+      unit_queries<G, PX, SPLIT>(D1, p, g, -1, tile * kTileItems, smem, sW1, sW2, sB1, sB2, tGi, lane, hi, x);
     }
   }
 }
@@ -589,7 +716,7 @@ static int score_variant() {
   return e ? atoi(e) : 0;
 }
 
-template <int PQ, int PX, int DD, int H, int NW, bool STAGED>
+template <int PQ, int PX, int DD, int H, int NW, bool STAGED, bool SPLIT>
 static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using G = Geo<PQ, PX, DD, H>;
   constexpr size_t lds = ((size_t)G::kWpackFloats + (STAGED ? 2 * (size_t)G::kTileFloats : 0)) * sizeof(float);
@@ -597,8 +724,8 @@ static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
     set_error("staged scoring kernel needs %zu B of LDS", lds);
     return kErrUnsupported;
   } else {
-    const void* fn = STAGED ? reinterpret_cast<const void*>(&mol_score_staged_kernel<PQ, PX, DD, H, NW>)
-                            : reinterpret_cast<const void*>(&mol_score_direct_kernel<PQ, PX, DD, H, NW>);
+    const void* fn = STAGED ? reinterpret_cast<const void*>(&mol_score_staged_kernel<PQ, PX, DD, H, NW, SPLIT>)
+                            : reinterpret_cast<const void*>(&mol_score_direct_kernel<PQ, PX, DD, H, NW, SPLIT>);
     static bool attr_set = false;
     if (!attr_set) {
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return kErrLaunch;
@@ -615,9 +742,9 @@ static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
     if (grid > (int64_t)n_cu * wg_per_cu) grid = (int64_t)n_cu * wg_per_cu;
     if (grid < 1) return kOk;
     if (STAGED)
-      hipLaunchKernelGGL((mol_score_staged_kernel<PQ, PX, DD, H, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
+      hipLaunchKernelGGL((mol_score_staged_kernel<PQ, PX, DD, H, NW, SPLIT>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
     else
-      hipLaunchKernelGGL((mol_score_direct_kernel<PQ, PX, DD, H, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
+      hipLaunchKernelGGL((mol_score_direct_kernel<PQ, PX, DD, H, NW, SPLIT>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
     return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
   }
 }
@@ -629,11 +756,18 @@ static int launch_score(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   int variant = score_variant();
   if (variant == 0) variant = (staged_fits && !a.per_row && a.n_groups >= kScoreWaves) ? 2 : 1;
   if ((variant == 2 || variant == 4) && a.per_row) { set_error("staged scoring kernel does not do per-row candidates"); return kErrUnsupported; }
+  if (a.split) {
+    switch (variant) {
+      case 1: return launch_kernel<PQ, PX, DD, H, 8, false, true>(a, n_cu, stream);
+      case 2: return launch_kernel<PQ, PX, DD, H, 8, true, true>(a, n_cu, stream);
+      default: set_error("RAILS_SCORE_VARIANT %d has no f16x3 build", variant); return kErrInvalid;
+    }
+  }
   switch (variant) {
-    case 1: return launch_kernel<PQ, PX, DD, H, 8, false>(a, n_cu, stream);
-    case 2: return launch_kernel<PQ, PX, DD, H, 8, true>(a, n_cu, stream);
-    case 3: return launch_kernel<PQ, PX, DD, H, 4, false>(a, n_cu, stream);
-    case 4: return launch_kernel<PQ, PX, DD, H, 4, true>(a, n_cu, stream);
+    case 1: return launch_kernel<PQ, PX, DD, H, 8, false, false>(a, n_cu, stream);
+    case 2: return launch_kernel<PQ, PX, DD, H, 8, true, false>(a, n_cu, stream);
+    case 3: return launch_kernel<PQ, PX, DD, H, 4, false, false>(a, n_cu, stream);
+    case 4: return launch_kernel<PQ, PX, DD, H, 4, true, false>(a, n_cu, stream);
     default: set_error("unknown RAILS_SCORE_VARIANT %d", variant); return kErrInvalid;
   }
 }
@@ -654,8 +788,10 @@ int score_launch(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t strea
   MOL_CASE(8, 4, 128)
   MOL_CASE(8, 8, 32)
 #undef MOL_CASE
-  if (s.query_dot_product_groups == 16 && s.item_dot_product_groups == 16 && s.dot_product_dimension == 64)
+  if (s.query_dot_product_groups == 16 && s.item_dot_product_groups == 16 && s.dot_product_dimension == 64) {
+    if (a.split) { set_error("the f16x3 precision mode is not built for 16x16x64"); return kErrUnsupported; }
     return launch_ksplit<16, 16, 64, 128, 4>(a, n_cu, stream);
+  }
   return kErrUnsupported;
 }
 

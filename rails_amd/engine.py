@@ -7,6 +7,8 @@ from __future__ import annotations
 
 import ctypes as C
 import dataclasses
+import math
+import os
 from typing import Dict, Optional, Sequence, Tuple
 
 import torch
@@ -14,6 +16,15 @@ import torch
 from . import _lib
 
 TILE_ITEMS = 32
+PRECISIONS = ("fp32", "f16x3")
+
+
+def default_precision() -> str:
+    """"fp32" (exact fp32 MFMA, the parity path) unless RAILS_PRECISION selects the opt-in "f16x3" mode."""
+    p = os.environ.get("RAILS_PRECISION", "fp32")
+    if p not in PRECISIONS:
+        raise ValueError(f"RAILS_PRECISION must be one of {PRECISIONS}, got {p!r}")
+    return p
 
 
 @dataclasses.dataclass(frozen=True)
@@ -108,9 +119,12 @@ class MolIndex:
 class MolEngine:
     """One MoL module's weights bound to the HIP kernels."""
 
-    def __init__(self, spec: MolShapeSpec, weights: Dict[str, torch.Tensor]):
+    def __init__(self, spec: MolShapeSpec, weights: Dict[str, torch.Tensor], precision: Optional[str] = None):
         self.lib = _lib.load()
         self.spec = spec
+        self.precision = precision or default_precision()
+        if self.precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {PRECISIONS}, got {self.precision!r}")
         self.shape = spec.to_c()
         if not self.lib.rails_mol_shape_supported(C.byref(self.shape)):
             raise NotImplementedError(_lib.last_error())
@@ -137,11 +151,41 @@ class MolEngine:
         self.device = self._keep[0].device
         n = self.lib.rails_mol_gate_pack_floats(C.byref(self.shape))
         self.gate_pack = torch.empty(n, dtype=torch.float32, device=self.device)
+        self.split_scales = None
         with torch.cuda.device(self.device):
-            _lib.check(
-                self.lib.rails_mol_pack_gate_weights(C.byref(self.shape), C.byref(self.weights), _ptr(self.gate_pack), _stream()),
-                "rails_mol_pack_gate_weights",
-            )
+            if self.precision == "f16x3":
+                self.split_scales = self._choose_split_scales(weights)
+                _lib.check(
+                    self.lib.rails_mol_pack_gate_weights_split(C.byref(self.shape), C.byref(self.weights), C.byref(self.split_scales), _ptr(self.gate_pack), _stream()),
+                    "rails_mol_pack_gate_weights_split",
+                )
+            else:
+                _lib.check(
+                    self.lib.rails_mol_pack_gate_weights(C.byref(self.shape), C.byref(self.weights), _ptr(self.gate_pack), _stream()),
+                    "rails_mol_pack_gate_weights",
+                )
+
+    def _choose_split_scales(self, weights: Dict[str, torch.Tensor]) -> "_lib.MolSplitScales":
+        """Power-of-two operand scales of the f16x3 mode, from a worst-case bound on the hidden layer: with
+        |cl| <= 1/temperature (unit-norm components) no f16 operand can overflow (mol_layout.h)."""
+        if not self.spec.dot_product_l2_norm:
+            raise NotImplementedError("precision='f16x3' needs dot_product_l2_norm=True (bounded cross logits)")
+        w1 = weights["_gating_fn._qi_partial_module.1.weight"].detach().float()
+        b1 = weights["_gating_fn._qi_partial_module.1.bias"].detach().float()
+        w2 = weights["_gating_fn._qi_partial_module.3.weight"].detach().float()
+        cl_max = 1.0 / self.spec.temperature * 1.001
+        t_max = 1.4426950408889634 * (cl_max * float(w1.abs().sum(1).max()) + float(b1.abs().max()))
+        limit = 60000.0
+        cl_scale = 2.0 ** math.floor(math.log2(min(16.0, limit / cl_max)))
+        w1_scale = 16.0
+        while cl_scale * w1_scale * t_max >= limit or w1_scale * 1.4426950408889634 * float(w1.abs().max()) >= limit:
+            w1_scale /= 2.0
+            if w1_scale < 2.0 ** -12:
+                raise NotImplementedError("precision='f16x3': pair-gate weights are too large for f16 operands; use fp32")
+        w2_scale = 16.0
+        while w2_scale * float(w2.abs().max()) >= limit:
+            w2_scale /= 2.0
+        return _lib.MolSplitScales(cl_scale, w1_scale, w2_scale)
 
     # ---- item side ----------------------------------------------------------------------------
     def build_index(self, items: torch.Tensor) -> MolIndex:
@@ -219,19 +263,31 @@ class MolEngine:
         if out is None:
             out = torch.empty((batch, index.n_items), dtype=torch.float32, device=index.buf.device)
         with torch.cuda.device(index.buf.device):
-            _lib.check(
-                self.lib.rails_mol_score_dense(C.byref(self.shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(index.buf), index.n_items, _ptr(out), out.stride(0), _stream()),
-                "rails_mol_score_dense",
-            )
+            if self.split_scales is not None:
+                _lib.check(
+                    self.lib.rails_mol_score_dense_split(C.byref(self.shape), _ptr(self.gate_pack), C.byref(self.split_scales), _ptr(qpack), batch, _ptr(index.buf), index.n_items, _ptr(out), out.stride(0), _stream()),
+                    "rails_mol_score_dense_split",
+                )
+            else:
+                _lib.check(
+                    self.lib.rails_mol_score_dense(C.byref(self.shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(index.buf), index.n_items, _ptr(out), out.stride(0), _stream()),
+                    "rails_mol_score_dense",
+                )
         return out
 
     def score_candidates(self, qpack: torch.Tensor, batch: int, cand_index: MolIndex, n_cand_padded: int) -> torch.Tensor:
         out = torch.empty((batch, n_cand_padded), dtype=torch.float32, device=cand_index.buf.device)
         with torch.cuda.device(cand_index.buf.device):
-            _lib.check(
-                self.lib.rails_mol_score_candidates(C.byref(self.shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(cand_index.buf), n_cand_padded, _ptr(out), out.stride(0), _stream()),
-                "rails_mol_score_candidates",
-            )
+            if self.split_scales is not None:
+                _lib.check(
+                    self.lib.rails_mol_score_candidates_split(C.byref(self.shape), _ptr(self.gate_pack), C.byref(self.split_scales), _ptr(qpack), batch, _ptr(cand_index.buf), n_cand_padded, _ptr(out), out.stride(0), _stream()),
+                    "rails_mol_score_candidates_split",
+                )
+            else:
+                _lib.check(
+                    self.lib.rails_mol_score_candidates(C.byref(self.shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(cand_index.buf), n_cand_padded, _ptr(out), out.stride(0), _stream()),
+                    "rails_mol_score_candidates",
+                )
         return out
 
 

@@ -242,6 +242,8 @@ class MoLSimilarity(SimilarityModule):
         self._autocast_bf16: bool = autocast_bf16
         self._engine: Optional[MolEngine] = None
         self._engine_key = None
+        # None -> RAILS_PRECISION or "fp32" (exact fp32 MFMA, the parity path); "f16x3" -> opt-in split-f16 gate MLP
+        self.precision: Optional[str] = None
 
     # ---- binding the parameters to the HIP engine -----------------------------------------------
     def shape_spec(self) -> MolShapeSpec:
@@ -287,9 +289,9 @@ class MoLSimilarity(SimilarityModule):
         if not self._apply_query_embeddings_fn or not self._apply_item_embeddings_fn:
             raise NotImplementedError("apply_query_embeddings_fn / apply_item_embeddings_fn = False is not supported")
         params = dict(self.state_dict(keep_vars=True))
-        key = tuple((k, v.data_ptr(), v._version, v.dtype) for k, v in params.items())
+        key = (self.precision,) + tuple((k, v.data_ptr(), v._version, v.dtype) for k, v in params.items())
         if self._engine is None or key != self._engine_key:
-            self._engine = MolEngine(self.shape_spec(), params)
+            self._engine = MolEngine(self.shape_spec(), params, precision=self.precision)
             self._engine_key = key
         return self._engine
 

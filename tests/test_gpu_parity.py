@@ -430,3 +430,24 @@ def test_degenerate_sizes(dev):
         s, i = tk(fx.t("q")[:1].to(dev), k=1)
     ref = O.mol_logits(fx.cfg, fx.weights, fx.t("q")[:1], fx.t("X")[:, :1])
     assert abs(float(s) - float(ref)) <= LOGIT_TOL and int(i) == int(fx.t("item_ids")[0, 0])
+
+
+# ---- opt-in precision mode "f16x3" --------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["c1_ml1m", "c2_ml20m", "c3_books"])
+def test_f16x3_mode_holds_the_logit_tolerance(dev, name):
+    """The split-f16 gate MLP must meet the same 1e-4 bar as the exact fp32 kernels, on the golden vectors."""
+    fx = Fixture(name)
+    mol = build_module(fx.cfg, fx.weights, dev)
+    mol.precision = "f16x3"
+    X, ids, q = fx.t("X").to(dev), fx.t("item_ids").to(dev), fx.t("q").to(dev)
+    with torch.inference_mode():
+        tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
+        logits = tk.all_logits(q, **kw_dev(fx, dev))
+        assert tk._engine.split_scales is not None
+        d = float((logits.cpu() - fx.t("F2/all_logits")).abs().max())
+        assert d <= LOGIT_TOL, d
+        s, i = tk(q, k=200, **kw_dev(fx, dev))
+        assert_topk_matches(s, i, fx.t("F2/k200/scores"), fx.t("F2/k200/ids"), atol=LOGIT_TOL, tie_tol=1e-4)
+        cand = fx.t("X").squeeze(0)[fx.t("F6/cand_idx")].to(dev)
+        rows, _ = mol(q, cand, **kw_dev(fx, dev))
+        assert float((rows.cpu() - fx.t("F6/logits")).abs().max()) <= LOGIT_TOL

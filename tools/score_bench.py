@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--items", type=int, default=0)
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--precision", default=None, help="fp32 | f16x3 (default: RAILS_PRECISION or fp32)")
+    ap.add_argument("--check-items", type=int, default=0, help="compare this many sampled columns with the CPU oracle")
     args = ap.parse_args()
     variants = [v for v in args.variants.split(",")]
     cfg_key, N, _ = bench.WORKLOADS[args.workload]
@@ -41,6 +43,7 @@ def main():
         query_nonlinearity=cfg.query_nonlinearity, uid_embedding_hash_sizes=list(cfg.uid_embedding_hash_sizes) or None)
     mol.load_state_dict(w, strict=True)
     mol = mol.to(dev).eval()
+    mol.precision = args.precision
     X = torch.from_numpy(O.hash_item_table(1, 0, N, cfg.item_embedding_dim)).to(dev)
     q = O.synthetic_queries(cfg, args.batch).to(dev)
     uid = None
@@ -65,6 +68,12 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 times[v].append(e0.elapsed_time(e1) / args.reps)
+    if args.check_items:
+        g = torch.Generator().manual_seed(0)
+        cols = torch.randperm(N, generator=g)[: args.check_items]
+        ref = O.mol_logits(cfg, w, q.cpu(), X[cols.to(dev)].cpu().unsqueeze(0), None if uid is None else uid.cpu())
+        err = (outs[variants[0]][:, cols.to(dev)].cpu() - ref).abs()
+        print(f"precision {eng.precision}: max|logit - oracle| over {args.check_items} sampled items x {args.batch} queries = {float(err.max()):.3e}  (mean {float(err.mean()):.3e})")
     flops = args.batch * N * bench.flops_per_pair(cfg)
     for v in variants:
         med, mn = statistics.median(times[v]), min(times[v])
