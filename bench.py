@@ -107,6 +107,7 @@ def main() -> None:
     ap.add_argument("--k-prime", type=int, default=200)
     ap.add_argument("--cpu-sample-items", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fast-path", action="store_true", help="skip the extra f16x3 measurement")
     args = ap.parse_args()
 
     from oracle import mol_oracle as O  # inputs generator + cpu_baseline checker only
@@ -223,12 +224,50 @@ def main() -> None:
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        score_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+
+    # ---- opt-in precision mode "f16x3" (same API, same index, same 1e-4 bar), timed the same
+    #      way AFTER the headline region so it cannot perturb it.  Reported separately; `value` stays the exact-fp32 path.
+    fast = None
+    if not args.no_fast_path:
+        with torch.inference_mode():
+            mol.precision = "f16x3"
+            eng = local._bind()          # new engine (split weight fragments); the item index is rebuilt in the same format
+            d_logits = torch.empty_like(logits)
+            qp, _, _ = eng.query_pack(q, kw.get("user_ids"))
+            eng.score_dense(qp, B, local._index, out=d_logits)
+            max_dev = float((d_logits - logits).abs().max())   # vs the exact-fp32 logits of the last headline step
+            ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+            ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+            for _ in range(args.warmup):
+                step()
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                step(i)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            fast_elapsed = time.perf_counter() - t0
+            fast_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+            mol.precision = None
+        if world > 1:
+            tf = torch.tensor([fast_elapsed], dtype=torch.float64, device="cpu" if test_backend else dev)
+            dist.all_reduce(tf, op=dist.ReduceOp.MAX)
+            fast_elapsed = float(tf.item())
+        fast = {
+            "precision": "f16x3: gate GEMMs + sub-embedding contraction on f16 MFMA, operands split hi+lo, 3 MFMAs per block, fp32 accumulate",
+            "value": B * args.steps / fast_elapsed, "unit": "queries/s", "ms_per_step": fast_elapsed / args.steps * 1e3,
+            "kernel_ms": fast_ms, "achieved_tflops_algorithmic": B * (hi - lo) * flops_per_pair(cfg) / (fast_ms * 1e-3) / 1e12,
+            "max_abs_logit_diff_vs_fp32_path": max_dev,
+        }
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if test_backend else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    score_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
     n_shard = hi - lo
     flops_alg = B * n_shard * flops_per_pair(cfg)
     achieved = flops_alg / (score_ms * 1e-3) / 1e12
@@ -275,6 +314,8 @@ def main() -> None:
             },
             "index_build_s": index_build_s,
         }
+        if fast is not None:
+            out["fast_path"] = fast
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, weights, q_cpu, uid_cpu, N, min(args.cpu_sample_items, N), kp)
         print(json.dumps(out), flush=True)

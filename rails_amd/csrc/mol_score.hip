@@ -51,16 +51,14 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 // GEMM1: D1[m][(qj,p), x] = sum_d Eq[qj,p,d] * Ex[x,m,d].  `eq` is the query group's A operand in fragment
 // order ([sc][lane] float4), `tEx` the tile's B operand ([m][sc][lane] float4) -- in HBM or in LDS.
 template <class G, int PX, int DD>
-__device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float4* __restrict__ eq, const float4* tEx, int lane,
-                                      float a_scale = 1.0f) {
+__device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float4* __restrict__ eq, const float4* tEx, int lane) {
 #pragma unroll
   for (int m = 0; m < PX; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) D1[m][r] = 0.0f;
 #pragma unroll
   for (int sc = 0; sc < DD / 8; ++sc) {
-    float4 a = eq[sc * 64 + lane];
-    a.x *= a_scale; a.y *= a_scale; a.z *= a_scale; a.w *= a_scale;  // 1 (fp32 mode) or the power-of-two s_a (f16x3)
+    const float4 a = eq[sc * 64 + lane];
 #pragma unroll
     for (int m = 0; m < PX; ++m) {
       const float4 b = tEx[(m * (DD / 8) + sc) * 64 + lane];
@@ -74,6 +72,13 @@ __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float4* __restrict
     asm volatile("" ::: "memory");
   }
 }
+
+// GEMM1 of the f16x3 mode: same fp32 fragments (query pack, item tile) as the exact kernel -- two consecutive float4
+// chunks of a lane are exactly its 8 k-values of a K=16 step (k = hi*d/2 + 8 ks + jj on both operands) -- split into
+// f16 hi/lo on the fly; three MFMAs per (item group, K-step).  `a_scale` (power of two) rides on the query operand.
+template <class G, int PX, int DD>
+__device__ __forceinline__ void gemm1_split(f32x16 (&D1)[PX], const float4* __restrict__ eq, const float4* tEx, int lane,
+                                            float a_scale);
 
 // One query of the group: gate MLP (GEMM2 -> silu -> GEMM3), combine, softmax, mixture, on pre-scaled operands
 // (mol_layout.h).  The query's cl values sit in accumulator registers [R0, R0 + RPQ) of every D1 tile.
@@ -180,10 +185,15 @@ __device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
-// two fp32 values -> packed f16 hi (round toward zero) and packed f16 lo (the exact fp32 remainder, RTZ to f16)
+// two fp32 values -> packed f16 hi (round toward zero) and packed f16 lo (the fp32 remainder x - hi, exact, RTZ to f16).
+// The remainder is one v_fma_mix_f32 per value (fma(f16 half of hi, -1.0, x) in fp32) instead of cvt + sub.
 __device__ __forceinline__ void split_pair(float x0, float x1, h2v& hi, h2v& lo) {
-  hi = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-  lo = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(x0 - (float)hi.x, x1 - (float)hi.y));
+  const unsigned hb = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+  float l0, l1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hb), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hb), "v"(x1));
+  hi = __builtin_bit_cast(h2v, hb);
+  lo = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(l0, l1));
 }
 
 template <class G, int PX, int R0>
@@ -213,14 +223,17 @@ __device__ __forceinline__ float query_mlp_split(f32x16 (&D1)[PX], const float* 
       split_pair(D1[e / G::RPQ][R0 + e % G::RPQ], D1[(e + 1) / G::RPQ][R0 + (e + 1) % G::RPQ], ph, pl);
       bh[jj] = ph.x; bh[jj + 1] = ph.y; bl[jj] = pl.x; bl[jj + 1] = pl.y;
     }
+    // three passes over the row tiles so consecutive MFMAs hit different accumulators
+    h8 ah[G::TH];
 #pragma unroll
     for (int t = 0; t < G::TH; ++t) {
-      const h8 ah = sW1hi[(ks * G::TH + t) * 64 + lane];
-      const h8 al = sW1lo[(ks * G::TH + t) * 64 + lane];
-      D2[t] = mfma16(al, bh, D2[t]);
-      D2[t] = mfma16(ah, bl, D2[t]);
-      D2[t] = mfma16(ah, bh, D2[t]);
+      ah[t] = sW1hi[(ks * G::TH + t) * 64 + lane];
+      D2[t] = mfma16(sW1lo[(ks * G::TH + t) * 64 + lane], bh, D2[t]);
     }
+#pragma unroll
+    for (int t = 0; t < G::TH; ++t) D2[t] = mfma16(ah[t], bl, D2[t]);
+#pragma unroll
+    for (int t = 0; t < G::TH; ++t) D2[t] = mfma16(ah[t], bh, D2[t]);
   }
   // hid'' = D2 * rcp(1 + exp2(D2 / c)) = c * hid'
   const f32x2 inv_c = {p.inv_c, p.inv_c};
@@ -250,14 +263,16 @@ __device__ __forceinline__ float query_mlp_split(f32x16 (&D1)[PX], const float* 
       split_pair(D2[f / 16][f % 16], D2[f / 16][f % 16 + 1], ph, pl);
       bh[jj] = ph.x; bh[jj + 1] = ph.y; bl[jj] = pl.x; bl[jj + 1] = pl.y;
     }
+    h8 ah[G::TL];
 #pragma unroll
     for (int v = 0; v < G::TL; ++v) {
-      const h8 ah = sW2hi[(ks * G::TL + v) * 64 + lane];
-      const h8 al = sW2lo[(ks * G::TL + v) * 64 + lane];
-      D3[v] = mfma16(al, bh, D3[v]);
-      D3[v] = mfma16(ah, bl, D3[v]);
-      D3[v] = mfma16(ah, bh, D3[v]);
+      ah[v] = sW2hi[(ks * G::TL + v) * 64 + lane];
+      D3[v] = mfma16(sW2lo[(ks * G::TL + v) * 64 + lane], bh, D3[v]);
     }
+#pragma unroll
+    for (int v = 0; v < G::TL; ++v) D3[v] = mfma16(ah[v], bl, D3[v]);
+#pragma unroll
+    for (int v = 0; v < G::TL; ++v) D3[v] = mfma16(ah[v], bh, D3[v]);
   }
 
   // epilogue: T2 = c2 * t2 = fma(c2 * gq', gi, D3);  u = t2 / (1 + 2^t2)
@@ -293,6 +308,42 @@ __device__ __forceinline__ float query_mlp_split(f32x16 (&D1)[PX], const float* 
   num += xor32(num);
   const float rden = __builtin_amdgcn_rcpf(den);
   return (num * rden * p.inv_cl_scale) / fmaxf(den * rden, 1e-6f);   // D1 holds s_a * cl
+}
+
+__device__ __forceinline__ void split_f4x2(const float4& u, const float4& v, float scale, h8& hi, h8& lo) {
+  const float x[8] = {u.x * scale, u.y * scale, u.z * scale, u.w * scale, v.x * scale, v.y * scale, v.z * scale, v.w * scale};
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    h2v ph, pl;
+    split_pair(x[j], x[j + 1], ph, pl);
+    hi[j] = ph.x; hi[j + 1] = ph.y; lo[j] = pl.x; lo[j + 1] = pl.y;
+  }
+}
+
+template <class G, int PX, int DD>
+__device__ __forceinline__ void gemm1_split(f32x16 (&D1)[PX], const float4* __restrict__ eq, const float4* tEx, int lane,
+                                            float a_scale) {
+  static_assert(DD % 16 == 0, "f16x3 GEMM1 walks K in steps of 16");
+#pragma unroll
+  for (int m = 0; m < PX; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) D1[m][r] = 0.0f;
+#pragma unroll
+  for (int ks = 0; ks < DD / 16; ++ks) {
+    h8 ah, al;
+    split_f4x2(eq[(2 * ks) * 64 + lane], eq[(2 * ks + 1) * 64 + lane], a_scale, ah, al);
+    h8 bh[PX], bl[PX];
+#pragma unroll
+    for (int m = 0; m < PX; ++m)
+      split_f4x2(tEx[(m * (DD / 8) + 2 * ks) * 64 + lane], tEx[(m * (DD / 8) + 2 * ks + 1) * 64 + lane], 1.0f, bh[m], bl[m]);
+#pragma unroll
+    for (int m = 0; m < PX; ++m) D1[m] = mfma16(al, bh[m], D1[m]);
+#pragma unroll
+    for (int m = 0; m < PX; ++m) D1[m] = mfma16(ah, bl[m], D1[m]);
+#pragma unroll
+    for (int m = 0; m < PX; ++m) D1[m] = mfma16(ah, bh[m], D1[m]);
+    asm volatile("" ::: "memory");
+  }
 }
 
 // All queries of one unit, each at its own static register offset (no register rotation).
@@ -358,7 +409,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(Score
     const float4* tGi = tEx + G::kTileExFloats / 4;
     const float4* eq = reinterpret_cast<const float4*>(p.eqfrag + (int64_t)g * G::kEqGroupFloats);
     f32x16 D1[PX];
-    gemm1<G, PX, DD>(D1, eq, tEx, lane, SPLIT ? p.cl_scale : 1.0f);
+    if constexpr (SPLIT) gemm1_split<G, PX, DD>(D1, eq, tEx, lane, p.cl_scale);
+    else gemm1<G, PX, DD>(D1, eq, tEx, lane);
     unit_queries<G, PX, SPLIT>(D1, p, g, row, tile * kTileItems, smem, sW1, sW2, sB1, sB2, tGi, lane, hi, x);
   }
 }
@@ -408,7 +460,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(Score
     for (int g = wave; g < p.n_groups; g += NW) {
       const float4* eq = reinterpret_cast<const float4*>(p.eqfrag + (int64_t)g * G::kEqGroupFloats);
       f32x16 D1[PX];
-      gemm1<G, PX, DD>(D1, eq, tEx, lane, SPLIT ? p.cl_scale : 1.0f);
+      if constexpr (SPLIT) gemm1_split<G, PX, DD>(D1, eq, tEx, lane, p.cl_scale);
+      else gemm1<G, PX, DD>(D1, eq, tEx, lane);
       unit_queries<G, PX, SPLIT>(D1, p, g, -1, tile * kTileItems, smem, sW1, sW2, sB1, sB2, tGi, lane, hi, x);
     }
   }

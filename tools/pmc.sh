@@ -5,7 +5,7 @@ set -u
 OUT=${1:-gpurun_out/pmc}; VAR=${2:-0}
 export TMPDIR=/tmp
 mkdir -p "$OUT"
-CMD="python tools/score_bench.py --variants $VAR --rounds 1 --reps 2"
+CMD="python tools/score_bench.py --variants $VAR --rounds 1 --reps 2 ${PMC_EXTRA:-}"
 P1="GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA"
 P2="GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_SCA"
 P3="FETCH_SIZE"
