@@ -370,7 +370,9 @@ int rails_topk(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t
   if (!scores || !out_scores || !out_ids) { set_error("topk: NULL pointer"); return RAILS_EINVAL; }
   if (ld < n) { set_error("topk: ld < n"); return RAILS_EINVAL; }
   if (n > 16384 && !workspace) { set_error("topk: workspace is required for n > 16384"); return RAILS_ENOMEM; }
-  const int r = topk(scores, ld, rows, n, k, ids, ids_row_stride, out_scores, out_ids, workspace, workspace_bytes,
+  const int cu = compute_units();
+  if (cu <= 0) { set_error("topk: no HIP device"); return RAILS_ELAUNCH; }
+  const int r = topk(scores, ld, rows, n, k, ids, ids_row_stride, out_scores, out_ids, workspace, workspace_bytes, cu,
                      (hipStream_t)stream);
   return r == kOk ? r : fail(r, "topk");
 }

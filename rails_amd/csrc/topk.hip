@@ -13,7 +13,10 @@
 //               score; if that score is tied, one in-order scan of the row finds the position of the last tied
 //               element to take, which completes the 64-bit threshold key T; one compaction pass gathers the
 //               exactly-k keys >= T; the LDS bitonic sort orders them.
+// (Measured and dropped: LDS-sorting 16K-element chunks and merging their top-k -- a 16K-key bitonic sort costs ~150 us,
+//  more than the whole radix path; and folding the bin pick into the histogram kernel with arrival tickets + fences.)
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "mol_kernels.h"
 
@@ -47,19 +50,26 @@ __device__ __forceinline__ unsigned long long make_key(float score, unsigned int
 }
 
 // ---- LDS bitonic sort (descending) + emit ------------------------------------------------------
-// mode 0: keys come from scores[row*ld + i], i < n.   mode 1: keys come from cand[row*cand_ld + i], i < k.
+// Input: keys from cand[row*cand_ld + i], i < count (cand != NULL), else from scores[row*ld + begin + i] with positions
+// begin + i, where [begin, begin + count) is this workgroup's chunk of the row (blockIdx.y * chunk ...).
+// Output: the k_out largest keys, descending -- decoded to (score, id) when out_scores != NULL, else raw keys to
+// keys_out[row*keys_ld + blockIdx.y*k_out + j] (first level of the chunked path).
 __global__ __launch_bounds__(kSortThreads) void sort_emit_kernel(const float* __restrict__ scores, int64_t ld,
-                                                                int64_t n, const unsigned long long* __restrict__ cand,
-                                                                int64_t cand_ld, int k, int npad,
+                                                                int64_t n, int64_t chunk,
+                                                                const unsigned long long* __restrict__ cand,
+                                                                int64_t cand_ld, int cand_count, int k_out, int npad,
                                                                 const int64_t* __restrict__ ids, int64_t ids_row_stride,
                                                                 float* __restrict__ out_scores,
-                                                                int64_t* __restrict__ out_ids) {
+                                                                int64_t* __restrict__ out_ids,
+                                                                unsigned long long* __restrict__ keys_out, int64_t keys_ld) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
   const int row = blockIdx.x;
-  const int count = cand ? k : (int)n;
+  const int64_t begin = (int64_t)blockIdx.y * chunk;
+  const int count = cand ? cand_count : (int)((begin + chunk < n ? begin + chunk : n) - begin);
+  const int k = k_out;
   for (int i = threadIdx.x; i < npad; i += kSortThreads) {
     unsigned long long kv = 0ull;  // below every real key (orderable() never returns 0 for a finite/inf score)
-    if (i < count) kv = cand ? cand[row * cand_ld + i] : make_key(scores[row * ld + i], (unsigned int)i);
+    if (i < count) kv = cand ? cand[row * cand_ld + i] : make_key(scores[row * ld + begin + i], (unsigned int)(begin + i));
     keys[i] = kv;
   }
   __syncthreads();
@@ -76,25 +86,64 @@ __global__ __launch_bounds__(kSortThreads) void sort_emit_kernel(const float* __
     }
   }
   for (int j = threadIdx.x; j < k; j += kSortThreads) {
-    const unsigned long long kv = keys[j];
-    const unsigned int pos = ~(unsigned int)(kv & 0xFFFFFFFFull);
-    out_scores[(int64_t)row * k + j] = unorderable((unsigned int)(kv >> 32));
-    out_ids[(int64_t)row * k + j] = ids ? ids[ids_row_stride * row + pos] : (int64_t)pos;
+    const unsigned long long kv = keys[j];   // j >= count: padding key 0, sorts below everything at the next level
+    if (out_scores) {
+      const unsigned int pos = ~(unsigned int)(kv & 0xFFFFFFFFull);
+      out_scores[(int64_t)row * k + j] = unorderable((unsigned int)(kv >> 32));
+      out_ids[(int64_t)row * k + j] = ids ? ids[ids_row_stride * row + pos] : (int64_t)pos;
+    } else {
+      keys_out[row * keys_ld + (int64_t)blockIdx.y * k + j] = kv;
+    }
   }
 }
 
 // ---- radix select ------------------------------------------------------------------------------
-__global__ void select_init_kernel(SelectState* st, int rows, int k) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < rows) { st[r].prefix = 0ull; st[r].need = (unsigned int)k; st[r].done = 0u; st[r].count = 0u; st[r].pad = 0u; }
+// Workspace state is zeroed by one memset per call: SelectState (prefix 0, need 0 = "k", done 0, count 0) and the
+// per-pass histograms.  Each pass is a histogram launch plus a one-workgroup-per-row pick launch.  (Folding the pick into
+// the histogram kernel through an arrival ticket + agent-scope release/acquire was measured: the 2048 release fences
+// cost 35-100 us per pass, against 8 us for the separate launch.)
+
+// one wave per row: walk the histogram from the top bin down to the bin holding the need-th key.
+// Lane l owns the nb/64 bins [top - l*per - per + 1, top - l*per]; a wave prefix sum finds the owning lane, which then
+// walks its own bins.
+__global__ __launch_bounds__(64) void pick_bin_kernel(SelectState* __restrict__ st, const unsigned int* __restrict__ hist,
+                                                      int pass, int rows, int k) {
+  const int row = blockIdx.x;
+  if (st[row].done) return;
+  const int shift = kPassShift[pass], bits = kPassBits[pass];
+  const int nb = 1 << bits, per = nb / 64;  // 32 or 16 bins per lane, top bins first
+  const unsigned int* gh = hist + ((int64_t)pass * rows + row) * kBins;
+  const unsigned int need = pass == 0 ? (unsigned int)k : st[row].need;
+  const int lane = threadIdx.x;
+  const int top = nb - 1 - lane * per;
+  unsigned int mine = 0;
+  for (int j = 0; j < per; ++j) mine += gh[top - j];
+  unsigned int incl = mine;  // inclusive prefix over lanes (lane 0 = top bins)
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  const unsigned int excl = incl - mine;
+  if (excl < need && need <= incl) {   // exactly one lane (need <= total by construction: k <= n)
+    unsigned int cum = excl;
+    int bin = top;
+    for (int j = 0; j < per; ++j, --bin) { const unsigned int c = gh[bin]; if (cum + c >= need) break; cum += c; }
+    const unsigned int c = gh[bin];
+    const unsigned int still = need - cum;
+    st[row].prefix |= ((unsigned long long)(unsigned int)bin) << shift;
+    st[row].need = still;
+    // all keys of this bin are wanted -> the threshold is the bin's lower edge; nothing left to resolve.
+    // Otherwise the next pass narrows it, and after the last pass tie_resolve_kernel finishes it.
+    if (c == still) st[row].done = 1u;
+  }
 }
 
 __global__ __launch_bounds__(kHistThreads) void hist_kernel(const float* __restrict__ scores, int64_t ld, int64_t n,
                                                            const SelectState* __restrict__ st,
-                                                           unsigned int* __restrict__ hist, int pass,
-                                                           int64_t chunk) {
+                                                           unsigned int* __restrict__ hist, int pass, int64_t chunk) {
   __shared__ unsigned int h[kBins];
-  const int row = blockIdx.y;
+  const int row = blockIdx.y, rows = gridDim.y;
   if (st[row].done) return;
   const int shift = kPassShift[pass], bits = kPassBits[pass];
   const unsigned long long prefix = st[row].prefix;
@@ -104,51 +153,21 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(const float* __restr
   const int64_t begin = (int64_t)blockIdx.x * chunk;
   const int64_t end = (begin + chunk < n) ? begin + chunk : n;
   const float* rowp = scores + (int64_t)row * ld;
-  for (int64_t i = begin + threadIdx.x; i < end; i += kHistThreads) {
-    const unsigned long long key = make_key(rowp[i], (unsigned int)i);
-    const bool match = (above >= 64) || ((key >> above) == (prefix >> above));
-    if (match) atomicAdd(&h[(unsigned int)(key >> shift) & ((1u << bits) - 1u)], 1u);
+  for (int64_t i0 = begin; i0 < end; i0 += kHistThreads) {
+    const int64_t i = i0 + threadIdx.x;
+    bool match = false;
+    unsigned int bin = 0;
+    if (i < end) {
+      const unsigned long long key = make_key(rowp[i], (unsigned int)i);
+      match = (above >= 64) || ((key >> above) == (prefix >> above));
+      bin = (unsigned int)(key >> shift) & ((1u << bits) - 1u);
+    }
+    if (match) atomicAdd(&h[bin], 1u);
   }
   __syncthreads();
-  unsigned int* gh = hist + ((int64_t)pass * gridDim.y + row) * kBins;
+  unsigned int* gh = hist + ((int64_t)pass * rows + row) * kBins;
   for (int i = threadIdx.x; i < kBins; i += kHistThreads)
     if (h[i]) atomicAdd(&gh[i], h[i]);
-}
-
-// one workgroup per row: walk the histogram from the top bin down to the bin holding the need-th key
-__global__ __launch_bounds__(256) void pick_bin_kernel(SelectState* __restrict__ st,
-                                                       const unsigned int* __restrict__ hist, int pass, int rows) {
-  __shared__ unsigned int part[256];
-  __shared__ unsigned int sel_bin, sel_above;
-  const int row = blockIdx.x;
-  if (st[row].done) return;
-  const int shift = kPassShift[pass], bits = kPassBits[pass];
-  const int nb = 1 << bits, per = nb / 256;  // 8 or 4 bins per thread, top bins first
-  const unsigned int* gh = hist + ((int64_t)pass * rows + row) * kBins;
-  const unsigned int need = st[row].need;
-  unsigned int mine = 0;
-  for (int j = 0; j < per; ++j) mine += gh[nb - 1 - (threadIdx.x * per + j)];
-  part[threadIdx.x] = mine;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned int cum = 0;
-    int t = 0;
-    for (; t < 256; ++t) { if (cum + part[t] >= need) break; cum += part[t]; }
-    // need <= total by construction (k <= n), so t < 256
-    int bin = nb - 1 - t * per;
-    for (int j = 0; j < per; ++j, --bin) { const unsigned int c = gh[bin]; if (cum + c >= need) break; cum += c; }
-    sel_bin = (unsigned int)bin;
-    sel_above = cum;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned int c = gh[sel_bin];
-    const unsigned int still = need - sel_above;
-    st[row].prefix |= ((unsigned long long)sel_bin) << shift;
-    st[row].need = still;
-    // all keys of this bin are wanted -> the threshold is the bin's lower edge; nothing left to resolve
-    if (c == still) st[row].done = 1u;  // otherwise tie_resolve_kernel finishes the threshold
-  }
 }
 
 // The k-th score is tied: `need` of the elements whose score equals it are wanted, lowest positions first.
@@ -228,7 +247,7 @@ static int ensure_sort_lds() {
 }
 
 int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int64_t* ids, int64_t ids_row_stride,
-         float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, hipStream_t stream) {
+         float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, int n_cu, hipStream_t stream) {
   if (rows <= 0 || k <= 0) return kOk;
   if (k > kSortCap) { set_error("k = %d exceeds the in-LDS sort capacity (%d)", k, kSortCap); return kErrUnsupported; }
   if (n >= (1ll << 32)) { set_error("n = %lld does not fit 32-bit positions; shard the corpus", (long long)n); return kErrUnsupported; }
@@ -236,8 +255,8 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
   if (n <= kSortCap) {
     const int npad = next_pow2((int)n < 2 ? 2 : (int)n);
     hipLaunchKernelGGL(sort_emit_kernel, dim3(rows), dim3(kSortThreads), npad * sizeof(unsigned long long), stream,
-                       scores, ld, n, (const unsigned long long*)nullptr, (int64_t)0, k, npad, ids, ids_row_stride,
-                       out_scores, out_ids);
+                       scores, ld, n, n, (const unsigned long long*)nullptr, (int64_t)0, 0, k, npad, ids, ids_row_stride,
+                       out_scores, out_ids, (unsigned long long*)nullptr, (int64_t)0);
     return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
   }
   if (ws_bytes < topk_workspace_bytes(rows, n, k)) { set_error("top-k workspace too small"); return kErrNoMem; }
@@ -247,10 +266,10 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
   unsigned int* hist = reinterpret_cast<unsigned int*>(base);
   const size_t hist_bytes = sizeof(unsigned int) * (size_t)kRadixPasses * rows * kBins;
   base += align_up(hist_bytes, 256);
+  const size_t state_bytes = (size_t)(base - static_cast<char*>(ws));
   unsigned long long* cand = reinterpret_cast<unsigned long long*>(base);
 
-  if (hipMemsetAsync(hist, 0, hist_bytes, stream) != hipSuccess) return kErrLaunch;
-  hipLaunchKernelGGL(select_init_kernel, dim3((rows + 63) / 64), dim3(64), 0, stream, st, rows, k);
+  if (hipMemsetAsync(ws, 0, state_bytes, stream) != hipSuccess) return kErrLaunch;   // state + histograms
   // enough workgroups to fill the chip, at least 8K elements each
   int64_t chunks = (2048 + rows - 1) / rows;
   const int64_t max_chunks = (n + 8191) / 8192;
@@ -258,16 +277,17 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
   if (chunks < 1) chunks = 1;
   const int64_t chunk = (n + chunks - 1) / chunks;
   for (int pass = 0; pass < kRadixPasses; ++pass) {
-    hipLaunchKernelGGL(hist_kernel, dim3((unsigned)chunks, rows), dim3(kHistThreads), 0, stream, scores, ld, n, st, hist,
-                       pass, chunk);
-    hipLaunchKernelGGL(pick_bin_kernel, dim3(rows), dim3(256), 0, stream, st, hist, pass, rows);
+    hipLaunchKernelGGL(hist_kernel, dim3((unsigned)chunks, rows), dim3(kHistThreads), 0, stream, scores, ld, n, st, hist, pass,
+                       chunk);
+    hipLaunchKernelGGL(pick_bin_kernel, dim3(rows), dim3(64), 0, stream, st, hist, pass, rows, k);
   }
   hipLaunchKernelGGL(tie_resolve_kernel, dim3(rows), dim3(kTieThreads), 0, stream, scores, ld, n, st);
   hipLaunchKernelGGL(compact_kernel, dim3((unsigned)chunks, rows), dim3(kHistThreads), 0, stream, scores, ld, n, st, cand,
                      (int64_t)k, k, chunk);
   const int npad = next_pow2(k < 2 ? 2 : k);
-  hipLaunchKernelGGL(sort_emit_kernel, dim3(rows), dim3(kSortThreads), npad * sizeof(unsigned long long), stream,
-                     scores, ld, n, cand, (int64_t)k, k, npad, ids, ids_row_stride, out_scores, out_ids);
+  hipLaunchKernelGGL(sort_emit_kernel, dim3(rows), dim3(kSortThreads), npad * sizeof(unsigned long long), stream, scores, ld, n, n,
+                     cand, (int64_t)k, k, k, npad, ids, ids_row_stride, out_scores, out_ids, (unsigned long long*)nullptr,
+                     (int64_t)0);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
