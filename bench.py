@@ -197,12 +197,8 @@ def main() -> None:
             k_local = min(kp, hi - lo)
             s, top = E.topk(logits, k_local, ids=local._ids_flat)
             if world > 1:
-                from rails_amd.sharded import pack_candidates, unpack_candidates
-
-                msg = pack_candidates(s, top, kp)
-                gathered = all_gather_rows(msg)
-                all_s, all_i = unpack_candidates(gathered.view(world, msg.shape[0], msg.shape[1]), kp)
-                s, top = E.topk(all_s, kp, ids=all_i)
+                gathered = all_gather_rows(E.pack_candidates(s, top, kp))
+                s, top = E.merge_candidates(gathered, world, kp, kp)
             return E.filter_seen_ids(top, s, inv, k)
 
         # sanity: the decomposed step equals the module API

@@ -213,6 +213,16 @@ int rails_topk(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t
                const int64_t* ids, int64_t ids_row_stride, float* out_scores, int64_t* out_ids,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- item-sharded top-k (no counterpart in the reference, whose eval is single-GPU: eval_from_checkpoint.py:554-555) ----
+ * Each rank turns its local top-k into one message row of 2k int64 (k score words: fp32 bits in the low half | k ids;
+ * rows with k_local < k are padded with (-inf, -1)); the caller all-gathers the messages in rank order; every rank
+ * merges them.  Contiguous item-id shards + rank order keep the tie rule, so the result equals the unsharded top-k. */
+int rails_pack_candidates(const float* scores, const int64_t* ids, int32_t rows, int32_t k_local, int32_t k, int64_t* msg,
+                          void* stream);
+/* gathered: (n_ranks, rows, 2k) int64.  n_ranks * k <= 16384.  k_out <= n_ranks * k. */
+int rails_merge_candidates(const int64_t* gathered, int32_t n_ranks, int32_t rows, int32_t k, int32_t k_out,
+                           float* out_scores, int64_t* out_ids, void* stream);
+
 /* ---- seen-id filter --------------------------------------------------------------------------
  * Replaces the row-wise masking of CandidateIndex.get_top_k_outputs (indexing/candidate_index.py:154-178):
  * keep the first k ids of each row of (rows, k_prime) that do not occur in invalid_ids (rows, width),

@@ -142,6 +142,11 @@ PROTOTYPES = {
         [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
          C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
     ),
+    "rails_pack_candidates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "rails_merge_candidates": (
+        C.c_int,
+        [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
     "rails_filter_seen_ids": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

@@ -377,6 +377,25 @@ int rails_topk(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t
   return r == kOk ? r : fail(r, "topk");
 }
 
+int rails_pack_candidates(const float* scores, const int64_t* ids, int32_t rows, int32_t k_local, int32_t k, int64_t* msg,
+                          void* stream) {
+  g_err[0] = '\0';
+  if (rows < 0 || k_local < 0 || k < 0 || k_local > k) { set_error("pack_candidates: bad size"); return RAILS_EINVAL; }
+  if (rows == 0 || k == 0) return RAILS_OK;
+  if (!msg || (k_local > 0 && (!scores || !ids))) { set_error("pack_candidates: NULL pointer"); return RAILS_EINVAL; }
+  return fail(pack_candidates(scores, ids, rows, k_local, k, msg, (hipStream_t)stream), "pack_candidates");
+}
+
+int rails_merge_candidates(const int64_t* gathered, int32_t n_ranks, int32_t rows, int32_t k, int32_t k_out, float* out_scores,
+                           int64_t* out_ids, void* stream) {
+  g_err[0] = '\0';
+  if (n_ranks <= 0 || rows < 0 || k <= 0 || k_out < 0 || (int64_t)k_out > (int64_t)n_ranks * k) { set_error("merge_candidates: bad size"); return RAILS_EINVAL; }
+  if (rows == 0 || k_out == 0) return RAILS_OK;
+  if (!gathered || !out_scores || !out_ids) { set_error("merge_candidates: NULL pointer"); return RAILS_EINVAL; }
+  const int r = merge_candidates(gathered, n_ranks, rows, k, k_out, out_scores, out_ids, (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "merge_candidates");
+}
+
 int rails_filter_seen_ids(const int64_t* top_ids, const float* top_scores, int32_t rows, int32_t k_prime,
                           const int64_t* invalid_ids, int32_t width, int32_t k, int64_t* out_ids, float* out_scores,
                           void* stream) {

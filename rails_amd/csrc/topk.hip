@@ -365,6 +365,86 @@ __global__ __launch_bounds__(kFilterThreads) void filter_seen_kernel(const int64
   }
 }
 
+// ---- item-sharded top-k: message pack + merge (rails_amd/sharded.py) -----------------------------------------
+// msg[row] = [k score words (fp32 bits in the low half of an int64) | k ids]; rows shorter than k are padded with
+// (-inf, -1) so every rank contributes the same size to the single all-gather.
+__global__ void pack_candidates_kernel(const float* __restrict__ scores, const int64_t* __restrict__ ids, int rows, int k_local,
+                                       int k, int64_t* __restrict__ msg) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * k) return;
+  const int row = i / k, j = i - row * k;
+  const float sc = j < k_local ? scores[(int64_t)row * k_local + j] : -INFINITY;
+  msg[(int64_t)row * 2 * k + j] = (int64_t)(unsigned long long)__float_as_uint(sc);
+  msg[(int64_t)row * 2 * k + k + j] = j < k_local ? ids[(int64_t)row * k_local + j] : -1;
+}
+
+// gathered: (R, rows, 2k) messages in rank order.  Candidate (r, j) gets position r*k + j: shard-major order is global
+// position order for contiguous shards, so the tie rule (score desc, position asc) carries over and the merged result
+// is bit-identical to the unsharded one.  One workgroup per row, LDS bitonic sort of R*k <= 16384 keys.
+__global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(const int64_t* __restrict__ gathered, int R, int rows,
+                                                                       int k, int k_out, int npad,
+                                                                       float* __restrict__ out_scores,
+                                                                       int64_t* __restrict__ out_ids) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  const int row = blockIdx.x;
+  const int count = R * k;
+  for (int i = threadIdx.x; i < npad; i += kSortThreads) {
+    unsigned long long kv = 0ull;
+    if (i < count) {
+      const int r = i / k, j = i - r * k;
+      const unsigned int bits = (unsigned int)(unsigned long long)gathered[((int64_t)r * rows + row) * 2 * k + j];
+      kv = ((unsigned long long)orderable(__uint_as_float(bits)) << 32) | (unsigned int)(~(unsigned int)i);
+    }
+    keys[i] = kv;
+  }
+  __syncthreads();
+  for (int size = 2; size <= npad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < (npad >> 1); t += kSortThreads) {
+        const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+        const int hi2 = lo | stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = keys[lo], b = keys[hi2];
+        if ((a < b) == desc) { keys[lo] = b; keys[hi2] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int j = threadIdx.x; j < k_out; j += kSortThreads) {
+    const unsigned long long kv = keys[j];
+    const unsigned int pos = ~(unsigned int)(kv & 0xFFFFFFFFull);
+    const int r = (int)(pos / (unsigned int)k), jj = (int)(pos - (unsigned int)r * (unsigned int)k);
+    out_scores[(int64_t)row * k_out + j] = unorderable((unsigned int)(kv >> 32));
+    out_ids[(int64_t)row * k_out + j] = gathered[((int64_t)r * rows + row) * 2 * k + k + jj];
+  }
+}
+
+int pack_candidates(const float* scores, const int64_t* ids, int rows, int k_local, int k, int64_t* msg, hipStream_t stream) {
+  const int total = rows * k;
+  if (total <= 0) return kOk;
+  hipLaunchKernelGGL(pack_candidates_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, scores, ids, rows, k_local, k, msg);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+int merge_candidates(const int64_t* gathered, int R, int rows, int k, int k_out, float* out_scores, int64_t* out_ids,
+                     hipStream_t stream) {
+  if (rows <= 0 || k_out <= 0) return kOk;
+  const int64_t count = (int64_t)R * k;
+  if (count > kSortCap) { set_error("merge_candidates: R*k = %lld exceeds the in-LDS sort capacity (%d)", (long long)count, kSortCap); return kErrUnsupported; }
+  if (ensure_sort_lds() != kOk) return kErrLaunch;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&merge_candidates_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kSortCap * (int)sizeof(unsigned long long)) != hipSuccess)
+      return kErrLaunch;
+    attr = true;
+  }
+  const int npad = next_pow2((int)count < 2 ? 2 : (int)count);
+  hipLaunchKernelGGL(merge_candidates_kernel, dim3(rows), dim3(kSortThreads), npad * sizeof(unsigned long long), stream, gathered, R,
+                     rows, k, k_out, npad, out_scores, out_ids);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 // ---- candidate-union helpers of MoLNaiveTopK / MoLCombTopK ------------------------------------------------
 // torch.sort(cat(all_indices), dim=1) (mol_top_k.py:257, :515): ascending LDS bitonic sort of each row of int64.
 __global__ __launch_bounds__(kSortThreads) void sort_rows_i64_kernel(const int64_t* __restrict__ in, int n, int npad,

@@ -442,6 +442,31 @@ def topk(scores: torch.Tensor, k: int, ids: Optional[torch.Tensor] = None, sorte
     return out_s, out_i
 
 
+def pack_candidates(scores: torch.Tensor, ids: torch.Tensor, k: int) -> torch.Tensor:
+    """(rows, k_local) fp32 scores + int64 ids -> (rows, 2k) int64 message (score bits | ids), padded with (-inf, -1)."""
+    lib = _lib.load()
+    _require_device(scores, "scores")
+    rows, kl = scores.shape
+    scores, ids = _f32c(scores), ids.to(torch.int64).contiguous()
+    msg = torch.empty((rows, 2 * k), dtype=torch.int64, device=scores.device)
+    with torch.cuda.device(scores.device):
+        _lib.check(lib.rails_pack_candidates(_ptr(scores), _ptr(ids), rows, kl, k, _ptr(msg), _stream()), "rails_pack_candidates")
+    return msg
+
+
+def merge_candidates(gathered: torch.Tensor, n_ranks: int, k: int, k_out: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """gathered (n_ranks * rows, 2k) int64 messages in rank order -> exact top-k_out (scores, ids) per row."""
+    lib = _lib.load()
+    _require_device(gathered, "gathered messages")
+    rows = gathered.shape[0] // n_ranks
+    gathered = gathered.contiguous()
+    out_s = torch.empty((rows, k_out), dtype=torch.float32, device=gathered.device)
+    out_i = torch.empty((rows, k_out), dtype=torch.int64, device=gathered.device)
+    with torch.cuda.device(gathered.device):
+        _lib.check(lib.rails_merge_candidates(_ptr(gathered), n_ranks, rows, k, k_out, _ptr(out_s), _ptr(out_i), _stream()), "rails_merge_candidates")
+    return out_s, out_i
+
+
 def filter_seen_ids(top_ids: torch.Tensor, top_scores: torch.Tensor, invalid_ids: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """Row-wise seen-id filter (reference indexing/candidate_index.py:154-178) -> (ids (rows,k), scores (rows,k))."""
     lib = _lib.load()

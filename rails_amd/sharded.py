@@ -88,7 +88,8 @@ class ShardedMoLBruteForceTopK(TopKModule):
             ids = torch.empty((B, 0), dtype=torch.int64, device=query_embeddings.device)
         if self._world == 1:
             return s, ids
-        msg = pack_candidates(s.float(), ids, k)
+        on_gpu = s.is_cuda and self._merge is _hip_merge
+        msg = E.pack_candidates(s, ids, k) if on_gpu else pack_candidates(s.float(), ids, k)
         # concatenated-along-dim-0 output: the layout both RCCL and gloo accept for all_gather_into_tensor
         if msg.is_cuda and dist.get_backend(self._group) == "gloo":   # test setups only: stage through the host
             host = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype)
@@ -97,6 +98,9 @@ class ShardedMoLBruteForceTopK(TopKModule):
         else:
             gathered = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype, device=msg.device)
             dist.all_gather_into_tensor(gathered, msg, group=self._group)
-        all_s, all_ids = unpack_candidates(gathered.view(self._world, msg.shape[0], msg.shape[1]), k)
-        ms, mi = self._merge(all_s, all_ids, k)
+        if on_gpu:   # one kernel: rank-major candidates -> exact top-k (scores, ids)
+            ms, mi = E.merge_candidates(gathered, self._world, k, k)
+        else:
+            all_s, all_ids = unpack_candidates(gathered.view(self._world, msg.shape[0], msg.shape[1]), k)
+            ms, mi = self._merge(all_s, all_ids, k)
         return ms.to(s.dtype), mi

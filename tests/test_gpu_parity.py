@@ -451,3 +451,27 @@ def test_f16x3_mode_holds_the_logit_tolerance(dev, name):
         cand = fx.t("X").squeeze(0)[fx.t("F6/cand_idx")].to(dev)
         rows, _ = mol(q, cand, **kw_dev(fx, dev))
         assert float((rows.cpu() - fx.t("F6/logits")).abs().max()) <= LOGIT_TOL
+
+
+def test_pack_and_merge_candidates_equal_the_unsharded_topk(dev):
+    """Message pack + merge kernels (the two HIP launches around the single all-gather of the sharded path)."""
+    from rails_amd.sharded import pack_candidates, shard_bounds
+
+    g = torch.Generator().manual_seed(3)
+    rows, n, k, R = 5, 9000, 300, 4
+    scores = torch.randint(0, 50, (rows, n), generator=g).float() / 7.0        # ties across shards
+    ids = torch.arange(n, dtype=torch.int64) * 2 + 5
+    msgs = []
+    for r in range(R):
+        lo, hi = shard_bounds(n, R, r)
+        s, i = E.topk(scores[:, lo:hi].to(dev), min(k, hi - lo), ids=ids[lo:hi].to(dev))
+        m = E.pack_candidates(s, i, k)
+        assert torch.equal(m.cpu(), pack_candidates(s.cpu(), i.cpu(), k))       # same wire format as the torch version
+        msgs.append(m)
+    ms, mi = E.merge_candidates(torch.cat(msgs, 0), R, k, k)
+    rs, rpos = O.select_topk_deterministic(scores, k)
+    assert torch.equal(ms.cpu(), rs) and torch.equal(mi.cpu(), ids[rpos])
+    # a shard shorter than k pads with (-inf, -1)
+    s, i = E.topk(scores[:, :7].to(dev), 7, ids=ids[:7].to(dev))
+    m = E.pack_candidates(s, i, 10).cpu()
+    assert bool((m[:, 17:] == -1).all()) and bool(torch.isinf(m[:, 7:10].to(torch.int32).view(torch.float32)).all())
