@@ -31,28 +31,59 @@ struct QueryArgs {
   float temperature;
 };
 
-// out[c] = bias[c] + sum_k W[c][k] in[k]; a wave owns four output columns at a time (four independent load
-// streams in flight), lanes stride k, then a shuffle reduction per column
+// out[c] = bias[c] + sum_k W[c][k] in[k]; a wave owns four output columns at a time, lanes stride k, then a shuffle
+// reduction per column.  KPL = ceil(K / 64) is a compile-time bound so that all 4 * KPL weight loads of a column group are
+// issued before the first FMA (the layer is a chain of L2 latencies otherwise); accumulation order is k ascending per lane.
+template <int KPL>
+__device__ __forceinline__ void wave_dense_t(const float* __restrict__ W, const float* __restrict__ bias, int ncols,
+                                             int K, const float* __restrict__ in_s, float* __restrict__ out_s,
+                                             bool silu) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = kQueryThreads / 64;
+  float xv[KPL];
+#pragma unroll
+  for (int i = 0; i < KPL; ++i) xv[i] = (lane + 64 * i < K) ? in_s[lane + 64 * i] : 0.0f;
+  for (int c0 = wave * 4; c0 < ncols; c0 += nw * 4) {
+    float wv[4][KPL];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < KPL; ++i)
+        wv[j][i] = (c0 + j < ncols && lane + 64 * i < K) ? W[(int64_t)(c0 + j) * K + lane + 64 * i] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int i = 0; i < KPL; ++i) acc = __builtin_fmaf(wv[j][i], xv[i], acc);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+      if (lane == 0 && c0 + j < ncols) {
+        float v = acc + (bias ? bias[c0 + j] : 0.0f);
+        if (silu) v = v / (1.0f + expf(-v));
+        out_s[c0 + j] = v;
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ void wave_dense(const float* __restrict__ W, const float* __restrict__ bias, int ncols,
                                            int K, const float* __restrict__ in_s, float* __restrict__ out_s,
                                            bool silu) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = kQueryThreads / 64;
-  for (int c0 = wave * 4; c0 < ncols; c0 += nw * 4) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = lane; k < K; k += 64) {
-      const float xv = in_s[k];
+  const int kpl = (K + 63) / 64;
+  if (kpl <= 1) wave_dense_t<1>(W, bias, ncols, K, in_s, out_s, silu);
+  else if (kpl <= 2) wave_dense_t<2>(W, bias, ncols, K, in_s, out_s, silu);
+  else if (kpl <= 4) wave_dense_t<4>(W, bias, ncols, K, in_s, out_s, silu);
+  else if (kpl <= 8) wave_dense_t<8>(W, bias, ncols, K, in_s, out_s, silu);
+  else {  // generic (query_hidden_dim > 512): rolled loop
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = kQueryThreads / 64;
+    for (int c = wave; c < ncols; c += nw) {
+      float acc = 0.0f;
+      for (int k = lane; k < K; k += 64) acc = __builtin_fmaf(W[(int64_t)c * K + k], in_s[k], acc);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (c0 + j < ncols) acc[j] = __builtin_fmaf(W[(int64_t)(c0 + j) * K + k], xv, acc[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o, 64);
-      if (lane == 0 && c0 + j < ncols) {
-        float v = acc[j] + (bias ? bias[c0 + j] : 0.0f);
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+      if (lane == 0) {
+        float v = acc + (bias ? bias[c] : 0.0f);
         if (silu) v = v / (1.0f + expf(-v));
-        out_s[c0 + j] = v;
+        out_s[c] = v;
       }
     }
   }
@@ -87,8 +118,15 @@ __global__ __launch_bounds__(kQueryThreads) void query_prologue_kernel(QueryArgs
   // GLU: h = q W + b (D x 2QH, row-major so lanes stride columns); act(lhs) * rhs
   for (int c = threadIdx.x; c < 2 * QH; c += kQueryThreads) {
     float acc = 0.0f;
-#pragma unroll 8
-    for (int k = 0; k < D; ++k) acc = __builtin_fmaf(qs[k], a.w.q_glu_w[(int64_t)k * 2 * QH + c], acc);
+    int k = 0;
+    for (; k + 16 <= D; k += 16) {   // 16 loads in flight, then 16 FMAs in k order
+      float wv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) wv[i] = a.w.q_glu_w[(int64_t)(k + i) * 2 * QH + c];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc = __builtin_fmaf(qs[k + i], wv[i], acc);
+    }
+    for (; k < D; ++k) acc = __builtin_fmaf(qs[k], a.w.q_glu_w[(int64_t)k * 2 * QH + c], acc);
     glu[c] = acc + a.w.q_glu_b[c];
   }
   __syncthreads();
