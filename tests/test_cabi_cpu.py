@@ -72,3 +72,24 @@ def test_module_mirror_state_dict_and_loud_failure_on_cpu():
         mol(fx.t("q"), fx.t("X"), **fx.kw)
     with pytest.raises(ValueError, match="Invalid top-k method"):
         rails_amd.get_top_k_module("Nope", None, None, None)
+
+
+def test_checkpoint_key_shim_and_extraction():
+    from rails_amd.eval_harness import extract_mol_state_dict
+
+    fx = Fixture("c3_books")
+    ckpt = {"module._ndp_module." + k: v for k, v in fx.weights.items()}
+    # a legacy checkpoint stores the item projection under _item_proj_module (eval_from_checkpoint.py:366-376)
+    for leaf in ("weight", "bias"):
+        new = f"module._ndp_module._item_embeddings_fn._item_emb_proj_module.1.{leaf}"
+        ckpt[f"module._ndp_module._item_proj_module.1.{leaf}"] = ckpt.pop(new)
+    ckpt["module._hstu._some_encoder_weight"] = torch.zeros(3)
+    sd = extract_mol_state_dict(ckpt)
+    assert set(sd) == set(fx.weights)
+    cfg = fx.cfg
+    mol, _ = rails_amd.create_mol_interaction_module(
+        cfg.query_embedding_dim, cfg.item_embedding_dim, cfg.dot_product_dimension, cfg.query_dot_product_groups,
+        cfg.item_dot_product_groups, cfg.temperature, 0.0, cfg.query_hidden_dim, 0.1, cfg.item_hidden_dim,
+        cfg.gating_query_hidden_dim, cfg.gating_qi_hidden_dim, cfg.gating_item_hidden_dim, cfg.softmax_dropout_rate, False,
+        query_nonlinearity=cfg.query_nonlinearity)
+    mol.load_state_dict(sd, strict=True)

@@ -475,3 +475,47 @@ def test_pack_and_merge_candidates_equal_the_unsharded_topk(dev):
     s, i = E.topk(scores[:, :7].to(dev), 7, ids=ids[:7].to(dev))
     m = E.pack_candidates(s, i, 10).cpu()
     assert bool((m[:, 17:] == -1).all()) and bool(torch.isinf(m[:, 7:10].to(torch.int32).view(torch.float32)).all())
+
+
+# ---- section 8(f) rank 3: the eval harness entry points, against the reference harness's own outputs (F5) -----------
+def test_eval_harness_reproduces_the_reference_harness(dev):
+    import random
+
+    from rails_amd import eval_harness as H
+
+    fx = Fixture("harness")
+    mol = build_module(fx.cfg, fx.weights, dev)
+    X, ids, q = fx.t("X").to(dev), fx.t("item_ids"), fx.t("q").to(dev)
+    past, target = fx.t("past_ids").to(dev), fx.t("target_ids").to(dev)
+    id_to_row = {int(v): j for j, v in enumerate(ids.view(-1).tolist())}
+
+    class StubEncoder:                       # the query encoder is upstream of the path: replay its output
+        def encode(self, **kw):
+            return q
+
+        def get_item_embeddings(self, item_ids):
+            flat = item_ids.reshape(-1).tolist()
+            rows = torch.tensor([id_to_row.get(int(v), 0) for v in flat], device=dev)
+            return X[0][rows].reshape(item_ids.shape + (X.shape[-1],))
+
+    model = StubEncoder()
+    holder = type("M", (), {"_ndp_module": mol})()
+    state = H.get_eval_state(model, ids.view(-1).tolist(), None,
+                             lambda e, i: rails_amd.get_top_k_module("MoLBruteForceTopK", holder, e, i), dev)
+    assert state.candidate_index.num_objects == X.shape[1]
+    feats = H.SequentialFeatures(past_lengths=torch.full((q.shape[0],), 61, device=dev), past_ids=past, past_embeddings=None, past_payloads={})
+    for mode, timing in (("accuracy", False), ("timing", True)):
+        random.seed(1)
+        res = H.eval_metrics_v2_from_tensors(state, model, feats, target_ids=target, filter_invalid_ids=True,
+                                             include_eval_time=timing, include_eval_top_k_ids=True)
+        # k = min(2500, N) returns (nearly) the whole corpus sorted: items whose scores differ by < 1e-5 may swap places,
+        # so compare ids position-wise with a small allowance and the metrics (functions of the target's rank) exactly
+        same = (res["eval_top_k_ids"].cpu() == fx.t(f"F5/{mode}/eval_top_k_ids")).float().mean()
+        assert float(same) >= 0.97, float(same)
+        for key in ("hr@1", "hr@5", "hr@10", "hr@50", "hr@100", "hr@200", "hr@500", "hr@1000"):
+            assert torch.equal(res[key].cpu(), fx.t(f"F5/{mode}/{key}")), key
+        for key in ("ndcg@1", "ndcg@5", "ndcg@10", "ndcg@50", "ndcg@100", "ndcg@200", "mrr"):
+            assert torch.allclose(res[key].float().cpu(), fx.t(f"F5/{mode}/{key}").float(), atol=1e-7), key
+        if timing:
+            assert all(t > 0 for t in res["eval_time"])
+    assert abs(float(H._avg(res["hr@10"].float(), 1)) - float(fx.t("F5/timing/hr@10").float().mean())) < 1e-7
