@@ -96,6 +96,56 @@ def cpu_baseline(cfg, weights, q, user_ids, n_total: int, sample_items: int, k_p
     }
 
 
+def quick_workload(name: str, B: int, k: int, kp: int, steps: int, dev) -> dict:
+    """Secondary measurement of another BASELINE.json config on one GPU (same step definition, fewer steps)."""
+    from oracle import mol_oracle as O
+
+    cfg_key, N, width = WORKLOADS[name]
+    cfg = O.CONFIGS[cfg_key]
+    weights = O.synthetic_weights(cfg, seed=0)
+    mol, _ = rails_amd.create_mol_interaction_module(
+        cfg.query_embedding_dim, cfg.item_embedding_dim, cfg.dot_product_dimension, cfg.query_dot_product_groups,
+        cfg.item_dot_product_groups, cfg.temperature, 0.0, cfg.query_hidden_dim, 0.1, cfg.item_hidden_dim,
+        cfg.gating_query_hidden_dim, cfg.gating_qi_hidden_dim, cfg.gating_item_hidden_dim, cfg.softmax_dropout_rate, False,
+        query_nonlinearity=cfg.query_nonlinearity, uid_embedding_hash_sizes=list(cfg.uid_embedding_hash_sizes) or None)
+    mol.load_state_dict(weights, strict=True)
+    mol = mol.to(dev).eval()
+    X = torch.from_numpy(O.hash_item_table(1, 0, N, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = torch.arange(1, N + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B).to(dev)
+    kw = {}
+    if len(cfg.uid_embedding_hash_sizes) > 0:
+        g = torch.Generator().manual_seed(3)
+        kw["user_ids"] = torch.randint(0, cfg.uid_embedding_hash_sizes[0], (B,), generator=g, dtype=torch.int64).to(dev)
+    with torch.inference_mode():
+        tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
+        cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)
+        _, top_ids = tk(q, k=min(kp, N), **kw)
+        inv = torch.zeros((B, width), dtype=torch.int64, device=dev)
+        g = torch.Generator().manual_seed(4)
+        for b in range(B):
+            sel = torch.randperm(top_ids.shape[1], generator=g)[: width // 2].to(dev)
+            inv[b, : width // 2] = top_ids[b, sel]
+        for _ in range(3):
+            cand.get_top_k_outputs(q, k, kw, tk, inv, truncate_k_prime_to=kp)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            cand.get_top_k_outputs(q, k, kw, tk, inv, truncate_k_prime_to=kp)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(steps):
+            tk.all_logits(q, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        score_ms = e0.elapsed_time(e1) / steps   # prologue + scoring kernel
+    return {"workload": f"{name} {cfg.query_dot_product_groups}x{cfg.item_dot_product_groups}x{cfg.dot_product_dimension}, N={N}",
+            "queries_per_s": B / dt, "ms_per_step": dt * 1e3, "prologue_plus_scoring_ms": score_ms,
+            "scoring_tflops_algorithmic_lower_bound": B * N * flops_per_pair(cfg) / (score_ms * 1e-3) / 1e12}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,6 +158,7 @@ def main() -> None:
     ap.add_argument("--cpu-sample-items", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-path", action="store_true", help="skip the extra f16x3 measurement")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the secondary ML-20M / ML-1M measurements")
     args = ap.parse_args()
 
     from oracle import mol_oracle as O  # inputs generator + cpu_baseline checker only
@@ -312,6 +363,9 @@ def main() -> None:
         }
         if fast is not None:
             out["fast_path"] = fast
+        if world == 1 and args.workload == "amzn-books" and not args.no_other_workloads:
+            # the two smaller real-dataset shapes of BASELINE.json (configs 1 and 2): fixed per-batch costs dominate there
+            out["other_workloads"] = [quick_workload(n, B, k, kp, 10, dev) for n in ("ml-20m", "ml-1m")]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, weights, q_cpu, uid_cpu, N, min(args.cpu_sample_items, N), kp)
         print(json.dumps(out), flush=True)
