@@ -8,7 +8,10 @@
 // distinct, so "the k largest keys" is a unique set and its descending order is "score descending,
 // then position ascending" -- the deterministic tie rule that makes 1/2/4/8-GPU results identical.
 //
-//   n <= 16384  one workgroup per row bitonic-sorts the whole row in LDS.
+//   n <= 1024   one workgroup per row bitonic-sorts the whole row in LDS (also n <= 16384 with k > 4096).
+//   n <= 40960  one workgroup per row holds the row in registers (<= 40 scores per thread), finds the k-th largest score
+//               by a 2-bits-per-step radix bisection (ballot counts, no atomics), compacts the k keys into LDS
+//               (ties by position, in order) and sorts them: one launch instead of nine.
 //   larger n    MSB-first radix select over the 32 score bits (11/11/10, LDS histograms) finds the k-th largest
 //               score; if that score is tied, one in-order scan of the row finds the position of the last tied
 //               element to take, which completes the 64-bit threshold key T; one compaction pass gathers the
@@ -49,6 +52,36 @@ __device__ __forceinline__ unsigned long long make_key(float score, unsigned int
   return ((unsigned long long)orderable(score) << 32) | (unsigned int)(~pos);
 }
 
+// ---- block bitonic sort, one key per thread (npad <= 1024) ----------------------------------------------------
+// Thread i holds key i.  Compare-exchange partners at distance < 64 sit in the same wavefront and are exchanged with
+// ds_bpermute (no barrier); only the distances >= 64 go through LDS (one barrier each, double-buffered): 3 barriers for
+// 256 keys, 10 for 1024, against 36 / 55 barrier-separated LDS passes for the plain loop (~0.4 us each with 16 waves).
+// Returns the key of descending rank threadIdx.x.  `buf` needs 2 * npad entries; all threads of the block must call.
+__device__ __forceinline__ unsigned long long block_sort_desc(unsigned long long key, int npad, unsigned long long* buf) {
+  const int i = threadIdx.x;
+  int flip = 0;
+  for (int size = 2; size <= npad; size <<= 1) {
+    const bool desc = (i & size) == 0;
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      unsigned long long other;
+      if (stride >= 64) {
+        unsigned long long* b = buf + flip * npad;
+        flip ^= 1;
+        if (i < npad) b[i] = key;
+        __syncthreads();
+        other = i < npad ? b[i ^ stride] : 0ull;
+      } else {
+        other = __shfl_xor(key, stride, 64);
+      }
+      const bool lower = (i & stride) == 0;
+      const bool take_max = lower == desc;
+      const unsigned long long mx = key > other ? key : other, mn = key > other ? other : key;
+      key = take_max ? mx : mn;
+    }
+  }
+  return key;
+}
+
 // ---- LDS bitonic sort (descending) + emit ------------------------------------------------------
 // Input: keys from cand[row*cand_ld + i], i < count (cand != NULL), else from scores[row*ld + begin + i] with positions
 // begin + i, where [begin, begin + count) is this workgroup's chunk of the row (blockIdx.y * chunk ...).
@@ -73,6 +106,13 @@ __global__ __launch_bounds__(kSortThreads) void sort_emit_kernel(const float* __
     keys[i] = kv;
   }
   __syncthreads();
+  if (npad <= kSortThreads) {   // one key per thread, sorted mostly in registers; keys[npad, 3 npad) is the exchange buffer
+    unsigned long long kv = (int)threadIdx.x < npad ? keys[threadIdx.x] : 0ull;
+    kv = block_sort_desc(kv, npad, keys + npad);
+    __syncthreads();
+    if ((int)threadIdx.x < npad) keys[threadIdx.x] = kv;
+    __syncthreads();
+  } else
   for (int size = 2; size <= npad; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       for (int t = threadIdx.x; t < (npad >> 1); t += kSortThreads) {
@@ -246,12 +286,200 @@ __global__ __launch_bounds__(kHistThreads) void compact_kernel(const float* __re
   });
 }
 
+// ---- single-launch select for rows that fit one workgroup's registers --------------------------------------------
+// Thread t holds the orderable scores of positions j*1024 + t, j < VPT (0 = padding, below every real score).
+// The k-th largest value T is the largest T with count(v >= T) >= k: resolve it two bits per step from the top.
+constexpr int kRowThreads = 1024;
+constexpr int kRowWaves = kRowThreads / 64;
+constexpr int kRowMaxK = 4096;
+
+constexpr int kRowCandCap = 4096;   // candidate keys the fast path may hand to the LDS sort
+
+template <int VPT>
+__global__ __launch_bounds__(kRowThreads) void row_select_kernel(const float* __restrict__ scores, int64_t ld, int n, int k,
+                                                                int lds_keys, const int64_t* __restrict__ ids,
+                                                                int64_t ids_row_stride, float* __restrict__ out_scores,
+                                                                int64_t* __restrict__ out_ids) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // lds_keys candidate keys
+  __shared__ unsigned int slot[2][3][kRowWaves];
+  __shared__ unsigned int cursor;
+  const int row = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* rowp = scores + (int64_t)row * ld;
+  unsigned int v[VPT];
+  unsigned int tmax = 0u;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int i = j * kRowThreads + threadIdx.x;
+    v[j] = i < n ? orderable(rowp[i]) : 0u;
+    tmax = v[j] > tmax ? v[j] : tmax;
+  }
+  if (threadIdx.x == 0) cursor = 0u;
+  for (int i = threadIdx.x; i < lds_keys; i += kRowThreads) keys[i] = 0ull;
+
+  // block-wide sums of three wave-uniform counters; one barrier per call (slots alternate by parity)
+  int it = 0;
+  auto wave_sum3 = [&](unsigned int a1, unsigned int a2, unsigned int a3, unsigned int& n1, unsigned int& n2, unsigned int& n3) {
+    const int par = it & 1;
+    ++it;
+    if (lane == 0) { slot[par][0][wave] = a1; slot[par][1][wave] = a2; slot[par][2][wave] = a3; }
+    __syncthreads();
+    n1 = n2 = n3 = 0;
+#pragma unroll
+    for (int w = 0; w < kRowWaves; ++w) { n1 += slot[par][0][w]; n2 += slot[par][1][w]; n3 += slot[par][2][w]; }
+  };
+  auto count3 = [&](unsigned int c1, unsigned int c2, unsigned int c3, unsigned int& n1, unsigned int& n2, unsigned int& n3) {
+    unsigned int a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) { a1 += v[j] >= c1; a2 += v[j] >= c2; a3 += v[j] >= c3; }
+    unsigned long long pk = (unsigned long long)a1 | ((unsigned long long)a2 << 21) | ((unsigned long long)a3 << 42);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pk += __shfl_xor(pk, o, 64);
+    wave_sum3((unsigned int)(pk & 0x1FFFFFu), (unsigned int)((pk >> 21) & 0x1FFFFFu), (unsigned int)(pk >> 42), n1, n2, n3);
+  };
+  auto emit = [&](unsigned long long kv, int j) {
+    const unsigned int pos = ~(unsigned int)(kv & 0xFFFFFFFFull);
+    out_scores[(int64_t)row * k + j] = unorderable((unsigned int)(kv >> 32));
+    out_ids[(int64_t)row * k + j] = ids ? ids[ids_row_stride * row + pos] : (int64_t)pos;
+  };
+  auto emit_sorted = [&](int npad) {   // sort keys[0, npad) descending, write the first k
+    __syncthreads();
+    if (npad <= kRowThreads) {
+      unsigned long long kv = (int)threadIdx.x < npad ? keys[threadIdx.x] : 0ull;
+      kv = block_sort_desc(kv, npad, keys + lds_keys);
+      if ((int)threadIdx.x < k) emit(kv, threadIdx.x);
+      return;
+    }
+    for (int size = 2; size <= npad; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int t = threadIdx.x; t < (npad >> 1); t += kRowThreads) {
+          const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+          const int hi2 = lo | stride;
+          const bool desc = ((lo & size) == 0);
+          const unsigned long long a = keys[lo], b = keys[hi2];
+          if ((a < b) == desc) { keys[lo] = b; keys[hi2] = a; }
+        }
+        __syncthreads();
+      }
+    }
+    for (int j = threadIdx.x; j < k; j += kRowThreads) emit(keys[j], j);
+  };
+  auto compact = [&](auto pred) {      // append the keys of the selected elements, any order; overflow is dropped
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const bool sel = (j * kRowThreads + (int)threadIdx.x < n) && pred(v[j]);
+      const unsigned long long m = __ballot(sel);
+      if (m) {
+        const int leader = __ffsll((long long)m) - 1;
+        unsigned int base = 0;
+        if (lane == leader) base = atomicAdd(&cursor, (unsigned int)__popcll(m));
+        base = (unsigned int)__shfl((int)base, leader, 64);
+        const unsigned int at = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+        if (sel && at < (unsigned int)lds_keys) {
+          const unsigned int pos = (unsigned int)(j * kRowThreads) + threadIdx.x;
+          keys[at] = ((unsigned long long)v[j] << 32) | (unsigned int)(~pos);
+        }
+      }
+    }
+  };
+
+  // ---- fast path: a lower bound from the per-thread maxima -----------------------------------------------------
+  // The k-th largest of any subset of the row is <= the row's k-th largest, so any L <= (k-th largest thread maximum)
+  // bounds the answer from below and every wanted key is among {v >= L}.  L is resolved to its top 16 bits only (8 steps
+  // of 2 bits; a slightly lower bound only admits a few more candidates).  Positions are dealt round-robin to threads, so
+  // for untied data only about -1024 ln(1 - k/1024) elements pass (222 for k = 200); they are sorted as 64-bit keys,
+  // which settles ties by position.  Heavy ties or adversarial layouts overflow the candidate buffer and fall through.
+  if (k <= kRowThreads / 2) {
+    unsigned int L = 0u;
+    for (int bit = 30; bit >= 16; bit -= 2) {
+      const unsigned int c1 = L | (1u << bit), c2 = L | (2u << bit), c3 = L | (3u << bit);
+      unsigned int n1, n2, n3;
+      wave_sum3((unsigned int)__popcll(__ballot(tmax >= c1)), (unsigned int)__popcll(__ballot(tmax >= c2)),
+                (unsigned int)__popcll(__ballot(tmax >= c3)), n1, n2, n3);
+      L = n3 >= (unsigned int)k ? c3 : n2 >= (unsigned int)k ? c2 : n1 >= (unsigned int)k ? c1 : L;
+    }
+    compact([&](unsigned int x) { return x >= L; });
+    __syncthreads();
+    const unsigned int m_ge = cursor;
+    if (m_ge <= (unsigned int)lds_keys) {
+      int npad = 2;
+      while (npad < (int)m_ge) npad <<= 1;
+      emit_sorted(npad);
+      return;
+    }
+    __syncthreads();                       // everyone has read the cursor: start over on the general path
+    if (threadIdx.x == 0) cursor = 0u;
+    for (int i = threadIdx.x; i < lds_keys; i += kRowThreads) keys[i] = 0ull;
+  }
+
+  // ---- general path: the k-th largest value T is the largest T with count(v >= T) >= k; two bits per step --------
+  unsigned int prefix = 0u;
+  for (int bit = 30; bit >= 0; bit -= 2) {
+    const unsigned int c1 = prefix | (1u << bit), c2 = prefix | (2u << bit), c3 = prefix | (3u << bit);
+    unsigned int n1, n2, n3;
+    count3(c1, c2, c3, n1, n2, n3);
+    prefix = n3 >= (unsigned int)k ? c3 : n2 >= (unsigned int)k ? c2 : n1 >= (unsigned int)k ? c1 : prefix;
+  }
+  const unsigned int T = prefix;
+  // strictly above T / equal to T  (T = 0xFFFFFFFF is a NaN pattern above every score: nothing is above it)
+  unsigned int n_ge, n_gt, unused;
+  const unsigned int Tp = T == 0xFFFFFFFFu ? T : T + 1u;
+  count3(T, Tp, Tp, n_ge, n_gt, unused);
+  if (T == 0xFFFFFFFFu) n_gt = 0u;
+  const unsigned int need_eq = (unsigned int)k - n_gt;   // >= 1
+  const bool all_eq = (n_ge - n_gt) == need_eq;          // every tied element is wanted: no ordering needed
+  if (all_eq) {
+    compact([&](unsigned int x) { return x >= T; });
+  } else {
+    compact([&](unsigned int x) { return x > T; });
+    // ties at T: take the need_eq lowest positions.  Positions j*1024 + t ascend with (j, t): an in-order scan.
+    unsigned int running = 0;
+    for (int j = 0; j < VPT; ++j) {     // uniform trip count / uniform break
+      const bool match = v[j] == T && (j * kRowThreads + (int)threadIdx.x) < n;
+      const unsigned long long bal = __ballot(match);
+      const int par = it & 1;
+      ++it;
+      if (lane == 0) slot[par][0][wave] = (unsigned int)__popcll(bal);
+      __syncthreads();
+      unsigned int before = running, total = 0;
+#pragma unroll
+      for (int w = 0; w < kRowWaves; ++w) {
+        const unsigned int c = slot[par][0][w];
+        if (w < wave) before += c;
+        total += c;
+      }
+      const unsigned int rank = before + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull));
+      if (match && rank < need_eq) {
+        const unsigned int pos = (unsigned int)(j * kRowThreads) + threadIdx.x;
+        keys[n_gt + rank] = ((unsigned long long)T << 32) | (unsigned int)(~pos);
+      }
+      running += total;
+      if (running >= need_eq) break;
+    }
+  }
+  int npad = 2;
+  while (npad < k) npad <<= 1;
+  emit_sorted(npad);
+}
+
+template <int VPT>
+static int launch_row_select(const float* scores, int64_t ld, int rows, int n, int k, const int64_t* ids, int64_t ids_row_stride,
+                             float* out_scores, int64_t* out_ids, hipStream_t stream) {
+  int lds_keys = 2;
+  while (lds_keys < k) lds_keys <<= 1;
+  if (k <= kRowThreads / 2) lds_keys = kRowCandCap;     // room for the pre-filtered candidates
+  // + the 2 x 1024-key exchange buffer of block_sort_desc
+  hipLaunchKernelGGL(row_select_kernel<VPT>, dim3(rows), dim3(kRowThreads), (lds_keys + 2 * kRowThreads) * sizeof(unsigned long long), stream,
+                     scores, ld, n, k, lds_keys, ids, ids_row_stride, out_scores, out_ids);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 size_t topk_workspace_bytes(int rows, int64_t n, int k) {
-  if (n <= kSortCap) return 256;
+  if (n <= kSortCap || (n <= 40 * 1024 && k <= 4096)) return 256;   // single-launch paths need no workspace
   size_t b = align_up(sizeof(SelectState) * (size_t)rows, 256);
   b += align_up(sizeof(unsigned int) * (size_t)kRadixPasses * rows * kBins, 256);
   b += align_up(sizeof(unsigned long long) * (size_t)rows * k, 256);
@@ -274,9 +502,17 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
   if (k > kSortCap) { set_error("k = %d exceeds the in-LDS sort capacity (%d)", k, kSortCap); return kErrUnsupported; }
   if (n >= (1ll << 32)) { set_error("n = %lld does not fit 32-bit positions; shard the corpus", (long long)n); return kErrUnsupported; }
   if (ensure_sort_lds() != kOk) return kErrLaunch;
+  if (n > 1024 && n <= 40 * kRowThreads && k <= kRowMaxK) {
+    const int ni = (int)n;
+    if (ni <= 4 * kRowThreads) return launch_row_select<4>(scores, ld, rows, ni, k, ids, ids_row_stride, out_scores, out_ids, stream);
+    if (ni <= 8 * kRowThreads) return launch_row_select<8>(scores, ld, rows, ni, k, ids, ids_row_stride, out_scores, out_ids, stream);
+    if (ni <= 16 * kRowThreads) return launch_row_select<16>(scores, ld, rows, ni, k, ids, ids_row_stride, out_scores, out_ids, stream);
+    if (ni <= 28 * kRowThreads) return launch_row_select<28>(scores, ld, rows, ni, k, ids, ids_row_stride, out_scores, out_ids, stream);
+    return launch_row_select<40>(scores, ld, rows, ni, k, ids, ids_row_stride, out_scores, out_ids, stream);
+  }
   if (n <= kSortCap) {
     const int npad = next_pow2((int)n < 2 ? 2 : (int)n);
-    hipLaunchKernelGGL(sort_emit_kernel, dim3(rows), dim3(kSortThreads), npad * sizeof(unsigned long long), stream,
+    hipLaunchKernelGGL(sort_emit_kernel, dim3(rows), dim3(kSortThreads), (npad <= kSortThreads ? 3 * npad : npad) * sizeof(unsigned long long), stream,
                        scores, ld, n, n, (const unsigned long long*)nullptr, (int64_t)0, 0, k, npad, ids, ids_row_stride,
                        out_scores, out_ids, (unsigned long long*)nullptr, (int64_t)0);
     return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
@@ -307,7 +543,7 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
   hipLaunchKernelGGL(compact_kernel, dim3((unsigned)chunks, rows), dim3(kHistThreads), 0, stream, scores, ld, n, st, cand,
                      (int64_t)k, k, chunk);
   const int npad = next_pow2(k < 2 ? 2 : k);
-  hipLaunchKernelGGL(sort_emit_kernel, dim3(rows), dim3(kSortThreads), npad * sizeof(unsigned long long), stream, scores, ld, n, n,
+  hipLaunchKernelGGL(sort_emit_kernel, dim3(rows), dim3(kSortThreads), (npad <= kSortThreads ? 3 * npad : npad) * sizeof(unsigned long long), stream, scores, ld, n, n,
                      cand, (int64_t)k, k, k, npad, ids, ids_row_stride, out_scores, out_ids, (unsigned long long*)nullptr,
                      (int64_t)0);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;

@@ -89,6 +89,28 @@ def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _on_device:
+    """`with _on_device(dev)`: make `dev` the current HIP device for the enclosed launches.  Unlike torch.cuda.device it
+    costs nothing when `dev` already is current (the one-process-per-GPU case), which matters for sub-millisecond steps."""
+
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, dev: torch.device):
+        self.idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.prev = -1
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            torch.cuda.set_device(self.prev)
+        return False
+
+
 def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
     return C.c_void_p(0 if t is None else t.data_ptr())
 
@@ -152,7 +174,7 @@ class MolEngine:
         n = self.lib.rails_mol_gate_pack_floats(C.byref(self.shape))
         self.gate_pack = torch.empty(n, dtype=torch.float32, device=self.device)
         self.split_scales = None
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             if self.precision == "f16x3":
                 self.split_scales = self._choose_split_scales(weights)
                 _lib.check(
@@ -198,7 +220,7 @@ class MolEngine:
         n = items.shape[0]
         floats = self.lib.rails_mol_index_floats(C.byref(self.shape), n)
         buf = torch.empty(floats, dtype=torch.float32, device=items.device)
-        with torch.cuda.device(items.device):
+        with _on_device(items.device):
             _lib.check(
                 self.lib.rails_mol_index_build(C.byref(self.shape), C.byref(self.weights), _ptr(items), n, _ptr(buf), _stream()),
                 "rails_mol_index_build",
@@ -209,7 +231,7 @@ class MolEngine:
         s = self.spec
         ex = torch.empty((index.n_items, s.item_dot_product_groups, s.dot_product_dimension), dtype=torch.float32, device=index.buf.device) if want_ex else None
         gi = torch.empty((index.n_items, s.num_logits), dtype=torch.float32, device=index.buf.device) if want_gi else None
-        with torch.cuda.device(index.buf.device):
+        with _on_device(index.buf.device):
             _lib.check(
                 self.lib.rails_mol_index_unpack(C.byref(self.shape), _ptr(index.buf), index.n_items, _ptr(ex), _ptr(gi), _stream()),
                 "rails_mol_index_unpack",
@@ -227,7 +249,7 @@ class MolEngine:
         idx = idx.contiguous()
         floats = self.lib.rails_mol_index_floats(C.byref(self.shape), rows * Kp)
         out = torch.empty(floats, dtype=torch.float32, device=idx.device)
-        with torch.cuda.device(idx.device):
+        with _on_device(idx.device):
             _lib.check(
                 self.lib.rails_mol_index_gather(C.byref(self.shape), _ptr(index.buf), index.n_items, _ptr(idx), rows, Kp, _ptr(out), _stream()),
                 "rails_mol_index_gather",
@@ -235,7 +257,8 @@ class MolEngine:
         return MolIndex(out, rows * Kp), Kp
 
     # ---- query side ---------------------------------------------------------------------------
-    def query_pack(self, q: torch.Tensor, user_ids: Optional[torch.Tensor] = None, want_plain: bool = False):
+    def query_pack(self, q: torch.Tensor, user_ids: Optional[torch.Tensor] = None, want_plain: bool = False,
+                   out: Optional[torch.Tensor] = None):
         _require_device(q, "query_embeddings")
         if q.dim() != 2 or q.shape[1] != self.spec.query_embedding_dim:
             raise ValueError(f"query_embeddings must be (B, {self.spec.query_embedding_dim}), got {tuple(q.shape)}")
@@ -247,11 +270,11 @@ class MolEngine:
                 raise KeyError("user_ids")  # the reference does kwargs["user_ids"] (query_embeddings_fns.py:206)
             uid = user_ids.to(device=q.device, dtype=torch.int64).contiguous()
         n = self.lib.rails_mol_query_pack_floats(C.byref(self.shape), B)
-        pack = torch.empty(n, dtype=torch.float32, device=q.device)
+        pack = out if out is not None and out.numel() == n and out.device == q.device else torch.empty(n, dtype=torch.float32, device=q.device)
         s = self.spec
         eq = torch.empty((B, s.query_dot_product_groups, s.dot_product_dimension), dtype=torch.float32, device=q.device) if want_plain else None
         gq = torch.empty((B, s.num_logits), dtype=torch.float32, device=q.device) if want_plain else None
-        with torch.cuda.device(q.device):
+        with _on_device(q.device):
             _lib.check(
                 self.lib.rails_mol_query_prologue(C.byref(self.shape), C.byref(self.weights), _ptr(q), _ptr(uid), B, _ptr(pack), _ptr(eq), _ptr(gq), _stream()),
                 "rails_mol_query_prologue",
@@ -262,7 +285,7 @@ class MolEngine:
     def score_dense(self, qpack: torch.Tensor, batch: int, index: MolIndex, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:
             out = torch.empty((batch, index.n_items), dtype=torch.float32, device=index.buf.device)
-        with torch.cuda.device(index.buf.device):
+        with _on_device(index.buf.device):
             if self.split_scales is not None:
                 _lib.check(
                     self.lib.rails_mol_score_dense_split(C.byref(self.shape), _ptr(self.gate_pack), C.byref(self.split_scales), _ptr(qpack), batch, _ptr(index.buf), index.n_items, _ptr(out), out.stride(0), _stream()),
@@ -277,7 +300,7 @@ class MolEngine:
 
     def score_candidates(self, qpack: torch.Tensor, batch: int, cand_index: MolIndex, n_cand_padded: int) -> torch.Tensor:
         out = torch.empty((batch, n_cand_padded), dtype=torch.float32, device=cand_index.buf.device)
-        with torch.cuda.device(cand_index.buf.device):
+        with _on_device(cand_index.buf.device):
             if self.split_scales is not None:
                 _lib.check(
                     self.lib.rails_mol_score_candidates_split(C.byref(self.shape), _ptr(self.gate_pack), C.byref(self.split_scales), _ptr(qpack), batch, _ptr(cand_index.buf), n_cand_padded, _ptr(out), out.stride(0), _stream()),
@@ -296,7 +319,7 @@ class MolEngine:
         """(N, d) bf16 table of P_X-averaged component embeddings (reference mol_top_k.py:321-325)."""
         nbytes = self.lib.rails_mol_coarse_table_bytes(C.byref(self.shape), index.n_items)
         table = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=index.buf.device)
-        with torch.cuda.device(index.buf.device):
+        with _on_device(index.buf.device):
             _lib.check(
                 self.lib.rails_mol_coarse_build(C.byref(self.shape), _ptr(index.buf), index.n_items, _ptr(table), _stream()),
                 "rails_mol_coarse_build",
@@ -308,7 +331,7 @@ class MolEngine:
         B, n = eq.shape[0], table.shape[0]
         eq = _f32c(eq)
         out = torch.empty((B, n), dtype=torch.float32, device=table.device)
-        with torch.cuda.device(table.device):
+        with _on_device(table.device):
             _lib.check(
                 self.lib.rails_mol_coarse_score(C.byref(self.shape), _ptr(eq), B, 1 if average_queries else 0, _ptr(table), n, _ptr(out), out.stride(0), _stream()),
                 "rails_mol_coarse_score",
@@ -321,7 +344,7 @@ class MolEngine:
         """(N, P_X, d) bf16 component embeddings (reference mol_top_k.py:61-73)."""
         nbytes = self.lib.rails_mol_component_table_bytes(C.byref(self.shape), index.n_items)
         table = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=index.buf.device)
-        with torch.cuda.device(index.buf.device):
+        with _on_device(index.buf.device):
             _lib.check(
                 self.lib.rails_mol_component_build(C.byref(self.shape), _ptr(index.buf), index.n_items, _ptr(table), _stream()),
                 "rails_mol_component_build",
@@ -334,7 +357,7 @@ class MolEngine:
         eq = _f32c(eq)
         rows = B * self.spec.query_dot_product_groups * self.spec.item_dot_product_groups
         out = torch.empty((rows, n), dtype=torch.float32, device=table.device)
-        with torch.cuda.device(table.device):
+        with _on_device(table.device):
             _lib.check(
                 self.lib.rails_mol_component_score(C.byref(self.shape), _ptr(eq), B, _ptr(table), n, _ptr(out), out.stride(0), _stream()),
                 "rails_mol_component_score",
@@ -348,7 +371,7 @@ def sort_rows(idx: torch.Tensor) -> torch.Tensor:
     _require_device(idx, "indices")
     idx = idx.to(torch.int64).contiguous()
     out = torch.empty_like(idx)
-    with torch.cuda.device(idx.device):
+    with _on_device(idx.device):
         _lib.check(lib.rails_sort_rows_i64(_ptr(idx), idx.shape[0], idx.shape[1], _ptr(out), _stream()), "rails_sort_rows_i64")
     return out
 
@@ -358,7 +381,7 @@ def mask_sorted_duplicates(sorted_idx: torch.Tensor, scores: torch.Tensor, fill:
     lib = _lib.load()
     rows, n = sorted_idx.shape
     assert scores.dtype == torch.float32 and scores.stride(1) == 1
-    with torch.cuda.device(scores.device):
+    with _on_device(scores.device):
         _lib.check(
             lib.rails_mask_sorted_duplicates(_ptr(sorted_idx), _ptr(scores), scores.stride(0), rows, n, C.c_float(fill), _stream()),
             "rails_mask_sorted_duplicates",
@@ -375,7 +398,7 @@ class MipsIndex:
         items = _f32c(items)
         self.n_items, self.dim = items.shape
         self.buf = torch.empty(lib.rails_mips_index_floats(self.dim, self.n_items), dtype=torch.float32, device=items.device)
-        with torch.cuda.device(items.device):
+        with _on_device(items.device):
             _lib.check(lib.rails_mips_index_build(_ptr(items), self.n_items, self.dim, _ptr(self.buf), _stream()), "rails_mips_index_build")
 
     def score(self, q: torch.Tensor) -> torch.Tensor:
@@ -388,7 +411,7 @@ class MipsIndex:
         B = q.shape[0]
         ws = torch.empty(lib.rails_mips_query_ws_floats(self.dim, B), dtype=torch.float32, device=q.device)
         out = torch.empty((B, self.n_items), dtype=torch.float32, device=q.device)
-        with torch.cuda.device(q.device):
+        with _on_device(q.device):
             _lib.check(lib.rails_mips_score(_ptr(q), B, self.dim, _ptr(self.buf), self.n_items, _ptr(ws), _ptr(out), out.stride(0), _stream()), "rails_mips_score")
         return out
 
@@ -401,13 +424,14 @@ def dot_rowwise(q: torch.Tensor, items: torch.Tensor) -> torch.Tensor:
     Bq, D = q.shape
     BI, X, _ = items.shape
     out = torch.empty((Bq, X), dtype=torch.float32, device=q.device)
-    with torch.cuda.device(q.device):
+    with _on_device(q.device):
         _lib.check(lib.rails_dot_rowwise(_ptr(q), _ptr(items), Bq, X, D, Bq // BI, _ptr(out), _stream()), "rails_dot_rowwise")
     return out
 
 
 # ---- shape-independent kernels ----------------------------------------------------------------
-def topk(scores: torch.Tensor, k: int, ids: Optional[torch.Tensor] = None, sorted: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+def topk(scores: torch.Tensor, k: int, ids: Optional[torch.Tensor] = None, sorted: bool = True,
+         workspace: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Exact top-k of every row of `scores` (rows, n) fp32 on the GPU; ties by position ascending.
     ids: None -> positions; (n,) or (1, n) -> shared id row; (rows, n) -> per-row ids.
     Replaces torch.topk + id gather (reference rails/indexing/mol_top_k.py:123-130)."""
@@ -422,7 +446,8 @@ def topk(scores: torch.Tensor, k: int, ids: Optional[torch.Tensor] = None, sorte
         raise RuntimeError(f"selected index k out of range (k={k}, n={n})")  # what torch.topk raises
     stride = 0
     if ids is not None:
-        ids = ids.to(device=scores.device, dtype=torch.int64)
+        if ids.dtype != torch.int64 or ids.device != scores.device:
+            ids = ids.to(device=scores.device, dtype=torch.int64)
         if ids.dim() == 2 and ids.shape[0] == rows and rows > 1:
             ids = ids.contiguous()
             stride = ids.shape[1]
@@ -433,8 +458,8 @@ def topk(scores: torch.Tensor, k: int, ids: Optional[torch.Tensor] = None, sorte
     out_s = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
     out_i = torch.empty((rows, k), dtype=torch.int64, device=scores.device)
     ws_bytes = lib.rails_topk_workspace_bytes(rows, n, k)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=scores.device)
-    with torch.cuda.device(scores.device):
+    ws = workspace if workspace is not None and workspace.numel() >= ws_bytes and workspace.device == scores.device else torch.empty(ws_bytes, dtype=torch.uint8, device=scores.device)
+    with _on_device(scores.device):
         _lib.check(
             lib.rails_topk(_ptr(scores), scores.stride(0), rows, n, k, 1 if sorted else 0, _ptr(ids), stride, _ptr(out_s), _ptr(out_i), _ptr(ws), ws_bytes, _stream()),
             "rails_topk",
@@ -449,7 +474,7 @@ def pack_candidates(scores: torch.Tensor, ids: torch.Tensor, k: int) -> torch.Te
     rows, kl = scores.shape
     scores, ids = _f32c(scores), ids.to(torch.int64).contiguous()
     msg = torch.empty((rows, 2 * k), dtype=torch.int64, device=scores.device)
-    with torch.cuda.device(scores.device):
+    with _on_device(scores.device):
         _lib.check(lib.rails_pack_candidates(_ptr(scores), _ptr(ids), rows, kl, k, _ptr(msg), _stream()), "rails_pack_candidates")
     return msg
 
@@ -462,7 +487,7 @@ def merge_candidates(gathered: torch.Tensor, n_ranks: int, k: int, k_out: int) -
     gathered = gathered.contiguous()
     out_s = torch.empty((rows, k_out), dtype=torch.float32, device=gathered.device)
     out_i = torch.empty((rows, k_out), dtype=torch.int64, device=gathered.device)
-    with torch.cuda.device(gathered.device):
+    with _on_device(gathered.device):
         _lib.check(lib.rails_merge_candidates(_ptr(gathered), n_ranks, rows, k, k_out, _ptr(out_s), _ptr(out_i), _stream()), "rails_merge_candidates")
     return out_s, out_i
 
@@ -478,7 +503,7 @@ def filter_seen_ids(top_ids: torch.Tensor, top_scores: torch.Tensor, invalid_ids
     inv = invalid_ids.to(device=top_ids.device, dtype=torch.int64).contiguous()
     out_i = torch.empty((rows, k), dtype=torch.int64, device=top_ids.device)
     out_s = torch.empty((rows, k), dtype=torch.float32, device=top_ids.device)
-    with torch.cuda.device(top_ids.device):
+    with _on_device(top_ids.device):
         _lib.check(
             lib.rails_filter_seen_ids(_ptr(top_ids), _ptr(top_scores), rows, kp, _ptr(inv), inv.shape[1], k, _ptr(out_i), _ptr(out_s), _stream()),
             "rails_filter_seen_ids",

@@ -42,7 +42,18 @@ class MoLTopKModule(TopKModule):
         self._ids_flat: torch.Tensor = item_ids.reshape(-1).to(device=item_embeddings.device, dtype=torch.int64).contiguous()
         self._engine: Optional[E.MolEngine] = None
         self._index: Optional[E.MolIndex] = None
+        self._scratch: Dict[tuple, torch.Tensor] = {}   # internal buffers recycled across calls (never returned)
         self._bind()
+
+    def _buf(self, tag: str, numel: int, dtype: torch.dtype) -> torch.Tensor:
+        key = (tag, numel, dtype)
+        t = self._scratch.get(key)
+        if t is None:
+            if len(self._scratch) > 16:
+                self._scratch.clear()
+            t = torch.empty(numel, dtype=dtype, device=self._item_embeddings.device)
+            self._scratch[key] = t
+        return t
 
     @property
     def mol_module(self) -> MoLSimilarity:
@@ -65,14 +76,24 @@ class MoLTopKModule(TopKModule):
         qpack, _, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"))
         return eng.score_dense(qpack, query_embeddings.size(0), self._index)
 
+    def _all_logits_scratch(self, query_embeddings: torch.Tensor, **kwargs) -> torch.Tensor:
+        """Same, into recycled internal buffers (the result is consumed by the top-k before the next call)."""
+        eng = self._bind()
+        B = query_embeddings.size(0)
+        n_q = eng.lib.rails_mol_query_pack_floats(E.C.byref(eng.shape), B)
+        qpack, _, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"), out=self._buf("qpack", n_q, torch.float32))
+        logits = self._buf("logits", B * self._index.n_items, torch.float32).view(B, self._index.n_items)
+        return eng.score_dense(qpack, B, self._index, out=logits)
+
 
 class MoLBruteForceTopK(MoLTopKModule):
     def __init__(self, mol_module: MoLSimilarity, item_embeddings: torch.Tensor, item_ids: torch.Tensor) -> None:
         super().__init__(mol_module=mol_module, item_embeddings=item_embeddings, item_ids=item_ids)
 
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
-        logits = self.all_logits(query_embeddings, **kwargs)
-        scores, ids = E.topk(logits, k, ids=self._ids_flat, sorted=sorted)
+        logits = self._all_logits_scratch(query_embeddings, **kwargs)
+        ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(logits.shape[0], logits.shape[1], k), torch.uint8)
+        scores, ids = E.topk(logits, k, ids=self._ids_flat, sorted=sorted, workspace=ws)
         return scores.to(query_embeddings.dtype), ids
 
 

@@ -140,7 +140,10 @@ def test_f7_full_size(name, dev):
 
 # ---- selection kernels on their own ---------------------------------------------------------------
 @pytest.mark.parametrize("rows,n,k", [(1, 1, 1), (3, 37, 5), (4, 1000, 1000), (2, 16384, 300), (5, 16385, 200),
-                                      (32, 100000, 2711), (1, 3000000, 16384), (7, 70001, 1)])
+                                      (32, 100000, 2711), (1, 3000000, 16384), (7, 70001, 1),
+                                      # single-launch register-resident select: every per-thread width and both edges
+                                      (3, 1025, 200), (4, 4096, 4096), (2, 8193, 17), (3, 27278, 200), (3, 30000, 1),
+                                      (2, 40960, 4096), (2, 40961, 100), (2, 9000, 5000), (2, 3883, 3883)])
 def test_topk_matches_deterministic_rule(dev, rows, n, k):
     g = torch.Generator().manual_seed(rows * 1000003 + n)
     scores = torch.randn((rows, n), generator=g)
@@ -149,7 +152,7 @@ def test_topk_matches_deterministic_rule(dev, rows, n, k):
     assert torch.equal(s.cpu(), rs) and torch.equal(i.cpu(), ri)
 
 
-@pytest.mark.parametrize("n", [5000, 200000])
+@pytest.mark.parametrize("n", [5000, 30000, 200000])
 def test_topk_with_heavy_ties_is_position_ordered(dev, n):
     g = torch.Generator().manual_seed(n)
     scores = torch.randint(0, 7, (6, n), generator=g).float() - 3.0   # only 7 distinct values
