@@ -9,7 +9,7 @@
 // then position ascending" -- the deterministic tie rule that makes 1/2/4/8-GPU results identical.
 //
 //   n <= 1024   one workgroup per row bitonic-sorts the whole row in LDS (also n <= 16384 with k > 4096).
-//   n <= 40960  one workgroup per row holds the row in registers (<= 40 scores per thread), finds the k-th largest score
+//   n <= 49152  one workgroup per row holds the row in registers (<= 48 scores per thread), finds the k-th largest score
 //               by a 2-bits-per-step radix bisection (ballot counts, no atomics), compacts the k keys into LDS
 //               (ties by position, in order) and sorts them: one launch instead of nine.
 //   larger n    MSB-first radix select over the 32 score bits (11/11/10, LDS histograms) finds the k-th largest
@@ -82,6 +82,33 @@ __device__ __forceinline__ unsigned long long block_sort_desc(unsigned long long
   return key;
 }
 
+// ---- block rank (64 <= npad <= 512 keys in LDS, zero-padded, distinct) ------------------------------------------
+// A key's descending rank is the number of larger keys.  The 1024 threads split into 1024/npad parts; thread (c, part)
+// counts the keys of its slice that exceed key c (broadcast 16-byte LDS reads, no conflicts) and adds the count to
+// rank_buf[c].  Two barriers and ~npad^2/2048 LDS reads per thread, against the 36-45 dependent shuffle steps of the
+// bitonic network (5.6 us -> ~1.5 us for the ~220 candidates of a k = 200 selection).  Afterwards every thread with
+// part 0 holds (key c, rank of key c).
+__device__ __forceinline__ void block_rank_desc(const unsigned long long* keys, int npad, unsigned int* rank_buf,
+                                                unsigned long long& mine, unsigned int& rank, bool& owner) {
+  const int tid = threadIdx.x;
+  const int c = tid & (npad - 1), part = tid / npad;
+  const int span = npad / ((int)blockDim.x / npad);      // keys per slice (>= 4 for npad >= 64 at 1024 threads)
+  if (tid < npad) rank_buf[tid] = 0u;
+  __syncthreads();
+  mine = keys[c];
+  unsigned int cnt = 0;
+  const ulonglong2* p = reinterpret_cast<const ulonglong2*>(keys + part * span);
+  for (int i = 0; i < span / 2; ++i) {
+    const ulonglong2 x = p[i];
+    cnt += x.x > mine ? 1u : 0u;
+    cnt += x.y > mine ? 1u : 0u;
+  }
+  if (cnt) atomicAdd(&rank_buf[c], cnt);
+  __syncthreads();
+  rank = rank_buf[c];
+  owner = part == 0;
+}
+
 // ---- LDS bitonic sort (descending) + emit ------------------------------------------------------
 // Input: keys from cand[row*cand_ld + i], i < count (cand != NULL), else from scores[row*ld + begin + i] with positions
 // begin + i, where [begin, begin + count) is this workgroup's chunk of the row (blockIdx.y * chunk ...).
@@ -106,6 +133,16 @@ __global__ __launch_bounds__(kSortThreads) void sort_emit_kernel(const float* __
     keys[i] = kv;
   }
   __syncthreads();
+  if (npad >= 64 && npad <= 512 && out_scores) {   // counting rank, each key written straight to its slot
+    unsigned long long kv; unsigned int rank; bool owner;
+    block_rank_desc(keys, npad, reinterpret_cast<unsigned int*>(keys + npad), kv, rank, owner);
+    if (owner && kv != 0ull && rank < (unsigned int)k) {
+      const unsigned int pos = ~(unsigned int)(kv & 0xFFFFFFFFull);
+      out_scores[(int64_t)row * k + rank] = unorderable((unsigned int)(kv >> 32));
+      out_ids[(int64_t)row * k + rank] = ids ? ids[ids_row_stride * row + pos] : (int64_t)pos;
+    }
+    return;
+  }
   if (npad <= kSortThreads) {   // one key per thread, sorted mostly in registers; keys[npad, 3 npad) is the exchange buffer
     unsigned long long kv = (int)threadIdx.x < npad ? keys[threadIdx.x] : 0ull;
     kv = block_sort_desc(kv, npad, keys + npad);
@@ -286,192 +323,293 @@ __global__ __launch_bounds__(kHistThreads) void compact_kernel(const float* __re
   });
 }
 
-// ---- single-launch select for rows that fit one workgroup's registers --------------------------------------------
-// Thread t holds the orderable scores of positions j*1024 + t, j < VPT (0 = padding, below every real score).
-// The k-th largest value T is the largest T with count(v >= T) >= k: resolve it two bits per step from the top.
+// ---- register-resident select: one workgroup per (row, chunk of <= 49152 elements) ---------------------------------
+// A workgroup holds its elements in registers (<= 48 per thread) and selects the k largest 64-bit keys.
+//   source  SCORES: a chunk of a score row, loaded as float4 (thread t owns elements (jv*1024 + t)*4 .. +3)
+//           KEYS:   a list of 64-bit keys (the per-chunk winners of a first level)
+//   output  final (score, id) pairs, or the k sorted keys into the workspace (first level of the two-level path)
+//
+// Fast path (k <= 512).  The k-th largest of any subset of the row is <= the row's k-th largest, so any
+// L <= (k-th largest per-thread maximum) bounds the answer from below and every wanted key is among {v >= L}.  L is
+// resolved to its top 16 bits, four bits per step: 15 ballots give the 15 threshold counts, lane c keeps count c, one LDS
+// atomic per wave accumulates them in a rotating counter set, one barrier, one LDS read per lane and a ballot pick the
+// digit.  Elements are dealt to threads in small runs, so for untied data only about -1024 ln(1 - k/1024) of them pass
+// (~220 for k = 200); they are compacted (per-thread counts, one wave scan and one LDS atomic per wave) and sorted as
+// 64-bit keys, which settles ties by position.  Measured phases for n = 27278, k = 200 (tools/row_select_phases.hip):
+// see DESIGN.md section 3.3.
+// General path (k > 512, heavy ties, adversarial layouts that overflow the candidate buffer): radix bisection of the
+// k-th largest key, two bits per step, first over the 32 score bits and -- only if the k-th score is tied -- on over the
+// 32 position bits among the tied elements; exactly k keys are then >= the threshold key.
 constexpr int kRowThreads = 1024;
-constexpr int kRowWaves = kRowThreads / 64;
 constexpr int kRowMaxK = 4096;
+constexpr int kRowMaxN = 48 * kRowThreads;
+constexpr int kRowFastK = 512;
+constexpr int kRowCandCap = 4096;   // candidate keys the fast path may hand to the sort
 
-constexpr int kRowCandCap = 4096;   // candidate keys the fast path may hand to the LDS sort
+#ifdef RAILS_TOPK_PHASES   // tools/row_select_phases.hip: wall-clock stamps (100 MHz) of workgroup 0's phases
+__device__ long long g_phase[16];
+#define RAILS_PHASE(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_phase[i] = (long long)wall_clock64(); } while (0)
+#else
+#define RAILS_PHASE(i)
+#endif
 
-template <int VPT>
-__global__ __launch_bounds__(kRowThreads) void row_select_kernel(const float* __restrict__ scores, int64_t ld, int n, int k,
-                                                                int lds_keys, const int64_t* __restrict__ ids,
-                                                                int64_t ids_row_stride, float* __restrict__ out_scores,
-                                                                int64_t* __restrict__ out_ids) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // lds_keys candidate keys
-  __shared__ unsigned int slot[2][3][kRowWaves];
+struct RowSelectArgs {
+  const float* scores; int64_t ld; int64_t n; int64_t chunk;     // SCORES source: row r, chunk c = [c*chunk, min(n, (c+1)*chunk))
+  const unsigned long long* keys_in; int keys_per_row;           // KEYS source
+  int k; int lds_keys;
+  const int64_t* ids; int64_t ids_row_stride;                    // final output (out_scores != NULL)
+  float* out_scores; int64_t* out_ids;
+  unsigned long long* keys_out;                                  // else: keys_out[(row*gridDim.y + c)*k + j]
+};
+
+template <int VPT, bool KEYS>
+__global__ __launch_bounds__(kRowThreads) void row_select_kernel(const RowSelectArgs a) {
+  static_assert(VPT % 4 == 0, "float4 loads");
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // lds_keys candidates + 2048 exchange
+  __shared__ unsigned int ctr[3][16];
   __shared__ unsigned int cursor;
   const int row = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* rowp = scores + (int64_t)row * ld;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int k = a.k, lds_keys = a.lds_keys;
   unsigned int v[VPT];
+  unsigned int lo[KEYS ? VPT : 1];
+  int cnt;
+  unsigned int begin = 0u;
+  RAILS_PHASE(0);
+  if constexpr (KEYS) {
+    cnt = a.keys_per_row;
+    const unsigned long long* src = a.keys_in + (int64_t)row * cnt;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const int i = j * kRowThreads + tid;
+      const unsigned long long kv = i < cnt ? src[i] : 0ull;
+      v[j] = (unsigned int)(kv >> 32);
+      lo[j] = (unsigned int)kv;
+    }
+  } else {
+    const int64_t b64 = (int64_t)blockIdx.y * a.chunk;
+    begin = (unsigned int)b64;
+    cnt = (int)((b64 + a.chunk < a.n ? b64 + a.chunk : a.n) - b64);
+    const float* rowp = a.scores + (int64_t)row * a.ld + b64;
+    const bool aligned = (reinterpret_cast<uintptr_t>(rowp) & 15) == 0;
+#pragma unroll
+    for (int jv = 0; jv < VPT / 4; ++jv) {
+      const int base = (jv * kRowThreads + tid) * 4;
+      if (aligned && base + 3 < cnt) {
+        const float4 x = *reinterpret_cast<const float4*>(rowp + base);
+        v[4 * jv] = orderable(x.x); v[4 * jv + 1] = orderable(x.y); v[4 * jv + 2] = orderable(x.z); v[4 * jv + 3] = orderable(x.w);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * jv + e] = base + e < cnt ? orderable(rowp[base + e]) : 0u;
+      }
+    }
+    lo[0] = 0u;
+  }
+  auto local_index = [&](int j) { return KEYS ? j * kRowThreads + tid : ((j >> 2) * kRowThreads + tid) * 4 + (j & 3); };
+  auto low_of = [&](int j) -> unsigned int {
+    if constexpr (KEYS) return lo[j];
+    else return ~(begin + (unsigned int)local_index(j));
+  };
   unsigned int tmax = 0u;
 #pragma unroll
-  for (int j = 0; j < VPT; ++j) {
-    const int i = j * kRowThreads + threadIdx.x;
-    v[j] = i < n ? orderable(rowp[i]) : 0u;
-    tmax = v[j] > tmax ? v[j] : tmax;
-  }
-  if (threadIdx.x == 0) cursor = 0u;
-  for (int i = threadIdx.x; i < lds_keys; i += kRowThreads) keys[i] = 0ull;
+  for (int j = 0; j < VPT; ++j) tmax = v[j] > tmax ? v[j] : tmax;
+  if (tid < 48) (&ctr[0][0])[tid] = 0u;
+  if (tid == 0) cursor = 0u;
+  for (int i = tid; i < lds_keys; i += kRowThreads) keys[i] = 0ull;
+  __syncthreads();
+  RAILS_PHASE(1);
 
-  // block-wide sums of three wave-uniform counters; one barrier per call (slots alternate by parity)
-  int it = 0;
-  auto wave_sum3 = [&](unsigned int a1, unsigned int a2, unsigned int a3, unsigned int& n1, unsigned int& n2, unsigned int& n3) {
-    const int par = it & 1;
-    ++it;
-    if (lane == 0) { slot[par][0][wave] = a1; slot[par][1][wave] = a2; slot[par][2][wave] = a3; }
-    __syncthreads();
-    n1 = n2 = n3 = 0;
-#pragma unroll
-    for (int w = 0; w < kRowWaves; ++w) { n1 += slot[par][0][w]; n2 += slot[par][1][w]; n3 += slot[par][2][w]; }
-  };
-  auto count3 = [&](unsigned int c1, unsigned int c2, unsigned int c3, unsigned int& n1, unsigned int& n2, unsigned int& n3) {
-    unsigned int a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll
-    for (int j = 0; j < VPT; ++j) { a1 += v[j] >= c1; a2 += v[j] >= c2; a3 += v[j] >= c3; }
-    unsigned long long pk = (unsigned long long)a1 | ((unsigned long long)a2 << 21) | ((unsigned long long)a3 << 42);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) pk += __shfl_xor(pk, o, 64);
-    wave_sum3((unsigned int)(pk & 0x1FFFFFu), (unsigned int)((pk >> 21) & 0x1FFFFFu), (unsigned int)(pk >> 42), n1, n2, n3);
-  };
+  int it = 0;   // rotating counter set: step `it` accumulates into ctr[it % 3] and clears ctr[(it + 1) % 3] before its barrier
   auto emit = [&](unsigned long long kv, int j) {
-    const unsigned int pos = ~(unsigned int)(kv & 0xFFFFFFFFull);
-    out_scores[(int64_t)row * k + j] = unorderable((unsigned int)(kv >> 32));
-    out_ids[(int64_t)row * k + j] = ids ? ids[ids_row_stride * row + pos] : (int64_t)pos;
+    if (a.out_scores) {
+      const unsigned int pos = ~(unsigned int)(kv & 0xFFFFFFFFull);
+      a.out_scores[(int64_t)row * k + j] = unorderable((unsigned int)(kv >> 32));
+      a.out_ids[(int64_t)row * k + j] = a.ids ? a.ids[a.ids_row_stride * row + pos] : (int64_t)pos;
+    } else {
+      a.keys_out[((int64_t)row * gridDim.y + blockIdx.y) * k + j] = kv;
+    }
   };
   auto emit_sorted = [&](int npad) {   // sort keys[0, npad) descending, write the first k
     __syncthreads();
+    if (npad >= 64 && npad <= 512) {
+      unsigned long long kv; unsigned int rank; bool owner;
+      block_rank_desc(keys, npad, reinterpret_cast<unsigned int*>(keys + lds_keys), kv, rank, owner);
+      if (owner && kv != 0ull && rank < (unsigned int)k) emit(kv, (int)rank);
+      return;
+    }
     if (npad <= kRowThreads) {
-      unsigned long long kv = (int)threadIdx.x < npad ? keys[threadIdx.x] : 0ull;
+      unsigned long long kv = tid < npad ? keys[tid] : 0ull;
       kv = block_sort_desc(kv, npad, keys + lds_keys);
-      if ((int)threadIdx.x < k) emit(kv, threadIdx.x);
+      if (tid < k) emit(kv, tid);
       return;
     }
     for (int size = 2; size <= npad; size <<= 1) {
       for (int stride = size >> 1; stride > 0; stride >>= 1) {
-        for (int t = threadIdx.x; t < (npad >> 1); t += kRowThreads) {
-          const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
-          const int hi2 = lo | stride;
-          const bool desc = ((lo & size) == 0);
-          const unsigned long long a = keys[lo], b = keys[hi2];
-          if ((a < b) == desc) { keys[lo] = b; keys[hi2] = a; }
+        for (int t = tid; t < (npad >> 1); t += kRowThreads) {
+          const int l = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+          const int h = l | stride;
+          const bool desc = ((l & size) == 0);
+          const unsigned long long x = keys[l], y = keys[h];
+          if ((x < y) == desc) { keys[l] = y; keys[h] = x; }
         }
         __syncthreads();
       }
     }
-    for (int j = threadIdx.x; j < k; j += kRowThreads) emit(keys[j], j);
+    for (int j = tid; j < k; j += kRowThreads) emit(keys[j], j);
   };
-  auto compact = [&](auto pred) {      // append the keys of the selected elements, any order; overflow is dropped
+  auto compact = [&](auto pred) {      // append the keys of the selected elements (any order); overflow is dropped
+    unsigned int c = 0;
 #pragma unroll
-    for (int j = 0; j < VPT; ++j) {
-      const bool sel = (j * kRowThreads + (int)threadIdx.x < n) && pred(v[j]);
-      const unsigned long long m = __ballot(sel);
-      if (m) {
-        const int leader = __ffsll((long long)m) - 1;
-        unsigned int base = 0;
-        if (lane == leader) base = atomicAdd(&cursor, (unsigned int)__popcll(m));
-        base = (unsigned int)__shfl((int)base, leader, 64);
-        const unsigned int at = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
-        if (sel && at < (unsigned int)lds_keys) {
-          const unsigned int pos = (unsigned int)(j * kRowThreads) + threadIdx.x;
-          keys[at] = ((unsigned long long)v[j] << 32) | (unsigned int)(~pos);
+    for (int j = 0; j < VPT; ++j) c += (local_index(j) < cnt && pred(j)) ? 1u : 0u;
+    unsigned int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned int x = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += x;
+    }
+    unsigned int base = 0;
+    if (lane == 63 && incl) base = atomicAdd(&cursor, incl);
+    base = (unsigned int)__shfl((int)base, 63, 64);
+    unsigned int at = base + incl - c;
+    if (c) {
+#pragma unroll
+      for (int j = 0; j < VPT; ++j) {
+        if (local_index(j) < cnt && pred(j)) {
+          if (at < (unsigned int)lds_keys) keys[at] = ((unsigned long long)v[j] << 32) | low_of(j);
+          ++at;
         }
       }
     }
   };
 
-  // ---- fast path: a lower bound from the per-thread maxima -----------------------------------------------------
-  // The k-th largest of any subset of the row is <= the row's k-th largest, so any L <= (k-th largest thread maximum)
-  // bounds the answer from below and every wanted key is among {v >= L}.  L is resolved to its top 16 bits only (8 steps
-  // of 2 bits; a slightly lower bound only admits a few more candidates).  Positions are dealt round-robin to threads, so
-  // for untied data only about -1024 ln(1 - k/1024) elements pass (222 for k = 200); they are sorted as 64-bit keys,
-  // which settles ties by position.  Heavy ties or adversarial layouts overflow the candidate buffer and fall through.
-  if (k <= kRowThreads / 2) {
+  if (k <= kRowFastK) {
     unsigned int L = 0u;
-    for (int bit = 30; bit >= 16; bit -= 2) {
-      const unsigned int c1 = L | (1u << bit), c2 = L | (2u << bit), c3 = L | (3u << bit);
-      unsigned int n1, n2, n3;
-      wave_sum3((unsigned int)__popcll(__ballot(tmax >= c1)), (unsigned int)__popcll(__ballot(tmax >= c2)),
-                (unsigned int)__popcll(__ballot(tmax >= c3)), n1, n2, n3);
-      L = n3 >= (unsigned int)k ? c3 : n2 >= (unsigned int)k ? c2 : n1 >= (unsigned int)k ? c1 : L;
+    for (int shift = 28; shift >= 16; shift -= 4) {
+      unsigned int mine = 0u;
+#pragma unroll
+      for (int d = 1; d < 16; ++d) {
+        const unsigned int cd = (unsigned int)__popcll(__ballot(tmax >= (L | ((unsigned int)d << shift))));
+        mine = lane == d ? cd : mine;
+      }
+      const int buf = it % 3;
+      if (lane >= 1 && lane < 16 && mine) atomicAdd(&ctr[buf][lane], mine);
+      if (tid < 16) ctr[(it + 1) % 3][tid] = 0u;
+      __syncthreads();
+      const unsigned int tot = lane < 16 ? ctr[buf][lane] : 0u;
+      const unsigned long long ok = __ballot(lane >= 1 && lane < 16 && tot >= (unsigned int)k);   // monotone in the digit
+      L |= (unsigned int)__popcll(ok) << shift;
+      ++it;
     }
-    compact([&](unsigned int x) { return x >= L; });
+    RAILS_PHASE(2);
+    compact([&](int j) { return v[j] >= L; });
     __syncthreads();
+    RAILS_PHASE(3);
     const unsigned int m_ge = cursor;
     if (m_ge <= (unsigned int)lds_keys) {
       int npad = 2;
       while (npad < (int)m_ge) npad <<= 1;
       emit_sorted(npad);
+      RAILS_PHASE(4);
+#ifdef RAILS_TOPK_PHASES
+      if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) g_phase[5] = m_ge;
+#endif
       return;
     }
     __syncthreads();                       // everyone has read the cursor: start over on the general path
-    if (threadIdx.x == 0) cursor = 0u;
-    for (int i = threadIdx.x; i < lds_keys; i += kRowThreads) keys[i] = 0ull;
+    if (tid == 0) cursor = 0u;
+    for (int i = tid; i < lds_keys; i += kRowThreads) keys[i] = 0ull;
   }
 
-  // ---- general path: the k-th largest value T is the largest T with count(v >= T) >= k; two bits per step --------
-  unsigned int prefix = 0u;
-  for (int bit = 30; bit >= 0; bit -= 2) {
-    const unsigned int c1 = prefix | (1u << bit), c2 = prefix | (2u << bit), c3 = prefix | (3u << bit);
-    unsigned int n1, n2, n3;
-    count3(c1, c2, c3, n1, n2, n3);
-    prefix = n3 >= (unsigned int)k ? c3 : n2 >= (unsigned int)k ? c2 : n1 >= (unsigned int)k ? c1 : prefix;
-  }
-  const unsigned int T = prefix;
-  // strictly above T / equal to T  (T = 0xFFFFFFFF is a NaN pattern above every score: nothing is above it)
-  unsigned int n_ge, n_gt, unused;
-  const unsigned int Tp = T == 0xFFFFFFFFu ? T : T + 1u;
-  count3(T, Tp, Tp, n_ge, n_gt, unused);
-  if (T == 0xFFFFFFFFu) n_gt = 0u;
-  const unsigned int need_eq = (unsigned int)k - n_gt;   // >= 1
-  const bool all_eq = (n_ge - n_gt) == need_eq;          // every tied element is wanted: no ordering needed
-  if (all_eq) {
-    compact([&](unsigned int x) { return x >= T; });
-  } else {
-    compact([&](unsigned int x) { return x > T; });
-    // ties at T: take the need_eq lowest positions.  Positions j*1024 + t ascend with (j, t): an in-order scan.
-    unsigned int running = 0;
-    for (int j = 0; j < VPT; ++j) {     // uniform trip count / uniform break
-      const bool match = v[j] == T && (j * kRowThreads + (int)threadIdx.x) < n;
-      const unsigned long long bal = __ballot(match);
-      const int par = it & 1;
-      ++it;
-      if (lane == 0) slot[par][0][wave] = (unsigned int)__popcll(bal);
-      __syncthreads();
-      unsigned int before = running, total = 0;
+  // block-wide counts of three per-element predicates; one barrier
+  auto count3 = [&](auto p1, auto p2, auto p3, unsigned int& n1, unsigned int& n2, unsigned int& n3) {
+    unsigned int a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
-      for (int w = 0; w < kRowWaves; ++w) {
-        const unsigned int c = slot[par][0][w];
-        if (w < wave) before += c;
-        total += c;
-      }
-      const unsigned int rank = before + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull));
-      if (match && rank < need_eq) {
-        const unsigned int pos = (unsigned int)(j * kRowThreads) + threadIdx.x;
-        keys[n_gt + rank] = ((unsigned long long)T << 32) | (unsigned int)(~pos);
-      }
-      running += total;
-      if (running >= need_eq) break;
+    for (int j = 0; j < VPT; ++j) { a1 += p1(j) ? 1u : 0u; a2 += p2(j) ? 1u : 0u; a3 += p3(j) ? 1u : 0u; }
+    unsigned long long pk = (unsigned long long)a1 | ((unsigned long long)a2 << 21) | ((unsigned long long)a3 << 42);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pk += __shfl_xor(pk, o, 64);
+    const int buf = it % 3;
+    if (lane == 0) {
+      atomicAdd(&ctr[buf][0], (unsigned int)(pk & 0x1FFFFFu));
+      atomicAdd(&ctr[buf][1], (unsigned int)((pk >> 21) & 0x1FFFFFu));
+      atomicAdd(&ctr[buf][2], (unsigned int)(pk >> 42));
+    }
+    if (tid < 16) ctr[(it + 1) % 3][tid] = 0u;
+    __syncthreads();
+    n1 = ctr[buf][0]; n2 = ctr[buf][1]; n3 = ctr[buf][2];
+    ++it;
+  };
+  // the k-th largest score T = the largest T with count(v >= T) >= k  (padding elements hold v = 0 and k <= cnt)
+  unsigned int T = 0u;
+  for (int bit = 30; bit >= 0; bit -= 2) {
+    const unsigned int c1 = T | (1u << bit), c2 = T | (2u << bit), c3 = T | (3u << bit);
+    unsigned int n1, n2, n3;
+    count3([&](int j) { return v[j] >= c1; }, [&](int j) { return v[j] >= c2; }, [&](int j) { return v[j] >= c3; }, n1, n2, n3);
+    T = n3 >= (unsigned int)k ? c3 : n2 >= (unsigned int)k ? c2 : n1 >= (unsigned int)k ? c1 : T;
+  }
+  unsigned int n_gt, n_eq, unused;
+  count3([&](int j) { return v[j] > T; }, [&](int j) { return v[j] == T && local_index(j) < cnt; }, [&](int) { return false; }, n_gt, n_eq, unused);
+  const unsigned int need_eq = (unsigned int)k - n_gt;   // >= 1
+  unsigned int P = 0u;                                   // threshold on the low key word among the elements tied at T
+  if (n_eq != need_eq) {
+    // lowest positions first = largest low words first: the need_eq-th largest low word among the tied elements
+    for (int bit = 30; bit >= 0; bit -= 2) {
+      const unsigned int c1 = P | (1u << bit), c2 = P | (2u << bit), c3 = P | (3u << bit);
+      unsigned int n1, n2, n3;
+      count3([&](int j) { return v[j] == T && local_index(j) < cnt && low_of(j) >= c1; },
+             [&](int j) { return v[j] == T && local_index(j) < cnt && low_of(j) >= c2; },
+             [&](int j) { return v[j] == T && local_index(j) < cnt && low_of(j) >= c3; }, n1, n2, n3);
+      P = n3 >= need_eq ? c3 : n2 >= need_eq ? c2 : n1 >= need_eq ? c1 : P;
     }
   }
+  compact([&](int j) { return v[j] > T || (v[j] == T && low_of(j) >= P); });
   int npad = 2;
   while (npad < k) npad <<= 1;
   emit_sorted(npad);
 }
 
-template <int VPT>
-static int launch_row_select(const float* scores, int64_t ld, int rows, int n, int k, const int64_t* ids, int64_t ids_row_stride,
-                             float* out_scores, int64_t* out_ids, hipStream_t stream) {
-  int lds_keys = 2;
-  while (lds_keys < k) lds_keys <<= 1;
-  if (k <= kRowThreads / 2) lds_keys = kRowCandCap;     // room for the pre-filtered candidates
-  // + the 2 x 1024-key exchange buffer of block_sort_desc
-  hipLaunchKernelGGL(row_select_kernel<VPT>, dim3(rows), dim3(kRowThreads), (lds_keys + 2 * kRowThreads) * sizeof(unsigned long long), stream,
-                     scores, ld, n, k, lds_keys, ids, ids_row_stride, out_scores, out_ids);
+template <int VPT, bool KEYS>
+static int launch_row_select_t(const RowSelectArgs& a, int rows, int chunks, hipStream_t stream) {
+  hipLaunchKernelGGL((row_select_kernel<VPT, KEYS>), dim3(rows, chunks), dim3(kRowThreads),
+                     (a.lds_keys + 2 * kRowThreads) * sizeof(unsigned long long), stream, a);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+// elements = per-workgroup element count (chunk size, or keys per row)
+template <bool KEYS>
+static int launch_row_select(RowSelectArgs a, int rows, int chunks, int elements, hipStream_t stream) {
+  int lds_keys = 2;
+  while (lds_keys < a.k) lds_keys <<= 1;
+  if (a.k <= kRowFastK) lds_keys = kRowCandCap;     // room for the pre-filtered candidates
+  a.lds_keys = lds_keys;
+  if (elements <= 4 * kRowThreads) return launch_row_select_t<4, KEYS>(a, rows, chunks, stream);
+  if (elements <= 8 * kRowThreads) return launch_row_select_t<8, KEYS>(a, rows, chunks, stream);
+  if (elements <= 16 * kRowThreads) return launch_row_select_t<16, KEYS>(a, rows, chunks, stream);
+  if constexpr (!KEYS) {
+    if (elements <= 28 * kRowThreads) return launch_row_select_t<28, KEYS>(a, rows, chunks, stream);
+    if (elements <= 40 * kRowThreads) return launch_row_select_t<40, KEYS>(a, rows, chunks, stream);
+    if (elements <= 48 * kRowThreads) return launch_row_select_t<48, KEYS>(a, rows, chunks, stream);
+  } else {
+    if (elements <= 24 * kRowThreads) return launch_row_select_t<24, KEYS>(a, rows, chunks, stream);
+  }
+  set_error("row select: %d elements per workgroup", elements);
+  return kErrUnsupported;
+}
+
+// two-level plan for n > kRowMaxN: chunks of <= kRowMaxN elements (multiples of 4, so float4 loads stay aligned when the
+// row is), chunks * k keys for the second level
+static bool two_level_plan(int64_t n, int k, int* chunks, int64_t* chunk) {
+  if (k > kRowFastK) return false;
+  const int64_t c = (n + kRowMaxN - 1) / kRowMaxN;
+  if (c * k > 24 * kRowThreads) return false;
+  int64_t len = (n + c - 1) / c;
+  len = (len + 3) / 4 * 4;
+  if (len > kRowMaxN || len < k) return false;
+  *chunks = (int)((n + len - 1) / len);
+  *chunk = len;
+  // the last chunk must still hold k elements (its k keys are all real); otherwise leave it to the radix path
+  if (n - (int64_t)(*chunks - 1) * len < k) return false;
+  return true;
 }
 
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -479,11 +617,13 @@ static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 size_t topk_workspace_bytes(int rows, int64_t n, int k) {
-  if (n <= kSortCap || (n <= 40 * 1024 && k <= 4096)) return 256;   // single-launch paths need no workspace
+  if (n <= kSortCap || (n <= 48 * 1024 && k <= 4096)) return 256;   // single-launch paths need no workspace
+  // sized for the radix path; the two-level path's rows * chunks * k keys (<= rows * 16384) are checked against it too
   size_t b = align_up(sizeof(SelectState) * (size_t)rows, 256);
   b += align_up(sizeof(unsigned int) * (size_t)kRadixPasses * rows * kBins, 256);
   b += align_up(sizeof(unsigned long long) * (size_t)rows * k, 256);
-  return b;
+  const size_t two_level = sizeof(unsigned long long) * (size_t)rows * 24 * 1024;
+  return b > two_level ? b : two_level;
 }
 
 static int ensure_sort_lds() {
@@ -502,13 +642,25 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
   if (k > kSortCap) { set_error("k = %d exceeds the in-LDS sort capacity (%d)", k, kSortCap); return kErrUnsupported; }
   if (n >= (1ll << 32)) { set_error("n = %lld does not fit 32-bit positions; shard the corpus", (long long)n); return kErrUnsupported; }
   if (ensure_sort_lds() != kOk) return kErrLaunch;
-  if (n > 1024 && n <= 40 * kRowThreads && k <= kRowMaxK) {
-    const int ni = (int)n;
-    if (ni <= 4 * kRowThreads) return launch_row_select<4>(scores, ld, rows, ni, k, ids, ids_row_stride, out_scores, out_ids, stream);
-    if (ni <= 8 * kRowThreads) return launch_row_select<8>(scores, ld, rows, ni, k, ids, ids_row_stride, out_scores, out_ids, stream);
-    if (ni <= 16 * kRowThreads) return launch_row_select<16>(scores, ld, rows, ni, k, ids, ids_row_stride, out_scores, out_ids, stream);
-    if (ni <= 28 * kRowThreads) return launch_row_select<28>(scores, ld, rows, ni, k, ids, ids_row_stride, out_scores, out_ids, stream);
-    return launch_row_select<40>(scores, ld, rows, ni, k, ids, ids_row_stride, out_scores, out_ids, stream);
+  if (n > 1024 && k <= kRowMaxK) {
+    RowSelectArgs a{};
+    a.scores = scores; a.ld = ld; a.n = n; a.k = k;
+    if (n <= kRowMaxN) {                 // one launch
+      a.chunk = n; a.ids = ids; a.ids_row_stride = ids_row_stride; a.out_scores = out_scores; a.out_ids = out_ids;
+      return launch_row_select<false>(a, rows, 1, (int)n, stream);
+    }
+    int chunks; int64_t chunk;
+    if (two_level_plan(n, k, &chunks, &chunk)) {   // two launches: per-chunk winners, then the winners' winners
+      if (ws_bytes < topk_workspace_bytes(rows, n, k)) { set_error("top-k workspace too small"); return kErrNoMem; }
+      unsigned long long* lvl1 = static_cast<unsigned long long*>(ws);
+      a.chunk = chunk; a.keys_out = lvl1;
+      const int rc = launch_row_select<false>(a, rows, chunks, (int)chunk, stream);
+      if (rc != kOk) return rc;
+      RowSelectArgs b{};
+      b.keys_in = lvl1; b.keys_per_row = chunks * k; b.k = k;
+      b.ids = ids; b.ids_row_stride = ids_row_stride; b.out_scores = out_scores; b.out_ids = out_ids;
+      return launch_row_select<true>(b, rows, 1, chunks * k, stream);
+    }
   }
   if (n <= kSortCap) {
     const int npad = next_pow2((int)n < 2 ? 2 : (int)n);
@@ -638,14 +790,22 @@ __global__ void pack_candidates_kernel(const float* __restrict__ scores, const i
 
 // gathered: (R, rows, 2k) messages in rank order.  Candidate (r, j) gets position r*k + j: shard-major order is global
 // position order for contiguous shards, so the tie rule (score desc, position asc) carries over and the merged result
-// is bit-identical to the unsharded one.  One workgroup per row, LDS bitonic sort of R*k <= 16384 keys.
+// is bit-identical to the unsharded one.  One workgroup per row, R*k <= 16384 keys in LDS.
+//
+// Each rank's list arrives sorted (it is that rank's top-k), so no sort is needed: a key's rank in the merged order is
+// the number of larger keys, = its index in its own list + one binary search in each other list (keys are distinct, so
+// ranks are a permutation); keys of rank < k_out are written straight to their slot.  One barrier instead of the
+// ~70 of a 2048-key bitonic sort (21 us -> ~6 us at R = 8, k = 200).  Unsorted input (not produced by this library, but
+// legal for the C entry point) is detected and takes the bitonic sort.
 __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(const int64_t* __restrict__ gathered, int R, int rows,
                                                                        int k, int k_out, int npad,
                                                                        float* __restrict__ out_scores,
                                                                        int64_t* __restrict__ out_ids) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  __shared__ int unsorted;
   const int row = blockIdx.x;
   const int count = R * k;
+  if (threadIdx.x == 0) unsorted = 0;
   for (int i = threadIdx.x; i < npad; i += kSortThreads) {
     unsigned long long kv = 0ull;
     if (i < count) {
@@ -656,6 +816,36 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(const in
     keys[i] = kv;
   }
   __syncthreads();
+  auto emit = [&](unsigned long long kv, int slot) {
+    const unsigned int pos = ~(unsigned int)(kv & 0xFFFFFFFFull);
+    const int r = (int)(pos / (unsigned int)k), jj = (int)(pos - (unsigned int)r * (unsigned int)k);
+    out_scores[(int64_t)row * k_out + slot] = unorderable((unsigned int)(kv >> 32));
+    out_ids[(int64_t)row * k_out + slot] = gathered[((int64_t)r * rows + row) * 2 * k + k + jj];
+  };
+  bool bad = false;
+  for (int i = threadIdx.x; i + 1 < count; i += kSortThreads)
+    if ((i + 1) % k != 0 && keys[i] < keys[i + 1]) bad = true;
+  if (bad) unsorted = 1;
+  __syncthreads();
+  if (!unsorted) {
+    for (int i = threadIdx.x; i < count; i += kSortThreads) {
+      const unsigned long long kv = keys[i];
+      const int r = i / k, j = i - r * k;
+      int rank = j;
+      for (int o = 0; o < R && rank < k_out; ++o) {
+        if (o == r) continue;
+        const unsigned long long* list = keys + o * k;   // descending
+        int lo = 0, hi = k;
+        while (lo < hi) {                                // first index whose key is < kv  = #keys > kv
+          const int mid = (lo + hi) >> 1;
+          if (list[mid] > kv) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
+      }
+      if (rank < k_out) emit(kv, rank);
+    }
+    return;
+  }
   for (int size = 2; size <= npad; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       for (int t = threadIdx.x; t < (npad >> 1); t += kSortThreads) {
@@ -668,13 +858,7 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(const in
       __syncthreads();
     }
   }
-  for (int j = threadIdx.x; j < k_out; j += kSortThreads) {
-    const unsigned long long kv = keys[j];
-    const unsigned int pos = ~(unsigned int)(kv & 0xFFFFFFFFull);
-    const int r = (int)(pos / (unsigned int)k), jj = (int)(pos - (unsigned int)r * (unsigned int)k);
-    out_scores[(int64_t)row * k_out + j] = unorderable((unsigned int)(kv >> 32));
-    out_ids[(int64_t)row * k_out + j] = gathered[((int64_t)r * rows + row) * 2 * k + k + jj];
-  }
+  for (int j = threadIdx.x; j < k_out; j += kSortThreads) emit(keys[j], j);
 }
 
 int pack_candidates(const float* scores, const int64_t* ids, int rows, int k_local, int k, int64_t* msg, hipStream_t stream) {

@@ -143,7 +143,10 @@ def test_f7_full_size(name, dev):
                                       (32, 100000, 2711), (1, 3000000, 16384), (7, 70001, 1),
                                       # single-launch register-resident select: every per-thread width and both edges
                                       (3, 1025, 200), (4, 4096, 4096), (2, 8193, 17), (3, 27278, 200), (3, 30000, 1),
-                                      (2, 40960, 4096), (2, 40961, 100), (2, 9000, 5000), (2, 3883, 3883)])
+                                      (2, 40960, 4096), (2, 40961, 100), (2, 9000, 5000), (2, 3883, 3883),
+                                      # two-level (per-chunk winners, then their winners): 2 .. 74 chunks
+                                      (4, 695762, 200), (3, 86971, 200), (2, 3000000, 200), (3, 81921, 512),
+                                      (2, 3400000, 200), (1, 4500000, 200), (2, 49152, 300), (2, 49153, 300)])
 def test_topk_matches_deterministic_rule(dev, rows, n, k):
     g = torch.Generator().manual_seed(rows * 1000003 + n)
     scores = torch.randn((rows, n), generator=g)
@@ -161,6 +164,16 @@ def test_topk_with_heavy_ties_is_position_ordered(dev, n):
     for k in (1, 50, 4096):
         s, i = E.topk(scores.to(dev), k)
         rs, ri = O.select_topk_deterministic(scores, k)
+        assert torch.equal(s.cpu(), rs) and torch.equal(i.cpu(), ri)
+
+
+def test_topk_rows_not_16_byte_aligned(dev):
+    g = torch.Generator().manual_seed(9)
+    big = torch.randn((3, 90001), generator=g).to(dev)       # odd leading dimension: rows 1, 2 start off 16-byte alignment
+    for n in (90001, 30001, 2049):
+        view = big[:, 1:n]
+        s, i = E.topk(view, 77)
+        rs, ri = O.select_topk_deterministic(view.cpu(), 77)
         assert torch.equal(s.cpu(), rs) and torch.equal(i.cpu(), ri)
 
 
@@ -474,6 +487,23 @@ def test_pack_and_merge_candidates_equal_the_unsharded_topk(dev):
     ms, mi = E.merge_candidates(torch.cat(msgs, 0), R, k, k)
     rs, rpos = O.select_topk_deterministic(scores, k)
     assert torch.equal(ms.cpu(), rs) and torch.equal(mi.cpu(), ids[rpos])
+    # k_out < k, and R = 8 lists of 200 (the amzn-books 8-GPU shape)
+    ms2, mi2 = E.merge_candidates(torch.cat(msgs, 0), R, k, 120)
+    assert torch.equal(ms2.cpu(), rs[:, :120]) and torch.equal(mi2.cpu(), ids[rpos][:, :120])
+    # the C entry point also accepts lists that are NOT sorted (takes the bitonic sort): distinct scores, shuffled lists
+    sc = torch.rand((3, 8 * 200), generator=g)
+    gid = torch.arange(8 * 200, dtype=torch.int64).repeat(3, 1) + 11
+    msg_sorted, msg_shuffled = [], []
+    for r in range(8):
+        blk, bid = sc[:, r * 200:(r + 1) * 200], gid[:, r * 200:(r + 1) * 200]
+        o = torch.argsort(blk, dim=1, descending=True)
+        msg_sorted.append(pack_candidates(torch.gather(blk, 1, o), torch.gather(bid, 1, o), 200))
+        msg_shuffled.append(pack_candidates(blk, bid, 200))
+    a_s, a_i = E.merge_candidates(torch.cat(msg_sorted, 0).to(dev), 8, 200, 200)
+    b_s, b_i = E.merge_candidates(torch.cat(msg_shuffled, 0).to(dev), 8, 200, 200)
+    es, eo = torch.sort(sc, dim=1, descending=True)
+    assert torch.equal(a_s.cpu(), es[:, :200]) and torch.equal(a_i.cpu(), torch.gather(gid, 1, eo)[:, :200])
+    assert torch.equal(b_s.cpu(), a_s.cpu()) and torch.equal(b_i.cpu(), a_i.cpu())
     # a shard shorter than k pads with (-inf, -1)
     s, i = E.topk(scores[:, :7].to(dev), 7, ids=ids[:7].to(dev))
     m = E.pack_candidates(s, i, 10).cpu()

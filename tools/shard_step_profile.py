@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Per-rank step of the item-sharded path at world size R, emulated on ONE GPU: rank 0's shard of amzn-books, the real
+prologue / scoring / local top-k / pack / merge / filter kernels, and the all-gather replaced by a device copy of the
+rank's own message R times (so merge sees R*k' keys).  Everything but the RCCL latency is real: run it under
+`rocprofv3 --kernel-trace --stats` to see the fixed per-step costs that bound strong scaling."""
+import argparse, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rails_amd
+from rails_amd import engine as E
+from rails_amd.sharded import shard_bounds
+from oracle import mol_oracle as O
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--world", type=int, default=8)
+ap.add_argument("--steps", type=int, default=200)
+ap.add_argument("--precision", default=None)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+cfg = O.CONFIGS["amzn-books"]
+N, B, k, kp, width = 695762, 32, 120, 200, 61
+w = O.synthetic_weights(cfg, seed=0)
+mol, _ = rails_amd.create_mol_interaction_module(
+    cfg.query_embedding_dim, cfg.item_embedding_dim, cfg.dot_product_dimension, cfg.query_dot_product_groups,
+    cfg.item_dot_product_groups, cfg.temperature, 0.0, cfg.query_hidden_dim, 0.1, cfg.item_hidden_dim,
+    cfg.gating_query_hidden_dim, cfg.gating_qi_hidden_dim, cfg.gating_item_hidden_dim, cfg.softmax_dropout_rate, False,
+    query_nonlinearity=cfg.query_nonlinearity, uid_embedding_hash_sizes=list(cfg.uid_embedding_hash_sizes) or None)
+mol.load_state_dict(w, strict=True)
+mol = mol.to(dev).eval()
+if a.precision:
+    mol.precision = a.precision
+lo, hi = shard_bounds(N, a.world, 0)
+X = torch.from_numpy(O.hash_item_table(1, lo, hi - lo, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+ids = torch.arange(lo + 1, hi + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+q = O.synthetic_queries(cfg, B).to(dev)
+inv = torch.zeros((B, width), dtype=torch.int64, device=dev)
+with torch.inference_mode():
+    tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
+    eng = tk._bind()
+    logits = torch.empty((B, hi - lo), dtype=torch.float32, device=dev)
+
+    def step():
+        qpack, _, _ = eng.query_pack(q, None)
+        eng.score_dense(qpack, B, tk._index, out=logits)
+        s, top = E.topk(logits, min(kp, hi - lo), ids=tk._ids_flat)
+        if a.world > 1:
+            msg = E.pack_candidates(s, top, kp)
+            gathered = msg.repeat(a.world, 1)
+            s, top = E.merge_candidates(gathered, a.world, kp, kp)
+        return E.filter_seen_ids(top, s, inv, k)
+
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / a.steps
+print(f"world={a.world} shard={hi - lo} items: {dt * 1e3:.3f} ms/step (no RCCL latency) -> {B / dt:.0f} q/s if all ranks match")
