@@ -406,8 +406,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(Score
   const int hi = lane >> 5, x = lane & 31;
   const int inner = p.per_row ? (int)p.n_tiles : p.n_groups;
   const int64_t n_units = p.per_row ? (int64_t)p.B * p.n_tiles : p.n_tiles * p.n_groups;
+  // Full rounds: the NW waves of a workgroup take NW consecutive units (the query groups of one item tile, so the tile's
+  // fragments are shared through L1).  The leftover round is dealt wave-major instead -- unit r goes to workgroup
+  // r % grid, wave r / grid -- so that it lands one unit per SIMD across the whole chip rather than two per SIMD on the
+  // first few CUs (ML-20M: 6824 units on 1024 SIMDs, worst SIMD 7 passes instead of 8; ML-1M: all 256 CUs busy).
   const int64_t stride = (int64_t)gridDim.x * NW;
-  for (int64_t u = (int64_t)blockIdx.x * NW + wave; u < n_units; u += stride) {
+  const int64_t rounds = n_units / stride;
+  for (int64_t it = 0; it <= rounds; ++it) {
+    const int64_t u = it < rounds ? it * stride + (int64_t)blockIdx.x * NW + wave
+                                  : rounds * stride + (int64_t)wave * gridDim.x + blockIdx.x;
+    if (u >= n_units) break;
     const int64_t outer = u / inner;
     const int innr = (int)(u - outer * inner);
     const int64_t tile = p.per_row ? innr : outer;  // tile index inside the row / corpus
@@ -637,8 +645,16 @@ __global__ __launch_bounds__(256, 1) void mol_score_ksplit_kernel(ScoreArgs p) {
   const int hi = lane >> 5, x = lane & 31;
   const int inner = p.per_row ? (int)p.n_tiles : p.n_groups;
   const int64_t n_units = p.per_row ? (int64_t)p.B * p.n_tiles : p.n_tiles * p.n_groups;
+  // Full rounds: the NW waves of a workgroup take NW consecutive units (the query groups of one item tile, so the tile's
+  // fragments are shared through L1).  The leftover round is dealt wave-major instead -- unit r goes to workgroup
+  // r % grid, wave r / grid -- so that it lands one unit per SIMD across the whole chip rather than two per SIMD on the
+  // first few CUs (ML-20M: 6824 units on 1024 SIMDs, worst SIMD 7 passes instead of 8; ML-1M: all 256 CUs busy).
   const int64_t stride = (int64_t)gridDim.x * NW;
-  for (int64_t u = (int64_t)blockIdx.x * NW + wave; u < n_units; u += stride) {
+  const int64_t rounds = n_units / stride;
+  for (int64_t it = 0; it <= rounds; ++it) {
+    const int64_t u = it < rounds ? it * stride + (int64_t)blockIdx.x * NW + wave
+                                  : rounds * stride + (int64_t)wave * gridDim.x + blockIdx.x;
+    if (u >= n_units) break;
     const int64_t outer = u / inner;
     const int innr = (int)(u - outer * inner);
     const int64_t tile = p.per_row ? innr : outer;
@@ -799,7 +815,7 @@ static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
       grid = a.n_tiles;
     } else {
       const int64_t n_units = a.per_row ? (int64_t)a.B * a.n_tiles : a.n_tiles * a.n_groups;
-      grid = (n_units + NW - 1) / NW;
+      grid = n_units;   // fewer units than wave slots: one unit per workgroup first (wave-major remainder mapping)
     }
     if (grid > (int64_t)n_cu * wg_per_cu) grid = (int64_t)n_cu * wg_per_cu;
     if (grid < 1) return kOk;
@@ -816,7 +832,12 @@ static int launch_score(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using G = Geo<PQ, PX, DD, H>;
   constexpr bool staged_fits = ((size_t)G::kWpackFloats + 2 * (size_t)G::kTileFloats) * sizeof(float) <= 160 * 1024;
   int variant = score_variant();
-  if (variant == 0) variant = (staged_fits && !a.per_row && a.n_groups >= kScoreWaves) ? 2 : 1;
+  if (variant == 0) {
+    variant = (staged_fits && !a.per_row && a.n_groups >= kScoreWaves) ? 2 : 1;
+    // a corpus of at most n_cu/2 tiles would leave half the chip idle under one-tile-per-workgroup staging; the direct
+    // kernel spreads its units one per SIMD over all CUs (ML-1M: 122 tiles)
+    if (variant == 2 && a.n_tiles * 2 <= n_cu) variant = 1;
+  }
   if ((variant == 2 || variant == 4) && a.per_row) { set_error("staged scoring kernel does not do per-row candidates"); return kErrUnsupported; }
   if (a.split) {
     switch (variant) {

@@ -86,7 +86,8 @@ WEIGHT_FIELDS = {
 
 
 def _stream() -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # raw handle of torch's current stream on the current device (torch.cuda.current_stream() costs ~9 us per call)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch.cuda.current_device()))
 
 
 class _on_device:

@@ -242,6 +242,7 @@ class MoLSimilarity(SimilarityModule):
         self._autocast_bf16: bool = autocast_bf16
         self._engine: Optional[MolEngine] = None
         self._engine_key = None
+        self._param_list = None
         # None -> RAILS_PRECISION or "fp32" (exact fp32 MFMA, the parity path); "f16x3" -> opt-in split-f16 gate MLP
         self.precision: Optional[str] = None
 
@@ -288,12 +289,28 @@ class MoLSimilarity(SimilarityModule):
         _eval_only(self)
         if not self._apply_query_embeddings_fn or not self._apply_item_embeddings_fn:
             raise NotImplementedError("apply_query_embeddings_fn / apply_item_embeddings_fn = False is not supported")
-        params = dict(self.state_dict(keep_vars=True))
-        key = (self.precision,) + tuple((k, v.data_ptr(), v._version, v.dtype) for k, v in params.items())
+        # The check runs on every call of the hot path, so it walks a cached list of the parameter objects rather than
+        # state_dict() (70 us per call for 27 tensors).  In-place edits (optimizer steps, load_state_dict's copy_) bump
+        # `_version`; `.to()/.float()` swap `.data` (new data_ptr) or go through _apply, which drops the cached list.
+        plist = self._param_list
+        if plist is None:
+            plist = self._param_list = [v for _, v in self.state_dict(keep_vars=True).items()]
+        key = (self.precision,) + tuple((v.data_ptr(), v._version) for v in plist)
         if self._engine is None or key != self._engine_key:
+            params = dict(self.state_dict(keep_vars=True))
+            self._param_list = list(params.values())
+            key = (self.precision,) + tuple((v.data_ptr(), v._version) for v in self._param_list)
             self._engine = MolEngine(self.shape_spec(), params, precision=self.precision)
             self._engine_key = key
         return self._engine
+
+    def _apply(self, fn, *args, **kwargs):
+        self._param_list = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self._param_list = None
+        return super().load_state_dict(*args, **kwargs)
 
     # ---- reference API --------------------------------------------------------------------------
     def get_query_component_embeddings(self, input_embeddings: torch.Tensor, decoupled_inference: bool = False, **kwargs):

@@ -414,6 +414,21 @@ def test_index_follows_parameter_updates(dev):
     ref = O.mol_logits(fx.cfg, w2, fx.t("q"), fx.t("X"))
     assert float((after.cpu() - ref).abs().max()) <= LOGIT_TOL
     assert float((after - before).abs().max()) > 1e-3
+    # the same for an optimizer-style in-place edit and for a `.data` swap (the engine check walks a cached parameter list)
+    name = "_gating_fn._qi_partial_module.1.bias"
+    prm = dict(mol.named_parameters())[name]
+    with torch.no_grad():
+        prm.add_(0.125)
+    w2[name] = w2[name] + 0.125
+    with torch.inference_mode():
+        third = tk.all_logits(q)
+    assert float((third.cpu() - O.mol_logits(fx.cfg, w2, fx.t("q"), fx.t("X"))).abs().max()) <= LOGIT_TOL
+    prm.data = (prm.data * 2.0).clone()
+    w2[name] = w2[name] * 2.0
+    with torch.inference_mode():
+        fourth = tk.all_logits(q)
+    assert float((fourth.cpu() - O.mol_logits(fx.cfg, w2, fx.t("q"), fx.t("X"))).abs().max()) <= LOGIT_TOL
+    assert float((fourth - third).abs().max()) > 1e-4
 
 
 def test_multi_million_item_corpus(dev):
