@@ -117,6 +117,8 @@ int rails_mol_index_gather(const rails_mol_shape* shape, const float* index, int
 /* ---- query side ------------------------------------------------------------------------------
  * Replaces RecoMoLQueryEmbeddingsFn.forward (rails/similarities/mol/query_embeddings_fns.py:175-254,
  * GLU at rails/similarities/layers.py:19-74) and the query-only gate (similarity_fn.py:166-169). */
+/* Floats of the query pack: Eq fragments of ceil(batch / (32/P_Q)) query groups, gq fragments of `batch` rows, and the
+ * prologue's own scratch (GLU output, first gate layer, raw projection and raw gate of ceil(batch/32)*32 rows). */
 size_t rails_mol_query_pack_floats(const rails_mol_shape* shape, int32_t batch);
 /* queries: (batch, D_q); user_ids: (batch) int64 or NULL when num_uid_tables == 0.
  * eq_out (batch, P_Q, d) and gq_out (batch, L) are optional plain copies (NULL to skip). */

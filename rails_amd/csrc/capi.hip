@@ -141,7 +141,8 @@ size_t rails_mol_query_pack_floats(const rails_mol_shape* s, int32_t batch) {
   if (!shape_ok(s) || batch < 0) return 0;
   const int QT = queries_per_group(*s);
   const size_t groups = (size_t)((batch + QT - 1) / QT);
-  return groups * 32 * (size_t)s->dot_product_dimension + (size_t)batch * (size_t)num_logits(*s);
+  return groups * 32 * (size_t)s->dot_product_dimension + (size_t)batch * (size_t)num_logits(*s) +
+         query_scratch_floats(*s, batch);   // + the prologue's own scratch rows (GLU output, first gate layer)
 }
 
 int rails_mol_query_prologue(const rails_mol_shape* s, const rails_mol_weights* w, const float* queries,

@@ -59,6 +59,7 @@ int index_build(const Shape& s, const Weights& w, const float* items, int64_t n,
 int index_unpack(const Shape& s, const float* ipack, int64_t n, float* ex, float* gi, hipStream_t stream);
 int index_gather(const Shape& s, const float* ipack, int64_t n, const int64_t* idx, int64_t rows, int64_t n_cand,
                  float* out, hipStream_t stream);
+size_t query_scratch_floats(const Shape& s, int B);
 int query_prologue(const Shape& s, const Weights& w, const float* q, const int64_t* user_ids, int B, float* qpack,
                    float* eq_out, float* gq_out, hipStream_t stream);
 

@@ -1,14 +1,25 @@
-// Query-side prologue: one workgroup per query row.
+// Query-side prologue.
 //
 //   Eq = l2norm(cat[Linear(GLU(q W + b)), uid_emb[(user_id % hash) + 1]])   (B, P_Q, d)
 //        reference: rails/similarities/mol/query_embeddings_fns.py:175-254, GLU rails/similarities/layers.py:19-74
 //   gq = Linear_nobias(silu(Linear(q)))                                     (B, L), from the RAW q
 //        reference: modeling/similarity_utils.py:153-168, applied rails/similarities/mol/similarity_fn.py:166-169
 //
-// B rows of a few hundred KFLOP each: not a tuning target.  The kernel
-// writes both the plain tensors (for the module's accessors) and the MFMA-fragment-ordered copies the
-// scoring kernel reads (mol_layout.h).  fp32, precise expf/erff, true divisions.
+// B rows of a few hundred KFLOP each, but it is on the critical path of every step: what
+// matters is latency.  The kernels write both the plain tensors (for the module's accessors) and the
+// MFMA-fragment-ordered copies the scoring kernel reads (mol_layout.h).  fp32, precise expf/erff, true divisions.
+//
+// Two implementations:
+//   batched (default)  a tile of 32 queries sits on the MFMA row axis and the weight columns are spread over
+//                      workgroups, so the 1-3 MB of query-side weights are read once chip-wide instead of once per
+//                      query by a single CU (which bounded the per-query kernel at ~150 GB/s of L2 per CU: 56 us for
+//                      ML-20M).  Three short dependent launches: P1 = GLU + first gate layer, P2 = projection + second
+//                      gate layer (raw), P3 = uid embeddings, l2norm, fragment packing.  In P1/P2 a workgroup owns 32
+//                      output columns and splits K over its waves, one load batch + 16 MFMAs per wave.
+//   per-query          one workgroup per query, wave-per-column dot products; kept for hidden sizes that are not
+//                      multiples of 32.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "mol_kernels.h"
 #include "mol_layout.h"
@@ -177,6 +188,265 @@ __global__ __launch_bounds__(kQueryThreads) void query_prologue_kernel(QueryArgs
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batched prologue (v_mfma_f32_32x32x2_f32: A = 32 queries x 2 k, B = 2 k x 32 output columns, exact fp32).
+// A "macro step" is 32 consecutive k: MFMA step s of half h takes k = 32*ms + 16*h + s, so every lane reads 16
+// consecutive floats of its query row / weight row.
+// ---------------------------------------------------------------------------------------------
+typedef float qf32x16 __attribute__((ext_vector_type(16)));
+
+#ifdef RAILS_QUERY_PHASES   // tools/query_phases.sh: wall-clock stamps (100 MHz) of P1's workgroup (0, 0)
+__device__ long long g_qphase[8];
+#define RAILS_QPHASE(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_qphase[i] = (long long)wall_clock64(); } while (0)
+#else
+#define RAILS_QPHASE(i)
+#endif
+constexpr int kP1Threads = 512;    // 8 waves: K split eight ways (one macro step per wave up to D = 256)
+constexpr int kP2Threads = 1024;   // 16 waves: K split sixteen ways (one macro step per wave at QH = 512)
+constexpr int kP3Threads = 1024;
+
+__device__ __forceinline__ float silu_precise(float v) { return v / (1.0f + expf(-v)); }
+
+// Sum of the NW per-wave partial tiles, wave order (deterministic).
+template <int NW>
+__device__ __forceinline__ float sum_parts(const float (*part)[32][33], int rr, int cc) {
+  float v = part[0][rr][cc];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) v += part[w][rr][cc];
+  return v;
+}
+
+// One (query tile, component p): bring the 32 x d raw values into LDS with one batch of independent loads (uid components
+// gather their embedding rows instead), l2-normalise each row, write the plain copy and the EqFrag entries.
+// val: 32*d floats of LDS, inv: 32 floats, urow_s: 32 int64.  NT = threads of the calling workgroup.
+template <int NT>
+__device__ __forceinline__ void finalize_component(const QueryArgs& a, int tile, int p, const float* __restrict__ eq_raw,
+                                                   float* val, float* inv, long long* urow_s) {
+  const int d = a.d, PQ = a.PQ;
+  const int QT = 32 / PQ;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int proj_groups = PQ - a.n_uid;
+  const bool is_uid = p >= proj_groups;
+  if (is_uid) {
+    if (threadIdx.x < 32) {
+      const int64_t bb = (int64_t)tile * 32 + threadIdx.x;
+      long long urow = 0;
+      if (bb < a.B) {
+        const int64_t hs = a.w.uid_hash_size[p - proj_groups];
+        urow = a.user_ids[bb] % hs;
+        if (urow < 0) urow += hs;  // python % is non-negative
+        urow += 1;
+      }
+      urow_s[threadIdx.x] = urow;
+    }
+    __syncthreads();
+  }
+  // (rr, k) = (e / d, e % d) for e = tid, tid + NT, ...: stepped incrementally -- with one to four waves per SIMD the
+  // runtime integer divisions of a per-element index decode were most of this kernel's time
+  const int step_r = NT / d, step_k = NT - step_r * d;
+  const int rr0 = (int)threadIdx.x / d, k0 = (int)threadIdx.x - rr0 * d;
+  {
+    int rr = rr0, k = k0;
+    for (int e = threadIdx.x; e < 32 * d; e += NT) {
+      const int bb = tile * 32 + rr;
+      float v = 0.0f;
+      if (bb < a.B) v = is_uid ? a.w.uid_table[p - proj_groups][urow_s[rr] * d + k] : eq_raw[(int64_t)bb * (PQ * d) + p * d + k];
+      val[e] = v;
+      rr += step_r; k += step_k;
+      if (k >= d) { k -= d; ++rr; }
+    }
+  }
+  __syncthreads();
+  for (int rr = wave; rr < 32; rr += NT / 64) {
+    float ss = 0.0f;
+    for (int k = lane; k < d; k += 64) ss = __builtin_fmaf(val[rr * d + k], val[rr * d + k], ss);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if (lane == 0) inv[rr] = a.l2norm ? fmaxf(sqrtf(ss), a.eps) : 1.0f;
+  }
+  __syncthreads();
+  const int padded = (a.B + QT - 1) / QT * QT;   // rows of the last query group exist in EqFrag
+  const int qt_shift = __ffs(QT) - 1;            // QT = 32 / P_Q is a power of two
+  const int half = d / 2;
+  {
+    int rr = rr0, k = k0;
+    for (int e = threadIdx.x; e < 32 * d; e += NT) {
+      const int bb = tile * 32 + rr;
+      if (bb < padded) {
+        const float v = bb < a.B ? val[e] / inv[rr] : 0.0f;
+        if (bb < a.B && a.eq_out) a.eq_out[(int64_t)bb * PQ * d + p * d + k] = v;
+        // EqFrag[g][sc][lane][j] = Eq[g*QT + row/PQ][row%PQ][kdim_of(4sc + j, hi)], lane = hi*32 + row
+        const int g = bb >> qt_shift, qj = bb & (QT - 1);
+        const int hi = k >= half ? 1 : 0, s = k - hi * half;
+        a.eqfrag[(int64_t)g * 32 * d + ((s >> 2) * 64 + hi * 32 + qj * PQ + p) * 4 + (s & 3)] = bb < a.B ? v / a.temperature : 0.0f;
+      }
+      rr += step_r; k += step_k;
+      if (k >= d) { k -= d; ++rr; }
+    }
+  }
+}
+
+// GEMM body of P1 (kept out of the kernel so that the uid role is a plain if/else: an early `return` next to the MFMA
+// loop crashed clang-22's SimplifyCFG).
+__device__ __forceinline__ void p1_gemm_block(const QueryArgs& a, int tile, int block, float (*part)[kP1Threads / 64][32][33],
+                                              float* __restrict__ glu_out, float* __restrict__ hq_out) {
+  constexpr int NW = kP1Threads / 64;
+  const int D = a.D, QH = a.QH;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = lane & 31, h = lane >> 5, col = lane & 31;
+  const int b = tile * 32 + row;
+  const bool valid = b < a.B;
+  const int nglu = QH / 32;
+  const bool is_glu = block < nglu;
+  const int c0 = (is_glu ? block : block - nglu) * 32;
+  // biases of this thread's two output elements (same column): loaded now so that the round trip (a first touch of
+  // that tensor since the scoring kernel streamed the corpus: TLB miss included) overlaps the operand loads
+  RAILS_QPHASE(0);
+  const int tcc = threadIdx.x & 31;
+  const float bias_l = is_glu ? a.w.q_glu_b[c0 + tcc] : a.w.gq_b1[c0 + tcc];
+  const float bias_r = is_glu ? a.w.q_glu_b[QH + c0 + tcc] : 0.0f;
+  qf32x16 accl = {0}, accr = {0};
+  const int MS = (D + 31) / 32;
+  for (int ms = wave; ms < MS; ms += NW) {   // all loads of the step are issued before its first MFMA
+    const int kb = ms * 32 + h * 16;
+    float av[16], bl[16], br[16];
+    // unconditional loads from clamped (always valid) addresses, zeroed afterwards: guarded loads (`k < D ? load : 0`)
+    // compiled to a branch per load and the batch took 6 us instead of one round trip
+    const int bc = valid ? b : a.B - 1;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int k = kb + s < D ? kb + s : D - 1;
+      av[s] = a.q[(int64_t)bc * D + k];
+      if (is_glu) {
+        bl[s] = a.w.q_glu_w[(int64_t)k * 2 * QH + c0 + col];
+        br[s] = a.w.q_glu_w[(int64_t)k * 2 * QH + QH + c0 + col];
+      } else {
+        bl[s] = a.w.gq_w1[(int64_t)(c0 + col) * D + k];
+        br[s] = 0.0f;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const bool in = kb + s < D;
+      av[s] = (valid && in) ? av[s] : 0.0f;
+      bl[s] = in ? bl[s] : 0.0f;
+      br[s] = in ? br[s] : 0.0f;
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      accl = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bl[s], accl, 0, 0, 0);
+      if (is_glu) accr = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], br[s], accr, 0, 0, 0);
+    }
+  }
+  RAILS_QPHASE(1);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    part[0][wave][acc_row(r, h)][col] = accl[r];
+    part[1][wave][acc_row(r, h)][col] = accr[r];
+  }
+  __syncthreads();
+  RAILS_QPHASE(2);
+  for (int e = threadIdx.x; e < 1024; e += kP1Threads) {
+    const int rr = e >> 5, cc = e & 31;
+    const int64_t bb = (int64_t)tile * 32 + rr;
+    float l = sum_parts<NW>(part[0], rr, cc) + bias_l;   // cc == tcc: kP1Threads is a multiple of 32
+    if (is_glu) {
+      const float r = sum_parts<NW>(part[1], rr, cc) + bias_r;
+      const float act = a.glu == RAILS_GEGLU ? 0.5f * l * (1.0f + erff(l * 0.70710678118654752440f)) : silu_precise(l);
+      glu_out[bb * QH + c0 + cc] = act * r;
+    } else {
+      hq_out[bb * a.Hq + c0 + cc] = silu_precise(l);
+    }
+  }
+  RAILS_QPHASE(3);
+}
+
+__global__ __launch_bounds__(kP1Threads) void query_p1_kernel(QueryArgs a, float* __restrict__ glu_out, float* __restrict__ hq_out) {
+  __shared__ float part[2][kP1Threads / 64][32][33];
+  __shared__ float inv[32];
+  __shared__ long long urow_s[32];
+  const int n_gemm = a.QH / 32 + a.Hq / 32;
+  if ((int)blockIdx.x < n_gemm) {
+    p1_gemm_block(a, blockIdx.y, blockIdx.x, part, glu_out, hq_out);
+  } else {   // uid component: 32*d <= 8192 floats of `part` serve as its value buffer
+    finalize_component<kP1Threads>(a, blockIdx.y, a.PQ - a.n_uid + ((int)blockIdx.x - n_gemm), nullptr, &part[0][0][0][0], inv, urow_s);
+  }
+}
+
+// P2: grid.x = 32-column blocks of the projection ((P_Q - n_uid) * d / 32), then L/32 blocks of the second gate layer;
+// grid.y = query tiles.  Raw outputs:  eq_raw[b][c] = Wp[c] . glu[b] + bp[c]   gq_raw[b][l] = W2[l] . hq[b]
+__global__ __launch_bounds__(kP2Threads) void query_p2_kernel(QueryArgs a, const float* __restrict__ glu, const float* __restrict__ hq,
+                                                             float* __restrict__ eq_raw, float* __restrict__ gq_raw) {
+  constexpr int NW = kP2Threads / 64;
+  __shared__ float part[NW][32][33];
+  const int L = a.PQ * a.PX;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = lane & 31, h = lane >> 5, col = lane & 31;
+  const int tile = blockIdx.y;
+  const int nproj = (a.PQ - a.n_uid) * a.d / 32;
+  const bool is_proj = (int)blockIdx.x < nproj;
+  const int c0 = (is_proj ? blockIdx.x : blockIdx.x - nproj) * 32;
+  const int K = is_proj ? a.QH : a.Hq;
+  const float* A = is_proj ? glu : hq;
+  const float* W = is_proj ? a.w.q_proj_w : a.w.gq_w2;
+  const int64_t bb = (int64_t)tile * 32 + row;
+  const float bias = is_proj ? a.w.q_proj_b[c0 + (threadIdx.x & 31)] : 0.0f;   // early: see P1
+  qf32x16 acc = {0};
+  for (int ms = wave; ms < K / 32; ms += NW) {
+    const int kb = ms * 32 + h * 16;
+    float av[16], bv[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      av[s] = A[bb * K + kb + s];                                 // scratch rows exist for the whole tile
+      bv[s] = W[(int64_t)(c0 + col) * K + kb + s];
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) part[wave][acc_row(r, h)][col] = acc[r];
+  __syncthreads();
+  {
+    const int rr = threadIdx.x >> 5, cc = threadIdx.x & 31;   // 1024 threads = 32 x 32 outputs
+    const float v = sum_parts<NW>(part, rr, cc);
+    const int64_t b2 = (int64_t)tile * 32 + rr;
+    if (is_proj) eq_raw[b2 * (a.PQ * a.d) + c0 + cc] = v + bias;
+    else gq_raw[b2 * L + c0 + cc] = v;
+  }
+}
+
+// P3: grid.x = the P_Q - n_uid projected components (l2norm + plain copy + EqFrag) and one more workgroup for the gate (plain copy + permuted, -log2e-scaled gqfrag); grid.y = query tiles.
+__global__ __launch_bounds__(kP3Threads) void query_p3_kernel(QueryArgs a, const float* __restrict__ eq_raw, const float* __restrict__ gq_raw) {
+  __shared__ float inv[32];
+  const int d = a.d, PQ = a.PQ, L = a.PQ * a.PX;
+  const int QT = 32 / PQ;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.y;
+  const int proj_groups = PQ - a.n_uid;
+  if ((int)blockIdx.x == proj_groups) {
+    for (int e = threadIdx.x; e < 32 * L; e += kP3Threads) {
+      const int rr = e / L, i = e - rr * L;
+      const int64_t bb = (int64_t)tile * 32 + rr;
+      if (bb >= a.B) continue;
+      if (a.gq_out) a.gq_out[bb * L + i] = gq_raw[bb * L + i];
+      // gqfrag[b][hi][e] = gq[b][logit_of(e, hi)]
+      const int hi = i / (L / 2), ee = i - hi * (L / 2);
+      a.gqfrag[bb * L + i] = -kLog2e * gq_raw[bb * L + logit_of(ee, hi, PQ, a.PX)];  // fragment copy carries -log2e
+    }
+    return;
+  }
+  extern __shared__ __attribute__((aligned(16))) float val[];   // [32][d]
+  __shared__ long long urow_s[32];
+  finalize_component<kP3Threads>(a, tile, blockIdx.x, eq_raw, val, inv, urow_s);
+}
+
+size_t query_scratch_floats(const Shape& s, int B) {
+  const size_t bt = (size_t)(B + 31) / 32 * 32;
+  return bt * ((size_t)s.query_hidden_dim + (size_t)s.gating_query_hidden_dim +
+               (size_t)s.query_dot_product_groups * s.dot_product_dimension +
+               (size_t)s.query_dot_product_groups * s.item_dot_product_groups);
+}
+
 int query_prologue(const Shape& s, const Weights& w, const float* q, const int64_t* user_ids, int B, float* qpack,
                    float* eq_out, float* gq_out, hipStream_t stream) {
   if (B <= 0) return kOk;
@@ -190,9 +460,38 @@ int query_prologue(const Shape& s, const Weights& w, const float* q, const int64
   a.eqfrag = qpack;
   a.gqfrag = qpack + (int64_t)n_groups * 32 * a.d;
   a.eq_out = eq_out; a.gq_out = gq_out;
+  const int L = a.PQ * a.PX;
+  // RAILS_PROLOGUE: 0 / unset = choose, 1 = per-query kernel, 2 = batched kernels (measurement override)
+  static const int forced = [] { const char* e = getenv("RAILS_PROLOGUE"); return e ? atoi(e) : 0; }();
+  const bool batched_ok = a.QH % 32 == 0 && a.Hq % 32 == 0 && a.d % 32 == 0 && L % 32 == 0 && a.d <= 256;
+  // The per-query kernel streams every weight matrix through one CU per query (~150 GB/s of L2 each); the batched
+  // kernels read them once but pay three dependent launches (~8 us each).  Crossover ~1.3 MB of weights per query.
+  const size_t weight_bytes = sizeof(float) * ((size_t)a.D * 2 * a.QH + (size_t)(a.PQ - a.n_uid) * a.d * a.QH + (size_t)a.Hq * a.D + (size_t)L * a.Hq);
+  const bool use_batched = forced == 2 || (forced != 1 && weight_bytes > (size_t)1300 * 1024);
+  if (batched_ok && use_batched) {
+    // scratch rows behind the fragment pack (rails_mol_query_pack_floats counts them)
+    const int64_t bt = (int64_t)(B + 31) / 32 * 32;
+    float* glu = a.gqfrag + (int64_t)B * L;
+    float* hq = glu + bt * a.QH;
+    float* eq_raw = hq + bt * a.Hq;
+    float* gq_raw = eq_raw + bt * a.PQ * a.d;
+    const int tiles = (B + 31) / 32;
+    hipLaunchKernelGGL(query_p1_kernel, dim3(a.QH / 32 + a.Hq / 32 + a.n_uid, tiles), dim3(kP1Threads), 0, stream, a, glu, hq);
+    hipLaunchKernelGGL(query_p2_kernel, dim3((a.PQ - a.n_uid) * a.d / 32 + L / 32, tiles), dim3(kP2Threads), 0, stream, a,
+                       (const float*)glu, (const float*)hq, eq_raw, gq_raw);
+    hipLaunchKernelGGL(query_p3_kernel, dim3(a.PQ - a.n_uid + 1, tiles), dim3(kP3Threads), 32 * a.d * sizeof(float), stream, a, (const float*)eq_raw,
+                       (const float*)gq_raw);
+    return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+  }
   const size_t lds = sizeof(float) * (size_t)(a.D + 2 * a.QH + a.PQ * a.d + a.Hq + a.PQ * a.PX + a.PQ);
   hipLaunchKernelGGL(query_prologue_kernel, dim3(n_groups * QT), dim3(kQueryThreads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
 }  // namespace mol
+
+#ifdef RAILS_QUERY_PHASES
+extern "C" int rails_debug_query_phases(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(mol::g_qphase), sizeof(long long) * 8) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -42,7 +42,7 @@ def test_size_helpers_and_validation(lib):
     assert lib.rails_mol_shape_supported(C.byref(s)) == 1
     assert lib.rails_mol_gate_pack_floats(C.byref(s)) == 2 * 128 * 64 + 128 + 64
     assert lib.rails_mol_index_floats(C.byref(s), 33) == 2 * 32 * (8 * 32 + 64)     # two tiles
-    assert lib.rails_mol_query_pack_floats(C.byref(s), 5) == 2 * 32 * 32 + 5 * 64   # two query groups of 4
+    assert lib.rails_mol_query_pack_floats(C.byref(s), 5) == 2 * 32 * 32 + 5 * 64 + 32 * (512 + 128 + 8 * 32 + 64)   # two query groups of 4 + scratch rows
     bad = E.MolShapeSpec(64, 64, 48, 8, 8, 512, 128, 128, 128).to_c()
     assert lib.rails_mol_shape_supported(C.byref(bad)) == 0 and "no fused scoring kernel" in _lib.last_error()
     assert lib.rails_mol_shape_supported(C.byref(E.MolShapeSpec(64, 64, 64, 16, 16, 512, 128, 128, 128).to_c())) == 1
