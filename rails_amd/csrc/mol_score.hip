@@ -485,6 +485,96 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(Score
 }
 
 // ---------------------------------------------------------------------------------------------
+// Kernel B1 ("staged, single Ex buffer"): for shapes whose tile does not fit LDS twice next to the gate weights
+// (8x4x128: 68 KiB tiles).  The sub-embedding part of a tile (Ex, 94 % of it) is only read by GEMM1, the first ~15 % of a
+// unit; the gate part (gi) is read at the end.  So ONE Ex buffer is enough: after a second barrier ("every wave is past
+// its last GEMM1") the next tile's Ex is DMA'd into the same buffer while the waves run the long gate MLP; gi is double
+// buffered (4 KiB each).  LDS: weights + Ex + 2 gi = 107 KiB for 8x4x128.
+//
+// Leftover round: when the tiles left after the full rounds are at most half the grid, each is shared by
+// nsub = grid / leftover workgroups that split its query groups (group = sub + nsub * wave), so the round runs one unit
+// per SIMD instead of two on a few CUs (ML-20M: 853 tiles on 256 CUs -> 3 full rounds + 85 leftover tiles x 3 workgroups).
+// ---------------------------------------------------------------------------------------------
+template <int NW>
+__device__ __forceinline__ void dma_floats(const float* __restrict__ src, float* lds, int n_floats, int wave, int lane) {
+  for (int piece = wave; piece < n_floats / 256; piece += NW) {   // 1 KiB pieces
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(src + piece * 256 + lane * 4),
+        (__attribute__((address_space(3))) void*)(lds + piece * 256), 16, 0, 0);
+  }
+}
+
+template <int PQ, int PX, int DD, int H, int NW, bool SPLIT>
+__global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged1_kernel(ScoreArgs p) {
+  using G = Geo<PQ, PX, DD, H>;
+  static_assert(G::kTileExFloats % 256 == 0 && G::kTileGiFloats % 256 == 0, "1 KiB DMA pieces");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const float4* sW1 = reinterpret_cast<const float4*>(smem);
+  const float4* sW2 = sW1 + G::kW1Floats / 4;
+  const float* sB1 = smem + G::kW1Floats + G::kW2Floats;
+  const float* sB2 = sB1 + H;
+  float* sEx = smem + G::kWpackFloats;
+  float* sGi = sEx + G::kTileExFloats;   // two gi buffers
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5, x = lane & 31;
+  const int64_t grid = gridDim.x, b = blockIdx.x;
+  const int64_t rounds = p.n_tiles / grid;
+  const int64_t left = p.n_tiles - rounds * grid;
+  int nsub = 1;
+  if (left > 0 && left * 2 <= grid) {
+    nsub = (int)(grid / left);
+    if (nsub > NW) nsub = NW;
+    if (nsub > p.n_groups) nsub = p.n_groups;
+  }
+  const bool has_left = b < left * nsub;
+  const int64_t mine = rounds + (has_left ? 1 : 0);
+  if (mine == 0) return;
+  stage_weights<G, NW>(p, smem);
+  auto tile_of = [&](int64_t i) -> int64_t { return i < rounds ? b + i * grid : rounds * grid + b % left; };
+
+  {
+    const float* t0 = p.ipack + tile_of(0) * (int64_t)G::kTileFloats;
+    dma_floats<NW>(t0, sEx, G::kTileExFloats, wave, lane);
+    dma_floats<NW>(t0 + G::kTileExFloats, sGi, G::kTileGiFloats, wave, lane);
+  }
+  int cur = 0;
+  for (int64_t i = 0; i < mine; ++i, cur ^= 1) {
+    const int64_t tile = tile_of(i);
+    const bool split_round = i >= rounds && nsub > 1;
+    const int off = split_round ? (int)(b / left) : 0, stride = split_round ? nsub : 1;
+    const int cnt = (p.n_groups - off + stride - 1) / stride;   // query groups of this tile handled here (>= 1)
+    const int n_it = (cnt + NW - 1) / NW;
+    // (1) my DMA pieces of `tile` have landed (vmcnt(0)); (2) barrier: every wave's pieces have, and every wave is
+    // done with the previous tile's gi buffer
+    __syncthreads();
+    const float4* tEx = reinterpret_cast<const float4*>(sEx);
+    const float4* tGi = reinterpret_cast<const float4*>(sGi + cur * G::kTileGiFloats);
+    for (int it = 0; it < n_it; ++it) {
+      const int gi_idx = wave + it * NW;
+      const bool has = gi_idx < cnt;
+      const int g = off + stride * gi_idx;
+      f32x16 D1[PX];
+      if (has) {
+        const float4* eq = reinterpret_cast<const float4*>(p.eqfrag + (int64_t)g * G::kEqGroupFloats);
+        if constexpr (SPLIT) gemm1_split<G, PX, DD>(D1, eq, tEx, lane, p.cl_scale);
+        else gemm1<G, PX, DD>(D1, eq, tEx, lane);
+      }
+      if (it == n_it - 1) {
+        __syncthreads();   // every wave is past its last GEMM1 of this tile: the Ex buffer is free
+        if (i + 1 < mine) {
+          const float* tn = p.ipack + tile_of(i + 1) * (int64_t)G::kTileFloats;
+          dma_floats<NW>(tn, sEx, G::kTileExFloats, wave, lane);
+          dma_floats<NW>(tn + G::kTileExFloats, sGi + (cur ^ 1) * G::kTileGiFloats, G::kTileGiFloats, wave, lane);
+        }
+      }
+      if (has) unit_queries<G, PX, SPLIT>(D1, p, g, -1, tile * kTileItems, smem, sW1, sW2, sB1, sB2, tGi, lane, hi, x);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Kernel C ("ksplit"): shapes whose logit axis is too long for the register-resident scheme above
 // (16x16x64: L = 256 -> a whole D1 would be 256 registers and the gate weights 256 KiB).
 // One wave per SIMD (4 waves, 512 registers).  Per unit = (query group of 32/P_Q queries, tile of 32 items):
@@ -788,7 +878,7 @@ static int launch_ksplit(const ScoreArgs& a, int n_cu, hipStream_t stream) {
 }
 
 // RAILS_SCORE_VARIANT: 0 = pick automatically; 1 / 2 = force direct / staged with 8 waves (2 per SIMD);
-// 3 / 4 = direct / staged with 4 waves (1 per SIMD, 512 registers)
+// 3 / 4 = direct / staged with 4 waves (1 per SIMD, 512 registers); 5 = staged with a single Ex buffer (8 waves)
 static int score_variant() {
   const char* e = getenv("RAILS_SCORE_VARIANT");
   return e ? atoi(e) : 0;
@@ -827,18 +917,48 @@ static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   }
 }
 
+template <int PQ, int PX, int DD, int H, bool SPLIT>
+static int launch_staged1(const ScoreArgs& a, int n_cu, hipStream_t stream) {
+  using G = Geo<PQ, PX, DD, H>;
+  constexpr int NW = 8;
+  constexpr size_t lds = ((size_t)G::kWpackFloats + (size_t)G::kTileExFloats + 2 * (size_t)G::kTileGiFloats) * sizeof(float);
+  if constexpr (lds > 160 * 1024) {
+    set_error("single-buffer staged scoring kernel needs %zu B of LDS", lds);
+    return kErrUnsupported;
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mol_score_staged1_kernel<PQ, PX, DD, H, NW, SPLIT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return kErrLaunch;
+      attr_set = true;
+    }
+    if (a.n_tiles < 1) return kOk;
+    // always a full grid: the leftover-round split needs the idle workgroups (they exit at once otherwise)
+    hipLaunchKernelGGL((mol_score_staged1_kernel<PQ, PX, DD, H, NW, SPLIT>), dim3((unsigned)n_cu), dim3(NW * 64), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+  }
+}
+
 template <int PQ, int PX, int DD, int H>
 static int launch_score(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using G = Geo<PQ, PX, DD, H>;
   constexpr bool staged_fits = ((size_t)G::kWpackFloats + 2 * (size_t)G::kTileFloats) * sizeof(float) <= 160 * 1024;
   int variant = score_variant();
   if (variant == 0) {
-    variant = (staged_fits && !a.per_row && a.n_groups >= kScoreWaves) ? 2 : 1;
-    // a corpus of at most n_cu/2 tiles would leave half the chip idle under one-tile-per-workgroup staging; the direct
-    // kernel spreads its units one per SIMD over all CUs (ML-1M: 122 tiles)
-    if (variant == 2 && a.n_tiles * 2 <= n_cu) variant = 1;
+    constexpr bool staged1_fits = ((size_t)G::kWpackFloats + (size_t)G::kTileExFloats + 2 * (size_t)G::kTileGiFloats) * sizeof(float) <= 160 * 1024;
+    variant = 1;                                            // few query groups / per-row candidates: independent waves
+    if (!a.per_row && a.n_groups >= kScoreWaves) {
+      // double-buffered tiles where they fit and the corpus fills the chip for many rounds (the measured headline path);
+      // otherwise the single-Ex-buffer kernel: 8x4x128 tiles only fit once, and its leftover-round split is what keeps
+      // small corpora (ML-1M: 122 tiles, ML-20M: 853) spread over all CUs
+      if (staged_fits && a.n_tiles >= 8 * (int64_t)n_cu) variant = 2;
+      else if (staged1_fits) variant = 5;
+      else if (staged_fits) variant = 2;
+    }
   }
-  if ((variant == 2 || variant == 4) && a.per_row) { set_error("staged scoring kernel does not do per-row candidates"); return kErrUnsupported; }
+  if ((variant == 2 || variant == 4 || variant == 5) && a.per_row) { set_error("staged scoring kernel does not do per-row candidates"); return kErrUnsupported; }
+  if (variant == 5) return a.split ? launch_staged1<PQ, PX, DD, H, true>(a, n_cu, stream) : launch_staged1<PQ, PX, DD, H, false>(a, n_cu, stream);
   if (a.split) {
     switch (variant) {
       case 1: return launch_kernel<PQ, PX, DD, H, 8, false, true>(a, n_cu, stream);
