@@ -187,6 +187,19 @@ int rails_mol_coarse_build(const rails_mol_shape* shape, const float* index, int
 int rails_mol_coarse_score(const rails_mol_shape* shape, const float* eq, int32_t batch, int32_t average_queries,
                            const void* table, int64_t n_items, float* scores, int64_t ld, void* stream);
 
+/* Fused coarse scoring + exact top-K' (the same scores as rails_mol_coarse_score followed by rails_topk, without
+ * materialising the (batch, n_items) matrix): a strided sample of the table fixes a per-query threshold, one streaming
+ * pass collects the items at or above it, and the K' best of those are selected with the position tie rule.
+ * out_scores / out_positions: (batch, k_prime), descending.  out_counts[b] = candidates query b collected; the result
+ * for query b is exact iff k_prime <= out_counts[b] <= the internal capacity (min(24576, max(4096, 8 k_prime)), rounded up
+ * to a multiple of 64; capacity + 1 is reported when one of the 16 internal sub-lists overflowed) -- otherwise (heavy
+ * ties at the threshold) the caller falls back to rails_mol_coarse_score + rails_topk.
+ * k_prime <= 4096.  rails_mol_coarse_topk_workspace_bytes returns 0 when the sizes are unsupported. */
+size_t rails_mol_coarse_topk_workspace_bytes(const rails_mol_shape* shape, int32_t batch, int64_t n_items, int32_t k_prime);
+int rails_mol_coarse_topk(const rails_mol_shape* shape, const float* eq, int32_t batch, int32_t average_queries,
+                          const void* table, int64_t n_items, int32_t k_prime, void* workspace, size_t workspace_bytes,
+                          float* out_scores, int64_t* out_positions, int32_t* out_counts, void* stream);
+
 /* ---- per-component candidate generation (MoLNaiveTopK / MoLCombTopK) ------------------------------
  * Replaces the bf16 component table (rails/indexing/mol_top_k.py:61-73, :172-174) and the per-query-group bf16 `mm`
  * (mol_top_k.py:247-251, :498-502).  scores has batch * P_Q * P_X rows, row (b * P_Q + i) * P_X + m, n_items columns;

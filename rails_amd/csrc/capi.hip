@@ -298,6 +298,27 @@ int rails_mol_coarse_build(const rails_mol_shape* s, const float* index, int64_t
   return fail(coarse_build(*s, index, n_items, table, (hipStream_t)stream), "coarse_build");
 }
 
+size_t rails_mol_coarse_topk_workspace_bytes(const rails_mol_shape* s, int32_t batch, int64_t n_items, int32_t k_prime) {
+  if (!shape_ok(s) || batch <= 0) return 0;
+  return coarse_topk_workspace_bytes(*s, batch, n_items, k_prime);
+}
+
+int rails_mol_coarse_topk(const rails_mol_shape* s, const float* eq, int32_t batch, int32_t average_queries, const void* table,
+                          int64_t n_items, int32_t k_prime, void* workspace, size_t workspace_bytes, float* out_scores,
+                          int64_t* out_positions, int32_t* out_counts, void* stream) {
+  g_err[0] = '\0';
+  if (!shape_ok(s)) return RAILS_EINVAL;
+  if (batch < 0 || n_items < 0 || k_prime < 0) { set_error("coarse_topk: negative size"); return RAILS_EINVAL; }
+  if (k_prime > n_items) { set_error("coarse_topk: selected index k out of range (k = %d > n = %lld)", k_prime, (long long)n_items); return RAILS_EINVAL; }
+  if (batch == 0 || k_prime == 0) return RAILS_OK;
+  if (!eq || !table || !workspace || !out_scores || !out_positions || !out_counts) { set_error("coarse_topk: NULL pointer"); return RAILS_EINVAL; }
+  const int cu = compute_units();
+  if (cu <= 0) { set_error("coarse_topk: no HIP device"); return RAILS_ELAUNCH; }
+  const int r = coarse_topk(*s, eq, batch, average_queries ? 1 : 0, table, n_items, k_prime, workspace, workspace_bytes,
+                            out_scores, out_positions, out_counts, cu, (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "coarse_topk");
+}
+
 int rails_mol_coarse_score(const rails_mol_shape* s, const float* eq, int32_t batch, int32_t average_queries,
                            const void* table, int64_t n_items, float* scores, int64_t ld, void* stream) {
   g_err[0] = '\0';

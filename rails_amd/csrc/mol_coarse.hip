@@ -9,6 +9,7 @@
 //   score[b, x] = bf16( sum_d qsum[b,d] * table[x,d] )                            returned as fp32
 // The scan is HBM-bound: 2*d bytes per item against 2*d*B flops.
 #include <hip/hip_runtime.h>
+#include <math.h>
 
 #include "mol_kernels.h"
 #include "mol_layout.h"
@@ -41,38 +42,145 @@ __global__ void coarse_build_kernel(const float* __restrict__ ipack, int64_t n, 
   table[i] = bf16_bits(bf16_rn(acc) / (float)PX);
 }
 
-// scores[b][x] for all b of one item per thread; query sums staged in LDS
-__global__ __launch_bounds__(256) void coarse_score_kernel(const float* __restrict__ eq, int B, int PQ, int d, int avg,
-                                                          const unsigned short* __restrict__ table, int64_t n,
-                                                          float* __restrict__ scores, int64_t ld) {
-  extern __shared__ __attribute__((aligned(16))) float qs[];  // [B][d]
-  for (int i = threadIdx.x; i < B * d; i += blockDim.x) {
+// ---- the coarse scan (bf16 MFMA) ------------------------------------------------------------------------------
+// 2*d*B flops against 2*d bytes per item: at B = 32 that is 2048 flop per 64-byte item -- 6x what the VALU can stream at
+// HBM rate, nothing for the bf16 MFMA.  A wave takes tiles of 32 items: v_mfma_f32_32x32x16_bf16 with the 32 queries of a
+// query tile on the row axis (A: the P_Q-summed query rows, bf16, fragment order in LDS -> registers) and the items on the
+// column axis (B: lane (x, h) reads 16 contiguous bytes of table row x per 16-wide K chunk, so a wave reads the tile's
+// 32*2d bytes exactly once, fully coalesced).  fp32 accumulate, result rounded to bf16 like the reference's bf16 mm.
+//
+// Three modes share the arithmetic (so their scores are bit-identical):
+//   kScanAll     scores[b][x] for every item                         (the materialising path)
+//   kScanSample  scores of every `stride`-th tile, compacted          (threshold estimation of the fused top-K')
+//   kScanSelect  keys (score, position) of the items whose score is >= thr[b] appended to per-query candidate lists
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float cf32x16 __attribute__((ext_vector_type(16)));
+enum { kScanAll = 0, kScanSample = 1, kScanSelect = 2 };
+// A query's candidate list is split into sub-lists by tile index (t % kSubLists): one device-scope counter per query
+// serialised ~600k appends at K' = 4000 (2.4 ms for a 0.75 ms scan); 16 counters per query spread them, and taking the
+// sub-list from the tile index keeps the split even for any item order.
+constexpr int kSubLists = 16;
+constexpr int kScanThreads = 256;
+
+struct CoarseScanArgs {
+  const float* eq; int B, PQ, d, avg;
+  const unsigned short* table; int64_t n;
+  float* scores; int64_t ld;            // kScanAll / kScanSample
+  int stride;                           // kScanSample: tiles t with t % stride == 0, column (t / stride) * 32 + x
+  const float* thr; int64_t thr_stride; // kScanSelect: thr[b * thr_stride], a bf16 value
+  unsigned long long* keys; int cap;    // kScanSelect: keys[b * cap + sub * (cap / kSubLists) + slot]
+  unsigned int* counts;                 // kScanSelect: counts[b * kSubLists + sub], candidates seen (may exceed the sub-list)
+};
+
+__device__ __forceinline__ unsigned int coarse_orderable(float f) {
+  const unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float coarse_unorderable(unsigned int k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+template <int DC, int MODE>   // DC = d / 16 K chunks
+__global__ __launch_bounds__(kScanThreads) void coarse_scan_kernel(CoarseScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short qfrag[];   // [n_qt][DC][64 lanes][8] bf16, then thr
+  const int d = a.d, B = a.B;
+  const int n_qt = (B + 31) / 32;
+  float* thr_s = reinterpret_cast<float*>(qfrag + (size_t)n_qt * DC * 64 * 8);   // [n_qt * 32]
+  for (int i = threadIdx.x; i < n_qt * 32 * d; i += kScanThreads) {
     const int b = i / d, dd = i - b * d;
     float acc = 0.0f;
-    for (int p = 0; p < PQ; ++p) acc += eq[((int64_t)b * PQ + p) * d + dd];
-    qs[i] = bf16_rn(avg ? acc / (float)PQ : acc);
+    if (b < B)
+      for (int p = 0; p < a.PQ; ++p) acc += a.eq[((int64_t)b * a.PQ + p) * d + dd];
+    const float v = b < B ? bf16_rn(a.avg ? acc / (float)a.PQ : acc) : 0.0f;
+    const int qt = b >> 5, row = b & 31, c = dd >> 4, h = (dd >> 3) & 1, j = dd & 7;
+    qfrag[(((size_t)qt * DC + c) * 64 + h * 32 + row) * 8 + j] = (unsigned short)(__float_as_uint(v) >> 16);
   }
+  if constexpr (MODE == kScanSelect)
+    for (int i = threadIdx.x; i < n_qt * 32; i += kScanThreads) thr_s[i] = i < B ? a.thr[(int64_t)i * a.thr_stride] : INFINITY;
   __syncthreads();
-  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (int64_t)gridDim.x * blockDim.x) {
-    const uint4* row = reinterpret_cast<const uint4*>(table + x * d);
-    for (int b0 = 0; b0 < B; b0 += 8) {  // 8 accumulators per pass over the row (row stays in L1/registers)
-      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      for (int c = 0; c < d / 8; ++c) {
-        const uint4 v = row[c];
-        const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = lane & 31, h = lane >> 5;
+  const int64_t n_tiles = (a.n + 31) >> 5;
+  const int64_t step = MODE == kScanSample ? a.stride : 1;
+  const int64_t n_work = (n_tiles + step - 1) / step;            // tiles this launch visits
+  const int64_t gw = (int64_t)blockIdx.x * (kScanThreads / 64) + wave, n_waves = (int64_t)gridDim.x * (kScanThreads / 64);
+  for (int qt = 0; qt < n_qt; ++qt) {
+    bf16x8 A[DC];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float t = bf16_to_f32((unsigned short)((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu));
+    for (int c = 0; c < DC; ++c) A[c] = *reinterpret_cast<const bf16x8*>(qfrag + (((size_t)qt * DC + c) * 64 + lane) * 8);
+    float thr[16], tlo[16];
+    if constexpr (MODE == kScanSelect) {
 #pragma unroll
-          for (int bb = 0; bb < 8; ++bb)
-            if (b0 + bb < B) acc[bb] = __builtin_fmaf(qs[(b0 + bb) * d + c * 8 + j], t, acc[bb]);
+      for (int r = 0; r < 16; ++r) {
+        thr[r] = thr_s[qt * 32 + acc_row(r, h)];
+        // pre-test bound: the bf16 value just below thr (an un-rounded sum at or above it may still round up to thr)
+        tlo[r] = coarse_unorderable(coarse_orderable(thr[r]) - 0x10000u);
+      }
+    }
+    for (int64_t w = gw; w < n_work; w += n_waves) {
+      const int64_t t = w * step;
+      int64_t item = t * 32 + x;
+      const bool in = item < a.n;
+      if (!in) item = a.n - 1;
+      const unsigned short* rowp = a.table + item * d + 8 * h;
+      bf16x8 Bv[DC];
+#pragma unroll
+      for (int c = 0; c < DC; ++c) Bv[c] = *reinterpret_cast<const bf16x8*>(rowp + 16 * c);
+      cf32x16 acc = {0};
+#pragma unroll
+      for (int c = 0; c < DC; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c], Bv[c], acc, 0, 0, 0);
+      if constexpr (MODE == kScanSelect) {
+        bool hit = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hit |= acc[r] >= tlo[r];
+        if (__any(hit && in)) {   // rare at shard scale (K'/N of the scores pass); per register, only lanes that pass work
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool maybe = in && acc[r] >= tlo[r];
+            if (__any(maybe)) {
+              const int q = qt * 32 + acc_row(r, h);
+              const float sc = bf16_rn(acc[r]);
+              if (maybe && q < B && sc >= thr[r]) {
+                const int sub = (int)(t % kSubLists), subcap = a.cap / kSubLists;
+                const unsigned int slot = atomicAdd(&a.counts[q * kSubLists + sub], 1u);
+                if (slot < (unsigned int)subcap)
+                  a.keys[(int64_t)q * a.cap + sub * subcap + slot] = ((unsigned long long)coarse_orderable(sc) << 32) | (unsigned int)(~(unsigned int)item);
+              }
+            }
+          }
+        }
+      } else {
+        const int64_t colx = MODE == kScanSample ? w * 32 + x : item;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int q = qt * 32 + acc_row(r, h);
+          if (q < B && (in || MODE == kScanSample)) a.scores[(int64_t)q * a.ld + colx] = in ? bf16_rn(acc[r]) : -INFINITY;
         }
       }
-#pragma unroll
-      for (int bb = 0; bb < 8; ++bb)
-        if (b0 + bb < B) scores[(int64_t)(b0 + bb) * ld + x] = bf16_rn(acc[bb]);
     }
   }
+}
+
+template <int MODE>
+static int launch_coarse_scan(const CoarseScanArgs& a, hipStream_t stream) {
+  const int n_qt = (a.B + 31) / 32;
+  const int dc = a.d / 16;
+  const size_t lds = (size_t)n_qt * dc * 64 * 8 * sizeof(unsigned short) + (size_t)n_qt * 32 * sizeof(float);
+  if (lds > 64 * 1024) { set_error("coarse scan: batch %d x d %d does not fit LDS", a.B, a.d); return kErrUnsupported; }
+  const int64_t n_tiles = (a.n + 31) >> 5;
+  const int64_t step = MODE == kScanSample ? a.stride : 1;
+  const int64_t n_work = (n_tiles + step - 1) / step;
+  int64_t grid = (n_work + 3) / 4;
+  if (grid > 2048) grid = 2048;     // 8 workgroups of 4 waves per CU: enough 16-byte loads in flight to stream HBM
+  if (grid < 1) return kOk;
+  switch (dc) {
+    case 2: hipLaunchKernelGGL((coarse_scan_kernel<2, MODE>), dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a); break;
+    case 4: hipLaunchKernelGGL((coarse_scan_kernel<4, MODE>), dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a); break;
+    case 8: hipLaunchKernelGGL((coarse_scan_kernel<8, MODE>), dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a); break;
+    default: set_error("coarse scan: d = %d (supported: 32, 64, 128)", a.d); return kErrUnsupported;
+  }
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
 int coarse_build(const Shape& s, const float* ipack, int64_t n, void* table, hipStream_t stream) {
@@ -86,17 +194,114 @@ int coarse_build(const Shape& s, const float* ipack, int64_t n, void* table, hip
 
 int coarse_score(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, float* scores, int64_t ld,
                  hipStream_t stream) {
-  const int d = s.dot_product_dimension;
   if (B <= 0 || n <= 0) return kOk;
-  const size_t lds = sizeof(float) * (size_t)B * d;
-  if (lds > 64 * 1024) { set_error("coarse_score: batch %d x d %d does not fit LDS", B, d); return kErrUnsupported; }
-  int64_t grid = (n + 255) / 256;
-  if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(coarse_score_kernel, dim3((unsigned)grid), dim3(256), lds, stream, eq, B, s.query_dot_product_groups,
-                     d, avg, static_cast<const unsigned short*>(table), n, scores, ld);
-  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+  CoarseScanArgs a{};
+  a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.d = s.dot_product_dimension; a.avg = avg;
+  a.table = static_cast<const unsigned short*>(table); a.n = n; a.scores = scores; a.ld = ld; a.stride = 1;
+  return launch_coarse_scan<kScanAll>(a, stream);
 }
 
+// ---- fused coarse top-K' -----------------------------------------------------------------------------------------
+// Exact top-K' of the coarse scores without materialising the (B, N) score matrix (16 GB per 125 M-item shard at
+// B = 32, and five more passes over it for the selection):
+//   1. kScanSample scores every stride-th tile                      (N / stride items per query)
+//   2. top-r of the sample -> thr[b] = its r-th largest score.  With m = K'/stride expected sample hits above the true
+//      K'-th score, r = 2m + 4 sqrt(m) + 8 puts thr below it with overwhelming probability, while only ~r*stride items
+//      of the corpus are expected at or above thr
+//   3. kScanSelect streams the whole table once and appends the keys (score, position) with score >= thr[b] to query b's
+//      candidate list (`cap` slots)
+//   4. row_select over the candidate keys: the K' largest, ties by position -- exactly what top-K' over the materialised
+//      scores returns, PROVIDED K' <= counts[b] <= cap for every query.  counts come back to the caller, who falls back
+//      to the materialising path otherwise (heavy ties at the threshold, adversarial item order).
+// out[b] = candidates of query b, or cap + 1 when one of its sub-lists overflowed (the caller then falls back)
+__global__ void coarse_counts_kernel(const unsigned int* __restrict__ counts, int B, int cap, int32_t* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  unsigned int total = 0;
+  bool over = false;
+  for (int sub = 0; sub < kSubLists; ++sub) {
+    const unsigned int c = counts[b * kSubLists + sub];
+    total += c;
+    over |= c > (unsigned int)(cap / kSubLists);
+  }
+  out[b] = over ? cap + 1 : (int32_t)total;
+}
+
+struct CoarseTopkPlan { int stride, r, cap; int64_t n_sample; size_t off_keys, off_sample, off_top_s, off_top_i, off_ws, total, topk_ws; };
+
+static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p) {
+  if (k_prime < 1 || k_prime > 4096 || n < k_prime) return false;
+  const int64_t n_tiles = (n + 31) >> 5;
+  // sample every stride-th tile: ~16 expected hits above the true K'-th score for large K', never denser than 1/64 of
+  // the table (small K' just get fewer expected hits m, and r = 2m + 4 sqrt(m) + 8 keeps the miss probability ~1e-10)
+  int stride = k_prime / 16;
+  if (stride < 64) stride = 64;
+  if (stride > 256) stride = 256;
+  auto r_of = [&](int st) {
+    const float m = (float)k_prime / st;
+    int r = (int)(2.0f * m + 4.0f * sqrtf(m) + 8.0f) + 1;
+    return r > 512 ? 512 : r;
+  };
+  while (stride > 1 && ((n_tiles + stride - 1) / stride) * 32 < 8 * (int64_t)r_of(stride)) stride /= 2;   // sample >= 8r
+  const int r = r_of(stride);
+  if ((float)k_prime / stride > 200.0f) return false;   // corpus too small for a sparse sample: nothing to gain
+  p->stride = stride; p->r = r;
+  p->n_sample = ((n_tiles + stride - 1) / stride) * 32;
+  if (p->n_sample < r) return false;
+  int cap = 8 * k_prime;
+  if (cap < 4096) cap = 4096;
+  if (cap > 24 * 1024) cap = 24 * 1024;
+  cap = (cap + kSubLists * 4 - 1) / (kSubLists * 4) * (kSubLists * 4);
+  p->cap = cap;
+  size_t o = align256(sizeof(unsigned int) * (size_t)B * kSubLists);
+  p->off_keys = o; o += align256(sizeof(unsigned long long) * (size_t)B * cap);
+  p->off_sample = o; o += align256(sizeof(float) * (size_t)B * p->n_sample);
+  p->off_top_s = o; o += align256(sizeof(float) * (size_t)B * r);
+  p->off_top_i = o; o += align256(sizeof(int64_t) * (size_t)B * r);
+  p->topk_ws = topk_workspace_bytes(B, p->n_sample, r);
+  p->off_ws = o; o += align256(p->topk_ws);
+  p->total = o;
+  return true;
+}
+
+size_t coarse_topk_workspace_bytes(const Shape& s, int B, int64_t n, int k_prime) {
+  CoarseTopkPlan p;
+  return coarse_topk_plan(B, n, k_prime, &p) ? p.total : 0;
+}
+
+int coarse_topk(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, int k_prime, void* ws,
+                size_t ws_bytes, float* out_scores, int64_t* out_pos, int32_t* out_counts, int n_cu, hipStream_t stream) {
+  CoarseTopkPlan p;
+  if (!coarse_topk_plan(B, n, k_prime, &p)) { set_error("coarse_topk: unsupported size (K' = %d, n = %lld)", k_prime, (long long)n); return kErrUnsupported; }
+  if (n >= (1ll << 32)) { set_error("coarse_topk: n does not fit 32-bit positions; shard the corpus"); return kErrUnsupported; }
+  if (ws_bytes < p.total) { set_error("coarse_topk: workspace too small"); return kErrNoMem; }
+  char* base = static_cast<char*>(ws);
+  unsigned int* counts = reinterpret_cast<unsigned int*>(base);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(base + p.off_keys);
+  float* sample = reinterpret_cast<float*>(base + p.off_sample);
+  float* top_s = reinterpret_cast<float*>(base + p.off_top_s);
+  int64_t* top_i = reinterpret_cast<int64_t*>(base + p.off_top_i);
+  if (hipMemsetAsync(base, 0, p.off_sample, stream) != hipSuccess) return kErrLaunch;   // counts + candidate keys
+
+  CoarseScanArgs a{};
+  a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.d = s.dot_product_dimension; a.avg = avg;
+  a.table = static_cast<const unsigned short*>(table); a.n = n;
+  a.scores = sample; a.ld = p.n_sample; a.stride = p.stride;
+  int rc = launch_coarse_scan<kScanSample>(a, stream);
+  if (rc != kOk) return rc;
+  rc = topk(sample, p.n_sample, B, p.n_sample, p.r, nullptr, 0, top_s, top_i, base + p.off_ws, p.topk_ws, n_cu, stream);
+  if (rc != kOk) return rc;
+  a.scores = nullptr; a.stride = 1;
+  a.thr = top_s + (p.r - 1); a.thr_stride = p.r; a.keys = keys; a.cap = p.cap; a.counts = counts;
+  rc = launch_coarse_scan<kScanSelect>(a, stream);
+  if (rc != kOk) return rc;
+  rc = select_keys(keys, B, p.cap, k_prime, out_scores, out_pos, stream);
+  if (rc != kOk) return rc;
+  hipLaunchKernelGGL(coarse_counts_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, counts, B, p.cap, out_counts);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Per-component candidate generation of MoLNaiveTopK / MoLCombTopK (reference rails/indexing/mol_top_k.py:

@@ -701,6 +701,21 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
+// Top-k of rows of 64-bit keys (score bits << 32 | ~position), zero-padded: out (score, position), descending.
+// Used by the fused coarse top-K' (mol_coarse.hip) on its candidate lists.
+int select_keys(const unsigned long long* keys, int rows, int keys_per_row, int k, float* out_scores, int64_t* out_pos,
+                hipStream_t stream) {
+  if (rows <= 0 || k <= 0) return kOk;
+  if (k > kRowMaxK || keys_per_row > 24 * kRowThreads || k > keys_per_row) {
+    set_error("select_keys: k = %d of %d keys per row is out of range", k, keys_per_row);
+    return kErrUnsupported;
+  }
+  RowSelectArgs b{};
+  b.keys_in = keys; b.keys_per_row = keys_per_row; b.k = k;
+  b.out_scores = out_scores; b.out_ids = out_pos;
+  return launch_row_select<true>(b, rows, 1, keys_per_row, stream);
+}
+
 // ---- seen-id filter ----------------------------------------------------------------------------
 // One workgroup per row.  Literal restatement of indexing/candidate_index.py:156-175:
 //   valid  = not seen, and among the first k such

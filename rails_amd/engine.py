@@ -339,6 +339,32 @@ class MolEngine:
             )
         return out
 
+    def coarse_topk(self, eq: torch.Tensor, table: torch.Tensor, average_queries: bool, k_prime: int):
+        """Fused coarse scoring + exact top-K' (no (B, N) score matrix).  -> (scores (B, K'), positions (B, K'), counts (B,)
+        int32) or None when the sizes are unsupported.  The result is exact iff K' <= counts[b] <= capacity for every b
+        (see include/rails_amd.h); the caller checks and falls back to coarse_scores + topk otherwise."""
+        B, n = eq.shape[0], table.shape[0]
+        ws_bytes = self.lib.rails_mol_coarse_topk_workspace_bytes(C.byref(self.shape), B, n, k_prime)
+        if ws_bytes == 0:
+            return None
+        eq = _f32c(eq)
+        dev = table.device
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        out_s = torch.empty((B, k_prime), dtype=torch.float32, device=dev)
+        out_p = torch.empty((B, k_prime), dtype=torch.int64, device=dev)
+        counts = torch.empty((B,), dtype=torch.int32, device=dev)
+        with _on_device(dev):
+            _lib.check(
+                self.lib.rails_mol_coarse_topk(C.byref(self.shape), _ptr(eq), B, 1 if average_queries else 0, _ptr(table), n, k_prime,
+                                               _ptr(ws), ws_bytes, _ptr(out_s), _ptr(out_p), _ptr(counts), _stream()),
+                "rails_mol_coarse_topk",
+            )
+        return out_s, out_p, counts
+
+    @staticmethod
+    def coarse_topk_capacity(k_prime: int) -> int:
+        cap = min(24576, max(4096, 8 * k_prime))
+        return (cap + 63) // 64 * 64
 
     # ---- per-component candidates (MoLNaiveTopK / MoLCombTopK) -----------------------------------------
     def build_component_table(self, index: MolIndex) -> torch.Tensor:

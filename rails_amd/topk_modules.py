@@ -105,6 +105,7 @@ class MoLAvgTopK(MoLTopKModule):
     def __init__(self, mol_module: MoLSimilarity, item_embeddings: torch.Tensor, item_ids: torch.Tensor, avg_top_k: int) -> None:
         super().__init__(mol_module=mol_module, item_embeddings=item_embeddings, item_ids=item_ids)
         self._avg_top_k: int = avg_top_k
+        self.fused_coarse_min_items: int = 262144    # below this the (B, N) scores are small and one launch chain shorter
         self._coarse_engine = None
         self._coarse_table = None
 
@@ -119,9 +120,20 @@ class MoLAvgTopK(MoLTopKModule):
         eng = self._bind()
         table = self._table()
         qpack, eq, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"), want_plain=True)
+        n = table.shape[0]
+        if self._avg_top_k > n:
+            raise RuntimeError(f"selected index k out of range (k={self._avg_top_k}, n={n})")
+        # large corpora: fused scan + threshold select, no (B, N) score matrix (16 GB per 125 M-item shard at B = 32).
+        # Same scores and the same exact top-K' as the materialising path below -- when every query's candidate count
+        # landed inside [K', capacity]; the check costs one 128-byte device-to-host copy.
+        if n >= self.fused_coarse_min_items and self._avg_top_k <= 4096:
+            fused = eng.coarse_topk(eq, table, average_queries, self._avg_top_k)
+            if fused is not None:
+                _, idx, counts = fused
+                lo, hi = int(counts.min()), int(counts.max())
+                if lo >= self._avg_top_k and hi <= eng.coarse_topk_capacity(self._avg_top_k):
+                    return qpack, idx
         coarse = eng.coarse_scores(eq, table, average_queries)
-        if self._avg_top_k > coarse.shape[1]:
-            raise RuntimeError(f"selected index k out of range (k={self._avg_top_k}, n={coarse.shape[1]})")
         _, idx = E.topk(coarse, self._avg_top_k)
         return qpack, idx
 

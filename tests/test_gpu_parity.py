@@ -283,6 +283,59 @@ def test_f4_avg_topk(fx, mol, dev, avg_k):
             at(q, k=avg_k + 1, **kw)
 
 
+@pytest.mark.parametrize("cfg_name,n,avg_k", [("amzn-books", 300_001, 100), ("amzn-books", 300_001, 1000), ("amzn-books", 700_000, 4000),
+                                              ("ml-1m", 280_000, 500), ("ml-20m", 270_000, 200)])
+def test_fused_coarse_topk_equals_the_materialised_path(dev, cfg_name, n, avg_k):
+    """Config 5's coarse pass at scale: scan + threshold select without the (B, N) score matrix.  Same MFMA arithmetic as
+    rails_mol_coarse_score, so (scores, positions) must equal coarse_scores + top-K' bit for bit."""
+    cfg = O.CONFIGS[cfg_name]
+    mol = build_module(cfg, O.synthetic_weights(cfg, seed=2), dev)
+    X = torch.from_numpy(O.hash_item_table(5, 0, n, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    B = 32 if cfg_name == "amzn-books" else 19
+    q = O.synthetic_queries(cfg, B, seed=4).to(dev)
+    kw = {}
+    if len(cfg.uid_embedding_hash_sizes) > 0:
+        kw["user_ids"] = torch.arange(B, dtype=torch.int64, device=dev) * 7 + 1
+    with torch.inference_mode():
+        at = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=avg_k)
+        eng = at._bind()
+        _, eq, _ = eng.query_pack(q, kw.get("user_ids"), want_plain=True)
+        for average in (False, True):
+            coarse = eng.coarse_scores(eq, at._table(), average)
+            rs, rp = E.topk(coarse, avg_k)
+            fs, fp, counts = eng.coarse_topk(eq, at._table(), average, avg_k)
+            assert int(counts.min()) >= avg_k and int(counts.max()) <= eng.coarse_topk_capacity(avg_k), counts
+            assert torch.equal(fs, rs) and torch.equal(fp, rp)
+        # the module takes the fused path at this size and returns what the materialising path returns
+        s1, i1 = at(q, k=50, **kw)
+        at.fused_coarse_min_items = 1 << 62
+        s2, i2 = at(q, k=50, **kw)
+        assert torch.equal(s1, s2) and torch.equal(i1, i2)
+
+
+def test_fused_coarse_topk_falls_back_on_heavy_ties(dev):
+    """A corpus of 300k copies of 40 distinct items: every coarse score is tied thousands of times, the candidate lists
+    overflow, and the module must notice (counts) and return the materialising path's answer."""
+    cfg = O.CONFIGS["amzn-books"]
+    mol = build_module(cfg, O.synthetic_weights(cfg, seed=2), dev)
+    base = torch.from_numpy(O.hash_item_table(6, 0, 40, cfg.item_embedding_dim))
+    n = 300_000
+    X = base[torch.arange(n) % 40].unsqueeze(0).to(dev)
+    ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    q = O.synthetic_queries(cfg, 8, seed=4).to(dev)
+    with torch.inference_mode():
+        at = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=200)
+        eng = at._bind()
+        _, eq, _ = eng.query_pack(q, None, want_plain=True)
+        _, _, counts = eng.coarse_topk(eq, at._table(), False, 200)
+        assert int(counts.max()) > eng.coarse_topk_capacity(200)
+        s1, i1 = at(q, k=50)
+        at.fused_coarse_min_items = 1 << 62
+        s2, i2 = at(q, k=50)
+        assert torch.equal(s1, s2) and torch.equal(i1, i2)
+
+
 # ---- section 8(f) rank 2: MIPSBruteForceTopK + DotProductSimilarity ------------------------------------
 def test_f9_mips_and_dot_product(dev):
     import os

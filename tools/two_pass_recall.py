@@ -17,6 +17,8 @@ ap.add_argument("--k", type=int, default=100)
 ap.add_argument("--avg-top-k", default="500,2000,4000")
 ap.add_argument("--precision", default=None)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--device-table", action="store_true", help="draw the item table on the GPU (truncated normal, sigma 0.02) "
+                "instead of the host counter hash: for shard-sized corpora (125 M items = 32 GB)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = O.CONFIGS["synthetic-8x8x32"]
@@ -31,9 +33,15 @@ mol.precision = a.precision
 N, B, k = a.items, a.batch, a.k
 t0 = time.time()
 X = torch.empty((1, N, cfg.item_embedding_dim), dtype=torch.float32, device=dev)
-for s in range(0, N, 1_000_000):   # counter-hash table, generated in bounded host chunks
-    n = min(1_000_000, N - s)
-    X[0, s : s + n] = torch.from_numpy(O.hash_item_table(1, s, n, cfg.item_embedding_dim)).to(dev)
+if a.device_table:
+    g = torch.Generator(device=dev).manual_seed(1)
+    for s in range(0, N, 8_000_000):
+        n = min(8_000_000, N - s)
+        X[0, s : s + n] = torch.fmod(torch.randn((n, cfg.item_embedding_dim), generator=g, device=dev), 2.0) * 0.02
+else:
+    for s in range(0, N, 1_000_000):   # counter-hash table, generated in bounded host chunks
+        n = min(1_000_000, N - s)
+        X[0, s : s + n] = torch.from_numpy(O.hash_item_table(1, s, n, cfg.item_embedding_dim)).to(dev)
 ids = torch.arange(1, N + 1, dtype=torch.int64, device=dev).unsqueeze(0)
 q = O.synthetic_queries(cfg, B).to(dev)
 gen_s = time.time() - t0
@@ -49,24 +57,47 @@ def timed(fn):
     return out, e0.elapsed_time(e1) / a.reps
 
 
+from rails_amd import engine as E
+
 with torch.inference_mode():
     t0 = time.time()
-    bf = rails_amd.MoLBruteForceTopK(mol, X, ids)
+    at = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=1000)     # ONE index (640 B/item) serves the exact and the two-pass runs
     torch.cuda.synchronize()
     build_s = time.time() - t0
-    (es, ei), exact_ms = timed(lambda: bf(q, k=k))
+    table = at._table()
+    eng = at._bind()
+
+    def exact():
+        logits = at._all_logits_scratch(q)
+        return E.topk(logits, k, ids=at._ids_flat)
+
+    (es, ei), exact_ms = timed(exact)
+    _, eq, _ = eng.query_pack(q, None, want_plain=True)
+    table_gb = table.numel() * table.element_size() / 1e9
     rows = []
     for kp in [int(x) for x in a.avg_top_k.split(",")]:
-        at = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=kp)
-        at._table()
+        at._avg_top_k = kp
+        at.fused_coarse_min_items = 262144
         (s, i), ms = timed(lambda: at(q, k=k))
+        fused, fused_ms = timed(lambda: eng.coarse_topk(eq, table, False, kp))
+        counts = fused[2]
+        mat_ms = None
+        if N * B * 4 <= 40e9:   # the materialising path needs the (B, N) fp32 score matrix
+            at.fused_coarse_min_items = 1 << 62
+            (s2, i2), mat_total_ms = timed(lambda: at(q, k=k))
+            _, mat_ms = timed(lambda: E.topk(eng.coarse_scores(eq, table, False), kp))
+            assert torch.equal(i, i2) and torch.equal(s, s2)
         rec = {}
         for kk in (10, k):
             hit = sum(len(set(x.tolist()) & set(y.tolist())) for x, y in zip(i[:, :kk].cpu(), ei[:, :kk].cpu()))
             rec[f"recall@{kk}"] = hit / (B * kk)
         top1 = float((i[:, 0] == ei[:, 0]).float().mean())
-        rows.append({"avg_top_k": kp, "ms_per_batch": ms, "queries_per_s": B / ms * 1e3, "top1_agreement": top1, **rec})
+        rows.append({"avg_top_k": kp, "ms_per_batch": ms, "queries_per_s": B / ms * 1e3,
+                     "coarse_fused_ms": fused_ms, "coarse_fused_table_GBps": table_gb / (fused_ms * 1e-3),
+                     "coarse_materialised_ms": mat_ms, "candidates_min_max": [int(counts.min()), int(counts.max())],
+                     "top1_agreement": top1, **rec})
 print(json.dumps({"workload": f"synthetic MoL 8x8x32, N={N}, B={B}, k={k}, precision={mol.precision or 'fp32'}",
-                  "item_table_gen_s": gen_s, "index_build_s": build_s,
+                  "item_table": "device truncated normal" if a.device_table else "host counter hash",
+                  "item_table_gen_s": gen_s, "index_build_s": build_s, "coarse_table_GB": table_gb,
                   "exact_brute_force": {"ms_per_batch": exact_ms, "queries_per_s": B / exact_ms * 1e3},
                   "two_pass": rows}, indent=1))
