@@ -209,6 +209,13 @@ int rails_mol_component_build(const rails_mol_shape* shape, const float* index, 
                               void* stream);
 int rails_mol_component_score(const rails_mol_shape* shape, const float* eq, int32_t batch, const void* table,
                               int64_t n_items, float* scores, int64_t ld, void* stream);
+/* Fused scoring + exact top-k_group of every (query group, item group) row, without the (rows, n_items) score matrix:
+ * same scheme, same outputs contract and same counts check as rails_mol_coarse_topk, over batch * P_Q * P_X rows.
+ * out_scores / out_positions: (batch * P_Q * P_X, k_group); out_counts: (batch * P_Q * P_X). */
+size_t rails_mol_component_topk_workspace_bytes(const rails_mol_shape* shape, int32_t batch, int64_t n_items, int32_t k_group);
+int rails_mol_component_topk(const rails_mol_shape* shape, const float* eq, int32_t batch, const void* table, int64_t n_items,
+                             int32_t k_group, void* workspace, size_t workspace_bytes, float* out_scores,
+                             int64_t* out_positions, int32_t* out_counts, void* stream);
 /* torch.sort(indices, dim=1) on (rows, n) int64, n <= 16384 (mol_top_k.py:257, :515); in == out allowed. */
 int rails_sort_rows_i64(const int64_t* in, int32_t rows, int32_t n, int64_t* out, void* stream);
 /* scores[r][j] = fill where sorted_idx[r][j] == sorted_idx[r][j-1] (mol_top_k.py:277-284, :535-542). */

@@ -346,6 +346,27 @@ int rails_mol_component_build(const rails_mol_shape* s, const float* index, int6
   return fail(component_build(*s, index, n_items, table, (hipStream_t)stream), "component_build");
 }
 
+size_t rails_mol_component_topk_workspace_bytes(const rails_mol_shape* s, int32_t batch, int64_t n_items, int32_t k_group) {
+  if (!shape_ok(s) || batch <= 0) return 0;
+  return component_topk_workspace_bytes(*s, batch, n_items, k_group);
+}
+
+int rails_mol_component_topk(const rails_mol_shape* s, const float* eq, int32_t batch, const void* table, int64_t n_items,
+                             int32_t k_group, void* workspace, size_t workspace_bytes, float* out_scores,
+                             int64_t* out_positions, int32_t* out_counts, void* stream) {
+  g_err[0] = '\0';
+  if (!shape_ok(s)) return RAILS_EINVAL;
+  if (batch < 0 || n_items < 0 || k_group < 0) { set_error("component_topk: negative size"); return RAILS_EINVAL; }
+  if (k_group > n_items) { set_error("component_topk: selected index k out of range (k = %d > n = %lld)", k_group, (long long)n_items); return RAILS_EINVAL; }
+  if (batch == 0 || k_group == 0) return RAILS_OK;
+  if (!eq || !table || !workspace || !out_scores || !out_positions || !out_counts) { set_error("component_topk: NULL pointer"); return RAILS_EINVAL; }
+  const int cu = compute_units();
+  if (cu <= 0) { set_error("component_topk: no HIP device"); return RAILS_ELAUNCH; }
+  const int r = component_topk(*s, eq, batch, table, n_items, k_group, workspace, workspace_bytes, out_scores, out_positions,
+                               out_counts, cu, (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "component_topk");
+}
+
 int rails_mol_component_score(const rails_mol_shape* s, const float* eq, int32_t batch, const void* table, int64_t n_items,
                               float* scores, int64_t ld, void* stream) {
   g_err[0] = '\0';

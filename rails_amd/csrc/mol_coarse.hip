@@ -80,12 +80,44 @@ __device__ __forceinline__ float coarse_unorderable(unsigned int k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
+// Append path of the select scans.  A hit's slot comes from a device-scope atomic whose result takes ~2 us to return;
+// issued one by one inside the scan they serialise (a wave of the component scan met ~40 per tile: 2 ms for a 0.1 ms
+// scan).  Hits are therefore staged in a per-wave LDS list (LDS atomic cursor) and flushed once per tile, one entry per
+// lane, so up to 64 global atomics are in flight per wave.  DS operations of one wave execute in issue order, so the
+// wave reads back its own staged entries without a barrier; `volatile` keeps the compiler from reordering them.
+struct StageEntry { unsigned long long key; unsigned int orow; unsigned int pad; };
+constexpr int kStage = 128;   // entries per wave (2 KiB)
+
+__device__ __forceinline__ void append_candidate(unsigned long long* keys, unsigned int* counts, int cap, int sub,
+                                                 unsigned int orow, unsigned long long key) {
+  const int subcap = cap / kSubLists;
+  const unsigned int slot = atomicAdd(&counts[(int64_t)orow * kSubLists + sub], 1u);
+  if (slot < (unsigned int)subcap) keys[(int64_t)orow * cap + sub * subcap + slot] = key;
+}
+__device__ __forceinline__ void stage_push(volatile StageEntry* st, unsigned int* cnt, unsigned long long* keys,
+                                           unsigned int* counts, int cap, int sub, unsigned int orow, unsigned long long key) {
+  const unsigned int i = atomicAdd(cnt, 1u);   // LDS
+  if (i < (unsigned int)kStage) { st[i].key = key; st[i].orow = orow; }
+  else append_candidate(keys, counts, cap, sub, orow, key);   // list full: straight to global
+}
+__device__ __forceinline__ void stage_flush(volatile StageEntry* st, volatile unsigned int* cnt, int lane, unsigned long long* keys,
+                                            unsigned int* counts, int cap, int sub) {
+  unsigned int n = *cnt;
+  if (n == 0) return;        // wave-uniform
+  if (n > (unsigned int)kStage) n = kStage;
+  for (unsigned int e = lane; e < n; e += 64) append_candidate(keys, counts, cap, sub, st[e].orow, st[e].key);
+  if (lane == 0) *cnt = 0u;
+}
+
 template <int DC, int MODE>   // DC = d / 16 K chunks
 __global__ __launch_bounds__(kScanThreads) void coarse_scan_kernel(CoarseScanArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned short qfrag[];   // [n_qt][DC][64 lanes][8] bf16, then thr
   const int d = a.d, B = a.B;
   const int n_qt = (B + 31) / 32;
   float* thr_s = reinterpret_cast<float*>(qfrag + (size_t)n_qt * DC * 64 * 8);   // [n_qt * 32]
+  __shared__ StageEntry stage_s[kScanThreads / 64][kStage];
+  __shared__ unsigned int stage_n[kScanThreads / 64];
+  if (threadIdx.x < kScanThreads / 64) stage_n[threadIdx.x] = 0u;
   for (int i = threadIdx.x; i < n_qt * 32 * d; i += kScanThreads) {
     const int b = i / d, dd = i - b * d;
     float acc = 0.0f;
@@ -118,44 +150,59 @@ __global__ __launch_bounds__(kScanThreads) void coarse_scan_kernel(CoarseScanArg
         tlo[r] = coarse_unorderable(coarse_orderable(thr[r]) - 0x10000u);
       }
     }
-    for (int64_t w = gw; w < n_work; w += n_waves) {
-      const int64_t t = w * step;
-      int64_t item = t * 32 + x;
-      const bool in = item < a.n;
-      if (!in) item = a.n - 1;
-      const unsigned short* rowp = a.table + item * d + 8 * h;
-      bf16x8 Bv[DC];
+    // TU tiles per trip: all their 16-byte loads are issued before the first MFMA
+    constexpr int TU = 1;   // 4 tiles per trip measured no faster (the scan sits at 5.1-5.5 TB/s either way)
+    for (int64_t w0 = gw * TU; w0 < n_work; w0 += n_waves * TU) {
+      bf16x8 Bv[TU][DC];
+      int64_t items[TU];
+      bool ins[TU];
 #pragma unroll
-      for (int c = 0; c < DC; ++c) Bv[c] = *reinterpret_cast<const bf16x8*>(rowp + 16 * c);
-      cf32x16 acc = {0};
+      for (int u = 0; u < TU; ++u) {
+        const int64_t t = (w0 + u) * step;
+        int64_t item = t * 32 + x;
+        ins[u] = (w0 + u) < n_work && item < a.n;
+        if (!ins[u]) item = a.n - 1;
+        items[u] = item;
+        const unsigned short* rowp = a.table + item * d + 8 * h;
 #pragma unroll
-      for (int c = 0; c < DC; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c], Bv[c], acc, 0, 0, 0);
-      if constexpr (MODE == kScanSelect) {
-        bool hit = false;
+        for (int c = 0; c < DC; ++c) Bv[u][c] = *reinterpret_cast<const bf16x8*>(rowp + 16 * c);
+      }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hit |= acc[r] >= tlo[r];
-        if (__any(hit && in)) {   // rare at shard scale (K'/N of the scores pass); per register, only lanes that pass work
+      for (int u = 0; u < TU; ++u) {
+        const int64_t w = w0 + u;
+        const int64_t t = w * step;
+        const int64_t item = items[u];
+        const bool in = ins[u];
+        cf32x16 acc = {0};
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const bool maybe = in && acc[r] >= tlo[r];
-            if (__any(maybe)) {
-              const int q = qt * 32 + acc_row(r, h);
-              const float sc = bf16_rn(acc[r]);
-              if (maybe && q < B && sc >= thr[r]) {
-                const int sub = (int)(t % kSubLists), subcap = a.cap / kSubLists;
-                const unsigned int slot = atomicAdd(&a.counts[q * kSubLists + sub], 1u);
-                if (slot < (unsigned int)subcap)
-                  a.keys[(int64_t)q * a.cap + sub * subcap + slot] = ((unsigned long long)coarse_orderable(sc) << 32) | (unsigned int)(~(unsigned int)item);
+        for (int c = 0; c < DC; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c], Bv[u][c], acc, 0, 0, 0);
+        if constexpr (MODE == kScanSelect) {
+          bool hit = false;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) hit |= acc[r] >= tlo[r];
+          if (__any(hit && in)) {   // rare at shard scale (K'/N of the scores pass); per register, only lanes that pass work
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const bool maybe = in && acc[r] >= tlo[r];
+              if (__any(maybe)) {
+                const int q = qt * 32 + acc_row(r, h);
+                const float sc = bf16_rn(acc[r]);
+                if (maybe && q < B && sc >= thr[r])
+                  stage_push(stage_s[wave], &stage_n[wave], a.keys, a.counts, a.cap, (int)(t % kSubLists), (unsigned int)q,
+                             ((unsigned long long)coarse_orderable(sc) << 32) | (unsigned int)(~(unsigned int)item));
               }
             }
+            stage_flush(stage_s[wave], &stage_n[wave], lane, a.keys, a.counts, a.cap, (int)(t % kSubLists));
           }
-        }
-      } else {
-        const int64_t colx = MODE == kScanSample ? w * 32 + x : item;
+        } else {
+          if (w < n_work) {
+            const int64_t colx = MODE == kScanSample ? w * 32 + x : item;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int q = qt * 32 + acc_row(r, h);
-          if (q < B && (in || MODE == kScanSample)) a.scores[(int64_t)q * a.ld + colx] = in ? bf16_rn(acc[r]) : -INFINITY;
+            for (int r = 0; r < 16; ++r) {
+              const int q = qt * 32 + acc_row(r, h);
+              if (q < B && (in || MODE == kScanSample)) a.scores[(int64_t)q * a.ld + colx] = in ? bf16_rn(acc[r]) : -INFINITY;
+            }
+          }
         }
       }
     }
@@ -172,7 +219,7 @@ static int launch_coarse_scan(const CoarseScanArgs& a, hipStream_t stream) {
   const int64_t step = MODE == kScanSample ? a.stride : 1;
   const int64_t n_work = (n_tiles + step - 1) / step;
   int64_t grid = (n_work + 3) / 4;
-  if (grid > 2048) grid = 2048;     // 8 workgroups of 4 waves per CU: enough 16-byte loads in flight to stream HBM
+  if (grid > 2048) grid = 2048;     // 8 workgroups of 4 waves per CU
   if (grid < 1) return kOk;
   switch (dc) {
     case 2: hipLaunchKernelGGL((coarse_scan_kernel<2, MODE>), dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a); break;
@@ -239,9 +286,13 @@ static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p) {
   int stride = k_prime / 16;
   if (stride < 64) stride = 64;
   if (stride > 256) stride = 256;
+  // r = the smallest rank with P(Poisson(m) >= r) <= e^-m (e m / r)^r < 1e-9 (Chernoff), and at least 2m + 4 sqrt(m):
+  // the r-th largest sample score is then below the true K'-th score except with negligible probability (and a miss
+  // only costs the fallback), while ~r * stride items are expected at or above it
   auto r_of = [&](int st) {
     const float m = (float)k_prime / st;
-    int r = (int)(2.0f * m + 4.0f * sqrtf(m) + 8.0f) + 1;
+    int r = (int)(2.0f * m + 4.0f * sqrtf(m)) + 2;
+    while (r < 512 && (-m + r * (1.0f + logf(m / r))) > -20.7f) ++r;
     return r > 512 ? 512 : r;
   };
   while (stride > 1 && ((n_tiles + stride - 1) / stride) * 32 < 8 * (int64_t)r_of(stride)) stride /= 2;   // sample >= 8r
@@ -326,33 +377,127 @@ __global__ void component_build_kernel(const float* __restrict__ ipack, int64_t 
   table[i] = bf16_bits(tEx[((m * (d / 8) + (s >> 2)) * 64 + hi * 32 + x) * 4 + (s & 3)]);
 }
 
-__global__ __launch_bounds__(256) void component_score_kernel(const float* __restrict__ eq, int B, int PQ, int PX, int d,
-                                                             const unsigned short* __restrict__ table, int64_t n,
-                                                             float* __restrict__ scores, int64_t ld) {
-  extern __shared__ __attribute__((aligned(16))) float qs[];  // [B*PQ][d], bf16-rounded
-  for (int i = threadIdx.x; i < B * PQ * d; i += blockDim.x) qs[i] = bf16_rn(eq[i]);
+// The component scan: the coarse scan's structure with P_X B-operands per item (one per item group m) and
+// B * P_Q query rows (A: bf16(Eq[b,i,:]), ceil(B P_Q / 32) row tiles kept in LDS).  Output row (b P_Q + i) P_X + m.
+// In select mode the 16 pre-test bounds of a (row tile, m, lane half) sit contiguously in LDS (4 ds_read_b128).
+struct ComponentScanArgs {
+  const float* eq; int B, PQ, PX, d;
+  const unsigned short* table; int64_t n;
+  float* scores; int64_t ld; int stride;
+  const float* thr; int64_t thr_stride;
+  unsigned long long* keys; int cap;
+  unsigned int* counts;
+};
+
+template <int DC, int MODE>
+__global__ __launch_bounds__(kScanThreads) void component_scan_kernel(ComponentScanArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short qfrag[];   // [n_qt][DC][64][8] bf16, then bounds
+  const int d = a.d, PX = a.PX;
+  const int R = a.B * a.PQ;                 // query rows
+  const int n_qt = (R + 31) / 32;
+  float* tlo_s = reinterpret_cast<float*>(qfrag + (size_t)n_qt * DC * 64 * 8);   // [n_qt][PX][2][16]
+  __shared__ StageEntry stage_s[kScanThreads / 64][kStage];
+  __shared__ unsigned int stage_n[kScanThreads / 64];
+  if (threadIdx.x < kScanThreads / 64) stage_n[threadIdx.x] = 0u;
+  for (int i = threadIdx.x; i < n_qt * 32 * d; i += kScanThreads) {
+    const int row = i / d, dd = i - row * d;
+    const float v = row < R ? bf16_rn(a.eq[(int64_t)row * d + dd]) : 0.0f;
+    const int qt = row >> 5, rr = row & 31, c = dd >> 4, h = (dd >> 3) & 1, j = dd & 7;
+    qfrag[(((size_t)qt * DC + c) * 64 + h * 32 + rr) * 8 + j] = (unsigned short)(__float_as_uint(v) >> 16);
+  }
+  if constexpr (MODE == kScanSelect) {
+    for (int i = threadIdx.x; i < n_qt * PX * 32; i += kScanThreads) {
+      const int r = i & 15, h = (i >> 4) & 1, m = (i >> 5) % PX, qt = (i >> 5) / PX;
+      const int row = qt * 32 + acc_row(r, h);
+      const float t = row < R ? a.thr[((int64_t)row * PX + m) * a.thr_stride] : INFINITY;
+      tlo_s[i] = coarse_unorderable(coarse_orderable(t) - 0x10000u);   // the bf16 value just below the threshold
+    }
+  }
   __syncthreads();
-  for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < n; x += (int64_t)gridDim.x * blockDim.x) {
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = lane & 31, h = lane >> 5;
+  const int64_t n_tiles = (a.n + 31) >> 5;
+  const int64_t step = MODE == kScanSample ? a.stride : 1;
+  const int64_t n_work = (n_tiles + step - 1) / step;
+  const int64_t gw = (int64_t)blockIdx.x * (kScanThreads / 64) + wave, n_waves = (int64_t)gridDim.x * (kScanThreads / 64);
+  for (int64_t w = gw; w < n_work; w += n_waves) {
+    const int64_t t = w * step;
+    int64_t item = t * 32 + x;
+    const bool in = item < a.n;
+    if (!in) item = a.n - 1;
     for (int m = 0; m < PX; ++m) {
-      const uint4* row = reinterpret_cast<const uint4*>(table + (x * PX + m) * d);
-      for (int r0 = 0; r0 < B * PQ; r0 += 8) {  // eight (b, i) rows per pass over the component
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int c = 0; c < d / 8; ++c) {
-          const uint4 v = row[c];
-          const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+      const unsigned short* rowp = a.table + (item * PX + m) * d + 8 * h;
+      bf16x8 Bv[DC];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float t = bf16_to_f32((unsigned short)((w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu));
+      for (int c = 0; c < DC; ++c) Bv[c] = *reinterpret_cast<const bf16x8*>(rowp + 16 * c);
+      for (int qt = 0; qt < n_qt; ++qt) {
+        cf32x16 acc = {0};
 #pragma unroll
-            for (int rr = 0; rr < 8; ++rr)
-              if (r0 + rr < B * PQ) acc[rr] = __builtin_fmaf(qs[(r0 + rr) * d + c * 8 + j], t, acc[rr]);
+        for (int c = 0; c < DC; ++c)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(qfrag + (((size_t)qt * DC + c) * 64 + lane) * 8),
+                                                        Bv[c], acc, 0, 0, 0);
+        if constexpr (MODE == kScanSelect) {
+          const float4* tl = reinterpret_cast<const float4*>(tlo_s + ((qt * PX + m) * 2 + h) * 16);
+          float tlo[16];
+#pragma unroll
+          for (int v4 = 0; v4 < 4; ++v4) { const float4 f = tl[v4]; tlo[4 * v4] = f.x; tlo[4 * v4 + 1] = f.y; tlo[4 * v4 + 2] = f.z; tlo[4 * v4 + 3] = f.w; }
+          bool hit = false;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) hit |= acc[r] >= tlo[r];
+          if (__any(hit && in)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const bool maybe = in && acc[r] >= tlo[r];
+              if (__any(maybe)) {
+                const int row = qt * 32 + acc_row(r, h);
+                const float sc = bf16_rn(acc[r]);
+                const float thr = coarse_unorderable(coarse_orderable(tlo[r]) + 0x10000u);
+                if (maybe && row < R && sc >= thr)
+                  stage_push(stage_s[wave], &stage_n[wave], a.keys, a.counts, a.cap, (int)(t % kSubLists), (unsigned int)(row * PX + m),
+                             ((unsigned long long)coarse_orderable(sc) << 32) | (unsigned int)(~(unsigned int)item));
+              }
+            }
+          }
+        } else {
+          const int64_t colx = MODE == kScanSample ? w * 32 + x : item;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = qt * 32 + acc_row(r, h);
+            if (row < R && (in || MODE == kScanSample)) a.scores[((int64_t)row * PX + m) * a.ld + colx] = in ? bf16_rn(acc[r]) : -INFINITY;
           }
         }
-#pragma unroll
-        for (int rr = 0; rr < 8; ++rr)
-          if (r0 + rr < B * PQ) scores[((int64_t)(r0 + rr) * PX + m) * ld + x] = bf16_rn(acc[rr]);
       }
     }
+    if constexpr (MODE == kScanSelect) stage_flush(stage_s[wave], &stage_n[wave], lane, a.keys, a.counts, a.cap, (int)(t % kSubLists));
+  }
+}
+
+template <int MODE>
+static int launch_component_scan(const ComponentScanArgs& a, hipStream_t stream) {
+  const int n_qt = (a.B * a.PQ + 31) / 32;
+  const int dc = a.d / 16;
+  const size_t lds = (size_t)n_qt * dc * 64 * 8 * sizeof(unsigned short) + (size_t)n_qt * a.PX * 32 * sizeof(float);
+  if (lds > 144 * 1024) { set_error("component scan: batch %d x P_Q %d x d %d does not fit LDS", a.B, a.PQ, a.d); return kErrUnsupported; }
+  const int64_t n_tiles = (a.n + 31) >> 5;
+  const int64_t step = MODE == kScanSample ? a.stride : 1;
+  const int64_t n_work = (n_tiles + step - 1) / step;
+  int64_t grid = (n_work + 3) / 4;
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) return kOk;
+  auto launch = [&](auto kernel) {
+    // query fragments of 8x4x128 at B = 32 are 64 KiB: past the default dynamic-LDS limit
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
+      return (int)kErrLaunch;
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? (int)kOk : (int)kErrLaunch;
+  };
+  switch (dc) {
+    case 2: return launch(&component_scan_kernel<2, MODE>);
+    case 4: return launch(&component_scan_kernel<4, MODE>);
+    case 8: return launch(&component_scan_kernel<8, MODE>);
+    default: set_error("component scan: d = %d (supported: 32, 64, 128)", a.d); return kErrUnsupported;
   }
 }
 
@@ -367,14 +512,49 @@ int component_build(const Shape& s, const float* ipack, int64_t n, void* table, 
 
 int component_score(const Shape& s, const float* eq, int B, const void* table, int64_t n, float* scores, int64_t ld,
                     hipStream_t stream) {
-  const int d = s.dot_product_dimension, PQ = s.query_dot_product_groups;
   if (B <= 0 || n <= 0) return kOk;
-  const size_t lds = sizeof(float) * (size_t)B * PQ * d;
-  if (lds > 64 * 1024) { set_error("component_score: batch %d x P_Q %d x d %d does not fit LDS", B, PQ, d); return kErrUnsupported; }
-  int64_t grid = (n + 255) / 256;
-  if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL(component_score_kernel, dim3((unsigned)grid), dim3(256), lds, stream, eq, B, PQ,
-                     s.item_dot_product_groups, d, static_cast<const unsigned short*>(table), n, scores, ld);
+  ComponentScanArgs a{};
+  a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.PX = s.item_dot_product_groups; a.d = s.dot_product_dimension;
+  a.table = static_cast<const unsigned short*>(table); a.n = n; a.scores = scores; a.ld = ld; a.stride = 1;
+  return launch_component_scan<kScanAll>(a, stream);
+}
+
+// Fused per-component top-k_g: the fused coarse top-K' scheme (sample threshold, streaming select, key selection) over
+// the B * P_Q * P_X (query group, item group) rows, instead of a (rows, N) score matrix (5.7 GB at amzn-books, B = 32).
+size_t component_topk_workspace_bytes(const Shape& s, int B, int64_t n, int k_group) {
+  CoarseTopkPlan p;
+  return coarse_topk_plan(B * s.query_dot_product_groups * s.item_dot_product_groups, n, k_group, &p) ? p.total : 0;
+}
+
+int component_topk(const Shape& s, const float* eq, int B, const void* table, int64_t n, int k_group, void* ws, size_t ws_bytes,
+                   float* out_scores, int64_t* out_pos, int32_t* out_counts, int n_cu, hipStream_t stream) {
+  const int rows = B * s.query_dot_product_groups * s.item_dot_product_groups;
+  CoarseTopkPlan p;
+  if (!coarse_topk_plan(rows, n, k_group, &p)) { set_error("component_topk: unsupported size (k = %d, n = %lld)", k_group, (long long)n); return kErrUnsupported; }
+  if (n >= (1ll << 32)) { set_error("component_topk: n does not fit 32-bit positions; shard the corpus"); return kErrUnsupported; }
+  if (ws_bytes < p.total) { set_error("component_topk: workspace too small"); return kErrNoMem; }
+  char* base = static_cast<char*>(ws);
+  unsigned int* counts = reinterpret_cast<unsigned int*>(base);
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(base + p.off_keys);
+  float* sample = reinterpret_cast<float*>(base + p.off_sample);
+  float* top_s = reinterpret_cast<float*>(base + p.off_top_s);
+  int64_t* top_i = reinterpret_cast<int64_t*>(base + p.off_top_i);
+  if (hipMemsetAsync(base, 0, p.off_sample, stream) != hipSuccess) return kErrLaunch;   // counts + candidate keys
+  ComponentScanArgs a{};
+  a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.PX = s.item_dot_product_groups; a.d = s.dot_product_dimension;
+  a.table = static_cast<const unsigned short*>(table); a.n = n;
+  a.scores = sample; a.ld = p.n_sample; a.stride = p.stride;
+  int rc = launch_component_scan<kScanSample>(a, stream);
+  if (rc != kOk) return rc;
+  rc = topk(sample, p.n_sample, rows, p.n_sample, p.r, nullptr, 0, top_s, top_i, base + p.off_ws, p.topk_ws, n_cu, stream);
+  if (rc != kOk) return rc;
+  a.scores = nullptr; a.stride = 1;
+  a.thr = top_s + (p.r - 1); a.thr_stride = p.r; a.keys = keys; a.cap = p.cap; a.counts = counts;
+  rc = launch_component_scan<kScanSelect>(a, stream);
+  if (rc != kOk) return rc;
+  rc = select_keys(keys, rows, p.cap, k_group, out_scores, out_pos, stream);
+  if (rc != kOk) return rc;
+  hipLaunchKernelGGL(coarse_counts_kernel, dim3((rows + 63) / 64), dim3(64), 0, stream, counts, rows, p.cap, out_counts);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

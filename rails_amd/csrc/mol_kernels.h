@@ -67,6 +67,9 @@ int coarse_build(const Shape& s, const float* ipack, int64_t n, void* table, hip
 size_t coarse_topk_workspace_bytes(const Shape& s, int B, int64_t n, int k_prime);
 int coarse_topk(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, int k_prime, void* ws,
                 size_t ws_bytes, float* out_scores, int64_t* out_pos, int32_t* out_counts, int n_cu, hipStream_t stream);
+size_t component_topk_workspace_bytes(const Shape& s, int B, int64_t n, int k_group);
+int component_topk(const Shape& s, const float* eq, int B, const void* table, int64_t n, int k_group, void* ws, size_t ws_bytes,
+                   float* out_scores, int64_t* out_pos, int32_t* out_counts, int n_cu, hipStream_t stream);
 int select_keys(const unsigned long long* keys, int rows, int keys_per_row, int k, float* out_scores, int64_t* out_pos,
                 hipStream_t stream);
 int coarse_score(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, float* scores, int64_t ld,

@@ -391,6 +391,29 @@ class MolEngine:
             )
         return out
 
+    def component_topk(self, eq: torch.Tensor, table: torch.Tensor, k_group: int):
+        """Fused component scoring + exact top-k_group per (b, i, m) row (no (rows, N) score matrix).
+        -> (scores (rows, k_group), positions (rows, k_group), counts (rows,) int32) or None when unsupported; exact iff
+        k_group <= counts <= coarse_topk_capacity(k_group) for every row (the caller checks and falls back)."""
+        B, n = eq.shape[0], table.shape[0]
+        ws_bytes = self.lib.rails_mol_component_topk_workspace_bytes(C.byref(self.shape), B, n, k_group)
+        if ws_bytes == 0:
+            return None
+        eq = _f32c(eq)
+        dev = table.device
+        rows = B * self.spec.query_dot_product_groups * self.spec.item_dot_product_groups
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        out_s = torch.empty((rows, k_group), dtype=torch.float32, device=dev)
+        out_p = torch.empty((rows, k_group), dtype=torch.int64, device=dev)
+        counts = torch.empty((rows,), dtype=torch.int32, device=dev)
+        with _on_device(dev):
+            _lib.check(
+                self.lib.rails_mol_component_topk(C.byref(self.shape), _ptr(eq), B, _ptr(table), n, k_group, _ptr(ws), ws_bytes,
+                                                  _ptr(out_s), _ptr(out_p), _ptr(counts), _stream()),
+                "rails_mol_component_topk",
+            )
+        return out_s, out_p, counts
+
 
 def sort_rows(idx: torch.Tensor) -> torch.Tensor:
     """Ascending sort of every row of an int64 (rows, n) tensor, n <= 16384 (torch.sort(dim=1) values)."""

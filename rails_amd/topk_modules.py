@@ -120,6 +120,12 @@ class MoLAvgTopK(MoLTopKModule):
         eng = self._bind()
         table = self._table()
         qpack, eq, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"), want_plain=True)
+        return qpack, self._coarse_topk_from_eq(eq, average_queries)
+
+    def _coarse_topk_from_eq(self, eq: torch.Tensor, average_queries: bool) -> torch.Tensor:
+        """(B, P_Q, d) query components -> (B, avg_top_k) positions of the coarse top-K', best first."""
+        eng = self._bind()
+        table = self._table()
         n = table.shape[0]
         if self._avg_top_k > n:
             raise RuntimeError(f"selected index k out of range (k={self._avg_top_k}, n={n})")
@@ -132,10 +138,10 @@ class MoLAvgTopK(MoLTopKModule):
                 _, idx, counts = fused
                 lo, hi = int(counts.min()), int(counts.max())
                 if lo >= self._avg_top_k and hi <= eng.coarse_topk_capacity(self._avg_top_k):
-                    return qpack, idx
+                    return idx
         coarse = eng.coarse_scores(eq, table, average_queries)
         _, idx = E.topk(coarse, self._avg_top_k)
-        return qpack, idx
+        return idx
 
     def rerank(self, qpack: torch.Tensor, batch: int, cand_idx: torch.Tensor, k: int):
         """Full MoL on per-row candidates (positions, (B, K')) -> exact top-min(k, K') among them."""
@@ -171,9 +177,19 @@ class _ComponentCandidates:
     def _component_topk(self, eq: torch.Tensor, k_per_group: int) -> torch.Tensor:
         """-> (B, P_Q * P_X * k_per_group) positions: top k_per_group items of every (query group, item group) pair."""
         eng = self._bind()
-        scores = eng.component_scores(eq, self._component_table())
-        if k_per_group > scores.shape[1]:
-            raise RuntimeError(f"selected index k out of range (k={k_per_group}, n={scores.shape[1]})")
+        table = self._component_table()
+        n = table.shape[0]
+        if k_per_group > n:
+            raise RuntimeError(f"selected index k out of range (k={k_per_group}, n={n})")
+        # large corpora: fused scan + threshold select, no (B*P_Q*P_X, N) score matrix (5.7 GB at amzn-books, B = 32);
+        # identical to the materialising path below whenever every row's candidate count is inside [k, capacity]
+        if n >= getattr(self, "fused_component_min_items", 262144):
+            fused = eng.component_topk(eq, table, k_per_group)
+            if fused is not None:
+                _, pos, counts = fused
+                if int(counts.min()) >= k_per_group and int(counts.max()) <= eng.coarse_topk_capacity(k_per_group):
+                    return pos.view(eq.shape[0], -1)
+        scores = eng.component_scores(eq, table)
         _, pos = E.topk(scores, k_per_group)
         return pos.view(eq.shape[0], -1)
 
@@ -220,10 +236,7 @@ class MoLCombTopK(MoLAvgTopK, _ComponentCandidates):
         eng = self._bind()
         qpack, eq, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"), want_plain=True)
         comp = self._component_topk(eq, self._k_per_group)
-        coarse = eng.coarse_scores(eq, self._table(), average_queries=True)
-        if self._avg_top_k > coarse.shape[1]:
-            raise RuntimeError(f"selected index k out of range (k={self._avg_top_k}, n={coarse.shape[1]})")
-        _, avg_idx = E.topk(coarse, self._avg_top_k)
+        avg_idx = self._coarse_topk_from_eq(eq, average_queries=True)
         scores, ids = self._rerank_union(qpack, query_embeddings.size(0), torch.cat([comp, avg_idx], dim=1), sorted)
         return scores.to(query_embeddings.dtype), ids
 

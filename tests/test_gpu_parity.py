@@ -336,6 +336,37 @@ def test_fused_coarse_topk_falls_back_on_heavy_ties(dev):
         assert torch.equal(s1, s2) and torch.equal(i1, i2)
 
 
+@pytest.mark.parametrize("cfg_name,n,k_g", [("amzn-books", 300_001, 5), ("amzn-books", 300_001, 100), ("ml-1m", 280_000, 50)])
+def test_fused_component_topk_equals_the_materialised_path(dev, cfg_name, n, k_g):
+    """Candidate generation of MoLNaiveTopK / MoLCombTopK at scale: same MFMA arithmetic as rails_mol_component_score, so the
+    per-(query group, item group) top-k_g must equal component_scores + top-k bit for bit; and the modules must return the
+    same final answer through either path."""
+    cfg = O.CONFIGS[cfg_name]
+    mol = build_module(cfg, O.synthetic_weights(cfg, seed=2), dev)
+    X = torch.from_numpy(O.hash_item_table(5, 0, n, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    B = 8
+    q = O.synthetic_queries(cfg, B, seed=4).to(dev)
+    kw = {}
+    if len(cfg.uid_embedding_hash_sizes) > 0:
+        kw["user_ids"] = torch.arange(B, dtype=torch.int64, device=dev) * 7 + 1
+    with torch.inference_mode():
+        nt = rails_amd.MoLNaiveTopK(mol, X, ids, k_per_group=k_g)
+        eng = nt._bind()
+        _, eq, _ = eng.query_pack(q, kw.get("user_ids"), want_plain=True)
+        table = nt._component_table()
+        rs, rp = E.topk(eng.component_scores(eq, table), k_g)
+        fs, fp, counts = eng.component_topk(eq, table, k_g)
+        assert int(counts.min()) >= k_g and int(counts.max()) <= eng.coarse_topk_capacity(k_g), (int(counts.min()), int(counts.max()))
+        assert torch.equal(fs, rs) and torch.equal(fp, rp)
+        for mod in (nt, rails_amd.MoLCombTopK(mol, X, ids, k_per_group=k_g, avg_top_k=200)):
+            s1, i1 = mod(q, k=50, **kw)
+            mod.fused_component_min_items = 1 << 62
+            mod.fused_coarse_min_items = 1 << 62
+            s2, i2 = mod(q, k=50, **kw)
+            assert torch.equal(s1, s2) and torch.equal(i1, i2)
+
+
 # ---- section 8(f) rank 2: MIPSBruteForceTopK + DotProductSimilarity ------------------------------------
 def test_f9_mips_and_dot_product(dev):
     import os

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""The retrieval algorithms eval_batch.py:20-71 runs, on one GPU, with its timing protocol (3 warm-ups + 20 timed
+get_top_k_outputs calls, k = 120, k' = 200, batch 32; data/eval.py:139-170) plus a device sync: milliseconds per batch
+and agreement with exact brute force on the same (random-init, synthetic) inputs.
+  python tools/algorithms_bench.py --workload amzn-books
+"""
+import argparse, json, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench, rails_amd
+from oracle import mol_oracle as O   # input generators only
+
+ALGOS = {
+    "amzn-books": ["MoLBruteForceTopK", "MoLNaiveTopK5", "MoLNaiveTopK10", "MoLNaiveTopK50", "MoLNaiveTopK100", "MoLAvgTopK200",
+                   "MoLAvgTopK500", "MoLAvgTopK1000", "MoLAvgTopK2000", "MoLAvgTopK4000", "MoLCombTopK5_200", "MoLCombTopK50_500",
+                   "MoLCombTopK100_1000"],
+    "ml-20m": ["MoLBruteForceTopK", "MoLNaiveTopK5", "MoLNaiveTopK10", "MoLNaiveTopK50", "MoLNaiveTopK100", "MoLAvgTopK200",
+               "MoLAvgTopK500", "MoLAvgTopK1000", "MoLAvgTopK2000", "MoLCombTopK5_200", "MoLCombTopK50_500"],
+}
+ALGOS["ml-1m"] = ALGOS["ml-20m"]
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="amzn-books", choices=sorted(ALGOS))
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--algorithms", default="")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+cfg_key, N, width = bench.WORKLOADS[a.workload]
+cfg = O.CONFIGS[cfg_key]
+B, k, kp = a.batch, 120, 200
+mol, _ = rails_amd.create_mol_interaction_module(
+    cfg.query_embedding_dim, cfg.item_embedding_dim, cfg.dot_product_dimension, cfg.query_dot_product_groups,
+    cfg.item_dot_product_groups, cfg.temperature, 0.0, cfg.query_hidden_dim, 0.1, cfg.item_hidden_dim,
+    cfg.gating_query_hidden_dim, cfg.gating_qi_hidden_dim, cfg.gating_item_hidden_dim, cfg.softmax_dropout_rate, False,
+    query_nonlinearity=cfg.query_nonlinearity, uid_embedding_hash_sizes=list(cfg.uid_embedding_hash_sizes) or None)
+mol.load_state_dict(O.synthetic_weights(cfg, seed=0), strict=True)
+mol = mol.to(dev).eval()
+X = torch.empty((1, N, cfg.item_embedding_dim), dtype=torch.float32, device=dev)
+for s in range(0, N, 1_000_000):
+    n = min(1_000_000, N - s)
+    X[0, s : s + n] = torch.from_numpy(O.hash_item_table(1, s, n, cfg.item_embedding_dim)).to(dev)
+ids = torch.arange(1, N + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+q = O.synthetic_queries(cfg, B).to(dev)
+kw = {}
+if len(cfg.uid_embedding_hash_sizes) > 0:
+    kw["user_ids"] = torch.randint(0, cfg.uid_embedding_hash_sizes[0], (B,), generator=torch.Generator().manual_seed(3), dtype=torch.int64).to(dev)
+inv = torch.zeros((B, width), dtype=torch.int64, device=dev)
+model = type("M", (), {"_ndp_module": mol})()
+cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)
+rows, exact_ids = [], None
+with torch.inference_mode():
+    for name in (a.algorithms.split(",") if a.algorithms else ALGOS[a.workload]):
+        tk = rails_amd.get_top_k_module(name, model, X, ids)
+        for _ in range(3):
+            out_ids, out_scores, _ = cand.get_top_k_outputs(q, k, kw, tk, inv, truncate_k_prime_to=kp)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            out_ids, out_scores, _ = cand.get_top_k_outputs(q, k, kw, tk, inv, truncate_k_prime_to=kp)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        if exact_ids is None:
+            exact_ids = out_ids.cpu()
+        got = out_ids.cpu()
+        rec = {f"agree@{kk}": sum(len(set(x.tolist()) & set(y.tolist())) for x, y in zip(got[:, :kk], exact_ids[:, :kk])) / (B * kk) for kk in (10, 120)}
+        rows.append({"algorithm": name, "BatchTimeMsAvg": sum(ts) / len(ts), "BatchTimeMsMin": min(ts), "queries_per_s": B / (sum(ts) / len(ts)) * 1e3,
+                     "returned_columns": int(out_ids.shape[1]), **rec})
+        del tk
+        torch.cuda.empty_cache()
+print(json.dumps({"workload": f"{a.workload} {cfg.query_dot_product_groups}x{cfg.item_dot_product_groups}x{cfg.dot_product_dimension}, N={N}, B={B}, k={k}, k'={kp}",
+                  "protocol": "3 warm-ups + 20 timed get_top_k_outputs calls, wall clock with device sync (data/eval.py:139-170)",
+                  "weights": "random-init (agreement with brute force is NOT the trained-model recall)", "rows": rows}, indent=1))
