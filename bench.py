@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 
 import rails_amd  # noqa: E402
 from rails_amd import engine as E  # noqa: E402
-from rails_amd.sharded import ShardedMoLBruteForceTopK, shard_bounds  # noqa: E402
+from rails_amd.sharded import ShardedMoLAvgTopK, ShardedMoLBruteForceTopK, shard_bounds  # noqa: E402
 
 WORKLOADS = {
     # name: (oracle config key, N, seen-id width)
@@ -159,6 +159,13 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-path", action="store_true", help="skip the extra f16x3 measurement")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the secondary ML-20M / ML-1M measurements")
+    ap.add_argument("--items", type=int, default=0, help="override the workload's corpus size N (total over all ranks)")
+    ap.add_argument("--device-table", action="store_true",
+                    help="draw the item table on the GPU (truncated normal, sigma 0.02) instead of the host counter hash; "
+                         "implied above 4 M items per rank (a 125 M-item shard is 32 GB)")
+    ap.add_argument("--two-pass", type=int, default=0, metavar="K'",
+                    help="BASELINE config 5: MoLAvgTopK(K' per shard) = fused coarse top-K' + MoL rerank, instead of exact "
+                         "brute force (the default, and the only mode the headline metric is quoted on)")
     args = ap.parse_args()
 
     from oracle import mol_oracle as O  # inputs generator + cpu_baseline checker only
@@ -194,8 +201,13 @@ def main() -> None:
         return buf
 
     cfg_key, N, width = WORKLOADS[args.workload]
+    if args.workload.startswith("synthetic") and not args.items:
+        N *= world          # the table lists ONE 8-way shard; the corpus of a run is one such shard per rank
+    if args.items:
+        N = args.items
     cfg = O.CONFIGS[cfg_key]
     B, k, kp = args.batch, args.k, args.k_prime
+    two_pass = args.two_pass > 0
     weights = O.synthetic_weights(cfg, seed=0)
     mol, _ = rails_amd.create_mol_interaction_module(
         cfg.query_embedding_dim, cfg.item_embedding_dim, cfg.dot_product_dimension, cfg.query_dot_product_groups,
@@ -206,7 +218,16 @@ def main() -> None:
     mol = mol.to(dev).eval()
 
     lo, hi = shard_bounds(N, world, rank)
-    X = torch.from_numpy(O.hash_item_table(1, lo, hi - lo, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    if args.device_table or hi - lo > 4_000_000:
+        X = torch.empty((1, hi - lo, cfg.item_embedding_dim), dtype=torch.float32, device=dev)
+        g = torch.Generator(device=dev).manual_seed(1000 + rank)
+        for s0 in range(0, hi - lo, 8_000_000):
+            n0 = min(8_000_000, hi - lo - s0)
+            X[0, s0 : s0 + n0] = torch.fmod(torch.randn((n0, cfg.item_embedding_dim), generator=g, device=dev), 2.0) * 0.02
+        table_kind = "device truncated normal"
+    else:
+        X = torch.from_numpy(O.hash_item_table(1, lo, hi - lo, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+        table_kind = "host counter hash"
     ids = torch.arange(lo + 1, hi + 1, dtype=torch.int64, device=dev).unsqueeze(0)  # 1-based item ids
     q_cpu = O.synthetic_queries(cfg, B)
     q = q_cpu.to(dev)
@@ -219,7 +240,10 @@ def main() -> None:
 
     with torch.inference_mode():
         t0 = time.perf_counter()
-        topk_mod = ShardedMoLBruteForceTopK(mol, X, ids, N)
+        if two_pass:
+            topk_mod = ShardedMoLAvgTopK(mol, X, ids, N, avg_top_k=args.two_pass)
+        else:
+            topk_mod = ShardedMoLBruteForceTopK(mol, X, ids, N)
         torch.cuda.synchronize()
         index_build_s = time.perf_counter() - t0
         local = topk_mod._local_module
@@ -235,7 +259,12 @@ def main() -> None:
 
         ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
         ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-        logits = torch.empty((B, hi - lo), dtype=torch.float32, device=dev)
+        logits = None if two_pass else torch.empty((B, hi - lo), dtype=torch.float32, device=dev)
+
+        def two_pass_step(i=None):
+            """get_top_k_outputs through the (sharded) two-pass module: coarse top-K' + rerank + merge + filter."""
+            out_ids, out_scores, _ = cand.get_top_k_outputs(q, k, kw, topk_mod, inv, truncate_k_prime_to=kp)
+            return out_ids, out_scores
 
         def step(i=None):
             """get_top_k_outputs with the scoring launch bracketed by events on the launch stream."""
@@ -252,10 +281,13 @@ def main() -> None:
                 s, top = E.merge_candidates(gathered, world, kp, kp)
             return E.filter_seen_ids(top, s, inv, k)
 
-        # sanity: the decomposed step equals the module API
-        ref_ids, ref_scores, _ = cand.get_top_k_outputs(q, k, kw, topk_mod, inv, truncate_k_prime_to=kp)
-        got_ids, got_scores = step()
-        assert torch.equal(ref_ids, got_ids) and torch.equal(ref_scores, got_scores)
+        if two_pass:
+            step = two_pass_step   # noqa: F811
+        else:
+            # sanity: the decomposed step equals the module API
+            ref_ids, ref_scores, _ = cand.get_top_k_outputs(q, k, kw, topk_mod, inv, truncate_k_prime_to=kp)
+            got_ids, got_scores = step()
+            assert torch.equal(ref_ids, got_ids) and torch.equal(ref_scores, got_scores)
 
         for _ in range(args.warmup):
             step()
@@ -271,12 +303,28 @@ def main() -> None:
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        score_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
+        if two_pass:
+            # the dominant kernel chain of this mode is the fused coarse top-K' (HBM-bound scan of the bf16 table):
+            # timed on its own, on the launch stream, after the step timing
+            table = local._table()
+            _, eq_plain, _ = eng.query_pack(q, kw.get("user_ids"), want_plain=True)
+            kp_local = min(args.two_pass, hi - lo)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            eng.coarse_topk(eq_plain, table, False, kp_local)
+            e0.record()
+            for _ in range(args.steps):
+                eng.coarse_topk(eq_plain, table, False, kp_local)
+            e1.record()
+            torch.cuda.synchronize()
+            score_ms = e0.elapsed_time(e1) / args.steps
+            coarse_table_bytes = table.numel() * table.element_size()
+        else:
+            score_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
 
     # ---- opt-in precision mode "f16x3" (same API, same index, same 1e-4 bar), timed the same
     #      way AFTER the headline region so it cannot perturb it.  Reported separately; `value` stays the exact-fp32 path.
     fast = None
-    if not args.no_fast_path:
+    if not args.no_fast_path and not two_pass:
         with torch.inference_mode():
             mol.precision = "f16x3"
             eng = local._bind()          # new engine (split weight fragments); the item index is rebuilt in the same format
@@ -361,12 +409,25 @@ def main() -> None:
             },
             "index_build_s": index_build_s,
         }
+        out["config"]["item_table"] = table_kind
+        if two_pass:
+            gbps = coarse_table_bytes / (score_ms * 1e-3) / 1e9
+            out["metric"] = "queries/sec, MoL two-pass approximate top-k over N items (get_top_k_outputs: coarse top-K' + MoL rerank + id map + seen-id filter)"
+            out["config"]["workload"] = (f"{args.workload} MoL {cfg.query_dot_product_groups}x{cfg.item_dot_product_groups}x{cfg.dot_product_dimension}, "
+                                         f"N={N} items, two-pass MoLAvgTopK, K'={args.two_pass} per shard")
+            out["config"]["avg_top_k_per_shard"] = args.two_pass
+            out["scaling"] = "weak" if args.workload.startswith("synthetic") and not args.items else "strong"
+            out["roofline"] = {
+                "kernel": "coarse_scan_kernel (fused coarse top-K': sample pass + select pass + key selection)",
+                "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                "traffic": None, "kernel_ms": score_ms, "hbm_bytes_alg_per_launch": coarse_table_bytes,
+            }
         if fast is not None:
             out["fast_path"] = fast
         if world == 1 and args.workload == "amzn-books" and not args.no_other_workloads:
             # the two smaller real-dataset shapes of BASELINE.json (configs 1 and 2): fixed per-batch costs dominate there
             out["other_workloads"] = [quick_workload(n, B, k, kp, 10, dev) for n in ("ml-20m", "ml-1m")]
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not two_pass:   # the CPU baseline is the exact path
             out["cpu_baseline"] = cpu_baseline(cfg, weights, q_cpu, uid_cpu, N, min(args.cpu_sample_items, N), kp)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -1,4 +1,4 @@
-"""Item-sharded exact MoL top-k: one process per GPU, one small all-gather per batch.
+"""Item-sharded MoL top-k (exact, and the two-pass approximate one): one process per GPU, one small all-gather per batch.
 
 The reference has no sharded retrieval (eval is asserted single-GPU, eval_from_checkpoint.py:554-555); this
 is the north-star's 8-GPU path.  Its oracle is "equals single-device brute force over the concatenated
@@ -8,6 +8,11 @@ corpus", which holds bit for bit because (a) per-pair arithmetic does not depend
   rank r owns items [r * ceil(N/R), min(N, (r+1) * ceil(N/R)))      (contiguous item-id ranges)
   queries and MoL weights are replicated (KBs); every rank redoes the query prologue
   per batch: local scoring -> local top-k -> ONE all_gather of B*k*16 bytes -> merge R*k -> k on every rank
+
+ShardedMoLAvgTopK (BASELINE config 5: 1 B items 8-way, coarse prefilter + MoL rerank) has the same shape: every rank
+runs MoLAvgTopK on its shard -- coarse top-K' of ITS items, full MoL on those, local top-k -- and the merge is the same,
+because what is merged are exact MoL scores.  It reranks R*K' candidates in total (K' per shard), a superset-quality
+variant of the single-device algorithm with the same K'; it equals it exactly when R = 1.
 """
 from __future__ import annotations
 
@@ -17,7 +22,7 @@ import torch
 import torch.distributed as dist
 
 from . import engine as E
-from .topk_modules import MoLBruteForceTopK, TopKModule
+from .topk_modules import MoLAvgTopK, MoLBruteForceTopK, TopKModule
 
 
 def shard_bounds(n_items: int, world_size: int, rank: int) -> Tuple[int, int]:
@@ -48,10 +53,13 @@ def _hip_merge(scores: torch.Tensor, ids: torch.Tensor, k: int) -> Tuple[torch.T
     return E.topk(scores, k, ids=ids)
 
 
-class ShardedMoLBruteForceTopK(TopKModule):
-    """forward(query_embeddings, k) -> (scores (B, k), ids (B, k)), identical on every rank and identical to
-    MoLBruteForceTopK over the whole corpus.  `local_topk` / `merge` default to the HIP kernels; the CPU tests
-    of the collective logic inject oracle-backed callables instead (gloo, world_size 2)."""
+class ShardedTopK(TopKModule):
+    """forward(query_embeddings, k) -> (scores (B, k), ids (B, k)), identical on every rank: the local module's top-k of
+    every shard, merged.  `local_topk` / `merge` default to the HIP kernels; the CPU tests of the collective logic inject
+    oracle-backed callables instead (gloo, world_size 2)."""
+
+    def _make_local_module(self, mol_module, item_embeddings_shard, item_ids_shard) -> TopKModule:
+        raise NotImplementedError
 
     def __init__(
         self,
@@ -68,7 +76,7 @@ class ShardedMoLBruteForceTopK(TopKModule):
         self._world = dist.get_world_size(group) if dist.is_initialized() else 1
         self._n_total = n_items_total
         if local_topk is None:
-            self._local_module = MoLBruteForceTopK(mol_module, item_embeddings_shard, item_ids_shard)
+            self._local_module = self._make_local_module(mol_module, item_embeddings_shard, item_ids_shard)
             self._n_local = self._local_module.num_items
             local_topk = lambda q, k, **kw: self._local_module(q, k=k, **kw)  # noqa: E731
         else:
@@ -104,3 +112,28 @@ class ShardedMoLBruteForceTopK(TopKModule):
             all_s, all_ids = unpack_candidates(gathered.view(self._world, msg.shape[0], msg.shape[1]), k)
             ms, mi = self._merge(all_s, all_ids, k)
         return ms.to(s.dtype), mi
+
+
+class ShardedMoLBruteForceTopK(ShardedTopK):
+    """Exact: identical to MoLBruteForceTopK over the whole corpus, bit for bit (see the module docstring)."""
+
+    def _make_local_module(self, mol_module, item_embeddings_shard, item_ids_shard) -> TopKModule:
+        return MoLBruteForceTopK(mol_module, item_embeddings_shard, item_ids_shard)
+
+
+class ShardedMoLAvgTopK(ShardedTopK):
+    """Two-pass approximate top-k on an item-sharded corpus (BASELINE config 5): MoLAvgTopK(avg_top_k) per shard, then
+    the same single all-gather + merge.  `avg_top_k` is PER SHARD; k <= avg_top_k as in the reference
+    (rails/indexing/mol_top_k.py:383-386)."""
+
+    def __init__(self, mol_module, item_embeddings_shard, item_ids_shard, n_items_total: int, avg_top_k: int, **kwargs) -> None:
+        self._avg_top_k = avg_top_k
+        super().__init__(mol_module, item_embeddings_shard, item_ids_shard, n_items_total, **kwargs)
+
+    def _make_local_module(self, mol_module, item_embeddings_shard, item_ids_shard) -> TopKModule:
+        return MoLAvgTopK(mol_module, item_embeddings_shard, item_ids_shard, avg_top_k=min(self._avg_top_k, int(item_ids_shard.numel())))
+
+    def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        if k > self._avg_top_k:
+            raise ValueError(f"avg_top_k ({self._avg_top_k}) must be larger than k ({k})")
+        return super().forward(query_embeddings, k, sorted, **kwargs)

@@ -367,6 +367,36 @@ def test_fused_component_topk_equals_the_materialised_path(dev, cfg_name, n, k_g
             assert torch.equal(s1, s2) and torch.equal(i1, i2)
 
 
+def test_sharded_two_pass_composition_on_the_gpu(dev):
+    """BASELINE config 5's per-rank work with the HIP kernels: MoLAvgTopK on each of R = 2 contiguous shards, the pack and
+    merge kernels around the (here: emulated) all-gather.  Must equal the top-k of the union of the shards' results, and
+    ShardedMoLAvgTopK at world size 1 must equal MoLAvgTopK."""
+    from rails_amd.sharded import ShardedMoLAvgTopK, shard_bounds
+
+    cfg = O.CONFIGS["amzn-books"]
+    mol = build_module(cfg, O.synthetic_weights(cfg, seed=2), dev)
+    n, B, k, avg_k = 600_000, 16, 100, 500
+    X = torch.from_numpy(O.hash_item_table(5, 0, n, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B, seed=4).to(dev)
+    with torch.inference_mode():
+        msgs, parts = [], []
+        for r in range(2):
+            lo, hi = shard_bounds(n, 2, r)
+            s, i = rails_amd.MoLAvgTopK(mol, X[:, lo:hi], ids[:, lo:hi], avg_top_k=avg_k)(q, k=k)
+            parts.append((s, i))
+            msgs.append(E.pack_candidates(s, i, k))
+        ms, mi = E.merge_candidates(torch.cat(msgs, 0), 2, k, k)
+        all_s = torch.cat([p[0] for p in parts], 1).cpu()
+        all_i = torch.cat([p[1] for p in parts], 1).cpu()
+        es, pos = O.select_topk_deterministic(all_s, k)
+        assert torch.equal(ms.cpu(), es) and torch.equal(mi.cpu(), torch.gather(all_i, 1, pos))
+        one = ShardedMoLAvgTopK(mol, X, ids, n, avg_top_k=avg_k)
+        s1, i1 = one(q, k=k)
+        s0, i0 = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=avg_k)(q, k=k)
+        assert torch.equal(s1, s0) and torch.equal(i1, i0)
+
+
 # ---- section 8(f) rank 2: MIPSBruteForceTopK + DotProductSimilarity ------------------------------------
 def test_f9_mips_and_dot_product(dev):
     import os

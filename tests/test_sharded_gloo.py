@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import mol_oracle as O
-from rails_amd.sharded import ShardedMoLBruteForceTopK, pack_candidates, shard_bounds, unpack_candidates
+from rails_amd.sharded import ShardedMoLAvgTopK, ShardedMoLBruteForceTopK, pack_candidates, shard_bounds, unpack_candidates
 
 
 def _free_port() -> int:
@@ -66,6 +66,51 @@ def test_sharded_topk_equals_unsharded_oracle(n_items, k):
     for rank in range(world):
         s, i = ret[rank]
         assert torch.equal(s, rs) and torch.equal(i, ids[rpos])
+
+
+def _avg_worker(rank: int, world: int, port: int, n_items: int, k: int, avg_k: int, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        cfg = O.CONFIGS["amzn-books"]
+        w = O.synthetic_weights(cfg, seed=0)
+        q = O.synthetic_queries(cfg, 4)
+        lo, hi = shard_bounds(n_items, world, rank)
+        X = torch.from_numpy(O.hash_item_table(1, lo, hi - lo, cfg.item_embedding_dim)).unsqueeze(0)
+        ids = (torch.arange(lo, hi, dtype=torch.int64) * 3 + 1).unsqueeze(0)
+
+        def local_topk(qq, kk, **kw):   # the oracle's MoLAvgTopK on this shard
+            s, i, _ = O.avg_topk(cfg, w, qq, X, ids, kk, min(avg_k, hi - lo))
+            return s, i
+
+        def merge(scores, all_ids, kk):
+            s, pos = O.select_topk_deterministic(scores, kk)
+            return s, torch.gather(all_ids, 1, pos)
+
+        mod = ShardedMoLAvgTopK(None, None, ids, n_items, avg_top_k=avg_k, local_topk=local_topk, merge=merge)
+        s, i = mod(q, k=k)
+        with pytest.raises(ValueError, match="must be larger than k"):
+            mod(q, k=avg_k + 1)
+        ret[rank] = (s.clone(), i.clone(), *local_topk(q, min(k, hi - lo)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_two_pass_merges_the_per_shard_reranks():
+    """Config 5's shape: MoLAvgTopK per shard + the single all-gather + merge.  Every rank must hold the top-k (by exact MoL
+    score, shard-major ties) of the union of the per-shard two-pass results."""
+    world, n_items, k, avg_k = 2, 600, 20, 60
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_avg_worker, args=(world, _free_port(), n_items, k, avg_k, ret), nprocs=world, join=True)
+    all_s = torch.cat([ret[r][2] for r in range(world)], dim=1)
+    all_i = torch.cat([ret[r][3] for r in range(world)], dim=1)
+    es, pos = O.select_topk_deterministic(all_s, k)
+    for rank in range(world):
+        s, i = ret[rank][0], ret[rank][1]
+        assert torch.equal(s, es) and torch.equal(i, torch.gather(all_i, 1, pos))
 
 
 def test_shard_bounds_cover_the_corpus():
