@@ -253,6 +253,36 @@ int rails_filter_seen_ids(const int64_t* top_ids, const float* top_scores, int32
                           const int64_t* invalid_ids, int32_t width, int32_t k, int64_t* out_ids,
                           float* out_scores, void* stream);
 
+/* ---- HSTU query encoder, eval path -----------------------------------
+ * The step upstream of the retrieval path: modeling/sequential/hstu.py (HSTU.encode with no cache / delta path), without
+ * fbgemm-gpu.  All tensors are fp32 and padded: (batch, seq_len, ...) with `lengths[b]` valid positions per row; rows at
+ * positions >= lengths[b] are held at zero, which is what the reference's jagged layout amounts to.
+ * rails_amd/hstu.py chains these per layer; a non-Python host would do the same. */
+/* x = [ids != 0 and n < lengths[b]] * (embeddings * scale + pos_emb[n])      input_features_preprocessors.py:75-92 */
+int rails_hstu_preprocess(const float* embeddings, const int64_t* ids, const int64_t* lengths, const float* pos_emb,
+                          int32_t batch, int32_t seq_len, int32_t dim, float scale, float* out, void* stream);
+/* out[r] = F.layer_norm(x[r], eps) (no affine) [* mul[r]]; ld* are row strides in floats.  hstu.py:268-276, :419-424 */
+int rails_rows_layer_norm(const float* x, int64_t ldx, int64_t rows, int32_t dim, float eps, const float* mul, int64_t ldm,
+                          float* out, int64_t ldo, void* stream);
+/* C = act(A W + bias) + residual.  w_is_nk 0: W is (K, N) row-major (the `_uvqk` parameter); 1: W is (N, K), a torch Linear
+ * weight (`_o.weight`).  act 0 none / 1 silu.  With lengths != NULL rows r = b * seq_len + n, n >= lengths[b], are written
+ * as zeros.  hstu.py:374-378 (torch.mm + silu), :426-434 (the output Linear + residual). */
+int rails_gemm_f32(const float* a, int64_t lda, const float* w, int32_t w_is_nk, const float* bias, const float* residual,
+                   int64_t ldr, int64_t m, int32_t n, int32_t k, int32_t act, const int64_t* lengths, int32_t seq_len, float* c,
+                   int64_t ldc, void* stream);
+/* uvqk: (batch * seq_len, ld) rows [u | v | q | k] (u, v: heads * dv wide; q, k: heads * dqk wide), the SiLU'd GEMM output.
+ * out[b, i, h, :] = sum_{j <= i} silu(q_i . k_j + pos_w[seq_len - 1 + j - i] + ts_w[bucket(ts[b, min(i+1, seq_len-1)] - ts[b, j])])
+ *                   / seq_len * v_j ; no bias at all when timestamps == NULL.  bucket(dt) = #{t : thresholds[t] <= |dt|},
+ * thresholds (num_buckets int64, ascending) being the bucket boundaries of floor(log(max(|dt|, 1)) / 0.301) evaluated in
+ * float32 exactly as torch does.  hstu.py:144-213 and :82-138.  dv <= 32, num_buckets <= 128. */
+int rails_hstu_attention(const float* uvqk, int64_t ld, int32_t batch, int32_t seq_len, int32_t heads, int32_t dqk, int32_t dv,
+                         const int64_t* lengths, const int64_t* timestamps, const float* ts_w, const float* pos_w,
+                         const int64_t* thresholds, int32_t num_buckets, float* out, void* stream);
+/* out[r] = normalise(x[row_index ? row_index[r] : r]); mode 0 LayerNorm (no affine), 1 x / max(||x||, eps).
+ * output_postprocessors.py:38-85 + get_current_embeddings (modeling/sequential/utils.py:74-90). */
+int rails_rows_normalize(const float* x, int64_t ldx, const int64_t* row_index, int64_t rows, int32_t dim, int32_t mode, float eps,
+                         float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -454,4 +454,57 @@ int rails_filter_seen_ids(const int64_t* top_ids, const float* top_scores, int32
   return r == kOk ? r : fail(r, "filter_seen_ids");
 }
 
+// ---- HSTU query encoder, eval path ----
+int rails_hstu_preprocess(const float* embeddings, const int64_t* ids, const int64_t* lengths, const float* pos_emb, int32_t batch,
+                          int32_t seq_len, int32_t dim, float scale, float* out, void* stream) {
+  g_err[0] = '\0';
+  if (batch < 0 || seq_len < 0 || dim < 0) { set_error("hstu_preprocess: negative size"); return RAILS_EINVAL; }
+  if (batch == 0 || seq_len == 0 || dim == 0) return RAILS_OK;
+  if (!embeddings || !ids || !lengths || !pos_emb || !out) { set_error("hstu_preprocess: NULL pointer"); return RAILS_EINVAL; }
+  return fail(hstu_preprocess(embeddings, ids, lengths, pos_emb, batch, seq_len, dim, scale, out, (hipStream_t)stream), "hstu_preprocess");
+}
+
+int rails_rows_layer_norm(const float* x, int64_t ldx, int64_t rows, int32_t dim, float eps, const float* mul, int64_t ldm, float* out,
+                          int64_t ldo, void* stream) {
+  g_err[0] = '\0';
+  if (rows < 0 || dim <= 0) { set_error("rows_layer_norm: bad size"); return RAILS_EINVAL; }
+  if (rows == 0) return RAILS_OK;
+  if (!x || !out || ldx < dim || ldo < dim || (mul && ldm < dim)) { set_error("rows_layer_norm: NULL pointer or short stride"); return RAILS_EINVAL; }
+  return fail(rows_layer_norm(x, ldx, rows, dim, eps, mul, ldm, out, ldo, (hipStream_t)stream), "rows_layer_norm");
+}
+
+int rails_gemm_f32(const float* a, int64_t lda, const float* w, int32_t w_is_nk, const float* bias, const float* residual, int64_t ldr,
+                   int64_t m, int32_t n, int32_t k, int32_t act, const int64_t* lengths, int32_t seq_len, float* c, int64_t ldc,
+                   void* stream) {
+  g_err[0] = '\0';
+  if (m < 0 || n < 0 || k <= 0) { set_error("gemm_f32: bad size"); return RAILS_EINVAL; }
+  if (m == 0 || n == 0) return RAILS_OK;
+  if (!a || !w || !c || lda < k || ldc < n || (residual && ldr < n)) { set_error("gemm_f32: NULL pointer or short stride"); return RAILS_EINVAL; }
+  if (act != 0 && act != 1) { set_error("gemm_f32: unknown activation %d", act); return RAILS_EINVAL; }
+  if (lengths && (seq_len <= 0 || m % seq_len != 0)) { set_error("gemm_f32: rows are not batch * seq_len"); return RAILS_EINVAL; }
+  return fail(gemm_f32(a, lda, w, w_is_nk ? 1 : 0, bias, residual, ldr, m, n, k, act, lengths, seq_len, c, ldc, (hipStream_t)stream), "gemm_f32");
+}
+
+int rails_hstu_attention(const float* uvqk, int64_t ld, int32_t batch, int32_t seq_len, int32_t heads, int32_t dqk, int32_t dv,
+                         const int64_t* lengths, const int64_t* timestamps, const float* ts_w, const float* pos_w,
+                         const int64_t* thresholds, int32_t num_buckets, float* out, void* stream) {
+  g_err[0] = '\0';
+  if (batch < 0 || seq_len < 0 || heads <= 0 || dqk <= 0 || dv <= 0) { set_error("hstu_attention: bad size"); return RAILS_EINVAL; }
+  if (batch == 0 || seq_len == 0) return RAILS_OK;
+  if (!uvqk || !lengths || !out || ld < (int64_t)2 * heads * (dqk + dv)) { set_error("hstu_attention: NULL pointer or short stride"); return RAILS_EINVAL; }
+  if (timestamps && (!ts_w || !pos_w || !thresholds || num_buckets <= 0)) { set_error("hstu_attention: timestamps without bias tables"); return RAILS_EINVAL; }
+  const int r = hstu_attention(uvqk, ld, batch, seq_len, heads, dqk, dv, lengths, timestamps, ts_w, pos_w, thresholds, num_buckets, out,
+                               (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "hstu_attention");
+}
+
+int rails_rows_normalize(const float* x, int64_t ldx, const int64_t* row_index, int64_t rows, int32_t dim, int32_t mode, float eps,
+                         float* out, void* stream) {
+  g_err[0] = '\0';
+  if (rows < 0 || dim <= 0 || (mode != 0 && mode != 1)) { set_error("rows_normalize: bad argument"); return RAILS_EINVAL; }
+  if (rows == 0) return RAILS_OK;
+  if (!x || !out || ldx < dim) { set_error("rows_normalize: NULL pointer or short stride"); return RAILS_EINVAL; }
+  return fail(rows_normalize(x, ldx, row_index, rows, dim, mode, eps, out, (hipStream_t)stream), "rows_normalize");
+}
+
 }  // extern "C"

@@ -70,6 +70,18 @@ int coarse_topk(const Shape& s, const float* eq, int B, int avg, const void* tab
 size_t component_topk_workspace_bytes(const Shape& s, int B, int64_t n, int k_group);
 int component_topk(const Shape& s, const float* eq, int B, const void* table, int64_t n, int k_group, void* ws, size_t ws_bytes,
                    float* out_scores, int64_t* out_pos, int32_t* out_counts, int n_cu, hipStream_t stream);
+// ---- HSTU query encoder, eval path (hstu.hip) ----
+int hstu_preprocess(const float* emb, const int64_t* ids, const int64_t* lengths, const float* pos_emb, int B, int N, int D,
+                    float scale, float* out, hipStream_t stream);
+int rows_layer_norm(const float* x, int64_t ldx, int64_t rows, int D, float eps, const float* mul, int64_t ldm, float* out, int64_t ldo,
+                    hipStream_t stream);
+int rows_normalize(const float* x, int64_t ldx, const int64_t* row_index, int64_t rows, int D, int mode, float eps, float* out,
+                   hipStream_t stream);
+int gemm_f32(const float* A, int64_t lda, const float* W, int w_is_nk, const float* bias, const float* residual, int64_t ldr, int64_t M,
+             int N, int K, int act, const int64_t* lengths, int seq_len, float* C, int64_t ldc, hipStream_t stream);
+int hstu_attention(const float* uvqk, int64_t ld, int B, int N, int H, int dqk, int dv, const int64_t* lengths,
+                   const int64_t* timestamps, const float* ts_w, const float* pos_w, const int64_t* thresholds, int num_buckets,
+                   float* out, hipStream_t stream);
 int select_keys(const unsigned long long* keys, int rows, int keys_per_row, int k, float* out_scores, int64_t* out_pos,
                 hipStream_t stream);
 int coarse_score(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, float* scores, int64_t ld,

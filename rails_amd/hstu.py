@@ -1,0 +1,199 @@
+"""HSTU query encoder, eval path -- the step upstream of the retrieval path.
+
+Mirror of modeling/sequential/hstu.py:HSTU for inference: same constructor arguments that matter at eval time, same
+parameter / buffer names (so `load_state_dict` of a reference checkpoint's `module.` entries works unchanged), same
+`get_item_embeddings` / `encode` / `forward` signatures.  No fbgemm: the layers run on the padded (B, N, D) tensor with
+rows at positions >= length held at zero.  Every floating-point operation runs in the HIP kernels
+of csrc/hstu.hip through the C ABI (rails_hstu_preprocess, rails_rows_layer_norm, rails_gemm_f32, rails_hstu_attention,
+rails_rows_normalize); torch only holds the parameters and moves rows (embedding lookup).
+
+Not supported (raises): training mode, the cache / delta_x_offsets decoding path (hstu.py:163-186), `concat_ua`,
+`normalization="softmax_rel_bias"`, `linear_activation` other than "silu" / "none".
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from .engine import _on_device, _ptr, _stream
+
+TIMESTAMPS_KEY = "timestamps"
+
+
+def _bucket_thresholds(num_buckets: int, max_dt: int = 1 << 62) -> torch.Tensor:
+    """thresholds[b - 1] = the smallest |dt| whose bucket floor(log(max(|dt|, 1)) / 0.301) (float32, as hstu.py:611-613
+    evaluates it) is >= b.  The attention kernel counts thresholds <= |dt|, which reproduces torch's bucketing exactly."""
+    def bucket(x: int) -> int:
+        return int((torch.log(torch.tensor([x]).abs().clamp(min=1)) / 0.301).long())
+    out = []
+    for b in range(1, num_buckets + 1):
+        if bucket(max_dt) < b:
+            out.append(max_dt + 1)
+            continue
+        lo, hi = 1, max_dt
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if bucket(mid) >= b:
+                hi = mid
+            else:
+                lo = mid + 1
+        out.append(lo)
+    return torch.tensor(out, dtype=torch.int64)
+
+
+class _ItemEmbedding(torch.nn.Module):          # LocalEmbeddingModule (embedding_modules.py:40-73): `_item_emb.weight`
+    def __init__(self, num_items: int, dim: int) -> None:
+        super().__init__()
+        self._item_embedding_dim = dim
+        self._item_emb = torch.nn.Embedding(num_items + 1, dim, padding_idx=0)
+        torch.nn.init.trunc_normal_(self._item_emb.weight, mean=0.0, std=0.02, a=-0.04, b=0.04)
+
+    @property
+    def item_embedding_dim(self) -> int:
+        return self._item_embedding_dim
+
+
+class _PositionalPreproc(torch.nn.Module):      # LearnablePositionalEmbeddingInputFeaturesPreprocessor: `_pos_emb.weight`
+    def __init__(self, max_sequence_len: int, dim: int) -> None:
+        super().__init__()
+        self._pos_emb = torch.nn.Embedding(max_sequence_len, dim)
+        std = (1.0 / dim) ** 0.5
+        torch.nn.init.trunc_normal_(self._pos_emb.weight, mean=0.0, std=std, a=-2 * std, b=2 * std)
+
+
+class _RelBias(torch.nn.Module):                # RelativeBucketedTimeAndPositionBasedBias (hstu.py:82-138)
+    def __init__(self, max_seq_len: int, num_buckets: int) -> None:
+        super().__init__()
+        self._ts_w = torch.nn.Parameter(torch.empty(num_buckets + 1).normal_(mean=0, std=0.02))
+        self._pos_w = torch.nn.Parameter(torch.empty(2 * max_seq_len - 1).normal_(mean=0, std=0.02))
+
+
+class _Layer(torch.nn.Module):                  # SequentialTransductionUnitJagged (hstu.py:215-437): `_uvqk`, `_o`, `_rel_attn_bias`
+    def __init__(self, dim: int, dv: int, dqk: int, heads: int, max_seq_len: int, num_buckets: int, rel_bias: bool) -> None:
+        super().__init__()
+        self._uvqk = torch.nn.Parameter(torch.empty((dim, dv * 2 * heads + dqk * heads * 2)).normal_(mean=0, std=0.02))
+        self._o = torch.nn.Linear(dv * heads, dim)
+        torch.nn.init.xavier_uniform_(self._o.weight)
+        self._rel_attn_bias = _RelBias(max_seq_len, num_buckets) if rel_bias else None
+
+
+class _Stack(torch.nn.Module):                  # HSTUJagged: `_attention_layers`
+    def __init__(self, layers) -> None:
+        super().__init__()
+        self._attention_layers = torch.nn.ModuleList(layers)
+
+
+class HSTU(torch.nn.Module):
+    """encode(past_lengths (B,), past_ids (B, N), past_embeddings (B, N, D), past_payloads {"timestamps": (B, N)}) -> (B, D).
+    N must equal max_sequence_len + max_output_len (what the reference's eval feeds, modeling/sequential/features.py:48-58)."""
+
+    def __init__(self, max_sequence_len: int, max_output_len: int, embedding_dim: int, num_blocks: int, num_heads: int, linear_dim: int,
+                 attention_dim: int, num_items: int, similarity_module: Optional[torch.nn.Module] = None, normalization: str = "rel_bias",
+                 linear_config: str = "uvqk", linear_activation: str = "silu", output_postproc: str = "layer_norm",
+                 enable_relative_attention_bias: bool = True, concat_ua: bool = False, num_buckets: int = 128, eps: float = 1e-6) -> None:
+        super().__init__()
+        if normalization not in ("rel_bias", "hstu_rel_bias") or linear_config != "uvqk" or concat_ua:
+            raise NotImplementedError("only normalization='rel_bias', linear_config='uvqk', concat_ua=False are built")
+        if linear_activation not in ("silu", "none"):
+            raise ValueError(f"Unknown linear_activation {linear_activation}")
+        if output_postproc not in ("layer_norm", "l2_norm"):
+            raise ValueError(f"Unknown output_postproc {output_postproc}")
+        self._ndp_module = similarity_module
+        self._embedding_dim = embedding_dim
+        self._max_sequence_length = max_sequence_len
+        self._seq = max_sequence_len + max_output_len
+        self._num_blocks, self._num_heads, self._dqk, self._dv = num_blocks, num_heads, attention_dim, linear_dim
+        self._linear_activation = linear_activation
+        self._postproc = output_postproc
+        self._num_buckets = num_buckets
+        self._eps = eps
+        self._embedding_module = _ItemEmbedding(num_items, embedding_dim)
+        self._input_features_preproc = _PositionalPreproc(self._seq, embedding_dim)
+        self._hstu = _Stack([_Layer(embedding_dim, linear_dim, attention_dim, num_heads, self._seq, num_buckets, enable_relative_attention_bias)
+                             for _ in range(num_blocks)])
+        self.register_buffer("_attn_mask", torch.triu(torch.ones((self._seq, self._seq), dtype=torch.bool), diagonal=1))
+        self.register_buffer("_bucket_thresholds", _bucket_thresholds(num_buckets), persistent=False)
+
+    # ---- reference API ------------------------------------------------------------------------------------------
+    def get_item_embeddings(self, ids: torch.Tensor) -> torch.Tensor:
+        return self._embedding_module._item_emb(ids)            # a row gather
+
+    def forward(self, past_lengths, past_ids, past_embeddings, past_payloads: Dict[str, torch.Tensor], batch_id=None) -> torch.Tensor:
+        """(B, N, D) postprocessed sequence embeddings (hstu.py:711-739); rows at positions >= length are zero rows
+        normalised, exactly as the reference's zero-padded output."""
+        x = self._run_layers(past_lengths, past_ids, past_embeddings, past_payloads)
+        B, N, D = x.shape
+        return self._normalize(x.view(B * N, D), None).view(B, N, D)
+
+    def encode(self, past_lengths, past_ids, past_embeddings, past_payloads: Dict[str, torch.Tensor], delta_x_offsets=None, cache=None,
+               return_cache_states: bool = False) -> torch.Tensor:
+        """(B, D): the postprocessed embedding at position past_lengths - 1 (hstu.py:741-803)."""
+        if delta_x_offsets is not None or cache is not None or return_cache_states:
+            raise NotImplementedError("the cached / incremental decoding path is not built")
+        x = self._run_layers(past_lengths, past_ids, past_embeddings, past_payloads)
+        B, N, D = x.shape
+        rows = torch.arange(B, device=x.device, dtype=torch.int64) * N + (past_lengths.to(torch.int64) - 1)
+        return self._normalize(x.view(B * N, D), rows)
+
+    # ---- HIP path ------------------------------------------------------------------------------------------------
+    def _normalize(self, x2d: torch.Tensor, rows: Optional[torch.Tensor]) -> torch.Tensor:
+        lib = _lib.load()
+        n = x2d.shape[0] if rows is None else rows.numel()
+        out = torch.empty((n, x2d.shape[1]), dtype=torch.float32, device=x2d.device)
+        with _on_device(x2d.device):
+            _lib.check(lib.rails_rows_normalize(_ptr(x2d), x2d.stride(0), _ptr(rows) if rows is not None else None, n, x2d.shape[1],
+                                                0 if self._postproc == "layer_norm" else 1, C.c_float(self._eps), _ptr(out), _stream()),
+                       "rails_rows_normalize")
+        return out
+
+    def _run_layers(self, past_lengths, past_ids, past_embeddings, past_payloads) -> torch.Tensor:
+        if self.training:
+            raise NotImplementedError("rails_amd.HSTU is eval-only: call .eval()")
+        if not past_embeddings.is_cuda:
+            raise RuntimeError("rails_amd.HSTU runs on the GPU only (no CPU fallback)")
+        lib = _lib.load()
+        dev = past_embeddings.device
+        B, N = past_ids.shape
+        D, H, dqk, dv = self._embedding_dim, self._num_heads, self._dqk, self._dv
+        if N != self._seq or past_embeddings.shape != (B, N, D):
+            raise ValueError(f"expected past_ids (B, {self._seq}) and past_embeddings (B, {self._seq}, {D})")
+        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()   # noqa: E731
+        lengths = past_lengths.to(device=dev, dtype=torch.int64).contiguous()
+        ids = past_ids.to(device=dev, dtype=torch.int64).contiguous()
+        ts = past_payloads.get(TIMESTAMPS_KEY) if past_payloads else None
+        if ts is not None:
+            ts = ts.to(device=dev, dtype=torch.int64).contiguous()
+        emb = f32(past_embeddings)
+        M, W = B * N, 2 * H * (dv + dqk)
+        x = torch.empty((B, N, D), dtype=torch.float32, device=dev)
+        nx = torch.empty((M, D), dtype=torch.float32, device=dev)
+        mm = torch.empty((M, W), dtype=torch.float32, device=dev)
+        att = torch.empty((M, H * dv), dtype=torch.float32, device=dev)
+        oin = torch.empty((M, H * dv), dtype=torch.float32, device=dev)
+        thr = self._bucket_thresholds.to(dev)
+        with _on_device(dev):
+            st = _stream()
+            _lib.check(lib.rails_hstu_preprocess(_ptr(emb), _ptr(ids), _ptr(lengths), _ptr(f32(self._input_features_preproc._pos_emb.weight)),
+                                                 B, N, D, C.c_float(float(D) ** 0.5), _ptr(x), st), "rails_hstu_preprocess")
+            for layer in self._hstu._attention_layers:
+                x2 = x.view(M, D)
+                _lib.check(lib.rails_rows_layer_norm(_ptr(x2), D, M, D, C.c_float(self._eps), None, 0, _ptr(nx), D, st), "rails_rows_layer_norm")
+                _lib.check(lib.rails_gemm_f32(_ptr(nx), D, _ptr(f32(layer._uvqk)), 0, None, None, 0, M, W, D,
+                                              1 if self._linear_activation == "silu" else 0, _ptr(lengths), N, _ptr(mm), W, st), "rails_gemm_f32")
+                rb = layer._rel_attn_bias
+                use_bias = ts is not None and rb is not None
+                _lib.check(lib.rails_hstu_attention(_ptr(mm), W, B, N, H, dqk, dv, _ptr(lengths), _ptr(ts) if use_bias else None,
+                                                    _ptr(f32(rb._ts_w)) if use_bias else None, _ptr(f32(rb._pos_w)) if use_bias else None,
+                                                    _ptr(thr) if use_bias else None, self._num_buckets if use_bias else 0, _ptr(att), st),
+                           "rails_hstu_attention")
+                # o_input = u * LN(attn);  u = the first H*dv columns of mm
+                _lib.check(lib.rails_rows_layer_norm(_ptr(att), H * dv, M, H * dv, C.c_float(self._eps), _ptr(mm), W, _ptr(oin), H * dv, st),
+                           "rails_rows_layer_norm")
+                xn = torch.empty((B, N, D), dtype=torch.float32, device=dev)
+                _lib.check(lib.rails_gemm_f32(_ptr(oin), H * dv, _ptr(f32(layer._o.weight)), 1, _ptr(f32(layer._o.bias)), _ptr(x2), D, M, D, H * dv,
+                                              0, _ptr(lengths), N, _ptr(xn), D, st), "rails_gemm_f32")
+                x = xn
+        return x

@@ -1,0 +1,182 @@
+"""HSTU query encoder: oracle and HIP path against the REFERENCE's outputs
+(tests/golden/hstu_*.npz, written by oracle/gen_golden_hstu.py from modeling/sequential/hstu.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import hstu_oracle as HO
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+NAMES = sorted(HO.HSTU_CONFIGS)
+TOL = 2e-5     # fp32 end to end; the outputs are unit-scale (LayerNorm / L2-normalised)
+
+
+def load(name):
+    d = np.load(os.path.join(GOLDEN, f"hstu_{name}.npz"))
+    w = {k[2:]: torch.from_numpy(d[k]) for k in d.files if k.startswith("w/")}
+    return d, w
+
+
+def build(cfg, w, dev):
+    from rails_amd.hstu import HSTU
+
+    m = HSTU(max_sequence_len=cfg.max_sequence_len - 1, max_output_len=1, embedding_dim=cfg.embedding_dim, num_blocks=cfg.num_blocks,
+             num_heads=cfg.num_heads, linear_dim=cfg.linear_dim, attention_dim=cfg.attention_dim, num_items=cfg.num_items,
+             output_postproc=cfg.postproc)
+    m.load_state_dict(w, strict=True)      # the reference's own names and shapes
+    return m.to(dev).eval()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_reproduces_the_reference(name):
+    d, w = load(name)
+    cfg = HO.HSTU_CONFIGS[name]
+    lengths, ids, ts = (torch.from_numpy(d[f"in/{k}"]) for k in ("past_lengths", "past_ids", "timestamps"))
+    cur, layers = HO.encode(cfg, w, lengths, ids, ts, return_layers=True)
+    assert float((cur - torch.from_numpy(d["out/current_embeddings"])).abs().max()) <= 1e-6
+    assert float((HO.encode(cfg, w, lengths, ids, None) - torch.from_numpy(d["out/current_embeddings_no_timestamps"])).abs().max()) <= 1e-6
+    # the padded sequence output at the valid positions (the reference's padded rows are postprocessed zeros)
+    y = layers[-1]
+    y = y / torch.clamp(torch.linalg.norm(y, dim=-1, keepdim=True), min=cfg.eps) if cfg.postproc == "l2_norm" else torch.nn.functional.layer_norm(y, [cfg.embedding_dim], eps=cfg.eps)
+    valid = torch.arange(cfg.max_sequence_len).unsqueeze(0) < lengths.unsqueeze(1)
+    assert float((y - torch.from_numpy(d["out/sequence_embeddings"]))[valid].abs().max()) <= 1e-6
+
+
+def test_module_mirrors_the_reference_state_dict_and_bucketing():
+    from rails_amd.hstu import HSTU, _bucket_thresholds
+
+    for name in NAMES:
+        d, w = load(name)
+        cfg = HO.HSTU_CONFIGS[name]
+        m = HSTU(cfg.max_sequence_len - 1, 1, cfg.embedding_dim, cfg.num_blocks, cfg.num_heads, cfg.linear_dim, cfg.attention_dim, cfg.num_items,
+                 output_postproc=cfg.postproc)
+        sd = m.state_dict()
+        assert sorted(sd) == sorted(w) and all(tuple(sd[k].shape) == tuple(w[k].shape) for k in w)
+    thr = _bucket_thresholds(128)
+    assert torch.equal(thr, HO.bucket_thresholds(128))
+    g = torch.Generator().manual_seed(0)
+    dt = torch.cat([torch.arange(0, 5000), (10.0 ** (torch.rand(20000, generator=g) * 11)).long(), thr, thr - 1, thr + 1])
+    by_table = (thr.unsqueeze(0) <= dt.abs().unsqueeze(1)).sum(1)
+    assert torch.equal(by_table, HO.bucketize(dt, 128))
+    with pytest.raises(NotImplementedError):
+        HSTU(10, 1, 16, 1, 1, 8, 8, 20, concat_ua=True)
+
+
+def test_encoder_refuses_cpu_and_training():
+    from rails_amd.hstu import HSTU
+
+    m = HSTU(10, 1, 16, 1, 1, 8, 8, 20).eval()
+    ids = torch.ones((2, 11), dtype=torch.int64)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m.encode(torch.tensor([3, 4]), ids, m.get_item_embeddings(ids), {})
+    m.train()
+    with pytest.raises(NotImplementedError, match="eval-only"):
+        m.encode(torch.tensor([3, 4]), ids, m.get_item_embeddings(ids), {})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_hip_encoder_matches_the_reference(name):
+    dev = torch.device("cuda", 0)
+    d, w = load(name)
+    cfg = HO.HSTU_CONFIGS[name]
+    m = build(cfg, w, dev)
+    lengths, ids, ts = (torch.from_numpy(d[f"in/{k}"]).to(dev) for k in ("past_lengths", "past_ids", "timestamps"))
+    with torch.inference_mode():
+        emb = m.get_item_embeddings(ids)
+        cur = m.encode(lengths, ids, emb, {"timestamps": ts})
+        cur_nots = m.encode(lengths, ids, emb, {})
+        seq = m(lengths, ids, emb, {"timestamps": ts})
+    assert float((cur.cpu() - torch.from_numpy(d["out/current_embeddings"])).abs().max()) <= TOL
+    assert float((cur_nots.cpu() - torch.from_numpy(d["out/current_embeddings_no_timestamps"])).abs().max()) <= TOL
+    valid = (torch.arange(cfg.max_sequence_len).unsqueeze(0) < lengths.cpu().unsqueeze(1))
+    assert float((seq.cpu() - torch.from_numpy(d["out/sequence_embeddings"]))[valid].abs().max()) <= TOL
+    # determinism
+    with torch.inference_mode():
+        assert torch.equal(cur, m.encode(lengths, ids, emb, {"timestamps": ts}))
+
+
+@pytest.mark.gpu
+def test_hip_encoder_full_width_against_the_oracle():
+    """The real ML-1M encoder geometry (8 blocks, 2 heads x 25, N = 211, B = 32): seven key tiles, the dv = 25 padding."""
+    dev = torch.device("cuda", 0)
+    cfg = HO.HSTUConfig(max_sequence_len=211, embedding_dim=50, num_blocks=8, num_heads=2, attention_dim=25, linear_dim=25, num_items=3883)
+    from rails_amd.hstu import HSTU
+
+    torch.manual_seed(3)
+    m = HSTU(210, 1, 50, 8, 2, 25, 25, 3883).eval()
+    with torch.no_grad():
+        for n_, p in m.named_parameters():
+            if n_.endswith("_o.bias"):
+                p.normal_(0, 0.05)
+    w = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    B, N = 32, 211
+    lengths = torch.randint(1, N + 1, (B,), generator=g)
+    lengths[0] = N
+    ids = torch.randint(1, 3884, (B, N), generator=g) * (torch.arange(N).unsqueeze(0) < lengths.unsqueeze(1))
+    ts = 1_000_000_000 + torch.cumsum((10.0 ** (torch.rand((B, N), generator=g) * 6)).long(), 1)
+    ref = HO.encode(cfg, w, lengths, ids, ts)
+    m = m.to(dev)
+    with torch.inference_mode():
+        cur = m.encode(lengths.to(dev), ids.to(dev), m.get_item_embeddings(ids.to(dev)), {"timestamps": ts.to(dev)})
+    assert float((cur.cpu() - ref).abs().max()) <= 5e-5
+
+
+@pytest.mark.gpu
+def test_sequences_to_metrics_end_to_end():
+    """Ranks 3 + 4 of SURVEY.md section 8(f) chained, all in HIP: interaction sequences -> HSTU encoder -> MoL brute-force
+    top-k with seen-id filter -> the harness's HR / NDCG / MRR; against the oracle chain (HSTU oracle -> MoL oracle)."""
+    import rails_amd
+    from oracle import mol_oracle as O
+    from rails_amd import eval_harness as H
+    from rails_amd.hstu import HSTU
+
+    dev = torch.device("cuda", 0)
+    mcfg = O.CONFIGS["amzn-books"]
+    n_items, N, B = 3000, 51, 24
+    hcfg = HO.HSTUConfig(max_sequence_len=N, embedding_dim=64, num_blocks=2, num_heads=8, attention_dim=8, linear_dim=8, num_items=n_items)
+    mol, _ = rails_amd.create_mol_interaction_module(
+        mcfg.query_embedding_dim, mcfg.item_embedding_dim, mcfg.dot_product_dimension, mcfg.query_dot_product_groups,
+        mcfg.item_dot_product_groups, mcfg.temperature, 0.0, mcfg.query_hidden_dim, 0.1, mcfg.item_hidden_dim,
+        mcfg.gating_query_hidden_dim, mcfg.gating_qi_hidden_dim, mcfg.gating_item_hidden_dim, mcfg.softmax_dropout_rate, False,
+        query_nonlinearity=mcfg.query_nonlinearity)
+    mw = O.synthetic_weights(mcfg, seed=4)
+    mol.load_state_dict(mw, strict=True)
+    torch.manual_seed(9)
+    model = HSTU(N - 1, 1, 64, 2, 8, 8, 8, n_items, similarity_module=mol).eval()
+    with torch.no_grad():   # item embeddings at the scale the MoL item tower was initialised for; non-zero output biases
+        for n_, p in model.named_parameters():
+            if n_.endswith("_o.bias"):
+                p.normal_(0, 0.05)
+    hw = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith("_ndp_module")}
+    g = torch.Generator().manual_seed(2)
+    lengths = torch.randint(2, N, (B,), generator=g)
+    ids = torch.stack([torch.randperm(n_items, generator=g)[:N] + 1 for _ in range(B)]) * (torch.arange(N).unsqueeze(0) < lengths.unsqueeze(1))
+    ts = 1_000_000_000 + torch.cumsum((10.0 ** (torch.rand((B, N), generator=g) * 6)).long(), 1)
+    target = torch.randint(1, n_items + 1, (B, 1), generator=g)
+
+    # oracle chain
+    q_ref = HO.encode(hcfg, hw, lengths, ids, ts)
+    all_ids = torch.arange(1, n_items + 1, dtype=torch.int64)
+    X = hw["_embedding_module._item_emb.weight"][all_ids].unsqueeze(0)
+    k = 120
+    kp = O.k_prime(k, ids, n_items, 200)
+    rs, ri, _ = O.brute_force_topk(mcfg, mw, q_ref, X, all_ids.unsqueeze(0), kp)
+    ref_ids, _ = O.filter_seen_ids(ri, rs, ids, k)
+    ref_metrics = O.eval_metrics(ref_ids, target, 120)
+
+    model = model.to(dev)
+    with torch.inference_mode():
+        state = H.get_eval_state(model, all_ids.tolist(), None, lambda emb, eids: rails_amd.MoLBruteForceTopK(model._ndp_module, emb, eids), dev)
+        feats = H.SequentialFeatures(lengths.to(dev), ids.to(dev), None, {"timestamps": ts.to(dev)})
+        random_state = __import__("random").getstate()
+        out = H.eval_metrics_v2_from_tensors(state, model, feats, target.to(dev), include_eval_time=True, include_eval_top_k_ids=True)
+        __import__("random").setstate(random_state)
+    got = out["eval_top_k_ids"].cpu()
+    agree = float((got == ref_ids).float().mean())
+    assert agree >= 0.98, agree            # near-tie swaps only (fp32 summation order in two chained models)
+    for key in ("hr@10", "hr@50", "hr@100"):
+        assert float((out[key].cpu() != ref_metrics[key]).float().mean()) <= 0.05
