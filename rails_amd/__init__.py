@@ -4,11 +4,12 @@ Importing the package does not load the HIP library; the first kernel call does 
 and fails loudly if librails_amd.so has not been built.
 """
 from .factory import create_mol_interaction_module
+from .hstu import HSTU
 from .mol_module import DotProductSimilarity, MoLSimilarity, SimilarityModule
 from .topk_modules import (CandidateIndex, MIPSBruteForceTopK, MoLAvgTopK, MoLBruteForceTopK, MoLCombTopK, MoLNaiveTopK,
                            TopKModule, get_top_k_module)
 
 __all__ = [
     "create_mol_interaction_module", "MoLSimilarity", "DotProductSimilarity", "SimilarityModule", "CandidateIndex", "MIPSBruteForceTopK",
-    "MoLBruteForceTopK", "MoLAvgTopK", "MoLNaiveTopK", "MoLCombTopK", "TopKModule", "get_top_k_module",
+    "MoLBruteForceTopK", "MoLAvgTopK", "MoLNaiveTopK", "MoLCombTopK", "TopKModule", "get_top_k_module", "HSTU",
 ]
