@@ -270,14 +270,18 @@ int rails_rows_layer_norm(const float* x, int64_t ldx, int64_t rows, int32_t dim
 int rails_gemm_f32(const float* a, int64_t lda, const float* w, int32_t w_is_nk, const float* bias, const float* residual,
                    int64_t ldr, int64_t m, int32_t n, int32_t k, int32_t act, const int64_t* lengths, int32_t seq_len, float* c,
                    int64_t ldc, void* stream);
+/* buckets[b][j][i] = #{t : thresholds[t] <= |ts[b, min(i+1, seq_len-1)] - ts[b, j]|} (uint8, key-major): the time bucket of
+ * (query i, key j) of RelativeBucketedTimeAndPositionBasedBias (hstu.py:107-138); thresholds (num_buckets int64, ascending)
+ * are the bucket edges of floor(log(max(|dt|, 1)) / 0.301) evaluated in float32 exactly as torch does.  Once per batch:
+ * it depends on neither the layer nor the head. */
+int rails_hstu_time_buckets(const int64_t* timestamps, int32_t batch, int32_t seq_len, const int64_t* thresholds,
+                            int32_t num_buckets, uint8_t* out, void* stream);
 /* uvqk: (batch * seq_len, ld) rows [u | v | q | k] (u, v: heads * dv wide; q, k: heads * dqk wide), the SiLU'd GEMM output.
- * out[b, i, h, :] = sum_{j <= i} silu(q_i . k_j + pos_w[seq_len - 1 + j - i] + ts_w[bucket(ts[b, min(i+1, seq_len-1)] - ts[b, j])])
- *                   / seq_len * v_j ; no bias at all when timestamps == NULL.  bucket(dt) = #{t : thresholds[t] <= |dt|},
- * thresholds (num_buckets int64, ascending) being the bucket boundaries of floor(log(max(|dt|, 1)) / 0.301) evaluated in
- * float32 exactly as torch does.  hstu.py:144-213 and :82-138.  dv <= 32, num_buckets <= 128. */
+ * out[b, i, h, :] = sum_{j <= i} silu(q_i . k_j + pos_w[seq_len - 1 + j - i] + ts_w[buckets[b, j, i]]) / seq_len * v_j ;
+ * no bias at all when buckets == NULL (the reference without timestamps).  hstu.py:144-213.  dv <= 32, dqk <= 32. */
 int rails_hstu_attention(const float* uvqk, int64_t ld, int32_t batch, int32_t seq_len, int32_t heads, int32_t dqk, int32_t dv,
-                         const int64_t* lengths, const int64_t* timestamps, const float* ts_w, const float* pos_w,
-                         const int64_t* thresholds, int32_t num_buckets, float* out, void* stream);
+                         const int64_t* lengths, const uint8_t* buckets, const float* ts_w, const float* pos_w,
+                         int32_t num_buckets, float* out, void* stream);
 /* out[r] = normalise(x[row_index ? row_index[r] : r]); mode 0 LayerNorm (no affine), 1 x / max(||x||, eps).
  * output_postprocessors.py:38-85 + get_current_embeddings (modeling/sequential/utils.py:74-90). */
 int rails_rows_normalize(const float* x, int64_t ldx, const int64_t* row_index, int64_t rows, int32_t dim, int32_t mode, float eps,

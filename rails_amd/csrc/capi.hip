@@ -485,16 +485,25 @@ int rails_gemm_f32(const float* a, int64_t lda, const float* w, int32_t w_is_nk,
   return fail(gemm_f32(a, lda, w, w_is_nk ? 1 : 0, bias, residual, ldr, m, n, k, act, lengths, seq_len, c, ldc, (hipStream_t)stream), "gemm_f32");
 }
 
+int rails_hstu_time_buckets(const int64_t* timestamps, int32_t batch, int32_t seq_len, const int64_t* thresholds, int32_t num_buckets,
+                            uint8_t* out, void* stream) {
+  g_err[0] = '\0';
+  if (batch < 0 || seq_len < 0 || num_buckets <= 0) { set_error("hstu_time_buckets: bad size"); return RAILS_EINVAL; }
+  if (batch == 0 || seq_len == 0) return RAILS_OK;
+  if (!timestamps || !thresholds || !out) { set_error("hstu_time_buckets: NULL pointer"); return RAILS_EINVAL; }
+  const int r = hstu_time_buckets(timestamps, batch, seq_len, thresholds, num_buckets, out, (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "hstu_time_buckets");
+}
+
 int rails_hstu_attention(const float* uvqk, int64_t ld, int32_t batch, int32_t seq_len, int32_t heads, int32_t dqk, int32_t dv,
-                         const int64_t* lengths, const int64_t* timestamps, const float* ts_w, const float* pos_w,
-                         const int64_t* thresholds, int32_t num_buckets, float* out, void* stream) {
+                         const int64_t* lengths, const uint8_t* buckets, const float* ts_w, const float* pos_w, int32_t num_buckets,
+                         float* out, void* stream) {
   g_err[0] = '\0';
   if (batch < 0 || seq_len < 0 || heads <= 0 || dqk <= 0 || dv <= 0) { set_error("hstu_attention: bad size"); return RAILS_EINVAL; }
   if (batch == 0 || seq_len == 0) return RAILS_OK;
   if (!uvqk || !lengths || !out || ld < (int64_t)2 * heads * (dqk + dv)) { set_error("hstu_attention: NULL pointer or short stride"); return RAILS_EINVAL; }
-  if (timestamps && (!ts_w || !pos_w || !thresholds || num_buckets <= 0)) { set_error("hstu_attention: timestamps without bias tables"); return RAILS_EINVAL; }
-  const int r = hstu_attention(uvqk, ld, batch, seq_len, heads, dqk, dv, lengths, timestamps, ts_w, pos_w, thresholds, num_buckets, out,
-                               (hipStream_t)stream);
+  if (buckets && (!ts_w || !pos_w || num_buckets <= 0)) { set_error("hstu_attention: buckets without bias tables"); return RAILS_EINVAL; }
+  const int r = hstu_attention(uvqk, ld, batch, seq_len, heads, dqk, dv, lengths, buckets, ts_w, pos_w, num_buckets, out, (hipStream_t)stream);
   return r == kOk ? r : fail(r, "hstu_attention");
 }
 

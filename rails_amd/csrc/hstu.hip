@@ -15,6 +15,7 @@
 //   rows_layer_norm_kernel   y = LN(x) (no affine, biased variance), optionally * u         one wave per row
 //   gemm_f32_kernel          C = act(A W + bias) + residual, rows of padded positions zeroed;  v_mfma_f32_32x32x2_f32,
 //                            one wave per 32 x 32 output tile, W given as (K, N) or as (N, K) (torch Linear)
+//   hstu_time_buckets_kernel the (B, N, N) time-bucket matrix of the relative bias, once per encode
 //   hstu_attention_kernel    a[b, i, h, :] = sum_{j <= i} silu(q_i . k_j + bias[b, i, j]) / N * v_j
 //                            register-chained like the scoring kernel: S^T = K Q^T puts key j of a tile in accumulator
 //                            register r, which IS the B operand of the K-step {row(r,0), row(r,1)} of O^T += V^T P^T
@@ -104,7 +105,26 @@ struct GemmArgs {
   float* C; int64_t ldc;
 };
 
-// one wave per 32 x 32 tile of C; A rows on the MFMA row axis, output columns on the column axis
+// one wave per 32 x 32 tile of C; A rows on the MFMA row axis, output columns on the column axis.
+// A lane needs 16 consecutive k of ITS row (A, and W in the (N, K) layout): as 16 dword loads that is 16 instructions of
+// 64 different cache lines each (the first version ran the uvqk GEMM at 19 % of the MFMA peak on address divergence
+// alone), so rows that are 16-byte aligned are read with four 16-byte loads; the next K step's operands are requested
+// before the current step's MFMAs.
+__device__ __forceinline__ void gemm_load16(const float* __restrict__ p, int k, int K, bool vec, float (&v)[16]) {
+  if (vec && k + 16 <= K) {
+    const float4* q = reinterpret_cast<const float4*>(p + k);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float4 f = q[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
+  } else {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const int kk = k + s < K ? k + s : K - 1;
+      const float x = p[kk];
+      v[s] = k + s < K ? x : 0.0f;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int row = lane & 31, h = lane >> 5, col = lane & 31;
@@ -113,22 +133,39 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   if (tile >= ((g.M + 31) / 32) * tiles_n) return;
   const int64_t m0 = (tile / tiles_n) * 32;
   const int n0 = (int)(tile % tiles_n) * 32;
-  const int64_t ar = m0 + row < g.M ? m0 + row : g.M - 1;   // clamped (always valid) addresses, zeroed below
+  const int64_t ar = m0 + row < g.M ? m0 + row : g.M - 1;   // clamped (always valid) addresses; such rows / columns are never stored
   const int wc = n0 + col < g.N ? n0 + col : g.N - 1;
-  hf32x16 acc = {0};
-  for (int k0 = 0; k0 < g.K; k0 += 32) {
-    float av[16], bv[16];
+  const float* arow = g.A + ar * g.lda;
+  const bool a_vec = ((reinterpret_cast<uintptr_t>(g.A) | (uintptr_t)(g.lda * 4)) & 15) == 0;
+  const bool w_vec = g.w_is_nk && ((reinterpret_cast<uintptr_t>(g.W) | (uintptr_t)((int64_t)g.K * 4)) & 15) == 0;
+  auto load_b = [&](int k, float (&v)[16]) {
+    if (g.w_is_nk) {
+      gemm_load16(g.W + (int64_t)wc * g.K, k, g.K, w_vec, v);
+    } else {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int k = k0 + 16 * h + s;
-      const int kc = k < g.K ? k : g.K - 1;
-      const float a = g.A[ar * g.lda + kc];
-      const float b = g.w_is_nk ? g.W[(int64_t)wc * g.K + kc] : g.W[(int64_t)kc * g.N + wc];
-      av[s] = k < g.K ? a : 0.0f;
-      bv[s] = k < g.K ? b : 0.0f;
+      for (int s = 0; s < 16; ++s) {
+        const int kk = k + s < g.K ? k + s : g.K - 1;
+        const float x = g.W[(int64_t)kk * g.N + wc];     // (K, N): lanes read consecutive columns, coalesced
+        v[s] = k + s < g.K ? x : 0.0f;
+      }
+    }
+  };
+  hf32x16 acc = {0};
+  float av[16], bv[16], an[16], bn[16];
+  gemm_load16(arow, 16 * h, g.K, a_vec, av);
+  load_b(16 * h, bv);
+  for (int k0 = 0; k0 < g.K; k0 += 32) {
+    const bool more = k0 + 32 < g.K;
+    if (more) {
+      gemm_load16(arow, k0 + 32 + 16 * h, g.K, a_vec, an);
+      load_b(k0 + 32 + 16 * h, bn);
     }
 #pragma unroll
     for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+    if (more) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) { av[s] = an[s]; bv[s] = bn[s]; }
+    }
   }
   const int n = n0 + col;
   if (n >= g.N) return;
@@ -152,20 +189,50 @@ struct AttnArgs {
   const float* uvqk; int64_t ld;        // (B * N, ld) rows [u | v | q | k], u/v: H*dv wide, q/k: H*dqk wide
   int B, N, H, dqk, dv;
   const int64_t* lengths;
-  const int64_t* timestamps;            // (B, N) or NULL (no bias at all, as the reference)
-  const float* ts_w; const float* pos_w;
-  const int64_t* thresholds; int num_buckets;   // thresholds[b-1] = smallest |dt| in bucket >= b
+  const unsigned char* buckets;         // (B, N keys, N queries) time buckets from hstu_time_buckets, or NULL (no bias at all)
+  const float* ts_w; const float* pos_w; int num_buckets;
   float* out;                           // (B * N, H * dv)
 };
 
-// grid (query tiles of 32, H, B), one wave each
+// buckets[b][j][i] = #{t : thresholds[t] <= |ts[b][min(i + 1, N - 1)] - ts[b][j]|}: the time bucket of (query i, key j),
+// which depends on neither the head nor the layer -- computed once per encode() instead of by every attention launch
+// (8 heads x 16 layers redid a 7-step binary search per element: 126 of the 146 us of an ML-20M attention launch).
+// Key-major so that the attention kernel's lanes (consecutive queries) read consecutive bytes.
+__global__ void hstu_time_buckets_kernel(const int64_t* __restrict__ ts, int B, int N, const int64_t* __restrict__ thresholds,
+                                         int num_buckets, unsigned char* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * N * N) return;
+  const int i = (int)(idx % N);
+  const int64_t bj = idx / N;
+  const int j = (int)(bj % N), b = (int)(bj / N);
+  long long dt = ts[(int64_t)b * N + (i + 1 < N ? i + 1 : N - 1)] - ts[(int64_t)b * N + j];
+  if (dt < 0) dt = -dt;
+  int lo = 0, hi = num_buckets;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (thresholds[mid] <= dt) lo = mid + 1; else hi = mid;
+  }
+  out[idx] = (unsigned char)lo;
+}
+
+// grid (query tiles of 32, H, B), one wave each.  Everything a bias lookup needs (the row's timestamps, pos_w, ts_w, the
+// bucket thresholds) is staged in LDS once, and a tile's Q / K / V fragments are requested in one batch before its MFMA
+// chains: the first version chased two dependent global loads per element and one per MFMA step (146 us per ML-20M block).
+constexpr int kAttnMaxSteps = 16;   // dqk <= 32
+
 __global__ __launch_bounds__(64) void hstu_attention_kernel(AttnArgs a) {
-  __shared__ long long thr_s[128];
+  extern __shared__ __attribute__((aligned(16))) float attn_smem[];   // pos_w[2N-1] | ts_w[nb+1]
   const int lane = threadIdx.x;
   const int x = lane & 31, h = lane >> 5;
   const int qt = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
   const int N = a.N, H = a.H, dqk = a.dqk, dv = a.dv;
-  for (int i = lane; i < a.num_buckets && i < 128; i += 64) thr_s[i] = a.thresholds[i];
+  float* pos_s = attn_smem;
+  float* tsw_s = pos_s + 2 * N;
+  const bool biased = a.buckets != nullptr;
+  if (biased) {
+    for (int i = lane; i < 2 * N - 1; i += 64) pos_s[i] = a.pos_w[i];
+    for (int i = lane; i <= a.num_buckets; i += 64) tsw_s[i] = a.ts_w[i];
+  }
   __syncthreads();
   const int64_t len = a.lengths[b];
   const int i0 = qt * 32;
@@ -175,42 +242,50 @@ __global__ __launch_bounds__(64) void hstu_attention_kernel(AttnArgs a) {
   const float* Kp = Q + (int64_t)H * dqk;
   const int qi = i0 + x < N ? i0 + x : N - 1;        // this lane's query (column axis)
   const float inv_n = 1.0f / (float)N;
-  // ts[b][min(i + 1, N - 1)] of the lane's query
-  long long ts_q = 0;
-  if (a.timestamps) ts_q = a.timestamps[(int64_t)b * N + (qi + 1 < N ? qi + 1 : N - 1)];
+  float qb[kAttnMaxSteps];
+#pragma unroll
+  for (int s = 0; s < kAttnMaxSteps; ++s) {
+    const int d = 2 * s + h;
+    const float v = Q[(int64_t)qi * a.ld + (d < dqk ? d : 0)];
+    qb[s] = d < dqk ? v : 0.0f;
+  }
   hf32x16 O = {0};                                    // O^T: row = value dim, column = query
   for (int kt = 0; kt <= qt; ++kt) {                  // causal: key tiles up to the query tile
     const int j0 = kt * 32;
-    // S^T = K_tile Q_tile^T : A = keys (rows), B = queries (columns), K axis = dqk
-    hf32x16 S = {0};
     const int kj = j0 + x < N ? j0 + x : N - 1;
-    for (int s = 0; s < (dqk + 1) / 2; ++s) {
-      const int d = 2 * s + h;
-      const float ka = d < dqk ? Kp[(int64_t)kj * a.ld + d] : 0.0f;
-      const float qb = d < dqk ? Q[(int64_t)qi * a.ld + d] : 0.0f;
-      S = __builtin_amdgcn_mfma_f32_32x32x2f32(ka, qb, S, 0, 0, 0);
-    }
-    // P^T[j][i] = silu(S + bias) / N for j <= i, and the K-step r of O^T += V^T P^T in one go
+    float ka[kAttnMaxSteps], va[16];
+    unsigned char bk[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int j = j0 + acc_row(r, h);   // this lane's key for register r
+      const int key = j0 + acc_row(r, h);
+      bk[r] = biased ? a.buckets[((int64_t)b * N + (key < N ? key : N - 1)) * N + qi] : (unsigned char)0;
+    }
+#pragma unroll
+    for (int s = 0; s < kAttnMaxSteps; ++s) {
+      const int d = 2 * s + h;
+      const float v = Kp[(int64_t)kj * a.ld + (d < dqk ? d : 0)];
+      ka[s] = d < dqk ? v : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                    // A operand of O^T's K-step r: V[key row(r, h)][d = lane & 31]
+      const int key = j0 + acc_row(r, h);
+      const float v = V[(int64_t)(key < N ? key : N - 1) * a.ld + (x < dv ? x : 0)];
+      va[r] = (x < dv && key < N) ? v : 0.0f;
+    }
+    // S^T = K_tile Q_tile^T : A = keys (rows), B = queries (columns), K axis = dqk
+    hf32x16 S = {0};
+#pragma unroll
+    for (int s = 0; s < kAttnMaxSteps; ++s)
+      if (2 * s < dqk) S = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[s], qb[s], S, 0, 0, 0);
+    // P^T[j][i] = silu(S + bias) / N for j <= i; register r of S^T is the B operand of K-step r of O^T += V^T P^T
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = j0 + acc_row(r, h);               // this lane's key for register r
       float sc = S[r];
-      if (a.timestamps && j < N) {
-        long long dt = ts_q - a.timestamps[(int64_t)b * N + j];
-        if (dt < 0) dt = -dt;
-        int lo = 0, hi2 = a.num_buckets;              // bucket = number of thresholds <= |dt|
-        while (lo < hi2) {
-          const int mid = (lo + hi2) >> 1;
-          if (thr_s[mid] <= dt) lo = mid + 1; else hi2 = mid;
-        }
-        sc += a.pos_w[N - 1 + j - qi] + a.ts_w[lo];
-      }
+      if (biased && j < N) sc += pos_s[N - 1 + j - qi] + tsw_s[bk[r]];
       float pv = sc / (1.0f + expf(-sc)) * inv_n;
       if (j > qi || j >= N || i0 + x >= N) pv = 0.0f;
-      // A operand of this K-step: V[key row(r, h)][d = lane & 31]
-      const int key = j0 + acc_row(r, h);
-      const float va = (x < dv && key < N) ? V[(int64_t)key * a.ld + x] : 0.0f;
-      O = __builtin_amdgcn_mfma_f32_32x32x2f32(va, pv, O, 0, 0, 0);
+      O = __builtin_amdgcn_mfma_f32_32x32x2f32(va[r], pv, O, 0, 0, 0);
     }
   }
   const int qrow = i0 + x;
@@ -254,14 +329,26 @@ int gemm_f32(const float* A, int64_t lda, const float* W, int w_is_nk, const flo
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
+int hstu_time_buckets(const int64_t* timestamps, int B, int N, const int64_t* thresholds, int num_buckets, unsigned char* out,
+                      hipStream_t stream) {
+  const int64_t total = (int64_t)B * N * N;
+  if (total == 0) return kOk;
+  if (num_buckets > 255) { set_error("hstu_time_buckets: %d buckets do not fit a byte", num_buckets); return kErrUnsupported; }
+  hipLaunchKernelGGL(hstu_time_buckets_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, timestamps, B, N, thresholds,
+                     num_buckets, out);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 int hstu_attention(const float* uvqk, int64_t ld, int B, int N, int H, int dqk, int dv, const int64_t* lengths,
-                   const int64_t* timestamps, const float* ts_w, const float* pos_w, const int64_t* thresholds, int num_buckets,
-                   float* out, hipStream_t stream) {
+                   const unsigned char* buckets, const float* ts_w, const float* pos_w, int num_buckets, float* out,
+                   hipStream_t stream) {
   if (B == 0 || N == 0) return kOk;
   if (dv > 32) { set_error("hstu_attention: dv = %d (supported: <= 32)", dv); return kErrUnsupported; }
-  if (num_buckets > 128) { set_error("hstu_attention: %d time buckets (supported: <= 128)", num_buckets); return kErrUnsupported; }
-  AttnArgs a{uvqk, ld, B, N, H, dqk, dv, lengths, timestamps, ts_w, pos_w, thresholds, num_buckets, out};
-  hipLaunchKernelGGL(hstu_attention_kernel, dim3((N + 31) / 32, H, B), dim3(64), 0, stream, a);
+  if (dqk > 2 * kAttnMaxSteps) { set_error("hstu_attention: dqk = %d (supported: <= %d)", dqk, 2 * kAttnMaxSteps); return kErrUnsupported; }
+  AttnArgs a{uvqk, ld, B, N, H, dqk, dv, lengths, buckets, ts_w, pos_w, num_buckets, out};
+  const size_t lds = sizeof(float) * ((size_t)2 * N + num_buckets + 2);
+  if (lds > 60 * 1024) { set_error("hstu_attention: seq_len = %d does not fit LDS", N); return kErrUnsupported; }
+  hipLaunchKernelGGL(hstu_attention_kernel, dim3((N + 31) / 32, H, B), dim3(64), lds, stream, a);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

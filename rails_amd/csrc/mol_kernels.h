@@ -79,9 +79,11 @@ int rows_normalize(const float* x, int64_t ldx, const int64_t* row_index, int64_
                    hipStream_t stream);
 int gemm_f32(const float* A, int64_t lda, const float* W, int w_is_nk, const float* bias, const float* residual, int64_t ldr, int64_t M,
              int N, int K, int act, const int64_t* lengths, int seq_len, float* C, int64_t ldc, hipStream_t stream);
+int hstu_time_buckets(const int64_t* timestamps, int B, int N, const int64_t* thresholds, int num_buckets, unsigned char* out,
+                      hipStream_t stream);
 int hstu_attention(const float* uvqk, int64_t ld, int B, int N, int H, int dqk, int dv, const int64_t* lengths,
-                   const int64_t* timestamps, const float* ts_w, const float* pos_w, const int64_t* thresholds, int num_buckets,
-                   float* out, hipStream_t stream);
+                   const unsigned char* buckets, const float* ts_w, const float* pos_w, int num_buckets, float* out,
+                   hipStream_t stream);
 int select_keys(const unsigned long long* keys, int rows, int keys_per_row, int k, float* out_scores, int64_t* out_pos,
                 hipStream_t stream);
 int coarse_score(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, float* scores, int64_t ld,

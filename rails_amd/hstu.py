@@ -4,8 +4,8 @@ Mirror of modeling/sequential/hstu.py:HSTU for inference: same constructor argum
 parameter / buffer names (so `load_state_dict` of a reference checkpoint's `module.` entries works unchanged), same
 `get_item_embeddings` / `encode` / `forward` signatures.  No fbgemm: the layers run on the padded (B, N, D) tensor with
 rows at positions >= length held at zero.  Every floating-point operation runs in the HIP kernels
-of csrc/hstu.hip through the C ABI (rails_hstu_preprocess, rails_rows_layer_norm, rails_gemm_f32, rails_hstu_attention,
-rails_rows_normalize); torch only holds the parameters and moves rows (embedding lookup).
+of csrc/hstu.hip through the C ABI (rails_hstu_preprocess, rails_hstu_time_buckets, rails_rows_layer_norm, rails_gemm_f32,
+rails_hstu_attention, rails_rows_normalize); torch only holds the parameters and moves rows (embedding lookup).
 
 Not supported (raises): training mode, the cache / delta_x_offsets decoding path (hstu.py:163-186), `concat_ua`,
 `normalization="softmax_rel_bias"`, `linear_activation` other than "silu" / "none".
@@ -174,8 +174,12 @@ class HSTU(torch.nn.Module):
         att = torch.empty((M, H * dv), dtype=torch.float32, device=dev)
         oin = torch.empty((M, H * dv), dtype=torch.float32, device=dev)
         thr = self._bucket_thresholds.to(dev)
+        has_bias = ts is not None and any(l._rel_attn_bias is not None for l in self._hstu._attention_layers)
+        buckets = torch.empty((B, N, N), dtype=torch.uint8, device=dev) if has_bias else None
         with _on_device(dev):
             st = _stream()
+            if has_bias:   # the time buckets depend on neither layer nor head: once per call
+                _lib.check(lib.rails_hstu_time_buckets(_ptr(ts), B, N, _ptr(thr), self._num_buckets, _ptr(buckets), st), "rails_hstu_time_buckets")
             _lib.check(lib.rails_hstu_preprocess(_ptr(emb), _ptr(ids), _ptr(lengths), _ptr(f32(self._input_features_preproc._pos_emb.weight)),
                                                  B, N, D, C.c_float(float(D) ** 0.5), _ptr(x), st), "rails_hstu_preprocess")
             for layer in self._hstu._attention_layers:
@@ -185,9 +189,9 @@ class HSTU(torch.nn.Module):
                                               1 if self._linear_activation == "silu" else 0, _ptr(lengths), N, _ptr(mm), W, st), "rails_gemm_f32")
                 rb = layer._rel_attn_bias
                 use_bias = ts is not None and rb is not None
-                _lib.check(lib.rails_hstu_attention(_ptr(mm), W, B, N, H, dqk, dv, _ptr(lengths), _ptr(ts) if use_bias else None,
+                _lib.check(lib.rails_hstu_attention(_ptr(mm), W, B, N, H, dqk, dv, _ptr(lengths), _ptr(buckets) if use_bias else None,
                                                     _ptr(f32(rb._ts_w)) if use_bias else None, _ptr(f32(rb._pos_w)) if use_bias else None,
-                                                    _ptr(thr) if use_bias else None, self._num_buckets if use_bias else 0, _ptr(att), st),
+                                                    self._num_buckets if use_bias else 0, _ptr(att), st),
                            "rails_hstu_attention")
                 # o_input = u * LN(attn);  u = the first H*dv columns of mm
                 _lib.check(lib.rails_rows_layer_norm(_ptr(att), H * dv, M, H * dv, C.c_float(self._eps), _ptr(mm), W, _ptr(oin), H * dv, st),
