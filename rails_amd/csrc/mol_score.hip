@@ -600,31 +600,49 @@ struct FragBuf {
   }
 };
 
+#ifdef RAILS_SCORE_PHASES   // tools/ksplit_phases.sh: wall-clock stamps (100 MHz) of workgroup 0 / wave 0's first unit
+__device__ long long g_sphase[16];
+#define RAILS_SPHASE(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && it == 0) g_sphase[i] = (long long)wall_clock64(); } while (0)
+#else
+#define RAILS_SPHASE(i)
+#endif
+
+// `bnext` carries block 0 of THIS chunk, requested by the previous call (or by the unit prologue); before returning, block 0
+// of chunk `next_chunk` (< 0: none) is requested into it.  The chunk order of a unit is 0,1,2,3 (pass 1), 0,1 (sweep of
+// half 0), 2,3 (sweep of half 1): eight calls whose first-block round trip used to be exposed (~2 us each of a 118 us unit).
 template <int MC, int DD>
 __device__ __forceinline__ void gemm1_chunk(f32x16 (&D1c)[MC], const FragBuf& eq, const FragBuf& tile, int chunk,
-                                            int lane16) {
+                                            int next_chunk, float4 (&bnext)[4], int lane16) {
 #pragma unroll
   for (int m = 0; m < MC; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) D1c[m][r] = 0.0f;
+  // Blocks of 4 fragment pairs (16 MFMAs, ~1000 cycles); the HBM/L2-side operand is double buffered (+16 VGPRs; buffering
+  // the L1-resident eq fragments as well only added spills): block i+1's loads are issued before block i's MFMAs.
+  constexpr int NB = DD / 32;          // blocks per item group
+  constexpr int NBLK = MC * NB;
+  float4 a[4], b[2][4];
+  auto load_b = [&](int c, int i, float4 (&dst)[4]) {
+    const int m = i / NB, s0 = (i % NB) * 4;
 #pragma unroll
-  for (int m = 0; m < MC; ++m) {
+    for (int sc = 0; sc < 4; ++sc) dst[sc] = tile.frag((c * MC + m) * (DD / 8) + s0 + sc, lane16);
+  };
 #pragma unroll
-    for (int s0 = 0; s0 < DD / 8; s0 += 4) {
-      float4 a[4], b[4];
+  for (int sc = 0; sc < 4; ++sc) b[0][sc] = bnext[sc];
 #pragma unroll
-      for (int sc = 0; sc < 4; ++sc) {
-        a[sc] = eq.frag(s0 + sc, lane16);  // L1-resident, re-read instead of pinning DD/2 registers
-        b[sc] = tile.frag((chunk * MC + m) * (DD / 8) + s0 + sc, lane16);
-      }
-      asm volatile("" ::: "memory");  // bound the operands in flight
+  for (int i = 0; i < NBLK; ++i) {
+    const int m = i / NB, s0 = (i % NB) * 4;
 #pragma unroll
-      for (int sc = 0; sc < 4; ++sc) {
-        D1c[m] = mfma32(a[sc].x, b[sc].x, D1c[m]);
-        D1c[m] = mfma32(a[sc].y, b[sc].y, D1c[m]);
-        D1c[m] = mfma32(a[sc].z, b[sc].z, D1c[m]);
-        D1c[m] = mfma32(a[sc].w, b[sc].w, D1c[m]);
-      }
+    for (int sc = 0; sc < 4; ++sc) a[sc] = eq.frag(s0 + sc, lane16);  // L1-resident, re-read instead of pinning DD/2 registers
+    if (i + 1 < NBLK) load_b(chunk, i + 1, b[(i + 1) & 1]);
+    else if (next_chunk >= 0) load_b(next_chunk, 0, bnext);
+    asm volatile("" ::: "memory");  // bound the operands in flight: exactly one block ahead
+#pragma unroll
+    for (int sc = 0; sc < 4; ++sc) {
+      D1c[m] = mfma32(a[sc].x, b[i & 1][sc].x, D1c[m]);
+      D1c[m] = mfma32(a[sc].y, b[i & 1][sc].y, D1c[m]);
+      D1c[m] = mfma32(a[sc].z, b[i & 1][sc].z, D1c[m]);
+      D1c[m] = mfma32(a[sc].w, b[i & 1][sc].w, D1c[m]);
     }
   }
 }
@@ -635,8 +653,8 @@ __device__ __forceinline__ void gemm1_chunk(f32x16 (&D1c)[MC], const FragBuf& eq
 // have been rescaled to it and den has this half's ex added (this lane half's partial sums).
 template <class G, int HALF>
 __device__ __forceinline__ void ksplit_half_gate(const f32x16 (&D2q)[G::TH], f32x16 (&D3h)[G::TL / 2],
-                                                 const FragBuf& gW2, const float* sB2, const FragBuf& tile,
-                                                 const float4* __restrict__ gq4, int lane16, int hi, float& mn,
+                                                 const FragBuf& gW2, const float* sB2, const float4 (&gih)[G::E / 8],
+                                                 const float4* gq4, int lane16, int hi, float& mn,
                                                  float& den, f32x2& num) {
   constexpr int HV = G::TL / 2;       // row tiles per half
   constexpr int EH = G::E / 2;        // K-steps (per lane values) per half
@@ -672,8 +690,8 @@ __device__ __forceinline__ void ksplit_half_gate(const f32x16 (&D2q)[G::TH], f32
   float lmn = INFINITY;
 #pragma unroll
   for (int ec = 0; ec < EH / 4; ++ec) {
-    const float4 gi = tile.frag(G::kTileExFloats / 256 + E0 / 4 + ec, lane16);
-    const float4 gq = gq4[E0 / 4 + ec];
+    const float4 gi = gih[ec];            // this half's item-gate fragments, loaded once for both queries by the caller
+    const float4 gq = gq4[E0 / 4 + ec];   // the query's gate row, staged in LDS at the start of the unit
     const f32x2 giv[2] = {{gi.x, gi.y}, {gi.z, gi.w}};
     const f32x2 gqv[2] = {{gq.x, gq.y}, {gq.z, gq.w}};
 #pragma unroll
@@ -685,7 +703,6 @@ __device__ __forceinline__ void ksplit_half_gate(const f32x16 (&D2q)[G::TH], f32
       D3h[e / 16][e % 16 + 1] = uu.y;
       lmn = fminf(lmn, fminf(uu.x, uu.y));
     }
-    if ((ec & 3) == 3) asm volatile("" ::: "memory");  // at most 4 gi/gq fragment pairs in flight
   }
   lmn = fminf(lmn, xor32(lmn));
   const float mnew = fminf(mn, lmn);
@@ -718,6 +735,7 @@ __global__ __launch_bounds__(256, 1) void mol_score_ksplit_kernel(ScoreArgs p) {
   const float4* sW1 = reinterpret_cast<const float4*>(smem);
   const float* sB1 = smem + G::kW1Floats;
   const float* sB2 = sB1 + H;
+  float* sGq = smem + G::kW1Floats + H + G::L;   // [NW][QT][L]: the current unit's query-gate rows, per wave
   {  // W1 fragments + both bias vectors into LDS; W2 stays in HBM/L2
     const float4* src = reinterpret_cast<const float4*>(p.wpack);
     float4* dst = reinterpret_cast<float4*>(smem);
@@ -757,6 +775,20 @@ __global__ __launch_bounds__(256, 1) void mol_score_ksplit_kernel(ScoreArgs p) {
 #pragma unroll
     for (int q = 0; q < G::QT; ++q) active[q] = (g * G::QT + q < p.B) && (row < 0 || g * G::QT + q == row);
 
+    // the unit's gq rows -> this wave's LDS slot (read back by the same wave only: DS operations of a wave are in order).
+    // Loading them (and gi) inside the gate loop exposed 4 round trips per call, 16 per unit: ~32 of a unit's 136 us.
+    float4 bnext[4];
+#pragma unroll
+    for (int sc = 0; sc < 4; ++sc) bnext[sc] = tileb.frag(sc, lane16);   // chunk 0, block 0
+    static_assert(G::L == 256, "one float4 per lane per query");
+    float4* sGqW = reinterpret_cast<float4*>(sGq + wave * G::QT * G::L);
+#pragma unroll
+    for (int q = 0; q < G::QT; ++q) {
+      // queries past the batch end (padding of the last group) run on zero operands; their store is skipped
+      const int qq = (g * G::QT + q < p.B) ? g * G::QT + q : p.B - 1;
+      sGqW[q * (G::L / 4) + lane] = *reinterpret_cast<const float4*>(p.gqfrag + (int64_t)qq * G::L + lane * 4);
+    }
+    RAILS_SPHASE(0);
     // ---- pass 1: chunked GEMM1 -> K-slices of GEMM2 (t = -log2e * pre)
     f32x16 D2[G::QT][G::TH];
 #pragma unroll
@@ -768,7 +800,8 @@ __global__ __launch_bounds__(256, 1) void mol_score_ksplit_kernel(ScoreArgs p) {
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
       f32x16 D1c[MC];
-      gemm1_chunk<MC, DD>(D1c, eqb, tileb, c, lane16);
+      gemm1_chunk<MC, DD>(D1c, eqb, tileb, c, (c + 1) % NCH, bnext, lane16);   // after the last chunk: chunk 0 again (sweep)
+      if (c == 0) RAILS_SPHASE(1);
 #pragma unroll
       for (int q = 0; q < G::QT; ++q) {
         {
@@ -791,6 +824,7 @@ __global__ __launch_bounds__(256, 1) void mol_score_ksplit_kernel(ScoreArgs p) {
     }
 
     // ---- hid' = t / (1 + 2^t), both queries, in place
+    RAILS_SPHASE(3);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < G::QT; ++q)
@@ -807,6 +841,7 @@ __global__ __launch_bounds__(256, 1) void mol_score_ksplit_kernel(ScoreArgs p) {
 
     // ---- two halves of the logit axis, online softmax across them: GEMM3 half -> gate -> ex (kept in D3h),
     //      then the GEMM1 chunks of that half again for num += ex * cl (cl is not kept across pass 1)
+    RAILS_SPHASE(4);
     float mn[G::QT], den[G::QT];
     f32x2 num[G::QT];
 #pragma unroll
@@ -815,18 +850,21 @@ __global__ __launch_bounds__(256, 1) void mol_score_ksplit_kernel(ScoreArgs p) {
       (
           [&] {
             f32x16 D3h[G::QT][G::TL / 2];
+            // this half's item-gate fragments: requested here, consumed after the first query's GEMM3 (256 MFMAs later)
+            float4 gih[G::E / 8];
+#pragma unroll
+            for (int ec = 0; ec < G::E / 8; ++ec) gih[ec] = tileb.frag(G::kTileExFloats / 256 + HALF * (G::E / 8) + ec, lane16);
 #pragma unroll
             for (int q = 0; q < G::QT; ++q) {
-              // queries past the batch end (padding of the last group) run on zero operands; their store is skipped
-              const int qq = (g * G::QT + q < p.B) ? g * G::QT + q : p.B - 1;
-              const float4* gq4 = reinterpret_cast<const float4*>(p.gqfrag + (int64_t)qq * G::L + hi * G::E);
-              ksplit_half_gate<G, HALF>(D2[q], D3h[q], gW2, sB2, tileb, gq4, lane16, hi, mn[q], den[q], num[q]);
+              const float4* gq4 = reinterpret_cast<const float4*>(sGq + (wave * G::QT + q) * G::L + hi * G::E);
+              ksplit_half_gate<G, HALF>(D2[q], D3h[q], gW2, sB2, gih, gq4, lane16, hi, mn[q], den[q], num[q]);
             }
+            RAILS_SPHASE(5 + 2 * HALF);
 #pragma unroll
             for (int cc = 0; cc < NCH / 2; ++cc) {
               const int c = HALF * (NCH / 2) + cc;
               f32x16 D1c[MC];
-              gemm1_chunk<MC, DD>(D1c, eqb, tileb, c, lane16);
+              gemm1_chunk<MC, DD>(D1c, eqb, tileb, c, c + 1 < NCH ? c + 1 : -1, bnext, lane16);
               __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
               for (int q = 0; q < G::QT; ++q)
@@ -840,6 +878,7 @@ __global__ __launch_bounds__(256, 1) void mol_score_ksplit_kernel(ScoreArgs p) {
                 }
               __builtin_amdgcn_sched_barrier(0);
             }
+            RAILS_SPHASE(6 + 2 * HALF);
           }(),
           ...);
     }(std::integer_sequence<int, 0, 1>{});
@@ -860,7 +899,7 @@ __global__ __launch_bounds__(256, 1) void mol_score_ksplit_kernel(ScoreArgs p) {
 template <int PQ, int PX, int DD, int H, int MC>
 static int launch_ksplit(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using G = Geo<PQ, PX, DD, H>;
-  constexpr size_t lds = ((size_t)G::kW1Floats + H + G::L) * sizeof(float);
+  constexpr size_t lds = ((size_t)G::kW1Floats + H + G::L + 4 * G::QT * G::L) * sizeof(float);   // + per-wave gq rows
   static_assert(lds <= 160 * 1024, "W1 fragments must fit LDS");
   static bool attr_set = false;
   if (!attr_set) {
@@ -998,4 +1037,11 @@ int score_launch(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t strea
   return kErrUnsupported;
 }
 
+#ifdef RAILS_SCORE_PHASES
+}  // namespace mol
+extern "C" int rails_debug_score_phases(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(mol::g_sphase), sizeof(long long) * 16) == hipSuccess ? 0 : -1;
+}
+namespace mol {
+#endif
 }  // namespace mol
