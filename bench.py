@@ -321,6 +321,29 @@ def main() -> None:
         else:
             score_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
 
+        # the same step without the seen-id filter (k' = k, invalid_ids = None), timed the same way
+        # after the headline region
+        def step_nofilter():
+            out_ids, out_scores, _ = cand.get_top_k_outputs(q, k, kw, topk_mod, None)
+            return out_ids
+
+        for _ in range(args.warmup):
+            step_nofilter()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step_nofilter()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        nofilter_elapsed = time.perf_counter() - t0
+        if world > 1:
+            tn = torch.tensor([nofilter_elapsed], dtype=torch.float64, device="cpu" if test_backend else dev)
+            dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+            nofilter_elapsed = float(tn.item())
+
     # ---- opt-in precision mode "f16x3" (same API, same index, same 1e-4 bar), timed the same
     #      way AFTER the headline region so it cannot perturb it.  Reported separately; `value` stays the exact-fp32 path.
     fast = None
@@ -410,6 +433,8 @@ def main() -> None:
             "index_build_s": index_build_s,
         }
         out["config"]["item_table"] = table_kind
+        out["without_seen_id_filter"] = {"value": B * args.steps / nofilter_elapsed, "unit": "queries/s",
+                                         "ms_per_step": nofilter_elapsed / args.steps * 1e3, "k": k}
         if two_pass:
             gbps = coarse_table_bytes / (score_ms * 1e-3) / 1e9
             out["metric"] = "queries/sec, MoL two-pass approximate top-k over N items (get_top_k_outputs: coarse top-K' + MoL rerank + id map + seen-id filter)"
