@@ -61,7 +61,7 @@ from rails_amd import engine as E
 
 with torch.inference_mode():
     t0 = time.time()
-    at = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=1000)     # ONE index (640 B/item) serves the exact and the two-pass runs
+    at = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=1000)     # ONE index (1280 B/item) serves the exact and the two-pass runs
     torch.cuda.synchronize()
     build_s = time.time() - t0
     table = at._table()
