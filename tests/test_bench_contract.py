@@ -1,0 +1,47 @@
+"""bench.py's output contract (the driver parses ONE JSON line): checked on the committed line of the last GPU run
+(profiles/r01_bench.json) on CPU, and on a live short run on the GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline"}
+ROOFLINE = {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+CPU_BASELINE = {"value", "unit", "cores", "kind", "sample"}
+
+
+def check_line(d, expect_cpu_baseline):
+    assert REQUIRED <= set(d), REQUIRED - set(d)
+    assert d["higher_is_better"] is True and d["unit"] == "queries/s" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert d["scaling"] in ("strong", "weak") and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["global_batch"] / d["ms_per_step"] * 1e3) / d["value"] < 1e-6
+    r = d["roofline"]
+    assert ROOFLINE <= set(r) and r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    if expect_cpu_baseline:
+        c = d["cpu_baseline"]
+        assert CPU_BASELINE <= set(c) and c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench.json")))
+    check_line(d, expect_cpu_baseline=True)
+    assert d["n_gpus"] == 1 and "amzn-books" in d["config"]["workload"]
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["traffic"] is not None
+
+
+@pytest.mark.gpu
+def test_live_bench_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-fast-path",
+                          "--no-other-workloads"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    check_line(d, expect_cpu_baseline=False)
+    assert d["steps"] == 3 and d["warmup"] == 1 and d["n_gpus"] == 1
