@@ -282,6 +282,24 @@ int rails_hstu_time_buckets(const int64_t* timestamps, int32_t batch, int32_t se
 int rails_hstu_attention(const float* uvqk, int64_t ld, int32_t batch, int32_t seq_len, int32_t heads, int32_t dqk, int32_t dv,
                          const int64_t* lengths, const uint8_t* buckets, const float* ts_w, const float* pos_w,
                          int32_t num_buckets, float* out, void* stream);
+/* The whole eval-path encoder in ONE launch for short sequences (seq_len <= 64 and the LDS bound checked by
+ * rails_hstu_fused_supported): one workgroup per sequence keeps the residual stream, the uvqk activations and the bias tables
+ * in LDS and runs all blocks back to back; writes the postprocessed embedding at position lengths[b] - 1 (HSTU.encode,
+ * hstu.py:741-803).  `layers`: DEVICE array of n_blocks rails_hstu_layer (device pointers to each block's parameters; ts_w /
+ * pos_w are only read when buckets != NULL).  buckets as for rails_hstu_attention.  RAILS_ENOTSUP for other geometries: the
+ * caller then chains the per-layer entry points above. */
+typedef struct rails_hstu_layer {
+  const float* uvqk;   /* (dim, 2 * heads * (dv + dqk)) */
+  const float* o_w;    /* (dim, heads * dv), a torch Linear weight */
+  const float* o_b;    /* (dim) */
+  const float* ts_w;   /* (num_buckets + 1) */
+  const float* pos_w;  /* (2 * seq_len - 1) */
+} rails_hstu_layer;
+int rails_hstu_fused_supported(int32_t seq_len, int32_t dim, int32_t heads, int32_t dqk, int32_t dv, int32_t num_buckets);
+int rails_hstu_encode_fused(const float* embeddings, const int64_t* ids, const int64_t* lengths, const uint8_t* buckets,
+                            const float* pos_emb, const rails_hstu_layer* layers, int32_t n_blocks, int32_t batch, int32_t seq_len,
+                            int32_t dim, int32_t heads, int32_t dqk, int32_t dv, int32_t num_buckets, int32_t postproc_mode, float eps,
+                            float* out, void* stream);
 /* out[r] = normalise(x[row_index ? row_index[r] : r]); mode 0 LayerNorm (no affine), 1 x / max(||x||, eps).
  * output_postprocessors.py:38-85 + get_current_embeddings (modeling/sequential/utils.py:74-90). */
 int rails_rows_normalize(const float* x, int64_t ldx, const int64_t* row_index, int64_t rows, int32_t dim, int32_t mode, float eps,

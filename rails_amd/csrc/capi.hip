@@ -507,6 +507,23 @@ int rails_hstu_attention(const float* uvqk, int64_t ld, int32_t batch, int32_t s
   return r == kOk ? r : fail(r, "hstu_attention");
 }
 
+int rails_hstu_fused_supported(int32_t seq_len, int32_t dim, int32_t heads, int32_t dqk, int32_t dv, int32_t num_buckets) {
+  return hstu_fused_supported(seq_len, dim, heads, dqk, dv, num_buckets) ? 1 : 0;
+}
+
+int rails_hstu_encode_fused(const float* embeddings, const int64_t* ids, const int64_t* lengths, const uint8_t* buckets,
+                            const float* pos_emb, const rails_hstu_layer* layers, int32_t n_blocks, int32_t batch, int32_t seq_len,
+                            int32_t dim, int32_t heads, int32_t dqk, int32_t dv, int32_t num_buckets, int32_t postproc_mode, float eps,
+                            float* out, void* stream) {
+  g_err[0] = '\0';
+  if (batch < 0 || n_blocks < 0 || (postproc_mode != 0 && postproc_mode != 1)) { set_error("hstu_encode_fused: bad argument"); return RAILS_EINVAL; }
+  if (batch == 0) return RAILS_OK;
+  if (!embeddings || !ids || !lengths || !pos_emb || !out || (n_blocks > 0 && !layers)) { set_error("hstu_encode_fused: NULL pointer"); return RAILS_EINVAL; }
+  const int r = hstu_encode_fused(embeddings, ids, lengths, buckets, pos_emb, layers, n_blocks, batch, seq_len, dim, heads, dqk, dv,
+                                  num_buckets, postproc_mode, eps, out, (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "hstu_encode_fused");
+}
+
 int rails_rows_normalize(const float* x, int64_t ldx, const int64_t* row_index, int64_t rows, int32_t dim, int32_t mode, float eps,
                          float* out, void* stream) {
   g_err[0] = '\0';

@@ -20,6 +20,7 @@
 //                            register-chained like the scoring kernel: S^T = K Q^T puts key j of a tile in accumulator
 //                            register r, which IS the B operand of the K-step {row(r,0), row(r,1)} of O^T += V^T P^T
 //   rows_normalize_kernel    LayerNorm or L2 normalisation of selected rows (the postprocessor + get_current_embeddings)
+//   hstu_fused_kernel        the whole encoder in one launch for seq_len <= 64: one workgroup per sequence, all in LDS
 #include <hip/hip_runtime.h>
 #include <math.h>
 
@@ -295,6 +296,239 @@ __global__ __launch_bounds__(64) void hstu_attention_kernel(AttnArgs a) {
     const int d = acc_row(r, h);
     if (d < dv) a.out[((int64_t)b * N + qrow) * ((int64_t)H * dv) + (int64_t)head * dv + d] = qrow < len ? O[r] : 0.0f;
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused encoder for short sequences (seq_len <= 64, e.g. amzn-books: N = 61, D = 64, 8 heads x 8): ONE workgroup per
+// sequence keeps the residual stream X, the uvqk activations Y and the attention output A in LDS (~103 KiB of the
+// 160 KiB) and runs every block back to back in one launch -- sequences are independent, so nothing crosses workgroups.
+// The multi-kernel path spends its time in per-kernel latency (83 launches of 5-20 us each for 16 blocks: 0.87 ms; a
+// hipGraph replay does not help); here a block is five barrier-separated phases of a few hundred MFMAs.
+//   LN1 -> NX | GEMM uvqk (+silu, padded rows zero) -> Y | attention per (head, query tile) -> A | LN2 * u -> A |
+//   GEMM o (+bias, +X, padded rows zero) -> X
+// 16 waves: phase work is dealt tile-wise (t = wave, wave + 16, ...).  LDS rows use odd strides (conflict-free column
+// walks).  Same arithmetic as the multi-kernel kernels except the K order inside the GEMMs (pairs 2s, 2s+1).
+// ---------------------------------------------------------------------------------------------
+struct FusedLayer { const float* uvqk; const float* o_w; const float* o_b; const float* ts_w; const float* pos_w; };
+
+struct FusedArgs {
+  const float* emb; const int64_t* ids; const int64_t* lengths; const unsigned char* buckets; const float* pos_emb;
+  const FusedLayer* layers; int n_blocks;
+  int B, N, D, H, dqk, dv, num_buckets, mode;
+  float eps;
+  float* out;      // (B, D) current embeddings
+};
+
+constexpr int kFusedThreads = 1024;
+constexpr int kFusedWaves = kFusedThreads / 64;
+constexpr int kFusedRows = 64;
+constexpr int kFusedMaxK = 128;   // D and heads * dv <= 128
+
+__global__ __launch_bounds__(kFusedThreads) void hstu_fused_kernel(FusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float fsm[];
+  const int N = a.N, D = a.D, H = a.H, dqk = a.dqk, dv = a.dv;
+  const int HV = H * dv, W = 2 * H * (dv + dqk);
+  const int XS = D + 1, AS = (HV > D ? HV : D) + 1, YS = W + 1;      // odd row strides
+  float* X = fsm;                                   // [64][XS]
+  float* A = X + kFusedRows * XS;                   // [64][AS]  LN1 output, then attention output / o input
+  float* Y = A + kFusedRows * AS;                   // [64][YS]  u | v | q | k
+  float* pos_s = Y + kFusedRows * YS;               // [2N - 1]
+  float* tsw_s = pos_s + 2 * kFusedRows;            // [num_buckets + 1]
+  unsigned char* bk_s = reinterpret_cast<unsigned char*>(tsw_s + 132);   // [N][N] key-major
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int x = lane & 31, h = lane >> 5;
+  const int64_t len = a.lengths[b];
+  const bool biased = a.buckets != nullptr;
+  const float scale = sqrtf((float)D);
+
+  // ---- prologue: X = [id != 0, n < len] * (emb * sqrt(D) + pos_emb[n]); rows >= N zero; bucket matrix to LDS
+  for (int i = tid; i < kFusedRows * D; i += kFusedThreads) {
+    const int n = i / D, dd = i - n * D;
+    float v = 0.0f;
+    if (n < N && n < len && a.ids[(int64_t)b * N + n] != 0) v = a.emb[((int64_t)b * N + n) * D + dd] * scale + a.pos_emb[(int64_t)n * D + dd];
+    X[n * XS + dd] = v;
+  }
+  if (biased)
+    for (int i = tid; i < N * N; i += kFusedThreads) bk_s[i] = a.buckets[(int64_t)b * N * N + i];
+  __syncthreads();
+
+  const float inv_n = 1.0f / (float)N;
+  for (int blk = 0; blk < a.n_blocks; ++blk) {
+    const FusedLayer L = a.layers[blk];
+    if (biased) {
+      for (int i = tid; i < 2 * N - 1; i += kFusedThreads) pos_s[i] = L.pos_w[i];
+      for (int i = tid; i <= a.num_buckets; i += kFusedThreads) tsw_s[i] = L.ts_w[i];
+    }
+    // ---- LN1: A[row][:D] = layer_norm(X[row])
+    for (int row = wave; row < kFusedRows; row += kFusedWaves) {
+      float sm = 0.0f;
+      for (int k = lane; k < D; k += 64) sm += X[row * XS + k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+      const float mean = sm / (float)D;
+      float vr = 0.0f;
+      for (int k = lane; k < D; k += 64) { const float c = X[row * XS + k] - mean; vr = __builtin_fmaf(c, c, vr); }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) vr += __shfl_xor(vr, o, 64);
+      const float rstd = 1.0f / sqrtf(vr / (float)D + a.eps);
+      for (int k = lane; k < D; k += 64) A[row * AS + k] = (X[row * XS + k] - mean) * rstd;
+    }
+    __syncthreads();
+    // ---- GEMM uvqk: Y = silu(A[:, :D] Wuvqk), rows >= len zero
+    for (int t = wave; t < 2 * (W / 32); t += kFusedWaves) {
+      const int mt = t / (W / 32), nt = t - mt * (W / 32);
+      // the tile's weight column first (one batch of loads; inside the MFMA loop every step waited for its own L2 trip)
+      hf32x16 acc = {0};
+      for (int k0 = 0; k0 < D; k0 += 64) {     // groups of 32 K-steps: 32 registers (1024 threads leave 128 per lane)
+        float bw[32];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+          const int k = k0 + 2 * s + h;
+          bw[s] = L.uvqk[(int64_t)(k < D ? k : D - 1) * W + nt * 32 + x];
+        }
+#pragma unroll
+        for (int s = 0; s < 32; ++s)
+          if (k0 + 2 * s < D) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(mt * 32 + x) * AS + k0 + 2 * s + h], bw[s], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + acc_row(r, h);
+        float v = acc[r];
+        v = v / (1.0f + expf(-v));
+        Y[row * YS + nt * 32 + x] = row < len && row < N ? v : 0.0f;
+      }
+    }
+    __syncthreads();
+    // ---- attention: A[i][head*dv + d] = sum_{j <= i} silu(q_i . k_j + bias) / N * v_j
+    for (int t = wave; t < 2 * H; t += kFusedWaves) {
+      const int head = t % H, qt = t / H;
+      const int i0 = qt * 32;
+      const int qi = i0 + x;                                  // < 64 always
+      const float* Vc = Y + HV + head * dv;
+      const float* Qc = Y + 2 * HV + head * dqk;
+      const float* Kc = Qc + H * dqk;
+      hf32x16 O = {0};
+      for (int kt = 0; kt <= qt; ++kt) {
+        const int j0 = kt * 32;
+        hf32x16 S = {0};
+        for (int s = 0; s < (dqk + 1) / 2; ++s) {
+          const int d = 2 * s + h;
+          const float ka = d < dqk ? Kc[(j0 + x) * YS + d] : 0.0f;
+          const float qb = d < dqk ? Qc[qi * YS + d] : 0.0f;
+          S = __builtin_amdgcn_mfma_f32_32x32x2f32(ka, qb, S, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = j0 + acc_row(r, h);
+          float sc = S[r];
+          if (biased && j < N && qi < N) sc += pos_s[N - 1 + j - qi] + tsw_s[bk_s[j * N + qi]];
+          float pv = sc / (1.0f + expf(-sc)) * inv_n;
+          if (j > qi || j >= N || qi >= N) pv = 0.0f;
+          const float va = x < dv ? Vc[j * YS + x] : 0.0f;      // rows >= N of Y are zero
+          O = __builtin_amdgcn_mfma_f32_32x32x2f32(va, pv, O, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = acc_row(r, h);
+        if (d < dv) A[qi * AS + head * dv + d] = (qi < len && qi < N) ? O[r] : 0.0f;
+      }
+    }
+    __syncthreads();
+    // ---- LN2 * u: A[row][:HV] = layer_norm(A[row][:HV]) * Y[row][:HV]
+    for (int row = wave; row < kFusedRows; row += kFusedWaves) {
+      float sm = 0.0f;
+      for (int k = lane; k < HV; k += 64) sm += A[row * AS + k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+      const float mean = sm / (float)HV;
+      float vr = 0.0f;
+      for (int k = lane; k < HV; k += 64) { const float c = A[row * AS + k] - mean; vr = __builtin_fmaf(c, c, vr); }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) vr += __shfl_xor(vr, o, 64);
+      const float rstd = 1.0f / sqrtf(vr / (float)HV + a.eps);
+      for (int k = lane; k < HV; k += 64) A[row * AS + k] = (A[row * AS + k] - mean) * rstd * Y[row * YS + k];
+    }
+    __syncthreads();
+    // ---- GEMM o: X = A[:, :HV] Wo^T + bo + X, rows >= len zero
+    for (int t = wave; t < 2 * (D / 32); t += kFusedWaves) {
+      const int mt = t / (D / 32), nt = t - mt * (D / 32);
+      hf32x16 acc = {0};
+      for (int k0 = 0; k0 < HV; k0 += 64) {
+        float bw[32];
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+          const int k = k0 + 2 * s + h;
+          bw[s] = L.o_w[(int64_t)(nt * 32 + x) * HV + (k < HV ? k : HV - 1)];
+        }
+#pragma unroll
+        for (int s = 0; s < 32; ++s)
+          if (k0 + 2 * s < HV) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[(mt * 32 + x) * AS + k0 + 2 * s + h], bw[s], acc, 0, 0, 0);
+      }
+      const float bias = L.o_b[nt * 32 + x];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + acc_row(r, h);
+        const float v = acc[r] + bias + X[row * XS + nt * 32 + x];
+        X[row * XS + nt * 32 + x] = row < len && row < N ? v : 0.0f;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- postprocessor on row len - 1
+  if (wave == 0) {
+    const int row = (int)len - 1;
+    if (a.mode == 0) {
+      float sm = 0.0f;
+      for (int k = lane; k < D; k += 64) sm += X[row * XS + k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o, 64);
+      const float mean = sm / (float)D;
+      float vr = 0.0f;
+      for (int k = lane; k < D; k += 64) { const float c = X[row * XS + k] - mean; vr = __builtin_fmaf(c, c, vr); }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) vr += __shfl_xor(vr, o, 64);
+      const float rstd = 1.0f / sqrtf(vr / (float)D + a.eps);
+      for (int k = lane; k < D; k += 64) a.out[(int64_t)b * D + k] = (X[row * XS + k] - mean) * rstd;
+    } else {
+      float vr = 0.0f;
+      for (int k = lane; k < D; k += 64) vr = __builtin_fmaf(X[row * XS + k], X[row * XS + k], vr);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) vr += __shfl_xor(vr, o, 64);
+      const float nrm = fmaxf(sqrtf(vr), a.eps);
+      for (int k = lane; k < D; k += 64) a.out[(int64_t)b * D + k] = X[row * XS + k] / nrm;
+    }
+  }
+}
+
+// 1 if the fused kernel handles this geometry
+bool hstu_fused_supported(int N, int D, int H, int dqk, int dv, int num_buckets) {
+  const int HV = H * dv, W = 2 * H * (dv + dqk);
+  if (N < 1 || N > kFusedRows || D % 32 != 0 || D > 128 || HV % 32 != 0 || HV > 128 || W % 32 != 0 || W > 512) return false;
+  if (dqk > 32 || dv > 32 || num_buckets > 128) return false;
+  const int XS = D + 1, AS = (HV > D ? HV : D) + 1, YS = W + 1;
+  const size_t lds = sizeof(float) * ((size_t)kFusedRows * (XS + AS + YS) + 2 * kFusedRows + 132) + (size_t)kFusedRows * kFusedRows;
+  return lds <= 150 * 1024;
+}
+
+int hstu_encode_fused(const float* emb, const int64_t* ids, const int64_t* lengths, const unsigned char* buckets, const float* pos_emb,
+                      const void* layers, int n_blocks, int B, int N, int D, int H, int dqk, int dv, int num_buckets, int mode,
+                      float eps, float* out, hipStream_t stream) {
+  if (B == 0) return kOk;
+  if (!hstu_fused_supported(N, D, H, dqk, dv, num_buckets)) { set_error("hstu_encode_fused: geometry not supported"); return kErrUnsupported; }
+  const int HV = H * dv, W = 2 * H * (dv + dqk);
+  const int XS = D + 1, AS = (HV > D ? HV : D) + 1, YS = W + 1;
+  const size_t lds = sizeof(float) * ((size_t)kFusedRows * (XS + AS + YS) + 2 * kFusedRows + 132) + (size_t)kFusedRows * kFusedRows;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hstu_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
+      return kErrLaunch;
+    attr = true;
+  }
+  FusedArgs a{emb, ids, lengths, buckets, pos_emb, static_cast<const FusedLayer*>(layers), n_blocks, B, N, D, H, dqk, dv, num_buckets, mode, eps, out};
+  hipLaunchKernelGGL(hstu_fused_kernel, dim3(B), dim3(kFusedThreads), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
 int hstu_preprocess(const float* emb, const int64_t* ids, const int64_t* lengths, const float* pos_emb, int B, int N, int D,

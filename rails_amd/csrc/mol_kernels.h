@@ -84,6 +84,10 @@ int hstu_time_buckets(const int64_t* timestamps, int B, int N, const int64_t* th
 int hstu_attention(const float* uvqk, int64_t ld, int B, int N, int H, int dqk, int dv, const int64_t* lengths,
                    const unsigned char* buckets, const float* ts_w, const float* pos_w, int num_buckets, float* out,
                    hipStream_t stream);
+bool hstu_fused_supported(int N, int D, int H, int dqk, int dv, int num_buckets);
+int hstu_encode_fused(const float* emb, const int64_t* ids, const int64_t* lengths, const unsigned char* buckets, const float* pos_emb,
+                      const void* layers, int n_blocks, int B, int N, int D, int H, int dqk, int dv, int num_buckets, int mode,
+                      float eps, float* out, hipStream_t stream);
 int select_keys(const unsigned long long* keys, int rows, int keys_per_row, int k, float* out_scores, int64_t* out_pos,
                 hipStream_t stream);
 int coarse_score(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, float* scores, int64_t ld,

@@ -114,6 +114,8 @@ class HSTU(torch.nn.Module):
         self._input_features_preproc = _PositionalPreproc(self._seq, embedding_dim)
         self._hstu = _Stack([_Layer(embedding_dim, linear_dim, attention_dim, num_heads, self._seq, num_buckets, enable_relative_attention_bias)
                              for _ in range(num_blocks)])
+        self.use_fused_kernel = True    # short sequences: the whole encoder in one launch (falls back when it does not fit)
+        self._fused_ptrs = None
         self.register_buffer("_attn_mask", torch.triu(torch.ones((self._seq, self._seq), dtype=torch.bool), diagonal=1))
         self.register_buffer("_bucket_thresholds", _bucket_thresholds(num_buckets), persistent=False)
 
@@ -133,10 +135,65 @@ class HSTU(torch.nn.Module):
         """(B, D): the postprocessed embedding at position past_lengths - 1 (hstu.py:741-803)."""
         if delta_x_offsets is not None or cache is not None or return_cache_states:
             raise NotImplementedError("the cached / incremental decoding path is not built")
+        if self.use_fused_kernel:
+            out = self._encode_fused(past_lengths, past_ids, past_embeddings, past_payloads)
+            if out is not None:
+                return out
         x = self._run_layers(past_lengths, past_ids, past_embeddings, past_payloads)
         B, N, D = x.shape
         rows = torch.arange(B, device=x.device, dtype=torch.int64) * N + (past_lengths.to(torch.int64) - 1)
         return self._normalize(x.view(B * N, D), rows)
+
+    def _encode_fused(self, past_lengths, past_ids, past_embeddings, past_payloads) -> Optional[torch.Tensor]:
+        """Single-launch encoder for short sequences (rails_hstu_encode_fused): one workgroup per sequence, everything in LDS.
+        None when the geometry does not fit (the per-layer kernels then run)."""
+        if self.training:
+            raise NotImplementedError("rails_amd.HSTU is eval-only: call .eval()")
+        if not past_embeddings.is_cuda:
+            raise RuntimeError("rails_amd.HSTU runs on the GPU only (no CPU fallback)")
+        lib = _lib.load()
+        B, N = past_ids.shape
+        D, H, dqk, dv = self._embedding_dim, self._num_heads, self._dqk, self._dv
+        layers = list(self._hstu._attention_layers)
+        if N != self._seq or past_embeddings.shape != (B, N, D) or self._linear_activation != "silu":
+            return None
+        if not lib.rails_hstu_fused_supported(N, D, H, dqk, dv, self._num_buckets):
+            return None
+        dev = past_embeddings.device
+        ts = past_payloads.get(TIMESTAMPS_KEY) if past_payloads else None
+        has_bias = ts is not None and all(l._rel_attn_bias is not None for l in layers)
+        if ts is not None and not has_bias and any(l._rel_attn_bias is not None for l in layers):
+            return None        # mixed bias / no-bias layers: leave to the general path
+        tensors = []           # keep fp32 contiguous views alive until the launch is enqueued
+        rows = []
+        for l in layers:
+            ptrs = []
+            for t in (l._uvqk, l._o.weight, l._o.bias) + ((l._rel_attn_bias._ts_w, l._rel_attn_bias._pos_w) if has_bias else ()):
+                t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+                tensors.append(t)
+                ptrs.append(t.data_ptr())
+            rows.append(ptrs + [0] * (5 - len(ptrs)))
+        key = tuple(p for r in rows for p in r)
+        if self._fused_ptrs is None or self._fused_ptrs[0] != key:
+            self._fused_ptrs = (key, torch.tensor(rows, dtype=torch.int64).to(dev))
+        ltab = self._fused_ptrs[1]
+        lengths = past_lengths.to(device=dev, dtype=torch.int64).contiguous()
+        ids = past_ids.to(device=dev, dtype=torch.int64).contiguous()
+        emb = past_embeddings.detach().to(dtype=torch.float32).contiguous()
+        pos = self._input_features_preproc._pos_emb.weight.detach().to(device=dev, dtype=torch.float32).contiguous()
+        out = torch.empty((B, D), dtype=torch.float32, device=dev)
+        with _on_device(dev):
+            st = _stream()
+            buckets = None
+            if has_bias:
+                ts = ts.to(device=dev, dtype=torch.int64).contiguous()
+                buckets = torch.empty((B, N, N), dtype=torch.uint8, device=dev)
+                _lib.check(lib.rails_hstu_time_buckets(_ptr(ts), B, N, _ptr(self._bucket_thresholds.to(dev)), self._num_buckets, _ptr(buckets), st),
+                           "rails_hstu_time_buckets")
+            _lib.check(lib.rails_hstu_encode_fused(_ptr(emb), _ptr(ids), _ptr(lengths), _ptr(buckets) if has_bias else None, _ptr(pos), _ptr(ltab),
+                                                   len(layers), B, N, D, H, dqk, dv, self._num_buckets, 0 if self._postproc == "layer_norm" else 1,
+                                                   C.c_float(self._eps), _ptr(out), st), "rails_hstu_encode_fused")
+        return out
 
     # ---- HIP path ------------------------------------------------------------------------------------------------
     def _normalize(self, x2d: torch.Tensor, rows: Optional[torch.Tensor]) -> torch.Tensor:

@@ -96,6 +96,17 @@ def test_hip_encoder_matches_the_reference(name):
     # determinism
     with torch.inference_mode():
         assert torch.equal(cur, m.encode(lengths, ids, emb, {"timestamps": ts}))
+    # the two implementations of encode (single-launch kernel for seq_len <= 64, per-layer kernels) against each other
+    from rails_amd import _lib
+    fits = bool(_lib.load().rails_hstu_fused_supported(cfg.max_sequence_len, cfg.embedding_dim, cfg.num_heads, cfg.attention_dim, cfg.linear_dim, 128))
+    assert fits == (name == "amzn-books")   # ML-1M: D = 50 is not a multiple of 32; the ML-20M fixture: D = 256 does not fit LDS
+    with torch.inference_mode():
+        m.use_fused_kernel = False
+        per_layer = m.encode(lengths, ids, emb, {"timestamps": ts})
+        per_layer_nots = m.encode(lengths, ids, emb, {})
+    assert float((per_layer.cpu() - torch.from_numpy(d["out/current_embeddings"])).abs().max()) <= TOL
+    assert float((per_layer_nots.cpu() - torch.from_numpy(d["out/current_embeddings_no_timestamps"])).abs().max()) <= TOL
+    assert float((per_layer - cur).abs().max()) <= TOL
 
 
 @pytest.mark.gpu
