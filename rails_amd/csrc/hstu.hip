@@ -353,6 +353,12 @@ __device__ __forceinline__ void fused_layer_norm_rows(const float* src, int ss, 
   }
 }
 
+// silu on the hardware transcendentals (v_exp_f32 = 2^x, v_rcp_f32; ~1 ulp each) instead of expf + an IEEE division:
+// with four waves per SIMD the attention phase was VALU-bound on ~50 instructions per element.
+__device__ __forceinline__ float silu_fast(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
+
 __global__ __launch_bounds__(kFusedThreads) void hstu_fused_kernel(FusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float fsm[];
   const int N = a.N, D = a.D, H = a.H, dqk = a.dqk, dv = a.dv;
@@ -414,9 +420,7 @@ __global__ __launch_bounds__(kFusedThreads) void hstu_fused_kernel(FusedArgs a) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = mt * 32 + acc_row(r, h);
-        float v = acc[r];
-        v = v / (1.0f + expf(-v));
-        Y[row * YS + nt * 32 + x] = row < len && row < N ? v : 0.0f;
+        Y[row * YS + nt * 32 + x] = row < len && row < N ? silu_fast(acc[r]) : 0.0f;
       }
     }
     __syncthreads();
@@ -439,16 +443,19 @@ __global__ __launch_bounds__(kFusedThreads) void hstu_fused_kernel(FusedArgs a) 
           const float qb = d < dqk ? Qc[qi * YS + d] : 0.0f;
           S = __builtin_amdgcn_mfma_f32_32x32x2f32(ka, qb, S, 0, 0, 0);
         }
+        float pv[16], va[16];      // all 16 probabilities / V operands first (independent LDS lookups overlap), then the MFMAs
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = j0 + acc_row(r, h);
           float sc = S[r];
           if (biased && j < N && qi < N) sc += pos_s[N - 1 + j - qi] + tsw_s[bk_s[j * N + qi]];
-          float pv = sc / (1.0f + expf(-sc)) * inv_n;
-          if (j > qi || j >= N || qi >= N) pv = 0.0f;
-          const float va = x < dv ? Vc[j * YS + x] : 0.0f;      // rows >= N of Y are zero
-          O = __builtin_amdgcn_mfma_f32_32x32x2f32(va, pv, O, 0, 0, 0);
+          float p = silu_fast(sc) * inv_n;
+          if (j > qi || j >= N || qi >= N) p = 0.0f;
+          pv[r] = p;
+          va[r] = x < dv ? Vc[j * YS + x] : 0.0f;               // rows >= N of Y are zero
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O = __builtin_amdgcn_mfma_f32_32x32x2f32(va[r], pv[r], O, 0, 0, 0);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
