@@ -31,6 +31,12 @@ namespace mol {
 
 typedef float hf32x16 __attribute__((ext_vector_type(16)));
 
+// silu on the hardware transcendentals (v_exp_f32 = 2^x, v_rcp_f32; ~1 ulp each) instead of expf + an IEEE division (~50
+// instructions per element: the attention kernels were VALU-bound on it); the scoring kernel does the same.
+__device__ __forceinline__ float silu_fast(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+}
+
 __global__ void hstu_preprocess_kernel(const float* __restrict__ emb, const int64_t* __restrict__ ids,
                                        const int64_t* __restrict__ lengths, const float* __restrict__ pos_emb, int B, int N,
                                        int D, float scale, float* __restrict__ out) {
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const int64_t m = m0 + acc_row(r, h);
     if (m >= g.M) continue;
     float v = acc[r] + bias;
-    if (g.act == 1) v = v / (1.0f + expf(-v));
+    if (g.act == 1) v = silu_fast(v);
     if (g.residual) v += g.residual[m * g.ldr + n];
     if (g.lengths) {
       const int64_t b = m / g.seq_len;
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(64) void hstu_attention_kernel(AttnArgs a) {
       const int j = j0 + acc_row(r, h);               // this lane's key for register r
       float sc = S[r];
       if (biased && j < N) sc += pos_s[N - 1 + j - qi] + tsw_s[bk[r]];
-      float pv = sc / (1.0f + expf(-sc)) * inv_n;
+      float pv = silu_fast(sc) * inv_n;
       if (j > qi || j >= N || i0 + x >= N) pv = 0.0f;
       O = __builtin_amdgcn_mfma_f32_32x32x2f32(va[r], pv, O, 0, 0, 0);
     }
@@ -351,12 +357,6 @@ __device__ __forceinline__ void fused_layer_norm_rows(const float* src, int ss, 
     if (mul) y *= mul[row * ms + k];
     dst[row * ds + k] = y;
   }
-}
-
-// silu on the hardware transcendentals (v_exp_f32 = 2^x, v_rcp_f32; ~1 ulp each) instead of expf + an IEEE division:
-// with four waves per SIMD the attention phase was VALU-bound on ~50 instructions per element.
-__device__ __forceinline__ float silu_fast(float v) {
-  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
 }
 
 __global__ __launch_bounds__(kFusedThreads) void hstu_fused_kernel(FusedArgs a) {
