@@ -810,7 +810,7 @@ __global__ void pack_candidates_kernel(const float* __restrict__ scores, const i
 // Each rank's list arrives sorted (it is that rank's top-k), so no sort is needed: a key's rank in the merged order is
 // the number of larger keys, = its index in its own list + one binary search in each other list (keys are distinct, so
 // ranks are a permutation); keys of rank < k_out are written straight to their slot.  One barrier instead of the
-// ~70 of a 2048-key bitonic sort (21 us -> ~6 us at R = 8, k = 200).  Unsorted input (not produced by this library, but
+// ~70 of a 2048-key bitonic sort (21 us -> 12 us at R = 8, k = 200).  Unsorted input (not produced by this library, but
 // legal for the C entry point) is detected and takes the bitonic sort.
 __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(const int64_t* __restrict__ gathered, int R, int rows,
                                                                        int k, int k_out, int npad,
