@@ -181,6 +181,9 @@ class _ComponentCandidates:
         n = table.shape[0]
         if k_per_group > n:
             raise RuntimeError(f"selected index k out of range (k={k_per_group}, n={n})")
+        # the component scan keeps the fragments of all B * P_Q query rows in LDS: batches beyond 64 queries go in slices
+        if eq.shape[0] > 64:
+            return torch.cat([self._component_topk(eq[b0 : b0 + 64], k_per_group) for b0 in range(0, eq.shape[0], 64)], dim=0)
         # large corpora: fused scan + threshold select, no (B*P_Q*P_X, N) score matrix (5.7 GB at amzn-books, B = 32);
         # identical to the materialising path below whenever every row's candidate count is inside [k, capacity]
         if n >= getattr(self, "fused_component_min_items", 262144):

@@ -367,6 +367,26 @@ def test_fused_component_topk_equals_the_materialised_path(dev, cfg_name, n, k_g
             assert torch.equal(s1, s2) and torch.equal(i1, i2)
 
 
+def test_large_batches_through_every_algorithm(dev):
+    """B = 200 queries (the eval default is 32): nothing may depend on the batch fitting one LDS-resident query block."""
+    cfg = O.CONFIGS["amzn-books"]
+    mol = build_module(cfg, O.synthetic_weights(cfg, seed=2), dev)
+    n, B = 270_000, 200
+    X = torch.from_numpy(O.hash_item_table(5, 0, n, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B, seed=4).to(dev)
+    model = type("M", (), {"_ndp_module": mol})()
+    with torch.inference_mode():
+        ref_s, ref_i = rails_amd.get_top_k_module("MoLBruteForceTopK", model, X, ids)(q, k=50)
+        for name in ("MoLAvgTopK500", "MoLNaiveTopK10", "MoLCombTopK5_200"):
+            mod = rails_amd.get_top_k_module(name, model, X, ids)
+            s, i = mod(q, k=50)
+            s32, i32 = mod(q[:32], k=50)
+            assert s.shape[0] == B and torch.equal(s[:32], s32) and torch.equal(i[:32], i32)   # batch slicing changes nothing
+        s, i = rails_amd.get_top_k_module("MoLBruteForceTopK", model, X, ids)(q[:32], k=50)
+        assert torch.equal(ref_i[:32], i) and torch.equal(ref_s[:32], s)
+
+
 def test_sharded_two_pass_composition_on_the_gpu(dev):
     """BASELINE config 5's per-rank work with the HIP kernels: MoLAvgTopK on each of R = 2 contiguous shards, the pack and
     merge kernels around the (here: emulated) all-gather.  Must equal the top-k of the union of the shards' results, and
