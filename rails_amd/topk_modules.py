@@ -129,6 +129,8 @@ class MoLAvgTopK(MoLTopKModule):
         n = table.shape[0]
         if self._avg_top_k > n:
             raise RuntimeError(f"selected index k out of range (k={self._avg_top_k}, n={n})")
+        if eq.shape[0] > 128:   # the scan keeps ceil(B / 32) query tiles in LDS: larger batches go in slices
+            return torch.cat([self._coarse_topk_from_eq(eq[b0 : b0 + 128], average_queries) for b0 in range(0, eq.shape[0], 128)], dim=0)
         # large corpora: fused scan + threshold select, no (B, N) score matrix (16 GB per 125 M-item shard at B = 32).
         # Same scores and the same exact top-K' as the materialising path below -- when every query's candidate count
         # landed inside [K', capacity]; the check costs one 128-byte device-to-host copy.

@@ -368,10 +368,10 @@ def test_fused_component_topk_equals_the_materialised_path(dev, cfg_name, n, k_g
 
 
 def test_large_batches_through_every_algorithm(dev):
-    """B = 200 queries (the eval default is 32): nothing may depend on the batch fitting one LDS-resident query block."""
+    """B = 300 queries (the eval default is 32): nothing may depend on the batch fitting one LDS-resident query block."""
     cfg = O.CONFIGS["amzn-books"]
     mol = build_module(cfg, O.synthetic_weights(cfg, seed=2), dev)
-    n, B = 270_000, 200
+    n, B = 270_000, 300
     X = torch.from_numpy(O.hash_item_table(5, 0, n, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
     ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
     q = O.synthetic_queries(cfg, B, seed=4).to(dev)
