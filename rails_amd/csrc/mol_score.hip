@@ -759,9 +759,14 @@ __global__ __launch_bounds__(256, 1) void mol_score_ksplit_kernel(ScoreArgs p) {
   // first few CUs (ML-20M: 6824 units on 1024 SIMDs, worst SIMD 7 passes instead of 8; ML-1M: all 256 CUs busy).
   const int64_t stride = (int64_t)gridDim.x * NW;
   const int64_t rounds = n_units / stride;
+  // XCD-aware numbering: hardware workgroup b runs on XCD b % 8 (each XCD has its own L2).  A tile's 16 query groups are
+  // 4 consecutive workgroups' worth of units; with the hardware numbering those land on 4 different XCDs and the tile is
+  // fetched from HBM into 4 L2s (PMC: 9 x the index bytes).  Logical id = (b % 8) * (grid / 8) + b / 8 keeps consecutive
+  // logical workgroups on one XCD.
+  const int64_t bx = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
   for (int64_t it = 0; it <= rounds; ++it) {
-    const int64_t u = it < rounds ? it * stride + (int64_t)blockIdx.x * NW + wave
-                                  : rounds * stride + (int64_t)wave * gridDim.x + blockIdx.x;
+    const int64_t u = it < rounds ? it * stride + bx * NW + wave
+                                  : rounds * stride + (int64_t)wave * gridDim.x + bx;
     if (u >= n_units) break;
     const int64_t outer = u / inner;
     const int innr = (int)(u - outer * inner);
