@@ -810,19 +810,29 @@ __global__ __launch_bounds__(256, 1) void mol_score_ksplit_kernel(ScoreArgs p) {
 #pragma unroll
       for (int q = 0; q < G::QT; ++q) {
         {
+          // W1 fragments of K-step group es + 1 are read (LDS) before group es's 16 MFMAs: with one wave per SIMD the
+          // ~150-cycle ds_read latency ahead of every group was exposed.  Exactly one group ahead (16 VGPRs).
+          float4 wa[G::TH], wn[G::TH];
+#pragma unroll
+          for (int t = 0; t < G::TH; ++t) wa[t] = sW1[((c * (ECH / 4)) * G::TH + t) * 64 + lane];
 #pragma unroll
           for (int es = 0; es < ECH / 4; ++es) {
+            if (es + 1 < ECH / 4) {
+#pragma unroll
+              for (int t = 0; t < G::TH; ++t) wn[t] = sW1[((c * (ECH / 4) + es + 1) * G::TH + t) * 64 + lane];
+            }
+            asm volatile("" ::: "memory");  // keep later K-steps' LDS reads below these MFMAs (register pressure)
 #pragma unroll
             for (int t = 0; t < G::TH; ++t) {
-              const float4 a = sW1[((c * (ECH / 4) + es) * G::TH + t) * 64 + lane];
-              const float av[4] = {a.x, a.y, a.z, a.w};
+              const float av[4] = {wa[t].x, wa[t].y, wa[t].z, wa[t].w};
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
                 const int e = es * 4 + j;
                 D2[q][t] = mfma32(av[j], D1c[e / G::RPQ][q * G::RPQ + e % G::RPQ], D2[q][t]);
               }
             }
-            asm volatile("" ::: "memory");  // keep later K-steps' LDS reads below these MFMAs (register pressure)
+#pragma unroll
+            for (int t = 0; t < G::TH; ++t) wa[t] = wn[t];
           }
         }
       }
