@@ -9,13 +9,17 @@
 // then position ascending" -- the deterministic tie rule that makes 1/2/4/8-GPU results identical.
 //
 //   n <= 1024   one workgroup per row bitonic-sorts the whole row in LDS (also n <= 16384 with k > 4096).
-//   n <= 49152  one workgroup per row holds the row in registers (<= 48 scores per thread), finds the k-th largest score
-//               by a 2-bits-per-step radix bisection (ballot counts, no atomics), compacts the k keys into LDS
-//               (ties by position, in order) and sorts them: one launch instead of nine.
-//   larger n    MSB-first radix select over the 32 score bits (11/11/10, LDS histograms) finds the k-th largest
+//   n <= 49152  (k <= 4096) row_select_kernel: one workgroup per row holds the row in registers (<= 48 scores per thread).
+//               k <= 512: a lower bound on the k-th score from the per-thread maxima (4 bits per step, per-lane LDS
+//               counters), compaction of the ~220 survivors, counting-rank emit.  Otherwise / on overflow (heavy ties):
+//               radix bisection of the k-th key, 2 bits per step, over the score bits and -- for a tied k-th score -- on
+//               over the position bits.  One launch.
+//   n <= ~4.5 M (k <= 512) two launches: row_select_kernel per (row, chunk <= 49152) writes each chunk's k winners as keys,
+//               a second row_select_kernel selects among the chunks * k <= 24576 keys.  Reads the scores once.
+//   otherwise   MSB-first radix select over the 32 score bits (11/11/10, LDS histograms) finds the k-th largest
 //               score; if that score is tied, one in-order scan of the row finds the position of the last tied
 //               element to take, which completes the 64-bit threshold key T; one compaction pass gathers the
-//               exactly-k keys >= T; the LDS bitonic sort orders them.
+//               exactly-k keys >= T; the LDS sort orders them.  Reads the scores five times.
 // (Measured and dropped: LDS-sorting 16K-element chunks and merging their top-k -- a 16K-key bitonic sort costs ~150 us,
 //  more than the whole radix path; and folding the bin pick into the histogram kernel with arrival tickets + fences.)
 #include <hip/hip_runtime.h>
