@@ -168,6 +168,16 @@ def main() -> None:
                          "brute force (the default, and the only mode the headline metric is quoted on)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher -- one rank per GPU under torch.distributed.run, same argv
+        import socket
+
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]])
+
     from oracle import mol_oracle as O  # inputs generator + cpu_baseline checker only
 
     rank = int(os.environ.get("RANK", "0"))

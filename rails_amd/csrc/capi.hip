@@ -18,6 +18,7 @@ void set_error(const char* fmt, ...) {
 }
 
 static int fail(int code, const char* what) {
+  if (code == kOk) return code;
   if (code == kErrLaunch) {
     const hipError_t e = hipGetLastError();
     set_error("%s: HIP launch failed (%s)", what, hipGetErrorString(e));

@@ -539,12 +539,8 @@ int hstu_encode_fused(const float* emb, const int64_t* ids, const int64_t* lengt
   const int HV = H * dv, W = 2 * H * (dv + dqk);
   const int XS = D + 1, AS = (HV > D ? HV : D) + 1, YS = W + 1;
   const size_t lds = sizeof(float) * ((size_t)kFusedRows * (XS + AS + YS) + 2 * kFusedRows + 132) + (size_t)kFusedRows * kFusedRows;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&hstu_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess)
-      return kErrLaunch;
-    attr = true;
-  }
+  static DynLdsOnce once;
+  if (ensure_dyn_lds(once, reinterpret_cast<const void*>(&hstu_fused_kernel), 150 * 1024) != kOk) return kErrLaunch;
   FusedArgs a{emb, ids, lengths, buckets, pos_emb, static_cast<const FusedLayer*>(layers), n_blocks, B, N, D, H, dqk, dv, num_buckets, mode, eps, out};
   hipLaunchKernelGGL(hstu_fused_kernel, dim3(B), dim3(kFusedThreads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/rails_amd.h"
 
 namespace mol {
@@ -50,6 +52,19 @@ struct SplitScales { float cl_scale, w1_scale, w2_scale; };
 int pack_gate_weights_split(const Shape& s, const Weights& w, const SplitScales& sc, float* wpack, hipStream_t stream);
 
 void set_error(const char* fmt, ...);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute and the Python layer drives several devices from
+// one process: remember the opt-in per (call site, device).  Two threads racing on the first call both set it (idempotent).
+struct DynLdsOnce { std::atomic<unsigned long long> mask{0}; };
+inline int ensure_dyn_lds(DynLdsOnce& once, const void* fn, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return kErrLaunch;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (once.mask.load(std::memory_order_acquire) & bit) return kOk;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return kErrLaunch;
+  once.mask.fetch_or(bit, std::memory_order_release);
+  return kOk;
+}
 
 int score_launch(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream);
 bool score_supported(const Shape& s);

@@ -916,13 +916,8 @@ static int launch_ksplit(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using G = Geo<PQ, PX, DD, H>;
   constexpr size_t lds = ((size_t)G::kW1Floats + H + G::L + 4 * G::QT * G::L) * sizeof(float);   // + per-wave gq rows
   static_assert(lds <= 160 * 1024, "W1 fragments must fit LDS");
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mol_score_ksplit_kernel<PQ, PX, DD, H, MC>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return kErrLaunch;
-    attr_set = true;
-  }
+  static DynLdsOnce once;
+  if (ensure_dyn_lds(once, reinterpret_cast<const void*>(&mol_score_ksplit_kernel<PQ, PX, DD, H, MC>), (int)lds) != kOk) return kErrLaunch;
   const int64_t n_units = a.per_row ? (int64_t)a.B * a.n_tiles : a.n_tiles * a.n_groups;
   int64_t grid = (n_units + 3) / 4;
   if (grid > n_cu) grid = n_cu;
@@ -948,11 +943,8 @@ static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   } else {
     const void* fn = STAGED ? reinterpret_cast<const void*>(&mol_score_staged_kernel<PQ, PX, DD, H, NW, SPLIT>)
                             : reinterpret_cast<const void*>(&mol_score_direct_kernel<PQ, PX, DD, H, NW, SPLIT>);
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return kErrLaunch;
-      attr_set = true;
-    }
+    static DynLdsOnce once;
+    if (ensure_dyn_lds(once, fn, (int)lds) != kOk) return kErrLaunch;
     const int wg_per_cu = (NW == 4 && lds <= 80 * 1024) ? 2 : 1;
     int64_t grid;
     if (STAGED) {
@@ -980,13 +972,8 @@ static int launch_staged1(const ScoreArgs& a, int n_cu, hipStream_t stream) {
     set_error("single-buffer staged scoring kernel needs %zu B of LDS", lds);
     return kErrUnsupported;
   } else {
-    static bool attr_set = false;
-    if (!attr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mol_score_staged1_kernel<PQ, PX, DD, H, NW, SPLIT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return kErrLaunch;
-      attr_set = true;
-    }
+    static DynLdsOnce once;
+    if (ensure_dyn_lds(once, reinterpret_cast<const void*>(&mol_score_staged1_kernel<PQ, PX, DD, H, NW, SPLIT>), (int)lds) != kOk) return kErrLaunch;
     if (a.n_tiles < 1) return kOk;
     // always a full grid: the leftover-round split needs the idle workgroups (they exit at once otherwise)
     hipLaunchKernelGGL((mol_score_staged1_kernel<PQ, PX, DD, H, NW, SPLIT>), dim3((unsigned)n_cu), dim3(NW * 64), lds, stream, a);

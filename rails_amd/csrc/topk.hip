@@ -631,13 +631,8 @@ size_t topk_workspace_bytes(int rows, int64_t n, int k) {
 }
 
 static int ensure_sort_lds() {
-  static bool done = false;
-  if (done) return kOk;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_emit_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          kSortCap * (int)sizeof(unsigned long long)) != hipSuccess)
-    return kErrLaunch;
-  done = true;
-  return kOk;
+  static DynLdsOnce once;
+  return ensure_dyn_lds(once, reinterpret_cast<const void*>(&sort_emit_kernel), kSortCap * (int)sizeof(unsigned long long));
 }
 
 int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int64_t* ids, int64_t ids_row_stride,
@@ -893,13 +888,9 @@ int merge_candidates(const int64_t* gathered, int R, int rows, int k, int k_out,
   const int64_t count = (int64_t)R * k;
   if (count > kSortCap) { set_error("merge_candidates: R*k = %lld exceeds the in-LDS sort capacity (%d)", (long long)count, kSortCap); return kErrUnsupported; }
   if (ensure_sort_lds() != kOk) return kErrLaunch;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&merge_candidates_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kSortCap * (int)sizeof(unsigned long long)) != hipSuccess)
-      return kErrLaunch;
-    attr = true;
-  }
+  static DynLdsOnce once;
+  if (ensure_dyn_lds(once, reinterpret_cast<const void*>(&merge_candidates_kernel), kSortCap * (int)sizeof(unsigned long long)) != kOk)
+    return kErrLaunch;
   const int npad = next_pow2((int)count < 2 ? 2 : (int)count);
   hipLaunchKernelGGL(merge_candidates_kernel, dim3(rows), dim3(kSortThreads), npad * sizeof(unsigned long long), stream, gathered, R,
                      rows, k, k_out, npad, out_scores, out_ids);
@@ -942,13 +933,9 @@ __global__ void mask_sorted_duplicates_kernel(const int64_t* __restrict__ idx, f
 int sort_rows_i64(const int64_t* in, int rows, int n, int64_t* out, hipStream_t stream) {
   if (rows <= 0 || n <= 0) return kOk;
   if (n > kSortCap) { set_error("sort_rows_i64: n = %d exceeds the in-LDS sort capacity (%d)", n, kSortCap); return kErrUnsupported; }
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_rows_i64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kSortCap * (int)sizeof(unsigned long long)) != hipSuccess)
-      return kErrLaunch;
-    attr = true;
-  }
+  static DynLdsOnce once;
+  if (ensure_dyn_lds(once, reinterpret_cast<const void*>(&sort_rows_i64_kernel), kSortCap * (int)sizeof(unsigned long long)) != kOk)
+    return kErrLaunch;
   const int npad = next_pow2(n < 2 ? 2 : n);
   hipLaunchKernelGGL(sort_rows_i64_kernel, dim3(rows), dim3(kSortThreads), npad * sizeof(unsigned long long), stream, in, n, npad, out);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;

@@ -270,6 +270,9 @@ class MolEngine:
             if user_ids is None:
                 raise KeyError("user_ids")  # the reference does kwargs["user_ids"] (query_embeddings_fns.py:206)
             uid = user_ids.to(device=q.device, dtype=torch.int64).contiguous()
+            if uid.numel() != B:
+                # the reference fails in torch.cat on the same mismatch (query_embeddings_fns.py:206-216)
+                raise RuntimeError(f"Sizes of tensors must match: user_ids has {tuple(uid.shape)} for a batch of {B} queries")
         n = self.lib.rails_mol_query_pack_floats(C.byref(self.shape), B)
         pack = out if out is not None and out.numel() == n and out.device == q.device else torch.empty(n, dtype=torch.float32, device=q.device)
         s = self.spec

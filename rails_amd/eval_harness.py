@@ -101,13 +101,19 @@ def eval_metrics_v2_from_tensors(
     num_batches = (q.size(0) + user_max_batch_size - 1) // user_max_batch_size
     ids_all, prs_all, eval_time_all = [], [], []
 
+    n_rows = q.size(0)
+
     def call(mb: int):
         sl = slice(mb * user_max_batch_size, (mb + 1) * user_max_batch_size)
+        # per-row payloads (user_ids, ...) travel with their rows; the reference passes them unsliced, which only works
+        # when there is a single mini-batch (data/eval.py:143-152)
+        payloads = {key: (v[sl] if torch.is_tensor(v) and v.dim() >= 1 and v.size(0) == n_rows else v)
+                    for key, v in seq_features.past_payloads.items()}
         return eval_state.candidate_index.get_top_k_outputs(
             query_embeddings=q[sl, ...],
             top_k_module=eval_state.top_k_module,
             k=k,
-            aux_payloads=seq_features.past_payloads,
+            aux_payloads=payloads,
             invalid_ids=seq_features.past_ids[sl, :] if filter_invalid_ids else None,
             return_embeddings=False,
             truncate_k_prime_to=truncate_k_prime_to,

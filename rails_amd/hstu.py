@@ -126,7 +126,7 @@ class HSTU(torch.nn.Module):
     def forward(self, past_lengths, past_ids, past_embeddings, past_payloads: Dict[str, torch.Tensor], batch_id=None) -> torch.Tensor:
         """(B, N, D) postprocessed sequence embeddings (hstu.py:711-739); rows at positions >= length are zero rows
         normalised, exactly as the reference's zero-padded output."""
-        x = self._run_layers(past_lengths, past_ids, past_embeddings, past_payloads)
+        x = self._run_layers(past_lengths, past_ids, past_embeddings, past_payloads, min_len=0)
         B, N, D = x.shape
         return self._normalize(x.view(B * N, D), None).view(B, N, D)
 
@@ -141,7 +141,7 @@ class HSTU(torch.nn.Module):
                 return out
         x = self._run_layers(past_lengths, past_ids, past_embeddings, past_payloads)
         B, N, D = x.shape
-        rows = torch.arange(B, device=x.device, dtype=torch.int64) * N + (past_lengths.to(torch.int64) - 1)
+        rows = torch.arange(B, device=x.device, dtype=torch.int64) * N + (self._lengths(past_lengths, x.device, N) - 1)
         return self._normalize(x.view(B * N, D), rows)
 
     def _encode_fused(self, past_lengths, past_ids, past_embeddings, past_payloads) -> Optional[torch.Tensor]:
@@ -177,7 +177,7 @@ class HSTU(torch.nn.Module):
         if self._fused_ptrs is None or self._fused_ptrs[0] != key:
             self._fused_ptrs = (key, torch.tensor(rows, dtype=torch.int64).to(dev))
         ltab = self._fused_ptrs[1]
-        lengths = past_lengths.to(device=dev, dtype=torch.int64).contiguous()
+        lengths = self._lengths(past_lengths, dev, N)
         ids = past_ids.to(device=dev, dtype=torch.int64).contiguous()
         emb = past_embeddings.detach().to(dtype=torch.float32).contiguous()
         pos = self._input_features_preproc._pos_emb.weight.detach().to(device=dev, dtype=torch.float32).contiguous()
@@ -196,6 +196,13 @@ class HSTU(torch.nn.Module):
         return out
 
     # ---- HIP path ------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _lengths(past_lengths: torch.Tensor, dev, N: int, min_len: int = 1) -> torch.Tensor:
+        """int64 lengths clamped to [min_len, N].  encode() indexes row `length - 1`, so it clamps to [1, N] on both of its
+        paths (the reference has no defined result for an empty history: its flattened gather at offset -1 fails,
+        hstu.py:773-781); forward() keeps 0 (an all-padding sequence is all zero rows, as in the reference)."""
+        return past_lengths.to(device=dev, dtype=torch.int64).clamp(min_len, N).contiguous()
+
     def _normalize(self, x2d: torch.Tensor, rows: Optional[torch.Tensor]) -> torch.Tensor:
         lib = _lib.load()
         n = x2d.shape[0] if rows is None else rows.numel()
@@ -206,7 +213,7 @@ class HSTU(torch.nn.Module):
                        "rails_rows_normalize")
         return out
 
-    def _run_layers(self, past_lengths, past_ids, past_embeddings, past_payloads) -> torch.Tensor:
+    def _run_layers(self, past_lengths, past_ids, past_embeddings, past_payloads, min_len: int = 1) -> torch.Tensor:
         if self.training:
             raise NotImplementedError("rails_amd.HSTU is eval-only: call .eval()")
         if not past_embeddings.is_cuda:
@@ -217,8 +224,15 @@ class HSTU(torch.nn.Module):
         D, H, dqk, dv = self._embedding_dim, self._num_heads, self._dqk, self._dv
         if N != self._seq or past_embeddings.shape != (B, N, D):
             raise ValueError(f"expected past_ids (B, {self._seq}) and past_embeddings (B, {self._seq}, {D})")
-        f32 = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()   # noqa: E731
-        lengths = past_lengths.to(device=dev, dtype=torch.int64).contiguous()
+        keep = []   # fp32 copies of non-fp32 parameters must outlive the launches that read them (the caching allocator
+                    # would otherwise hand the same block to the next conversion before the kernel has run)
+
+        def f32(t):
+            t = t.detach().to(device=dev, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t
+
+        lengths = self._lengths(past_lengths, dev, N, min_len)
         ids = past_ids.to(device=dev, dtype=torch.int64).contiguous()
         ts = past_payloads.get(TIMESTAMPS_KEY) if past_payloads else None
         if ts is not None:

@@ -110,6 +110,51 @@ def test_hip_encoder_matches_the_reference(name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_bf16_module_equals_fp32_module_with_rounded_weights(name):
+    """The reference evaluates with model.to(bfloat16) (eval_from_checkpoint.py:320).  The HIP path upcasts such parameters to
+    fp32 copies per call; the copies must stay alive until the launches that read them are enqueued (a freed copy's block
+    is handed to the next conversion).  A bf16 module must therefore equal, bit for bit, an fp32 module holding the same
+    bf16-rounded values -- on the per-layer path (many conversions per call) and on the fused one."""
+    dev = torch.device("cuda", 0)
+    d, w = load(name)
+    cfg = HO.HSTU_CONFIGS[name]
+    w_rounded = {k: (v.to(torch.bfloat16).float() if v.is_floating_point() else v) for k, v in w.items()}
+    m16 = build(cfg, w, dev).to(torch.bfloat16)
+    m32 = build(cfg, w_rounded, dev)
+    lengths, ids, ts = (torch.from_numpy(d[f"in/{k}"]).to(dev) for k in ("past_lengths", "past_ids", "timestamps"))
+    with torch.inference_mode():
+        emb32 = m32.get_item_embeddings(ids)
+        emb16 = m16.get_item_embeddings(ids)
+        assert torch.equal(emb16.float(), emb32)
+        for fused in (True, False):
+            m16.use_fused_kernel = m32.use_fused_kernel = fused
+            for _ in range(3):   # repeated calls recycle the allocator's blocks
+                a = m16.encode(lengths, ids, emb16, {"timestamps": ts})
+                b = m32.encode(lengths, ids, emb32, {"timestamps": ts})
+                assert torch.equal(a, b), (name, fused, float((a - b).abs().max()))
+
+
+@pytest.mark.gpu
+def test_encode_clamps_out_of_range_lengths():
+    """past_lengths outside [1, N] must not index outside the activation buffer (encode reads row length - 1)."""
+    dev = torch.device("cuda", 0)
+    d, w = load("amzn-books")
+    cfg = HO.HSTU_CONFIGS["amzn-books"]
+    m = build(cfg, w, dev)
+    lengths, ids = (torch.from_numpy(d[f"in/{k}"]).to(dev) for k in ("past_lengths", "past_ids"))
+    bad = lengths.clone()
+    bad[0], bad[1] = 0, cfg.max_sequence_len + 5
+    ok = lengths.clone()
+    ok[0], ok[1] = 1, cfg.max_sequence_len
+    with torch.inference_mode():
+        emb = m.get_item_embeddings(ids)
+        for fused in (True, False):
+            m.use_fused_kernel = fused
+            assert torch.equal(m.encode(bad, ids, emb, {}), m.encode(ok, ids, emb, {}))
+
+
+@pytest.mark.gpu
 def test_hip_encoder_full_width_against_the_oracle():
     """The real ML-1M encoder geometry (8 blocks, 2 heads x 25, N = 211, B = 32): seven key tiles, the dv = 25 padding."""
     dev = torch.device("cuda", 0)

@@ -1,0 +1,104 @@
+"""GPU, two processes: the item-sharded path through the REAL HIP modules and a real process group.
+
+  >= 2 visible devices: one rank per GPU, backend nccl (= RCCL), the all-gather runs on device tensors over xGMI;
+  1 visible device (the gpurun box): both ranks share GPU 0, backend gloo, the 102 KB message is staged through
+    the host by rails_amd/sharded.py -- everything else (local scoring, local top-k, pack, merge) is the same HIP code.
+
+Oracle: the single-process module over the whole corpus, which the sharded result must equal bit for bit
+(rails_amd/sharded.py docstring).  Also runs `python bench.py --gpus 2` the way the driver does (plain python, no launcher).
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, n_items: int, precision, ret):
+    import rails_amd
+    from oracle import mol_oracle as O
+    from rails_amd import engine as E
+    from rails_amd.sharded import ShardedMoLAvgTopK, ShardedMoLBruteForceTopK, shard_bounds
+    from tests.test_gpu_parity import build_module
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    multi = torch.cuda.device_count() >= world
+    dev = torch.device("cuda", rank if multi else 0)
+    torch.cuda.set_device(dev)
+    if multi:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = O.CONFIGS["amzn-books"]
+        mol = build_module(cfg, O.synthetic_weights(cfg, seed=1), dev)
+        mol.precision = precision
+        B, k, avg_k = 9, 200, 300
+        q = O.synthetic_queries(cfg, B, seed=5).to(dev)
+        X = torch.from_numpy(O.hash_item_table(7, 0, n_items, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+        ids = (torch.arange(n_items, dtype=torch.int64, device=dev) * 3 + 1).unsqueeze(0)
+        lo, hi = shard_bounds(n_items, world, rank)
+        with torch.inference_mode():
+            # exact: sharded == single-device brute force, bit for bit, on every rank
+            sh = ShardedMoLBruteForceTopK(mol, X[:, lo:hi], ids[:, lo:hi], n_items)
+            s, i = sh(q, k=k)
+            s2, i2 = sh(q, k=k)   # second call: recycled buffers
+            full_s, full_i = rails_amd.MoLBruteForceTopK(mol, X, ids)(q, k=k)
+            assert torch.equal(s, s2) and torch.equal(i, i2)
+            assert torch.equal(s, full_s) and torch.equal(i, full_i), "sharded exact top-k differs from the single-device result"
+            # two-pass: sharded == merge of the per-shard MoLAvgTopK results (exact MoL scores, shard-major ties)
+            sa = ShardedMoLAvgTopK(mol, X[:, lo:hi], ids[:, lo:hi], n_items, avg_top_k=avg_k)
+            a_s, a_i = sa(q, k=k)
+            parts = []
+            for r in range(world):
+                l2, h2 = shard_bounds(n_items, world, r)
+                parts.append(rails_amd.MoLAvgTopK(mol, X[:, l2:h2], ids[:, l2:h2], avg_top_k=min(avg_k, h2 - l2))(q, k=min(k, h2 - l2)))
+            es, epos = E.topk(torch.cat([p[0] for p in parts], 1), k)
+            assert torch.equal(a_s, es) and torch.equal(a_i, torch.gather(torch.cat([p[1] for p in parts], 1), 1, epos))
+        ret[rank] = (dist.get_backend(), s.cpu(), i.cpu())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("precision", [None, "f16x3"])
+@pytest.mark.parametrize("n_items", [70_001, 331])   # second case: the last shard is shorter than k
+def test_two_ranks_through_the_hip_modules(n_items, precision):
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), n_items, precision, ret), nprocs=world, join=True)
+    assert set(ret.keys()) == {0, 1}
+    assert torch.equal(ret[0][1], ret[1][1]) and torch.equal(ret[0][2], ret[1][2])   # identical on every rank
+    assert ret[0][0] == ("nccl" if torch.cuda.device_count() >= world else "gloo")
+
+
+def test_bench_self_spawns_two_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE (how the driver may call it) must re-exec itself under
+    torch.distributed.run and print one JSON line with n_gpus = 2."""
+    env = dict(os.environ)
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(v, None)
+    if torch.cuda.device_count() < 2:
+        env["RAILS_BENCH_TEST_BACKEND"] = "gloo"     # both ranks on GPU 0; the message is staged through the host
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--items", "200000",
+                          "--no-cpu-baseline", "--no-other-workloads"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong"
+    assert d["config"]["n_items"] == 200000 and "roofline" in d
