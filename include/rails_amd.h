@@ -33,6 +33,17 @@ extern "C" {
 
 #define RAILS_GEGLU 0
 #define RAILS_SWIGLU 1
+
+/* rails_mol_shape.precision -- the arithmetic of the fused scoring pass and, with it, the FORMAT of the three packed
+ * buffers (gate pack, query pack, item index); every buffer must be built and used with the same value.
+ *   RAILS_PRECISION_FP32   exact fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 fragments.  The parity path and the default.
+ *   RAILS_PRECISION_F16X3  every operand of the three contractions is stored as f16 hi + f16 lo (same bytes as the fp32
+ *                          fragment it replaces) and every product block costs three f16 MFMAs (lo*hi, hi*lo, hi*hi),
+ *                          fp32 accumulate: ~22 significant bits per product, same 1e-4 logit bar, ~3-4x the speed.
+ *                          The item index then holds Ex to 22 bits (rails_mol_index_unpack returns hi + lo);
+ *                          rails_mol_coarse_build / rails_mol_component_build take an fp32-format index only. */
+#define RAILS_PRECISION_FP32 0
+#define RAILS_PRECISION_F16X3 1
 #define RAILS_MAX_UID_TABLES 4
 
 /* Hyper-parameters of one MoL module; field names follow create_mol_interaction_module
@@ -52,6 +63,7 @@ typedef struct rails_mol_shape {
   int32_t dot_product_l2_norm;        /* 0 | 1 */
   float temperature;                  /* 0.05 */
   float eps;                          /* 1e-6 */
+  int32_t precision;                  /* RAILS_PRECISION_FP32 | RAILS_PRECISION_F16X3 */
 } rails_mol_shape;
 
 /* Raw module weights, one pointer per state_dict() tensor (SURVEY.md section 8b lists the keys). */
@@ -137,27 +149,6 @@ int rails_mol_score_dense(const rails_mol_shape* shape, const float* gate_pack, 
 int rails_mol_score_candidates(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack,
                                int32_t batch, const float* cand_index, int64_t n_cand, float* logits,
                                int64_t ld, void* stream);
-
-/* ---- opt-in precision mode "f16x3" -----------------------------------------------------------------
- * Same results to fp32-class accuracy (~22 significant bits per product), ~3x the speed: the two pair-gate GEMMs run
- * on f16 MFMA with every operand split into f16 hi + lo and three MFMAs per product block, fp32 accumulate; the
- * sub-embedding contraction stays exact fp32 (rails_amd/csrc/mol_layout.h).  Scales are powers of two chosen by the
- * caller so that  cl_scale * w1_scale * log2(e) * (20 * max_row ||W1||_1 + max|b1|) < 60000  (no f16 overflow is then
- * possible); typical: {16, 16, 16}.  Requires dot_product_l2_norm = 1.  The packed buffer has the same size as the
- * fp32 one (rails_mol_gate_pack_floats); query pack and item index are shared with the fp32 mode. */
-typedef struct rails_mol_split_scales {
-  float cl_scale;   /* applied to the cross logits  (f16 operand of the first gate GEMM)  */
-  float w1_scale;   /* applied to W1 / b1 fragments                                        */
-  float w2_scale;   /* applied to W2 / b2 fragments                                        */
-} rails_mol_split_scales;
-int rails_mol_pack_gate_weights_split(const rails_mol_shape* shape, const rails_mol_weights* w,
-                                      const rails_mol_split_scales* scales, float* gate_pack, void* stream);
-int rails_mol_score_dense_split(const rails_mol_shape* shape, const float* gate_pack,
-                                const rails_mol_split_scales* scales, const float* query_pack, int32_t batch,
-                                const float* index, int64_t n_items, float* logits, int64_t ld, void* stream);
-int rails_mol_score_candidates_split(const rails_mol_shape* shape, const float* gate_pack,
-                                     const rails_mol_split_scales* scales, const float* query_pack, int32_t batch,
-                                     const float* cand_index, int64_t n_cand, float* logits, int64_t ld, void* stream);
 
 /* ---- dot-product (MIPS) scoring ---------------------------------------------------------------
  * Replaces torch.mm(query_embeddings, item_embeddings_t) of MIPSBruteForceTopK.forward

@@ -21,6 +21,8 @@ RAILS_ELAUNCH = -5
 RAILS_GEGLU = 0
 RAILS_SWIGLU = 1
 RAILS_MAX_UID_TABLES = 4
+RAILS_PRECISION_FP32 = 0
+RAILS_PRECISION_F16X3 = 1
 
 _f32p = C.POINTER(C.c_float)
 
@@ -41,6 +43,7 @@ class MolShape(C.Structure):
         ("dot_product_l2_norm", C.c_int32),
         ("temperature", C.c_float),
         ("eps", C.c_float),
+        ("precision", C.c_int32),
     ]
 
 
@@ -65,10 +68,6 @@ class MolWeights(C.Structure):
         ("gqi_w2", C.c_void_p),
         ("gqi_b2", C.c_void_p),
     ]
-
-
-class MolSplitScales(C.Structure):
-    _fields_ = [("cl_scale", C.c_float), ("w1_scale", C.c_float), ("w2_scale", C.c_float)]
 
 
 # name -> (restype, argtypes): one entry per declaration in include/rails_amd.h
@@ -99,15 +98,6 @@ PROTOTYPES = {
     "rails_mol_score_candidates": (
         C.c_int,
         [_SHAPE_P, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p],
-    ),
-    "rails_mol_pack_gate_weights_split": (C.c_int, [_SHAPE_P, _WEIGHTS_P, C.POINTER(MolSplitScales), C.c_void_p, C.c_void_p]),
-    "rails_mol_score_dense_split": (
-        C.c_int,
-        [_SHAPE_P, C.c_void_p, C.POINTER(MolSplitScales), C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p],
-    ),
-    "rails_mol_score_candidates_split": (
-        C.c_int,
-        [_SHAPE_P, C.c_void_p, C.POINTER(MolSplitScales), C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p],
     ),
     "rails_mips_index_floats": (C.c_size_t, [C.c_int32, C.c_int64]),
     "rails_mips_index_build": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),

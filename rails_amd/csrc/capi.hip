@@ -50,6 +50,14 @@ static bool shape_supported(const Shape* s) {
     set_error("query_hidden_dim / gating hidden dims must be > 0 (plain-Linear variants are not built)");
     return false;
   }
+  if (s->precision != RAILS_PRECISION_FP32 && s->precision != RAILS_PRECISION_F16X3) {
+    set_error("precision must be RAILS_PRECISION_FP32 or RAILS_PRECISION_F16X3, got %d", s->precision);
+    return false;
+  }
+  if (is_split(*s) && !s->dot_product_l2_norm) {
+    set_error("precision f16x3 needs dot_product_l2_norm = 1 (cross logits bounded by 1/temperature keep the f16 operands in range)");
+    return false;
+  }
   if (!score_supported(*s)) {
     set_error("no fused scoring kernel for P_Q x P_X x d = %dx%dx%d with gating_qi_hidden_dim = %d "
               "(built: 8x4x64, 8x4x128, 8x8x32, 16x16x64 with 128)",
@@ -96,6 +104,7 @@ int rails_mol_pack_gate_weights(const rails_mol_shape* s, const rails_mol_weight
     set_error("pack_gate_weights: NULL pointer");
     return RAILS_EINVAL;
   }
+  if (is_split(*s)) return fail(pack_gate_weights_split(*s, *w, gate_pack, (hipStream_t)stream), "pack_gate_weights");
   return fail(pack_gate_weights(*s, *w, gate_pack, (hipStream_t)stream), "pack_gate_weights");
 }
 
@@ -114,7 +123,8 @@ int rails_mol_index_build(const rails_mol_shape* s, const rails_mol_weights* w, 
     set_error("index_build: NULL pointer");
     return RAILS_EINVAL;
   }
-  const int r = index_build(*s, *w, items, n_items, index, (hipStream_t)stream);
+  int r = index_build(*s, *w, items, n_items, index, (hipStream_t)stream);
+  if (r == kOk && is_split(*s)) r = index_split_inplace(*s, index, n_items, (hipStream_t)stream);
   return r == kOk ? r : fail(r, "index_build");
 }
 
@@ -169,7 +179,7 @@ int rails_mol_query_prologue(const rails_mol_shape* s, const rails_mol_weights* 
 
 static int score_common(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch,
                         const float* index, int64_t n_items, float* logits, int64_t ld, int per_row, void* stream,
-                        const char* what, const rails_mol_split_scales* split = nullptr) {
+                        const char* what) {
   g_err[0] = '\0';
   if (!shape_supported(s)) return RAILS_ENOTSUP;
   if (batch < 0 || n_items < 0) { set_error("%s: negative size", what); return RAILS_EINVAL; }
@@ -194,17 +204,7 @@ static int score_common(const rails_mol_shape* s, const float* gate_pack, const 
   a.per_row = per_row;
   a.temperature = s->temperature;
   a.rcp_temperature = 1.0f / s->temperature;
-  a.split = split ? 1 : 0;
-  a.cl_scale = a.inv_c = a.c2 = a.inv_c2 = a.inv_cl_scale = 1.0f;
-  if (split) {
-    if (!(split->cl_scale > 0.0f && split->w1_scale > 0.0f && split->w2_scale > 0.0f)) { set_error("%s: scales must be > 0", what); return RAILS_EINVAL; }
-    const float c = split->cl_scale * split->w1_scale;
-    a.cl_scale = split->cl_scale;
-    a.inv_cl_scale = 1.0f / split->cl_scale;
-    a.inv_c = 1.0f / c;
-    a.c2 = c * split->w2_scale;
-    a.inv_c2 = 1.0f / a.c2;
-  }
+  a.split = is_split(*s) ? 1 : 0;
   const int r = score_launch(*s, a, cu, (hipStream_t)stream);
   return r == kOk ? r : fail(r, what);
 }
@@ -217,32 +217,6 @@ int rails_mol_score_dense(const rails_mol_shape* s, const float* gate_pack, cons
 int rails_mol_score_candidates(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch,
                                const float* cand_index, int64_t n_cand, float* logits, int64_t ld, void* stream) {
   return score_common(s, gate_pack, query_pack, batch, cand_index, n_cand, logits, ld, 1, stream, "score_candidates");
-}
-
-int rails_mol_pack_gate_weights_split(const rails_mol_shape* s, const rails_mol_weights* w,
-                                      const rails_mol_split_scales* scales, float* gate_pack, void* stream) {
-  g_err[0] = '\0';
-  if (!shape_supported(s)) return RAILS_ENOTSUP;
-  if (!w || !scales || !gate_pack || !w->gqi_w1 || !w->gqi_b1 || !w->gqi_w2 || !w->gqi_b2) {
-    set_error("pack_gate_weights_split: NULL pointer");
-    return RAILS_EINVAL;
-  }
-  const SplitScales sc = {scales->cl_scale, scales->w1_scale, scales->w2_scale};
-  return fail(pack_gate_weights_split(*s, *w, sc, gate_pack, (hipStream_t)stream), "pack_gate_weights_split");
-}
-
-int rails_mol_score_dense_split(const rails_mol_shape* s, const float* gate_pack, const rails_mol_split_scales* scales,
-                                const float* query_pack, int32_t batch, const float* index, int64_t n_items, float* logits,
-                                int64_t ld, void* stream) {
-  if (!scales) { set_error("score_dense_split: NULL scales"); return RAILS_EINVAL; }
-  return score_common(s, gate_pack, query_pack, batch, index, n_items, logits, ld, 0, stream, "score_dense_split", scales);
-}
-
-int rails_mol_score_candidates_split(const rails_mol_shape* s, const float* gate_pack, const rails_mol_split_scales* scales,
-                                     const float* query_pack, int32_t batch, const float* cand_index, int64_t n_cand,
-                                     float* logits, int64_t ld, void* stream) {
-  if (!scales) { set_error("score_candidates_split: NULL scales"); return RAILS_EINVAL; }
-  return score_common(s, gate_pack, query_pack, batch, cand_index, n_cand, logits, ld, 1, stream, "score_candidates_split", scales);
 }
 
 size_t rails_mips_index_floats(int32_t dim, int64_t n_items) {
@@ -296,6 +270,7 @@ int rails_mol_coarse_build(const rails_mol_shape* s, const float* index, int64_t
   if (n_items < 0) { set_error("coarse_build: n_items < 0"); return RAILS_EINVAL; }
   if (n_items == 0) return RAILS_OK;
   if (!index || !table) { set_error("coarse_build: NULL pointer"); return RAILS_EINVAL; }
+  if (is_split(*s)) { set_error("coarse_build: needs an fp32-format item index (build one with precision = RAILS_PRECISION_FP32)"); return RAILS_ENOTSUP; }
   return fail(coarse_build(*s, index, n_items, table, (hipStream_t)stream), "coarse_build");
 }
 
@@ -344,6 +319,7 @@ int rails_mol_component_build(const rails_mol_shape* s, const float* index, int6
   if (n_items < 0) { set_error("component_build: n_items < 0"); return RAILS_EINVAL; }
   if (n_items == 0) return RAILS_OK;
   if (!index || !table) { set_error("component_build: NULL pointer"); return RAILS_EINVAL; }
+  if (is_split(*s)) { set_error("component_build: needs an fp32-format item index (build one with precision = RAILS_PRECISION_FP32)"); return RAILS_ENOTSUP; }
   return fail(component_build(*s, index, n_items, table, (hipStream_t)stream), "component_build");
 }
 

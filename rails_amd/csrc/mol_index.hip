@@ -64,8 +64,7 @@ __device__ __forceinline__ void split_f16(float x, unsigned short& hi, unsigned 
 
 __global__ void pack_gate_split_kernel(const float* __restrict__ w1, const float* __restrict__ b1,
                                        const float* __restrict__ w2, const float* __restrict__ b2,
-                                       float* __restrict__ out, int PQ, int PX, int H, float s_w1, float s_w2, float c,
-                                       float c2) {
+                                       float* __restrict__ out, int PQ, int PX, int H) {
   const int L = PQ * PX, TH = H / 32, TL = L / 32, E = L / 2;
   unsigned short* w1hi = reinterpret_cast<unsigned short*>(out);
   unsigned short* w1lo = w1hi + H * L;
@@ -78,7 +77,7 @@ __global__ void pack_gate_split_kernel(const float* __restrict__ w1, const float
     if (i < H * L) {  // W1 fragment [s][t][lane][jj]: row 32t + (lane&31), logit logit_of(8s + jj, lane>>5)
       const int jj = i & 7, lane = (i >> 3) & 63, blk = i >> 9;
       const int t = blk % TH, ks = blk / TH;
-      const float v = s_w1 * (-kLog2e * w1[(32 * t + (lane & 31)) * L + logit_of(8 * ks + jj, lane >> 5, PQ, PX)]);
+      const float v = -kLog2e * w1[(32 * t + (lane & 31)) * L + logit_of(8 * ks + jj, lane >> 5, PQ, PX)];
       split_f16(v, w1hi[i], w1lo[i]);
     } else if (i < 2 * H * L) {  // W2 fragment [s][v][lane][jj]: row lrow(v, lane&31), hidden hidden_of(8s + jj, lane>>5)
       const int k = i - H * L;
@@ -86,27 +85,25 @@ __global__ void pack_gate_split_kernel(const float* __restrict__ w1, const float
       const int tv = blk % TL, ks = blk / TL;
       const int row = lane & 31;
       const int l = logit_of(16 * tv + reg_of_row(row), half_of_row(row), PQ, PX);
-      const float v = s_w2 * w2[l * H + hidden_of(8 * ks + jj, lane >> 5)];
+      const float v = w2[l * H + hidden_of(8 * ks + jj, lane >> 5)];
       split_f16(v, w2hi[k], w2lo[k]);
-    } else if (i < 2 * H * L + H) {  // b1frag[t][hi][r], carries c * (-log2e)
+    } else if (i < 2 * H * L + H) {  // b1frag[t][hi][r], carries -log2e
       const int k = i - 2 * H * L;
       const int r = k & 15, hi = (k >> 4) & 1, t = k >> 5;
-      b1f[k] = c * (-kLog2e * b1[32 * t + acc_row(r, hi)]);
-    } else {  // b2frag[hi][e], carries c2 * (-log2e)
+      b1f[k] = -kLog2e * b1[32 * t + acc_row(r, hi)];
+    } else {  // b2frag[hi][e], carries -log2e
       const int k = i - 2 * H * L - H;
       const int hi = k / E, e = k % E;
-      b2f[k] = c2 * (-kLog2e * b2[logit_of(e, hi, PQ, PX)]);
+      b2f[k] = -kLog2e * b2[logit_of(e, hi, PQ, PX)];
     }
   }
 }
 
-int pack_gate_weights_split(const Shape& s, const Weights& w, const SplitScales& sc, float* wpack, hipStream_t stream) {
+int pack_gate_weights_split(const Shape& s, const Weights& w, float* wpack, hipStream_t stream) {
   const int H = s.gating_qi_hidden_dim, L = num_logits(s);
   const int total = 2 * H * L + H + L;
-  const float c = sc.cl_scale * sc.w1_scale;
   hipLaunchKernelGGL(pack_gate_split_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w.gqi_w1, w.gqi_b1,
-                     w.gqi_w2, w.gqi_b2, wpack, s.query_dot_product_groups, s.item_dot_product_groups, H, sc.w1_scale,
-                     sc.w2_scale, c, c * sc.w2_scale);
+                     w.gqi_w2, w.gqi_b2, wpack, s.query_dot_product_groups, s.item_dot_product_groups, H);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
@@ -252,9 +249,46 @@ int index_build(const Shape& s, const Weights& w, const float* items, int64_t n,
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
+// ---- precision f16x3: the Ex fragments of a tile, fp32 -> f16 hi/lo, in place ---------------------------------------
+// A lane's two consecutive 16-byte chunks (2ks, 2ks+1) of an item group are its 8 k-values of K=16 step ks (k = hi*d/2 +
+// 8ks + jj); they are replaced by the 8 hi halves (chunk 2ks) and the 8 lo halves (chunk 2ks+1).  Each lane rewrites only
+// what it read, so the conversion is race-free in place; gi stays fp32.  Bytes per item unchanged.
+__global__ void index_split_kernel(float4* __restrict__ ipack, int64_t n_tiles, int pairs_per_tile, int tile_f4) {
+  const int64_t total = n_tiles * pairs_per_tile * 64;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const int64_t pr = i >> 6;
+    const int64_t tile = pr / pairs_per_tile;
+    const int pair = (int)(pr - tile * pairs_per_tile);
+    float4* a = ipack + tile * tile_f4 + (2 * pair) * 64 + lane;
+    const float4 u = a[0], v = a[64];
+    const float x[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+    unsigned short hb[8], lb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) split_f16(x[j], hb[j], lb[j]);
+    uint4 H, Lo;
+    H.x = hb[0] | (unsigned)hb[1] << 16; H.y = hb[2] | (unsigned)hb[3] << 16; H.z = hb[4] | (unsigned)hb[5] << 16; H.w = hb[6] | (unsigned)hb[7] << 16;
+    Lo.x = lb[0] | (unsigned)lb[1] << 16; Lo.y = lb[2] | (unsigned)lb[3] << 16; Lo.z = lb[4] | (unsigned)lb[5] << 16; Lo.w = lb[6] | (unsigned)lb[7] << 16;
+    *reinterpret_cast<uint4*>(a) = H;
+    *reinterpret_cast<uint4*>(a + 64) = Lo;
+  }
+}
+
+int index_split_inplace(const Shape& s, float* ipack, int64_t n, hipStream_t stream) {
+  const int64_t tiles = num_tiles(n);
+  if (tiles == 0) return kOk;
+  if (s.dot_product_dimension % 16 != 0) { set_error("precision f16x3 needs dot_product_dimension % 16 == 0"); return kErrUnsupported; }
+  const int pairs = s.item_dot_product_groups * s.dot_product_dimension / 16;
+  int64_t blocks = (tiles * pairs * 64 + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(index_split_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<float4*>(ipack), tiles, pairs,
+                     (int)(tile_floats(s) / 4));
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 // ---- unpack: fragment order -> plain (n, PX, d) / (n, L) -----------------------------------------
 __global__ void index_unpack_kernel(const float* __restrict__ ipack, int64_t n, int PQ, int PX, int d,
-                                    float* __restrict__ ex, float* __restrict__ gi) {
+                                    float* __restrict__ ex, float* __restrict__ gi, int split) {
   const int L = PQ * PX;
   const int64_t tile = blockIdx.x;
   const float* tEx = ipack + tile * (int64_t)(kTileItems * (PX * d + L));
@@ -264,7 +298,14 @@ __global__ void index_unpack_kernel(const float* __restrict__ ipack, int64_t n, 
       const int j = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
       const int c8 = blk % (d / 8), m = blk / (d / 8);
       const int64_t item = tile * kTileItems + (lane & 31);
-      if (item < n) ex[(item * PX + m) * d + kdim_of(4 * c8 + j, lane >> 5, d)] = tEx[i];
+      float v = tEx[i];
+      if (split) {   // hi + lo of the f16x3 fragments (exact in fp32): chunk pair (2ks, 2ks+1) holds 8 hi, then 8 lo halves
+        const unsigned short* th = reinterpret_cast<const unsigned short*>(tEx);
+        const int jj = 4 * (c8 & 1) + j, base = ((m * (d / 8) + (c8 & ~1)) * 64 + lane) * 8;
+        const _Float16 h = __builtin_bit_cast(_Float16, th[base + jj]), l = __builtin_bit_cast(_Float16, th[base + 512 + jj]);
+        v = (float)h + (float)l;
+      }
+      if (item < n) ex[(item * PX + m) * d + kdim_of(4 * c8 + j, lane >> 5, d)] = v;
     }
   }
   if (gi) {
@@ -280,7 +321,7 @@ int index_unpack(const Shape& s, const float* ipack, int64_t n, float* ex, float
   const int64_t tiles = num_tiles(n);
   if (tiles == 0) return kOk;
   hipLaunchKernelGGL(index_unpack_kernel, dim3((unsigned)tiles), dim3(256), 0, stream, ipack, n,
-                     s.query_dot_product_groups, s.item_dot_product_groups, s.dot_product_dimension, ex, gi);
+                     s.query_dot_product_groups, s.item_dot_product_groups, s.dot_product_dimension, ex, gi, is_split(s) ? 1 : 0);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

@@ -39,17 +39,11 @@ struct ScoreArgs {
   int per_row;          // 1: tile t of row b lives at ipack tile (b * n_tiles + t)
   float temperature;
   float rcp_temperature;
-  // split-f16 gate MLP (precision mode "f16x3", mol_layout.h): power-of-two operand scales; 0 -> exact fp32 kernels
-  int split;
-  float cl_scale;       // s_a: GEMM1 output is s_a * cl
-  float inv_c;          // 1 / (s_a * s_w1): D2 holds c * t
-  float c2;             // s_a * s_w1 * s_w2: D3 holds c2 * gqi'
-  float inv_c2;
-  float inv_cl_scale;
+  int split;            // 1: precision mode f16x3 -- gate pack, query pack and item index hold f16 hi/lo fragments (mol_layout.h)
 };
 
-struct SplitScales { float cl_scale, w1_scale, w2_scale; };
-int pack_gate_weights_split(const Shape& s, const Weights& w, const SplitScales& sc, float* wpack, hipStream_t stream);
+int pack_gate_weights_split(const Shape& s, const Weights& w, float* wpack, hipStream_t stream);
+inline bool is_split(const Shape& s) { return s.precision == RAILS_PRECISION_F16X3; }
 
 void set_error(const char* fmt, ...);
 
@@ -67,11 +61,14 @@ inline int ensure_dyn_lds(DynLdsOnce& once, const void* fn, int bytes) {
 }
 
 int score_launch(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream);
+int score_launch_f16(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream);
 bool score_supported(const Shape& s);
 
 int pack_gate_weights(const Shape& s, const Weights& w, float* wpack, hipStream_t stream);
 int index_build(const Shape& s, const Weights& w, const float* items, int64_t n, float* ipack, hipStream_t stream);
 int index_unpack(const Shape& s, const float* ipack, int64_t n, float* ex, float* gi, hipStream_t stream);
+// fp32 Ex fragments of a freshly built index -> f16 hi/lo fragments, in place (precision f16x3)
+int index_split_inplace(const Shape& s, float* ipack, int64_t n, hipStream_t stream);
 int index_gather(const Shape& s, const float* ipack, int64_t n, const int64_t* idx, int64_t rows, int64_t n_cand,
                  float* out, hipStream_t stream);
 size_t query_scratch_floats(const Shape& s, int B);

@@ -40,7 +40,26 @@ struct QueryArgs {
   int D, PQ, PX, d, QH, Hq, n_uid, glu, l2norm;
   float eps;
   float temperature;
+  int split;   // precision f16x3: Eq fragments are written as f16 hi/lo (mol_layout.h)
 };
+
+// One element of a query group's Eq fragment: K index s of lane half hi, accumulator row `row` (= qj*P_Q + p).
+//   fp32:   EqFrag[sc = s/4][lane = hi*32 + row][j = s%4]
+//   f16x3:  the lane's chunk pair (2ks, 2ks+1) holds its 8 k-values of K=16 step ks as 8 hi halves, then 8 lo halves
+__device__ __forceinline__ void eq_frag_store(float* eqf, int s, int hi, int row, float v, int split) {
+  const int sc = s >> 2, lane = hi * 32 + row;
+  if (!split) {
+    eqf[(sc * 64 + lane) * 4 + (s & 3)] = v;
+    return;
+  }
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  const h2 h = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(v, 0.0f));   // round toward zero
+  const _Float16 l = (_Float16)(v - (float)h.x);                              // remainder is exact in fp32
+  unsigned short* e16 = reinterpret_cast<unsigned short*>(eqf);
+  const int jj = 4 * (sc & 1) + (s & 3), base = ((sc & ~1) * 64 + lane) * 8;
+  e16[base + jj] = __builtin_bit_cast(unsigned short, h.x);
+  e16[base + 512 + jj] = __builtin_bit_cast(unsigned short, l);
+}
 
 // out[c] = bias[c] + sum_k W[c][k] in[k]; a wave owns four output columns at a time, lanes stride k, then a shuffle
 // reduction per column.  KPL = ceil(K / 64) is a compile-time bound so that all 4 * KPL weight loads of a column group are
@@ -118,7 +137,7 @@ __global__ __launch_bounds__(kQueryThreads) void query_prologue_kernel(QueryArgs
     for (int i = threadIdx.x; i < PQ * d; i += kQueryThreads) {
       const int p = i / d, k = i - p * d;
       const int hi = k / (d / 2), s = k - hi * (d / 2);
-      eqf[((s >> 2) * 64 + hi * 32 + qj * PQ + p) * 4 + (s & 3)] = 0.0f;
+      eq_frag_store(eqf, s, hi, qj * PQ + p, 0.0f, a.split);
     }
     return;
   }
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(kQueryThreads) void query_prologue_kernel(QueryArgs
     if (a.eq_out) a.eq_out[(int64_t)b * PQ * d + i] = v;
     // EqFrag[g][sc][lane][j] = Eq[g*QT + row/PQ][row%PQ][kdim_of(4sc + j, hi)], lane = hi*32 + row
     const int hi = k / (d / 2), s = k - hi * (d / 2);
-    eqf[((s >> 2) * 64 + hi * 32 + qj * PQ + p) * 4 + (s & 3)] = v / a.temperature;  // fragment copy carries 1/tau
+    eq_frag_store(eqf, s, hi, qj * PQ + p, v / a.temperature, a.split);  // fragment copy carries 1/tau
   }
   for (int i = threadIdx.x; i < L; i += kQueryThreads) {
     if (a.gq_out) a.gq_out[(int64_t)b * L + i] = gqs[i];
@@ -278,7 +297,7 @@ __device__ __forceinline__ void finalize_component(const QueryArgs& a, int tile,
         // EqFrag[g][sc][lane][j] = Eq[g*QT + row/PQ][row%PQ][kdim_of(4sc + j, hi)], lane = hi*32 + row
         const int g = bb >> qt_shift, qj = bb & (QT - 1);
         const int hi = k >= half ? 1 : 0, s = k - hi * half;
-        a.eqfrag[(int64_t)g * 32 * d + ((s >> 2) * 64 + hi * 32 + qj * PQ + p) * 4 + (s & 3)] = bb < a.B ? v / a.temperature : 0.0f;
+        eq_frag_store(a.eqfrag + (int64_t)g * 32 * d, s, hi, qj * PQ + p, bb < a.B ? v / a.temperature : 0.0f, a.split);
       }
       rr += step_r; k += step_k;
       if (k >= d) { k -= d; ++rr; }
@@ -455,6 +474,7 @@ int query_prologue(const Shape& s, const Weights& w, const float* q, const int64
   a.D = s.query_embedding_dim; a.PQ = s.query_dot_product_groups; a.PX = s.item_dot_product_groups;
   a.d = s.dot_product_dimension; a.QH = s.query_hidden_dim; a.Hq = s.gating_query_hidden_dim;
   a.n_uid = s.num_uid_tables; a.glu = s.query_nonlinearity; a.l2norm = s.dot_product_l2_norm; a.eps = s.eps; a.temperature = s.temperature;
+  a.split = is_split(s) ? 1 : 0;
   const int QT = queries_per_group(s);
   const int n_groups = (B + QT - 1) / QT;
   a.eqfrag = qpack;

@@ -24,10 +24,9 @@
 
 #include "mol_kernels.h"
 #include "mol_layout.h"
+#include "mol_score_shell.h"
 
 namespace mol {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -72,13 +71,6 @@ __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float4* __restrict
     asm volatile("" ::: "memory");
   }
 }
-
-// GEMM1 of the f16x3 mode: same fp32 fragments (query pack, item tile) as the exact kernel -- two consecutive float4
-// chunks of a lane are exactly its 8 k-values of a K=16 step (k = hi*d/2 + 8 ks + jj on both operands) -- split into
-// f16 hi/lo on the fly; three MFMAs per (item group, K-step).  `a_scale` (power of two) rides on the query operand.
-template <class G, int PX, int DD>
-__device__ __forceinline__ void gemm1_split(f32x16 (&D1)[PX], const float4* __restrict__ eq, const float4* tEx, int lane,
-                                            float a_scale);
 
 // One query of the group: gate MLP (GEMM2 -> silu -> GEMM3), combine, softmax, mixture, on pre-scaled operands
 // (mol_layout.h).  The query's cl values sit in accumulator registers [R0, R0 + RPQ) of every D1 tile.
@@ -177,402 +169,36 @@ __device__ __forceinline__ float query_mlp(f32x16 (&D1)[PX], const float4* sW1, 
   return (num * rden) / fmaxf(den * rden, 1e-6f);
 }
 
-// ---- precision mode "f16x3": the gate GEMMs on f16 MFMA with hi/lo-split operands (mol_layout.h) ---------
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h2v __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
-}
-
-// two fp32 values -> packed f16 hi (round toward zero) and packed f16 lo (the fp32 remainder x - hi, exact, RTZ to f16).
-// The remainder is one v_fma_mix_f32 per value (fma(f16 half of hi, -1.0, x) in fp32) instead of cvt + sub.
-__device__ __forceinline__ void split_pair(float x0, float x1, h2v& hi, h2v& lo) {
-  const unsigned hb = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-  float l0, l1;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hb), "v"(x0));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hb), "v"(x1));
-  hi = __builtin_bit_cast(h2v, hb);
-  lo = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(l0, l1));
-}
-
-template <class G, int PX, int R0>
-__device__ __forceinline__ float query_mlp_split(f32x16 (&D1)[PX], const float* smem, const float4* tGi,
-                                                 const float4* __restrict__ gq4, int lane, int hi, const ScoreArgs& p) {
-  constexpr int HL8 = G::kW1Floats / 8;  // h8 fragments per weight matrix half
-  const h8* sW1hi = reinterpret_cast<const h8*>(smem);
-  const h8* sW1lo = sW1hi + HL8;
-  const h8* sW2hi = sW1lo + HL8;
-  const h8* sW2lo = sW2hi + HL8;
-  const float* sB1 = smem + G::kW1Floats + G::kW2Floats;
-  const float* sB2 = sB1 + G::TH * 32;
-
-  // GEMM2: D2 = c * t,  t = -log2e * (b1 + W1 cl);  K-step ks covers cl registers e in [8 ks, 8 ks + 8)
-  f32x16 D2[G::TH];
-#pragma unroll
-  for (int t = 0; t < G::TH; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) D2[t][r] = sB1[t * 32 + hi * 16 + r];
-#pragma unroll
-  for (int ks = 0; ks < G::E / 8; ++ks) {
-    // this K-step's weight fragments first: their LDS latency hides under the operand split below
-    h8 ah[G::TH], al[G::TH];
-#pragma unroll
-    for (int t = 0; t < G::TH; ++t) {
-      ah[t] = sW1hi[(ks * G::TH + t) * 64 + lane];
-      al[t] = sW1lo[(ks * G::TH + t) * 64 + lane];
-    }
-    asm volatile("" ::: "memory");
-    h8 bh, bl;
-#pragma unroll
-    for (int jj = 0; jj < 8; jj += 2) {
-      const int e = ks * 8 + jj;
-      h2v ph, pl;
-      split_pair(D1[e / G::RPQ][R0 + e % G::RPQ], D1[(e + 1) / G::RPQ][R0 + (e + 1) % G::RPQ], ph, pl);
-      bh[jj] = ph.x; bh[jj + 1] = ph.y; bl[jj] = pl.x; bl[jj + 1] = pl.y;
-    }
-    // three passes over the row tiles so consecutive MFMAs hit different accumulators
-#pragma unroll
-    for (int t = 0; t < G::TH; ++t) D2[t] = mfma16(al[t], bh, D2[t]);
-#pragma unroll
-    for (int t = 0; t < G::TH; ++t) D2[t] = mfma16(ah[t], bl, D2[t]);
-#pragma unroll
-    for (int t = 0; t < G::TH; ++t) D2[t] = mfma16(ah[t], bh, D2[t]);
+// The exact-fp32 unit policy of the kernel shells (mol_score_shell.h).
+struct Fp32Unit {
+  template <class G, int PX, int DD>
+  static __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float* __restrict__ eq, const float4* tEx, int lane) {
+    mol::gemm1<G, PX, DD>(D1, reinterpret_cast<const float4*>(eq), tEx, lane);
   }
-  // hid'' = D2 * rcp(1 + exp2(D2 / c)) = c * hid'
-  f32x2 inv_c = {p.inv_c, p.inv_c};
-  asm volatile("" : "+v"(inv_c));  // keep the power-of-two rescale in a VGPR pair so it stays one v_pk_mul_f32 per two values
-#pragma unroll
-  for (int t = 0; t < G::TH; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-      const f32x2 tv = {D2[t][r], D2[t][r + 1]};
-      const f32x2 h = tv * pk_sigmoid_arg(tv * inv_c);
-      D2[t][r] = h.x;
-      D2[t][r + 1] = h.y;
-    }
-
-  // GEMM3: D3 = c2 * gqi';  K-step ks covers hidden registers f in [8 ks, 8 ks + 8)
-  f32x16 D3[G::TL];
-#pragma unroll
-  for (int v = 0; v < G::TL; ++v)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) D3[v][r] = sB2[hi * G::E + v * 16 + r];
-#pragma unroll
-  for (int ks = 0; ks < G::F / 8; ++ks) {
-    h8 ah[G::TL], al[G::TL];
-#pragma unroll
-    for (int v = 0; v < G::TL; ++v) {
-      ah[v] = sW2hi[(ks * G::TL + v) * 64 + lane];
-      al[v] = sW2lo[(ks * G::TL + v) * 64 + lane];
-    }
-    asm volatile("" ::: "memory");
-    h8 bh, bl;
-#pragma unroll
-    for (int jj = 0; jj < 8; jj += 2) {
-      const int f = ks * 8 + jj;
-      h2v ph, pl;
-      split_pair(D2[f / 16][f % 16], D2[f / 16][f % 16 + 1], ph, pl);
-      bh[jj] = ph.x; bh[jj + 1] = ph.y; bl[jj] = pl.x; bl[jj + 1] = pl.y;
-    }
-#pragma unroll
-    for (int v = 0; v < G::TL; ++v) D3[v] = mfma16(al[v], bh, D3[v]);
-#pragma unroll
-    for (int v = 0; v < G::TL; ++v) D3[v] = mfma16(ah[v], bl, D3[v]);
-#pragma unroll
-    for (int v = 0; v < G::TL; ++v) D3[v] = mfma16(ah[v], bh, D3[v]);
+  // All queries of one unit, each at its own static register offset (no register rotation).
+  // `only` >= 0 restricts the unit to that query (per-row candidates).
+  template <class G, int PX>
+  static __device__ __forceinline__ void queries(f32x16 (&D1)[PX], const ScoreArgs& p, int g, int only, int64_t item0,
+                                                 const float* smem, const float4* tGi, int lane, int hi, int x) {
+    const float4* sW1 = reinterpret_cast<const float4*>(smem);
+    const float4* sW2 = sW1 + G::kW1Floats / 4;
+    const float* sB1 = smem + G::kW1Floats + G::kW2Floats;
+    const float* sB2 = sB1 + G::TH * 32;
+    [&]<int... Q>(std::integer_sequence<int, Q...>) {
+      (
+          [&] {
+            const int q = g * G::QT + Q;
+            if (q < p.B && (only < 0 || q == only)) {
+              const float4* gq4 = reinterpret_cast<const float4*>(p.gqfrag + (int64_t)q * G::L + hi * G::E);
+              const float out = query_mlp<G, PX, Q * G::RPQ>(D1, sW1, sW2, sB1, sB2, tGi, gq4, lane, hi);
+              const int64_t item = item0 + x;
+              if (hi == 0 && item < p.n_items) p.logits[(int64_t)q * p.ld + item] = out;
+            }
+          }(),
+          ...);
+    }(std::make_integer_sequence<int, G::QT>{});
   }
-
-  // epilogue: T2 = c2 * t2 = fma(c2 * gq', gi, D3);  u = t2 / (1 + 2^t2)
-  f32x2 c2 = {p.c2, p.c2}, inv_c2 = {p.inv_c2, p.inv_c2};
-  asm volatile("" : "+v"(c2), "+v"(inv_c2));
-  float mn = INFINITY;
-#pragma unroll
-  for (int ec = 0; ec < G::E / 4; ++ec) {
-    const float4 gi = tGi[ec * 64 + lane];
-    const float4 gq = gq4[ec];
-    const f32x2 giv[2] = {{gi.x, gi.y}, {gi.z, gi.w}};
-    const f32x2 gqv[2] = {{gq.x, gq.y}, {gq.z, gq.w}};
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int e = ec * 4 + 2 * j;
-      const f32x2 t2 = pk_fma(gqv[j] * c2, giv[j], f32x2{D3[e / 16][e % 16], D3[e / 16][e % 16 + 1]}) * inv_c2;
-      const f32x2 u = t2 * pk_sigmoid_arg(t2);
-      D3[e / 16][e % 16] = u.x;
-      D3[e / 16][e % 16 + 1] = u.y;
-      mn = fminf(mn, fminf(u.x, u.y));
-    }
-  }
-  mn = fminf(mn, xor32(mn));
-  f32x2 den2 = {0.0f, 0.0f}, num2 = {0.0f, 0.0f};
-#pragma unroll
-  for (int e = 0; e < G::E; e += 2) {
-    const f32x2 d = mn - f32x2{D3[e / 16][e % 16], D3[e / 16][e % 16 + 1]};
-    const f32x2 ex = {__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};
-    den2 = den2 + ex;
-    num2 = pk_fma(ex, f32x2{D1[e / G::RPQ][R0 + e % G::RPQ], D1[e / G::RPQ][R0 + e % G::RPQ + 1]}, num2);
-  }
-  float den = den2.x + den2.y, num = num2.x + num2.y;
-  den += xor32(den);
-  num += xor32(num);
-  const float rden = __builtin_amdgcn_rcpf(den);
-  return (num * rden * p.inv_cl_scale) / fmaxf(den * rden, 1e-6f);   // D1 holds s_a * cl
-}
-
-__device__ __forceinline__ void split_f4x2(const float4& u, const float4& v, float scale, h8& hi, h8& lo) {
-  const float x[8] = {u.x * scale, u.y * scale, u.z * scale, u.w * scale, v.x * scale, v.y * scale, v.z * scale, v.w * scale};
-#pragma unroll
-  for (int j = 0; j < 8; j += 2) {
-    h2v ph, pl;
-    split_pair(x[j], x[j + 1], ph, pl);
-    hi[j] = ph.x; hi[j + 1] = ph.y; lo[j] = pl.x; lo[j + 1] = pl.y;
-  }
-}
-
-template <class G, int PX, int DD>
-__device__ __forceinline__ void gemm1_split(f32x16 (&D1)[PX], const float4* __restrict__ eq, const float4* tEx, int lane,
-                                            float a_scale) {
-  static_assert(DD % 16 == 0, "f16x3 GEMM1 walks K in steps of 16");
-#pragma unroll
-  for (int m = 0; m < PX; ++m)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) D1[m][r] = 0.0f;
-#pragma unroll
-  for (int ks = 0; ks < DD / 16; ++ks) {
-    h8 ah, al;
-    split_f4x2(eq[(2 * ks) * 64 + lane], eq[(2 * ks + 1) * 64 + lane], a_scale, ah, al);
-    h8 bh[PX], bl[PX];
-#pragma unroll
-    for (int m = 0; m < PX; ++m)
-      split_f4x2(tEx[(m * (DD / 8) + 2 * ks) * 64 + lane], tEx[(m * (DD / 8) + 2 * ks + 1) * 64 + lane], 1.0f, bh[m], bl[m]);
-#pragma unroll
-    for (int m = 0; m < PX; ++m) D1[m] = mfma16(al, bh[m], D1[m]);
-#pragma unroll
-    for (int m = 0; m < PX; ++m) D1[m] = mfma16(ah, bl[m], D1[m]);
-#pragma unroll
-    for (int m = 0; m < PX; ++m) D1[m] = mfma16(ah, bh[m], D1[m]);
-    asm volatile("" ::: "memory");
-  }
-}
-
-// All queries of one unit, each at its own static register offset (no register rotation).
-// `only` >= 0 restricts the unit to that query (per-row candidates).
-template <class G, int PX, bool SPLIT>
-__device__ __forceinline__ void unit_queries(f32x16 (&D1)[PX], const ScoreArgs& p, int g, int only, int64_t item0,
-                                             const float* smem, const float4* sW1, const float4* sW2, const float* sB1,
-                                             const float* sB2, const float4* tGi, int lane, int hi, int x) {
-  [&]<int... Q>(std::integer_sequence<int, Q...>) {
-    (
-        [&] {
-          const int q = g * G::QT + Q;
-          if (q < p.B && (only < 0 || q == only)) {
-            const float4* gq4 = reinterpret_cast<const float4*>(p.gqfrag + (int64_t)q * G::L + hi * G::E);
-            float out;
-            if constexpr (SPLIT) out = query_mlp_split<G, PX, Q * G::RPQ>(D1, smem, tGi, gq4, lane, hi, p);
-            else out = query_mlp<G, PX, Q * G::RPQ>(D1, sW1, sW2, sB1, sB2, tGi, gq4, lane, hi);
-            const int64_t item = item0 + x;
-            if (hi == 0 && item < p.n_items) p.logits[(int64_t)q * p.ld + item] = out;
-          }
-        }(),
-        ...);
-  }(std::make_integer_sequence<int, G::QT>{});
-}
-
-template <class G, int NW>
-__device__ __forceinline__ void stage_weights(const ScoreArgs& p, float* smem) {
-  const float4* src = reinterpret_cast<const float4*>(p.wpack);
-  float4* dst = reinterpret_cast<float4*>(smem);
-  for (int i = threadIdx.x; i < G::kWpackFloats / 4; i += NW * 64) dst[i] = src[i];
-}
-
-// ---------------------------------------------------------------------------------------------
-// Kernel A ("direct"): every wave is independent and reads its tile straight from HBM/L2.
-// Used when fewer than 8 query groups exist (B < 8 * 32/P_Q), for per-row candidates, and for shapes whose
-// tile does not fit LDS twice.  unit = (tile, query group), groups fastest.
-// ---------------------------------------------------------------------------------------------
-template <int PQ, int PX, int DD, int H, int NW, bool SPLIT>
-__global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(ScoreArgs p) {
-  using G = Geo<PQ, PX, DD, H>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const float4* sW1 = reinterpret_cast<const float4*>(smem);
-  const float4* sW2 = sW1 + G::kW1Floats / 4;
-  const float* sB1 = smem + G::kW1Floats + G::kW2Floats;
-  const float* sB2 = sB1 + H;
-  stage_weights<G, NW>(p, smem);
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int hi = lane >> 5, x = lane & 31;
-  const int inner = p.per_row ? (int)p.n_tiles : p.n_groups;
-  const int64_t n_units = p.per_row ? (int64_t)p.B * p.n_tiles : p.n_tiles * p.n_groups;
-  // Full rounds: the NW waves of a workgroup take NW consecutive units (the query groups of one item tile, so the tile's
-  // fragments are shared through L1).  The leftover round is dealt wave-major instead -- unit r goes to workgroup
-  // r % grid, wave r / grid -- so that it lands one unit per SIMD across the whole chip rather than two per SIMD on the
-  // first few CUs (ML-20M: 6824 units on 1024 SIMDs, worst SIMD 7 passes instead of 8; ML-1M: all 256 CUs busy).
-  const int64_t stride = (int64_t)gridDim.x * NW;
-  const int64_t rounds = n_units / stride;
-  for (int64_t it = 0; it <= rounds; ++it) {
-    const int64_t u = it < rounds ? it * stride + (int64_t)blockIdx.x * NW + wave
-                                  : rounds * stride + (int64_t)wave * gridDim.x + blockIdx.x;
-    if (u >= n_units) break;
-    const int64_t outer = u / inner;
-    const int innr = (int)(u - outer * inner);
-    const int64_t tile = p.per_row ? innr : outer;  // tile index inside the row / corpus
-    const int row = p.per_row ? (int)outer : -1;    // per-row mode: the only query of this unit
-    const int g = p.per_row ? row / G::QT : innr;
-    const int64_t tile_addr = p.per_row ? (int64_t)row * p.n_tiles + tile : tile;
-    const float4* tEx = reinterpret_cast<const float4*>(p.ipack + tile_addr * (int64_t)G::kTileFloats);
-    const float4* tGi = tEx + G::kTileExFloats / 4;
-    const float4* eq = reinterpret_cast<const float4*>(p.eqfrag + (int64_t)g * G::kEqGroupFloats);
-    f32x16 D1[PX];
-    if constexpr (SPLIT) gemm1_split<G, PX, DD>(D1, eq, tEx, lane, p.cl_scale);
-    else gemm1<G, PX, DD>(D1, eq, tEx, lane);
-    unit_queries<G, PX, SPLIT>(D1, p, g, row, tile * kTileItems, smem, sW1, sW2, sB1, sB2, tGi, lane, hi, x);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Kernel B ("staged"): the workgroup's 8 waves share one item tile per step.  The tile is copied
-// HBM -> LDS by LDS-DMA (global_load_lds, 1 KiB per wave-instruction, no registers) one tile ahead of
-// its use, double buffered, so each tile is read from HBM exactly once per batch and its latency is
-// hidden behind a whole tile of MFMA work.  One barrier per tile.
-// ---------------------------------------------------------------------------------------------
-template <class G, int NW>
-__device__ __forceinline__ void dma_tile(const float* __restrict__ src_tile, float* lds_tile, int wave, int lane) {
-  constexpr int kPieces = G::kTileFloats / 256;  // 1 KiB pieces
-  static_assert(G::kTileFloats % 256 == 0, "tile must be a whole number of 1 KiB pieces");
-  for (int piece = wave; piece < kPieces; piece += NW) {
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(src_tile + piece * 256 + lane * 4),
-        (__attribute__((address_space(3))) void*)(lds_tile + piece * 256), 16, 0, 0);
-  }
-}
-
-template <int PQ, int PX, int DD, int H, int NW, bool SPLIT>
-__global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(ScoreArgs p) {
-  using G = Geo<PQ, PX, DD, H>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const float4* sW1 = reinterpret_cast<const float4*>(smem);
-  const float4* sW2 = sW1 + G::kW1Floats / 4;
-  const float* sB1 = smem + G::kW1Floats + G::kW2Floats;
-  const float* sB2 = sB1 + H;
-  float* tiles = smem + G::kWpackFloats;  // two tile buffers
-  stage_weights<G, NW>(p, smem);
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int hi = lane >> 5, x = lane & 31;
-  const int64_t first = blockIdx.x;
-  if (first < p.n_tiles) dma_tile<G, NW>(p.ipack + first * (int64_t)G::kTileFloats, tiles, wave, lane);
-  int cur = 0;
-  for (int64_t tile = first; tile < p.n_tiles; tile += gridDim.x, cur ^= 1) {
-    // (1) my pieces of `tile` have landed (vmcnt(0)); (2) barrier: every wave's pieces have, and every wave
-    // is done with the previous tile, so the other buffer may be overwritten
-    __syncthreads();
-    const int64_t next = tile + gridDim.x;
-    if (next < p.n_tiles) dma_tile<G, NW>(p.ipack + next * (int64_t)G::kTileFloats, tiles + (cur ^ 1) * G::kTileFloats, wave, lane);
-    const float4* tEx = reinterpret_cast<const float4*>(tiles + cur * G::kTileFloats);
-    const float4* tGi = tEx + G::kTileExFloats / 4;
-    for (int g = wave; g < p.n_groups; g += NW) {
-      const float4* eq = reinterpret_cast<const float4*>(p.eqfrag + (int64_t)g * G::kEqGroupFloats);
-      f32x16 D1[PX];
-      if constexpr (SPLIT) gemm1_split<G, PX, DD>(D1, eq, tEx, lane, p.cl_scale);
-      else gemm1<G, PX, DD>(D1, eq, tEx, lane);
-      unit_queries<G, PX, SPLIT>(D1, p, g, -1, tile * kTileItems, smem, sW1, sW2, sB1, sB2, tGi, lane, hi, x);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Kernel B1 ("staged, single Ex buffer"): for shapes whose tile does not fit LDS twice next to the gate weights
-// (8x4x128: 68 KiB tiles).  The sub-embedding part of a tile (Ex, 94 % of it) is only read by GEMM1, the first ~15 % of a
-// unit; the gate part (gi) is read at the end.  So ONE Ex buffer is enough: after a second barrier ("every wave is past
-// its last GEMM1") the next tile's Ex is DMA'd into the same buffer while the waves run the long gate MLP; gi is double
-// buffered (4 KiB each).  LDS: weights + Ex + 2 gi = 107 KiB for 8x4x128.
-//
-// Leftover round: when the tiles left after the full rounds are at most half the grid, each is shared by
-// nsub = grid / leftover workgroups that split its query groups (group = sub + nsub * wave), so the round runs one unit
-// per SIMD instead of two on a few CUs (ML-20M: 853 tiles on 256 CUs -> 3 full rounds + 85 leftover tiles x 3 workgroups).
-// ---------------------------------------------------------------------------------------------
-template <int NW>
-__device__ __forceinline__ void dma_floats(const float* __restrict__ src, float* lds, int n_floats, int wave, int lane) {
-  for (int piece = wave; piece < n_floats / 256; piece += NW) {   // 1 KiB pieces
-    __builtin_amdgcn_global_load_lds(
-        (const __attribute__((address_space(1))) void*)(src + piece * 256 + lane * 4),
-        (__attribute__((address_space(3))) void*)(lds + piece * 256), 16, 0, 0);
-  }
-}
-
-template <int PQ, int PX, int DD, int H, int NW, bool SPLIT>
-__global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged1_kernel(ScoreArgs p) {
-  using G = Geo<PQ, PX, DD, H>;
-  static_assert(G::kTileExFloats % 256 == 0 && G::kTileGiFloats % 256 == 0, "1 KiB DMA pieces");
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const float4* sW1 = reinterpret_cast<const float4*>(smem);
-  const float4* sW2 = sW1 + G::kW1Floats / 4;
-  const float* sB1 = smem + G::kW1Floats + G::kW2Floats;
-  const float* sB2 = sB1 + H;
-  float* sEx = smem + G::kWpackFloats;
-  float* sGi = sEx + G::kTileExFloats;   // two gi buffers
-
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int hi = lane >> 5, x = lane & 31;
-  const int64_t grid = gridDim.x, b = blockIdx.x;
-  const int64_t rounds = p.n_tiles / grid;
-  const int64_t left = p.n_tiles - rounds * grid;
-  int nsub = 1;
-  if (left > 0 && left * 2 <= grid) {
-    nsub = (int)(grid / left);
-    if (nsub > NW) nsub = NW;
-    if (nsub > p.n_groups) nsub = p.n_groups;
-  }
-  const bool has_left = b < left * nsub;
-  const int64_t mine = rounds + (has_left ? 1 : 0);
-  if (mine == 0) return;
-  stage_weights<G, NW>(p, smem);
-  auto tile_of = [&](int64_t i) -> int64_t { return i < rounds ? b + i * grid : rounds * grid + b % left; };
-
-  {
-    const float* t0 = p.ipack + tile_of(0) * (int64_t)G::kTileFloats;
-    dma_floats<NW>(t0, sEx, G::kTileExFloats, wave, lane);
-    dma_floats<NW>(t0 + G::kTileExFloats, sGi, G::kTileGiFloats, wave, lane);
-  }
-  int cur = 0;
-  for (int64_t i = 0; i < mine; ++i, cur ^= 1) {
-    const int64_t tile = tile_of(i);
-    const bool split_round = i >= rounds && nsub > 1;
-    const int off = split_round ? (int)(b / left) : 0, stride = split_round ? nsub : 1;
-    const int cnt = (p.n_groups - off + stride - 1) / stride;   // query groups of this tile handled here (>= 1)
-    const int n_it = (cnt + NW - 1) / NW;
-    // (1) my DMA pieces of `tile` have landed (vmcnt(0)); (2) barrier: every wave's pieces have, and every wave is
-    // done with the previous tile's gi buffer
-    __syncthreads();
-    const float4* tEx = reinterpret_cast<const float4*>(sEx);
-    const float4* tGi = reinterpret_cast<const float4*>(sGi + cur * G::kTileGiFloats);
-    for (int it = 0; it < n_it; ++it) {
-      const int gi_idx = wave + it * NW;
-      const bool has = gi_idx < cnt;
-      const int g = off + stride * gi_idx;
-      f32x16 D1[PX];
-      if (has) {
-        const float4* eq = reinterpret_cast<const float4*>(p.eqfrag + (int64_t)g * G::kEqGroupFloats);
-        if constexpr (SPLIT) gemm1_split<G, PX, DD>(D1, eq, tEx, lane, p.cl_scale);
-        else gemm1<G, PX, DD>(D1, eq, tEx, lane);
-      }
-      if (it == n_it - 1) {
-        __syncthreads();   // every wave is past its last GEMM1 of this tile: the Ex buffer is free
-        if (i + 1 < mine) {
-          const float* tn = p.ipack + tile_of(i + 1) * (int64_t)G::kTileFloats;
-          dma_floats<NW>(tn, sEx, G::kTileExFloats, wave, lane);
-          dma_floats<NW>(tn + G::kTileExFloats, sGi + (cur ^ 1) * G::kTileGiFloats, G::kTileGiFloats, wave, lane);
-        }
-      }
-      if (has) unit_queries<G, PX, SPLIT>(D1, p, g, -1, tile * kTileItems, smem, sW1, sW2, sB1, sB2, tGi, lane, hi, x);
-    }
-  }
-}
+};
 
 // ---------------------------------------------------------------------------------------------
 // Kernel C ("ksplit"): shapes whose logit axis is too long for the register-resident scheme above
@@ -926,92 +552,17 @@ static int launch_ksplit(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
-// RAILS_SCORE_VARIANT: 0 = pick automatically; 1 / 2 = force direct / staged with 8 waves (2 per SIMD);
-// 3 / 4 = direct / staged with 4 waves (1 per SIMD, 512 registers); 5 = staged with a single Ex buffer (8 waves)
-static int score_variant() {
-  const char* e = getenv("RAILS_SCORE_VARIANT");
-  return e ? atoi(e) : 0;
-}
-
-template <int PQ, int PX, int DD, int H, int NW, bool STAGED, bool SPLIT>
-static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
-  using G = Geo<PQ, PX, DD, H>;
-  constexpr size_t lds = ((size_t)G::kWpackFloats + (STAGED ? 2 * (size_t)G::kTileFloats : 0)) * sizeof(float);
-  if constexpr (lds > 160 * 1024) {
-    set_error("staged scoring kernel needs %zu B of LDS", lds);
-    return kErrUnsupported;
-  } else {
-    const void* fn = STAGED ? reinterpret_cast<const void*>(&mol_score_staged_kernel<PQ, PX, DD, H, NW, SPLIT>)
-                            : reinterpret_cast<const void*>(&mol_score_direct_kernel<PQ, PX, DD, H, NW, SPLIT>);
-    static DynLdsOnce once;
-    if (ensure_dyn_lds(once, fn, (int)lds) != kOk) return kErrLaunch;
-    const int wg_per_cu = (NW == 4 && lds <= 80 * 1024) ? 2 : 1;
-    int64_t grid;
-    if (STAGED) {
-      grid = a.n_tiles;
-    } else {
-      const int64_t n_units = a.per_row ? (int64_t)a.B * a.n_tiles : a.n_tiles * a.n_groups;
-      grid = n_units;   // fewer units than wave slots: one unit per workgroup first (wave-major remainder mapping)
-    }
-    if (grid > (int64_t)n_cu * wg_per_cu) grid = (int64_t)n_cu * wg_per_cu;
-    if (grid < 1) return kOk;
-    if (STAGED)
-      hipLaunchKernelGGL((mol_score_staged_kernel<PQ, PX, DD, H, NW, SPLIT>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
-    else
-      hipLaunchKernelGGL((mol_score_direct_kernel<PQ, PX, DD, H, NW, SPLIT>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
-    return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
-  }
-}
-
-template <int PQ, int PX, int DD, int H, bool SPLIT>
-static int launch_staged1(const ScoreArgs& a, int n_cu, hipStream_t stream) {
-  using G = Geo<PQ, PX, DD, H>;
-  constexpr int NW = 8;
-  constexpr size_t lds = ((size_t)G::kWpackFloats + (size_t)G::kTileExFloats + 2 * (size_t)G::kTileGiFloats) * sizeof(float);
-  if constexpr (lds > 160 * 1024) {
-    set_error("single-buffer staged scoring kernel needs %zu B of LDS", lds);
-    return kErrUnsupported;
-  } else {
-    static DynLdsOnce once;
-    if (ensure_dyn_lds(once, reinterpret_cast<const void*>(&mol_score_staged1_kernel<PQ, PX, DD, H, NW, SPLIT>), (int)lds) != kOk) return kErrLaunch;
-    if (a.n_tiles < 1) return kOk;
-    // always a full grid: the leftover-round split needs the idle workgroups (they exit at once otherwise)
-    hipLaunchKernelGGL((mol_score_staged1_kernel<PQ, PX, DD, H, NW, SPLIT>), dim3((unsigned)n_cu), dim3(NW * 64), lds, stream, a);
-    return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
-  }
-}
-
 template <int PQ, int PX, int DD, int H>
 static int launch_score(const ScoreArgs& a, int n_cu, hipStream_t stream) {
-  using G = Geo<PQ, PX, DD, H>;
-  constexpr bool staged_fits = ((size_t)G::kWpackFloats + 2 * (size_t)G::kTileFloats) * sizeof(float) <= 160 * 1024;
-  int variant = score_variant();
-  if (variant == 0) {
-    constexpr bool staged1_fits = ((size_t)G::kWpackFloats + (size_t)G::kTileExFloats + 2 * (size_t)G::kTileGiFloats) * sizeof(float) <= 160 * 1024;
-    variant = 1;                                            // few query groups / per-row candidates: independent waves
-    if (!a.per_row && a.n_groups >= kScoreWaves) {
-      // double-buffered tiles where they fit and the corpus fills the chip for many rounds (the measured headline path);
-      // otherwise the single-Ex-buffer kernel: 8x4x128 tiles only fit once, and its leftover-round split is what keeps
-      // small corpora (ML-1M: 122 tiles, ML-20M: 853) spread over all CUs
-      if (staged_fits && a.n_tiles >= 8 * (int64_t)n_cu) variant = 2;
-      else if (staged1_fits) variant = 5;
-      else if (staged_fits) variant = 2;
-    }
-  }
+  using U = Fp32Unit;
+  const int variant = choose_variant<PQ, PX, DD, H>(a, n_cu);
   if ((variant == 2 || variant == 4 || variant == 5) && a.per_row) { set_error("staged scoring kernel does not do per-row candidates"); return kErrUnsupported; }
-  if (variant == 5) return a.split ? launch_staged1<PQ, PX, DD, H, true>(a, n_cu, stream) : launch_staged1<PQ, PX, DD, H, false>(a, n_cu, stream);
-  if (a.split) {
-    switch (variant) {
-      case 1: return launch_kernel<PQ, PX, DD, H, 8, false, true>(a, n_cu, stream);
-      case 2: return launch_kernel<PQ, PX, DD, H, 8, true, true>(a, n_cu, stream);
-      default: set_error("RAILS_SCORE_VARIANT %d has no f16x3 build", variant); return kErrInvalid;
-    }
-  }
   switch (variant) {
-    case 1: return launch_kernel<PQ, PX, DD, H, 8, false, false>(a, n_cu, stream);
-    case 2: return launch_kernel<PQ, PX, DD, H, 8, true, false>(a, n_cu, stream);
-    case 3: return launch_kernel<PQ, PX, DD, H, 4, false, false>(a, n_cu, stream);
-    case 4: return launch_kernel<PQ, PX, DD, H, 4, true, false>(a, n_cu, stream);
+    case 1: return launch_kernel<U, PQ, PX, DD, H, 8, false>(a, n_cu, stream);
+    case 2: return launch_kernel<U, PQ, PX, DD, H, 8, true>(a, n_cu, stream);
+    case 3: return launch_kernel<U, PQ, PX, DD, H, 4, false>(a, n_cu, stream);
+    case 4: return launch_kernel<U, PQ, PX, DD, H, 4, true>(a, n_cu, stream);
+    case 5: return launch_staged1<U, PQ, PX, DD, H, 8>(a, n_cu, stream);
     default: set_error("unknown RAILS_SCORE_VARIANT %d", variant); return kErrInvalid;
   }
 }
@@ -1019,12 +570,14 @@ static int launch_score(const ScoreArgs& a, int n_cu, hipStream_t stream) {
 bool score_supported(const Shape& s) {
   if (s.gating_qi_hidden_dim != 128) return false;
   const int pq = s.query_dot_product_groups, px = s.item_dot_product_groups, dd = s.dot_product_dimension;
+  if (is_split(s) && pq == 16) return false;   // f16x3 is not built for 16x16x64
   return (pq == 8 && px == 4 && dd == 64) || (pq == 8 && px == 4 && dd == 128) || (pq == 8 && px == 8 && dd == 32) ||
          (pq == 16 && px == 16 && dd == 64);
 }
 
 int score_launch(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream) {
   if (!score_supported(s)) return kErrUnsupported;
+  if (a.split) return score_launch_f16(s, a, n_cu, stream);
 #define MOL_CASE(pq, px, dd)                                                                             \
   if (s.query_dot_product_groups == pq && s.item_dot_product_groups == px && s.dot_product_dimension == dd) \
     return launch_score<pq, px, dd, 128>(a, n_cu, stream);
@@ -1033,7 +586,6 @@ int score_launch(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t strea
   MOL_CASE(8, 8, 32)
 #undef MOL_CASE
   if (s.query_dot_product_groups == 16 && s.item_dot_product_groups == 16 && s.dot_product_dimension == 64) {
-    if (a.split) { set_error("the f16x3 precision mode is not built for 16x16x64"); return kErrUnsupported; }
     return launch_ksplit<16, 16, 64, 128, 4>(a, n_cu, stream);
   }
   return kErrUnsupported;

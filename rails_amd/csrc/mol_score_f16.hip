@@ -1,0 +1,562 @@
+// Fused MoL scoring, precision mode "f16x3": the three contractions of a (query, item) pair
+//
+//   cl = <Eq, Ex>/tau  ->  hid = silu(W1 cl + b1)  ->  gqi = W2 hid + b2          (similarity_fn.py:389-405, :148-201)
+//
+// run on v_mfma_f32_32x32x16_f16 with every operand split into f16 hi + f16 lo and three MFMAs per product block
+// (lo*hi, hi*lo, hi*hi), fp32 accumulate: ~22 significant bits per product at 3/16 of the fp32-MFMA time (mol_layout.h).
+// Same kernel shells, same buffers and the same 1e-4 logit bar as the exact build (mol_score.hip).
+//
+// What shapes this file (measured on the part, profiles/r02_ubench_f16_mfma_vs_valu.txt):
+//  * f16 MFMA overlaps with plain VALU work of the same or the partner wave (v_fma / v_cvt_pkrtz / v_fma_mix cost nothing
+//    next to an MFMA stream until the VALU itself saturates at ~4.7 cycles per instruction), but NOT with packed-fp32
+//    instructions (v_pk_*_f32: ~8 cycles each and they stall the matrix pipe) and only partly with transcendentals
+//    (v_exp / v_rcp: ~9 cycles, ~4 of them not overlappable).  So this kernel is VALU-bound, and every VALU instruction
+//    counts: no packed fp32 (the TU is built with -fno-slp-vectorize), no operand rescaling (f16 subnormals are kept by the
+//    MFMA and by v_cvt_pkrtz, so all power-of-two scales are 1), no in-kernel conversion of Ex / Eq (both arrive pre-split,
+//    written once by the index build / query prologue), v_fma_mixlo/hi avoided (transcendental-rate).
+//  * one wave's stream is software-pipelined so that MFMAs always have independent VALU work next to them:
+//      stage X(q)   GEMM2 of query q       ||  softmax/mixture epilogue of query q-1 (+ the operand split of cl)
+//      stage Y(q)   GEMM3 K-step s         ||  silu + operand split of K-step s+1
+//    Two waves per SIMD (or one with 512 registers) fill what is left.
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include <utility>
+
+#include "mol_kernels.h"
+#include "mol_layout.h"
+#include "mol_score_shell.h"
+
+namespace mol {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
+// Scheduling directives (LLVM AMDGPU IGroupLP): inside one scheduling region, "then N instructions of class M" in program
+// order of the calls.  Used to deal a region's VALU work between its MFMAs: the compiler's own schedule puts all VALU
+// first and the MFMAs last, which leaves each pipe idle while the other works (PMC: MFMA busy + VALU busy = 100 %).
+#define SG_VALU 0x002
+#define SG_MFMA 0x008
+#define SG_DS_READ 0x100
+#define SG_TRANS 0x400
+// N x { NV plain VALU, NT transcendental, 1 MFMA }
+template <int N, int NV, int NT>
+__device__ __forceinline__ void sched_interleave() {
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    __builtin_amdgcn_sched_group_barrier(SG_VALU, NV, 0);
+    __builtin_amdgcn_sched_group_barrier(SG_TRANS, NT, 0);
+    __builtin_amdgcn_sched_group_barrier(SG_MFMA, 1, 0);
+  }
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>): a compile-time loop whose index is usable as a
+// template argument (every register index of the unit is static)
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
+}
+
+// RAILS_F16_ABLATE (debug builds, tools/f16_ablation.sh): 1 = no MFMAs, 2 = no transcendentals, 3 = no VALU arithmetic at all --
+// wrong results, used to price each instruction class in situ
+#ifndef RAILS_F16_ABLATE
+#define RAILS_F16_ABLATE 0
+#endif
+__device__ __forceinline__ f32x16 mfma16(h8 a, h8 b, f32x16 c) {
+#if RAILS_F16_ABLATE == 1
+  asm volatile("" : "+v"(c) : "v"(a), "v"(b));
+  return c;
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ float f_exp2(float x) {
+#if RAILS_F16_ABLATE >= 2
+  return x * x;
+#else
+  return __builtin_amdgcn_exp2f(x);
+#endif
+}
+__device__ __forceinline__ float f_rcp(float x) {
+#if RAILS_F16_ABLATE >= 2
+  return x + 0.5f;
+#else
+  return __builtin_amdgcn_rcpf(x);
+#endif
+}
+__device__ __forceinline__ float swap32(float v) { return __shfl_xor(v, 32, 64); }
+
+// two fp32 values -> packed f16 hi (round toward zero) and packed f16 lo (the fp32 remainder x - hi, exact, RTZ to f16):
+// four full-rate VALU instructions per pair.  The remainder is one v_fma_mix_f32 (fma(f16 half of hi, -1.0, x) in fp32).
+// `m1` is -1.0 in a VGPR the compiler cannot see through: fma(fpext(h), m1, x) then selects v_fma_mix_f32 (a visible -1.0 is
+// folded into cvt + sub, two instructions), and unlike inline asm the instruction stays visible to the scheduler.
+__device__ __forceinline__ void split_pair(float x0, float x1, float m1, unsigned& hi, unsigned& lo) {
+#if RAILS_F16_ABLATE == 3
+  hi = __builtin_bit_cast(unsigned, x0);
+  lo = __builtin_bit_cast(unsigned, x1);
+  return;
+#endif
+  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+  const h2v h = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+  const float l0 = __builtin_fmaf((float)h.x, m1, x0), l1 = __builtin_fmaf((float)h.y, m1, x1);   // v_fma_mix_f32
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+}
+// this lane's 8 values of a K=16 step -> the step's hi and lo B operands
+__device__ __forceinline__ void split8(const float (&x)[8], float m1, h8& hi, h8& lo) {
+  u32x4v H, L;
+#pragma unroll
+  for (int pr = 0; pr < 4; ++pr) {
+    unsigned h, l;
+    split_pair(x[2 * pr], x[2 * pr + 1], m1, h, l);
+    H[pr] = h;
+    L[pr] = l;
+  }
+  hi = __builtin_bit_cast(h8, H);
+  lo = __builtin_bit_cast(h8, L);
+}
+// t / (1 + 2^t) on the -log2e-prescaled argument (mol_layout.h): exp2, add, rcp, mul
+__device__ __forceinline__ float nsilu(float t) {
+#if RAILS_F16_ABLATE == 3
+  return t;
+#else
+  const float e = f_exp2(t) + 1.0f;
+  return t * f_rcp(e);
+#endif
+}
+
+// LDS views of the split gate pack (rails_mol_pack_gate_weights with precision f16x3)
+template <class G>
+struct SplitPack {
+  const h8* w1hi; const h8* w1lo; const h8* w2hi; const h8* w2lo; const float* b1; const float* b2;
+  float m1;   // -1.0, opaque (split_pair)
+  __device__ __forceinline__ explicit SplitPack(const float* smem) {
+    m1 = -1.0f;
+    asm volatile("" : "+v"(m1));
+    constexpr int N8 = G::kW1Floats / 8;   // h8 fragments per half of a weight matrix (hi or lo)
+    w1hi = reinterpret_cast<const h8*>(smem);
+    w1lo = w1hi + N8;
+    w2hi = w1lo + N8;
+    w2lo = w2hi + N8;
+    b1 = smem + G::kW1Floats + G::kW2Floats;
+    b2 = b1 + G::TH * 32;
+  }
+};
+
+// GEMM1 on pre-split operands: eq = [ks][hi|lo][lane] h8 (query pack), tEx = [m][ks][hi|lo][lane] h8 (tile, LDS or HBM).
+template <class G, int PX, int DD>
+__device__ __forceinline__ void gemm1_presplit(f32x16 (&D1)[PX], const h8* __restrict__ eq, const h8* tEx, int lane) {
+  static_assert(DD % 16 == 0, "f16x3 GEMM1 walks K in steps of 16");
+#pragma unroll
+  for (int m = 0; m < PX; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) D1[m][r] = 0.0f;
+#pragma unroll
+  for (int ks = 0; ks < DD / 16; ++ks) {
+    const h8 ah = eq[(2 * ks) * 64 + lane], al = eq[(2 * ks + 1) * 64 + lane];
+    h8 bh[PX], bl[PX];
+#pragma unroll
+    for (int m = 0; m < PX; ++m) {
+      bh[m] = tEx[(m * (DD / 8) + 2 * ks) * 64 + lane];
+      bl[m] = tEx[(m * (DD / 8) + 2 * ks + 1) * 64 + lane];
+    }
+    // products outermost: consecutive MFMAs never share an accumulator (dependent-accumulate latency = 2 x issue time)
+#pragma unroll
+    for (int m = 0; m < PX; ++m) D1[m] = mfma16(al, bh[m], D1[m]);
+#pragma unroll
+    for (int m = 0; m < PX; ++m) D1[m] = mfma16(ah, bl[m], D1[m]);
+#pragma unroll
+    for (int m = 0; m < PX; ++m) D1[m] = mfma16(ah, bh[m], D1[m]);
+    // keep the operand fetches of later K-steps below this step's MFMAs (register pressure)
+    asm volatile("" ::: "memory");
+  }
+}
+
+// =================================================================================================================
+// The unit's instruction stream is laid out BY HAND: a phase is a list of MFMAs and a list of VALU "slices" (a few
+// instructions each, independent of the phase's MFMAs), emitted alternately with a scheduling fence after every MFMA, so
+// that in program order every MFMA is followed by its share of VALU work.  (Left alone the compiler emits all VALU of a
+// region, then all its MFMAs; IGroupLP's greedy solver only half fixes that and its exact solver does not terminate.)
+// =================================================================================================================
+template <int NM, int NS, class FM, class FS>
+__device__ __forceinline__ void interleave(FM&& mf, FS&& sf) {
+  static_for<NM>([&](auto ic) {
+    constexpr int I = decltype(ic)::value;
+    mf(ic);
+    constexpr int s0 = I * NS / NM, s1 = (I + 1) * NS / NM;
+    static_for<s1 - s0>([&](auto jc) { sf(std::integral_constant<int, s0 + decltype(jc)::value>{}); });
+    __builtin_amdgcn_sched_barrier(0);
+  });
+}
+
+// ---- softmax / mixture epilogue of one query, in slices of two logits ------------------------------------------------
+// softmax(w) is shift invariant and w = g*sigmoid(g) >= -0.2785, so the numerators are taken WITHOUT the usual maximum
+// subtraction: ex = exp(w) = 2^(-u) with u = -log2e * w <= 0.402, i.e. ex >= 0.757 (no underflow, the denominator is
+// >= 0.757 L) and ex overflows only for w > 88.7, a gate logit no trained model produces.  That saves a min3 per pair, a
+// subtraction per logit and the cross-lane minimum; an overflow is detected on the denominator (inf / NaN) and that
+// query is redone with the shifted form from the u values, which are still in registers -- same result as the
+// reference's stable softmax (similarity_fn.py:31-46) in every case.
+template <class G>
+struct Epi {
+  f32x16 D3[G::TL];   // -log2e * gqi on entry; u after pass 1
+  float den, num;
+  const float* gq;    // this query's -log2e * gq row, lane half's part ([hi][e] layout)
+  __device__ __forceinline__ void reset(const float* gq_) { den = 0.0f; num = 0.0f; gq = gq_; }
+};
+// pass 1, logits e = 2P, 2P+1 of this lane:  t2 = -log2e*(gq*gi + gqi);  u = t2/(1+2^t2) = -log2e * g*sigmoid(g)
+template <class G, int P>
+__device__ __forceinline__ void epi_p1(Epi<G>& s, const float* tGi, int lane) {
+  constexpr int e = 2 * P;
+  // gi fragment [ec = e/4][lane][4]: this pair is floats (e%4, e%4+1) of the lane's float4
+  const float2 gi = *reinterpret_cast<const float2*>(tGi + ((e / 4) * 64 + lane) * 4 + e % 4);
+  const float2 gq = *reinterpret_cast<const float2*>(s.gq + e);
+  s.D3[e / 16][e % 16] = nsilu(__builtin_fmaf(gq.x, gi.x, s.D3[e / 16][e % 16]));
+  s.D3[e / 16][e % 16 + 1] = nsilu(__builtin_fmaf(gq.y, gi.y, s.D3[e / 16][e % 16 + 1]));
+}
+// pass 2:  ex = 2^(-u) = softmax numerator;  den += ex;  num += ex * cl   (cl of this query: D1 registers R0 + ...)
+template <class G, int PX, int R0, int P>
+__device__ __forceinline__ void epi_p2(Epi<G>& s, const f32x16 (&D1)[PX]) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    constexpr int e0 = 2 * P;
+    const int e = e0 + j;
+    const float ex = f_exp2(-s.D3[e / 16][e % 16]);
+    s.den += ex;
+    s.num = __builtin_fmaf(ex, D1[e / G::RPQ][R0 + e % G::RPQ], s.num);
+  }
+}
+// slice S of the E slices of an epilogue: S < E/2 -> pass 1 of pair S; else pass 2 of pair S - E/2
+template <class G, int PX, int R0, int S>
+__device__ __forceinline__ void epi_slice(Epi<G>& s, const f32x16 (&D1)[PX], const float* tGi, int lane) {
+  constexpr int HALF = G::E / 2;
+  if constexpr (S < HALF) epi_p1<G, S>(s, tGi, lane);
+  else epi_p2<G, PX, R0, S - HALF>(s, D1);
+}
+// pi = ex/den, then the eval-time renormalisation pi / clamp(sum pi, 1e-6) (similarity_fn.py:42-46): sum pi = den * (1/den)
+template <class G, int PX, int R0>
+__device__ __forceinline__ float epi_final(Epi<G>& s, const f32x16 (&D1)[PX]) {
+  float den = s.den + swap32(s.den), num = s.num + swap32(s.num);
+  if (__builtin_amdgcn_ballot_w64(!(den < 3.0e38f)) != 0) {   // an exp overflowed somewhere in this wave: the stable form
+    float mn = INFINITY;
+#pragma unroll
+    for (int e = 0; e < G::E; ++e) mn = __builtin_fminf(mn, s.D3[e / 16][e % 16]);
+    mn = __builtin_fminf(mn, swap32(mn));
+    den = 0.0f;
+    num = 0.0f;
+#pragma unroll
+    for (int e = 0; e < G::E; ++e) {
+      const float ex = f_exp2(mn - s.D3[e / 16][e % 16]);
+      den += ex;
+      num = __builtin_fmaf(ex, D1[e / G::RPQ][R0 + e % G::RPQ], num);
+    }
+    den += swap32(den);
+    num += swap32(num);
+  }
+  const float rden = __builtin_amdgcn_rcpf(den);
+  return (num * rden) / fmaxf(den * rden, 1e-6f);
+}
+
+// ---- the two gate GEMMs as MFMA sequences ---------------------------------------------------------------------------
+// A stage has T row tiles, NK K-steps and three products per (row tile, K-step): lo*hi, hi*lo, hi*hi.  The dependent-
+// accumulate latency of v_mfma_f32_32x32x16_f16 is twice its issue time (64 vs 32 cycles: back-to-back MFMAs into one
+// accumulator run at half rate -- the MFMA-only ablation of the first hand-ordered version took 1.78 ms against 1.0), so
+// consecutive MFMAs always alternate between two accumulators:
+//   T even:  row tiles in pairs (a, b); per pair and K-step  p0a p0b p1a p1b p2a p2b
+//   T == 1:  the single row tile accumulates into two partial accumulators, MFMA n -> accumulator n & 1, summed at the end
+// Weight fragments sit in four register slots (lo/hi x a/b); a slot is refilled from LDS right after its last use, i.e.
+// >= 4 MFMAs before the next use, with no second buffer.
+template <int T, int NK>
+struct Seq {
+  static_assert(T == 1 || T % 2 == 0, "row tiles: one, or an even number");
+  static constexpr int N = 3 * T * NK;
+  static constexpr int GS = T == 1 ? 1 : 2;             // row tiles per group
+  static constexpr int NGRP = T * NK / GS;              // groups of the stage, K-step major
+  static constexpr int PER = 3 * GS;                    // MFMAs per group
+  static constexpr int group(int I) { return I / PER; }
+  static constexpr int kstep(int I) { return group(I) / (T / GS); }
+  static constexpr int side(int I) { return T == 1 ? 0 : (I % PER) & 1; }              // a / b
+  static constexpr int prod(int I) { return T == 1 ? I % 3 : (I % PER) / 2; }
+  static constexpr int tile(int I) { return T == 1 ? 0 : GS * (group(I) % (T / GS)) + side(I); }
+  static constexpr int acc(int I) { return T == 1 ? (I & 1) : tile(I); }                // accumulator index (T == 1: two partials)
+  static constexpr int frag(int grp, int sd) { return T == 1 ? grp : (grp / (T / GS)) * T + GS * (grp % (T / GS)) + sd; }   // [ks][tile]
+};
+struct WSlots { h8 lo[2], hi[2]; };   // [side]
+
+// one MFMA of a stage + the slot refills that become possible after it.  W(hi?, fragment) reads a weight fragment from LDS.
+template <class S, int I, int NACC, class WF>
+__device__ __forceinline__ void seq_mfma(f32x16 (&acc)[NACC], WSlots& ws, h8 bh, h8 bl, WF&& W) {
+  constexpr int sd = S::side(I), pr = S::prod(I), grp = S::group(I);
+  f32x16& d = acc[S::acc(I)];
+  if constexpr (pr == 0) d = mfma16(ws.lo[sd], bh, d);
+  else if constexpr (pr == 1) d = mfma16(ws.hi[sd], bl, d);
+  else d = mfma16(ws.hi[sd], bh, d);
+  if constexpr (grp + 1 < S::NGRP) {
+    if constexpr (pr == 0) ws.lo[sd] = W(false, S::frag(grp + 1, sd));
+    if constexpr (pr == 2) ws.hi[sd] = W(true, S::frag(grp + 1, sd));
+  }
+}
+template <class S, class WF>
+__device__ __forceinline__ void seq_begin(WSlots& ws, WF&& W) {
+#pragma unroll
+  for (int sd = 0; sd < S::GS; ++sd) {
+    ws.lo[sd] = W(false, S::frag(0, sd));
+    ws.hi[sd] = W(true, S::frag(0, sd));
+  }
+}
+
+// ---- stage X: GEMM2 of the query whose cl sit in D1 registers [R0, R0 + RPQ):  D2 = -log2e * (b1 + W1 cl) -----------
+template <class G>
+struct XState {
+  WSlots ws;
+  h8 bh, bl;         // current K-step's cl operand, split right before the K-step's first MFMA
+};
+template <class G>
+__device__ __forceinline__ void init_d2(f32x16 (&D2)[G::TH], const SplitPack<G>& w, int hi) {
+#pragma unroll
+  for (int t = 0; t < G::TH; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) D2[t][r] = w.b1[t * 32 + hi * 16 + r];
+}
+template <class G, int PX, int R0, int KS>
+__device__ __forceinline__ void cl_split(const f32x16 (&D1)[PX], const SplitPack<G>& w, h8& bh, h8& bl) {
+  float xs[8];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj) {
+    const int e = 8 * KS + jj;
+    xs[jj] = D1[e / G::RPQ][R0 + e % G::RPQ];
+  }
+  split8(xs, w.m1, bh, bl);
+}
+template <class G>
+using XSeq = Seq<G::TH, G::E / 8>;
+template <class G>
+__device__ __forceinline__ void x_begin(XState<G>& st, const SplitPack<G>& w, int lane) {
+  static_assert(G::TH % 2 == 0, "stage X keeps one accumulator per row tile: the hidden dim must be a multiple of 64");
+  seq_begin<XSeq<G>>(st.ws, [&](bool hi_part, int f) { return (hi_part ? w.w1hi : w.w1lo)[f * 64 + lane]; });
+}
+template <class G, int PX, int R0, int I>
+__device__ __forceinline__ void x_mfma(const f32x16 (&D1)[PX], f32x16 (&D2)[G::TH], XState<G>& st, const SplitPack<G>& w, int lane) {
+  using S = XSeq<G>;
+  if constexpr (I % (3 * G::TH) == 0) cl_split<G, PX, R0, S::kstep(I)>(D1, w, st.bh, st.bl);
+  seq_mfma<S, I>(D2, st.ws, st.bh, st.bl, [&](bool hi_part, int f) { return (hi_part ? w.w1hi : w.w1lo)[f * 64 + lane]; });
+}
+
+// ---- stage Y: hid' = t/(1+2^t);  D3 = -log2e * (b2 + W2 hid) -----------------------------------------------------------
+// The B operand of K-step s+1 (silu + split of 8 hidden values, four slices of one value pair each) is produced under the
+// MFMAs of K-step s, into the other of two operand slots.
+template <class G>
+struct YState {
+  static constexpr int NACC = G::TL == 1 ? 2 : G::TL;
+  f32x16 part[G::TL == 1 ? 2 : 1];   // TL == 1 only: the two partial accumulators (Seq); otherwise D3 itself is accumulated into
+  WSlots ws;
+  u32x4v bh[2], bl[2];  // hid operands of K-steps s (slot s & 1), built pair by pair
+};
+template <class G>
+using YSeq = Seq<G::TL, G::F / 8>;
+template <class G, int SL>   // slice SL: value pair SL % 4 of K-step SL / 4
+__device__ __forceinline__ void silu_slice(const f32x16 (&D2)[G::TH], YState<G>& st, const SplitPack<G>& w) {
+  constexpr int ks = SL / 4, pr = SL % 4, f = 8 * ks + 2 * pr;
+  const float h0 = nsilu(D2[f / 16][f % 16]), h1 = nsilu(D2[f / 16][f % 16 + 1]);
+  unsigned h, l;
+  split_pair(h0, h1, w.m1, h, l);
+  st.bh[ks & 1][pr] = h;
+  st.bl[ks & 1][pr] = l;
+}
+template <class G>
+__device__ __forceinline__ void y_begin(f32x16 (&D3)[G::TL], YState<G>& st, const SplitPack<G>& w, int lane, int hi) {
+  if constexpr (G::TL == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      st.part[0][r] = w.b2[hi * G::E + r];
+      st.part[1][r] = 0.0f;
+    }
+  } else {
+#pragma unroll
+    for (int v = 0; v < G::TL; ++v)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) D3[v][r] = w.b2[hi * G::E + v * 16 + r];
+  }
+  seq_begin<YSeq<G>>(st.ws, [&](bool hi_part, int f) { return (hi_part ? w.w2hi : w.w2lo)[f * 64 + lane]; });
+}
+template <class G, int I>
+__device__ __forceinline__ void y_mfma(f32x16 (&D3)[G::TL], YState<G>& st, const SplitPack<G>& w, int lane) {
+  using S = YSeq<G>;
+  constexpr int ks = S::kstep(I);
+  auto W = [&](bool hi_part, int f) { return (hi_part ? w.w2hi : w.w2lo)[f * 64 + lane]; };
+  const h8 bh = __builtin_bit_cast(h8, st.bh[ks & 1]), bl = __builtin_bit_cast(h8, st.bl[ks & 1]);
+  if constexpr (G::TL == 1) seq_mfma<S, I>(st.part, st.ws, bh, bl, W);
+  else seq_mfma<S, I>(D3, st.ws, bh, bl, W);
+}
+template <class G>
+__device__ __forceinline__ void y_end(const YState<G>& st, f32x16 (&D3)[G::TL]) {
+  if constexpr (G::TL == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) D3[0][r] = st.part[0][r] + st.part[1][r];
+  }
+}
+
+#ifdef RAILS_F16_PHASES   // tools/f16_phases.sh: shader-clock stamps of workgroup 0 / wave 0's units (the last one stays)
+__device__ long long g_f16_phase[32];
+#define F16_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && item0 == 32 * 20 * (int64_t)gridDim.x) g_f16_phase[i] = (long long)clock64(); } while (0)
+#else
+#define F16_STAMP(i)
+#endif
+
+// OVERLAP: stage X of query Q+1 carries the epilogue of query Q (needs D2 and D3 of two queries live at once).
+// TIGHT:   the accumulators alone fill the register budget (8x8x32 at two waves per SIMD: 224 of 256): no operand double
+//          buffering in stage Y and no pinned order -- the compiler's own schedule fits without spilling, a pinned one does not.
+template <bool OVERLAP, bool TIGHT>
+struct F16Unit {
+  template <class G, int PX, int DD>
+  static __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float* __restrict__ eq, const float4* tEx, int lane) {
+    gemm1_presplit<G, PX, DD>(D1, reinterpret_cast<const h8*>(eq), reinterpret_cast<const h8*>(tEx), lane);
+  }
+
+  template <class G, int PX>
+  static __device__ __forceinline__ void queries(f32x16 (&D1)[PX], const ScoreArgs& p, int g, int only, int64_t item0,
+                                                 const float* smem, const float4* tGi4, int lane, int hi, int x) {
+    constexpr int NXM = (G::E / 8) * G::TH * 3;   // MFMAs of stage X
+    constexpr int NYM = (G::F / 8) * G::TL * 3;   // MFMAs of stage Y
+    constexpr int NYS = G::F / 8;                 // K-steps of stage Y
+    const SplitPack<G> w(smem);
+    const float* tGi = reinterpret_cast<const float*>(tGi4);
+    const int64_t item = item0 + x;
+    const bool lane_stores = hi == 0 && item < p.n_items;
+    // rows past the batch end (padding of the last group) run on zero operands and the last real gate row; never stored
+    auto gq_of = [&](int q) { return p.gqfrag + (int64_t)(q < p.B ? q : p.B - 1) * G::L + hi * G::E; };
+    auto store = [&](int q, float out) {
+      if (lane_stores && q < p.B) p.logits[(int64_t)q * p.ld + item] = out;
+    };
+
+    f32x16 D2[G::TH];
+    Epi<G> ep;
+    XState<G> xs;
+    YState<G> ys;
+    auto stage_x_alone = [&](auto qc) {   // GEMM2 with nothing to hide it under but the operand splits
+      constexpr int Q = decltype(qc)::value;
+      init_d2<G>(D2, w, hi);
+      x_begin<G>(xs, w, lane);
+      if constexpr (TIGHT) {
+        static_for<G::E / 8>([&](auto kc) {
+          static_for<3 * G::TH>([&](auto ic) { x_mfma<G, PX, Q * G::RPQ, 3 * G::TH * decltype(kc)::value + decltype(ic)::value>(D1, D2, xs, w, lane); });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        return;
+      }
+      interleave<NXM, 0>([&](auto ic) { x_mfma<G, PX, Q * G::RPQ, decltype(ic)::value>(D1, D2, xs, w, lane); }, [&](auto) {});
+    };
+    auto stage_y = [&](auto qc) {         // silu of K-step 0 exposed, then GEMM3 || silu of the following K-steps
+      y_begin<G>(ep.D3, ys, w, lane, hi);
+      if constexpr (TIGHT) {
+        static_for<NYS>([&](auto kc) {
+          constexpr int KS = decltype(kc)::value;
+          static_for<4>([&](auto sc) { silu_slice<G, 4 * KS + decltype(sc)::value>(D2, ys, w); });
+          static_for<3 * G::TL>([&](auto ic) { y_mfma<G, 3 * G::TL * KS + decltype(ic)::value>(ep.D3, ys, w, lane); });
+          __builtin_amdgcn_sched_barrier(0);   // K-steps stay in order (left alone the scheduler hoists every LDS read of the stage and spills)
+        });
+        y_end<G>(ys, ep.D3);
+        return;
+      }
+      static_for<4>([&](auto sc) { silu_slice<G, decltype(sc)::value>(D2, ys, w); });
+      __builtin_amdgcn_sched_barrier(0);
+      interleave<NYM - 3 * G::TL, 4 * (NYS - 1)>([&](auto ic) { y_mfma<G, decltype(ic)::value>(ep.D3, ys, w, lane); },
+                                                 [&](auto sc) { silu_slice<G, 4 + decltype(sc)::value>(D2, ys, w); });
+      static_for<3 * G::TL>([&](auto ic) { y_mfma<G, NYM - 3 * G::TL + decltype(ic)::value>(ep.D3, ys, w, lane); });
+      y_end<G>(ys, ep.D3);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto epilogue_alone = [&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      static_for<G::E>([&](auto sc) { epi_slice<G, PX, Q * G::RPQ, decltype(sc)::value>(ep, D1, tGi, lane); });
+      return epi_final<G, PX, Q * G::RPQ>(ep, D1);
+    };
+
+    if (only >= 0 || !OVERLAP) {
+      // per-row candidates (one query of the group), or the cross-query overlap switched off: query by query
+      static_for<G::QT>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        const int q = g * G::QT + Q;
+        if (only < 0 || q == only) {
+          F16_STAMP(4 * Q);
+          stage_x_alone(qc);
+          F16_STAMP(4 * Q + 1);
+          ep.reset(gq_of(q));
+          stage_y(qc);
+          F16_STAMP(4 * Q + 2);
+          store(q, epilogue_alone(qc));
+          F16_STAMP(4 * Q + 3);
+        }
+      });
+      return;
+    }
+    // shared corpus: all QT queries of the group in one straight-line stream;
+    // stage X of query Q+1 carries the epilogue of query Q between its MFMAs
+    F16_STAMP(0);
+    stage_x_alone(std::integral_constant<int, 0>{});
+    F16_STAMP(1);
+    static_for<G::QT>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      const int q = g * G::QT + Q;
+      ep.reset(gq_of(q));
+      stage_y(qc);
+      F16_STAMP(2 + 2 * Q);
+      if constexpr (Q + 1 < G::QT) {
+        init_d2<G>(D2, w, hi);
+        x_begin<G>(xs, w, lane);
+        interleave<NXM, G::E>([&](auto ic) { x_mfma<G, PX, (Q + 1) * G::RPQ, decltype(ic)::value>(D1, D2, xs, w, lane); },
+                              [&](auto sc) { epi_slice<G, PX, Q * G::RPQ, decltype(sc)::value>(ep, D1, tGi, lane); });
+        store(q, epi_final<G, PX, Q * G::RPQ>(ep, D1));
+      } else {
+        store(q, epilogue_alone(qc));
+      }
+      F16_STAMP(3 + 2 * Q);
+    });
+  }
+};
+
+// RAILS_F16_OVERLAP=0 disables the cross-query overlap of stage X (measurement override)
+static bool f16_overlap() {
+  const char* e = getenv("RAILS_F16_OVERLAP");
+  return e ? atoi(e) != 0 : true;
+}
+
+template <bool OVL, int PQ, int PX, int DD, int H>
+static int launch_f16(const ScoreArgs& a, int n_cu, hipStream_t stream) {
+  using G = Geo<PQ, PX, DD, H>;
+  // two waves per SIMD leave 256 registers per lane: when the accumulators of a unit (D1, D2, D3) take most of them, the
+  // untied stream without cross-query overlap is the one that does not spill
+  constexpr bool tight = (PX + G::TH + G::TL) * 16 > 200;
+  using U8 = std::conditional_t<tight, F16Unit<false, true>, F16Unit<OVL, false>>;
+  using U4 = F16Unit<OVL, false>;
+  const int variant = choose_variant<PQ, PX, DD, H>(a, n_cu);
+  if ((variant == 2 || variant == 4 || variant == 5 || variant == 6) && a.per_row) { set_error("staged scoring kernel does not do per-row candidates"); return kErrUnsupported; }
+  switch (variant) {
+    case 1: return launch_kernel<U8, PQ, PX, DD, H, 8, false>(a, n_cu, stream);
+    case 2: return launch_kernel<U8, PQ, PX, DD, H, 8, true>(a, n_cu, stream);
+    case 3: return launch_kernel<U4, PQ, PX, DD, H, 4, false>(a, n_cu, stream);
+    case 4: return launch_kernel<U4, PQ, PX, DD, H, 4, true>(a, n_cu, stream);
+    case 5: return launch_staged1<U8, PQ, PX, DD, H, 8>(a, n_cu, stream);
+    case 6: return launch_staged1<U4, PQ, PX, DD, H, 4>(a, n_cu, stream);
+    default: set_error("unknown RAILS_SCORE_VARIANT %d", variant); return kErrInvalid;
+  }
+}
+
+int score_launch_f16(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream) {
+#define MOL_CASE(pq, px, dd)                                                                                 \
+  if (s.query_dot_product_groups == pq && s.item_dot_product_groups == px && s.dot_product_dimension == dd)   \
+    return f16_overlap() ? launch_f16<true, pq, px, dd, 128>(a, n_cu, stream) : launch_f16<false, pq, px, dd, 128>(a, n_cu, stream);
+  MOL_CASE(8, 4, 64)
+  MOL_CASE(8, 4, 128)
+  MOL_CASE(8, 8, 32)
+#undef MOL_CASE
+  set_error("the f16x3 precision mode is not built for this shape");
+  return kErrUnsupported;
+}
+
+#ifdef RAILS_F16_PHASES
+}  // namespace mol
+extern "C" int rails_debug_f16_phases(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(mol::g_f16_phase), sizeof(long long) * 32) == hipSuccess ? 0 : -1;
+}
+namespace mol {
+#endif
+}  // namespace mol

@@ -1,0 +1,267 @@
+// Kernel shells of the fused MoL scoring pass, shared by the exact-fp32 build (mol_score.hip) and the f16x3 build
+// (mol_score_f16.hip).  A shell decides WHICH (query group, item tile) unit a wave works on and where the tile's operands
+// come from (HBM/L2 directly, or LDS filled by LDS-DMA one tile ahead); the arithmetic of a unit is a policy class U:
+//
+//   U::gemm1<G, PX, DD>(D1, eq, tEx, lane)              sub-embedding contraction of the unit -> D1[PX] accumulators
+//   U::queries<G, PX>(D1, p, g, only, item0, smem, tGi, lane, hi, x)
+//                                                       gate MLP + softmax mixture of every query of the group, stores
+//
+// Both builds use the same buffer sizes (the f16 hi/lo fragments of the f16x3 mode take exactly the bytes of the fp32
+// fragments they replace, mol_layout.h), so tile geometry, LDS budgets and DMA are common.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+
+#include "mol_kernels.h"
+#include "mol_layout.h"
+
+namespace mol {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <class G, int NW>
+__device__ __forceinline__ void stage_weights(const ScoreArgs& p, float* smem) {
+  const float4* src = reinterpret_cast<const float4*>(p.wpack);
+  float4* dst = reinterpret_cast<float4*>(smem);
+  for (int i = threadIdx.x; i < G::kWpackFloats / 4; i += NW * 64) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel A ("direct"): every wave is independent and reads its tile straight from HBM/L2.
+// Used when fewer than 8 query groups exist (B < 8 * 32/P_Q), for per-row candidates, and for shapes whose
+// tile does not fit LDS twice.  unit = (tile, query group), groups fastest.
+// ---------------------------------------------------------------------------------------------
+template <class U, int PQ, int PX, int DD, int H, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(ScoreArgs p) {
+  using G = Geo<PQ, PX, DD, H>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  stage_weights<G, NW>(p, smem);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5, x = lane & 31;
+  const int inner = p.per_row ? (int)p.n_tiles : p.n_groups;
+  const int64_t n_units = p.per_row ? (int64_t)p.B * p.n_tiles : p.n_tiles * p.n_groups;
+  // Full rounds: the NW waves of a workgroup take NW consecutive units (the query groups of one item tile, so the tile's
+  // fragments are shared through L1).  The leftover round is dealt wave-major instead -- unit r goes to workgroup
+  // r % grid, wave r / grid -- so that it lands one unit per SIMD across the whole chip rather than two per SIMD on the
+  // first few CUs (ML-20M: 6824 units on 1024 SIMDs, worst SIMD 7 passes instead of 8; ML-1M: all 256 CUs busy).
+  const int64_t stride = (int64_t)gridDim.x * NW;
+  const int64_t rounds = n_units / stride;
+  for (int64_t it = 0; it <= rounds; ++it) {
+    const int64_t u = it < rounds ? it * stride + (int64_t)blockIdx.x * NW + wave
+                                  : rounds * stride + (int64_t)wave * gridDim.x + blockIdx.x;
+    if (u >= n_units) break;
+    const int64_t outer = u / inner;
+    const int innr = (int)(u - outer * inner);
+    const int64_t tile = p.per_row ? innr : outer;  // tile index inside the row / corpus
+    const int row = p.per_row ? (int)outer : -1;    // per-row mode: the only query of this unit
+    const int g = p.per_row ? row / G::QT : innr;
+    const int64_t tile_addr = p.per_row ? (int64_t)row * p.n_tiles + tile : tile;
+    const float4* tEx = reinterpret_cast<const float4*>(p.ipack + tile_addr * (int64_t)G::kTileFloats);
+    const float4* tGi = tEx + G::kTileExFloats / 4;
+    const float* eq = p.eqfrag + (int64_t)g * G::kEqGroupFloats;
+    f32x16 D1[PX];
+    U::template gemm1<G, PX, DD>(D1, eq, tEx, lane);
+    U::template queries<G, PX>(D1, p, g, row, tile * kTileItems, smem, tGi, lane, hi, x);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel B ("staged"): the workgroup's waves share one item tile per step.  The tile is copied
+// HBM -> LDS by LDS-DMA (global_load_lds, 1 KiB per wave-instruction, no registers) one tile ahead of
+// its use, double buffered, so each tile is read from HBM exactly once per batch and its latency is
+// hidden behind a whole tile of MFMA work.  One barrier per tile.
+// ---------------------------------------------------------------------------------------------
+template <int NW>
+__device__ __forceinline__ void dma_floats(const float* __restrict__ src, float* lds, int n_floats, int wave, int lane) {
+  for (int piece = wave; piece < n_floats / 256; piece += NW) {   // 1 KiB pieces
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)(src + piece * 256 + lane * 4),
+        (__attribute__((address_space(3))) void*)(lds + piece * 256), 16, 0, 0);
+  }
+}
+
+template <class U, int PQ, int PX, int DD, int H, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(ScoreArgs p) {
+  using G = Geo<PQ, PX, DD, H>;
+  static_assert(G::kTileFloats % 256 == 0, "tile must be a whole number of 1 KiB pieces");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* tiles = smem + G::kWpackFloats;  // two tile buffers
+  stage_weights<G, NW>(p, smem);
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5, x = lane & 31;
+  const int64_t first = blockIdx.x;
+  if (first < p.n_tiles) dma_floats<NW>(p.ipack + first * (int64_t)G::kTileFloats, tiles, G::kTileFloats, wave, lane);
+  int cur = 0;
+  for (int64_t tile = first; tile < p.n_tiles; tile += gridDim.x, cur ^= 1) {
+    // (1) my pieces of `tile` have landed (vmcnt(0)); (2) barrier: every wave's pieces have, and every wave
+    // is done with the previous tile, so the other buffer may be overwritten
+    __syncthreads();
+    const int64_t next = tile + gridDim.x;
+    if (next < p.n_tiles) dma_floats<NW>(p.ipack + next * (int64_t)G::kTileFloats, tiles + (cur ^ 1) * G::kTileFloats, G::kTileFloats, wave, lane);
+    const float4* tEx = reinterpret_cast<const float4*>(tiles + cur * G::kTileFloats);
+    const float4* tGi = tEx + G::kTileExFloats / 4;
+    for (int g = wave; g < p.n_groups; g += NW) {
+      const float* eq = p.eqfrag + (int64_t)g * G::kEqGroupFloats;
+      f32x16 D1[PX];
+      U::template gemm1<G, PX, DD>(D1, eq, tEx, lane);
+      U::template queries<G, PX>(D1, p, g, -1, tile * kTileItems, smem, tGi, lane, hi, x);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel B1 ("staged, single Ex buffer"): for shapes whose tile does not fit LDS twice next to the gate weights
+// (8x4x128: 68 KiB tiles).  The sub-embedding part of a tile (Ex, 94 % of it) is only read by GEMM1, the first ~15 % of a
+// unit; the gate part (gi) is read at the end.  So ONE Ex buffer is enough: after a second barrier ("every wave is past
+// its last GEMM1") the next tile's Ex is DMA'd into the same buffer while the waves run the long gate MLP; gi is double
+// buffered (4 KiB each).  LDS: weights + Ex + 2 gi = 107 KiB for 8x4x128.
+//
+// Leftover round: when the tiles left after the full rounds are at most half the grid, each is shared by
+// nsub = grid / leftover workgroups that split its query groups (group = sub + nsub * wave), so the round runs one unit
+// per SIMD instead of two on a few CUs (ML-20M: 853 tiles on 256 CUs -> 3 full rounds + 85 leftover tiles x 3 workgroups).
+// ---------------------------------------------------------------------------------------------
+template <class U, int PQ, int PX, int DD, int H, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged1_kernel(ScoreArgs p) {
+  using G = Geo<PQ, PX, DD, H>;
+  static_assert(G::kTileExFloats % 256 == 0 && G::kTileGiFloats % 256 == 0, "1 KiB DMA pieces");
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sEx = smem + G::kWpackFloats;
+  float* sGi = sEx + G::kTileExFloats;   // two gi buffers
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5, x = lane & 31;
+  const int64_t grid = gridDim.x, b = blockIdx.x;
+  const int64_t rounds = p.n_tiles / grid;
+  const int64_t left = p.n_tiles - rounds * grid;
+  int nsub = 1;
+  if (left > 0 && left * 2 <= grid) {
+    nsub = (int)(grid / left);
+    if (nsub > NW) nsub = NW;
+    if (nsub > p.n_groups) nsub = p.n_groups;
+  }
+  const bool has_left = b < left * nsub;
+  const int64_t mine = rounds + (has_left ? 1 : 0);
+  if (mine == 0) return;
+  stage_weights<G, NW>(p, smem);
+  auto tile_of = [&](int64_t i) -> int64_t { return i < rounds ? b + i * grid : rounds * grid + b % left; };
+
+  {
+    const float* t0 = p.ipack + tile_of(0) * (int64_t)G::kTileFloats;
+    dma_floats<NW>(t0, sEx, G::kTileExFloats, wave, lane);
+    dma_floats<NW>(t0 + G::kTileExFloats, sGi, G::kTileGiFloats, wave, lane);
+  }
+  int cur = 0;
+  for (int64_t i = 0; i < mine; ++i, cur ^= 1) {
+    const int64_t tile = tile_of(i);
+    const bool split_round = i >= rounds && nsub > 1;
+    const int off = split_round ? (int)(b / left) : 0, stride = split_round ? nsub : 1;
+    const int cnt = (p.n_groups - off + stride - 1) / stride;   // query groups of this tile handled here (>= 1)
+    const int n_it = (cnt + NW - 1) / NW;
+    // (1) my DMA pieces of `tile` have landed (vmcnt(0)); (2) barrier: every wave's pieces have, and every wave is
+    // done with the previous tile's gi buffer
+    __syncthreads();
+    const float4* tEx = reinterpret_cast<const float4*>(sEx);
+    const float4* tGi = reinterpret_cast<const float4*>(sGi + cur * G::kTileGiFloats);
+    for (int it = 0; it < n_it; ++it) {
+      const int gi_idx = wave + it * NW;
+      const bool has = gi_idx < cnt;
+      const int g = off + stride * gi_idx;
+      f32x16 D1[PX];
+      if (has) U::template gemm1<G, PX, DD>(D1, p.eqfrag + (int64_t)g * G::kEqGroupFloats, tEx, lane);
+      if (it == n_it - 1) {
+        __syncthreads();   // every wave is past its last GEMM1 of this tile: the Ex buffer is free
+        if (i + 1 < mine) {
+          const float* tn = p.ipack + tile_of(i + 1) * (int64_t)G::kTileFloats;
+          dma_floats<NW>(tn, sEx, G::kTileExFloats, wave, lane);
+          dma_floats<NW>(tn + G::kTileExFloats, sGi + (cur ^ 1) * G::kTileGiFloats, G::kTileGiFloats, wave, lane);
+        }
+      }
+      if (has) U::template queries<G, PX>(D1, p, g, -1, tile * kTileItems, smem, tGi, lane, hi, x);
+    }
+  }
+}
+
+// ---- launch helpers ----------------------------------------------------------------------------------------------
+// RAILS_SCORE_VARIANT: 0 = pick automatically; 1 / 2 = force direct / staged with 8 waves (2 per SIMD);
+// 3 / 4 = direct / staged with 4 waves (1 per SIMD, 512 registers); 5 = staged with a single Ex buffer (8 waves);
+// 6 = staged with a single Ex buffer, 4 waves
+inline int score_variant() {
+  const char* e = getenv("RAILS_SCORE_VARIANT");
+  return e ? atoi(e) : 0;
+}
+
+template <class U, int PQ, int PX, int DD, int H, int NW, bool STAGED>
+static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
+  using G = Geo<PQ, PX, DD, H>;
+  constexpr size_t lds = ((size_t)G::kWpackFloats + (STAGED ? 2 * (size_t)G::kTileFloats : 0)) * sizeof(float);
+  if constexpr (lds > 160 * 1024) {
+    set_error("staged scoring kernel needs %zu B of LDS", lds);
+    return kErrUnsupported;
+  } else {
+    const void* fn = STAGED ? reinterpret_cast<const void*>(&mol_score_staged_kernel<U, PQ, PX, DD, H, NW>)
+                            : reinterpret_cast<const void*>(&mol_score_direct_kernel<U, PQ, PX, DD, H, NW>);
+    static DynLdsOnce once;
+    if (ensure_dyn_lds(once, fn, (int)lds) != kOk) return kErrLaunch;
+    const int wg_per_cu = (NW == 4 && lds <= 80 * 1024) ? 2 : 1;
+    int64_t grid;
+    if (STAGED) {
+      grid = a.n_tiles;
+    } else {
+      const int64_t n_units = a.per_row ? (int64_t)a.B * a.n_tiles : a.n_tiles * a.n_groups;
+      grid = n_units;   // fewer units than wave slots: one unit per workgroup first (wave-major remainder mapping)
+    }
+    if (grid > (int64_t)n_cu * wg_per_cu) grid = (int64_t)n_cu * wg_per_cu;
+    if (grid < 1) return kOk;
+    if (STAGED)
+      hipLaunchKernelGGL((mol_score_staged_kernel<U, PQ, PX, DD, H, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
+    else
+      hipLaunchKernelGGL((mol_score_direct_kernel<U, PQ, PX, DD, H, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+  }
+}
+
+template <class U, int PQ, int PX, int DD, int H, int NW>
+static int launch_staged1(const ScoreArgs& a, int n_cu, hipStream_t stream) {
+  using G = Geo<PQ, PX, DD, H>;
+  constexpr size_t lds = ((size_t)G::kWpackFloats + (size_t)G::kTileExFloats + 2 * (size_t)G::kTileGiFloats) * sizeof(float);
+  if constexpr (lds > 160 * 1024) {
+    set_error("single-buffer staged scoring kernel needs %zu B of LDS", lds);
+    return kErrUnsupported;
+  } else {
+    static DynLdsOnce once;
+    if (ensure_dyn_lds(once, reinterpret_cast<const void*>(&mol_score_staged1_kernel<U, PQ, PX, DD, H, NW>), (int)lds) != kOk) return kErrLaunch;
+    if (a.n_tiles < 1) return kOk;
+    // always a full grid: the leftover-round split needs the idle workgroups (they exit at once otherwise)
+    hipLaunchKernelGGL((mol_score_staged1_kernel<U, PQ, PX, DD, H, NW>), dim3((unsigned)n_cu), dim3(NW * 64), lds, stream, a);
+    return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+  }
+}
+
+// Which shell for this launch (0 = automatic): few query groups / per-row candidates -> independent waves (1);
+// double-buffered tiles where they fit and the corpus fills the chip for many rounds (2, the measured headline path);
+// otherwise the single-Ex-buffer kernel (5): 8x4x128 tiles only fit once, and its leftover-round split is what keeps small
+// corpora (ML-1M: 122 tiles, ML-20M: 853) spread over all CUs.
+template <int PQ, int PX, int DD, int H>
+inline int choose_variant(const ScoreArgs& a, int n_cu) {
+  using G = Geo<PQ, PX, DD, H>;
+  constexpr bool staged_fits = ((size_t)G::kWpackFloats + 2 * (size_t)G::kTileFloats) * sizeof(float) <= 160 * 1024;
+  constexpr bool staged1_fits = ((size_t)G::kWpackFloats + (size_t)G::kTileExFloats + 2 * (size_t)G::kTileGiFloats) * sizeof(float) <= 160 * 1024;
+  int variant = score_variant();
+  if (variant == 0) {
+    variant = 1;
+    if (!a.per_row && a.n_groups >= kScoreWaves) {
+      if (staged_fits && a.n_tiles >= 8 * (int64_t)n_cu) variant = 2;
+      else if (staged1_fits) variant = 5;
+      else if (staged_fits) variant = 2;
+    }
+  }
+  return variant;
+}
+
+}  // namespace mol

@@ -51,7 +51,7 @@ class MolShapeSpec:
     def num_logits(self) -> int:
         return self.query_dot_product_groups * self.item_dot_product_groups
 
-    def to_c(self) -> _lib.MolShape:
+    def to_c(self, precision: str = "fp32") -> _lib.MolShape:
         if self.query_nonlinearity not in ("geglu", "swiglu"):
             raise ValueError(f"Unknown query_nonlinearity {self.query_nonlinearity}")
         return _lib.MolShape(
@@ -61,6 +61,7 @@ class MolShapeSpec:
             _lib.RAILS_GEGLU if self.query_nonlinearity == "geglu" else _lib.RAILS_SWIGLU,
             len(self.uid_embedding_hash_sizes), 1 if self.dot_product_l2_norm else 0,
             float(self.temperature), float(self.eps),
+            _lib.RAILS_PRECISION_F16X3 if precision == "f16x3" else _lib.RAILS_PRECISION_FP32,
         )
 
 
@@ -148,7 +149,8 @@ class MolEngine:
         self.precision = precision or default_precision()
         if self.precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {PRECISIONS}, got {self.precision!r}")
-        self.shape = spec.to_c()
+        self.shape = spec.to_c(self.precision)
+        self._fp32_shape = spec.to_c("fp32")     # for the derived bf16 tables, which are cut from an fp32-format index
         if not self.lib.rails_mol_shape_supported(C.byref(self.shape)):
             raise NotImplementedError(_lib.last_error())
         self._keep = []  # fp32 contiguous device tensors the weight struct points into
@@ -172,43 +174,29 @@ class MolEngine:
             w.uid_hash_size[i] = int(hs)
         self.weights = w
         self.device = self._keep[0].device
+        if self.precision == "f16x3":
+            self._check_f16_range(weights)
         n = self.lib.rails_mol_gate_pack_floats(C.byref(self.shape))
         self.gate_pack = torch.empty(n, dtype=torch.float32, device=self.device)
-        self.split_scales = None
         with _on_device(self.device):
-            if self.precision == "f16x3":
-                self.split_scales = self._choose_split_scales(weights)
-                _lib.check(
-                    self.lib.rails_mol_pack_gate_weights_split(C.byref(self.shape), C.byref(self.weights), C.byref(self.split_scales), _ptr(self.gate_pack), _stream()),
-                    "rails_mol_pack_gate_weights_split",
-                )
-            else:
-                _lib.check(
-                    self.lib.rails_mol_pack_gate_weights(C.byref(self.shape), C.byref(self.weights), _ptr(self.gate_pack), _stream()),
-                    "rails_mol_pack_gate_weights",
-                )
+            _lib.check(
+                self.lib.rails_mol_pack_gate_weights(C.byref(self.shape), C.byref(self.weights), _ptr(self.gate_pack), _stream()),
+                "rails_mol_pack_gate_weights",
+            )
 
-    def _choose_split_scales(self, weights: Dict[str, torch.Tensor]) -> "_lib.MolSplitScales":
-        """Power-of-two operand scales of the f16x3 mode, from a worst-case bound on the hidden layer: with
-        |cl| <= 1/temperature (unit-norm components) no f16 operand can overflow (mol_layout.h)."""
-        if not self.spec.dot_product_l2_norm:
-            raise NotImplementedError("precision='f16x3' needs dot_product_l2_norm=True (bounded cross logits)")
+    def _check_f16_range(self, weights: Dict[str, torch.Tensor]) -> None:
+        """precision='f16x3' keeps cl, hid and the gate weights as f16 hi + lo.  Small values are safe (f16 subnormals are
+        kept by the MFMA: absolute resolution 2^-25); large ones are not (f16 max 65504), so bound the hidden layer for
+        |cl| <= 1/temperature (unit-norm components) and refuse weights that could overflow."""
         w1 = weights["_gating_fn._qi_partial_module.1.weight"].detach().float()
         b1 = weights["_gating_fn._qi_partial_module.1.bias"].detach().float()
         w2 = weights["_gating_fn._qi_partial_module.3.weight"].detach().float()
         cl_max = 1.0 / self.spec.temperature * 1.001
-        t_max = 1.4426950408889634 * (cl_max * float(w1.abs().sum(1).max()) + float(b1.abs().max()))
+        log2e = 1.4426950408889634
+        t_max = log2e * (cl_max * float(w1.abs().sum(1).max()) + float(b1.abs().max()))
         limit = 60000.0
-        cl_scale = 2.0 ** math.floor(math.log2(min(16.0, limit / cl_max)))
-        w1_scale = 16.0
-        while cl_scale * w1_scale * t_max >= limit or w1_scale * 1.4426950408889634 * float(w1.abs().max()) >= limit:
-            w1_scale /= 2.0
-            if w1_scale < 2.0 ** -12:
-                raise NotImplementedError("precision='f16x3': pair-gate weights are too large for f16 operands; use fp32")
-        w2_scale = 16.0
-        while w2_scale * float(w2.abs().max()) >= limit:
-            w2_scale /= 2.0
-        return _lib.MolSplitScales(cl_scale, w1_scale, w2_scale)
+        if cl_max >= limit or t_max >= limit or log2e * float(w1.abs().max()) >= limit or float(w2.abs().max()) >= limit:
+            raise NotImplementedError("precision='f16x3': pair-gate weights / temperature put an operand outside the f16 range; use fp32")
 
     # ---- item side ----------------------------------------------------------------------------
     def build_index(self, items: torch.Tensor) -> MolIndex:
@@ -290,45 +278,49 @@ class MolEngine:
         if out is None:
             out = torch.empty((batch, index.n_items), dtype=torch.float32, device=index.buf.device)
         with _on_device(index.buf.device):
-            if self.split_scales is not None:
-                _lib.check(
-                    self.lib.rails_mol_score_dense_split(C.byref(self.shape), _ptr(self.gate_pack), C.byref(self.split_scales), _ptr(qpack), batch, _ptr(index.buf), index.n_items, _ptr(out), out.stride(0), _stream()),
-                    "rails_mol_score_dense_split",
-                )
-            else:
-                _lib.check(
-                    self.lib.rails_mol_score_dense(C.byref(self.shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(index.buf), index.n_items, _ptr(out), out.stride(0), _stream()),
-                    "rails_mol_score_dense",
-                )
+            _lib.check(
+                self.lib.rails_mol_score_dense(C.byref(self.shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(index.buf), index.n_items, _ptr(out), out.stride(0), _stream()),
+                "rails_mol_score_dense",
+            )
         return out
 
     def score_candidates(self, qpack: torch.Tensor, batch: int, cand_index: MolIndex, n_cand_padded: int) -> torch.Tensor:
         out = torch.empty((batch, n_cand_padded), dtype=torch.float32, device=cand_index.buf.device)
         with _on_device(cand_index.buf.device):
-            if self.split_scales is not None:
-                _lib.check(
-                    self.lib.rails_mol_score_candidates_split(C.byref(self.shape), _ptr(self.gate_pack), C.byref(self.split_scales), _ptr(qpack), batch, _ptr(cand_index.buf), n_cand_padded, _ptr(out), out.stride(0), _stream()),
-                    "rails_mol_score_candidates_split",
-                )
-            else:
-                _lib.check(
-                    self.lib.rails_mol_score_candidates(C.byref(self.shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(cand_index.buf), n_cand_padded, _ptr(out), out.stride(0), _stream()),
-                    "rails_mol_score_candidates",
-                )
+            _lib.check(
+                self.lib.rails_mol_score_candidates(C.byref(self.shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(cand_index.buf), n_cand_padded, _ptr(out), out.stride(0), _stream()),
+                "rails_mol_score_candidates",
+            )
         return out
 
 
     # ---- coarse pass of the two-pass approximate top-k ------------------------------------------------
-    def build_coarse_table(self, index: MolIndex) -> torch.Tensor:
+    def _derived_table(self, fn_name: str, row_elems: int, index: MolIndex, items: Optional[torch.Tensor]) -> torch.Tensor:
+        """A bf16 table cut from the fp32 Ex of the index.  In f16x3 precision the index only holds Ex to 22 bits, so the
+        table is cut from temporary fp32-format index chunks rebuilt from `items` (same values as the fp32 engine's)."""
+        fn = getattr(self.lib, fn_name)
+        n, dev = index.n_items, index.buf.device
+        table = torch.empty(n * row_elems, dtype=torch.bfloat16, device=dev)
+        with _on_device(dev):
+            if self.precision == "fp32":
+                _lib.check(fn(C.byref(self.shape), _ptr(index.buf), n, _ptr(table), _stream()), fn_name)
+            else:
+                if items is None:
+                    raise ValueError(f"{fn_name}: precision='f16x3' needs the raw item embeddings to cut the bf16 table from")
+                items = _f32c(items)
+                chunk = 1 << 20   # a multiple of the 32-item tile
+                tmp = torch.empty(self.lib.rails_mol_index_floats(C.byref(self._fp32_shape), min(chunk, n)), dtype=torch.float32, device=dev)
+                for lo in range(0, n, chunk):
+                    m = min(chunk, n - lo)
+                    _lib.check(self.lib.rails_mol_index_build(C.byref(self._fp32_shape), C.byref(self.weights), _ptr(items[lo : lo + m]), m, _ptr(tmp), _stream()),
+                               "rails_mol_index_build")
+                    _lib.check(fn(C.byref(self._fp32_shape), _ptr(tmp), m, C.c_void_p(table.data_ptr() + 2 * lo * row_elems), _stream()), fn_name)
+        return table
+
+    def build_coarse_table(self, index: MolIndex, items: Optional[torch.Tensor] = None) -> torch.Tensor:
         """(N, d) bf16 table of P_X-averaged component embeddings (reference mol_top_k.py:321-325)."""
-        nbytes = self.lib.rails_mol_coarse_table_bytes(C.byref(self.shape), index.n_items)
-        table = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=index.buf.device)
-        with _on_device(index.buf.device):
-            _lib.check(
-                self.lib.rails_mol_coarse_build(C.byref(self.shape), _ptr(index.buf), index.n_items, _ptr(table), _stream()),
-                "rails_mol_coarse_build",
-            )
-        return table.view(index.n_items, self.spec.dot_product_dimension)
+        d = self.spec.dot_product_dimension
+        return self._derived_table("rails_mol_coarse_build", d, index, items).view(index.n_items, d)
 
     def coarse_scores(self, eq: torch.Tensor, table: torch.Tensor, average_queries: bool) -> torch.Tensor:
         """eq (B, P_Q, d) fp32 -> (B, N) fp32 holding bf16-rounded dot products (reference mol_top_k.py:351-354)."""
@@ -370,16 +362,10 @@ class MolEngine:
         return (cap + 63) // 64 * 64
 
     # ---- per-component candidates (MoLNaiveTopK / MoLCombTopK) -----------------------------------------
-    def build_component_table(self, index: MolIndex) -> torch.Tensor:
+    def build_component_table(self, index: MolIndex, items: Optional[torch.Tensor] = None) -> torch.Tensor:
         """(N, P_X, d) bf16 component embeddings (reference mol_top_k.py:61-73)."""
-        nbytes = self.lib.rails_mol_component_table_bytes(C.byref(self.shape), index.n_items)
-        table = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=index.buf.device)
-        with _on_device(index.buf.device):
-            _lib.check(
-                self.lib.rails_mol_component_build(C.byref(self.shape), _ptr(index.buf), index.n_items, _ptr(table), _stream()),
-                "rails_mol_component_build",
-            )
-        return table.view(index.n_items, self.spec.item_dot_product_groups, self.spec.dot_product_dimension)
+        px, d = self.spec.item_dot_product_groups, self.spec.dot_product_dimension
+        return self._derived_table("rails_mol_component_build", px * d, index, items).view(index.n_items, px, d)
 
     def component_scores(self, eq: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
         """eq (B, P_Q, d) -> (B * P_Q * P_X, N) fp32 holding bf16 values, row (b * P_Q + i) * P_X + m."""

@@ -113,7 +113,7 @@ class MoLAvgTopK(MoLTopKModule):
         eng = self._bind()
         if self._coarse_engine is not eng:
             self._coarse_engine = eng
-            self._coarse_table = eng.build_coarse_table(self._index)
+            self._coarse_table = eng.build_coarse_table(self._index, self._item_embeddings[0])
         return self._coarse_table
 
     def _coarse_topk(self, query_embeddings: torch.Tensor, average_queries: bool, **kwargs):
@@ -173,7 +173,7 @@ class _ComponentCandidates:
         eng = self._bind()
         if getattr(self, "_comp_engine", None) is not eng:
             self._comp_engine = eng
-            self._comp_table = eng.build_component_table(self._index)
+            self._comp_table = eng.build_component_table(self._index, self._item_embeddings[0])
         return self._comp_table
 
     def _component_topk(self, eq: torch.Tensor, k_per_group: int) -> torch.Tensor:

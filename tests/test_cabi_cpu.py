@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_struct_layout_matches_header(lib):
-    assert C.sizeof(_lib.MolShape) == 14 * 4
+    assert C.sizeof(_lib.MolShape) == 15 * 4
     assert C.sizeof(_lib.MolWeights) == 8 * (4 + 4 + 4 + 12)  # 24 pointer-sized fields
 
 
@@ -46,6 +46,15 @@ def test_size_helpers_and_validation(lib):
     bad = E.MolShapeSpec(64, 64, 48, 8, 8, 512, 128, 128, 128).to_c()
     assert lib.rails_mol_shape_supported(C.byref(bad)) == 0 and "no fused scoring kernel" in _lib.last_error()
     assert lib.rails_mol_shape_supported(C.byref(E.MolShapeSpec(64, 64, 64, 16, 16, 512, 128, 128, 128).to_c())) == 1
+    # precision f16x3: same buffer sizes (f16 hi + lo in the bytes of the fp32 fragment); needs bounded cross logits
+    s16 = E.MolShapeSpec(64, 64, 32, 8, 8, 512, 128, 128, 128).to_c("f16x3")
+    assert s16.precision == _lib.RAILS_PRECISION_F16X3 and lib.rails_mol_shape_supported(C.byref(s16)) == 1
+    assert lib.rails_mol_index_floats(C.byref(s16), 33) == lib.rails_mol_index_floats(C.byref(s), 33)
+    assert lib.rails_mol_gate_pack_floats(C.byref(s16)) == lib.rails_mol_gate_pack_floats(C.byref(s))
+    no_norm = E.MolShapeSpec(64, 64, 32, 8, 8, 512, 128, 128, 128, dot_product_l2_norm=False).to_c("f16x3")
+    assert lib.rails_mol_shape_supported(C.byref(no_norm)) == 0 and "dot_product_l2_norm" in _lib.last_error()
+    s.precision = 7
+    assert lib.rails_mol_shape_supported(C.byref(s)) == 0 and "precision" in _lib.last_error()
     # k > n is rejected before any launch
     assert lib.rails_topk(1, 10, 1, 10, 11, 1, None, 0, 1, 1, None, 0, None) == _lib.RAILS_EINVAL
     with pytest.raises(ValueError):

@@ -608,7 +608,7 @@ def test_f16x3_mode_holds_the_logit_tolerance(dev, name):
     with torch.inference_mode():
         tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
         logits = tk.all_logits(q, **kw_dev(fx, dev))
-        assert tk._engine.split_scales is not None
+        assert tk._engine.precision == "f16x3"
         d = float((logits.cpu() - fx.t("F2/all_logits")).abs().max())
         assert d <= LOGIT_TOL, d
         s, i = tk(q, k=200, **kw_dev(fx, dev))

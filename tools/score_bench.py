@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A/B harness for the scoring kernel: interleaved rounds of every variant in ONE process
 (cdna_hip_programming.md section 5.4 rule 24), median/min ms and TFLOP/s per variant, max |diff| vs variant 0.
-Variants are selected by the RAILS_SCORE_VARIANT env var read at launch time by librails_amd.so.
+Variants are selected by the RAILS_SCORE_VARIANT env var read at launch time by librails_amd.so; a trailing "n" (e.g. "2n")
+also sets RAILS_F16_OVERLAP=0 (f16x3 kernels without the cross-query overlap of stage X).
   python tools/score_bench.py --variants 0,1,2 --workload amzn-books --batch 32 --rounds 7
 """
 import argparse
@@ -54,13 +55,18 @@ def main():
         index = eng.build_index(X)
         qpack, _, _ = eng.query_pack(q, uid)
         outs, times = {}, {v: [] for v in variants}
+
+        def select(v):
+            os.environ["RAILS_SCORE_VARIANT"] = v.rstrip("n")
+            os.environ["RAILS_F16_OVERLAP"] = "0" if v.endswith("n") else "1"
+
         for v in variants:
-            os.environ["RAILS_SCORE_VARIANT"] = v
+            select(v)
             outs[v] = eng.score_dense(qpack, args.batch, index).clone()
         torch.cuda.synchronize()
         for _ in range(args.rounds):
             for v in variants:
-                os.environ["RAILS_SCORE_VARIANT"] = v
+                select(v)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.reps):
