@@ -43,6 +43,9 @@ WORKLOADS = {
     "synthetic-8x8x32": ("synthetic-8x8x32", 125_000_000, 0),
 }
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_F16_MFMA_TFLOPS = 2500.0  # same guide: v_mfma_f32_32x32x16_f16, dense
+# precision f16x3 issues three f16 MFMAs per algorithmic product block: its ceiling in algorithmic flops is a third of the f16 peak
+PEAK_F16X3_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -56,6 +59,27 @@ def bytes_per_item_fp32(cfg) -> int:
     """fp32 index: (P_X*d + L) * 4 bytes per item, streamed once per batch."""
     L = cfg.query_dot_product_groups * cfg.item_dot_product_groups
     return (cfg.item_dot_product_groups * cfg.dot_product_dimension + L) * 4
+
+
+def host_cpu_info() -> dict:
+    """CPU model and physical core count of the box (the reference's protocol reports them, data/eval.py:139-170)."""
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    return {"cpu_model": model, "logical_cpus": os.cpu_count() or 1, "physical_cores": len(phys) or (os.cpu_count() or 1)}
 
 
 def cpu_baseline(cfg, weights, q, user_ids, n_total: int, sample_items: int, k_prime: int):
@@ -87,13 +111,64 @@ def cpu_baseline(cfg, weights, q, user_ids, n_total: int, sample_items: int, k_p
     run(2048, 2048)
     dt = min(run(sample_items, 4096), run(sample_items, 4096))  # best of two passes: shared hosts are noisy
     qps = B / (dt * (n_total / sample_items))
+    scaled = "" if sample_items == n_total else ", scaled linearly in N"
     return {
         "value": qps,
         "unit": "queries/s",
-        "cores": torch.get_num_threads(),
+        "cores": torch.get_num_threads(),   # threads the timed passes actually used (the best of the calibration)
         "kind": "port",
-        "sample": f"B={B} queries x first {sample_items} of {n_total} items, best of 2 timed passes ({dt:.1f} s) at the best of 8..{ncpu} threads, scaled linearly in N",
+        "sample": f"B={B} queries x {'all' if sample_items == n_total else 'first'} {sample_items} of {n_total} items, best of 2 timed passes ({dt:.1f} s each) at the best of 8..{ncpu} threads{scaled}",
+        **host_cpu_info(),
     }
+
+
+def measurement_matrix(mol, X, ids, q, kw, inv, cfg, n_items: int, steps: int, dev) -> list:
+    """Points of the reference's timing protocol (data/eval.py:128-170) beside the headline one, same step definition
+    (get_top_k_outputs), both precisions: (B, k, k') = (1, 120, 200), (8, 120, 200) and the accuracy protocol (32, 2500, 2561)."""
+    points = []
+    for precision in ("fp32", "f16x3"):
+        mol.precision = None if precision == "fp32" else precision
+        with torch.inference_mode():
+            tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
+            cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)
+            for Bx, kx, trunc in ((1, 120, 200), (8, 120, 200), (q.shape[0], 2500, None)):
+                qx, invx = q[:Bx], inv[:Bx]
+                kwx = {key: v[:Bx] for key, v in kw.items()}
+                kx = min(kx, n_items)
+                for _ in range(2):
+                    cand.get_top_k_outputs(qx, kx, kwx, tk, invx, truncate_k_prime_to=trunc)
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    ev[i].record()
+                    cand.get_top_k_outputs(qx, kx, kwx, tk, invx, truncate_k_prime_to=trunc)
+                ev[steps].record()
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / steps
+                per = torch.tensor([ev[i].elapsed_time(ev[i + 1]) for i in range(steps)])
+                eng = tk._bind()
+                qp, _, _ = eng.query_pack(qx, kwx.get("user_ids"))
+                buf = torch.empty((Bx, n_items), dtype=torch.float32, device=dev)
+                eng.score_dense(qp, Bx, tk._index, out=buf)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(steps):
+                    eng.score_dense(qp, Bx, tk._index, out=buf)
+                e1.record()
+                torch.cuda.synchronize()
+                kms = e0.elapsed_time(e1) / steps
+                tf = Bx * n_items * flops_per_pair(cfg) / (kms * 1e-3) / 1e12
+                points.append({
+                    "precision": precision, "batch": Bx, "k": kx, "k_prime": min(kx + inv.shape[1], n_items) if trunc is None else min(trunc, n_items),
+                    "queries_per_s": Bx / dt, "ms_per_step": dt * 1e3, "ms_per_step_stdev": float(per.std()) if steps > 1 else 0.0,
+                    "scoring_kernel_ms": kms, "scoring_tflops_algorithmic": tf,
+                    "mfma_frac": tf / (PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_F16X3_TFLOPS),
+                    "hbm_frac": n_items * bytes_per_item_fp32(cfg) / (kms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+                })
+            del tk
+    mol.precision = None
+    return points
 
 
 def quick_workload(name: str, B: int, k: int, kp: int, steps: int, dev) -> dict:
@@ -155,10 +230,11 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--k", type=int, default=120)
     ap.add_argument("--k-prime", type=int, default=200)
-    ap.add_argument("--cpu-sample-items", type=int, default=65536)
+    ap.add_argument("--cpu-sample-items", type=int, default=0, help="items of the CPU-baseline sample (0 = the whole corpus: ~10 s per pass on a many-core host)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fast-path", action="store_true", help="skip the extra f16x3 measurement")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the secondary ML-20M / ML-1M measurements")
+    ap.add_argument("--no-matrix", action="store_true", help="skip the B = 1 / 8 and accuracy-protocol points")
     ap.add_argument("--items", type=int, default=0, help="override the workload's corpus size N (total over all ranks)")
     ap.add_argument("--device-table", action="store_true",
                     help="draw the item table on the GPU (truncated normal, sigma 0.02) instead of the host counter hash; "
@@ -269,6 +345,7 @@ def main() -> None:
 
         ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
         ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+        ev_step = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]   # step boundaries, for the spread
         logits = None if two_pass else torch.empty((B, hi - lo), dtype=torch.float32, device=dev)
 
         def two_pass_step(i=None):
@@ -308,11 +385,14 @@ def main() -> None:
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(args.steps):
+            ev_step[i].record()
             step(i)
+        ev_step[args.steps].record()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        per_step_ms = [ev_step[i].elapsed_time(ev_step[i + 1]) for i in range(args.steps)]
         if two_pass:
             # the dominant kernel chain of this mode is the fused coarse top-K' (HBM-bound scan of the bf16 table):
             # timed on its own, on the launch stream, after the step timing
@@ -365,6 +445,12 @@ def main() -> None:
             qp, _, _ = eng.query_pack(q, kw.get("user_ids"))
             eng.score_dense(qp, B, local._index, out=d_logits)
             max_dev = float((d_logits - logits).abs().max())   # vs the exact-fp32 logits of the last headline step
+            # do the two precisions return the same items?  top-k' of both logit matrices over this rank's whole shard
+            k_cmp = min(kp, hi - lo)
+            _, ids32 = E.topk(logits, k_cmp, ids=local._ids_flat)
+            _, ids16 = E.topk(d_logits, k_cmp, ids=local._ids_flat)
+            same_rank = float((ids32 == ids16).float().mean())
+            same_set = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(ids32.cpu(), ids16.cpu())) / ids32.numel()
             ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
             ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
             for _ in range(args.warmup):
@@ -390,7 +476,13 @@ def main() -> None:
             "value": B * args.steps / fast_elapsed, "unit": "queries/s", "ms_per_step": fast_elapsed / args.steps * 1e3,
             "kernel_ms": fast_ms, "achieved_tflops_algorithmic": B * (hi - lo) * flops_per_pair(cfg) / (fast_ms * 1e-3) / 1e12,
             "max_abs_logit_diff_vs_fp32_path": max_dev,
+            f"top{k_cmp}_ids_identical_to_fp32_path": {"same_item_at_same_rank": same_rank, "same_item_set": same_set,
+                                                         "note": "differences are swaps inside groups of fp32 logits closer than the two paths' rounding (~2e-5)"},
         }
+        a16 = fast["achieved_tflops_algorithmic"]
+        fast["roofline"] = {"kernel": "mol_score_*_kernel<F16Unit>", "bound": "mfma", "achieved": a16, "peak": PEAK_F16X3_TFLOPS, "unit": "TFLOP/s",
+                            "frac": a16 / PEAK_F16X3_TFLOPS, "traffic": None,
+                            "peak_note": "2500 TFLOP/s dense f16 MFMA / 3 MFMAs per product block; issued-MFMA rate = 3 x achieved"}
 
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if test_backend else dev)
@@ -417,6 +509,7 @@ def main() -> None:
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_stdev": float(torch.tensor(per_step_ms).std()) if len(per_step_ms) > 1 else 0.0,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -435,6 +528,7 @@ def main() -> None:
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS,
                 "traffic": traffic,
+                "traffic_source": "profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the same kernel and workload, corrected as MI355X_MICROARCH.md prescribes; not collected in this run)" if traffic else None,
                 "kernel_ms": score_ms,
                 "flops_per_launch": flops_alg,
                 "hbm_bytes_alg_per_launch": n_shard * bytes_per_item_fp32(cfg),
@@ -459,11 +553,15 @@ def main() -> None:
             }
         if fast is not None:
             out["fast_path"] = fast
+        if world == 1 and not two_pass and not args.no_matrix:
+            # the other points of the reference's protocol on this workload -- small batches (B = 1 is the
+            # HBM-bound end: one index pass per query) and the accuracy protocol (k = 2500 -> k' = 2561, no truncation)
+            out["matrix"] = measurement_matrix(mol, X, ids, q, kw, inv, cfg, hi - lo, min(args.steps, 10), dev)
         if world == 1 and args.workload == "amzn-books" and not args.no_other_workloads:
             # the two smaller real-dataset shapes of BASELINE.json (configs 1 and 2): fixed per-batch costs dominate there
             out["other_workloads"] = [quick_workload(n, B, k, kp, 10, dev) for n in ("ml-20m", "ml-1m")]
         if world == 1 and not args.no_cpu_baseline and not two_pass:   # the CPU baseline is the exact path
-            out["cpu_baseline"] = cpu_baseline(cfg, weights, q_cpu, uid_cpu, N, min(args.cpu_sample_items, N), kp)
+            out["cpu_baseline"] = cpu_baseline(cfg, weights, q_cpu, uid_cpu, N, min(args.cpu_sample_items or N, N), kp)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -1,5 +1,5 @@
 """bench.py's output contract (the driver parses ONE JSON line): checked on the committed line of the last GPU run
-(profiles/r01_bench.json) on CPU, and on a live short run on the GPU."""
+(profiles/r02_bench.json) on CPU, and on a live short run on the GPU."""
 import json
 import os
 import subprocess
@@ -29,15 +29,20 @@ def check_line(d, expect_cpu_baseline):
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r01_bench.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r02_bench.json")))
     check_line(d, expect_cpu_baseline=True)
     assert d["n_gpus"] == 1 and "amzn-books" in d["config"]["workload"]
-    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["traffic"] is not None
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["traffic"] is not None and "profiles/" in d["roofline"]["traffic_source"]
+    assert d["ms_per_step_stdev"] >= 0 and d["cpu_baseline"]["physical_cores"] >= 1 and "scaled" not in d["cpu_baseline"]["sample"]
+    f = d["fast_path"]["roofline"]
+    assert f["bound"] == "mfma" and abs(f["frac"] - f["achieved"] / f["peak"]) < 1e-9 and abs(f["peak"] - 2500 / 3) < 1e-6
+    pts = {(p["precision"], p["batch"], p["k_prime"]) for p in d["matrix"]}
+    assert {("fp32", 1, 200), ("fp32", 8, 200), ("fp32", 32, 2561), ("f16x3", 1, 200), ("f16x3", 8, 200), ("f16x3", 32, 2561)} <= pts
 
 
 @pytest.mark.gpu
 def test_live_bench_line():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-fast-path",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-fast-path", "--no-matrix",
                           "--no-other-workloads"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -14,7 +14,18 @@ STAGE_TOL = 2e-6   # unit-norm embeddings / O(1) gates: a few ulp of summation-o
 SUPPORTED = ["c1_ml1m", "c2_ml20m", "c3_books", "c4_16x16x64"]
 
 
-def build_module(cfg, weights, dev):
+PRECISIONS = ["fp32", "f16x3"]   # every scoring test runs on both builds of the fused kernel, against the same vectors and bar
+
+
+def build_module(cfg, weights, dev, precision=None):
+    if precision == "f16x3" and cfg.query_dot_product_groups * cfg.item_dot_product_groups > 64:
+        pytest.skip("precision f16x3 is not built for 16x16x64")
+    mol = _build_module(cfg, weights, dev)
+    mol.precision = precision
+    return mol
+
+
+def _build_module(cfg, weights, dev):
     mol, _ = rails_amd.create_mol_interaction_module(
         cfg.query_embedding_dim, cfg.item_embedding_dim, cfg.dot_product_dimension, cfg.query_dot_product_groups,
         cfg.item_dot_product_groups, cfg.temperature, 0.0, cfg.query_hidden_dim, 0.1, cfg.item_hidden_dim,
@@ -35,9 +46,9 @@ def fx(request):
     return Fixture(request.param)
 
 
-@pytest.fixture(scope="module")
-def mol(fx, dev):
-    return build_module(fx.cfg, fx.weights, dev)
+@pytest.fixture(scope="module", params=PRECISIONS)
+def mol(fx, dev, request):
+    return build_module(fx.cfg, fx.weights, dev, request.param)
 
 
 def kw_dev(fx, dev):
@@ -124,10 +135,11 @@ def test_f5_harness_metrics(dev):
             assert torch.allclose(m["mrr"].float(), fx.t(f"F5/{mode}/mrr").float(), atol=1e-7)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("name", ["full_c1_ml1m", "full_c2_ml20m"])
-def test_f7_full_size(name, dev):
+def test_f7_full_size(name, dev, precision):
     fx = Fixture(name)
-    mol = build_module(fx.cfg, fx.weights, dev)
+    mol = build_module(fx.cfg, fx.weights, dev, precision)
     X, ids = full_size_inputs(fx)
     with torch.inference_mode():
         tk = rails_amd.MoLBruteForceTopK(mol, X.to(dev), ids.to(dev))
@@ -205,12 +217,13 @@ def test_filter_seen_ids_matches_oracle(dev, rows, kp, width, k):
 
 
 # ---- properties at the full amzn-books size --------------------------------------------------------
-def test_full_size_books_properties(dev):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_full_size_books_properties(dev, precision):
     """N = 695 762, B = 32 (BASELINE.json config 3): the oracle cannot score this in seconds, so check
     (a) a random sample of columns against the oracle, (b) shard-merge == global top-k, (c) idempotence."""
     cfg = O.CONFIGS["amzn-books"]
     w = O.synthetic_weights(cfg, seed=0)
-    mol = build_module(cfg, w, dev)
+    mol = build_module(cfg, w, dev, precision)
     N, B, k = 695762, 32, 200
     X = torch.from_numpy(O.hash_item_table(1, 0, N, cfg.item_embedding_dim))
     q = O.synthetic_queries(cfg, B)
@@ -499,13 +512,14 @@ def test_sort_rows_and_duplicate_mask(dev):
 
 
 # ---- robustness -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("B", [1, 3, 33, 100])
-def test_batch_sizes_cover_padding_and_both_kernels(dev, B):
+def test_batch_sizes_cover_padding_and_both_kernels(dev, B, precision):
     """B = 1, 3: partial query group on the direct kernel; B = 33, 100: >= 8 groups -> staged kernel with the group
     loop wrapping (g += 8) and a padded last group."""
     cfg = O.CONFIGS["amzn-books"]
     w = O.synthetic_weights(cfg, seed=5)
-    mol = build_module(cfg, w, dev)
+    mol = build_module(cfg, w, dev, precision)
     N = 2000 + B
     X = torch.from_numpy(O.hash_item_table(3, 0, N, cfg.item_embedding_dim)).unsqueeze(0)
     q = O.synthetic_queries(cfg, B, seed=B)
@@ -565,11 +579,12 @@ def test_index_follows_parameter_updates(dev):
     assert float((fourth - third).abs().max()) > 1e-4
 
 
-def test_multi_million_item_corpus(dev):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_multi_million_item_corpus(dev, precision):
     """3 M items (3.8 GB index): 64-bit addressing of tiles / logits, radix top-k over a long row."""
     cfg = O.CONFIGS["amzn-books"]
     w = O.synthetic_weights(cfg, seed=6)
-    mol = build_module(cfg, w, dev)
+    mol = build_module(cfg, w, dev, precision)
     N, B, k = 3_000_001, 4, 500
     X = torch.cat([torch.from_numpy(O.hash_item_table(8, s, min(500_000, N - s), cfg.item_embedding_dim)) for s in range(0, N, 500_000)])
     q = O.synthetic_queries(cfg, B, seed=11)
@@ -586,9 +601,10 @@ def test_multi_million_item_corpus(dev):
     assert torch.equal(s.cpu(), rs) and torch.equal(i.cpu(), ri)
 
 
-def test_degenerate_sizes(dev):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_degenerate_sizes(dev, precision):
     fx = Fixture("c3_books")
-    mol = build_module(fx.cfg, fx.weights, dev)
+    mol = build_module(fx.cfg, fx.weights, dev, precision)
     X, ids = fx.t("X")[:, :1].to(dev), fx.t("item_ids")[:, :1].to(dev)     # a corpus of one item
     with torch.inference_mode():
         tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
@@ -616,6 +632,26 @@ def test_f16x3_mode_holds_the_logit_tolerance(dev, name):
         cand = fx.t("X").squeeze(0)[fx.t("F6/cand_idx")].to(dev)
         rows, _ = mol(q, cand, **kw_dev(fx, dev))
         assert float((rows.cpu() - fx.t("F6/logits")).abs().max()) <= LOGIT_TOL
+
+
+def test_f16x3_softmax_overflow_guard(dev):
+    """The f16x3 kernel takes softmax numerators without the maximum subtraction and falls back to the stable form when one
+    overflows (gate logits > 88).  Force that with a huge pair-gate output bias on one logit: results must stay finite and
+    equal the oracle's (which uses torch's stable softmax)."""
+    cfg = O.CONFIGS["amzn-books"]
+    w = {k: v.clone() for k, v in O.synthetic_weights(cfg, seed=8).items()}
+    # w = g*sigmoid(g) ~ 200 on one logit -> exp overflows fp32 without a shift.  (One, not two: the softmax between two
+    # logits of magnitude 200 amplifies the fp32 rounding of g itself beyond 1e-4 in ANY fp32 implementation.)
+    w["_gating_fn._qi_partial_module.3.bias"][5] = 200.0
+    mol = build_module(cfg, w, dev, "f16x3")
+    N, B = 1000, 9
+    X = torch.from_numpy(O.hash_item_table(4, 0, N, cfg.item_embedding_dim)).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B, seed=3)
+    with torch.inference_mode():
+        got, _ = mol(q.to(dev), X.to(dev))
+    ref = O.mol_logits(cfg, w, q, X)
+    assert bool(torch.isfinite(got).all())
+    assert float((got.cpu() - ref).abs().max()) <= LOGIT_TOL
 
 
 def test_pack_and_merge_candidates_equal_the_unsharded_topk(dev):
