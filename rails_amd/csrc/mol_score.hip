@@ -171,6 +171,10 @@ __device__ __forceinline__ float query_mlp(f32x16 (&D1)[PX], const float4* sW1, 
 
 // The exact-fp32 unit policy of the kernel shells (mol_score_shell.h).
 struct Fp32Unit {
+  template <class G>
+  static constexpr int kLdsWeightFloats = G::kWpackFloats;
+  template <class G, int NW>
+  static __device__ __forceinline__ void stage(const ScoreArgs& p, float* smem) { stage_weights<G, NW>(p, smem); }
   template <class G, int PX, int DD>
   static __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float* __restrict__ eq, const float4* tEx, int lane) {
     mol::gemm1<G, PX, DD>(D1, reinterpret_cast<const float4*>(eq), tEx, lane);
@@ -570,7 +574,6 @@ static int launch_score(const ScoreArgs& a, int n_cu, hipStream_t stream) {
 bool score_supported(const Shape& s) {
   if (s.gating_qi_hidden_dim != 128) return false;
   const int pq = s.query_dot_product_groups, px = s.item_dot_product_groups, dd = s.dot_product_dimension;
-  if (is_split(s) && pq == 16) return false;   // f16x3 is not built for 16x16x64
   return (pq == 8 && px == 4 && dd == 64) || (pq == 8 && px == 4 && dd == 128) || (pq == 8 && px == 8 && dd == 32) ||
          (pq == 16 && px == 16 && dd == 64);
 }

@@ -124,28 +124,67 @@ __device__ __forceinline__ float nsilu(float t) {
 #endif
 }
 
-// LDS views of the split gate pack (rails_mol_pack_gate_weights with precision f16x3)
-template <class G>
+// Views of the split gate pack (rails_mol_pack_gate_weights with precision f16x3): [W1 hi][W1 lo][W2 hi][W2 lo][b1][b2].
+// BIG = false: the whole pack sits in LDS.  BIG = true (16x16x64: the pack is 256 KiB): W1 and the biases in LDS, the W2
+// fragments are streamed from L2 through a deeper register ring.
+template <class G, bool BIG>
 struct SplitPack {
   const h8* w1hi; const h8* w1lo; const h8* w2hi; const h8* w2lo; const float* b1; const float* b2;
   float m1;   // -1.0, opaque (split_pair)
-  __device__ __forceinline__ explicit SplitPack(const float* smem) {
+  __amdgpu_buffer_rsrc_t grsrc;   // BIG: the whole pack in global memory as a buffer resource
+  static constexpr int N8 = G::kW1Floats / 8;   // h8 fragments per half of a weight matrix (hi or lo)
+  static constexpr int kLdsFloats = BIG ? G::kW1Floats + G::TH * 32 + G::L : G::kWpackFloats;
+  __device__ __forceinline__ SplitPack(const float* smem, const float* gpack) {
     m1 = -1.0f;
     asm volatile("" : "+v"(m1));
-    constexpr int N8 = G::kW1Floats / 8;   // h8 fragments per half of a weight matrix (hi or lo)
     w1hi = reinterpret_cast<const h8*>(smem);
     w1lo = w1hi + N8;
-    w2hi = w1lo + N8;
-    w2lo = w2hi + N8;
-    b1 = smem + G::kW1Floats + G::kW2Floats;
+    if constexpr (BIG) {
+      // buffer addressing (SGPR descriptor + scalar byte offset + one per-lane VGPR offset): with flat addressing the
+      // compiler keeps -- and spills -- one 64-bit address pair per streamed fragment
+      grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gpack), 0, (int)(G::kWpackFloats * sizeof(float)), 0x00020000);
+      w2hi = w2lo = nullptr;
+      b1 = smem + G::kW1Floats;
+    } else {
+      w2hi = w1lo + N8;
+      w2lo = w2hi + N8;
+      b1 = smem + G::kW1Floats + G::kW2Floats;
+    }
     b2 = b1 + G::TH * 32;
+  }
+  // W2 fragment f (hi or lo part) of this lane
+  __device__ __forceinline__ h8 w2frag(bool hi_part, int f, int lane) const {
+    if constexpr (BIG) {
+      typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+      const u4 v = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane * 16, ((hi_part ? 2 : 3) * (N8 / 64) + f) * 1024, 0);
+      return __builtin_bit_cast(h8, v);
+    } else {
+      return (hi_part ? w2hi : w2lo)[f * 64 + lane];
+    }
+  }
+  template <int NW>
+  static __device__ __forceinline__ void stage(const ScoreArgs& p, float* smem) {
+    if constexpr (BIG) {
+      const float4* src = reinterpret_cast<const float4*>(p.wpack);
+      float4* dst = reinterpret_cast<float4*>(smem);
+      for (int i = threadIdx.x; i < G::kW1Floats / 4; i += NW * 64) dst[i] = src[i];
+      const float4* srcb = reinterpret_cast<const float4*>(p.wpack + G::kW1Floats + G::kW2Floats);
+      float4* dstb = reinterpret_cast<float4*>(smem + G::kW1Floats);
+      for (int i = threadIdx.x; i < (G::TH * 32 + G::L) / 4; i += NW * 64) dstb[i] = srcb[i];
+    } else {
+      stage_weights<G, NW>(p, smem);
+    }
   }
 };
 
 // GEMM1 on pre-split operands: eq = [ks][hi|lo][lane] h8 (query pack), tEx = [m][ks][hi|lo][lane] h8 (tile, LDS or HBM).
+// Item groups in chunks of <= 8 (their B fragments of a K-step are fetched together); inside a chunk the products are
+// outermost so that consecutive MFMAs go to different accumulators.
 template <class G, int PX, int DD>
 __device__ __forceinline__ void gemm1_presplit(f32x16 (&D1)[PX], const h8* __restrict__ eq, const h8* tEx, int lane) {
   static_assert(DD % 16 == 0, "f16x3 GEMM1 walks K in steps of 16");
+  constexpr int MC = PX > 8 ? 4 : PX;
+  static_assert(PX % MC == 0, "item groups come in whole chunks");
 #pragma unroll
   for (int m = 0; m < PX; ++m)
 #pragma unroll
@@ -153,21 +192,23 @@ __device__ __forceinline__ void gemm1_presplit(f32x16 (&D1)[PX], const h8* __res
 #pragma unroll
   for (int ks = 0; ks < DD / 16; ++ks) {
     const h8 ah = eq[(2 * ks) * 64 + lane], al = eq[(2 * ks + 1) * 64 + lane];
-    h8 bh[PX], bl[PX];
 #pragma unroll
-    for (int m = 0; m < PX; ++m) {
-      bh[m] = tEx[(m * (DD / 8) + 2 * ks) * 64 + lane];
-      bl[m] = tEx[(m * (DD / 8) + 2 * ks + 1) * 64 + lane];
+    for (int m0 = 0; m0 < PX; m0 += MC) {
+      h8 bh[MC], bl[MC];
+#pragma unroll
+      for (int m = 0; m < MC; ++m) {
+        bh[m] = tEx[((m0 + m) * (DD / 8) + 2 * ks) * 64 + lane];
+        bl[m] = tEx[((m0 + m) * (DD / 8) + 2 * ks + 1) * 64 + lane];
+      }
+#pragma unroll
+      for (int m = 0; m < MC; ++m) D1[m0 + m] = mfma16(al, bh[m], D1[m0 + m]);
+#pragma unroll
+      for (int m = 0; m < MC; ++m) D1[m0 + m] = mfma16(ah, bl[m], D1[m0 + m]);
+#pragma unroll
+      for (int m = 0; m < MC; ++m) D1[m0 + m] = mfma16(ah, bh[m], D1[m0 + m]);
+      // keep the operand fetches of later chunks below this chunk's MFMAs (register pressure)
+      asm volatile("" ::: "memory");
     }
-    // products outermost: consecutive MFMAs never share an accumulator (dependent-accumulate latency = 2 x issue time)
-#pragma unroll
-    for (int m = 0; m < PX; ++m) D1[m] = mfma16(al, bh[m], D1[m]);
-#pragma unroll
-    for (int m = 0; m < PX; ++m) D1[m] = mfma16(ah, bl[m], D1[m]);
-#pragma unroll
-    for (int m = 0; m < PX; ++m) D1[m] = mfma16(ah, bh[m], D1[m]);
-    // keep the operand fetches of later K-steps below this step's MFMAs (register pressure)
-    asm volatile("" ::: "memory");
   }
 }
 
@@ -195,20 +236,31 @@ __device__ __forceinline__ void interleave(FM&& mf, FS&& sf) {
 // subtraction per logit and the cross-lane minimum; an overflow is detected on the denominator (inf / NaN) and that
 // query is redone with the shifted form from the u values, which are still in registers -- same result as the
 // reference's stable softmax (similarity_fn.py:31-46) in every case.
+constexpr int kEpiPrefetch = 8;   // logit pairs whose gi / gq operands are requested ahead of their slice (gi may sit in HBM/L2)
 template <class G>
 struct Epi {
   f32x16 D3[G::TL];   // -log2e * gqi on entry; u after pass 1
   float den, num;
   const float* gq;    // this query's -log2e * gq row, lane half's part ([hi][e] layout)
-  __device__ __forceinline__ void reset(const float* gq_) { den = 0.0f; num = 0.0f; gq = gq_; }
+  float2 gi_r[kEpiPrefetch], gq_r[kEpiPrefetch];
+  // gi fragment [ec = e/4][lane][4]: pair P is floats (e%4, e%4+1), e = 2P, of the lane's float4
+  template <int P>
+  __device__ __forceinline__ void fetch(const float* tGi, int lane) {
+    constexpr int e = 2 * P;
+    gi_r[P % kEpiPrefetch] = *reinterpret_cast<const float2*>(tGi + ((e / 4) * 64 + lane) * 4 + e % 4);
+    gq_r[P % kEpiPrefetch] = *reinterpret_cast<const float2*>(gq + e);
+  }
+  __device__ __forceinline__ void reset(const float* gq_, const float* tGi, int lane) {
+    den = 0.0f; num = 0.0f; gq = gq_;
+    static_for<(kEpiPrefetch < G::E / 2 ? kEpiPrefetch : G::E / 2)>([&](auto pc) { fetch<decltype(pc)::value>(tGi, lane); });
+  }
 };
 // pass 1, logits e = 2P, 2P+1 of this lane:  t2 = -log2e*(gq*gi + gqi);  u = t2/(1+2^t2) = -log2e * g*sigmoid(g)
 template <class G, int P>
 __device__ __forceinline__ void epi_p1(Epi<G>& s, const float* tGi, int lane) {
   constexpr int e = 2 * P;
-  // gi fragment [ec = e/4][lane][4]: this pair is floats (e%4, e%4+1) of the lane's float4
-  const float2 gi = *reinterpret_cast<const float2*>(tGi + ((e / 4) * 64 + lane) * 4 + e % 4);
-  const float2 gq = *reinterpret_cast<const float2*>(s.gq + e);
+  const float2 gi = s.gi_r[P % kEpiPrefetch], gq = s.gq_r[P % kEpiPrefetch];
+  if constexpr (P + kEpiPrefetch < G::E / 2) s.template fetch<P + kEpiPrefetch>(tGi, lane);
   s.D3[e / 16][e % 16] = nsilu(__builtin_fmaf(gq.x, gi.x, s.D3[e / 16][e % 16]));
   s.D3[e / 16][e % 16 + 1] = nsilu(__builtin_fmaf(gq.y, gi.y, s.D3[e / 16][e % 16 + 1]));
 }
@@ -279,45 +331,49 @@ struct Seq {
   static constexpr int acc(int I) { return T == 1 ? (I & 1) : tile(I); }                // accumulator index (T == 1: two partials)
   static constexpr int frag(int grp, int sd) { return T == 1 ? grp : (grp / (T / GS)) * T + GS * (grp % (T / GS)) + sd; }   // [ks][tile]
 };
-struct WSlots { h8 lo[2], hi[2]; };   // [side]
+// R = groups in flight: 1 for fragments in LDS (refilled >= 4 MFMAs before the next use), more for fragments streamed from L2
+template <int R>
+struct WSlots { h8 lo[R][2], hi[R][2]; };   // [ring slot][side]
 
-// one MFMA of a stage + the slot refills that become possible after it.  W(hi?, fragment) reads a weight fragment from LDS.
-template <class S, int I, int NACC, class WF>
-__device__ __forceinline__ void seq_mfma(f32x16 (&acc)[NACC], WSlots& ws, h8 bh, h8 bl, WF&& W) {
-  constexpr int sd = S::side(I), pr = S::prod(I), grp = S::group(I);
+// one MFMA of a stage + the slot refills that become possible after it.  W(hi?, fragment) reads a weight fragment.
+template <class S, int I, int R, int NACC, class WF>
+__device__ __forceinline__ void seq_mfma(f32x16 (&acc)[NACC], WSlots<R>& ws, h8 bh, h8 bl, WF&& W) {
+  constexpr int sd = S::side(I), pr = S::prod(I), grp = S::group(I), slot = grp % R;
   f32x16& d = acc[S::acc(I)];
-  if constexpr (pr == 0) d = mfma16(ws.lo[sd], bh, d);
-  else if constexpr (pr == 1) d = mfma16(ws.hi[sd], bl, d);
-  else d = mfma16(ws.hi[sd], bh, d);
-  if constexpr (grp + 1 < S::NGRP) {
-    if constexpr (pr == 0) ws.lo[sd] = W(false, S::frag(grp + 1, sd));
-    if constexpr (pr == 2) ws.hi[sd] = W(true, S::frag(grp + 1, sd));
+  if constexpr (pr == 0) d = mfma16(ws.lo[slot][sd], bh, d);
+  else if constexpr (pr == 1) d = mfma16(ws.hi[slot][sd], bl, d);
+  else d = mfma16(ws.hi[slot][sd], bh, d);
+  if constexpr (grp + R < S::NGRP) {
+    if constexpr (pr == 0) ws.lo[slot][sd] = W(false, S::frag(grp + R, sd));
+    if constexpr (pr == 2) ws.hi[slot][sd] = W(true, S::frag(grp + R, sd));
   }
 }
-template <class S, class WF>
-__device__ __forceinline__ void seq_begin(WSlots& ws, WF&& W) {
+template <class S, int R, class WF>
+__device__ __forceinline__ void seq_begin(WSlots<R>& ws, WF&& W) {
 #pragma unroll
-  for (int sd = 0; sd < S::GS; ++sd) {
-    ws.lo[sd] = W(false, S::frag(0, sd));
-    ws.hi[sd] = W(true, S::frag(0, sd));
-  }
+  for (int g = 0; g < (R < S::NGRP ? R : S::NGRP); ++g)
+#pragma unroll
+    for (int sd = 0; sd < S::GS; ++sd) {
+      ws.lo[g][sd] = W(false, S::frag(g, sd));
+      ws.hi[g][sd] = W(true, S::frag(g, sd));
+    }
 }
 
 // ---- stage X: GEMM2 of the query whose cl sit in D1 registers [R0, R0 + RPQ):  D2 = -log2e * (b1 + W1 cl) -----------
 template <class G>
 struct XState {
-  WSlots ws;
+  WSlots<1> ws;
   h8 bh, bl;         // current K-step's cl operand, split right before the K-step's first MFMA
 };
-template <class G>
-__device__ __forceinline__ void init_d2(f32x16 (&D2)[G::TH], const SplitPack<G>& w, int hi) {
+template <class G, class WP>
+__device__ __forceinline__ void init_d2(f32x16 (&D2)[G::TH], const WP& w, int hi) {
 #pragma unroll
   for (int t = 0; t < G::TH; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) D2[t][r] = w.b1[t * 32 + hi * 16 + r];
 }
-template <class G, int PX, int R0, int KS>
-__device__ __forceinline__ void cl_split(const f32x16 (&D1)[PX], const SplitPack<G>& w, h8& bh, h8& bl) {
+template <class G, int PX, int R0, int KS, class WP>
+__device__ __forceinline__ void cl_split(const f32x16 (&D1)[PX], const WP& w, h8& bh, h8& bl) {
   float xs[8];
 #pragma unroll
   for (int jj = 0; jj < 8; ++jj) {
@@ -328,13 +384,13 @@ __device__ __forceinline__ void cl_split(const f32x16 (&D1)[PX], const SplitPack
 }
 template <class G>
 using XSeq = Seq<G::TH, G::E / 8>;
-template <class G>
-__device__ __forceinline__ void x_begin(XState<G>& st, const SplitPack<G>& w, int lane) {
+template <class G, class WP>
+__device__ __forceinline__ void x_begin(XState<G>& st, const WP& w, int lane) {
   static_assert(G::TH % 2 == 0, "stage X keeps one accumulator per row tile: the hidden dim must be a multiple of 64");
   seq_begin<XSeq<G>>(st.ws, [&](bool hi_part, int f) { return (hi_part ? w.w1hi : w.w1lo)[f * 64 + lane]; });
 }
-template <class G, int PX, int R0, int I>
-__device__ __forceinline__ void x_mfma(const f32x16 (&D1)[PX], f32x16 (&D2)[G::TH], XState<G>& st, const SplitPack<G>& w, int lane) {
+template <class G, int PX, int R0, int I, class WP>
+__device__ __forceinline__ void x_mfma(const f32x16 (&D1)[PX], f32x16 (&D2)[G::TH], XState<G>& st, const WP& w, int lane) {
   using S = XSeq<G>;
   if constexpr (I % (3 * G::TH) == 0) cl_split<G, PX, R0, S::kstep(I)>(D1, w, st.bh, st.bl);
   seq_mfma<S, I>(D2, st.ws, st.bh, st.bl, [&](bool hi_part, int f) { return (hi_part ? w.w1hi : w.w1lo)[f * 64 + lane]; });
@@ -343,17 +399,17 @@ __device__ __forceinline__ void x_mfma(const f32x16 (&D1)[PX], f32x16 (&D2)[G::T
 // ---- stage Y: hid' = t/(1+2^t);  D3 = -log2e * (b2 + W2 hid) -----------------------------------------------------------
 // The B operand of K-step s+1 (silu + split of 8 hidden values, four slices of one value pair each) is produced under the
 // MFMAs of K-step s, into the other of two operand slots.
-template <class G>
+template <class G, int RY>
 struct YState {
   static constexpr int NACC = G::TL == 1 ? 2 : G::TL;
   f32x16 part[G::TL == 1 ? 2 : 1];   // TL == 1 only: the two partial accumulators (Seq); otherwise D3 itself is accumulated into
-  WSlots ws;
+  WSlots<RY> ws;
   u32x4v bh[2], bl[2];  // hid operands of K-steps s (slot s & 1), built pair by pair
 };
 template <class G>
 using YSeq = Seq<G::TL, G::F / 8>;
-template <class G, int SL>   // slice SL: value pair SL % 4 of K-step SL / 4
-__device__ __forceinline__ void silu_slice(const f32x16 (&D2)[G::TH], YState<G>& st, const SplitPack<G>& w) {
+template <class G, int SL, class WP, class YS>   // slice SL: value pair SL % 4 of K-step SL / 4
+__device__ __forceinline__ void silu_slice(const f32x16 (&D2)[G::TH], YS& st, const WP& w) {
   constexpr int ks = SL / 4, pr = SL % 4, f = 8 * ks + 2 * pr;
   const float h0 = nsilu(D2[f / 16][f % 16]), h1 = nsilu(D2[f / 16][f % 16 + 1]);
   unsigned h, l;
@@ -361,8 +417,8 @@ __device__ __forceinline__ void silu_slice(const f32x16 (&D2)[G::TH], YState<G>&
   st.bh[ks & 1][pr] = h;
   st.bl[ks & 1][pr] = l;
 }
-template <class G>
-__device__ __forceinline__ void y_begin(f32x16 (&D3)[G::TL], YState<G>& st, const SplitPack<G>& w, int lane, int hi) {
+template <class G, class WP, class YS>
+__device__ __forceinline__ void y_begin(f32x16 (&D3)[G::TL], YS& st, const WP& w, int lane, int hi) {
   if constexpr (G::TL == 1) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -375,22 +431,86 @@ __device__ __forceinline__ void y_begin(f32x16 (&D3)[G::TL], YState<G>& st, cons
 #pragma unroll
       for (int r = 0; r < 16; ++r) D3[v][r] = w.b2[hi * G::E + v * 16 + r];
   }
-  seq_begin<YSeq<G>>(st.ws, [&](bool hi_part, int f) { return (hi_part ? w.w2hi : w.w2lo)[f * 64 + lane]; });
+  seq_begin<YSeq<G>>(st.ws, [&](bool hi_part, int f) { return w.w2frag(hi_part, f, lane); });
 }
-template <class G, int I>
-__device__ __forceinline__ void y_mfma(f32x16 (&D3)[G::TL], YState<G>& st, const SplitPack<G>& w, int lane) {
+template <class G, int I, class WP, class YS>
+__device__ __forceinline__ void y_mfma(f32x16 (&D3)[G::TL], YS& st, const WP& w, int lane) {
   using S = YSeq<G>;
   constexpr int ks = S::kstep(I);
-  auto W = [&](bool hi_part, int f) { return (hi_part ? w.w2hi : w.w2lo)[f * 64 + lane]; };
+  auto W = [&](bool hi_part, int f) { return w.w2frag(hi_part, f, lane); };
   const h8 bh = __builtin_bit_cast(h8, st.bh[ks & 1]), bl = __builtin_bit_cast(h8, st.bl[ks & 1]);
   if constexpr (G::TL == 1) seq_mfma<S, I>(st.part, st.ws, bh, bl, W);
   else seq_mfma<S, I>(D3, st.ws, bh, bl, W);
 }
-template <class G>
-__device__ __forceinline__ void y_end(const YState<G>& st, f32x16 (&D3)[G::TL]) {
+template <class G, class YS>
+__device__ __forceinline__ void y_end(const YS& st, f32x16 (&D3)[G::TL]) {
   if constexpr (G::TL == 1) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) D3[0][r] = st.part[0][r] + st.part[1][r];
+  }
+}
+
+// ---- BIG (L = 256, 16x16x64): stage Y and the epilogue in two halves of the logit axis -------------------------------
+// D1 alone is 256 registers per lane, so GEMM3's accumulators exist one half (TL/2 row tiles = 64 registers) at a time:
+//   silu + split of the whole hidden layer, in place of D2 (same 64 registers, now packed f16 hi/lo)
+//   per half:  GEMM3 of the half's row tiles (W2 fragments streamed from L2, three groups in flight)
+//              -> u, this half's minimum, ex = 2^(min - u), den_h, num_h -> folded into the running (min, den, num)
+// i.e. an online softmax across the two halves: exact and overflow-free like the reference's, no fallback path needed.
+template <class G, int PX, int R0, int HALF, class WP>
+__device__ __forceinline__ void big_half(const f32x16 (&D1)[PX], const u32x4v (&hh)[G::F / 8], const u32x4v (&hl)[G::F / 8],
+                                         const WP& w, const float* tGi, const float* gq, int lane, int hi, float& mn, float& den, float& num) {
+  constexpr int NT = G::TL / 2, NYS = G::F / 8, EH = G::E / 2, E0 = HALF * EH;   // row tiles / K-steps / per-lane logits of the half
+  using S = Seq<NT, NYS>;
+  f32x16 D3[NT];
+#pragma unroll
+  for (int v = 0; v < NT; ++v)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) D3[v][r] = w.b2[hi * G::E + E0 + v * 16 + r];
+  // fragment f = ks * NT + local tile  ->  global fragment ks * TL + HALF * NT + local tile
+  auto W = [&](bool hi_part, int f) { return w.w2frag(hi_part, (f / NT) * G::TL + HALF * NT + f % NT, lane); };
+  WSlots<3> ws;
+  seq_begin<S>(ws, W);
+  // operands of the first logit pairs of the epilogue: requested before the GEMM, consumed after it
+  constexpr int PF = kEpiPrefetch;
+  float2 gi_r[PF], gq_r[PF];
+  auto fetch = [&](auto pc) {
+    constexpr int P = decltype(pc)::value, e = E0 + 2 * P;
+    gi_r[P % PF] = *reinterpret_cast<const float2*>(tGi + ((e / 4) * 64 + lane) * 4 + e % 4);
+    gq_r[P % PF] = *reinterpret_cast<const float2*>(gq + e);
+  };
+  static_for<PF>(fetch);
+  static_for<NYS>([&](auto kc) {
+    constexpr int KS = decltype(kc)::value;
+    static_for<3 * NT>([&](auto ic) {
+      seq_mfma<S, 3 * NT * KS + decltype(ic)::value>(D3, ws, __builtin_bit_cast(h8, hh[KS]), __builtin_bit_cast(h8, hl[KS]), W);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  // pass 1: u = t2 / (1 + 2^t2), t2 = -log2e * (gq * gi + gqi); minimum of the half
+  float hmn = INFINITY;
+  static_for<EH / 2>([&](auto pc) {
+    constexpr int P = decltype(pc)::value, el = 2 * P;
+    const float2 gi = gi_r[P % PF], gqv = gq_r[P % PF];
+    if constexpr (P + PF < EH / 2) fetch(std::integral_constant<int, P + PF>{});
+    const float u0 = nsilu(__builtin_fmaf(gqv.x, gi.x, D3[el / 16][el % 16]));
+    const float u1 = nsilu(__builtin_fmaf(gqv.y, gi.y, D3[el / 16][el % 16 + 1]));
+    D3[el / 16][el % 16] = u0;
+    D3[el / 16][el % 16 + 1] = u1;
+    hmn = __builtin_fminf(__builtin_fminf(hmn, u0), u1);
+  });
+  hmn = __builtin_fminf(hmn, swap32(hmn));
+  // fold into the running softmax state: everything accumulated so far is rescaled to the new minimum (first half: mn = +inf -> factor 0)
+  const float mnew = __builtin_fminf(mn, hmn);
+  const float scale = f_exp2(mnew - mn);
+  den *= scale;
+  num *= scale;
+  mn = mnew;
+#pragma unroll
+  for (int el = 0; el < EH; ++el) {
+    const int e = E0 + el;
+    const float ex = f_exp2(mn - D3[el / 16][el % 16]);
+    den += ex;
+    num = __builtin_fmaf(ex, D1[e / G::RPQ][R0 + e % G::RPQ], num);
   }
 }
 
@@ -404,8 +524,14 @@ __device__ long long g_f16_phase[32];
 // OVERLAP: stage X of query Q+1 carries the epilogue of query Q (needs D2 and D3 of two queries live at once).
 // TIGHT:   the accumulators alone fill the register budget (8x8x32 at two waves per SIMD: 224 of 256): no operand double
 //          buffering in stage Y and no pinned order -- the compiler's own schedule fits without spilling, a pinned one does not.
-template <bool OVERLAP, bool TIGHT>
+// BIG:     16x16x64 -- the gate pack does not fit LDS (SplitPack), W2 fragments go through a 3-deep register ring.
+template <bool OVERLAP, bool TIGHT, bool BIG = false>
 struct F16Unit {
+  template <class G>
+  static constexpr int kLdsWeightFloats = SplitPack<G, BIG>::kLdsFloats;
+  template <class G, int NW>
+  static __device__ __forceinline__ void stage(const ScoreArgs& p, float* smem) { SplitPack<G, BIG>::template stage<NW>(p, smem); }
+
   template <class G, int PX, int DD>
   static __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float* __restrict__ eq, const float4* tEx, int lane) {
     gemm1_presplit<G, PX, DD>(D1, reinterpret_cast<const h8*>(eq), reinterpret_cast<const h8*>(tEx), lane);
@@ -417,7 +543,7 @@ struct F16Unit {
     constexpr int NXM = (G::E / 8) * G::TH * 3;   // MFMAs of stage X
     constexpr int NYM = (G::F / 8) * G::TL * 3;   // MFMAs of stage Y
     constexpr int NYS = G::F / 8;                 // K-steps of stage Y
-    const SplitPack<G> w(smem);
+    const SplitPack<G, BIG> w(smem, p.wpack);
     const float* tGi = reinterpret_cast<const float*>(tGi4);
     const int64_t item = item0 + x;
     const bool lane_stores = hi == 0 && item < p.n_items;
@@ -430,7 +556,7 @@ struct F16Unit {
     f32x16 D2[G::TH];
     Epi<G> ep;
     XState<G> xs;
-    YState<G> ys;
+    YState<G, (BIG ? 3 : 1)> ys;
     auto stage_x_alone = [&](auto qc) {   // GEMM2 with nothing to hide it under but the operand splits
       constexpr int Q = decltype(qc)::value;
       init_d2<G>(D2, w, hi);
@@ -470,6 +596,35 @@ struct F16Unit {
       return epi_final<G, PX, Q * G::RPQ>(ep, D1);
     };
 
+    if constexpr (BIG) {
+      static_for<G::QT>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        const int q = g * G::QT + Q;
+        if (only < 0 || q == only) {
+          F16_STAMP(4 * Q);
+          stage_x_alone(qc);
+          F16_STAMP(4 * Q + 1);
+          u32x4v hh[NYS], hl[NYS];   // the hidden layer as packed f16 hi / lo operands, in the registers D2 frees
+          static_for<4 * NYS>([&](auto sc) {
+            constexpr int SL = decltype(sc)::value, ks = SL / 4, pr = SL % 4, f = 8 * ks + 2 * pr;
+            unsigned h, l;
+            split_pair(nsilu(D2[f / 16][f % 16]), nsilu(D2[f / 16][f % 16 + 1]), w.m1, h, l);
+            hh[ks][pr] = h;
+            hl[ks][pr] = l;
+          });
+          F16_STAMP(4 * Q + 2);
+          float mn = INFINITY, den = 0.0f, num = 0.0f;
+          big_half<G, PX, Q * G::RPQ, 0>(D1, hh, hl, w, tGi, gq_of(q), lane, hi, mn, den, num);
+          big_half<G, PX, Q * G::RPQ, 1>(D1, hh, hl, w, tGi, gq_of(q), lane, hi, mn, den, num);
+          den += swap32(den);
+          num += swap32(num);
+          const float rden = __builtin_amdgcn_rcpf(den);
+          store(q, (num * rden) / fmaxf(den * rden, 1e-6f));
+          F16_STAMP(4 * Q + 3);
+        }
+      });
+      return;
+    }
     if (only >= 0 || !OVERLAP) {
       // per-row candidates (one query of the group), or the cross-query overlap switched off: query by query
       static_for<G::QT>([&](auto qc) {
@@ -479,7 +634,7 @@ struct F16Unit {
           F16_STAMP(4 * Q);
           stage_x_alone(qc);
           F16_STAMP(4 * Q + 1);
-          ep.reset(gq_of(q));
+          ep.reset(gq_of(q), tGi, lane);
           stage_y(qc);
           F16_STAMP(4 * Q + 2);
           store(q, epilogue_alone(qc));
@@ -496,7 +651,7 @@ struct F16Unit {
     static_for<G::QT>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       const int q = g * G::QT + Q;
-      ep.reset(gq_of(q));
+      ep.reset(gq_of(q), tGi, lane);
       stage_y(qc);
       F16_STAMP(2 + 2 * Q);
       if constexpr (Q + 1 < G::QT) {
@@ -548,6 +703,11 @@ int score_launch_f16(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t s
   MOL_CASE(8, 4, 128)
   MOL_CASE(8, 8, 32)
 #undef MOL_CASE
+  if (s.query_dot_product_groups == 16 && s.item_dot_product_groups == 16 && s.dot_product_dimension == 64) {
+    // L = 256: tiles (160 KiB) and the gate pack (256 KiB) are beyond LDS staging -- independent waves, one per SIMD
+    // (512 registers hold the whole D1), W1 in LDS, W2 streamed from L2
+    return launch_kernel<F16Unit<false, true, true>, 16, 16, 64, 128, 4, false>(a, n_cu, stream);
+  }
   set_error("the f16x3 precision mode is not built for this shape");
   return kErrUnsupported;
 }

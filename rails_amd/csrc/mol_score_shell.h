@@ -35,7 +35,7 @@ template <class U, int PQ, int PX, int DD, int H, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(ScoreArgs p) {
   using G = Geo<PQ, PX, DD, H>;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  stage_weights<G, NW>(p, smem);
+  U::template stage<G, NW>(p, smem);
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -49,9 +49,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(Score
   // first few CUs (ML-20M: 6824 units on 1024 SIMDs, worst SIMD 7 passes instead of 8; ML-1M: all 256 CUs busy).
   const int64_t stride = (int64_t)gridDim.x * NW;
   const int64_t rounds = n_units / stride;
+  // XCD-aware numbering: hardware workgroup b runs on XCD b % 8 (each XCD has its own L2).  Consecutive workgroups share
+  // a tile's query groups; logical id = (b % 8) * (grid / 8) + b / 8 keeps consecutive logical workgroups on one XCD, so
+  // a tile is fetched into one L2 instead of several.  Placement is only a speed matter: any mapping is correct.
+  const int64_t bx = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
   for (int64_t it = 0; it <= rounds; ++it) {
-    const int64_t u = it < rounds ? it * stride + (int64_t)blockIdx.x * NW + wave
-                                  : rounds * stride + (int64_t)wave * gridDim.x + blockIdx.x;
+    const int64_t u = it < rounds ? it * stride + bx * NW + wave
+                                  : rounds * stride + (int64_t)wave * gridDim.x + bx;
     if (u >= n_units) break;
     const int64_t outer = u / inner;
     const int innr = (int)(u - outer * inner);
@@ -88,8 +92,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(Score
   using G = Geo<PQ, PX, DD, H>;
   static_assert(G::kTileFloats % 256 == 0, "tile must be a whole number of 1 KiB pieces");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* tiles = smem + G::kWpackFloats;  // two tile buffers
-  stage_weights<G, NW>(p, smem);
+  float* tiles = smem + U::template kLdsWeightFloats<G>;  // two tile buffers
+  U::template stage<G, NW>(p, smem);
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged1_kernel(Scor
   using G = Geo<PQ, PX, DD, H>;
   static_assert(G::kTileExFloats % 256 == 0 && G::kTileGiFloats % 256 == 0, "1 KiB DMA pieces");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sEx = smem + G::kWpackFloats;
+  float* sEx = smem + U::template kLdsWeightFloats<G>;
   float* sGi = sEx + G::kTileExFloats;   // two gi buffers
 
   const int lane = threadIdx.x & 63;
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged1_kernel(Scor
   const bool has_left = b < left * nsub;
   const int64_t mine = rounds + (has_left ? 1 : 0);
   if (mine == 0) return;
-  stage_weights<G, NW>(p, smem);
+  U::template stage<G, NW>(p, smem);
   auto tile_of = [&](int64_t i) -> int64_t { return i < rounds ? b + i * grid : rounds * grid + b % left; };
 
   {
@@ -199,7 +203,7 @@ inline int score_variant() {
 template <class U, int PQ, int PX, int DD, int H, int NW, bool STAGED>
 static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using G = Geo<PQ, PX, DD, H>;
-  constexpr size_t lds = ((size_t)G::kWpackFloats + (STAGED ? 2 * (size_t)G::kTileFloats : 0)) * sizeof(float);
+  constexpr size_t lds = ((size_t)U::template kLdsWeightFloats<G> + (STAGED ? 2 * (size_t)G::kTileFloats : 0)) * sizeof(float);
   if constexpr (lds > 160 * 1024) {
     set_error("staged scoring kernel needs %zu B of LDS", lds);
     return kErrUnsupported;
@@ -229,7 +233,7 @@ static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
 template <class U, int PQ, int PX, int DD, int H, int NW>
 static int launch_staged1(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using G = Geo<PQ, PX, DD, H>;
-  constexpr size_t lds = ((size_t)G::kWpackFloats + (size_t)G::kTileExFloats + 2 * (size_t)G::kTileGiFloats) * sizeof(float);
+  constexpr size_t lds = ((size_t)U::template kLdsWeightFloats<G> + (size_t)G::kTileExFloats + 2 * (size_t)G::kTileGiFloats) * sizeof(float);
   if constexpr (lds > 160 * 1024) {
     set_error("single-buffer staged scoring kernel needs %zu B of LDS", lds);
     return kErrUnsupported;

@@ -18,8 +18,6 @@ PRECISIONS = ["fp32", "f16x3"]   # every scoring test runs on both builds of the
 
 
 def build_module(cfg, weights, dev, precision=None):
-    if precision == "f16x3" and cfg.query_dot_product_groups * cfg.item_dot_product_groups > 64:
-        pytest.skip("precision f16x3 is not built for 16x16x64")
     mol = _build_module(cfg, weights, dev)
     mol.precision = precision
     return mol

@@ -20,6 +20,9 @@ from rails_amd import _lib  # noqa: E402
 def main():
     workload = sys.argv[1] if len(sys.argv) > 1 else "amzn-books"
     cfg_key, N, _ = bench.WORKLOADS[workload]
+    if len(sys.argv) > 2:
+        N = int(sys.argv[2])
+    variants = (("0", "1"),) if cfg_key.endswith("16x16x64") else (("2", "1"), ("2", "0"), ("4", "1"), ("4", "0"), ("5", "1"), ("5", "0"))
     cfg = O.CONFIGS[cfg_key]
     dev = torch.device("cuda:0")
     w = O.synthetic_weights(cfg, seed=0)
@@ -40,7 +43,7 @@ def main():
         eng = mol.engine()
         index = eng.build_index(X)
         qpack, _, _ = eng.query_pack(q, uid)
-        for variant, overlap in (("2", "1"), ("2", "0"), ("4", "1"), ("4", "0"), ("5", "1"), ("5", "0")):
+        for variant, overlap in variants:
             os.environ["RAILS_SCORE_VARIANT"], os.environ["RAILS_F16_OVERLAP"] = variant, overlap
             try:
                 for _ in range(2):
