@@ -116,30 +116,38 @@ class MoLAvgTopK(MoLTopKModule):
             self._coarse_table = eng.build_coarse_table(self._index, self._item_embeddings[0])
         return self._coarse_table
 
-    def _coarse_topk(self, query_embeddings: torch.Tensor, average_queries: bool, **kwargs):
+    def _coarse_topk(self, query_embeddings: torch.Tensor, average_queries: bool, pending: Optional[list] = None, **kwargs):
         eng = self._bind()
         table = self._table()
         qpack, eq, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"), want_plain=True)
-        return qpack, self._coarse_topk_from_eq(eq, average_queries)
+        return qpack, self._coarse_topk_from_eq(eq, average_queries, pending)
 
-    def _coarse_topk_from_eq(self, eq: torch.Tensor, average_queries: bool) -> torch.Tensor:
-        """(B, P_Q, d) query components -> (B, avg_top_k) positions of the coarse top-K', best first."""
+    def _coarse_topk_from_eq(self, eq: torch.Tensor, average_queries: bool, pending: Optional[list] = None) -> torch.Tensor:
+        """(B, P_Q, d) query components -> (B, avg_top_k) positions of the coarse top-K', best first.
+        The fused scan's result is exact iff every row collected between K' and `capacity` candidates.  With `pending` (a
+        list) the check is DEFERRED: the positions are returned at once, a closure that reads the counts is appended, and the
+        caller verifies after it has enqueued everything that depends on the positions (speculate, then verify: the GPU
+        never waits for the host in mid-pipeline).  Without it the check is made here (one 128-byte D2H copy)."""
         eng = self._bind()
         table = self._table()
         n = table.shape[0]
         if self._avg_top_k > n:
             raise RuntimeError(f"selected index k out of range (k={self._avg_top_k}, n={n})")
         if eq.shape[0] > 128:   # the scan keeps ceil(B / 32) query tiles in LDS: larger batches go in slices
-            return torch.cat([self._coarse_topk_from_eq(eq[b0 : b0 + 128], average_queries) for b0 in range(0, eq.shape[0], 128)], dim=0)
+            return torch.cat([self._coarse_topk_from_eq(eq[b0 : b0 + 128], average_queries, pending) for b0 in range(0, eq.shape[0], 128)], dim=0)
         # large corpora: fused scan + threshold select, no (B, N) score matrix (16 GB per 125 M-item shard at B = 32).
         # Same scores and the same exact top-K' as the materialising path below -- when every query's candidate count
         # landed inside [K', capacity]; the check costs one 128-byte device-to-host copy.
-        if n >= self.fused_coarse_min_items and self._avg_top_k <= 4096:
+        if n >= self.fused_coarse_min_items and self._avg_top_k <= 4096 and not getattr(self, "_no_fused", False):
             fused = eng.coarse_topk(eq, table, average_queries, self._avg_top_k)
             if fused is not None:
                 _, idx, counts = fused
-                lo, hi = int(counts.min()), int(counts.max())
-                if lo >= self._avg_top_k and hi <= eng.coarse_topk_capacity(self._avg_top_k):
+                k_lo, k_hi = self._avg_top_k, eng.coarse_topk_capacity(self._avg_top_k)
+                check = lambda: int(counts.min()) >= k_lo and int(counts.max()) <= k_hi   # noqa: E731
+                if pending is not None:
+                    pending.append(check)
+                    return idx
+                if check():
                     return idx
         coarse = eng.coarse_scores(eq, table, average_queries)
         _, idx = E.topk(coarse, self._avg_top_k)
@@ -155,10 +163,23 @@ class MoLAvgTopK(MoLTopKModule):
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
         if k > self._avg_top_k:  # the reference raises after doing the work (mol_top_k.py:383-386)
             raise ValueError(f"avg_top_k ({self._avg_top_k}) must be larger than k ({k})")
-        with torch.profiler.record_function("avg_top_k_scoring"):
-            qpack, idx = self._coarse_topk(query_embeddings, average_queries=False, **kwargs)
-        with torch.profiler.record_function("filtered_scoring"):
-            scores, ids = self.rerank(qpack, query_embeddings.size(0), idx, k)
+        # the reference's four profiler spans (mol_top_k.py:350-382), around the launches that do the same work here
+        for attempt in range(2):
+            pending: list = []
+            with torch.profiler.record_function("avg_top_k_scoring"):
+                qpack, idx = self._coarse_topk(query_embeddings, average_queries=False, pending=pending, **kwargs)
+            eng = self._bind()
+            with torch.profiler.record_function("avg_topk_selection"):
+                cand, kp = eng.gather_index(self._index, idx)
+            with torch.profiler.record_function("filtered_scoring"):
+                cand_scores = eng.score_candidates(qpack, query_embeddings.size(0), cand, kp)[:, : idx.shape[1]]
+            with torch.profiler.record_function("final_topk"):
+                scores, ids = E.topk(cand_scores, min(k, idx.shape[1]), ids=self._ids_flat[idx])
+            # everything is enqueued; only now look at the fused scan's candidate counts (rarely out of range: heavy ties)
+            if all(chk() for chk in pending):
+                break
+            self._no_fused = True      # redo this call on the materialising path
+        self._no_fused = False
         return scores.to(query_embeddings.dtype), ids
 
     def topk_ids(self, query_embeddings: torch.Tensor, sorted: bool = True, **kwargs) -> torch.Tensor:
@@ -169,6 +190,16 @@ class MoLAvgTopK(MoLTopKModule):
 class _ComponentCandidates:
     """Per-component candidate generation shared by MoLNaiveTopK and MoLCombTopK."""
 
+    UNION_CAP = 16384   # candidates per query the rerank can sort and select in LDS (rails_sort_rows_i64 / rails_topk, k <= 16384)
+
+    def _check_union_size(self, n_candidates: int) -> None:
+        """The union is sorted and fully ranked per query inside one workgroup's LDS; reject configurations beyond that
+        at construction (16x16x64 with k_per_group >= 75: 256 * 75 = 19 200) instead of failing in the first forward."""
+        if n_candidates > self.UNION_CAP:
+            raise NotImplementedError(
+                f"{type(self).__name__}: {n_candidates} candidates per query exceed the rerank capacity of {self.UNION_CAP} "
+                "(P_Q * P_X * k_per_group [+ avg_top_k]); use a smaller k_per_group for this shape")
+
     def _component_table(self) -> torch.Tensor:
         eng = self._bind()
         if getattr(self, "_comp_engine", None) is not eng:
@@ -176,8 +207,9 @@ class _ComponentCandidates:
             self._comp_table = eng.build_component_table(self._index, self._item_embeddings[0])
         return self._comp_table
 
-    def _component_topk(self, eq: torch.Tensor, k_per_group: int) -> torch.Tensor:
-        """-> (B, P_Q * P_X * k_per_group) positions: top k_per_group items of every (query group, item group) pair."""
+    def _component_topk(self, eq: torch.Tensor, k_per_group: int, pending: Optional[list] = None) -> torch.Tensor:
+        """-> (B, P_Q * P_X * k_per_group) positions: top k_per_group items of every (query group, item group) pair.
+        `pending`: deferred validity check of the fused scan, as in MoLAvgTopK._coarse_topk_from_eq."""
         eng = self._bind()
         table = self._component_table()
         n = table.shape[0]
@@ -185,14 +217,19 @@ class _ComponentCandidates:
             raise RuntimeError(f"selected index k out of range (k={k_per_group}, n={n})")
         # the component scan keeps the fragments of all B * P_Q query rows in LDS: batches beyond 64 queries go in slices
         if eq.shape[0] > 64:
-            return torch.cat([self._component_topk(eq[b0 : b0 + 64], k_per_group) for b0 in range(0, eq.shape[0], 64)], dim=0)
+            return torch.cat([self._component_topk(eq[b0 : b0 + 64], k_per_group, pending) for b0 in range(0, eq.shape[0], 64)], dim=0)
         # large corpora: fused scan + threshold select, no (B*P_Q*P_X, N) score matrix (5.7 GB at amzn-books, B = 32);
         # identical to the materialising path below whenever every row's candidate count is inside [k, capacity]
-        if n >= getattr(self, "fused_component_min_items", 262144):
+        if n >= getattr(self, "fused_component_min_items", 262144) and not getattr(self, "_no_fused", False):
             fused = eng.component_topk(eq, table, k_per_group)
             if fused is not None:
                 _, pos, counts = fused
-                if int(counts.min()) >= k_per_group and int(counts.max()) <= eng.coarse_topk_capacity(k_per_group):
+                k_hi = eng.coarse_topk_capacity(k_per_group)
+                check = lambda: int(counts.min()) >= k_per_group and int(counts.max()) <= k_hi   # noqa: E731
+                if pending is not None:
+                    pending.append(check)
+                    return pos.view(eq.shape[0], -1)
+                if check():
                     return pos.view(eq.shape[0], -1)
         scores = eng.component_scores(eq, table)
         _, pos = E.topk(scores, k_per_group)
@@ -220,12 +257,19 @@ class MoLNaiveTopK(MoLTopKModule, _ComponentCandidates):
         super().__init__(mol_module=mol_module, item_embeddings=item_embeddings, item_ids=item_ids)
         self._k_per_group: int = k_per_group
         self._use_faiss: bool = False
+        self._check_union_size(mol_module._query_dot_product_groups * mol_module._item_dot_product_groups * k_per_group)
 
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
         eng = self._bind()
         qpack, eq, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"), want_plain=True)
-        all_indices = self._component_topk(eq, self._k_per_group)
-        scores, ids = self._rerank_union(qpack, query_embeddings.size(0), all_indices, sorted)
+        for attempt in range(2):     # speculate on the fused scans, verify after everything is enqueued
+            pending: list = []
+            all_indices = self._component_topk(eq, self._k_per_group, pending)
+            scores, ids = self._rerank_union(qpack, query_embeddings.size(0), all_indices, sorted)
+            if all(chk() for chk in pending):
+                break
+            self._no_fused = True
+        self._no_fused = False
         return scores.to(query_embeddings.dtype), ids
 
 
@@ -236,13 +280,20 @@ class MoLCombTopK(MoLAvgTopK, _ComponentCandidates):
     def __init__(self, mol_module: MoLSimilarity, item_embeddings: torch.Tensor, item_ids: torch.Tensor, avg_top_k: int, k_per_group: int) -> None:
         super().__init__(mol_module=mol_module, item_embeddings=item_embeddings, item_ids=item_ids, avg_top_k=avg_top_k)
         self._k_per_group: int = k_per_group
+        self._check_union_size(mol_module._query_dot_product_groups * mol_module._item_dot_product_groups * k_per_group + avg_top_k)
 
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
         eng = self._bind()
         qpack, eq, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"), want_plain=True)
-        comp = self._component_topk(eq, self._k_per_group)
-        avg_idx = self._coarse_topk_from_eq(eq, average_queries=True)
-        scores, ids = self._rerank_union(qpack, query_embeddings.size(0), torch.cat([comp, avg_idx], dim=1), sorted)
+        for attempt in range(2):
+            pending: list = []
+            comp = self._component_topk(eq, self._k_per_group, pending)
+            avg_idx = self._coarse_topk_from_eq(eq, average_queries=True, pending=pending)
+            scores, ids = self._rerank_union(qpack, query_embeddings.size(0), torch.cat([comp, avg_idx], dim=1), sorted)
+            if all(chk() for chk in pending):
+                break
+            self._no_fused = True
+        self._no_fused = False
         return scores.to(query_embeddings.dtype), ids
 
 
