@@ -171,11 +171,12 @@ def measurement_matrix(mol, X, ids, q, kw, inv, cfg, n_items: int, steps: int, d
     return points
 
 
-def quick_workload(name: str, B: int, k: int, kp: int, steps: int, dev) -> dict:
+def quick_workload(name: str, B: int, k: int, kp: int, steps: int, dev, items: int = 0, precision: str = "fp32") -> dict:
     """Secondary measurement of another BASELINE.json config on one GPU (same step definition, fewer steps)."""
     from oracle import mol_oracle as O
 
     cfg_key, N, width = WORKLOADS[name]
+    N = items or N
     cfg = O.CONFIGS[cfg_key]
     weights = O.synthetic_weights(cfg, seed=0)
     mol, _ = rails_amd.create_mol_interaction_module(
@@ -185,6 +186,7 @@ def quick_workload(name: str, B: int, k: int, kp: int, steps: int, dev) -> dict:
         query_nonlinearity=cfg.query_nonlinearity, uid_embedding_hash_sizes=list(cfg.uid_embedding_hash_sizes) or None)
     mol.load_state_dict(weights, strict=True)
     mol = mol.to(dev).eval()
+    mol.precision = None if precision == "fp32" else precision
     X = torch.from_numpy(O.hash_item_table(1, 0, N, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
     ids = torch.arange(1, N + 1, dtype=torch.int64, device=dev).unsqueeze(0)
     q = O.synthetic_queries(cfg, B).to(dev)
@@ -196,7 +198,7 @@ def quick_workload(name: str, B: int, k: int, kp: int, steps: int, dev) -> dict:
         tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
         cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)
         _, top_ids = tk(q, k=min(kp, N), **kw)
-        inv = torch.zeros((B, width), dtype=torch.int64, device=dev)
+        inv = torch.zeros((B, max(width, 1)), dtype=torch.int64, device=dev)
         g = torch.Generator().manual_seed(4)
         for b in range(B):
             sel = torch.randperm(top_ids.shape[1], generator=g)[: width // 2].to(dev)
@@ -216,9 +218,11 @@ def quick_workload(name: str, B: int, k: int, kp: int, steps: int, dev) -> dict:
         e1.record()
         torch.cuda.synchronize()
         score_ms = e0.elapsed_time(e1) / steps   # prologue + scoring kernel
-    return {"workload": f"{name} {cfg.query_dot_product_groups}x{cfg.item_dot_product_groups}x{cfg.dot_product_dimension}, N={N}",
+    tf = B * N * flops_per_pair(cfg) / (score_ms * 1e-3) / 1e12
+    return {"workload": f"{name} {cfg.query_dot_product_groups}x{cfg.item_dot_product_groups}x{cfg.dot_product_dimension}, N={N}", "precision": precision,
             "queries_per_s": B / dt, "ms_per_step": dt * 1e3, "prologue_plus_scoring_ms": score_ms,
-            "scoring_tflops_algorithmic_lower_bound": B * N * flops_per_pair(cfg) / (score_ms * 1e-3) / 1e12}
+            "scoring_tflops_algorithmic_lower_bound": tf,
+            "mfma_frac_lower_bound": tf / (PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_F16X3_TFLOPS)}
 
 
 def main() -> None:
@@ -559,7 +563,9 @@ def main() -> None:
             out["matrix"] = measurement_matrix(mol, X, ids, q, kw, inv, cfg, hi - lo, min(args.steps, 10), dev)
         if world == 1 and args.workload == "amzn-books" and not args.no_other_workloads:
             # the two smaller real-dataset shapes of BASELINE.json (configs 1 and 2): fixed per-batch costs dominate there
-            out["other_workloads"] = [quick_workload(n, B, k, kp, 10, dev) for n in ("ml-20m", "ml-1m")]
+            out["other_workloads"] = [quick_workload(n, B, k, kp, 10, dev, precision=pr) for n in ("ml-20m", "ml-1m") for pr in ("fp32", "f16x3")]
+            # BASELINE config 4 (16x16x64, 100 M items 8-way): a 400 k-item sub-range of one shard -- the kernels are linear in N
+            out["other_workloads"] += [quick_workload("synthetic-16x16x64", B, k, kp, 5, dev, items=400_000, precision=pr) for pr in ("fp32", "f16x3")]
         if world == 1 and not args.no_cpu_baseline and not two_pass:   # the CPU baseline is the exact path
             out["cpu_baseline"] = cpu_baseline(cfg, weights, q_cpu, uid_cpu, N, min(args.cpu_sample_items or N, N), kp)
         print(json.dumps(out), flush=True)

@@ -13,6 +13,11 @@ ShardedMoLAvgTopK (BASELINE config 5: 1 B items 8-way, coarse prefilter + MoL re
 runs MoLAvgTopK on its shard -- coarse top-K' of ITS items, full MoL on those, local top-k -- and the merge is the same,
 because what is merged are exact MoL scores.  It reranks R*K' candidates in total (K' per shard), a superset-quality
 variant of the single-device algorithm with the same K'; it equals it exactly when R = 1.
+
+ShardedMoLAvgTopK(global_k_prime=True) is the single-device algorithm itself on a sharded corpus:
+one more all-gather first exchanges every shard's coarse top-K' (coarse score bits | global position), every rank
+selects the GLOBAL coarse top-K' with the same total order (score desc, global position asc), reranks only its own
+members of it, and the usual merge follows.  Bit-identical to MoLAvgTopK(avg_top_k = K') over the whole corpus.
 """
 from __future__ import annotations
 
@@ -126,14 +131,79 @@ class ShardedMoLAvgTopK(ShardedTopK):
     the same single all-gather + merge.  `avg_top_k` is PER SHARD; k <= avg_top_k as in the reference
     (rails/indexing/mol_top_k.py:383-386)."""
 
-    def __init__(self, mol_module, item_embeddings_shard, item_ids_shard, n_items_total: int, avg_top_k: int, **kwargs) -> None:
+    def __init__(self, mol_module, item_embeddings_shard, item_ids_shard, n_items_total: int, avg_top_k: int,
+                 global_k_prime: bool = False, shard_offset: Optional[int] = None,
+                 coarse_local: Optional[Callable[..., Tuple[torch.Tensor, torch.Tensor]]] = None,
+                 rerank_local: Optional[Callable[..., Tuple[torch.Tensor, torch.Tensor]]] = None, **kwargs) -> None:
+        """global_k_prime: exchange coarse candidates first so that exactly the global coarse top-K' is reranked (see the module
+        docstring); `shard_offset` = global position of this shard's first item (default: the contiguous split of shard_bounds).
+        `coarse_local(q, **kw) -> (scores, local positions)` / `rerank_local(q, local positions with -1 holes, k, **kw) ->
+        (scores, ids)` default to the HIP module's methods; the CPU test of the collective logic injects oracle callables."""
         self._avg_top_k = avg_top_k
+        self._global = global_k_prime
+        if coarse_local is not None and "local_topk" not in kwargs:
+            kwargs["local_topk"] = lambda q, k, **kw: (_ for _ in ()).throw(RuntimeError("global_k_prime path only"))   # noqa: E731
         super().__init__(mol_module, item_embeddings_shard, item_ids_shard, n_items_total, **kwargs)
+        rank = dist.get_rank(self._group) if dist.is_initialized() else 0
+        self._offset = shard_offset if shard_offset is not None else shard_bounds(n_items_total, self._world, rank)[0]
+        self._coarse_local = coarse_local if coarse_local is not None else (lambda q, **kw: self._local_module.coarse_candidates(q, **kw))
+        self._rerank_local = rerank_local if rerank_local is not None else (lambda q, idx, k, **kw: self._local_module.rerank_masked(q, idx, k, **kw))
 
     def _make_local_module(self, mol_module, item_embeddings_shard, item_ids_shard) -> TopKModule:
         return MoLAvgTopK(mol_module, item_embeddings_shard, item_ids_shard, avg_top_k=min(self._avg_top_k, int(item_ids_shard.numel())))
 
+    def _gather(self, msg: torch.Tensor) -> torch.Tensor:
+        """(B, W) -> (world * B, W), rank-major (host-staged only for device tensors on a gloo group: test setups)."""
+        if msg.is_cuda and dist.get_backend(self._group) == "gloo":
+            host = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype)
+            dist.all_gather_into_tensor(host, msg.cpu(), group=self._group)
+            return host.to(msg.device)
+        out = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype, device=msg.device)
+        dist.all_gather_into_tensor(out, msg, group=self._group)
+        return out
+
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
         if k > self._avg_top_k:
             raise ValueError(f"avg_top_k ({self._avg_top_k}) must be larger than k ({k})")
-        return super().forward(query_embeddings, k, sorted, **kwargs)
+        if not self._global or self._world == 1:
+            return super().forward(query_embeddings, k, sorted, **kwargs)
+        K = self._avg_top_k
+        if K > self._n_total:
+            raise RuntimeError(f"selected index k out of range (k={K}, n={self._n_total})")
+        B = query_embeddings.size(0)
+        dev = query_embeddings.device
+        # (1) local coarse top-K' -> message (coarse score bits | GLOBAL position), K' slots, short shards padded with (-inf, -1)
+        if self._n_local > 0:
+            cs, cpos = self._coarse_local(query_embeddings, **kwargs)
+            cpos = cpos + self._offset
+        else:
+            cs = torch.empty((B, 0), dtype=torch.float32, device=dev)
+            cpos = torch.empty((B, 0), dtype=torch.int64, device=dev)
+        on_gpu = cs.is_cuda and self._merge is _hip_merge
+        msg = E.pack_candidates(cs, cpos, K) if on_gpu else pack_candidates(cs.float(), cpos, K)
+        gathered = self._gather(msg)
+        # (2) the global coarse top-K' (same total order on every rank: score desc, global position asc)
+        if on_gpu and self._world * K <= 16384:   # one kernel (its lists are sorted in LDS)
+            _, gpos = E.merge_candidates(gathered, self._world, K, K)
+        elif on_gpu:                              # long lists: the general top-k over the shard-major concatenation (same tie rule)
+            all_s, all_p = unpack_candidates(gathered.view(self._world, B, 2 * K), K)
+            _, gpos = E.topk(all_s, K, ids=all_p)
+        else:
+            all_s, all_p = unpack_candidates(gathered.view(self._world, B, 2 * K), K)
+            _, gpos = self._merge(all_s, all_p, K)
+        # (3) rerank my members of it (others become holes), local top-k, and the usual exchange of exact MoL scores
+        mine = (gpos >= self._offset) & (gpos < self._offset + self._n_local)
+        local_idx = torch.where(mine, gpos - self._offset, gpos.new_full((), -1))
+        if self._n_local > 0:
+            s, ids = self._rerank_local(query_embeddings, local_idx, k, **kwargs)
+        else:
+            s = torch.full((B, k), float("-inf"), dtype=torch.float32, device=dev)
+            ids = torch.full((B, k), -1, dtype=torch.int64, device=dev)
+        msg2 = E.pack_candidates(s, ids, k) if on_gpu else pack_candidates(s.float(), ids, k)
+        gathered2 = self._gather(msg2)
+        if on_gpu:
+            ms, mi = E.merge_candidates(gathered2, self._world, k, k)
+        else:
+            all_s, all_i = unpack_candidates(gathered2.view(self._world, B, 2 * k), k)
+            ms, mi = self._merge(all_s, all_i, k)
+        return ms.to(s.dtype), mi

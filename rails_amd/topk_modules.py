@@ -122,8 +122,9 @@ class MoLAvgTopK(MoLTopKModule):
         qpack, eq, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"), want_plain=True)
         return qpack, self._coarse_topk_from_eq(eq, average_queries, pending)
 
-    def _coarse_topk_from_eq(self, eq: torch.Tensor, average_queries: bool, pending: Optional[list] = None) -> torch.Tensor:
-        """(B, P_Q, d) query components -> (B, avg_top_k) positions of the coarse top-K', best first.
+    def _coarse_topk_from_eq(self, eq: torch.Tensor, average_queries: bool, pending: Optional[list] = None, with_scores: bool = False):
+        """(B, P_Q, d) query components -> (B, avg_top_k) positions of the coarse top-K', best first
+        (with_scores: -> (scores, positions), the bf16 coarse scores as fp32).
         The fused scan's result is exact iff every row collected between K' and `capacity` candidates.  With `pending` (a
         list) the check is DEFERRED: the positions are returned at once, a closure that reads the counts is appended, and the
         caller verifies after it has enqueued everything that depends on the positions (speculate, then verify: the GPU
@@ -134,24 +135,25 @@ class MoLAvgTopK(MoLTopKModule):
         if self._avg_top_k > n:
             raise RuntimeError(f"selected index k out of range (k={self._avg_top_k}, n={n})")
         if eq.shape[0] > 128:   # the scan keeps ceil(B / 32) query tiles in LDS: larger batches go in slices
-            return torch.cat([self._coarse_topk_from_eq(eq[b0 : b0 + 128], average_queries, pending) for b0 in range(0, eq.shape[0], 128)], dim=0)
+            parts = [self._coarse_topk_from_eq(eq[b0 : b0 + 128], average_queries, pending, with_scores) for b0 in range(0, eq.shape[0], 128)]
+            return (torch.cat([p[0] for p in parts], 0), torch.cat([p[1] for p in parts], 0)) if with_scores else torch.cat(parts, dim=0)
         # large corpora: fused scan + threshold select, no (B, N) score matrix (16 GB per 125 M-item shard at B = 32).
         # Same scores and the same exact top-K' as the materialising path below -- when every query's candidate count
         # landed inside [K', capacity]; the check costs one 128-byte device-to-host copy.
         if n >= self.fused_coarse_min_items and self._avg_top_k <= 4096 and not getattr(self, "_no_fused", False):
             fused = eng.coarse_topk(eq, table, average_queries, self._avg_top_k)
             if fused is not None:
-                _, idx, counts = fused
+                sc, idx, counts = fused
                 k_lo, k_hi = self._avg_top_k, eng.coarse_topk_capacity(self._avg_top_k)
                 check = lambda: int(counts.min()) >= k_lo and int(counts.max()) <= k_hi   # noqa: E731
                 if pending is not None:
                     pending.append(check)
-                    return idx
+                    return (sc, idx) if with_scores else idx
                 if check():
-                    return idx
+                    return (sc, idx) if with_scores else idx
         coarse = eng.coarse_scores(eq, table, average_queries)
-        _, idx = E.topk(coarse, self._avg_top_k)
-        return idx
+        sc, idx = E.topk(coarse, self._avg_top_k)
+        return (sc, idx) if with_scores else idx
 
     def rerank(self, qpack: torch.Tensor, batch: int, cand_idx: torch.Tensor, k: int):
         """Full MoL on per-row candidates (positions, (B, K')) -> exact top-min(k, K') among them."""
@@ -181,6 +183,24 @@ class MoLAvgTopK(MoLTopKModule):
             self._no_fused = True      # redo this call on the materialising path
         self._no_fused = False
         return scores.to(query_embeddings.dtype), ids
+
+    def coarse_candidates(self, query_embeddings: torch.Tensor, **kwargs):
+        """Pass 1 on this module's items: -> (coarse scores (B, K'), positions (B, K')), best first (ties by position)."""
+        eng = self._bind()
+        _, eq, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"), want_plain=True)
+        return self._coarse_topk_from_eq(eq, False, None, with_scores=True)
+
+    def rerank_masked(self, query_embeddings: torch.Tensor, cand_idx: torch.Tensor, k: int, **kwargs):
+        """Pass 2 on a candidate list with holes: positions < 0 are not this module's items; they score -inf and come back
+        with id -1.  -> exact top-min(k, K') (scores, ids)."""
+        eng = self._bind()
+        qpack, _, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"))
+        cand, kp = eng.gather_index(self._index, cand_idx)
+        scores = eng.score_candidates(qpack, query_embeddings.size(0), cand, kp)[:, : cand_idx.shape[1]]
+        hole = cand_idx < 0
+        scores = torch.where(hole, scores.new_full((), float("-inf")), scores)
+        ids = torch.where(hole, cand_idx.new_full((), -1), self._ids_flat[cand_idx.clamp_min(0)])
+        return E.topk(scores, min(k, cand_idx.shape[1]), ids=ids)
 
     def topk_ids(self, query_embeddings: torch.Tensor, sorted: bool = True, **kwargs) -> torch.Tensor:
         """Coarse candidates only, with the P_Q-averaged query (reference mol_top_k.py:398-429) -> positions."""

@@ -320,6 +320,38 @@ def test_f4_avg_topk(fx, mol, dev, avg_k):
             at(q, k=avg_k + 1, **kw)
 
 
+def planted_weights(cfg, seed, gate_scale):
+    """Random-init weights make the averaged dot product of pass 1 nearly uncorrelated with the MoL score (recall ~ 0: there is
+    nothing to retrieve).  Scaling the three gate networks' output layers towards zero makes the mixture weights near-uniform, so
+    that MoL ~ mean cross logit = the coarse score up to a constant, plus a gate-dependent perturbation: a corpus on which the
+    two-pass algorithm has something to find."""
+    w = {k: v.clone() for k, v in O.synthetic_weights(cfg, seed=seed).items()}
+    for key in ("_gating_fn._query_only_partial_module.2.weight", "_gating_fn._item_only_partial_module.3.weight",
+                "_gating_fn._qi_partial_module.3.weight", "_gating_fn._qi_partial_module.3.bias"):
+        w[key] = w[key] * gate_scale
+    return w
+
+
+def test_two_pass_recall_on_planted_structure(dev):
+    """BASELINE config 5's quality side at 1 M items: on a corpus with planted structure the HIP two-pass returns what the
+    oracle's two-pass returns, and that is a real retrieval result (recall@10 against exact brute force well above chance)."""
+    cfg = O.CONFIGS["amzn-books"]
+    w = planted_weights(cfg, seed=3, gate_scale=0.25)
+    mol = build_module(cfg, w, dev)
+    N, B, k, avg_k = 1_000_000, 8, 10, 1000
+    X = torch.cat([torch.from_numpy(O.hash_item_table(21, s0, 250_000, cfg.item_embedding_dim)) for s0 in range(0, N, 250_000)]).unsqueeze(0)
+    ids = torch.arange(1, N + 1, dtype=torch.int64).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B, seed=6)
+    with torch.inference_mode():
+        two = rails_amd.MoLAvgTopK(mol, X.to(dev), ids.to(dev), avg_top_k=avg_k)
+        s, i = two(q.to(dev), k=k)
+        _, exact = rails_amd.MoLBruteForceTopK(mol, X.to(dev), ids.to(dev))(q.to(dev), k=k)
+    os_, oi, _ = O.avg_topk(cfg, w, q, X, ids, k, avg_k)                 # the oracle's own two-pass (its own candidates)
+    assert_topk_matches(s, i, os_, oi, atol=LOGIT_TOL)
+    recall = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(i.cpu(), exact.cpu())) / exact.numel()
+    assert recall >= 0.5, recall
+
+
 @pytest.mark.parametrize("cfg_name,n,avg_k", [("amzn-books", 300_001, 100), ("amzn-books", 300_001, 1000), ("amzn-books", 700_000, 4000),
                                               ("ml-1m", 280_000, 500), ("ml-20m", 270_000, 200)])
 def test_fused_coarse_topk_equals_the_materialised_path(dev, cfg_name, n, avg_k):
@@ -634,6 +666,28 @@ def test_multi_million_item_corpus(dev, precision):
     cols = torch.tensor([0, 1, 31, 32, 1_048_575, 1_048_576, 2_147_483 , N - 2, N - 1])
     g = torch.Generator().manual_seed(2)
     cols = torch.cat([cols, torch.randint(0, N, (2048,), generator=g)])
+    ref = O.mol_logits(cfg, w, q, X[cols].unsqueeze(0))
+    assert float((logits[:, cols.to(dev)].cpu() - ref).abs().max()) <= LOGIT_TOL
+    rs, ri = O.select_topk_deterministic(logits.cpu(), k)
+    assert torch.equal(s.cpu(), rs) and torch.equal(i.cpu(), ri)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_million_item_corpus_16x16x64(dev, precision):
+    """BASELINE config 4's shape at 1 M items (a 2.2 GB index, 31 251 tiles): the k-split fp32 kernel and the f16x3 big-L kernel
+    over a corpus far beyond the fixture's, XCD-aware unit numbering included; sampled columns against the oracle."""
+    cfg = O.CONFIGS["synthetic-16x16x64"]
+    w = O.synthetic_weights(cfg, seed=12)
+    mol = build_module(cfg, w, dev, precision)
+    N, B, k = 1_000_001, 5, 200
+    X = torch.cat([torch.from_numpy(O.hash_item_table(13, s0, min(250_000, N - s0), cfg.item_embedding_dim)) for s0 in range(0, N, 250_000)])
+    q = O.synthetic_queries(cfg, B, seed=17)
+    with torch.inference_mode():
+        tk = rails_amd.MoLBruteForceTopK(mol, X.unsqueeze(0).to(dev), torch.arange(N, dtype=torch.int64).unsqueeze(0).to(dev))
+        logits = tk.all_logits(q.to(dev))
+        s, i = tk(q.to(dev), k=k)
+    g = torch.Generator().manual_seed(3)
+    cols = torch.cat([torch.tensor([0, 31, 32, 524_287, 524_288, N - 2, N - 1]), torch.randint(0, N, (1024,), generator=g)])
     ref = O.mol_logits(cfg, w, q, X[cols].unsqueeze(0))
     assert float((logits[:, cols.to(dev)].cpu() - ref).abs().max()) <= LOGIT_TOL
     rs, ri = O.select_topk_deterministic(logits.cpu(), k)

@@ -113,6 +113,64 @@ def test_sharded_two_pass_merges_the_per_shard_reranks():
         assert torch.equal(s, es) and torch.equal(i, torch.gather(all_i, 1, pos))
 
 
+def _global_worker(rank: int, world: int, port: int, n_items: int, k: int, avg_k: int, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        cfg = O.CONFIGS["amzn-books"]
+        w = O.synthetic_weights(cfg, seed=0)
+        q = O.synthetic_queries(cfg, 4)
+        lo, hi = shard_bounds(n_items, world, rank)
+        X = torch.from_numpy(O.hash_item_table(1, lo, hi - lo, cfg.item_embedding_dim)).unsqueeze(0)
+        ids = (torch.arange(lo, hi, dtype=torch.int64) * 3 + 1).unsqueeze(0)
+
+        def coarse_local(qq, **kw):      # pass 1 on this shard, deterministic order (score desc, position asc)
+            return O.select_topk_deterministic(O.avg_topk_coarse_scores(cfg, w, qq, X).float(), min(avg_k, hi - lo))
+
+        def rerank_local(qq, idx, kk, **kw):   # pass 2 on a candidate list with holes
+            hole = idx < 0
+            cand = X.squeeze(0)[idx.clamp_min(0)]
+            sc = O.mol_stages(cfg, w, qq, cand)["logits"]
+            sc = torch.where(hole, torch.full_like(sc, float("-inf")), sc)
+            s, pos = O.select_topk_deterministic(sc, min(kk, idx.shape[1]))
+            cid = torch.where(hole, torch.full_like(idx, -1), ids.reshape(-1)[idx.clamp_min(0)])
+            return s, torch.gather(cid, 1, pos)
+
+        def merge(scores, all_ids, kk):
+            s, pos = O.select_topk_deterministic(scores, kk)
+            return s, torch.gather(all_ids, 1, pos)
+
+        mod = ShardedMoLAvgTopK(None, None, ids, n_items, avg_top_k=avg_k, global_k_prime=True, coarse_local=coarse_local,
+                                rerank_local=rerank_local, merge=merge)
+        ret[rank] = tuple(t.clone() for t in mod(q, k=k))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_items,avg_k", [(600, 60), (70, 50)])   # second case: K' exceeds the items of a shard
+def test_sharded_two_pass_with_global_k_prime_equals_the_single_device_algorithm(n_items, avg_k):
+    """global_k_prime=True: coarse candidates are exchanged first, so exactly the GLOBAL coarse top-K' is reranked -- the result
+    must equal MoLAvgTopK over the whole corpus (with the deterministic tie rule at both selections)."""
+    world, k = 2, 20
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_global_worker, args=(world, _free_port(), n_items, k, avg_k, ret), nprocs=world, join=True)
+    cfg = O.CONFIGS["amzn-books"]
+    w = O.synthetic_weights(cfg, seed=0)
+    q = O.synthetic_queries(cfg, 4)
+    X = torch.from_numpy(O.hash_item_table(1, 0, n_items, cfg.item_embedding_dim)).unsqueeze(0)
+    ids = torch.arange(0, n_items, dtype=torch.int64) * 3 + 1
+    _, coarse_idx = O.select_topk_deterministic(O.avg_topk_coarse_scores(cfg, w, q, X).float(), avg_k)
+    sc = O.mol_stages(cfg, w, q, X.squeeze(0)[coarse_idx])["logits"]
+    es, pos = O.select_topk_deterministic(sc, k)
+    ei = ids[torch.gather(coarse_idx, 1, pos)]
+    for rank in range(world):
+        s, i = ret[rank]
+        assert torch.equal(i, ei) and torch.allclose(s, es, atol=1e-6)
+
+
 def test_shard_bounds_cover_the_corpus():
     for n in (0, 1, 7, 695762, 10**9):
         for world in (1, 2, 4, 8):

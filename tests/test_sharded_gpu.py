@@ -70,6 +70,12 @@ def _worker(rank: int, world: int, port: int, n_items: int, precision, ret):
                 parts.append(rails_amd.MoLAvgTopK(mol, X[:, l2:h2], ids[:, l2:h2], avg_top_k=min(avg_k, h2 - l2))(q, k=min(k, h2 - l2)))
             es, epos = E.topk(torch.cat([p[0] for p in parts], 1), k)
             assert torch.equal(a_s, es) and torch.equal(a_i, torch.gather(torch.cat([p[1] for p in parts], 1), 1, epos))
+            # global K': coarse candidates exchanged first -> exactly the single-device MoLAvgTopK, bit for bit
+            gk = min(avg_k, n_items)
+            sg = ShardedMoLAvgTopK(mol, X[:, lo:hi], ids[:, lo:hi], n_items, avg_top_k=gk, global_k_prime=True)
+            g_s, g_i = sg(q, k=min(k, gk))
+            o_s, o_i = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=gk)(q, k=min(k, gk))
+            assert torch.equal(g_s, o_s) and torch.equal(g_i, o_i), "global-K' sharded two-pass differs from the single-device algorithm"
         ret[rank] = (dist.get_backend(), s.cpu(), i.cpu())
     finally:
         dist.destroy_process_group()

@@ -17,12 +17,19 @@ ap.add_argument("--k", type=int, default=100)
 ap.add_argument("--avg-top-k", default="500,2000,4000")
 ap.add_argument("--precision", default=None)
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--gate-scale", type=float, default=1.0, help="scale the gate networks' output layers (1.0 = the reference's "
+                "random init, where pass 1 is uncorrelated with MoL and recall is ~0; 0.25 = planted structure: near-uniform "
+                "mixture weights, MoL ~ coarse score + gate perturbation, the two-pass has something to find)")
 ap.add_argument("--device-table", action="store_true", help="draw the item table on the GPU (truncated normal, sigma 0.02) "
                 "instead of the host counter hash: for shard-sized corpora (125 M items = 32 GB)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 cfg = O.CONFIGS["synthetic-8x8x32"]
 w = O.synthetic_weights(cfg, seed=0)
+if a.gate_scale != 1.0:
+    for key in ("_gating_fn._query_only_partial_module.2.weight", "_gating_fn._item_only_partial_module.3.weight",
+                "_gating_fn._qi_partial_module.3.weight", "_gating_fn._qi_partial_module.3.bias"):
+        w[key] = w[key] * a.gate_scale
 mol, _ = rails_amd.create_mol_interaction_module(
     cfg.query_embedding_dim, cfg.item_embedding_dim, cfg.dot_product_dimension, cfg.query_dot_product_groups,
     cfg.item_dot_product_groups, cfg.temperature, 0.0, cfg.query_hidden_dim, 0.1, cfg.item_hidden_dim,
@@ -96,7 +103,7 @@ with torch.inference_mode():
                      "coarse_fused_ms": fused_ms, "coarse_fused_table_GBps": table_gb / (fused_ms * 1e-3),
                      "coarse_materialised_ms": mat_ms, "candidates_min_max": [int(counts.min()), int(counts.max())],
                      "top1_agreement": top1, **rec})
-print(json.dumps({"workload": f"synthetic MoL 8x8x32, N={N}, B={B}, k={k}, precision={mol.precision or 'fp32'}",
+print(json.dumps({"workload": f"synthetic MoL 8x8x32, N={N}, B={B}, k={k}, precision={mol.precision or 'fp32'}, gate_scale={a.gate_scale}",
                   "item_table": "device truncated normal" if a.device_table else "host counter hash",
                   "item_table_gen_s": gen_s, "index_build_s": build_s, "coarse_table_GB": table_gb,
                   "exact_brute_force": {"ms_per_batch": exact_ms, "queries_per_s": B / exact_ms * 1e3},
