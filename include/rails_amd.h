@@ -44,6 +44,12 @@ extern "C" {
  *                          rails_mol_coarse_build / rails_mol_component_build take an fp32-format index only. */
 #define RAILS_PRECISION_FP32 0
 #define RAILS_PRECISION_F16X3 1
+
+/* rails_mol_shape.gating_combination: how the three gate parts become mixture weights (MoLGatingFn.forward).
+ *   GLU_SILU  g = gq * gi + gqi;  w = g * sigmoid(g)      (every shipped config; needs all three parts)
+ *   NONE      w = [gq] + [gi] + gqi                        (absent parts contribute nothing); exact-fp32 precision only */
+#define RAILS_COMBINE_GLU_SILU 0
+#define RAILS_COMBINE_NONE 1
 #define RAILS_MAX_UID_TABLES 4
 
 /* Hyper-parameters of one MoL module; field names follow create_mol_interaction_module
@@ -54,7 +60,7 @@ typedef struct rails_mol_shape {
   int32_t dot_product_dimension;      /* d */
   int32_t query_dot_product_groups;   /* P_Q */
   int32_t item_dot_product_groups;    /* P_X */
-  int32_t query_hidden_dim;           /* GLU width of the query projection (512); must be > 0 */
+  int32_t query_hidden_dim;           /* GLU width of the query projection (512); <= 0: plain Linear (similarity_utils.py:108-116) */
   int32_t gating_query_hidden_dim;    /* 128 */
   int32_t gating_item_hidden_dim;     /* 128 */
   int32_t gating_qi_hidden_dim;       /* 128 */
@@ -64,14 +70,19 @@ typedef struct rails_mol_shape {
   float temperature;                  /* 0.05 */
   float eps;                          /* 1e-6 */
   int32_t precision;                  /* RAILS_PRECISION_FP32 | RAILS_PRECISION_F16X3 */
+  int32_t item_hidden_dim;            /* > 0: the item projection has a GLU hidden layer of this width (similarity_utils.py:127-143) */
+  int32_t item_nonlinearity;          /* RAILS_GEGLU | RAILS_SWIGLU, used when item_hidden_dim > 0 */
+  int32_t gating_combination;         /* RAILS_COMBINE_GLU_SILU | RAILS_COMBINE_NONE (similarity_fn.py:175-197) */
+  int32_t gating_has_query;           /* 0: no query-only gate part (gating_query_fn = False); only with RAILS_COMBINE_NONE */
+  int32_t gating_has_item;            /* 0: no item-only gate part  (gating_item_fn = False);  only with RAILS_COMBINE_NONE */
 } rails_mol_shape;
 
 /* Raw module weights, one pointer per state_dict() tensor (SURVEY.md section 8b lists the keys). */
 typedef struct rails_mol_weights {
-  const float* q_glu_w;   /* _query_embeddings_fn._query_emb_proj_module.1._w   (D_q, 2*query_hidden) */
+  const float* q_glu_w;   /* _query_embeddings_fn._query_emb_proj_module.1._w   (D_q, 2*query_hidden); NULL if query_hidden_dim <= 0 */
   const float* q_glu_b;   /* ...1._b                                            (2*query_hidden)      */
-  const float* q_proj_w;  /* ...2.weight                            (d*(P_Q-u), query_hidden)         */
-  const float* q_proj_b;  /* ...2.bias                                                                */
+  const float* q_proj_w;  /* ...2.weight  (d*(P_Q-u), query_hidden);  query_hidden_dim <= 0: ...1.weight (d*(P_Q-u), D_q) */
+  const float* q_proj_b;  /* ...2.bias / ...1.bias                                                    */
   const float* uid_table[RAILS_MAX_UID_TABLES];  /* _uid_embeddings_{i}.weight   (hash_i + 1, d)       */
   int64_t uid_hash_size[RAILS_MAX_UID_TABLES];
   const float* i_proj_w;  /* _item_embeddings_fn._item_emb_proj_module.1.weight  (P_X*d, D_i)         */
@@ -86,6 +97,8 @@ typedef struct rails_mol_weights {
   const float* gqi_b1;
   const float* gqi_w2;    /* ...3.weight                                          (L, H)              */
   const float* gqi_b2;
+  const float* i_glu_w;   /* item_hidden_dim > 0: _item_embeddings_fn._item_emb_proj_module.1._w (D_i, 2*item_hidden); then      */
+  const float* i_glu_b;   /* ...1._b, and i_proj_w / i_proj_b are ...2.weight (P_X*d, item_hidden) / ...2.bias; else NULL  */
 } rails_mol_weights;
 
 /* Thread-local message of the last failed call ("" if none). */

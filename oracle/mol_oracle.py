@@ -63,6 +63,8 @@ class MoLConfig:
     gating_combination_type: str = "glu_silu"
     dot_product_l2_norm: bool = True
     eps: float = 1e-6
+    gating_query_fn: bool = True    # modeling/similarity_utils.py:147-161: False -> no query-only gate part
+    gating_item_fn: bool = True     # modeling/similarity_utils.py:162-179: False -> no item-only gate part
 
     @property
     def num_logits(self) -> int:
@@ -153,7 +155,10 @@ def item_component_embeddings(cfg: MoLConfig, w: Dict[str, object], x: torch.Ten
 
 
 def item_gate(cfg: MoLConfig, w: Dict[str, object], x: torch.Tensor) -> torch.Tensor:
-    """Step 3 -> (..., L).  Sequential(Dropout, Linear, SiLU, Linear(no bias))."""
+    """Step 3 -> (..., L).  Sequential(Dropout, Linear, SiLU, Linear(no bias)); an absent part adds nothing
+    (similarity_fn.py:187-197, combination "none")."""
+    if not cfg.gating_item_fn:
+        return torch.zeros(_t(x).shape[:-1] + (cfg.num_logits,), dtype=torch.float32)
     w = _weights(w)
     pre = "_gating_fn._item_only_partial_module."
     h = F.silu(F.linear(_t(x), w[pre + "1.weight"], w[pre + "1.bias"]))
@@ -161,7 +166,9 @@ def item_gate(cfg: MoLConfig, w: Dict[str, object], x: torch.Tensor) -> torch.Te
 
 
 def query_gate(cfg: MoLConfig, w: Dict[str, object], q: torch.Tensor) -> torch.Tensor:
-    """Step 4 -> (B, L) from the RAW query embedding.  Sequential(Linear, SiLU, Linear(no bias))."""
+    """Step 4 -> (B, L) from the RAW query embedding.  Sequential(Linear, SiLU, Linear(no bias)); absent -> zeros."""
+    if not cfg.gating_query_fn:
+        return torch.zeros((_t(q).shape[0], cfg.num_logits), dtype=torch.float32)
     w = _weights(w)
     pre = "_gating_fn._query_only_partial_module."
     h = F.silu(F.linear(_t(q), w[pre + "0.weight"], w[pre + "0.bias"]))
@@ -183,7 +190,7 @@ def combine(cfg: MoLConfig, gq: torch.Tensor, gi: torch.Tensor, gqi: torch.Tenso
     if cfg.gating_combination_type == "glu_silu":
         g = gq * gi + gqi
         return g * torch.sigmoid(g)
-    if cfg.gating_combination_type == "none":
+    if cfg.gating_combination_type == "none":   # absent parts are zeros here (query_gate / item_gate)
         return gq + gi + gqi
     raise ValueError(f"Unknown combination_type {cfg.gating_combination_type}")
 
@@ -438,26 +445,36 @@ def synthetic_weights(cfg: MoLConfig, seed: int = 0, uid_rows: Optional[int] = N
     D, Di, d = cfg.query_embedding_dim, cfg.item_embedding_dim, cfg.dot_product_dimension
     L, n_uid = cfg.num_logits, len(cfg.uid_embedding_hash_sizes)
     w: Dict[str, torch.Tensor] = {}
-    p = "_gating_fn._query_only_partial_module."
-    w[p + "0.weight"], w[p + "0.bias"] = xavier(cfg.gating_query_hidden_dim, D), torch.zeros(cfg.gating_query_hidden_dim)
-    w[p + "2.weight"] = xavier(L, cfg.gating_query_hidden_dim)
-    p = "_gating_fn._item_only_partial_module."
-    w[p + "1.weight"], w[p + "1.bias"] = xavier(cfg.gating_item_hidden_dim, Di), torch.zeros(cfg.gating_item_hidden_dim)
-    w[p + "3.weight"] = xavier(L, cfg.gating_item_hidden_dim)
+    if cfg.gating_query_fn:
+        p = "_gating_fn._query_only_partial_module."
+        w[p + "0.weight"], w[p + "0.bias"] = xavier(cfg.gating_query_hidden_dim, D), torch.zeros(cfg.gating_query_hidden_dim)
+        w[p + "2.weight"] = xavier(L, cfg.gating_query_hidden_dim)
+    if cfg.gating_item_fn:
+        p = "_gating_fn._item_only_partial_module."
+        w[p + "1.weight"], w[p + "1.bias"] = xavier(cfg.gating_item_hidden_dim, Di), torch.zeros(cfg.gating_item_hidden_dim)
+        w[p + "3.weight"] = xavier(L, cfg.gating_item_hidden_dim)
     p = "_gating_fn._qi_partial_module."
     w[p + "1.weight"], w[p + "1.bias"] = xavier(cfg.gating_qi_hidden_dim, L), torch.zeros(cfg.gating_qi_hidden_dim)
     w[p + "3.weight"], w[p + "3.bias"] = xavier(L, cfg.gating_qi_hidden_dim), torch.zeros(L)
     p = "_query_embeddings_fn._query_emb_proj_module."
-    w[p + "1._w"] = torch.randn((D, 2 * cfg.query_hidden_dim), generator=g) * 0.02
-    w[p + "1._b"] = torch.zeros((1, 2 * cfg.query_hidden_dim))
-    w[p + "2.weight"], w[p + "2.bias"] = kaiming_linear(d * (cfg.query_dot_product_groups - n_uid), cfg.query_hidden_dim)
+    if cfg.query_hidden_dim > 0:
+        w[p + "1._w"] = torch.randn((D, 2 * cfg.query_hidden_dim), generator=g) * 0.02
+        w[p + "1._b"] = torch.zeros((1, 2 * cfg.query_hidden_dim))
+        w[p + "2.weight"], w[p + "2.bias"] = kaiming_linear(d * (cfg.query_dot_product_groups - n_uid), cfg.query_hidden_dim)
+    else:   # plain Linear, xavier + zero bias (modeling/similarity_utils.py:108-116)
+        w[p + "1.weight"], w[p + "1.bias"] = xavier(d * (cfg.query_dot_product_groups - n_uid), D), torch.zeros(d * (cfg.query_dot_product_groups - n_uid))
     for i, hs in enumerate(cfg.uid_embedding_hash_sizes):
         rows = hs + 1 if uid_rows is None else uid_rows
         t = torch.randn((rows, d), generator=g)
         t[0] = 0.0  # padding_idx=0
         w[f"_query_embeddings_fn._uid_embeddings_{i}.weight"] = t
     p = "_item_embeddings_fn._item_emb_proj_module."
-    w[p + "1.weight"], w[p + "1.bias"] = xavier(d * cfg.item_dot_product_groups, Di), torch.zeros(d * cfg.item_dot_product_groups)
+    if cfg.item_hidden_dim > 0:   # GLU (N(0, 0.02^2), zero bias) then Linear (xavier, zero bias) (similarity_utils.py:127-143)
+        w[p + "1._w"] = torch.randn((Di, 2 * cfg.item_hidden_dim), generator=g) * 0.02
+        w[p + "1._b"] = torch.zeros((1, 2 * cfg.item_hidden_dim))
+        w[p + "2.weight"], w[p + "2.bias"] = xavier(d * cfg.item_dot_product_groups, cfg.item_hidden_dim), torch.zeros(d * cfg.item_dot_product_groups)
+    else:
+        w[p + "1.weight"], w[p + "1.bias"] = xavier(d * cfg.item_dot_product_groups, Di), torch.zeros(d * cfg.item_dot_product_groups)
     return w
 
 

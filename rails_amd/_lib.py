@@ -23,6 +23,8 @@ RAILS_SWIGLU = 1
 RAILS_MAX_UID_TABLES = 4
 RAILS_PRECISION_FP32 = 0
 RAILS_PRECISION_F16X3 = 1
+RAILS_COMBINE_GLU_SILU = 0
+RAILS_COMBINE_NONE = 1
 
 _f32p = C.POINTER(C.c_float)
 
@@ -44,6 +46,11 @@ class MolShape(C.Structure):
         ("temperature", C.c_float),
         ("eps", C.c_float),
         ("precision", C.c_int32),
+        ("item_hidden_dim", C.c_int32),
+        ("item_nonlinearity", C.c_int32),
+        ("gating_combination", C.c_int32),
+        ("gating_has_query", C.c_int32),
+        ("gating_has_item", C.c_int32),
     ]
 
 
@@ -67,6 +74,8 @@ class MolWeights(C.Structure):
         ("gqi_b1", C.c_void_p),
         ("gqi_w2", C.c_void_p),
         ("gqi_b2", C.c_void_p),
+        ("i_glu_w", C.c_void_p),
+        ("i_glu_b", C.c_void_p),
     ]
 
 

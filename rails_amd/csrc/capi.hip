@@ -46,8 +46,24 @@ static bool shape_ok(const Shape* s) {
 
 static bool shape_supported(const Shape* s) {
   if (!shape_ok(s)) return false;
-  if (s->query_hidden_dim <= 0 || s->gating_query_hidden_dim <= 0 || s->gating_item_hidden_dim <= 0) {
-    set_error("query_hidden_dim / gating hidden dims must be > 0 (plain-Linear variants are not built)");
+  if (s->gating_qi_hidden_dim <= 0) {
+    set_error("a pair gate without hidden layer (gating_qi_hidden_dim <= 0) has no fused kernel");
+    return false;
+  }
+  if (s->gating_combination != RAILS_COMBINE_GLU_SILU && s->gating_combination != RAILS_COMBINE_NONE) {
+    set_error("gating_combination must be RAILS_COMBINE_GLU_SILU or RAILS_COMBINE_NONE, got %d", s->gating_combination);
+    return false;
+  }
+  if (s->gating_combination == RAILS_COMBINE_GLU_SILU && (!s->gating_has_query || !s->gating_has_item)) {
+    set_error("gating_combination glu_silu needs the query-only and the item-only gate part (the reference multiplies them)");
+    return false;
+  }
+  if ((s->gating_has_query && s->gating_query_hidden_dim <= 0) || (s->gating_has_item && s->gating_item_hidden_dim <= 0)) {
+    set_error("gating hidden dims must be > 0 for the gate parts that exist");
+    return false;
+  }
+  if (s->gating_combination == RAILS_COMBINE_NONE && (is_split(*s) || num_logits(*s) > 64)) {
+    set_error("gating_combination none is built for the exact-fp32 register-resident kernels only (not f16x3, not 16x16x64)");
     return false;
   }
   if (s->precision != RAILS_PRECISION_FP32 && s->precision != RAILS_PRECISION_F16X3) {
@@ -119,7 +135,8 @@ int rails_mol_index_build(const rails_mol_shape* s, const rails_mol_weights* w, 
   if (!shape_supported(s)) return RAILS_ENOTSUP;
   if (n_items < 0) { set_error("index_build: n_items < 0"); return RAILS_EINVAL; }
   if (n_items == 0) return RAILS_OK;
-  if (!w || !items || !index || !w->i_proj_w || !w->i_proj_b || !w->gi_w1 || !w->gi_b1 || !w->gi_w2) {
+  if (!w || !items || !index || !w->i_proj_w || !w->i_proj_b || (s->gating_has_item && (!w->gi_w1 || !w->gi_b1 || !w->gi_w2)) ||
+      (s->item_hidden_dim > 0 && (!w->i_glu_w || !w->i_glu_b))) {
     set_error("index_build: NULL pointer");
     return RAILS_EINVAL;
   }
@@ -163,8 +180,8 @@ int rails_mol_query_prologue(const rails_mol_shape* s, const rails_mol_weights* 
   if (!shape_supported(s)) return RAILS_ENOTSUP;
   if (batch < 0) { set_error("query_prologue: batch < 0"); return RAILS_EINVAL; }
   if (batch == 0) return RAILS_OK;
-  if (!w || !queries || !query_pack || !w->q_glu_w || !w->q_glu_b || !w->q_proj_w || !w->q_proj_b || !w->gq_w1 ||
-      !w->gq_b1 || !w->gq_w2) {
+  if (!w || !queries || !query_pack || !w->q_proj_w || !w->q_proj_b || (s->query_hidden_dim > 0 && (!w->q_glu_w || !w->q_glu_b)) ||
+      (s->gating_has_query && (!w->gq_w1 || !w->gq_b1 || !w->gq_w2))) {
     set_error("query_prologue: NULL pointer");
     return RAILS_EINVAL;
   }
@@ -205,6 +222,7 @@ static int score_common(const rails_mol_shape* s, const float* gate_pack, const 
   a.temperature = s->temperature;
   a.rcp_temperature = 1.0f / s->temperature;
   a.split = is_split(*s) ? 1 : 0;
+  a.combine_none = s->gating_combination == RAILS_COMBINE_NONE ? 1 : 0;
   const int r = score_launch(*s, a, cu, (hipStream_t)stream);
   return r == kOk ? r : fail(r, what);
 }

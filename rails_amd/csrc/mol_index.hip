@@ -116,7 +116,11 @@ constexpr int kBuildThreads = 256;
 
 struct BuildArgs {
   const float* items;   // (n, D)
-  const float* pw;      // (PX*d, D)
+  const float* gluw;    // item_hidden_dim > 0: (D, 2*IH) GLU weight (x @ W), else NULL
+  const float* glub;    // (2*IH)
+  int IH, glu_kind;
+  int has_gate;         // 0: no item-only gate part -> gi = 0
+  const float* pw;      // (PX*d, D) or (PX*d, IH)
   const float* pb;      // (PX*d)
   const float* g1w;     // (Hi, D)
   const float* g1b;     // (Hi)
@@ -163,6 +167,8 @@ __global__ __launch_bounds__(kBuildThreads) void index_build_kernel(BuildArgs a)
   float* hs = xs + kTileItems * xs_ld;       // [32][Hi+1]
   float* cs = hs + kTileItems * hs_ld;       // [32][max(chunk_cols, L)+1]
   float* ns = cs + kTileItems * cs_ld;       // [32][mpc] inverse norms
+  const int gs_ld = a.IH + 1;
+  float* gs = ns + kTileItems * mpc;         // [32][IH+1] GLU hidden layer of the item projection (item_hidden_dim > 0)
   const int64_t tile = blockIdx.x;
   const int64_t item0 = tile * kTileItems;
   float* tEx = a.ipack + tile * (int64_t)(kTileItems * (PX * d + L));
@@ -174,10 +180,39 @@ __global__ __launch_bounds__(kBuildThreads) void index_build_kernel(BuildArgs a)
   }
   __syncthreads();
 
+  // item projection with a GLU hidden layer (similarity_utils.py:127-143, layers.py:19-74): h = act(x W_l + b_l) * (x W_r + b_r),
+  // W = (D, 2 IH) applied as x @ W.  Thread c owns hidden column c: both halves, 32 items each.
+  if (a.IH > 0) {
+    for (int c = threadIdx.x; c < a.IH; c += kBuildThreads) {
+      float al[kTileItems], ar[kTileItems];
+#pragma unroll
+      for (int x = 0; x < kTileItems; ++x) { al[x] = 0.0f; ar[x] = 0.0f; }
+      for (int k = 0; k < D; ++k) {
+        const float wl = a.gluw[(int64_t)k * 2 * a.IH + c], wr = a.gluw[(int64_t)k * 2 * a.IH + a.IH + c];
+#pragma unroll
+        for (int x = 0; x < kTileItems; ++x) {
+          const float xv = xs[x * xs_ld + k];
+          al[x] = __builtin_fmaf(xv, wl, al[x]);
+          ar[x] = __builtin_fmaf(xv, wr, ar[x]);
+        }
+      }
+      const float bl = a.glub[c], br = a.glub[a.IH + c];
+#pragma unroll
+      for (int x = 0; x < kTileItems; ++x) {
+        const float l = al[x] + bl, r = ar[x] + br;
+        const float act = a.glu_kind == RAILS_GEGLU ? 0.5f * l * (1.0f + erff(l * 0.70710678118654752440f)) : l / (1.0f + expf(-l));
+        gs[x * gs_ld + c] = act * r;
+      }
+    }
+    __syncthreads();
+  }
+  const float* pin = a.IH > 0 ? gs : xs;
+  const int pin_ld = a.IH > 0 ? gs_ld : xs_ld, pK = a.IH > 0 ? a.IH : D;
+
   // component embeddings, one chunk of whole component groups at a time
   for (int m0 = 0; m0 < PX; m0 += mpc) {
     const int groups = (PX - m0 < mpc) ? (PX - m0) : mpc;
-    dense_cols(a.pw, a.pb, m0 * d, groups * d, D, xs, xs_ld, cs, cs_ld, false);
+    dense_cols(a.pw, a.pb, m0 * d, groups * d, pK, pin, pin_ld, cs, cs_ld, false);
     __syncthreads();
     for (int i = threadIdx.x; i < kTileItems * groups; i += kBuildThreads) {
       const int x = i / groups, mg = i - x * groups;
@@ -206,10 +241,14 @@ __global__ __launch_bounds__(kBuildThreads) void index_build_kernel(BuildArgs a)
     __syncthreads();
   }
 
-  // item gate: gi = W2 silu(W1 x + b1)   (modeling/similarity_utils.py:169-185)
-  dense_cols(a.g1w, a.g1b, 0, Hi, D, xs, xs_ld, hs, hs_ld, true);
-  __syncthreads();
-  dense_cols(a.g2w, nullptr, 0, L, Hi, hs, hs_ld, cs, cs_ld, false);
+  // item gate: gi = W2 silu(W1 x + b1)   (modeling/similarity_utils.py:169-185); absent part (gating_item_fn = False): zeros
+  if (a.has_gate) {
+    dense_cols(a.g1w, a.g1b, 0, Hi, D, xs, xs_ld, hs, hs_ld, true);
+    __syncthreads();
+    dense_cols(a.g2w, nullptr, 0, L, Hi, hs, hs_ld, cs, cs_ld, false);
+  } else {
+    for (int i = threadIdx.x; i < kTileItems * L; i += kBuildThreads) cs[(i / L) * cs_ld + i % L] = 0.0f;
+  }
   __syncthreads();
   for (int i = threadIdx.x; i < (L / 8) * 64; i += kBuildThreads) {
     const int lane = i & 63, ec = i >> 6;
@@ -228,8 +267,8 @@ static size_t build_lds_bytes(const Shape& s) {
   const int mpc = (kBuildThreads / d) > 0 ? (kBuildThreads / d) : 1;
   const int chunk_cols = mpc * d;
   const int cs_ld = (chunk_cols > L ? chunk_cols : L) + 1;
-  return sizeof(float) * (size_t)kTileItems *
-         ((s.item_embedding_dim + 1) + (s.gating_item_hidden_dim + 1) + cs_ld + mpc);
+  const int hi_w = s.gating_has_item ? s.gating_item_hidden_dim : 0, ih = s.item_hidden_dim > 0 ? s.item_hidden_dim : 0;
+  return sizeof(float) * (size_t)kTileItems * ((s.item_embedding_dim + 1) + (hi_w + 1) + cs_ld + mpc + (ih + 1));
 }
 
 int index_build(const Shape& s, const Weights& w, const float* items, int64_t n, float* ipack, hipStream_t stream) {
@@ -238,7 +277,9 @@ int index_build(const Shape& s, const Weights& w, const float* items, int64_t n,
   BuildArgs a;
   a.items = items; a.pw = w.i_proj_w; a.pb = w.i_proj_b; a.g1w = w.gi_w1; a.g1b = w.gi_b1; a.g2w = w.gi_w2;
   a.ipack = ipack; a.n = n; a.D = s.item_embedding_dim; a.PQ = s.query_dot_product_groups;
-  a.PX = s.item_dot_product_groups; a.d = s.dot_product_dimension; a.Hi = s.gating_item_hidden_dim;
+  a.PX = s.item_dot_product_groups; a.d = s.dot_product_dimension; a.Hi = s.gating_has_item ? s.gating_item_hidden_dim : 0;
+  a.gluw = w.i_glu_w; a.glub = w.i_glu_b; a.IH = s.item_hidden_dim > 0 ? s.item_hidden_dim : 0; a.glu_kind = s.item_nonlinearity;
+  a.has_gate = s.gating_has_item;
   a.l2norm = s.dot_product_l2_norm; a.eps = s.eps;
   const size_t lds = build_lds_bytes(s);
   if (lds > 160 * 1024) { set_error("index build needs %zu B of LDS (> 160 KiB) for this shape", lds); return kErrUnsupported; }

@@ -39,6 +39,7 @@ struct ScoreArgs {
   int per_row;          // 1: tile t of row b lives at ipack tile (b * n_tiles + t)
   float temperature;
   float rcp_temperature;
+  int combine_none;     // 1: gating_combination "none": w = gq + gi + gqi (absent parts are stored as zeros), no silu
   int split;            // 1: precision mode f16x3 -- gate pack, query pack and item index hold f16 hi/lo fragments (mol_layout.h)
 };
 
@@ -62,6 +63,9 @@ inline int ensure_dyn_lds(DynLdsOnce& once, const void* fn, int bytes) {
 
 int score_launch(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream);
 int score_launch_f16(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream);
+bool score_extra_shape(const Shape& s);   // mol_score_extra_shapes.h
+int score_launch_extra(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream);
+int score_launch_f16_extra(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream);
 bool score_supported(const Shape& s);
 
 int pack_gate_weights(const Shape& s, const Weights& w, float* wpack, hipStream_t stream);

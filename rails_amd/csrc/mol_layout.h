@@ -53,6 +53,8 @@ MOL_HD int acc_row(int reg, int hi) { return (reg & 3) + 8 * (reg >> 2) + 4 * hi
 // geometry derived from (P_Q, P_X, d, H)
 template <int PQ, int PX, int DD, int H>
 struct Geo {
+  // a query's P_Q rows must cover both lane halves of the accumulator layout (rows 4..7 of every 8 sit in the upper half):
+  // P_Q = 4 would put two queries into the same registers
   static_assert(PQ == 8 || PQ == 16 || PQ == 32, "P_Q must be 8, 16 or 32");
   static_assert(DD % 8 == 0, "dot_product_dimension must be a multiple of 8");
   static_assert(H % 32 == 0, "gate hidden dim must be a multiple of 32");

@@ -41,6 +41,7 @@ struct QueryArgs {
   float eps;
   float temperature;
   int split;   // precision f16x3: Eq fragments are written as f16 hi/lo (mol_layout.h)
+  int has_gate;   // 0: no query-only gate part -> gq = 0
 };
 
 // One element of a query group's Eq fragment: K index s of lane half hi, accumulator row `row` (= qj*P_Q + p).
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(kQueryThreads) void query_prologue_kernel(QueryArgs
   for (int i = threadIdx.x; i < D; i += kQueryThreads) qs[i] = a.q[(int64_t)b * D + i];
   __syncthreads();
 
-  // GLU: h = q W + b (D x 2QH, row-major so lanes stride columns); act(lhs) * rhs
+  // GLU: h = q W + b (D x 2QH, row-major so lanes stride columns); act(lhs) * rhs.  QH = 0: the projection is a plain Linear
   for (int c = threadIdx.x; c < 2 * QH; c += kQueryThreads) {
     float acc = 0.0f;
     int k = 0;
@@ -169,7 +170,8 @@ __global__ __launch_bounds__(kQueryThreads) void query_prologue_kernel(QueryArgs
   __syncthreads();
 
   const int proj_groups = PQ - a.n_uid;
-  wave_dense(a.w.q_proj_w, a.w.q_proj_b, proj_groups * d, QH, glu, eqs, false);
+  if (QH > 0) wave_dense(a.w.q_proj_w, a.w.q_proj_b, proj_groups * d, QH, glu, eqs, false);
+  else wave_dense(a.w.q_proj_w, a.w.q_proj_b, proj_groups * d, D, qs, eqs, false);   // similarity_utils.py:108-116
   for (int t = 0; t < a.n_uid; ++t) {
     const int64_t hs = a.w.uid_hash_size[t];
     int64_t row = a.user_ids[b] % hs;
@@ -177,10 +179,15 @@ __global__ __launch_bounds__(kQueryThreads) void query_prologue_kernel(QueryArgs
     row += 1;
     for (int k = threadIdx.x; k < d; k += kQueryThreads) eqs[(proj_groups + t) * d + k] = a.w.uid_table[t][row * d + k];
   }
-  // query-only gate on the raw query
-  wave_dense(a.w.gq_w1, a.w.gq_b1, a.Hq, D, qs, hq, true);
-  __syncthreads();
-  wave_dense(a.w.gq_w2, nullptr, L, a.Hq, hq, gqs, false);
+  // query-only gate on the raw query; absent part (gating_query_fn = False): zeros
+  if (a.has_gate) {
+    wave_dense(a.w.gq_w1, a.w.gq_b1, a.Hq, D, qs, hq, true);
+    __syncthreads();
+    wave_dense(a.w.gq_w2, nullptr, L, a.Hq, hq, gqs, false);
+  } else {
+    for (int i = threadIdx.x; i < L; i += kQueryThreads) gqs[i] = 0.0f;
+    __syncthreads();   // the projection's eqs (written by all waves above) are read for the norms below
+  }
   if (threadIdx.x < PQ) {
     float ss = 0.0f;
     for (int k = 0; k < d; ++k) {
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(kP3Threads) void query_p3_kernel(QueryArgs a, const
 
 size_t query_scratch_floats(const Shape& s, int B) {
   const size_t bt = (size_t)(B + 31) / 32 * 32;
-  return bt * ((size_t)s.query_hidden_dim + (size_t)s.gating_query_hidden_dim +
+  return bt * ((size_t)(s.query_hidden_dim > 0 ? s.query_hidden_dim : 0) + (size_t)(s.gating_query_hidden_dim > 0 ? s.gating_query_hidden_dim : 0) +
                (size_t)s.query_dot_product_groups * s.dot_product_dimension +
                (size_t)s.query_dot_product_groups * s.item_dot_product_groups);
 }
@@ -472,7 +479,8 @@ int query_prologue(const Shape& s, const Weights& w, const float* q, const int64
   QueryArgs a;
   a.q = q; a.user_ids = user_ids; a.w = w; a.B = B;
   a.D = s.query_embedding_dim; a.PQ = s.query_dot_product_groups; a.PX = s.item_dot_product_groups;
-  a.d = s.dot_product_dimension; a.QH = s.query_hidden_dim; a.Hq = s.gating_query_hidden_dim;
+  a.d = s.dot_product_dimension; a.QH = s.query_hidden_dim > 0 ? s.query_hidden_dim : 0; a.Hq = s.gating_has_query ? s.gating_query_hidden_dim : 0;
+  a.has_gate = s.gating_has_query;
   a.n_uid = s.num_uid_tables; a.glu = s.query_nonlinearity; a.l2norm = s.dot_product_l2_norm; a.eps = s.eps; a.temperature = s.temperature;
   a.split = is_split(s) ? 1 : 0;
   const int QT = queries_per_group(s);
@@ -483,7 +491,7 @@ int query_prologue(const Shape& s, const Weights& w, const float* q, const int64
   const int L = a.PQ * a.PX;
   // RAILS_PROLOGUE: 0 / unset = choose, 1 = per-query kernel, 2 = batched kernels (measurement override)
   static const int forced = [] { const char* e = getenv("RAILS_PROLOGUE"); return e ? atoi(e) : 0; }();
-  const bool batched_ok = a.QH % 32 == 0 && a.Hq % 32 == 0 && a.d % 32 == 0 && L % 32 == 0 && a.d <= 256;
+  const bool batched_ok = a.QH > 0 && a.has_gate && a.QH % 32 == 0 && a.Hq % 32 == 0 && a.d % 32 == 0 && L % 32 == 0 && a.d <= 256;
   // The per-query kernel streams every weight matrix through one CU per query (~150 GB/s of L2 each); the batched
   // kernels read them once but pay three dependent launches (~8 us each).  Crossover ~1.3 MB of weights per query.
   const size_t weight_bytes = sizeof(float) * ((size_t)a.D * 2 * a.QH + (size_t)(a.PQ - a.n_uid) * a.d * a.QH + (size_t)a.Hq * a.D + (size_t)L * a.Hq);

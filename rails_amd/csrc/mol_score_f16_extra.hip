@@ -1,0 +1,24 @@
+// f16x3 scoring kernels for the shapes of mol_score_extra_shapes.h (direct shell only).
+#include "mol_score_extra_shapes.h"
+#include "mol_score_f16_unit.h"
+
+namespace mol {
+
+template <int PQ, int PX, int DD, int H>
+static int launch_f16_extra(const ScoreArgs& a, int n_cu, hipStream_t stream) {
+  using G = Geo<PQ, PX, DD, H>;
+  constexpr bool tight = (PX + G::TH + G::TL) * 16 > 200;   // as in mol_score_f16.hip
+  using U = std::conditional_t<tight, F16Unit<false, true>, F16Unit<true, false>>;
+  return launch_kernel<U, PQ, PX, DD, H, 8, false>(a, n_cu, stream);
+}
+
+int score_launch_f16_extra(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream) {
+#define X(pq, px, dd, h)                                                                                                             \
+  if (s.query_dot_product_groups == pq && s.item_dot_product_groups == px && s.dot_product_dimension == dd && s.gating_qi_hidden_dim == h) \
+    return launch_f16_extra<pq, px, dd, h>(a, n_cu, stream);
+  MOL_EXTRA_SHAPES(X)
+#undef X
+  return kErrUnsupported;
+}
+
+}  // namespace mol

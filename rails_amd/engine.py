@@ -46,14 +46,21 @@ class MolShapeSpec:
     dot_product_l2_norm: bool = True
     temperature: float = 0.05
     eps: float = 1e-6
+    item_hidden_dim: int = -1                    # > 0: GLU hidden layer in the item projection
+    item_nonlinearity: str = "geglu"
+    gating_combination_type: str = "glu_silu"    # "glu_silu" | "none"
+    gating_query_fn: bool = True                 # False: no query-only gate part (only with "none")
+    gating_item_fn: bool = True                  # False: no item-only gate part (only with "none")
 
     @property
     def num_logits(self) -> int:
         return self.query_dot_product_groups * self.item_dot_product_groups
 
     def to_c(self, precision: str = "fp32") -> _lib.MolShape:
-        if self.query_nonlinearity not in ("geglu", "swiglu"):
-            raise ValueError(f"Unknown query_nonlinearity {self.query_nonlinearity}")
+        if self.query_nonlinearity not in ("geglu", "swiglu") or self.item_nonlinearity not in ("geglu", "swiglu"):
+            raise ValueError(f"Unknown nonlinearity {self.query_nonlinearity} / {self.item_nonlinearity}")
+        if self.gating_combination_type not in ("glu_silu", "none"):
+            raise ValueError(f"Unknown combination_type {self.gating_combination_type}")
         return _lib.MolShape(
             self.query_embedding_dim, self.item_embedding_dim, self.dot_product_dimension,
             self.query_dot_product_groups, self.item_dot_product_groups, self.query_hidden_dim,
@@ -62,10 +69,37 @@ class MolShapeSpec:
             len(self.uid_embedding_hash_sizes), 1 if self.dot_product_l2_norm else 0,
             float(self.temperature), float(self.eps),
             _lib.RAILS_PRECISION_F16X3 if precision == "f16x3" else _lib.RAILS_PRECISION_FP32,
+            int(self.item_hidden_dim), _lib.RAILS_GEGLU if self.item_nonlinearity == "geglu" else _lib.RAILS_SWIGLU,
+            _lib.RAILS_COMBINE_NONE if self.gating_combination_type == "none" else _lib.RAILS_COMBINE_GLU_SILU,
+            1 if self.gating_query_fn else 0, 1 if self.gating_item_fn else 0,
         )
 
+    def weight_fields(self) -> Dict[str, str]:
+        """state_dict key -> field of rails_mol_weights for THIS topology (the module indices inside the
+        reference's Sequentials are part of the keys, modeling/similarity_utils.py:88-207)."""
+        f: Dict[str, str] = {}
+        q = "_query_embeddings_fn._query_emb_proj_module."
+        if self.query_hidden_dim > 0:
+            f.update({q + "1._w": "q_glu_w", q + "1._b": "q_glu_b", q + "2.weight": "q_proj_w", q + "2.bias": "q_proj_b"})
+        else:
+            f.update({q + "1.weight": "q_proj_w", q + "1.bias": "q_proj_b"})
+        i = "_item_embeddings_fn._item_emb_proj_module."
+        if self.item_hidden_dim > 0:
+            f.update({i + "1._w": "i_glu_w", i + "1._b": "i_glu_b", i + "2.weight": "i_proj_w", i + "2.bias": "i_proj_b"})
+        else:
+            f.update({i + "1.weight": "i_proj_w", i + "1.bias": "i_proj_b"})
+        if self.gating_query_fn:
+            g = "_gating_fn._query_only_partial_module."
+            f.update({g + "0.weight": "gq_w1", g + "0.bias": "gq_b1", g + "2.weight": "gq_w2"})
+        if self.gating_item_fn:
+            g = "_gating_fn._item_only_partial_module."
+            f.update({g + "1.weight": "gi_w1", g + "1.bias": "gi_b1", g + "3.weight": "gi_w2"})
+        g = "_gating_fn._qi_partial_module."
+        f.update({g + "1.weight": "gqi_w1", g + "1.bias": "gqi_b1", g + "3.weight": "gqi_w2", g + "3.bias": "gqi_b2"})
+        return f
 
-# state_dict key -> field of rails_mol_weights
+
+# state_dict key -> field of rails_mol_weights for the shipped topology (MolShapeSpec.weight_fields() covers the variants)
 WEIGHT_FIELDS = {
     "_query_embeddings_fn._query_emb_proj_module.1._w": "q_glu_w",
     "_query_embeddings_fn._query_emb_proj_module.1._b": "q_glu_b",
@@ -155,7 +189,7 @@ class MolEngine:
             raise NotImplementedError(_lib.last_error())
         self._keep = []  # fp32 contiguous device tensors the weight struct points into
         w = _lib.MolWeights()
-        for key, field in WEIGHT_FIELDS.items():
+        for key, field in spec.weight_fields().items():
             if key not in weights:
                 raise KeyError(f"MoL weight '{key}' is missing")
             t = weights[key]

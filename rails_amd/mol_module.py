@@ -248,22 +248,23 @@ class MoLSimilarity(SimilarityModule):
 
     # ---- binding the parameters to the HIP engine -----------------------------------------------
     def shape_spec(self) -> MolShapeSpec:
-        if self._gating_fn._combination_type != "glu_silu":
-            if self._gating_fn._combination_type in ("none", "glu_silu_ln"):
-                raise NotImplementedError(
-                    f"gating_combination_type '{self._gating_fn._combination_type}' has no HIP kernel (every shipped config uses glu_silu)"
-                )
-            raise ValueError(f"Unknown combination_type {self._gating_fn._combination_type}")  # similarity_fn.py:198-199
-        qf, itf, g = self._query_embeddings_fn, self._item_embeddings_fn, self._gating_fn
+        """The module's topology as the C ABI's shape (every variant create_mol_interaction_module can wire,
+        modeling/similarity_utils.py:41-245, except a pair gate without hidden layer and the broken glu_silu_ln)."""
+        g = self._gating_fn
+        if g._combination_type not in ("glu_silu", "none"):
+            if g._combination_type == "glu_silu_ln":   # the reference's own branch raises a TypeError (normalized_shapes=)
+                raise NotImplementedError("gating_combination_type 'glu_silu_ln' has no HIP kernel (it is unreachable in the reference too)")
+            raise ValueError(f"Unknown combination_type {g._combination_type}")  # similarity_fn.py:198-199
+        qf, itf = self._query_embeddings_fn, self._item_embeddings_fn
         if not isinstance(qf, RecoMoLQueryEmbeddingsFn) or not isinstance(itf, RecoMoLItemEmbeddingsFn):
             raise NotImplementedError("only RecoMoLQueryEmbeddingsFn / RecoMoLItemEmbeddingsFn are supported (LMMoL* is out of scope)")
-        glus = _find(qf._query_emb_proj_module, _GLU)
-        if len(glus) != 1:
-            raise NotImplementedError("query projection without a GLU hidden layer (query_hidden_dim <= 0) has no HIP kernel")
-        if len(_find(itf._item_emb_proj_module, _GLU)) != 0:
-            raise NotImplementedError("item projection with a GLU hidden layer (item_hidden_dim > 0) has no HIP kernel")
-        if g._query_only_partial_module is None or g._item_only_partial_module is None or g._qi_partial_module is None:
-            raise NotImplementedError("the fused kernel needs all three gate parts (query-only, item-only, pair)")
+        q_glus, i_glus = _find(qf._query_emb_proj_module, _GLU), _find(itf._item_emb_proj_module, _GLU)
+        if g._qi_partial_module is None:
+            raise NotImplementedError("the fused kernel needs the pair gate part")
+        has_q, has_i = g._query_only_partial_module is not None, g._item_only_partial_module is not None
+        if g._combination_type == "glu_silu" and not (has_q and has_i):
+            # the reference fails here too (None * tensor, similarity_fn.py:176-178)
+            raise TypeError("gating_combination_type 'glu_silu' needs the query-only and the item-only gate part")
         qi_linears = _find(g._qi_partial_module, torch.nn.Linear)
         if len(qi_linears) != 2:
             raise NotImplementedError("pair gate without a hidden layer (gating_qi_hidden_dim <= 0) has no HIP kernel")
@@ -273,15 +274,20 @@ class MoLSimilarity(SimilarityModule):
             dot_product_dimension=self._dot_product_dimension,
             query_dot_product_groups=self._query_dot_product_groups,
             item_dot_product_groups=self._item_dot_product_groups,
-            query_hidden_dim=glus[0]._out_features,
-            gating_query_hidden_dim=_find(g._query_only_partial_module, torch.nn.Linear)[0].out_features,
-            gating_item_hidden_dim=_find(g._item_only_partial_module, torch.nn.Linear)[0].out_features,
+            query_hidden_dim=q_glus[0]._out_features if q_glus else -1,
+            gating_query_hidden_dim=_find(g._query_only_partial_module, torch.nn.Linear)[0].out_features if has_q else -1,
+            gating_item_hidden_dim=_find(g._item_only_partial_module, torch.nn.Linear)[0].out_features if has_i else -1,
             gating_qi_hidden_dim=qi_linears[0].out_features,
-            query_nonlinearity=glus[0].kind,
+            query_nonlinearity=q_glus[0].kind if q_glus else "geglu",
             uid_embedding_hash_sizes=tuple(qf._uid_embedding_hash_sizes),
             dot_product_l2_norm=bool(self._dot_product_l2_norm),
             temperature=float(self._temperature),
             eps=float(self._eps),
+            item_hidden_dim=i_glus[0]._out_features if i_glus else -1,
+            item_nonlinearity=i_glus[0].kind if i_glus else "geglu",
+            gating_combination_type=g._combination_type,
+            gating_query_fn=has_q,
+            gating_item_fn=has_i,
         )
 
     def engine(self) -> MolEngine:

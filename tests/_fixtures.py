@@ -76,3 +76,16 @@ def assert_topk_matches(scores, ids, ref_scores, ref_ids, atol=1e-4, tie_tol=2e-
                     assert j == k, f"row {b}: ids differ outside a tie group at [{start},{j})"
                     assert (rs[start] - rs[k - 1]) <= tie_tol
                 start = j
+
+
+def variant_cases():
+    """(name, cfg, weights, arrays) of tests/golden/variants.npz (oracle/gen_golden_variants.py: the reference on model
+    variants and shapes beyond the BASELINE configs)."""
+    z = np.load(os.path.join(GOLDEN, "variants.npz"))
+    for name in sorted({k.split("/")[0] for k in z.files}):
+        d = json.loads(str(z[f"{name}/cfg_json"]))
+        d["uid_embedding_hash_sizes"] = tuple(d["uid_embedding_hash_sizes"])
+        cfg = MoLConfig(**d)
+        w = {k[len(name) + 3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(name + "/w/")}
+        arrays = {k[len(name) + 1:]: torch.from_numpy(np.asarray(z[k])) for k in z.files if k.startswith(name + "/") and "/w/" not in k and not k.endswith("cfg_json")}
+        yield name, cfg, w, arrays

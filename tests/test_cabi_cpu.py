@@ -33,8 +33,8 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_struct_layout_matches_header(lib):
-    assert C.sizeof(_lib.MolShape) == 15 * 4
-    assert C.sizeof(_lib.MolWeights) == 8 * (4 + 4 + 4 + 12)  # 24 pointer-sized fields
+    assert C.sizeof(_lib.MolShape) == 20 * 4
+    assert C.sizeof(_lib.MolWeights) == 8 * (4 + 4 + 4 + 12 + 2)  # 26 pointer-sized fields
 
 
 def test_size_helpers_and_validation(lib):
@@ -43,8 +43,17 @@ def test_size_helpers_and_validation(lib):
     assert lib.rails_mol_gate_pack_floats(C.byref(s)) == 2 * 128 * 64 + 128 + 64
     assert lib.rails_mol_index_floats(C.byref(s), 33) == 2 * 32 * (8 * 32 + 64)     # two tiles
     assert lib.rails_mol_query_pack_floats(C.byref(s), 5) == 2 * 32 * 32 + 5 * 64 + 32 * (512 + 128 + 8 * 32 + 64)   # two query groups of 4 + scratch rows
-    bad = E.MolShapeSpec(64, 64, 48, 8, 8, 512, 128, 128, 128).to_c()
+    bad = E.MolShapeSpec(64, 64, 40, 8, 8, 512, 128, 128, 128).to_c()
     assert lib.rails_mol_shape_supported(C.byref(bad)) == 0 and "no fused scoring kernel" in _lib.last_error()
+    # shapes beyond the tuned ones and the model variants (modeling/similarity_utils.py:41-245)
+    for spec in (E.MolShapeSpec(64, 64, 48, 8, 8, 512, 128, 128, 128), E.MolShapeSpec(64, 64, 32, 16, 4, 512, 128, 128, 64 * 2),
+                 E.MolShapeSpec(64, 64, 32, 8, 8, -1, 128, 128, 128), E.MolShapeSpec(64, 64, 32, 8, 8, 512, 128, 128, 128, item_hidden_dim=256),
+                 E.MolShapeSpec(64, 64, 32, 8, 8, 512, -1, -1, 128, gating_combination_type="none", gating_query_fn=False, gating_item_fn=False)):
+        assert lib.rails_mol_shape_supported(C.byref(spec.to_c())) == 1, _lib.last_error()
+    none16 = E.MolShapeSpec(64, 64, 32, 8, 8, 512, 128, 128, 128, gating_combination_type="none").to_c("f16x3")
+    assert lib.rails_mol_shape_supported(C.byref(none16)) == 0 and "none" in _lib.last_error()
+    glu_missing = E.MolShapeSpec(64, 64, 32, 8, 8, 512, 128, 128, 128, gating_query_fn=False).to_c()
+    assert lib.rails_mol_shape_supported(C.byref(glu_missing)) == 0 and "glu_silu needs" in _lib.last_error()
     assert lib.rails_mol_shape_supported(C.byref(E.MolShapeSpec(64, 64, 64, 16, 16, 512, 128, 128, 128).to_c())) == 1
     # precision f16x3: same buffer sizes (f16 hi + lo in the bytes of the fp32 fragment); needs bounded cross logits
     s16 = E.MolShapeSpec(64, 64, 32, 8, 8, 512, 128, 128, 128).to_c("f16x3")

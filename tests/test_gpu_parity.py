@@ -706,6 +706,80 @@ def test_degenerate_sizes(dev, precision):
     assert abs(float(s) - float(ref)) <= LOGIT_TOL and int(i) == int(fx.t("item_ids")[0, 0])
 
 
+# ---- model variants and shapes beyond the BASELINE configs ---------------------------------------------------------
+def _module_for(cfg, w, dev, precision):
+    mol, _ = rails_amd.create_mol_interaction_module(
+        cfg.query_embedding_dim, cfg.item_embedding_dim, cfg.dot_product_dimension, cfg.query_dot_product_groups,
+        cfg.item_dot_product_groups, cfg.temperature, 0.0, cfg.query_hidden_dim, 0.1, cfg.item_hidden_dim,
+        cfg.gating_query_hidden_dim, cfg.gating_qi_hidden_dim, cfg.gating_item_hidden_dim, cfg.softmax_dropout_rate, False,
+        gating_query_fn=cfg.gating_query_fn, gating_item_fn=cfg.gating_item_fn, query_nonlinearity=cfg.query_nonlinearity,
+        item_nonlinearity=cfg.item_nonlinearity, uid_embedding_hash_sizes=list(cfg.uid_embedding_hash_sizes) or None,
+        gating_combination_type=cfg.gating_combination_type)
+    mol.load_state_dict(w, strict=True)
+    mol = mol.to(dev).eval()
+    mol.precision = precision
+    return mol
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_model_variants_against_the_reference(dev, precision):
+    """tests/golden/variants.npz: the reference's outputs for a plain-Linear query projection (8x8x64), a GLU item projection
+    (8x4x32), gating_combination_type "none" (16x4x32, exact-fp32 only) and a 64-wide pair gate (8x4x64)."""
+    from tests._fixtures import variant_cases
+
+    for name, cfg, w, a in variant_cases():
+        if precision == "f16x3" and cfg.gating_combination_type == "none":
+            with pytest.raises(NotImplementedError):
+                _module_for(cfg, w, dev, precision).engine()
+            continue
+        mol = _module_for(cfg, w, dev, precision)
+        with torch.inference_mode():
+            logits, _ = mol(a["q"].to(dev), a["X"].to(dev))
+            rows, _ = mol(a["q"].to(dev), a["cand"].to(dev))
+            eq, _ = mol.get_query_component_embeddings(a["q"].to(dev))
+            ex, _ = mol.get_item_component_embeddings(a["X"].to(dev))
+        assert float((logits.cpu() - a["logits"]).abs().max()) <= LOGIT_TOL, name
+        assert float((rows.cpu() - a["row_logits"]).abs().max()) <= LOGIT_TOL, name
+        assert float((eq.cpu() - a["Eq"]).abs().max()) <= STAGE_TOL and float((ex.cpu() - a["Ex"]).abs().max()) <= STAGE_TOL, name
+    with pytest.raises(NotImplementedError, match="pair gate without a hidden layer"):
+        cfg0 = O.MoLConfig(64, 64, 32, 8, 8, gating_qi_hidden_dim=-1)
+        m0, _ = rails_amd.create_mol_interaction_module(64, 64, 32, 8, 8, 0.05, 0.0, 512, 0.1, -1, 128, -1, 128, 0.2, False)
+        m0.to(dev).eval().engine()
+
+
+_FUZZ_SHAPES = [(8, 4, 64, 128), (8, 4, 128, 128), (8, 8, 32, 128), (16, 16, 64, 128),          # the tuned shapes
+                (8, 4, 32, 128), (8, 8, 16, 128), (8, 8, 64, 128), (8, 8, 128, 128), (8, 8, 48, 128), (8, 4, 16, 128),
+                (16, 2, 64, 128), (16, 4, 32, 128), (16, 4, 64, 128), (32, 2, 32, 128), (8, 8, 32, 64), (8, 4, 64, 64)]
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("shape", _FUZZ_SHAPES, ids=lambda s: "x".join(str(v) for v in s))
+def test_shape_fuzz(dev, shape, precision):
+    """Every built (P_Q, P_X, d, H) in both precisions (32 kernels' worth): random dims of the outer layers, a ragged corpus,
+    a batch that leaves the last query group partial, shared-corpus and per-row-candidate scoring against the oracle."""
+    pq, px, d, h = shape
+    g = torch.Generator().manual_seed(pq * 1000 + px * 100 + d + h)
+    dq, di = int(torch.randint(24, 96, (1,), generator=g)), int(torch.randint(24, 96, (1,), generator=g))
+    cfg = O.MoLConfig(dq, di, d, pq, px, gating_qi_hidden_dim=h, query_hidden_dim=int(torch.randint(1, 5, (1,), generator=g)) * 64,
+                      gating_query_hidden_dim=int(torch.randint(1, 4, (1,), generator=g)) * 32,
+                      gating_item_hidden_dim=int(torch.randint(1, 4, (1,), generator=g)) * 32,
+                      query_nonlinearity=("geglu", "swiglu")[int(torch.randint(0, 2, (1,), generator=g))])
+    w = O.synthetic_weights(cfg, seed=pq + px + d)
+    for key in list(w):   # non-zero biases
+        if key.endswith("bias") or key.endswith("_b"):
+            w[key] = torch.randn(w[key].shape, generator=g) * 0.05
+    mol = _module_for(cfg, w, dev, precision)
+    B, N = int(torch.randint(1, 42, (1,), generator=g)), int(torch.randint(33, 900, (1,), generator=g))
+    X = torch.from_numpy(O.hash_item_table(pq + d, 0, N, di)).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B, seed=px + h)
+    cand = X.squeeze(0)[torch.randint(0, N, (B, 37), generator=g)]
+    with torch.inference_mode():
+        got, _ = mol(q.to(dev), X.to(dev))
+        rows, _ = mol(q.to(dev), cand.to(dev))
+    assert float((got.cpu() - O.mol_logits(cfg, w, q, X)).abs().max()) <= LOGIT_TOL
+    assert float((rows.cpu() - O.mol_logits(cfg, w, q, cand)).abs().max()) <= LOGIT_TOL
+
+
 # ---- opt-in precision mode "f16x3" --------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["c1_ml1m", "c2_ml20m", "c3_books"])
 def test_f16x3_mode_holds_the_logit_tolerance(dev, name):

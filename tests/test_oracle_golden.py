@@ -176,3 +176,17 @@ def test_f10_naive_and_comb_rerank(cname):
     allowed = (cs >= kth).any(1).any(1)                                          # (B, N): item reachable by some pair
     idx = T("naive5/sorted_all_indices")
     assert bool(torch.gather(allowed, 1, idx).all())
+
+
+def test_oracle_reproduces_the_reference_on_model_variants():
+    """Plain-Linear query projection, GLU item projection, combination "none", H = 64, new shapes (variants.npz)."""
+    from tests._fixtures import variant_cases
+
+    n = 0
+    for name, cfg, w, a in variant_cases():
+        st = O.mol_stages(cfg, w, a["q"], a["X"])
+        assert torch.equal(st["logits"], a["logits"]) and torch.equal(st["Eq"], a["Eq"]) and torch.equal(st["Ex"].reshape(a["Ex"].shape), a["Ex"]), name
+        rows = O.mol_stages(cfg, w, a["q"], a["cand"])["logits"]
+        assert float((rows - a["row_logits"]).abs().max()) <= 2e-6, name
+        n += 1
+    assert n == 4

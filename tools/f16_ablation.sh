@@ -10,10 +10,10 @@ if [ "${1:-build}" = build ]; then
   make -s -j8
   for a in 1 2 3; do
     /opt/rocm/bin/hipcc $FLAGS -DRAILS_F16_ABLATE=$a -c mol_score_f16.hip -o /tmp/mol_score_f16_abl$a.o
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC capi.o mol_score.o /tmp/mol_score_f16_abl$a.o mol_index.o mol_query.o mol_coarse.o mips.o topk.o hstu.o -o ../librails_amd_abl$a.so
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC capi.o mol_score.o mol_score_extra.o mol_score_f16_extra.o /tmp/mol_score_f16_abl$a.o mol_index.o mol_query.o mol_coarse.o mips.o topk.o hstu.o -o ../librails_amd_abl$a.so
   done
   /opt/rocm/bin/hipcc $FLAGS -DRAILS_F16_PHASES -c mol_score_f16.hip -o /tmp/mol_score_f16_ph.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC capi.o mol_score.o /tmp/mol_score_f16_ph.o mol_index.o mol_query.o mol_coarse.o mips.o topk.o hstu.o -o ../librails_amd_phases16.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC capi.o mol_score.o mol_score_extra.o mol_score_f16_extra.o /tmp/mol_score_f16_ph.o mol_index.o mol_query.o mol_coarse.o mips.o topk.o hstu.o -o ../librails_amd_phases16.so
 else
   shift
   cd ../..
