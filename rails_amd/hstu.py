@@ -44,24 +44,77 @@ def _bucket_thresholds(num_buckets: int, max_dt: int = 1 << 62) -> torch.Tensor:
     return torch.tensor(out, dtype=torch.int64)
 
 
-class _ItemEmbedding(torch.nn.Module):          # LocalEmbeddingModule (embedding_modules.py:40-73): `_item_emb.weight`
-    def __init__(self, num_items: int, dim: int) -> None:
+class LocalEmbeddingModule(torch.nn.Module):
+    """Reference modeling/sequential/embedding_modules.py:40-73: `_item_emb.weight` (num_items + 1, D), row 0 = padding."""
+
+    def __init__(self, num_items: int, item_embedding_dim: int) -> None:
         super().__init__()
-        self._item_embedding_dim = dim
-        self._item_emb = torch.nn.Embedding(num_items + 1, dim, padding_idx=0)
+        self._item_embedding_dim = item_embedding_dim
+        self._item_emb = torch.nn.Embedding(num_items + 1, item_embedding_dim, padding_idx=0)
         torch.nn.init.trunc_normal_(self._item_emb.weight, mean=0.0, std=0.02, a=-0.04, b=0.04)
+
+    def debug_str(self) -> str:
+        return f"local_emb_d{self._item_embedding_dim}"
+
+    def get_item_embeddings(self, item_ids: torch.Tensor) -> torch.Tensor:
+        return self._item_emb(item_ids)
 
     @property
     def item_embedding_dim(self) -> int:
         return self._item_embedding_dim
 
 
-class _PositionalPreproc(torch.nn.Module):      # LearnablePositionalEmbeddingInputFeaturesPreprocessor: `_pos_emb.weight`
-    def __init__(self, max_sequence_len: int, dim: int) -> None:
+_ItemEmbedding = LocalEmbeddingModule
+
+
+class LearnablePositionalEmbeddingInputFeaturesPreprocessor(torch.nn.Module):
+    """Reference modeling/sequential/input_features_preprocessors.py:43-92: `_pos_emb.weight` (max_sequence_len, D).  A parameter
+    holder here: x = emb * sqrt(D) + pos_emb, masked by id != 0, is evaluated by rails_hstu_preprocess / the fused encoder."""
+
+    def __init__(self, max_sequence_len: int, embedding_dim: int, dropout_rate: float = 0.0) -> None:
         super().__init__()
-        self._pos_emb = torch.nn.Embedding(max_sequence_len, dim)
-        std = (1.0 / dim) ** 0.5
+        self._embedding_dim = embedding_dim
+        self._pos_emb = torch.nn.Embedding(max_sequence_len, embedding_dim)
+        self._dropout_rate = dropout_rate
+        std = (1.0 / embedding_dim) ** 0.5
         torch.nn.init.trunc_normal_(self._pos_emb.weight, mean=0.0, std=std, a=-2 * std, b=2 * std)
+
+    def debug_str(self) -> str:
+        return f"posi_d{self._dropout_rate}"
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("evaluated inside rails_amd's HSTU encoder kernels")
+
+
+_PositionalPreproc = LearnablePositionalEmbeddingInputFeaturesPreprocessor
+
+
+class _Postproc(torch.nn.Module):
+    mode = ""
+
+    def __init__(self, embedding_dim: int, eps: float = 1e-6) -> None:
+        super().__init__()
+        self._embedding_dim = embedding_dim
+        self._eps = eps
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("evaluated by rails_rows_normalize / the fused encoder kernel")
+
+
+class L2NormEmbeddingPostprocessor(_Postproc):
+    """Reference modeling/sequential/output_postprocessors.py:37-59."""
+    mode = "l2_norm"
+
+    def debug_str(self) -> str:
+        return "l2"
+
+
+class LayerNormEmbeddingPostprocessor(_Postproc):
+    """Reference modeling/sequential/output_postprocessors.py:62-85."""
+    mode = "layer_norm"
+
+    def debug_str(self) -> str:
+        return "ln"
 
 
 class _RelBias(torch.nn.Module):                # RelativeBucketedTimeAndPositionBasedBias (hstu.py:82-138)
@@ -91,10 +144,51 @@ class HSTU(torch.nn.Module):
     N must equal max_sequence_len + max_output_len (what the reference's eval feeds, modeling/sequential/features.py:48-58)."""
 
     def __init__(self, max_sequence_len: int, max_output_len: int, embedding_dim: int, num_blocks: int, num_heads: int, linear_dim: int,
-                 attention_dim: int, num_items: int, similarity_module: Optional[torch.nn.Module] = None, normalization: str = "rel_bias",
-                 linear_config: str = "uvqk", linear_activation: str = "silu", output_postproc: str = "layer_norm",
-                 enable_relative_attention_bias: bool = True, concat_ua: bool = False, num_buckets: int = 128, eps: float = 1e-6) -> None:
+                 attention_dim: int, *args, **kwargs) -> None:
+        """Two signatures:
+          the reference's (modeling/sequential/hstu.py:544-565) -- ..., normalization, linear_config, linear_activation,
+            linear_dropout_rate, attn_dropout_rate, embedding_module, similarity_module, input_features_preproc_module,
+            output_postproc_module, enable_relative_attention_bias=True, concat_ua=False, verbose=True -- with rails_amd's
+            LocalEmbeddingModule / LearnablePositionalEmbeddingInputFeaturesPreprocessor / {L2Norm,LayerNorm}EmbeddingPostprocessor
+            (or any objects with the same attributes), so encoder_utils.py needs only its imports swapped;
+          the compact one -- ..., num_items, similarity_module=None, normalization="rel_bias", linear_config="uvqk",
+            linear_activation="silu", output_postproc="layer_norm", enable_relative_attention_bias=True, concat_ua=False,
+            num_buckets=128, eps=1e-6."""
         super().__init__()
+        reference_style = "embedding_module" in kwargs or (len(args) > 0 and isinstance(args[0], str))
+        if reference_style:
+            names = ["normalization", "linear_config", "linear_activation", "linear_dropout_rate", "attn_dropout_rate", "embedding_module",
+                     "similarity_module", "input_features_preproc_module", "output_postproc_module", "enable_relative_attention_bias",
+                     "concat_ua", "verbose"]
+            a = dict(enable_relative_attention_bias=True, concat_ua=False, verbose=True)
+        else:
+            names = ["num_items", "similarity_module", "normalization", "linear_config", "linear_activation", "output_postproc",
+                     "enable_relative_attention_bias", "concat_ua", "num_buckets", "eps"]
+            a = dict(similarity_module=None, normalization="rel_bias", linear_config="uvqk", linear_activation="silu",
+                     output_postproc="layer_norm", enable_relative_attention_bias=True, concat_ua=False, num_buckets=128, eps=1e-6)
+        if len(args) > len(names):
+            raise TypeError(f"HSTU() takes at most {7 + len(names)} positional arguments")
+        a.update(dict(zip(names, args)))
+        for key, v in kwargs.items():
+            if key not in names:
+                raise TypeError(f"HSTU() got an unexpected keyword argument '{key}'")
+            a[key] = v
+        missing = [n for n in names if n not in a]
+        if missing:
+            raise TypeError(f"HSTU() missing required arguments: {missing}")
+        normalization, linear_config, linear_activation = a["normalization"], a["linear_config"], a["linear_activation"]
+        similarity_module, concat_ua = a["similarity_module"], a["concat_ua"]
+        enable_relative_attention_bias = a["enable_relative_attention_bias"]
+        if reference_style:
+            emb_mod, pre_mod, post_mod = a["embedding_module"], a["input_features_preproc_module"], a["output_postproc_module"]
+            if not hasattr(emb_mod, "_item_emb") or not hasattr(pre_mod, "_pos_emb"):
+                raise NotImplementedError("HSTU needs a LocalEmbeddingModule-like embedding_module (`_item_emb`) and a "
+                                          "LearnablePositionalEmbeddingInputFeaturesPreprocessor-like preprocessor (`_pos_emb`)")
+            output_postproc = getattr(post_mod, "mode", None) or {"l2": "l2_norm", "ln": "layer_norm"}.get(post_mod.debug_str())
+            num_buckets, eps = 128, float(getattr(post_mod, "_eps", 1e-6))
+        else:
+            emb_mod = pre_mod = post_mod = None
+            output_postproc, num_buckets, eps = a["output_postproc"], a["num_buckets"], a["eps"]
         if normalization not in ("rel_bias", "hstu_rel_bias") or linear_config != "uvqk" or concat_ua:
             raise NotImplementedError("only normalization='rel_bias', linear_config='uvqk', concat_ua=False are built")
         if linear_activation not in ("silu", "none"):
@@ -110,8 +204,10 @@ class HSTU(torch.nn.Module):
         self._postproc = output_postproc
         self._num_buckets = num_buckets
         self._eps = eps
-        self._embedding_module = _ItemEmbedding(num_items, embedding_dim)
-        self._input_features_preproc = _PositionalPreproc(self._seq, embedding_dim)
+        self._embedding_module = emb_mod if emb_mod is not None else LocalEmbeddingModule(a["num_items"], embedding_dim)
+        self._input_features_preproc = pre_mod if pre_mod is not None else LearnablePositionalEmbeddingInputFeaturesPreprocessor(self._seq, embedding_dim)
+        self._output_postproc = post_mod if post_mod is not None else (
+            LayerNormEmbeddingPostprocessor(embedding_dim, eps) if output_postproc == "layer_norm" else L2NormEmbeddingPostprocessor(embedding_dim, eps))
         self._hstu = _Stack([_Layer(embedding_dim, linear_dim, attention_dim, num_heads, self._seq, num_buckets, enable_relative_attention_bias)
                              for _ in range(num_blocks)])
         self.use_fused_kernel = True    # short sequences: the whole encoder in one launch (falls back when it does not fit)

@@ -617,6 +617,39 @@ def test_bf16_module_and_inputs_round_trip(dev):
     assert float((logits.cpu() - ref).abs().max()) <= LOGIT_TOL
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_f8_against_the_references_own_bf16_run(dev, precision):
+    """F8 (tests/golden/bf16_books.npz): eval_batch.py evaluates with model.to(bfloat16) and a bf16 item table.  rails_amd
+    keeps such a module's operands as their bf16-rounded values and computes in fp32 / f16x3, so it must (a) equal the
+    reference's FP32 arithmetic on those bf16 operands within the 1e-4 bar and (b) stay within the bf16 run's own rounding
+    noise of the reference's BF16 run: stated tolerance 0.15 on logits in [-20, 20] (the two reference runs differ by up to
+    0.127 here), >= 85 % of the bf16 run's top-200 items retrieved."""
+    import numpy as np
+
+    from tests._fixtures import GOLDEN
+    import json
+    import os
+
+    z = np.load(os.path.join(GOLDEN, "bf16_books.npz"))
+    d = json.loads(str(z["cfg_json"]))
+    d["uid_embedding_hash_sizes"] = tuple(d["uid_embedding_hash_sizes"])
+    cfg = O.MoLConfig(**d)
+    w = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w/")}
+    mol = build_module(cfg, w, dev, precision).to(torch.bfloat16)
+    mol.precision = precision
+    q, X = torch.from_numpy(z["q"]).to(dev).bfloat16(), torch.from_numpy(z["X"]).to(dev).bfloat16()
+    ids = torch.arange(X.shape[1], dtype=torch.int64, device=dev).unsqueeze(0)
+    with torch.inference_mode():
+        tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
+        logits = tk.all_logits(q).cpu()
+        _, top = tk(q, k=200)
+    assert float((logits - torch.from_numpy(z["logits_fp32_run_on_bf16_operands"])).abs().max()) <= LOGIT_TOL
+    assert float((logits - torch.from_numpy(z["logits_bf16_run"])).abs().max()) <= 0.15
+    ref_top = torch.from_numpy(z["top200_idx_bf16_run"])
+    overlap = sum(len(set(a.tolist()) & set(b.tolist())) for a, b in zip(top.cpu(), ref_top)) / ref_top.numel()
+    assert overlap >= 0.85, overlap
+
+
 def test_index_follows_parameter_updates(dev):
     fx = Fixture("c3_books")
     mol = build_module(fx.cfg, fx.weights, dev)

@@ -64,6 +64,32 @@ def test_module_mirrors_the_reference_state_dict_and_bucketing():
         HSTU(10, 1, 16, 1, 1, 8, 8, 20, concat_ua=True)
 
 
+def test_reference_style_constructor_builds_the_same_module():
+    """modeling/sequential/encoder_utils.py constructs HSTU from module objects (hstu.py:544-565); with rails_amd's classes of
+    the same names that call works unchanged and yields the same parameters as the compact constructor."""
+    from rails_amd.hstu import HSTU
+    from rails_amd.modeling.sequential.embedding_modules import LocalEmbeddingModule
+    from rails_amd.modeling.sequential.input_features_preprocessors import LearnablePositionalEmbeddingInputFeaturesPreprocessor
+    from rails_amd.modeling.sequential.output_postprocessors import L2NormEmbeddingPostprocessor, LayerNormEmbeddingPostprocessor
+
+    for post in (L2NormEmbeddingPostprocessor(embedding_dim=16, eps=1e-6), LayerNormEmbeddingPostprocessor(embedding_dim=16, eps=1e-6)):
+        ref_style = HSTU(
+            max_sequence_len=10, max_output_len=1, embedding_dim=16, num_blocks=2, num_heads=1, linear_dim=8, attention_dim=8,
+            normalization="rel_bias", linear_config="uvqk", linear_activation="silu", linear_dropout_rate=0.2, attn_dropout_rate=0.0,
+            embedding_module=LocalEmbeddingModule(num_items=20, item_embedding_dim=16), similarity_module=None,
+            input_features_preproc_module=LearnablePositionalEmbeddingInputFeaturesPreprocessor(max_sequence_len=11, embedding_dim=16, dropout_rate=0.2),
+            output_postproc_module=post, enable_relative_attention_bias=True, verbose=False)
+        compact = HSTU(10, 1, 16, 2, 1, 8, 8, 20, output_postproc=post.mode)
+        assert sorted(ref_style.state_dict()) == sorted(compact.state_dict())
+        assert all(tuple(ref_style.state_dict()[k].shape) == tuple(v.shape) for k, v in compact.state_dict().items())
+        assert ref_style._postproc == post.mode and ref_style._output_postproc is post
+    positional = HSTU(10, 1, 16, 2, 1, 8, 8, "rel_bias", "uvqk", "silu", 0.2, 0.0, LocalEmbeddingModule(20, 16), None,
+                      LearnablePositionalEmbeddingInputFeaturesPreprocessor(11, 16, 0.2), L2NormEmbeddingPostprocessor(16))
+    assert positional._postproc == "l2_norm"
+    with pytest.raises(TypeError):
+        HSTU(10, 1, 16, 2, 1, 8, 8, 20, no_such_argument=1)
+
+
 def test_encoder_refuses_cpu_and_training():
     from rails_amd.hstu import HSTU
 
