@@ -469,10 +469,10 @@ __device__ __forceinline__ void big_half(const f32x16 (&D1)[PX], const u32x4v (&
     for (int r = 0; r < 16; ++r) D3[v][r] = w.b2[hi * G::E + E0 + v * 16 + r];
   // fragment f = ks * NT + local tile  ->  global fragment ks * TL + HALF * NT + local tile
   auto W = [&](bool hi_part, int f) { return w.w2frag(hi_part, (f / NT) * G::TL + HALF * NT + f % NT, lane); };
-  WSlots<3> ws;
+  WSlots<4> ws;   // four groups of W2 fragments in flight (L2 latency ~ 3 groups of MFMAs; measured 3: 10.7 ms, 4: 10.1, 6: 10.4 at 400 k items)
   seq_begin<S>(ws, W);
   // operands of the first logit pairs of the epilogue: requested before the GEMM, consumed after it
-  constexpr int PF = kEpiPrefetch;
+  constexpr int PF = 16;   // gi comes from HBM/L2 here (direct shell): twice the usual prefetch distance
   float2 gi_r[PF], gq_r[PF];
   auto fetch = [&](auto pc) {
     constexpr int P = decltype(pc)::value, e = E0 + 2 * P;
