@@ -237,37 +237,38 @@ __device__ __forceinline__ void interleave(FM&& mf, FS&& sf) {
 // subtraction per logit and the cross-lane minimum; an overflow is detected on the denominator (inf / NaN) and that
 // query is redone with the shifted form from the u values, which are still in registers -- same result as the
 // reference's stable softmax (similarity_fn.py:31-46) in every case.
-constexpr int kEpiPrefetch = 8;   // logit pairs whose gi / gq operands are requested ahead of their slice (gi may sit in HBM/L2)
-template <class G>
+// PF = logit pairs whose gi / gq operands are requested ahead of their slice (gi may sit in HBM/L2); 4 registers each
+template <class G, int PF>
 struct Epi {
+  static constexpr int kPF = PF;
   f32x16 D3[G::TL];   // -log2e * gqi on entry; u after pass 1
   float den, num;
   const float* gq;    // this query's -log2e * gq row, lane half's part ([hi][e] layout)
-  float2 gi_r[kEpiPrefetch], gq_r[kEpiPrefetch];
+  float2 gi_r[PF], gq_r[PF];
   // gi fragment [ec = e/4][lane][4]: pair P is floats (e%4, e%4+1), e = 2P, of the lane's float4
   template <int P>
   __device__ __forceinline__ void fetch(const float* tGi, int lane) {
     constexpr int e = 2 * P;
-    gi_r[P % kEpiPrefetch] = *reinterpret_cast<const float2*>(tGi + ((e / 4) * 64 + lane) * 4 + e % 4);
-    gq_r[P % kEpiPrefetch] = *reinterpret_cast<const float2*>(gq + e);
+    gi_r[P % PF] = *reinterpret_cast<const float2*>(tGi + ((e / 4) * 64 + lane) * 4 + e % 4);
+    gq_r[P % PF] = *reinterpret_cast<const float2*>(gq + e);
   }
   __device__ __forceinline__ void reset(const float* gq_, const float* tGi, int lane) {
     den = 0.0f; num = 0.0f; gq = gq_;
-    static_for<(kEpiPrefetch < G::E / 2 ? kEpiPrefetch : G::E / 2)>([&](auto pc) { fetch<decltype(pc)::value>(tGi, lane); });
+    static_for<(PF < G::E / 2 ? PF : G::E / 2)>([&](auto pc) { fetch<decltype(pc)::value>(tGi, lane); });
   }
 };
 // pass 1, logits e = 2P, 2P+1 of this lane:  t2 = -log2e*(gq*gi + gqi);  u = t2/(1+2^t2) = -log2e * g*sigmoid(g)
-template <class G, int P>
-__device__ __forceinline__ void epi_p1(Epi<G>& s, const float* tGi, int lane) {
-  constexpr int e = 2 * P;
-  const float2 gi = s.gi_r[P % kEpiPrefetch], gq = s.gq_r[P % kEpiPrefetch];
-  if constexpr (P + kEpiPrefetch < G::E / 2) s.template fetch<P + kEpiPrefetch>(tGi, lane);
+template <class G, int P, class EP>
+__device__ __forceinline__ void epi_p1(EP& s, const float* tGi, int lane) {
+  constexpr int e = 2 * P, PF = EP::kPF;
+  const float2 gi = s.gi_r[P % PF], gq = s.gq_r[P % PF];
+  if constexpr (P + PF < G::E / 2) s.template fetch<P + PF>(tGi, lane);
   s.D3[e / 16][e % 16] = nsilu(__builtin_fmaf(gq.x, gi.x, s.D3[e / 16][e % 16]));
   s.D3[e / 16][e % 16 + 1] = nsilu(__builtin_fmaf(gq.y, gi.y, s.D3[e / 16][e % 16 + 1]));
 }
 // pass 2:  ex = 2^(-u) = softmax numerator;  den += ex;  num += ex * cl   (cl of this query: D1 registers R0 + ...)
-template <class G, int PX, int R0, int P>
-__device__ __forceinline__ void epi_p2(Epi<G>& s, const f32x16 (&D1)[PX]) {
+template <class G, int PX, int R0, int P, class EP>
+__device__ __forceinline__ void epi_p2(EP& s, const f32x16 (&D1)[PX]) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     constexpr int e0 = 2 * P;
@@ -278,15 +279,15 @@ __device__ __forceinline__ void epi_p2(Epi<G>& s, const f32x16 (&D1)[PX]) {
   }
 }
 // slice S of the E slices of an epilogue: S < E/2 -> pass 1 of pair S; else pass 2 of pair S - E/2
-template <class G, int PX, int R0, int S>
-__device__ __forceinline__ void epi_slice(Epi<G>& s, const f32x16 (&D1)[PX], const float* tGi, int lane) {
+template <class G, int PX, int R0, int S, class EP>
+__device__ __forceinline__ void epi_slice(EP& s, const f32x16 (&D1)[PX], const float* tGi, int lane) {
   constexpr int HALF = G::E / 2;
   if constexpr (S < HALF) epi_p1<G, S>(s, tGi, lane);
   else epi_p2<G, PX, R0, S - HALF>(s, D1);
 }
 // pi = ex/den, then the eval-time renormalisation pi / clamp(sum pi, 1e-6) (similarity_fn.py:42-46): sum pi = den * (1/den)
-template <class G, int PX, int R0>
-__device__ __forceinline__ float epi_final(Epi<G>& s, const f32x16 (&D1)[PX]) {
+template <class G, int PX, int R0, class EP>
+__device__ __forceinline__ float epi_final(EP& s, const f32x16 (&D1)[PX]) {
   float den = s.den + swap32(s.den), num = s.num + swap32(s.num);
   if (__builtin_amdgcn_ballot_w64(!(den < 3.0e38f)) != 0) {   // an exp overflowed somewhere in this wave: the stable form
     float mn = INFINITY;
@@ -555,7 +556,7 @@ struct F16Unit {
     };
 
     f32x16 D2[G::TH];
-    Epi<G> ep;
+    Epi<G, (TIGHT ? 2 : 8)> ep;   // TIGHT has no registers to spare for a deeper operand ring (and its epilogue is not fenced: the compiler hoists)
     XState<G> xs;
     YState<G, (BIG ? 3 : 1)> ys;
     auto stage_x_alone = [&](auto qc) {   // GEMM2 with nothing to hide it under but the operand splits
