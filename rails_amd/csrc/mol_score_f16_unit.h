@@ -181,7 +181,10 @@ struct SplitPack {
 // GEMM1 on pre-split operands: eq = [ks][hi|lo][lane] h8 (query pack), tEx = [m][ks][hi|lo][lane] h8 (tile, LDS or HBM).
 // Item groups in chunks of <= 8 (their B fragments of a K-step are fetched together); inside a chunk the products are
 // outermost so that consecutive MFMAs go to different accumulators.
-template <class G, int PX, int DD>
+// BULK: no fences between chunks -- the compiler then requests the whole tile up front (PX * d / 4 registers), which is what a
+// wave that fetches its tile straight from HBM wants (one round trip per unit instead of one per chunk) and what only a
+// one-wave-per-SIMD build has the registers for.
+template <class G, int PX, int DD, bool BULK = false>
 __device__ __forceinline__ void gemm1_presplit(f32x16 (&D1)[PX], const h8* __restrict__ eq, const h8* tEx, int lane) {
   static_assert(DD % 16 == 0, "f16x3 GEMM1 walks K in steps of 16");
   constexpr int MC = PX > 8 ? 4 : PX;
@@ -190,6 +193,27 @@ __device__ __forceinline__ void gemm1_presplit(f32x16 (&D1)[PX], const h8* __res
   for (int m = 0; m < PX; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) D1[m][r] = 0.0f;
+  if constexpr (BULK) {
+    // every fragment of the tile and of the query group requested before the first MFMA: ONE memory round trip per unit
+    h8 a[DD / 8], b[PX][DD / 8];
+#pragma unroll
+    for (int c = 0; c < DD / 8; ++c) a[c] = eq[c * 64 + lane];
+#pragma unroll
+    for (int m = 0; m < PX; ++m)
+#pragma unroll
+      for (int c = 0; c < DD / 8; ++c) b[m][c] = tEx[(m * (DD / 8) + c) * 64 + lane];
+    asm volatile("" ::: "memory");   // the requests stay above the MFMAs
+#pragma unroll
+    for (int ks = 0; ks < DD / 16; ++ks) {
+#pragma unroll
+      for (int m = 0; m < PX; ++m) D1[m] = mfma16(a[2 * ks + 1], b[m][2 * ks], D1[m]);
+#pragma unroll
+      for (int m = 0; m < PX; ++m) D1[m] = mfma16(a[2 * ks], b[m][2 * ks + 1], D1[m]);
+#pragma unroll
+      for (int m = 0; m < PX; ++m) D1[m] = mfma16(a[2 * ks], b[m][2 * ks], D1[m]);
+    }
+    return;
+  }
 #pragma unroll
   for (int ks = 0; ks < DD / 16; ++ks) {
     const h8 ah = eq[(2 * ks) * 64 + lane], al = eq[(2 * ks + 1) * 64 + lane];
@@ -534,9 +558,9 @@ struct F16Unit {
   template <class G, int NW>
   static __device__ __forceinline__ void stage(const ScoreArgs& p, float* smem) { SplitPack<G, BIG>::template stage<NW>(p, smem); }
 
-  template <class G, int PX, int DD>
+  template <class G, int PX, int DD, bool BULK = false>
   static __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float* __restrict__ eq, const float4* tEx, int lane) {
-    gemm1_presplit<G, PX, DD>(D1, reinterpret_cast<const h8*>(eq), reinterpret_cast<const h8*>(tEx), lane);
+    gemm1_presplit<G, PX, DD, BULK && !BIG>(D1, reinterpret_cast<const h8*>(eq), reinterpret_cast<const h8*>(tEx), lane);
   }
 
   template <class G, int PX>
@@ -627,12 +651,13 @@ struct F16Unit {
       });
       return;
     }
-    if (only >= 0 || !OVERLAP) {
-      // per-row candidates (one query of the group), or the cross-query overlap switched off: query by query
+    if (only >= 0 || !OVERLAP || (g + 1) * G::QT > p.B) {
+      // per-row candidates (one query of the group), a group that reaches past the batch end (small batches: skip the padding
+      // queries), or the cross-query overlap switched off: query by query
       static_for<G::QT>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
         const int q = g * G::QT + Q;
-        if (only < 0 || q == only) {
+        if (q < p.B && (only < 0 || q == only)) {
           F16_STAMP(4 * Q);
           stage_x_alone(qc);
           F16_STAMP(4 * Q + 1);

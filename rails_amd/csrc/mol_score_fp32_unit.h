@@ -50,7 +50,7 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 
 // GEMM1: D1[m][(qj,p), x] = sum_d Eq[qj,p,d] * Ex[x,m,d].  `eq` is the query group's A operand in fragment
 // order ([sc][lane] float4), `tEx` the tile's B operand ([m][sc][lane] float4) -- in HBM or in LDS.
-template <class G, int PX, int DD>
+template <class G, int PX, int DD, bool BULK = false>
 __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float4* __restrict__ eq, const float4* tEx, int lane) {
 #pragma unroll
   for (int m = 0; m < PX; ++m)
@@ -68,8 +68,9 @@ __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float4* __restrict
       D1[m] = mfma32(a.w, b.w, D1[m]);
     }
     // keep the operand fetches of later K-chunks below this chunk's MFMAs: left alone, the scheduler hoists
-    // every read of the tile to the top (128 live registers) and spills
-    asm volatile("" ::: "memory");
+    // every read of the tile to the top (128 live registers) and spills.  BULK (one wave per SIMD, tile straight from HBM)
+    // wants exactly that hoist: one memory round trip per unit instead of one per chunk.
+    if constexpr (!BULK) asm volatile("" ::: "memory");
   }
 }
 
@@ -193,9 +194,9 @@ struct Fp32Unit {
   static constexpr int kLdsWeightFloats = G::kWpackFloats;
   template <class G, int NW>
   static __device__ __forceinline__ void stage(const ScoreArgs& p, float* smem) { stage_weights<G, NW>(p, smem); }
-  template <class G, int PX, int DD>
+  template <class G, int PX, int DD, bool BULK = false>
   static __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float* __restrict__ eq, const float4* tEx, int lane) {
-    mol::gemm1<G, PX, DD>(D1, reinterpret_cast<const float4*>(eq), tEx, lane);
+    mol::gemm1<G, PX, DD, BULK>(D1, reinterpret_cast<const float4*>(eq), tEx, lane);
   }
   // All queries of one unit, each at its own static register offset (no register rotation).
   // `only` >= 0 restricts the unit to that query (per-row candidates).
