@@ -274,6 +274,13 @@ int rails_rows_layer_norm(const float* x, int64_t ldx, int64_t rows, int32_t dim
 int rails_gemm_f32(const float* a, int64_t lda, const float* w, int32_t w_is_nk, const float* bias, const float* residual,
                    int64_t ldr, int64_t m, int32_t n, int32_t k, int32_t act, const int64_t* lengths, int32_t seq_len, float* c,
                    int64_t ldc, void* stream);
+/* out = act(l) * g with [l | g] = x W + b: GeGLU (act = erf gelu) / SwiGLU (act = silu) as stand-alone layers
+ * (reference rails/similarities/layers.py:19-74; `kind` RAILS_GEGLU | RAILS_SWIGLU).  w is the `_w` parameter, (in_features,
+ * 2 * out_features) row-major; b the `_b` parameter (2 * out_features) or NULL; scratch holds rows * 2 * out_features floats
+ * (the pre-activations); out is (rows, out_features) dense.  Inside the MoL path the same unit is fused into the query prologue
+ * and the index build; this entry point serves callers that use the layer on its own. */
+int rails_glu_f32(const float* x, int64_t ldx, const float* w, const float* b, int64_t rows, int32_t in_features, int32_t out_features,
+                  int32_t kind, float* scratch, float* out, void* stream);
 /* buckets[b][j][i] = #{t : thresholds[t] <= |ts[b, min(i+1, seq_len-1)] - ts[b, j]|} (uint8, key-major): the time bucket of
  * (query i, key j) of RelativeBucketedTimeAndPositionBasedBias (hstu.py:107-138); thresholds (num_buckets int64, ascending)
  * are the bucket edges of floor(log(max(|dt|, 1)) / 0.301) evaluated in float32 exactly as torch does.  Once per batch:

@@ -480,6 +480,19 @@ int rails_gemm_f32(const float* a, int64_t lda, const float* w, int32_t w_is_nk,
   return fail(gemm_f32(a, lda, w, w_is_nk ? 1 : 0, bias, residual, ldr, m, n, k, act, lengths, seq_len, c, ldc, (hipStream_t)stream), "gemm_f32");
 }
 
+int rails_glu_f32(const float* x, int64_t ldx, const float* w, const float* b, int64_t rows, int32_t in_features, int32_t out_features,
+                  int32_t kind, float* scratch, float* out, void* stream) {
+  g_err[0] = '\0';
+  if (rows < 0 || in_features <= 0 || out_features <= 0) { set_error("glu_f32: bad size"); return RAILS_EINVAL; }
+  if (kind != RAILS_GEGLU && kind != RAILS_SWIGLU) { set_error("glu_f32: unknown kind %d", kind); return RAILS_EINVAL; }
+  if (rows == 0) return RAILS_OK;
+  if (!x || !w || !scratch || !out || ldx < in_features) { set_error("glu_f32: NULL pointer or short stride"); return RAILS_EINVAL; }
+  const int n2 = 2 * out_features;
+  const int rc = gemm_f32(x, ldx, w, 0, b, nullptr, 0, rows, n2, in_features, 0, nullptr, 0, scratch, n2, (hipStream_t)stream);
+  if (rc != kOk) return fail(rc, "glu_f32 (gemm)");
+  return fail(glu_gate(scratch, n2, rows, out_features, kind, out, (hipStream_t)stream), "glu_f32 (gate)");
+}
+
 int rails_hstu_time_buckets(const int64_t* timestamps, int32_t batch, int32_t seq_len, const int64_t* thresholds, int32_t num_buckets,
                             uint8_t* out, void* stream) {
   g_err[0] = '\0';

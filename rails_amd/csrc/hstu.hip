@@ -562,6 +562,19 @@ int rows_layer_norm(const float* x, int64_t ldx, int64_t rows, int D, float eps,
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
+// out[r][j] = act(t[r][j]) * t[r][F + j]: the gate of GeGLU (erf gelu) / SwiGLU (x * sigmoid x) over the (rows, 2F) pre-activations
+// t = x W + b written by gemm_f32 (reference rails/similarities/layers.py:36-43, :68-74).  Precise erff / expf, a true division.
+__global__ __launch_bounds__(256) void glu_gate_kernel(const float* __restrict__ t, int64_t ldt, int64_t rows, int F, int kind,
+                                                       float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * F) return;
+  const int64_t r = i / F;
+  const int j = (int)(i - r * F);
+  const float l = t[r * ldt + j], g = t[r * ldt + F + j];
+  const float act = kind == RAILS_GEGLU ? 0.5f * l * (1.0f + erff(l * 0.70710678118654752440f)) : l / (1.0f + expf(-l));
+  out[i] = act * g;
+}
+
 int rows_normalize(const float* x, int64_t ldx, const int64_t* row_index, int64_t rows, int D, int mode, float eps, float* out,
                    hipStream_t stream) {
   if (rows == 0) return kOk;
@@ -575,6 +588,12 @@ int gemm_f32(const float* A, int64_t lda, const float* W, int w_is_nk, const flo
   GemmArgs g{A, lda, W, w_is_nk, bias, residual, ldr, M, N, K, act, lengths, seq_len, C, ldc};
   const int64_t tiles = ((M + 31) / 32) * ((N + 31) / 32);
   hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, g);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+int glu_gate(const float* t, int64_t ldt, int64_t rows, int F, int kind, float* out, hipStream_t stream) {
+  if (rows == 0 || F == 0) return kOk;
+  hipLaunchKernelGGL(glu_gate_kernel, dim3((unsigned)((rows * F + 255) / 256)), dim3(256), 0, stream, t, ldt, rows, F, kind, out);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

@@ -67,7 +67,24 @@ class _GLU(torch.nn.Module):
         self._b = torch.nn.Parameter(torch.zeros((1, out_features * 2)))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError(f"{type(self).__name__} is evaluated inside rails_amd's query-prologue HIP kernel")
+        """The layer on its own (reference layers.py:36-43 / :68-74): rails_glu_f32 = the fp32 MFMA tile GEMM of csrc/hstu.hip for
+        x W + b, then the gate pass.  Inside MoLSimilarity the unit is fused into the query prologue / index build instead."""
+        from . import _lib
+        from .engine import _on_device, _ptr, _require_device, _stream
+
+        _require_device(x, f"{type(self).__name__} input")
+        bs = x.size()[:-1]
+        x2 = x.reshape(-1, self._in_features).float().contiguous()
+        rows, F = x2.size(0), self._out_features
+        w = self._w.detach().float().contiguous()
+        b = self._b.detach().float().contiguous()
+        scratch = torch.empty((rows, 2 * F), dtype=torch.float32, device=x.device)
+        out = torch.empty((rows, F), dtype=torch.float32, device=x.device)
+        kind = _lib.RAILS_GEGLU if self.kind == "geglu" else _lib.RAILS_SWIGLU
+        with _on_device(x.device):
+            _lib.check(_lib.load().rails_glu_f32(_ptr(x2), self._in_features, _ptr(w), _ptr(b), rows, self._in_features, F, kind,
+                                                 _ptr(scratch), _ptr(out), _stream()), "rails_glu_f32")
+        return out.to(x.dtype).reshape(bs + (F,))
 
 
 class GeGLU(_GLU):

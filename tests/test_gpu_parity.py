@@ -937,3 +937,30 @@ def test_eval_harness_reproduces_the_reference_harness(dev):
         if timing:
             assert all(t > 0 for t in res["eval_time"])
     assert abs(float(H._avg(res["hr@10"].float(), 1)) - float(fx.t("F5/timing/hr@10").float().mean())) < 1e-7
+
+
+GLU_CASES = ["geglu_2d", "swiglu_2d", "geglu_3d", "swiglu_1row"]
+
+
+@pytest.mark.parametrize("case", GLU_CASES)
+def test_glu_layers_standalone_against_the_reference_modules(dev, case):
+    """GeGLU / SwiGLU forward on their own (reference layers.py:36-43, :68-74) through rails_glu_f32, against the outputs of the
+    reference's modules on the same seeded inputs (tests/golden/glu.npz, oracle/gen_golden_glu.py).  fp32 GEMM with another
+    summation order: 2e-6 absolute on outputs of order 1."""
+    import os
+
+    import numpy as np
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glu.npz"))
+    x, w, b, y = (torch.from_numpy(z[f"{case}.{k}"]) for k in ("x", "w", "b", "y"))
+    cls = rails_amd.GeGLU if case.startswith("geglu") else rails_amd.SwiGLU
+    m = cls(w.shape[0], w.shape[1] // 2)
+    m.load_state_dict({"_w": w, "_b": b})
+    m = m.to(dev)
+    with torch.inference_mode():
+        got = m(x.to(dev))
+    assert got.shape == y.shape and got.dtype == y.dtype
+    err = float((got.cpu() - y).abs().max())
+    assert err <= 2e-6 * max(1.0, float(y.abs().max())), err
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(x)

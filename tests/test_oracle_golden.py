@@ -190,3 +190,17 @@ def test_oracle_reproduces_the_reference_on_model_variants():
         assert float((rows - a["row_logits"]).abs().max()) <= 2e-6, name
         n += 1
     assert n == 4
+
+
+def test_oracle_glu_matches_the_reference_layers():
+    """oracle._glu (the restatement used inside the query / item projections) against the reference's GeGLU / SwiGLU modules run
+    on their own (tests/golden/glu.npz)."""
+    import os
+
+    import numpy as np
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "glu.npz"))
+    for case in ("geglu_2d", "swiglu_2d", "geglu_3d", "swiglu_1row"):
+        x, w, b, y = (torch.from_numpy(z[f"{case}.{k}"]) for k in ("x", "w", "b", "y"))
+        got = O._glu(x.reshape(-1, x.shape[-1]), w, b, "geglu" if case.startswith("geglu") else "swiglu").reshape(y.shape)
+        assert torch.equal(got, y), case
