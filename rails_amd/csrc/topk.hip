@@ -897,6 +897,82 @@ int merge_candidates(const int64_t* gathered, int R, int rows, int k, int k_out,
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
+// ---- precision "f16x3-exact": the verified finish of a speculative brute-force top-k -------------------------------------
+// Per row: kc candidates with their exact fp32 logits `exact`, the f16x3 logits `approx` that selected them (same order) and
+// their corpus positions.  One workgroup sorts the row by (exact desc, position asc) -- the dense fp32 path's total order -- in
+// LDS, emits the top k (scores, ids[position]) and the row's verdict:
+//   ok[row] = (k-th exact score > min approx + margin_eps)  and  (max |exact - approx| <= check_eps)
+// The first clause means no item outside the candidates (approx <= min approx, exact <= approx + eps) can reach the k-th place;
+// the second monitors the error bound eps on the candidates themselves.  NaNs fail both.  (topk_modules._forward_rescored)
+__global__ __launch_bounds__(kSortThreads) void rescore_select_kernel(const float* __restrict__ exact, int64_t ld,
+                                                                      const float* __restrict__ approx,
+                                                                      const int64_t* __restrict__ positions,
+                                                                      const int64_t* __restrict__ ids, int kc, int k, int npad,
+                                                                      float margin_eps, float check_eps, float* __restrict__ out_scores,
+                                                                      int64_t* __restrict__ out_ids, int* __restrict__ ok) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  __shared__ float red_min[kSortThreads / 64];
+  __shared__ int red_nan[kSortThreads / 64];
+  const int row = blockIdx.x;
+  float mn = INFINITY;
+  int bad = 0;
+  for (int i = threadIdx.x; i < npad; i += kSortThreads) {
+    unsigned long long kv = 0ull;
+    if (i < kc) {
+      const float e = exact[(int64_t)row * ld + i], a = approx[(int64_t)row * kc + i];
+      kv = ((unsigned long long)orderable(e) << 32) | (unsigned int)(~(unsigned int)positions[(int64_t)row * kc + i]);
+      mn = fminf(mn, a);
+      bad |= !(fabsf(e - a) <= check_eps);       // catches NaN as well
+    }
+    keys[i] = kv;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+    bad |= __shfl_xor(bad, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) { red_min[threadIdx.x >> 6] = mn; red_nan[threadIdx.x >> 6] = bad; }
+  __syncthreads();
+  for (int size = 2; size <= npad; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = threadIdx.x; t < (npad >> 1); t += kSortThreads) {
+        const int lo = ((t & ~(stride - 1)) << 1) | (t & (stride - 1));
+        const int hi2 = lo | stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = keys[lo], b = keys[hi2];
+        if ((a < b) == desc) { keys[lo] = b; keys[hi2] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int j = threadIdx.x; j < k; j += kSortThreads) {
+    const unsigned long long kv = keys[j];
+    const int64_t pos = (int64_t)(~(unsigned int)(kv & 0xFFFFFFFFull));
+    out_scores[(int64_t)row * k + j] = unorderable((unsigned int)(kv >> 32));
+    out_ids[(int64_t)row * k + j] = ids ? ids[pos] : pos;
+  }
+  if (threadIdx.x == 0) {
+    float m = INFINITY;
+    int b = 0;
+    for (int w = 0; w < kSortThreads / 64; ++w) { m = fminf(m, red_min[w]); b |= red_nan[w]; }
+    const float kth = unorderable((unsigned int)(keys[k - 1] >> 32));
+    ok[row] = (!b && kth > m + margin_eps) ? 1 : 0;
+  }
+}
+
+int rescore_select(const float* exact, int64_t ld, const float* approx, const int64_t* positions, const int64_t* ids, int rows, int kc,
+                   int k, float margin_eps, float check_eps, float* out_scores, int64_t* out_ids, int* ok, hipStream_t stream) {
+  if (rows <= 0) return kOk;
+  if (kc > kSortCap) { set_error("rescore_select: %d candidates exceed the in-LDS sort capacity (%d)", kc, kSortCap); return kErrUnsupported; }
+  static DynLdsOnce once;
+  if (ensure_dyn_lds(once, reinterpret_cast<const void*>(&rescore_select_kernel), kSortCap * (int)sizeof(unsigned long long)) != kOk)
+    return kErrLaunch;
+  const int npad = next_pow2(kc < 2 ? 2 : kc);
+  hipLaunchKernelGGL(rescore_select_kernel, dim3(rows), dim3(kSortThreads), npad * sizeof(unsigned long long), stream, exact, ld, approx,
+                     positions, ids, kc, k, npad, margin_eps, check_eps, out_scores, out_ids, ok);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 // ---- candidate-union helpers of MoLNaiveTopK / MoLCombTopK ------------------------------------------------
 // torch.sort(cat(all_indices), dim=1) (mol_top_k.py:257, :515): ascending LDS bitonic sort of each row of int64.
 __global__ __launch_bounds__(kSortThreads) void sort_rows_i64_kernel(const int64_t* __restrict__ in, int n, int npad,

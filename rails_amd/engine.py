@@ -16,11 +16,13 @@ import torch
 from . import _lib
 
 TILE_ITEMS = 32
-PRECISIONS = ("fp32", "f16x3")
+PRECISIONS = ("fp32", "f16x3", "f16x3-exact")
+# "f16x3-exact": the f16x3 kernels pick candidates, an fp32 companion engine (`MolEngine.exact`) re-scores them, so the
+# brute-force top-k is the fp32 path's result bit for bit (topk_modules.MoLBruteForceTopK); every other use behaves as "f16x3".
 
 
 def default_precision() -> str:
-    """"fp32" (exact fp32 MFMA, the parity path) unless RAILS_PRECISION selects the opt-in "f16x3" mode."""
+    """"fp32" (exact fp32 MFMA, the parity path) unless RAILS_PRECISION selects an opt-in mode ("f16x3", "f16x3-exact")."""
     p = os.environ.get("RAILS_PRECISION", "fp32")
     if p not in PRECISIONS:
         raise ValueError(f"RAILS_PRECISION must be one of {PRECISIONS}, got {p!r}")
@@ -180,9 +182,11 @@ class MolEngine:
     def __init__(self, spec: MolShapeSpec, weights: Dict[str, torch.Tensor], precision: Optional[str] = None):
         self.lib = _lib.load()
         self.spec = spec
-        self.precision = precision or default_precision()
-        if self.precision not in PRECISIONS:
-            raise ValueError(f"precision must be one of {PRECISIONS}, got {self.precision!r}")
+        precision = precision or default_precision()
+        if precision not in PRECISIONS:
+            raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")
+        self.precision = "f16x3" if precision == "f16x3-exact" else precision      # the format of this engine's packs / kernels
+        self.exact: Optional["MolEngine"] = MolEngine(spec, weights, "fp32") if precision == "f16x3-exact" else None
         self.shape = spec.to_c(self.precision)
         self._fp32_shape = spec.to_c("fp32")     # for the derived bf16 tables, which are cut from an fp32-format index
         if not self.lib.rails_mol_shape_supported(C.byref(self.shape)):
@@ -538,6 +542,23 @@ def topk(scores: torch.Tensor, k: int, ids: Optional[torch.Tensor] = None, sorte
             "rails_topk",
         )
     return out_s, out_i
+
+
+def rescore_select(exact: torch.Tensor, approx: torch.Tensor, positions: torch.Tensor, ids: Optional[torch.Tensor], n_items: int, k: int,
+                   margin_eps: float, check_eps: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Verified finish of a speculative brute-force top-k (include/rails_amd.h rails_rescore_select): exact (rows, >= kc) fp32,
+    approx / positions (rows, kc) -> (scores (rows, k), ids (rows, k), row_ok (rows,) int32)."""
+    lib = _lib.load()
+    _require_device(exact, "exact scores")
+    rows, kc = positions.shape
+    approx, positions = _f32c(approx), positions.to(torch.int64).contiguous()
+    out_s = torch.empty((rows, k), dtype=torch.float32, device=exact.device)
+    out_i = torch.empty((rows, k), dtype=torch.int64, device=exact.device)
+    ok = torch.empty((rows,), dtype=torch.int32, device=exact.device)
+    with _on_device(exact.device):
+        _lib.check(lib.rails_rescore_select(_ptr(exact), exact.stride(0), _ptr(approx), _ptr(positions), _ptr(ids), n_items, rows, kc, k, margin_eps,
+                                            check_eps, _ptr(out_s), _ptr(out_i), _ptr(ok), _stream()), "rails_rescore_select")
+    return out_s, out_i, ok
 
 
 def pack_candidates(scores: torch.Tensor, ids: torch.Tensor, k: int) -> torch.Tensor:

@@ -203,6 +203,11 @@ def _find(seq: torch.nn.Module, kind) -> List[torch.nn.Module]:
     return [m for m in seq.children() if isinstance(m, kind)] if seq is not None else []
 
 
+def _version(t: torch.Tensor) -> int:
+    # tensors created under torch.inference_mode() carry no version counter (and cannot be modified in place outside it)
+    return 0 if t.is_inference() else t._version
+
+
 class MoLSimilarity(SimilarityModule):
     """Drop-in for reference rails/similarities/mol/similarity_fn.py:204-413 (eval mode)."""
 
@@ -318,11 +323,11 @@ class MoLSimilarity(SimilarityModule):
         plist = self._param_list
         if plist is None:
             plist = self._param_list = [v for _, v in self.state_dict(keep_vars=True).items()]
-        key = (self.precision,) + tuple((v.data_ptr(), v._version) for v in plist)
+        key = (self.precision,) + tuple((v.data_ptr(), _version(v)) for v in plist)
         if self._engine is None or key != self._engine_key:
             params = dict(self.state_dict(keep_vars=True))
             self._param_list = list(params.values())
-            key = (self.precision,) + tuple((v.data_ptr(), v._version) for v in self._param_list)
+            key = (self.precision,) + tuple((v.data_ptr(), _version(v)) for v in self._param_list)
             self._engine = MolEngine(self.shape_spec(), params, precision=self.precision)
             self._engine_key = key
         return self._engine

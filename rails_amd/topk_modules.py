@@ -88,14 +88,88 @@ class MoLTopKModule(TopKModule):
 
 class MoLBruteForceTopK(MoLTopKModule):
     def __init__(self, mol_module: MoLSimilarity, item_embeddings: torch.Tensor, item_ids: torch.Tensor) -> None:
+        self._index32: Optional[E.MolIndex] = None          # precision "f16x3-exact": dense fp32 index (candidate gather, fallback)
+        self._index32_engine = None
+        self.keep_dense_fp32_index: Optional[bool] = self.KEEP_DENSE_FP32_INDEX
+        self.rescore_stats = {"calls": 0, "fallbacks": 0}
         super().__init__(mol_module=mol_module, item_embeddings=item_embeddings, item_ids=item_ids)
 
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self._bind().exact is not None:
+            return self._forward_rescored(query_embeddings, k, **kwargs)
         logits = self._all_logits_scratch(query_embeddings, **kwargs)
         ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(logits.shape[0], logits.shape[1], k), torch.uint8)
         scores, ids = E.topk(logits, k, ids=self._ids_flat, sorted=sorted, workspace=ws)
         return scores.to(query_embeddings.dtype), ids
 
+    # ---- precision "f16x3-exact": speculate with the f16x3 kernels, verify in fp32 ---------------------------------------
+    KEEP_DENSE_FP32_INDEX: Optional[bool] = None   # None: when memory allows; True / False: always / never (candidates' rows are rebuilt)
+    RESCORE_EPS_PER_INV_TEMPERATURE = 5e-5   # eps = this / temperature: 1e-3 on logits in [-20, 20], 30 x the largest
+                                             # |f16x3 - fp32| seen over 22 M pairs (profiles/r02_bench.json fast_path)
+
+    def _forward_rescored(self, query_embeddings: torch.Tensor, k: int, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The fp32 brute-force result -- same scores, same ids, same tie order -- at the f16x3 kernel's speed.
+          1. f16x3 logits s16 over the whole index; the top Kc = k + max(64, k/4) of them (rounded up to whole tiles) are the
+             candidates, m = the smallest candidate's s16.  Every other item has s16 <= m.
+          2. the candidates are gathered from the dense fp32 index (kept next to the f16x3 one when memory allows; otherwise
+             their raw rows go through the fp32 index build) and scored by the fp32 kernel: e32, their exact fp32 logits (the
+             same arithmetic per (query, item) pair as the dense fp32 path, hence the same bits).
+          3. rails_rescore_select: top-k of e32 by (score desc, corpus position asc) -- the dense path's total order.
+        The result is the dense fp32 top-k iff no item outside the candidates can reach the k-th exact score e_k, i.e. iff
+        e_k > m + eps where |s16 - s32| <= eps.  Step 3 checks that inequality per row with the exact e_k, and monitors the
+        error bound itself on the Kc candidates of every query (they must agree to eps / 4); when either fails the call is
+        redone on the dense fp32 index.  One (B x 4)-byte device-to-host copy per call."""
+        eng = self._bind()
+        ex = eng.exact
+        B, N = query_embeddings.size(0), self._index.n_items
+        if k > N:
+            raise RuntimeError(f"selected index k out of range (k={k}, n={N})")
+        kc = (k + max(64, k // 4) + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS
+        if kc >= N or k == 0 or kc > 16384 or N > 0xFFFFFFFF:
+            return self._forward_fp32_dense(query_embeddings, k, **kwargs)
+        s16 = self._all_logits_scratch(query_embeddings, **kwargs)
+        ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(B, N, kc), torch.uint8)
+        c16, pos = E.topk(s16, kc, workspace=ws)
+        if self._index32 is not None:
+            cand, _ = ex.gather_index(self._index32, pos)
+        else:
+            cand = ex.build_index(self._item_embeddings[0].index_select(0, pos.reshape(-1)))
+        qpack32, _, _ = ex.query_pack(query_embeddings, kwargs.get("user_ids"))
+        e32 = ex.score_candidates(qpack32, B, cand, kc)
+        eps = self.RESCORE_EPS_PER_INV_TEMPERATURE / eng.spec.temperature
+        scores, ids, ok = E.rescore_select(e32, c16, pos, self._ids_flat, N, k, eps, 0.25 * eps)
+        self.rescore_stats["calls"] += 1
+        if not bool(ok.all()):
+            self.rescore_stats["fallbacks"] += 1
+            return self._forward_fp32_dense(query_embeddings, k, **kwargs)
+        return scores.to(query_embeddings.dtype), ids
+
+    def _dense_fp32_index(self) -> E.MolIndex:
+        ex = self._engine.exact
+        if self._index32 is None or self._index32_engine is not ex:
+            self._index32, self._index32_engine = ex.build_index(self._item_embeddings[0]), ex
+        return self._index32
+
+    def _forward_fp32_dense(self, query_embeddings: torch.Tensor, k: int, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        ex = self._engine.exact
+        index32 = self._dense_fp32_index()
+        qpack32, _, _ = ex.query_pack(query_embeddings, kwargs.get("user_ids"))
+        scores, ids = E.topk(ex.score_dense(qpack32, query_embeddings.size(0), index32), k, ids=self._ids_flat)
+        return scores.to(query_embeddings.dtype), ids
+
+    def _bind(self) -> E.MolEngine:
+        eng = super()._bind()
+        if eng.exact is not None and self._index32_engine is not eng.exact and self.keep_dense_fp32_index is not False:
+            # precision "f16x3-exact": a dense fp32 index next to the f16x3 one makes the candidates a gather (10 us) instead of
+            # an index build of their raw rows (160 us), and is the fallback's index.  Same bytes again; skipped (None) when
+            # less than twice that is free, or when keep_dense_fp32_index is set to False.
+            need = self._index.buf.numel() * 4
+            free, _ = torch.cuda.mem_get_info(self._item_embeddings.device)
+            self._index32 = None
+            self._index32_engine = eng.exact
+            if self.keep_dense_fp32_index or free > 2 * need:
+                self._index32 = eng.exact.build_index(self._item_embeddings[0])
+        return eng
 
 class MoLAvgTopK(MoLTopKModule):
     """Two-pass approximate top-k (reference rails/indexing/mol_top_k.py:296-429): a bf16 dot product of the

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Step time of MoLBruteForceTopK in precisions fp32 / f16x3 / f16x3-exact through get_top_k_outputs on amzn-books (B = 32, k = 120,
+k' = 200), for `rocprofv3 --kernel-trace --stats` (per-kernel times of the exact path's extra launches) or on its own (wall time).
+  python tools/exact_step_profile.py [--precisions f16x3-exact] [--steps 50]
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import rails_amd  # noqa: E402
+from oracle import mol_oracle as O  # noqa: E402  (input generator only)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--precisions", default="fp32,f16x3,f16x3-exact")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--k", type=int, default=120)
+    ap.add_argument("--width", type=int, default=80)
+    args = ap.parse_args()
+    cfg_key, N, _ = bench.WORKLOADS["amzn-books"]
+    cfg = O.CONFIGS[cfg_key]
+    dev = torch.device("cuda:0")
+    w = O.synthetic_weights(cfg, seed=0)
+    mol, _ = rails_amd.create_mol_interaction_module(
+        cfg.query_embedding_dim, cfg.item_embedding_dim, cfg.dot_product_dimension, cfg.query_dot_product_groups,
+        cfg.item_dot_product_groups, cfg.temperature, 0.0, cfg.query_hidden_dim, 0.1, cfg.item_hidden_dim,
+        cfg.gating_query_hidden_dim, cfg.gating_qi_hidden_dim, cfg.gating_item_hidden_dim, cfg.softmax_dropout_rate, False,
+        query_nonlinearity=cfg.query_nonlinearity, uid_embedding_hash_sizes=list(cfg.uid_embedding_hash_sizes) or None)
+    mol.load_state_dict(w, strict=True)
+    mol = mol.to(dev).eval()
+    X = torch.from_numpy(O.hash_item_table(1, 0, N, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = torch.arange(1, N + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    q = O.synthetic_queries(cfg, args.batch).to(dev)
+    inv = ids[0, torch.randint(0, N, (args.batch, args.width), device=dev)]
+    cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)
+    with torch.inference_mode():
+        for pr in args.precisions.split(","):
+            mol.precision = None if pr == "fp32" else pr
+            tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
+            for _ in range(5):
+                cand.get_top_k_outputs(q, args.k, {}, tk, inv)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                cand.get_top_k_outputs(q, args.k, {}, tk, inv)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / args.steps * 1e3
+            print(f"{pr:12s} {ms:7.3f} ms per step  {args.batch / ms * 1e3:9.1f} queries/s  {getattr(tk, 'rescore_stats', '')}")
+
+
+if __name__ == "__main__":
+    main()
