@@ -250,15 +250,17 @@ int rails_merge_candidates(const int64_t* gathered, int32_t n_ranks, int32_t row
                            float* out_scores, int64_t* out_ids, void* stream);
 
 /* Finish of a speculate-then-verify brute-force top-k (precision "f16x3-exact"; no counterpart in the reference, whose
- * MoLBruteForceTopK scores everything in one precision, mol_top_k.py:84-130).  Per row: n_cand candidates with their exact fp32
- * logits (row stride ld), the approximate logits that selected them and their corpus positions (< n_items <= 2^32), all in the
- * same order.  Writes the top k by (exact score desc, position asc) -- the dense path's total order -- as (scores, ids[position]
- * or the position when ids is NULL), and row_ok[row] = 1 iff  k-th exact score > min approx + margin_eps  and
- * max |exact - approx| <= check_eps  (then no item outside the candidates can belong to the row's top k, given
- * |approx - exact| <= margin_eps everywhere).  n_cand <= 16384. */
-int rails_rescore_select(const float* exact_scores, int64_t ld, const float* approx_scores, const int64_t* positions, const int64_t* ids,
-                         int64_t n_items, int32_t rows, int32_t n_cand, int32_t k, float margin_eps, float check_eps, float* out_scores,
-                         int64_t* out_ids, int32_t* row_ok, void* stream);
+ * MoLBruteForceTopK scores everything in one precision, mol_top_k.py:84-130).  Per row: n_cand entries with their exact fp32
+ * logits (row stride ld) and corpus positions (< n_items <= 2^32).  The first n_ranked are the candidates: the top n_ranked items
+ * by the approximate logits approx_scores (rows, n_ranked), same order.  The rest are probes: arbitrary items whose approximate
+ * logit is read from the dense matrix approx_dense (row stride ld_dense) at their position.
+ * Writes the candidates' top k by (exact score desc, position asc) -- the dense path's total order -- as (scores, ids[position]
+ * or the position when ids is NULL), and row_ok[row] = 1 iff  k-th exact score > min candidate approx + margin_eps  and
+ * |exact - approx| <= check_eps on every candidate and probe  (then no item outside the candidates can belong to the row's
+ * top k, given |approx - exact| <= margin_eps everywhere; the probes watch that bound outside the candidates).  n_cand <= 16384. */
+int rails_rescore_select(const float* exact_scores, int64_t ld, const float* approx_scores, const float* approx_dense, int64_t ld_dense,
+                         const int64_t* positions, const int64_t* ids, int64_t n_items, int32_t rows, int32_t n_ranked, int32_t n_cand,
+                         int32_t k, float margin_eps, float check_eps, float* out_scores, int64_t* out_ids, int32_t* row_ok, void* stream);
 
 /* ---- seen-id filter --------------------------------------------------------------------------
  * Replaces the row-wise masking of CandidateIndex.get_top_k_outputs (indexing/candidate_index.py:154-178):

@@ -904,10 +904,13 @@ int merge_candidates(const int64_t* gathered, int R, int rows, int k, int k_out,
 //   ok[row] = (k-th exact score > min approx + margin_eps)  and  (max |exact - approx| <= check_eps)
 // The first clause means no item outside the candidates (approx <= min approx, exact <= approx + eps) can reach the k-th place;
 // the second monitors the error bound eps on the candidates themselves.  NaNs fail both.  (topk_modules._forward_rescored)
+// Entries [n_ranked, kc) are PROBES: items drawn at random from the whole corpus, re-scored with the candidates.  They only feed
+// the error monitor (their approximate logit is read from the dense matrix at their position); they take no part in the selection.
 __global__ __launch_bounds__(kSortThreads) void rescore_select_kernel(const float* __restrict__ exact, int64_t ld,
                                                                       const float* __restrict__ approx,
+                                                                      const float* __restrict__ approx_dense, int64_t ld_dense,
                                                                       const int64_t* __restrict__ positions,
-                                                                      const int64_t* __restrict__ ids, int kc, int k, int npad,
+                                                                      const int64_t* __restrict__ ids, int n_ranked, int kc, int k, int npad,
                                                                       float margin_eps, float check_eps, float* __restrict__ out_scores,
                                                                       int64_t* __restrict__ out_ids, int* __restrict__ ok) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
@@ -919,9 +922,16 @@ __global__ __launch_bounds__(kSortThreads) void rescore_select_kernel(const floa
   for (int i = threadIdx.x; i < npad; i += kSortThreads) {
     unsigned long long kv = 0ull;
     if (i < kc) {
-      const float e = exact[(int64_t)row * ld + i], a = approx[(int64_t)row * kc + i];
-      kv = ((unsigned long long)orderable(e) << 32) | (unsigned int)(~(unsigned int)positions[(int64_t)row * kc + i]);
-      mn = fminf(mn, a);
+      const float e = exact[(int64_t)row * ld + i];
+      const int64_t pos = positions[(int64_t)row * kc + i];
+      float a;
+      if (i < n_ranked) {
+        a = approx[(int64_t)row * n_ranked + i];
+        kv = ((unsigned long long)orderable(e) << 32) | (unsigned int)(~(unsigned int)pos);
+        mn = fminf(mn, a);
+      } else {
+        a = approx_dense[(int64_t)row * ld_dense + pos];
+      }
       bad |= !(fabsf(e - a) <= check_eps);       // catches NaN as well
     }
     keys[i] = kv;
@@ -960,8 +970,9 @@ __global__ __launch_bounds__(kSortThreads) void rescore_select_kernel(const floa
   }
 }
 
-int rescore_select(const float* exact, int64_t ld, const float* approx, const int64_t* positions, const int64_t* ids, int rows, int kc,
-                   int k, float margin_eps, float check_eps, float* out_scores, int64_t* out_ids, int* ok, hipStream_t stream) {
+int rescore_select(const float* exact, int64_t ld, const float* approx, const float* approx_dense, int64_t ld_dense, const int64_t* positions,
+                   const int64_t* ids, int rows, int n_ranked, int kc, int k, float margin_eps, float check_eps, float* out_scores,
+                   int64_t* out_ids, int* ok, hipStream_t stream) {
   if (rows <= 0) return kOk;
   if (kc > kSortCap) { set_error("rescore_select: %d candidates exceed the in-LDS sort capacity (%d)", kc, kSortCap); return kErrUnsupported; }
   static DynLdsOnce once;
@@ -969,7 +980,7 @@ int rescore_select(const float* exact, int64_t ld, const float* approx, const in
     return kErrLaunch;
   const int npad = next_pow2(kc < 2 ? 2 : kc);
   hipLaunchKernelGGL(rescore_select_kernel, dim3(rows), dim3(kSortThreads), npad * sizeof(unsigned long long), stream, exact, ld, approx,
-                     positions, ids, kc, k, npad, margin_eps, check_eps, out_scores, out_ids, ok);
+                     approx_dense, ld_dense, positions, ids, n_ranked, kc, k, npad, margin_eps, check_eps, out_scores, out_ids, ok);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

@@ -545,19 +545,21 @@ def topk(scores: torch.Tensor, k: int, ids: Optional[torch.Tensor] = None, sorte
 
 
 def rescore_select(exact: torch.Tensor, approx: torch.Tensor, positions: torch.Tensor, ids: Optional[torch.Tensor], n_items: int, k: int,
-                   margin_eps: float, check_eps: float) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """Verified finish of a speculative brute-force top-k (include/rails_amd.h rails_rescore_select): exact (rows, >= kc) fp32,
-    approx / positions (rows, kc) -> (scores (rows, k), ids (rows, k), row_ok (rows,) int32)."""
+                   margin_eps: float, check_eps: float, approx_dense: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Verified finish of a speculative brute-force top-k (include/rails_amd.h rails_rescore_select): exact (rows, >= n_cand) fp32,
+    approx (rows, n_ranked), positions (rows, n_cand >= n_ranked; the tail are probes looked up in approx_dense (rows, n_items))
+    -> (scores (rows, k), ids (rows, k), row_ok (rows,) int32)."""
     lib = _lib.load()
     _require_device(exact, "exact scores")
-    rows, kc = positions.shape
+    rows, n_cand = positions.shape
     approx, positions = _f32c(approx), positions.to(torch.int64).contiguous()
     out_s = torch.empty((rows, k), dtype=torch.float32, device=exact.device)
     out_i = torch.empty((rows, k), dtype=torch.int64, device=exact.device)
     ok = torch.empty((rows,), dtype=torch.int32, device=exact.device)
     with _on_device(exact.device):
-        _lib.check(lib.rails_rescore_select(_ptr(exact), exact.stride(0), _ptr(approx), _ptr(positions), _ptr(ids), n_items, rows, kc, k, margin_eps,
-                                            check_eps, _ptr(out_s), _ptr(out_i), _ptr(ok), _stream()), "rails_rescore_select")
+        _lib.check(lib.rails_rescore_select(_ptr(exact), exact.stride(0), _ptr(approx), _ptr(approx_dense), 0 if approx_dense is None else approx_dense.stride(0),
+                                            _ptr(positions), _ptr(ids), n_items, rows, approx.shape[1], n_cand, k, margin_eps, check_eps,
+                                            _ptr(out_s), _ptr(out_i), _ptr(ok), _stream()), "rails_rescore_select")
     return out_s, out_i, ok
 
 

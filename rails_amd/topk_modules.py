@@ -92,6 +92,11 @@ class MoLBruteForceTopK(MoLTopKModule):
         self._index32_engine = None
         self.keep_dense_fp32_index: Optional[bool] = self.KEEP_DENSE_FP32_INDEX
         self.rescore_stats = {"calls": 0, "fallbacks": 0}
+        self._probe_pool: Optional[torch.Tensor] = None
+        self._ok_host: Optional[torch.Tensor] = None
+        self._side_stream = None
+        self._ok_event = None
+        self._probe_n = -1
         super().__init__(mol_module=mol_module, item_embeddings=item_embeddings, item_ids=item_ids)
 
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -117,8 +122,9 @@ class MoLBruteForceTopK(MoLTopKModule):
           3. rails_rescore_select: top-k of e32 by (score desc, corpus position asc) -- the dense path's total order.
         The result is the dense fp32 top-k iff no item outside the candidates can reach the k-th exact score e_k, i.e. iff
         e_k > m + eps where |s16 - s32| <= eps.  Step 3 checks that inequality per row with the exact e_k, and monitors the
-        error bound itself on the Kc candidates of every query (they must agree to eps / 4); when either fails the call is
-        redone on the dense fp32 index.  One (B x 4)-byte device-to-host copy per call."""
+        error bound itself on every call: on the Kc candidates of every query and on 32 items per query drawn at random from
+        the whole corpus (they must agree to eps / 4).  When either fails the call is redone on the dense fp32 index.
+        One (B x 4)-byte device-to-host copy per call."""
         eng = self._bind()
         ex = eng.exact
         B, N = query_embeddings.size(0), self._index.n_items
@@ -127,22 +133,56 @@ class MoLBruteForceTopK(MoLTopKModule):
         kc = (k + max(64, k // 4) + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS
         if kc >= N or k == 0 or kc > 16384 or N > 0xFFFFFFFF:
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
+        # the fp32 query pack is independent of everything up to the re-scoring: a side stream runs its prologue beside the big kernel
+        dev = query_embeddings.device
+        cur = torch.cuda.current_stream(dev)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=dev)
+        self._side_stream.wait_stream(cur)          # the query is ready; the last call's reader of the pack buffer is done
+        n_q32 = ex.lib.rails_mol_query_pack_floats(E.C.byref(ex.shape), B)
+        with torch.cuda.stream(self._side_stream):
+            qpack32, _, _ = ex.query_pack(query_embeddings, kwargs.get("user_ids"), out=self._buf("qpack32", n_q32, torch.float32))
         s16 = self._all_logits_scratch(query_embeddings, **kwargs)
         ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(B, N, kc), torch.uint8)
         c16, pos = E.topk(s16, kc, workspace=ws)
+        # one more tile per query of probes: items drawn from the whole corpus, re-scored too, so that the bound |s16 - s32| <= eps
+        # is watched outside the candidates as well (a fresh draw of a fixed pool every call)
+        pos = torch.cat([pos, self._probes(B, N)], dim=1)
         if self._index32 is not None:
             cand, _ = ex.gather_index(self._index32, pos)
         else:
             cand = ex.build_index(self._item_embeddings[0].index_select(0, pos.reshape(-1)))
-        qpack32, _, _ = ex.query_pack(query_embeddings, kwargs.get("user_ids"))
-        e32 = ex.score_candidates(qpack32, B, cand, kc)
+        cur.wait_stream(self._side_stream)
+        e32 = ex.score_candidates(qpack32, B, cand, pos.shape[1])
         eps = self.RESCORE_EPS_PER_INV_TEMPERATURE / eng.spec.temperature
-        scores, ids, ok = E.rescore_select(e32, c16, pos, self._ids_flat, N, k, eps, 0.25 * eps)
+        scores, ids, ok = E.rescore_select(e32, c16, pos, self._ids_flat, N, k, eps, 0.25 * eps, approx_dense=s16)
         self.rescore_stats["calls"] += 1
-        if not bool(ok.all()):
+        if not self._all_rows_ok(ok):
             self.rescore_stats["fallbacks"] += 1
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
         return scores.to(query_embeddings.dtype), ids
+
+    def _all_rows_ok(self, ok: torch.Tensor) -> bool:
+        """Read the per-row verdicts on the host: an async copy into pinned memory and a spin on its event.  (`bool(ok.all())`
+        parks the thread on an interrupt-driven wait whose wake-up cost 0.1-0.5 ms per call here; the result is due in microseconds.)"""
+        B = ok.shape[0]
+        if self._ok_host is None or self._ok_host.shape[0] < B:
+            self._ok_host = torch.empty(max(B, 64), dtype=torch.int32).pin_memory()
+            self._ok_event = torch.cuda.Event()
+        self._ok_host[:B].copy_(ok, non_blocking=True)
+        self._ok_event.record()
+        while not self._ok_event.query():
+            pass
+        return bool(self._ok_host[:B].all())
+
+    def _probes(self, B: int, N: int) -> torch.Tensor:
+        """(B, 32) random corpus positions: row block (call number mod 64) of a pool drawn once per (B, N)."""
+        pool = self._probe_pool
+        if pool is None or pool.shape[1] != B or self._probe_n != N:
+            g = torch.Generator(device=self._item_embeddings.device).manual_seed(0x5EED)
+            pool = self._probe_pool = torch.randint(0, N, (64, B, E.TILE_ITEMS), generator=g, device=self._item_embeddings.device, dtype=torch.int64)
+            self._probe_n = N
+        return pool[self.rescore_stats["calls"] % 64]
 
     def _dense_fp32_index(self) -> E.MolIndex:
         ex = self._engine.exact

@@ -1026,3 +1026,36 @@ def test_f16x3_exact_ties_and_forced_fallback(dev):
         assert tk2._index32 is None
         s, i = tk2(q, k=204)
         assert torch.equal(s, r_s) and torch.equal(i, r_i) and tk2.rescore_stats["calls"] == 1
+
+
+def test_rescore_select_kernel_against_a_host_restatement(dev):
+    """rails_rescore_select on synthetic rows: order (exact desc, position asc) with real ties, id map, and the verdict's
+    clauses one by one (margin, candidate mismatch, probe mismatch, NaN)."""
+    g = torch.Generator().manual_seed(5)
+    rows, n_ranked, n_probe, k, N = 6, 96, 32, 40, 5000
+    pos = torch.stack([torch.randperm(N, generator=g)[: n_ranked + n_probe] for _ in range(rows)])
+    exact = torch.randn(rows, n_ranked + n_probe, generator=g).mul(3).round(decimals=1)     # many exact ties
+    approx_c = exact[:, :n_ranked] + (torch.rand(rows, n_ranked, generator=g) - 0.5) * 1e-4
+    dense = torch.zeros(rows, N)
+    dense.scatter_(1, pos, exact + (torch.rand(rows, n_ranked + n_probe, generator=g) - 0.5) * 1e-4)
+    ids = torch.arange(N) * 7 + 3
+    margin, check = 1e-3, 2.5e-4
+    # rows: 0 plain ok; 1 margin too small (k-th exact == min approx); 2 one candidate off by 1e-3; 3 one probe off; 4 a NaN; 5 ok
+    approx_c[1] = approx_c[1].clamp_min(float(exact[1, :n_ranked].topk(k).values[-1]))
+    approx_c[2, 17] += 1e-3
+    dense[3, pos[3, n_ranked + 5]] += 1e-3
+    exact[4, 3] = float("nan")
+    approx_c[0] -= 20.0; dense[0] -= 20.0; approx_c[5] -= 20.0; dense[5] -= 20.0     # rows 0, 5: wide margin ...
+    check_big = 25.0                                                                  # ... checked with their own tolerance below
+    def run(chk):
+        return E.rescore_select(exact.to(dev), approx_c.to(dev), pos.to(dev), ids.to(dev), N, k, margin, chk, approx_dense=dense.to(dev))
+    s, i, ok = run(check)
+    assert ok.cpu().tolist() == [0, 0, 0, 0, 0, 0]           # rows 0 / 5 fail the monitor (shifted by 20), the others by construction
+    s, i, ok = run(check_big)
+    assert ok.cpu().tolist() == [1, 0, 1, 1, 0, 1]           # with a loose monitor only the margin (1) and the NaN (4) rows fail
+    for r in (0, 2, 3, 5):
+        e, p = exact[r, :n_ranked], pos[r, :n_ranked]
+        order = sorted(range(n_ranked), key=lambda j: (-float(e[j]), int(p[j])))[:k]
+        assert torch.equal(s[r].cpu(), e[order]) and torch.equal(i[r].cpu(), ids[p[order]])
+    s2, i2, _ = E.rescore_select(exact.to(dev), approx_c.to(dev), pos.to(dev), None, N, k, margin, check_big, approx_dense=dense.to(dev))
+    assert torch.equal(i2[5].cpu(), (i[5].cpu() - 3) // 7)    # ids = None -> positions
