@@ -175,6 +175,15 @@ class MolIndex:
         self.buf = buf
         self.n_items = n_items
 
+    def items(self, lo: int, hi: int) -> "MolIndex":
+        """The sub-index of items [lo, hi) as a view (lo must be a tile boundary: tiles are stored back to back)."""
+        if lo % TILE_ITEMS != 0 or not 0 <= lo <= hi <= self.n_items:
+            raise ValueError(f"sub-index [{lo}, {hi}) must start on a {TILE_ITEMS}-item tile boundary inside [0, {self.n_items}]")
+        tiles = (self.n_items + TILE_ITEMS - 1) // TILE_ITEMS
+        tile_floats = self.buf.numel() // max(tiles, 1)
+        t0, t1 = lo // TILE_ITEMS, (hi + TILE_ITEMS - 1) // TILE_ITEMS
+        return MolIndex(self.buf[t0 * tile_floats : t1 * tile_floats], hi - lo)
+
 
 class MolEngine:
     """One MoL module's weights bound to the HIP kernels."""

@@ -102,10 +102,37 @@ class MoLBruteForceTopK(MoLTopKModule):
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
         if self._bind().exact is not None:
             return self._forward_rescored(query_embeddings, k, **kwargs)
+        if query_embeddings.size(0) * self._index.n_items * 4 > self.MAX_LOGIT_BYTES and k <= self.CHUNK_ITEMS:
+            return self._forward_chunked(query_embeddings, k, **kwargs)
         logits = self._all_logits_scratch(query_embeddings, **kwargs)
         ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(logits.shape[0], logits.shape[1], k), torch.uint8)
         scores, ids = E.topk(logits, k, ids=self._ids_flat, sorted=sorted, workspace=ws)
         return scores.to(query_embeddings.dtype), ids
+
+    MAX_LOGIT_BYTES = 4 << 30      # larger (B, N) logit matrices are never materialised: the corpus is scored in chunks
+    CHUNK_ITEMS = 1 << 23          # 8 Mi items per chunk (a multiple of the tile): 1 GiB of logits at B = 32
+
+    def _forward_chunked(self, query_embeddings: torch.Tensor, k: int, _engine=None, _index=None, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Exact top-k of a corpus whose (B, N) logits would not fit comfortably (a 125 M-item shard at B = 32 is 16 GB): score
+        CHUNK_ITEMS at a time into one recycled buffer, keep each chunk's top-k, merge.  Same result as the one-pass path bit for
+        bit: chunks are position ranges in order and every list is sorted (score desc, position asc), so the final top-k over
+        the chunk-major concatenation breaks ties by position as well (the item-sharded merge's argument, rails_amd/sharded.py)."""
+        eng = _engine if _engine is not None else self._bind()
+        index = _index if _index is not None else self._index
+        B, N, C = query_embeddings.size(0), index.n_items, self.CHUNK_ITEMS
+        n_q = eng.lib.rails_mol_query_pack_floats(E.C.byref(eng.shape), B)
+        qpack, _, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"), out=self._buf("qpack", n_q, torch.float32))
+        buf = self._buf("logits_chunk", B * min(C, N), torch.float32)
+        ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(B, min(C, N), min(k, C)), torch.uint8)
+        part_s, part_p = [], []
+        for lo in range(0, N, C):
+            n = min(C, N - lo)
+            logits = eng.score_dense(qpack, B, index.items(lo, lo + n), out=buf[: B * n].view(B, n))
+            s, p = E.topk(logits, min(k, n), workspace=ws)
+            part_s.append(s)
+            part_p.append(p + lo)
+        scores, pos = E.topk(torch.cat(part_s, 1), k, ids=torch.cat(part_p, 1))
+        return scores.to(query_embeddings.dtype), self._ids_flat[pos]
 
     # ---- precision "f16x3-exact": speculate with the f16x3 kernels, verify in fp32 ---------------------------------------
     KEEP_DENSE_FP32_INDEX: Optional[bool] = None   # None: when memory allows; True / False: always / never (candidates' rows are rebuilt)
@@ -133,6 +160,8 @@ class MoLBruteForceTopK(MoLTopKModule):
         kc = (k + max(64, k // 4) + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS
         if kc >= N or k == 0 or kc > 16384 or N > 0xFFFFFFFF:
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
+        if B * N * 4 > self.MAX_LOGIT_BYTES:      # the speculative pass wants the whole s16 matrix; beyond the limit: fp32, in chunks
+            return self._forward_chunked(query_embeddings, k, _engine=ex, _index=self._dense_fp32_index(), **kwargs)
         # the fp32 query pack is independent of everything up to the re-scoring: a side stream runs its prologue beside the big kernel
         dev = query_embeddings.device
         cur = torch.cuda.current_stream(dev)

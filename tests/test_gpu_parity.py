@@ -1059,3 +1059,28 @@ def test_rescore_select_kernel_against_a_host_restatement(dev):
         assert torch.equal(s[r].cpu(), e[order]) and torch.equal(i[r].cpu(), ids[p[order]])
     s2, i2, _ = E.rescore_select(exact.to(dev), approx_c.to(dev), pos.to(dev), None, N, k, margin, check_big, approx_dense=dense.to(dev))
     assert torch.equal(i2[5].cpu(), (i[5].cpu() - 3) // 7)    # ids = None -> positions
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_chunked_brute_force_equals_the_one_pass_result(dev, precision):
+    """MoLBruteForceTopK never materialises more than MAX_LOGIT_BYTES of logits: above that the corpus is scored in chunks whose
+    top-k lists are merged.  Forced here with small limits (ragged last chunk, k larger than the last chunk, duplicated items so
+    that equal scores straddle chunk boundaries): must equal the one-pass result bit for bit."""
+    cfg = O.CONFIGS["amzn-books"]
+    w = O.synthetic_weights(cfg, seed=6)
+    base = torch.from_numpy(O.hash_item_table(13, 0, 5000, cfg.item_embedding_dim))
+    X = torch.cat([base, base[:3000], base[100:2150]]).unsqueeze(0).to(dev)      # 10 050 items, many exact duplicates
+    N = X.shape[1]
+    ids = (torch.arange(N, dtype=torch.int64, device=dev) * 3 + 7).unsqueeze(0)
+    q = O.synthetic_queries(cfg, 9, seed=23).to(dev)
+    with torch.inference_mode():
+        tk = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, precision), X, ids)
+        r_s, r_i = tk(q, k=300)
+        tk.MAX_LOGIT_BYTES, tk.CHUNK_ITEMS = 1024, 4096          # chunks of 4096, 4096, 1858 items
+        s, i = tk(q, k=300)
+        assert torch.equal(s, r_s) and torch.equal(i, r_i)
+        tk.CHUNK_ITEMS = 320                                     # 32 chunks, the last one (130 items) shorter than k
+        s, i = tk(q, k=300)
+        assert torch.equal(s, r_s) and torch.equal(i, r_i)
+    with pytest.raises(ValueError, match="tile boundary"):
+        tk._index.items(5, 100)
