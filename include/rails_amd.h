@@ -41,9 +41,14 @@ extern "C" {
  *                          fragment it replaces) and every product block costs three f16 MFMAs (lo*hi, hi*lo, hi*hi),
  *                          fp32 accumulate: ~22 significant bits per product, same 1e-4 logit bar, ~3-4x the speed.
  *                          The item index then holds Ex to 22 bits (rails_mol_index_unpack returns hi + lo);
- *                          rails_mol_coarse_build / rails_mol_component_build take an fp32-format index only. */
+ *                          rails_mol_coarse_build / rails_mol_component_build take an fp32-format index only.
+ *   RAILS_PRECISION_F16X1  the F16X3 buffers (same format, interchangeable) scored with the hi * hi product only: plain f16
+ *                          operands, fp32 accumulate, 1.6x the speed of F16X3, logits ~1e-2 off (NOT within the 1e-4 bar).
+ *                          It exists as the first pass of a speculate-then-verify top-k whose candidates are re-scored in
+ *                          fp32 (rails_rescore_select; rails_amd precision "f16-exact"), not as a result-producing mode. */
 #define RAILS_PRECISION_FP32 0
 #define RAILS_PRECISION_F16X3 1
+#define RAILS_PRECISION_F16X1 2
 
 /* rails_mol_shape.gating_combination: how the three gate parts become mixture weights (MoLGatingFn.forward).
  *   GLU_SILU  g = gq * gi + gqi;  w = g * sigmoid(g)      (every shipped config; needs all three parts)
@@ -69,7 +74,7 @@ typedef struct rails_mol_shape {
   int32_t dot_product_l2_norm;        /* 0 | 1 */
   float temperature;                  /* 0.05 */
   float eps;                          /* 1e-6 */
-  int32_t precision;                  /* RAILS_PRECISION_FP32 | RAILS_PRECISION_F16X3 */
+  int32_t precision;                  /* RAILS_PRECISION_FP32 | RAILS_PRECISION_F16X3 | RAILS_PRECISION_F16X1 */
   int32_t item_hidden_dim;            /* > 0: the item projection has a GLU hidden layer of this width (similarity_utils.py:127-143) */
   int32_t item_nonlinearity;          /* RAILS_GEGLU | RAILS_SWIGLU, used when item_hidden_dim > 0 */
   int32_t gating_combination;         /* RAILS_COMBINE_GLU_SILU | RAILS_COMBINE_NONE (similarity_fn.py:175-197) */

@@ -23,6 +23,7 @@ RAILS_SWIGLU = 1
 RAILS_MAX_UID_TABLES = 4
 RAILS_PRECISION_FP32 = 0
 RAILS_PRECISION_F16X3 = 1
+RAILS_PRECISION_F16X1 = 2
 RAILS_COMBINE_GLU_SILU = 0
 RAILS_COMBINE_NONE = 1
 

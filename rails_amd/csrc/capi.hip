@@ -66,8 +66,8 @@ static bool shape_supported(const Shape* s) {
     set_error("gating_combination none is built for the exact-fp32 register-resident kernels only (not f16x3, not 16x16x64)");
     return false;
   }
-  if (s->precision != RAILS_PRECISION_FP32 && s->precision != RAILS_PRECISION_F16X3) {
-    set_error("precision must be RAILS_PRECISION_FP32 or RAILS_PRECISION_F16X3, got %d", s->precision);
+  if (s->precision != RAILS_PRECISION_FP32 && s->precision != RAILS_PRECISION_F16X3 && s->precision != RAILS_PRECISION_F16X1) {
+    set_error("precision must be RAILS_PRECISION_FP32, _F16X3 or _F16X1, got %d", s->precision);
     return false;
   }
   if (is_split(*s) && !s->dot_product_l2_norm) {
@@ -222,6 +222,7 @@ static int score_common(const rails_mol_shape* s, const float* gate_pack, const 
   a.temperature = s->temperature;
   a.rcp_temperature = 1.0f / s->temperature;
   a.split = is_split(*s) ? 1 : 0;
+  a.single = s->precision == RAILS_PRECISION_F16X1 ? 1 : 0;
   a.combine_none = s->gating_combination == RAILS_COMBINE_NONE ? 1 : 0;
   const int r = score_launch(*s, a, cu, (hipStream_t)stream);
   return r == kOk ? r : fail(r, what);

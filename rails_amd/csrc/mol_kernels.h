@@ -40,11 +40,12 @@ struct ScoreArgs {
   float temperature;
   float rcp_temperature;
   int combine_none;     // 1: gating_combination "none": w = gq + gi + gqi (absent parts are stored as zeros), no silu
+  int single;           // 1 (with split): precision F16X1 -- the one-product kernels, which ignore the lo fragments
   int split;            // 1: precision mode f16x3 -- gate pack, query pack and item index hold f16 hi/lo fragments (mol_layout.h)
 };
 
 int pack_gate_weights_split(const Shape& s, const Weights& w, float* wpack, hipStream_t stream);
-inline bool is_split(const Shape& s) { return s.precision == RAILS_PRECISION_F16X3; }
+inline bool is_split(const Shape& s) { return s.precision == RAILS_PRECISION_F16X3 || s.precision == RAILS_PRECISION_F16X1; }
 
 void set_error(const char* fmt, ...);
 
@@ -63,9 +64,11 @@ inline int ensure_dyn_lds(DynLdsOnce& once, const void* fn, int bytes) {
 
 int score_launch(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream);
 int score_launch_f16(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream);
+int score_launch_f16x1(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream);
 bool score_extra_shape(const Shape& s);   // mol_score_extra_shapes.h
 int score_launch_extra(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream);
 int score_launch_f16_extra(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream);
+int score_launch_f16x1_extra(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream);
 bool score_supported(const Shape& s);
 
 int pack_gate_weights(const Shape& s, const Weights& w, float* wpack, hipStream_t stream);

@@ -381,8 +381,9 @@ bool score_supported(const Shape& s) {
 
 int score_launch(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream) {
   if (!score_supported(s)) return kErrUnsupported;
-  if (score_extra_shape(s)) return a.split ? score_launch_f16_extra(s, a, n_cu, stream) : score_launch_extra(s, a, n_cu, stream);
-  if (a.split) return score_launch_f16(s, a, n_cu, stream);
+  if (score_extra_shape(s))
+    return !a.split ? score_launch_extra(s, a, n_cu, stream) : a.single ? score_launch_f16x1_extra(s, a, n_cu, stream) : score_launch_f16_extra(s, a, n_cu, stream);
+  if (a.split) return a.single ? score_launch_f16x1(s, a, n_cu, stream) : score_launch_f16(s, a, n_cu, stream);
 #define MOL_CASE(pq, px, dd)                                                                             \
   if (s.query_dot_product_groups == pq && s.item_dot_product_groups == px && s.dot_product_dimension == dd) \
     return launch_score<pq, px, dd, 128>(a, n_cu, stream);

@@ -1,5 +1,8 @@
 // Launch side of the f16x3 scoring kernels for the shapes with tuned variants (see mol_score_f16_unit.h for the kernel).
 #include "mol_score_f16_unit.h"
+#if RAILS_F16_SINGLE   // the one-product build of this file (mol_score_f16x1*.hip)
+#define score_launch_f16 score_launch_f16x1
+#endif
 
 namespace mol {
 

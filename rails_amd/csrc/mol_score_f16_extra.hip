@@ -1,6 +1,9 @@
 // f16x3 scoring kernels for the shapes of mol_score_extra_shapes.h (direct shell only).
 #include "mol_score_extra_shapes.h"
 #include "mol_score_f16_unit.h"
+#if RAILS_F16_SINGLE   // the one-product build of this file (mol_score_f16x1*.hip)
+#define score_launch_f16_extra score_launch_f16x1_extra
+#endif
 
 namespace mol {
 

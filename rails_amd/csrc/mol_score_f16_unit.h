@@ -27,7 +27,21 @@
 #include "mol_layout.h"
 #include "mol_score_shell.h"
 
+// RAILS_F16_SINGLE = 1 (mol_score_f16x1.hip, mol_score_f16x1_extra.hip): the SAME kernels with the hi * hi product only and no lo
+// halves anywhere -- plain f16 operands, fp32 accumulate: precision RAILS_PRECISION_F16X1, 1.6 x faster than f16x3 and ~1e-2
+// away from the fp32 logits.  It reads the f16x3 packs (index, gate pack, query pack) and ignores their lo fragments.  Not a
+// parity mode: it is the first pass of the speculate-then-verify top-k "f16-exact" (rails_amd/topk_modules.py).  Each build
+// lives in its own inline namespace so that the two sets of template instantiations do not collide at link time.
+#ifndef RAILS_F16_SINGLE
+#define RAILS_F16_SINGLE 0
+#endif
+
 namespace mol {
+#if RAILS_F16_SINGLE
+inline namespace f16x1 {
+#else
+inline namespace f16x3 {
+#endif
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
@@ -98,6 +112,11 @@ __device__ __forceinline__ void split_pair(float x0, float x1, float m1, unsigne
 #endif
   typedef _Float16 h2v __attribute__((ext_vector_type(2)));
   const h2v h = __builtin_bit_cast(h2v, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+#if RAILS_F16_SINGLE
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = 0u;
+  return;
+#endif
   const float l0 = __builtin_fmaf((float)h.x, m1, x0), l1 = __builtin_fmaf((float)h.y, m1, x1);   // v_fma_mix_f32
   hi = __builtin_bit_cast(unsigned, h);
   lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
@@ -205,10 +224,12 @@ __device__ __forceinline__ void gemm1_presplit(f32x16 (&D1)[PX], const h8* __res
     asm volatile("" ::: "memory");   // the requests stay above the MFMAs
 #pragma unroll
     for (int ks = 0; ks < DD / 16; ++ks) {
+#if !RAILS_F16_SINGLE
 #pragma unroll
       for (int m = 0; m < PX; ++m) D1[m] = mfma16(a[2 * ks + 1], b[m][2 * ks], D1[m]);
 #pragma unroll
       for (int m = 0; m < PX; ++m) D1[m] = mfma16(a[2 * ks], b[m][2 * ks + 1], D1[m]);
+#endif
 #pragma unroll
       for (int m = 0; m < PX; ++m) D1[m] = mfma16(a[2 * ks], b[m][2 * ks], D1[m]);
     }
@@ -225,10 +246,12 @@ __device__ __forceinline__ void gemm1_presplit(f32x16 (&D1)[PX], const h8* __res
         bh[m] = tEx[((m0 + m) * (DD / 8) + 2 * ks) * 64 + lane];
         bl[m] = tEx[((m0 + m) * (DD / 8) + 2 * ks + 1) * 64 + lane];
       }
+#if !RAILS_F16_SINGLE
 #pragma unroll
       for (int m = 0; m < MC; ++m) D1[m0 + m] = mfma16(al, bh[m], D1[m0 + m]);
 #pragma unroll
       for (int m = 0; m < MC; ++m) D1[m0 + m] = mfma16(ah, bl[m], D1[m0 + m]);
+#endif
 #pragma unroll
       for (int m = 0; m < MC; ++m) D1[m0 + m] = mfma16(ah, bh[m], D1[m0 + m]);
       // keep the operand fetches of later chunks below this chunk's MFMAs (register pressure)
@@ -366,6 +389,12 @@ template <class S, int I, int R, int NACC, class WF>
 __device__ __forceinline__ void seq_mfma(f32x16 (&acc)[NACC], WSlots<R>& ws, h8 bh, h8 bl, WF&& W) {
   constexpr int sd = S::side(I), pr = S::prod(I), grp = S::group(I), slot = grp % R;
   f32x16& d = acc[S::acc(I)];
+#if RAILS_F16_SINGLE
+  if constexpr (pr == 2) d = mfma16(ws.hi[slot][sd], bh, d);
+  if constexpr (grp + R < S::NGRP) {
+    if constexpr (pr == 2) ws.hi[slot][sd] = W(true, S::frag(grp + R, sd));
+  }
+#else
   if constexpr (pr == 0) d = mfma16(ws.lo[slot][sd], bh, d);
   else if constexpr (pr == 1) d = mfma16(ws.hi[slot][sd], bl, d);
   else d = mfma16(ws.hi[slot][sd], bh, d);
@@ -373,6 +402,7 @@ __device__ __forceinline__ void seq_mfma(f32x16 (&acc)[NACC], WSlots<R>& ws, h8 
     if constexpr (pr == 0) ws.lo[slot][sd] = W(false, S::frag(grp + R, sd));
     if constexpr (pr == 2) ws.hi[slot][sd] = W(true, S::frag(grp + R, sd));
   }
+#endif
 }
 template <class S, int R, class WF>
 __device__ __forceinline__ void seq_begin(WSlots<R>& ws, WF&& W) {
@@ -380,7 +410,9 @@ __device__ __forceinline__ void seq_begin(WSlots<R>& ws, WF&& W) {
   for (int g = 0; g < (R < S::NGRP ? R : S::NGRP); ++g)
 #pragma unroll
     for (int sd = 0; sd < S::GS; ++sd) {
+#if !RAILS_F16_SINGLE
       ws.lo[g][sd] = W(false, S::frag(g, sd));
+#endif
       ws.hi[g][sd] = W(true, S::frag(g, sd));
     }
 }
@@ -695,4 +727,5 @@ struct F16Unit {
   }
 };
 
+}  // inline namespace f16x3 / f16x1
 }  // namespace mol

@@ -16,9 +16,12 @@ import torch
 from . import _lib
 
 TILE_ITEMS = 32
-PRECISIONS = ("fp32", "f16x3", "f16x3-exact")
-# "f16x3-exact": the f16x3 kernels pick candidates, an fp32 companion engine (`MolEngine.exact`) re-scores them, so the
-# brute-force top-k is the fp32 path's result bit for bit (topk_modules.MoLBruteForceTopK); every other use behaves as "f16x3".
+PRECISIONS = ("fp32", "f16x3", "f16x3-exact", "f16-exact", "f16x1")
+# "f16x3-exact" / "f16-exact": the f16x3 / one-product f16 kernels pick candidates, an fp32 companion engine (`MolEngine.exact`)
+# re-scores them, so the brute-force top-k is the fp32 path's result bit for bit (topk_modules.MoLBruteForceTopK).  Every other
+# use of such an engine behaves as "f16x3": the packs are the same, only the dense pass of "f16-exact" runs the one-product kernels.
+# "f16x1": the one-product kernels as they are (logits ~1e-2 off: measurement and tools only, NOT a parity mode).
+_C_PRECISION = {"fp32": _lib.RAILS_PRECISION_FP32, "f16x3": _lib.RAILS_PRECISION_F16X3, "f16x1": _lib.RAILS_PRECISION_F16X1}
 
 
 def default_precision() -> str:
@@ -70,7 +73,7 @@ class MolShapeSpec:
             _lib.RAILS_GEGLU if self.query_nonlinearity == "geglu" else _lib.RAILS_SWIGLU,
             len(self.uid_embedding_hash_sizes), 1 if self.dot_product_l2_norm else 0,
             float(self.temperature), float(self.eps),
-            _lib.RAILS_PRECISION_F16X3 if precision == "f16x3" else _lib.RAILS_PRECISION_FP32,
+            _C_PRECISION[precision],
             int(self.item_hidden_dim), _lib.RAILS_GEGLU if self.item_nonlinearity == "geglu" else _lib.RAILS_SWIGLU,
             _lib.RAILS_COMBINE_NONE if self.gating_combination_type == "none" else _lib.RAILS_COMBINE_GLU_SILU,
             1 if self.gating_query_fn else 0, 1 if self.gating_item_fn else 0,
@@ -194,9 +197,12 @@ class MolEngine:
         precision = precision or default_precision()
         if precision not in PRECISIONS:
             raise ValueError(f"precision must be one of {PRECISIONS}, got {precision!r}")
-        self.precision = "f16x3" if precision == "f16x3-exact" else precision      # the format of this engine's packs / kernels
-        self.exact: Optional["MolEngine"] = MolEngine(spec, weights, "fp32") if precision == "f16x3-exact" else None
+        self.precision = {"f16x3-exact": "f16x3", "f16-exact": "f16x3", "f16x1": "f16x3"}.get(precision, precision)   # format of the packs
+        self.exact: Optional["MolEngine"] = MolEngine(spec, weights, "fp32") if precision.endswith("-exact") else None
         self.shape = spec.to_c(self.precision)
+        # the shape the DENSE pass is launched with: the one-product kernels for "f16-exact" / "f16x1" (same packs, lo halves ignored)
+        self.dense_precision = "f16x1" if precision in ("f16-exact", "f16x1") else self.precision
+        self.dense_shape = spec.to_c(self.dense_precision)
         self._fp32_shape = spec.to_c("fp32")     # for the derived bf16 tables, which are cut from an fp32-format index
         if not self.lib.rails_mol_shape_supported(C.byref(self.shape)):
             raise NotImplementedError(_lib.last_error())
@@ -326,7 +332,7 @@ class MolEngine:
             out = torch.empty((batch, index.n_items), dtype=torch.float32, device=index.buf.device)
         with _on_device(index.buf.device):
             _lib.check(
-                self.lib.rails_mol_score_dense(C.byref(self.shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(index.buf), index.n_items, _ptr(out), out.stride(0), _stream()),
+                self.lib.rails_mol_score_dense(C.byref(self.dense_shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(index.buf), index.n_items, _ptr(out), out.stride(0), _stream()),
                 "rails_mol_score_dense",
             )
         return out

@@ -138,6 +138,9 @@ class MoLBruteForceTopK(MoLTopKModule):
     KEEP_DENSE_FP32_INDEX: Optional[bool] = None   # None: when memory allows; True / False: always / never (candidates' rows are rebuilt)
     RESCORE_EPS_PER_INV_TEMPERATURE = 5e-5   # eps = this / temperature: 1e-3 on logits in [-20, 20], 30 x the largest
                                              # |f16x3 - fp32| seen over 22 M pairs (profiles/r02_bench.json fast_path)
+    # first pass on the one-product f16 kernels ("f16-exact"): |s16 - s32| up to 4.3e-2 on amzn-books, 1.7e-2 on ML-20M
+    # (tools/single_f16_probe.py) -> eps = 0.15 on logits in [-20, 20]; the monitor trips at eps / 2; twice the candidate margin
+    RESCORE_EPS_PER_INV_TEMPERATURE_F16X1 = 7.5e-3
 
     def _forward_rescored(self, query_embeddings: torch.Tensor, k: int, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
         """The fp32 brute-force result -- same scores, same ids, same tie order -- at the f16x3 kernel's speed.
@@ -157,7 +160,8 @@ class MoLBruteForceTopK(MoLTopKModule):
         B, N = query_embeddings.size(0), self._index.n_items
         if k > N:
             raise RuntimeError(f"selected index k out of range (k={k}, n={N})")
-        kc = (k + max(64, k // 4) + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS
+        single = eng.dense_precision == "f16x1"
+        kc = (k + (max(128, k // 2) if single else max(64, k // 4)) + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS
         if kc >= N or k == 0 or kc > 16384 or N > 0xFFFFFFFF:
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
         if B * N * 4 > self.MAX_LOGIT_BYTES:      # the speculative pass wants the whole s16 matrix; beyond the limit: fp32, in chunks
@@ -183,8 +187,8 @@ class MoLBruteForceTopK(MoLTopKModule):
             cand = ex.build_index(self._item_embeddings[0].index_select(0, pos.reshape(-1)))
         cur.wait_stream(self._side_stream)
         e32 = ex.score_candidates(qpack32, B, cand, pos.shape[1])
-        eps = self.RESCORE_EPS_PER_INV_TEMPERATURE / eng.spec.temperature
-        scores, ids, ok = E.rescore_select(e32, c16, pos, self._ids_flat, N, k, eps, 0.25 * eps, approx_dense=s16)
+        eps = (self.RESCORE_EPS_PER_INV_TEMPERATURE_F16X1 if single else self.RESCORE_EPS_PER_INV_TEMPERATURE) / eng.spec.temperature
+        scores, ids, ok = E.rescore_select(e32, c16, pos, self._ids_flat, N, k, eps, (0.5 if single else 0.25) * eps, approx_dense=s16)
         self.rescore_stats["calls"] += 1
         if not self._all_rows_ok(ok):
             self.rescore_stats["fallbacks"] += 1

@@ -969,8 +969,9 @@ def test_glu_layers_standalone_against_the_reference_modules(dev, case):
 # ---- precision "f16x3-exact": f16x3 candidates, fp32 verification -> the fp32 result bit for bit -------------------------
 @pytest.mark.parametrize("workload,N,B,k", [("amzn-books", 695762, 32, 200), ("amzn-books", 100_003, 5, 2561), ("ml-1m", 3649, 8, 120),
                                             ("ml-20m", 26_000, 1, 1), ("amzn-books", 300, 4, 200)])
-def test_f16x3_exact_equals_the_fp32_path_bit_for_bit(dev, workload, N, B, k):
-    """MoLBruteForceTopK in precision "f16x3-exact" == the same module in fp32: scores, ids and tie order, via forward and via
+@pytest.mark.parametrize("mode", ["f16x3-exact", "f16-exact"])
+def test_f16x3_exact_equals_the_fp32_path_bit_for_bit(dev, workload, N, B, k, mode):
+    """MoLBruteForceTopK in precision "f16x3-exact" / "f16-exact" (one-product first pass) == the same module in fp32: scores, ids and tie order, via forward and via
     CandidateIndex.get_top_k_outputs with the seen-id filter.  The last case (N < k + margin) takes the dense fp32 route."""
     cfg = O.CONFIGS[workload]
     w = O.synthetic_weights(cfg, seed=3)
@@ -982,13 +983,14 @@ def test_f16x3_exact_equals_the_fp32_path_bit_for_bit(dev, workload, N, B, k):
     with torch.inference_mode():
         m32 = build_module(cfg, w, dev, None)
         r_s, r_i = rails_amd.MoLBruteForceTopK(m32, X, ids)(q, k=k, **kw)
-        mx = build_module(cfg, w, dev, "f16x3-exact")
+        mx = build_module(cfg, w, dev, mode)
         tk = rails_amd.MoLBruteForceTopK(mx, X, ids)
         for _ in range(2):
             s, i = tk(q, k=k, **kw)
             assert torch.equal(s, r_s) and torch.equal(i, r_i)
         if N > 1000:
-            assert tk.rescore_stats == {"calls": 2, "fallbacks": 0}, tk.rescore_stats
+            assert tk.rescore_stats["calls"] == 2 and (tk.rescore_stats["fallbacks"] == 0 or mode == "f16-exact"), tk.rescore_stats
+            print(mode, workload, N, B, k, tk.rescore_stats)
         inv = ids[0, torch.randint(0, N, (B, 7), device=dev)]
         kk = min(k, 120)
         ci = rails_amd.CandidateIndex(ids, X)
@@ -997,7 +999,8 @@ def test_f16x3_exact_equals_the_fp32_path_bit_for_bit(dev, workload, N, B, k):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
 
 
-def test_f16x3_exact_ties_and_forced_fallback(dev):
+@pytest.mark.parametrize("mode", ["f16x3-exact", "f16-exact"])
+def test_f16x3_exact_ties_and_forced_fallback(dev, mode):
     """Duplicated items tie exactly in fp32 (and may straddle the k-th place): the tie order must still be the dense path's
     (position ascending).  Then the verification is made to fail (eps = inf): the dense fp32 fallback returns the same result."""
     cfg = O.CONFIGS["amzn-books"]
@@ -1009,18 +1012,18 @@ def test_f16x3_exact_ties_and_forced_fallback(dev):
     q = O.synthetic_queries(cfg, 16, seed=22).to(dev)
     with torch.inference_mode():
         r_s, r_i = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, None), X, ids)(q, k=204)
-        tk = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, "f16x3-exact"), X, ids)
+        tk = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, mode), X, ids)
         s, i = tk(q, k=204)
         assert torch.equal(s, r_s) and torch.equal(i, r_i)
         assert bool((r_s[:, 0] == r_s[:, 7]).all())           # the ties are real
-        tk.RESCORE_EPS_PER_INV_TEMPERATURE = float("inf")
+        tk.RESCORE_EPS_PER_INV_TEMPERATURE = tk.RESCORE_EPS_PER_INV_TEMPERATURE_F16X1 = float("inf")
         before = tk.rescore_stats["fallbacks"]
         s, i = tk(q, k=204)
         assert torch.equal(s, r_s) and torch.equal(i, r_i) and tk.rescore_stats["fallbacks"] == before + 1
         # without the dense fp32 index (memory-tight deployments): the candidates' raw rows are rebuilt instead of gathered
         try:
             rails_amd.MoLBruteForceTopK.KEEP_DENSE_FP32_INDEX = False
-            tk2 = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, "f16x3-exact"), X, ids)
+            tk2 = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, mode), X, ids)
         finally:
             rails_amd.MoLBruteForceTopK.KEEP_DENSE_FP32_INDEX = None
         assert tk2._index32 is None

@@ -61,7 +61,7 @@ def _worker(rank: int, world: int, port: int, n_items: int, precision, ret):
             full_s, full_i = rails_amd.MoLBruteForceTopK(mol, X, ids)(q, k=k)
             assert torch.equal(s, s2) and torch.equal(i, i2)
             assert torch.equal(s, full_s) and torch.equal(i, full_i), "sharded exact top-k differs from the single-device result"
-            if precision == "f16x3-exact":   # ... and both are the fp32 path's result, bit for bit
+            if precision in ("f16x3-exact", "f16-exact"):   # ... and both are the fp32 path's result, bit for bit
                 mol32 = build_module(cfg, O.synthetic_weights(cfg, seed=1), dev)
                 f32_s, f32_i = rails_amd.MoLBruteForceTopK(mol32, X, ids)(q, k=k)
                 assert torch.equal(s, f32_s) and torch.equal(i, f32_i), "f16x3-exact sharded top-k differs from the fp32 path"
@@ -85,7 +85,7 @@ def _worker(rank: int, world: int, port: int, n_items: int, precision, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("precision", [None, "f16x3", "f16x3-exact"])
+@pytest.mark.parametrize("precision", [None, "f16x3", "f16x3-exact", "f16-exact"])
 @pytest.mark.parametrize("n_items", [70_001, 331])   # second case: the last shard is shorter than k
 def test_two_ranks_through_the_hip_modules(n_items, precision):
     world = 2

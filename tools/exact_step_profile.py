@@ -19,7 +19,7 @@ from oracle import mol_oracle as O  # noqa: E402  (input generator only)
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--precisions", default="fp32,f16x3,f16x3-exact")
+    ap.add_argument("--precisions", default="fp32,f16x3,f16x3-exact,f16-exact")
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--k", type=int, default=120)
