@@ -4,6 +4,10 @@
 #define score_launch_f16 score_launch_f16x1
 #endif
 
+#ifndef RAILS_F16_TIGHT_LIMIT
+#define RAILS_F16_TIGHT_LIMIT 200   // accumulator registers of a unit above which the 8-wave build takes the TIGHT stream
+#endif
+
 namespace mol {
 
 // RAILS_F16_OVERLAP=0 disables the cross-query overlap of stage X (measurement override)
@@ -17,7 +21,7 @@ static int launch_f16(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using G = Geo<PQ, PX, DD, H>;
   // two waves per SIMD leave 256 registers per lane: when the accumulators of a unit (D1, D2, D3) take most of them, the
   // untied stream without cross-query overlap is the one that does not spill
-  constexpr bool tight = (PX + G::TH + G::TL) * 16 > 200;
+  constexpr bool tight = (PX + G::TH + G::TL) * 16 > RAILS_F16_TIGHT_LIMIT;
   using U8 = std::conditional_t<tight, F16Unit<false, true>, F16Unit<OVL, false>>;
   using U4 = F16Unit<OVL, false>;
   const int variant = choose_variant<PQ, PX, DD, H>(a, n_cu);

@@ -5,12 +5,16 @@
 #define score_launch_f16_extra score_launch_f16x1_extra
 #endif
 
+#ifndef RAILS_F16_TIGHT_LIMIT
+#define RAILS_F16_TIGHT_LIMIT 200   // accumulator registers of a unit above which the 8-wave build takes the TIGHT stream
+#endif
+
 namespace mol {
 
 template <int PQ, int PX, int DD, int H>
 static int launch_f16_extra(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using G = Geo<PQ, PX, DD, H>;
-  constexpr bool tight = (PX + G::TH + G::TL) * 16 > 200;   // as in mol_score_f16.hip
+  constexpr bool tight = (PX + G::TH + G::TL) * 16 > RAILS_F16_TIGHT_LIMIT;   // as in mol_score_f16.hip
   using U = std::conditional_t<tight, F16Unit<false, true>, F16Unit<true, false>>;
   return launch_kernel<U, PQ, PX, DD, H, 8, false>(a, n_cu, stream);
 }
