@@ -219,6 +219,10 @@ def quick_workload(name: str, B: int, k: int, kp: int, steps: int, dev, items: i
         torch.cuda.synchronize()
         score_ms = e0.elapsed_time(e1) / steps   # prologue + scoring kernel
     tf = B * N * flops_per_pair(cfg) / (score_ms * 1e-3) / 1e12
+    if precision.endswith("-exact"):   # verified fast mode: output identical to fp32 (tests); the first pass is not a parity kernel, no roofline claim
+        return {"workload": f"{name} {cfg.query_dot_product_groups}x{cfg.item_dot_product_groups}x{cfg.dot_product_dimension}, N={N}", "precision": precision,
+                "queries_per_s": B / dt, "ms_per_step": dt * 1e3, "prologue_plus_first_pass_ms": score_ms,
+                "rescore_calls": tk.rescore_stats["calls"], "dense_fp32_fallbacks": tk.rescore_stats["fallbacks"]}
     return {"workload": f"{name} {cfg.query_dot_product_groups}x{cfg.item_dot_product_groups}x{cfg.dot_product_dimension}, N={N}", "precision": precision,
             "queries_per_s": B / dt, "ms_per_step": dt * 1e3, "prologue_plus_scoring_ms": score_ms,
             "scoring_tflops_algorithmic_lower_bound": tf,
@@ -607,9 +611,9 @@ def main() -> None:
             out["matrix"] = measurement_matrix(mol, X, ids, q, kw, inv, cfg, hi - lo, min(args.steps, 10), dev)
         if world == 1 and args.workload == "amzn-books" and not args.no_other_workloads:
             # the two smaller real-dataset shapes of BASELINE.json (configs 1 and 2): fixed per-batch costs dominate there
-            out["other_workloads"] = [quick_workload(n, B, k, kp, 10, dev, precision=pr) for n in ("ml-20m", "ml-1m") for pr in ("fp32", "f16x3")]
+            out["other_workloads"] = [quick_workload(n, B, k, kp, 10, dev, precision=pr) for n in ("ml-20m", "ml-1m") for pr in ("fp32", "f16x3", "f16-exact")]
             # BASELINE config 4 (16x16x64, 100 M items 8-way): a 400 k-item sub-range of one shard -- the kernels are linear in N
-            out["other_workloads"] += [quick_workload("synthetic-16x16x64", B, k, kp, 5, dev, items=400_000, precision=pr) for pr in ("fp32", "f16x3")]
+            out["other_workloads"] += [quick_workload("synthetic-16x16x64", B, k, kp, 5, dev, items=400_000, precision=pr) for pr in ("fp32", "f16x3", "f16-exact")]
         if world == 1 and not args.no_cpu_baseline and not two_pass:   # the CPU baseline is the exact path
             out["cpu_baseline"] = cpu_baseline(cfg, weights, q_cpu, uid_cpu, N, min(args.cpu_sample_items or N, N), kp)
         print(json.dumps(out), flush=True)

@@ -95,6 +95,8 @@ class MoLBruteForceTopK(MoLTopKModule):
         self._probe_pool: Optional[torch.Tensor] = None
         self._ok_host: Optional[torch.Tensor] = None
         self._side_stream = None
+        self._recent: list = []       # verdicts of the last speculative calls
+        self._pause_left = 0
         self._ok_event = None
         self._probe_n = -1
         super().__init__(mol_module=mol_module, item_embeddings=item_embeddings, item_ids=item_ids)
@@ -162,7 +164,7 @@ class MoLBruteForceTopK(MoLTopKModule):
             raise RuntimeError(f"selected index k out of range (k={k}, n={N})")
         single = eng.dense_precision == "f16x1"
         kc = (k + (max(128, k // 2) if single else max(64, k // 4)) + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS
-        if kc >= N or k == 0 or kc > 16384 or N > 0xFFFFFFFF:
+        if kc >= N or k == 0 or kc > 16384 or N > 0xFFFFFFFF or N < self.SPECULATE_MIN_ITEMS or self._speculation_paused():
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
         if B * N * 4 > self.MAX_LOGIT_BYTES:      # the speculative pass wants the whole s16 matrix; beyond the limit: fp32, in chunks
             return self._forward_chunked(query_embeddings, k, _engine=ex, _index=self._dense_fp32_index(), **kwargs)
@@ -190,10 +192,30 @@ class MoLBruteForceTopK(MoLTopKModule):
         eps = (self.RESCORE_EPS_PER_INV_TEMPERATURE_F16X1 if single else self.RESCORE_EPS_PER_INV_TEMPERATURE) / eng.spec.temperature
         scores, ids, ok = E.rescore_select(e32, c16, pos, self._ids_flat, N, k, eps, (0.5 if single else 0.25) * eps, approx_dense=s16)
         self.rescore_stats["calls"] += 1
-        if not self._all_rows_ok(ok):
+        good = self._all_rows_ok(ok)
+        self._recent.append(good)
+        if not good:
             self.rescore_stats["fallbacks"] += 1
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
         return scores.to(query_embeddings.dtype), ids
+
+    # Speculation pays on large corpora only: below SPECULATE_MIN_ITEMS the fixed cost of the verification (~0.15 ms) exceeds what
+    # the faster first pass saves (ML-20M, 27 278 items: fp32 step 0.27 ms), so the exact modes run the dense fp32 kernels there.
+    # It also needs scores that are not crowded around the k-th place: when more than a quarter of the last 16 speculative calls
+    # had to be redone, the next 256 calls go straight to the dense fp32 path, then speculation is tried again.
+    SPECULATE_MIN_ITEMS = 1 << 16
+
+    def _speculation_paused(self) -> bool:
+        if self._pause_left == 0 and len(self._recent) >= 16:
+            bad = self._recent.count(False)
+            self._recent.clear()
+            if bad > 4:
+                self._pause_left = 256
+        if self._pause_left > 0:
+            self._pause_left -= 1
+            self.rescore_stats["paused_calls"] = self.rescore_stats.get("paused_calls", 0) + 1
+            return True
+        return False
 
     def _all_rows_ok(self, ok: torch.Tensor) -> bool:
         """Read the per-row verdicts on the host: an async copy into pinned memory and a spin on its event.  (`bool(ok.all())`

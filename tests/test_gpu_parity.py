@@ -985,6 +985,7 @@ def test_f16x3_exact_equals_the_fp32_path_bit_for_bit(dev, workload, N, B, k, mo
         r_s, r_i = rails_amd.MoLBruteForceTopK(m32, X, ids)(q, k=k, **kw)
         mx = build_module(cfg, w, dev, mode)
         tk = rails_amd.MoLBruteForceTopK(mx, X, ids)
+        tk.SPECULATE_MIN_ITEMS = 0          # exercise the speculative route on the small corpora as well
         for _ in range(2):
             s, i = tk(q, k=k, **kw)
             assert torch.equal(s, r_s) and torch.equal(i, r_i)
@@ -1013,6 +1014,7 @@ def test_f16x3_exact_ties_and_forced_fallback(dev, mode):
     with torch.inference_mode():
         r_s, r_i = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, None), X, ids)(q, k=204)
         tk = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, mode), X, ids)
+        tk.SPECULATE_MIN_ITEMS = 0
         s, i = tk(q, k=204)
         assert torch.equal(s, r_s) and torch.equal(i, r_i)
         assert bool((r_s[:, 0] == r_s[:, 7]).all())           # the ties are real
@@ -1027,6 +1029,7 @@ def test_f16x3_exact_ties_and_forced_fallback(dev, mode):
         finally:
             rails_amd.MoLBruteForceTopK.KEEP_DENSE_FP32_INDEX = None
         assert tk2._index32 is None
+        tk2.SPECULATE_MIN_ITEMS = 0
         s, i = tk2(q, k=204)
         assert torch.equal(s, r_s) and torch.equal(i, r_i) and tk2.rescore_stats["calls"] == 1
 
@@ -1087,3 +1090,25 @@ def test_chunked_brute_force_equals_the_one_pass_result(dev, precision):
         assert torch.equal(s, r_s) and torch.equal(i, r_i)
     with pytest.raises(ValueError, match="tile boundary"):
         tk._index.items(5, 100)
+
+
+def test_exact_modes_speculate_only_where_it_pays(dev):
+    """Policy of the verified fast modes: corpora below SPECULATE_MIN_ITEMS take the dense fp32 kernels at once; a run of failed
+    verifications pauses the speculation (dense fp32 for the next 256 calls).  The result is the fp32 result throughout."""
+    cfg = O.CONFIGS["amzn-books"]
+    w = O.synthetic_weights(cfg, seed=8)
+    N = 20_000
+    X = torch.from_numpy(O.hash_item_table(14, 0, N, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = torch.arange(1, N + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    q = O.synthetic_queries(cfg, 4, seed=24).to(dev)
+    with torch.inference_mode():
+        r_s, r_i = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, None), X, ids)(q, k=50)
+        tk = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, "f16-exact"), X, ids)
+        s, i = tk(q, k=50)
+        assert torch.equal(s, r_s) and torch.equal(i, r_i) and tk.rescore_stats["calls"] == 0      # 20 000 items: dense fp32
+        tk.SPECULATE_MIN_ITEMS = 0
+        tk.RESCORE_EPS_PER_INV_TEMPERATURE_F16X1 = float("inf")                                     # every verification fails
+        for _ in range(20):
+            s, i = tk(q, k=50)
+            assert torch.equal(s, r_s) and torch.equal(i, r_i)
+        assert tk.rescore_stats["calls"] == 16 and tk.rescore_stats["fallbacks"] == 16 and tk.rescore_stats["paused_calls"] == 4

@@ -35,6 +35,7 @@ def _worker(rank: int, world: int, port: int, n_items: int, precision, ret):
     from rails_amd.sharded import ShardedMoLAvgTopK, ShardedMoLBruteForceTopK, shard_bounds
     from tests.test_gpu_parity import build_module
 
+    rails_amd.MoLBruteForceTopK.SPECULATE_MIN_ITEMS = 0     # the shards are small: keep the verified modes on their speculative route
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     multi = torch.cuda.device_count() >= world

@@ -5,6 +5,7 @@
 //      without a workgroup barrier every few phases (the per-tile barrier of the staged kernel)?
 // hipcc --offload-arch=gfx950 -O3 tools/ubench_f16_coexec.hip -o tools/ubench_f16_coexec
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdio.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -34,9 +35,10 @@ __global__ void denorm_kernel(float* out) {
 }
 
 // ---- (2) one VALU kind next to MFMAs ---------------------------------------------------------------------------
-enum { K_FMA, K_PKFMA, K_EXP, K_RCP, K_CVTPK, K_MIX, K_MIXLO, K_PKMUL, K_PKADD, K_MIN3, K_LDS128, K_COUNT };
+enum { K_FMA, K_PKFMA, K_EXP, K_RCP, K_CVTPK, K_MIX, K_MIXLO, K_PKMUL, K_PKADD, K_MIN3, K_LDS128, K_PKFMA16, K_PKMUL16, K_PKMAX16, K_EXP16, K_RCP16, K_DOT2, K_COUNT };
 static const char* kNames[K_COUNT] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_rcp_f32", "v_cvt_pkrtz", "v_fma_mix_f32",
-                                      "v_fma_mixlo_f16", "v_pk_mul_f32", "v_pk_add_f32", "v_min3_f32", "ds_read_b128"};
+                                      "v_fma_mixlo_f16", "v_pk_mul_f32", "v_pk_add_f32", "v_min3_f32", "ds_read_b128",
+                                      "v_pk_fma_f16", "v_pk_mul_f16", "v_pk_max_f16", "v_exp_f16", "v_rcp_f16", "v_dot2_f32_f16"};
 
 template <int KIND>
 __device__ __forceinline__ void valu(float (&v)[16], f32x2 (&w)[8], int j, const float4* lds, float4 (&ld)[4]) {
@@ -53,6 +55,12 @@ __device__ __forceinline__ void valu(float (&v)[16], f32x2 (&w)[8], int j, const
   else if constexpr (KIND == K_PKADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(y) : "v"(w[(j + 3) % 8]));
   else if constexpr (KIND == K_MIN3) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(x) : "v"(v[(j + 5) % 16]), "v"(v[(j + 9) % 16]));
   else if constexpr (KIND == K_LDS128) ld[j % 4] = lds[(j * 64 + threadIdx.x) & 1023];
+  else if constexpr (KIND == K_PKFMA16) asm volatile("v_pk_fma_f16 %0, %0, %1, %2" : "+v"(x) : "v"(v[(j + 5) % 16]), "v"(v[(j + 9) % 16]));
+  else if constexpr (KIND == K_PKMUL16) asm volatile("v_pk_mul_f16 %0, %0, %1" : "+v"(x) : "v"(v[(j + 5) % 16]));
+  else if constexpr (KIND == K_PKMAX16) asm volatile("v_pk_max_f16 %0, %0, %1" : "+v"(x) : "v"(v[(j + 5) % 16]));
+  else if constexpr (KIND == K_EXP16) asm volatile("v_exp_f16 %0, %0" : "+v"(x));
+  else if constexpr (KIND == K_RCP16) asm volatile("v_rcp_f16 %0, %0" : "+v"(x));
+  else if constexpr (KIND == K_DOT2) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(x) : "v"(v[(j + 5) % 16]), "v"(v[(j + 9) % 16]));
 }
 
 template <int KIND, int NV>
@@ -235,6 +243,8 @@ int main() {
          (unsigned)h[1], (unsigned)h[2], (unsigned)h[3]);
   sweep<K_FMA>(d); sweep<K_PKFMA>(d); sweep<K_EXP>(d); sweep<K_RCP>(d); sweep<K_CVTPK>(d); sweep<K_MIX>(d); sweep<K_MIXLO>(d);
   sweep<K_PKMUL>(d); sweep<K_PKADD>(d); sweep<K_MIN3>(d); sweep<K_LDS128>(d);
+  sweep<K_PKFMA16>(d); sweep<K_PKMUL16>(d); sweep<K_PKMAX16>(d); sweep<K_EXP16>(d); sweep<K_RCP16>(d); sweep<K_DOT2>(d);
+  if (getenv("UBENCH_SWEEPS_ONLY")) { hipFree(d); return 0; }
   for (int w = 1; w <= 2; ++w) {
     run_phase<48, 384, 0, 0>(w, d);
     run_phase<48, 384, 4, 0>(w, d);
