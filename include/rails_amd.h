@@ -155,6 +155,12 @@ size_t rails_mol_query_pack_floats(const rails_mol_shape* shape, int32_t batch);
 int rails_mol_query_prologue(const rails_mol_shape* shape, const rails_mol_weights* w, const float* queries,
                              const int64_t* user_ids, int32_t batch, float* query_pack, float* eq_out,
                              float* gq_out, void* stream);
+/* The same launch(es), writing the pack TWICE: query_pack in shape->precision's format and query_pack_other in the other
+ * one (fp32 fragments <-> f16 hi/lo fragments; same values, rails_mol_query_pack_floats floats each).  For callers that score
+ * one batch in two precisions (the verified fast modes: f16 first pass, fp32 re-scoring of the candidates). */
+int rails_mol_query_prologue_both(const rails_mol_shape* shape, const rails_mol_weights* w, const float* queries,
+                                  const int64_t* user_ids, int32_t batch, float* query_pack, float* query_pack_other,
+                                  void* stream);
 
 /* ---- scoring ---------------------------------------------------------------------------------
  * Replaces MoLSimilarity.forward for the shared-corpus case (similarity_fn.py:341-413, B' == 1):

@@ -101,6 +101,10 @@ PROTOTYPES = {
         C.c_int,
         [_SHAPE_P, _WEIGHTS_P, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     ),
+    "rails_mol_query_prologue_both": (
+        C.c_int,
+        [_SHAPE_P, _WEIGHTS_P, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p],
+    ),
     "rails_mol_score_dense": (
         C.c_int,
         [_SHAPE_P, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p],

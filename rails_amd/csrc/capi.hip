@@ -173,9 +173,24 @@ size_t rails_mol_query_pack_floats(const rails_mol_shape* s, int32_t batch) {
          query_scratch_floats(*s, batch);   // + the prologue's own scratch rows (GLU output, first gate layer)
 }
 
+static int query_prologue_checked(const rails_mol_shape* s, const rails_mol_weights* w, const float* queries, const int64_t* user_ids,
+                                  int32_t batch, float* query_pack, float* query_pack_other, float* eq_out, float* gq_out, void* stream);
+
 int rails_mol_query_prologue(const rails_mol_shape* s, const rails_mol_weights* w, const float* queries,
                              const int64_t* user_ids, int32_t batch, float* query_pack, float* eq_out, float* gq_out,
                              void* stream) {
+  return query_prologue_checked(s, w, queries, user_ids, batch, query_pack, nullptr, eq_out, gq_out, stream);
+}
+
+int rails_mol_query_prologue_both(const rails_mol_shape* s, const rails_mol_weights* w, const float* queries,
+                                  const int64_t* user_ids, int32_t batch, float* query_pack, float* query_pack_other,
+                                  void* stream) {
+  if (!query_pack_other) { g_err[0] = '\0'; set_error("query_prologue_both: NULL pointer"); return RAILS_EINVAL; }
+  return query_prologue_checked(s, w, queries, user_ids, batch, query_pack, query_pack_other, nullptr, nullptr, stream);
+}
+
+static int query_prologue_checked(const rails_mol_shape* s, const rails_mol_weights* w, const float* queries, const int64_t* user_ids,
+                                  int32_t batch, float* query_pack, float* query_pack_other, float* eq_out, float* gq_out, void* stream) {
   g_err[0] = '\0';
   if (!shape_supported(s)) return RAILS_ENOTSUP;
   if (batch < 0) { set_error("query_prologue: batch < 0"); return RAILS_EINVAL; }
@@ -190,7 +205,7 @@ int rails_mol_query_prologue(const rails_mol_shape* s, const rails_mol_weights* 
     for (int t = 0; t < s->num_uid_tables; ++t)
       if (!w->uid_table[t] || w->uid_hash_size[t] <= 0) { set_error("query_prologue: uid table %d missing", t); return RAILS_EINVAL; }
   }
-  return fail(query_prologue(*s, *w, queries, user_ids, batch, query_pack, eq_out, gq_out, (hipStream_t)stream),
+  return fail(query_prologue(*s, *w, queries, user_ids, batch, query_pack, eq_out, gq_out, (hipStream_t)stream, query_pack_other),
               "query_prologue");
 }
 

@@ -80,7 +80,7 @@ int index_gather(const Shape& s, const float* ipack, int64_t n, const int64_t* i
                  float* out, hipStream_t stream);
 size_t query_scratch_floats(const Shape& s, int B);
 int query_prologue(const Shape& s, const Weights& w, const float* q, const int64_t* user_ids, int B, float* qpack,
-                   float* eq_out, float* gq_out, hipStream_t stream);
+                   float* eq_out, float* gq_out, hipStream_t stream, float* qpack_other = nullptr);
 
 int coarse_build(const Shape& s, const float* ipack, int64_t n, void* table, hipStream_t stream);
 size_t coarse_topk_workspace_bytes(const Shape& s, int B, int64_t n, int k_prime);

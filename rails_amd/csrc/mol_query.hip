@@ -41,6 +41,8 @@ struct QueryArgs {
   float eps;
   float temperature;
   int split;   // precision f16x3: Eq fragments are written as f16 hi/lo (mol_layout.h)
+  float* eqfrag2;   // optional second pack in the OTHER format (fp32 <-> f16 hi/lo), same values: the verified fast modes need both
+  float* gqfrag2;
   int has_gate;   // 0: no query-only gate part -> gq = 0
 };
 
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(kQueryThreads) void query_prologue_kernel(QueryArgs
       const int p = i / d, k = i - p * d;
       const int hi = k / (d / 2), s = k - hi * (d / 2);
       eq_frag_store(eqf, s, hi, qj * PQ + p, 0.0f, a.split);
+      if (a.eqfrag2) eq_frag_store(a.eqfrag2 + (int64_t)g * 32 * d, s, hi, qj * PQ + p, 0.0f, !a.split);
     }
     return;
   }
@@ -205,12 +208,14 @@ __global__ __launch_bounds__(kQueryThreads) void query_prologue_kernel(QueryArgs
     // EqFrag[g][sc][lane][j] = Eq[g*QT + row/PQ][row%PQ][kdim_of(4sc + j, hi)], lane = hi*32 + row
     const int hi = k / (d / 2), s = k - hi * (d / 2);
     eq_frag_store(eqf, s, hi, qj * PQ + p, v / a.temperature, a.split);  // fragment copy carries 1/tau
+    if (a.eqfrag2) eq_frag_store(a.eqfrag2 + (int64_t)g * 32 * d, s, hi, qj * PQ + p, v / a.temperature, !a.split);
   }
   for (int i = threadIdx.x; i < L; i += kQueryThreads) {
     if (a.gq_out) a.gq_out[(int64_t)b * L + i] = gqs[i];
     // gqfrag[b][hi][e] = gq[b][logit_of(e, hi)]
     const int hi = i / (L / 2), e = i - hi * (L / 2);
     a.gqfrag[(int64_t)b * L + i] = -kLog2e * gqs[logit_of(e, hi, PQ, a.PX)];  // fragment copy carries -log2e
+    if (a.gqfrag2) a.gqfrag2[(int64_t)b * L + i] = -kLog2e * gqs[logit_of(e, hi, PQ, a.PX)];
   }
 }
 
@@ -305,6 +310,7 @@ __device__ __forceinline__ void finalize_component(const QueryArgs& a, int tile,
         const int g = bb >> qt_shift, qj = bb & (QT - 1);
         const int hi = k >= half ? 1 : 0, s = k - hi * half;
         eq_frag_store(a.eqfrag + (int64_t)g * 32 * d, s, hi, qj * PQ + p, bb < a.B ? v / a.temperature : 0.0f, a.split);
+        if (a.eqfrag2) eq_frag_store(a.eqfrag2 + (int64_t)g * 32 * d, s, hi, qj * PQ + p, bb < a.B ? v / a.temperature : 0.0f, !a.split);
       }
       rr += step_r; k += step_k;
       if (k >= d) { k -= d; ++rr; }
@@ -458,6 +464,7 @@ __global__ __launch_bounds__(kP3Threads) void query_p3_kernel(QueryArgs a, const
       // gqfrag[b][hi][e] = gq[b][logit_of(e, hi)]
       const int hi = i / (L / 2), ee = i - hi * (L / 2);
       a.gqfrag[bb * L + i] = -kLog2e * gq_raw[bb * L + logit_of(ee, hi, PQ, a.PX)];  // fragment copy carries -log2e
+      if (a.gqfrag2) a.gqfrag2[bb * L + i] = -kLog2e * gq_raw[bb * L + logit_of(ee, hi, PQ, a.PX)];
     }
     return;
   }
@@ -474,7 +481,7 @@ size_t query_scratch_floats(const Shape& s, int B) {
 }
 
 int query_prologue(const Shape& s, const Weights& w, const float* q, const int64_t* user_ids, int B, float* qpack,
-                   float* eq_out, float* gq_out, hipStream_t stream) {
+                   float* eq_out, float* gq_out, hipStream_t stream, float* qpack_other) {
   if (B <= 0) return kOk;
   QueryArgs a;
   a.q = q; a.user_ids = user_ids; a.w = w; a.B = B;
@@ -487,6 +494,8 @@ int query_prologue(const Shape& s, const Weights& w, const float* q, const int64
   const int n_groups = (B + QT - 1) / QT;
   a.eqfrag = qpack;
   a.gqfrag = qpack + (int64_t)n_groups * 32 * a.d;
+  a.eqfrag2 = qpack_other;
+  a.gqfrag2 = qpack_other ? qpack_other + (int64_t)n_groups * 32 * a.d : nullptr;
   a.eq_out = eq_out; a.gq_out = gq_out;
   const int L = a.PQ * a.PX;
   // RAILS_PROLOGUE: 0 / unset = choose, 1 = per-query kernel, 2 = batched kernels (measurement override)

@@ -326,6 +326,29 @@ class MolEngine:
             )
         return pack, eq, gq
 
+    def query_pack_both(self, q: torch.Tensor, user_ids: Optional[torch.Tensor], out: torch.Tensor, out_other: torch.Tensor):
+        """One prologue, two packs: `out` in this engine's format, `out_other` in the other one (for the fp32 companion of a
+        verified fast mode).  Both must hold rails_mol_query_pack_floats floats."""
+        _require_device(q, "query_embeddings")
+        if q.dim() != 2 or q.shape[1] != self.spec.query_embedding_dim:
+            raise ValueError(f"query_embeddings must be (B, {self.spec.query_embedding_dim}), got {tuple(q.shape)}")
+        q = _f32c(q)
+        B = q.shape[0]
+        uid = None
+        if len(self.spec.uid_embedding_hash_sizes) > 0:
+            if user_ids is None:
+                raise KeyError("user_ids")
+            uid = user_ids.to(device=q.device, dtype=torch.int64).contiguous()
+            if uid.numel() != B:
+                raise RuntimeError(f"Sizes of tensors must match: user_ids has {tuple(uid.shape)} for a batch of {B} queries")
+        n = self.lib.rails_mol_query_pack_floats(C.byref(self.shape), B)
+        if out.numel() != n or out_other.numel() != n:
+            raise ValueError(f"query packs must hold {n} floats")
+        with _on_device(q.device):
+            _lib.check(self.lib.rails_mol_query_prologue_both(C.byref(self.shape), C.byref(self.weights), _ptr(q), _ptr(uid), B, _ptr(out),
+                                                              _ptr(out_other), _stream()), "rails_mol_query_prologue_both")
+        return out, out_other
+
     # ---- scoring ------------------------------------------------------------------------------
     def score_dense(self, qpack: torch.Tensor, batch: int, index: MolIndex, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         if out is None:

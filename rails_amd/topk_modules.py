@@ -94,7 +94,6 @@ class MoLBruteForceTopK(MoLTopKModule):
         self.rescore_stats = {"calls": 0, "fallbacks": 0}
         self._probe_pool: Optional[torch.Tensor] = None
         self._ok_host: Optional[torch.Tensor] = None
-        self._side_stream = None
         self._recent: list = []       # verdicts of the last speculative calls
         self._pause_left = 0
         self._ok_event = None
@@ -168,16 +167,11 @@ class MoLBruteForceTopK(MoLTopKModule):
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
         if B * N * 4 > self.MAX_LOGIT_BYTES:      # the speculative pass wants the whole s16 matrix; beyond the limit: fp32, in chunks
             return self._forward_chunked(query_embeddings, k, _engine=ex, _index=self._dense_fp32_index(), **kwargs)
-        # the fp32 query pack is independent of everything up to the re-scoring: a side stream runs its prologue beside the big kernel
-        dev = query_embeddings.device
-        cur = torch.cuda.current_stream(dev)
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=dev)
-        self._side_stream.wait_stream(cur)          # the query is ready; the last call's reader of the pack buffer is done
-        n_q32 = ex.lib.rails_mol_query_pack_floats(E.C.byref(ex.shape), B)
-        with torch.cuda.stream(self._side_stream):
-            qpack32, _, _ = ex.query_pack(query_embeddings, kwargs.get("user_ids"), out=self._buf("qpack32", n_q32, torch.float32))
-        s16 = self._all_logits_scratch(query_embeddings, **kwargs)
+        # one prologue writes the query pack in both formats: f16 hi/lo for the first pass, fp32 for the re-scoring
+        n_q = eng.lib.rails_mol_query_pack_floats(E.C.byref(eng.shape), B)
+        qpack16, qpack32 = eng.query_pack_both(query_embeddings, kwargs.get("user_ids"), self._buf("qpack", n_q, torch.float32),
+                                               self._buf("qpack32", n_q, torch.float32))
+        s16 = eng.score_dense(qpack16, B, self._index, out=self._buf("logits", B * N, torch.float32).view(B, N))
         ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(B, N, kc), torch.uint8)
         c16, pos = E.topk(s16, kc, workspace=ws)
         # one more tile per query of probes: items drawn from the whole corpus, re-scored too, so that the bound |s16 - s32| <= eps
@@ -187,7 +181,6 @@ class MoLBruteForceTopK(MoLTopKModule):
             cand, _ = ex.gather_index(self._index32, pos)
         else:
             cand = ex.build_index(self._item_embeddings[0].index_select(0, pos.reshape(-1)))
-        cur.wait_stream(self._side_stream)
         e32 = ex.score_candidates(qpack32, B, cand, pos.shape[1])
         eps = (self.RESCORE_EPS_PER_INV_TEMPERATURE_F16X1 if single else self.RESCORE_EPS_PER_INV_TEMPERATURE) / eng.spec.temperature
         scores, ids, ok = E.rescore_select(e32, c16, pos, self._ids_flat, N, k, eps, (0.5 if single else 0.25) * eps, approx_dense=s16)
