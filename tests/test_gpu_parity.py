@@ -1135,3 +1135,29 @@ def test_exact_modes_speculate_only_where_it_pays(dev):
             s, i = tk(q, k=50)
             assert torch.equal(s, r_s) and torch.equal(i, r_i)
         assert tk.rescore_stats["calls"] == 16 and tk.rescore_stats["fallbacks"] == 16 and tk.rescore_stats["paused_calls"] == 4
+
+
+@pytest.mark.parametrize("workload", ["amzn-books", "ml-20m", "ml-1m"])
+@pytest.mark.parametrize("B", [1, 7, 32])
+def test_query_prologue_both_formats(dev, workload, B):
+    """rails_mol_query_prologue_both: the second pack is bit for bit what the other-precision prologue writes (per-query and
+    batched implementations, uid embeddings, partial last query group)."""
+    cfg = O.CONFIGS[workload]
+    w = O.synthetic_weights(cfg, seed=9)
+    q = O.synthetic_queries(cfg, B, seed=25).to(dev)
+    uid = torch.arange(B, dtype=torch.int64, device=dev) * 13 if cfg.uid_embedding_hash_sizes else None
+    with torch.inference_mode():
+        e16 = build_module(cfg, w, dev, "f16x3").engine()
+        e32 = build_module(cfg, w, dev, None).engine()
+        n = e16.lib.rails_mol_query_pack_floats(E.C.byref(e16.shape), B)
+        assert n == e32.lib.rails_mol_query_pack_floats(E.C.byref(e32.shape), B)
+        a, b = torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+        e16.query_pack_both(q, uid, a, b)
+        r16, _, _ = e16.query_pack(q, uid)
+        r32, _, _ = e32.query_pack(q, uid)
+        # compare the fragment part (the tail of the pack is the prologue's scratch)
+        L = cfg.query_dot_product_groups * cfg.item_dot_product_groups
+        qt = 32 // cfg.query_dot_product_groups
+        n_frag = (B + qt - 1) // qt * 32 * cfg.dot_product_dimension + B * L
+        assert torch.equal(a[:n_frag].view(torch.int32), r16[:n_frag].view(torch.int32))
+        assert torch.equal(b[:n_frag].view(torch.int32), r32[:n_frag].view(torch.int32))
