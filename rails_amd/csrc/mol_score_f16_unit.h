@@ -35,6 +35,9 @@
 #ifndef RAILS_F16_SINGLE
 #define RAILS_F16_SINGLE 0
 #endif
+#ifndef RAILS_F16_TIGHT_PF
+#define RAILS_F16_TIGHT_PF 2   // epilogue operand ring depth of the TIGHT stream
+#endif
 
 namespace mol {
 #if RAILS_F16_SINGLE
@@ -612,7 +615,7 @@ struct F16Unit {
     };
 
     f32x16 D2[G::TH];
-    Epi<G, (TIGHT ? 2 : 8)> ep;   // TIGHT has no registers to spare for a deeper operand ring (and its epilogue is not fenced: the compiler hoists)
+    Epi<G, (TIGHT ? RAILS_F16_TIGHT_PF : 8)> ep;   // TIGHT has no registers to spare for a deeper operand ring (and its epilogue is not fenced: the compiler hoists)
     XState<G> xs;
     YState<G, (BIG ? 3 : 1)> ys;
     auto stage_x_alone = [&](auto qc) {   // GEMM2 with nothing to hide it under but the operand splits
