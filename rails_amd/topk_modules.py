@@ -165,8 +165,15 @@ class MoLBruteForceTopK(MoLTopKModule):
         kc = (k + (max(128, k // 2) if single else max(64, k // 4)) + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS
         if kc >= N or k == 0 or kc > 16384 or N > 0xFFFFFFFF or N < self.SPECULATE_MIN_ITEMS or self._speculation_paused():
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
-        if B * N * 4 > self.MAX_LOGIT_BYTES:      # the speculative pass wants the whole s16 matrix; beyond the limit: fp32, in chunks
-            return self._forward_chunked(query_embeddings, k, _engine=ex, _index=self._dense_fp32_index(), **kwargs)
+        if B * N * 4 > self.MAX_LOGIT_BYTES:      # the speculative pass wants the whole (B, N) s16 matrix
+            rows = self.MAX_LOGIT_BYTES // (N * 4)
+            if rows >= 1:                         # ... of a slice of the batch at a time (per-row payloads are sliced with it)
+                parts = []
+                for b0 in range(0, B, rows):
+                    kw = {key: (v[b0 : b0 + rows] if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B else v) for key, v in kwargs.items()}
+                    parts.append(self._forward_rescored(query_embeddings[b0 : b0 + rows], k, **kw))
+                return torch.cat([p[0] for p in parts], 0), torch.cat([p[1] for p in parts], 0)
+            return self._forward_chunked(query_embeddings, k, _engine=ex, _index=self._dense_fp32_index(), **kwargs)   # one row is too long: fp32, in corpus chunks
         # one prologue writes the query pack in both formats: f16 hi/lo for the first pass, fp32 for the re-scoring
         n_q = eng.lib.rails_mol_query_pack_floats(E.C.byref(eng.shape), B)
         qpack16, qpack32 = eng.query_pack_both(query_embeddings, kwargs.get("user_ids"), self._buf("qpack", n_q, torch.float32),

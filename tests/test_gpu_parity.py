@@ -1012,6 +1012,12 @@ def test_f16x3_exact_equals_the_fp32_path_bit_for_bit(dev, workload, N, B, k, mo
         for _ in range(2):
             s, i = tk(q, k=k, **kw)
             assert torch.equal(s, r_s) and torch.equal(i, r_i)
+        if B > 2 and N > 1000:     # a logit budget of two rows: the batch goes through the speculative route in slices
+            tk.MAX_LOGIT_BYTES, before = 2 * N * 4, tk.rescore_stats["calls"]
+            s, i = tk(q, k=k, **kw)
+            assert torch.equal(s, r_s) and torch.equal(i, r_i) and tk.rescore_stats["calls"] == before + (B + 1) // 2
+            tk.MAX_LOGIT_BYTES = type(tk).MAX_LOGIT_BYTES
+            tk.rescore_stats["calls"] = before
         if N > 1000:
             assert tk.rescore_stats["calls"] == 2 and (tk.rescore_stats["fallbacks"] == 0 or mode == "f16-exact"), tk.rescore_stats
             print(mode, workload, N, B, k, tk.rescore_stats)
