@@ -137,6 +137,80 @@ __global__ __launch_bounds__(kScanThreads) void coarse_scan_kernel(CoarseScanArg
   const int64_t step = MODE == kScanSample ? a.stride : 1;
   const int64_t n_work = (n_tiles + step - 1) / step;            // tiles this launch visits
   const int64_t gw = (int64_t)blockIdx.x * (kScanThreads / 64) + wave, n_waves = (int64_t)gridDim.x * (kScanThreads / 64);
+  if (n_qt > 1) {
+    // More than one tile of 32 queries (B > 32): the table is still read ONCE.  A wave takes kMT item tiles into registers, then
+    // walks the query tiles over them: per query tile its A fragments and the 16 + 16 per-register thresholds come from LDS
+    // once and serve kMT tiles.  (The single-tile loop below ran once per query tile: B = 128 read the table four times, 7.75 ms
+    // per 125 M-item shard.)
+    constexpr int kMT = DC <= 2 ? 8 : (DC <= 4 ? 4 : 2);
+    for (int64_t w0 = gw * kMT; w0 < n_work; w0 += n_waves * kMT) {
+      bf16x8 Bv[kMT][DC];
+      int64_t items[kMT];
+      bool ins[kMT];
+#pragma unroll
+      for (int u = 0; u < kMT; ++u) {
+        int64_t item = (w0 + u) * step * 32 + x;
+        ins[u] = (w0 + u) < n_work && item < a.n;
+        if (!ins[u]) item = a.n - 1;
+        items[u] = item;
+        const unsigned short* rowp = a.table + item * d + 8 * h;
+#pragma unroll
+        for (int c = 0; c < DC; ++c) Bv[u][c] = *reinterpret_cast<const bf16x8*>(rowp + 16 * c);
+      }
+      for (int qt = 0; qt < n_qt; ++qt) {
+        bf16x8 A[DC];
+#pragma unroll
+        for (int c = 0; c < DC; ++c) A[c] = *reinterpret_cast<const bf16x8*>(qfrag + (((size_t)qt * DC + c) * 64 + lane) * 8);
+        float thr[16], tlo[16];
+        if constexpr (MODE == kScanSelect) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            thr[r] = thr_s[qt * 32 + acc_row(r, h)];
+            tlo[r] = coarse_unorderable(coarse_orderable(thr[r]) - 0x10000u);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < kMT; ++u) {
+          const int64_t w = w0 + u;
+          const int64_t t = w * step;
+          const int64_t item = items[u];
+          const bool in = ins[u];
+          cf32x16 acc = {0};
+#pragma unroll
+          for (int c = 0; c < DC; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c], Bv[u][c], acc, 0, 0, 0);
+          if constexpr (MODE == kScanSelect) {
+            bool hit = false;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) hit |= acc[r] >= tlo[r];
+            if (__any(hit && in)) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const bool maybe = in && acc[r] >= tlo[r];
+                if (__any(maybe)) {
+                  const int q = qt * 32 + acc_row(r, h);
+                  const float sc = bf16_rn(acc[r]);
+                  if (maybe && q < B && sc >= thr[r])
+                    stage_push(stage_s[wave], &stage_n[wave], a.keys, a.counts, a.cap, (int)(t % kSubLists), (unsigned int)q,
+                               ((unsigned long long)coarse_orderable(sc) << 32) | (unsigned int)(~(unsigned int)item));
+                }
+              }
+              stage_flush(stage_s[wave], &stage_n[wave], lane, a.keys, a.counts, a.cap, (int)(t % kSubLists));
+            }
+          } else {
+            if (w < n_work) {
+              const int64_t colx = MODE == kScanSample ? w * 32 + x : item;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int q = qt * 32 + acc_row(r, h);
+                if (q < B && (in || MODE == kScanSample)) a.scores[(int64_t)q * a.ld + colx] = in ? bf16_rn(acc[r]) : -INFINITY;
+              }
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
   for (int qt = 0; qt < n_qt; ++qt) {
     bf16x8 A[DC];
 #pragma unroll

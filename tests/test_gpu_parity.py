@@ -1167,3 +1167,26 @@ def test_query_prologue_both_formats(dev, workload, B):
         n_frag = (B + qt - 1) // qt * 32 * cfg.dot_product_dimension + B * L
         assert torch.equal(a[:n_frag].view(torch.int32), r16[:n_frag].view(torch.int32))
         assert torch.equal(b[:n_frag].view(torch.int32), r32[:n_frag].view(torch.int32))
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_two_pass_batches_beyond_one_query_tile(dev, precision):
+    """B > 32 keeps several query tiles in the coarse scan (one read of the table, query tiles inside): the fused scan, the
+    materialising path and the 32-query slices of the same batch must all agree, bit for bit (B = 100: a partial fourth tile)."""
+    cfg = O.CONFIGS["amzn-books"]
+    w = O.synthetic_weights(cfg, seed=10)
+    N, B = 300_017, 100
+    X = torch.from_numpy(O.hash_item_table(15, 0, N, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = torch.arange(1, N + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B, seed=26).to(dev)
+    with torch.inference_mode():
+        at = rails_amd.MoLAvgTopK(build_module(cfg, w, dev, precision), X, ids, avg_top_k=500)
+        s, i = at(q, k=100)
+        cs, cp = at.coarse_candidates(q)
+        parts = [at(q[b0 : b0 + 32], k=100) for b0 in range(0, B, 32)]
+        assert torch.equal(s, torch.cat([p[0] for p in parts])) and torch.equal(i, torch.cat([p[1] for p in parts]))
+        at._no_fused = True                       # the materialising path: (B, N) coarse scores + rails_topk
+        s2, i2 = at(q, k=100)
+        cs2, cp2 = at.coarse_candidates(q)
+        at._no_fused = False
+        assert torch.equal(s, s2) and torch.equal(i, i2) and torch.equal(cs, cs2) and torch.equal(cp, cp2)
