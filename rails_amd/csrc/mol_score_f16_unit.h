@@ -35,6 +35,10 @@
 #ifndef RAILS_F16_SINGLE
 #define RAILS_F16_SINGLE 0
 #endif
+#ifndef RAILS_F16_GEMM1_MC
+#define RAILS_F16_GEMM1_MC 16   // item groups whose B fragments of a GEMM1 K-step are requested together when P_X > 8 (16x16x64, one wave per SIMD:
+                                // 4 -> 16 = four dependent round trips per unit instead of sixteen; f16x3 10.2 -> 9.2 ms, one-product 6.2 -> 5.75 ms at 400 k items)
+#endif
 #ifndef RAILS_F16_TIGHT_PF
 #define RAILS_F16_TIGHT_PF 2   // epilogue operand ring depth of the TIGHT stream
 #endif
@@ -156,7 +160,11 @@ struct SplitPack {
   float m1;   // -1.0, opaque (split_pair)
   __amdgpu_buffer_rsrc_t grsrc;   // BIG: the whole pack in global memory as a buffer resource
   static constexpr int N8 = G::kW1Floats / 8;   // h8 fragments per half of a weight matrix (hi or lo)
-  static constexpr int kLdsFloats = BIG ? G::kW1Floats + G::TH * 32 + G::L : G::kWpackFloats;
+  // The one-product build never touches a lo half: for BIG it stages W1 hi only (64 KiB); W2 hi is streamed like in the f16x3 build
+  // (W2 hi in LDS as well measured the same once GEMM1 asks for a whole K-step of the tile at a time).
+  static constexpr bool kBigHiOnly = BIG && RAILS_F16_SINGLE;
+  static constexpr int kLdsFloats = kBigHiOnly ? G::kW1Floats / 2 + G::TH * 32 + G::L
+                                               : (BIG ? G::kW1Floats + G::TH * 32 + G::L : G::kWpackFloats);
   __device__ __forceinline__ SplitPack(const float* smem, const float* gpack) {
     m1 = -1.0f;
     asm volatile("" : "+v"(m1));
@@ -167,7 +175,8 @@ struct SplitPack {
       // compiler keeps -- and spills -- one 64-bit address pair per streamed fragment
       grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gpack), 0, (int)(G::kWpackFloats * sizeof(float)), 0x00020000);
       w2hi = w2lo = nullptr;
-      b1 = smem + G::kW1Floats;
+      b1 = smem + (kBigHiOnly ? G::kW1Floats / 2 : G::kW1Floats);
+      if constexpr (kBigHiOnly) w1lo = nullptr;
     } else {
       w2hi = w1lo + N8;
       w2lo = w2hi + N8;
@@ -187,7 +196,13 @@ struct SplitPack {
   }
   template <int NW>
   static __device__ __forceinline__ void stage(const ScoreArgs& p, float* smem) {
-    if constexpr (BIG) {
+    if constexpr (kBigHiOnly) {
+      const float4* s1 = reinterpret_cast<const float4*>(p.wpack);                     // W1 hi
+      const float4* sb = reinterpret_cast<const float4*>(p.wpack + G::kW1Floats + G::kW2Floats);
+      float4* dst = reinterpret_cast<float4*>(smem);
+      for (int i = threadIdx.x; i < G::kW1Floats / 8; i += NW * 64) dst[i] = s1[i];
+      for (int i = threadIdx.x; i < (G::TH * 32 + G::L) / 4; i += NW * 64) dst[G::kW1Floats / 8 + i] = sb[i];
+    } else if constexpr (BIG) {
       const float4* src = reinterpret_cast<const float4*>(p.wpack);
       float4* dst = reinterpret_cast<float4*>(smem);
       for (int i = threadIdx.x; i < G::kW1Floats / 4; i += NW * 64) dst[i] = src[i];
@@ -209,7 +224,7 @@ struct SplitPack {
 template <class G, int PX, int DD, bool BULK = false>
 __device__ __forceinline__ void gemm1_presplit(f32x16 (&D1)[PX], const h8* __restrict__ eq, const h8* tEx, int lane) {
   static_assert(DD % 16 == 0, "f16x3 GEMM1 walks K in steps of 16");
-  constexpr int MC = PX > 8 ? 4 : PX;
+  constexpr int MC = PX > 8 ? RAILS_F16_GEMM1_MC : PX;
   static_assert(PX % MC == 0, "item groups come in whole chunks");
 #pragma unroll
   for (int m = 0; m < PX; ++m)

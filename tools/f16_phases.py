@@ -33,7 +33,7 @@ def main():
         query_nonlinearity=cfg.query_nonlinearity, uid_embedding_hash_sizes=list(cfg.uid_embedding_hash_sizes) or None)
     mol.load_state_dict(w, strict=True)
     mol = mol.to(dev).eval()
-    mol.precision = "f16x3"
+    mol.precision = sys.argv[3] if len(sys.argv) > 3 else "f16x3"    # "f16x1": the one-product build (its own phases library)
     X = torch.from_numpy(O.hash_item_table(1, 0, N, cfg.item_embedding_dim)).to(dev)
     q = O.synthetic_queries(cfg, 32).to(dev)
     uid = torch.arange(32, dtype=torch.int64, device=dev) if cfg.uid_embedding_hash_sizes else None
