@@ -268,10 +268,13 @@ int rails_merge_candidates(const int64_t* gathered, int32_t n_ranks, int32_t row
  * Writes the candidates' top k by (exact score desc, position asc) -- the dense path's total order -- as (scores, ids[position]
  * or the position when ids is NULL), and row_ok[row] = 1 iff  k-th exact score > min candidate approx + margin_eps  and
  * |exact - approx| <= check_eps on every candidate and probe  (then no item outside the candidates can belong to the row's
- * top k, given |approx - exact| <= margin_eps everywhere; the probes watch that bound outside the candidates).  n_cand <= 16384. */
+ * top k, given |approx - exact| <= margin_eps everywhere; the probes watch that bound outside the candidates).  n_cand <= 16384.
+ * row_stats (rows x 2 floats, optional): [largest |exact - approx| over the row's candidates and probes (inf for a NaN), k-th exact
+ * score - min candidate approx], for callers that calibrate the bound from what they observe; row_ok or row_stats may be NULL. */
 int rails_rescore_select(const float* exact_scores, int64_t ld, const float* approx_scores, const float* approx_dense, int64_t ld_dense,
                          const int64_t* positions, const int64_t* ids, int64_t n_items, int32_t rows, int32_t n_ranked, int32_t n_cand,
-                         int32_t k, float margin_eps, float check_eps, float* out_scores, int64_t* out_ids, int32_t* row_ok, void* stream);
+                         int32_t k, float margin_eps, float check_eps, float* out_scores, int64_t* out_ids, int32_t* row_ok, float* row_stats,
+                         void* stream);
 
 /* ---- seen-id filter --------------------------------------------------------------------------
  * Replaces the row-wise masking of CandidateIndex.get_top_k_outputs (indexing/candidate_index.py:154-178):

@@ -452,17 +452,18 @@ int rails_merge_candidates(const int64_t* gathered, int32_t n_ranks, int32_t row
 
 int rails_rescore_select(const float* exact_scores, int64_t ld, const float* approx_scores, const float* approx_dense, int64_t ld_dense,
                          const int64_t* positions, const int64_t* ids, int64_t n_items, int32_t rows, int32_t n_ranked, int32_t n_cand,
-                         int32_t k, float margin_eps, float check_eps, float* out_scores, int64_t* out_ids, int32_t* row_ok, void* stream) {
+                         int32_t k, float margin_eps, float check_eps, float* out_scores, int64_t* out_ids, int32_t* row_ok, float* row_stats,
+                         void* stream) {
   g_err[0] = '\0';
   if (rows < 0 || n_ranked <= 0 || n_cand < n_ranked || k <= 0 || k > n_ranked || ld < n_cand) { set_error("rescore_select: bad size"); return RAILS_EINVAL; }
   if (n_items <= 0 || n_items > 0xFFFFFFFFll) { set_error("rescore_select: positions must fit 32 bits (n_items = %lld)", (long long)n_items); return RAILS_EINVAL; }
   if (rows == 0) return RAILS_OK;
-  if (!exact_scores || !approx_scores || !positions || !out_scores || !out_ids || !row_ok || (n_cand > n_ranked && (!approx_dense || ld_dense < n_items))) {
+  if (!exact_scores || !approx_scores || !positions || !out_scores || !out_ids || (!row_ok && !row_stats) || (n_cand > n_ranked && (!approx_dense || ld_dense < n_items))) {
     set_error("rescore_select: NULL pointer or short stride");
     return RAILS_EINVAL;
   }
   const int r = rescore_select(exact_scores, ld, approx_scores, approx_dense, ld_dense, positions, ids, rows, n_ranked, n_cand, k, margin_eps,
-                               check_eps, out_scores, out_ids, row_ok, (hipStream_t)stream);
+                               check_eps, out_scores, out_ids, row_ok, row_stats, (hipStream_t)stream);
   return r == kOk ? r : fail(r, "rescore_select");
 }
 

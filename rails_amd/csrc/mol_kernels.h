@@ -131,7 +131,7 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
 int pack_candidates(const float* scores, const int64_t* ids, int rows, int k_local, int k, int64_t* msg, hipStream_t stream);
 int rescore_select(const float* exact, int64_t ld, const float* approx, const float* approx_dense, int64_t ld_dense, const int64_t* positions,
                    const int64_t* ids, int rows, int n_ranked, int kc, int k, float margin_eps, float check_eps, float* out_scores,
-                   int64_t* out_ids, int* ok, hipStream_t stream);
+                   int64_t* out_ids, int* ok, float* stats, hipStream_t stream);
 int merge_candidates(const int64_t* gathered, int R, int rows, int k, int k_out, float* out_scores, int64_t* out_ids,
                      hipStream_t stream);
 int filter_seen(const int64_t* top_ids, const float* top_scores, int rows, int k_prime, const int64_t* invalid,

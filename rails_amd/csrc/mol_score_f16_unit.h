@@ -354,7 +354,10 @@ __device__ __forceinline__ void epi_slice(EP& s, const f32x16 (&D1)[PX], const f
 template <class G, int PX, int R0, class EP>
 __device__ __forceinline__ float epi_final(EP& s, const f32x16 (&D1)[PX]) {
   float den = s.den + swap32(s.den), num = s.num + swap32(s.num);
-  if (__builtin_amdgcn_ballot_w64(!(den < 3.0e38f)) != 0) {   // an exp overflowed somewhere in this wave: the stable form
+  // The guard sits well below FLT_MAX: with den near 1e38 the sum is still finite, but num = sum ex * cl (|cl| <= 1/tau) overflows
+  // first and 1/den is a denormal that v_rcp flushes to zero -- NaNs and zeros for gate logits just under the exp overflow
+  // (found with pair-gate weights x 3: 1 084 non-finite logits of 2.4 M; x 5 and x 10 overflowed den itself and were caught).
+  if (__builtin_amdgcn_ballot_w64(!(den < 1.0e30f)) != 0) {   // an exp got large somewhere in this wave: the stable form
     float mn = INFINITY;
 #pragma unroll
     for (int e = 0; e < G::E; ++e) mn = __builtin_fminf(mn, s.D3[e / 16][e % 16]);

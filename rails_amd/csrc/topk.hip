@@ -924,12 +924,13 @@ __global__ __launch_bounds__(kSortThreads) void rescore_select_kernel(const floa
                                                                       const int64_t* __restrict__ positions,
                                                                       const int64_t* __restrict__ ids, int n_ranked, int kc, int k, int npad,
                                                                       float margin_eps, float check_eps, float* __restrict__ out_scores,
-                                                                      int64_t* __restrict__ out_ids, int* __restrict__ ok) {
+                                                                      int64_t* __restrict__ out_ids, int* __restrict__ ok,
+                                                                      float* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
-  __shared__ float red_min[kSortThreads / 64];
+  __shared__ float red_min[kSortThreads / 64], red_err[kSortThreads / 64];
   __shared__ int red_nan[kSortThreads / 64];
   const int row = blockIdx.x;
-  float mn = INFINITY;
+  float mn = INFINITY, err = 0.0f;
   int bad = 0;
   for (int i = threadIdx.x; i < npad; i += kSortThreads) {
     unsigned long long kv = 0ull;
@@ -944,16 +945,19 @@ __global__ __launch_bounds__(kSortThreads) void rescore_select_kernel(const floa
       } else {
         a = approx_dense[(int64_t)row * ld_dense + pos];
       }
-      bad |= !(fabsf(e - a) <= check_eps);       // catches NaN as well
+      const float dd = fabsf(e - a);
+      bad |= !(dd <= check_eps);       // catches NaN as well
+      err = fmaxf(err, dd == dd ? dd : INFINITY);
     }
     keys[i] = kv;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     mn = fminf(mn, __shfl_xor(mn, o, 64));
+    err = fmaxf(err, __shfl_xor(err, o, 64));
     bad |= __shfl_xor(bad, o, 64);
   }
-  if ((threadIdx.x & 63) == 0) { red_min[threadIdx.x >> 6] = mn; red_nan[threadIdx.x >> 6] = bad; }
+  if ((threadIdx.x & 63) == 0) { red_min[threadIdx.x >> 6] = mn; red_err[threadIdx.x >> 6] = err; red_nan[threadIdx.x >> 6] = bad; }
   __syncthreads();
   for (int size = 2; size <= npad; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -974,17 +978,18 @@ __global__ __launch_bounds__(kSortThreads) void rescore_select_kernel(const floa
     out_ids[(int64_t)row * k + j] = ids ? ids[pos] : pos;
   }
   if (threadIdx.x == 0) {
-    float m = INFINITY;
+    float m = INFINITY, er = 0.0f;
     int b = 0;
-    for (int w = 0; w < kSortThreads / 64; ++w) { m = fminf(m, red_min[w]); b |= red_nan[w]; }
+    for (int w = 0; w < kSortThreads / 64; ++w) { m = fminf(m, red_min[w]); er = fmaxf(er, red_err[w]); b |= red_nan[w]; }
     const float kth = unorderable((unsigned int)(keys[k - 1] >> 32));
-    ok[row] = (!b && kth > m + margin_eps) ? 1 : 0;
+    if (ok) ok[row] = (!b && kth > m + margin_eps) ? 1 : 0;
+    if (stats) { stats[2 * row] = er; stats[2 * row + 1] = kth - m; }   // largest |exact - approx| seen, and the margin the row has
   }
 }
 
 int rescore_select(const float* exact, int64_t ld, const float* approx, const float* approx_dense, int64_t ld_dense, const int64_t* positions,
                    const int64_t* ids, int rows, int n_ranked, int kc, int k, float margin_eps, float check_eps, float* out_scores,
-                   int64_t* out_ids, int* ok, hipStream_t stream) {
+                   int64_t* out_ids, int* ok, float* stats, hipStream_t stream) {
   if (rows <= 0) return kOk;
   if (kc > kSortCap) { set_error("rescore_select: %d candidates exceed the in-LDS sort capacity (%d)", kc, kSortCap); return kErrUnsupported; }
   static DynLdsOnce once;
@@ -992,7 +997,7 @@ int rescore_select(const float* exact, int64_t ld, const float* approx, const fl
     return kErrLaunch;
   const int npad = next_pow2(kc < 2 ? 2 : kc);
   hipLaunchKernelGGL(rescore_select_kernel, dim3(rows), dim3(kSortThreads), npad * sizeof(unsigned long long), stream, exact, ld, approx,
-                     approx_dense, ld_dense, positions, ids, n_ranked, kc, k, npad, margin_eps, check_eps, out_scores, out_ids, ok);
+                     approx_dense, ld_dense, positions, ids, n_ranked, kc, k, npad, margin_eps, check_eps, out_scores, out_ids, ok, stats);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

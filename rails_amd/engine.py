@@ -583,10 +583,12 @@ def topk(scores: torch.Tensor, k: int, ids: Optional[torch.Tensor] = None, sorte
 
 
 def rescore_select(exact: torch.Tensor, approx: torch.Tensor, positions: torch.Tensor, ids: Optional[torch.Tensor], n_items: int, k: int,
-                   margin_eps: float, check_eps: float, approx_dense: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                   margin_eps: float = float("inf"), check_eps: float = float("inf"),
+                   approx_dense: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """Verified finish of a speculative brute-force top-k (include/rails_amd.h rails_rescore_select): exact (rows, >= n_cand) fp32,
     approx (rows, n_ranked), positions (rows, n_cand >= n_ranked; the tail are probes looked up in approx_dense (rows, n_items))
-    -> (scores (rows, k), ids (rows, k), row_ok (rows,) int32)."""
+    -> (scores (rows, k), ids (rows, k), row_ok (rows,) int32 for the given eps, row_stats (rows, 2) fp32 = [max |exact - approx|,
+    k-th exact - min candidate approx])."""
     lib = _lib.load()
     _require_device(exact, "exact scores")
     rows, n_cand = positions.shape
@@ -594,11 +596,12 @@ def rescore_select(exact: torch.Tensor, approx: torch.Tensor, positions: torch.T
     out_s = torch.empty((rows, k), dtype=torch.float32, device=exact.device)
     out_i = torch.empty((rows, k), dtype=torch.int64, device=exact.device)
     ok = torch.empty((rows,), dtype=torch.int32, device=exact.device)
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=exact.device)
     with _on_device(exact.device):
         _lib.check(lib.rails_rescore_select(_ptr(exact), exact.stride(0), _ptr(approx), _ptr(approx_dense), 0 if approx_dense is None else approx_dense.stride(0),
                                             _ptr(positions), _ptr(ids), n_items, rows, approx.shape[1], n_cand, k, margin_eps, check_eps,
-                                            _ptr(out_s), _ptr(out_i), _ptr(ok), _stream()), "rails_rescore_select")
-    return out_s, out_i, ok
+                                            _ptr(out_s), _ptr(out_i), _ptr(ok), _ptr(stats), _stream()), "rails_rescore_select")
+    return out_s, out_i, ok, stats
 
 
 def pack_candidates(scores: torch.Tensor, ids: torch.Tensor, k: int) -> torch.Tensor:

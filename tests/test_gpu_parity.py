@@ -1084,15 +1084,21 @@ def test_rescore_select_kernel_against_a_host_restatement(dev):
     check_big = 25.0                                                                  # ... checked with their own tolerance below
     def run(chk):
         return E.rescore_select(exact.to(dev), approx_c.to(dev), pos.to(dev), ids.to(dev), N, k, margin, chk, approx_dense=dense.to(dev))
-    s, i, ok = run(check)
+    s, i, ok, st = run(check)
     assert ok.cpu().tolist() == [0, 0, 0, 0, 0, 0]           # rows 0 / 5 fail the monitor (shifted by 20), the others by construction
-    s, i, ok = run(check_big)
+    s, i, ok, st = run(check_big)
+    st = st.cpu()
+    for r in (1, 2, 3):                                      # row_stats: [largest |exact - approx| incl. probes, k-th exact - min candidate approx]
+        e, a = exact[r, :n_ranked], approx_c[r]
+        want_err = max(float((e - a).abs().max()), float((exact[r, n_ranked:] - dense[r, pos[r, n_ranked:]]).abs().max()))
+        assert abs(float(st[r, 0]) - want_err) <= 1e-6 and abs(float(st[r, 1]) - (float(e.topk(k).values[-1]) - float(a.min()))) <= 1e-6
+    assert float(st[4, 0]) == float("inf")                   # a NaN among the exact scores
     assert ok.cpu().tolist() == [1, 0, 1, 1, 0, 1]           # with a loose monitor only the margin (1) and the NaN (4) rows fail
     for r in (0, 2, 3, 5):
         e, p = exact[r, :n_ranked], pos[r, :n_ranked]
         order = sorted(range(n_ranked), key=lambda j: (-float(e[j]), int(p[j])))[:k]
         assert torch.equal(s[r].cpu(), e[order]) and torch.equal(i[r].cpu(), ids[p[order]])
-    s2, i2, _ = E.rescore_select(exact.to(dev), approx_c.to(dev), pos.to(dev), None, N, k, margin, check_big, approx_dense=dense.to(dev))
+    s2, i2, _, _ = E.rescore_select(exact.to(dev), approx_c.to(dev), pos.to(dev), None, N, k, margin, check_big, approx_dense=dense.to(dev))
     assert torch.equal(i2[5].cpu(), (i[5].cpu() - 3) // 7)    # ids = None -> positions
 
 
@@ -1190,3 +1196,51 @@ def test_two_pass_batches_beyond_one_query_tile(dev, precision):
         cs2, cp2 = at.coarse_candidates(q)
         at._no_fused = False
         assert torch.equal(s, s2) and torch.equal(i, i2) and torch.equal(cs, cs2) and torch.equal(cp, cp2)
+
+
+@pytest.mark.parametrize("mode", ["f16x3-exact", "f16-exact"])
+@pytest.mark.parametrize("gain", [3.0, 10.0])
+def test_exact_modes_under_stressed_gate_weights(dev, mode, gain):
+    """Pair-gate weights scaled far beyond their initialisation make the first pass's error grow past the calibrated bound: the
+    monitor must notice and the fallback must keep the result equal to the fp32 path's (fallbacks are allowed here, wrong
+    results are not)."""
+    cfg = O.CONFIGS["amzn-books"]
+    w = dict(O.synthetic_weights(cfg, seed=11))
+    for key in ("_gating_fn._qi_partial_module.1.weight", "_gating_fn._qi_partial_module.3.weight"):
+        w[key] = w[key] * gain
+    N, B, k = 150_000, 16, 200
+    X = torch.from_numpy(O.hash_item_table(16, 0, N, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = torch.arange(1, N + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B, seed=27).to(dev)
+    with torch.inference_mode():
+        r_s, r_i = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, None), X, ids)(q, k=k)
+        tk = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, mode), X, ids)
+        for _ in range(6):
+            s, i = tk(q, k=k)
+            assert torch.equal(s, r_s) and torch.equal(i, r_i)
+        print(mode, "gate gain", gain, tk.rescore_stats, "pad scale", tk._pad_scale)
+        if gain <= 3.0:      # the bound calibrates itself: after at most a couple of redone calls the speculation holds
+            assert tk.rescore_stats["fallbacks"] <= 2, tk.rescore_stats
+
+
+@pytest.mark.parametrize("gain", [2.0, 3.0, 5.0])
+def test_f16_kernels_near_the_exp_overflow(dev, gain):
+    """Gate logits just under the fp32 exp overflow (pair-gate weights x 3 on this model): the un-shifted softmax sum is still
+    finite there, but its product with the cross logits overflows and 1/den is a flushed denormal -- the overflow guard must
+    take the stable form before that.  (x 3 produced 1 084 non-finite logits of 2.4 M with the guard at FLT_MAX; x 5 overflows
+    the sum itself and was always caught.)  Both f16 builds: finite everywhere and as close to fp32 as their precision allows."""
+    cfg = O.CONFIGS["amzn-books"]
+    w = dict(O.synthetic_weights(cfg, seed=11))
+    for key in ("_gating_fn._qi_partial_module.1.weight", "_gating_fn._qi_partial_module.3.weight"):
+        w[key] = w[key] * gain
+    N, B = 150_000, 16
+    X = torch.from_numpy(O.hash_item_table(16, 0, N, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = torch.arange(1, N + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B, seed=27).to(dev)
+    with torch.inference_mode():
+        ref = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, None), X, ids).all_logits(q)
+        assert bool(torch.isfinite(ref).all())
+        for pr, tol in (("f16x3", 2e-4 * gain), ("f16x1", 0.15 * gain)):
+            got = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, pr), X, ids).all_logits(q)
+            assert bool(torch.isfinite(got).all()), pr
+            assert float((got - ref).abs().max()) <= tol, (pr, float((got - ref).abs().max()))
