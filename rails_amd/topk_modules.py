@@ -95,6 +95,7 @@ class MoLBruteForceTopK(MoLTopKModule):
         self._probe_pool: Optional[torch.Tensor] = None
         self._ok_host: Optional[torch.Tensor] = None
         self._recent: list = []       # verdicts of the last speculative calls
+        self._calib_engine = None
         self._err_seen = 0.0          # running maximum (slowly decaying) of |first pass - fp32| over re-scored candidates and probes
         self._pad_scale = 1           # candidate margin multiplier, doubled (up to 4) when a verification fails
         self._pause_left = 0
@@ -277,6 +278,10 @@ class MoLBruteForceTopK(MoLTopKModule):
 
     def _bind(self) -> E.MolEngine:
         eng = super()._bind()
+        if eng.exact is not None and self._calib_engine is not eng:   # a new engine (other weights or precision): calibrate afresh
+            self._calib_engine = eng
+            self._err_seen, self._pad_scale, self._pause_left = 0.0, 1, 0
+            self._recent.clear()
         if eng.exact is not None and self._index32_engine is not eng.exact and self.keep_dense_fp32_index is not False:
             # precision "f16x3-exact": a dense fp32 index next to the f16x3 one makes the candidates a gather (10 us) instead of
             # an index build of their raw rows (160 us), and is the fallback's index.  Same bytes again; skipped (None) when
