@@ -143,7 +143,7 @@ class MoLBruteForceTopK(MoLTopKModule):
     RESCORE_EPS_PER_INV_TEMPERATURE = 5e-5   # eps = this / temperature: 1e-3 on logits in [-20, 20], 30 x the largest
                                              # |f16x3 - fp32| seen over 22 M pairs (profiles/r02_bench.json fast_path)
     # first pass on the one-product f16 kernels ("f16-exact"): |s16 - s32| up to 4.3e-2 on amzn-books, 1.7e-2 on ML-20M
-    # (tools/single_f16_probe.py) -> eps = 0.15 on logits in [-20, 20]; the monitor trips at eps / 2; twice the candidate margin
+    # (tools/single_f16_probe.py) -> default eps = 0.15 on logits in [-20, 20], twice the candidate margin of the f16x3 first pass
     RESCORE_EPS_PER_INV_TEMPERATURE_F16X1 = 7.5e-3
 
     def _forward_rescored(self, query_embeddings: torch.Tensor, k: int, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
