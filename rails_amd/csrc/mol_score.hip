@@ -12,13 +12,15 @@ namespace mol {
 // ---------------------------------------------------------------------------------------------
 struct WsFp32 {
   static constexpr int CE = 4, OPV = 1;
+  static constexpr int kW1Stream = 0;
 #ifndef RAILS_WS_PD1
-#define RAILS_WS_PD1 1
+#define RAILS_WS_PD1 2
 #endif
   static constexpr int PD1 = RAILS_WS_PD1;  // GEMM1 chunks (16 MFMAs = 1024 cycles each) requested ahead: L2 latency with the tile touched a unit earlier
   static constexpr int PD2 = 1, PD3 = 1;    // a chunk is 8 MFMAs = 512 cycles: one chunk ahead covers the LDS latency
   struct Op { float4 v; };
   __device__ __forceinline__ void init() {}
+  static __device__ __forceinline__ void pin(Op& o) { asm volatile("" : "+a"(o.v.x), "+a"(o.v.y), "+a"(o.v.z), "+a"(o.v.w)); }
   static __device__ __forceinline__ Op ld(const WsBuf& b, int idx, int lane16) {
     const ws_u32x4 v = b.frag(idx, lane16);
     return Op{make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w))};
@@ -28,15 +30,26 @@ struct WsFp32 {
   template <class G> static __device__ __forceinline__ Op w1_op(const WsBuf& b, int c, int t, int lane16) { return ld(b, c * G::TH + t, lane16); }
   template <class G> static __device__ __forceinline__ Op w2_op(const WsBuf& b, int c, int v, int lane16) { return ld(b, G::kW1Floats / 256 + c * G::TL + v, lane16); }
   template <int N>
-  static __device__ __forceinline__ void mma_n(f32x16 (&d)[N], const Op (&a)[N], const Op (&b)[N]) {
+  static __device__ __forceinline__ void mma_a(f32x16 (&d)[N], const Op& a, const Op (&b)[N]) {
 #pragma unroll
-    for (int n = 0; n < N; ++n) d[n] = mfma32(a[n].v.x, b[n].v.x, d[n]);
+    for (int n = 0; n < N; ++n) d[n] = mfma32(a.v.x, b[n].v.x, d[n]);
 #pragma unroll
-    for (int n = 0; n < N; ++n) d[n] = mfma32(a[n].v.y, b[n].v.y, d[n]);
+    for (int n = 0; n < N; ++n) d[n] = mfma32(a.v.y, b[n].v.y, d[n]);
 #pragma unroll
-    for (int n = 0; n < N; ++n) d[n] = mfma32(a[n].v.z, b[n].v.z, d[n]);
+    for (int n = 0; n < N; ++n) d[n] = mfma32(a.v.z, b[n].v.z, d[n]);
 #pragma unroll
-    for (int n = 0; n < N; ++n) d[n] = mfma32(a[n].v.w, b[n].v.w, d[n]);
+    for (int n = 0; n < N; ++n) d[n] = mfma32(a.v.w, b[n].v.w, d[n]);
+  }
+  template <int N>
+  static __device__ __forceinline__ void mma_b(f32x16 (&d)[N], const Op (&a)[N], const Op& b) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) d[n] = mfma32(a[n].v.x, b.v.x, d[n]);
+#pragma unroll
+    for (int n = 0; n < N; ++n) d[n] = mfma32(a[n].v.y, b.v.y, d[n]);
+#pragma unroll
+    for (int n = 0; n < N; ++n) d[n] = mfma32(a[n].v.z, b.v.z, d[n]);
+#pragma unroll
+    for (int n = 0; n < N; ++n) d[n] = mfma32(a[n].v.w, b.v.w, d[n]);
   }
   template <int R0>
   __device__ __forceinline__ Op pack(const f32x16& acc) const { return Op{make_float4(acc[R0], acc[R0 + 1], acc[R0 + 2], acc[R0 + 3])}; }
@@ -52,67 +65,85 @@ struct WsFp32 {
       d[r + 1] = h.y;
     }
   }
-  // Gate, softmax numerators and mixture of ONE query over this wave's EW logit K-steps:  t2 = -log2e * (gq*gi + gqi);
-  // u = t2 / (1 + 2^t2) = -log2e * g*sigmoid(g);  ex = 2^(min u - u);  returns the wave's (min u, sum ex, sum ex * cl),
-  // identical in both lane halves.  gating_combination "none" (similarity_fn.py:187-197): u = gq' + gqi' - log2e * gi.
-  template <class G, int MW, int TLW, int EW, int Q>
-  static __device__ __forceinline__ void epilogue(f32x16 (&D3)[TLW], const f32x16 (&D1w)[MW], const float4* cl_lds /* [c * 64] */, const float4 (&gi4)[EW / 4],
-                                                  const float4* gq4, int combine_none, float& mn_out, float& den_out, float& num_out) {
-    float mn = INFINITY;
-    if (combine_none) {
+  // Gate, softmax numerators and mixture of ONE query over this wave's EW logit K-steps, in slices the shell deals between
+  // the MFMA chunks of the other query's GEMM3 (fp32 MFMA and VALU share the ALUs, but the dependency stalls of a lone VALU
+  // stream at one wave per SIMD disappear):
+  //   slices 0 .. EW/4-1   t2 = -log2e * (gq*gi + gqi);  u = t2 / (1 + 2^t2) = -log2e * g*sigmoid(g);  running min
+  //                        gating_combination "none" (similarity_fn.py:187-197): u = gq' + gqi' - log2e * gi
+  //   slice  EW/4          min over both lane halves
+  //   slices EW/4+1 ..     ex = 2^(min u - u); den += ex; num += ex * cl   (cl re-read from the wave's own chunks in LDS: the exact
+  //                        fp32 values it wrote there in phase 1; keeping D1w through phases 2 and 3 cost 64 registers next to 256 of weights)
+  //   end                  the wave's (min u, sum ex, sum ex * cl), identical in both lane halves
+  template <class G, int MW, int TLW, int EW>
+  struct Epi {
+    static constexpr int NS = EW / 4 + 1 + EW / 4;
+    static constexpr int PF = 2;   // LDS operands (gq, gi, cl) are requested PF slices ahead of their use: a slice that waits for its own reads
+                                   // pays the LDS latency every time (no second wave on the SIMD to cover it)
+    float mn;
+    f32x2 den2, num2;
+    float4 gqr[PF + 1], gir[PF + 1], clr[PF + 1];
+    __device__ __forceinline__ void begin(const float4* cl_lds, const float4* gi_lds, const float4* gq4) {
+      mn = INFINITY; den2 = f32x2{0.0f, 0.0f}; num2 = f32x2{0.0f, 0.0f};
 #pragma unroll
-      for (int ec = 0; ec < EW / 4; ++ec) {
-        const float4 gq = gq4[ec], gi = gi4[ec];
-        const float giv[4] = {gi.x, gi.y, gi.z, gi.w}, gqv[4] = {gq.x, gq.y, gq.z, gq.w};
+      for (int i = 0; i < PF; ++i) { gqr[i] = gq4[i]; gir[i] = gi_lds[i * 64]; }
+    }
+    template <int Q, int S>
+    __device__ __forceinline__ void slice(f32x16 (&D3)[TLW], const f32x16 (&D1w)[MW], const float4* cl_lds /* [c * 64] */, const float4* gi_lds /* [ec * 64] */,
+                                          const float4* gq4, int combine_none) {
+      if constexpr (S < EW / 4) {
+        constexpr int ec = S;
+        if constexpr (ec + PF < EW / 4) { gqr[(ec + PF) % (PF + 1)] = gq4[ec + PF]; gir[(ec + PF) % (PF + 1)] = gi_lds[(ec + PF) * 64]; }
+        else if constexpr (ec + PF - EW / 4 < PF) clr[ec + PF - EW / 4] = cl_lds[(ec + PF - EW / 4) * 64];   // the first cl chunks, for pass 2
+        const float4 gq = gqr[ec % (PF + 1)], gi = gir[ec % (PF + 1)];
+        if (combine_none) {
+          const float giv[4] = {gi.x, gi.y, gi.z, gi.w}, gqv[4] = {gq.x, gq.y, gq.z, gq.w};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int e = ec * 4 + j;
-          const float u = __builtin_fmaf(giv[j], -kLog2e, gqv[j] + D3[e / 16][e % 16]);
-          D3[e / 16][e % 16] = u;
-          mn = fminf(mn, u);
+          for (int j = 0; j < 4; ++j) {
+            const int e = ec * 4 + j;
+            const float u = __builtin_fmaf(giv[j], -kLog2e, gqv[j] + D3[e / 16][e % 16]);
+            D3[e / 16][e % 16] = u;
+            mn = fminf(mn, u);
+          }
+        } else {
+          const f32x2 giv[2] = {{gi.x, gi.y}, {gi.z, gi.w}};
+          const f32x2 gqv[2] = {{gq.x, gq.y}, {gq.z, gq.w}};
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int e = ec * 4 + 2 * j;
+            const f32x2 t2 = pk_fma(gqv[j], giv[j], f32x2{D3[e / 16][e % 16], D3[e / 16][e % 16 + 1]});
+            const f32x2 uu = t2 * pk_sigmoid_arg(t2);
+            D3[e / 16][e % 16] = uu.x;
+            D3[e / 16][e % 16 + 1] = uu.y;
+            mn = fminf(mn, fminf(uu.x, uu.y));
+          }
         }
-      }
-    } else {
-#pragma unroll
-      for (int ec = 0; ec < EW / 4; ++ec) {
-        const float4 gq = gq4[ec], gi = gi4[ec];
-        const f32x2 giv[2] = {{gi.x, gi.y}, {gi.z, gi.w}};
-        const f32x2 gqv[2] = {{gq.x, gq.y}, {gq.z, gq.w}};
+      } else if constexpr (S == EW / 4) {
+        mn = fminf(mn, xor32(mn));
+      } else {
+        constexpr int c = S - EW / 4 - 1;
+        if constexpr (c + PF < EW / 4) clr[(c + PF) % (PF + 1)] = cl_lds[(c + PF) * 64];
+        const float4 cl = clr[c % (PF + 1)];
+        const f32x2 clv[2] = {{cl.x, cl.y}, {cl.z, cl.w}};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int e = ec * 4 + 2 * j;
-          const f32x2 t2 = pk_fma(gqv[j], giv[j], f32x2{D3[e / 16][e % 16], D3[e / 16][e % 16 + 1]});
-          const f32x2 uu = t2 * pk_sigmoid_arg(t2);
-          D3[e / 16][e % 16] = uu.x;
-          D3[e / 16][e % 16 + 1] = uu.y;
-          mn = fminf(mn, fminf(uu.x, uu.y));
+          const int e = 4 * c + 2 * j;
+          const f32x2 d = mn - f32x2{D3[e / 16][e % 16], D3[e / 16][e % 16 + 1]};
+          const f32x2 ex = {__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};
+          den2 = den2 + ex;
+          num2 = pk_fma(ex, clv[j], num2);
         }
       }
     }
-    mn = fminf(mn, xor32(mn));
-    f32x2 den2 = {0.0f, 0.0f}, num2 = {0.0f, 0.0f};
-    // cl of this wave's logits: re-read from the wave's own chunks in LDS (the exact fp32 values it wrote there in phase 1);
-    // keeping D1w in registers through phases 2 and 3 instead cost 64 registers next to 256 of weights -- and spills
-#pragma unroll
-    for (int c = 0; c < EW / 4; ++c) {
-      const float4 cl = cl_lds[c * 64];
-      const f32x2 clv[2] = {{cl.x, cl.y}, {cl.z, cl.w}};
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int e = 4 * c + 2 * j;
-        const f32x2 d = mn - f32x2{D3[e / 16][e % 16], D3[e / 16][e % 16 + 1]};
-        const f32x2 ex = {__builtin_amdgcn_exp2f(d.x), __builtin_amdgcn_exp2f(d.y)};
-        den2 = den2 + ex;
-        num2 = pk_fma(ex, clv[j], num2);
-      }
+    template <int Q>
+    __device__ __forceinline__ void end(f32x16 (&D3)[TLW], const f32x16 (&D1w)[MW], const float4* cl_lds, float& mn_out, float& den_out, float& num_out) {
+      float den = den2.x + den2.y, num = num2.x + num2.y;
+      den += xor32(den);
+      num += xor32(num);
+      mn_out = mn;
+      den_out = den;
+      num_out = num;
     }
-    float den = den2.x + den2.y, num = num2.x + num2.y;
-    den += xor32(den);
-    num += xor32(num);
-    mn_out = mn;
-    den_out = den;
-    num_out = num;
-  }
+  };
 };
 
 template <int PQ, int PX, int DD, int H>

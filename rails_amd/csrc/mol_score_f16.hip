@@ -1,5 +1,6 @@
 // Launch side of the f16x3 scoring kernels for the shapes with tuned variants (see mol_score_f16_unit.h for the kernel).
 #include "mol_score_f16_unit.h"
+#include "mol_score_wsplit_f16.h"
 #if RAILS_F16_SINGLE   // the one-product build of this file (mol_score_f16x1*.hip)
 #define score_launch_f16 score_launch_f16x1
 #endif
@@ -46,14 +47,24 @@ int score_launch_f16(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t s
   MOL_CASE(8, 8, 32)
 #undef MOL_CASE
   if (s.query_dot_product_groups == 16 && s.item_dot_product_groups == 16 && s.dot_product_dimension == 64) {
-    // L = 256: tiles (160 KiB) and the gate pack (256 KiB) are beyond LDS staging -- independent waves, one per SIMD
-    // (512 registers hold the whole D1), W1 in LDS, W2 streamed from L2
-    return launch_kernel<F16Unit<false, true, true>, 16, 16, 64, 128, 4, false>(a, n_cu, stream);
+    // L = 256: tiles (160 KiB) and the gate pack (256 KiB) are beyond LDS staging -- the team kernel (mol_score_wsplit.h)
+    return launch_wsplit<WsF16, 16, 16, 64, 128>(a, n_cu, stream);
   }
   set_error("the f16x3 precision mode is not built for this shape");
   return kErrUnsupported;
 }
 
+#ifdef RAILS_WS_PHASES
+}  // namespace mol
+#if RAILS_F16_SINGLE
+extern "C" int rails_debug_ws_phases_f16x1(long long* out) {
+#else
+extern "C" int rails_debug_ws_phases_f16x3(long long* out) {
+#endif
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(mol::g_ws_phase), sizeof(long long) * 16) == hipSuccess ? 0 : -1;
+}
+namespace mol {
+#endif
 #ifdef RAILS_F16_PHASES
 }  // namespace mol
 extern "C" int rails_debug_f16_phases(long long* out) {

@@ -27,8 +27,10 @@
 //   P::CE                       accumulator registers (K-steps of two rows) covered by one operand chunk
 //   P::Op                       one operand chunk of a lane; P::OPV 16-byte vectors
 //   eq_op / ex_op / w1_op / w2_op   chunk loads from the query pack, the item tile, the gate pack (buffer loads)
-//   mma_n<N>(D[N], A[N], B[N])  one chunk of N independent accumulators
+//   mma_a<N>(D[N], A, B[N]) / mma_b<N>(D[N], A[N], B)   one chunk of N independent accumulators sharing the A / the B operand
 //   pack<R0>(acc)               accumulator registers [R0, R0 + CE) -> B operand chunk
+//   pin(op)                     put a stationary weight chunk into the AGPR half of the register file (MFMA A operands may be
+//                               AGPRs; left to itself the allocator keeps them as VGPR "spills" there and copies at every use)
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
@@ -61,6 +63,11 @@ __device__ __forceinline__ void ws_static_for(F&& f) {
 
 __device__ __forceinline__ float ws_xor32(float v) { return __shfl_xor(v, 32, 64); }
 
+// Team barrier that orders LDS traffic only.  __syncthreads() also drains the wave's outstanding GLOBAL loads (its fence waits
+// for vmcnt(0)): the next unit's operand prefetch, the gate fragments and the L2 touches would all have to land before every
+// barrier -- at 6 k cycles per unit (one-product build) that is the HBM latency exposed twice per unit.
+__device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #ifdef RAILS_WS_PHASES   // tools/wsplit_phases.sh: shader-clock stamps of workgroup 0 / wave 0, second unit
 static __device__ long long g_ws_phase[16];
 #define WS_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && it == 1) g_ws_phase[i] = (long long)clock64(); } while (0)
@@ -91,8 +98,9 @@ struct WsGeo {
   static constexpr int kClFloats = G::QT * NC2 * OPV * 256;
   static constexpr int kHidFloats = G::QT * NC3 * OPV * 256;
   static constexpr int kGqFloats = NWT * G::QT * 2 * EW;     // [wave][query][lane half][EW]
+  static constexpr int kGiFloats = NWT * (EW / 4) * 256;
   static constexpr int kPartFloats = NWT * 3 * 64;
-  static constexpr int kLdsFloats = kBiasFloats + kClFloats + kHidFloats + kGqFloats + kPartFloats;
+  static constexpr int kLdsFloats = kBiasFloats + kClFloats + kHidFloats + kGqFloats + kGiFloats + kPartFloats;
 };
 
 template <class P, int PQ, int PX, int DD, int H>
@@ -108,7 +116,8 @@ __global__ __launch_bounds__(256, 1) void mol_score_wsplit_kernel(ScoreArgs p) {
   float4* sCl = reinterpret_cast<float4*>(smem + W::kBiasFloats);
   float4* sHid = sCl + W::kClFloats / 4;
   float4* sGq = sHid + W::kHidFloats / 4;
-  float* sPart = reinterpret_cast<float*>(sGq + W::kGqFloats / 4);
+  float4* sGi = sGq + W::kGqFloats / 4;     // [wave][EW / 4][lane]: the wave's item-gate fragments of the current unit
+  float* sPart = reinterpret_cast<float*>(sGi + W::kGiFloats / 4);
 
   const int lane = threadIdx.x & 63;
   const int lane16 = lane * 16;
@@ -123,13 +132,16 @@ __global__ __launch_bounds__(256, 1) void mol_score_wsplit_kernel(ScoreArgs p) {
   }
   // this wave's weight slices -> registers, once per launch
   const WsBuf wb(p.wpack, (unsigned)(G::kWpackFloats * sizeof(float)));
-  Op w1r[NC2], w2r[NC3][TLW];
+  // (P::kW1Stream chunks of the W1 slice are NOT kept: a policy whose weights alone fill half the register file re-reads them
+  // from L2 at the head of every phase 2, where nothing else is live, instead of letting the allocator spill them to scratch)
+  constexpr int NC2R = NC2 - P::kW1Stream;
+  Op w1r[NC2R], w2r[NC3][TLW];
 #pragma unroll
-  for (int c = 0; c < NC2; ++c) w1r[c] = P::template w1_op<G>(wb, c, wave, lane16);
+  for (int c = 0; c < NC2R; ++c) { w1r[c] = P::template w1_op<G>(wb, c, wave, lane16); P::pin(w1r[c]); }
 #pragma unroll
   for (int c = 0; c < NC3; ++c)
 #pragma unroll
-    for (int v = 0; v < TLW; ++v) w2r[c][v] = P::template w2_op<G>(wb, c, wave * TLW + v, lane16);
+    for (int v = 0; v < TLW; ++v) { w2r[c][v] = P::template w2_op<G>(wb, c, wave * TLW + v, lane16); P::pin(w2r[c][v]); }
   __syncthreads();
 
   const int inner = p.per_row ? (int)p.n_tiles : p.n_groups;
@@ -168,15 +180,24 @@ __global__ __launch_bounds__(256, 1) void mol_score_wsplit_kernel(ScoreArgs p) {
       for (int mm = 0; mm < MW; ++mm) b_pf[c][mm] = P::template ex_op<G, DD>(tb, wave * MW + mm, c, lane16);
     }
   };
-  // L2 touch of a unit's Ex slice (this wave's item groups: MW * d / 8 KiB, contiguous), a whole unit ahead: one dword per
-  // 128-byte line, 8 KiB per instruction, into registers nobody reads.  Every unit works on a tile its workgroup has not seen
-  // before, so without this each GEMM1 operand request is an HBM-latency miss.  (Not by LDS-DMA: the compiler orders every
-  // later LDS read behind an LDS-DMA it cannot disambiguate, i.e. GEMM2 would start with a wait for these misses.)
-  constexpr int NTOUCH = MW * (DD / 8) / 8;
-  auto touch = [&](const Unit& un, float (&sink)[NTOUCH]) {
-    const float* slice = tile_base(un) + (int64_t)wave * MW * (DD / 8) * 256;
+  // L2 touch of a unit's Ex slice (this wave's item groups: MW * d / 8 KiB, contiguous) and gi slice (EW / 4 KiB), TWO units
+  // ahead: one dword per 128-byte line, 8 KiB per instruction, into registers nobody reads.  Every unit works on a tile its
+  // workgroup has not seen before, so without this each GEMM1 operand request is an HBM-latency miss.  (Not by LDS-DMA: the
+  // compiler orders every later LDS read behind an LDS-DMA it cannot disambiguate.  Not at the head of phase 2 either: there the
+  // 64-line requests slowed GEMM2's LDS operand reads by ~1.2 k cycles per unit in every precision.)
+  // The touch loads are issued from inline asm into ONE register that stays reserved for the whole loop and is never read:
+  // the compiler does not count them, so nothing ever waits for their HBM misses (a builtin load has to be "used" somewhere,
+  // and that use became a wait of 1-2 k cycles per unit).  Uncounted loads only make the compiler's own vmcnt waits
+  // conservative (results return in order).
+  constexpr int NTOUCH = MW * (DD / 8) / 8 + 1;
+  static_assert(EW / 4 == 8, "one touch instruction covers the wave's gi slice");
+  float sink = 0.0f;
+  auto touch = [&](const Unit& un) {
+    const float* tb = tile_base(un);
+    const float* slice = tb + (int64_t)wave * MW * (DD / 8) * 256 + lane * 32;
 #pragma unroll
-    for (int i = 0; i < NTOUCH; ++i) sink[i] = __builtin_nontemporal_load(slice + i * 2048 + lane * 32);
+    for (int i = 0; i < NTOUCH - 1; ++i) asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(slice + i * 2048) : "memory");
+    asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(tb + G::kTileExFloats + wave * (EW / 4) * 256 + lane * 32) : "memory");
   };
   // the previous unit's output is folded and stored by ONE wave after the next barrier: lane = (query of the group, item)
   bool have_prev = false;
@@ -245,10 +266,7 @@ __global__ __launch_bounds__(256, 1) void mol_score_wsplit_kernel(ScoreArgs p) {
           for (int mm = 0; mm < MW; ++mm) b[slot][mm] = P::template ex_op<G, DD>(tileb, wave * MW + mm, c + PD1, lane16);
         }
         __builtin_amdgcn_sched_barrier(0);   // exactly PD1 chunks ahead: the requests stay ABOVE this chunk's MFMAs (a memory clobber alone lets the scheduler hoist MFMAs over them)
-        Op as[MW];
-#pragma unroll
-        for (int mm = 0; mm < MW; ++mm) as[mm] = a[c % (PD1 + 1)];
-        P::template mma_n<MW>(D1w, as, b[c % (PD1 + 1)]);
+        P::template mma_a<MW>(D1w, a[c % (PD1 + 1)], b[c % (PD1 + 1)]);
       });
     }
     WS_STAMP(1);
@@ -259,14 +277,20 @@ __global__ __launch_bounds__(256, 1) void mol_score_wsplit_kernel(ScoreArgs p) {
       const Op o = pol.template pack<Q * G::RPQ + e0 % G::RPQ>(D1w[e0 / G::RPQ]);
       P::st(sCl + ((Q * NC2 + wave * NC2W + c) * OPV) * 64, lane, o);
     });
-    __syncthreads();   // B1: every wave's cl chunks are in LDS; every wave is done with the previous unit's hid and partials
+    ws_barrier();   // B1: every wave's cl chunks are in LDS; every wave is done with the previous unit's hid and partials
     WS_STAMP(2);
     if (have_prev && wave == (it & 3)) combine_store(prev);
     // Memory requests that nothing waits for soon go HERE, behind the barrier: vector-memory results return in order, so in
     // phase 1 they sat in front of GEMM1's operand loads and every chunk waited for their HBM misses (GEMM1 at half rate).
     // Phase 2 reads LDS only.
-    float sink[NTOUCH] = {};
-    if (un < n_units) touch(nxt, sink);
+    // this wave's item-gate fragments (shared by the two queries): requested here, parked in the wave's own LDS slot before B2
+    // (32 registers that phase 3 needs for the second query's accumulators), read back slice by slice in phase 3
+    float4 gi[EW / 4];
+#pragma unroll
+    for (int ec = 0; ec < EW / 4; ++ec) {
+      const ws_u32x4 v = tileb.frag(G::kTileExFloats / 256 + wave * (EW / 4) + ec, lane16);
+      gi[ec] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+    }
     // the unit's query-gate rows, this wave's logits: [query][lane half][EW] -> the wave's own LDS slot (read back by the
     // same wave only: DS operations of a wave are in order).  Rows past the batch end (padding of the last group) read the
     // last real row; their output is never stored.
@@ -278,6 +302,9 @@ __global__ __launch_bounds__(256, 1) void mol_score_wsplit_kernel(ScoreArgs p) {
       gq_stage = *reinterpret_cast<const float4*>(p.gqfrag + (int64_t)qq * G::L + hh * G::E + wave * EW + 4 * j);
     }
     // ---- phase 2: GEMM2 of hidden row tile `wave`, both queries:  D2 = -log2e * (b1 + W1 cl)
+    Op w1s[P::kW1Stream > 0 ? P::kW1Stream : 1];
+#pragma unroll
+    for (int c = 0; c < P::kW1Stream; ++c) w1s[c] = P::template w1_op<G>(wb, NC2R + c, wave, lane16);
     f32x16 D2[QT];
 #pragma unroll
     for (int Q = 0; Q < QT; ++Q)
@@ -297,22 +324,11 @@ __global__ __launch_bounds__(256, 1) void mol_score_wsplit_kernel(ScoreArgs p) {
           for (int Q = 0; Q < QT; ++Q) ring[(c + PD) % (PD + 1)][Q] = P::ldl(sCl + ((Q * NC2 + c + PD) * OPV) * 64, lane);
         }
         __builtin_amdgcn_sched_barrier(0);
-        Op as[QT];
-#pragma unroll
-        for (int Q = 0; Q < QT; ++Q) as[Q] = w1r[c];
-        P::template mma_n<QT>(D2, as, ring[c % (PD + 1)]);
+        if constexpr (c < NC2R) P::template mma_a<QT>(D2, w1r[c], ring[c % (PD + 1)]);
+        else P::template mma_a<QT>(D2, w1s[c - NC2R], ring[c % (PD + 1)]);
       });
     }
     WS_STAMP(3);
-    // this wave's item-gate fragments (shared by the two queries): requested here, behind GEMM2, used in phase 3.  (Requested
-    // together with the touches at the head of phase 2 they slowed GEMM2 by ~2 k cycles per unit.)
-    float4 gi[EW / 4];
-#pragma unroll
-    for (int ec = 0; ec < EW / 4; ++ec) {
-      const ws_u32x4 v = tileb.frag(G::kTileExFloats / 256 + wave * (EW / 4) + ec, lane16);
-      gi[ec] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-    }
-
     // hid' = t / (1 + 2^t) = -log2e * silu(pre), then the tile's hidden values as B-operand chunks -> LDS
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -324,46 +340,79 @@ __global__ __launch_bounds__(256, 1) void mol_score_wsplit_kernel(ScoreArgs p) {
     });
     if (lane < QT * 2 * (EW / 4)) sGq[wave * (QT * 2 * (EW / 4)) + lane] = gq_stage;
 #pragma unroll
-    for (int i = 0; i < NTOUCH; ++i) asm volatile("" ::"v"(sink[i]));   // the touches are "used" here, a phase after their issue
+    for (int ec = 0; ec < EW / 4; ++ec) sGi[(wave * (EW / 4) + ec) * 64 + lane] = gi[ec];
     __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();   // B2: the whole hidden layer of both queries is in LDS; every wave is done with the cl chunks
+    ws_barrier();   // B2: the whole hidden layer of both queries is in LDS; every wave is done with the cl chunks
     WS_STAMP(4);
 
-    // next unit: request the first GEMM1 chunks now, a whole phase ahead of their use
-    if (un < n_units) prefetch_first(nxt);
+    // the unit after next: L2 touch
+    if (un + stride < n_units) touch(decode(un + stride));
 
-    // ---- phase 3, per query: GEMM3 of the wave's logit rows  D3 = -log2e * (b2 + W2 hid), gate, softmax numerators
+    // ---- phase 3: GEMM3 of the wave's logit rows  D3 = -log2e * (b2 + W2 hid), gate, softmax numerators.
+    //   GEMM3(query 0)  ->  GEMM3(query 1) || gate + softmax of query 0, dealt slice by slice between the MFMA chunks
+    //   ->  gate + softmax of query 1
     float pmn[QT], pden[QT], pnum[QT];
-    ws_static_for<QT>([&](auto qc) {
+    f32x16 D3[QT][TLW];
+    using EpiT = typename P::template Epi<G, MW, TLW, EW>;
+    constexpr int PD = P::PD3;
+    Op ring3[PD + 1];
+    auto gemm3_begin = [&](auto qc) {
       constexpr int Q = decltype(qc)::value;
-      f32x16 D3[TLW];
 #pragma unroll
       for (int v = 0; v < TLW; ++v)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) D3[v][r] = sB2[hi * G::E + wave * EW + v * 16 + r];
-      {
-        constexpr int PD = P::PD3;
-        Op ring[PD + 1];
+        for (int r = 0; r < 16; ++r) D3[Q][v][r] = sB2[hi * G::E + wave * EW + v * 16 + r];
 #pragma unroll
-        for (int c = 0; c < PD; ++c) ring[c] = P::ldl(sHid + ((Q * NC3 + c) * OPV) * 64, lane);
-        ws_static_for<NC3>([&](auto cc) {
-          constexpr int c = decltype(cc)::value;
-          if constexpr (c + PD < NC3) ring[(c + PD) % (PD + 1)] = P::ldl(sHid + ((Q * NC3 + c + PD) * OPV) * 64, lane);
-          __builtin_amdgcn_sched_barrier(0);
-          Op bs[TLW];
-#pragma unroll
-          for (int v = 0; v < TLW; ++v) bs[v] = ring[c % (PD + 1)];
-          P::template mma_n<TLW>(D3, w2r[c], bs);
-        });
-      }
+      for (int c = 0; c < PD; ++c) ring3[c] = P::ldl(sHid + ((Q * NC3 + c) * OPV) * 64, lane);
+    };
+    auto gemm3_chunk = [&](auto qc, auto cc) {
+      constexpr int Q = decltype(qc)::value, c = decltype(cc)::value;
+      if constexpr (c + PD < NC3) ring3[(c + PD) % (PD + 1)] = P::ldl(sHid + ((Q * NC3 + c + PD) * OPV) * 64, lane);
       __builtin_amdgcn_sched_barrier(0);
-      const float4* gq4 = sGq + wave * (QT * 2 * (EW / 4)) + (Q * 2 + hi) * (EW / 4);
+      P::template mma_b<TLW>(D3[Q], w2r[c], ring3[c % (PD + 1)]);
+    };
+    auto epi_args = [&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
       // the wave's own cl chunks are still in LDS (other waves only read them in phase 2 and never write them): a policy may
       // re-read them there instead of keeping D1w alive through phases 2 and 3
-      const float4* cl_own = sCl + ((Q * NC2 + wave * NC2W) * OPV) * 64 + lane;
-      P::template epilogue<G, MW, TLW, EW, Q>(D3, D1w, cl_own, gi, gq4, p.combine_none, pmn[Q], pden[Q], pnum[Q]);
+      struct A { const float4* gq4; const float4* cl_own; const float4* gi_own; };
+      return A{sGq + wave * (QT * 2 * (EW / 4)) + (Q * 2 + hi) * (EW / 4), sCl + ((Q * NC2 + wave * NC2W) * OPV) * 64 + lane,
+               sGi + wave * (EW / 4) * 64 + lane};
+    };
+    {
+      using Q0 = std::integral_constant<int, 0>;
+      using Q1 = std::integral_constant<int, 1>;
+      gemm3_begin(Q0{});
+      ws_static_for<NC3>([&](auto cc) { gemm3_chunk(Q0{}, cc); });
       __builtin_amdgcn_sched_barrier(0);
-    });
+      WS_STAMP(7);
+      EpiT ep;
+      const auto a0 = epi_args(Q0{});
+      ep.begin(a0.cl_own, a0.gi_own, a0.gq4);
+      gemm3_begin(Q1{});
+      ws_static_for<NC3>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        gemm3_chunk(Q1{}, cc);
+        constexpr int s0 = c * EpiT::NS / NC3, s1 = (c + 1) * EpiT::NS / NC3;
+        ws_static_for<s1 - s0>([&](auto sc) { ep.template slice<0, s0 + decltype(sc)::value>(D3[0], D1w, a0.cl_own, a0.gi_own, a0.gq4, p.combine_none); });
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      WS_STAMP(8);
+      ep.template end<0>(D3[0], D1w, a0.cl_own, pmn[0], pden[0], pnum[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      WS_STAMP(9);
+      // next unit: request the first GEMM1 chunks now (L2 hits: touched a unit ago), behind the register peak of the overlapped
+      // part and one gate + softmax pass ahead of their use
+      if (un < n_units) prefetch_first(nxt);
+      const auto a1 = epi_args(Q1{});
+      ep.begin(a1.cl_own, a1.gi_own, a1.gq4);
+      ws_static_for<EpiT::NS>([&](auto sc) {
+        ep.template slice<1, decltype(sc)::value>(D3[1], D1w, a1.cl_own, a1.gi_own, a1.gq4, p.combine_none);
+        __builtin_amdgcn_sched_barrier(0);   // slices keep their own instruction order (they are laid out for dependent-issue distance)
+      });
+      ep.template end<1>(D3[1], D1w, a1.cl_own, pmn[1], pden[1], pnum[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     WS_STAMP(5);
     // partial softmax state of (query = lane half, item) -> LDS; both lane halves hold the wave's totals
     sPart[(wave * 3 + 0) * 64 + lane] = hi ? pmn[1] : pmn[0];
@@ -375,9 +424,10 @@ __global__ __launch_bounds__(256, 1) void mol_score_wsplit_kernel(ScoreArgs p) {
     WS_STAMP(6);
   }
   if (have_prev) {
-    __syncthreads();
+    __syncthreads();   // also drains the uncounted touch loads before the wave ends
     if (wave == 0) combine_store(prev);
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::"v"(sink));
 }
 
 template <class P, int PQ, int PX, int DD, int H>

@@ -37,7 +37,7 @@ with torch.inference_mode():
     for i in range(4):
         eng.score_dense(qpack, B, index); torch.cuda.synchronize(); getattr(lib, fn)(out)
         p = list(out)
-        print("%s cycles | GEMM1 %d | cl pack+store+B1 %d | GEMM2 %d | silu+store+B2 %d | GEMM3+gate x2 %d | partials %d | unit %d"
-              % (prec, p[1]-p[0], p[2]-p[1], p[3]-p[2], p[4]-p[3], p[5]-p[4], p[6]-p[5], p[6]-p[0]))
+        print("%s cycles | GEMM1 %d | cl pack+store+B1 %d | GEMM2 %d | silu+store+B2 %d | GEMM3 q0 %d, GEMM3 q1 || gate q0 %d, end q0 %d, prefetch + gate q1 %d | partials %d | unit %d"
+              % (prec, p[1]-p[0], p[2]-p[1], p[3]-p[2], p[4]-p[3], p[7]-p[4], p[8]-p[7], p[9]-p[8], p[5]-p[9], p[6]-p[5], p[6]-p[0]))
 PY
 fi
