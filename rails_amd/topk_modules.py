@@ -91,12 +91,16 @@ class MoLBruteForceTopK(MoLTopKModule):
         self._index32: Optional[E.MolIndex] = None          # precision "f16x3-exact": dense fp32 index (candidate gather, fallback)
         self._index32_engine = None
         self.keep_dense_fp32_index: Optional[bool] = self.KEEP_DENSE_FP32_INDEX
-        self.rescore_stats = {"calls": 0, "fallbacks": 0}
+        self.rescore_stats = {"calls": 0, "fallbacks": 0, "audited": 0, "mismatches": 0}
         self._probe_pool: Optional[torch.Tensor] = None
         self._ok_host: Optional[torch.Tensor] = None
         self._recent: list = []       # verdicts of the last speculative calls
         self._calib_engine = None
-        self._err_seen = 0.0          # running maximum (slowly decaying) of |first pass - fp32| over re-scored candidates and probes
+        self._err_seen = 0.0          # largest |first pass - fp32| ever seen on re-scored candidates and probes (reset only with the engine)
+        self._risk_pool: Optional[torch.Tensor] = None   # positions of the highest-norm items (probed every call)
+        self.audit_every: int = int(self.AUDIT_EVERY)    # > 0: every n-th speculative call is also run on the dense fp32 path and compared
+        self._audit_stream = None
+        self._debug_first_pass_bias = None
         self._pad_scale = 1           # candidate margin multiplier, doubled (up to 4) when a verification fails
         self._pause_left = 0
         self._ok_event = None
@@ -169,9 +173,10 @@ class MoLBruteForceTopK(MoLTopKModule):
         kc = (k + pad + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS
         if k <= 384:
             kc = min(kc, 512)       # rails_topk's two-launch path ends at k = 512; beyond it a selection costs five reads of the logits
+        oversize = B * N * 4 > self.MAX_LOGIT_BYTES      # the 4 GiB logit policy comes first: no route below may materialise (B, N)
         if kc >= N or k == 0 or kc > 16384 or N > 0xFFFFFFFF or N < self.SPECULATE_MIN_ITEMS or self._speculation_paused():
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
-        if B * N * 4 > self.MAX_LOGIT_BYTES:      # the speculative pass wants the whole (B, N) s16 matrix
+        if oversize:                              # the speculative pass wants the whole (B, N) s16 matrix
             rows = self.MAX_LOGIT_BYTES // (N * 4)
             if rows >= 1:                         # ... of a slice of the batch at a time (per-row payloads are sliced with it)
                 parts = []
@@ -179,16 +184,18 @@ class MoLBruteForceTopK(MoLTopKModule):
                     kw = {key: (v[b0 : b0 + rows] if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B else v) for key, v in kwargs.items()}
                     parts.append(self._forward_rescored(query_embeddings[b0 : b0 + rows], k, **kw))
                 return torch.cat([p[0] for p in parts], 0), torch.cat([p[1] for p in parts], 0)
-            return self._forward_chunked(query_embeddings, k, _engine=ex, _index=self._dense_fp32_index(), **kwargs)   # one row is too long: fp32, in corpus chunks
+            return self._forward_fp32_dense(query_embeddings, k, **kwargs)   # one row is too long: fp32, in corpus chunks
         # one prologue writes the query pack in both formats: f16 hi/lo for the first pass, fp32 for the re-scoring
         n_q = eng.lib.rails_mol_query_pack_floats(E.C.byref(eng.shape), B)
         qpack16, qpack32 = eng.query_pack_both(query_embeddings, kwargs.get("user_ids"), self._buf("qpack", n_q, torch.float32),
                                                self._buf("qpack32", n_q, torch.float32))
         s16 = eng.score_dense(qpack16, B, self._index, out=self._buf("logits", B * N, torch.float32).view(B, N))
+        if self._debug_first_pass_bias is not None:   # tests only: (positions, delta) -- the first pass is made to under-score these items
+            s16[:, self._debug_first_pass_bias[0]] -= self._debug_first_pass_bias[1]
         ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(B, N, kc), torch.uint8)
         c16, pos = E.topk(s16, kc, workspace=ws)
-        # one more tile per query of probes: items drawn from the whole corpus, re-scored too, so that the bound |s16 - s32| <= eps
-        # is watched outside the candidates as well (a fresh draw of a fixed pool every call)
+        # two more tiles per query of probes (random + highest-norm items), re-scored too, so that the bound |s16 - s32| <= eps is
+        # watched outside the candidates as well
         pos = torch.cat([pos, self._probes(B, N)], dim=1)
         if self._index32 is not None:
             cand, _ = ex.gather_index(self._index32, pos)
@@ -203,7 +210,7 @@ class MoLBruteForceTopK(MoLTopKModule):
         err, gap = self._read_stats(stats)
         default = (self.RESCORE_EPS_PER_INV_TEMPERATURE_F16X1 if single else self.RESCORE_EPS_PER_INV_TEMPERATURE) / eng.spec.temperature
         if err == err and err != float("inf"):
-            self._err_seen = max(err, 0.99 * self._err_seen)
+            self._err_seen = max(err, self._err_seen)   # never forgotten: a rare outlier keeps the margin wide until the engine changes
         eps = max(default, (self.SAFETY_F16X1 if single else self.SAFETY_F16X3) * self._err_seen)
         good = err == err and err != float("inf") and gap > eps
         self.rescore_stats["eps"] = eps
@@ -213,7 +220,37 @@ class MoLBruteForceTopK(MoLTopKModule):
             if self._pad_scale < 4 and not (k <= 384 and kc >= 512):
                 self._pad_scale *= 2          # crowded scores or a coarse first pass: more candidates from the next call on
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
+        if self.audit_every > 0 and self.rescore_stats["calls"] % self.audit_every == 0:
+            self._audit(query_embeddings, k, scores, ids, **kwargs)
         return scores.to(query_embeddings.dtype), ids
+
+    # Shadow audit: every AUDIT_EVERY-th verified call is ALSO run on the dense fp32 path and compared bit for bit; the counts are in
+    # rescore_stats["audited" / "mismatches"] (bench.py reports them).  0 = off.  RAILS_AUDIT_EVERY overrides the default.
+    AUDIT_EVERY = int(__import__("os").environ.get("RAILS_AUDIT_EVERY", "0"))
+
+    def _audit(self, query_embeddings: torch.Tensor, k: int, scores: torch.Tensor, ids: torch.Tensor, **kwargs) -> None:
+        """Dense fp32 top-k of the same batch on a side stream (after the verified result is complete), compared on the device; the
+        mismatch count is accumulated in a device counter and read when rescore_stats is next summarised (audit_summary())."""
+        cur = torch.cuda.current_stream(query_embeddings.device)
+        if self._audit_stream is None:
+            self._audit_stream = torch.cuda.Stream(query_embeddings.device)
+            self._audit_bad = torch.zeros(1, dtype=torch.int64, device=query_embeddings.device)
+        side = self._audit_stream
+        side.wait_stream(cur)
+        for t in (query_embeddings, scores, ids):
+            t.record_stream(side)
+        with torch.cuda.stream(side):
+            ref_s, ref_i = self._forward_fp32_dense(query_embeddings, k, _private=True, **kwargs)
+            bad = (ref_i != ids).any() | (ref_s != scores.to(ref_s.dtype)).any()
+            self._audit_bad += bad.to(torch.int64)
+        cur.wait_stream(side)     # the recycled scratch buffers of the next call must not race with the audit
+        self.rescore_stats["audited"] += 1
+
+    def audit_summary(self) -> Dict[str, int]:
+        """rescore_stats with the device-side mismatch counter folded in (one synchronising read)."""
+        if self._audit_stream is not None:
+            self.rescore_stats["mismatches"] = int(self._audit_bad.item())
+        return dict(self.rescore_stats)
 
     SAFETY_F16X3 = 8.0      # eps >= SAFETY x the running maximum of |s16 - s32| over the re-scored candidates and probes
     SAFETY_F16X1 = 3.0
@@ -254,14 +291,44 @@ class MoLBruteForceTopK(MoLTopKModule):
             err = float("inf")
         return err, gap
 
+    RISK_POOL = 4096      # highest-norm items of the corpus kept as a probe pool
+    RISK_ALWAYS = 16      # ... the top of it is probed on every call
+
     def _probes(self, B: int, N: int) -> torch.Tensor:
-        """(B, 32) random corpus positions: row block (call number mod 64) of a pool drawn once per (B, N)."""
+        """(B, 64) corpus positions re-scored next to the candidates so that |first pass - fp32| is watched OUTSIDE them too:
+        32 drawn uniformly from the whole corpus (row block `call mod 64` of a pool drawn once per (B, N)), the RISK_ALWAYS items
+        of largest embedding norm on every call, and 16 more rotating through the RISK_POOL highest-norm items -- large inputs make
+        large gate pre-activations, which is where a reduced-precision first pass is furthest off."""
+        dev = self._item_embeddings.device
         pool = self._probe_pool
         if pool is None or pool.shape[1] != B or self._probe_n != N:
-            g = torch.Generator(device=self._item_embeddings.device).manual_seed(0x5EED)
-            pool = self._probe_pool = torch.randint(0, N, (64, B, E.TILE_ITEMS), generator=g, device=self._item_embeddings.device, dtype=torch.int64)
+            g = torch.Generator(device=dev).manual_seed(0x5EED)
+            pool = self._probe_pool = torch.randint(0, N, (64, B, E.TILE_ITEMS), generator=g, device=dev, dtype=torch.int64)
             self._probe_n = N
-        return pool[self.rescore_stats["calls"] % 64]
+            self._risk_pool = None
+        if self._risk_pool is None:
+            # row norms of the raw item table, in slices (monitoring metadata computed once per corpus; not part of the scoring path)
+            X, best_v, best_i = self._item_embeddings[0], None, None
+            for lo in range(0, N, 1 << 22):
+                nv = torch.linalg.vector_norm(X[lo : lo + (1 << 22)].float(), dim=1)
+                kk = min(self.RISK_POOL, nv.numel())
+                v, i = torch.topk(nv, kk)
+                i = i + lo
+                if best_v is not None:
+                    v, i = torch.cat([best_v, v]), torch.cat([best_i, i])
+                    v, sel = torch.topk(v, min(self.RISK_POOL, v.numel()))
+                    i = i[sel]
+                best_v, best_i = v, i
+            self._risk_pool = best_i.to(torch.int64)
+        call = self.rescore_stats["calls"]
+        risk = self._risk_pool
+        n_always = min(self.RISK_ALWAYS, risk.numel())
+        rest = risk[n_always:] if risk.numel() > n_always else risk
+        n_rot = E.TILE_ITEMS - n_always
+        start = (call * n_rot) % max(rest.numel(), 1)
+        rot = rest[(start + torch.arange(n_rot, device=dev)) % rest.numel()]
+        extra = torch.cat([risk[:n_always], rot]).unsqueeze(0).expand(B, -1)
+        return torch.cat([pool[call % 64], extra], dim=1)
 
     def _dense_fp32_index(self) -> E.MolIndex:
         ex = self._engine.exact
@@ -269,12 +336,35 @@ class MoLBruteForceTopK(MoLTopKModule):
             self._index32, self._index32_engine = ex.build_index(self._item_embeddings[0]), ex
         return self._index32
 
-    def _forward_fp32_dense(self, query_embeddings: torch.Tensor, k: int, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+    def _forward_fp32_dense(self, query_embeddings: torch.Tensor, k: int, _private: bool = False, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The exact-fp32 brute force of this module's corpus (fallback of a failed verification, small corpora, the audit).
+        Same policies as the plain fp32 module: never more than MAX_LOGIT_BYTES of logits (corpus chunks beyond that), and with
+        keep_dense_fp32_index False -- or when _bind declined the second index for lack of memory -- no resident fp32 index either:
+        each chunk's index is rebuilt from the raw rows and dropped."""
         ex = self._engine.exact
-        index32 = self._dense_fp32_index()
+        B, N = query_embeddings.size(0), self._index.n_items
+        have32 = self._index32 is not None and self._index32_engine is ex
+        if have32 and B * N * 4 <= self.MAX_LOGIT_BYTES:
+            qpack32, _, _ = ex.query_pack(query_embeddings, kwargs.get("user_ids"))
+            out = None if _private else self._buf("logits", B * N, torch.float32).view(B, N)
+            scores, ids = E.topk(ex.score_dense(qpack32, B, self._index32, out=out), k, ids=self._ids_flat)
+            return scores.to(query_embeddings.dtype), ids
+        if have32:
+            return self._forward_chunked(query_embeddings, k, _engine=ex, _index=self._index32, **kwargs)
+        # no resident fp32 index: temporary per-chunk indexes (CHUNK_ITEMS rows at a time), merged like _forward_chunked
+        C = min(self.CHUNK_ITEMS, max(1, self.MAX_LOGIT_BYTES // (4 * max(B, 1))))
+        C = max(E.TILE_ITEMS, C // E.TILE_ITEMS * E.TILE_ITEMS)
         qpack32, _, _ = ex.query_pack(query_embeddings, kwargs.get("user_ids"))
-        scores, ids = E.topk(ex.score_dense(qpack32, query_embeddings.size(0), index32), k, ids=self._ids_flat)
-        return scores.to(query_embeddings.dtype), ids
+        part_s, part_p = [], []
+        for lo in range(0, N, C):
+            n = min(C, N - lo)
+            idx = ex.build_index(self._item_embeddings[0, lo : lo + n])
+            s_, p_ = E.topk(ex.score_dense(qpack32, B, idx), min(k, n))
+            part_s.append(s_)
+            part_p.append(p_ + lo)
+            del idx
+        scores, pos = E.topk(torch.cat(part_s, 1), k, ids=torch.cat(part_p, 1))
+        return scores.to(query_embeddings.dtype), self._ids_flat[pos]
 
     def _bind(self) -> E.MolEngine:
         eng = super()._bind()

@@ -1244,3 +1244,55 @@ def test_f16_kernels_near_the_exp_overflow(dev, gain):
             got = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, pr), X, ids).all_logits(q)
             assert bool(torch.isfinite(got).all()), pr
             assert float((got - ref).abs().max()) <= tol, (pr, float((got - ref).abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f16x3-exact", "f16-exact"])
+def test_exact_modes_against_planted_first_pass_outliers(dev, mode):
+    """What the verified modes rest on is |first pass - fp32| <= eps for every item OUTSIDE the candidates.  Plant violations: the first
+    pass is made to under-score true top-k items by far more than eps (a test hook subtracts from their first-pass logits), so
+    they drop out of the candidate set while their exact scores belong in the result.
+      (a) outliers among the highest-norm items of the corpus: those are probed on every call -> the error is seen, eps widens
+          past the margin, the call falls back, the result is the fp32 path's;
+      (b) an outlier nothing probes: the verification cannot see it (the guarantee is conditional on the monitored bound, as the
+          docs say) -- the shadow audit does: with audit_every = 1 the mismatch is counted."""
+    cfg = O.CONFIGS["amzn-books"]
+    w = O.synthetic_weights(cfg, seed=11)
+    N, B, k = 120_000, 8, 100
+    Xc = torch.from_numpy(O.hash_item_table(16, 0, N, cfg.item_embedding_dim))
+    q = O.synthetic_queries(cfg, B, seed=27).to(dev)
+    ids = torch.arange(1, N + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    with torch.inference_mode():
+        ref0 = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, None), Xc.unsqueeze(0).to(dev), ids)
+        _, top_i = ref0(q, k=k)
+        # items that are in the fp32 top-k of row 0 (positions = id - 1)
+        victims = (top_i[0, :3] - 1).cpu()
+        # (a) make the victims the highest-norm rows of the table (the scores barely move: Ex is l2-normalised, scale 1.02)
+        Xa = Xc.clone()
+        Xa[victims] *= 1.02 * float(Xc.norm(dim=1).max() / Xc[victims].norm(dim=1).min())
+        Xa = Xa.unsqueeze(0).to(dev)
+        r_s, r_i = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, None), Xa, ids)(q, k=k)
+        tk = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, mode), Xa, ids)
+        tk.SPECULATE_MIN_ITEMS = 0
+        tk._debug_first_pass_bias = (victims.to(dev), 5.0)
+        s, i = tk(q, k=k)
+        assert torch.equal(s, r_s) and torch.equal(i, r_i)
+        assert tk.rescore_stats["fallbacks"] == 1 and tk.rescore_stats["eps"] > 5.0, tk.rescore_stats
+        # (b) an outlier of ordinary norm that no probe covers: only the audit notices
+        Xb = Xc.unsqueeze(0).to(dev)
+        r_s, r_i = ref0(q, k=k)
+        tk = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, mode), Xb, ids)
+        tk.SPECULATE_MIN_ITEMS = 0
+        tk.audit_every = 1
+        s, i = tk(q, k=k)                      # clean call: verified and audited, no mismatch
+        assert torch.equal(s, r_s) and torch.equal(i, r_i)
+        assert tk.audit_summary()["audited"] == 1 and tk.audit_summary()["mismatches"] == 0
+        probed = set(tk._probes(B, N).reshape(-1).tolist()) | set(tk._risk_pool[: tk.RISK_ALWAYS].tolist())
+        lone = next(int(v) for v in (top_i[0] - 1).tolist() if int(v) not in probed)
+        tk._debug_first_pass_bias = (torch.tensor([lone], device=dev), 5.0)
+        s, i = tk(q, k=k)
+        if tk.rescore_stats["fallbacks"] == 0:   # the planted error went unseen by the verification ...
+            assert not torch.equal(i, r_i)
+            assert tk.audit_summary()["mismatches"] == 1, tk.rescore_stats   # ... and was caught by the audit
+        else:
+            assert torch.equal(s, r_s) and torch.equal(i, r_i)
