@@ -163,7 +163,7 @@ def measurement_matrix(mol, X, ids, q, kw, inv, cfg, n_items: int, steps: int, d
                     points.append({
                         "precision": precision, "batch": Bx, "k": kx, "k_prime": min(kx + inv.shape[1], n_items) if trunc is None else min(trunc, n_items),
                         "queries_per_s": Bx / dt, "ms_per_step": dt * 1e3, "ms_per_step_stdev": float(per.std()) if steps > 1 else 0.0,
-                        "first_pass_kernel_ms": kms, "rescore_calls": tk.rescore_stats["calls"], "dense_fp32_fallbacks": tk.rescore_stats["fallbacks"],
+                        "first_pass_kernel_ms": kms, "rescore_calls": tk.stats()["calls"], "dense_fp32_fallbacks": tk.stats()["fallbacks"],
                     })
                     continue
                 points.append({
@@ -229,7 +229,7 @@ def quick_workload(name: str, B: int, k: int, kp: int, steps: int, dev, items: i
     if precision.endswith("-exact"):   # verified fast mode: output identical to fp32 (tests); the first pass is not a parity kernel, no roofline claim
         return {"workload": f"{name} {cfg.query_dot_product_groups}x{cfg.item_dot_product_groups}x{cfg.dot_product_dimension}, N={N}", "precision": precision,
                 "queries_per_s": B / dt, "ms_per_step": dt * 1e3, "prologue_plus_first_pass_ms": score_ms,
-                "rescore_calls": tk.rescore_stats["calls"], "dense_fp32_fallbacks": tk.rescore_stats["fallbacks"]}
+                "rescore_calls": tk.stats()["calls"], "dense_fp32_fallbacks": tk.stats()["fallbacks"]}
     return {"workload": f"{name} {cfg.query_dot_product_groups}x{cfg.item_dot_product_groups}x{cfg.dot_product_dimension}, N={N}", "precision": precision,
             "queries_per_s": B / dt, "ms_per_step": dt * 1e3, "prologue_plus_scoring_ms": score_ms,
             "scoring_tflops_algorithmic_lower_bound": tf,
@@ -508,7 +508,8 @@ def main() -> None:
         for mode, what in (("f16-exact", "one-product f16 scoring of the whole index (logits ~1e-2 off)"), ("f16x3-exact", "f16x3 scoring of the whole index")):
             with torch.inference_mode():
                 mol.precision = mode
-                local.rescore_stats = {"calls": 0, "fallbacks": 0}
+                local.stats()
+                local.rescore_stats.update({"calls": 0, "fallbacks": 0, "audited": 0, "mismatches": 0})
 
                 def step_exact():
                     out_ids, out_scores, _ = cand.get_top_k_outputs(q, k, kw, topk_mod, inv, truncate_k_prime_to=kp)
@@ -528,7 +529,7 @@ def main() -> None:
                 if world > 1:
                     dist.barrier()
                 exact_elapsed = time.perf_counter() - t0
-                stats = dict(local.rescore_stats)
+                stats = dict(local.stats())
                 mol.precision = None
             if world > 1:
                 tf = torch.tensor([exact_elapsed], dtype=torch.float64, device="cpu" if test_backend else dev)

@@ -25,6 +25,12 @@
 extern "C" {
 #endif
 
+/* Version of this interface: bumped whenever a struct gains a field or an entry point changes meaning (round 2 -> 3: 3, the
+ * structs of round 2 carried no version).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
+ * against an older header pass shorter structs, and the library would read the new fields from whatever follows them. */
+#define RAILS_ABI_VERSION 3
+int rails_abi_version(void);
+
 #define RAILS_OK 0
 #define RAILS_EINVAL (-22)       /* bad argument (null pointer, non-positive size, k > n ...) */
 #define RAILS_ENOTSUP (-95)      /* shape / option outside what the HIP kernels implement */
@@ -271,6 +277,19 @@ int rails_merge_candidates(const int64_t* gathered, int32_t n_ranks, int32_t row
  * top k, given |approx - exact| <= margin_eps everywhere; the probes watch that bound outside the candidates).  n_cand <= 16384.
  * row_stats (rows x 2 floats, optional): [largest |exact - approx| over the row's candidates and probes (inf for a NaN), k-th exact
  * score - min candidate approx], for callers that calibrate the bound from what they observe; row_ok or row_stats may be NULL. */
+/* Launch predicate of the CALLING THREAD: while a device flag is set here, every rails_mol_score_dense / _score_candidates / rails_topk
+ * launched from this thread is a no-op unless *device_flag != 0 when the kernel starts (the flag is read on the device, in stream
+ * order).  NULL clears it.  This is how the verified modes run their dense fp32 fallback without the host reading the verdict:
+ * rails_rescore_verdict writes the flag, the fallback is enqueued unconditionally behind it.  No counterpart in the reference. */
+int rails_set_run_predicate(const int32_t* device_flag);
+
+/* Verdict of a speculate-then-verify call, on the device: from the row_stats of rails_rescore_select (rows x 2 floats) and the
+ * caller's calibration state (8 floats in device memory, zero-initialised once):
+ *   state[0]  largest |first pass - fp32| ever observed (updated here; never decreases)
+ *   state[1]  REDO flag, an int32 (written here): 1 iff some row's margin <= eps or a NaN was seen, eps = max(default_eps, safety * state[0])
+ *   state[2]  eps   state[3] / state[4]  this call's largest error / smallest margin   state[5] / state[6]  calls / redone calls so far */
+int rails_rescore_verdict(const float* row_stats, int32_t rows, float default_eps, float safety, float* state, void* stream);
+
 int rails_rescore_select(const float* exact_scores, int64_t ld, const float* approx_scores, const float* approx_dense, int64_t ld_dense,
                          const int64_t* positions, const int64_t* ids, int64_t n_items, int32_t rows, int32_t n_ranked, int32_t n_cand,
                          int32_t k, float margin_eps, float check_eps, float* out_scores, int64_t* out_ids, int32_t* row_ok, float* row_stats,

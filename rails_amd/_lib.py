@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RAILS_AMD_LIBRARY: load another build of the same library (e.g. the phase-stamp debug build of tools/query_phases.sh)
 LIB_PATH = os.environ.get("RAILS_AMD_LIBRARY") or os.path.join(_HERE, "librails_amd.so")
 
+RAILS_ABI_VERSION = 3   # include/rails_amd.h
 RAILS_OK = 0
 RAILS_EINVAL = -22
 RAILS_ENOTSUP = -95
@@ -173,6 +174,9 @@ PROTOTYPES = {
     ),
     "rails_rescore_select": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rails_abi_version": (C.c_int, []),
+    "rails_set_run_predicate": (C.c_int, [C.c_void_p]),
+    "rails_rescore_verdict": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "rails_filter_seen_ids": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
@@ -203,6 +207,10 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    got = lib.rails_abi_version()
+    if got != RAILS_ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} implements ABI version {got}, this binding was written for {RAILS_ABI_VERSION}: rebuild the library "
+                          "(the structs of include/rails_amd.h changed size between versions)")
     _lib = lib
     return lib
 

@@ -9,6 +9,8 @@
 namespace mol {
 
 static thread_local char g_err[512] = "";
+static thread_local const int32_t* g_run_if = nullptr;
+const int32_t* run_predicate() { return g_run_if; }
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -239,6 +241,7 @@ static int score_common(const rails_mol_shape* s, const float* gate_pack, const 
   a.split = is_split(*s) ? 1 : 0;
   a.single = s->precision == RAILS_PRECISION_F16X1 ? 1 : 0;
   a.combine_none = s->gating_combination == RAILS_COMBINE_NONE ? 1 : 0;
+  a.run_if = g_run_if;
   const int r = score_launch(*s, a, cu, (hipStream_t)stream);
   return r == kOk ? r : fail(r, what);
 }
@@ -448,6 +451,20 @@ int rails_merge_candidates(const int64_t* gathered, int32_t n_ranks, int32_t row
   if (!gathered || !out_scores || !out_ids) { set_error("merge_candidates: NULL pointer"); return RAILS_EINVAL; }
   const int r = merge_candidates(gathered, n_ranks, rows, k, k_out, out_scores, out_ids, (hipStream_t)stream);
   return r == kOk ? r : fail(r, "merge_candidates");
+}
+
+int rails_abi_version(void) { return RAILS_ABI_VERSION; }
+
+int rails_set_run_predicate(const int32_t* device_flag) {
+  g_run_if = device_flag;
+  return RAILS_OK;
+}
+
+int rails_rescore_verdict(const float* row_stats, int32_t rows, float default_eps, float safety, float* state, void* stream) {
+  g_err[0] = '\0';
+  if (rows <= 0 || !row_stats || !state || !(default_eps >= 0.0f) || !(safety >= 0.0f)) { set_error("rescore_verdict: bad argument"); return RAILS_EINVAL; }
+  const int r = rescore_verdict(row_stats, rows, default_eps, safety, state, (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "rescore_verdict");
 }
 
 int rails_rescore_select(const float* exact_scores, int64_t ld, const float* approx_scores, const float* approx_dense, int64_t ld_dense,

@@ -42,12 +42,17 @@ struct ScoreArgs {
   int combine_none;     // 1: gating_combination "none": w = gq + gi + gqi (absent parts are stored as zeros), no silu
   int single;           // 1 (with split): precision F16X1 -- the one-product kernels, which ignore the lo fragments
   int split;            // 1: precision mode f16x3 -- gate pack, query pack and item index hold f16 hi/lo fragments (mol_layout.h)
+  const int32_t* run_if;   // device flag (rails_set_run_predicate): the launch is a no-op when *run_if == 0; NULL = unconditional
 };
 
 int pack_gate_weights_split(const Shape& s, const Weights& w, float* wpack, hipStream_t stream);
 inline bool is_split(const Shape& s) { return s.precision == RAILS_PRECISION_F16X3 || s.precision == RAILS_PRECISION_F16X1; }
 
 void set_error(const char* fmt, ...);
+// Launch predicate of the calling thread (rails_set_run_predicate): scoring and top-k kernels launched while it is set return at
+// once unless the device flag is non-zero -- a device-side conditional (the verified modes' fallback) without a host round trip.
+const int32_t* run_predicate();
+#define MOL_RUN_IF(flag) do { if ((flag) != nullptr && *(flag) == 0) return; } while (0)
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute and the Python layer drives several devices from
 // one process: remember the opt-in per (call site, device).  Two threads racing on the first call both set it (idempotent).
@@ -129,6 +134,7 @@ size_t topk_workspace_bytes(int rows, int64_t n, int k);
 int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int64_t* ids, int64_t ids_row_stride,
          float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, int n_cu, hipStream_t stream);
 int pack_candidates(const float* scores, const int64_t* ids, int rows, int k_local, int k, int64_t* msg, hipStream_t stream);
+int rescore_verdict(const float* row_stats, int rows, float default_eps, float safety, float* state, hipStream_t stream);
 int rescore_select(const float* exact, int64_t ld, const float* approx, const float* approx_dense, int64_t ld_dense, const int64_t* positions,
                    const int64_t* ids, int rows, int n_ranked, int kc, int k, float margin_eps, float check_eps, float* out_scores,
                    int64_t* out_ids, int* ok, float* stats, hipStream_t stream);

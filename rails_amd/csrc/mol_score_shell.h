@@ -34,6 +34,7 @@ __device__ __forceinline__ void stage_weights(const ScoreArgs& p, float* smem) {
 template <class U, int PQ, int PX, int DD, int H, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(ScoreArgs p) {
   using G = Geo<PQ, PX, DD, H>;
+  MOL_RUN_IF(p.run_if);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   U::template stage<G, NW>(p, smem);
   __syncthreads();
@@ -90,6 +91,7 @@ __device__ __forceinline__ void dma_floats(const float* __restrict__ src, float*
 template <class U, int PQ, int PX, int DD, int H, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(ScoreArgs p) {
   using G = Geo<PQ, PX, DD, H>;
+  MOL_RUN_IF(p.run_if);
   static_assert(G::kTileFloats % 256 == 0, "tile must be a whole number of 1 KiB pieces");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tiles = smem + U::template kLdsWeightFloats<G>;  // two tile buffers
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(Score
 template <class U, int PQ, int PX, int DD, int H, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged1_kernel(ScoreArgs p) {
   using G = Geo<PQ, PX, DD, H>;
+  MOL_RUN_IF(p.run_if);
   static_assert(G::kTileExFloats % 256 == 0 && G::kTileGiFloats % 256 == 0, "1 KiB DMA pieces");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sEx = smem + U::template kLdsWeightFloats<G>;

@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256, 1) void mol_score_wsplit_kernel(ScoreArgs p) {
   using Op = typename P::Op;
   constexpr int NWT = W::NWT, QT = G::QT, MW = W::MW, EW = W::EW, TLW = W::TLW, CE = W::CE, OPV = W::OPV;
   constexpr int NC1 = W::NC1, NC2 = W::NC2, NC3 = W::NC3, NC2W = W::NC2W, NC3W = W::NC3W;
+  MOL_RUN_IF(p.run_if);
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sB1 = smem;
   float* sB2 = smem + H;

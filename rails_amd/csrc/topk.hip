@@ -125,7 +125,8 @@ __global__ __launch_bounds__(kSortThreads) void sort_emit_kernel(const float* __
                                                                 const int64_t* __restrict__ ids, int64_t ids_row_stride,
                                                                 float* __restrict__ out_scores,
                                                                 int64_t* __restrict__ out_ids,
-                                                                unsigned long long* __restrict__ keys_out, int64_t keys_ld) {
+                                                                unsigned long long* __restrict__ keys_out, int64_t keys_ld, const int32_t* __restrict__ run_if) {
+  MOL_RUN_IF(run_if);
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
   const int row = blockIdx.x;
   const int64_t begin = (int64_t)blockIdx.y * chunk;
@@ -205,7 +206,8 @@ __device__ __forceinline__ void for_each_in_chunk(const float* __restrict__ rowp
 // Lane l owns the nb/64 bins [top - l*per - per + 1, top - l*per]; a wave prefix sum finds the owning lane, which then
 // walks its own bins.
 __global__ __launch_bounds__(64) void pick_bin_kernel(SelectState* __restrict__ st, const unsigned int* __restrict__ hist,
-                                                      int pass, int rows, int k) {
+                                                      int pass, int rows, int k, const int32_t* __restrict__ run_if) {
+  MOL_RUN_IF(run_if);
   const int row = blockIdx.x;
   if (st[row].done) return;
   const int shift = kPassShift[pass], bits = kPassBits[pass];
@@ -239,7 +241,8 @@ __global__ __launch_bounds__(64) void pick_bin_kernel(SelectState* __restrict__ 
 
 __global__ __launch_bounds__(kHistThreads) void hist_kernel(const float* __restrict__ scores, int64_t ld, int64_t n,
                                                            const SelectState* __restrict__ st,
-                                                           unsigned int* __restrict__ hist, int pass, int64_t chunk) {
+                                                           unsigned int* __restrict__ hist, int pass, int64_t chunk, const int32_t* __restrict__ run_if) {
+  MOL_RUN_IF(run_if);
   __shared__ unsigned int h[kBins];
   const int row = blockIdx.y, rows = gridDim.y;
   if (st[row].done) return;
@@ -267,7 +270,8 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(const float* __restr
 // that completes the threshold key (score bits | ~position).  Rows whose threshold is already final exit at once.
 constexpr int kTieThreads = 1024;
 __global__ __launch_bounds__(kTieThreads) void tie_resolve_kernel(const float* __restrict__ scores, int64_t ld, int64_t n,
-                                                                 SelectState* __restrict__ st) {
+                                                                 SelectState* __restrict__ st, const int32_t* __restrict__ run_if) {
+  MOL_RUN_IF(run_if);
   __shared__ unsigned int wave_cnt[kTieThreads / 64];
   const int row = blockIdx.x;
   if (st[row].done) return;
@@ -301,7 +305,8 @@ __global__ __launch_bounds__(kTieThreads) void tie_resolve_kernel(const float* _
 __global__ __launch_bounds__(kHistThreads) void compact_kernel(const float* __restrict__ scores, int64_t ld, int64_t n,
                                                               SelectState* __restrict__ st,
                                                               unsigned long long* __restrict__ cand, int64_t cand_ld,
-                                                              int k, int64_t chunk) {
+                                                              int k, int64_t chunk, const int32_t* __restrict__ run_if) {
+  MOL_RUN_IF(run_if);
   const int row = blockIdx.y;
   const unsigned long long thr = st[row].prefix;
   const int lane = threadIdx.x & 63;
@@ -364,11 +369,13 @@ struct RowSelectArgs {
   const int64_t* ids; int64_t ids_row_stride;                    // final output (out_scores != NULL)
   float* out_scores; int64_t* out_ids;
   unsigned long long* keys_out;                                  // else: keys_out[(row*gridDim.y + c)*k + j]
+  const int32_t* run_if;                                         // launch predicate (mol_kernels.h)
 };
 
 template <int VPT, bool KEYS>
 __global__ __launch_bounds__(kRowThreads) void row_select_kernel(const RowSelectArgs a) {
   static_assert(VPT % 4 == 0, "float4 loads");
+  MOL_RUN_IF(a.run_if);
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // lds_keys candidates + 2048 exchange
   __shared__ unsigned int ctr[3][16];
   __shared__ unsigned int cursor;
@@ -641,8 +648,10 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
   if (k > kSortCap) { set_error("k = %d exceeds the in-LDS sort capacity (%d)", k, kSortCap); return kErrUnsupported; }
   if (n >= (1ll << 32)) { set_error("n = %lld does not fit 32-bit positions; shard the corpus", (long long)n); return kErrUnsupported; }
   if (ensure_sort_lds() != kOk) return kErrLaunch;
+  const int32_t* pred = run_predicate();
   if (n > 1024 && k <= kRowMaxK) {
     RowSelectArgs a{};
+    a.run_if = pred;
     a.scores = scores; a.ld = ld; a.n = n; a.k = k;
     if (n <= kRowMaxN) {                 // one launch
       a.chunk = n; a.ids = ids; a.ids_row_stride = ids_row_stride; a.out_scores = out_scores; a.out_ids = out_ids;
@@ -656,6 +665,7 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
       const int rc = launch_row_select<false>(a, rows, chunks, (int)chunk, stream);
       if (rc != kOk) return rc;
       RowSelectArgs b{};
+      b.run_if = pred;
       b.keys_in = lvl1; b.keys_per_row = chunks * k; b.k = k;
       b.ids = ids; b.ids_row_stride = ids_row_stride; b.out_scores = out_scores; b.out_ids = out_ids;
       return launch_row_select<true>(b, rows, 1, chunks * k, stream);
@@ -665,7 +675,7 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
     const int npad = next_pow2((int)n < 2 ? 2 : (int)n);
     hipLaunchKernelGGL(sort_emit_kernel, dim3(rows), dim3(kSortThreads), (npad <= kSortThreads ? 3 * npad : npad) * sizeof(unsigned long long), stream,
                        scores, ld, n, n, (const unsigned long long*)nullptr, (int64_t)0, 0, k, npad, ids, ids_row_stride,
-                       out_scores, out_ids, (unsigned long long*)nullptr, (int64_t)0);
+                       out_scores, out_ids, (unsigned long long*)nullptr, (int64_t)0, pred);
     return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
   }
   if (ws_bytes < topk_workspace_bytes(rows, n, k)) { set_error("top-k workspace too small"); return kErrNoMem; }
@@ -687,16 +697,16 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
   const int64_t chunk = (n + chunks - 1) / chunks;
   for (int pass = 0; pass < kRadixPasses; ++pass) {
     hipLaunchKernelGGL(hist_kernel, dim3((unsigned)chunks, rows), dim3(kHistThreads), 0, stream, scores, ld, n, st, hist, pass,
-                       chunk);
-    hipLaunchKernelGGL(pick_bin_kernel, dim3(rows), dim3(64), 0, stream, st, hist, pass, rows, k);
+                       chunk, pred);
+    hipLaunchKernelGGL(pick_bin_kernel, dim3(rows), dim3(64), 0, stream, st, hist, pass, rows, k, pred);
   }
-  hipLaunchKernelGGL(tie_resolve_kernel, dim3(rows), dim3(kTieThreads), 0, stream, scores, ld, n, st);
+  hipLaunchKernelGGL(tie_resolve_kernel, dim3(rows), dim3(kTieThreads), 0, stream, scores, ld, n, st, pred);
   hipLaunchKernelGGL(compact_kernel, dim3((unsigned)chunks, rows), dim3(kHistThreads), 0, stream, scores, ld, n, st, cand,
-                     (int64_t)k, k, chunk);
+                     (int64_t)k, k, chunk, pred);
   const int npad = next_pow2(k < 2 ? 2 : k);
   hipLaunchKernelGGL(sort_emit_kernel, dim3(rows), dim3(kSortThreads), (npad <= kSortThreads ? 3 * npad : npad) * sizeof(unsigned long long), stream, scores, ld, n, n,
                      cand, (int64_t)k, k, k, npad, ids, ids_row_stride, out_scores, out_ids, (unsigned long long*)nullptr,
-                     (int64_t)0);
+                     (int64_t)0, pred);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
@@ -985,6 +995,52 @@ __global__ __launch_bounds__(kSortThreads) void rescore_select_kernel(const floa
     if (ok) ok[row] = (!b && kth > m + margin_eps) ? 1 : 0;
     if (stats) { stats[2 * row] = er; stats[2 * row + 1] = kth - m; }   // largest |exact - approx| seen, and the margin the row has
   }
+}
+
+// Verdict of a speculative call on the device (the host used to read the per-row stats and decide: ~100 us of GPU idle per call).
+// state[0] largest |first pass - fp32| ever seen (in/out)   state[1] REDO flag as int32 (out; the fallback's launch predicate)
+// state[2] eps used   state[3] this call's largest error   state[4] this call's smallest margin   state[5] calls   state[6] redone calls
+__global__ __launch_bounds__(256) void rescore_verdict_kernel(const float* __restrict__ row_stats, int rows, float default_eps, float safety,
+                                                              float* __restrict__ state) {
+  __shared__ float s_err[256], s_gap[256];
+  __shared__ int s_bad[256];
+  float err = 0.0f, gap = INFINITY;
+  int bad = 0;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const float e = row_stats[2 * r], g = row_stats[2 * r + 1];
+    if (!(e == e) || !(g == g)) bad = 1;        // NaN anywhere: the call is redone
+    err = fmaxf(err, e);
+    gap = fminf(gap, g);
+  }
+  s_err[threadIdx.x] = err; s_gap[threadIdx.x] = gap; s_bad[threadIdx.x] = bad;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      s_err[threadIdx.x] = fmaxf(s_err[threadIdx.x], s_err[threadIdx.x + w]);
+      s_gap[threadIdx.x] = fminf(s_gap[threadIdx.x], s_gap[threadIdx.x + w]);
+      s_bad[threadIdx.x] |= s_bad[threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    err = s_err[0]; gap = s_gap[0]; bad = s_bad[0] || !(err < INFINITY);
+    float seen = state[0];
+    if (!bad) seen = fmaxf(seen, err);          // never forgotten
+    const float eps = fmaxf(default_eps, safety * seen);
+    const int redo = bad || !(gap > eps);
+    state[0] = seen;
+    reinterpret_cast<int32_t*>(state)[1] = redo;
+    state[2] = eps;
+    state[3] = bad ? INFINITY : err;
+    state[4] = gap;
+    state[5] += 1.0f;
+    if (redo) state[6] += 1.0f;
+  }
+}
+
+int rescore_verdict(const float* row_stats, int rows, float default_eps, float safety, float* state, hipStream_t stream) {
+  hipLaunchKernelGGL(rescore_verdict_kernel, dim3(1), dim3(256), 0, stream, row_stats, rows, default_eps, safety, state);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
 int rescore_select(const float* exact, int64_t ld, const float* approx, const float* approx_dense, int64_t ld_dense, const int64_t* positions,

@@ -546,7 +546,7 @@ def dot_rowwise(q: torch.Tensor, items: torch.Tensor) -> torch.Tensor:
 
 # ---- shape-independent kernels ----------------------------------------------------------------
 def topk(scores: torch.Tensor, k: int, ids: Optional[torch.Tensor] = None, sorted: bool = True,
-         workspace: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+         workspace: Optional[torch.Tensor] = None, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Exact top-k of every row of `scores` (rows, n) fp32 on the GPU; ties by position ascending.
     ids: None -> positions; (n,) or (1, n) -> shared id row; (rows, n) -> per-row ids.
     Replaces torch.topk + id gather (reference rails/indexing/mol_top_k.py:123-130)."""
@@ -570,8 +570,13 @@ def topk(scores: torch.Tensor, k: int, ids: Optional[torch.Tensor] = None, sorte
             ids = ids.reshape(-1).contiguous()
         if ids.shape[-1] < n:
             raise ValueError("ids has fewer entries than scores has columns")
-    out_s = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
-    out_i = torch.empty((rows, k), dtype=torch.int64, device=scores.device)
+    if out is not None:      # (rows, k) fp32 / int64, contiguous: overwritten (the predicated fallback of the verified modes)
+        out_s, out_i = out
+        if out_s.shape != (rows, k) or out_i.shape != (rows, k) or out_s.dtype != torch.float32 or out_i.dtype != torch.int64 or not (out_s.is_contiguous() and out_i.is_contiguous()):
+            raise ValueError("topk: out must be contiguous (rows, k) fp32 and int64 tensors")
+    else:
+        out_s = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
+        out_i = torch.empty((rows, k), dtype=torch.int64, device=scores.device)
     ws_bytes = lib.rails_topk_workspace_bytes(rows, n, k)
     ws = workspace if workspace is not None and workspace.numel() >= ws_bytes and workspace.device == scores.device else torch.empty(ws_bytes, dtype=torch.uint8, device=scores.device)
     with _on_device(scores.device):
@@ -580,6 +585,31 @@ def topk(scores: torch.Tensor, k: int, ids: Optional[torch.Tensor] = None, sorte
             "rails_topk",
         )
     return out_s, out_i
+
+
+class run_predicate:
+    """with run_predicate(flag):  every scoring / top-k launch inside is a no-op unless the int32 device scalar `flag` is non-zero
+    when the kernel starts (include/rails_amd.h rails_set_run_predicate).  Thread-local; not re-entrant."""
+
+    def __init__(self, flag: torch.Tensor) -> None:
+        if flag.dtype != torch.int32 or not flag.is_cuda:
+            raise ValueError("the launch predicate is an int32 device tensor")
+        self._flag = flag
+
+    def __enter__(self):
+        _lib.check(_lib.load().rails_set_run_predicate(_ptr(self._flag)), "rails_set_run_predicate")
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().rails_set_run_predicate(None)
+        return False
+
+
+def rescore_verdict(stats: torch.Tensor, state: torch.Tensor, default_eps: float, safety: float) -> None:
+    """Device-side verdict of a speculative call (rails_rescore_verdict): updates `state` (8 fp32 on the device) in stream order."""
+    lib = _lib.load()
+    with _on_device(stats.device):
+        _lib.check(lib.rails_rescore_verdict(_ptr(stats), stats.shape[0], float(default_eps), float(safety), _ptr(state), _stream()), "rails_rescore_verdict")
 
 
 def rescore_select(exact: torch.Tensor, approx: torch.Tensor, positions: torch.Tensor, ids: Optional[torch.Tensor], n_items: int, k: int,

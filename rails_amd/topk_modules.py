@@ -101,6 +101,8 @@ class MoLBruteForceTopK(MoLTopKModule):
         self.audit_every: int = int(self.AUDIT_EVERY)    # > 0: every n-th speculative call is also run on the dense fp32 path and compared
         self._audit_stream = None
         self._debug_first_pass_bias = None
+        self._verdict_state: Optional[torch.Tensor] = None
+        self._state_pending = None
         self._pad_scale = 1           # candidate margin multiplier, doubled (up to 4) when a verification fails
         self._pause_left = 0
         self._ok_event = None
@@ -165,6 +167,7 @@ class MoLBruteForceTopK(MoLTopKModule):
         fp32 index (and later calls take more candidates).  One (B x 8)-byte device-to-host copy per call."""
         eng = self._bind()
         ex = eng.exact
+        self._absorb_state()
         B, N = query_embeddings.size(0), self._index.n_items
         if k > N:
             raise RuntimeError(f"selected index k out of range (k={k}, n={N})")
@@ -207,22 +210,79 @@ class MoLBruteForceTopK(MoLTopKModule):
         # The bound eps on |s16 - s32|: never below the calibrated default, and SAFETY x the largest error this module has seen on its
         # candidates and probes (this call included) -- a model whose weights make the first pass coarser widens its own margin
         # instead of failing the monitor forever.  The row passes when its k-th exact score clears the best non-candidate by eps.
-        err, gap = self._read_stats(stats)
         default = (self.RESCORE_EPS_PER_INV_TEMPERATURE_F16X1 if single else self.RESCORE_EPS_PER_INV_TEMPERATURE) / eng.spec.temperature
-        if err == err and err != float("inf"):
-            self._err_seen = max(err, self._err_seen)   # never forgotten: a rare outlier keeps the margin wide until the engine changes
-        eps = max(default, (self.SAFETY_F16X1 if single else self.SAFETY_F16X3) * self._err_seen)
-        good = err == err and err != float("inf") and gap > eps
-        self.rescore_stats["eps"] = eps
+        safety = self.SAFETY_F16X1 if single else self.SAFETY_F16X3
+        if self._index32 is not None and self._index32_engine is ex and self.DEVICE_VERDICT:
+            # Verdict and fallback ON THE DEVICE: rails_rescore_verdict folds the row stats into the calibration state and writes the
+            # REDO flag; the dense fp32 pass and its top-k are enqueued behind it under that flag as their launch predicate (no-ops
+            # unless the verification failed) and overwrite (scores, ids).  The host never waits; it looks at a snapshot of the
+            # state when the NEXT call starts (statistics, candidate margin, pause logic).
+            state = self._state()
+            E.rescore_verdict(stats, state, default, safety)
+            with E.run_predicate(state.view(torch.int32)[1:2]):
+                l32 = ex.score_dense(qpack32, B, self._index32, out=self._buf("logits", B * N, torch.float32).view(B, N))
+                E.topk(l32, k, ids=self._ids_flat, workspace=ws, out=(scores, ids))
+            self._state_host.copy_(state, non_blocking=True)
+            self._state_event.record()
+            self._state_pending = (k, kc)
+        else:
+            err, gap = self._read_stats(stats)
+            if err == err and err != float("inf"):
+                self._err_seen = max(err, self._err_seen)   # never forgotten: a rare outlier keeps the margin wide until the engine changes
+            eps = max(default, safety * self._err_seen)
+            good = err == err and err != float("inf") and gap > eps
+            self.rescore_stats["eps"] = eps
+            self._note_verdict(good, k, kc)
+            if not good:
+                return self._forward_fp32_dense(query_embeddings, k, **kwargs)
+        if self.audit_every > 0 and self.rescore_stats["calls"] % self.audit_every == 0:
+            self._audit(query_embeddings, k, scores, ids, **kwargs)
+        return scores.to(query_embeddings.dtype), ids
+
+    DEVICE_VERDICT = True     # False: the host reads the verdict (one event spin per call) -- kept for deployments without a resident fp32 index
+
+    def _note_verdict(self, good: bool, k: int, kc: int) -> None:
         self._recent.append(good)
         if not good:
             self.rescore_stats["fallbacks"] += 1
             if self._pad_scale < 4 and not (k <= 384 and kc >= 512):
                 self._pad_scale *= 2          # crowded scores or a coarse first pass: more candidates from the next call on
-            return self._forward_fp32_dense(query_embeddings, k, **kwargs)
-        if self.audit_every > 0 and self.rescore_stats["calls"] % self.audit_every == 0:
-            self._audit(query_embeddings, k, scores, ids, **kwargs)
-        return scores.to(query_embeddings.dtype), ids
+
+    def _state(self) -> torch.Tensor:
+        if self._verdict_state is None:
+            dev = self._item_embeddings.device
+            self._verdict_state = torch.zeros(8, dtype=torch.float32, device=dev)
+            self._state_host = torch.zeros(8, dtype=torch.float32).pin_memory()
+            self._state_event = torch.cuda.Event()
+            self._state_pending = None
+            self._state_seen = (0.0, 0.0)     # (calls, redone calls) already folded into rescore_stats
+        return self._verdict_state
+
+    def _absorb_state(self, wait: bool = False) -> None:
+        """Fold the device verdict of the PREVIOUS call(s) into rescore_stats / the candidate margin / the pause logic.  Non-blocking
+        unless `wait` (stats()): a snapshot that has not landed yet is picked up by a later call."""
+        if self._verdict_state is None or self._state_pending is None:
+            return
+        if wait:
+            self._state_event.synchronize()
+        elif not self._state_event.query():
+            return
+        h = self._state_host
+        calls, redone = float(h[5]), float(h[6])
+        new_redone = int(redone - self._state_seen[1])
+        new_calls = int(calls - self._state_seen[0])
+        self._state_seen = (calls, redone)
+        self._err_seen = max(self._err_seen, float(h[0]))
+        self.rescore_stats["eps"] = float(h[2])
+        k, kc = self._state_pending
+        self._state_pending = None
+        for i in range(new_calls):
+            self._note_verdict(i >= new_redone, k, kc)
+
+    def stats(self) -> Dict[str, float]:
+        """rescore_stats brought up to date with the device-side verdicts and the audit counter (synchronises)."""
+        self._absorb_state(wait=True)
+        return self.audit_summary()
 
     # Shadow audit: every AUDIT_EVERY-th verified call is ALSO run on the dense fp32 path and compared bit for bit; the counts are in
     # rescore_stats["audited" / "mismatches"] (bench.py reports them).  0 = off.  RAILS_AUDIT_EVERY overrides the default.
@@ -372,6 +432,8 @@ class MoLBruteForceTopK(MoLTopKModule):
             self._calib_engine = eng
             self._err_seen, self._pad_scale, self._pause_left = 0.0, 1, 0
             self._recent.clear()
+            self._verdict_state = None
+            self._state_pending = None
         if eng.exact is not None and self._index32_engine is not eng.exact and self.keep_dense_fp32_index is not False:
             # precision "f16x3-exact": a dense fp32 index next to the f16x3 one makes the candidates a gather (10 us) instead of
             # an index build of their raw rows (160 us), and is the fallback's index.  Same bytes again; skipped (None) when

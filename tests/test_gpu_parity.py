@@ -1013,13 +1013,13 @@ def test_f16x3_exact_equals_the_fp32_path_bit_for_bit(dev, workload, N, B, k, mo
             s, i = tk(q, k=k, **kw)
             assert torch.equal(s, r_s) and torch.equal(i, r_i)
         if B > 2 and N > 1000:     # a logit budget of two rows: the batch goes through the speculative route in slices
-            tk.MAX_LOGIT_BYTES, before = 2 * N * 4, tk.rescore_stats["calls"]
+            tk.MAX_LOGIT_BYTES, before = 2 * N * 4, tk.stats()["calls"]
             s, i = tk(q, k=k, **kw)
-            assert torch.equal(s, r_s) and torch.equal(i, r_i) and tk.rescore_stats["calls"] == before + (B + 1) // 2
+            assert torch.equal(s, r_s) and torch.equal(i, r_i) and tk.stats()["calls"] == before + (B + 1) // 2
             tk.MAX_LOGIT_BYTES = type(tk).MAX_LOGIT_BYTES
             tk.rescore_stats["calls"] = before
         if N > 1000:
-            assert tk.rescore_stats["calls"] == 2 and (tk.rescore_stats["fallbacks"] == 0 or mode == "f16-exact"), tk.rescore_stats
+            assert tk.stats()["calls"] == 2 and (tk.rescore_stats["fallbacks"] == 0 or mode == "f16-exact"), tk.rescore_stats
             print(mode, workload, N, B, k, tk.rescore_stats)
         inv = ids[0, torch.randint(0, N, (B, 7), device=dev)]
         kk = min(k, 120)
@@ -1048,9 +1048,9 @@ def test_f16x3_exact_ties_and_forced_fallback(dev, mode):
         assert torch.equal(s, r_s) and torch.equal(i, r_i)
         assert bool((r_s[:, 0] == r_s[:, 7]).all())           # the ties are real
         tk.RESCORE_EPS_PER_INV_TEMPERATURE = tk.RESCORE_EPS_PER_INV_TEMPERATURE_F16X1 = float("inf")
-        before = tk.rescore_stats["fallbacks"]
+        before = tk.stats()["fallbacks"]
         s, i = tk(q, k=204)
-        assert torch.equal(s, r_s) and torch.equal(i, r_i) and tk.rescore_stats["fallbacks"] == before + 1
+        assert torch.equal(s, r_s) and torch.equal(i, r_i) and tk.stats()["fallbacks"] == before + 1
         # without the dense fp32 index (memory-tight deployments): the candidates' raw rows are rebuilt instead of gathered
         try:
             rails_amd.MoLBruteForceTopK.KEEP_DENSE_FP32_INDEX = False
@@ -1146,6 +1146,7 @@ def test_exact_modes_speculate_only_where_it_pays(dev):
         for _ in range(20):
             s, i = tk(q, k=50)
             assert torch.equal(s, r_s) and torch.equal(i, r_i)
+            tk.stats()      # the verdicts are folded in lazily (no host wait inside forward): bring them in before the next call decides
         assert tk.rescore_stats["calls"] == 16 and tk.rescore_stats["fallbacks"] == 16 and tk.rescore_stats["paused_calls"] == 4
 
 
@@ -1218,9 +1219,9 @@ def test_exact_modes_under_stressed_gate_weights(dev, mode, gain):
         for _ in range(6):
             s, i = tk(q, k=k)
             assert torch.equal(s, r_s) and torch.equal(i, r_i)
-        print(mode, "gate gain", gain, tk.rescore_stats, "pad scale", tk._pad_scale)
+        print(mode, "gate gain", gain, tk.stats(), "pad scale", tk._pad_scale)
         if gain <= 3.0:      # the bound calibrates itself: after at most a couple of redone calls the speculation holds
-            assert tk.rescore_stats["fallbacks"] <= 2, tk.rescore_stats
+            assert tk.stats()["fallbacks"] <= 2, tk.rescore_stats
 
 
 @pytest.mark.parametrize("gain", [2.0, 3.0, 5.0])
@@ -1277,7 +1278,7 @@ def test_exact_modes_against_planted_first_pass_outliers(dev, mode):
         tk._debug_first_pass_bias = (victims.to(dev), 5.0)
         s, i = tk(q, k=k)
         assert torch.equal(s, r_s) and torch.equal(i, r_i)
-        assert tk.rescore_stats["fallbacks"] == 1 and tk.rescore_stats["eps"] > 5.0, tk.rescore_stats
+        assert tk.stats()["fallbacks"] == 1 and tk.rescore_stats["eps"] > 5.0, tk.rescore_stats
         # (b) an outlier of ordinary norm that no probe covers: only the audit notices
         Xb = Xc.unsqueeze(0).to(dev)
         r_s, r_i = ref0(q, k=k)
@@ -1291,7 +1292,7 @@ def test_exact_modes_against_planted_first_pass_outliers(dev, mode):
         lone = next(int(v) for v in (top_i[0] - 1).tolist() if int(v) not in probed)
         tk._debug_first_pass_bias = (torch.tensor([lone], device=dev), 5.0)
         s, i = tk(q, k=k)
-        if tk.rescore_stats["fallbacks"] == 0:   # the planted error went unseen by the verification ...
+        if tk.stats()["fallbacks"] == 0:   # the planted error went unseen by the verification ...
             assert not torch.equal(i, r_i)
             assert tk.audit_summary()["mismatches"] == 1, tk.rescore_stats   # ... and was caught by the audit
         else:
