@@ -278,10 +278,14 @@ int rails_merge_candidates(const int64_t* gathered, int32_t n_ranks, int32_t row
  * row_stats (rows x 2 floats, optional): [largest |exact - approx| over the row's candidates and probes (inf for a NaN), k-th exact
  * score - min candidate approx], for callers that calibrate the bound from what they observe; row_ok or row_stats may be NULL. */
 /* Launch predicate of the CALLING THREAD: while a device flag is set here, every rails_mol_score_dense / _score_candidates / rails_topk
- * launched from this thread is a no-op unless *device_flag != 0 when the kernel starts (the flag is read on the device, in stream
+ * (and rails_mol_coarse_score / rails_mol_component_score) launched from this thread is a no-op unless *device_flag != 0 when the kernel starts (the flag is read on the device, in stream
  * order).  NULL clears it.  This is how the verified modes run their dense fp32 fallback without the host reading the verdict:
  * rails_rescore_verdict writes the flag, the fallback is enqueued unconditionally behind it.  No counterpart in the reference. */
 int rails_set_run_predicate(const int32_t* device_flag);
+/* *flag |= 1 if any of the n int32 values lies outside [lo, hi]: the validity check of the fused scans' candidate counts
+ * (rails_mol_coarse_topk / rails_mol_component_topk) on the device, feeding the launch predicate of their materialising redo
+ * (rails_mol_coarse_score / rails_mol_component_score honour the predicate as well).  The caller zeroes *flag. */
+int rails_range_flag_i32(const int32_t* values, int32_t n, int32_t lo, int32_t hi, int32_t* flag, void* stream);
 
 /* Verdict of a speculate-then-verify call, on the device: from the row_stats of rails_rescore_select (rows x 2 floats) and the
  * caller's calibration state (8 floats in device memory, zero-initialised once):

@@ -176,6 +176,7 @@ PROTOTYPES = {
                                        C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rails_abi_version": (C.c_int, []),
     "rails_set_run_predicate": (C.c_int, [C.c_void_p]),
+    "rails_range_flag_i32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "rails_rescore_verdict": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "rails_filter_seen_ids": (
         C.c_int,

@@ -460,6 +460,12 @@ int rails_set_run_predicate(const int32_t* device_flag) {
   return RAILS_OK;
 }
 
+int rails_range_flag_i32(const int32_t* values, int32_t n, int32_t lo, int32_t hi, int32_t* flag, void* stream) {
+  g_err[0] = '\0';
+  if (n < 0 || (n > 0 && (!values || !flag))) { set_error("range_flag: bad argument"); return RAILS_EINVAL; }
+  return fail(range_flag(values, n, lo, hi, flag, (hipStream_t)stream), "range_flag");
+}
+
 int rails_rescore_verdict(const float* row_stats, int32_t rows, float default_eps, float safety, float* state, void* stream) {
   g_err[0] = '\0';
   if (rows <= 0 || !row_stats || !state || !(default_eps >= 0.0f) || !(safety >= 0.0f)) { set_error("rescore_verdict: bad argument"); return RAILS_EINVAL; }

@@ -70,6 +70,7 @@ struct CoarseScanArgs {
   const float* thr; int64_t thr_stride; // kScanSelect: thr[b * thr_stride], a bf16 value
   unsigned long long* keys; int cap;    // kScanSelect: keys[b * cap + sub * (cap / kSubLists) + slot]
   unsigned int* counts;                 // kScanSelect: counts[b * kSubLists + sub], candidates seen (may exceed the sub-list)
+  const int32_t* run_if;                // launch predicate (mol_kernels.h); set for the materialising scan only
 };
 
 __device__ __forceinline__ unsigned int coarse_orderable(float f) {
@@ -111,6 +112,7 @@ __device__ __forceinline__ void stage_flush(volatile StageEntry* st, volatile un
 
 template <int DC, int MODE>   // DC = d / 16 K chunks
 __global__ __launch_bounds__(kScanThreads) void coarse_scan_kernel(CoarseScanArgs a) {
+  MOL_RUN_IF(a.run_if);
   extern __shared__ __attribute__((aligned(16))) unsigned short qfrag[];   // [n_qt][DC][64 lanes][8] bf16, then thr
   const int d = a.d, B = a.B;
   const int n_qt = (B + 31) / 32;
@@ -319,6 +321,7 @@ int coarse_score(const Shape& s, const float* eq, int B, int avg, const void* ta
   CoarseScanArgs a{};
   a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.d = s.dot_product_dimension; a.avg = avg;
   a.table = static_cast<const unsigned short*>(table); a.n = n; a.scores = scores; a.ld = ld; a.stride = 1;
+  a.run_if = run_predicate();
   return launch_coarse_scan<kScanAll>(a, stream);
 }
 
@@ -396,6 +399,17 @@ size_t coarse_topk_workspace_bytes(const Shape& s, int B, int64_t n, int k_prime
   return coarse_topk_plan(B, n, k_prime, &p) ? p.total : 0;
 }
 
+// flag |= any(v[i] < lo || v[i] > hi): the validity check of a fused scan's candidate counts, on the device
+__global__ void range_flag_kernel(const int32_t* __restrict__ v, int n, int lo, int hi, int32_t* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && (v[i] < lo || v[i] > hi)) atomicOr(flag, 1);
+}
+int range_flag(const int32_t* v, int n, int lo, int hi, int32_t* flag, hipStream_t stream) {
+  if (n <= 0) return kOk;
+  hipLaunchKernelGGL(range_flag_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, v, n, lo, hi, flag);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 int coarse_topk(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, int k_prime, void* ws,
                 size_t ws_bytes, float* out_scores, int64_t* out_pos, int32_t* out_counts, int n_cu, hipStream_t stream) {
   CoarseTopkPlan p;
@@ -461,10 +475,12 @@ struct ComponentScanArgs {
   const float* thr; int64_t thr_stride;
   unsigned long long* keys; int cap;
   unsigned int* counts;
+  const int32_t* run_if;
 };
 
 template <int DC, int MODE>
 __global__ __launch_bounds__(kScanThreads) void component_scan_kernel(ComponentScanArgs a) {
+  MOL_RUN_IF(a.run_if);
   extern __shared__ __attribute__((aligned(16))) unsigned short qfrag[];   // [n_qt][DC][64][8] bf16, then bounds
   const int d = a.d, PX = a.PX;
   const int R = a.B * a.PQ;                 // query rows
@@ -590,6 +606,7 @@ int component_score(const Shape& s, const float* eq, int B, const void* table, i
   ComponentScanArgs a{};
   a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.PX = s.item_dot_product_groups; a.d = s.dot_product_dimension;
   a.table = static_cast<const unsigned short*>(table); a.n = n; a.scores = scores; a.ld = ld; a.stride = 1;
+  a.run_if = run_predicate();
   return launch_component_scan<kScanAll>(a, stream);
 }
 

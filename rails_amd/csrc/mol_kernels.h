@@ -134,6 +134,7 @@ size_t topk_workspace_bytes(int rows, int64_t n, int k);
 int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int64_t* ids, int64_t ids_row_stride,
          float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, int n_cu, hipStream_t stream);
 int pack_candidates(const float* scores, const int64_t* ids, int rows, int k_local, int k, int64_t* msg, hipStream_t stream);
+int range_flag(const int32_t* v, int n, int lo, int hi, int32_t* flag, hipStream_t stream);
 int rescore_verdict(const float* row_stats, int rows, float default_eps, float safety, float* state, hipStream_t stream);
 int rescore_select(const float* exact, int64_t ld, const float* approx, const float* approx_dense, int64_t ld_dense, const int64_t* positions,
                    const int64_t* ids, int rows, int n_ranked, int kc, int k, float margin_eps, float check_eps, float* out_scores,

@@ -398,11 +398,12 @@ class MolEngine:
         d = self.spec.dot_product_dimension
         return self._derived_table("rails_mol_coarse_build", d, index, items).view(index.n_items, d)
 
-    def coarse_scores(self, eq: torch.Tensor, table: torch.Tensor, average_queries: bool) -> torch.Tensor:
+    def coarse_scores(self, eq: torch.Tensor, table: torch.Tensor, average_queries: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """eq (B, P_Q, d) fp32 -> (B, N) fp32 holding bf16-rounded dot products (reference mol_top_k.py:351-354)."""
         B, n = eq.shape[0], table.shape[0]
         eq = _f32c(eq)
-        out = torch.empty((B, n), dtype=torch.float32, device=table.device)
+        if out is None:
+            out = torch.empty((B, n), dtype=torch.float32, device=table.device)
         with _on_device(table.device):
             _lib.check(
                 self.lib.rails_mol_coarse_score(C.byref(self.shape), _ptr(eq), B, 1 if average_queries else 0, _ptr(table), n, _ptr(out), out.stride(0), _stream()),
@@ -443,12 +444,13 @@ class MolEngine:
         px, d = self.spec.item_dot_product_groups, self.spec.dot_product_dimension
         return self._derived_table("rails_mol_component_build", px * d, index, items).view(index.n_items, px, d)
 
-    def component_scores(self, eq: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    def component_scores(self, eq: torch.Tensor, table: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """eq (B, P_Q, d) -> (B * P_Q * P_X, N) fp32 holding bf16 values, row (b * P_Q + i) * P_X + m."""
         B, n = eq.shape[0], table.shape[0]
         eq = _f32c(eq)
         rows = B * self.spec.query_dot_product_groups * self.spec.item_dot_product_groups
-        out = torch.empty((rows, n), dtype=torch.float32, device=table.device)
+        if out is None:
+            out = torch.empty((rows, n), dtype=torch.float32, device=table.device)
         with _on_device(table.device):
             _lib.check(
                 self.lib.rails_mol_component_score(C.byref(self.shape), _ptr(eq), B, _ptr(table), n, _ptr(out), out.stride(0), _stream()),
@@ -603,6 +605,13 @@ class run_predicate:
     def __exit__(self, *exc):
         _lib.load().rails_set_run_predicate(None)
         return False
+
+
+def range_flag(values: torch.Tensor, lo: int, hi: int, flag: torch.Tensor) -> None:
+    """flag |= any(values < lo or values > hi), on the device (rails_range_flag_i32); `flag` is an int32 device scalar the caller zeroed."""
+    lib = _lib.load()
+    with _on_device(values.device):
+        _lib.check(lib.rails_range_flag_i32(_ptr(values), values.numel(), int(lo), int(hi), _ptr(flag), _stream()), "rails_range_flag_i32")
 
 
 def rescore_verdict(stats: torch.Tensor, state: torch.Tensor, default_eps: float, safety: float) -> None:

@@ -447,6 +447,9 @@ class MoLBruteForceTopK(MoLTopKModule):
         return eng
 
 class MoLAvgTopK(MoLTopKModule):
+    DEVICE_REDO_BYTES = 1 << 30   # materialised score matrices up to this size are kept as the device-side redo buffer of a fused scan;
+                                  # beyond it (a 125 M-item shard: 16 GB) the counts are read on the host after the call is enqueued
+
     """Two-pass approximate top-k (reference rails/indexing/mol_top_k.py:296-429): a bf16 dot product of the
     P_Q-summed query components against the P_X-averaged item components picks `avg_top_k` candidates per query,
     which are then scored with the full MoL and cut to k.  Spans keep the reference's profiler names."""
@@ -494,6 +497,17 @@ class MoLAvgTopK(MoLTopKModule):
             if fused is not None:
                 sc, idx, counts = fused
                 k_lo, k_hi = self._avg_top_k, eng.coarse_topk_capacity(self._avg_top_k)
+                if eq.shape[0] * n * 4 <= self.DEVICE_REDO_BYTES:
+                    # the check and the redo ON THE DEVICE: a flag kernel looks at the counts, the materialising scan and its top-K'
+                    # are enqueued under that flag as their launch predicate and overwrite (sc, idx) -- no-ops unless a count was
+                    # out of range; nothing for the host to wait for (the (B, N) score buffer is recycled across calls)
+                    flag = self._buf("redo_flag", 1, torch.int32)
+                    flag.zero_()
+                    E.range_flag(counts, k_lo, k_hi, flag)
+                    with E.run_predicate(flag):
+                        coarse = eng.coarse_scores(eq, table, average_queries, out=self._buf("coarse_all", eq.shape[0] * n, torch.float32).view(eq.shape[0], n))
+                        E.topk(coarse, self._avg_top_k, out=(sc, idx))
+                    return (sc, idx) if with_scores else idx
                 check = lambda: int(counts.min()) >= k_lo and int(counts.max()) <= k_hi   # noqa: E731
                 if pending is not None:
                     pending.append(check)
@@ -592,8 +606,17 @@ class _ComponentCandidates:
         if n >= getattr(self, "fused_component_min_items", 262144) and not getattr(self, "_no_fused", False):
             fused = eng.component_topk(eq, table, k_per_group)
             if fused is not None:
-                _, pos, counts = fused
+                sc_c, pos, counts = fused
                 k_hi = eng.coarse_topk_capacity(k_per_group)
+                rows = counts.numel()
+                if rows * n * 4 <= MoLAvgTopK.DEVICE_REDO_BYTES:     # check + redo on the device, as in MoLAvgTopK._coarse_topk_from_eq
+                    flag = self._buf("redo_flag_c", 1, torch.int32)
+                    flag.zero_()
+                    E.range_flag(counts, k_per_group, k_hi, flag)
+                    with E.run_predicate(flag):
+                        scores = eng.component_scores(eq, table, out=self._buf("component_all", rows * n, torch.float32).view(rows, n))
+                        E.topk(scores, k_per_group, out=(sc_c, pos))
+                    return pos.view(eq.shape[0], -1)
                 check = lambda: int(counts.min()) >= k_per_group and int(counts.max()) <= k_hi   # noqa: E731
                 if pending is not None:
                     pending.append(check)
