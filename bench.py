@@ -257,6 +257,9 @@ def main() -> None:
     ap.add_argument("--two-pass", type=int, default=0, metavar="K'",
                     help="BASELINE config 5: MoLAvgTopK(K' per shard) = fused coarse top-K' + MoL rerank, instead of exact "
                          "brute force (the default, and the only mode the headline metric is quoted on)")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="N > 1: time the steps with batch i's all-gather + merge + filter overlapped with batch i+1's prologue + scoring "
+                         "(ShardedTopK.submit / result, two streams); without it the pipelined rate is still reported next to `value`")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -391,6 +394,19 @@ def main() -> None:
             got_ids, got_scores = step()
             assert torch.equal(ref_ids, got_ids) and torch.equal(ref_scores, got_scores)
 
+        def run_pipelined(n):
+            """n steps with the exchange of batch i (all-gather, merge) and its filter behind batch i+1's prologue + scoring."""
+            h = topk_mod.submit(q, k=min(kp, N), **kw)
+            out = None
+            for i in range(n):
+                ev_step[i].record()
+                hn = topk_mod.submit(q, k=min(kp, N), **kw) if i + 1 < n else None
+                s_, top_ = topk_mod.result(h)
+                out = E.filter_seen_ids(top_, s_, inv, k)
+                h = hn
+            return out
+
+        pipelined_headline = args.pipeline and world > 1 and not two_pass
         for _ in range(args.warmup):
             step()
         if world > 1:
@@ -399,14 +415,57 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            ev_step[i].record()
-            step(i)
+        if pipelined_headline:
+            run_pipelined(args.steps)
+        else:
+            for i in range(args.steps):
+                ev_step[i].record()
+                step(i)
         ev_step[args.steps].record()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+
+        sharded_info = None
+        if world > 1 and not two_pass:
+            # what carried the exchange, where a step's time goes (events on the launch stream, unpipelined), and the pipelined rate
+            pe = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
+            for i in range(args.steps):
+                qpack, _, _ = eng.query_pack(q, kw.get("user_ids"))
+                pe[i][0].record()
+                eng.score_dense(qpack, B, local._index, out=logits)
+                pe[i][1].record()
+                s_, top_ = E.topk(logits, min(kp, hi - lo), ids=local._ids_flat)
+                msg_ = E.pack_candidates(s_, top_, kp)
+                pe[i][2].record()
+                gathered_ = all_gather_rows(msg_)
+                pe[i][3].record()
+                s_, top_ = E.merge_candidates(gathered_, world, kp, kp)
+                E.filter_seen_ids(top_, s_, inv, k)
+                pe[i][4].record()
+            torch.cuda.synchronize()
+            phase = [sum(pe[i][j].elapsed_time(pe[i][j + 1]) for i in range(args.steps)) / args.steps for j in range(4)]
+            ref_out = step()
+            p_out = run_pipelined(2)
+            equal = bool(torch.equal(ref_out[0], p_out[0]) and torch.equal(ref_out[1], p_out[1]))
+            dist.barrier()
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            run_pipelined(args.steps)
+            torch.cuda.synchronize()
+            dist.barrier()
+            p_elapsed = time.perf_counter() - tp
+            tpp = torch.tensor([p_elapsed], dtype=torch.float64, device="cpu" if test_backend else dev)
+            dist.all_reduce(tpp, op=dist.ReduceOp.MAX)
+            sharded_info = {
+                "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(),
+                "exchange": "one all_gather_into_tensor of (B, 2k') int64 per batch" + (" (host-staged: test hook)" if test_backend else " on device tensors"),
+                "message_bytes_per_rank": B * 2 * kp * 8,
+                "phase_ms": {"score": phase[0], "select_and_pack": phase[1], "all_gather": phase[2], "merge_and_filter": phase[3]},
+                "pipelined": {"ms_per_step": float(tpp.item()) / args.steps * 1e3, "value": B * args.steps / float(tpp.item()), "unit": "queries/s",
+                              "output_equal_to_unpipelined": equal, "headline_uses_it": bool(pipelined_headline)},
+            }
         per_step_ms = [ev_step[i].elapsed_time(ev_step[i + 1]) for i in range(args.steps)]
         if two_pass:
             # the dominant kernel chain of this mode is the fused coarse top-K' (HBM-bound scan of the bf16 table):
@@ -609,6 +668,8 @@ def main() -> None:
                 "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
                 "traffic": None, "kernel_ms": score_ms, "hbm_bytes_alg_per_launch": coarse_table_bytes,
             }
+        if sharded_info is not None:
+            out["sharded"] = sharded_info
         if fast is not None:
             out["fast_path"] = fast
         if exact_fast is not None:

@@ -88,8 +88,17 @@ class ShardedTopK(TopKModule):
             self._n_local = int(item_ids_shard.numel())
         self._local_topk = local_topk
         self._merge = merge if merge is not None else _hip_merge
+        self._xstream = None     # exchange stream (all-gather + merge), created on first GPU use
 
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self.result(self.submit(query_embeddings, k, sorted, **kwargs))
+
+    # ---- two-stage form of forward: submit() enqueues this rank's part, result() the exchange ------------------------------
+    # A caller that has the next batch at hand calls submit(batch i+1) BEFORE result(batch i): the all-gather and the merge of
+    # batch i then run on a second stream while batch i+1's prologue and scoring occupy the first ("overlap
+    # it with the next batch's scoring").  Same kernels, same order of arithmetic: the output is bit-equal to forward's.
+    def submit(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs):
+        """Local scoring + local top-k + pack on the current stream -> handle for result()."""
         if k > self._n_total:
             raise RuntimeError(f"selected index k out of range (k={k}, n={self._n_total})")
         k_local = min(k, self._n_local)
@@ -100,23 +109,58 @@ class ShardedTopK(TopKModule):
             s = torch.empty((B, 0), dtype=torch.float32, device=query_embeddings.device)
             ids = torch.empty((B, 0), dtype=torch.int64, device=query_embeddings.device)
         if self._world == 1:
-            return s, ids
+            return ("done", s, ids)
         on_gpu = s.is_cuda and self._merge is _hip_merge
         msg = E.pack_candidates(s, ids, k) if on_gpu else pack_candidates(s.float(), ids, k)
-        # concatenated-along-dim-0 output: the layout both RCCL and gloo accept for all_gather_into_tensor
-        if msg.is_cuda and dist.get_backend(self._group) == "gloo":   # test setups only: stage through the host
-            host = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype)
-            dist.all_gather_into_tensor(host, msg.cpu(), group=self._group)
-            gathered = host.to(msg.device)
-        else:
-            gathered = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype, device=msg.device)
+        ready = None
+        if msg.is_cuda:
+            ready = torch.cuda.Event()
+            ready.record()
+        return ("pending", msg, ready, k, on_gpu, s.dtype)
+
+    def result(self, handle) -> Tuple[torch.Tensor, torch.Tensor]:
+        """All-gather of the per-shard candidates + merge -> (scores, ids), identical on every rank.  On the GPU both run on this
+        module's exchange stream, behind the handle's event; the current stream waits for the merge only."""
+        if handle[0] == "done":
+            return handle[1], handle[2]
+        _, msg, ready, k, on_gpu, dtype = handle
+        if not msg.is_cuda:
+            gathered = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype)
             dist.all_gather_into_tensor(gathered, msg, group=self._group)
-        if on_gpu:   # one kernel: rank-major candidates -> exact top-k (scores, ids)
-            ms, mi = E.merge_candidates(gathered, self._world, k, k)
-        else:
             all_s, all_ids = unpack_candidates(gathered.view(self._world, msg.shape[0], msg.shape[1]), k)
             ms, mi = self._merge(all_s, all_ids, k)
-        return ms.to(s.dtype), mi
+            return ms.to(dtype), mi
+        cur = torch.cuda.current_stream(msg.device)
+        if self._xstream is None:
+            self._xstream = torch.cuda.Stream(msg.device)
+        side = self._xstream
+        side.wait_event(ready)
+        msg.record_stream(side)
+        with torch.cuda.stream(side):
+            # concatenated-along-dim-0 output: the layout both RCCL and gloo accept for all_gather_into_tensor
+            if dist.get_backend(self._group) == "gloo":   # test setups only: stage through the host
+                host = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype)
+                dist.all_gather_into_tensor(host, msg.cpu(), group=self._group)
+                gathered = host.to(msg.device)
+            else:
+                gathered = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype, device=msg.device)
+                dist.all_gather_into_tensor(gathered, msg, group=self._group)
+            if on_gpu:   # one kernel: rank-major candidates -> exact top-k (scores, ids)
+                ms, mi = E.merge_candidates(gathered, self._world, k, k)
+            else:
+                all_s, all_ids = unpack_candidates(gathered.view(self._world, msg.shape[0], msg.shape[1]), k)
+                ms, mi = self._merge(all_s, all_ids, k)
+            ms = ms.to(dtype)
+        cur.wait_stream(side)
+        ms.record_stream(cur)
+        mi.record_stream(cur)
+        return ms, mi
+
+    def exchange_info(self) -> dict:
+        """What carried the exchange: backend of the process group and its size (bench.py reports it)."""
+        if not dist.is_initialized():
+            return {"backend": None, "ranks": 1}
+        return {"backend": dist.get_backend(self._group), "ranks": dist.get_world_size(self._group)}
 
 
 class ShardedMoLBruteForceTopK(ShardedTopK):
@@ -146,6 +190,13 @@ class ShardedMoLAvgTopK(ShardedTopK):
         super().__init__(mol_module, item_embeddings_shard, item_ids_shard, n_items_total, **kwargs)
         rank = dist.get_rank(self._group) if dist.is_initialized() else 0
         self._offset = shard_offset if shard_offset is not None else shard_bounds(n_items_total, self._world, rank)[0]
+        if self._global and self._world > 1 and shard_offset is not None:
+            # ties are broken by the slot in the rank-major concatenation: that is the global position order only when the shards
+            # are disjoint position ranges in rank order
+            spans = [None] * self._world
+            dist.all_gather_object(spans, (int(self._offset), int(self._offset + self._n_local)), group=self._group)
+            if any(spans[r][1] > spans[r + 1][0] for r in range(self._world - 1)):
+                raise ValueError(f"global_k_prime needs shard ranges that ascend with the rank without overlap, got {spans}")
         self._coarse_local = coarse_local if coarse_local is not None else (lambda q, **kw: self._local_module.coarse_candidates(q, **kw))
         self._rerank_local = rerank_local if rerank_local is not None else (lambda q, idx, k, **kw: self._local_module.rerank_masked(q, idx, k, **kw))
 
@@ -206,4 +257,4 @@ class ShardedMoLAvgTopK(ShardedTopK):
         else:
             all_s, all_i = unpack_candidates(gathered2.view(self._world, B, 2 * k), k)
             ms, mi = self._merge(all_s, all_i, k)
-        return ms.to(s.dtype), mi
+        return ms.to(query_embeddings.dtype), mi

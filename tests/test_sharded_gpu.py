@@ -28,7 +28,7 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _worker(rank: int, world: int, port: int, n_items: int, precision, ret):
+def _worker(rank: int, world: int, port: int, n_items: int, precision, ret, workload: str = "amzn-books"):
     import rails_amd
     from oracle import mol_oracle as O
     from rails_amd import engine as E
@@ -46,7 +46,7 @@ def _worker(rank: int, world: int, port: int, n_items: int, precision, ret):
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        cfg = O.CONFIGS["amzn-books"]
+        cfg = O.CONFIGS[workload]
         mol = build_module(cfg, O.synthetic_weights(cfg, seed=1), dev)
         mol.precision = precision
         B, k, avg_k = 9, 200, 300
@@ -62,6 +62,14 @@ def _worker(rank: int, world: int, port: int, n_items: int, precision, ret):
             full_s, full_i = rails_amd.MoLBruteForceTopK(mol, X, ids)(q, k=k)
             assert torch.equal(s, s2) and torch.equal(i, i2)
             assert torch.equal(s, full_s) and torch.equal(i, full_i), "sharded exact top-k differs from the single-device result"
+            # pipelined: batch 2 is submitted before batch 1's exchange is taken -- bit-equal to the plain calls
+            q2 = O.synthetic_queries(cfg, B, seed=6).to(dev)
+            h1 = sh.submit(q, k)
+            h2 = sh.submit(q2, k)
+            p1 = sh.result(h1)
+            p2 = sh.result(h2)
+            r2 = sh(q2, k=k)
+            assert torch.equal(p1[0], s) and torch.equal(p1[1], i) and torch.equal(p2[0], r2[0]) and torch.equal(p2[1], r2[1]), "pipelined != unpipelined"
             if precision in ("f16x3-exact", "f16-exact"):   # ... and both are the fp32 path's result, bit for bit
                 mol32 = build_module(cfg, O.synthetic_weights(cfg, seed=1), dev)
                 f32_s, f32_i = rails_amd.MoLBruteForceTopK(mol32, X, ids)(q, k=k)
@@ -97,6 +105,17 @@ def test_two_ranks_through_the_hip_modules(n_items, precision):
     assert ret[0][0] == ("nccl" if torch.cuda.device_count() >= world else "gloo")
 
 
+@pytest.mark.parametrize("precision", [None, "f16x3", "f16-exact"])
+def test_two_ranks_16x16x64(precision):
+    """BASELINE config 4's shape (L = 256: the team kernel of mol_score_wsplit.h) through the same two-rank checks: sharded ==
+    single device bit for bit, the verified mode == the fp32 path, pipelined == unpipelined, two-pass compositions."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), 20_003, precision, ret, "synthetic-16x16x64"), nprocs=world, join=True)
+    assert set(ret.keys()) == {0, 1}
+    assert torch.equal(ret[0][1], ret[1][1]) and torch.equal(ret[0][2], ret[1][2])
+
+
 def test_bench_self_spawns_two_ranks():
     """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE (how the driver may call it) must re-exec itself under
     torch.distributed.run and print one JSON line with n_gpus = 2."""
@@ -113,3 +132,6 @@ def test_bench_self_spawns_two_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong"
     assert d["config"]["n_items"] == 200000 and "roofline" in d
+    sh = d["sharded"]
+    assert sh["rccl_ranks"] == 2 and sh["backend"] in ("nccl", "gloo") and sh["pipelined"]["output_equal_to_unpipelined"] is True
+    assert set(sh["phase_ms"]) == {"score", "select_and_pack", "all_gather", "merge_and_filter"}
