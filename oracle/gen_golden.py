@@ -37,6 +37,8 @@ sys.path.insert(0, REF)
 sys.path.insert(0, REPO)
 
 import numpy as np  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _npz import savez_deterministic  # noqa: E402
 import torch  # noqa: E402
 
 from modeling.similarity_utils import create_mol_interaction_module  # noqa: E402  (reference)
@@ -222,7 +224,7 @@ def per_config_fixture(name: str, cfg: MoLConfig, seed: int, B: int = 6, N: int 
         cand = X.squeeze(0)[cand_idx]
         rows, _ = mol(q, cand, **kw)
         out["F6/cand_idx"], out["F6/logits"] = cand_idx.numpy(), rows.numpy()
-    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    savez_deterministic(os.path.join(OUT, f"{name}.npz"), **out)
     print(f"{name}: wrote {len(out)} arrays")
 
 
@@ -278,7 +280,7 @@ def harness_fixture(seed: int = 11):
         out["w/" + k] = v
     out["q"], out["X"], out["item_ids"] = q.numpy(), X.numpy(), ids.numpy()
     out["past_ids"], out["target_ids"] = past_ids.numpy(), target_ids.numpy()
-    np.savez_compressed(os.path.join(OUT, "harness.npz"), **out)
+    savez_deterministic(os.path.join(OUT, "harness.npz"), **out)
     print(f"harness: wrote {len(out)} arrays")
 
 
@@ -306,7 +308,7 @@ def full_size_fixture(name: str, cfg: MoLConfig, N: int, seed: int, B: int = 32,
     out["logits_rowsum_f64"] = logits.double().sum(1).numpy()
     out["logits_quantiles"] = torch.quantile(logits, torch.tensor([0.0, 0.01, 0.5, 0.99, 1.0]), dim=1).numpy()
     out["logits_first_row"] = logits[0].numpy()
-    np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+    savez_deterministic(os.path.join(OUT, f"{name}.npz"), **out)
     print(f"{name}: wrote {len(out)} arrays")
 
 
@@ -341,7 +343,7 @@ def mips_fixture(seed: int = 707):
         out["rows/X"], out["rows/q1"], out["rows/q3"] = Xr.numpy(), q1.numpy(), q3.numpy()
         out["rows/out1"] = dp(q1, Xr)[0].numpy()
         out["rows/out3"] = dp(q3, Xr)[0].numpy()
-    np.savez_compressed(os.path.join(OUT, "mips.npz"), **out)
+    savez_deterministic(os.path.join(OUT, "mips.npz"), **out)
     print(f"mips: wrote {len(out)} arrays")
 
 
@@ -386,7 +388,7 @@ def union_fixture(seed: int = 808):
                     torch.sort = orig_sort
             out[f"{cname}/{mname}/scores"], out[f"{cname}/{mname}/ids"] = s.numpy(), i.numpy()
             out[f"{cname}/{mname}/sorted_all_indices"] = rec["sorted"].numpy()
-    np.savez_compressed(os.path.join(OUT, "union.npz"), **out)
+    savez_deterministic(os.path.join(OUT, "union.npz"), **out)
     print(f"union: wrote {len(out)} arrays")
 
 

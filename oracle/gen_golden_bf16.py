@@ -17,6 +17,8 @@ import gen_golden as GG  # noqa: E402  (reference import + shims)
 import json  # noqa: E402
 
 import numpy as np  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _npz import savez_deterministic  # noqa: E402
 import torch  # noqa: E402
 
 from oracle.mol_oracle import CONFIGS, hash_item_table, synthetic_queries  # noqa: E402
@@ -40,7 +42,7 @@ def main():
     out = {"cfg_json": np.array(json.dumps(cfg.to_dict())), "q": q.numpy(), "X": X.numpy(), "logits_bf16_run": l16.float().numpy(),
            "logits_fp32_run_on_bf16_operands": l32.numpy(), "top200_idx_bf16_run": i16.numpy()}
     out.update({"w/" + k: v for k, v in w32.items()})
-    np.savez_compressed(os.path.join(GG.OUT, "bf16_books.npz"), **out)
+    savez_deterministic(os.path.join(GG.OUT, "bf16_books.npz"), **out)
     d = (l16.float() - l32).abs()
     print("bf16 run vs fp32 run on the same bf16 operands: max |d| = %.4f, mean %.5f" % (float(d.max()), float(d.mean())))
 

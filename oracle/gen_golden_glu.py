@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import gen_golden as GG  # noqa: E402,F401  (puts /root/reference on sys.path + shims)
 
 import numpy as np  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _npz import savez_deterministic  # noqa: E402
 import torch  # noqa: E402
 
 from rails.similarities.layers import GeGLU, SwiGLU  # noqa: E402
@@ -31,7 +33,7 @@ def main():
             y = m(x)
         out[f"{name}.x"], out[f"{name}.w"], out[f"{name}.b"], out[f"{name}.y"] = x.numpy(), m._w.detach().numpy(), m._b.detach().numpy(), y.numpy()
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "glu.npz")
-    np.savez_compressed(path, **out)
+    savez_deterministic(path, **out)
     print("wrote", os.path.normpath(path), {k: v.shape for k, v in out.items() if k.endswith(".y")})
 
 

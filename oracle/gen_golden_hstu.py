@@ -25,6 +25,8 @@ sys.path.insert(0, REF)
 sys.path.insert(0, REPO)
 
 import numpy as np  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _npz import savez_deterministic  # noqa: E402
 import torch  # noqa: E402
 
 
@@ -138,7 +140,7 @@ def main():
                   "meta/torch_version": np.array(torch.__version__)}
         for k, v in sd.items():
             arrays["w/" + k] = v.numpy()
-        np.savez_compressed(os.path.join(OUT, f"hstu_{name}.npz"), **arrays)
+        savez_deterministic(os.path.join(OUT, f"hstu_{name}.npz"), **arrays)
         print(f"  wrote tests/golden/hstu_{name}.npz ({os.path.getsize(os.path.join(OUT, f'hstu_{name}.npz')) // 1024} KB)")
 
 

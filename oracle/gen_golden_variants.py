@@ -22,6 +22,8 @@ import gen_golden as GG  # noqa: E402  (sets up the reference import + shims)
 import json  # noqa: E402
 
 import numpy as np  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _npz import savez_deterministic  # noqa: E402
 import torch  # noqa: E402
 
 from modeling.similarity_utils import create_mol_interaction_module  # noqa: E402  (reference)
@@ -74,7 +76,7 @@ def main():
         out[f"{name}/logits"], out[f"{name}/Eq"], out[f"{name}/Ex"], out[f"{name}/row_logits"] = logits.numpy(), eq.numpy(), ex.numpy(), rows.numpy()
         for k, v in mol.state_dict().items():
             out[f"{name}/w/{k}"] = v.detach().numpy()
-    np.savez_compressed(os.path.join(GG.OUT, "variants.npz"), **out)
+    savez_deterministic(os.path.join(GG.OUT, "variants.npz"), **out)
     print("wrote variants.npz:", {k: v.shape for k, v in out.items() if k.endswith("logits")})
 
 
