@@ -64,10 +64,6 @@ static bool shape_supported(const Shape* s) {
     set_error("gating hidden dims must be > 0 for the gate parts that exist");
     return false;
   }
-  if (s->gating_combination == RAILS_COMBINE_NONE && (is_split(*s) || num_logits(*s) > 64)) {
-    set_error("gating_combination none is built for the exact-fp32 register-resident kernels only (not f16x3, not 16x16x64)");
-    return false;
-  }
   if (s->precision != RAILS_PRECISION_FP32 && s->precision != RAILS_PRECISION_F16X3 && s->precision != RAILS_PRECISION_F16X1) {
     set_error("precision must be RAILS_PRECISION_FP32, _F16X3 or _F16X1, got %d", s->precision);
     return false;

@@ -35,10 +35,6 @@
 #ifndef RAILS_F16_SINGLE
 #define RAILS_F16_SINGLE 0
 #endif
-#ifndef RAILS_F16_GEMM1_MC
-#define RAILS_F16_GEMM1_MC 16   // item groups whose B fragments of a GEMM1 K-step are requested together when P_X > 8 (16x16x64, one wave per SIMD:
-                                // 4 -> 16 = four dependent round trips per unit instead of sixteen; f16x3 10.2 -> 9.2 ms, one-product 6.2 -> 5.75 ms at 400 k items)
-#endif
 #ifndef RAILS_F16_TIGHT_PF
 #define RAILS_F16_TIGHT_PF 2   // epilogue operand ring depth of the TIGHT stream
 #endif
@@ -151,68 +147,28 @@ __device__ __forceinline__ float nsilu(float t) {
 #endif
 }
 
-// Views of the split gate pack (rails_mol_pack_gate_weights with precision f16x3): [W1 hi][W1 lo][W2 hi][W2 lo][b1][b2].
-// BIG = false: the whole pack sits in LDS.  BIG = true (16x16x64: the pack is 256 KiB): W1 and the biases in LDS, the W2
-// fragments are streamed from L2 through a deeper register ring.
-template <class G, bool BIG>
+// Views of the split gate pack (rails_mol_pack_gate_weights with precision f16x3): [W1 hi][W1 lo][W2 hi][W2 lo][b1][b2], the whole
+// pack in LDS.  (L = 256, whose pack is 256 KiB, runs the team kernel of mol_score_wsplit.h instead.)
+template <class G>
 struct SplitPack {
   const h8* w1hi; const h8* w1lo; const h8* w2hi; const h8* w2lo; const float* b1; const float* b2;
   float m1;   // -1.0, opaque (split_pair)
-  __amdgpu_buffer_rsrc_t grsrc;   // BIG: the whole pack in global memory as a buffer resource
   static constexpr int N8 = G::kW1Floats / 8;   // h8 fragments per half of a weight matrix (hi or lo)
-  // The one-product build never touches a lo half: for BIG it stages W1 hi only (64 KiB); W2 hi is streamed like in the f16x3 build
-  // (W2 hi in LDS as well measured the same once GEMM1 asks for a whole K-step of the tile at a time).
-  static constexpr bool kBigHiOnly = BIG && RAILS_F16_SINGLE;
-  static constexpr int kLdsFloats = kBigHiOnly ? G::kW1Floats / 2 + G::TH * 32 + G::L
-                                               : (BIG ? G::kW1Floats + G::TH * 32 + G::L : G::kWpackFloats);
+  static constexpr int kLdsFloats = G::kWpackFloats;
   __device__ __forceinline__ SplitPack(const float* smem, const float* gpack) {
     m1 = -1.0f;
     asm volatile("" : "+v"(m1));
     w1hi = reinterpret_cast<const h8*>(smem);
     w1lo = w1hi + N8;
-    if constexpr (BIG) {
-      // buffer addressing (SGPR descriptor + scalar byte offset + one per-lane VGPR offset): with flat addressing the
-      // compiler keeps -- and spills -- one 64-bit address pair per streamed fragment
-      grsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gpack), 0, (int)(G::kWpackFloats * sizeof(float)), 0x00020000);
-      w2hi = w2lo = nullptr;
-      b1 = smem + (kBigHiOnly ? G::kW1Floats / 2 : G::kW1Floats);
-      if constexpr (kBigHiOnly) w1lo = nullptr;
-    } else {
-      w2hi = w1lo + N8;
-      w2lo = w2hi + N8;
-      b1 = smem + G::kW1Floats + G::kW2Floats;
-    }
+    w2hi = w1lo + N8;
+    w2lo = w2hi + N8;
+    b1 = smem + G::kW1Floats + G::kW2Floats;
     b2 = b1 + G::TH * 32;
   }
   // W2 fragment f (hi or lo part) of this lane
-  __device__ __forceinline__ h8 w2frag(bool hi_part, int f, int lane) const {
-    if constexpr (BIG) {
-      typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-      const u4 v = __builtin_amdgcn_raw_buffer_load_b128(grsrc, lane * 16, ((hi_part ? 2 : 3) * (N8 / 64) + f) * 1024, 0);
-      return __builtin_bit_cast(h8, v);
-    } else {
-      return (hi_part ? w2hi : w2lo)[f * 64 + lane];
-    }
-  }
+  __device__ __forceinline__ h8 w2frag(bool hi_part, int f, int lane) const { return (hi_part ? w2hi : w2lo)[f * 64 + lane]; }
   template <int NW>
-  static __device__ __forceinline__ void stage(const ScoreArgs& p, float* smem) {
-    if constexpr (kBigHiOnly) {
-      const float4* s1 = reinterpret_cast<const float4*>(p.wpack);                     // W1 hi
-      const float4* sb = reinterpret_cast<const float4*>(p.wpack + G::kW1Floats + G::kW2Floats);
-      float4* dst = reinterpret_cast<float4*>(smem);
-      for (int i = threadIdx.x; i < G::kW1Floats / 8; i += NW * 64) dst[i] = s1[i];
-      for (int i = threadIdx.x; i < (G::TH * 32 + G::L) / 4; i += NW * 64) dst[G::kW1Floats / 8 + i] = sb[i];
-    } else if constexpr (BIG) {
-      const float4* src = reinterpret_cast<const float4*>(p.wpack);
-      float4* dst = reinterpret_cast<float4*>(smem);
-      for (int i = threadIdx.x; i < G::kW1Floats / 4; i += NW * 64) dst[i] = src[i];
-      const float4* srcb = reinterpret_cast<const float4*>(p.wpack + G::kW1Floats + G::kW2Floats);
-      float4* dstb = reinterpret_cast<float4*>(smem + G::kW1Floats);
-      for (int i = threadIdx.x; i < (G::TH * 32 + G::L) / 4; i += NW * 64) dstb[i] = srcb[i];
-    } else {
-      stage_weights<G, NW>(p, smem);
-    }
-  }
+  static __device__ __forceinline__ void stage(const ScoreArgs& p, float* smem) { stage_weights<G, NW>(p, smem); }
 };
 
 // GEMM1 on pre-split operands: eq = [ks][hi|lo][lane] h8 (query pack), tEx = [m][ks][hi|lo][lane] h8 (tile, LDS or HBM).
@@ -224,8 +180,8 @@ struct SplitPack {
 template <class G, int PX, int DD, bool BULK = false>
 __device__ __forceinline__ void gemm1_presplit(f32x16 (&D1)[PX], const h8* __restrict__ eq, const h8* tEx, int lane) {
   static_assert(DD % 16 == 0, "f16x3 GEMM1 walks K in steps of 16");
-  constexpr int MC = PX > 8 ? RAILS_F16_GEMM1_MC : PX;
-  static_assert(PX % MC == 0, "item groups come in whole chunks");
+  static_assert(PX <= 8, "the register-resident unit holds all item groups of a K-step at once");
+  constexpr int MC = PX;
 #pragma unroll
   for (int m = 0; m < PX; ++m)
 #pragma unroll
@@ -308,6 +264,7 @@ struct Epi {
   static constexpr int kPF = PF;
   f32x16 D3[G::TL];   // -log2e * gqi on entry; u after pass 1
   float den, num;
+  int none;           // gating_combination "none" (similarity_fn.py:187-197): w = gq + gi + gqi, no silu
   const float* gq;    // this query's -log2e * gq row, lane half's part ([hi][e] layout)
   float2 gi_r[PF], gq_r[PF];
   // gi fragment [ec = e/4][lane][4]: pair P is floats (e%4, e%4+1), e = 2P, of the lane's float4
@@ -317,8 +274,8 @@ struct Epi {
     gi_r[P % PF] = *reinterpret_cast<const float2*>(tGi + ((e / 4) * 64 + lane) * 4 + e % 4);
     gq_r[P % PF] = *reinterpret_cast<const float2*>(gq + e);
   }
-  __device__ __forceinline__ void reset(const float* gq_, const float* tGi, int lane) {
-    den = 0.0f; num = 0.0f; gq = gq_;
+  __device__ __forceinline__ void reset(const float* gq_, const float* tGi, int lane, int none_ = 0) {
+    den = 0.0f; num = 0.0f; gq = gq_; none = none_;
     static_for<(PF < G::E / 2 ? PF : G::E / 2)>([&](auto pc) { fetch<decltype(pc)::value>(tGi, lane); });
   }
 };
@@ -328,8 +285,13 @@ __device__ __forceinline__ void epi_p1(EP& s, const float* tGi, int lane) {
   constexpr int e = 2 * P, PF = EP::kPF;
   const float2 gi = s.gi_r[P % PF], gq = s.gq_r[P % PF];
   if constexpr (P + PF < G::E / 2) s.template fetch<P + PF>(tGi, lane);
-  s.D3[e / 16][e % 16] = nsilu(__builtin_fmaf(gq.x, gi.x, s.D3[e / 16][e % 16]));
-  s.D3[e / 16][e % 16 + 1] = nsilu(__builtin_fmaf(gq.y, gi.y, s.D3[e / 16][e % 16 + 1]));
+  if (s.none) {   // u = -log2e * (gq + gi + gqi): gq and gqi arrive prescaled, gi does not
+    s.D3[e / 16][e % 16] = __builtin_fmaf(gi.x, -kLog2e, gq.x + s.D3[e / 16][e % 16]);
+    s.D3[e / 16][e % 16 + 1] = __builtin_fmaf(gi.y, -kLog2e, gq.y + s.D3[e / 16][e % 16 + 1]);
+  } else {
+    s.D3[e / 16][e % 16] = nsilu(__builtin_fmaf(gq.x, gi.x, s.D3[e / 16][e % 16]));
+    s.D3[e / 16][e % 16 + 1] = nsilu(__builtin_fmaf(gq.y, gi.y, s.D3[e / 16][e % 16 + 1]));
+  }
 }
 // pass 2:  ex = 2^(-u) = softmax numerator;  den += ex;  num += ex * cl   (cl of this query: D1 registers R0 + ...)
 template <class G, int PX, int R0, int P, class EP>
@@ -357,7 +319,7 @@ __device__ __forceinline__ float epi_final(EP& s, const f32x16 (&D1)[PX]) {
   // The guard sits well below FLT_MAX: with den near 1e38 the sum is still finite, but num = sum ex * cl (|cl| <= 1/tau) overflows
   // first and 1/den is a denormal that v_rcp flushes to zero -- NaNs and zeros for gate logits just under the exp overflow
   // (found with pair-gate weights x 3: 1 084 non-finite logits of 2.4 M; x 5 and x 10 overflowed den itself and were caught).
-  if (__builtin_amdgcn_ballot_w64(!(den < 1.0e30f)) != 0) {   // an exp got large somewhere in this wave: the stable form
+  if (__builtin_amdgcn_ballot_w64(!(den < 1.0e30f && den > 1.0e-30f)) != 0) {   // an exp got large (or, with "none", all of them tiny) somewhere in this wave: the stable form
     float mn = INFINITY;
 #pragma unroll
     for (int e = 0; e < G::E; ++e) mn = __builtin_fminf(mn, s.D3[e / 16][e % 16]);
@@ -529,70 +491,6 @@ __device__ __forceinline__ void y_end(const YS& st, f32x16 (&D3)[G::TL]) {
   }
 }
 
-// ---- BIG (L = 256, 16x16x64): stage Y and the epilogue in two halves of the logit axis -------------------------------
-// D1 alone is 256 registers per lane, so GEMM3's accumulators exist one half (TL/2 row tiles = 64 registers) at a time:
-//   silu + split of the whole hidden layer, in place of D2 (same 64 registers, now packed f16 hi/lo)
-//   per half:  GEMM3 of the half's row tiles (W2 fragments streamed from L2, three groups in flight)
-//              -> u, this half's minimum, ex = 2^(min - u), den_h, num_h -> folded into the running (min, den, num)
-// i.e. an online softmax across the two halves: exact and overflow-free like the reference's, no fallback path needed.
-template <class G, int PX, int R0, int HALF, class WP>
-__device__ __forceinline__ void big_half(const f32x16 (&D1)[PX], const u32x4v (&hh)[G::F / 8], const u32x4v (&hl)[G::F / 8],
-                                         const WP& w, const float* tGi, const float* gq, int lane, int hi, float& mn, float& den, float& num) {
-  constexpr int NT = G::TL / 2, NYS = G::F / 8, EH = G::E / 2, E0 = HALF * EH;   // row tiles / K-steps / per-lane logits of the half
-  using S = Seq<NT, NYS>;
-  f32x16 D3[NT];
-#pragma unroll
-  for (int v = 0; v < NT; ++v)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) D3[v][r] = w.b2[hi * G::E + E0 + v * 16 + r];
-  // fragment f = ks * NT + local tile  ->  global fragment ks * TL + HALF * NT + local tile
-  auto W = [&](bool hi_part, int f) { return w.w2frag(hi_part, (f / NT) * G::TL + HALF * NT + f % NT, lane); };
-  WSlots<4> ws;   // four groups of W2 fragments in flight (L2 latency ~ 3 groups of MFMAs; measured 3: 10.7 ms, 4: 10.1, 6: 10.4 at 400 k items)
-  seq_begin<S>(ws, W);
-  // operands of the first logit pairs of the epilogue: requested before the GEMM, consumed after it
-  constexpr int PF = 16;   // gi comes from HBM/L2 here (direct shell): twice the usual prefetch distance
-  float2 gi_r[PF], gq_r[PF];
-  auto fetch = [&](auto pc) {
-    constexpr int P = decltype(pc)::value, e = E0 + 2 * P;
-    gi_r[P % PF] = *reinterpret_cast<const float2*>(tGi + ((e / 4) * 64 + lane) * 4 + e % 4);
-    gq_r[P % PF] = *reinterpret_cast<const float2*>(gq + e);
-  };
-  static_for<PF>(fetch);
-  static_for<NYS>([&](auto kc) {
-    constexpr int KS = decltype(kc)::value;
-    static_for<3 * NT>([&](auto ic) {
-      seq_mfma<S, 3 * NT * KS + decltype(ic)::value>(D3, ws, __builtin_bit_cast(h8, hh[KS]), __builtin_bit_cast(h8, hl[KS]), W);
-    });
-    __builtin_amdgcn_sched_barrier(0);
-  });
-  // pass 1: u = t2 / (1 + 2^t2), t2 = -log2e * (gq * gi + gqi); minimum of the half
-  float hmn = INFINITY;
-  static_for<EH / 2>([&](auto pc) {
-    constexpr int P = decltype(pc)::value, el = 2 * P;
-    const float2 gi = gi_r[P % PF], gqv = gq_r[P % PF];
-    if constexpr (P + PF < EH / 2) fetch(std::integral_constant<int, P + PF>{});
-    const float u0 = nsilu(__builtin_fmaf(gqv.x, gi.x, D3[el / 16][el % 16]));
-    const float u1 = nsilu(__builtin_fmaf(gqv.y, gi.y, D3[el / 16][el % 16 + 1]));
-    D3[el / 16][el % 16] = u0;
-    D3[el / 16][el % 16 + 1] = u1;
-    hmn = __builtin_fminf(__builtin_fminf(hmn, u0), u1);
-  });
-  hmn = __builtin_fminf(hmn, swap32(hmn));
-  // fold into the running softmax state: everything accumulated so far is rescaled to the new minimum (first half: mn = +inf -> factor 0)
-  const float mnew = __builtin_fminf(mn, hmn);
-  const float scale = f_exp2(mnew - mn);
-  den *= scale;
-  num *= scale;
-  mn = mnew;
-#pragma unroll
-  for (int el = 0; el < EH; ++el) {
-    const int e = E0 + el;
-    const float ex = f_exp2(mn - D3[el / 16][el % 16]);
-    den += ex;
-    num = __builtin_fmaf(ex, D1[e / G::RPQ][R0 + e % G::RPQ], num);
-  }
-}
-
 #ifdef RAILS_F16_PHASES   // tools/f16_phases.sh: shader-clock stamps of workgroup 0 / wave 0's units (the last one stays)
 static __device__ long long g_f16_phase[32];
 #define F16_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0 && item0 == 32 * 20 * (int64_t)gridDim.x) g_f16_phase[i] = (long long)clock64(); } while (0)
@@ -603,17 +501,16 @@ static __device__ long long g_f16_phase[32];
 // OVERLAP: stage X of query Q+1 carries the epilogue of query Q (needs D2 and D3 of two queries live at once).
 // TIGHT:   the accumulators alone fill the register budget (8x8x32 at two waves per SIMD: 224 of 256): no operand double
 //          buffering in stage Y and no pinned order -- the compiler's own schedule fits without spilling, a pinned one does not.
-// BIG:     16x16x64 -- the gate pack does not fit LDS (SplitPack), W2 fragments go through a 3-deep register ring.
-template <bool OVERLAP, bool TIGHT, bool BIG = false>
+template <bool OVERLAP, bool TIGHT>
 struct F16Unit {
   template <class G>
-  static constexpr int kLdsWeightFloats = SplitPack<G, BIG>::kLdsFloats;
+  static constexpr int kLdsWeightFloats = SplitPack<G>::kLdsFloats;
   template <class G, int NW>
-  static __device__ __forceinline__ void stage(const ScoreArgs& p, float* smem) { SplitPack<G, BIG>::template stage<NW>(p, smem); }
+  static __device__ __forceinline__ void stage(const ScoreArgs& p, float* smem) { SplitPack<G>::template stage<NW>(p, smem); }
 
   template <class G, int PX, int DD, bool BULK = false>
   static __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float* __restrict__ eq, const float4* tEx, int lane) {
-    gemm1_presplit<G, PX, DD, BULK && !BIG>(D1, reinterpret_cast<const h8*>(eq), reinterpret_cast<const h8*>(tEx), lane);
+    gemm1_presplit<G, PX, DD, BULK>(D1, reinterpret_cast<const h8*>(eq), reinterpret_cast<const h8*>(tEx), lane);
   }
 
   template <class G, int PX>
@@ -622,7 +519,7 @@ struct F16Unit {
     constexpr int NXM = (G::E / 8) * G::TH * 3;   // MFMAs of stage X
     constexpr int NYM = (G::F / 8) * G::TL * 3;   // MFMAs of stage Y
     constexpr int NYS = G::F / 8;                 // K-steps of stage Y
-    const SplitPack<G, BIG> w(smem, p.wpack);
+    const SplitPack<G> w(smem, p.wpack);
     const float* tGi = reinterpret_cast<const float*>(tGi4);
     const int64_t item = item0 + x;
     const bool lane_stores = hi == 0 && item < p.n_items;
@@ -635,7 +532,7 @@ struct F16Unit {
     f32x16 D2[G::TH];
     Epi<G, (TIGHT ? RAILS_F16_TIGHT_PF : 8)> ep;   // TIGHT has no registers to spare for a deeper operand ring (and its epilogue is not fenced: the compiler hoists)
     XState<G> xs;
-    YState<G, (BIG ? 3 : 1)> ys;
+    YState<G, 1> ys;
     auto stage_x_alone = [&](auto qc) {   // GEMM2 with nothing to hide it under but the operand splits
       constexpr int Q = decltype(qc)::value;
       init_d2<G>(D2, w, hi);
@@ -675,35 +572,6 @@ struct F16Unit {
       return epi_final<G, PX, Q * G::RPQ>(ep, D1);
     };
 
-    if constexpr (BIG) {
-      static_for<G::QT>([&](auto qc) {
-        constexpr int Q = decltype(qc)::value;
-        const int q = g * G::QT + Q;
-        if (only < 0 || q == only) {
-          F16_STAMP(4 * Q);
-          stage_x_alone(qc);
-          F16_STAMP(4 * Q + 1);
-          u32x4v hh[NYS], hl[NYS];   // the hidden layer as packed f16 hi / lo operands, in the registers D2 frees
-          static_for<4 * NYS>([&](auto sc) {
-            constexpr int SL = decltype(sc)::value, ks = SL / 4, pr = SL % 4, f = 8 * ks + 2 * pr;
-            unsigned h, l;
-            split_pair(nsilu(D2[f / 16][f % 16]), nsilu(D2[f / 16][f % 16 + 1]), w.m1, h, l);
-            hh[ks][pr] = h;
-            hl[ks][pr] = l;
-          });
-          F16_STAMP(4 * Q + 2);
-          float mn = INFINITY, den = 0.0f, num = 0.0f;
-          big_half<G, PX, Q * G::RPQ, 0>(D1, hh, hl, w, tGi, gq_of(q), lane, hi, mn, den, num);
-          big_half<G, PX, Q * G::RPQ, 1>(D1, hh, hl, w, tGi, gq_of(q), lane, hi, mn, den, num);
-          den += swap32(den);
-          num += swap32(num);
-          const float rden = __builtin_amdgcn_rcpf(den);
-          store(q, (num * rden) / fmaxf(den * rden, 1e-6f));
-          F16_STAMP(4 * Q + 3);
-        }
-      });
-      return;
-    }
     if (only >= 0 || !OVERLAP || (g + 1) * G::QT > p.B) {
       // per-row candidates (one query of the group), a group that reaches past the batch end (small batches: skip the padding
       // queries), or the cross-query overlap switched off: query by query
@@ -714,7 +582,7 @@ struct F16Unit {
           F16_STAMP(4 * Q);
           stage_x_alone(qc);
           F16_STAMP(4 * Q + 1);
-          ep.reset(gq_of(q), tGi, lane);
+          ep.reset(gq_of(q), tGi, lane, p.combine_none);
           stage_y(qc);
           F16_STAMP(4 * Q + 2);
           store(q, epilogue_alone(qc));
@@ -731,7 +599,7 @@ struct F16Unit {
     static_for<G::QT>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       const int q = g * G::QT + Q;
-      ep.reset(gq_of(q), tGi, lane);
+      ep.reset(gq_of(q), tGi, lane, p.combine_none);
       stage_y(qc);
       F16_STAMP(2 + 2 * Q);
       if constexpr (Q + 1 < G::QT) {

@@ -178,14 +178,19 @@ struct WsF16 {
       float t[4], r[4], ex[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) t[j] = __builtin_fmaf(gqv[j], giv[j], D3[(e0 + j) / 16][(e0 + j) % 16]);
+      if (combine_none) {   // gating_combination "none": u = -log2e * (gq + gi + gqi); gq and gqi arrive prescaled, gi does not
 #pragma unroll
-      for (int j = 0; j < 4; ++j) r[j] = f_exp2(t[j]);
+        for (int j = 0; j < 4; ++j) t[j] = __builtin_fmaf(giv[j], -kLog2e, gqv[j] + D3[(e0 + j) / 16][(e0 + j) % 16]);
+      } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) r[j] += 1.0f;
+        for (int j = 0; j < 4; ++j) r[j] = f_exp2(t[j]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) r[j] = f_rcp(r[j]);
+        for (int j = 0; j < 4; ++j) r[j] += 1.0f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) t[j] *= r[j];   // u = t2 / (1 + 2^t2)
+        for (int j = 0; j < 4; ++j) r[j] = f_rcp(r[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] *= r[j];   // u = t2 / (1 + 2^t2)
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) ex[j] = f_exp2(-t[j]);
 #pragma unroll
@@ -214,7 +219,7 @@ struct WsF16 {
       nm += swap32(nm);
       float mn = 0.0f;
       // guard well below FLT_MAX: see epi_final (mol_score_f16_unit.h)
-      if (__builtin_amdgcn_ballot_w64(!(dn < 1.0e30f)) != 0) {   // an exp got large somewhere in this wave: the stable form
+      if (__builtin_amdgcn_ballot_w64(!(dn < 1.0e30f && dn > 1.0e-30f)) != 0) {   // an exp got large (or, with "none", all tiny) somewhere in this wave: the stable form
         mn = INFINITY;
 #pragma unroll
         for (int e = 0; e < EW; ++e) mn = __builtin_fminf(mn, D3[e / 16][e % 16]);

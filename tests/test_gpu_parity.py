@@ -757,14 +757,10 @@ def _module_for(cfg, w, dev, precision):
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_model_variants_against_the_reference(dev, precision):
     """tests/golden/variants.npz: the reference's outputs for a plain-Linear query projection (8x8x64), a GLU item projection
-    (8x4x32), gating_combination_type "none" (16x4x32, exact-fp32 only) and a 64-wide pair gate (8x4x64)."""
+    (8x4x32), gating_combination_type "none" (16x4x32, both precisions) and a 64-wide pair gate (8x4x64)."""
     from tests._fixtures import variant_cases
 
     for name, cfg, w, a in variant_cases():
-        if precision == "f16x3" and cfg.gating_combination_type == "none":
-            with pytest.raises(NotImplementedError):
-                _module_for(cfg, w, dev, precision).engine()
-            continue
         mol = _module_for(cfg, w, dev, precision)
         with torch.inference_mode():
             logits, _ = mol(a["q"].to(dev), a["X"].to(dev))
@@ -1297,3 +1293,22 @@ def test_exact_modes_against_planted_first_pass_outliers(dev, mode):
             assert tk.audit_summary()["mismatches"] == 1, tk.rescore_stats   # ... and was caught by the audit
         else:
             assert torch.equal(s, r_s) and torch.equal(i, r_i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_gating_combination_none_at_256_logits(dev, precision):
+    """gating_combination_type "none" (reference rails/similarities/mol/similarity_fn.py:187-197) on the 16x16x64 team kernel, both
+    precisions, against the oracle (whose "none" branch is pinned on the reference by tests/golden/variants.npz at 16x4x32)."""
+    import dataclasses
+
+    cfg = dataclasses.replace(O.CONFIGS["synthetic-16x16x64"], gating_combination_type="none")
+    w = O.synthetic_weights(cfg, seed=13)
+    N, B = 777, 5
+    X = torch.from_numpy(O.hash_item_table(18, 0, N, cfg.item_embedding_dim))
+    q = O.synthetic_queries(cfg, B, seed=31)
+    ref = O.mol_logits(cfg, w, q, X.unsqueeze(0))
+    mol = _module_for(cfg, w, dev, precision)
+    with torch.inference_mode():
+        got, _ = mol(q.to(dev), X.unsqueeze(0).to(dev))
+    assert float((got.cpu() - ref).abs().max()) <= LOGIT_TOL

@@ -14,7 +14,8 @@ from oracle import mol_oracle as O
 ap = argparse.ArgumentParser()
 ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--steps", type=int, default=200)
-ap.add_argument("--precision", default=None)
+ap.add_argument("--precision", default=None, help="fp32 (default) | f16x3 | f16x3-exact | f16-exact (the module's verified route)")
+ap.add_argument("--pipeline", action="store_true", help="exchange (copy + merge + filter) of step i on a second stream, behind step i+1's scoring")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 cfg = O.CONFIGS["amzn-books"]
@@ -39,22 +40,46 @@ with torch.inference_mode():
     eng = tk._bind()
     logits = torch.empty((B, hi - lo), dtype=torch.float32, device=dev)
 
-    def step():
-        qpack, _, _ = eng.query_pack(q, None)
-        eng.score_dense(qpack, B, tk._index, out=logits)
-        s, top = E.topk(logits, min(kp, hi - lo), ids=tk._ids_flat)
+    tk.SPECULATE_MIN_ITEMS = 0
+    side = torch.cuda.Stream(dev)
+
+    def local_part():
+        if a.precision and a.precision.endswith("-exact"):
+            s, top = tk(q, k=min(kp, hi - lo))
+        else:
+            qpack, _, _ = eng.query_pack(q, None)
+            eng.score_dense(qpack, B, tk._index, out=logits)
+            s, top = E.topk(logits, min(kp, hi - lo), ids=tk._ids_flat)
+        return E.pack_candidates(s, top, kp) if a.world > 1 else (s, top)
+
+    def exchange(msg):
         if a.world > 1:
-            msg = E.pack_candidates(s, top, kp)
             gathered = msg.repeat(a.world, 1)
             s, top = E.merge_candidates(gathered, a.world, kp, kp)
+        else:
+            s, top = msg
         return E.filter_seen_ids(top, s, inv, k)
 
-    for _ in range(5):
-        step()
+    def run(n):
+        if not a.pipeline:
+            for _ in range(n):
+                exchange(local_part())
+            return
+        cur = torch.cuda.current_stream(dev)
+        msg = local_part()
+        for i in range(n):
+            ev = torch.cuda.Event(); ev.record()
+            nxt = local_part() if i + 1 < n else None
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                exchange(msg)
+            msg = nxt
+        cur.wait_stream(side)
+
+    run(5)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
+    run(a.steps)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-print(f"world={a.world} shard={hi - lo} items: {dt * 1e3:.3f} ms/step (no RCCL latency) -> {B / dt:.0f} q/s if all ranks match")
+print(f"world={a.world} shard={hi - lo} items precision={a.precision or 'fp32'} pipeline={a.pipeline}: {dt * 1e3:.3f} ms/step (no RCCL latency) -> {B / dt:.0f} q/s if all ranks match")
