@@ -178,6 +178,15 @@ def measurement_matrix(mol, X, ids, q, kw, inv, cfg, n_items: int, steps: int, d
     return points
 
 
+def committed_traffic(key: str):
+    """HBM bytes per launch of a scoring kernel from the committed PMC passes (profiles/pmc_summary.json; not collected in the run)."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary.json"))).get(key)
+        return rec and rec.get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def quick_workload(name: str, B: int, k: int, kp: int, steps: int, dev, items: int = 0, precision: str = "fp32") -> dict:
     """Secondary measurement of another BASELINE.json config on one GPU (same step definition, fewer steps)."""
     from oracle import mol_oracle as O
@@ -226,14 +235,19 @@ def quick_workload(name: str, B: int, k: int, kp: int, steps: int, dev, items: i
         torch.cuda.synchronize()
         score_ms = e0.elapsed_time(e1) / steps   # prologue + scoring kernel
     tf = B * N * flops_per_pair(cfg) / (score_ms * 1e-3) / 1e12
+    traffic = None
+    if name == "synthetic-16x16x64" and N == 400_000 and B == 32:
+        traffic = committed_traffic("synthetic-16x16x64:N400k:B32:r03:" + {"fp32": "fp32", "f16x3": "f16x3", "f16-exact": "f16x1"}.get(precision, precision))
+    tr = {"traffic": traffic, "traffic_source": "profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the scoring kernel on this workload; FETCH_SIZE x 2 on gfx950; not collected in this run)",
+          "hbm_bytes_alg_per_launch": N * bytes_per_item_fp32(cfg) + B * N * 4} if traffic else {}
     if precision.endswith("-exact"):   # verified fast mode: output identical to fp32 (tests); the first pass is not a parity kernel, no roofline claim
         return {"workload": f"{name} {cfg.query_dot_product_groups}x{cfg.item_dot_product_groups}x{cfg.dot_product_dimension}, N={N}", "precision": precision,
                 "queries_per_s": B / dt, "ms_per_step": dt * 1e3, "prologue_plus_first_pass_ms": score_ms,
-                "rescore_calls": tk.stats()["calls"], "dense_fp32_fallbacks": tk.stats()["fallbacks"]}
+                "rescore_calls": tk.stats()["calls"], "dense_fp32_fallbacks": tk.stats()["fallbacks"], **tr}
     return {"workload": f"{name} {cfg.query_dot_product_groups}x{cfg.item_dot_product_groups}x{cfg.dot_product_dimension}, N={N}", "precision": precision,
             "queries_per_s": B / dt, "ms_per_step": dt * 1e3, "prologue_plus_scoring_ms": score_ms,
             "scoring_tflops_algorithmic_lower_bound": tf,
-            "mfma_frac_lower_bound": tf / (PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_F16X3_TFLOPS)}
+            "mfma_frac_lower_bound": tf / (PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_F16X3_TFLOPS), **tr}
 
 
 def main() -> None:
@@ -555,7 +569,10 @@ def main() -> None:
         }
         a16 = fast["achieved_tflops_algorithmic"]
         fast["roofline"] = {"kernel": "mol_score_*_kernel<F16Unit>", "bound": "mfma", "achieved": a16, "peak": PEAK_F16X3_TFLOPS, "unit": "TFLOP/s",
-                            "frac": a16 / PEAK_F16X3_TFLOPS, "traffic": None,
+                            "frac": a16 / PEAK_F16X3_TFLOPS,
+                            "traffic": committed_traffic(f"{args.workload}:B{B}:gpus{world}:f16x3"),
+                            "traffic_source": "profiles/pmc_summary.json (rocprofv3 --pmc passes of this kernel and workload; not collected in this run)",
+                            "hbm_bytes_alg_per_launch": (hi - lo) * bytes_per_item_fp32(cfg) + B * (hi - lo) * 4,
                             "peak_note": "2500 TFLOP/s dense f16 MFMA / 3 MFMAs per product block; issued-MFMA rate = 3 x achieved"}
 
     # ---- precisions "f16x3-exact" / "f16-exact": the f16x3 (or one-product f16) kernels pick k' + margin candidates per query, the
@@ -589,6 +606,13 @@ def main() -> None:
                     dist.barrier()
                 exact_elapsed = time.perf_counter() - t0
                 stats = dict(local.stats())
+                # shadow audit (not timed): the same step with every call also run on the dense fp32 path on a side stream and compared
+                local.audit_every = 1
+                for _ in range(min(args.steps, 5)):
+                    step_exact()
+                audit = local.stats()
+                local.audit_every = 0
+                stats["audited"], stats["mismatches"] = audit["audited"], audit["mismatches"]
                 mol.precision = None
             if world > 1:
                 tf = torch.tensor([exact_elapsed], dtype=torch.float64, device="cpu" if test_backend else dev)
@@ -599,6 +623,7 @@ def main() -> None:
                              "fp32 top-k' (dense fp32 fallback when the verification fails)",
                 "value": B * args.steps / exact_elapsed, "unit": "queries/s", "ms_per_step": exact_elapsed / args.steps * 1e3,
                 "output_identical_to_fp32_path": identical, "rescore_calls": stats["calls"], "dense_fp32_fallbacks": stats["fallbacks"],
+                "shadow_audit": {"audited_calls": stats["audited"], "mismatches": stats["mismatches"]}, "eps": stats.get("eps"),
             }
 
     if world > 1:
