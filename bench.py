@@ -394,6 +394,8 @@ def main() -> None:
             if i is not None:
                 ev1[i].record()
             k_local = min(kp, hi - lo)
+            if world == 1 and E.topk_filter_fusable(hi - lo, k_local, inv.shape[1], k):   # what the module API does: filter fused into the selection
+                return E.topk_filtered(logits, k_local, local._ids_flat, inv, k)
             s, top = E.topk(logits, k_local, ids=local._ids_flat)
             if world > 1:
                 gathered = all_gather_rows(E.pack_candidates(s, top, kp))

@@ -256,6 +256,16 @@ int rails_topk(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t
                const int64_t* ids, int64_t ids_row_stride, float* out_scores, int64_t* out_ids,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/* CandidateIndex.get_top_k_outputs' selection in ONE chain (reference indexing/candidate_index.py:149-175 after
+ * rails/indexing/mol_top_k.py:123-130): exact top-k' of every row with the id map, then the seen-id filter of
+ * rails_filter_seen_ids applied to the k' winners INSIDE the final selection launch -> (out_ids, out_scores) of k per row, the
+ * same bits as rails_topk followed by rails_filter_seen_ids.  Sizes: rails_topk_filter_fusable(n, k', width, k) != 0
+ * (n > 1024, k' <= 512, width <= 256); RAILS_ENOTSUP otherwise -- call the two entry points then.  Honours the launch predicate. */
+int rails_topk_filter_fusable(int64_t n, int32_t k_prime, int32_t width, int32_t k);
+int rails_topk_filtered(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t k_prime, const int64_t* ids, int64_t ids_row_stride,
+                        const int64_t* invalid_ids, int32_t width, int32_t k, int64_t* out_ids, float* out_scores, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 /* ---- item-sharded top-k (no counterpart in the reference, whose eval is single-GPU: eval_from_checkpoint.py:554-555) ----
  * Each rank turns its local top-k into one message row of 2k int64 (k score words: fp32 bits in the low half | k ids;
  * rows with k_local < k are padded with (-inf, -1)); the caller all-gathers the messages in rank order; every rank

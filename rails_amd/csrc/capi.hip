@@ -430,6 +430,26 @@ int rails_topk(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t
   return r == kOk ? r : fail(r, "topk");
 }
 
+int rails_topk_filter_fusable(int64_t n, int32_t k_prime, int32_t width, int32_t k) { return topk_can_fuse_filter(n, k_prime, width, k) ? 1 : 0; }
+
+int rails_topk_filtered(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t k_prime, const int64_t* ids, int64_t ids_row_stride,
+                        const int64_t* invalid_ids, int32_t width, int32_t k, int64_t* out_ids, float* out_scores, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+  g_err[0] = '\0';
+  if (rows < 0 || n < 0 || k_prime < 0 || k < 0 || width < 0) { set_error("topk_filtered: negative size"); return RAILS_EINVAL; }
+  if (k_prime > n) { set_error("topk_filtered: selected index k out of range (k' = %d > n = %lld)", k_prime, (long long)n); return RAILS_EINVAL; }
+  if (k > k_prime) { set_error("topk_filtered: k = %d > k' = %d", k, k_prime); return RAILS_EINVAL; }
+  if (rows == 0 || k == 0) return RAILS_OK;
+  if (!scores || !out_scores || !out_ids || !invalid_ids) { set_error("topk_filtered: NULL pointer"); return RAILS_EINVAL; }
+  if (ld < n) { set_error("topk_filtered: ld < n"); return RAILS_EINVAL; }
+  if (!topk_can_fuse_filter(n, k_prime, width, k)) { set_error("topk_filtered: sizes outside the fused path (rails_topk_filter_fusable)"); return RAILS_ENOTSUP; }
+  const int cu = compute_units();
+  if (cu <= 0) { set_error("topk_filtered: no HIP device"); return RAILS_ELAUNCH; }
+  const int r = topk(scores, ld, rows, n, k_prime, ids, ids_row_stride, out_scores, out_ids, workspace, workspace_bytes, cu, (hipStream_t)stream,
+                     invalid_ids, width, k);
+  return r == kOk ? r : fail(r, "topk_filtered");
+}
+
 int rails_pack_candidates(const float* scores, const int64_t* ids, int32_t rows, int32_t k_local, int32_t k, int64_t* msg,
                           void* stream) {
   g_err[0] = '\0';

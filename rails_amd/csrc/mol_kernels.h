@@ -131,8 +131,11 @@ int mips_score(const float* q, int B, int D, const float* ifrag, int64_t n, floa
 int dot_rowwise(const float* q, const float* items, int64_t Bq, int X, int D, int r, float* out, hipStream_t stream);
 
 size_t topk_workspace_bytes(int rows, int64_t n, int k);
+// f_invalid != NULL: the seen-id filter of filter_seen fused into the final selection launch (out_* then hold f_k per row)
+bool topk_can_fuse_filter(int64_t n, int k, int width, int k_out);
 int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int64_t* ids, int64_t ids_row_stride,
-         float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, int n_cu, hipStream_t stream);
+         float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, int n_cu, hipStream_t stream,
+         const int64_t* f_invalid = nullptr, int f_width = 0, int f_k = 0);
 int pack_candidates(const float* scores, const int64_t* ids, int rows, int k_local, int k, int64_t* msg, hipStream_t stream);
 int range_flag(const int32_t* v, int n, int lo, int hi, int32_t* flag, hipStream_t stream);
 int rescore_verdict(const float* row_stats, int rows, float default_eps, float safety, float* state, hipStream_t stream);

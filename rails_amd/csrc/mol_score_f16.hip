@@ -25,6 +25,8 @@ static int launch_f16(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   constexpr bool tight = (PX + G::TH + G::TL) * 16 > RAILS_F16_TIGHT_LIMIT;
   using U8 = std::conditional_t<tight, F16Unit<false, true>, F16Unit<OVL, false>>;
   using U4 = F16Unit<OVL, false>;
+  if (a.combine_none)   // gating_combination "none": its own instantiation of the unit, direct shell only
+    return launch_kernel<F16Unit<false, tight, true>, PQ, PX, DD, H, 8, false>(a, n_cu, stream);
   const int variant = choose_variant<PQ, PX, DD, H>(a, n_cu);
   if ((variant == 2 || variant == 4 || variant == 5 || variant == 6) && a.per_row) { set_error("staged scoring kernel does not do per-row candidates"); return kErrUnsupported; }
   switch (variant) {
@@ -48,7 +50,7 @@ int score_launch_f16(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t s
 #undef MOL_CASE
   if (s.query_dot_product_groups == 16 && s.item_dot_product_groups == 16 && s.dot_product_dimension == 64) {
     // L = 256: tiles (160 KiB) and the gate pack (256 KiB) are beyond LDS staging -- the team kernel (mol_score_wsplit.h)
-    return launch_wsplit<WsF16, 16, 16, 64, 128>(a, n_cu, stream);
+    return a.combine_none ? launch_wsplit<WsF16T<true>, 16, 16, 64, 128>(a, n_cu, stream) : launch_wsplit<WsF16, 16, 16, 64, 128>(a, n_cu, stream);
   }
   set_error("the f16x3 precision mode is not built for this shape");
   return kErrUnsupported;

@@ -16,6 +16,7 @@ static int launch_f16_extra(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using G = Geo<PQ, PX, DD, H>;
   constexpr bool tight = (PX + G::TH + G::TL) * 16 > RAILS_F16_TIGHT_LIMIT;   // as in mol_score_f16.hip
   using U = std::conditional_t<tight, F16Unit<false, true>, F16Unit<true, false>>;
+  if (a.combine_none) return launch_kernel<F16Unit<false, tight, true>, PQ, PX, DD, H, 8, false>(a, n_cu, stream);
   return launch_kernel<U, PQ, PX, DD, H, 8, false>(a, n_cu, stream);
 }
 

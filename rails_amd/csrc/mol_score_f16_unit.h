@@ -259,12 +259,13 @@ __device__ __forceinline__ void interleave(FM&& mf, FS&& sf) {
 // query is redone with the shifted form from the u values, which are still in registers -- same result as the
 // reference's stable softmax (similarity_fn.py:31-46) in every case.
 // PF = logit pairs whose gi / gq operands are requested ahead of their slice (gi may sit in HBM/L2); 4 registers each
-template <class G, int PF>
+template <class G, int PF, bool NONE = false>
 struct Epi {
+  static constexpr bool kNone = NONE;   // gating_combination "none" (similarity_fn.py:187-197): w = gq + gi + gqi, no silu.  A COMPILE-TIME
+                                        // switch: as a run-time branch in every slice it cost the glu_silu kernels 15-25 % (2.52 -> 2.91 ms)
   static constexpr int kPF = PF;
   f32x16 D3[G::TL];   // -log2e * gqi on entry; u after pass 1
   float den, num;
-  int none;           // gating_combination "none" (similarity_fn.py:187-197): w = gq + gi + gqi, no silu
   const float* gq;    // this query's -log2e * gq row, lane half's part ([hi][e] layout)
   float2 gi_r[PF], gq_r[PF];
   // gi fragment [ec = e/4][lane][4]: pair P is floats (e%4, e%4+1), e = 2P, of the lane's float4
@@ -274,8 +275,8 @@ struct Epi {
     gi_r[P % PF] = *reinterpret_cast<const float2*>(tGi + ((e / 4) * 64 + lane) * 4 + e % 4);
     gq_r[P % PF] = *reinterpret_cast<const float2*>(gq + e);
   }
-  __device__ __forceinline__ void reset(const float* gq_, const float* tGi, int lane, int none_ = 0) {
-    den = 0.0f; num = 0.0f; gq = gq_; none = none_;
+  __device__ __forceinline__ void reset(const float* gq_, const float* tGi, int lane) {
+    den = 0.0f; num = 0.0f; gq = gq_;
     static_for<(PF < G::E / 2 ? PF : G::E / 2)>([&](auto pc) { fetch<decltype(pc)::value>(tGi, lane); });
   }
 };
@@ -285,7 +286,7 @@ __device__ __forceinline__ void epi_p1(EP& s, const float* tGi, int lane) {
   constexpr int e = 2 * P, PF = EP::kPF;
   const float2 gi = s.gi_r[P % PF], gq = s.gq_r[P % PF];
   if constexpr (P + PF < G::E / 2) s.template fetch<P + PF>(tGi, lane);
-  if (s.none) {   // u = -log2e * (gq + gi + gqi): gq and gqi arrive prescaled, gi does not
+  if constexpr (EP::kNone) {   // u = -log2e * (gq + gi + gqi): gq and gqi arrive prescaled, gi does not
     s.D3[e / 16][e % 16] = __builtin_fmaf(gi.x, -kLog2e, gq.x + s.D3[e / 16][e % 16]);
     s.D3[e / 16][e % 16 + 1] = __builtin_fmaf(gi.y, -kLog2e, gq.y + s.D3[e / 16][e % 16 + 1]);
   } else {
@@ -319,7 +320,8 @@ __device__ __forceinline__ float epi_final(EP& s, const f32x16 (&D1)[PX]) {
   // The guard sits well below FLT_MAX: with den near 1e38 the sum is still finite, but num = sum ex * cl (|cl| <= 1/tau) overflows
   // first and 1/den is a denormal that v_rcp flushes to zero -- NaNs and zeros for gate logits just under the exp overflow
   // (found with pair-gate weights x 3: 1 084 non-finite logits of 2.4 M; x 5 and x 10 overflowed den itself and were caught).
-  if (__builtin_amdgcn_ballot_w64(!(den < 1.0e30f && den > 1.0e-30f)) != 0) {   // an exp got large (or, with "none", all of them tiny) somewhere in this wave: the stable form
+  // an exp got large somewhere in this wave (or, with "none", whose gate logits have no lower bound, all of them tiny): the stable form
+  if (__builtin_amdgcn_ballot_w64(EP::kNone ? !(den < 1.0e30f && den > 1.0e-30f) : !(den < 1.0e30f)) != 0) {
     float mn = INFINITY;
 #pragma unroll
     for (int e = 0; e < G::E; ++e) mn = __builtin_fminf(mn, s.D3[e / 16][e % 16]);
@@ -501,7 +503,7 @@ static __device__ long long g_f16_phase[32];
 // OVERLAP: stage X of query Q+1 carries the epilogue of query Q (needs D2 and D3 of two queries live at once).
 // TIGHT:   the accumulators alone fill the register budget (8x8x32 at two waves per SIMD: 224 of 256): no operand double
 //          buffering in stage Y and no pinned order -- the compiler's own schedule fits without spilling, a pinned one does not.
-template <bool OVERLAP, bool TIGHT>
+template <bool OVERLAP, bool TIGHT, bool NONE = false>
 struct F16Unit {
   template <class G>
   static constexpr int kLdsWeightFloats = SplitPack<G>::kLdsFloats;
@@ -530,7 +532,7 @@ struct F16Unit {
     };
 
     f32x16 D2[G::TH];
-    Epi<G, (TIGHT ? RAILS_F16_TIGHT_PF : 8)> ep;   // TIGHT has no registers to spare for a deeper operand ring (and its epilogue is not fenced: the compiler hoists)
+    Epi<G, (TIGHT ? RAILS_F16_TIGHT_PF : 8), NONE> ep;   // TIGHT has no registers to spare for a deeper operand ring (and its epilogue is not fenced: the compiler hoists)
     XState<G> xs;
     YState<G, 1> ys;
     auto stage_x_alone = [&](auto qc) {   // GEMM2 with nothing to hide it under but the operand splits
@@ -582,7 +584,7 @@ struct F16Unit {
           F16_STAMP(4 * Q);
           stage_x_alone(qc);
           F16_STAMP(4 * Q + 1);
-          ep.reset(gq_of(q), tGi, lane, p.combine_none);
+          ep.reset(gq_of(q), tGi, lane);
           stage_y(qc);
           F16_STAMP(4 * Q + 2);
           store(q, epilogue_alone(qc));
@@ -599,7 +601,7 @@ struct F16Unit {
     static_for<G::QT>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       const int q = g * G::QT + Q;
-      ep.reset(gq_of(q), tGi, lane, p.combine_none);
+      ep.reset(gq_of(q), tGi, lane);
       stage_y(qc);
       F16_STAMP(2 + 2 * Q);
       if constexpr (Q + 1 < G::QT) {

@@ -14,7 +14,9 @@ inline namespace f16x1 {
 inline namespace f16x3 {
 #endif
 
-struct WsF16 {
+// NONE: gating_combination "none" as a compile-time switch (a run-time branch in every slice cost the glu_silu kernels ~7 %)
+template <bool NONE>
+struct WsF16T {
   static constexpr int CE = 8;
   static constexpr int OPV = RAILS_F16_SINGLE ? 1 : 2;
 #ifndef RAILS_WS16_W1STREAM
@@ -178,7 +180,7 @@ struct WsF16 {
       float t[4], r[4], ex[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) t[j] = __builtin_fmaf(gqv[j], giv[j], D3[(e0 + j) / 16][(e0 + j) % 16]);
-      if (combine_none) {   // gating_combination "none": u = -log2e * (gq + gi + gqi); gq and gqi arrive prescaled, gi does not
+      if constexpr (NONE) {   // gating_combination "none": u = -log2e * (gq + gi + gqi); gq and gqi arrive prescaled, gi does not
 #pragma unroll
         for (int j = 0; j < 4; ++j) t[j] = __builtin_fmaf(giv[j], -kLog2e, gqv[j] + D3[(e0 + j) / 16][(e0 + j) % 16]);
       } else {
@@ -219,7 +221,8 @@ struct WsF16 {
       nm += swap32(nm);
       float mn = 0.0f;
       // guard well below FLT_MAX: see epi_final (mol_score_f16_unit.h)
-      if (__builtin_amdgcn_ballot_w64(!(dn < 1.0e30f && dn > 1.0e-30f)) != 0) {   // an exp got large (or, with "none", all tiny) somewhere in this wave: the stable form
+      // an exp got large somewhere in this wave (or, with "none", all of them tiny): the stable form
+      if (__builtin_amdgcn_ballot_w64(NONE ? !(dn < 1.0e30f && dn > 1.0e-30f) : !(dn < 1.0e30f)) != 0) {
         mn = INFINITY;
 #pragma unroll
         for (int e = 0; e < EW; ++e) mn = __builtin_fminf(mn, D3[e / 16][e % 16]);
@@ -246,6 +249,7 @@ struct WsF16 {
     }
   };
 };
+using WsF16 = WsF16T<false>;
 
 }  // inline namespace f16x3 / f16x1
 }  // namespace mol

@@ -362,6 +362,55 @@ __device__ long long g_phase[16];
 #define RAILS_PHASE(i)
 #endif
 
+constexpr int kFuseMaxK = 512;    // candidates per row the fused seen-id filter stages in LDS
+constexpr int kFuseMaxW = 256;    // seen ids per row
+
+// The seen-id filter of the candidate index (reference indexing/candidate_index.py:149-175) over a row's k' selected candidates
+// held in LDS, best first: keep the first k NOT-seen ones in order; if fewer than k exist, back-fill with the earliest dropped
+// ones (seen, or beyond the first k) -- exactly what filter_seen_kernel does, one thread per candidate.  All threads of the
+// workgroup call it (NT threads, NT >= kp); `scratch` = NT / 64 + 2 ints.
+template <int NT>
+__device__ __forceinline__ void filter_from_lds(const int64_t* id_s, const float* sc_s, int kp, const int64_t* inv_s, int width, int k,
+                                                int64_t* __restrict__ out_ids, float* __restrict__ out_scores, int* scratch) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  auto block_scan = [&](int v, int& total) -> int {   // inclusive scan over the NT threads
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+    __syncthreads();
+    if (lane == 63) scratch[wv] = inc;
+    __syncthreads();
+    int base = 0;
+    total = 0;
+#pragma unroll
+    for (int t = 0; t < NT / 64; ++t) { const int tv = scratch[t]; if (t < wv) base += tv; total += tv; }
+    return base + inc;
+  };
+  int ok = 0;
+  int64_t id = 0;
+  if (tid < kp) {
+    id = id_s[tid];
+    bool seen = false;
+    for (int w = 0; w < width; ++w) seen |= (inv_s[w] == id);
+    ok = seen ? 0 : 1;
+  }
+  int total_ok;
+  const int okc = block_scan(ok, total_ok);                 // not-seen candidates up to and including this one
+  const bool valid = ok && okc <= k;
+  const int gap = k - (total_ok < k ? total_ok : k);
+  int total_bad;
+  const int badc = block_scan(tid < kp && !valid ? 1 : 0, total_bad) - (tid < kp && !valid ? 1 : 0);   // dropped candidates before this one
+  if (tid < kp) {
+    int out_pos = -1;
+    if (valid) out_pos = (okc - 1) + (badc < gap ? badc : gap);
+    else if (badc + 1 <= gap) out_pos = (okc < k ? okc : k) + badc;
+    if (out_pos >= 0 && out_pos < k) {
+      out_ids[out_pos] = id;
+      out_scores[out_pos] = sc_s[tid];
+    }
+  }
+}
+
 struct RowSelectArgs {
   const float* scores; int64_t ld; int64_t n; int64_t chunk;     // SCORES source: row r, chunk c = [c*chunk, min(n, (c+1)*chunk))
   const unsigned long long* keys_in; int keys_per_row;           // KEYS source
@@ -370,6 +419,9 @@ struct RowSelectArgs {
   float* out_scores; int64_t* out_ids;
   unsigned long long* keys_out;                                  // else: keys_out[(row*gridDim.y + c)*k + j]
   const int32_t* run_if;                                         // launch predicate (mol_kernels.h)
+  // fused seen-id filter (final output only; k <= kFuseMaxK, width <= kFuseMaxW): the k selected (score, id) pairs go through the
+  // filter of filter_seen_kernel inside this launch and f_k of them are written (out_scores / out_ids then hold f_k per row)
+  const int64_t* f_invalid; int f_width; int f_k;
 };
 
 template <int VPT, bool KEYS>
@@ -379,9 +431,15 @@ __global__ __launch_bounds__(kRowThreads) void row_select_kernel(const RowSelect
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // lds_keys candidates + 2048 exchange
   __shared__ unsigned int ctr[3][16];
   __shared__ unsigned int cursor;
+  __shared__ int64_t f_id[kFuseMaxK], f_inv[kFuseMaxW];
+  __shared__ float f_sc[kFuseMaxK];
+  __shared__ int f_scratch[kRowThreads / 64 + 2];
   const int row = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int k = a.k, lds_keys = a.lds_keys;
+  const bool fuse = a.f_invalid != nullptr;   // wave-uniform
+  if (fuse)
+    for (int i = tid; i < a.f_width; i += kRowThreads) f_inv[i] = a.f_invalid[(int64_t)row * a.f_width + i];   // visible after the barriers below
   unsigned int v[VPT];
   unsigned int lo[KEYS ? VPT : 1];
   int cnt;
@@ -434,8 +492,10 @@ __global__ __launch_bounds__(kRowThreads) void row_select_kernel(const RowSelect
   auto emit = [&](unsigned long long kv, int j) {
     if (a.out_scores) {
       const unsigned int pos = ~(unsigned int)(kv & 0xFFFFFFFFull);
-      a.out_scores[(int64_t)row * k + j] = unorderable((unsigned int)(kv >> 32));
-      a.out_ids[(int64_t)row * k + j] = a.ids ? a.ids[a.ids_row_stride * row + pos] : (int64_t)pos;
+      const float sc = unorderable((unsigned int)(kv >> 32));
+      const int64_t id = a.ids ? a.ids[a.ids_row_stride * row + pos] : (int64_t)pos;
+      if (fuse) { f_sc[j] = sc; f_id[j] = id; }
+      else { a.out_scores[(int64_t)row * k + j] = sc; a.out_ids[(int64_t)row * k + j] = id; }
     } else {
       a.keys_out[((int64_t)row * gridDim.y + blockIdx.y) * k + j] = kv;
     }
@@ -467,6 +527,11 @@ __global__ __launch_bounds__(kRowThreads) void row_select_kernel(const RowSelect
       }
     }
     for (int j = tid; j < k; j += kRowThreads) emit(keys[j], j);
+  };
+  auto finish = [&]() {   // fused seen-id filter over the k staged candidates
+    if (!fuse) return;
+    __syncthreads();
+    filter_from_lds<kRowThreads>(f_id, f_sc, k, f_inv, a.f_width, a.f_k, a.out_ids + (int64_t)row * a.f_k, a.out_scores + (int64_t)row * a.f_k, f_scratch);
   };
   auto compact = [&](auto pred) {      // append the keys of the selected elements (any order); overflow is dropped
     unsigned int c = 0;
@@ -520,6 +585,7 @@ __global__ __launch_bounds__(kRowThreads) void row_select_kernel(const RowSelect
       int npad = 2;
       while (npad < (int)m_ge) npad <<= 1;
       emit_sorted(npad);
+      finish();
       RAILS_PHASE(4);
 #ifdef RAILS_TOPK_PHASES
       if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) g_phase[5] = m_ge;
@@ -577,6 +643,7 @@ __global__ __launch_bounds__(kRowThreads) void row_select_kernel(const RowSelect
   int npad = 2;
   while (npad < k) npad <<= 1;
   emit_sorted(npad);
+  finish();
 }
 
 template <int VPT, bool KEYS>
@@ -642,9 +709,16 @@ static int ensure_sort_lds() {
   return ensure_dyn_lds(once, reinterpret_cast<const void*>(&sort_emit_kernel), kSortCap * (int)sizeof(unsigned long long));
 }
 
+bool topk_can_fuse_filter(int64_t n, int k, int width, int k_out) {
+  return n > 1024 && n < (1ll << 32) && k <= kFuseMaxK && k <= kRowMaxK && width >= 0 && width <= kFuseMaxW && k_out > 0 && k_out <= k &&
+         (n <= kRowMaxN || [&] { int c; int64_t l; return two_level_plan(n, k, &c, &l); }());
+}
+
 int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int64_t* ids, int64_t ids_row_stride,
-         float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, int n_cu, hipStream_t stream) {
+         float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, int n_cu, hipStream_t stream,
+         const int64_t* f_invalid, int f_width, int f_k) {
   if (rows <= 0 || k <= 0) return kOk;
+  if (f_invalid && !topk_can_fuse_filter(n, k, f_width, f_k)) { set_error("topk: the seen-id filter cannot be fused at n = %lld, k = %d, width = %d", (long long)n, k, f_width); return kErrUnsupported; }
   if (k > kSortCap) { set_error("k = %d exceeds the in-LDS sort capacity (%d)", k, kSortCap); return kErrUnsupported; }
   if (n >= (1ll << 32)) { set_error("n = %lld does not fit 32-bit positions; shard the corpus", (long long)n); return kErrUnsupported; }
   if (ensure_sort_lds() != kOk) return kErrLaunch;
@@ -655,6 +729,7 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
     a.scores = scores; a.ld = ld; a.n = n; a.k = k;
     if (n <= kRowMaxN) {                 // one launch
       a.chunk = n; a.ids = ids; a.ids_row_stride = ids_row_stride; a.out_scores = out_scores; a.out_ids = out_ids;
+      a.f_invalid = f_invalid; a.f_width = f_width; a.f_k = f_k;
       return launch_row_select<false>(a, rows, 1, (int)n, stream);
     }
     int chunks; int64_t chunk;
@@ -668,6 +743,7 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
       b.run_if = pred;
       b.keys_in = lvl1; b.keys_per_row = chunks * k; b.k = k;
       b.ids = ids; b.ids_row_stride = ids_row_stride; b.out_scores = out_scores; b.out_ids = out_ids;
+      b.f_invalid = f_invalid; b.f_width = f_width; b.f_k = f_k;
       return launch_row_select<true>(b, rows, 1, chunks * k, stream);
     }
   }

@@ -589,6 +589,39 @@ def topk(scores: torch.Tensor, k: int, ids: Optional[torch.Tensor] = None, sorte
     return out_s, out_i
 
 
+def topk_filter_fusable(n: int, k_prime: int, width: int, k: int) -> bool:
+    return bool(_lib.load().rails_topk_filter_fusable(int(n), int(k_prime), int(width), int(k)))
+
+
+def topk_filtered(scores: torch.Tensor, k_prime: int, ids: Optional[torch.Tensor], invalid_ids: torch.Tensor, k: int,
+                  workspace: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """topk(scores, k_prime, ids) followed by filter_seen_ids(..., invalid_ids, k), the filter fused into the final selection launch
+    (include/rails_amd.h rails_topk_filtered).  -> (out_ids (rows, k), out_scores (rows, k)), ids first like filter_seen_ids."""
+    lib = _lib.load()
+    _require_device(scores, "scores")
+    if scores.dtype != torch.float32 or scores.stride(1) != 1:
+        scores = _f32c(scores)
+    rows, n = scores.shape
+    stride = 0
+    if ids is not None:
+        if ids.dtype != torch.int64 or ids.device != scores.device:
+            ids = ids.to(device=scores.device, dtype=torch.int64)
+        if ids.dim() == 2 and ids.shape[0] == rows and rows > 1:
+            ids = ids.contiguous()
+            stride = ids.shape[1]
+        else:
+            ids = ids.reshape(-1).contiguous()
+    invalid_ids = invalid_ids.to(device=scores.device, dtype=torch.int64).contiguous()
+    out_i = torch.empty((rows, k), dtype=torch.int64, device=scores.device)
+    out_s = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
+    ws_bytes = lib.rails_topk_workspace_bytes(rows, n, k_prime)
+    ws = workspace if workspace is not None and workspace.numel() >= ws_bytes and workspace.device == scores.device else torch.empty(ws_bytes, dtype=torch.uint8, device=scores.device)
+    with _on_device(scores.device):
+        _lib.check(lib.rails_topk_filtered(_ptr(scores), scores.stride(0), rows, n, k_prime, _ptr(ids), stride, _ptr(invalid_ids), invalid_ids.shape[1], k,
+                                           _ptr(out_i), _ptr(out_s), _ptr(ws), ws_bytes, _stream()), "rails_topk_filtered")
+    return out_i, out_s
+
+
 class run_predicate:
     """with run_predicate(flag):  every scoring / top-k launch inside is a no-op unless the int32 device scalar `flag` is non-zero
     when the kernel starts (include/rails_amd.h rails_set_run_predicate).  Thread-local; not re-entrant."""

@@ -119,6 +119,19 @@ class MoLBruteForceTopK(MoLTopKModule):
         scores, ids = E.topk(logits, k, ids=self._ids_flat, sorted=sorted, workspace=ws)
         return scores.to(query_embeddings.dtype), ids
 
+    def forward_filtered(self, query_embeddings: torch.Tensor, k_prime: int, invalid_ids: torch.Tensor, k: int, **kwargs):
+        """CandidateIndex.get_top_k_outputs' body for this module: top-k' + id map + seen-id filter with the filter fused into the final
+        selection launch (rails_topk_filtered) -> (top_k_ids (B, k), top_k_scores (B, k)), or None when the sizes / the precision
+        route are outside the fused path (the caller then composes forward + filter_seen_ids: same bits)."""
+        eng = self._bind()
+        B, N = query_embeddings.size(0), self._index.n_items
+        if eng.exact is not None or B * N * 4 > self.MAX_LOGIT_BYTES or not E.topk_filter_fusable(N, k_prime, invalid_ids.shape[1], k):
+            return None
+        logits = self._all_logits_scratch(query_embeddings, **kwargs)
+        ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(B, N, k_prime), torch.uint8)
+        ids, scores = E.topk_filtered(logits, k_prime, self._ids_flat, invalid_ids, k, workspace=ws)
+        return ids, scores.to(query_embeddings.dtype)
+
     MAX_LOGIT_BYTES = 4 << 30      # larger (B, N) logit matrices are never materialised: the corpus is scored in chunks
     CHUNK_ITEMS = 1 << 23          # 8 Mi items per chunk (a multiple of the tile): 1 GiB of logits at B = 32
 
@@ -757,6 +770,10 @@ class CandidateIndex(object):
         k_prime = min(k + max_num_invalid_ids, self.num_objects)
         if truncate_k_prime_to is not None:
             k_prime = min(k_prime, truncate_k_prime_to)
+        if invalid_ids is not None and k <= k_prime and hasattr(top_k_module, "forward_filtered"):
+            fused = top_k_module.forward_filtered(query_embeddings, k_prime, invalid_ids, k, **aux_payloads)
+            if fused is not None:
+                return fused[0], fused[1], None
         top_k_prime_scores, top_k_prime_ids = top_k_module(query_embeddings=query_embeddings, k=k_prime, **aux_payloads)
         if invalid_ids is not None:
             if top_k_prime_ids.shape[1] < k:

@@ -1312,3 +1312,30 @@ def test_gating_combination_none_at_256_logits(dev, precision):
     with torch.inference_mode():
         got, _ = mol(q.to(dev), X.unsqueeze(0).to(dev))
     assert float((got.cpu() - ref).abs().max()) <= LOGIT_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,n,kp,width,k", [(4, 5000, 200, 61, 120), (32, 200_000, 200, 61, 120), (3, 30_000, 512, 211, 300), (2, 3883, 200, 211, 120),
+                                               (5, 27_278, 25, 30, 20), (2, 1500, 10, 1, 10), (3, 100_003, 331, 256, 331)])
+def test_fused_topk_filter_equals_the_two_kernels(dev, rows, n, kp, width, k):
+    """rails_topk_filtered == rails_topk followed by rails_filter_seen_ids, bit for bit: seen ids among the winners (dropped), fewer than
+    k unseen winners (back-fill), ties, both the one-launch and the two-level selection."""
+    g = torch.Generator().manual_seed(rows * 1000 + kp)
+    scores = torch.randn((rows, n), generator=g)
+    m = scores[:, 1::7].shape[1]
+    scores[:, ::7][:, :m] = scores[:, 1::7]                                  # ties
+    scores = scores.to(dev)
+    ids = (torch.randperm(n, generator=g) * 3 + 5).to(dev)
+    s_ref, i_ref = E.topk(scores, kp, ids=ids)
+    for frac in (0.0, 0.3, 0.95):                                            # share of each row's seen-id slots filled with its own winners
+        inv = torch.zeros((rows, width), dtype=torch.int64)
+        n_fill = min(int(width * frac), kp)
+        for r in range(rows):
+            sel = torch.randperm(kp, generator=g)[:n_fill]
+            inv[r, :n_fill] = i_ref[r].cpu()[sel]
+        inv = inv.to(dev)
+        assert E.topk_filter_fusable(n, kp, width, k)
+        want_i, want_s = E.filter_seen_ids(i_ref, s_ref, inv, k)
+        got_i, got_s = E.topk_filtered(scores, kp, ids, inv, k)
+        assert torch.equal(got_i, want_i) and torch.equal(got_s, want_s), (frac, int((got_i != want_i).sum()))
+    assert not E.topk_filter_fusable(n, 600, width, k) and not E.topk_filter_fusable(500, min(kp, 500), width, min(k, 500))
