@@ -334,6 +334,18 @@ int rails_rows_layer_norm(const float* x, int64_t ldx, int64_t rows, int32_t dim
 int rails_gemm_f32(const float* a, int64_t lda, const float* w, int32_t w_is_nk, const float* bias, const float* residual,
                    int64_t ldr, int64_t m, int32_t n, int32_t k, int32_t act, const int64_t* lengths, int32_t seq_len, float* c,
                    int64_t ldc, void* stream);
+/* MoLGatingFn.forward's combination + SoftmaxDropoutCombiner.forward as a stand-alone unit (reference
+ * rails/similarities/mol/similarity_fn.py:148-201 and :31-46/:66-96, eval mode), for callers that use the modules on their own --
+ * inside the scoring path all of this is fused into the scoring kernels.  Row r = b * items_per_query + x:
+ *   g = query_part[b] * item_part[x or r] + pair_part[r]   (RAILS_COMBINE_GLU_SILU: w = g * sigmoid(g))
+ *   g = the sum of the parts that are not NULL             (RAILS_COMBINE_NONE: w = g)
+ *   pi = softmax(w) [/ clamp(sum pi, eps) if renormalise: the combiner does that whenever its dropout rate is > 0]
+ *   out[r] = sum_l pi[l] * logits[r][l];  probs_out (rows, num_logits), optional, receives pi.
+ * The combiner alone: pair_part = the gating weights, the other parts NULL, RAILS_COMBINE_NONE.  num_logits <= 1024. */
+int rails_mol_gate_combine(const float* logits, int64_t ld_logits, const float* pair_part, int64_t ld_pair, const float* query_part,
+                           const float* item_part, int64_t rows, int32_t items_per_query, int32_t num_logits, int32_t item_part_per_row,
+                           int32_t combination, int32_t renormalise, float eps, float* out, float* probs_out, void* stream);
+
 /* out = act(l) * g with [l | g] = x W + b: GeGLU (act = erf gelu) / SwiGLU (act = silu) as stand-alone layers
  * (reference rails/similarities/layers.py:19-74; `kind` RAILS_GEGLU | RAILS_SWIGLU).  w is the `_w` parameter, (in_features,
  * 2 * out_features) row-major; b the `_b` parameter (2 * out_features) or NULL; scratch holds rows * 2 * out_features floats

@@ -552,6 +552,23 @@ int rails_gemm_f32(const float* a, int64_t lda, const float* w, int32_t w_is_nk,
   return fail(gemm_f32(a, lda, w, w_is_nk ? 1 : 0, bias, residual, ldr, m, n, k, act, lengths, seq_len, c, ldc, (hipStream_t)stream), "gemm_f32");
 }
 
+int rails_mol_gate_combine(const float* logits, int64_t ld_logits, const float* pair_part, int64_t ld_pair, const float* query_part,
+                           const float* item_part, int64_t rows, int32_t items_per_query, int32_t num_logits, int32_t item_part_per_row,
+                           int32_t combination, int32_t renormalise, float eps, float* out, float* probs_out, void* stream) {
+  g_err[0] = '\0';
+  if (rows < 0 || items_per_query <= 0 || num_logits <= 0) { set_error("gate_combine: bad size"); return RAILS_EINVAL; }
+  if (rows == 0) return RAILS_OK;
+  if (!logits || !out || ld_logits < num_logits || (pair_part && ld_pair < num_logits) || rows % items_per_query != 0) {
+    set_error("gate_combine: NULL pointer, short stride or rows not a multiple of items_per_query");
+    return RAILS_EINVAL;
+  }
+  if (combination != RAILS_COMBINE_GLU_SILU && combination != RAILS_COMBINE_NONE) { set_error("gate_combine: unknown combination %d", combination); return RAILS_EINVAL; }
+  if (combination == RAILS_COMBINE_GLU_SILU && (!pair_part || !query_part || !item_part)) { set_error("gate_combine: glu_silu needs all three gate parts"); return RAILS_EINVAL; }
+  if (!pair_part && !query_part && !item_part) { set_error("gate_combine: no gate part"); return RAILS_EINVAL; }
+  return fail(gate_combine(logits, ld_logits, pair_part, ld_pair, query_part, item_part, rows, items_per_query, num_logits, item_part_per_row ? 1 : 0,
+                           combination == RAILS_COMBINE_GLU_SILU ? 1 : 0, renormalise ? 1 : 0, eps, out, probs_out, (hipStream_t)stream), "gate_combine");
+}
+
 int rails_glu_f32(const float* x, int64_t ldx, const float* w, const float* b, int64_t rows, int32_t in_features, int32_t out_features,
                   int32_t kind, float* scratch, float* out, void* stream) {
   g_err[0] = '\0';

@@ -591,6 +591,80 @@ int gemm_f32(const float* A, int64_t lda, const float* W, int w_is_nk, const flo
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
+// ---- stand-alone MoLGatingFn / SoftmaxDropoutCombiner (reference rails/similarities/mol/similarity_fn.py:31-46, :148-201) ----
+// One wave per (query, item) row r = b * X + x:  g = gq[b] * gi + gqi (glu_silu) or the sum of the parts that exist (none);
+// w = g * sigmoid(g) (glu_silu) or g;  pi = softmax(w) [/ clamp(sum pi, eps) when the combiner's dropout rate is > 0];
+// out[r] = sum_l pi[l] * y[r][l].  Precise expf and true divisions: this is the module API for callers that use the pieces on
+// their own, not the scoring path (there all of it is fused into the scoring kernels).
+__global__ __launch_bounds__(256) void gate_combine_kernel(const float* __restrict__ y, int64_t ldy, const float* __restrict__ gqi, int64_t ldq,
+                                                          const float* __restrict__ gq, const float* __restrict__ gi, int64_t rows, int X,
+                                                          int L, int gi_per_row, int glu_silu, int renorm, float eps, float* __restrict__ out,
+                                                          float* __restrict__ pi_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int64_t b = r / X, x = r - b * X;
+  const float* gqr = gq ? gq + b * L : nullptr;
+  const float* gir = gi ? gi + (gi_per_row ? r : x) * (int64_t)L : nullptr;
+  constexpr int kMaxPerLane = 16;   // L <= 1024
+  float w[kMaxPerLane];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    const int l = lane + 64 * i;
+    float g = -INFINITY;
+    if (l < L) {
+      const float a = gqr ? gqr[l] : 0.0f, c = gir ? gir[l] : 0.0f, d = gqi ? gqi[r * ldq + l] : 0.0f;
+      if (glu_silu) {
+        g = a * c + d;
+        g = g * (1.0f / (1.0f + expf(-g)));
+      } else {
+        g = (gqr ? a : 0.0f) + (gir ? c : 0.0f) + (gqi ? d : 0.0f);
+      }
+    }
+    w[i] = g;
+    mx = fmaxf(mx, g);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float den = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    w[i] = lane + 64 * i < L ? expf(w[i] - mx) : 0.0f;
+    den += w[i];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) den += __shfl_xor(den, o, 64);
+  float sum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) { w[i] = w[i] / den; sum += w[i]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float norm = renorm ? fmaxf(sum, eps) : 1.0f;
+  float acc = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kMaxPerLane; ++i) {
+    const int l = lane + 64 * i;
+    if (l < L) {
+      const float pi = renorm ? w[i] / norm : w[i];
+      if (pi_out) pi_out[r * L + l] = pi;
+      acc = __builtin_fmaf(pi, y[r * ldy + l], acc);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) out[r] = acc;
+}
+
+int gate_combine(const float* y, int64_t ldy, const float* gqi, int64_t ldq, const float* gq, const float* gi, int64_t rows, int X, int L,
+                 int gi_per_row, int glu_silu, int renorm, float eps, float* out, float* pi_out, hipStream_t stream) {
+  if (rows == 0) return kOk;
+  if (L > 1024) { set_error("gate_combine: %d logits (supported: <= 1024)", L); return kErrUnsupported; }
+  hipLaunchKernelGGL(gate_combine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, y, ldy, gqi, ldq, gq, gi, rows, X, L, gi_per_row,
+                     glu_silu, renorm, eps, out, pi_out);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 int glu_gate(const float* t, int64_t ldt, int64_t rows, int F, int kind, float* out, hipStream_t stream) {
   if (rows == 0 || F == 0) return kOk;
   hipLaunchKernelGGL(glu_gate_kernel, dim3((unsigned)((rows * F + 255) / 256)), dim3(256), 0, stream, t, ldt, rows, F, kind, out);

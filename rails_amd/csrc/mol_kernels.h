@@ -103,6 +103,8 @@ int rows_normalize(const float* x, int64_t ldx, const int64_t* row_index, int64_
                    hipStream_t stream);
 int gemm_f32(const float* A, int64_t lda, const float* W, int w_is_nk, const float* bias, const float* residual, int64_t ldr, int64_t M,
              int N, int K, int act, const int64_t* lengths, int seq_len, float* C, int64_t ldc, hipStream_t stream);
+int gate_combine(const float* y, int64_t ldy, const float* gqi, int64_t ldq, const float* gq, const float* gi, int64_t rows, int X, int L,
+                 int gi_per_row, int glu_silu, int renorm, float eps, float* out, float* pi_out, hipStream_t stream);
 int glu_gate(const float* t, int64_t ldt, int64_t rows, int F, int kind, float* out, hipStream_t stream);
 int hstu_time_buckets(const int64_t* timestamps, int B, int N, const int64_t* thresholds, int num_buckets, unsigned char* out,
                       hipStream_t stream);

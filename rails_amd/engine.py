@@ -589,6 +589,40 @@ def topk(scores: torch.Tensor, k: int, ids: Optional[torch.Tensor] = None, sorte
     return out_s, out_i
 
 
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, silu: bool = False) -> torch.Tensor:
+    """act(x @ weight.T + bias) for 2-D fp32 x on the GPU through rails_gemm_f32 (fp32 MFMA); `weight` is a torch Linear weight (N, K)."""
+    lib = _lib.load()
+    _require_device(x, "x")
+    x, weight = _f32c(x), _f32c(weight.detach())
+    bias = None if bias is None else _f32c(bias.detach())
+    M, K = x.shape
+    N = weight.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    with _on_device(x.device):
+        _lib.check(lib.rails_gemm_f32(_ptr(x), K, _ptr(weight), 1, _ptr(bias), None, 0, M, N, K, 1 if silu else 0, None, 0, _ptr(out), N, _stream()), "rails_gemm_f32")
+    return out
+
+
+def gate_combine(logits: torch.Tensor, pair_part: Optional[torch.Tensor], query_part: Optional[torch.Tensor], item_part: Optional[torch.Tensor],
+                 items_per_query: int, item_part_per_row: bool, glu_silu: bool, renormalise: bool, eps: float,
+                 want_probs: bool = False) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """rails_mol_gate_combine: logits / pair_part (rows, L), query_part (rows / X, L), item_part (X or rows, L) -> (out (rows,), pi or None)."""
+    lib = _lib.load()
+    _require_device(logits, "logits")
+    logits = _f32c(logits)
+    rows, L = logits.shape
+    pair_part = None if pair_part is None else _f32c(pair_part)
+    query_part = None if query_part is None else _f32c(query_part)
+    item_part = None if item_part is None else _f32c(item_part)
+    out = torch.empty((rows,), dtype=torch.float32, device=logits.device)
+    probs = torch.empty((rows, L), dtype=torch.float32, device=logits.device) if want_probs else None
+    with _on_device(logits.device):
+        _lib.check(lib.rails_mol_gate_combine(_ptr(logits), L, _ptr(pair_part), L, _ptr(query_part), _ptr(item_part), rows, items_per_query, L,
+                                              1 if item_part_per_row else 0, _lib.RAILS_COMBINE_GLU_SILU if glu_silu else _lib.RAILS_COMBINE_NONE,
+                                              1 if renormalise else 0, float(eps), _ptr(out), _ptr(probs), _stream()), "rails_mol_gate_combine")
+    return out, probs
+
+
 def topk_filter_fusable(n: int, k_prime: int, width: int, k: int) -> bool:
     return bool(_lib.load().rails_topk_filter_fusable(int(n), int(k_prime), int(width), int(k)))
 

@@ -129,7 +129,10 @@ class RecoMoLQueryEmbeddingsFn(MoLEmbeddingsFn):
         self._eps: float = eps
 
     def forward(self, input_embeddings: torch.Tensor, **kwargs):
-        raise NotImplementedError("evaluated through MoLSimilarity.get_query_component_embeddings (HIP)")
+        """(B, D) -> ((B, P_Q, d) component embeddings, {}) (reference query_embeddings_fns.py:175-254, eval mode): the query prologue
+        kernel of the MoLSimilarity this module belongs to."""
+        owner = _owner_of(self)
+        return owner.get_query_component_embeddings(input_embeddings, **kwargs)
 
 
 class RecoMoLItemEmbeddingsFn(MoLEmbeddingsFn):
@@ -152,7 +155,10 @@ class RecoMoLItemEmbeddingsFn(MoLEmbeddingsFn):
         self._eps: float = eps
 
     def forward(self, input_embeddings: torch.Tensor, **kwargs):
-        raise NotImplementedError("evaluated through MoLSimilarity.get_item_component_embeddings (HIP)")
+        """(..., D') -> ((..., P_X, d) component embeddings, {}) (reference item_embeddings_fns.py:149-183, eval mode): the index-build
+        kernel of the MoLSimilarity this module belongs to."""
+        owner = _owner_of(self)
+        return owner.get_item_component_embeddings(input_embeddings, **kwargs)
 
 
 class SoftmaxDropoutCombiner(torch.nn.Module):
@@ -166,7 +172,17 @@ class SoftmaxDropoutCombiner(torch.nn.Module):
         self._eps: float = eps
 
     def forward(self, gating_weights: torch.Tensor, x: torch.Tensor):
-        raise NotImplementedError("fused into rails_amd's scoring HIP kernel")
+        """(..., L) gating weights, (..., L) logits -> ((...,) combined logits, {}): softmax, the eval-time renormalisation when
+        dropout_rate > 0, weighted sum (reference similarity_fn.py:31-46, :66-96, eval mode) -- rails_mol_gate_combine.  Inside
+        MoLSimilarity.forward the same arithmetic is fused into the scoring kernels."""
+        if self.training:
+            raise NotImplementedError("rails_amd is eval-only (no dropout / mi_loss)")
+        from . import engine as E
+
+        lead = gating_weights.shape[:-1]
+        L = gating_weights.shape[-1]
+        out, _ = E.gate_combine(x.reshape(-1, L), gating_weights.reshape(-1, L), None, None, 1, False, False, self._dropout_rate > 0.0, self._eps)
+        return out.reshape(lead).to(x.dtype), {}
 
 
 class MoLGatingFn(torch.nn.Module):
@@ -195,8 +211,46 @@ class MoLGatingFn(torch.nn.Module):
         self._combination_type: str = combination_type
         self._normalization_fn: torch.nn.Module = normalization_fn(num_logits)
 
-    def forward(self, logits, query_embeddings, item_embeddings):
-        raise NotImplementedError("fused into rails_amd's scoring HIP kernel")
+    def forward(self, logits: torch.Tensor, query_embeddings: torch.Tensor, item_embeddings: torch.Tensor):
+        """logits (B, X, L) [already / temperature], query_embeddings (B, D), item_embeddings (1 or B, X, D') -> ((B, X), {}):
+        reference similarity_fn.py:148-201 in eval mode, for callers that use the gate on its own (MoLSimilarity.forward never
+        materialises these tensors: the same arithmetic is fused into the scoring kernels).  The three partial modules' Linear
+        layers run on rails_gemm_f32 (fp32 MFMA), the combination + normalisation on rails_mol_gate_combine."""
+        if self.training:
+            raise NotImplementedError("rails_amd is eval-only")
+        if self._combination_type not in ("glu_silu", "none"):
+            raise NotImplementedError(f"combination_type {self._combination_type!r}")
+        from . import engine as E
+
+        B, X, L = logits.shape
+
+        def mlp(seq, x2d):
+            lin = _find(seq, torch.nn.Linear)
+            if len(lin) == 1:
+                return E.linear(x2d, lin[0].weight, lin[0].bias)
+            if len(lin) != 2 or not _find(seq, torch.nn.SiLU):
+                raise NotImplementedError("gate partial modules are Linear or Linear-SiLU-Linear (modeling/similarity_utils.py:147-207)")
+            return E.linear(E.linear(x2d, lin[0].weight, lin[0].bias, silu=True), lin[1].weight, lin[1].bias)
+
+        gq = mlp(self._query_only_partial_module, query_embeddings.reshape(B, -1)) if self._query_only_partial_module is not None else None
+        per_row = item_embeddings.shape[0] != 1 or B == 1
+        gi = mlp(self._item_only_partial_module, item_embeddings.reshape(-1, item_embeddings.shape[-1])) if self._item_only_partial_module is not None else None
+        gqi = mlp(self._qi_partial_module, logits.reshape(B * X, L)) if self._qi_partial_module is not None else None
+        norm = self._normalization_fn
+        if not isinstance(norm, SoftmaxDropoutCombiner):
+            raise NotImplementedError("normalization_fn must be a SoftmaxDropoutCombiner")
+        out, _ = E.gate_combine(logits.reshape(B * X, L), gqi, gq, gi, X, per_row, self._combination_type == "glu_silu", norm._dropout_rate > 0.0, norm._eps)
+        return out.reshape(B, X).to(logits.dtype), {}
+
+
+def _owner_of(fn: torch.nn.Module):
+    """The MoLSimilarity an embeddings-fn module was built into (set by MoLSimilarity.__init__; a weak reference, so the parent can
+    still be collected).  The embeddings fns only hold parameters; their kernels belong to the parent's engine."""
+    ref = getattr(fn, "_rails_owner", None)
+    owner = ref() if ref is not None else None
+    if owner is None:
+        raise NotImplementedError(f"{type(fn).__name__}.forward needs the MoLSimilarity it was built into (its HIP engine holds the packed weights)")
+    return owner
 
 
 def _find(seq: torch.nn.Module, kind) -> List[torch.nn.Module]:
@@ -246,6 +300,11 @@ class MoLSimilarity(SimilarityModule):
         )
         self._query_embeddings_fn: MoLEmbeddingsFn = query_embeddings_fn
         self._item_embeddings_fn: Optional[MoLEmbeddingsFn] = item_embeddings_fn
+        import weakref
+
+        for fn in (query_embeddings_fn, item_embeddings_fn):
+            if fn is not None:
+                object.__setattr__(fn, "_rails_owner", weakref.ref(self))   # not a submodule / parameter: plain attribute
         self._item_proj_module: Optional[torch.nn.Module] = None
         if item_embeddings_fn is None:
             raise NotImplementedError("the legacy item_proj_fn path (similarity_fn.py:252-259) is not supported")

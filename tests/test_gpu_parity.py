@@ -1339,3 +1339,23 @@ def test_fused_topk_filter_equals_the_two_kernels(dev, rows, n, kp, width, k):
         got_i, got_s = E.topk_filtered(scores, kp, ids, inv, k)
         assert torch.equal(got_i, want_i) and torch.equal(got_s, want_s), (frac, int((got_i != want_i).sum()))
     assert not E.topk_filter_fusable(n, 600, width, k) and not E.topk_filter_fusable(500, min(kp, 500), width, min(k, 500))
+
+
+@pytest.mark.gpu
+def test_standalone_module_forwards(fx, mol, dev):
+    """The pieces of MoLSimilarity called on their own, against the reference's stage outputs (fixture F1): the embeddings fns, the
+    gating fn on materialised cross logits, and the softmax combiner on the reference's gating weights.  (MoLSimilarity.forward never
+    materialises these tensors; the stand-alone forwards exist for callers that do.)"""
+    n = int(fx.z["F1/n"])
+    q, X = fx.t("q").to(dev), fx.t("X")[:, :n].to(dev)
+    cl, w, ref = fx.t("F1/cl").to(dev), fx.t("F1/w").to(dev), fx.t("F1/logits")
+    with torch.inference_mode():
+        eq, aux_q = mol._query_embeddings_fn(q, **kw_dev(fx, dev))
+        ex, aux_x = mol._item_embeddings_fn(X)
+        out_c, aux_c = mol._gating_fn._normalization_fn(w, cl)
+        out_g, aux_g = mol._gating_fn(cl, q, X)
+        out_b, _ = mol._gating_fn(cl, q, X.expand(q.shape[0], -1, -1).contiguous())      # per-row item embeddings (B' = B)
+    assert aux_q == {} and aux_x == {} and aux_c == {} and aux_g == {}
+    assert float((eq.cpu() - fx.t("F1/Eq")).abs().max()) <= STAGE_TOL and float((ex.cpu() - fx.t("F1/Ex")).abs().max()) <= STAGE_TOL
+    for name, got in (("combiner", out_c), ("gating fn", out_g), ("gating fn, per-row items", out_b)):
+        assert got.shape == ref.shape and float((got.cpu() - ref).abs().max()) <= LOGIT_TOL, (fx.name, name, float((got.cpu() - ref).abs().max()))
