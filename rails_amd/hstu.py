@@ -294,10 +294,15 @@ class HSTU(torch.nn.Module):
     # ---- HIP path ------------------------------------------------------------------------------------------------
     @staticmethod
     def _lengths(past_lengths: torch.Tensor, dev, N: int, min_len: int = 1) -> torch.Tensor:
-        """int64 lengths clamped to [min_len, N].  encode() indexes row `length - 1`, so it clamps to [1, N] on both of its
-        paths (the reference has no defined result for an empty history: its flattened gather at offset -1 fails,
-        hstu.py:773-781); forward() keeps 0 (an all-padding sequence is all zero rows, as in the reference)."""
-        return past_lengths.to(device=dev, dtype=torch.int64).clamp(min_len, N).contiguous()
+        """int64 lengths on the device, VALIDATED to lie in [min_len, N]: a length beyond the padded width, or an empty history in
+        encode() (which indexes row `length - 1`; the reference's flattened gather at offset -1 fails there too, hstu.py:773-781),
+        is an upstream data bug and raises instead of returning a plausible embedding of the wrong row.  forward() accepts 0 (an
+        all-padding sequence is all zero rows, as in the reference).  The check reads one flag back (lengths usually arrive from the
+        host, where it is free)."""
+        lengths = past_lengths.to(dtype=torch.int64)
+        if bool(((lengths < min_len) | (lengths > N)).any()):
+            raise ValueError(f"past_lengths must lie in [{min_len}, {N}] (got min {int(lengths.min())}, max {int(lengths.max())})")
+        return lengths.to(device=dev).contiguous()
 
     def _normalize(self, x2d: torch.Tensor, rows: Optional[torch.Tensor]) -> torch.Tensor:
         lib = _lib.load()

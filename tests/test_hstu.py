@@ -162,22 +162,29 @@ def test_bf16_module_equals_fp32_module_with_rounded_weights(name):
 
 
 @pytest.mark.gpu
-def test_encode_clamps_out_of_range_lengths():
-    """past_lengths outside [1, N] must not index outside the activation buffer (encode reads row length - 1)."""
+def test_encode_rejects_out_of_range_lengths():
+    """past_lengths outside [1, N] are an upstream data bug: encode raises instead of returning the embedding of a clamped row
+    (the reference fails on both: its gather at offset length - 1 leaves the buffer)."""
     dev = torch.device("cuda", 0)
     d, w = load("amzn-books")
     cfg = HO.HSTU_CONFIGS["amzn-books"]
     m = build(cfg, w, dev)
     lengths, ids = (torch.from_numpy(d[f"in/{k}"]).to(dev) for k in ("past_lengths", "past_ids"))
-    bad = lengths.clone()
-    bad[0], bad[1] = 0, cfg.max_sequence_len + 5
-    ok = lengths.clone()
-    ok[0], ok[1] = 1, cfg.max_sequence_len
     with torch.inference_mode():
         emb = m.get_item_embeddings(ids)
         for fused in (True, False):
             m.use_fused_kernel = fused
-            assert torch.equal(m.encode(bad, ids, emb, {}), m.encode(ok, ids, emb, {}))
+            for pos, val in ((0, 0), (1, cfg.max_sequence_len + 5), (2, -3)):
+                bad = lengths.clone()
+                bad[pos] = val
+                with pytest.raises(ValueError, match="past_lengths"):
+                    m.encode(bad, ids, emb, {})
+            ok = lengths.clone()
+            ok[0], ok[1] = 1, cfg.max_sequence_len
+            assert m.encode(ok, ids, emb, {}).shape == (lengths.shape[0], cfg.embedding_dim)
+        empty = lengths.clone()
+        empty[0] = 0
+        assert m(empty, ids, emb, {}).shape[0] == lengths.shape[0]       # forward() accepts an all-padding sequence
 
 
 @pytest.mark.gpu
