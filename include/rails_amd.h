@@ -104,7 +104,8 @@ typedef struct rails_mol_weights {
   const float* gi_w1;     /* _gating_fn._item_only_partial_module.1.weight       (H_i, D_i)           */
   const float* gi_b1;
   const float* gi_w2;     /* ...3.weight                                          (L, H_i)            */
-  const float* gqi_w1;    /* _gating_fn._qi_partial_module.1.weight              (H, L)               */
+  const float* gqi_w1;    /* _gating_fn._qi_partial_module.1.weight              (H, L); gating_qi_hidden_dim <= 0 (pair gate without hidden
+                           * layer, similarity_utils.py:199-206): the single Linear's (L, L) weight, gqi_b1 its (L) bias, gqi_w2 / gqi_b2 NULL */
   const float* gqi_b1;
   const float* gqi_w2;    /* ...3.weight                                          (L, H)              */
   const float* gqi_b2;

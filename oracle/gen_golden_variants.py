@@ -34,6 +34,7 @@ CASES = {
     "v_itemglu_8x4x32": (MoLConfig(48, 40, 32, 8, 4, item_hidden_dim=96, item_nonlinearity="swiglu"), {}),
     "v_none_16x4x32": (MoLConfig(64, 64, 32, 16, 4, gating_combination_type="none", gating_query_fn=False, gating_item_fn=False), {}),
     "v_h64_8x4x64": (MoLConfig(64, 64, 64, 8, 4, gating_qi_hidden_dim=64), {}),
+    "v_nohid_8x8x32": (MoLConfig(64, 64, 32, 8, 8, gating_qi_hidden_dim=-1), {}),    # pair gate = one Linear(L, L): similarity_utils.py:199-206
 }
 
 

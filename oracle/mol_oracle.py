@@ -454,8 +454,11 @@ def synthetic_weights(cfg: MoLConfig, seed: int = 0, uid_rows: Optional[int] = N
         w[p + "1.weight"], w[p + "1.bias"] = xavier(cfg.gating_item_hidden_dim, Di), torch.zeros(cfg.gating_item_hidden_dim)
         w[p + "3.weight"] = xavier(L, cfg.gating_item_hidden_dim)
     p = "_gating_fn._qi_partial_module."
-    w[p + "1.weight"], w[p + "1.bias"] = xavier(cfg.gating_qi_hidden_dim, L), torch.zeros(cfg.gating_qi_hidden_dim)
-    w[p + "3.weight"], w[p + "3.bias"] = xavier(L, cfg.gating_qi_hidden_dim), torch.zeros(L)
+    if cfg.gating_qi_hidden_dim > 0:
+        w[p + "1.weight"], w[p + "1.bias"] = xavier(cfg.gating_qi_hidden_dim, L), torch.zeros(cfg.gating_qi_hidden_dim)
+        w[p + "3.weight"], w[p + "3.bias"] = xavier(L, cfg.gating_qi_hidden_dim), torch.zeros(L)
+    else:   # one Linear(L, L) (modeling/similarity_utils.py:199-206)
+        w[p + "1.weight"], w[p + "1.bias"] = xavier(L, L), torch.zeros(L)
     p = "_query_embeddings_fn._query_emb_proj_module."
     if cfg.query_hidden_dim > 0:
         w[p + "1._w"] = torch.randn((D, 2 * cfg.query_hidden_dim), generator=g) * 0.02

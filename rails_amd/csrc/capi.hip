@@ -48,8 +48,9 @@ static bool shape_ok(const Shape* s) {
 
 static bool shape_supported(const Shape* s) {
   if (!shape_ok(s)) return false;
-  if (s->gating_qi_hidden_dim <= 0) {
-    set_error("a pair gate without hidden layer (gating_qi_hidden_dim <= 0) has no fused kernel");
+  if (s->gating_qi_hidden_dim <= 0 && (s->precision != RAILS_PRECISION_FP32 || !score_extra_shape(*s))) {
+    set_error("a pair gate without hidden layer (gating_qi_hidden_dim <= 0) is built in precision fp32 for P_Q x P_X x d = 8x8x32, 8x4x64, 16x4x32 "
+              "(mol_score_extra_shapes.h)");
     return false;
   }
   if (s->gating_combination != RAILS_COMBINE_GLU_SILU && s->gating_combination != RAILS_COMBINE_NONE) {
@@ -107,14 +108,14 @@ int rails_mol_shape_supported(const rails_mol_shape* shape) { return shape_suppo
 
 size_t rails_mol_gate_pack_floats(const rails_mol_shape* s) {
   if (!shape_ok(s)) return 0;
-  const size_t H = (size_t)s->gating_qi_hidden_dim, L = (size_t)num_logits(*s);
-  return 2 * H * L + H + L;
+  const size_t H = s->gating_qi_hidden_dim > 0 ? (size_t)s->gating_qi_hidden_dim : 0, L = (size_t)num_logits(*s);
+  return H > 0 ? 2 * H * L + H + L : L * L + L;   // no hidden layer: one (L, L) matrix + bias
 }
 
 int rails_mol_pack_gate_weights(const rails_mol_shape* s, const rails_mol_weights* w, float* gate_pack, void* stream) {
   g_err[0] = '\0';
   if (!shape_supported(s)) return RAILS_ENOTSUP;
-  if (!w || !gate_pack || !w->gqi_w1 || !w->gqi_b1 || !w->gqi_w2 || !w->gqi_b2) {
+  if (!w || !gate_pack || !w->gqi_w1 || !w->gqi_b1 || (s->gating_qi_hidden_dim > 0 && (!w->gqi_w2 || !w->gqi_b2))) {
     set_error("pack_gate_weights: NULL pointer");
     return RAILS_EINVAL;
   }

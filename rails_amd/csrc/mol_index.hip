@@ -18,6 +18,23 @@ __global__ void pack_gate_kernel(const float* __restrict__ w1, const float* __re
                                  const float* __restrict__ w2, const float* __restrict__ b2,
                                  float* __restrict__ out, int PQ, int PX, int H) {
   const int L = PQ * PX, TH = H / 32, TL = L / 32, E = L / 2;
+  if (H <= 0) {   // no hidden layer: Wfrag[ec][v][lane][j] = -log2e * W[lrow(v, lane&31)][logit_of(4ec+j, lane>>5)], then b2frag[hi][e]
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L * L + L; i += gridDim.x * blockDim.x) {
+      float v;
+      if (i < L * L) {
+        const int j = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
+        const int tv = blk % TL, ec = blk / TL;
+        const int row = lane & 31;
+        const int l = logit_of(16 * tv + reg_of_row(row), half_of_row(row), PQ, PX);
+        v = -kLog2e * w1[l * L + logit_of(4 * ec + j, lane >> 5, PQ, PX)];
+      } else {
+        const int k = i - L * L;
+        v = -kLog2e * b1[logit_of(k % E, k / E, PQ, PX)];
+      }
+      out[i] = v;
+    }
+    return;
+  }
   const int total = 2 * H * L + H + L;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     float v;
@@ -46,8 +63,8 @@ __global__ void pack_gate_kernel(const float* __restrict__ w1, const float* __re
 }
 
 int pack_gate_weights(const Shape& s, const Weights& w, float* wpack, hipStream_t stream) {
-  const int H = s.gating_qi_hidden_dim, L = num_logits(s);
-  const int total = 2 * H * L + H + L;
+  const int H = s.gating_qi_hidden_dim > 0 ? s.gating_qi_hidden_dim : 0, L = num_logits(s);
+  const int total = H > 0 ? 2 * H * L + H + L : L * L + L;
   hipLaunchKernelGGL(pack_gate_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w.gqi_w1, w.gqi_b1,
                      w.gqi_w2, w.gqi_b2, wpack, s.query_dot_product_groups, s.item_dot_product_groups, H);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;

@@ -72,7 +72,9 @@ struct Geo {
   static constexpr int kTileGiFloats = kTileItems * L;
   static constexpr int kTileFloats = kTileExFloats + kTileGiFloats;
   static constexpr int kEqGroupFloats = 32 * DD;  // one query group of Eq in fragment order
-  static constexpr int kW1Floats = H * L, kW2Floats = L * H;
+  // H == 0: a pair gate WITHOUT hidden layer (modeling/similarity_utils.py:199-206: one Linear(L, L)): its weights take the W1 slot
+  // (K axis = logits, in cl's register order) with the gate-output rows in W2's row order, its bias the b2 slot; no W2, no b1
+  static constexpr int kW1Floats = H > 0 ? H * L : L * L, kW2Floats = L * H;
   static constexpr int kWpackFloats = kW1Floats + kW2Floats + H + L;
 };
 

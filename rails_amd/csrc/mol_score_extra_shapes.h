@@ -16,3 +16,10 @@
   X(32, 2, 32, 128)         \
   X(8, 8, 32, 64)           \
   X(8, 4, 64, 64)
+
+// Pair gate WITHOUT hidden layer (gating_qi_hidden_dim <= 0, modeling/similarity_utils.py:199-206): exact-fp32 precision, direct
+// shell.  X(P_Q, P_X, d)
+#define MOL_NOHID_SHAPES(X) \
+  X(8, 8, 32)               \
+  X(8, 4, 64)               \
+  X(16, 4, 32)

@@ -80,8 +80,30 @@ template <class G, int PX, int R0>
 __device__ __forceinline__ float query_mlp(f32x16 (&D1)[PX], const float4* sW1, const float4* sW2, const float* sB1,
                                            const float* sB2, const float4* tGi, const float4* __restrict__ gq4,
                                            int lane, int hi, int combine_none) {
+  f32x16 D3[G::TL];
+  if constexpr (G::TH == 0) {
+    // pair gate without hidden layer: gqi'[l, x] = -log2e * (b[l] + sum_l' W[l, l'] cl[l', x]) -- one GEMM over the logit axis, its
+    // weights in the W1 slot (sW1), its bias in the b2 slot (sB2)
+#pragma unroll
+    for (int v = 0; v < G::TL; ++v)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) D3[v][r] = sB2[hi * G::E + v * 16 + r];
+#pragma unroll
+    for (int ec = 0; ec < G::E / 4; ++ec) {
+#pragma unroll
+      for (int v = 0; v < G::TL; ++v) {
+        const float4 a = sW1[(ec * G::TL + v) * 64 + lane];
+        const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = ec * 4 + j;
+          D3[v] = mfma32(av[j], D1[e / G::RPQ][R0 + e % G::RPQ], D3[v]);
+        }
+      }
+    }
+  } else {
   // GEMM2: t[h, x] = -log2e * (b1[h] + sum_l W1[h, l] cl[l, x])
-  f32x16 D2[G::TH];
+  f32x16 D2[G::TH > 0 ? G::TH : 1];
 #pragma unroll
   for (int t = 0; t < G::TH; ++t)
 #pragma unroll
@@ -114,7 +136,6 @@ __device__ __forceinline__ float query_mlp(f32x16 (&D1)[PX], const float4* sW1, 
   __builtin_amdgcn_sched_barrier(0);
 
   // GEMM3: gqi'[l, x] = -log2e * (b2[l] + sum_h W2[l, h] hid[h, x])
-  f32x16 D3[G::TL];
 #pragma unroll
   for (int v = 0; v < G::TL; ++v)
 #pragma unroll
@@ -133,6 +154,7 @@ __device__ __forceinline__ float query_mlp(f32x16 (&D1)[PX], const float4* sW1, 
     }
   }
 
+  }
   // epilogue.  t2 = -log2e * (gq*gi + gqi);  u = t2 / (1 + 2^t2) = -log2e * g*sigmoid(g);  softmax(w) = 2^(min u - u) / sum
   // gating_combination "none" (similarity_fn.py:187-197): w = gq + gi + gqi, no silu: u = gq' + gqi' - log2e * gi
   __builtin_amdgcn_sched_barrier(0);

@@ -100,7 +100,10 @@ class MolShapeSpec:
             g = "_gating_fn._item_only_partial_module."
             f.update({g + "1.weight": "gi_w1", g + "1.bias": "gi_b1", g + "3.weight": "gi_w2"})
         g = "_gating_fn._qi_partial_module."
-        f.update({g + "1.weight": "gqi_w1", g + "1.bias": "gqi_b1", g + "3.weight": "gqi_w2", g + "3.bias": "gqi_b2"})
+        if self.gating_qi_hidden_dim > 0:
+            f.update({g + "1.weight": "gqi_w1", g + "1.bias": "gqi_b1", g + "3.weight": "gqi_w2", g + "3.bias": "gqi_b2"})
+        else:   # Sequential(Dropout, Linear(L, L)): modeling/similarity_utils.py:199-206
+            f.update({g + "1.weight": "gqi_w1", g + "1.bias": "gqi_b1"})
         return f
 
 

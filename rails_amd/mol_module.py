@@ -347,8 +347,8 @@ class MoLSimilarity(SimilarityModule):
             # the reference fails here too (None * tensor, similarity_fn.py:176-178)
             raise TypeError("gating_combination_type 'glu_silu' needs the query-only and the item-only gate part")
         qi_linears = _find(g._qi_partial_module, torch.nn.Linear)
-        if len(qi_linears) != 2:
-            raise NotImplementedError("pair gate without a hidden layer (gating_qi_hidden_dim <= 0) has no HIP kernel")
+        if len(qi_linears) not in (1, 2):
+            raise NotImplementedError("the pair gate is Linear-SiLU-Linear or one Linear (modeling/similarity_utils.py:186-207)")
         return MolShapeSpec(
             query_embedding_dim=self._query_embedding_dim,
             item_embedding_dim=self._item_embedding_dim,
@@ -358,7 +358,7 @@ class MoLSimilarity(SimilarityModule):
             query_hidden_dim=q_glus[0]._out_features if q_glus else -1,
             gating_query_hidden_dim=_find(g._query_only_partial_module, torch.nn.Linear)[0].out_features if has_q else -1,
             gating_item_hidden_dim=_find(g._item_only_partial_module, torch.nn.Linear)[0].out_features if has_i else -1,
-            gating_qi_hidden_dim=qi_linears[0].out_features,
+            gating_qi_hidden_dim=qi_linears[0].out_features if len(qi_linears) == 2 else -1,   # -1: no hidden layer (one Linear(L, L))
             query_nonlinearity=q_glus[0].kind if q_glus else "geglu",
             uid_embedding_hash_sizes=tuple(qf._uid_embedding_hash_sizes),
             dot_product_l2_norm=bool(self._dot_product_l2_norm),

@@ -189,7 +189,7 @@ def test_oracle_reproduces_the_reference_on_model_variants():
         rows = O.mol_stages(cfg, w, a["q"], a["cand"])["logits"]
         assert float((rows - a["row_logits"]).abs().max()) <= 2e-6, name
         n += 1
-    assert n == 4
+    assert n == 5
 
 
 def test_oracle_glu_matches_the_reference_layers():
