@@ -63,7 +63,7 @@ with torch.inference_mode():
             exact_ids = out_ids.cpu()
         got = out_ids.cpu()
         rec = {f"agree@{kk}": sum(len(set(x.tolist()) & set(y.tolist())) for x, y in zip(got[:, :kk], exact_ids[:, :kk])) / (B * kk) for kk in (10, 120)}
-        rows.append({"algorithm": name, "BatchTimeMsAvg": sum(ts) / len(ts), "BatchTimeMsMin": min(ts), "queries_per_s": B / (sum(ts) / len(ts)) * 1e3,
+        rows.append({"algorithm": name, "BatchTimeMsAvg": sum(ts) / len(ts), "BatchTimeMsMin": min(ts), "BatchTimeMsMedian": sorted(ts)[len(ts) // 2], "BatchTimeMsMax": max(ts), "queries_per_s": B / (sum(ts) / len(ts)) * 1e3,
                      "returned_columns": int(out_ids.shape[1]), **rec})
         del tk
         torch.cuda.empty_cache()
