@@ -28,7 +28,7 @@ extern "C" {
 /* Version of this interface: bumped whenever a struct gains a field or an entry point changes meaning (round 2 -> 3: 3, the
  * structs of round 2 carried no version).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
  * against an older header pass shorter structs, and the library would read the new fields from whatever follows them. */
-#define RAILS_ABI_VERSION 3
+#define RAILS_ABI_VERSION 4
 int rails_abi_version(void);
 
 #define RAILS_OK 0
@@ -266,6 +266,34 @@ int rails_topk_filter_fusable(int64_t n, int32_t k_prime, int32_t width, int32_t
 int rails_topk_filtered(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t k_prime, const int64_t* ids, int64_t ids_row_stride,
                         const int64_t* invalid_ids, int32_t width, int32_t k, int64_t* out_ids, float* out_scores, void* workspace,
                         size_t workspace_bytes, void* stream);
+
+/* Scoring with the selection fused in: MoLBruteForceTopK.forward's `all_logits = mol(...)` + `torch.topk` + id gather
+ * (reference rails/indexing/mol_top_k.py:118-130) and, optionally, CandidateIndex.get_top_k_outputs' seen-id filter
+ * (indexing/candidate_index.py:149-175) as ONE scoring launch + ONE selection launch that never reads (B, N) logits: the scoring
+ * kernels compare every logit with a running per-query lower bound on the k-th largest and append the survivors as 64-bit keys
+ * (the keys of rails_topk) to per-query lists, the selection launch picks the k largest keys of each list.  Same keys, same total
+ * order: the result equals rails_mol_score_dense + rails_topk (+ rails_filter_seen_ids) bit for bit.
+ *   logits      NULL, or a (B, ld) buffer that additionally receives the dense logits (the verified modes read them)
+ *   invalid_ids NULL, or (B, width) seen ids: the filter runs inside the selection launch and k_out results per row are written
+ *   workspace   rails_mol_score_topk_workspace_bytes(B) bytes, ZERO-FILLED ONCE by the caller; every call leaves it zeroed again.
+ *               Its word at byte offset 4 * B is the status: 0, or 1 when a list overflowed (adversarial orders, e.g. scores
+ *               ascending in position) -- the outputs are then NOT valid and the caller re-runs the dense entry points, typically
+ *               enqueued right behind this call under rails_set_run_predicate(status word), with no host round trip.
+ * Available (rails_mol_score_topk_supported != 0) for B <= 256, k <= 384, n >= 131 072 on the staged and team shells (>= 8 query
+ * groups); RAILS_ENOTSUP otherwise -- call the dense entry points then.  Honours the launch predicate. */
+size_t rails_mol_score_topk_workspace_bytes(int32_t batch);
+int rails_mol_score_topk_supported(const rails_mol_shape* shape, int32_t batch, int64_t n_items, int32_t k);
+int rails_mol_score_topk(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack, int32_t batch, const float* index,
+                         int64_t n_items, int32_t k, const int64_t* ids, int64_t ids_row_stride, float* logits, int64_t ld,
+                         const int64_t* invalid_ids, int32_t width, int32_t k_out, float* out_scores, int64_t* out_ids, void* workspace,
+                         size_t workspace_bytes, void* stream);
+/* The two launches of rails_mol_score_topk on their own (same arguments, same workspace): the scoring launch that fills the survivor
+ * lists, and the selection launch that consumes them.  For callers that want something between them (events around the scoring
+ * kernel, as bench.py does) -- rails_mol_score_topk is exactly one call of each. */
+int rails_mol_score_survivors(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack, int32_t batch, const float* index,
+                              int64_t n_items, int32_t k, float* logits, int64_t ld, void* workspace, size_t workspace_bytes, void* stream);
+int rails_select_survivors(int32_t batch, int32_t k, const int64_t* ids, int64_t ids_row_stride, const int64_t* invalid_ids, int32_t width,
+                           int32_t k_out, float* out_scores, int64_t* out_ids, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- item-sharded top-k (no counterpart in the reference, whose eval is single-GPU: eval_from_checkpoint.py:554-555) ----
  * Each rank turns its local top-k into one message row of 2k int64 (k score words: fp32 bits in the low half | k ids;

@@ -43,6 +43,12 @@ struct ScoreArgs {
   int single;           // 1 (with split): precision F16X1 -- the one-product kernels, which ignore the lo fragments
   int split;            // 1: precision mode f16x3 -- gate pack, query pack and item index hold f16 hi/lo fragments (mol_layout.h)
   const int32_t* run_if;   // device flag (rails_set_run_predicate): the launch is a no-op when *run_if == 0; NULL = unconditional
+  // selection fused into the scoring pass (mol_select.h): NULL list = dense logits only; with a list, `logits` may be NULL
+  unsigned long long* sel_list;   // [B][kSelSegs workgroups][kSelSegCap] keys; empty slots are 0
+  unsigned int* sel_thr;          // [B] running lower bound on the k-th largest orderable score (0: none yet)
+  int sel_k;
+  int32_t* sel_status;            // zeroed by the scoring launch, set by the final selection when a list overflowed
+  int dry_run;                    // 1: validate the dispatch (shape, shell, fused selection possible) without launching
 };
 
 int pack_gate_weights_split(const Shape& s, const Weights& w, float* wpack, hipStream_t stream);
@@ -138,6 +144,9 @@ bool topk_can_fuse_filter(int64_t n, int k, int width, int k_out);
 int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int64_t* ids, int64_t ids_row_stride,
          float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, int n_cu, hipStream_t stream,
          const int64_t* f_invalid = nullptr, int f_width = 0, int f_k = 0);
+int select_lists(unsigned long long* lists, unsigned int* thr, int rows, int cap, int k, const int64_t* ids,
+                 int64_t ids_row_stride, float* out_scores, int64_t* out_ids, hipStream_t stream,
+                 const int64_t* f_invalid = nullptr, int f_width = 0, int f_k = 0);
 int pack_candidates(const float* scores, const int64_t* ids, int rows, int k_local, int k, int64_t* msg, hipStream_t stream);
 int range_flag(const int32_t* v, int n, int lo, int hi, int32_t* flag, hipStream_t stream);
 int rescore_verdict(const float* row_stats, int rows, float default_eps, float safety, float* state, hipStream_t stream);

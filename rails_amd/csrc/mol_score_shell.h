@@ -11,9 +11,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "mol_kernels.h"
 #include "mol_layout.h"
+#include "mol_select.h"
 
 namespace mol {
 
@@ -69,7 +71,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(Score
     const float* eq = p.eqfrag + (int64_t)g * G::kEqGroupFloats;
     f32x16 D1[PX];
     U::template gemm1<G, PX, DD, (NW == 4)>(D1, eq, tEx, lane);   // one wave per SIMD: the whole tile requested up front
-    U::template queries<G, PX>(D1, p, g, row, tile * kTileItems, smem, tGi, lane, hi, x);
+    SelNone none;
+    U::template queries<G, PX, false>(D1, p, none, g, row, tile * kTileItems, smem, tGi, lane, hi, x);
   }
 }
 
@@ -88,13 +91,15 @@ __device__ __forceinline__ void dma_floats(const float* __restrict__ src, float*
   }
 }
 
-template <class U, int PQ, int PX, int DD, int H, int NW>
+template <class U, int PQ, int PX, int DD, int H, int NW, bool SEL = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(ScoreArgs p) {
   using G = Geo<PQ, PX, DD, H>;
   MOL_RUN_IF(p.run_if);
   static_assert(G::kTileFloats % 256 == 0, "tile must be a whole number of 1 KiB pieces");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tiles = smem + U::template kLdsWeightFloats<G>;  // two tile buffers
+  __shared__ std::conditional_t<SEL, SelLds, SelNone> sel;   // fused selection (mol_select.h): a separate instantiation, the dense kernel carries none of it
+  if constexpr (SEL) sel_init(p, sel);
   U::template stage<G, NW>(p, smem);
 
   const int lane = threadIdx.x & 63;
@@ -103,10 +108,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(Score
   const int64_t first = blockIdx.x;
   if (first < p.n_tiles) dma_floats<NW>(p.ipack + first * (int64_t)G::kTileFloats, tiles, G::kTileFloats, wave, lane);
   int cur = 0;
-  for (int64_t tile = first; tile < p.n_tiles; tile += gridDim.x, cur ^= 1) {
+  int64_t it = 0;
+  for (int64_t tile = first; tile < p.n_tiles; tile += gridDim.x, cur ^= 1, ++it) {
     // (1) my pieces of `tile` have landed (vmcnt(0)); (2) barrier: every wave's pieces have, and every wave
     // is done with the previous tile, so the other buffer may be overwritten
     __syncthreads();
+    if constexpr (SEL) {   // before the DMA: see sel_refresh
+      sel_refresh<NW * 64>(p, sel, it);
+      sel_checkpoint<NW * 64>(p, sel, it, (int)blockIdx.x, (int)gridDim.x);
+    }
     const int64_t next = tile + gridDim.x;
     if (next < p.n_tiles) dma_floats<NW>(p.ipack + next * (int64_t)G::kTileFloats, tiles + (cur ^ 1) * G::kTileFloats, G::kTileFloats, wave, lane);
     const float4* tEx = reinterpret_cast<const float4*>(tiles + cur * G::kTileFloats);
@@ -115,7 +125,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(Score
       const float* eq = p.eqfrag + (int64_t)g * G::kEqGroupFloats;
       f32x16 D1[PX];
       U::template gemm1<G, PX, DD>(D1, eq, tEx, lane);
-      U::template queries<G, PX>(D1, p, g, -1, tile * kTileItems, smem, tGi, lane, hi, x);
+      U::template queries<G, PX, SEL>(D1, p, sel, g, -1, tile * kTileItems, smem, tGi, lane, hi, x);
     }
   }
 }
@@ -131,7 +141,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(Score
 // nsub = grid / leftover workgroups that split its query groups (group = sub + nsub * wave), so the round runs one unit
 // per SIMD instead of two on a few CUs (ML-20M: 853 tiles on 256 CUs -> 3 full rounds + 85 leftover tiles x 3 workgroups).
 // ---------------------------------------------------------------------------------------------
-template <class U, int PQ, int PX, int DD, int H, int NW>
+template <class U, int PQ, int PX, int DD, int H, int NW, bool SEL = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged1_kernel(ScoreArgs p) {
   using G = Geo<PQ, PX, DD, H>;
   MOL_RUN_IF(p.run_if);
@@ -155,6 +165,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged1_kernel(Scor
   const bool has_left = b < left * nsub;
   const int64_t mine = rounds + (has_left ? 1 : 0);
   if (mine == 0) return;
+  __shared__ std::conditional_t<SEL, SelLds, SelNone> sel;
+  if constexpr (SEL) sel_init(p, sel);
   U::template stage<G, NW>(p, smem);
   auto tile_of = [&](int64_t i) -> int64_t { return i < rounds ? b + i * grid : rounds * grid + b % left; };
 
@@ -173,6 +185,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged1_kernel(Scor
     // (1) my DMA pieces of `tile` have landed (vmcnt(0)); (2) barrier: every wave's pieces have, and every wave is
     // done with the previous tile's gi buffer
     __syncthreads();
+    if constexpr (SEL) {
+      sel_refresh<NW * 64>(p, sel, i);
+      sel_checkpoint<NW * 64>(p, sel, i, (int)b, (int)grid);
+    }
     const float4* tEx = reinterpret_cast<const float4*>(sEx);
     const float4* tGi = reinterpret_cast<const float4*>(sGi + cur * G::kTileGiFloats);
     for (int it = 0; it < n_it; ++it) {
@@ -189,7 +205,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged1_kernel(Scor
           dma_floats<NW>(tn + G::kTileExFloats, sGi + (cur ^ 1) * G::kTileGiFloats, G::kTileGiFloats, wave, lane);
         }
       }
-      if (has) U::template queries<G, PX>(D1, p, g, -1, tile * kTileItems, smem, tGi, lane, hi, x);
+      if (has) U::template queries<G, PX, SEL>(D1, p, sel, g, -1, tile * kTileItems, smem, tGi, lane, hi, x);
     }
   }
 }
@@ -207,14 +223,14 @@ template <class U, int PQ, int PX, int DD, int H, int NW, bool STAGED>
 static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using G = Geo<PQ, PX, DD, H>;
   constexpr size_t lds = ((size_t)U::template kLdsWeightFloats<G> + (STAGED ? 2 * (size_t)G::kTileFloats : 0)) * sizeof(float);
-  if constexpr (lds > 160 * 1024) {
+  constexpr bool kSelBuilt = STAGED && NW == 8;   // the fused-selection instantiation exists for the default staged kernel only
+  if constexpr (lds + sizeof(SelLds) > 160 * 1024) {
     set_error("staged scoring kernel needs %zu B of LDS", lds);
     return kErrUnsupported;
   } else {
-    const void* fn = STAGED ? reinterpret_cast<const void*>(&mol_score_staged_kernel<U, PQ, PX, DD, H, NW>)
-                            : reinterpret_cast<const void*>(&mol_score_direct_kernel<U, PQ, PX, DD, H, NW>);
-    static DynLdsOnce once;
-    if (ensure_dyn_lds(once, fn, (int)lds) != kOk) return kErrLaunch;
+    // fused selection needs the tile loop's barriers for its checkpoints: the independent-wave shell stays dense
+    if (a.sel_list && !kSelBuilt) { set_error("fused selection is not available in this shell (fewer than %d query groups, per-row candidates, forced variants)", kScoreWaves); return kErrUnsupported; }
+    if (a.dry_run) return kOk;
     const int wg_per_cu = (NW == 4 && lds <= 80 * 1024) ? 2 : 1;
     int64_t grid;
     if (STAGED) {
@@ -224,12 +240,19 @@ static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
       grid = n_units;   // fewer units than wave slots: one unit per workgroup first (wave-major remainder mapping)
     }
     if (grid > (int64_t)n_cu * wg_per_cu) grid = (int64_t)n_cu * wg_per_cu;
+    if (a.sel_list && grid > kSelSegs) grid = kSelSegs;   // one survivor segment per workgroup
     if (grid < 1) return kOk;
-    if (STAGED)
-      hipLaunchKernelGGL((mol_score_staged_kernel<U, PQ, PX, DD, H, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
-    else
-      hipLaunchKernelGGL((mol_score_direct_kernel<U, PQ, PX, DD, H, NW>), dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
-    return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+    auto go = [&](auto kernel) {
+      static DynLdsOnce once;   // one per kernel (the lambda is instantiated per kernel type)
+      if (ensure_dyn_lds(once, reinterpret_cast<const void*>(kernel), (int)lds) != kOk) return (int)kErrLaunch;
+      hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
+      return hipGetLastError() == hipSuccess ? (int)kOk : (int)kErrLaunch;
+    };
+    if constexpr (kSelBuilt) {
+      if (a.sel_list) return go(&mol_score_staged_kernel<U, PQ, PX, DD, H, NW, true>);
+    }
+    if constexpr (STAGED) return go(&mol_score_staged_kernel<U, PQ, PX, DD, H, NW, false>);
+    else return go(&mol_score_direct_kernel<U, PQ, PX, DD, H, NW>);
   }
 }
 
@@ -237,16 +260,25 @@ template <class U, int PQ, int PX, int DD, int H, int NW>
 static int launch_staged1(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using G = Geo<PQ, PX, DD, H>;
   constexpr size_t lds = ((size_t)U::template kLdsWeightFloats<G> + (size_t)G::kTileExFloats + 2 * (size_t)G::kTileGiFloats) * sizeof(float);
-  if constexpr (lds > 160 * 1024) {
+  constexpr bool kSelBuilt = NW == 8;
+  if constexpr (lds + sizeof(SelLds) > 160 * 1024) {
     set_error("single-buffer staged scoring kernel needs %zu B of LDS", lds);
     return kErrUnsupported;
   } else {
-    static DynLdsOnce once;
-    if (ensure_dyn_lds(once, reinterpret_cast<const void*>(&mol_score_staged1_kernel<U, PQ, PX, DD, H, NW>), (int)lds) != kOk) return kErrLaunch;
+    if (a.sel_list && !kSelBuilt) { set_error("fused selection is not available in this forced variant"); return kErrUnsupported; }
+    if (a.dry_run) return kOk;
     if (a.n_tiles < 1) return kOk;
-    // always a full grid: the leftover-round split needs the idle workgroups (they exit at once otherwise)
-    hipLaunchKernelGGL((mol_score_staged1_kernel<U, PQ, PX, DD, H, NW>), dim3((unsigned)n_cu), dim3(NW * 64), lds, stream, a);
-    return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+    auto go = [&](auto kernel) {
+      static DynLdsOnce once;
+      if (ensure_dyn_lds(once, reinterpret_cast<const void*>(kernel), (int)lds) != kOk) return (int)kErrLaunch;
+      // always a full grid: the leftover-round split needs the idle workgroups (they exit at once otherwise)
+      hipLaunchKernelGGL(kernel, dim3((unsigned)(a.sel_list && n_cu > kSelSegs ? kSelSegs : n_cu)), dim3(NW * 64), lds, stream, a);
+      return hipGetLastError() == hipSuccess ? (int)kOk : (int)kErrLaunch;
+    };
+    if constexpr (kSelBuilt) {
+      if (a.sel_list) return go(&mol_score_staged1_kernel<U, PQ, PX, DD, H, NW, true>);
+    }
+    return go(&mol_score_staged1_kernel<U, PQ, PX, DD, H, NW, false>);
   }
 }
 
@@ -257,8 +289,8 @@ static int launch_staged1(const ScoreArgs& a, int n_cu, hipStream_t stream) {
 template <int PQ, int PX, int DD, int H>
 inline int choose_variant(const ScoreArgs& a, int n_cu) {
   using G = Geo<PQ, PX, DD, H>;
-  constexpr bool staged_fits = ((size_t)G::kWpackFloats + 2 * (size_t)G::kTileFloats) * sizeof(float) <= 160 * 1024;
-  constexpr bool staged1_fits = ((size_t)G::kWpackFloats + (size_t)G::kTileExFloats + 2 * (size_t)G::kTileGiFloats) * sizeof(float) <= 160 * 1024;
+  constexpr bool staged_fits = ((size_t)G::kWpackFloats + 2 * (size_t)G::kTileFloats) * sizeof(float) + sizeof(SelLds) <= 160 * 1024;
+  constexpr bool staged1_fits = ((size_t)G::kWpackFloats + (size_t)G::kTileExFloats + 2 * (size_t)G::kTileGiFloats) * sizeof(float) + sizeof(SelLds) <= 160 * 1024;
   int variant = score_variant();
   if (variant == 0) {
     variant = 1;

@@ -436,6 +436,11 @@ static int launch_wsplit(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using W = WsGeo<P, PQ, PX, DD, H>;
   constexpr size_t lds = (size_t)W::kLdsFloats * sizeof(float);
   static_assert(lds <= 160 * 1024, "exchange buffers must fit LDS");
+  // Fused selection (mol_select.h) is not built into the team kernel: a workgroup here keeps meeting the same query pair (its
+  // survivors would need 16 x the segment of the register-resident shells), and what the dense path pays for the selection at this
+  // shape is 0.5 % of a step.
+  if (a.sel_list) { set_error("fused selection is not available for the 256-logit team kernel"); return kErrUnsupported; }
+  if (a.dry_run) return kOk;
   static DynLdsOnce once;
   if (ensure_dyn_lds(once, reinterpret_cast<const void*>(&mol_score_wsplit_kernel<P, PQ, PX, DD, H>), (int)lds) != kOk) return kErrLaunch;
   const int64_t n_units = a.per_row ? (int64_t)a.B * a.n_tiles : a.n_tiles * a.n_groups;

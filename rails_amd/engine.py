@@ -363,6 +363,64 @@ class MolEngine:
             )
         return out
 
+    # scoring with the selection fused in (include/rails_amd.h rails_mol_score_topk): no (B, N) logits are read back
+    def score_topk_supported(self, batch: int, n_items: int, k: int) -> bool:
+        return bool(self.lib.rails_mol_score_topk_supported(C.byref(self.dense_shape), int(batch), int(n_items), int(k)))
+
+    def _score_topk_workspace(self, batch: int, device: torch.device) -> torch.Tensor:
+        """Zero-filled once; every call leaves it zeroed again (the selection launch consumes the lists)."""
+        key = (batch, device)
+        ws = self._sel_ws.get(key) if hasattr(self, "_sel_ws") else None
+        if ws is None:
+            if not hasattr(self, "_sel_ws"):
+                self._sel_ws = {}
+            ws = torch.zeros(self.lib.rails_mol_score_topk_workspace_bytes(batch), dtype=torch.uint8, device=device)
+            self._sel_ws[key] = ws
+        return ws
+
+    def score_topk(self, qpack: torch.Tensor, batch: int, index: MolIndex, k: int, ids: Optional[torch.Tensor] = None,
+                   invalid_ids: Optional[torch.Tensor] = None, k_out: int = 0, logits_out: Optional[torch.Tensor] = None, between=None):
+        """-> (scores (B, k), ids (B, k), status) or, with invalid_ids, (out_ids (B, k_out), out_scores (B, k_out), status): what
+        score_dense + topk (+ filter_seen_ids) return, bit for bit, unless status (a device int32) is non-zero -- a survivor list
+        overflowed; the caller then re-runs the dense entry points, e.g. under run_predicate(status)."""
+        dev = index.buf.device
+        stride = 0
+        if ids is not None:
+            if ids.dtype != torch.int64 or ids.device != dev:
+                ids = ids.to(device=dev, dtype=torch.int64)
+            if ids.dim() == 2 and ids.shape[0] == batch and batch > 1:
+                ids = ids.contiguous()
+                stride = ids.shape[1]
+            else:
+                ids = ids.reshape(-1).contiguous()
+        ws = self._score_topk_workspace(batch, dev)
+        width = 0
+        if invalid_ids is not None:
+            invalid_ids = invalid_ids.to(device=dev, dtype=torch.int64).contiguous()
+            width = invalid_ids.shape[1]
+        ko = k_out if invalid_ids is not None else k
+        out_s = torch.empty((batch, ko), dtype=torch.float32, device=dev)
+        out_i = torch.empty((batch, ko), dtype=torch.int64, device=dev)
+        ld = logits_out.stride(0) if logits_out is not None else 0
+        with _on_device(dev):
+            if between is None:
+                _lib.check(
+                    self.lib.rails_mol_score_topk(C.byref(self.dense_shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(index.buf), index.n_items, k, _ptr(ids), stride,
+                                                  _ptr(logits_out), ld, _ptr(invalid_ids), width, k_out if invalid_ids is not None else 0,
+                                                  _ptr(out_s), _ptr(out_i), _ptr(ws), ws.numel(), _stream()),
+                    "rails_mol_score_topk",
+                )
+            else:   # the same two launches with a callback between them (bench.py: the event that closes the scoring kernel's bracket)
+                _lib.check(self.lib.rails_mol_score_survivors(C.byref(self.dense_shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(index.buf), index.n_items, k,
+                                                              _ptr(logits_out), ld, _ptr(ws), ws.numel(), _stream()), "rails_mol_score_survivors")
+                between()
+                _lib.check(self.lib.rails_select_survivors(batch, k, _ptr(ids), stride, _ptr(invalid_ids), width, k_out if invalid_ids is not None else 0,
+                                                           _ptr(out_s), _ptr(out_i), _ptr(ws), ws.numel(), _stream()), "rails_select_survivors")
+        status = ws[4 * batch: 4 * batch + 4].view(torch.int32)
+        if invalid_ids is not None:
+            return out_i, out_s, status
+        return out_s, out_i, status
+
     def score_candidates(self, qpack: torch.Tensor, batch: int, cand_index: MolIndex, n_cand_padded: int) -> torch.Tensor:
         out = torch.empty((batch, n_cand_padded), dtype=torch.float32, device=cand_index.buf.device)
         with _on_device(cand_index.buf.device):
@@ -631,7 +689,7 @@ def topk_filter_fusable(n: int, k_prime: int, width: int, k: int) -> bool:
 
 
 def topk_filtered(scores: torch.Tensor, k_prime: int, ids: Optional[torch.Tensor], invalid_ids: torch.Tensor, k: int,
-                  workspace: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                  workspace: Optional[torch.Tensor] = None, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """topk(scores, k_prime, ids) followed by filter_seen_ids(..., invalid_ids, k), the filter fused into the final selection launch
     (include/rails_amd.h rails_topk_filtered).  -> (out_ids (rows, k), out_scores (rows, k)), ids first like filter_seen_ids."""
     lib = _lib.load()
@@ -649,8 +707,13 @@ def topk_filtered(scores: torch.Tensor, k_prime: int, ids: Optional[torch.Tensor
         else:
             ids = ids.reshape(-1).contiguous()
     invalid_ids = invalid_ids.to(device=scores.device, dtype=torch.int64).contiguous()
-    out_i = torch.empty((rows, k), dtype=torch.int64, device=scores.device)
-    out_s = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
+    if out is not None:      # (out_ids, out_scores): overwritten (the predicated fallback of the fused score + select path)
+        out_i, out_s = out
+        if out_i.shape != (rows, k) or out_s.shape != (rows, k) or out_i.dtype != torch.int64 or out_s.dtype != torch.float32 or not (out_i.is_contiguous() and out_s.is_contiguous()):
+            raise ValueError("topk_filtered: out must be contiguous (rows, k) int64 and fp32 tensors")
+    else:
+        out_i = torch.empty((rows, k), dtype=torch.int64, device=scores.device)
+        out_s = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
     ws_bytes = lib.rails_topk_workspace_bytes(rows, n, k_prime)
     ws = workspace if workspace is not None and workspace.numel() >= ws_bytes and workspace.device == scores.device else torch.empty(ws_bytes, dtype=torch.uint8, device=scores.device)
     with _on_device(scores.device):

@@ -1362,3 +1362,119 @@ def test_standalone_module_forwards(fx, mol, dev):
     assert float((eq.cpu() - fx.t("F1/Eq")).abs().max()) <= STAGE_TOL and float((ex.cpu() - fx.t("F1/Ex")).abs().max()) <= STAGE_TOL
     for name, got in (("combiner", out_c), ("gating fn", out_g), ("gating fn, per-row items", out_b)):
         assert got.shape == ref.shape and float((got.cpu() - ref).abs().max()) <= LOGIT_TOL, (fx.name, name, float((got.cpu() - ref).abs().max()))
+
+
+# ---- selection fused into the scoring kernels (rails_mol_score_topk) -----------------------------------------------------------
+def _fused_case(cfg_name, N, B, dev, precision, seed=31, dup=1):
+    cfg = O.CONFIGS[cfg_name]
+    w = O.synthetic_weights(cfg, seed=seed)
+    base = torch.from_numpy(O.hash_item_table(seed, 0, (N + dup - 1) // dup, cfg.item_embedding_dim))
+    X = base.repeat(dup, 1)[:N].unsqueeze(0).to(dev)
+    ids = (torch.arange(N, dtype=torch.int64, device=dev) * 5 + 3).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B, seed=seed + 1).to(dev)
+    kw = {"user_ids": torch.arange(B, dtype=torch.int64, device=dev) * 7 + 1} if cfg.uid_embedding_hash_sizes else {}
+    tk = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, precision), X, ids)
+    return cfg, tk, q, kw
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("cfg_name,N,B,k", [("amzn-books", 140_003, 32, 200), ("amzn-books", 300_000, 37, 288), ("amzn-books", 131_072, 32, 10),
+                                            ("amzn-books", 695_762, 32, 384), ("ml-20m", 150_001, 32, 200), ("ml-1m", 200_011, 64, 120)])
+def test_fused_score_topk_equals_the_dense_path(dev, cfg_name, N, B, k, precision):
+    """rails_mol_score_topk (survivor lists appended by the scoring kernels under a running bound + one selection launch) against
+    rails_mol_score_dense + rails_topk: same scores, same ids, same tie order, bit for bit; the status word stays 0; the workspace is
+    left zeroed; a second call (which starts from the state the first one left) agrees."""
+    cfg, tk, q, kw = _fused_case(cfg_name, N, B, dev, precision)
+    with torch.inference_mode():
+        eng = tk._bind()
+        assert eng.score_topk_supported(B, N, k), "the case is meant to run the fused path"
+        tk.FUSED_SELECT = False
+        r_s, r_i = tk(q, k=k, **kw)
+        tk.FUSED_SELECT = True
+        for _ in range(2):
+            qpack, _, _ = eng.query_pack(q, kw.get("user_ids"))
+            s, i, status = eng.score_topk(qpack, B, tk._index, k, ids=tk._ids_flat)
+            assert int(status) == 0
+            assert torch.equal(s, r_s) and torch.equal(i, r_i)
+            ws = eng._score_topk_workspace(B, q.device)
+            assert int(ws.count_nonzero()) == 0, "the selection launch must leave the lists and bounds zeroed"
+        s, i = tk(q, k=k, **kw)                      # the module route (fused path + predicated dense fallback that does not run)
+        assert torch.equal(s, r_s) and torch.equal(i, r_i)
+        # with the seen-id filter fused into the selection launch
+        width, k_out = 61, max(1, k // 2)
+        inv = r_i[:, torch.randperm(k, device=dev)[:width]] if k >= width else r_i[:, :1].repeat(1, width)
+        if E.topk_filter_fusable(N, k, width, k_out):
+            want_i, want_s = E.filter_seen_ids(r_i, r_s, inv, k_out)
+            got_i, got_s = tk.forward_filtered(q, k, inv, k_out, **kw)
+            assert torch.equal(got_i, want_i) and torch.equal(got_s, want_s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_fused_score_topk_with_ties_across_the_kth_place(dev, precision):
+    """Every item eight times: equal scores straddle the k-th place and the survivors of a tie group arrive in any order; the
+    64-bit keys (score, ~position) still give the dense path's order."""
+    cfg, tk, q, kw = _fused_case("amzn-books", 160_000, 32, dev, precision, dup=8)
+    with torch.inference_mode():
+        tk.FUSED_SELECT = False
+        r_s, r_i = tk(q, k=204)
+        tk.FUSED_SELECT = True
+        s, i = tk(q, k=204)
+        assert torch.equal(s, r_s) and torch.equal(i, r_i)
+        assert bool((r_s[:, 0] == r_s[:, 7]).all())
+
+
+@pytest.mark.gpu
+def test_fused_score_topk_overflow_takes_the_dense_pass(dev):
+    """Adversarial order: the corpus sorted by ASCENDING score of the query, so every item beats the running bound and the survivor
+    list (32 768 keys) overflows.  The status word is raised and the module's dense pass, enqueued under it as launch predicate,
+    returns the right answer; the next call on a benign batch runs fused again (the workspace was left clean)."""
+    cfg = O.CONFIGS["amzn-books"]
+    w = O.synthetic_weights(cfg, seed=8)
+    N, B, k = 150_000, 32, 200
+    X0 = torch.from_numpy(O.hash_item_table(21, 0, N, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = torch.arange(N, dtype=torch.int64, device=dev).unsqueeze(0)
+    q1 = O.synthetic_queries(cfg, 1, seed=5).to(dev)
+    with torch.inference_mode():
+        mol = build_module(cfg, w, dev, None)
+        order = rails_amd.MoLBruteForceTopK(mol, X0, ids).all_logits(q1)[0].argsort()
+        X = X0[:, order]                                   # ascending in the query's score
+        tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
+        q = q1.repeat(B, 1)
+        eng = tk._bind()
+        assert eng.score_topk_supported(B, N, k)
+        qpack, _, _ = eng.query_pack(q, None)
+        _, _, status = eng.score_topk(qpack, B, tk._index, k, ids=tk._ids_flat)
+        assert int(status) == 1
+        ws = eng._score_topk_workspace(B, q.device)
+        assert int(ws[: 4 * B].count_nonzero()) == 0 and int(ws[4 * B + 4:].count_nonzero()) == 0   # bounds and lists clean, only the status word set
+        tk.FUSED_SELECT = False
+        r_s, r_i = tk(q, k=k)
+        tk.FUSED_SELECT = True
+        s, i = tk(q, k=k)
+        assert torch.equal(s, r_s) and torch.equal(i, r_i)
+        q2 = O.synthetic_queries(cfg, B, seed=6).to(dev)  # benign batch afterwards, on the shuffled corpus of another module
+        tk2 = rails_amd.MoLBruteForceTopK(mol, X0, ids)
+        tk2.FUSED_SELECT = False
+        r_s, r_i = tk2(q2, k=k)
+        tk2.FUSED_SELECT = True
+        s, i = tk2(q2, k=k)
+        assert torch.equal(s, r_s) and torch.equal(i, r_i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["f16x3-exact", "f16-exact"])
+def test_verified_modes_with_the_fused_first_pass(dev, mode):
+    """The verified modes' first pass through rails_mol_score_topk (dense first-pass logits for the probes AND survivor lists for the
+    candidate selection): still the fp32 module's output bit for bit."""
+    cfg, tk32, q, kw = _fused_case("amzn-books", 200_003, 32, dev, None)
+    with torch.inference_mode():
+        r_s, r_i = tk32(q, k=200, **kw)
+        tk = rails_amd.MoLBruteForceTopK(build_module(cfg, O.synthetic_weights(cfg, seed=31), dev, mode), tk32._item_embeddings, tk32._item_ids)
+        tk.FUSED_SELECT = True
+        for _ in range(3):
+            s, i = tk(q, k=200, **kw)
+            assert torch.equal(s, r_s) and torch.equal(i, r_i)
+        st = tk.stats()
+        assert st["calls"] == 3 and st["fallbacks"] == 0
