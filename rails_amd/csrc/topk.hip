@@ -690,7 +690,9 @@ static int launch_row_select(RowSelectArgs a, int rows, int chunks, int elements
 // row is), chunks * k keys for the second level
 static bool two_level_plan(int64_t n, int k, int* chunks, int64_t* chunk) {
   if (k > kRowFastK) return false;
-  const int64_t c = (n + kRowMaxN - 1) / kRowMaxN;
+  // first-level chunk size: RAILS_ROW_CHUNK (measurement override) or the largest a workgroup holds in registers
+  static const int64_t max_chunk = [] { const char* e = getenv("RAILS_ROW_CHUNK"); const int64_t v = e ? atoll(e) : 0; return v >= 4096 && v <= kRowMaxN ? v / 4 * 4 : (int64_t)kRowMaxN; }();
+  const int64_t c = (n + max_chunk - 1) / max_chunk;
   if (c * k > 24 * kRowThreads) return false;
   int64_t len = (n + c - 1) / c;
   len = (len + 3) / 4 * 4;
