@@ -67,7 +67,7 @@ __device__ __forceinline__ void eq_frag_store(float* eqf, int s, int hi, int row
 // out[c] = bias[c] + sum_k W[c][k] in[k]; a wave owns four output columns at a time, lanes stride k, then a shuffle
 // reduction per column.  KPL = ceil(K / 64) is a compile-time bound so that all 4 * KPL weight loads of a column group are
 // issued before the first FMA (the layer is a chain of L2 latencies otherwise); accumulation order is k ascending per lane.
-template <int KPL>
+template <int KPL, int NC = 4>
 __device__ __forceinline__ void wave_dense_t(const float* __restrict__ W, const float* __restrict__ bias, int ncols,
                                              int K, const float* __restrict__ in_s, float* __restrict__ out_s,
                                              bool silu) {
@@ -75,15 +75,15 @@ __device__ __forceinline__ void wave_dense_t(const float* __restrict__ W, const 
   float xv[KPL];
 #pragma unroll
   for (int i = 0; i < KPL; ++i) xv[i] = (lane + 64 * i < K) ? in_s[lane + 64 * i] : 0.0f;
-  for (int c0 = wave * 4; c0 < ncols; c0 += nw * 4) {
-    float wv[4][KPL];
+  for (int c0 = wave * NC; c0 < ncols; c0 += nw * NC) {
+    float wv[NC][KPL];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NC; ++j)
 #pragma unroll
       for (int i = 0; i < KPL; ++i)
         wv[j][i] = (c0 + j < ncols && lane + 64 * i < K) ? W[(int64_t)(c0 + j) * K + lane + 64 * i] : 0.0f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NC; ++j) {
       float acc = 0.0f;
 #pragma unroll
       for (int i = 0; i < KPL; ++i) acc = __builtin_fmaf(wv[j][i], xv[i], acc);
@@ -102,10 +102,13 @@ __device__ __forceinline__ void wave_dense(const float* __restrict__ W, const fl
                                            int K, const float* __restrict__ in_s, float* __restrict__ out_s,
                                            bool silu) {
   const int kpl = (K + 63) / 64;
-  if (kpl <= 1) wave_dense_t<1>(W, bias, ncols, K, in_s, out_s, silu);
-  else if (kpl <= 2) wave_dense_t<2>(W, bias, ncols, K, in_s, out_s, silu);
-  else if (kpl <= 4) wave_dense_t<4>(W, bias, ncols, K, in_s, out_s, silu);
-  else if (kpl <= 8) wave_dense_t<8>(W, bias, ncols, K, in_s, out_s, silu);
+  // a wave owns NC output columns per pass and has all their weight loads in flight: a layer is ceil(ncols / (16 NC)) L2 round
+  // trips.  Eight columns where four would need more than one pass (the per-column arithmetic does not depend on NC).
+  const bool wide = ncols > 4 * (kQueryThreads / 64);
+  if (kpl <= 1) { if (wide) wave_dense_t<1, 8>(W, bias, ncols, K, in_s, out_s, silu); else wave_dense_t<1>(W, bias, ncols, K, in_s, out_s, silu); }
+  else if (kpl <= 2) { if (wide) wave_dense_t<2, 8>(W, bias, ncols, K, in_s, out_s, silu); else wave_dense_t<2>(W, bias, ncols, K, in_s, out_s, silu); }
+  else if (kpl <= 4) { if (wide) wave_dense_t<4, 8>(W, bias, ncols, K, in_s, out_s, silu); else wave_dense_t<4>(W, bias, ncols, K, in_s, out_s, silu); }
+  else if (kpl <= 8) { if (wide) wave_dense_t<8, 8>(W, bias, ncols, K, in_s, out_s, silu); else wave_dense_t<8>(W, bias, ncols, K, in_s, out_s, silu); }
   else {  // generic (query_hidden_dim > 512): rolled loop
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = kQueryThreads / 64;
     for (int c = wave; c < ncols; c += nw) {
@@ -122,6 +125,9 @@ __device__ __forceinline__ void wave_dense(const float* __restrict__ W, const fl
   }
 }
 
+// grid (padded queries, 2): blockIdx.y = 0 computes the query's sub-embeddings (GLU -> projection -> l2norm -> Eq fragments),
+// blockIdx.y = 1 its query-only gate row (two small layers -> gq fragments).  The two chains share nothing but the input row, so
+// they run as separate workgroups on different CUs instead of one after the other (the gate chain was ~4 us of a 29 us kernel).
 __global__ __launch_bounds__(kQueryThreads) void query_prologue_kernel(QueryArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int D = a.D, d = a.d, PQ = a.PQ, L = a.PQ * a.PX, QH = a.QH;
@@ -135,8 +141,10 @@ __global__ __launch_bounds__(kQueryThreads) void query_prologue_kernel(QueryArgs
   const int b = blockIdx.x;     // padded query index: [0, n_groups * QT)
   const int g = b / QT, qj = b % QT;
   float* eqf = a.eqfrag + (int64_t)g * 32 * d;
+  const bool gate_role = blockIdx.y == 1;
 
   if (b >= a.B) {  // padding row of the last query group: zero operand rows
+    if (gate_role) return;
     for (int i = threadIdx.x; i < PQ * d; i += kQueryThreads) {
       const int p = i / d, k = i - p * d;
       const int hi = k / (d / 2), s = k - hi * (d / 2);
@@ -149,11 +157,45 @@ __global__ __launch_bounds__(kQueryThreads) void query_prologue_kernel(QueryArgs
   for (int i = threadIdx.x; i < D; i += kQueryThreads) qs[i] = a.q[(int64_t)b * D + i];
   __syncthreads();
 
+  if (gate_role) {
+    // query-only gate on the raw query; absent part (gating_query_fn = False): zeros
+    if (a.has_gate) {
+      wave_dense(a.w.gq_w1, a.w.gq_b1, a.Hq, D, qs, hq, true);
+      __syncthreads();
+      wave_dense(a.w.gq_w2, nullptr, L, a.Hq, hq, gqs, false);
+    } else {
+      for (int i = threadIdx.x; i < L; i += kQueryThreads) gqs[i] = 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L; i += kQueryThreads) {
+      if (a.gq_out) a.gq_out[(int64_t)b * L + i] = gqs[i];
+      // gqfrag[b][hi][e] = gq[b][logit_of(e, hi)]
+      const int hi = i / (L / 2), e = i - hi * (L / 2);
+      a.gqfrag[(int64_t)b * L + i] = -kLog2e * gqs[logit_of(e, hi, PQ, a.PX)];  // fragment copy carries -log2e
+      if (a.gqfrag2) a.gqfrag2[(int64_t)b * L + i] = -kLog2e * gqs[logit_of(e, hi, PQ, a.PX)];
+    }
+    return;
+  }
+
   // GLU: h = q W + b (D x 2QH, row-major so lanes stride columns); act(lhs) * rhs.  QH = 0: the projection is a plain Linear
   for (int c = threadIdx.x; c < 2 * QH; c += kQueryThreads) {
     float acc = 0.0f;
     int k = 0;
-    for (; k + 16 <= D; k += 16) {   // 16 loads in flight, then 16 FMAs in k order
+    for (; k + 64 <= D; k += 64) {   // 64 loads in flight (one L2 round trip for D = 64), then 64 FMAs in k order
+      float wv[64];
+#pragma unroll
+      for (int i = 0; i < 64; ++i) wv[i] = a.w.q_glu_w[(int64_t)(k + i) * 2 * QH + c];
+#pragma unroll
+      for (int i = 0; i < 64; ++i) acc = __builtin_fmaf(qs[k + i], wv[i], acc);
+    }
+    for (; k + 32 <= D; k += 32) {   // 32 loads in flight, then 32 FMAs in k order
+      float wv[32];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) wv[i] = a.w.q_glu_w[(int64_t)(k + i) * 2 * QH + c];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) acc = __builtin_fmaf(qs[k + i], wv[i], acc);
+    }
+    for (; k + 16 <= D; k += 16) {
       float wv[16];
 #pragma unroll
       for (int i = 0; i < 16; ++i) wv[i] = a.w.q_glu_w[(int64_t)(k + i) * 2 * QH + c];
@@ -182,15 +224,7 @@ __global__ __launch_bounds__(kQueryThreads) void query_prologue_kernel(QueryArgs
     row += 1;
     for (int k = threadIdx.x; k < d; k += kQueryThreads) eqs[(proj_groups + t) * d + k] = a.w.uid_table[t][row * d + k];
   }
-  // query-only gate on the raw query; absent part (gating_query_fn = False): zeros
-  if (a.has_gate) {
-    wave_dense(a.w.gq_w1, a.w.gq_b1, a.Hq, D, qs, hq, true);
-    __syncthreads();
-    wave_dense(a.w.gq_w2, nullptr, L, a.Hq, hq, gqs, false);
-  } else {
-    for (int i = threadIdx.x; i < L; i += kQueryThreads) gqs[i] = 0.0f;
-    __syncthreads();   // the projection's eqs (written by all waves above) are read for the norms below
-  }
+  __syncthreads();   // the projection's eqs (written by all waves above) are read for the norms below
   if (threadIdx.x < PQ) {
     float ss = 0.0f;
     for (int k = 0; k < d; ++k) {
@@ -209,13 +243,6 @@ __global__ __launch_bounds__(kQueryThreads) void query_prologue_kernel(QueryArgs
     const int hi = k / (d / 2), s = k - hi * (d / 2);
     eq_frag_store(eqf, s, hi, qj * PQ + p, v / a.temperature, a.split);  // fragment copy carries 1/tau
     if (a.eqfrag2) eq_frag_store(a.eqfrag2 + (int64_t)g * 32 * d, s, hi, qj * PQ + p, v / a.temperature, !a.split);
-  }
-  for (int i = threadIdx.x; i < L; i += kQueryThreads) {
-    if (a.gq_out) a.gq_out[(int64_t)b * L + i] = gqs[i];
-    // gqfrag[b][hi][e] = gq[b][logit_of(e, hi)]
-    const int hi = i / (L / 2), e = i - hi * (L / 2);
-    a.gqfrag[(int64_t)b * L + i] = -kLog2e * gqs[logit_of(e, hi, PQ, a.PX)];  // fragment copy carries -log2e
-    if (a.gqfrag2) a.gqfrag2[(int64_t)b * L + i] = -kLog2e * gqs[logit_of(e, hi, PQ, a.PX)];
   }
 }
 
@@ -521,7 +548,7 @@ int query_prologue(const Shape& s, const Weights& w, const float* q, const int64
     return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
   }
   const size_t lds = sizeof(float) * (size_t)(a.D + 2 * a.QH + a.PQ * a.d + a.Hq + a.PQ * a.PX + a.PQ);
-  hipLaunchKernelGGL(query_prologue_kernel, dim3(n_groups * QT), dim3(kQueryThreads), lds, stream, a);
+  hipLaunchKernelGGL(query_prologue_kernel, dim3(n_groups * QT, 2), dim3(kQueryThreads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
