@@ -415,6 +415,8 @@ def main() -> None:
                 s, top = E.topk(logits, k_local, ids=local._ids_flat)
             if world > 1:
                 gathered = all_gather_rows(E.pack_candidates(s, top, kp))
+                if E.merge_filter_fusable(kp, inv.shape[1], k):   # what the sharded module does: the filter inside the merge launch
+                    return E.merge_candidates_filtered(gathered, world, kp, kp, inv, k)
                 s, top = E.merge_candidates(gathered, world, kp, kp)
             return E.filter_seen_ids(top, s, inv, k)
 
@@ -433,8 +435,11 @@ def main() -> None:
             for i in range(n):
                 ev_step[i].record()
                 hn = topk_mod.submit(q, k=min(kp, N), **kw) if i + 1 < n else None
-                s_, top_ = topk_mod.result(h)
-                out = E.filter_seen_ids(top_, s_, inv, k)
+                if E.merge_filter_fusable(min(kp, N), inv.shape[1], k):
+                    out = topk_mod.result(h, seen=(inv, k))
+                else:
+                    s_, top_ = topk_mod.result(h)
+                    out = E.filter_seen_ids(top_, s_, inv, k)
                 h = hn
             return out
 

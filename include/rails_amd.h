@@ -304,6 +304,12 @@ int rails_pack_candidates(const float* scores, const int64_t* ids, int32_t rows,
 /* gathered: (n_ranks, rows, 2k) int64.  n_ranks * k <= 16384.  k_out <= n_ranks * k. */
 int rails_merge_candidates(const int64_t* gathered, int32_t n_ranks, int32_t rows, int32_t k, int32_t k_out,
                            float* out_scores, int64_t* out_ids, void* stream);
+/* rails_merge_candidates followed by rails_filter_seen_ids in ONE launch (the sharded counterpart of rails_topk_filtered): the k_prime
+ * merged winners of every row go through the seen-id filter inside the merge kernel and k_out (ids, scores) per row are written --
+ * the same bits as the two calls.  k_prime <= 512, width <= 256 (RAILS_ENOTSUP otherwise). */
+int rails_merge_candidates_filtered(const int64_t* gathered, int32_t n_ranks, int32_t rows, int32_t k, int32_t k_prime,
+                                    const int64_t* invalid_ids, int32_t width, int32_t k_out, int64_t* out_ids, float* out_scores,
+                                    void* stream);
 
 /* Finish of a speculate-then-verify brute-force top-k (precision "f16x3-exact"; no counterpart in the reference, whose
  * MoLBruteForceTopK scores everything in one precision, mol_top_k.py:84-130).  Per row: n_cand entries with their exact fp32

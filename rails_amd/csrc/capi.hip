@@ -551,6 +551,16 @@ int rails_merge_candidates(const int64_t* gathered, int32_t n_ranks, int32_t row
   return r == kOk ? r : fail(r, "merge_candidates");
 }
 
+int rails_merge_candidates_filtered(const int64_t* gathered, int32_t n_ranks, int32_t rows, int32_t k, int32_t k_prime, const int64_t* invalid_ids,
+                                    int32_t width, int32_t k_out, int64_t* out_ids, float* out_scores, void* stream) {
+  g_err[0] = '\0';
+  if (n_ranks <= 0 || rows < 0 || k <= 0 || k_prime <= 0 || (int64_t)k_prime > (int64_t)n_ranks * k || width < 0 || k_out <= 0 || k_out > k_prime) { set_error("merge_candidates_filtered: bad size"); return RAILS_EINVAL; }
+  if (rows == 0) return RAILS_OK;
+  if (!gathered || !out_scores || !out_ids || !invalid_ids) { set_error("merge_candidates_filtered: NULL pointer"); return RAILS_EINVAL; }
+  const int r = merge_candidates(gathered, n_ranks, rows, k, k_prime, out_scores, out_ids, (hipStream_t)stream, invalid_ids, width, k_out);
+  return r == kOk ? r : fail(r, "merge_candidates_filtered");
+}
+
 int rails_abi_version(void) { return RAILS_ABI_VERSION; }
 
 int rails_set_run_predicate(const int32_t* device_flag) {

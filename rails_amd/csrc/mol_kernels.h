@@ -154,7 +154,7 @@ int rescore_select(const float* exact, int64_t ld, const float* approx, const fl
                    const int64_t* ids, int rows, int n_ranked, int kc, int k, float margin_eps, float check_eps, float* out_scores,
                    int64_t* out_ids, int* ok, float* stats, hipStream_t stream);
 int merge_candidates(const int64_t* gathered, int R, int rows, int k, int k_out, float* out_scores, int64_t* out_ids,
-                     hipStream_t stream);
+                     hipStream_t stream, const int64_t* f_invalid = nullptr, int f_width = 0, int f_k = 0);
 int filter_seen(const int64_t* top_ids, const float* top_scores, int rows, int k_prime, const int64_t* invalid,
                 int width, int k, int64_t* out_ids, float* out_scores, hipStream_t stream);
 

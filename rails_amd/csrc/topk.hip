@@ -940,14 +940,23 @@ __global__ void pack_candidates_kernel(const float* __restrict__ scores, const i
 // ranks are a permutation); keys of rank < k_out are written straight to their slot.  One barrier instead of the
 // ~70 of a 2048-key bitonic sort (21 us -> 12 us at R = 8, k = 200).  Unsorted input (not produced by this library, but
 // legal for the C entry point) is detected and takes the bitonic sort.
+// f_invalid != NULL: the seen-id filter of the candidate index runs inside this launch over the k_out merged winners (staged in LDS,
+// filter_from_lds) and f_k results per row are written -- the sharded counterpart of rails_topk_filtered.
 __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(const int64_t* __restrict__ gathered, int R, int rows,
                                                                        int k, int k_out, int npad,
                                                                        float* __restrict__ out_scores,
-                                                                       int64_t* __restrict__ out_ids) {
+                                                                       int64_t* __restrict__ out_ids,
+                                                                       const int64_t* __restrict__ f_invalid, int f_width, int f_k) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
   __shared__ int unsorted;
+  __shared__ int64_t f_id[kFuseMaxK], f_inv[kFuseMaxW];
+  __shared__ float f_sc[kFuseMaxK];
+  __shared__ int f_scratch[kSortThreads / 64 + 2];
   const int row = blockIdx.x;
   const int count = R * k;
+  const bool fuse = f_invalid != nullptr;
+  if (fuse)
+    for (int i = threadIdx.x; i < f_width; i += kSortThreads) f_inv[i] = f_invalid[(int64_t)row * f_width + i];   // visible after the barriers below
   if (threadIdx.x == 0) unsorted = 0;
   for (int i = threadIdx.x; i < npad; i += kSortThreads) {
     unsigned long long kv = 0ull;
@@ -962,8 +971,15 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(const in
   auto emit = [&](unsigned long long kv, int slot) {
     const unsigned int pos = ~(unsigned int)(kv & 0xFFFFFFFFull);
     const int r = (int)(pos / (unsigned int)k), jj = (int)(pos - (unsigned int)r * (unsigned int)k);
-    out_scores[(int64_t)row * k_out + slot] = unorderable((unsigned int)(kv >> 32));
-    out_ids[(int64_t)row * k_out + slot] = gathered[((int64_t)r * rows + row) * 2 * k + k + jj];
+    const float sc = unorderable((unsigned int)(kv >> 32));
+    const int64_t id = gathered[((int64_t)r * rows + row) * 2 * k + k + jj];
+    if (fuse) { f_sc[slot] = sc; f_id[slot] = id; }
+    else { out_scores[(int64_t)row * k_out + slot] = sc; out_ids[(int64_t)row * k_out + slot] = id; }
+  };
+  auto finish = [&]() {
+    if (!fuse) return;
+    __syncthreads();
+    filter_from_lds<kSortThreads>(f_id, f_sc, k_out, f_inv, f_width, f_k, out_ids + (int64_t)row * f_k, out_scores + (int64_t)row * f_k, f_scratch);
   };
   bool bad = false;
   for (int i = threadIdx.x; i + 1 < count; i += kSortThreads)
@@ -987,6 +1003,7 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(const in
       }
       if (rank < k_out) emit(kv, rank);
     }
+    finish();
     return;
   }
   for (int size = 2; size <= npad; size <<= 1) {
@@ -1002,6 +1019,7 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(const in
     }
   }
   for (int j = threadIdx.x; j < k_out; j += kSortThreads) emit(keys[j], j);
+  finish();
 }
 
 int pack_candidates(const float* scores, const int64_t* ids, int rows, int k_local, int k, int64_t* msg, hipStream_t stream) {
@@ -1012,8 +1030,12 @@ int pack_candidates(const float* scores, const int64_t* ids, int rows, int k_loc
 }
 
 int merge_candidates(const int64_t* gathered, int R, int rows, int k, int k_out, float* out_scores, int64_t* out_ids,
-                     hipStream_t stream) {
+                     hipStream_t stream, const int64_t* f_invalid, int f_width, int f_k) {
   if (rows <= 0 || k_out <= 0) return kOk;
+  if (f_invalid && !(k_out <= kFuseMaxK && f_width >= 0 && f_width <= kFuseMaxW && f_k > 0 && f_k <= k_out)) {
+    set_error("merge_candidates: the seen-id filter cannot be fused at k = %d, width = %d", k_out, f_width);
+    return kErrUnsupported;
+  }
   const int64_t count = (int64_t)R * k;
   if (count > kSortCap) { set_error("merge_candidates: R*k = %lld exceeds the in-LDS sort capacity (%d)", (long long)count, kSortCap); return kErrUnsupported; }
   if (ensure_sort_lds() != kOk) return kErrLaunch;
@@ -1022,7 +1044,7 @@ int merge_candidates(const int64_t* gathered, int R, int rows, int k, int k_out,
     return kErrLaunch;
   const int npad = next_pow2((int)count < 2 ? 2 : (int)count);
   hipLaunchKernelGGL(merge_candidates_kernel, dim3(rows), dim3(kSortThreads), npad * sizeof(unsigned long long), stream, gathered, R,
-                     rows, k, k_out, npad, out_scores, out_ids);
+                     rows, k, k_out, npad, out_scores, out_ids, f_invalid, f_width, f_k);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

@@ -801,6 +801,26 @@ def merge_candidates(gathered: torch.Tensor, n_ranks: int, k: int, k_out: int) -
     return out_s, out_i
 
 
+def merge_filter_fusable(k_prime: int, width: int, k: int) -> bool:
+    return 0 < k <= k_prime <= 512 and 0 <= width <= 256
+
+
+def merge_candidates_filtered(gathered: torch.Tensor, n_ranks: int, k: int, k_prime: int, invalid_ids: torch.Tensor, k_out: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """merge_candidates(gathered, n_ranks, k, k_prime) followed by filter_seen_ids(..., invalid_ids, k_out) in one launch
+    (include/rails_amd.h rails_merge_candidates_filtered) -> (out_ids (rows, k_out), out_scores (rows, k_out))."""
+    lib = _lib.load()
+    _require_device(gathered, "gathered messages")
+    rows = gathered.shape[0] // n_ranks
+    gathered = gathered.contiguous()
+    invalid_ids = invalid_ids.to(device=gathered.device, dtype=torch.int64).contiguous()
+    out_s = torch.empty((rows, k_out), dtype=torch.float32, device=gathered.device)
+    out_i = torch.empty((rows, k_out), dtype=torch.int64, device=gathered.device)
+    with _on_device(gathered.device):
+        _lib.check(lib.rails_merge_candidates_filtered(_ptr(gathered), n_ranks, rows, k, k_prime, _ptr(invalid_ids), invalid_ids.shape[1], k_out,
+                                                       _ptr(out_i), _ptr(out_s), _stream()), "rails_merge_candidates_filtered")
+    return out_i, out_s
+
+
 def filter_seen_ids(top_ids: torch.Tensor, top_scores: torch.Tensor, invalid_ids: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
     """Row-wise seen-id filter (reference indexing/candidate_index.py:154-178) -> (ids (rows,k), scores (rows,k))."""
     lib = _lib.load()

@@ -118,12 +118,28 @@ class ShardedTopK(TopKModule):
             ready.record()
         return ("pending", msg, ready, k, on_gpu, s.dtype)
 
-    def result(self, handle) -> Tuple[torch.Tensor, torch.Tensor]:
+    def forward_filtered(self, query_embeddings: torch.Tensor, k_prime: int, invalid_ids: torch.Tensor, k: int, **kwargs):
+        """CandidateIndex.get_top_k_outputs' body for the sharded modules: the seen-id filter runs inside the merge launch
+        (rails_merge_candidates_filtered) -> (top_k_ids (B, k), top_k_scores (B, k)), or None when the sizes are outside the fused path
+        or the merge is not the HIP one (the caller then composes forward + filter_seen_ids: same bits)."""
+        if self._world == 1:
+            local = getattr(self, "_local_module", None)
+            return local.forward_filtered(query_embeddings, k_prime, invalid_ids, k, **kwargs) if hasattr(local, "forward_filtered") else None
+        if not (query_embeddings.is_cuda and self._merge is _hip_merge and E.merge_filter_fusable(k_prime, invalid_ids.shape[1], k)) or k_prime > self._n_total:
+            return None
+        return self.result(self.submit(query_embeddings, k_prime, **kwargs), seen=(invalid_ids, k))
+
+    def result(self, handle, seen=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """All-gather of the per-shard candidates + merge -> (scores, ids), identical on every rank.  On the GPU both run on this
-        module's exchange stream, behind the handle's event; the current stream waits for the merge only."""
+        module's exchange stream, behind the handle's event; the current stream waits for the merge only.
+        seen = (invalid_ids, k): the seen-id filter inside the merge launch -> (ids (B, k), scores (B, k)) instead (GPU merge only)."""
         if handle[0] == "done":
+            if seen is not None:
+                return E.filter_seen_ids(handle[2], handle[1], seen[0], seen[1])
             return handle[1], handle[2]
         _, msg, ready, k, on_gpu, dtype = handle
+        if seen is not None and not (msg.is_cuda and on_gpu):
+            raise RuntimeError("result(seen=...) needs the HIP merge")
         if not msg.is_cuda:
             gathered = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype)
             dist.all_gather_into_tensor(gathered, msg, group=self._group)
@@ -145,7 +161,11 @@ class ShardedTopK(TopKModule):
             else:
                 gathered = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype, device=msg.device)
                 dist.all_gather_into_tensor(gathered, msg, group=self._group)
-            if on_gpu:   # one kernel: rank-major candidates -> exact top-k (scores, ids)
+            if on_gpu and seen is not None:   # one kernel: rank-major candidates -> exact top-k -> seen-id filter
+                mi, ms = E.merge_candidates_filtered(gathered, self._world, k, k, seen[0], seen[1])
+                invalid_keep = seen[0]
+                invalid_keep.record_stream(side)
+            elif on_gpu:   # one kernel: rank-major candidates -> exact top-k (scores, ids)
                 ms, mi = E.merge_candidates(gathered, self._world, k, k)
             else:
                 all_s, all_ids = unpack_candidates(gathered.view(self._world, msg.shape[0], msg.shape[1]), k)
@@ -154,6 +174,8 @@ class ShardedTopK(TopKModule):
         cur.wait_stream(side)
         ms.record_stream(cur)
         mi.record_stream(cur)
+        if seen is not None:
+            return mi, ms
         return ms, mi
 
     def exchange_info(self) -> dict:
@@ -212,6 +234,11 @@ class ShardedMoLAvgTopK(ShardedTopK):
         out = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype, device=msg.device)
         dist.all_gather_into_tensor(out, msg, group=self._group)
         return out
+
+    def forward_filtered(self, query_embeddings: torch.Tensor, k_prime: int, invalid_ids: torch.Tensor, k: int, **kwargs):
+        if k_prime > self._avg_top_k or (self._global and self._world > 1):
+            return None   # forward's own checks / the global-K' exchange: the caller composes forward + filter_seen_ids
+        return super().forward_filtered(query_embeddings, k_prime, invalid_ids, k, **kwargs)
 
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
         if k > self._avg_top_k:

@@ -1478,3 +1478,26 @@ def test_verified_modes_with_the_fused_first_pass(dev, mode):
             assert torch.equal(s, r_s) and torch.equal(i, r_i)
         st = tk.stats()
         assert st["calls"] == 3 and st["fallbacks"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,rows,k,width,k_out", [(2, 9, 200, 61, 120), (8, 32, 200, 61, 120), (4, 5, 64, 211, 50), (3, 7, 512, 1, 512), (8, 3, 25, 256, 20)])
+def test_filtered_merge_equals_merge_then_filter(dev, R, rows, k, width, k_out):
+    """rails_merge_candidates_filtered (the seen-id filter inside the shard-merge launch) against rails_merge_candidates +
+    rails_filter_seen_ids: sorted per-rank lists with ties across ranks, seen ids hitting 0-100 % of the winners."""
+    g = torch.Generator().manual_seed(R * 1000 + rows)
+    msgs = []
+    for r in range(R):
+        s = torch.randint(0, 60, (rows, k), generator=g).float().div(8.0).sort(dim=1, descending=True).values   # many ties, within and across ranks
+        i = torch.arange(k, dtype=torch.int64).repeat(rows, 1) * R + r + 1000 * torch.arange(rows, dtype=torch.int64)[:, None]
+        msgs.append(E.pack_candidates(s.to(dev), i.to(dev), k))
+    gathered = torch.cat(msgs, 0)
+    ms, mi = E.merge_candidates(gathered, R, k, k)
+    for frac in (0.0, 0.5, 1.0):
+        hit = int(width * frac)
+        inv = torch.full((rows, width), -7, dtype=torch.int64, device=dev)
+        if hit:
+            inv[:, :hit] = mi[:, torch.randperm(k, generator=g)[:hit].to(dev)] if hit <= k else mi[:, :1]
+        want_i, want_s = E.filter_seen_ids(mi, ms, inv, k_out)
+        got_i, got_s = E.merge_candidates_filtered(gathered, R, k, k, inv, k_out)
+        assert torch.equal(got_i, want_i) and torch.equal(got_s, want_s)

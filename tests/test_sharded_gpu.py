@@ -70,6 +70,15 @@ def _worker(rank: int, world: int, port: int, n_items: int, precision, ret, work
             p2 = sh.result(h2)
             r2 = sh(q2, k=k)
             assert torch.equal(p1[0], s) and torch.equal(p1[1], i) and torch.equal(p2[0], r2[0]) and torch.equal(p2[1], r2[1]), "pipelined != unpipelined"
+            # CandidateIndex route: the seen-id filter inside the merge launch == forward + filter_seen_ids
+            kk = min(120, i.shape[1])
+            inv = i[:, torch.randperm(i.shape[1], device=dev)[:61]] if i.shape[1] >= 61 else i[:, :1].repeat(1, 61)
+            want_i, want_s = E.filter_seen_ids(i, s, inv, kk)
+            got = sh.forward_filtered(q, min(k, n_items), inv, kk)
+            assert got is not None and torch.equal(got[0], want_i) and torch.equal(got[1], want_s), "filtered merge != merge + filter"
+            cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)      # the harness object holds the whole id table; the module is sharded
+            c_i, c_s, _ = cand.get_top_k_outputs(q, kk, {}, sh, inv, truncate_k_prime_to=min(k, n_items))
+            assert torch.equal(c_i, want_i) and torch.equal(c_s, want_s)
             if precision in ("f16x3-exact", "f16-exact"):   # ... and both are the fp32 path's result, bit for bit
                 mol32 = build_module(cfg, O.synthetic_weights(cfg, seed=1), dev)
                 f32_s, f32_i = rails_amd.MoLBruteForceTopK(mol32, X, ids)(q, k=k)

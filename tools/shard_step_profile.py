@@ -55,6 +55,8 @@ with torch.inference_mode():
     def exchange(msg):
         if a.world > 1:
             gathered = msg.repeat(a.world, 1)
+            if E.merge_filter_fusable(kp, inv.shape[1], k):   # the sharded module's route: the seen-id filter inside the merge launch
+                return E.merge_candidates_filtered(gathered, a.world, kp, kp, inv, k)
             s, top = E.merge_candidates(gathered, a.world, kp, kp)
         else:
             s, top = msg
