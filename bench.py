@@ -251,6 +251,13 @@ def quick_workload(name: str, B: int, k: int, kp: int, steps: int, dev, items: i
 
 
 def main() -> None:
+    # The cyclic garbage collector stays off while anything is timed: a generation-2 collection of this process (torch modules, numpy
+    # fixtures, thousands of event objects) is a 30-40 ms host pause, and a step is 2-6 ms -- one collection inside a 20-step region
+    # reads as + 2 ms per step (seen as 4.7 instead of 2.8 ms on the f16x3-exact leg; the kernel trace showed the GPU idle for 30.6 ms
+    # in front of ONE launch).  Reference counting still frees every tensor at once; cycles are collected between the legs.
+    import gc
+
+    gc.disable()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -444,6 +451,7 @@ def main() -> None:
             return out
 
         pipelined_headline = args.pipeline and world > 1 and not two_pass
+        gc.collect()
         for _ in range(args.warmup):
             step()
         if world > 1:
@@ -645,6 +653,7 @@ def main() -> None:
                     out_ids, out_scores, _ = cand.get_top_k_outputs(q, k, kw, topk_mod, inv, truncate_k_prime_to=kp)
                     return out_ids, out_scores
 
+                gc.collect()
                 x_ids, x_scores = step_exact()
                 identical = bool(torch.equal(x_ids, ref_ids) and torch.equal(x_scores, ref_scores))
                 for _ in range(args.warmup):
@@ -652,13 +661,22 @@ def main() -> None:
                 if world > 1:
                     dist.barrier()
                 torch.cuda.synchronize()
+                dbg = os.environ.get("RAILS_BENCH_DEBUG")
+                evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if dbg else None
                 t0 = time.perf_counter()
-                for _ in range(args.steps):
+                for i_ in range(args.steps):
+                    if dbg:
+                        evs[i_].record()
                     step_exact()
+                if dbg:
+                    evs[args.steps].record()
                 torch.cuda.synchronize()
                 if world > 1:
                     dist.barrier()
                 exact_elapsed = time.perf_counter() - t0
+                if dbg:
+                    print(mode, "per-step ms:", [round(a.elapsed_time(b), 2) for a, b in zip(evs, evs[1:])], "pad_scale", local._pad_scale, "pause", local._pause_left,
+                          "index32", local._index32 is not None, file=sys.stderr)
                 stats = dict(local.stats())
                 # shadow audit (not timed): the same step with every call also run on the dense fp32 path on a side stream and compared
                 local.audit_every = 1

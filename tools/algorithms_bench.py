@@ -4,7 +4,8 @@ get_top_k_outputs calls, k = 120, k' = 200, batch 32; data/eval.py:139-170) plus
 and agreement with exact brute force on the same (random-init, synthetic) inputs.
   python tools/algorithms_bench.py --workload amzn-books
 """
-import argparse, json, os, sys, time
+import argparse
+import gc, json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench, rails_amd
@@ -47,13 +48,15 @@ inv = torch.zeros((B, width), dtype=torch.int64, device=dev)
 model = type("M", (), {"_ndp_module": mol})()
 cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)
 rows, exact_ids = [], None
+gc.disable()
 with torch.inference_mode():
     for name in (a.algorithms.split(",") if a.algorithms else ALGOS[a.workload]):
         tk = rails_amd.get_top_k_module(name, model, X, ids)
         for _ in range(3):
             out_ids, out_scores, _ = cand.get_top_k_outputs(q, k, kw, tk, inv, truncate_k_prime_to=kp)
         torch.cuda.synchronize()
-        ts = []
+        gc.collect()      # the cyclic collector is off while calls are timed (a generation-2 pass is a 30-40 ms host pause: the one-off
+        ts = []           # outliers of the round-2 / round-3 tables), cycles are collected between the algorithms
         for _ in range(20):
             t0 = time.perf_counter()
             out_ids, out_scores, _ = cand.get_top_k_outputs(q, k, kw, tk, inv, truncate_k_prime_to=kp)
