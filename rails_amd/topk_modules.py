@@ -16,6 +16,8 @@ from __future__ import annotations
 import abc
 from typing import Dict, Optional, Tuple
 
+import math
+
 import torch
 
 from . import engine as E
@@ -98,6 +100,7 @@ class MoLBruteForceTopK(MoLTopKModule):
         self._calib_engine = None
         self._err_seen = 0.0          # largest |first pass - fp32| ever seen on re-scored candidates and probes (reset only with the engine)
         self._risk_pool: Optional[torch.Tensor] = None   # positions of the highest-norm items (probed every call)
+        self._risk_rows: Optional[torch.Tensor] = None   # the probe rows the rotation over them produces, precomputed
         self.audit_every: int = int(self.AUDIT_EVERY)    # > 0: every n-th speculative call is also run on the dense fp32 path and compared
         self._audit_stream = None
         self._debug_first_pass_bias = None
@@ -258,7 +261,7 @@ class MoLBruteForceTopK(MoLTopKModule):
             c16, pos = E.topk(s16, kc, workspace=ws)
         # two more tiles per query of probes (random + highest-norm items), re-scored too, so that the bound |s16 - s32| <= eps is
         # watched outside the candidates as well
-        pos = torch.cat([pos, self._probes(B, N)], dim=1)
+        pos = torch.cat([pos, *self._probes(B, N)], dim=1)
         if self._index32 is not None:
             cand, _ = ex.gather_index(self._index32, pos)
         else:
@@ -413,8 +416,8 @@ class MoLBruteForceTopK(MoLTopKModule):
     RISK_POOL = 4096      # highest-norm items of the corpus kept as a probe pool
     RISK_ALWAYS = 16      # ... the top of it is probed on every call
 
-    def _probes(self, B: int, N: int) -> torch.Tensor:
-        """(B, 64) corpus positions re-scored next to the candidates so that |first pass - fp32| is watched OUTSIDE them too:
+    def _probes(self, B: int, N: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Two (B, 32) blocks of corpus positions re-scored next to the candidates so that |first pass - fp32| is watched OUTSIDE them too:
         32 drawn uniformly from the whole corpus (row block `call mod 64` of a pool drawn once per (B, N)), the RISK_ALWAYS items
         of largest embedding norm on every call, and 16 more rotating through the RISK_POOL highest-norm items -- large inputs make
         large gate pre-activations, which is where a reduced-precision first pass is furthest off."""
@@ -439,15 +442,21 @@ class MoLBruteForceTopK(MoLTopKModule):
                     i = i[sel]
                 best_v, best_i = v, i
             self._risk_pool = best_i.to(torch.int64)
+            self._risk_rows = None
+        if self._risk_rows is None:
+            # every row the rotation can produce, once: (phases, 32) positions = the RISK_ALWAYS items + 16 of the rest, window start
+            # (phase * 16) mod len(rest).  Per call the probes are then two views -- no index arithmetic on the device (the arange /
+            # add / remainder / index / cat chain of the first version was seven small launches, ~40 us of a 1.7 ms step).
+            risk = self._risk_pool
+            n_always = min(self.RISK_ALWAYS, risk.numel())
+            rest = risk[n_always:] if risk.numel() > n_always else risk
+            n_rot = E.TILE_ITEMS - n_always
+            m = max(rest.numel(), 1)
+            phases = m // math.gcd(m, n_rot)
+            idx = (torch.arange(phases, device=dev)[:, None] * n_rot + torch.arange(n_rot, device=dev)[None, :]) % m
+            self._risk_rows = torch.cat([risk[:n_always].unsqueeze(0).expand(phases, -1), rest[idx]], dim=1).contiguous()
         call = self.rescore_stats["calls"]
-        risk = self._risk_pool
-        n_always = min(self.RISK_ALWAYS, risk.numel())
-        rest = risk[n_always:] if risk.numel() > n_always else risk
-        n_rot = E.TILE_ITEMS - n_always
-        start = (call * n_rot) % max(rest.numel(), 1)
-        rot = rest[(start + torch.arange(n_rot, device=dev)) % rest.numel()]
-        extra = torch.cat([risk[:n_always], rot]).unsqueeze(0).expand(B, -1)
-        return torch.cat([pool[call % 64], extra], dim=1)
+        return pool[call % 64], self._risk_rows[call % self._risk_rows.shape[0]].unsqueeze(0).expand(B, -1)
 
     def _dense_fp32_index(self) -> E.MolIndex:
         ex = self._engine.exact

@@ -1287,7 +1287,7 @@ def test_exact_modes_against_planted_first_pass_outliers(dev, mode):
         s, i = tk(q, k=k)                      # clean call: verified and audited, no mismatch
         assert torch.equal(s, r_s) and torch.equal(i, r_i)
         assert tk.audit_summary()["audited"] == 1 and tk.audit_summary()["mismatches"] == 0
-        probed = set(tk._probes(B, N).reshape(-1).tolist()) | set(tk._risk_pool[: tk.RISK_ALWAYS].tolist())
+        probed = set(torch.cat(tk._probes(B, N), dim=1).reshape(-1).tolist()) | set(tk._risk_pool[: tk.RISK_ALWAYS].tolist())
         lone = next(int(v) for v in (top_i[0] - 1).tolist() if int(v) not in probed)
         tk._debug_first_pass_bias = (torch.tensor([lone], device=dev), 5.0)
         s, i = tk(q, k=k)
