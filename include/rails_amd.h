@@ -180,6 +180,13 @@ int rails_mol_score_dense(const rails_mol_shape* shape, const float* gate_pack, 
 int rails_mol_score_candidates(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack,
                                int32_t batch, const float* cand_index, int64_t n_cand, float* logits,
                                int64_t ld, void* stream);
+/* Per-row candidates scored IN PLACE: logits[b][j] = MoL(query b, item positions[b][j]) with the item operands read straight from the
+ * shared index -- rails_mol_index_gather + rails_mol_score_candidates without the gathered copy and its launch (same arithmetic per
+ * pair, same bits).  Exact-fp32 shapes on the independent-wave shell (rails_mol_score_indexed_supported != 0); the 256-logit shape
+ * and the f16 precisions gather.  positions must lie in [0, n_items) (they are clamped, not masked); n_cand a multiple of 32. */
+int rails_mol_score_indexed_supported(const rails_mol_shape* shape, int32_t batch, int64_t n_cand);
+int rails_mol_score_indexed(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack, int32_t batch, const float* index,
+                            int64_t n_items, const int64_t* positions, int64_t n_cand, float* logits, int64_t ld, void* stream);
 
 /* ---- dot-product (MIPS) scoring ---------------------------------------------------------------
  * Replaces torch.mm(query_embeddings, item_embeddings_t) of MIPSBruteForceTopK.forward

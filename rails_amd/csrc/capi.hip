@@ -329,6 +329,39 @@ int rails_mol_score_dense(const rails_mol_shape* s, const float* gate_pack, cons
   return score_common(s, gate_pack, query_pack, batch, index, n_items, logits, ld, 0, stream, "score_dense");
 }
 
+int rails_mol_score_indexed_supported(const rails_mol_shape* s, int32_t batch, int64_t n_cand) {
+  if (!s || !shape_supported(s) || is_split(*s) || batch <= 0 || n_cand <= 0 || n_cand % 32 != 0) return 0;
+  const int cu = compute_units();
+  if (cu <= 0) return 0;
+  ScoreArgs a;
+  fill_score_args(s, nullptr, nullptr, batch, nullptr, n_cand, nullptr, n_cand, 1, &a);
+  a.cand_pos = reinterpret_cast<const int64_t*>(8);   // never dereferenced: dry run
+  a.dry_run = 1;
+  const int r = score_launch(*s, a, cu, nullptr);
+  g_err[0] = '\0';
+  return r == kOk ? 1 : 0;
+}
+
+int rails_mol_score_indexed(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch, const float* index,
+                            int64_t n_items, const int64_t* positions, int64_t n_cand, float* logits, int64_t ld, void* stream) {
+  g_err[0] = '\0';
+  if (!shape_supported(s)) return RAILS_ENOTSUP;
+  if (batch < 0 || n_items <= 0 || n_cand < 0) { set_error("score_indexed: bad size"); return RAILS_EINVAL; }
+  if (batch == 0 || n_cand == 0) return RAILS_OK;
+  if (!gate_pack || !query_pack || !index || !positions || !logits) { set_error("score_indexed: NULL pointer"); return RAILS_EINVAL; }
+  if (n_cand % 32 != 0) { set_error("score_indexed: n_cand must be a multiple of 32"); return RAILS_EINVAL; }
+  if (ld < n_cand) { set_error("score_indexed: ld < n_cand"); return RAILS_EINVAL; }
+  if (is_split(*s)) { set_error("score_indexed: exact-fp32 precision only"); return RAILS_ENOTSUP; }
+  const int cu = compute_units();
+  if (cu <= 0) { set_error("score_indexed: no HIP device"); return RAILS_ELAUNCH; }
+  ScoreArgs a;
+  fill_score_args(s, gate_pack, query_pack, batch, index, n_cand, logits, ld, 1, &a);
+  a.cand_pos = positions;
+  a.index_items = n_items;
+  const int r = score_launch(*s, a, cu, (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "score_indexed");
+}
+
 int rails_mol_score_candidates(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch,
                                const float* cand_index, int64_t n_cand, float* logits, int64_t ld, void* stream) {
   return score_common(s, gate_pack, query_pack, batch, cand_index, n_cand, logits, ld, 1, stream, "score_candidates");

@@ -47,6 +47,10 @@ struct ScoreArgs {
   unsigned long long* sel_list;   // [B][kSelSegs workgroups][kSelSegCap] keys; empty slots are 0
   unsigned int* sel_thr;          // [B] running lower bound on the k-th largest orderable score (0: none yet)
   int sel_k;
+  // per-row candidates addressed IN the shared index (rails_mol_score_indexed): candidate j of row b is item cand_pos[b * n_items + j]
+  // of an index of index_items items; NULL = per-row candidates come as their own gathered tiles (rails_mol_score_candidates)
+  const int64_t* cand_pos;
+  int64_t index_items;
   int32_t* sel_status;            // zeroed by the scoring launch, set by the final selection when a list overflowed
   int dry_run;                    // 1: validate the dispatch (shape, shell, fused selection possible) without launching
 };

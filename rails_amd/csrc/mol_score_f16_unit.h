@@ -505,6 +505,7 @@ static __device__ long long g_f16_phase[32];
 //          buffering in stage Y and no pinned order -- the compiler's own schedule fits without spilling, a pinned one does not.
 template <bool OVERLAP, bool TIGHT, bool NONE = false>
 struct F16Unit {
+  static constexpr bool kIndexedCandidates = false;
   template <class G>
   static constexpr int kLdsWeightFloats = SplitPack<G>::kLdsFloats;
   template <class G, int NW>

@@ -212,6 +212,7 @@ __device__ __forceinline__ float query_mlp(f32x16 (&D1)[PX], const float4* sW1, 
 
 // The exact-fp32 unit policy of the kernel shells (mol_score_shell.h).
 struct Fp32Unit {
+  static constexpr bool kIndexedCandidates = true;   // the indexed-candidate instantiation of the direct shell is built (mol_score_shell.h)
   template <class G>
   static constexpr int kLdsWeightFloats = G::kWpackFloats;
   template <class G, int NW>

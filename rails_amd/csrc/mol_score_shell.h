@@ -33,7 +33,12 @@ __device__ __forceinline__ void stage_weights(const ScoreArgs& p, float* smem) {
 // Used when fewer than 8 query groups exist (B < 8 * 32/P_Q), for per-row candidates, and for shapes whose
 // tile does not fit LDS twice.  unit = (tile, query group), groups fastest.
 // ---------------------------------------------------------------------------------------------
-template <class U, int PQ, int PX, int DD, int H, int NW>
+// INDEXED (per-row candidates only): the candidates are not gathered into tiles of their own first; lane x of a unit reads the
+// fragments of ITS candidate straight from the shared index -- item i's share of fragment slot s sits at float4
+// (i / 32) * tile + s * 64 + (lane & 32) + i % 32, i.e. at a per-lane base plus the same slot offsets a tile has.  Handing the unit
+// policies `base - lane` as the tile pointer makes their `tile[slot * 64 + lane]` reads land there with no change to them.  A separate
+// instantiation: the dense direct path keeps its wave-uniform tile pointer.
+template <class U, int PQ, int PX, int DD, int H, int NW, bool INDEXED = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(ScoreArgs p) {
   using G = Geo<PQ, PX, DD, H>;
   MOL_RUN_IF(p.run_if);
@@ -67,6 +72,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(Score
     const int g = p.per_row ? row / G::QT : innr;
     const int64_t tile_addr = p.per_row ? (int64_t)row * p.n_tiles + tile : tile;
     const float4* tEx = reinterpret_cast<const float4*>(p.ipack + tile_addr * (int64_t)G::kTileFloats);
+    if constexpr (INDEXED) {
+      int64_t src = p.cand_pos[(int64_t)row * p.n_items + tile * kTileItems + x];
+      src = src < 0 ? 0 : (src >= p.index_items ? p.index_items - 1 : src);   // callers pass positions of the index; clamped for memory safety only
+      tEx = reinterpret_cast<const float4*>(p.ipack) + (src >> 5) * (int64_t)(G::kTileFloats / 4) + (lane & 32) + (src & 31) - lane;
+    }
     const float4* tGi = tEx + G::kTileExFloats / 4;
     const float* eq = p.eqfrag + (int64_t)g * G::kEqGroupFloats;
     f32x16 D1[PX];
@@ -251,8 +261,16 @@ static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
     if constexpr (kSelBuilt) {
       if (a.sel_list) return go(&mol_score_staged_kernel<U, PQ, PX, DD, H, NW, true>);
     }
-    if constexpr (STAGED) return go(&mol_score_staged_kernel<U, PQ, PX, DD, H, NW, false>);
-    else return go(&mol_score_direct_kernel<U, PQ, PX, DD, H, NW>);
+    if constexpr (STAGED) {
+      if (a.cand_pos) { set_error("indexed candidates need the independent-wave shell"); return kErrUnsupported; }
+      return go(&mol_score_staged_kernel<U, PQ, PX, DD, H, NW, false>);
+    } else {
+      if constexpr (U::kIndexedCandidates && NW == 8) {
+        if (a.cand_pos) return go(&mol_score_direct_kernel<U, PQ, PX, DD, H, NW, true>);
+      }
+      if (a.cand_pos) { set_error("indexed candidates are built for the exact-fp32 kernels only"); return kErrUnsupported; }
+      return go(&mol_score_direct_kernel<U, PQ, PX, DD, H, NW>);
+    }
   }
 }
 

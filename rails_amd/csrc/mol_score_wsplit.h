@@ -440,6 +440,7 @@ static int launch_wsplit(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   // survivors would need 16 x the segment of the register-resident shells), and what the dense path pays for the selection at this
   // shape is 0.5 % of a step.
   if (a.sel_list) { set_error("fused selection is not available for the 256-logit team kernel"); return kErrUnsupported; }
+  if (a.cand_pos) { set_error("indexed candidates are not available for the 256-logit team kernel (gather them: rails_mol_index_gather)"); return kErrUnsupported; }
   if (a.dry_run) return kOk;
   static DynLdsOnce once;
   if (ensure_dyn_lds(once, reinterpret_cast<const void*>(&mol_score_wsplit_kernel<P, PQ, PX, DD, H>), (int)lds) != kOk) return kErrLaunch;

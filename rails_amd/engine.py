@@ -363,6 +363,23 @@ class MolEngine:
             )
         return out
 
+    def score_indexed_supported(self, batch: int, n_cand: int) -> bool:
+        return bool(self.lib.rails_mol_score_indexed_supported(C.byref(self.shape), int(batch), int(n_cand)))
+
+    def score_indexed(self, qpack: torch.Tensor, batch: int, index: MolIndex, positions: torch.Tensor) -> torch.Tensor:
+        """(B, n_cand) logits of per-row candidates given as positions of `index` (a multiple of 32 per row, all inside the index):
+        gather_index + score_candidates without the gathered copy (include/rails_amd.h rails_mol_score_indexed)."""
+        positions = positions.to(device=index.buf.device, dtype=torch.int64).contiguous()
+        n_cand = positions.shape[1]
+        out = torch.empty((batch, n_cand), dtype=torch.float32, device=index.buf.device)
+        with _on_device(index.buf.device):
+            _lib.check(
+                self.lib.rails_mol_score_indexed(C.byref(self.shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(index.buf), index.n_items, _ptr(positions), n_cand,
+                                                 _ptr(out), out.stride(0), _stream()),
+                "rails_mol_score_indexed",
+            )
+        return out
+
     # scoring with the selection fused in (include/rails_amd.h rails_mol_score_topk): no (B, N) logits are read back
     def score_topk_supported(self, batch: int, n_items: int, k: int) -> bool:
         return bool(self.lib.rails_mol_score_topk_supported(C.byref(self.dense_shape), int(batch), int(n_items), int(k)))

@@ -1501,3 +1501,25 @@ def test_filtered_merge_equals_merge_then_filter(dev, R, rows, k, width, k_out):
         want_i, want_s = E.filter_seen_ids(mi, ms, inv, k_out)
         got_i, got_s = E.merge_candidates_filtered(gathered, R, k, k, inv, k_out)
         assert torch.equal(got_i, want_i) and torch.equal(got_s, want_s)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name,N,B,n_cand", [("amzn-books", 50_003, 5, 64), ("amzn-books", 200_000, 33, 352), ("ml-20m", 27_278, 32, 288), ("ml-1m", 3_883, 7, 32)])
+def test_indexed_candidate_scoring_equals_gather_then_score(dev, cfg_name, N, B, n_cand):
+    """rails_mol_score_indexed (per-row candidates read in place from the shared index) against rails_mol_index_gather +
+    rails_mol_score_candidates: the same arithmetic per (query, item) pair, hence the same bits -- duplicates, the first and the
+    last item of the corpus (a ragged last tile) included."""
+    cfg, tk, q, kw = _fused_case(cfg_name, N, B, dev, None)
+    with torch.inference_mode():
+        eng = tk._bind()
+        assert eng.score_indexed_supported(B, n_cand)
+        qpack, _, _ = eng.query_pack(q, kw.get("user_ids"))
+        g = torch.Generator().manual_seed(N + B)
+        pos = torch.randint(0, N, (B, n_cand), generator=g).to(dev)
+        pos[:, 0], pos[:, 1], pos[:, 2] = 0, N - 1, pos[:, 3]
+        cand, _ = eng.gather_index(tk._index, pos)
+        want = eng.score_candidates(qpack, B, cand, n_cand)
+        got = eng.score_indexed(qpack, B, tk._index, pos)
+        assert torch.equal(got, want)
+        dense = eng.score_dense(qpack, B, tk._index)
+        assert torch.equal(got, torch.gather(dense, 1, pos))      # and both are the dense kernel's values at those positions
