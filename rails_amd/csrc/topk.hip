@@ -688,12 +688,9 @@ static int launch_row_select(RowSelectArgs a, int rows, int chunks, int elements
 
 // two-level plan for n > kRowMaxN: chunks of <= kRowMaxN elements (multiples of 4, so float4 loads stay aligned when the
 // row is), chunks * k keys for the second level
-static bool two_level_plan(int64_t n, int k, int* chunks, int64_t* chunk) {
-  if (k > kRowFastK) return false;
-  // first-level chunk size: RAILS_ROW_CHUNK (measurement override) or the largest a workgroup holds in registers
-  static const int64_t max_chunk = [] { const char* e = getenv("RAILS_ROW_CHUNK"); const int64_t v = e ? atoll(e) : 0; return v >= 4096 && v <= kRowMaxN ? v / 4 * 4 : (int64_t)kRowMaxN; }();
+static bool two_level_plan_at(int64_t n, int k, int64_t max_chunk, int* chunks, int64_t* chunk) {
   const int64_t c = (n + max_chunk - 1) / max_chunk;
-  if (c * k > 24 * kRowThreads) return false;
+  if (c * k > 24 * kRowThreads) return false;   // the second level holds 24 576 keys per row
   int64_t len = (n + c - 1) / c;
   len = (len + 3) / 4 * 4;
   if (len > kRowMaxN || len < k) return false;
@@ -702,6 +699,17 @@ static bool two_level_plan(int64_t n, int k, int* chunks, int64_t* chunk) {
   // the last chunk must still hold k elements (its k keys are all real); otherwise leave it to the radix path
   if (n - (int64_t)(*chunks - 1) * len < k) return false;
   return true;
+}
+static bool two_level_plan(int64_t n, int k, int* chunks, int64_t* chunk, int rows = 1 << 30) {
+  if (k > kRowFastK) return false;
+  // first-level chunk size: RAILS_ROW_CHUNK (measurement override), else the largest a workgroup holds in registers -- half of that
+  // for up to eight rows, where 49 152-element chunks leave most of the chip idle (695 762 elements: 1 row 29 -> 27 us, 4 rows
+  // 37 -> 31, 8 rows 37 -> 32; from 32 rows on smaller chunks only add second-level work: 63 -> 75 us).  A plan that does not work
+  // out with the smaller chunks is retried with the full ones, so feasibility does not depend on the row count.
+  static const int64_t forced = [] { const char* e = getenv("RAILS_ROW_CHUNK"); const int64_t v = e ? atoll(e) : 0; return v >= 4096 && v <= kRowMaxN ? v / 4 * 4 : (int64_t)0; }();
+  const int64_t first = forced ? forced : (rows <= 8 ? (int64_t)kRowMaxN / 2 : (int64_t)kRowMaxN);
+  if (two_level_plan_at(n, k, first, chunks, chunk)) return true;
+  return first != kRowMaxN && two_level_plan_at(n, k, kRowMaxN, chunks, chunk);
 }
 
 static int next_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
@@ -747,7 +755,7 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
       return launch_row_select<false>(a, rows, 1, (int)n, stream);
     }
     int chunks; int64_t chunk;
-    if (two_level_plan(n, k, &chunks, &chunk)) {   // two launches: per-chunk winners, then the winners' winners
+    if (two_level_plan(n, k, &chunks, &chunk, rows)) {   // two launches: per-chunk winners, then the winners' winners
       if (ws_bytes < topk_workspace_bytes(rows, n, k)) { set_error("top-k workspace too small"); return kErrNoMem; }
       unsigned long long* lvl1 = static_cast<unsigned long long*>(ws);
       a.chunk = chunk; a.keys_out = lvl1;
