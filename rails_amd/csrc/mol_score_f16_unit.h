@@ -511,7 +511,7 @@ struct F16Unit {
   template <class G, int NW>
   static __device__ __forceinline__ void stage(const ScoreArgs& p, float* smem) { SplitPack<G>::template stage<NW>(p, smem); }
 
-  template <class G, int PX, int DD, bool BULK = false>
+  template <class G, int PX, int DD, bool BULK = false, bool PIPE = false>   // PIPE: fp32 policy only (mol_score_fp32_unit.h)
   static __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float* __restrict__ eq, const float4* tEx, int lane) {
     gemm1_presplit<G, PX, DD, BULK>(D1, reinterpret_cast<const h8*>(eq), reinterpret_cast<const h8*>(tEx), lane);
   }

@@ -50,12 +50,42 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 
 // GEMM1: D1[m][(qj,p), x] = sum_d Eq[qj,p,d] * Ex[x,m,d].  `eq` is the query group's A operand in fragment
 // order ([sc][lane] float4), `tEx` the tile's B operand ([m][sc][lane] float4) -- in HBM or in LDS.
-template <class G, int PX, int DD, bool BULK = false>
+template <class G, int PX, int DD, bool BULK = false, bool PIPE = false>
 __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float4* __restrict__ eq, const float4* tEx, int lane) {
 #pragma unroll
   for (int m = 0; m < PX; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) D1[m][r] = 0.0f;
+  if constexpr (PIPE) {
+    // Operands straight from memory (independent-wave shell): K-chunk sc + 1 is requested BEFORE chunk sc's MFMAs, so a chunk's
+    // memory latency runs under 2 048 cycles of this wave's matrix work (and its partner's) instead of in front of them.  Costs PX
+    // more float4 of registers, in the one phase of the unit that has them to spare (no D2 / D3 yet).
+    float4 a_n = eq[lane], b_n[PX];
+#pragma unroll
+    for (int m = 0; m < PX; ++m) b_n[m] = tEx[(m * (DD / 8)) * 64 + lane];
+#pragma unroll
+    for (int sc = 0; sc < DD / 8; ++sc) {
+      const float4 a = a_n;
+      float4 b[PX];
+#pragma unroll
+      for (int m = 0; m < PX; ++m) b[m] = b_n[m];
+      if (sc + 1 < DD / 8) {
+        a_n = eq[(sc + 1) * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < PX; ++m) b_n[m] = tEx[(m * (DD / 8) + sc + 1) * 64 + lane];
+      }
+      __builtin_amdgcn_sched_barrier(0);   // the requests stay above this chunk's MFMAs
+#pragma unroll
+      for (int m = 0; m < PX; ++m) {
+        D1[m] = mfma32(a.x, b[m].x, D1[m]);
+        D1[m] = mfma32(a.y, b[m].y, D1[m]);
+        D1[m] = mfma32(a.z, b[m].z, D1[m]);
+        D1[m] = mfma32(a.w, b[m].w, D1[m]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
 #pragma unroll
   for (int sc = 0; sc < DD / 8; ++sc) {
     const float4 a = eq[sc * 64 + lane];
@@ -217,9 +247,9 @@ struct Fp32Unit {
   static constexpr int kLdsWeightFloats = G::kWpackFloats;
   template <class G, int NW>
   static __device__ __forceinline__ void stage(const ScoreArgs& p, float* smem) { stage_weights<G, NW>(p, smem); }
-  template <class G, int PX, int DD, bool BULK = false>
+  template <class G, int PX, int DD, bool BULK = false, bool PIPE = false>
   static __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float* __restrict__ eq, const float4* tEx, int lane) {
-    mol::gemm1<G, PX, DD, BULK>(D1, reinterpret_cast<const float4*>(eq), tEx, lane);
+    mol::gemm1<G, PX, DD, BULK, PIPE>(D1, reinterpret_cast<const float4*>(eq), tEx, lane);
   }
   // All queries of one unit, each at its own static register offset (no register rotation).
   // `only` >= 0 restricts the unit to that query (per-row candidates).

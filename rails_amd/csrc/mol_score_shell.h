@@ -80,7 +80,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(Score
     const float4* tGi = tEx + G::kTileExFloats / 4;
     const float* eq = p.eqfrag + (int64_t)g * G::kEqGroupFloats;
     f32x16 D1[PX];
-    U::template gemm1<G, PX, DD, (NW == 4)>(D1, eq, tEx, lane);   // one wave per SIMD: the whole tile requested up front
+#ifndef RAILS_DIRECT_PIPE
+#define RAILS_DIRECT_PIPE 1
+#endif
+    U::template gemm1<G, PX, DD, (NW == 4), (NW == 8 && RAILS_DIRECT_PIPE != 0)>(D1, eq, tEx, lane);   // one wave per SIMD: the whole tile requested up front; two: one K-chunk ahead
     SelNone none;
     U::template queries<G, PX, false>(D1, p, none, g, row, tile * kTileItems, smem, tGi, lane, hi, x);
   }
