@@ -177,8 +177,13 @@ struct SplitPack {
 // BULK: no fences between chunks -- the compiler then requests the whole tile up front (PX * d / 4 registers), which is what a
 // wave that fetches its tile straight from HBM wants (one round trip per unit instead of one per chunk) and what only a
 // one-wave-per-SIMD build has the registers for.
-template <class G, int PX, int DD, bool BULK = false>
+template <class G, int PX, int DD, bool BULK_ = false, bool PIPE = false>
 __device__ __forceinline__ void gemm1_presplit(f32x16 (&D1)[PX], const h8* __restrict__ eq, const h8* tEx, int lane) {
+  // PIPE (independent waves at two per SIMD, operands straight from memory): the one-product build reads only the hi fragments --
+  // half the registers -- so it can request its whole tile up front like BULK (B = 1: 0.127 -> 0.110 ms); the three-product build cannot
+  // (tile = 128 registers next to 128 of accumulators) and keeps one round trip per K-step (its hi fragments alone one step ahead
+  // measured 2-6 % SLOWER at B = 1 ... 16).
+  constexpr bool BULK = BULK_ || (PIPE && RAILS_F16_SINGLE != 0 && PX * (DD / 16) * 4 <= 64);
   static_assert(DD % 16 == 0, "f16x3 GEMM1 walks K in steps of 16");
   static_assert(PX <= 8, "the register-resident unit holds all item groups of a K-step at once");
   constexpr int MC = PX;
@@ -190,11 +195,13 @@ __device__ __forceinline__ void gemm1_presplit(f32x16 (&D1)[PX], const h8* __res
     // every fragment of the tile and of the query group requested before the first MFMA: ONE memory round trip per unit
     h8 a[DD / 8], b[PX][DD / 8];
 #pragma unroll
-    for (int c = 0; c < DD / 8; ++c) a[c] = eq[c * 64 + lane];
+    for (int c = 0; c < DD / 8; ++c)
+      if (!RAILS_F16_SINGLE || c % 2 == 0) a[c] = eq[c * 64 + lane];
 #pragma unroll
     for (int m = 0; m < PX; ++m)
 #pragma unroll
-      for (int c = 0; c < DD / 8; ++c) b[m][c] = tEx[(m * (DD / 8) + c) * 64 + lane];
+      for (int c = 0; c < DD / 8; ++c)
+        if (!RAILS_F16_SINGLE || c % 2 == 0) b[m][c] = tEx[(m * (DD / 8) + c) * 64 + lane];   // the one-product build never touches the lo fragments
     asm volatile("" ::: "memory");   // the requests stay above the MFMAs
 #pragma unroll
     for (int ks = 0; ks < DD / 16; ++ks) {
@@ -511,9 +518,9 @@ struct F16Unit {
   template <class G, int NW>
   static __device__ __forceinline__ void stage(const ScoreArgs& p, float* smem) { SplitPack<G>::template stage<NW>(p, smem); }
 
-  template <class G, int PX, int DD, bool BULK = false, bool PIPE = false>   // PIPE: fp32 policy only (mol_score_fp32_unit.h)
+  template <class G, int PX, int DD, bool BULK = false, bool PIPE = false>
   static __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float* __restrict__ eq, const float4* tEx, int lane) {
-    gemm1_presplit<G, PX, DD, BULK>(D1, reinterpret_cast<const h8*>(eq), reinterpret_cast<const h8*>(tEx), lane);
+    gemm1_presplit<G, PX, DD, BULK, PIPE>(D1, reinterpret_cast<const h8*>(eq), reinterpret_cast<const h8*>(tEx), lane);
   }
 
   template <class G, int PX, bool SEL = false, class SelT = SelNone>
