@@ -84,6 +84,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(Score
 #define RAILS_DIRECT_PIPE 1
 #endif
     U::template gemm1<G, PX, DD, (NW == 4), (NW == 8 && RAILS_DIRECT_PIPE != 0)>(D1, eq, tEx, lane);   // one wave per SIMD: the whole tile requested up front; two: one K-chunk ahead
+    // (Measured three times and not kept: an L2 touch of this wave's next tile from here -- untracked asm loads in rounds 1 and 3,
+    // ordinary loads consumed at the end of the unit in round 3: B = 1 ... 8 all 2-5 % slower.  What does help these shells is the
+    // K-chunk lookahead inside GEMM1, above.)
     SelNone none;
     U::template queries<G, PX, false>(D1, p, none, g, row, tile * kTileItems, smem, tGi, lane, hi, x);
   }
