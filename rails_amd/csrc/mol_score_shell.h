@@ -140,7 +140,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(Score
     for (int g = wave; g < p.n_groups; g += NW) {
       const float* eq = p.eqfrag + (int64_t)g * G::kEqGroupFloats;
       f32x16 D1[PX];
-      U::template gemm1<G, PX, DD>(D1, eq, tEx, lane);
+#ifndef RAILS_STAGED_PIPE
+#define RAILS_STAGED_PIPE 0   // GEMM1 one K-chunk ahead with the tile in LDS: measured no difference (6.34 ms either way)
+#endif
+      U::template gemm1<G, PX, DD, false, (RAILS_STAGED_PIPE != 0)>(D1, eq, tEx, lane);
       U::template queries<G, PX, SEL>(D1, p, sel, g, -1, tile * kTileItems, smem, tGi, lane, hi, x);
     }
   }
@@ -212,7 +215,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged1_kernel(Scor
       const bool has = gi_idx < cnt;
       const int g = off + stride * gi_idx;
       f32x16 D1[PX];
-      if (has) U::template gemm1<G, PX, DD>(D1, p.eqfrag + (int64_t)g * G::kEqGroupFloats, tEx, lane);
+#ifndef RAILS_STAGED1_PIPE
+#define RAILS_STAGED1_PIPE 0   // likewise: ML-20M 0.211 ms, ML-1M 0.032 ms either way
+#endif
+      if (has) U::template gemm1<G, PX, DD, false, (RAILS_STAGED1_PIPE != 0)>(D1, p.eqfrag + (int64_t)g * G::kEqGroupFloats, tEx, lane);
       if (it == n_it - 1) {
         __syncthreads();   // every wave is past its last GEMM1 of this tile: the Ex buffer is free
         if (i + 1 < mine) {
