@@ -86,7 +86,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(Score
     U::template gemm1<G, PX, DD, (NW == 4), (NW == 8 && RAILS_DIRECT_PIPE != 0)>(D1, eq, tEx, lane);   // one wave per SIMD: the whole tile requested up front; two: one K-chunk ahead
     // (Measured three times and not kept: an L2 touch of this wave's next tile from here -- untracked asm loads in rounds 1 and 3,
     // ordinary loads consumed at the end of the unit in round 3: B = 1 ... 8 all 2-5 % slower.  What does help these shells is the
-    // K-chunk lookahead inside GEMM1, above.)
+    // K-chunk lookahead inside GEMM1, above.  An early touch of THIS tile's gate rows, read at the head of the epilogue, changed nothing
+    // either: the epilogue's own request-ahead ring already covers them.)
     SelNone none;
     U::template queries<G, PX, false>(D1, p, none, g, row, tile * kTileItems, smem, tGi, lane, hi, x);
   }
