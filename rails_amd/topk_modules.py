@@ -648,14 +648,15 @@ class MoLAvgTopK(MoLTopKModule):
 class _ComponentCandidates:
     """Per-component candidate generation shared by MoLNaiveTopK and MoLCombTopK."""
 
-    UNION_CAP = 16384   # candidates per query the rerank can sort and select in LDS (rails_sort_rows_i64 / rails_topk, k <= 16384)
+    UNION_CAP = 16384          # candidates per query the rerank sorts and ranks in one workgroup's LDS (rails_sort_rows_i64 / rails_topk)
+    UNION_HARD_CAP = 1 << 20   # beyond UNION_CAP (16x16x64 with k_per_group >= 75: 256 * 75 = 19 200) the two integer / float sorts of the
+                               # rerank go through torch.sort on the device -- the reference "just runs" there (mol_top_k.py:260, :518);
+                               # scoring and duplicate masking stay on the HIP kernels
 
     def _check_union_size(self, n_candidates: int) -> None:
-        """The union is sorted and fully ranked per query inside one workgroup's LDS; reject configurations beyond that
-        at construction (16x16x64 with k_per_group >= 75: 256 * 75 = 19 200) instead of failing in the first forward."""
-        if n_candidates > self.UNION_CAP:
+        if n_candidates > self.UNION_HARD_CAP:
             raise NotImplementedError(
-                f"{type(self).__name__}: {n_candidates} candidates per query exceed the rerank capacity of {self.UNION_CAP} "
+                f"{type(self).__name__}: {n_candidates} candidates per query exceed the rerank capacity of {self.UNION_HARD_CAP} "
                 "(P_Q * P_X * k_per_group [+ avg_top_k]); use a smaller k_per_group for this shape")
 
     def _component_table(self) -> torch.Tensor:
@@ -706,11 +707,15 @@ class _ComponentCandidates:
         """sort -> gather -> full MoL -> mask duplicates with -32767.0 -> top-k over ALL candidates
         (the reference overwrites k with the candidate count, mol_top_k.py:260 / :518)."""
         eng = self._bind()
-        sorted_idx = E.sort_rows(all_indices)
+        big = all_indices.shape[1] > self.UNION_CAP
+        sorted_idx = torch.sort(all_indices.to(torch.int64), dim=1).values if big else E.sort_rows(all_indices)
         k = sorted_idx.shape[1]
         cand, kp = eng.gather_index(self._index, sorted_idx)
         scores = eng.score_candidates(qpack, batch, cand, kp)[:, :k]
         E.mask_sorted_duplicates(sorted_idx, scores, -32767.0)
+        if big:   # full ranking of more than 16 384 candidates: stable descending sort = (score desc, column asc), rails_topk's tie rule
+            vals, order = torch.sort(scores, dim=1, descending=True, stable=True)
+            return vals, torch.gather(self._ids_flat[sorted_idx], 1, order)
         return E.topk(scores, k, ids=self._ids_flat[sorted_idx], sorted=sorted)
 
 

@@ -1523,3 +1523,39 @@ def test_indexed_candidate_scoring_equals_gather_then_score(dev, cfg_name, N, B,
         assert torch.equal(got, want)
         dense = eng.score_dense(qpack, B, tk._index)
         assert torch.equal(got, torch.gather(dense, 1, pos))      # and both are the dense kernel's values at those positions
+
+
+@pytest.mark.gpu
+def test_candidate_unions_beyond_the_lds_sort_capacity(dev):
+    """MoLNaiveTopK / MoLCombTopK with more than 16 384 candidates per query (16x16x64 with k_per_group >= 75: the reference "just
+    runs", mol_top_k.py:260 / :518).  (a) the large-union route (device torch.sort around the HIP scoring) forced on a small union
+    equals the LDS route bit for bit; (b) 256 * 75 = 19 200 candidates run, ranked, with exact MoL scores."""
+    cfg = O.CONFIGS["amzn-books"]
+    w = O.synthetic_weights(cfg, seed=3)
+    N = 20_000
+    X = torch.from_numpy(O.hash_item_table(5, 0, N, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = (torch.arange(N, dtype=torch.int64, device=dev) * 2 + 1).unsqueeze(0)
+    q = O.synthetic_queries(cfg, 6, seed=9).to(dev)
+    with torch.inference_mode():
+        mol = build_module(cfg, w, dev)
+        a = rails_amd.MoLNaiveTopK(mol, X, ids, k_per_group=10)
+        s0, i0 = a(q, k=50)
+        a.UNION_CAP = 64                                   # 640 candidates > 64: the torch.sort route
+        s1, i1 = a(q, k=50)
+        assert torch.equal(s0, s1) and torch.equal(i0, i1)
+        c = rails_amd.MoLCombTopK(mol, X, ids, k_per_group=10, avg_top_k=100)
+        s0, i0 = c(q, k=50)
+        c.UNION_CAP = 64
+        s1, i1 = c(q, k=50)
+        assert torch.equal(s0, s1) and torch.equal(i0, i1)
+        cfg4 = O.CONFIGS["synthetic-16x16x64"]
+        w4 = O.synthetic_weights(cfg4, seed=3)
+        X4 = torch.from_numpy(O.hash_item_table(6, 0, N, cfg4.item_embedding_dim)).unsqueeze(0).to(dev)
+        q4 = O.synthetic_queries(cfg4, 3, seed=10).to(dev)
+        mol4 = build_module(cfg4, w4, dev)
+        big = rails_amd.MoLNaiveTopK(mol4, X4, ids, k_per_group=75)      # 19 200 candidates per query
+        s, i = big(q4, k=10)
+        assert s.shape == (3, 256 * 75) and bool((s[:, :-1] >= s[:, 1:]).all())
+        dense = rails_amd.MoLBruteForceTopK(mol4, X4, ids).all_logits(q4)     # the rerank is exact: the head carries the dense kernel's scores
+        head = torch.gather(dense, 1, (i[:, :50] - 1) // 2)
+        assert float((head - s[:, :50]).abs().max()) <= 2e-5 and bool((s[:, 0] <= dense.max(dim=1).values + 1e-6).all())
