@@ -192,6 +192,92 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
+// The same GEMM for the sizes the encoder's layers have (K % 32 == 0, 16-byte aligned rows): a workgroup of four waves owns a
+// 64 x 64 tile of C, the 64 x 32 blocks of A and W of a K-step are read from memory ONCE per workgroup with coalesced 16-byte
+// loads (eight threads cover a row's 128 bytes) into LDS, double buffered, and every wave takes its 32 x 32 quarter's MFMA
+// operands from there.  The per-wave kernel above has each lane read 64 bytes of its own row per step: 64 cache lines per load
+// instruction and no reuse between the waves that share a row block -- 28 % of the fp32 MFMA peak on the uvqk GEMM of an ML-20M
+// block.  Same operand assignment per lane (k = k0 + 16 h + s for MFMA s), same order over k: bit-identical results.
+// LDS rows are 36 floats apart: the 16 lanes of a ds_read_b128 phase then hit 16 distinct 16-byte bank groups.
+constexpr int kGemmLd = 36;
+
+__global__ __launch_bounds__(256) void gemm_f32_tiled_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float sA[2][64][kGemmLd], sW[2][64][kGemmLd];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row = lane & 31, h = lane >> 5, col = lane & 31;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t tiles_n = (g.N + 63) / 64;
+  const int64_t m0 = ((int64_t)blockIdx.x / tiles_n) * 64;
+  const int n0 = (int)((int64_t)blockIdx.x % tiles_n) * 64;
+  // this thread's pieces of a K-step: A rows (tid / 8) and (tid / 8) + 32, 16 bytes at k = (tid % 8) * 4; W likewise, or -- (K, N)
+  // layout -- k rows (tid / 16) and (tid / 16) + 16, 16 bytes at n = (tid % 16) * 4
+  const int pr = tid >> 3, pc = (tid & 7) * 4;
+  const int64_t ar0 = m0 + pr < g.M ? m0 + pr : g.M - 1, ar1 = m0 + pr + 32 < g.M ? m0 + pr + 32 : g.M - 1;   // clamped: never stored
+  const int wr0 = n0 + pr < g.N ? n0 + pr : g.N - 1, wr1 = n0 + pr + 32 < g.N ? n0 + pr + 32 : g.N - 1;
+  const int kr = tid >> 4, kc = (tid & 15) * 4;
+  const int wcn = n0 + kc + 3 < g.N ? n0 + kc : (g.N >= 4 ? g.N - 4 : 0);   // (K, N): a 16-byte piece inside the row
+  float4 ra0, ra1, rw0, rw1;
+  auto fetch = [&](int k0) {
+    ra0 = *reinterpret_cast<const float4*>(g.A + ar0 * g.lda + k0 + pc);
+    ra1 = *reinterpret_cast<const float4*>(g.A + ar1 * g.lda + k0 + pc);
+    if (g.w_is_nk) {
+      rw0 = *reinterpret_cast<const float4*>(g.W + (int64_t)wr0 * g.K + k0 + pc);
+      rw1 = *reinterpret_cast<const float4*>(g.W + (int64_t)wr1 * g.K + k0 + pc);
+    } else {
+      rw0 = *reinterpret_cast<const float4*>(g.W + (int64_t)(k0 + kr) * g.N + wcn);
+      rw1 = *reinterpret_cast<const float4*>(g.W + (int64_t)(k0 + kr + 16) * g.N + wcn);
+    }
+  };
+  auto stash = [&](int buf) {
+    *reinterpret_cast<float4*>(&sA[buf][pr][pc]) = ra0;
+    *reinterpret_cast<float4*>(&sA[buf][pr + 32][pc]) = ra1;
+    if (g.w_is_nk) {
+      *reinterpret_cast<float4*>(&sW[buf][pr][pc]) = rw0;
+      *reinterpret_cast<float4*>(&sW[buf][pr + 32][pc]) = rw1;
+    } else if (n0 + kc + 3 < g.N || g.N < 4) {   // transposed into [n][k]; a piece clamped to the row's end belongs to columns nobody stores
+      sW[buf][kc][kr] = rw0.x; sW[buf][kc + 1][kr] = rw0.y; sW[buf][kc + 2][kr] = rw0.z; sW[buf][kc + 3][kr] = rw0.w;
+      sW[buf][kc][kr + 16] = rw1.x; sW[buf][kc + 1][kr + 16] = rw1.y; sW[buf][kc + 2][kr + 16] = rw1.z; sW[buf][kc + 3][kr + 16] = rw1.w;
+    }
+  };
+  hf32x16 acc = {0};
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  const int steps = g.K / 32;
+  for (int t = 0; t < steps; ++t) {
+    const int buf = t & 1;
+    if (t + 1 < steps) fetch((t + 1) * 32);
+    float av[16], bv[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float4 a = *reinterpret_cast<const float4*>(&sA[buf][wm * 32 + row][16 * h + 4 * i]);
+      const float4 b = *reinterpret_cast<const float4*>(&sW[buf][wn * 32 + col][16 * h + 4 * i]);
+      av[4 * i] = a.x; av[4 * i + 1] = a.y; av[4 * i + 2] = a.z; av[4 * i + 3] = a.w;
+      bv[4 * i] = b.x; bv[4 * i + 1] = b.y; bv[4 * i + 2] = b.z; bv[4 * i + 3] = b.w;
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+    if (t + 1 < steps) stash(buf ^ 1);
+    __syncthreads();
+  }
+  const int n = n0 + wn * 32 + col;
+  if (n >= g.N) return;
+  const float bias = g.bias ? g.bias[n] : 0.0f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t m = m0 + wm * 32 + acc_row(r, h);
+    if (m >= g.M) continue;
+    float v = acc[r] + bias;
+    if (g.act == 1) v = silu_fast(v);
+    if (g.residual) v += g.residual[m * g.ldr + n];
+    if (g.lengths) {
+      const int64_t b = m / g.seq_len;
+      if (m - b * g.seq_len >= g.lengths[b]) v = 0.0f;
+    }
+    g.C[m * g.ldc + n] = v;
+  }
+}
+
 struct AttnArgs {
   const float* uvqk; int64_t ld;        // (B * N, ld) rows [u | v | q | k], u/v: H*dv wide, q/k: H*dqk wide
   int B, N, H, dqk, dv;
@@ -586,6 +672,15 @@ int gemm_f32(const float* A, int64_t lda, const float* W, int w_is_nk, const flo
              int N, int K, int act, const int64_t* lengths, int seq_len, float* C, int64_t ldc, hipStream_t stream) {
   if (M == 0 || N == 0) return kOk;
   GemmArgs g{A, lda, W, w_is_nk, bias, residual, ldr, M, N, K, act, lengths, seq_len, C, ldc};
+  // RAILS_GEMM: 0 / unset = choose, 1 = per-wave kernel, 2 = tiled kernel where its alignment conditions hold (measurement override)
+  static const int forced = [] { const char* e = getenv("RAILS_GEMM"); return e ? atoi(e) : 0; }();
+  const bool aligned = K % 32 == 0 && K >= 32 && lda % 4 == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0 &&
+                       (w_is_nk ? true : (N % 4 == 0 && N >= 4));
+  if (aligned && forced != 1 && (forced == 2 || (M >= 256 && N >= 64))) {
+    const int64_t wgs = ((M + 63) / 64) * ((N + 63) / 64);
+    hipLaunchKernelGGL(gemm_f32_tiled_kernel, dim3((unsigned)wgs), dim3(256), 0, stream, g);
+    return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+  }
   const int64_t tiles = ((M + 31) / 32) * ((N + 31) / 32);
   hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, stream, g);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;

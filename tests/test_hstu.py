@@ -269,3 +269,39 @@ def test_sequences_to_metrics_end_to_end():
     assert agree >= 0.98, agree            # near-tie swaps only (fp32 summation order in two chained models)
     for key in ("hr@10", "hr@50", "hr@100"):
         assert float((out[key].cpu() != ref_metrics[key]).float().mean()) <= 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,N,K,seq,small", [(6752, 1024, 256, 211, 211), (300, 64, 32, 50, 200), (320, 192, 96, 64, 192), (1000, 260, 64, 50, 200)])
+@pytest.mark.parametrize("w_is_nk", [1, 0])
+def test_tiled_gemm_equals_the_per_wave_kernel(M, N, K, seq, small, w_is_nk):
+    """rails_gemm_f32 takes the LDS-tiled kernel for M >= 256 rows with aligned K; the per-wave kernel for fewer rows.  Same operand
+    assignment and order over k in both, so the first rows computed alone (fewer than 256: per-wave) equal the same rows of the big call
+    (tiled) bit for bit; both sit within fp32 rounding of a float64 product; padded rows are written as zeros."""
+    import ctypes as C
+
+    from rails_amd import _lib
+    from rails_amd.engine import _ptr, _stream
+
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + N + K + w_is_nk)
+    x = torch.randn((M, K), generator=g).to(dev)
+    w = (torch.randn((N, K) if w_is_nk else (K, N), generator=g) / K ** 0.5).to(dev)
+    bias = torch.randn((N,), generator=g).to(dev)
+    res = torch.randn((M, N), generator=g).to(dev)
+    lengths = torch.randint(1, seq + 1, (M // seq,), generator=g).to(dev)
+
+    def run(rows):
+        out = torch.full((rows, N), float("nan"), device=dev)
+        _lib.check(lib.rails_gemm_f32(_ptr(x), K, _ptr(w), w_is_nk, _ptr(bias), _ptr(res), N, rows, N, K, 1, _ptr(lengths), seq, _ptr(out), N, _stream()), "rails_gemm_f32")
+        return out
+
+    big, part = run(M), run(small)
+    assert torch.equal(big[:small], part)
+    ref = x.double() @ (w.double().T if w_is_nk else w.double()) + bias.double()
+    ref = ref * torch.sigmoid(ref) + res.double()
+    pos = torch.arange(M, device=dev)
+    pad = (pos % seq) >= lengths[pos // seq]
+    ref[pad] = 0.0
+    assert float((big.double() - ref).abs().max()) < 5e-5 and bool((big[pad] == 0).all())
