@@ -335,51 +335,68 @@ __global__ __launch_bounds__(64) void hstu_attention_kernel(AttnArgs a) {
   const float* Kp = Q + (int64_t)H * dqk;
   const int qi = i0 + x < N ? i0 + x : N - 1;        // this lane's query (column axis)
   const float inv_n = 1.0f / (float)N;
-  float qb[kAttnMaxSteps];
+  // K-step s of S^T multiplies the d pair {s, 16 + s}: lane half h holds d = 16 h + s, sixteen CONSECUTIVE floats of its row, read
+  // as four 16-byte loads where the rows are 16-byte aligned (the first version paired {2 s, 2 s + 1}: sixteen dword loads of 32
+  // different cache lines each, for Q and again for every key tile's K).
+  const bool vec = dqk == 32 && ((reinterpret_cast<uintptr_t>(Q) | (uintptr_t)(a.ld * 4)) & 15) == 0;
+  auto load_d16 = [&](const float* rowp, float (&v)[kAttnMaxSteps]) {
+    if (vec) {
+      const float4* q4 = reinterpret_cast<const float4*>(rowp + 16 * h);
 #pragma unroll
-  for (int s = 0; s < kAttnMaxSteps; ++s) {
-    const int d = 2 * s + h;
-    const float v = Q[(int64_t)qi * a.ld + (d < dqk ? d : 0)];
-    qb[s] = d < dqk ? v : 0.0f;
-  }
+      for (int i = 0; i < 4; ++i) { const float4 f = q4[i]; v[4 * i] = f.x; v[4 * i + 1] = f.y; v[4 * i + 2] = f.z; v[4 * i + 3] = f.w; }
+    } else {
+#pragma unroll
+      for (int s = 0; s < kAttnMaxSteps; ++s) {
+        const int d = 16 * h + s;
+        const float t = rowp[d < dqk ? d : 0];
+        v[s] = d < dqk ? t : 0.0f;
+      }
+    }
+  };
+  float qb[kAttnMaxSteps];
+  load_d16(Q + (int64_t)qi * a.ld, qb);
   hf32x16 O = {0};                                    // O^T: row = value dim, column = query
-  for (int kt = 0; kt <= qt; ++kt) {                  // causal: key tiles up to the query tile
+  // a key tile's operands: K rows (A operand of S^T), V rows (A operand of O^T), the (key, query) time buckets.  The NEXT tile's are
+  // requested before this tile's MFMA chains (one wave per workgroup and < 2 waves per SIMD in flight: nothing else hides the
+  // round trip)
+  struct Tile { float ka[kAttnMaxSteps], va[16]; unsigned char bk[16]; };
+  auto fetch = [&](int kt, Tile& t) {
     const int j0 = kt * 32;
     const int kj = j0 + x < N ? j0 + x : N - 1;
-    float ka[kAttnMaxSteps], va[16];
-    unsigned char bk[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int key = j0 + acc_row(r, h);
-      bk[r] = biased ? a.buckets[((int64_t)b * N + (key < N ? key : N - 1)) * N + qi] : (unsigned char)0;
+      t.bk[r] = biased ? a.buckets[((int64_t)b * N + (key < N ? key : N - 1)) * N + qi] : (unsigned char)0;
     }
-#pragma unroll
-    for (int s = 0; s < kAttnMaxSteps; ++s) {
-      const int d = 2 * s + h;
-      const float v = Kp[(int64_t)kj * a.ld + (d < dqk ? d : 0)];
-      ka[s] = d < dqk ? v : 0.0f;
-    }
+    load_d16(Kp + (int64_t)kj * a.ld, t.ka);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {                    // A operand of O^T's K-step r: V[key row(r, h)][d = lane & 31]
       const int key = j0 + acc_row(r, h);
       const float v = V[(int64_t)(key < N ? key : N - 1) * a.ld + (x < dv ? x : 0)];
-      va[r] = (x < dv && key < N) ? v : 0.0f;
+      t.va[r] = (x < dv && key < N) ? v : 0.0f;
     }
+  };
+  Tile cur, nxt;
+  fetch(0, cur);
+  for (int kt = 0; kt <= qt; ++kt) {                  // causal: key tiles up to the query tile
+    const int j0 = kt * 32;
+    if (kt < qt) fetch(kt + 1, nxt);
     // S^T = K_tile Q_tile^T : A = keys (rows), B = queries (columns), K axis = dqk
     hf32x16 S = {0};
 #pragma unroll
     for (int s = 0; s < kAttnMaxSteps; ++s)
-      if (2 * s < dqk) S = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[s], qb[s], S, 0, 0, 0);
+      if (s < dqk) S = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.ka[s], qb[s], S, 0, 0, 0);   // step s carries d = s and d = 16 + s
     // P^T[j][i] = silu(S + bias) / N for j <= i; register r of S^T is the B operand of K-step r of O^T += V^T P^T
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int j = j0 + acc_row(r, h);               // this lane's key for register r
       float sc = S[r];
-      if (biased && j < N) sc += pos_s[N - 1 + j - qi] + tsw_s[bk[r]];
+      if (biased && j < N) sc += pos_s[N - 1 + j - qi] + tsw_s[cur.bk[r]];
       float pv = silu_fast(sc) * inv_n;
       if (j > qi || j >= N || i0 + x >= N) pv = 0.0f;
-      O = __builtin_amdgcn_mfma_f32_32x32x2f32(va[r], pv, O, 0, 0, 0);
+      O = __builtin_amdgcn_mfma_f32_32x32x2f32(cur.va[r], pv, O, 0, 0, 0);
     }
+    if (kt < qt) cur = nxt;
   }
   const int qrow = i0 + x;
   if (qrow >= N) return;
