@@ -407,6 +407,134 @@ __global__ __launch_bounds__(64) void hstu_attention_kernel(AttnArgs a) {
   }
 }
 
+// The same attention with one WORKGROUP per (head, sequence): the head's K, V and Q rows (N x 32 floats each, zero-padded) are staged
+// in LDS once and all query tiles of the sequence take their key-tile operands from there -- the per-tile global round trips of the
+// one-wave kernel above (51 us per ML-20M block even with the next tile prefetched: < 2 waves per SIMD, nothing to hide them) are
+// gone.  Four waves; the causal triangle is dealt in snake order over the tiles sorted by cost (tile t costs t + 1 key tiles:
+// 7 tiles -> 7 units per wave).  Operand assignment and summation order are those of the one-wave kernel: bit-identical results.
+// LDS rows are 36 floats apart (conflict-free ds_read_b128 of a lane's 16 consecutive d).
+constexpr int kAttnLd = 36;
+
+__global__ __launch_bounds__(256) void hstu_attention_wg_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float attn_smem[];   // pos_w[2N] | ts_w[nb+2, padded to 4] | K, V, Q [N][36] each
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int x = lane & 31, h = lane >> 5;
+  const int head = blockIdx.x, b = blockIdx.y;
+  const int N = a.N, H = a.H, dqk = a.dqk, dv = a.dv;
+  float* pos_s = attn_smem;
+  float* tsw_s = pos_s + 2 * N;
+  float* Ks = tsw_s + ((a.num_buckets + 2 + 3) & ~3);
+  float* Vs = Ks + (size_t)N * kAttnLd;
+  float* Qs = Vs + (size_t)N * kAttnLd;
+  const bool biased = a.buckets != nullptr;
+  const float* base = a.uvqk + (int64_t)b * N * a.ld;
+  const float* V = base + (int64_t)H * dv + (int64_t)head * dv;
+  const float* Q = base + 2 * (int64_t)H * dv + (int64_t)head * dqk;
+  const float* Kp = Q + (int64_t)H * dqk;
+  if (biased) {
+    for (int i = tid; i < 2 * N - 1; i += 256) pos_s[i] = a.pos_w[i];
+    for (int i = tid; i <= a.num_buckets; i += 256) tsw_s[i] = a.ts_w[i];
+  }
+  // 32 consecutive threads = one row (coalesced).  Eight rows per thread are requested before the first is written: a rolled loop of
+  // load -> wait -> LDS write cost one L2 round trip per row (27 of them at N = 211: most of the kernel's time in its first version).
+  for (int i0 = tid; i0 < N * 32; i0 += 256 * 8) {
+    float kv[8], vv[8], qv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 256 < N * 32 ? i0 + u * 256 : N * 32 - 1;   // clamped (always valid) address; such values are not written
+      const int r = i >> 5, d = i & 31;
+      kv[u] = Kp[(int64_t)r * a.ld + (d < dqk ? d : 0)];
+      qv[u] = Q[(int64_t)r * a.ld + (d < dqk ? d : 0)];
+      vv[u] = V[(int64_t)r * a.ld + (d < dv ? d : 0)];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 256;
+      if (i < N * 32) {
+        const int r = i >> 5, d = i & 31;
+        Ks[r * kAttnLd + d] = d < dqk ? kv[u] : 0.0f;
+        Qs[r * kAttnLd + d] = d < dqk ? qv[u] : 0.0f;
+        Vs[r * kAttnLd + d] = d < dv ? vv[u] : 0.0f;
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t len = a.lengths[b];
+  const float inv_n = 1.0f / (float)N;
+  const int nqt = (N + 31) / 32;
+  for (int i = 0; i < nqt; ++i) {
+    if (((i & 7) < 4 ? (i & 7) : 7 - (i & 7)) != wave) continue;   // snake over the tiles in descending cost
+    const int qt = nqt - 1 - i;
+    const int i0 = qt * 32;
+    const int qi = i0 + x < N ? i0 + x : N - 1;        // this lane's query (column axis)
+    float qb[kAttnMaxSteps];
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const float4 f = *reinterpret_cast<const float4*>(Qs + qi * kAttnLd + 16 * h + 4 * q4);
+      qb[4 * q4] = f.x; qb[4 * q4 + 1] = f.y; qb[4 * q4 + 2] = f.z; qb[4 * q4 + 3] = f.w;
+    }
+    hf32x16 O = {0};
+    unsigned char bk[16], bkn[16];
+    auto fetch_bk = [&](int kt, unsigned char (&o)[16]) {   // (key, query) time buckets of a key tile: L2-resident bytes, one tile ahead
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + acc_row(r, h);
+        o[r] = biased ? a.buckets[((int64_t)b * N + (key < N ? key : N - 1)) * N + qi] : (unsigned char)0;
+      }
+    };
+    fetch_bk(0, bk);
+    for (int kt = 0; kt <= qt; ++kt) {
+      const int j0 = kt * 32;
+      if (kt < qt) fetch_bk(kt + 1, bkn);
+      const int kj = j0 + x < N ? j0 + x : N - 1;
+      float ka[kAttnMaxSteps], va[16];
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const float4 f = *reinterpret_cast<const float4*>(Ks + kj * kAttnLd + 16 * h + 4 * q4);
+        ka[4 * q4] = f.x; ka[4 * q4 + 1] = f.y; ka[4 * q4 + 2] = f.z; ka[4 * q4 + 3] = f.w;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = j0 + acc_row(r, h);
+        va[r] = key < N ? Vs[key * kAttnLd + x] : 0.0f;
+      }
+      // the 16 bias terms of this lane's (key, query) pairs first -- two LDS gathers each, all in flight under the S^T chain -- then
+      // the 16 activations, then the O^T chain: at one wave per SIMD a lookup -> silu -> MFMA sequence per register exposed every latency
+      float bias[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = j0 + acc_row(r, h);
+        bias[r] = (biased && j < N) ? pos_s[N - 1 + j - qi] + tsw_s[bk[r]] : 0.0f;
+      }
+      hf32x16 S = {0};
+#pragma unroll
+      for (int s = 0; s < kAttnMaxSteps; ++s)
+        if (s < dqk) S = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[s], qb[s], S, 0, 0, 0);
+      float pv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = j0 + acc_row(r, h);
+        const float t = silu_fast(S[r] + bias[r]) * inv_n;
+        pv[r] = (j > qi || j >= N || i0 + x >= N) ? 0.0f : t;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) O = __builtin_amdgcn_mfma_f32_32x32x2f32(va[r], pv[r], O, 0, 0, 0);
+      if (kt < qt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bk[r] = bkn[r];
+      }
+    }
+    const int qrow = i0 + x;
+    if (qrow < N) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = acc_row(r, h);
+        if (d < dv) a.out[((int64_t)b * N + qrow) * ((int64_t)H * dv) + (int64_t)head * dv + d] = qrow < len ? O[r] : 0.0f;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Fused encoder for short sequences (seq_len <= 64, e.g. amzn-books: N = 61, D = 64, 8 heads x 8): ONE workgroup per
 // sequence keeps the residual stream X, the uvqk activations Y and the attention output A in LDS (~103 KiB of the
@@ -802,6 +930,15 @@ int hstu_attention(const float* uvqk, int64_t ld, int B, int N, int H, int dqk, 
   AttnArgs a{uvqk, ld, B, N, H, dqk, dv, lengths, buckets, ts_w, pos_w, num_buckets, out};
   const size_t lds = sizeof(float) * ((size_t)2 * N + num_buckets + 2);
   if (lds > 60 * 1024) { set_error("hstu_attention: seq_len = %d does not fit LDS", N); return kErrUnsupported; }
+  // RAILS_ATTN: 0 / unset = choose, 1 = one wave per (query tile, head, sequence), 2 = one workgroup per (head, sequence) with K / V in LDS
+  static const int forced = [] { const char* e = getenv("RAILS_ATTN"); return e ? atoi(e) : 0; }();
+  const size_t lds_wg = sizeof(float) * ((size_t)2 * N + ((num_buckets + 2 + 3) & ~3) + (size_t)3 * N * kAttnLd);
+  if (forced != 1 && lds_wg <= 150 * 1024 && (forced == 2 || N > 64)) {
+    static DynLdsOnce once;
+    if (ensure_dyn_lds(once, reinterpret_cast<const void*>(&hstu_attention_wg_kernel), 150 * 1024) != kOk) return kErrLaunch;
+    hipLaunchKernelGGL(hstu_attention_wg_kernel, dim3(H, B), dim3(256), lds_wg, stream, a);
+    return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+  }
   hipLaunchKernelGGL(hstu_attention_kernel, dim3((N + 31) / 32, H, B), dim3(64), lds, stream, a);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
