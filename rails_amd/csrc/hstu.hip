@@ -416,32 +416,34 @@ __global__ __launch_bounds__(64) void hstu_attention_kernel(AttnArgs a) {
 constexpr int kAttnLd = 36;
 
 __global__ __launch_bounds__(256) void hstu_attention_wg_kernel(AttnArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float attn_smem[];   // pos_w[2N] | ts_w[nb+2, padded to 4] | K, V, Q [N][36] each
+  // pos_w[NP + N, zero beyond 2N - 1] | ts_w[nb + 2, padded to 4] | K, V, Q [NP][36] each, rows >= N zero.  NP = N rounded up to whole
+  // tiles: with the padding rows and bias slots in place the tile loops need NO per-element conditions (the first version guarded
+  // every MFMA of the S chain and every bias lookup: ~150 branches and exec-mask regions per unit, nothing could be overlapped).
+  extern __shared__ __attribute__((aligned(16))) float attn_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int x = lane & 31, h = lane >> 5;
   const int head = blockIdx.x, b = blockIdx.y;
   const int N = a.N, H = a.H, dqk = a.dqk, dv = a.dv;
+  const int nqt = (N + 31) / 32, NP = nqt * 32;
   float* pos_s = attn_smem;
-  float* tsw_s = pos_s + 2 * N;
+  float* tsw_s = pos_s + ((NP + N + 3) & ~3);
   float* Ks = tsw_s + ((a.num_buckets + 2 + 3) & ~3);
-  float* Vs = Ks + (size_t)N * kAttnLd;
-  float* Qs = Vs + (size_t)N * kAttnLd;
+  float* Vs = Ks + (size_t)NP * kAttnLd;
+  float* Qs = Vs + (size_t)NP * kAttnLd;
   const bool biased = a.buckets != nullptr;
   const float* base = a.uvqk + (int64_t)b * N * a.ld;
   const float* V = base + (int64_t)H * dv + (int64_t)head * dv;
   const float* Q = base + 2 * (int64_t)H * dv + (int64_t)head * dqk;
   const float* Kp = Q + (int64_t)H * dqk;
-  if (biased) {
-    for (int i = tid; i < 2 * N - 1; i += 256) pos_s[i] = a.pos_w[i];
-    for (int i = tid; i <= a.num_buckets; i += 256) tsw_s[i] = a.ts_w[i];
-  }
+  for (int i = tid; i < NP + N; i += 256) pos_s[i] = (biased && i < 2 * N - 1) ? a.pos_w[i] : 0.0f;
+  for (int i = tid; i <= a.num_buckets + 1; i += 256) tsw_s[i] = (biased && i <= a.num_buckets) ? a.ts_w[i] : 0.0f;
   // 32 consecutive threads = one row (coalesced).  Eight rows per thread are requested before the first is written: a rolled loop of
-  // load -> wait -> LDS write cost one L2 round trip per row (27 of them at N = 211: most of the kernel's time in its first version).
-  for (int i0 = tid; i0 < N * 32; i0 += 256 * 8) {
+  // load -> wait -> LDS write cost one L2 round trip per row (27 of them at N = 211).
+  for (int i0 = tid; i0 < NP * 32; i0 += 256 * 8) {
     float kv[8], vv[8], qv[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int i = i0 + u * 256 < N * 32 ? i0 + u * 256 : N * 32 - 1;   // clamped (always valid) address; such values are not written
+      const int i = i0 + u * 256 < N * 32 ? i0 + u * 256 : N * 32 - 1;   // clamped (always valid) address
       const int r = i >> 5, d = i & 31;
       kv[u] = Kp[(int64_t)r * a.ld + (d < dqk ? d : 0)];
       qv[u] = Q[(int64_t)r * a.ld + (d < dqk ? d : 0)];
@@ -450,23 +452,25 @@ __global__ __launch_bounds__(256) void hstu_attention_wg_kernel(AttnArgs a) {
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = i0 + u * 256;
-      if (i < N * 32) {
+      if (i < NP * 32) {
         const int r = i >> 5, d = i & 31;
-        Ks[r * kAttnLd + d] = d < dqk ? kv[u] : 0.0f;
-        Qs[r * kAttnLd + d] = d < dqk ? qv[u] : 0.0f;
-        Vs[r * kAttnLd + d] = d < dv ? vv[u] : 0.0f;
+        const bool real = i < N * 32;
+        Ks[r * kAttnLd + d] = (real && d < dqk) ? kv[u] : 0.0f;
+        Qs[r * kAttnLd + d] = (real && d < dqk) ? qv[u] : 0.0f;
+        Vs[r * kAttnLd + d] = (real && d < dv) ? vv[u] : 0.0f;
       }
     }
   }
   __syncthreads();
   const int64_t len = a.lengths[b];
   const float inv_n = 1.0f / (float)N;
-  const int nqt = (N + 31) / 32;
+  const unsigned char* brow = biased ? a.buckets + (int64_t)b * N * N : nullptr;
   for (int i = 0; i < nqt; ++i) {
     if (((i & 7) < 4 ? (i & 7) : 7 - (i & 7)) != wave) continue;   // snake over the tiles in descending cost
     const int qt = nqt - 1 - i;
     const int i0 = qt * 32;
-    const int qi = i0 + x < N ? i0 + x : N - 1;        // this lane's query (column axis)
+    const int qi = i0 + x;                              // this lane's query (column axis); rows >= N are zero rows
+    const int qc = qi < N ? qi : N - 1;                 // ... clamped for the bucket matrix
     float qb[kAttnMaxSteps];
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
@@ -479,43 +483,34 @@ __global__ __launch_bounds__(256) void hstu_attention_wg_kernel(AttnArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kt * 32 + acc_row(r, h);
-        o[r] = biased ? a.buckets[((int64_t)b * N + (key < N ? key : N - 1)) * N + qi] : (unsigned char)0;
+        o[r] = biased ? brow[(int64_t)(key < N ? key : N - 1) * N + qc] : (unsigned char)(a.num_buckets + 1);   // slot nb + 1 holds 0
       }
     };
     fetch_bk(0, bk);
     for (int kt = 0; kt <= qt; ++kt) {
       const int j0 = kt * 32;
       if (kt < qt) fetch_bk(kt + 1, bkn);
-      const int kj = j0 + x < N ? j0 + x : N - 1;
-      float ka[kAttnMaxSteps], va[16];
+      float ka[kAttnMaxSteps], va[16], bias[16];
 #pragma unroll
       for (int q4 = 0; q4 < 4; ++q4) {
-        const float4 f = *reinterpret_cast<const float4*>(Ks + kj * kAttnLd + 16 * h + 4 * q4);
+        const float4 f = *reinterpret_cast<const float4*>(Ks + (j0 + x) * kAttnLd + 16 * h + 4 * q4);
         ka[4 * q4] = f.x; ka[4 * q4 + 1] = f.y; ka[4 * q4 + 2] = f.z; ka[4 * q4 + 3] = f.w;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = j0 + acc_row(r, h);
-        va[r] = key < N ? Vs[key * kAttnLd + x] : 0.0f;
-      }
-      // the 16 bias terms of this lane's (key, query) pairs first -- two LDS gathers each, all in flight under the S^T chain -- then
-      // the 16 activations, then the O^T chain: at one wave per SIMD a lookup -> silu -> MFMA sequence per register exposed every latency
-      float bias[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
         const int j = j0 + acc_row(r, h);
-        bias[r] = (biased && j < N) ? pos_s[N - 1 + j - qi] + tsw_s[bk[r]] : 0.0f;
+        va[r] = Vs[j * kAttnLd + x];
+        bias[r] = pos_s[N - 1 + j - qc] + tsw_s[bk[r]];
       }
       hf32x16 S = {0};
 #pragma unroll
-      for (int s = 0; s < kAttnMaxSteps; ++s)
-        if (s < dqk) S = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[s], qb[s], S, 0, 0, 0);
+      for (int s = 0; s < kAttnMaxSteps; ++s) S = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[s], qb[s], S, 0, 0, 0);   // zero-padded beyond dqk
       float pv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int j = j0 + acc_row(r, h);
         const float t = silu_fast(S[r] + bias[r]) * inv_n;
-        pv[r] = (j > qi || j >= N || i0 + x >= N) ? 0.0f : t;
+        pv[r] = (j > qi || j >= N || qi >= N) ? 0.0f : t;
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) O = __builtin_amdgcn_mfma_f32_32x32x2f32(va[r], pv[r], O, 0, 0, 0);
@@ -524,12 +519,11 @@ __global__ __launch_bounds__(256) void hstu_attention_wg_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) bk[r] = bkn[r];
       }
     }
-    const int qrow = i0 + x;
-    if (qrow < N) {
+    if (qi < N) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int d = acc_row(r, h);
-        if (d < dv) a.out[((int64_t)b * N + qrow) * ((int64_t)H * dv) + (int64_t)head * dv + d] = qrow < len ? O[r] : 0.0f;
+        if (d < dv) a.out[((int64_t)b * N + qi) * ((int64_t)H * dv) + (int64_t)head * dv + d] = qi < len ? O[r] : 0.0f;
       }
     }
   }
@@ -932,7 +926,8 @@ int hstu_attention(const float* uvqk, int64_t ld, int B, int N, int H, int dqk, 
   if (lds > 60 * 1024) { set_error("hstu_attention: seq_len = %d does not fit LDS", N); return kErrUnsupported; }
   // RAILS_ATTN: 0 / unset = choose, 1 = one wave per (query tile, head, sequence), 2 = one workgroup per (head, sequence) with K / V in LDS
   static const int forced = [] { const char* e = getenv("RAILS_ATTN"); return e ? atoi(e) : 0; }();
-  const size_t lds_wg = sizeof(float) * ((size_t)2 * N + ((num_buckets + 2 + 3) & ~3) + (size_t)3 * N * kAttnLd);
+  const int NP = (N + 31) / 32 * 32;
+  const size_t lds_wg = sizeof(float) * ((size_t)((NP + N + 3) & ~3) + ((num_buckets + 2 + 3) & ~3) + (size_t)3 * NP * kAttnLd);
   if (forced != 1 && lds_wg <= 150 * 1024 && (forced == 2 || N > 64)) {
     static DynLdsOnce once;
     if (ensure_dyn_lds(once, reinterpret_cast<const void*>(&hstu_attention_wg_kernel), 150 * 1024) != kOk) return kErrLaunch;
