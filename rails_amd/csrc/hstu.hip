@@ -480,10 +480,15 @@ __global__ __launch_bounds__(256) void hstu_attention_wg_kernel(AttnArgs a) {
     hf32x16 O = {0};
     unsigned char bk[16], bkn[16];
     auto fetch_bk = [&](int kt, unsigned char (&o)[16]) {   // (key, query) time buckets of a key tile: L2-resident bytes, one tile ahead
+      if (biased) {     // ONE branch per tile (written per element the compiler made it sixteen)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + acc_row(r, h);
-        o[r] = biased ? brow[(int64_t)(key < N ? key : N - 1) * N + qc] : (unsigned char)(a.num_buckets + 1);   // slot nb + 1 holds 0
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + acc_row(r, h);
+          o[r] = brow[(int64_t)(key < N ? key : N - 1) * N + qc];
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = (unsigned char)(a.num_buckets + 1);   // slot nb + 1 holds 0
       }
     };
     fetch_bk(0, bk);
