@@ -199,6 +199,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 // instruction and no reuse between the waves that share a row block -- 28 % of the fp32 MFMA peak on the uvqk GEMM of an ML-20M
 // block.  Same operand assignment per lane (k = k0 + 16 h + s for MFMA s), same order over k: bit-identical results.
 // LDS rows are 36 floats apart: the 16 lanes of a ds_read_b128 phase then hit 16 distinct 16-byte bank groups.
+// (A 128 x 64 tile per workgroup -- a wave owning 64 x 32, half the operand traffic per MFMA -- measured slower: 67 vs 52 us on the
+// uvqk GEMM; two workgroups per CU instead of four hide less than the halved traffic buys.)
 constexpr int kGemmLd = 36;
 
 __global__ __launch_bounds__(256) void gemm_f32_tiled_kernel(GemmArgs g) {
