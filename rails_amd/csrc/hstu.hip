@@ -200,7 +200,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 // block.  Same operand assignment per lane (k = k0 + 16 h + s for MFMA s), same order over k: bit-identical results.
 // LDS rows are 36 floats apart: the 16 lanes of a ds_read_b128 phase then hit 16 distinct 16-byte bank groups.
 // (A 128 x 64 tile per workgroup -- a wave owning 64 x 32, half the operand traffic per MFMA -- measured slower: 67 vs 52 us on the
-// uvqk GEMM; two workgroups per CU instead of four hide less than the halved traffic buys.)
+// uvqk GEMM; two workgroups per CU instead of four hide less than the halved traffic buys.  Also measured without effect: two K-steps
+// of operands in flight in registers (51.1 us), XCD-aware workgroup numbering (52.5 us) -- neither the L2 round trip nor its locality
+// is what holds this kernel at 0.44 of the peak.)
 constexpr int kGemmLd = 36;
 
 __global__ __launch_bounds__(256) void gemm_f32_tiled_kernel(GemmArgs g) {
