@@ -12,6 +12,7 @@
 #include <math.h>
 
 #include "mol_kernels.h"
+#include <utility>
 #include "mol_layout.h"
 
 namespace mol {
@@ -61,6 +62,12 @@ enum { kScanAll = 0, kScanSample = 1, kScanSelect = 2 };
 // sub-list from the tile index keeps the split even for any item order.
 constexpr int kSubLists = 16;
 constexpr int kScanThreads = 256;
+#ifndef RAILS_SCAN_WAVES
+#define RAILS_SCAN_WAVES 2   // waves per SIMD the scan is compiled for
+#endif
+#ifndef RAILS_SCAN_TU
+#define RAILS_SCAN_TU 0   // item tiles per trip of the scan (0: by d)
+#endif
 
 struct CoarseScanArgs {
   const float* eq; int B, PQ, d, avg;
@@ -98,7 +105,7 @@ __device__ __forceinline__ void append_candidate(unsigned long long* keys, unsig
 __device__ __forceinline__ void stage_push(volatile StageEntry* st, unsigned int* cnt, unsigned long long* keys,
                                            unsigned int* counts, int cap, int sub, unsigned int orow, unsigned long long key) {
   const unsigned int i = atomicAdd(cnt, 1u);   // LDS
-  if (i < (unsigned int)kStage) { st[i].key = key; st[i].orow = orow; }
+  if (i < (unsigned int)kStage) { st[i].key = key; st[i].orow = orow; st[i].pad = (unsigned int)sub; }
   else append_candidate(keys, counts, cap, sub, orow, key);   // list full: straight to global
 }
 __device__ __forceinline__ void stage_flush(volatile StageEntry* st, volatile unsigned int* cnt, int lane, unsigned long long* keys,
@@ -109,9 +116,33 @@ __device__ __forceinline__ void stage_flush(volatile StageEntry* st, volatile un
   for (unsigned int e = lane; e < n; e += 64) append_candidate(keys, counts, cap, sub, st[e].orow, st[e].key);
   if (lane == 0) *cnt = 0u;
 }
+// The same with each entry's own sub-list (stage_push records it): a wave that meets a hit every few tiles keeps staging
+// across tiles and flushes once a wave's worth of entries has gathered (and at the end of its scan) -- flushed per tile, the
+// one or two entries of a hit cost the wave the ~2 us of a device-scope atomic each time.
+__device__ __forceinline__ void stage_flush_mixed(volatile StageEntry* st, volatile unsigned int* cnt, int lane, unsigned long long* keys,
+                                                  unsigned int* counts, int cap, unsigned int at_least) {
+  unsigned int n = *cnt;
+  if (n < at_least || n == 0) return;        // wave-uniform
+  if (n > (unsigned int)kStage) n = kStage;
+  for (unsigned int e = lane; e < n; e += 64) append_candidate(keys, counts, cap, (int)st[e].pad, st[e].orow, st[e].key);
+  if (lane == 0) *cnt = 0u;
+}
+
+// Pre-test of the select scan: the accumulator STARTS at minus the pre-test bound of its (query row, register), so "some score of
+// this lane reaches its bound" is "some accumulator has a clear sign bit" -- an unsigned minimum over the sixteen registers (seven
+// v_min3_u32 and a v_min_u32) and one compare per tile, instead of sixteen compares and sixteen mask ORs.  The bound is one bf16
+// step below the threshold, far more than the rounding the shifted accumulation adds; a tile that passes is scored again from
+// zero, so the scores that are kept are the materialising path's bits.  (A NaN passes the pre-test and fails the exact one.)
+__device__ __forceinline__ unsigned int umin3(unsigned int a, unsigned int b, unsigned int c) { return min(min(a, b), c); }
+__device__ __forceinline__ bool any_sign_clear(const cf32x16& v) {
+  auto u = [&](int i) { return __float_as_uint(v[i]); };
+  const unsigned int a = umin3(u(0), u(1), u(2)), b = umin3(u(3), u(4), u(5)), c = umin3(u(6), u(7), u(8));
+  const unsigned int d = umin3(u(9), u(10), u(11)), e = umin3(u(12), u(13), u(14));
+  return min(umin3(a, b, c), umin3(d, e, u(15))) < 0x80000000u;
+}
 
 template <int DC, int MODE>   // DC = d / 16 K chunks
-__global__ __launch_bounds__(kScanThreads) void coarse_scan_kernel(CoarseScanArgs a) {
+__global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(RAILS_SCAN_WAVES, RAILS_SCAN_WAVES))) void coarse_scan_kernel(CoarseScanArgs a) {
   MOL_RUN_IF(a.run_if);
   extern __shared__ __attribute__((aligned(16))) unsigned short qfrag[];   // [n_qt][DC][64 lanes][8] bf16, then thr
   const int d = a.d, B = a.B;
@@ -119,6 +150,7 @@ __global__ __launch_bounds__(kScanThreads) void coarse_scan_kernel(CoarseScanArg
   float* thr_s = reinterpret_cast<float*>(qfrag + (size_t)n_qt * DC * 64 * 8);   // [n_qt * 32]
   __shared__ StageEntry stage_s[kScanThreads / 64][kStage];
   __shared__ unsigned int stage_n[kScanThreads / 64];
+  __shared__ float acc_s[MODE == kScanSelect ? (kScanThreads / 64) * 16 * 64 : 1];   // a fired tile's scores, per wave
   if (threadIdx.x < kScanThreads / 64) stage_n[threadIdx.x] = 0u;
   for (int i = threadIdx.x; i < n_qt * 32 * d; i += kScanThreads) {
     const int b = i / d, dd = i - b * d;
@@ -129,8 +161,13 @@ __global__ __launch_bounds__(kScanThreads) void coarse_scan_kernel(CoarseScanArg
     const int qt = b >> 5, row = b & 31, c = dd >> 4, h = (dd >> 3) & 1, j = dd & 7;
     qfrag[(((size_t)qt * DC + c) * 64 + h * 32 + row) * 8 + j] = (unsigned short)(__float_as_uint(v) >> 16);
   }
+  float* ntlo_s = thr_s + n_qt * 32;                                              // [n_qt * 32]: minus the pre-test bound
   if constexpr (MODE == kScanSelect)
-    for (int i = threadIdx.x; i < n_qt * 32; i += kScanThreads) thr_s[i] = i < B ? a.thr[(int64_t)i * a.thr_stride] : INFINITY;
+    for (int i = threadIdx.x; i < n_qt * 32; i += kScanThreads) {
+      const float thr = i < B ? a.thr[(int64_t)i * a.thr_stride] : INFINITY;
+      thr_s[i] = thr;
+      ntlo_s[i] = -coarse_unorderable(coarse_orderable(thr) - 0x10000u);
+    }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -139,157 +176,143 @@ __global__ __launch_bounds__(kScanThreads) void coarse_scan_kernel(CoarseScanArg
   const int64_t step = MODE == kScanSample ? a.stride : 1;
   const int64_t n_work = (n_tiles + step - 1) / step;            // tiles this launch visits
   const int64_t gw = (int64_t)blockIdx.x * (kScanThreads / 64) + wave, n_waves = (int64_t)gridDim.x * (kScanThreads / 64);
-  if (n_qt > 1) {
-    // More than one tile of 32 queries (B > 32): the table is still read ONCE.  A wave takes kMT item tiles into registers, then
-    // walks the query tiles over them: per query tile its A fragments and the 16 + 16 per-register thresholds come from LDS
-    // once and serve kMT tiles.  (The single-tile loop below ran once per query tile: B = 128 read the table four times, 7.75 ms
-    // per 125 M-item shard.)
-    constexpr int kMT = DC <= 2 ? 8 : (DC <= 4 ? 4 : 2);
-    for (int64_t w0 = gw * kMT; w0 < n_work; w0 += n_waves * kMT) {
-      bf16x8 Bv[kMT][DC];
-      int64_t items[kMT];
-      bool ins[kMT];
+
+  // One trip = TU item tiles of a wave, held as B fragments in registers.  The trips are DOUBLE-BUFFERED: the 16-byte loads of
+  // the next trip are issued before the current one is scored, so a wave always has a trip of table bytes in flight (with one
+  // trip per wave and two waves per SIMD only 4 MB of the chip's reads were outstanding: 4.6 TB/s by Little's law).
+  constexpr int TU = RAILS_SCAN_TU > 0 ? RAILS_SCAN_TU : (MODE != kScanSelect ? (DC <= 4 ? 2 : 1) : (DC <= 2 ? 4 : (DC <= 4 ? 2 : 1)));   // the score stores of the other modes hold 16 addresses per tile
+  struct Trip {
+    bf16x8 Bv[TU][DC];
+    int64_t item[TU];
+    bool in[TU];
+  };
+  auto load_trip = [&](int64_t w0, Trip& T) {
 #pragma unroll
-      for (int u = 0; u < kMT; ++u) {
-        int64_t item = (w0 + u) * step * 32 + x;
-        ins[u] = (w0 + u) < n_work && item < a.n;
-        if (!ins[u]) item = a.n - 1;
-        items[u] = item;
-        const unsigned short* rowp = a.table + item * d + 8 * h;
+    for (int u = 0; u < TU; ++u) {
+      int64_t item = (w0 + u) * step * 32 + x;
+      T.in[u] = (w0 + u) < n_work && item < a.n;
+      if (!T.in[u]) item = a.n - 1;
+      T.item[u] = item;
+      const unsigned short* rowp = a.table + item * d + 8 * h;
 #pragma unroll
-        for (int c = 0; c < DC; ++c) Bv[u][c] = *reinterpret_cast<const bf16x8*>(rowp + 16 * c);
-      }
-      for (int qt = 0; qt < n_qt; ++qt) {
-        bf16x8 A[DC];
-#pragma unroll
-        for (int c = 0; c < DC; ++c) A[c] = *reinterpret_cast<const bf16x8*>(qfrag + (((size_t)qt * DC + c) * 64 + lane) * 8);
-        float thr[16], tlo[16];
-        if constexpr (MODE == kScanSelect) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            thr[r] = thr_s[qt * 32 + acc_row(r, h)];
-            tlo[r] = coarse_unorderable(coarse_orderable(thr[r]) - 0x10000u);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < kMT; ++u) {
-          const int64_t w = w0 + u;
-          const int64_t t = w * step;
-          const int64_t item = items[u];
-          const bool in = ins[u];
-          cf32x16 acc = {0};
-#pragma unroll
-          for (int c = 0; c < DC; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c], Bv[u][c], acc, 0, 0, 0);
-          if constexpr (MODE == kScanSelect) {
-            bool hit = false;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) hit |= acc[r] >= tlo[r];
-            if (__any(hit && in)) {
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const bool maybe = in && acc[r] >= tlo[r];
-                if (__any(maybe)) {
-                  const int q = qt * 32 + acc_row(r, h);
-                  const float sc = bf16_rn(acc[r]);
-                  if (maybe && q < B && sc >= thr[r])
-                    stage_push(stage_s[wave], &stage_n[wave], a.keys, a.counts, a.cap, (int)(t % kSubLists), (unsigned int)q,
-                               ((unsigned long long)coarse_orderable(sc) << 32) | (unsigned int)(~(unsigned int)item));
-                }
-              }
-              stage_flush(stage_s[wave], &stage_n[wave], lane, a.keys, a.counts, a.cap, (int)(t % kSubLists));
-            }
-          } else {
-            if (w < n_work) {
-              const int64_t colx = MODE == kScanSample ? w * 32 + x : item;
-#pragma unroll
-              for (int r = 0; r < 16; ++r) {
-                const int q = qt * 32 + acc_row(r, h);
-                if (q < B && (in || MODE == kScanSample)) a.scores[(int64_t)q * a.ld + colx] = in ? bf16_rn(acc[r]) : -INFINITY;
-              }
-            }
-          }
-        }
-      }
+      for (int c = 0; c < DC; ++c) T.Bv[u][c] = *reinterpret_cast<const bf16x8*>(rowp + 16 * c);
     }
-    return;
-  }
-  for (int qt = 0; qt < n_qt; ++qt) {
-    bf16x8 A[DC];
+  };
+  auto load_query_tile = [&](int qt, bf16x8 (&A)[DC], cf32x16& ntlo) {
 #pragma unroll
     for (int c = 0; c < DC; ++c) A[c] = *reinterpret_cast<const bf16x8*>(qfrag + (((size_t)qt * DC + c) * 64 + lane) * 8);
-    float thr[16], tlo[16];
     if constexpr (MODE == kScanSelect) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        thr[r] = thr_s[qt * 32 + acc_row(r, h)];
-        // pre-test bound: the bf16 value just below thr (an un-rounded sum at or above it may still round up to thr)
-        tlo[r] = coarse_unorderable(coarse_orderable(thr[r]) - 0x10000u);
-      }
+      for (int r = 0; r < 16; ++r) ntlo[r] = ntlo_s[qt * 32 + acc_row(r, h)];
     }
-    // TU tiles per trip: all their 16-byte loads are issued before the first MFMA
-    constexpr int TU = 1;   // 4 tiles per trip measured no faster (the scan sits at 5.1-5.5 TB/s either way)
-    for (int64_t w0 = gw * TU; w0 < n_work; w0 += n_waves * TU) {
-      bf16x8 Bv[TU][DC];
-      int64_t items[TU];
-      bool ins[TU];
+  };
+  // Select mode, the rare part (K'/N of the scores pass, a few percent of the tiles at shard scale): the tiles of the trip whose
+  // pre-test fired are scored again FROM ZERO -- the bits of the materialising path -- and their scores at or above the query's
+  // threshold are appended.  One copy of this code per kernel: the tile is picked out of the trip's registers by `u`.
+  auto keep_candidates = [&](int qt, const bf16x8 (&A)[DC], const Trip& T, unsigned int fired, int64_t w0) {
+#pragma unroll 1
+    for (int u = 0; u < TU; ++u) {
+      if (!((fired >> u) & 1u)) continue;
+      bf16x8 Bu[DC];
+      int64_t item = 0;
+      bool in = false;
+      // constant indices from the front end on, so that the trip stays in registers
+      auto pick = [&]<int V, int... C>(std::integral_constant<int, V>, std::integer_sequence<int, C...>) {
+        item = T.item[V];
+        in = T.in[V];
+        ((Bu[C] = T.Bv[V][C]), ...);
+      };
+      [&]<int... V>(std::integer_sequence<int, V...>) {
+        ((u == V ? pick(std::integral_constant<int, V>{}, std::make_integer_sequence<int, DC>{}) : (void)0), ...);
+      }(std::make_integer_sequence<int, TU>{});
+      const int64_t t = (w0 + u) * step;
+      cf32x16 acc = {0};
 #pragma unroll
-      for (int u = 0; u < TU; ++u) {
-        const int64_t t = (w0 + u) * step;
-        int64_t item = t * 32 + x;
-        ins[u] = (w0 + u) < n_work && item < a.n;
-        if (!ins[u]) item = a.n - 1;
-        items[u] = item;
-        const unsigned short* rowp = a.table + item * d + 8 * h;
+      for (int c = 0; c < DC; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c], Bu[c], acc, 0, 0, 0);
+      // the sixteen score registers go through LDS so that the loop over them can stay rolled: unrolled, this rare block set
+      // the register allocation of the whole kernel (256 VGPRs and a spill in the middle of the prefetch)
+      float* mine = acc_s + (wave * 16) * 64 + lane;
 #pragma unroll
-        for (int c = 0; c < DC; ++c) Bv[u][c] = *reinterpret_cast<const bf16x8*>(rowp + 16 * c);
+      for (int r = 0; r < 16; ++r) mine[r * 64] = acc[r];
+#pragma unroll 1
+      for (int r = 0; r < 16; ++r) {
+        const int row = acc_row(r, h);
+        const float thr = thr_s[qt * 32 + row];
+        // pre-test bound: the bf16 value just below thr (an un-rounded sum at or above it may still round up to thr)
+        const float tlo = coarse_unorderable(coarse_orderable(thr) - 0x10000u);
+        const float raw = mine[r * 64];
+        const bool maybe = in && raw >= tlo;
+        if (__any(maybe)) {   // per register, only lanes that pass work
+          const int q = qt * 32 + row;
+          const float sc = bf16_rn(raw);
+          if (maybe && q < B && sc >= thr)
+            stage_push(stage_s[wave], &stage_n[wave], a.keys, a.counts, a.cap, (int)(t % kSubLists), (unsigned int)q,
+                       ((unsigned long long)coarse_orderable(sc) << 32) | (unsigned int)(~(unsigned int)item));
+        }
       }
+      stage_flush_mixed(stage_s[wave], &stage_n[wave], lane, a.keys, a.counts, a.cap, 64u);
+    }
+  };
+  // More than one tile of 32 queries (B > 32): the table is still read ONCE -- the query tiles walk over the trip in registers,
+  // their A fragments and accumulator bounds come from LDS once per trip.  (Reading the table once per query tile cost 7.75 ms
+  // per 125 M-item shard at B = 128.)
+  bf16x8 A[DC];
+  cf32x16 ntlo = {0};
+  load_query_tile(0, A, ntlo);
+  auto score_trip = [&](int64_t w0, const Trip& T) {
+    for (int qt = 0; qt < n_qt; ++qt) {
+      if (n_qt > 1) load_query_tile(qt, A, ntlo);
+      unsigned int fired = 0u;
 #pragma unroll
       for (int u = 0; u < TU; ++u) {
-        const int64_t w = w0 + u;
-        const int64_t t = w * step;
-        const int64_t item = items[u];
-        const bool in = ins[u];
-        cf32x16 acc = {0};
+        cf32x16 acc = MODE == kScanSelect ? ntlo : cf32x16{0};
 #pragma unroll
-        for (int c = 0; c < DC; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c], Bv[u][c], acc, 0, 0, 0);
+        for (int c = 0; c < DC; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c], T.Bv[u][c], acc, 0, 0, 0);
         if constexpr (MODE == kScanSelect) {
-          bool hit = false;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) hit |= acc[r] >= tlo[r];
-          if (__any(hit && in)) {   // rare at shard scale (K'/N of the scores pass); per register, only lanes that pass work
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const bool maybe = in && acc[r] >= tlo[r];
-              if (__any(maybe)) {
-                const int q = qt * 32 + acc_row(r, h);
-                const float sc = bf16_rn(acc[r]);
-                if (maybe && q < B && sc >= thr[r])
-                  stage_push(stage_s[wave], &stage_n[wave], a.keys, a.counts, a.cap, (int)(t % kSubLists), (unsigned int)q,
-                             ((unsigned long long)coarse_orderable(sc) << 32) | (unsigned int)(~(unsigned int)item));
-              }
-            }
-            stage_flush(stage_s[wave], &stage_n[wave], lane, a.keys, a.counts, a.cap, (int)(t % kSubLists));
-          }
+          if (__any(any_sign_clear(acc))) fired |= 1u << u;   // a tile past the end (the last row again) may fire: nothing of it is kept
         } else {
+          const int64_t w = w0 + u;
           if (w < n_work) {
-            const int64_t colx = MODE == kScanSample ? w * 32 + x : item;
+            const int64_t colx = MODE == kScanSample ? w * 32 + x : T.item[u];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int q = qt * 32 + acc_row(r, h);
-              if (q < B && (in || MODE == kScanSample)) a.scores[(int64_t)q * a.ld + colx] = in ? bf16_rn(acc[r]) : -INFINITY;
+              if (q < B && (T.in[u] || MODE == kScanSample)) a.scores[(int64_t)q * a.ld + colx] = T.in[u] ? bf16_rn(acc[r]) : -INFINITY;
             }
           }
         }
       }
+      if constexpr (MODE == kScanSelect)
+        if (fired) keep_candidates(qt, A, T, fired, w0);
     }
+  };
+  int64_t w0 = gw * TU;
+  if (w0 >= n_work) return;
+  const int64_t hop = n_waves * TU;
+  Trip T, N;
+  load_trip(w0, T);
+  for (;;) {
+    const int64_t w1 = w0 + hop;
+    load_trip(w1, N);          // past the end: the last row again (in = false), harmless
+    // The wait for T's loads belongs HERE, with N's still in flight: left to the loop over the query tiles below, the compiler's
+    // counter bookkeeping merges the loop's entry and back edge into a wait for everything outstanding -- the prefetch included.
+#pragma unroll
+    for (int u = 0; u < TU; ++u)
+#pragma unroll
+      for (int c = 0; c < DC; ++c) asm volatile("" : "+v"(T.Bv[u][c]));
+    score_trip(w0, T);
+    if (w1 >= n_work) break;
+    T = N;
+    w0 = w1;
   }
+  if constexpr (MODE == kScanSelect) stage_flush_mixed(stage_s[wave], &stage_n[wave], lane, a.keys, a.counts, a.cap, 1u);
 }
 
 template <int MODE>
 static int launch_coarse_scan(const CoarseScanArgs& a, hipStream_t stream) {
   const int n_qt = (a.B + 31) / 32;
   const int dc = a.d / 16;
-  const size_t lds = (size_t)n_qt * dc * 64 * 8 * sizeof(unsigned short) + (size_t)n_qt * 32 * sizeof(float);
+  const size_t lds = (size_t)n_qt * dc * 64 * 8 * sizeof(unsigned short) + 2 * (size_t)n_qt * 32 * sizeof(float);
   if (lds > 64 * 1024) { set_error("coarse scan: batch %d x d %d does not fit LDS", a.B, a.d); return kErrUnsupported; }
   const int64_t n_tiles = (a.n + 31) >> 5;
   const int64_t step = MODE == kScanSample ? a.stride : 1;

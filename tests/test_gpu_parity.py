@@ -1383,7 +1383,7 @@ def _fused_case(cfg_name, N, B, dev, precision, seed=31, dup=1):
                                             ("amzn-books", 695_762, 32, 384), ("ml-20m", 150_001, 32, 200), ("ml-1m", 200_011, 64, 120)])
 def test_fused_score_topk_equals_the_dense_path(dev, cfg_name, N, B, k, precision):
     """rails_mol_score_topk (survivor lists appended by the scoring kernels under a running bound + one selection launch) against
-    rails_mol_score_dense + rails_topk: same scores, same ids, same tie order, bit for bit; the status word stays 0; the workspace is
+    rails_mol_score_dense + rails_topk: same scores, same ids, same tie order, bit for bit (also when the status word reports the dense pass); the workspace is
     left zeroed; a second call (which starts from the state the first one left) agrees."""
     cfg, tk, q, kw = _fused_case(cfg_name, N, B, dev, precision)
     with torch.inference_mode():
@@ -1395,7 +1395,10 @@ def test_fused_score_topk_equals_the_dense_path(dev, cfg_name, N, B, k, precisio
         for _ in range(2):
             qpack, _, _ = eng.query_pack(q, kw.get("user_ids"))
             s, i, status = eng.score_topk(qpack, B, tk._index, k, ids=tk._ids_flat)
-            assert int(status) == 0
+            # 0, or 1 when a survivor segment filled up and the predicated dense pass produced the result: which workgroup publishes
+            # a bound first is a matter of scheduling, and a corpus just above the fused path's minimum leaves little slack
+            # (tools/fused_select_stats.py counts the overflows; the forced case is the overflow test below)
+            assert int(status) in (0, 1)
             assert torch.equal(s, r_s) and torch.equal(i, r_i)
             ws = eng._score_topk_workspace(B, q.device)
             assert int(ws.count_nonzero()) == 0, "the selection launch must leave the lists and bounds zeroed"
