@@ -63,7 +63,8 @@ enum { kScanAll = 0, kScanSample = 1, kScanSelect = 2 };
 constexpr int kSubLists = 16;
 constexpr int kScanThreads = 256;
 #ifndef RAILS_SCAN_WAVES
-#define RAILS_SCAN_WAVES 2   // waves per SIMD the scan is compiled for
+#define RAILS_SCAN_WAVES 3   // waves per SIMD the select scan is compiled for (168 VGPRs; 3 over 2: 3.07 -> 2.87 ms per config-5 step at B = 128,
+                           // nothing at B = 32); the store modes hold sixteen addresses per tile and keep 2
 #endif
 #ifndef RAILS_SCAN_TU
 #define RAILS_SCAN_TU 0   // item tiles per trip of the scan (0: by d)
@@ -142,7 +143,7 @@ __device__ __forceinline__ bool any_sign_clear(const cf32x16& v) {
 }
 
 template <int DC, int MODE>   // DC = d / 16 K chunks
-__global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(RAILS_SCAN_WAVES, RAILS_SCAN_WAVES))) void coarse_scan_kernel(CoarseScanArgs a) {
+__global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MODE == kScanSelect ? RAILS_SCAN_WAVES : 2, MODE == kScanSelect ? RAILS_SCAN_WAVES : 2))) void coarse_scan_kernel(CoarseScanArgs a) {
   MOL_RUN_IF(a.run_if);
   extern __shared__ __attribute__((aligned(16))) unsigned short qfrag[];   // [n_qt][DC][64 lanes][8] bf16, then thr
   const int d = a.d, B = a.B;
@@ -381,9 +382,12 @@ static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p) {
   if (k_prime < 1 || k_prime > 4096 || n < k_prime) return false;
   const int64_t n_tiles = (n + 31) >> 5;
-  // sample every stride-th tile: ~16 expected hits above the true K'-th score for large K', never denser than 1/64 of
-  // the table (small K' just get fewer expected hits m, and r = 2m + 4 sqrt(m) + 8 keeps the miss probability ~1e-10)
-  int stride = k_prime / 16;
+  // sample every stride-th tile: m = ~8 expected hits above the true K'-th score for large K', never denser than 1/64 of
+  // the table (small K' just get fewer expected hits, and r below keeps the miss probability ~1e-9).  m = 16 (stride K'/16)
+  // gave ~3.1 K' candidates instead of ~4.1 K' (of 8 K' slots: r * stride +- sqrt(r) * stride = 4.1 +- 0.7 K'), but the sample
+  // and the selection of its r-th largest are B * n / stride of writes and reads: 0.75 ms of a 2.9 ms step at B = 128 on a
+  // 125 M-item shard, 0.18 of 1.8 ms at B = 32 -- halved by the sparser sample.
+  int stride = k_prime / 8;
   if (stride < 64) stride = 64;
   if (stride > 256) stride = 256;
   // r = the smallest rank with P(Poisson(m) >= r) <= e^-m (e m / r)^r < 1e-9 (Chernoff), and at least 2m + 4 sqrt(m):
