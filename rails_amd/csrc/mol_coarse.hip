@@ -210,7 +210,7 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
   // Select mode, the rare part (K'/N of the scores pass, a few percent of the tiles at shard scale): the tiles of the trip whose
   // pre-test fired are scored again FROM ZERO -- the bits of the materialising path -- and their scores at or above the query's
   // threshold are appended.  One copy of this code per kernel: the tile is picked out of the trip's registers by `u`.
-  auto keep_candidates = [&](int qt, const bf16x8 (&A)[DC], const Trip& T, unsigned int fired, int64_t w0) {
+  auto keep_candidates = [&](int qt, const bf16x8 (&A)[DC], const cf32x16& ntlo, const Trip& T, unsigned int fired, int64_t w0) {
 #pragma unroll 1
     for (int u = 0; u < TU; ++u) {
       if (!((fired >> u) & 1u)) continue;
@@ -230,25 +230,30 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
       cf32x16 acc = {0};
 #pragma unroll
       for (int c = 0; c < DC; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c], Bu[c], acc, 0, 0, 0);
-      // the sixteen score registers go through LDS so that the loop over them can stay rolled: unrolled, this rare block set
-      // the register allocation of the whole kernel (256 VGPRs and a spill in the middle of the prefetch)
-      float* mine = acc_s + (wave * 16) * 64 + lane;
+      // Which of the lane's sixteen scores reach their bound (still in the accumulator-start registers, negated): a bit mask per
+      // lane, one compare each.  Then a ROLLED loop over the set bits -- normally one bit in one lane -- with the scores read
+      // back from LDS by register number.  (Unrolled over the registers, this rare block set the register allocation of the
+      // whole kernel: 256 VGPRs and a spill in the middle of the prefetch; rolled over all sixteen with a ballot each, it cost
+      // as many VALU instructions per fired tile as 25 tiles of the pre-test.)
+      unsigned int mask = 0u;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mine[r * 64] = acc[r];
-#pragma unroll 1
-      for (int r = 0; r < 16; ++r) {
-        const int row = acc_row(r, h);
-        const float thr = thr_s[qt * 32 + row];
-        // pre-test bound: the bf16 value just below thr (an un-rounded sum at or above it may still round up to thr)
-        const float tlo = coarse_unorderable(coarse_orderable(thr) - 0x10000u);
-        const float raw = mine[r * 64];
-        const bool maybe = in && raw >= tlo;
-        if (__any(maybe)) {   // per register, only lanes that pass work
-          const int q = qt * 32 + row;
-          const float sc = bf16_rn(raw);
-          if (maybe && q < B && sc >= thr)
-            stage_push(stage_s[wave], &stage_n[wave], a.keys, a.counts, a.cap, (int)(t % kSubLists), (unsigned int)q,
-                       ((unsigned long long)coarse_orderable(sc) << 32) | (unsigned int)(~(unsigned int)item));
+      for (int r = 0; r < 16; ++r) mask |= acc[r] >= -ntlo[r] ? 1u << r : 0u;   // -ntlo = the bf16 value just below the threshold
+      if (!in) mask = 0u;
+      if (__any(mask != 0u)) {
+        float* mine = acc_s + (wave * 16) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mine[r * 64] = acc[r];
+        while (__any(mask != 0u)) {
+          if (mask != 0u) {
+            const int r = __ffs(mask) - 1;
+            mask &= mask - 1u;
+            const int q = qt * 32 + acc_row(r, h);
+            const float thr = thr_s[q];
+            const float sc = bf16_rn(mine[r * 64]);   // an un-rounded sum at or above the bound may round up to thr
+            if (q < B && sc >= thr)
+              stage_push(stage_s[wave], &stage_n[wave], a.keys, a.counts, a.cap, (int)(t % kSubLists), (unsigned int)q,
+                         ((unsigned long long)coarse_orderable(sc) << 32) | (unsigned int)(~(unsigned int)item));
+          }
         }
       }
       stage_flush_mixed(stage_s[wave], &stage_n[wave], lane, a.keys, a.counts, a.cap, 64u);
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
         }
       }
       if constexpr (MODE == kScanSelect)
-        if (fired) keep_candidates(qt, A, T, fired, w0);
+        if (fired) keep_candidates(qt, A, ntlo, T, fired, w0);
     }
   };
   int64_t w0 = gw * TU;
