@@ -74,6 +74,7 @@ struct CoarseScanArgs {
   const float* eq; int B, PQ, d, avg;
   const unsigned short* table; int64_t n;
   float* scores; int64_t ld;            // kScanAll / kScanSample
+  unsigned short* scores16;             // kScanSample: the sample as bf16 bit patterns instead (the scores ARE bf16 values)
   int stride;                           // kScanSample: tiles t with t % stride == 0, column (t / stride) * 32 + x
   const float* thr; int64_t thr_stride; // kScanSelect: thr[b * thr_stride], a bf16 value
   unsigned long long* keys; int cap;    // kScanSelect: keys[b * cap + sub * (cap / kSubLists) + slot]
@@ -283,7 +284,11 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int q = qt * 32 + acc_row(r, h);
-              if (q < B && (T.in[u] || MODE == kScanSample)) a.scores[(int64_t)q * a.ld + colx] = T.in[u] ? bf16_rn(acc[r]) : -INFINITY;
+              if (q < B && (T.in[u] || MODE == kScanSample)) {
+                const float sc = T.in[u] ? bf16_rn(acc[r]) : -INFINITY;
+                if (MODE == kScanSample && a.scores16) a.scores16[(int64_t)q * a.ld + colx] = (unsigned short)(__float_as_uint(sc) >> 16);
+                else a.scores[(int64_t)q * a.ld + colx] = sc;
+              }
             }
           }
         }
@@ -380,7 +385,7 @@ __global__ void coarse_counts_kernel(const unsigned int* __restrict__ counts, in
   out[b] = over ? cap + 1 : (int32_t)total;
 }
 
-struct CoarseTopkPlan { int stride, r, cap; int64_t n_sample; size_t off_keys, off_sample, off_top_s, off_top_i, off_ws, total, topk_ws; };
+struct CoarseTopkPlan { int stride, r, cap; bool sample16; int64_t n_sample; size_t off_keys, off_sample, off_top_s, off_top_i, off_ws, total, topk_ws; };
 
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -417,7 +422,10 @@ static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p) {
   p->cap = cap;
   size_t o = align256(sizeof(unsigned int) * (size_t)B * kSubLists);
   p->off_keys = o; o += align256(sizeof(unsigned long long) * (size_t)B * cap);
-  p->off_sample = o; o += align256(sizeof(float) * (size_t)B * p->n_sample);
+  // the sample holds bf16 values: kept as 16-bit patterns where the selection of its r-th largest reads them (B * n_sample
+  // elements written by the sample scan and read back once: 0.5 GB per batch of 128 on a 125 M-item shard as fp32)
+  p->sample16 = topk_bf16_source_ok(B, p->n_sample, r);
+  p->off_sample = o; o += align256((p->sample16 ? sizeof(unsigned short) : sizeof(float)) * (size_t)B * p->n_sample);
   p->off_top_s = o; o += align256(sizeof(float) * (size_t)B * r);
   p->off_top_i = o; o += align256(sizeof(int64_t) * (size_t)B * r);
   p->topk_ws = topk_workspace_bytes(B, p->n_sample, r);
@@ -459,10 +467,11 @@ int coarse_topk(const Shape& s, const float* eq, int B, int avg, const void* tab
   CoarseScanArgs a{};
   a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.d = s.dot_product_dimension; a.avg = avg;
   a.table = static_cast<const unsigned short*>(table); a.n = n;
-  a.scores = sample; a.ld = p.n_sample; a.stride = p.stride;
+  a.scores = p.sample16 ? nullptr : sample; a.scores16 = p.sample16 ? reinterpret_cast<unsigned short*>(sample) : nullptr;
+  a.ld = p.n_sample; a.stride = p.stride;
   int rc = launch_coarse_scan<kScanSample>(a, stream);
   if (rc != kOk) return rc;
-  rc = topk(sample, p.n_sample, B, p.n_sample, p.r, nullptr, 0, top_s, top_i, base + p.off_ws, p.topk_ws, n_cu, stream);
+  rc = topk(a.scores, p.n_sample, B, p.n_sample, p.r, nullptr, 0, top_s, top_i, base + p.off_ws, p.topk_ws, n_cu, stream, nullptr, 0, 0, a.scores16);
   if (rc != kOk) return rc;
   a.scores = nullptr; a.stride = 1;
   a.thr = top_s + (p.r - 1); a.thr_stride = p.r; a.keys = keys; a.cap = p.cap; a.counts = counts;
@@ -504,6 +513,7 @@ struct ComponentScanArgs {
   const float* eq; int B, PQ, PX, d;
   const unsigned short* table; int64_t n;
   float* scores; int64_t ld; int stride;
+  unsigned short* scores16;             // kScanSample: the sample as bf16 bit patterns instead
   const float* thr; int64_t thr_stride;
   unsigned long long* keys; int cap;
   unsigned int* counts;
@@ -586,7 +596,11 @@ __global__ __launch_bounds__(kScanThreads) void component_scan_kernel(ComponentS
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int row = qt * 32 + acc_row(r, h);
-            if (row < R && (in || MODE == kScanSample)) a.scores[((int64_t)row * PX + m) * a.ld + colx] = in ? bf16_rn(acc[r]) : -INFINITY;
+            if (row < R && (in || MODE == kScanSample)) {
+              const float sc = in ? bf16_rn(acc[r]) : -INFINITY;
+              if (MODE == kScanSample && a.scores16) a.scores16[((int64_t)row * PX + m) * a.ld + colx] = (unsigned short)(__float_as_uint(sc) >> 16);
+              else a.scores[((int64_t)row * PX + m) * a.ld + colx] = sc;
+            }
           }
         }
       }
@@ -666,10 +680,11 @@ int component_topk(const Shape& s, const float* eq, int B, const void* table, in
   ComponentScanArgs a{};
   a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.PX = s.item_dot_product_groups; a.d = s.dot_product_dimension;
   a.table = static_cast<const unsigned short*>(table); a.n = n;
-  a.scores = sample; a.ld = p.n_sample; a.stride = p.stride;
+  a.scores = p.sample16 ? nullptr : sample; a.scores16 = p.sample16 ? reinterpret_cast<unsigned short*>(sample) : nullptr;
+  a.ld = p.n_sample; a.stride = p.stride;
   int rc = launch_component_scan<kScanSample>(a, stream);
   if (rc != kOk) return rc;
-  rc = topk(sample, p.n_sample, rows, p.n_sample, p.r, nullptr, 0, top_s, top_i, base + p.off_ws, p.topk_ws, n_cu, stream);
+  rc = topk(a.scores, p.n_sample, rows, p.n_sample, p.r, nullptr, 0, top_s, top_i, base + p.off_ws, p.topk_ws, n_cu, stream, nullptr, 0, 0, a.scores16);
   if (rc != kOk) return rc;
   a.scores = nullptr; a.stride = 1;
   a.thr = top_s + (p.r - 1); a.thr_stride = p.r; a.keys = keys; a.cap = p.cap; a.counts = counts;

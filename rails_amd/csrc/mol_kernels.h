@@ -147,7 +147,9 @@ size_t topk_workspace_bytes(int rows, int64_t n, int k);
 bool topk_can_fuse_filter(int64_t n, int k, int width, int k_out);
 int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int64_t* ids, int64_t ids_row_stride,
          float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, int n_cu, hipStream_t stream,
-         const int64_t* f_invalid = nullptr, int f_width = 0, int f_k = 0);
+         const int64_t* f_invalid = nullptr, int f_width = 0, int f_k = 0, const unsigned short* scores16 = nullptr);
+// scores16 != NULL: the rows are bf16 bit patterns (ld, n in elements); only where topk_bf16_source_ok says so
+bool topk_bf16_source_ok(int rows, int64_t n, int k);
 int select_lists(unsigned long long* lists, unsigned int* thr, int rows, int cap, int k, const int64_t* ids,
                  int64_t ids_row_stride, float* out_scores, int64_t* out_ids, hipStream_t stream,
                  const int64_t* f_invalid = nullptr, int f_width = 0, int f_k = 0);

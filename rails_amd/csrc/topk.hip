@@ -413,6 +413,7 @@ __device__ __forceinline__ void filter_from_lds(const int64_t* id_s, const float
 
 struct RowSelectArgs {
   const float* scores; int64_t ld; int64_t n; int64_t chunk;     // SCORES source: row r, chunk c = [c*chunk, min(n, (c+1)*chunk))
+  const unsigned short* scores16;                                // SCORES source held as bf16 bit patterns (then `scores` is unused)
   const unsigned long long* keys_in; int keys_per_row;           // KEYS source
   // KEYS source filled by the scoring kernels (mol_select.h): sparse rows, empty slots are 0.  The launch consumes the lists: it
   // zeroes the slots it read and resets the rows' bounds
@@ -470,17 +471,34 @@ __global__ __launch_bounds__(kRowThreads) void row_select_kernel(const RowSelect
     const int64_t b64 = (int64_t)blockIdx.y * a.chunk;
     begin = (unsigned int)b64;
     cnt = (int)((b64 + a.chunk < a.n ? b64 + a.chunk : a.n) - b64);
-    const float* rowp = a.scores + (int64_t)row * a.ld + b64;
-    const bool aligned = (reinterpret_cast<uintptr_t>(rowp) & 15) == 0;
+    if (a.scores16) {   // bf16 bit patterns (the coarse sample): the same keys as their fp32 values give, half the bytes
+      const unsigned short* rowp = a.scores16 + (int64_t)row * a.ld + b64;
+      const bool aligned = (reinterpret_cast<uintptr_t>(rowp) & 7) == 0;
 #pragma unroll
-    for (int jv = 0; jv < VPT / 4; ++jv) {
-      const int base = (jv * kRowThreads + tid) * 4;
-      if (aligned && base + 3 < cnt) {
-        const float4 x = *reinterpret_cast<const float4*>(rowp + base);
-        v[4 * jv] = orderable(x.x); v[4 * jv + 1] = orderable(x.y); v[4 * jv + 2] = orderable(x.z); v[4 * jv + 3] = orderable(x.w);
-      } else {
+      for (int jv = 0; jv < VPT / 4; ++jv) {
+        const int base = (jv * kRowThreads + tid) * 4;
+        if (aligned && base + 3 < cnt) {
+          const uint2 x = *reinterpret_cast<const uint2*>(rowp + base);
+          v[4 * jv] = orderable(__uint_as_float(x.x << 16)); v[4 * jv + 1] = orderable(__uint_as_float(x.x & 0xFFFF0000u));
+          v[4 * jv + 2] = orderable(__uint_as_float(x.y << 16)); v[4 * jv + 3] = orderable(__uint_as_float(x.y & 0xFFFF0000u));
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[4 * jv + e] = base + e < cnt ? orderable(rowp[base + e]) : 0u;
+          for (int e = 0; e < 4; ++e) v[4 * jv + e] = base + e < cnt ? orderable(__uint_as_float((unsigned int)rowp[base + e] << 16)) : 0u;
+        }
+      }
+    } else {
+      const float* rowp = a.scores + (int64_t)row * a.ld + b64;
+      const bool aligned = (reinterpret_cast<uintptr_t>(rowp) & 15) == 0;
+#pragma unroll
+      for (int jv = 0; jv < VPT / 4; ++jv) {
+        const int base = (jv * kRowThreads + tid) * 4;
+        if (aligned && base + 3 < cnt) {
+          const float4 x = *reinterpret_cast<const float4*>(rowp + base);
+          v[4 * jv] = orderable(x.x); v[4 * jv + 1] = orderable(x.y); v[4 * jv + 2] = orderable(x.z); v[4 * jv + 3] = orderable(x.w);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[4 * jv + e] = base + e < cnt ? orderable(rowp[base + e]) : 0u;
+        }
       }
     }
     lo[0] = 0u;
@@ -736,10 +754,16 @@ bool topk_can_fuse_filter(int64_t n, int k, int width, int k_out) {
          (n <= kRowMaxN || [&] { int c; int64_t l; return two_level_plan(n, k, &c, &l); }());
 }
 
+// bf16 sources run the row-select launches only (one launch, or per-chunk winners + winners' winners)
+bool topk_bf16_source_ok(int rows, int64_t n, int k) {
+  return n > 1024 && n < (1ll << 32) && k <= kRowMaxK && (n <= kRowMaxN || [&] { int c; int64_t l; return two_level_plan(n, k, &c, &l, rows); }());
+}
+
 int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int64_t* ids, int64_t ids_row_stride,
          float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, int n_cu, hipStream_t stream,
-         const int64_t* f_invalid, int f_width, int f_k) {
+         const int64_t* f_invalid, int f_width, int f_k, const unsigned short* scores16) {
   if (rows <= 0 || k <= 0) return kOk;
+  if (scores16 && !topk_bf16_source_ok(rows, n, k)) { set_error("topk: no bf16-source path at n = %lld, k = %d", (long long)n, k); return kErrUnsupported; }
   if (f_invalid && !topk_can_fuse_filter(n, k, f_width, f_k)) { set_error("topk: the seen-id filter cannot be fused at n = %lld, k = %d, width = %d", (long long)n, k, f_width); return kErrUnsupported; }
   if (k > kSortCap) { set_error("k = %d exceeds the in-LDS sort capacity (%d)", k, kSortCap); return kErrUnsupported; }
   if (n >= (1ll << 32)) { set_error("n = %lld does not fit 32-bit positions; shard the corpus", (long long)n); return kErrUnsupported; }
@@ -748,7 +772,7 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
   if (n > 1024 && k <= kRowMaxK) {
     RowSelectArgs a{};
     a.run_if = pred;
-    a.scores = scores; a.ld = ld; a.n = n; a.k = k;
+    a.scores = scores; a.scores16 = scores16; a.ld = ld; a.n = n; a.k = k;
     if (n <= kRowMaxN) {                 // one launch
       a.chunk = n; a.ids = ids; a.ids_row_stride = ids_row_stride; a.out_scores = out_scores; a.out_ids = out_ids;
       a.f_invalid = f_invalid; a.f_width = f_width; a.f_k = f_k;
