@@ -72,6 +72,7 @@ constexpr int kScanThreads = 256;
 
 struct CoarseScanArgs {
   const float* eq; int B, PQ, d, avg;
+  const unsigned short* qfrag;          // the queries' A fragments made once by coarse_query_kernel (else every workgroup makes them from eq)
   const unsigned short* table; int64_t n;
   float* scores; int64_t ld;            // kScanAll / kScanSample
   unsigned short* scores16;             // kScanSample: the sample as bf16 bit patterns instead (the scores ARE bf16 values)
@@ -143,6 +144,23 @@ __device__ __forceinline__ bool any_sign_clear(const cf32x16& v) {
   return min(umin3(a, b, c), umin3(d, e, u(15))) < 0x80000000u;
 }
 
+// Element i = (query b, dimension dd) of the coarse query  bf16(sum or mean over the P_Q groups of Eq[b])  into its slot of the
+// MFMA A fragments [query tile][K chunk][64 lanes][8] (lane = 32 * (k half) + row).
+__device__ __forceinline__ void coarse_query_element(const float* __restrict__ eq, int B, int PQ, int d, int avg, int i, unsigned short* frag) {
+  const int DC = d / 16;
+  const int b = i / d, dd = i - b * d;
+  float acc = 0.0f;
+  if (b < B)
+    for (int p = 0; p < PQ; ++p) acc += eq[((int64_t)b * PQ + p) * d + dd];
+  const float v = b < B ? bf16_rn(avg ? acc / (float)PQ : acc) : 0.0f;
+  const int qt = b >> 5, row = b & 31, c = dd >> 4, h = (dd >> 3) & 1, j = dd & 7;
+  frag[(((size_t)qt * DC + c) * 64 + h * 32 + row) * 8 + j] = (unsigned short)(__float_as_uint(v) >> 16);
+}
+__global__ void coarse_query_kernel(const float* __restrict__ eq, int B, int PQ, int d, int avg, unsigned short* __restrict__ frag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (B + 31) / 32 * 32 * d) coarse_query_element(eq, B, PQ, d, avg, i, frag);
+}
+
 template <int DC, int MODE>   // DC = d / 16 K chunks
 __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MODE == kScanSelect ? RAILS_SCAN_WAVES : 2, MODE == kScanSelect ? RAILS_SCAN_WAVES : 2))) void coarse_scan_kernel(CoarseScanArgs a) {
   MOL_RUN_IF(a.run_if);
@@ -154,14 +172,11 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
   __shared__ unsigned int stage_n[kScanThreads / 64];
   __shared__ float acc_s[MODE == kScanSelect ? (kScanThreads / 64) * 16 * 64 : 1];   // a fired tile's scores, per wave
   if (threadIdx.x < kScanThreads / 64) stage_n[threadIdx.x] = 0u;
-  for (int i = threadIdx.x; i < n_qt * 32 * d; i += kScanThreads) {
-    const int b = i / d, dd = i - b * d;
-    float acc = 0.0f;
-    if (b < B)
-      for (int p = 0; p < a.PQ; ++p) acc += a.eq[((int64_t)b * a.PQ + p) * d + dd];
-    const float v = b < B ? bf16_rn(a.avg ? acc / (float)a.PQ : acc) : 0.0f;
-    const int qt = b >> 5, row = b & 31, c = dd >> 4, h = (dd >> 3) & 1, j = dd & 7;
-    qfrag[(((size_t)qt * DC + c) * 64 + h * 32 + row) * 8 + j] = (unsigned short)(__float_as_uint(v) >> 16);
+  if (a.qfrag) {   // 16 bytes per thread and step instead of P_Q dependent loads per element (2 048 workgroups each made them)
+    for (int i = threadIdx.x; i < n_qt * DC * 64; i += kScanThreads)
+      reinterpret_cast<bf16x8*>(qfrag)[i] = reinterpret_cast<const bf16x8*>(a.qfrag)[i];
+  } else {
+    for (int i = threadIdx.x; i < n_qt * 32 * d; i += kScanThreads) coarse_query_element(a.eq, B, a.PQ, d, a.avg, i, qfrag);
   }
   float* ntlo_s = thr_s + n_qt * 32;                                              // [n_qt * 32]: minus the pre-test bound
   if constexpr (MODE == kScanSelect)
@@ -328,8 +343,10 @@ static int launch_coarse_scan(const CoarseScanArgs& a, hipStream_t stream) {
   const int64_t n_tiles = (a.n + 31) >> 5;
   const int64_t step = MODE == kScanSample ? a.stride : 1;
   const int64_t n_work = (n_tiles + step - 1) / step;
-  int64_t grid = (n_work + 3) / 4;
-  if (grid > 2048) grid = 2048;     // 8 workgroups of 4 waves per CU
+  constexpr int tu = MODE != kScanSelect ? 2 : 4;   // tiles per trip at d = 32 (fewer at larger d: then some waves get no trip)
+  int64_t grid = (n_work + 4 * tu - 1) / (4 * tu);
+  static const int64_t grid_cap = [] { const char* e = getenv("RAILS_SCAN_GRID"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : (int64_t)2048; }();
+  if (grid > grid_cap) grid = grid_cap;     // 2048: 8 workgroups of 4 waves per CU
   if (grid < 1) return kOk;
   switch (dc) {
     case 2: hipLaunchKernelGGL((coarse_scan_kernel<2, MODE>), dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a); break;
@@ -385,7 +402,7 @@ __global__ void coarse_counts_kernel(const unsigned int* __restrict__ counts, in
   out[b] = over ? cap + 1 : (int32_t)total;
 }
 
-struct CoarseTopkPlan { int stride, r, cap; bool sample16; int64_t n_sample; size_t off_keys, off_sample, off_top_s, off_top_i, off_ws, total, topk_ws; };
+struct CoarseTopkPlan { int stride, r, cap; bool sample16; int64_t n_sample; size_t off_keys, off_sample, off_top_s, off_top_i, off_ws, off_qfrag, total, topk_ws; };
 
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -430,6 +447,7 @@ static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p) {
   p->off_top_i = o; o += align256(sizeof(int64_t) * (size_t)B * r);
   p->topk_ws = topk_workspace_bytes(B, p->n_sample, r);
   p->off_ws = o; o += align256(p->topk_ws);
+  p->off_qfrag = o; o += align256(sizeof(unsigned short) * (size_t)((B + 31) / 32) * 32 * 128);   // coarse_topk's query fragments (d <= 128)
   p->total = o;
   return true;
 }
@@ -467,6 +485,12 @@ int coarse_topk(const Shape& s, const float* eq, int B, int avg, const void* tab
   CoarseScanArgs a{};
   a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.d = s.dot_product_dimension; a.avg = avg;
   a.table = static_cast<const unsigned short*>(table); a.n = n;
+  {   // the queries' A fragments, once for both scans
+    unsigned short* frag = reinterpret_cast<unsigned short*>(base + p.off_qfrag);
+    const int elems = (B + 31) / 32 * 32 * a.d;
+    hipLaunchKernelGGL(coarse_query_kernel, dim3((elems + 255) / 256), dim3(256), 0, stream, eq, B, a.PQ, a.d, avg, frag);
+    a.qfrag = frag;
+  }
   a.scores = p.sample16 ? nullptr : sample; a.scores16 = p.sample16 ? reinterpret_cast<unsigned short*>(sample) : nullptr;
   a.ld = p.n_sample; a.stride = p.stride;
   int rc = launch_coarse_scan<kScanSample>(a, stream);
