@@ -406,6 +406,9 @@ struct CoarseTopkPlan { int stride, r, cap; bool sample16; int64_t n_sample; siz
 
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
+#ifndef RAILS_SAMPLE16
+#define RAILS_SAMPLE16 1   // 0: fp32 threshold samples (measurement)
+#endif
 static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p) {
   if (k_prime < 1 || k_prime > 4096 || n < k_prime) return false;
   const int64_t n_tiles = (n + 31) >> 5;
@@ -441,7 +444,7 @@ static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p) {
   p->off_keys = o; o += align256(sizeof(unsigned long long) * (size_t)B * cap);
   // the sample holds bf16 values: kept as 16-bit patterns where the selection of its r-th largest reads them (B * n_sample
   // elements written by the sample scan and read back once: 0.5 GB per batch of 128 on a 125 M-item shard as fp32)
-  p->sample16 = topk_bf16_source_ok(B, p->n_sample, r);
+  p->sample16 = RAILS_SAMPLE16 && topk_bf16_source_ok(B, p->n_sample, r);
   p->off_sample = o; o += align256((p->sample16 ? sizeof(unsigned short) : sizeof(float)) * (size_t)B * p->n_sample);
   p->off_top_s = o; o += align256(sizeof(float) * (size_t)B * r);
   p->off_top_i = o; o += align256(sizeof(int64_t) * (size_t)B * r);

@@ -10,4 +10,8 @@ python tools/fused_select_stats.py > $O/fused_select_stats.txt 2>&1
 python tools/fused_select_timing.py > $O/fused_select_timing.txt 2>&1
 python tools/hstu_bench.py > $O/hstu_encoder.json 2> $O/hstu.err
 python bench.py --batch 128 --no-cpu-baseline --no-matrix --no-other-workloads --steps 10 --warmup 2 > $O/bench_b128.json 2> $O/bench_b128.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c5 -o r03c5 -- python bench.py --workload synthetic-8x8x32 --two-pass 1000 --device-table --no-cpu-baseline --no-matrix --no-other-workloads --no-fast-path --steps 10 --warmup 2 > $O/two_pass_125m.json 2> $O/two_pass_125m.err
+python bench.py --workload synthetic-8x8x32 --two-pass 1000 --device-table --batch 32 --no-cpu-baseline --no-matrix --no-other-workloads --no-fast-path --steps 10 --warmup 2 > $O/two_pass_125m_noprof.json 2>> $O/two_pass_125m.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c5_b128 -o r03c5b128 -- python bench.py --workload synthetic-8x8x32 --two-pass 1000 --device-table --batch 128 --no-cpu-baseline --no-matrix --no-other-workloads --no-fast-path --steps 10 --warmup 2 > $O/two_pass_125m_b128_prof.json 2> $O/two_pass_125m_b128.err
+python bench.py --workload synthetic-8x8x32 --two-pass 1000 --device-table --batch 128 --no-cpu-baseline --no-matrix --no-other-workloads --no-fast-path --steps 10 --warmup 2 > $O/two_pass_125m_b128.json 2>> $O/two_pass_125m_b128.err
 ls $O
