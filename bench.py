@@ -769,6 +769,14 @@ def main() -> None:
                 "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
                 "traffic": None, "kernel_ms": score_ms, "hbm_bytes_alg_per_launch": coarse_table_bytes,
             }
+            if args.workload == "synthetic-8x8x32" and hi - lo == 125_000_000 and B in (32, 128):
+                # committed PMC passes of the select scan (the launch that reads the table; the time above also covers the sample
+                # pass and the key selection)
+                tr = committed_traffic(f"synthetic-8x8x32:coarse_scan:N125M:B{B}:r03")
+                if tr:
+                    out["roofline"]["traffic"] = tr
+                    out["roofline"]["traffic_source"] = ("profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the select-scan launch on this "
+                                                         "workload; FETCH_SIZE x 2 on gfx950; not collected in this run)")
         if sharded_info is not None:
             out["sharded"] = sharded_info
         if fast is not None:
