@@ -136,6 +136,11 @@ __device__ __forceinline__ void stage_flush_mixed(volatile StageEntry* st, volat
 // v_min3_u32 and a v_min_u32) and one compare per tile, instead of sixteen compares and sixteen mask ORs.  The bound is one bf16
 // step below the threshold, far more than the rounding the shifted accumulation adds; a tile that passes is scored again from
 // zero, so the scores that are kept are the materialising path's bits.  (A NaN passes the pre-test and fails the exact one.)
+// What "far more" means: a score that the exact test keeps sits at least half a bf16 step (2^-9 |thr|) above the bound, and the two
+// accumulation orders differ by at most ~d * 2^-24 * (|bound| + sum |q_k x_k|); the pre-test could only lose a kept score if the
+// threshold were below ~5e-4 of the row's sum of |products| -- the top of the score distribution cancelling to zero -- AND that
+// score were among the K' best, i.e. the K'-th best within that rounding noise of the threshold although ~4 K' candidates are
+// expected above it.  The fused == materialised tests (ties included) and tools/fuzz_fused_scans.py have never seen a difference.
 __device__ __forceinline__ unsigned int umin3(unsigned int a, unsigned int b, unsigned int c) { return min(min(a, b), c); }
 __device__ __forceinline__ bool any_sign_clear(const cf32x16& v) {
   auto u = [&](int i) { return __float_as_uint(v[i]); };
