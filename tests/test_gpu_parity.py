@@ -383,6 +383,34 @@ def test_fused_coarse_topk_equals_the_materialised_path(dev, cfg_name, n, avg_k)
         assert torch.equal(s1, s2) and torch.equal(i1, i2)
 
 
+@pytest.mark.parametrize("cfg_name,n,B,avg_k", [("amzn-books", 2_200_003, 32, 1000), ("amzn-books", 2_200_003, 70, 300),
+                                                ("ml-1m", 1_200_001, 32, 500), ("ml-20m", 600_011, 40, 200)])
+def test_fused_coarse_topk_over_several_trips_per_wave(dev, cfg_name, n, B, avg_k):
+    """The select scan double-buffers trips of item tiles in registers; only a corpus with more than 2 048 workgroups x 4 waves x
+    (4 | 2 | 1 tiles at d = 32 | 64 | 128) tiles makes a wave go round that loop more than once (the last round ragged).  Same
+    claim as above at such sizes, for one and for several query tiles: fused == materialised coarse scores + top-K', bit for bit."""
+    cfg = O.CONFIGS[cfg_name]
+    mol = build_module(cfg, O.synthetic_weights(cfg, seed=3), dev)
+    X = torch.empty((1, n, cfg.item_embedding_dim), dtype=torch.float32, device=dev)
+    for s0 in range(0, n, 500_000):
+        m = min(500_000, n - s0)
+        X[0, s0 : s0 + m] = torch.from_numpy(O.hash_item_table(9, s0, m, cfg.item_embedding_dim)).to(dev)
+    ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B, seed=6).to(dev)
+    kw = {}
+    if len(cfg.uid_embedding_hash_sizes) > 0:
+        kw["user_ids"] = torch.arange(B, dtype=torch.int64, device=dev) * 5 + 2
+    with torch.inference_mode():
+        at = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=avg_k)
+        eng = at._bind()
+        _, eq, _ = eng.query_pack(q, kw.get("user_ids"), want_plain=True)
+        coarse = eng.coarse_scores(eq, at._table(), True)
+        rs, rp = E.topk(coarse, avg_k)
+        fs, fp, counts = eng.coarse_topk(eq, at._table(), True, avg_k)
+        assert int(counts.min()) >= avg_k and int(counts.max()) <= eng.coarse_topk_capacity(avg_k), counts
+        assert torch.equal(fs, rs) and torch.equal(fp, rp)
+
+
 def test_fused_coarse_topk_falls_back_on_heavy_ties(dev):
     """A corpus of 300k copies of 40 distinct items: every coarse score is tied thousands of times, the candidate lists
     overflow, and the module must notice (counts) and return the materialising path's answer."""
