@@ -1,0 +1,170 @@
+"""BASELINE.json configs 4 and 5 at the size of ONE 8-way shard (12.5 M items of 16x16x64; 125 M items of 8x8x32), through the
+same modules the sharded bench runs on each rank.  The oracle cannot score corpora of this size in seconds, so parity is held
+through size-independent properties plus a random sample of columns against the oracle:
+  exact top-k (config 4): determinism, sortedness, sampled logits vs the oracle, "nothing outside beats the k-th",
+                          per-sub-shard top-k merged == the shard's top-k bit for bit;
+  two-pass (config 5):    fused coarse top-K' == materialised coarse scores + exact top-K' bit for bit, the rerank is the exact
+                          MoL top-k of the candidate set, sampled logits vs the oracle, recall@k against exact brute force over
+                          all 125 M items (planted structure, as tools/two_pass_recall.py: with the reference's random init the
+                          coarse score is uncorrelated with MoL and there is nothing to recall).
+Item tables are drawn on the device (truncated normal, sigma 0.02: a host table would be 3.2 / 32 GB).  Skipped when the device
+has less free memory than the shard needs (MI355X: 288 GB)."""
+import pytest
+import torch
+
+import rails_amd
+from oracle import mol_oracle as O
+from rails_amd import engine as E
+from tests.test_gpu_parity import LOGIT_TOL, build_module
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _need_free(dev, gb: float) -> None:
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info(dev)
+    if free < gb * 1e9:
+        pytest.skip(f"needs {gb:.0f} GB of free device memory, {free / 1e9:.0f} GB available")
+
+
+def _device_table(n: int, dim: int, dev, seed: int) -> torch.Tensor:
+    X = torch.empty((1, n, dim), dtype=torch.float32, device=dev)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    for s in range(0, n, 8_000_000):
+        m = min(8_000_000, n - s)
+        X[0, s : s + m] = torch.fmod(torch.randn((m, dim), generator=g, device=dev), 2.0) * 0.02
+    return X
+
+
+def _sample_columns(n: int, seed: int) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed)
+    return torch.cat([torch.randint(0, n, (2048,), generator=g), torch.tensor([0, 31, 32, 127, 128, n - 2, n - 1])])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_config4_shard_exact_topk_properties(dev, precision):
+    """16x16x64, N = 12 500 000 (100 M / 8), B = 32, k = 200: MoLBruteForceTopK on one rank's shard."""
+    _need_free(dev, 110)
+    cfg = O.CONFIGS["synthetic-16x16x64"]
+    w = O.synthetic_weights(cfg, seed=0)
+    mol = build_module(cfg, w, dev, precision)
+    N, B, k = 12_500_000, 32, 200
+    X = _device_table(N, cfg.item_embedding_dim, dev, seed=4)
+    ids = torch.arange(1, N + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B, seed=4)
+    with torch.inference_mode():
+        tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
+        s, i = tk(q.to(dev), k=k)
+        s2, i2 = tk(q.to(dev), k=k)
+        logits = tk.all_logits(q.to(dev))          # (32, 12.5 M) fp32 = 1.6 GB
+    assert torch.equal(s, s2) and torch.equal(i, i2)
+    assert bool((s[:, :-1] >= s[:, 1:]).all())
+    assert int(i.min()) >= 1 and int(i.max()) <= N
+    cols = _sample_columns(N, seed=44)
+    ref = O.mol_logits(cfg, w, q, X[:, cols.to(dev)].cpu())
+    d = float((logits[:, cols.to(dev)].cpu() - ref).abs().max())
+    assert d <= LOGIT_TOL, d
+    assert torch.equal(torch.gather(logits, 1, i - 1), s)
+    assert bool((logits >= s[:, -1:]).sum(1).ge(k).all()) and bool((logits > s[:, -1:]).sum(1).lt(k).all())
+    R = 8   # the merge the 8 ranks do, on sub-ranges of this shard
+    bounds = [((N + R - 1) // R) * r for r in range(R)] + [N]
+    parts = [E.topk(logits[:, bounds[r]:bounds[r + 1]], k) for r in range(R)]
+    ms, mi = E.topk(torch.cat([p[0] for p in parts], 1), k, ids=torch.cat([p[1] + bounds[r] + 1 for r, p in enumerate(parts)], 1))
+    assert torch.equal(ms, s) and torch.equal(mi, i)
+    del tk, logits, X
+    torch.cuda.empty_cache()
+
+
+def test_config4_shard_verified_mode_equals_fp32(dev):
+    """The speculate-and-verify mode (`f16-exact`: one-product f16 first pass, fp32 re-scoring of the candidates, device-side
+    verdict) returns the plain fp32 module's top-k bit for bit on a whole 12.5 M-item shard, with no dense fallback."""
+    _need_free(dev, 230)
+    cfg = O.CONFIGS["synthetic-16x16x64"]
+    w = O.synthetic_weights(cfg, seed=0)
+    N, B, k = 12_500_000, 32, 200
+    X = _device_table(N, cfg.item_embedding_dim, dev, seed=4)
+    ids = torch.arange(1, N + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B, seed=4).to(dev)
+    with torch.inference_mode():
+        plain = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, "fp32"), X, ids)
+        s, i = plain(q, k=k)
+        del plain
+        torch.cuda.empty_cache()
+        fast = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, "f16-exact"), X, ids)
+        for _ in range(3):
+            fs, fi = fast(q, k=k)
+            assert torch.equal(fs, s) and torch.equal(fi, i)
+        torch.cuda.synchronize()
+        st = fast.stats()
+    assert st["calls"] >= 3 and st["fallbacks"] == 0, st
+    del fast, X
+    torch.cuda.empty_cache()
+
+
+def test_config5_shard_two_pass_properties(dev):
+    """8x8x32, N = 125 000 000 (1 B / 8), B = 32, K' = 1000, k = 100: MoLAvgTopK on one rank's shard."""
+    _need_free(dev, 235)
+    cfg = O.CONFIGS["synthetic-8x8x32"]
+    w = O.synthetic_weights(cfg, seed=0)
+    for key in ("_gating_fn._query_only_partial_module.2.weight", "_gating_fn._item_only_partial_module.3.weight",
+                "_gating_fn._qi_partial_module.3.weight", "_gating_fn._qi_partial_module.3.bias"):
+        w[key] = w[key] * 0.25      # planted structure: near-uniform mixture weights, MoL ~ coarse score + gate perturbation
+    mol = build_module(cfg, w, dev, None)
+    N, B, k, kp = 125_000_000, 32, 100, 1000
+    X = _device_table(N, cfg.item_embedding_dim, dev, seed=5)
+    ids = torch.arange(1, N + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B, seed=5)
+    qd = q.to(dev)
+    with torch.inference_mode():
+        at = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=kp)
+        eng = at._bind()
+        table = at._table()
+        assert table.shape[0] == N
+        s, i = at(qd, k=k)
+        s2, i2 = at(qd, k=k)
+        assert torch.equal(s, s2) and torch.equal(i, i2)
+        assert bool((s[:, :-1] >= s[:, 1:]).all())
+        assert int(i.min()) >= 1 and int(i.max()) <= N
+        assert all(len(set(r.tolist())) == k for r in i.cpu())
+        # pass 1: the fused scan (no (B, N) matrix) against coarse scores of all items + exact top-K', eight queries (4 GB) at a time
+        _, eq, _ = eng.query_pack(qd, None, want_plain=True)
+        fs, fp, counts = eng.coarse_topk(eq, table, False, kp)
+        assert int(counts.min()) >= kp and int(counts.max()) <= eng.coarse_topk_capacity(kp)
+        for b0 in range(0, B, 8):
+            coarse = eng.coarse_scores(eq[b0 : b0 + 8].contiguous(), table, False)
+            rs, rp = E.topk(coarse, kp)
+            assert torch.equal(fs[b0 : b0 + 8], rs) and torch.equal(fp[b0 : b0 + 8], rp)
+            del coarse
+        cs, cp = at.coarse_candidates(qd)
+        assert torch.equal(cs, fs) and torch.equal(cp, fp)
+        # exact brute force over the whole shard, eight queries (4 GB of logits) at a time; pass 2 == exact MoL top-k of the candidates
+        cols = _sample_columns(N, seed=55).to(dev)
+        ref = O.mol_logits(cfg, w, q, X[:, cols].cpu())
+        hits10 = hitsk = 0
+        for b0 in range(0, B, 8):
+            logits = at.all_logits(qd[b0 : b0 + 8])
+            d = float((logits[:, cols].cpu() - ref[b0 : b0 + 8]).abs().max())
+            assert d <= LOGIT_TOL, d
+            es, ei = E.topk(logits, k, ids=at._ids_flat)
+            cand_logits = torch.gather(logits, 1, fp[b0 : b0 + 8])
+            ws, wi = E.topk(cand_logits, k, ids=at._ids_flat[fp[b0 : b0 + 8]])
+            assert float((ws - s[b0 : b0 + 8]).abs().max()) <= 2e-5      # candidate kernel vs dense kernel: summation order only
+            same = wi == i[b0 : b0 + 8]
+            assert float(same.float().mean()) >= 0.99                      # swaps inside groups of logits closer than that
+            for r in range(8):
+                mine, truth = i[b0 + r].tolist(), ei[r].tolist()
+                hits10 += len(set(mine[:10]) & set(truth[:10]))
+                hitsk += len(set(mine) & set(truth))
+            del logits, cand_logits
+        recall10, recallk = hits10 / (B * 10), hitsk / (B * k)
+        # profiles/r02_two_pass_125m_planted.json: 0.44 / 0.37 with another table seed; the bar leaves room for the seed
+        assert recall10 >= 0.25 and recallk >= 0.2, (recall10, recallk)
+    del at, X, table
+    torch.cuda.empty_cache()
