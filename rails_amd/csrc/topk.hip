@@ -86,6 +86,63 @@ __device__ __forceinline__ unsigned long long block_sort_desc(unsigned long long
   return key;
 }
 
+// ---- more keys than threads: KPT = npad / 1024 keys per thread (npad = 2048 .. 16384) --------------------------------
+// Thread t holds the keys of LDS slots [t * KPT, (t + 1) * KPT).  Compare-exchange distances below KPT stay inside the
+// thread, distances below 64 * KPT are one ds_bpermute per key inside the wavefront, only the rest go through LDS (two
+// barriers each, `keys` itself is the exchange buffer): 10 LDS steps of 78 for 4096 keys, where the plain loop took a
+// barrier-separated LDS pass for every step (39 us per 4096-key row).
+// In: keys[0, npad) in LDS, visible to all threads.  Out: the same, sorted descending, visible to all threads.
+template <int KPT>
+__device__ __forceinline__ void block_sort_desc_multi(unsigned long long* keys) {
+  constexpr int npad = KPT * kSortThreads;
+  const int t = threadIdx.x;
+  unsigned long long key[KPT];
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) key[j] = keys[t * KPT + j];
+  for (int size = 2; size <= npad; size <<= 1) {
+    for (int stride = size >> 1; stride >= KPT; stride >>= 1) {
+      unsigned long long other[KPT];
+      if (stride >= 64 * KPT) {
+        __syncthreads();                       // every thread is done reading the previous exchange
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) keys[t * KPT + j] = key[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) other[j] = keys[(t * KPT + j) ^ stride];
+      } else {
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) other[j] = __shfl_xor(key[j], stride / KPT, 64);
+      }
+#pragma unroll
+      for (int j = 0; j < KPT; ++j) {
+        const int e = t * KPT + j;
+        const bool take_max = ((e & stride) == 0) == ((e & size) == 0);
+        const unsigned long long mx = key[j] > other[j] ? key[j] : other[j], mn = key[j] > other[j] ? other[j] : key[j];
+        key[j] = take_max ? mx : mn;
+      }
+    }
+#pragma unroll
+    for (int s = KPT / 2; s > 0; s >>= 1) {
+      if (s < size) {
+#pragma unroll
+        for (int j = 0; j < KPT; ++j) {
+          if ((j & s) == 0) {
+            const bool desc = (((t * KPT + j) & size) == 0);
+            const unsigned long long a = key[j], b = key[j | s];
+            const bool sw = (a < b) == desc;
+            key[j] = sw ? b : a;
+            key[j | s] = sw ? a : b;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < KPT; ++j) keys[t * KPT + j] = key[j];
+  __syncthreads();
+}
+
 // ---- block rank (64 <= npad <= 512 keys in LDS, zero-padded, distinct) ------------------------------------------
 // A key's descending rank is the number of larger keys.  The 1024 threads split into 1024/npad parts; thread (c, part)
 // counts the keys of its slice that exceed key c (broadcast 16-byte LDS reads, no conflicts) and adds the count to
@@ -125,12 +182,16 @@ __global__ __launch_bounds__(kSortThreads) void sort_emit_kernel(const float* __
                                                                 const int64_t* __restrict__ ids, int64_t ids_row_stride,
                                                                 float* __restrict__ out_scores,
                                                                 int64_t* __restrict__ out_ids,
-                                                                unsigned long long* __restrict__ keys_out, int64_t keys_ld, const int32_t* __restrict__ run_if) {
+                                                                unsigned long long* __restrict__ keys_out, int64_t keys_ld, const int32_t* __restrict__ run_if,
+                                                                const SelectState* __restrict__ count_from = nullptr) {
   MOL_RUN_IF(run_if);
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
   const int row = blockIdx.x;
   const int64_t begin = (int64_t)blockIdx.y * chunk;
-  const int count = cand ? cand_count : (int)((begin + chunk < n ? begin + chunk : n) - begin);
+  // count_from: the radix path's compaction may have kept MORE than k keys (a threshold settled early at a bin edge): the row's
+  // cursor says how many, at most cand_count = npad
+  const int count = cand ? (count_from ? (int)(count_from[row].count < (unsigned int)cand_count ? count_from[row].count : (unsigned int)cand_count) : cand_count)
+                         : (int)((begin + chunk < n ? begin + chunk : n) - begin);
   const int k = k_out;
   for (int i = threadIdx.x; i < npad; i += kSortThreads) {
     unsigned long long kv = 0ull;  // below every real key (orderable() never returns 0 for a finite/inf score)
@@ -154,7 +215,11 @@ __global__ __launch_bounds__(kSortThreads) void sort_emit_kernel(const float* __
     __syncthreads();
     if ((int)threadIdx.x < npad) keys[threadIdx.x] = kv;
     __syncthreads();
-  } else
+  } else if (npad == 2 * kSortThreads) block_sort_desc_multi<2>(keys);
+  else if (npad == 4 * kSortThreads) block_sort_desc_multi<4>(keys);
+  else if (npad == 8 * kSortThreads) block_sort_desc_multi<8>(keys);
+  else if (npad == 16 * kSortThreads) block_sort_desc_multi<16>(keys);
+  else
   for (int size = 2; size <= npad; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       for (int t = threadIdx.x; t < (npad >> 1); t += kSortThreads) {
@@ -206,7 +271,7 @@ __device__ __forceinline__ void for_each_in_chunk(const float* __restrict__ rowp
 // Lane l owns the nb/64 bins [top - l*per - per + 1, top - l*per]; a wave prefix sum finds the owning lane, which then
 // walks its own bins.
 __global__ __launch_bounds__(64) void pick_bin_kernel(SelectState* __restrict__ st, const unsigned int* __restrict__ hist,
-                                                      int pass, int rows, int k, const int32_t* __restrict__ run_if) {
+                                                      int pass, int rows, int k, const int32_t* __restrict__ run_if, int cap) {
   MOL_RUN_IF(run_if);
   const int row = blockIdx.x;
   if (st[row].done) return;
@@ -235,7 +300,10 @@ __global__ __launch_bounds__(64) void pick_bin_kernel(SelectState* __restrict__ 
     st[row].need = still;
     // all keys of this bin are wanted -> the threshold is the bin's lower edge; nothing left to resolve.
     // Otherwise the next pass narrows it, and after the last pass tie_resolve_kernel finishes it.
-    if (c == still) st[row].done = 1u;
+    // Also final when everything at or above this bin's lower edge fits the sort's `cap` slots: the compaction keeps those
+    // (k - still) + c >= k keys and the sort cuts them to k -- the remaining passes and the tie scan exit at once.  (With
+    // 22 bits resolved after the second pass a bin of amzn-books-sized logit rows holds a handful of keys.)
+    if (c == still || (unsigned int)k - still + c <= (unsigned int)cap) st[row].done = 1u;
   }
 }
 
@@ -342,7 +410,7 @@ __global__ __launch_bounds__(kHistThreads) void compact_kernel(const float* __re
       base = (unsigned int)__shfl((int)base, leader, 64);
       if (sel) {
         const unsigned int slot = wbase + base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
-        if (slot < (unsigned int)k) cand[row * cand_ld + slot] = key;
+        if (slot < (unsigned int)cand_ld) cand[row * cand_ld + slot] = key;
       }
     }
   });
@@ -755,7 +823,7 @@ size_t topk_workspace_bytes(int rows, int64_t n, int k) {
   // sized for the radix path; the two-level path's rows * chunks * k keys (<= rows * 16384) are checked against it too
   size_t b = align_up(sizeof(SelectState) * (size_t)rows, 256);
   b += align_up(sizeof(unsigned int) * (size_t)kRadixPasses * rows * kBins, 256);
-  b += align_up(sizeof(unsigned long long) * (size_t)rows * k, 256);
+  b += align_up(sizeof(unsigned long long) * (size_t)rows * next_pow2(k < 2 ? 2 : k), 256);   // npad candidate slots per row
   const size_t two_level = sizeof(unsigned long long) * (size_t)rows * 24 * 1024;
   return b > two_level ? b : two_level;
 }
@@ -833,18 +901,18 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
   if (chunks > max_chunks) chunks = max_chunks;
   if (chunks < 1) chunks = 1;
   const int64_t chunk = (n + chunks - 1) / chunks;
+  const int npad = next_pow2(k < 2 ? 2 : k);
   for (int pass = 0; pass < kRadixPasses; ++pass) {
     hipLaunchKernelGGL(hist_kernel, dim3((unsigned)chunks, rows), dim3(kHistThreads), 0, stream, scores, ld, n, st, hist, pass,
                        chunk, pred);
-    hipLaunchKernelGGL(pick_bin_kernel, dim3(rows), dim3(64), 0, stream, st, hist, pass, rows, k, pred);
+    hipLaunchKernelGGL(pick_bin_kernel, dim3(rows), dim3(64), 0, stream, st, hist, pass, rows, k, pred, npad);
   }
   hipLaunchKernelGGL(tie_resolve_kernel, dim3(rows), dim3(kTieThreads), 0, stream, scores, ld, n, st, pred);
   hipLaunchKernelGGL(compact_kernel, dim3((unsigned)chunks, rows), dim3(kHistThreads), 0, stream, scores, ld, n, st, cand,
-                     (int64_t)k, k, chunk, pred);
-  const int npad = next_pow2(k < 2 ? 2 : k);
+                     (int64_t)npad, k, chunk, pred);
   hipLaunchKernelGGL(sort_emit_kernel, dim3(rows), dim3(kSortThreads), (npad <= kSortThreads ? 3 * npad : npad) * sizeof(unsigned long long), stream, scores, ld, n, n,
-                     cand, (int64_t)k, k, k, npad, ids, ids_row_stride, out_scores, out_ids, (unsigned long long*)nullptr,
-                     (int64_t)0, pred);
+                     cand, (int64_t)npad, npad, k, npad, ids, ids_row_stride, out_scores, out_ids, (unsigned long long*)nullptr,
+                     (int64_t)0, pred, (const SelectState*)st);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
