@@ -177,6 +177,31 @@ def test_topk_with_heavy_ties_is_position_ordered(dev, n):
         assert torch.equal(s.cpu(), rs) and torch.equal(i.cpu(), ri)
 
 
+@pytest.mark.parametrize("k", [513, 2561, 4096, 6000])
+def test_radix_topk_settles_early_or_late(dev, k):
+    """The radix path (k' > 512 on long rows) stops resolving the threshold as soon as everything at or above the current bin's lower edge
+    fits the sort's next_pow2(k') slots, and hands the sort MORE than k' keys.  Rows built to hit every branch: spread values (settles
+    after the first or second pass), the narrow spread of MoL logits, a k'-th score shared by thousands of items (never fits: all passes +
+    the tie scan), a tie group that just fits / just does not fit the slots, and -inf padding."""
+    n, npad = 200_000, 1 << (k - 1).bit_length()
+    g = torch.Generator().manual_seed(k)
+    rows = [torch.randn(n, generator=g) * 2.0,
+            0.1 + 0.02 * torch.randn(n, generator=g),
+            torch.round(torch.randn(n, generator=g) * 2) / 2,
+            torch.randn(n, generator=g)]
+    for extra in (npad - k, npad - k + 1):           # k-th place inside a tie group of `extra + 2` items, k - 1 items above it
+        r = torch.rand(n, generator=g) * 0.5
+        perm = torch.randperm(n, generator=g)
+        r[perm[: k - 1]] = 2.0 + torch.rand(k - 1, generator=g)
+        r[perm[k - 1 : k + 1 + extra]] = 1.0
+        rows.append(r)
+    rows[3][::7] = float("-inf")
+    scores = torch.stack(rows)
+    s, i = E.topk(scores.to(dev), k)
+    rs, ri = O.select_topk_deterministic(scores, k)
+    assert torch.equal(s.cpu(), rs) and torch.equal(i.cpu(), ri)
+
+
 def test_topk_rows_not_16_byte_aligned(dev):
     g = torch.Generator().manual_seed(9)
     big = torch.randn((3, 90001), generator=g).to(dev)       # odd leading dimension: rows 1, 2 start off 16-byte alignment
