@@ -323,6 +323,8 @@ __global__ __launch_bounds__(kHistThreads) void hist_kernel(const float* __restr
   const int64_t end = (begin + chunk < n) ? begin + chunk : n;
   const float* rowp = scores + (int64_t)row * ld;
   const unsigned int mask = (1u << bits) - 1u;
+  // (Measured and not kept: peeling the wave's most common bins into one LDS atomic each in the first pass, where logit rows
+  // share a handful of bins: 32 -> 44 us.)
   for_each_in_chunk(rowp, begin, end, kHistThreads, [&](float sc, int64_t i) {
     const unsigned long long key = make_key(sc, (unsigned int)i);
     if ((above >= 64) || ((key >> above) == (prefix >> above))) atomicAdd(&h[(unsigned int)(key >> shift) & mask], 1u);
@@ -381,24 +383,42 @@ __global__ __launch_bounds__(kHistThreads) void compact_kernel(const float* __re
   const int64_t begin = (int64_t)blockIdx.x * chunk;
   const int64_t end = (begin + chunk < n) ? begin + chunk : n;
   const float* rowp = scores + (int64_t)row * ld;
-  // One GLOBAL atomic per workgroup: the chunk is walked twice (the second walk hits L2).  Walk 1 counts the workgroup's
-  // selected keys and reserves their range of the row's list with a single atomicAdd on the row cursor; walk 2 places them
-  // with one LDS atomic per wave.  (One global atomic per WAVE that held a selected key was 222 us at k = 2561, n = 695 762,
-  // 32 rows: ~2 500 dependent same-address atomics per row, each a round trip to L2; this is 2 x 64 per row.)
-  __shared__ unsigned int wg_total, wg_base, wg_cursor;
-  if (threadIdx.x == 0) { wg_total = 0u; wg_cursor = 0u; }
+  // One GLOBAL atomic per workgroup.  The selected keys of the chunk are staged in LDS (one LDS atomic per wave that holds one),
+  // their range of the row's list is reserved with a single atomicAdd on the row cursor, and the staged keys are copied out.
+  // A chunk with more selected keys than the stage holds (all of a row's winners in one chunk) is walked a second time and
+  // placed directly (the second walk hits L2).  (One global atomic per WAVE that held a selected key was 222 us at k = 2561,
+  // n = 695 762, 32 rows: ~2 500 dependent same-address atomics per row, each a round trip to L2; this is 64 per row.)
+  constexpr int kStage = 2048;
+  __shared__ unsigned long long stage[kStage];
+  __shared__ unsigned int wg_base, wg_cursor;
+  if (threadIdx.x == 0) wg_cursor = 0u;
   __syncthreads();
-  unsigned int mine = 0;
-  for_each_in_chunk(rowp, begin, end, kHistThreads, [&](float sc, int64_t i) { mine += make_key(sc, (unsigned int)i) >= thr ? 1u : 0u; });
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
-  if (lane == 0 && mine) atomicAdd(&wg_total, mine);
+  for_each_in_chunk(rowp, begin, end, kHistThreads, [&](float sc, int64_t i) {
+    const unsigned long long key = make_key(sc, (unsigned int)i);
+    const bool sel = key >= thr;
+    const unsigned long long m = __ballot(sel);
+    if (m) {
+      const int leader = __ffsll((long long)m) - 1;
+      unsigned int base = 0;
+      if (lane == leader) base = atomicAdd(&wg_cursor, (unsigned int)__popcll(m));
+      base = (unsigned int)__shfl((int)base, leader, 64);
+      if (sel) {
+        const unsigned int slot = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+        if (slot < (unsigned int)kStage) stage[slot] = key;
+      }
+    }
+  });
   __syncthreads();
-  const unsigned int total = wg_total;
+  const unsigned int total = wg_cursor;
   if (total == 0u) return;
-  if (threadIdx.x == 0) wg_base = atomicAdd(&st[row].count, total);
+  if (threadIdx.x == 0) { wg_base = atomicAdd(&st[row].count, total); wg_cursor = 0u; }
   __syncthreads();
   const unsigned int wbase = wg_base;
+  if (total <= (unsigned int)kStage) {
+    for (unsigned int j = threadIdx.x; j < total; j += kHistThreads)
+      if (wbase + j < (unsigned int)cand_ld) cand[row * cand_ld + wbase + j] = stage[j];
+    return;
+  }
   for_each_in_chunk(rowp, begin, end, kHistThreads, [&](float sc, int64_t i) {
     const unsigned long long key = make_key(sc, (unsigned int)i);
     const bool sel = key >= thr;
