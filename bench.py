@@ -252,6 +252,85 @@ def quick_workload(name: str, B: int, k: int, kp: int, steps: int, dev, items: i
             "mfma_frac_lower_bound": tf / (PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_F16X3_TFLOPS), **tr}
 
 
+def full_shard_legs(B: int, k: int, dev) -> list:
+    """BASELINE.json configs 4 and 5 at the size of ONE 8-way shard on this GPU (12.5 M items of 16x16x64, exact top-k in three precisions;
+    125 M items of 8x8x32, two-pass MoLAvgTopK with K' = 1000): what each of the 8 ranks of `--gpus 8 --workload synthetic-*` runs before the
+    all-gather, timed through the module API.  Device-generated item tables (truncated normal, sigma 0.02).  A leg is skipped, and says so,
+    when the device lacks the memory for it (config 5 needs ~210 GB: 32 GB table + 160 GB index + 8 GB coarse table + buffers)."""
+    import gc
+    from oracle import mol_oracle as O
+
+    def build(cfg_key, n, precision):
+        cfg = O.CONFIGS[cfg_key]
+        mol, _ = rails_amd.create_mol_interaction_module(
+            cfg.query_embedding_dim, cfg.item_embedding_dim, cfg.dot_product_dimension, cfg.query_dot_product_groups,
+            cfg.item_dot_product_groups, cfg.temperature, 0.0, cfg.query_hidden_dim, 0.1, cfg.item_hidden_dim,
+            cfg.gating_query_hidden_dim, cfg.gating_qi_hidden_dim, cfg.gating_item_hidden_dim, cfg.softmax_dropout_rate, False,
+            query_nonlinearity=cfg.query_nonlinearity, uid_embedding_hash_sizes=list(cfg.uid_embedding_hash_sizes) or None)
+        mol.load_state_dict(O.synthetic_weights(cfg, seed=0), strict=True)
+        mol = mol.to(dev).eval()
+        mol.precision = None if precision == "fp32" else precision
+        X = torch.empty((1, n, cfg.item_embedding_dim), dtype=torch.float32, device=dev)
+        g = torch.Generator(device=dev).manual_seed(1000)
+        for s0 in range(0, n, 8_000_000):
+            n0 = min(8_000_000, n - s0)
+            X[0, s0 : s0 + n0] = torch.fmod(torch.randn((n0, cfg.item_embedding_dim), generator=g, device=dev), 2.0) * 0.02
+        ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+        return cfg, mol, X, ids, O.synthetic_queries(cfg, B).to(dev)
+
+    def timed(fn, warm, steps):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    legs = []
+    for name, n, need_gb, variants in (("synthetic-16x16x64", 12_500_000, 150, ("fp32", "f16x3", "f16-exact")), ("synthetic-8x8x32", 125_000_000, 235, ("two-pass",))):
+        for variant in variants:
+            gc.collect()
+            torch.cuda.empty_cache()
+            free = torch.cuda.mem_get_info(dev)[0]
+            label = {"workload": f"{name}, one 8-way shard, N={n}", "batch": B, "k": k}
+            if free < need_gb * 1e9:
+                legs.append({**label, "variant": variant, "skipped": f"needs {need_gb} GB of free device memory, {free / 1e9:.0f} GB available"})
+                continue
+            with torch.inference_mode():
+                cfg, mol, X, ids, q = build(name, n, "fp32" if variant == "two-pass" else variant)
+                cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)
+                t0 = time.perf_counter()
+                if variant == "two-pass":
+                    mod = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=1000)
+                    mod._table()
+                else:
+                    mod = rails_amd.MoLBruteForceTopK(mol, X, ids)
+                    mod._bind()
+                torch.cuda.synchronize()
+                build_s = time.perf_counter() - t0
+                dt = timed(lambda: cand.get_top_k_outputs(q, k, {}, mod, None), 2, 10 if variant == "two-pass" else 3)
+                leg = {**label, "variant": variant if variant != "two-pass" else "two-pass MoLAvgTopK, K'=1000 (coarse bf16 scan + MoL rerank)", "queries_per_s": B / dt,
+                       "ms_per_step": dt * 1e3, "index_build_s": build_s, "item_table": "device truncated normal"}
+                if variant == "two-pass":
+                    leg["coarse_table_bytes"] = int(mod._table().numel() * mod._table().element_size())
+                    # the whole step (prologue, sample + select scan, key selection, gather, rerank, final top-k) against ONE read of the table
+                    leg["hbm_frac_lower_bound"] = leg["coarse_table_bytes"] / dt / 8.0e12
+                elif variant == "fp32" or variant == "f16x3":
+                    tf = B * n * flops_per_pair(cfg) / dt / 1e12       # lower bound: the step also holds the prologue and the selection
+                    leg["tflops_algorithmic_lower_bound"] = tf
+                    leg["mfma_frac_lower_bound"] = tf / (PEAK_F32_MFMA_TFLOPS if variant == "fp32" else PEAK_F16X3_TFLOPS)
+                else:
+                    st = mod.stats()
+                    leg["rescore_calls"], leg["dense_fp32_fallbacks"] = st["calls"], st["fallbacks"]
+                legs.append(leg)
+                del mod, cand, X, ids, mol
+    gc.collect()
+    torch.cuda.empty_cache()
+    return legs
+
+
 def main() -> None:
     # The cyclic garbage collector stays off while anything is timed: a generation-2 collection of this process (torch modules, numpy
     # fixtures, thousands of event objects) is a 30-40 ms host pause, and a step is 2-6 ms -- one collection inside a 20-step region
@@ -273,6 +352,7 @@ def main() -> None:
     ap.add_argument("--no-fast-path", action="store_true", help="skip the extra f16x3 measurement")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the secondary ML-20M / ML-1M measurements")
     ap.add_argument("--no-matrix", action="store_true", help="skip the B = 1 / 8 and accuracy-protocol points")
+    ap.add_argument("--no-full-shards", action="store_true", help="skip the legs that run one full 8-way shard of BASELINE configs 4 and 5 (12.5 M / 125 M items) on this GPU")
     ap.add_argument("--items", type=int, default=0, help="override the workload's corpus size N (total over all ranks)")
     ap.add_argument("--device-table", action="store_true",
                     help="draw the item table on the GPU (truncated normal, sigma 0.02) instead of the host counter hash; "
@@ -792,6 +872,12 @@ def main() -> None:
             out["other_workloads"] = [quick_workload(n, B, k, kp, 10, dev, precision=pr) for n in ("ml-20m", "ml-1m") for pr in ("fp32", "f16x3", "f16-exact")]
             # BASELINE config 4 (16x16x64, 100 M items 8-way): a 400 k-item sub-range of one shard -- the kernels are linear in N
             out["other_workloads"] += [quick_workload("synthetic-16x16x64", B, k, kp, 5, dev, items=400_000, precision=pr) for pr in ("fp32", "f16x3", "f16-exact")]
+        if world == 1 and args.workload == "amzn-books" and not args.no_other_workloads and not args.no_full_shards:
+            try:
+                out["full_shards"] = full_shard_legs(B, k, dev)
+            except Exception as e:   # noqa: BLE001 -- a secondary leg must not take the headline line down with it (e.g. a smaller device)
+                out["full_shards"] = [{"skipped": f"{type(e).__name__}: {e}"[:300]}]
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline and not two_pass:   # the CPU baseline is the exact path
             out["cpu_baseline"] = cpu_baseline(cfg, weights, q_cpu, uid_cpu, N, min(args.cpu_sample_items or N, N), kp)
         print(json.dumps(out), flush=True)
