@@ -263,9 +263,12 @@ class MoLBruteForceTopK(MoLTopKModule):
         # watched outside the candidates as well
         pos = torch.cat([pos, *self._probes(B, N)], dim=1)
         if self._index32 is not None and B * pos.shape[1] <= self.INDEXED_MAX_CANDIDATES and ex.score_indexed_supported(B, pos.shape[1]):
-            # few candidates (B = 1, 2): read them in place from the fp32 index -- one launch less (B = 1 step 0.272 -> 0.255 ms).  Beyond
-            # that the scattered 16-byte reads inside the scoring kernel cost more than the gather kernel's streaming copy saves
-            # (B = 32: 1.65 -> 1.69 ms), so larger batches gather.
+            # read the candidates in place from the fp32 index: one launch less and no gathered copy.  A candidate's 1 280 bytes are 80
+            # pieces of 16 bytes in the tile-packed index, each in its own cache line, whoever fetches them -- the gather kernel paid
+            # that amplification AND wrote and re-read the copy.  Measured with the GEMM1 lookahead of the independent-wave kernels in
+            # (tools/indexed_rescore_probe.py, amzn-books, `f16-exact`): k' = 200  B = 8 / 32 / 128: 0.501 / 1.59 / 5.81 -> 0.494 /
+            # 1.59 / 5.76 ms; k' = 2561: 0.631 / 1.93 / 6.88 -> 0.610 / 1.835 / 6.55 ms.  (Before the lookahead the in-place reads cost
+            # more than the copy beyond B x Kc = 1024 candidates: B = 32 1.65 -> 1.69 ms; INDEXED_MAX_CANDIDATES keeps the switch.)
             e32 = ex.score_indexed(qpack32, B, self._index32, pos)
         else:
             if self._index32 is not None:
@@ -307,7 +310,7 @@ class MoLBruteForceTopK(MoLTopKModule):
             self._audit(query_embeddings, k, scores, ids, **kwargs)
         return scores.to(query_embeddings.dtype), ids
 
-    INDEXED_MAX_CANDIDATES = 1024   # rails_mol_score_indexed instead of gather + score_candidates up to this many (B x Kc) candidates
+    INDEXED_MAX_CANDIDATES = 1 << 30   # rails_mol_score_indexed instead of gather + score_candidates up to this many (B x Kc) candidates (was 1024)
     DEVICE_VERDICT = True     # False: the host reads the verdict (one event spin per call) -- kept for deployments without a resident fp32 index
 
     def _note_verdict(self, good: bool, k: int, kc: int) -> None:
