@@ -88,6 +88,21 @@ class MoLTopKModule(TopKModule):
         return eng.score_dense(qpack, B, self._index, out=logits)
 
 
+    def _score_at(self, eng, qpack: torch.Tensor, batch: int, positions: torch.Tensor) -> torch.Tensor:
+        """(B, K) full-MoL logits of per-row candidates given as VALID positions of this module's index.  fp32 engines read the
+        candidates in place (rails_mol_score_indexed: no gathered copy, one launch; the same bits as gather + score_candidates);
+        the f16 builds, which have no indexed instantiation, gather a per-row index of the candidates first."""
+        K = positions.shape[1]
+        Kp = (K + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS
+        if eng.score_indexed_supported(batch, Kp):
+            pos = positions.to(torch.int64)
+            if Kp != K:
+                pos = torch.nn.functional.pad(pos, (0, Kp - K), value=0)    # position 0 always exists; its columns are cut off below
+            return eng.score_indexed(qpack, batch, self._index, pos)[:, :K]
+        cand, kp = eng.gather_index(self._index, positions)
+        return eng.score_candidates(qpack, batch, cand, kp)[:, :K]
+
+
 class MoLBruteForceTopK(MoLTopKModule):
     def __init__(self, mol_module: MoLSimilarity, item_embeddings: torch.Tensor, item_ids: torch.Tensor) -> None:
         self._index32: Optional[E.MolIndex] = None          # precision "f16x3-exact": dense fp32 index (candidate gather, fallback)
@@ -599,8 +614,7 @@ class MoLAvgTopK(MoLTopKModule):
     def rerank(self, qpack: torch.Tensor, batch: int, cand_idx: torch.Tensor, k: int):
         """Full MoL on per-row candidates (positions, (B, K')) -> exact top-min(k, K') among them."""
         eng = self._bind()
-        cand, kp = eng.gather_index(self._index, cand_idx)
-        scores = eng.score_candidates(qpack, batch, cand, kp)[:, : cand_idx.shape[1]]
+        scores = self._score_at(eng, qpack, batch, cand_idx)
         return E.topk(scores, min(k, cand_idx.shape[1]), ids=self._ids_flat[cand_idx])
 
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -613,9 +627,9 @@ class MoLAvgTopK(MoLTopKModule):
                 qpack, idx = self._coarse_topk(query_embeddings, average_queries=False, pending=pending, **kwargs)
             eng = self._bind()
             with torch.profiler.record_function("avg_topk_selection"):
-                cand, kp = eng.gather_index(self._index, idx)
+                pass    # the reference gathers the candidates' embeddings here; they are read in place by the scoring launch below
             with torch.profiler.record_function("filtered_scoring"):
-                cand_scores = eng.score_candidates(qpack, query_embeddings.size(0), cand, kp)[:, : idx.shape[1]]
+                cand_scores = self._score_at(eng, qpack, query_embeddings.size(0), idx)
             with torch.profiler.record_function("final_topk"):
                 scores, ids = E.topk(cand_scores, min(k, idx.shape[1]), ids=self._ids_flat[idx])
             # everything is enqueued; only now look at the fused scan's candidate counts (rarely out of range: heavy ties)
@@ -713,8 +727,7 @@ class _ComponentCandidates:
         big = all_indices.shape[1] > self.UNION_CAP
         sorted_idx = torch.sort(all_indices.to(torch.int64), dim=1).values if big else E.sort_rows(all_indices)
         k = sorted_idx.shape[1]
-        cand, kp = eng.gather_index(self._index, sorted_idx)
-        scores = eng.score_candidates(qpack, batch, cand, kp)[:, :k]
+        scores = self._score_at(eng, qpack, batch, sorted_idx)
         E.mask_sorted_duplicates(sorted_idx, scores, -32767.0)
         if big:   # full ranking of more than 16 384 candidates: stable descending sort = (score desc, column asc), rails_topk's tie rule
             vals, order = torch.sort(scores, dim=1, descending=True, stable=True)
