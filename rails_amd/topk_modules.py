@@ -650,9 +650,8 @@ class MoLAvgTopK(MoLTopKModule):
         with id -1.  -> exact top-min(k, K') (scores, ids)."""
         eng = self._bind()
         qpack, _, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"))
-        cand, kp = eng.gather_index(self._index, cand_idx)
-        scores = eng.score_candidates(qpack, query_embeddings.size(0), cand, kp)[:, : cand_idx.shape[1]]
         hole = cand_idx < 0
+        scores = self._score_at(eng, qpack, query_embeddings.size(0), cand_idx.clamp_min(0))   # holes read item 0 and are overwritten below
         scores = torch.where(hole, scores.new_full((), float("-inf")), scores)
         ids = torch.where(hole, cand_idx.new_full((), -1), self._ids_flat[cand_idx.clamp_min(0)])
         return E.topk(scores, min(k, cand_idx.shape[1]), ids=ids)
