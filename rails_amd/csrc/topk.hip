@@ -915,8 +915,9 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
   unsigned long long* cand = reinterpret_cast<unsigned long long*>(base);
 
   if (hipMemsetAsync(ws, 0, state_bytes, stream) != hipSuccess) return kErrLaunch;   // state + histograms
-  // enough workgroups to fill the chip, at least 8K elements each
-  int64_t chunks = (2048 + rows - 1) / rows;
+  // enough workgroups to fill the chip (four per CU), at least 8K elements each
+  static const int radix_wgs = [] { const char* e = getenv("RAILS_RADIX_WGS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 16384 ? v : 1024; }();   // workgroups per launch (override for measurements): 512 / 1024 / 2048 / 4096 -> 135 / 131 / 140 / 147 us at k' = 2561, 32 x 695 762 (fewer per-workgroup histogram merges)
+  int64_t chunks = (radix_wgs + rows - 1) / rows;
   const int64_t max_chunks = (n + 8191) / 8192;
   if (chunks > max_chunks) chunks = max_chunks;
   if (chunks < 1) chunks = 1;
