@@ -40,6 +40,20 @@ def test_committed_bench_line_has_the_contract_fields():
     assert {("fp32", 1, 200), ("fp32", 8, 200), ("fp32", 32, 2561), ("f16x3", 1, 200), ("f16x3", 8, 200), ("f16x3", 32, 2561)} <= pts
 
 
+def test_committed_round3_bench_line_carries_the_full_shard_legs():
+    """profiles/r03_bench.json (the default `python bench.py` run at the end of round 3): the contract fields, and BASELINE configs 4 and 5
+    timed at the size of one 8-way shard (12.5 M / 125 M items) next to the headline."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    check_line(d, expect_cpu_baseline=True)
+    assert d["roofline"]["bound"] == "mfma" and abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
+    legs = d["full_shards"]
+    assert [l["variant"][:8] for l in legs] == ["fp32", "f16x3", "f16-exac", "two-pass"] and not any("skipped" in l for l in legs)
+    assert all("N=12500000" in l["workload"] for l in legs[:3]) and "N=125000000" in legs[3]["workload"]
+    for l in legs:
+        assert l["queries_per_s"] > 0 and abs(l["queries_per_s"] - l["batch"] / (l["ms_per_step"] * 1e-3)) < 1e-6 * l["queries_per_s"]
+    assert legs[2]["dense_fp32_fallbacks"] == 0 and 0 < legs[3]["hbm_frac_lower_bound"] < 1 and 0 < legs[0]["mfma_frac_lower_bound"] < 1
+
+
 @pytest.mark.gpu
 def test_live_bench_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-fast-path", "--no-matrix",
