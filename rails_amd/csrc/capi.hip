@@ -109,8 +109,8 @@ int rails_mol_shape_supported(const rails_mol_shape* shape) { return shape_suppo
 
 size_t rails_mol_gate_pack_floats(const rails_mol_shape* s) {
   if (!shape_ok(s)) return 0;
-  const size_t H = s->gating_qi_hidden_dim > 0 ? (size_t)s->gating_qi_hidden_dim : 0, L = (size_t)num_logits(*s);
-  return H > 0 ? 2 * H * L + H + L : L * L + L;   // no hidden layer: one (L, L) matrix + bias
+  // the small-unit kernel's shapes carry the pair-gate weights twice: 32x32x2 fragment order, then 16x16x4 fragment order
+  return gate_pack32_floats(*s) * (score_small_shape(*s) ? 2 : 1);
 }
 
 int rails_mol_pack_gate_weights(const rails_mol_shape* s, const rails_mol_weights* w, float* gate_pack, void* stream) {

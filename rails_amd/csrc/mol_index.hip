@@ -62,11 +62,49 @@ __global__ void pack_gate_kernel(const float* __restrict__ w1, const float* __re
   }
 }
 
+// The same weights in the fragment order of the small-unit kernel (mol_score_small.h, layout in mol_layout.h; P_Q = 8):
+//   W1s[mc][t][lane][c]   = -log2e W1[hidden16(4t + i, go)][logit16(4mc + c, g)]     lane = 16g + 4go + i: A operand (row 4go + i, k = g)
+//   W2s[t][v][lane][c]    =        W2[logit16(4v + i, go)][hidden16(4t + c, g)]      of K-steps 4mc + c / 4t + c
+//   b1s[t][g][i]          = -log2e b1[hidden16(4t + i, g)]                           accumulator start of D2 tile t, register i
+//   b2s[v][g][i]          = -log2e b2[logit16(4v + i, g)]
+__global__ void pack_gate16_kernel(const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                   const float* __restrict__ b2, float* __restrict__ out, int PX, int H) {
+  const int L = 8 * PX, TH = H / 16, TL = L / 16;
+  const int total = 2 * H * L + H + L;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    float v;
+    if (idx < 2 * H * L) {
+      const bool second = idx >= H * L;
+      const int k = second ? idx - H * L : idx;
+      const int c = k & 3, lane = (k >> 2) & 63, blk = k >> 8;
+      const int g = lane >> 4, go = (lane >> 2) & 3, i = lane & 3;
+      if (!second) {
+        const int t = blk % TH, mc = blk / TH;
+        v = -kLog2e * w1[hidden16(4 * t + i, go) * L + logit16(4 * mc + c, g, PX)];
+      } else {
+        const int tv = blk % TL, t = blk / TL;
+        v = w2[logit16(4 * tv + i, go, PX) * H + hidden16(4 * t + c, g)];
+      }
+    } else if (idx < 2 * H * L + H) {
+      const int k = idx - 2 * H * L;
+      v = -kLog2e * b1[hidden16(4 * (k >> 4) + (k & 3), (k >> 2) & 3)];
+    } else {
+      const int k = idx - 2 * H * L - H;
+      v = -kLog2e * b2[logit16(4 * (k >> 4) + (k & 3), (k >> 2) & 3, PX)];
+    }
+    out[idx] = v;
+  }
+}
+
 int pack_gate_weights(const Shape& s, const Weights& w, float* wpack, hipStream_t stream) {
   const int H = s.gating_qi_hidden_dim > 0 ? s.gating_qi_hidden_dim : 0, L = num_logits(s);
   const int total = H > 0 ? 2 * H * L + H + L : L * L + L;
   hipLaunchKernelGGL(pack_gate_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w.gqi_w1, w.gqi_b1,
                      w.gqi_w2, w.gqi_b2, wpack, s.query_dot_product_groups, s.item_dot_product_groups, H);
+  if (hipGetLastError() != hipSuccess) return kErrLaunch;
+  if (score_small_shape(s))
+    hipLaunchKernelGGL(pack_gate16_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w.gqi_w1, w.gqi_b1, w.gqi_w2, w.gqi_b2,
+                       wpack + total, s.item_dot_product_groups, H);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

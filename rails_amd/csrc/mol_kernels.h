@@ -77,6 +77,18 @@ inline int ensure_dyn_lds(DynLdsOnce& once, const void* fn, int bytes) {
   return kOk;
 }
 
+// Shapes of the small-unit kernel (mol_score_small.h: v_mfma_f32_16x16x4_f32, 2 queries x 16 items per wave, exact fp32): the three
+// real-dataset shapes.  For them the gate pack carries a second copy of the pair-gate weights in that kernel's fragment order.
+inline bool score_small_shape(const Shape& s) {
+  if (s.precision != RAILS_PRECISION_FP32 || s.query_dot_product_groups != 8 || s.gating_qi_hidden_dim != 128) return false;
+  const int px = s.item_dot_product_groups, dd = s.dot_product_dimension;
+  return (px == 4 && dd == 64) || (px == 4 && dd == 128) || (px == 8 && dd == 32);
+}
+inline size_t gate_pack32_floats(const Shape& s) {
+  const size_t H = s.gating_qi_hidden_dim > 0 ? (size_t)s.gating_qi_hidden_dim : 0, L = (size_t)num_logits(s);
+  return H > 0 ? 2 * H * L + H + L : L * L + L;   // no hidden layer: one (L, L) matrix + bias
+}
+int score_launch_small(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream);
 int score_launch(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream);
 int score_launch_f16(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream);
 int score_launch_f16x1(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream);

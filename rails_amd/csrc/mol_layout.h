@@ -92,4 +92,20 @@ MOL_HD int kdim_of(int s, int hi, int DD) { return hi * (DD / 2) + s; }
 MOL_HD int reg_of_row(int i) { return (i & 3) + 4 * (i >> 3); }
 MOL_HD int half_of_row(int i) { return (i >> 2) & 1; }
 
+// ---- small-unit layout: v_mfma_f32_16x16x4_f32, unit = 2 queries x 16 items (mol_score_small.h; P_Q = 8 only) -----------------
+// Accumulator register i (0..3) of lane group g = lane >> 4 holds row 4g + i of item column lane & 15; as the B operand of the
+// next GEMM, register i is one K = 4 step with k = g.  fp32 MFMA is an fmaf chain in k order, and the small kernel must return the
+// SAME BITS as the 32x32x2 kernels above (a shard of a corpus may take either shell), so every contraction visits its terms in the
+// order the 32x32x2 layout does: K-step s of lane halves (0, 1) there  ==  lane groups (0, 1) and (2, 3) of half a K-step here.
+// With P_Q = 8 the 32-layout visits the query groups of one item group m as p = 0, 4, 1, 5, 2, 6, 3, 7 and the hidden units of a
+// block of 8 in the same pattern; so group g of K-step parity b holds
+//     p16(b, g) = 2b + (g >> 1) + 4 (g & 1)
+// and every packed 32-layout float4 (four K-steps of ONE lane half) carries, for lane group g, exactly its components
+// (g >> 1) and (g >> 1) + 2 of the half (g & 1): the small kernel reads the item index and the query pack as they are.
+MOL_HD int p16(int b, int g) { return 2 * b + (g >> 1) + 4 * (g & 1); }
+// logit held by register pair index e16 = 2m + b (D1[m] register 2q + b of query q; D3 tile e16 / 4, register e16 % 4) of lane group g
+MOL_HD int logit16(int e16, int g, int PX) { return p16(e16 & 1, g) * PX + (e16 >> 1); }
+// hidden unit held by K-step kappa = 4t + i (D2 tile t, register i) of lane group g
+MOL_HD int hidden16(int kappa, int g) { return 16 * (kappa >> 2) + 8 * ((kappa >> 1) & 1) + p16(kappa & 1, g); }
+
 }  // namespace mol

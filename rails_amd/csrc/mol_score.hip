@@ -169,11 +169,32 @@ bool score_supported(const Shape& s) {
          (pq == 16 && px == 16 && dd == 64);
 }
 
+// Small-unit shell (mol_score_small.hip) or the 32x32x2 shells?  Same bits either way; RAILS_SCORE_VARIANT=7 forces the small
+// units, any other non-zero value keeps them off.
+static bool use_small_units(const Shape& s, const ScoreArgs& a, int n_cu) {
+  if (!score_small_shape(s) || a.per_row || a.cand_pos || a.sel_list || a.split) return false;
+  const int variant = score_variant();
+  if (variant != 0) return variant == 7;
+  // Measured on MI355X (profiles/r04_small_units.txt).  The 32x32x2 shells are faster per flop once the chip is full (0.84 against
+  // 0.76 of the fp32 MFMA peak on amzn-books at B = 32: half the VALU instructions per pair and a quarter of the L1 traffic per
+  // flop), so the small units are for launches that cannot fill it with 32x32x2 units or that stream a large index for one or two
+  // queries:
+  //   (a) fewer big units than two per CU -- ML-1M at B = 4 ... 16: 26-27 us -> 17-18 us (B = 32 is 976 units: 29 us either way);
+  //   (b) B <= 2 over >= 8 tiles per CU-round -- amzn-books B = 1: 0.317-0.331 -> 0.282-0.292 ms, B = 2: 0.483-0.508 -> 0.464-0.482 ms
+  //       (half of GEMM1's padding rows gone, four waves per SIMD keep more of the index in flight); ML-20M's 853 tiles stay on
+  //       the 32x32x2 shell (18 vs 19 us).
+  const int64_t big_units = a.n_tiles * a.n_groups;
+  if (big_units <= 2 * (int64_t)n_cu) return true;
+  if (a.B <= 2 && a.n_tiles >= 8 * (int64_t)n_cu) return true;
+  return false;
+}
+
 int score_launch(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream) {
   if (!score_supported(s)) return kErrUnsupported;
   if (score_extra_shape(s))
     return !a.split ? score_launch_extra(s, a, n_cu, stream) : a.single ? score_launch_f16x1_extra(s, a, n_cu, stream) : score_launch_f16_extra(s, a, n_cu, stream);
   if (a.split) return a.single ? score_launch_f16x1(s, a, n_cu, stream) : score_launch_f16(s, a, n_cu, stream);
+  if (use_small_units(s, a, n_cu)) return score_launch_small(s, a, n_cu, stream);
 #define MOL_CASE(pq, px, dd)                                                                             \
   if (s.query_dot_product_groups == pq && s.item_dot_product_groups == px && s.dot_product_dimension == dd) \
     return launch_score<pq, px, dd, 128>(a, n_cu, stream);

@@ -410,7 +410,8 @@ __global__ __launch_bounds__(kHistThreads) void compact_kernel(const float* __re
   });
   __syncthreads();
   const unsigned int total = wg_cursor;
-  if (total == 0u) return;
+  if (total == 0u) return;   // uniform: every thread read the same value after the barrier above
+  __syncthreads();           // every thread has read `total` before thread 0 resets the cursor for the overflow re-walk
   if (threadIdx.x == 0) { wg_base = atomicAdd(&st[row].count, total); wg_cursor = 0u; }
   __syncthreads();
   const unsigned int wbase = wg_base;

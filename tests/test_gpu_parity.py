@@ -654,6 +654,34 @@ def test_batch_sizes_cover_padding_and_both_kernels(dev, B, precision):
     assert float((got.cpu() - ref).abs().max()) <= LOGIT_TOL
 
 
+@pytest.mark.parametrize("B", [1, 2, 3, 8, 32, 33])
+@pytest.mark.parametrize("cfg_name,N", [("ml-1m", 3883), ("ml-20m", 2777), ("amzn-books", 5009)])
+def test_small_unit_kernel_returns_the_bits_of_the_32x32_kernels(dev, monkeypatch, cfg_name, N, B):
+    """The small-unit shell (v_mfma_f32_16x16x4_f32, 2 queries x 16 items per wave; mol_score_small.hip) visits the terms of every
+    contraction and of the softmax sums in the order the 32x32x2 kernels do: the logits are the same BITS, whichever shell a
+    corpus (or a shard of one) is given.  Odd batch sizes leave the second query of the last pair empty; N is not a multiple of 16."""
+    cfg = O.CONFIGS[cfg_name]
+    w = O.synthetic_weights(cfg, seed=11)
+    mol = build_module(cfg, w, dev, "fp32")
+    X = torch.from_numpy(O.hash_item_table(7, 0, N, cfg.item_embedding_dim)).to(dev)
+    q = O.synthetic_queries(cfg, B, seed=B).to(dev)
+    uid = torch.arange(B, dtype=torch.int64, device=dev) * 37 if cfg.uid_embedding_hash_sizes else None
+    with torch.inference_mode():
+        eng = mol.engine()
+        index = eng.build_index(X)
+        qpack, _, _ = eng.query_pack(q, uid)
+        outs = {}
+        for variant in ("7", "1", "0"):   # small units; the independent-wave 32x32x2 shell; whatever the dispatcher picks
+            monkeypatch.setenv("RAILS_SCORE_VARIANT", variant)
+            outs[variant] = eng.score_dense(qpack, B, index).clone()
+        torch.cuda.synchronize()
+    assert torch.equal(outs["7"], outs["1"])
+    assert torch.equal(outs["7"], outs["0"])
+    cols = torch.randperm(N, generator=torch.Generator().manual_seed(B))[:256]
+    ref = O.mol_logits(cfg, w, q.cpu(), X[cols.to(dev)].cpu().unsqueeze(0), None if uid is None else uid.cpu())
+    assert float((outs["7"][:, cols.to(dev)].cpu() - ref).abs().max()) <= LOGIT_TOL
+
+
 def test_bf16_module_and_inputs_round_trip(dev):
     """eval_batch.py runs --eval_dtype=bf16 (model and item table cast to bf16): parameters and inputs are
     up-cast, arithmetic stays fp32, outputs come back in the query dtype."""
