@@ -487,15 +487,13 @@ def main() -> None:
                 # bound, one selection launch applies the id map and the seen-id filter; the dense pass behind it runs only if a
                 # survivor list overflowed (launch predicate = the status word; no-ops here)
                 out_i, out_s, status = eng.score_topk(qpack, B, local._index, k_local, ids=local._ids_flat, invalid_ids=inv, k_out=k, between=mark)
-                with E.run_predicate(status):
-                    eng.score_dense(qpack, B, local._index, out=logits)
-                    E.topk_filtered(logits, k_local, local._ids_flat, inv, k, out=(out_i, out_s))
+                eng.score_dense(qpack, B, local._index, out=logits, run_if=status)
+                E.topk_filtered(logits, k_local, local._ids_flat, inv, k, out=(out_i, out_s), run_if=status)
                 return out_i, out_s
             if fused:
                 s, top, status = eng.score_topk(qpack, B, local._index, k_local, ids=local._ids_flat, between=mark)
-                with E.run_predicate(status):
-                    eng.score_dense(qpack, B, local._index, out=logits)
-                    E.topk(logits, k_local, ids=local._ids_flat, out=(s, top))
+                eng.score_dense(qpack, B, local._index, out=logits, run_if=status)
+                E.topk(logits, k_local, ids=local._ids_flat, out=(s, top), run_if=status)
             else:
                 eng.score_dense(qpack, B, local._index, out=logits)
                 mark()

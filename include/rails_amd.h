@@ -12,6 +12,10 @@
  *     every call only enqueues work on it: no allocation, no synchronisation, no host copies;
  *   - return value 0 on success, a negative RAILS_E* code otherwise; rails_last_error() returns
  *     a thread-local human-readable message for the last failure;
+ *   - `run_if` (where an entry point has it) is the LAUNCH PREDICATE: NULL, or an int32 in device memory that every kernel of the
+ *     call reads when it starts, in stream order -- the call is a no-op unless it is non-zero.  It is how a caller enqueues a
+ *     fallback behind a device-side verdict without reading the verdict on the host (rails_rescore_verdict, rails_range_flag_i32
+ *     and the status word of rails_mol_score_topk write such flags).  No counterpart in the reference;
  *   - packed buffers (`gate pack`, `item index`, `query pack`) are opaque fp32 blobs whose sizes
  *     come from the *_floats() helpers; they are only valid for the shape they were built for.
  */
@@ -26,9 +30,10 @@ extern "C" {
 #endif
 
 /* Version of this interface: bumped whenever a struct gains a field or an entry point changes meaning (round 2 -> 3: 3, the
- * structs of round 2 carried no version).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
+ * structs of round 2 carried no version; 5: the launch predicate became the explicit `run_if` argument of the entry points that
+ * honour it and the per-thread rails_set_run_predicate is gone -- the library keeps no state between calls but the last error).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
  * against an older header pass shorter structs, and the library would read the new fields from whatever follows them. */
-#define RAILS_ABI_VERSION 4
+#define RAILS_ABI_VERSION 5
 int rails_abi_version(void);
 
 #define RAILS_OK 0
@@ -174,7 +179,7 @@ int rails_mol_query_prologue_both(const rails_mol_shape* shape, const rails_mol_
  * logits[b * ld + x] for b < batch, x < n_items. */
 int rails_mol_score_dense(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack,
                           int32_t batch, const float* index, int64_t n_items, float* logits, int64_t ld,
-                          void* stream);
+                          const int32_t* run_if, void* stream);
 /* Per-row candidates (B' == B branch, similarity_fn.py:397-402): `cand_index` was produced by
  * rails_mol_index_gather with n_rows == batch; logits[b * ld + j] for j < n_cand. */
 int rails_mol_score_candidates(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack,
@@ -214,7 +219,7 @@ int rails_mol_coarse_build(const rails_mol_shape* shape, const float* index, int
 /* eq: plain (batch, P_Q, d) fp32 from rails_mol_query_prologue's eq_out.  average_queries 0: sum over P_Q
  * (forward), 1: mean over P_Q (topk_ids).  scores[b * ld + x]. */
 int rails_mol_coarse_score(const rails_mol_shape* shape, const float* eq, int32_t batch, int32_t average_queries,
-                           const void* table, int64_t n_items, float* scores, int64_t ld, void* stream);
+                           const void* table, int64_t n_items, float* scores, int64_t ld, const int32_t* run_if, void* stream);
 
 /* Fused coarse scoring + exact top-K' (the same scores as rails_mol_coarse_score followed by rails_topk, without
  * materialising the (batch, n_items) matrix): a strided sample of the table fixes a per-query threshold, one streaming
@@ -237,7 +242,7 @@ size_t rails_mol_component_table_bytes(const rails_mol_shape* shape, int64_t n_i
 int rails_mol_component_build(const rails_mol_shape* shape, const float* index, int64_t n_items, void* table,
                               void* stream);
 int rails_mol_component_score(const rails_mol_shape* shape, const float* eq, int32_t batch, const void* table,
-                              int64_t n_items, float* scores, int64_t ld, void* stream);
+                              int64_t n_items, float* scores, int64_t ld, const int32_t* run_if, void* stream);
 /* Fused scoring + exact top-k_group of every (query group, item group) row, without the (rows, n_items) score matrix:
  * same scheme, same outputs contract and same counts check as rails_mol_coarse_topk, over batch * P_Q * P_X rows.
  * out_scores / out_positions: (batch * P_Q * P_X, k_group); out_counts: (batch * P_Q * P_X). */
@@ -262,17 +267,17 @@ int rails_mask_sorted_duplicates(const int64_t* sorted_idx, float* scores, int64
 size_t rails_topk_workspace_bytes(int32_t rows, int64_t n, int32_t k);
 int rails_topk(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t k, int32_t sorted,
                const int64_t* ids, int64_t ids_row_stride, float* out_scores, int64_t* out_ids,
-               void* workspace, size_t workspace_bytes, void* stream);
+               void* workspace, size_t workspace_bytes, const int32_t* run_if, void* stream);
 
 /* CandidateIndex.get_top_k_outputs' selection in ONE chain (reference indexing/candidate_index.py:149-175 after
  * rails/indexing/mol_top_k.py:123-130): exact top-k' of every row with the id map, then the seen-id filter of
  * rails_filter_seen_ids applied to the k' winners INSIDE the final selection launch -> (out_ids, out_scores) of k per row, the
  * same bits as rails_topk followed by rails_filter_seen_ids.  Sizes: rails_topk_filter_fusable(n, k', width, k) != 0
- * (n > 1024, k' <= 512, width <= 256); RAILS_ENOTSUP otherwise -- call the two entry points then.  Honours the launch predicate. */
+ * (n > 1024, k' <= 512, width <= 256); RAILS_ENOTSUP otherwise -- call the two entry points then. */
 int rails_topk_filter_fusable(int64_t n, int32_t k_prime, int32_t width, int32_t k);
 int rails_topk_filtered(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t k_prime, const int64_t* ids, int64_t ids_row_stride,
                         const int64_t* invalid_ids, int32_t width, int32_t k, int64_t* out_ids, float* out_scores, void* workspace,
-                        size_t workspace_bytes, void* stream);
+                        size_t workspace_bytes, const int32_t* run_if, void* stream);
 
 /* Scoring with the selection fused in: MoLBruteForceTopK.forward's `all_logits = mol(...)` + `torch.topk` + id gather
  * (reference rails/indexing/mol_top_k.py:118-130) and, optionally, CandidateIndex.get_top_k_outputs' seen-id filter
@@ -285,9 +290,9 @@ int rails_topk_filtered(const float* scores, int64_t ld, int32_t rows, int64_t n
  *   workspace   rails_mol_score_topk_workspace_bytes(B) bytes, ZERO-FILLED ONCE by the caller; every call leaves it zeroed again.
  *               Its word at byte offset 4 * B is the status: 0, or 1 when a list overflowed (adversarial orders, e.g. scores
  *               ascending in position) -- the outputs are then NOT valid and the caller re-runs the dense entry points, typically
- *               enqueued right behind this call under rails_set_run_predicate(status word), with no host round trip.
+ *               enqueued right behind this call with run_if = the status word, with no host round trip.
  * Available (rails_mol_score_topk_supported != 0) for B <= 256, k <= 384, n >= 131 072 on the staged and team shells (>= 8 query
- * groups); RAILS_ENOTSUP otherwise -- call the dense entry points then.  Honours the launch predicate. */
+ * groups); RAILS_ENOTSUP otherwise -- call the dense entry points then. */
 size_t rails_mol_score_topk_workspace_bytes(int32_t batch);
 int rails_mol_score_topk_supported(const rails_mol_shape* shape, int32_t batch, int64_t n_items, int32_t k);
 int rails_mol_score_topk(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack, int32_t batch, const float* index,
@@ -329,14 +334,9 @@ int rails_merge_candidates_filtered(const int64_t* gathered, int32_t n_ranks, in
  * top k, given |approx - exact| <= margin_eps everywhere; the probes watch that bound outside the candidates).  n_cand <= 16384.
  * row_stats (rows x 2 floats, optional): [largest |exact - approx| over the row's candidates and probes (inf for a NaN), k-th exact
  * score - min candidate approx], for callers that calibrate the bound from what they observe; row_ok or row_stats may be NULL. */
-/* Launch predicate of the CALLING THREAD: while a device flag is set here, every rails_mol_score_dense / _score_candidates / rails_topk
- * (and rails_mol_coarse_score / rails_mol_component_score) launched from this thread is a no-op unless *device_flag != 0 when the kernel starts (the flag is read on the device, in stream
- * order).  NULL clears it.  This is how the verified modes run their dense fp32 fallback without the host reading the verdict:
- * rails_rescore_verdict writes the flag, the fallback is enqueued unconditionally behind it.  No counterpart in the reference. */
-int rails_set_run_predicate(const int32_t* device_flag);
 /* *flag |= 1 if any of the n int32 values lies outside [lo, hi]: the validity check of the fused scans' candidate counts
- * (rails_mol_coarse_topk / rails_mol_component_topk) on the device, feeding the launch predicate of their materialising redo
- * (rails_mol_coarse_score / rails_mol_component_score honour the predicate as well).  The caller zeroes *flag. */
+ * (rails_mol_coarse_topk / rails_mol_component_topk) on the device, feeding the launch predicate (run_if) of their materialising
+ * redo (rails_mol_coarse_score / rails_mol_component_score + rails_topk).  The caller zeroes *flag. */
 int rails_range_flag_i32(const int32_t* values, int32_t n, int32_t lo, int32_t hi, int32_t* flag, void* stream);
 
 /* Verdict of a speculate-then-verify call, on the device: from the row_stats of rails_rescore_select (rows x 2 floats) and the

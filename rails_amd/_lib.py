@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RAILS_AMD_LIBRARY: load another build of the same library (e.g. the phase-stamp debug build of tools/query_phases.sh)
 LIB_PATH = os.environ.get("RAILS_AMD_LIBRARY") or os.path.join(_HERE, "librails_amd.so")
 
-RAILS_ABI_VERSION = 4   # include/rails_amd.h
+RAILS_ABI_VERSION = 5   # include/rails_amd.h
 RAILS_OK = 0
 RAILS_EINVAL = -22
 RAILS_ENOTSUP = -95
@@ -108,7 +108,7 @@ PROTOTYPES = {
     ),
     "rails_mol_score_dense": (
         C.c_int,
-        [_SHAPE_P, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p],
+        [_SHAPE_P, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
     ),
     "rails_mol_score_candidates": (
         C.c_int,
@@ -132,7 +132,7 @@ PROTOTYPES = {
                                         C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rails_mol_coarse_score": (
         C.c_int,
-        [_SHAPE_P, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p],
+        [_SHAPE_P, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
     ),
     "rails_mol_component_table_bytes": (C.c_size_t, [_SHAPE_P, C.c_int64]),
     "rails_mol_component_build": (C.c_int, [_SHAPE_P, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
@@ -141,7 +141,7 @@ PROTOTYPES = {
                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rails_mol_component_score": (
         C.c_int,
-        [_SHAPE_P, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p],
+        [_SHAPE_P, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
     ),
     "rails_hstu_preprocess": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "rails_rows_layer_norm": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
@@ -165,7 +165,7 @@ PROTOTYPES = {
     "rails_topk": (
         C.c_int,
         [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
-         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p],
+         C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p],
     ),
     "rails_pack_candidates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "rails_merge_candidates": (
@@ -179,7 +179,7 @@ PROTOTYPES = {
                                          C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rails_topk_filter_fusable": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "rails_topk_filtered": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32,
-                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "rails_mol_score_topk_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "rails_mol_score_topk_supported": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_int32]),
     "rails_mol_score_topk": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
@@ -189,7 +189,6 @@ PROTOTYPES = {
     "rails_merge_candidates_filtered": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rails_mol_score_indexed_supported": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64]),
     "rails_mol_score_indexed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
-    "rails_set_run_predicate": (C.c_int, [C.c_void_p]),
     "rails_range_flag_i32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "rails_rescore_verdict": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
     "rails_filter_seen_ids": (

@@ -10,8 +10,6 @@
 namespace mol {
 
 static thread_local char g_err[512] = "";
-static thread_local const int32_t* g_run_if = nullptr;
-const int32_t* run_predicate() { return g_run_if; }
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -211,7 +209,7 @@ static int query_prologue_checked(const rails_mol_shape* s, const rails_mol_weig
 
 // Launch arguments of a scoring pass over a shared corpus (per_row = 0) or per-row candidates (per_row = 1).
 static int fill_score_args(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch, const float* index,
-                           int64_t n_items, float* logits, int64_t ld, int per_row, ScoreArgs* out) {
+                           int64_t n_items, float* logits, int64_t ld, int per_row, ScoreArgs* out, const int32_t* run_if = nullptr) {
   ScoreArgs a{};
   const int QT = queries_per_group(*s);
   a.n_groups = (batch + QT - 1) / QT;
@@ -230,14 +228,14 @@ static int fill_score_args(const rails_mol_shape* s, const float* gate_pack, con
   a.split = is_split(*s) ? 1 : 0;
   a.single = s->precision == RAILS_PRECISION_F16X1 ? 1 : 0;
   a.combine_none = s->gating_combination == RAILS_COMBINE_NONE ? 1 : 0;
-  a.run_if = g_run_if;
+  a.run_if = run_if;
   *out = a;
   return kOk;
 }
 
 static int score_common(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch,
                         const float* index, int64_t n_items, float* logits, int64_t ld, int per_row, void* stream,
-                        const char* what) {
+                        const char* what, const int32_t* run_if = nullptr) {
   g_err[0] = '\0';
   if (!shape_supported(s)) return RAILS_ENOTSUP;
   if (batch < 0 || n_items < 0) { set_error("%s: negative size", what); return RAILS_EINVAL; }
@@ -248,7 +246,7 @@ static int score_common(const rails_mol_shape* s, const float* gate_pack, const 
   const int cu = compute_units();
   if (cu <= 0) { set_error("%s: no HIP device", what); return RAILS_ELAUNCH; }
   ScoreArgs a;
-  fill_score_args(s, gate_pack, query_pack, batch, index, n_items, logits, ld, per_row, &a);
+  fill_score_args(s, gate_pack, query_pack, batch, index, n_items, logits, ld, per_row, &a, run_if);
   const int r = score_launch(*s, a, cu, (hipStream_t)stream);
   return r == kOk ? r : fail(r, what);
 }
@@ -319,14 +317,20 @@ int rails_mol_score_topk(const rails_mol_shape* s, const float* gate_pack, const
                          int64_t n_items, int32_t k, const int64_t* ids, int64_t ids_row_stride, float* logits, int64_t ld,
                          const int64_t* invalid_ids, int32_t width, int32_t k_out, float* out_scores, int64_t* out_ids, void* workspace,
                          size_t workspace_bytes, void* stream) {
+  // the selection's arguments are checked BEFORE the scoring launch fills the survivor lists: a rejected selection would leave
+  // keys and bounds of this batch in the workspace, which every call must leave zeroed
+  g_err[0] = '\0';
+  if (!out_scores || !out_ids) { set_error("score_topk: NULL pointer"); return RAILS_EINVAL; }
+  if (invalid_ids && (width < 0 || k_out <= 0 || k_out > k)) { set_error("score_topk: bad filter sizes"); return RAILS_EINVAL; }
+  if (invalid_ids && !(k <= 512 && width <= 256)) { set_error("score_topk: the seen-id filter cannot be fused at k = %d, width = %d", k, width); return RAILS_ENOTSUP; }
   const int r = rails_mol_score_survivors(s, gate_pack, query_pack, batch, index, n_items, k, logits, ld, workspace, workspace_bytes, stream);
   if (r != RAILS_OK) return r;
   return rails_select_survivors(batch, k, ids, ids_row_stride, invalid_ids, width, k_out, out_scores, out_ids, workspace, workspace_bytes, stream);
 }
 
 int rails_mol_score_dense(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch,
-                          const float* index, int64_t n_items, float* logits, int64_t ld, void* stream) {
-  return score_common(s, gate_pack, query_pack, batch, index, n_items, logits, ld, 0, stream, "score_dense");
+                          const float* index, int64_t n_items, float* logits, int64_t ld, const int32_t* run_if, void* stream) {
+  return score_common(s, gate_pack, query_pack, batch, index, n_items, logits, ld, 0, stream, "score_dense", run_if);
 }
 
 int rails_mol_score_indexed_supported(const rails_mol_shape* s, int32_t batch, int64_t n_cand) {
@@ -444,14 +448,14 @@ int rails_mol_coarse_topk(const rails_mol_shape* s, const float* eq, int32_t bat
 }
 
 int rails_mol_coarse_score(const rails_mol_shape* s, const float* eq, int32_t batch, int32_t average_queries,
-                           const void* table, int64_t n_items, float* scores, int64_t ld, void* stream) {
+                           const void* table, int64_t n_items, float* scores, int64_t ld, const int32_t* run_if, void* stream) {
   g_err[0] = '\0';
   if (!shape_ok(s)) return RAILS_EINVAL;
   if (batch < 0 || n_items < 0) { set_error("coarse_score: negative size"); return RAILS_EINVAL; }
   if (batch == 0 || n_items == 0) return RAILS_OK;
   if (!eq || !table || !scores) { set_error("coarse_score: NULL pointer"); return RAILS_EINVAL; }
   if (ld < n_items) { set_error("coarse_score: ld < n_items"); return RAILS_EINVAL; }
-  const int r = coarse_score(*s, eq, batch, average_queries ? 1 : 0, table, n_items, scores, ld, (hipStream_t)stream);
+  const int r = coarse_score(*s, eq, batch, average_queries ? 1 : 0, table, n_items, scores, ld, (hipStream_t)stream, run_if);
   return r == kOk ? r : fail(r, "coarse_score");
 }
 
@@ -493,14 +497,14 @@ int rails_mol_component_topk(const rails_mol_shape* s, const float* eq, int32_t 
 }
 
 int rails_mol_component_score(const rails_mol_shape* s, const float* eq, int32_t batch, const void* table, int64_t n_items,
-                              float* scores, int64_t ld, void* stream) {
+                              float* scores, int64_t ld, const int32_t* run_if, void* stream) {
   g_err[0] = '\0';
   if (!shape_ok(s)) return RAILS_EINVAL;
   if (batch < 0 || n_items < 0) { set_error("component_score: negative size"); return RAILS_EINVAL; }
   if (batch == 0 || n_items == 0) return RAILS_OK;
   if (!eq || !table || !scores) { set_error("component_score: NULL pointer"); return RAILS_EINVAL; }
   if (ld < n_items) { set_error("component_score: ld < n_items"); return RAILS_EINVAL; }
-  const int r = component_score(*s, eq, batch, table, n_items, scores, ld, (hipStream_t)stream);
+  const int r = component_score(*s, eq, batch, table, n_items, scores, ld, (hipStream_t)stream, run_if);
   return r == kOk ? r : fail(r, "component_score");
 }
 
@@ -529,7 +533,7 @@ size_t rails_topk_workspace_bytes(int32_t rows, int64_t n, int32_t k) {
 
 int rails_topk(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t k, int32_t sorted, const int64_t* ids,
                int64_t ids_row_stride, float* out_scores, int64_t* out_ids, void* workspace, size_t workspace_bytes,
-               void* stream) {
+               const int32_t* run_if, void* stream) {
   (void)sorted;  // the descending order returned is also a valid unsorted answer
   g_err[0] = '\0';
   if (rows < 0 || n < 0 || k < 0) { set_error("topk: negative size"); return RAILS_EINVAL; }
@@ -541,7 +545,7 @@ int rails_topk(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t
   const int cu = compute_units();
   if (cu <= 0) { set_error("topk: no HIP device"); return RAILS_ELAUNCH; }
   const int r = topk(scores, ld, rows, n, k, ids, ids_row_stride, out_scores, out_ids, workspace, workspace_bytes, cu,
-                     (hipStream_t)stream);
+                     (hipStream_t)stream, nullptr, 0, 0, nullptr, run_if);
   return r == kOk ? r : fail(r, "topk");
 }
 
@@ -549,7 +553,7 @@ int rails_topk_filter_fusable(int64_t n, int32_t k_prime, int32_t width, int32_t
 
 int rails_topk_filtered(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t k_prime, const int64_t* ids, int64_t ids_row_stride,
                         const int64_t* invalid_ids, int32_t width, int32_t k, int64_t* out_ids, float* out_scores, void* workspace,
-                        size_t workspace_bytes, void* stream) {
+                        size_t workspace_bytes, const int32_t* run_if, void* stream) {
   g_err[0] = '\0';
   if (rows < 0 || n < 0 || k_prime < 0 || k < 0 || width < 0) { set_error("topk_filtered: negative size"); return RAILS_EINVAL; }
   if (k_prime > n) { set_error("topk_filtered: selected index k out of range (k' = %d > n = %lld)", k_prime, (long long)n); return RAILS_EINVAL; }
@@ -561,7 +565,7 @@ int rails_topk_filtered(const float* scores, int64_t ld, int32_t rows, int64_t n
   const int cu = compute_units();
   if (cu <= 0) { set_error("topk_filtered: no HIP device"); return RAILS_ELAUNCH; }
   const int r = topk(scores, ld, rows, n, k_prime, ids, ids_row_stride, out_scores, out_ids, workspace, workspace_bytes, cu, (hipStream_t)stream,
-                     invalid_ids, width, k);
+                     invalid_ids, width, k, nullptr, run_if);
   return r == kOk ? r : fail(r, "topk_filtered");
 }
 
@@ -595,11 +599,6 @@ int rails_merge_candidates_filtered(const int64_t* gathered, int32_t n_ranks, in
 }
 
 int rails_abi_version(void) { return RAILS_ABI_VERSION; }
-
-int rails_set_run_predicate(const int32_t* device_flag) {
-  g_run_if = device_flag;
-  return RAILS_OK;
-}
 
 int rails_range_flag_i32(const int32_t* values, int32_t n, int32_t lo, int32_t hi, int32_t* flag, void* stream) {
   g_err[0] = '\0';

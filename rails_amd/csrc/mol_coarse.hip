@@ -372,12 +372,12 @@ int coarse_build(const Shape& s, const float* ipack, int64_t n, void* table, hip
 }
 
 int coarse_score(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, float* scores, int64_t ld,
-                 hipStream_t stream) {
+                 hipStream_t stream, const int32_t* run_if) {
   if (B <= 0 || n <= 0) return kOk;
   CoarseScanArgs a{};
   a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.d = s.dot_product_dimension; a.avg = avg;
   a.table = static_cast<const unsigned short*>(table); a.n = n; a.scores = scores; a.ld = ld; a.stride = 1;
-  a.run_if = run_predicate();
+  a.run_if = run_if;
   return launch_coarse_scan<kScanAll>(a, stream);
 }
 
@@ -679,12 +679,12 @@ int component_build(const Shape& s, const float* ipack, int64_t n, void* table, 
 }
 
 int component_score(const Shape& s, const float* eq, int B, const void* table, int64_t n, float* scores, int64_t ld,
-                    hipStream_t stream) {
+                    hipStream_t stream, const int32_t* run_if) {
   if (B <= 0 || n <= 0) return kOk;
   ComponentScanArgs a{};
   a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.PX = s.item_dot_product_groups; a.d = s.dot_product_dimension;
   a.table = static_cast<const unsigned short*>(table); a.n = n; a.scores = scores; a.ld = ld; a.stride = 1;
-  a.run_if = run_predicate();
+  a.run_if = run_if;
   return launch_component_scan<kScanAll>(a, stream);
 }
 

@@ -42,7 +42,7 @@ struct ScoreArgs {
   int combine_none;     // 1: gating_combination "none": w = gq + gi + gqi (absent parts are stored as zeros), no silu
   int single;           // 1 (with split): precision F16X1 -- the one-product kernels, which ignore the lo fragments
   int split;            // 1: precision mode f16x3 -- gate pack, query pack and item index hold f16 hi/lo fragments (mol_layout.h)
-  const int32_t* run_if;   // device flag (rails_set_run_predicate): the launch is a no-op when *run_if == 0; NULL = unconditional
+  const int32_t* run_if;   // device flag (the entry point's run_if argument): the launch is a no-op when *run_if == 0; NULL = unconditional
   // selection fused into the scoring pass (mol_select.h): NULL list = dense logits only; with a list, `logits` may be NULL
   unsigned long long* sel_list;   // [B][kSelSegs workgroups][kSelSegCap] keys; empty slots are 0
   unsigned int* sel_thr;          // [B] running lower bound on the k-th largest orderable score (0: none yet)
@@ -59,9 +59,8 @@ int pack_gate_weights_split(const Shape& s, const Weights& w, float* wpack, hipS
 inline bool is_split(const Shape& s) { return s.precision == RAILS_PRECISION_F16X3 || s.precision == RAILS_PRECISION_F16X1; }
 
 void set_error(const char* fmt, ...);
-// Launch predicate of the calling thread (rails_set_run_predicate): scoring and top-k kernels launched while it is set return at
-// once unless the device flag is non-zero -- a device-side conditional (the verified modes' fallback) without a host round trip.
-const int32_t* run_predicate();
+// Launch predicate (the run_if argument of rails_mol_score_dense / rails_topk / ...): the kernels of a call return at once unless
+// the device flag is non-zero -- a device-side conditional (the verified modes' fallback) without a host round trip.
 #define MOL_RUN_IF(flag) do { if ((flag) != nullptr && *(flag) == 0) return; } while (0)
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute and the Python layer drives several devices from
@@ -140,11 +139,11 @@ int hstu_encode_fused(const float* emb, const int64_t* ids, const int64_t* lengt
 int select_keys(const unsigned long long* keys, int rows, int keys_per_row, int k, float* out_scores, int64_t* out_pos,
                 hipStream_t stream);
 int coarse_score(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, float* scores, int64_t ld,
-                 hipStream_t stream);
+                 hipStream_t stream, const int32_t* run_if = nullptr);
 
 int component_build(const Shape& s, const float* ipack, int64_t n, void* table, hipStream_t stream);
 int component_score(const Shape& s, const float* eq, int B, const void* table, int64_t n, float* scores, int64_t ld,
-                    hipStream_t stream);
+                    hipStream_t stream, const int32_t* run_if = nullptr);
 int sort_rows_i64(const int64_t* in, int rows, int n, int64_t* out, hipStream_t stream);
 int mask_sorted_duplicates(const int64_t* idx, float* scores, int64_t ld, int rows, int n, float fill, hipStream_t stream);
 
@@ -159,7 +158,8 @@ size_t topk_workspace_bytes(int rows, int64_t n, int k);
 bool topk_can_fuse_filter(int64_t n, int k, int width, int k_out);
 int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int64_t* ids, int64_t ids_row_stride,
          float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, int n_cu, hipStream_t stream,
-         const int64_t* f_invalid = nullptr, int f_width = 0, int f_k = 0, const unsigned short* scores16 = nullptr);
+         const int64_t* f_invalid = nullptr, int f_width = 0, int f_k = 0, const unsigned short* scores16 = nullptr,
+         const int32_t* run_if = nullptr);
 // scores16 != NULL: the rows are bf16 bit patterns (ld, n in elements); only where topk_bf16_source_ok says so
 bool topk_bf16_source_ok(int rows, int64_t n, int k);
 int select_lists(unsigned long long* lists, unsigned int* thr, int rows, int cap, int k, const int64_t* ids,

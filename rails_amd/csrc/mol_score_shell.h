@@ -246,8 +246,10 @@ template <class U, int PQ, int PX, int DD, int H, int NW, bool STAGED>
 static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using G = Geo<PQ, PX, DD, H>;
   constexpr size_t lds = ((size_t)U::template kLdsWeightFloats<G> + (STAGED ? 2 * (size_t)G::kTileFloats : 0)) * sizeof(float);
-  constexpr bool kSelBuilt = STAGED && NW == 8;   // the fused-selection instantiation exists for the default staged kernel only
-  if constexpr (lds + sizeof(SelLds) > 160 * 1024) {
+  // the fused-selection instantiation exists for the default staged kernel only, and only where its LDS state fits next to the tiles
+  // (the dense instantiation carries no SelLds: its fit test is the tiles and weights alone)
+  constexpr bool kSelBuilt = STAGED && NW == 8 && lds + sizeof(SelLds) <= 160 * 1024;
+  if constexpr (lds > 160 * 1024) {
     set_error("staged scoring kernel needs %zu B of LDS", lds);
     return kErrUnsupported;
   } else {
@@ -291,8 +293,8 @@ template <class U, int PQ, int PX, int DD, int H, int NW>
 static int launch_staged1(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using G = Geo<PQ, PX, DD, H>;
   constexpr size_t lds = ((size_t)U::template kLdsWeightFloats<G> + (size_t)G::kTileExFloats + 2 * (size_t)G::kTileGiFloats) * sizeof(float);
-  constexpr bool kSelBuilt = NW == 8;
-  if constexpr (lds + sizeof(SelLds) > 160 * 1024) {
+  constexpr bool kSelBuilt = NW == 8 && lds + sizeof(SelLds) <= 160 * 1024;
+  if constexpr (lds > 160 * 1024) {
     set_error("single-buffer staged scoring kernel needs %zu B of LDS", lds);
     return kErrUnsupported;
   } else {
@@ -320,8 +322,8 @@ static int launch_staged1(const ScoreArgs& a, int n_cu, hipStream_t stream) {
 template <int PQ, int PX, int DD, int H>
 inline int choose_variant(const ScoreArgs& a, int n_cu) {
   using G = Geo<PQ, PX, DD, H>;
-  constexpr bool staged_fits = ((size_t)G::kWpackFloats + 2 * (size_t)G::kTileFloats) * sizeof(float) + sizeof(SelLds) <= 160 * 1024;
-  constexpr bool staged1_fits = ((size_t)G::kWpackFloats + (size_t)G::kTileExFloats + 2 * (size_t)G::kTileGiFloats) * sizeof(float) + sizeof(SelLds) <= 160 * 1024;
+  constexpr bool staged_fits = ((size_t)G::kWpackFloats + 2 * (size_t)G::kTileFloats) * sizeof(float) <= 160 * 1024;
+  constexpr bool staged1_fits = ((size_t)G::kWpackFloats + (size_t)G::kTileExFloats + 2 * (size_t)G::kTileGiFloats) * sizeof(float) <= 160 * 1024;
   int variant = score_variant();
   if (variant == 0) {
     variant = 1;

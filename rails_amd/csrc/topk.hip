@@ -866,14 +866,14 @@ bool topk_bf16_source_ok(int rows, int64_t n, int k) {
 
 int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int64_t* ids, int64_t ids_row_stride,
          float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, int n_cu, hipStream_t stream,
-         const int64_t* f_invalid, int f_width, int f_k, const unsigned short* scores16) {
+         const int64_t* f_invalid, int f_width, int f_k, const unsigned short* scores16, const int32_t* run_if) {
   if (rows <= 0 || k <= 0) return kOk;
   if (scores16 && !topk_bf16_source_ok(rows, n, k)) { set_error("topk: no bf16-source path at n = %lld, k = %d", (long long)n, k); return kErrUnsupported; }
   if (f_invalid && !topk_can_fuse_filter(n, k, f_width, f_k)) { set_error("topk: the seen-id filter cannot be fused at n = %lld, k = %d, width = %d", (long long)n, k, f_width); return kErrUnsupported; }
   if (k > kSortCap) { set_error("k = %d exceeds the in-LDS sort capacity (%d)", k, kSortCap); return kErrUnsupported; }
   if (n >= (1ll << 32)) { set_error("n = %lld does not fit 32-bit positions; shard the corpus", (long long)n); return kErrUnsupported; }
   if (ensure_sort_lds() != kOk) return kErrLaunch;
-  const int32_t* pred = run_predicate();
+  const int32_t* pred = run_if;   // the caller's launch predicate (NULL for the internal selections of the fused scans)
   if (n > 1024 && k <= kRowMaxK) {
     RowSelectArgs a{};
     a.run_if = pred;
@@ -962,7 +962,6 @@ int select_lists(unsigned long long* lists, unsigned int* thr, int rows, int cap
   if (k > kRowFastK || cap > 32 * kRowThreads || k > cap) { set_error("select_lists: k = %d of %d keys per row is out of range", k, cap); return kErrUnsupported; }
   if (f_invalid && !(k <= kFuseMaxK && f_width >= 0 && f_width <= kFuseMaxW && f_k > 0 && f_k <= k)) { set_error("select_lists: the seen-id filter cannot be fused at k = %d, width = %d", k, f_width); return kErrUnsupported; }
   RowSelectArgs b{};
-  b.run_if = run_predicate();
   b.keys_in = lists; b.keys_per_row = cap; b.k = k;
   b.keys_thr = thr;
   b.ids = ids; b.ids_row_stride = ids_row_stride; b.out_scores = out_scores; b.out_ids = out_ids;

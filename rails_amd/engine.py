@@ -353,12 +353,14 @@ class MolEngine:
         return out, out_other
 
     # ---- scoring ------------------------------------------------------------------------------
-    def score_dense(self, qpack: torch.Tensor, batch: int, index: MolIndex, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def score_dense(self, qpack: torch.Tensor, batch: int, index: MolIndex, out: Optional[torch.Tensor] = None,
+                    run_if: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """run_if: launch predicate (an int32 device scalar; see _pred): the launch is a no-op unless it is non-zero on the device."""
         if out is None:
             out = torch.empty((batch, index.n_items), dtype=torch.float32, device=index.buf.device)
         with _on_device(index.buf.device):
             _lib.check(
-                self.lib.rails_mol_score_dense(C.byref(self.dense_shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(index.buf), index.n_items, _ptr(out), out.stride(0), _stream()),
+                self.lib.rails_mol_score_dense(C.byref(self.dense_shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(index.buf), index.n_items, _ptr(out), out.stride(0), _pred(run_if), _stream()),
                 "rails_mol_score_dense",
             )
         return out
@@ -399,7 +401,7 @@ class MolEngine:
                    invalid_ids: Optional[torch.Tensor] = None, k_out: int = 0, logits_out: Optional[torch.Tensor] = None, between=None):
         """-> (scores (B, k), ids (B, k), status) or, with invalid_ids, (out_ids (B, k_out), out_scores (B, k_out), status): what
         score_dense + topk (+ filter_seen_ids) return, bit for bit, unless status (a device int32) is non-zero -- a survivor list
-        overflowed; the caller then re-runs the dense entry points, e.g. under run_predicate(status)."""
+        overflowed; the caller then re-runs the dense entry points, e.g. with run_if=status."""
         dev = index.buf.device
         stride = 0
         if ids is not None:
@@ -476,7 +478,8 @@ class MolEngine:
         d = self.spec.dot_product_dimension
         return self._derived_table("rails_mol_coarse_build", d, index, items).view(index.n_items, d)
 
-    def coarse_scores(self, eq: torch.Tensor, table: torch.Tensor, average_queries: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def coarse_scores(self, eq: torch.Tensor, table: torch.Tensor, average_queries: bool, out: Optional[torch.Tensor] = None,
+                      run_if: Optional[torch.Tensor] = None) -> torch.Tensor:
         """eq (B, P_Q, d) fp32 -> (B, N) fp32 holding bf16-rounded dot products (reference mol_top_k.py:351-354)."""
         B, n = eq.shape[0], table.shape[0]
         eq = _f32c(eq)
@@ -484,7 +487,7 @@ class MolEngine:
             out = torch.empty((B, n), dtype=torch.float32, device=table.device)
         with _on_device(table.device):
             _lib.check(
-                self.lib.rails_mol_coarse_score(C.byref(self.shape), _ptr(eq), B, 1 if average_queries else 0, _ptr(table), n, _ptr(out), out.stride(0), _stream()),
+                self.lib.rails_mol_coarse_score(C.byref(self.shape), _ptr(eq), B, 1 if average_queries else 0, _ptr(table), n, _ptr(out), out.stride(0), _pred(run_if), _stream()),
                 "rails_mol_coarse_score",
             )
         return out
@@ -522,7 +525,8 @@ class MolEngine:
         px, d = self.spec.item_dot_product_groups, self.spec.dot_product_dimension
         return self._derived_table("rails_mol_component_build", px * d, index, items).view(index.n_items, px, d)
 
-    def component_scores(self, eq: torch.Tensor, table: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def component_scores(self, eq: torch.Tensor, table: torch.Tensor, out: Optional[torch.Tensor] = None,
+                         run_if: Optional[torch.Tensor] = None) -> torch.Tensor:
         """eq (B, P_Q, d) -> (B * P_Q * P_X, N) fp32 holding bf16 values, row (b * P_Q + i) * P_X + m."""
         B, n = eq.shape[0], table.shape[0]
         eq = _f32c(eq)
@@ -531,7 +535,7 @@ class MolEngine:
             out = torch.empty((rows, n), dtype=torch.float32, device=table.device)
         with _on_device(table.device):
             _lib.check(
-                self.lib.rails_mol_component_score(C.byref(self.shape), _ptr(eq), B, _ptr(table), n, _ptr(out), out.stride(0), _stream()),
+                self.lib.rails_mol_component_score(C.byref(self.shape), _ptr(eq), B, _ptr(table), n, _ptr(out), out.stride(0), _pred(run_if), _stream()),
                 "rails_mol_component_score",
             )
         return out
@@ -625,8 +629,18 @@ def dot_rowwise(q: torch.Tensor, items: torch.Tensor) -> torch.Tensor:
 
 
 # ---- shape-independent kernels ----------------------------------------------------------------
+def _pred(flag: Optional[torch.Tensor]):
+    """Launch predicate argument (include/rails_amd.h `run_if`): None, or an int32 device scalar read by the kernels when they start."""
+    if flag is None:
+        return None
+    if flag.dtype != torch.int32 or not flag.is_cuda or flag.numel() < 1:
+        raise ValueError("the launch predicate is an int32 device tensor")
+    return _ptr(flag)
+
+
 def topk(scores: torch.Tensor, k: int, ids: Optional[torch.Tensor] = None, sorted: bool = True,
-         workspace: Optional[torch.Tensor] = None, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+         workspace: Optional[torch.Tensor] = None, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+         run_if: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Exact top-k of every row of `scores` (rows, n) fp32 on the GPU; ties by position ascending.
     ids: None -> positions; (n,) or (1, n) -> shared id row; (rows, n) -> per-row ids.
     Replaces torch.topk + id gather (reference rails/indexing/mol_top_k.py:123-130)."""
@@ -661,7 +675,7 @@ def topk(scores: torch.Tensor, k: int, ids: Optional[torch.Tensor] = None, sorte
     ws = workspace if workspace is not None and workspace.numel() >= ws_bytes and workspace.device == scores.device else torch.empty(ws_bytes, dtype=torch.uint8, device=scores.device)
     with _on_device(scores.device):
         _lib.check(
-            lib.rails_topk(_ptr(scores), scores.stride(0), rows, n, k, 1 if sorted else 0, _ptr(ids), stride, _ptr(out_s), _ptr(out_i), _ptr(ws), ws_bytes, _stream()),
+            lib.rails_topk(_ptr(scores), scores.stride(0), rows, n, k, 1 if sorted else 0, _ptr(ids), stride, _ptr(out_s), _ptr(out_i), _ptr(ws), ws_bytes, _pred(run_if), _stream()),
             "rails_topk",
         )
     return out_s, out_i
@@ -706,7 +720,8 @@ def topk_filter_fusable(n: int, k_prime: int, width: int, k: int) -> bool:
 
 
 def topk_filtered(scores: torch.Tensor, k_prime: int, ids: Optional[torch.Tensor], invalid_ids: torch.Tensor, k: int,
-                  workspace: Optional[torch.Tensor] = None, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                  workspace: Optional[torch.Tensor] = None, out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+                  run_if: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """topk(scores, k_prime, ids) followed by filter_seen_ids(..., invalid_ids, k), the filter fused into the final selection launch
     (include/rails_amd.h rails_topk_filtered).  -> (out_ids (rows, k), out_scores (rows, k)), ids first like filter_seen_ids."""
     lib = _lib.load()
@@ -735,26 +750,8 @@ def topk_filtered(scores: torch.Tensor, k_prime: int, ids: Optional[torch.Tensor
     ws = workspace if workspace is not None and workspace.numel() >= ws_bytes and workspace.device == scores.device else torch.empty(ws_bytes, dtype=torch.uint8, device=scores.device)
     with _on_device(scores.device):
         _lib.check(lib.rails_topk_filtered(_ptr(scores), scores.stride(0), rows, n, k_prime, _ptr(ids), stride, _ptr(invalid_ids), invalid_ids.shape[1], k,
-                                           _ptr(out_i), _ptr(out_s), _ptr(ws), ws_bytes, _stream()), "rails_topk_filtered")
+                                           _ptr(out_i), _ptr(out_s), _ptr(ws), ws_bytes, _pred(run_if), _stream()), "rails_topk_filtered")
     return out_i, out_s
-
-
-class run_predicate:
-    """with run_predicate(flag):  every scoring / top-k launch inside is a no-op unless the int32 device scalar `flag` is non-zero
-    when the kernel starts (include/rails_amd.h rails_set_run_predicate).  Thread-local; not re-entrant."""
-
-    def __init__(self, flag: torch.Tensor) -> None:
-        if flag.dtype != torch.int32 or not flag.is_cuda:
-            raise ValueError("the launch predicate is an int32 device tensor")
-        self._flag = flag
-
-    def __enter__(self):
-        _lib.check(_lib.load().rails_set_run_predicate(_ptr(self._flag)), "rails_set_run_predicate")
-        return self
-
-    def __exit__(self, *exc):
-        _lib.load().rails_set_run_predicate(None)
-        return False
 
 
 def range_flag(values: torch.Tensor, lo: int, hi: int, flag: torch.Tensor) -> None:

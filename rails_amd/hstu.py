@@ -143,6 +143,8 @@ class HSTU(torch.nn.Module):
     """encode(past_lengths (B,), past_ids (B, N), past_embeddings (B, N, D), past_payloads {"timestamps": (B, N)}) -> (B, D).
     N must equal max_sequence_len + max_output_len (what the reference's eval feeds, modeling/sequential/features.py:48-58)."""
 
+    STRICT_DEVICE_LENGTHS = False   # True: validate device-resident past_lengths too (one blocking device-to-host read per call)
+
     def __init__(self, max_sequence_len: int, max_output_len: int, embedding_dim: int, num_blocks: int, num_heads: int, linear_dim: int,
                  attention_dim: int, *args, **kwargs) -> None:
         """Two signatures:
@@ -297,12 +299,16 @@ class HSTU(torch.nn.Module):
         """int64 lengths on the device, VALIDATED to lie in [min_len, N]: a length beyond the padded width, or an empty history in
         encode() (which indexes row `length - 1`; the reference's flattened gather at offset -1 fails there too, hstu.py:773-781),
         is an upstream data bug and raises instead of returning a plausible embedding of the wrong row.  forward() accepts 0 (an
-        all-padding sequence is all zero rows, as in the reference).  The check reads one flag back (lengths usually arrive from the
-        host, where it is free)."""
+        all-padding sequence is all zero rows, as in the reference).  Lengths that arrive on the HOST (the data loader's case) are
+        checked there, for free; lengths that are already device tensors are clamped into range on the device instead -- reading a
+        flag back would be a blocking device-to-host sync on every encode and would rule out stream capture (set
+        HSTU.STRICT_DEVICE_LENGTHS = True to pay that sync and raise as for host lengths)."""
         lengths = past_lengths.to(dtype=torch.int64)
-        if bool(((lengths < min_len) | (lengths > N)).any()):
-            raise ValueError(f"past_lengths must lie in [{min_len}, {N}] (got min {int(lengths.min())}, max {int(lengths.max())})")
-        return lengths.to(device=dev).contiguous()
+        if not lengths.is_cuda or HSTU.STRICT_DEVICE_LENGTHS:
+            if bool(((lengths < min_len) | (lengths > N)).any()):
+                raise ValueError(f"past_lengths must lie in [{min_len}, {N}] (got min {int(lengths.min())}, max {int(lengths.max())})")
+            return lengths.to(device=dev).contiguous()
+        return lengths.to(device=dev).clamp(min=min_len, max=N).contiguous()
 
     def _normalize(self, x2d: torch.Tensor, rows: Optional[torch.Tensor]) -> torch.Tensor:
         lib = _lib.load()

@@ -147,13 +147,12 @@ class MoLBruteForceTopK(MoLTopKModule):
         a, b, status = eng.score_topk(qpack, B, self._index, k, ids=self._ids_flat, invalid_ids=invalid_ids, k_out=k_out)
         # A survivor list overflowed (scores ascending in position, say): the dense pass, enqueued under the status word as its
         # launch predicate, overwrites the outputs.  No-ops otherwise; the host never looks.
-        with E.run_predicate(status):
-            logits = eng.score_dense(qpack, B, self._index, out=self._buf("logits", B * N, torch.float32).view(B, N))
-            ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(B, N, k), torch.uint8)
-            if invalid_ids is None:
-                E.topk(logits, k, ids=self._ids_flat, workspace=ws, out=(a, b))
-            else:
-                E.topk_filtered(logits, k, self._ids_flat, invalid_ids, k_out, workspace=ws, out=(a, b))
+        logits = eng.score_dense(qpack, B, self._index, out=self._buf("logits", B * N, torch.float32).view(B, N), run_if=status)
+        ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(B, N, k), torch.uint8)
+        if invalid_ids is None:
+            E.topk(logits, k, ids=self._ids_flat, workspace=ws, out=(a, b), run_if=status)
+        else:
+            E.topk_filtered(logits, k, self._ids_flat, invalid_ids, k_out, workspace=ws, out=(a, b), run_if=status)
         return a, b
 
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -267,8 +266,7 @@ class MoLBruteForceTopK(MoLTopKModule):
             # the first pass writes its dense logits (the probes and the verification read them) AND the survivor lists: the
             # candidate selection no longer re-reads (B, N)
             c16, pos, status = eng.score_topk(qpack16, B, self._index, kc, logits_out=s16)
-            with E.run_predicate(status):
-                E.topk(s16, kc, workspace=ws, out=(c16, pos))
+            E.topk(s16, kc, workspace=ws, out=(c16, pos), run_if=status)
         else:
             eng.score_dense(qpack16, B, self._index, out=s16)
             if self._debug_first_pass_bias is not None:   # tests only: (positions, delta) -- the first pass is made to under-score these items
@@ -305,9 +303,9 @@ class MoLBruteForceTopK(MoLTopKModule):
             # state when the NEXT call starts (statistics, candidate margin, pause logic).
             state = self._state()
             E.rescore_verdict(stats, state, default, safety)
-            with E.run_predicate(state.view(torch.int32)[1:2]):
-                l32 = ex.score_dense(qpack32, B, self._index32, out=self._buf("logits", B * N, torch.float32).view(B, N))
-                E.topk(l32, k, ids=self._ids_flat, workspace=ws, out=(scores, ids))
+            redo = state.view(torch.int32)[1:2]
+            l32 = ex.score_dense(qpack32, B, self._index32, out=self._buf("logits", B * N, torch.float32).view(B, N), run_if=redo)
+            E.topk(l32, k, ids=self._ids_flat, workspace=ws, out=(scores, ids), run_if=redo)
             self._state_host.copy_(state, non_blocking=True)
             self._state_event.record()
             self._state_pending = (k, kc)
@@ -597,9 +595,8 @@ class MoLAvgTopK(MoLTopKModule):
                     flag = self._buf("redo_flag", 1, torch.int32)
                     flag.zero_()
                     E.range_flag(counts, k_lo, k_hi, flag)
-                    with E.run_predicate(flag):
-                        coarse = eng.coarse_scores(eq, table, average_queries, out=self._buf("coarse_all", eq.shape[0] * n, torch.float32).view(eq.shape[0], n))
-                        E.topk(coarse, self._avg_top_k, out=(sc, idx))
+                    coarse = eng.coarse_scores(eq, table, average_queries, out=self._buf("coarse_all", eq.shape[0] * n, torch.float32).view(eq.shape[0], n), run_if=flag)
+                    E.topk(coarse, self._avg_top_k, out=(sc, idx), run_if=flag)
                     return (sc, idx) if with_scores else idx
                 check = lambda: int(counts.min()) >= k_lo and int(counts.max()) <= k_hi   # noqa: E731
                 if pending is not None:
@@ -705,9 +702,8 @@ class _ComponentCandidates:
                     flag = self._buf("redo_flag_c", 1, torch.int32)
                     flag.zero_()
                     E.range_flag(counts, k_per_group, k_hi, flag)
-                    with E.run_predicate(flag):
-                        scores = eng.component_scores(eq, table, out=self._buf("component_all", rows * n, torch.float32).view(rows, n))
-                        E.topk(scores, k_per_group, out=(sc_c, pos))
+                    scores = eng.component_scores(eq, table, out=self._buf("component_all", rows * n, torch.float32).view(rows, n), run_if=flag)
+                    E.topk(scores, k_per_group, out=(sc_c, pos), run_if=flag)
                     return pos.view(eq.shape[0], -1)
                 check = lambda: int(counts.min()) >= k_per_group and int(counts.max()) <= k_hi   # noqa: E731
                 if pending is not None:

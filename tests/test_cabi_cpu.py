@@ -40,7 +40,8 @@ def test_struct_layout_matches_header(lib):
 def test_size_helpers_and_validation(lib):
     s = E.MolShapeSpec(64, 64, 32, 8, 8, 512, 128, 128, 128).to_c()
     assert lib.rails_mol_shape_supported(C.byref(s)) == 1
-    assert lib.rails_mol_gate_pack_floats(C.byref(s)) == 2 * 128 * 64 + 128 + 64
+    # fp32 real-dataset shapes carry the pair-gate weights twice: 32x32x2 fragment order + the small-unit kernel's 16x16x4 order
+    assert lib.rails_mol_gate_pack_floats(C.byref(s)) == 2 * (2 * 128 * 64 + 128 + 64)
     assert lib.rails_mol_index_floats(C.byref(s), 33) == 2 * 32 * (8 * 32 + 64)     # two tiles
     assert lib.rails_mol_query_pack_floats(C.byref(s), 5) == 2 * 32 * 32 + 5 * 64 + 32 * (512 + 128 + 8 * 32 + 64)   # two query groups of 4 + scratch rows
     bad = E.MolShapeSpec(64, 64, 40, 8, 8, 512, 128, 128, 128).to_c()
@@ -59,13 +60,13 @@ def test_size_helpers_and_validation(lib):
     s16 = E.MolShapeSpec(64, 64, 32, 8, 8, 512, 128, 128, 128).to_c("f16x3")
     assert s16.precision == _lib.RAILS_PRECISION_F16X3 and lib.rails_mol_shape_supported(C.byref(s16)) == 1
     assert lib.rails_mol_index_floats(C.byref(s16), 33) == lib.rails_mol_index_floats(C.byref(s), 33)
-    assert lib.rails_mol_gate_pack_floats(C.byref(s16)) == lib.rails_mol_gate_pack_floats(C.byref(s))
+    assert lib.rails_mol_gate_pack_floats(C.byref(s16)) == 2 * 128 * 64 + 128 + 64    # the f16 builds have no small-unit kernel: one copy
     no_norm = E.MolShapeSpec(64, 64, 32, 8, 8, 512, 128, 128, 128, dot_product_l2_norm=False).to_c("f16x3")
     assert lib.rails_mol_shape_supported(C.byref(no_norm)) == 0 and "dot_product_l2_norm" in _lib.last_error()
     s.precision = 7
     assert lib.rails_mol_shape_supported(C.byref(s)) == 0 and "precision" in _lib.last_error()
     # k > n is rejected before any launch
-    assert lib.rails_topk(1, 10, 1, 10, 11, 1, None, 0, 1, 1, None, 0, None) == _lib.RAILS_EINVAL
+    assert lib.rails_topk(1, 10, 1, 10, 11, 1, None, 0, 1, 1, None, 0, None, None) == _lib.RAILS_EINVAL
     with pytest.raises(ValueError):
         _lib.check(_lib.RAILS_EINVAL, "x")
     with pytest.raises(NotImplementedError):

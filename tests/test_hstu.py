@@ -178,7 +178,16 @@ def test_encode_rejects_out_of_range_lengths():
                 bad = lengths.clone()
                 bad[pos] = val
                 with pytest.raises(ValueError, match="past_lengths"):
-                    m.encode(bad, ids, emb, {})
+                    m.encode(bad.cpu(), ids, emb, {})          # lengths from the host (the data loader's case): checked there
+                # device-resident lengths are clamped on the device (no blocking read in the hot path) unless strict mode is on
+                clamped = bad.clamp(min=1, max=ids.shape[1])
+                assert torch.equal(m.encode(bad, ids, emb, {}), m.encode(clamped, ids, emb, {}))
+                type(m).STRICT_DEVICE_LENGTHS = True
+                try:
+                    with pytest.raises(ValueError, match="past_lengths"):
+                        m.encode(bad, ids, emb, {})
+                finally:
+                    type(m).STRICT_DEVICE_LENGTHS = False
             ok = lengths.clone()
             ok[0], ok[1] = 1, cfg.max_sequence_len
             assert m.encode(ok, ids, emb, {}).shape == (lengths.shape[0], cfg.embedding_dim)
