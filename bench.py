@@ -252,6 +252,106 @@ def quick_workload(name: str, B: int, k: int, kp: int, steps: int, dev, items: i
             "mfma_frac_lower_bound": tf / (PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_F16X3_TFLOPS), **tr}
 
 
+def hr_parity_leg(cfg, weights, mol, B: int, k: int, kp: int, dev, n_items: int = 65_536) -> dict:
+    """The quality half of BASELINE.json's metric ("queries/sec + HR@10/50 parity"): HR@k / NDCG@10 / MRR of the HIP path against the
+    CPU oracle chain on the same inputs -- a sub-corpus of the workload's shape (counter-hash items, sparse ids), seen ids taken from
+    each row's own winners, and targets PLANTED at known oracle ranks (uniform in 1..100, absent for ~15 % of the rows) so that the
+    metrics are not trivially 0 or 1 (trained checkpoints are git-LFS pointers: SURVEY.md section 2).  Both sides run the reference's
+    harness arithmetic (data/eval.py:194-243: rank of the target in the returned ids, HR@k = rank <= k, NDCG@k, MRR) on their OWN
+    returned ids; the GPU side goes through rails_amd.eval_harness (get_eval_state + eval_metrics_v2_from_tensors, the reference's
+    protocol incl. its k / k' / truncate rules).  Not timed; runs after the headline region."""
+    from oracle import mol_oracle as O
+    from rails_amd import eval_harness as H
+
+    N = n_items
+    X = torch.from_numpy(O.hash_item_table(2, 0, N, cfg.item_embedding_dim)).unsqueeze(0)
+    ids = (torch.arange(N, dtype=torch.int64) * 3 + 7).unsqueeze(0)          # sparse ids, as the datasets have
+    q = O.synthetic_queries(cfg, B, seed=5)
+    g = torch.Generator().manual_seed(6)
+    uid = torch.randint(0, 5000, (B,), generator=g) if len(cfg.uid_embedding_hash_sizes) else None
+    width = 40
+    seen = torch.zeros((B, width), dtype=torch.int64)
+    t0 = time.perf_counter()
+    rs, ri, _ = O.brute_force_topk(cfg, weights, q, X, ids, O.k_prime(k, seen, N, kp), uid)
+    oracle_s = time.perf_counter() - t0
+    for b in range(B):   # 20 of each row's own top-60, so that the filter really removes winners
+        seen[b, :20] = ri[b, torch.randperm(60, generator=g)[:20]]
+    ref_ids, ref_sc = O.filter_seen_ids(ri, rs, seen, k)
+    planted = torch.randint(0, 100, (B,), generator=g)
+    target = ref_ids[torch.arange(B), planted].clone()
+    target[torch.rand(B, generator=g) < 0.15] = ids[0, -1]   # an id that is practically never retrieved
+    target = target.unsqueeze(1)
+    ref = O.eval_metrics(ref_ids, target, k)
+
+    class Enc:      # the encoder is upstream of the path: replay the query embeddings
+        def encode(self, **kw):
+            return q.to(dev)
+
+        def get_item_embeddings(self, item_ids):
+            return X.to(dev)[0][(item_ids.to(dev) - 7) // 3]
+
+    model = Enc()
+    model._ndp_module = mol
+    feats = H.SequentialFeatures(torch.full((B,), width), seen.to(dev), None, {"user_ids": uid.to(dev)} if uid is not None else {})
+    with torch.inference_mode():
+        state = H.get_eval_state(model, ids[0].tolist(), None, lambda e, i: rails_amd.MoLBruteForceTopK(mol, e, i), dev)
+        got = H.eval_metrics_v2_from_tensors(state, model, feats, target.to(dev), include_eval_time=True, include_eval_top_k_ids=True)
+    got_ids = got["eval_top_k_ids"].cpu()
+    out = {"what": f"HIP path vs CPU oracle chain, {N} items of the workload's shape, B = {B}, k = {k}, k' = {kp} (timing protocol), 20 seen ids per row, "
+                   "targets planted at oracle ranks 1..100 (15 % absent)",
+           "identical_rows": int((got_ids == ref_ids).all(1).sum()), "rows": B,
+           "ids_identical_fraction": float((got_ids == ref_ids).float().mean()), "oracle_cpu_seconds": oracle_s}
+    for key in ("hr@1", "hr@5", "hr@10", "hr@50", "hr@100", "ndcg@10", "mrr"):
+        mine, theirs = got[key].float().cpu(), ref[key].float()
+        out[key] = {"hip": float(mine.mean()), "oracle": float(theirs.mean()), "rows_differing": int(((mine - theirs).abs() > 1e-6).sum())}
+    # rows whose ids differ from the oracle's: only swaps inside groups of ORACLE scores closer than the two paths' rounding (2e-5; SURVEY.md
+    # section 7 "bit-exact indices vs ties") -- same id set, and at every differing position the oracle's scores of the two ids are that close
+    tie_rows = 0
+    for b in range(B):
+        if bool((got_ids[b] == ref_ids[b]).all()):
+            continue
+        pos_of = {int(v): j for j, v in enumerate(ref_ids[b].tolist())}
+        diff = (got_ids[b] != ref_ids[b]).nonzero().flatten().tolist()
+        if set(got_ids[b].tolist()) == set(pos_of) and all(abs(float(ref_sc[b, j]) - float(ref_sc[b, pos_of[int(got_ids[b, j])]])) <= 2e-5 for j in diff):
+            tie_rows += 1
+    out["rows_differing_only_inside_oracle_ties"] = tie_rows
+    out["parity"] = bool(out["identical_rows"] + tie_rows == B and all(out[key]["rows_differing"] == 0 for key in ("hr@1", "hr@5", "hr@10", "hr@50", "hr@100", "ndcg@10", "mrr")))
+    return out
+
+
+PLANTED_GATE_KEYS = ("_gating_fn._query_only_partial_module.2.weight", "_gating_fn._item_only_partial_module.3.weight",
+                     "_gating_fn._qi_partial_module.3.weight", "_gating_fn._qi_partial_module.3.bias")
+
+
+def planted_weights(weights: dict, gate_scale: float = 0.25) -> dict:
+    """Random-init MoL weights with the gate networks' output layers scaled down: near-uniform mixture weights, so that MoL ~ the
+    coarse dot product + a gate perturbation and a two-pass search has structure to find.  (At the reference's plain random init the
+    coarse score of pass 1 is uncorrelated with the MoL logit and recall is ~ K'/N whatever the implementation.)"""
+    w = dict(weights)
+    for key in PLANTED_GATE_KEYS:
+        w[key] = w[key] * gate_scale
+    return w
+
+
+def two_pass_recall(at, q, k: int, chunk: int = 8) -> dict:
+    """recall@10 / recall@k of a two-pass module (MoLAvgTopK semantics: coarse top-K' + MoL rerank, rails/indexing/mol_top_k.py:328-396)
+    against EXACT brute force over the same shard: the exact side scores every item with the module's own fp32 kernels (`chunk`
+    queries = chunk * N * 4 bytes of logits at a time) and selects with the exact top-k."""
+    _, got = at(q, k=k)
+    hits10 = hitsk = 0
+    B = q.shape[0]
+    for b0 in range(0, B, chunk):
+        logits = at.all_logits(q[b0 : b0 + chunk])
+        _, truth = E.topk(logits, k, ids=at._ids_flat)
+        del logits
+        for r in range(truth.shape[0]):
+            mine, ref = got[b0 + r].tolist(), truth[r].tolist()
+            hits10 += len(set(mine[:10]) & set(ref[:10]))
+            hitsk += len(set(mine) & set(ref))
+    return {"recall@10": hits10 / (B * 10), f"recall@{k}": hitsk / (B * k), "k": k, "queries": B,
+            "against": "exact brute-force MoL top-k over the same items (fp32 kernels, every item scored)"}
+
+
 def full_shard_legs(B: int, k: int, dev) -> list:
     """BASELINE.json configs 4 and 5 at the size of ONE 8-way shard on this GPU (12.5 M items of 16x16x64, exact top-k in three precisions;
     125 M items of 8x8x32, two-pass MoLAvgTopK with K' = 1000): what each of the 8 ranks of `--gpus 8 --workload synthetic-*` runs before the
@@ -317,6 +417,15 @@ def full_shard_legs(B: int, k: int, dev) -> list:
                     leg["coarse_table_bytes"] = int(mod._table().numel() * mod._table().element_size())
                     # the whole step (prologue, sample + select scan, key selection, gather, rerank, final top-k) against ONE read of the table
                     leg["hbm_frac_lower_bound"] = leg["coarse_table_bytes"] / dt / 8.0e12
+                    # north_star: "recall@k vs exact reported".  On the planted-structure weights (the plain random init has nothing
+                    # for a two-pass search to find): the module is rebuilt on the same table -- one 160 GB index at a time
+                    del mod, cand
+                    torch.cuda.empty_cache()
+                    w_p = planted_weights(O.synthetic_weights(cfg, seed=0))
+                    mol.load_state_dict({kk: vv.to(dev) if torch.is_tensor(vv) else vv for kk, vv in w_p.items()}, strict=True)
+                    mod = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=1000)
+                    leg["recall"] = {**two_pass_recall(mod, q, k), "avg_top_k": 1000, "weights": "planted structure: gate output layers x 0.25"}
+                    cand = None
                 elif variant == "fp32" or variant == "f16x3":
                     tf = B * n * flops_per_pair(cfg) / dt / 1e12       # lower bound: the step also holds the prologue and the selection
                     leg["tflops_algorithmic_lower_bound"] = tf
@@ -352,6 +461,8 @@ def main() -> None:
     ap.add_argument("--no-fast-path", action="store_true", help="skip the extra f16x3 measurement")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the secondary ML-20M / ML-1M measurements")
     ap.add_argument("--no-matrix", action="store_true", help="skip the B = 1 / 8 and accuracy-protocol points")
+    ap.add_argument("--no-recall", action="store_true", help="--two-pass: skip the recall@k measurement against exact brute force (planted-structure weights)")
+    ap.add_argument("--no-hr-parity", action="store_true", help="skip the HR@k / NDCG / MRR comparison with the CPU oracle chain (the metric's quality half)")
     ap.add_argument("--no-full-shards", action="store_true", help="skip the legs that run one full 8-way shard of BASELINE configs 4 and 5 (12.5 M / 125 M items) on this GPU")
     ap.add_argument("--items", type=int, default=0, help="override the workload's corpus size N (total over all ranks)")
     ap.add_argument("--device-table", action="store_true",
@@ -392,10 +503,18 @@ def main() -> None:
     if world > 1:
         import torch.distributed as dist
 
+        import datetime
+
+        # a hung collective must end the run with rc != 0, not with a number: 60 s per collective, asynchronous errors tear the process down
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
         if test_backend:
-            dist.init_process_group(test_backend)
+            dist.init_process_group(test_backend, timeout=datetime.timedelta(seconds=60))
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            if torch.cuda.device_count() < world:
+                raise SystemExit(f"--gpus {world} needs {world} visible devices, found {torch.cuda.device_count()} (one rank per GPU over RCCL)")
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=60))
+            if dist.get_backend() != "nccl":
+                raise SystemExit(f"backend is {dist.get_backend()}, expected nccl (= RCCL on ROCm)")
 
     def all_gather_rows(msg):
         """(B, W) -> (world * B, W), rank-major.  RCCL over xGMI; host-staged only under the test hook."""
@@ -444,6 +563,35 @@ def main() -> None:
         g = torch.Generator().manual_seed(3)
         uid_cpu = torch.randint(0, cfg.uid_embedding_hash_sizes[0], (B,), generator=g, dtype=torch.int64)
         kw["user_ids"] = uid_cpu.to(dev)
+
+    recall_info = None
+    if two_pass and not args.no_recall:
+        # north_star: config 5 "with recall@k vs exact reported".  Untimed, BEFORE the timed module exists (one index per rank at a
+        # time: a full shard's is 160 GB): the same two-pass module on planted-structure weights against exact brute force over the
+        # whole (sharded) corpus -- every item scored by the fp32 kernels, exact local top-k, the same all-gather + merge.
+        with torch.inference_mode():
+            mol.load_state_dict({kk: vv.to(dev) for kk, vv in planted_weights(weights).items()}, strict=True)
+            mod_p = ShardedMoLAvgTopK(mol, X, ids, N, avg_top_k=args.two_pass)
+            k_r = min(k, args.two_pass)
+            _, got = mod_p(q, k=k_r, **kw)
+            local_p = mod_p._local_module
+            hits10 = hitsk = 0
+            for b0 in range(0, B, 8):
+                lg = local_p.all_logits(q[b0 : b0 + 8], **{kk: vv[b0 : b0 + 8] for kk, vv in kw.items()})
+                s_, top_ = E.topk(lg, min(k_r, hi - lo), ids=local_p._ids_flat)
+                del lg
+                if world > 1:
+                    s_, top_ = E.merge_candidates(all_gather_rows(E.pack_candidates(s_, top_, k_r)), world, k_r, k_r)
+                for r in range(top_.shape[0]):
+                    mine, ref = got[b0 + r].tolist(), top_[r].tolist()
+                    hits10 += len(set(mine[:10]) & set(ref[:10]))
+                    hitsk += len(set(mine) & set(ref))
+            recall_info = {"recall@10": hits10 / (B * 10), f"recall@{k_r}": hitsk / (B * k_r), "k": k_r, "queries": B, "avg_top_k_per_shard": args.two_pass,
+                           "against": "exact brute-force MoL top-k over the whole corpus (every item of every shard scored by the fp32 kernels, same all-gather + merge)",
+                           "weights": "planted structure (gate output layers x 0.25); the timed region below uses the plain random init, where pass 1 is uncorrelated with MoL"}
+            del mod_p, local_p
+            torch.cuda.empty_cache()
+            mol.load_state_dict({kk: vv.to(dev) for kk, vv in weights.items()}, strict=True)
 
     with torch.inference_mode():
         t0 = time.perf_counter()
@@ -583,7 +731,52 @@ def main() -> None:
             p_elapsed = time.perf_counter() - tp
             tpp = torch.tensor([p_elapsed], dtype=torch.float64, device="cpu" if test_backend else dev)
             dist.all_reduce(tpp, op=dist.ReduceOp.MAX)
+            # ---- in-run correctness evidence (pytest does not run on the multi-GPU node: the line must carry its own) ----
+            k_loc = min(kp, hi - lo)
+            qpack, _, _ = eng.query_pack(q, kw.get("user_ids"))
+            eng.score_dense(qpack, B, local._index, out=logits)
+            ls_, li_ = E.topk(logits, k_loc, ids=local._ids_flat)
+            ms_, mi_ = E.merge_candidates(all_gather_rows(E.pack_candidates(ls_, li_, kp)), world, kp, kp)    # merged top-k', before the filter
+            fin_i, fin_s = step()
+
+            def gather_i64(t):   # (n,) int64 per rank -> (world, n)
+                return all_gather_rows(t.reshape(1, -1).to(torch.int64).contiguous())
+
+            # (1) every rank holds the same final (ids, score bits): a 64-bit mix of both, all-gathered
+            mix = (fin_i * 0x9E3779B97F4A7C15 + fin_s.contiguous().view(torch.int32).to(torch.int64) * 0xC2B2AE3D27D4EB4F
+                   + torch.arange(fin_i.numel(), device=dev, dtype=torch.int64).view_as(fin_i) * 0x165667B19E3779F9)
+            digest = gather_i64(mix.sum().reshape(1))
+            all_identical = bool((digest == digest[0]).all())
+            # (2) merged == unsharded: the item rows of every rank's local top-k' are all-gathered, ONE device scores their union (a
+            #     superset of every query's candidates: anything that beats a query's k'-th overall is in its shard's local top-k') as a
+            #     corpus of its own and selects.  Ids sorted ascending = global position order, so ties break as in the whole corpus;
+            #     the scoring kernels return the same bits whatever the corpus size (small-unit and 32x32x2 shells alike).
+            rows = X[0].index_select(0, (li_.reshape(-1) - (lo + 1)).clamp(min=0))
+            g_rows = all_gather_rows(rows.reshape(1, -1)).view(-1, X.shape[2])
+            g_ids = gather_i64(li_.reshape(-1)).reshape(-1)
+            u_ids = torch.unique(g_ids, sorted=True)
+            order = torch.argsort(g_ids, stable=True)
+            keep = torch.ones_like(order, dtype=torch.bool)
+            keep[1:] = g_ids[order][1:] != g_ids[order][:-1]
+            u_rows = g_rows[order][keep]
+            assert u_rows.shape[0] == u_ids.numel()
+            union = rails_amd.MoLBruteForceTopK(mol, u_rows.unsqueeze(0).contiguous(), u_ids.unsqueeze(0))
+            us_, ui_ = union(q, k=kp, **kw)
+            merged_equals_unsharded = bool(torch.equal(us_, ms_) and torch.equal(ui_, mi_))
+            # (3) per shard: nothing outside the merged list beats its k'-th score
+            kth = ms_[:, -1:]
+            above_local = (logits > kth).sum(1)
+            mine_in_merged = ((mi_ > lo) & (mi_ <= hi) & (ms_ > kth)).sum(1)
+            ok_local = torch.tensor([int(bool((above_local == mine_in_merged).all()))], dtype=torch.int64, device=dev)
+            nothing_outside = bool((gather_i64(ok_local) == 1).all())
+            sharded_check = {"all_ranks_identical": all_identical, "merged_equals_unsharded": merged_equals_unsharded,
+                             "nothing_outside_beats_kth": nothing_outside, "union_items": int(u_ids.numel()),
+                             "how": "digest of (ids, score bits) all-gathered; union of every rank's local top-k' rows re-scored and re-selected on one device; "
+                                    "per-shard count of logits above the merged k'-th"}
+            if not (all_identical and merged_equals_unsharded and nothing_outside):
+                raise SystemExit(f"sharded result failed its in-run check: {sharded_check}")
             sharded_info = {
+                "check": sharded_check,
                 "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(),
                 "exchange": "one all_gather_into_tensor of (B, 2k') int64 per batch" + (" (host-staged: test hook)" if test_backend else " on device tensors"),
                 "message_bytes_per_rank": B * 2 * kp * 8,
@@ -591,6 +784,18 @@ def main() -> None:
                 "pipelined": {"ms_per_step": float(tpp.item()) / args.steps * 1e3, "value": B * args.steps / float(tpp.item()), "unit": "queries/s",
                               "output_equal_to_unpipelined": equal, "headline_uses_it": bool(pipelined_headline)},
             }
+        if world > 1 and two_pass:
+            # the approximate mode has no unsharded twin to equal (K' per shard); what the line can carry is that every rank ends with
+            # the same (ids, score bits), plus the recall measurement above
+            fin_i, fin_s = step()
+            mix = (fin_i * 0x9E3779B97F4A7C15 + fin_s.contiguous().view(torch.int32).to(torch.int64) * 0xC2B2AE3D27D4EB4F
+                   + torch.arange(fin_i.numel(), device=dev, dtype=torch.int64).view_as(fin_i) * 0x165667B19E3779F9)
+            digest = all_gather_rows(mix.sum().reshape(1, 1))
+            same = bool((digest == digest[0]).all())
+            if not same:
+                raise SystemExit("sharded two-pass result differs between ranks")
+            sharded_info = {"check": {"all_ranks_identical": same}, "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size(),
+                            "exchange": "one all_gather_into_tensor of (B, 2k') int64 per batch" + (" (host-staged: test hook)" if test_backend else " on device tensors")}
         per_step_ms = [ev_step[i].elapsed_time(ev_step[i + 1]) for i in range(args.steps)]
         if two_pass:
             # the dominant kernel chain of this mode is the fused coarse top-K' (HBM-bound scan of the bf16 table):
@@ -855,6 +1060,8 @@ def main() -> None:
                     out["roofline"]["traffic"] = tr
                     out["roofline"]["traffic_source"] = ("profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the select-scan launch on this "
                                                          "workload; FETCH_SIZE x 2 on gfx950; not collected in this run)")
+        if two_pass and recall_info is not None:
+            out["recall"] = recall_info
         if sharded_info is not None:
             out["sharded"] = sharded_info
         if fast is not None:
@@ -876,6 +1083,16 @@ def main() -> None:
             except Exception as e:   # noqa: BLE001 -- a secondary leg must not take the headline line down with it (e.g. a smaller device)
                 out["full_shards"] = [{"skipped": f"{type(e).__name__}: {e}"[:300]}]
                 torch.cuda.empty_cache()
+        if world == 1 and not two_pass and not args.no_hr_parity:
+            # the quality half of the metric + the reference's own CSV line (eval_from_checkpoint.py:507-515; BatchTimeMs = this run's step)
+            hp = hr_parity_leg(cfg, weights, mol, B, 120, 200, dev)   # the harness's own timing-protocol constants (data/eval.py:128-130)
+            out["hr_parity"] = hp
+            out["reference_csv"] = {"header": "HR@1,HR@5,HR@10,HR@50,HR@100,BatchTimeMsAvg,BatchTimeMsDev",
+                                    "row": ",".join([f"{hp[m]['hip']}" for m in ("hr@1", "hr@5", "hr@10", "hr@50", "hr@100")]
+                                                    + [f"{out['ms_per_step']:.3f}", f"{out['ms_per_step_stdev']:.3f}"]),
+                                    "oracle_row": ",".join(f"{hp[m]['oracle']}" for m in ("hr@1", "hr@5", "hr@10", "hr@50", "hr@100")),
+                                    "note": "HR columns: hr_parity sub-corpus with planted targets (HIP path; oracle_row = the CPU oracle chain on the same inputs); "
+                                            "time columns: the headline step of this run"}
         if world == 1 and not args.no_cpu_baseline and not two_pass:   # the CPU baseline is the exact path
             out["cpu_baseline"] = cpu_baseline(cfg, weights, q_cpu, uid_cpu, N, min(args.cpu_sample_items or N, N), kp)
         print(json.dumps(out), flush=True)

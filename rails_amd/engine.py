@@ -159,6 +159,21 @@ def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+_EMPTY_INV: Dict[torch.device, torch.Tensor] = {}
+
+
+def _inv_ptr(invalid_ids: Optional[torch.Tensor]) -> C.c_void_p:
+    """Pointer of a (rows, width) seen-id tensor for the entry points that filter.  A zero-WIDTH tensor (a workload without history:
+    BASELINE configs 4 and 5) has a null data_ptr, which the C ABI reads as "no filter requested": hand it one never-read word instead,
+    so that `width == 0` keeps meaning "filter with nothing to remove" (k of the k' winners, same outputs contract)."""
+    if invalid_ids is None or invalid_ids.numel() > 0:
+        return _ptr(invalid_ids)
+    dev = invalid_ids.device
+    if dev not in _EMPTY_INV:
+        _EMPTY_INV[dev] = torch.zeros(1, dtype=torch.int64, device=dev)
+    return _ptr(_EMPTY_INV[dev])
+
+
 def _require_device(t: torch.Tensor, what: str) -> None:
     if not t.is_cuda:
         raise RuntimeError(
@@ -425,7 +440,7 @@ class MolEngine:
             if between is None:
                 _lib.check(
                     self.lib.rails_mol_score_topk(C.byref(self.dense_shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(index.buf), index.n_items, k, _ptr(ids), stride,
-                                                  _ptr(logits_out), ld, _ptr(invalid_ids), width, k_out if invalid_ids is not None else 0,
+                                                  _ptr(logits_out), ld, _inv_ptr(invalid_ids), width, k_out if invalid_ids is not None else 0,
                                                   _ptr(out_s), _ptr(out_i), _ptr(ws), ws.numel(), _stream()),
                     "rails_mol_score_topk",
                 )
@@ -433,7 +448,7 @@ class MolEngine:
                 _lib.check(self.lib.rails_mol_score_survivors(C.byref(self.dense_shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(index.buf), index.n_items, k,
                                                               _ptr(logits_out), ld, _ptr(ws), ws.numel(), _stream()), "rails_mol_score_survivors")
                 between()
-                _lib.check(self.lib.rails_select_survivors(batch, k, _ptr(ids), stride, _ptr(invalid_ids), width, k_out if invalid_ids is not None else 0,
+                _lib.check(self.lib.rails_select_survivors(batch, k, _ptr(ids), stride, _inv_ptr(invalid_ids), width, k_out if invalid_ids is not None else 0,
                                                            _ptr(out_s), _ptr(out_i), _ptr(ws), ws.numel(), _stream()), "rails_select_survivors")
         status = ws[4 * batch: 4 * batch + 4].view(torch.int32)
         if invalid_ids is not None:
@@ -749,7 +764,7 @@ def topk_filtered(scores: torch.Tensor, k_prime: int, ids: Optional[torch.Tensor
     ws_bytes = lib.rails_topk_workspace_bytes(rows, n, k_prime)
     ws = workspace if workspace is not None and workspace.numel() >= ws_bytes and workspace.device == scores.device else torch.empty(ws_bytes, dtype=torch.uint8, device=scores.device)
     with _on_device(scores.device):
-        _lib.check(lib.rails_topk_filtered(_ptr(scores), scores.stride(0), rows, n, k_prime, _ptr(ids), stride, _ptr(invalid_ids), invalid_ids.shape[1], k,
+        _lib.check(lib.rails_topk_filtered(_ptr(scores), scores.stride(0), rows, n, k_prime, _ptr(ids), stride, _inv_ptr(invalid_ids), invalid_ids.shape[1], k,
                                            _ptr(out_i), _ptr(out_s), _ptr(ws), ws_bytes, _pred(run_if), _stream()), "rails_topk_filtered")
     return out_i, out_s
 
@@ -830,7 +845,7 @@ def merge_candidates_filtered(gathered: torch.Tensor, n_ranks: int, k: int, k_pr
     out_s = torch.empty((rows, k_out), dtype=torch.float32, device=gathered.device)
     out_i = torch.empty((rows, k_out), dtype=torch.int64, device=gathered.device)
     with _on_device(gathered.device):
-        _lib.check(lib.rails_merge_candidates_filtered(_ptr(gathered), n_ranks, rows, k, k_prime, _ptr(invalid_ids), invalid_ids.shape[1], k_out,
+        _lib.check(lib.rails_merge_candidates_filtered(_ptr(gathered), n_ranks, rows, k, k_prime, _inv_ptr(invalid_ids), invalid_ids.shape[1], k_out,
                                                        _ptr(out_i), _ptr(out_s), _stream()), "rails_merge_candidates_filtered")
     return out_i, out_s
 
@@ -848,7 +863,7 @@ def filter_seen_ids(top_ids: torch.Tensor, top_scores: torch.Tensor, invalid_ids
     out_s = torch.empty((rows, k), dtype=torch.float32, device=top_ids.device)
     with _on_device(top_ids.device):
         _lib.check(
-            lib.rails_filter_seen_ids(_ptr(top_ids), _ptr(top_scores), rows, kp, _ptr(inv), inv.shape[1], k, _ptr(out_i), _ptr(out_s), _stream()),
+            lib.rails_filter_seen_ids(_ptr(top_ids), _ptr(top_scores), rows, kp, _inv_ptr(inv), inv.shape[1], k, _ptr(out_i), _ptr(out_s), _stream()),
             "rails_filter_seen_ids",
         )
     return out_i, out_s.to(score_dtype)

@@ -64,3 +64,12 @@ def test_live_bench_line():
     d = json.loads(lines[0])
     check_line(d, expect_cpu_baseline=False)
     assert d["steps"] == 3 and d["warmup"] == 1 and d["n_gpus"] == 1
+    # the quality half of BASELINE.json's metric ("+ HR@10/50 parity") rides on the line: HIP path vs the CPU oracle chain, row by row
+    hp = d["hr_parity"]
+    assert hp["parity"] is True and hp["identical_rows"] + hp["rows_differing_only_inside_oracle_ties"] == hp["rows"] == d["config"]["global_batch"]
+    assert hp["identical_rows"] >= hp["rows"] - 2
+    for key in ("hr@1", "hr@5", "hr@10", "hr@50", "hr@100", "ndcg@10", "mrr"):
+        assert hp[key]["rows_differing"] == 0 and hp[key]["hip"] == hp[key]["oracle"]
+    assert 0.0 < hp["hr@50"]["hip"] < hp["hr@100"]["hip"] < 1.0      # planted targets: neither trivially 0 nor 1
+    csv = d["reference_csv"]                                           # eval_from_checkpoint.py:507-515
+    assert csv["header"] == "HR@1,HR@5,HR@10,HR@50,HR@100,BatchTimeMsAvg,BatchTimeMsDev" and len(csv["row"].split(",")) == 7

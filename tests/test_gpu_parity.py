@@ -682,6 +682,25 @@ def test_small_unit_kernel_returns_the_bits_of_the_32x32_kernels(dev, monkeypatc
     assert float((outs["7"][:, cols.to(dev)].cpu() - ref).abs().max()) <= LOGIT_TOL
 
 
+def test_seen_id_filters_with_zero_width_history(dev):
+    """A workload without history (BASELINE configs 4 and 5: seen-id width 0) hands the filters a (rows, 0) tensor, whose data pointer
+    is null: every filtering entry point must treat it as "nothing to remove" -- the first k of the k' winners -- not as a NULL argument
+    (the sharded bench of the 16x16x64 shape died on exactly that before round 4)."""
+    g = torch.Generator().manual_seed(3)
+    rows, n, kp, k = 5, 5000, 200, 120
+    scores = torch.randn((rows, n), generator=g).to(dev)
+    ids = (torch.arange(n, dtype=torch.int64) * 2 + 1).to(dev)
+    inv = torch.zeros((rows, 0), dtype=torch.int64, device=dev)
+    s, i = E.topk(scores, kp, ids=ids)
+    fi, fs = E.filter_seen_ids(i, s, inv, k)
+    assert torch.equal(fi, i[:, :k]) and torch.equal(fs, s[:, :k])
+    ti, ts = E.topk_filtered(scores, kp, ids, inv, k)
+    assert torch.equal(ti, i[:, :k]) and torch.equal(ts, s[:, :k])
+    msg = E.pack_candidates(s, i, kp)
+    mi, ms = E.merge_candidates_filtered(msg, 1, kp, kp, inv, k)
+    assert torch.equal(mi, i[:, :k]) and torch.equal(ms, s[:, :k])
+
+
 def test_bf16_module_and_inputs_round_trip(dev):
     """eval_batch.py runs --eval_dtype=bf16 (model and item table cast to bf16): parameters and inputs are
     up-cast, arithmetic stays fp32, outputs come back in the query dtype."""

@@ -125,22 +125,49 @@ def test_two_ranks_16x16x64(precision):
     assert torch.equal(ret[0][1], ret[1][1]) and torch.equal(ret[0][2], ret[1][2])
 
 
-def test_bench_self_spawns_two_ranks():
-    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE (how the driver may call it) must re-exec itself under
-    torch.distributed.run and print one JSON line with n_gpus = 2."""
+def _bench_two_ranks(*extra):
     env = dict(os.environ)
     for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(v, None)
     if torch.cuda.device_count() < 2:
         env["RAILS_BENCH_TEST_BACKEND"] = "gloo"     # both ranks on GPU 0; the message is staged through the host
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--items", "200000",
-                          "--no-cpu-baseline", "--no-other-workloads"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-other-workloads", *extra], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong"
-    assert d["config"]["n_items"] == 200000 and "roofline" in d
+    assert d["n_gpus"] == 2 and d["steps"] == 3
+    assert d["sharded"]["rccl_ranks"] == 2 and d["sharded"]["backend"] in ("nccl", "gloo")
+    return d
+
+
+def test_bench_self_spawns_two_ranks():
+    """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE (how the driver may call it) must re-exec itself under
+    torch.distributed.run and print one JSON line with n_gpus = 2 -- a line that carries its own correctness evidence (pytest does
+    not run on the multi-GPU node): every rank ends with the same result, the merged top-k' equals a one-device recompute over the
+    union of the shards' candidates, and no shard holds anything that beats the merged k'-th."""
+    d = _bench_two_ranks("--items", "200000")
+    assert d["scaling"] == "strong" and d["config"]["n_items"] == 200000 and "roofline" in d
     sh = d["sharded"]
-    assert sh["rccl_ranks"] == 2 and sh["backend"] in ("nccl", "gloo") and sh["pipelined"]["output_equal_to_unpipelined"] is True
+    assert sh["pipelined"]["output_equal_to_unpipelined"] is True
     assert set(sh["phase_ms"]) == {"score", "select_and_pack", "all_gather", "merge_and_filter"}
+    chk = sh["check"]
+    assert chk["all_ranks_identical"] is True and chk["merged_equals_unsharded"] is True and chk["nothing_outside_beats_kth"] is True
+    assert 200 <= chk["union_items"] <= 2 * 32 * 200
+
+
+def test_bench_two_ranks_on_the_256_logit_shape():
+    """BASELINE config 4's shape (16x16x64, the team kernel) through the same self-verifying sharded run."""
+    d = _bench_two_ranks("--workload", "synthetic-16x16x64", "--items", "40000", "--no-fast-path")
+    chk = d["sharded"]["check"]
+    assert chk["all_ranks_identical"] is True and chk["merged_equals_unsharded"] is True and chk["nothing_outside_beats_kth"] is True
+
+
+def test_bench_two_ranks_two_pass_reports_recall():
+    """BASELINE config 5's mode (two-pass: coarse prefilter + MoL rerank) on two ranks: same result on every rank, recall@k against exact
+    brute force over the whole sharded corpus on the line."""
+    d = _bench_two_ranks("--workload", "synthetic-8x8x32", "--items", "600000", "--two-pass", "500")
+    assert d["sharded"]["check"]["all_ranks_identical"] is True
+    r = d["recall"]
+    assert 0.0 < r["recall@10"] <= 1.0 and 0.0 < r[f"recall@{r['k']}"] <= 1.0 and r["avg_top_k_per_shard"] == 500
