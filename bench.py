@@ -355,7 +355,7 @@ def two_pass_recall(at, q, k: int, chunk: int = 8) -> dict:
 def full_shard_legs(B: int, k: int, dev) -> list:
     """BASELINE.json configs 4 and 5 at the size of ONE 8-way shard on this GPU (12.5 M items of 16x16x64, exact top-k in three precisions;
     125 M items of 8x8x32, two-pass MoLAvgTopK with K' = 1000): what each of the 8 ranks of `--gpus 8 --workload synthetic-*` runs before the
-    all-gather, timed through the module API.  Device-generated item tables (truncated normal, sigma 0.02).  A leg is skipped, and says so,
+    all-gather, timed through the module API.  Item tables drawn on the device by the counter hash (rails_hash_item_table).  A leg is skipped, and says so,
     when the device lacks the memory for it (config 5 needs ~210 GB: 32 GB table + 160 GB index + 8 GB coarse table + buffers)."""
     import gc
     from oracle import mol_oracle as O
@@ -370,11 +370,7 @@ def full_shard_legs(B: int, k: int, dev) -> list:
         mol.load_state_dict(O.synthetic_weights(cfg, seed=0), strict=True)
         mol = mol.to(dev).eval()
         mol.precision = None if precision == "fp32" else precision
-        X = torch.empty((1, n, cfg.item_embedding_dim), dtype=torch.float32, device=dev)
-        g = torch.Generator(device=dev).manual_seed(1000)
-        for s0 in range(0, n, 8_000_000):
-            n0 = min(8_000_000, n - s0)
-            X[0, s0 : s0 + n0] = torch.fmod(torch.randn((n0, cfg.item_embedding_dim), generator=g, device=dev), 2.0) * 0.02
+        X = E.hash_item_table(1, 0, n, cfg.item_embedding_dim, dev).unsqueeze(0)   # counter hash, drawn on the device (reproducible on a CPU by id)
         ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
         return cfg, mol, X, ids, O.synthetic_queries(cfg, B).to(dev)
 
@@ -412,7 +408,7 @@ def full_shard_legs(B: int, k: int, dev) -> list:
                 build_s = time.perf_counter() - t0
                 dt = timed(lambda: cand.get_top_k_outputs(q, k, {}, mod, None), 2, 10 if variant == "two-pass" else 3)
                 leg = {**label, "variant": variant if variant != "two-pass" else "two-pass MoLAvgTopK, K'=1000 (coarse bf16 scan + MoL rerank)", "queries_per_s": B / dt,
-                       "ms_per_step": dt * 1e3, "index_build_s": build_s, "item_table": "device truncated normal"}
+                       "ms_per_step": dt * 1e3, "index_build_s": build_s, "item_table": "device counter hash"}
                 if variant == "two-pass":
                     leg["coarse_table_bytes"] = int(mod._table().numel() * mod._table().element_size())
                     # the whole step (prologue, sample + select scan, key selection, gather, rerank, final top-k) against ONE read of the table
@@ -466,7 +462,7 @@ def main() -> None:
     ap.add_argument("--no-full-shards", action="store_true", help="skip the legs that run one full 8-way shard of BASELINE configs 4 and 5 (12.5 M / 125 M items) on this GPU")
     ap.add_argument("--items", type=int, default=0, help="override the workload's corpus size N (total over all ranks)")
     ap.add_argument("--device-table", action="store_true",
-                    help="draw the item table on the GPU (truncated normal, sigma 0.02) instead of the host counter hash; "
+                    help="draw the item table on the GPU (the same counter hash, rails_hash_item_table) instead of on the host; "
                          "implied above 4 M items per rank (a 125 M-item shard is 32 GB)")
     ap.add_argument("--two-pass", type=int, default=0, metavar="K'",
                     help="BASELINE config 5: MoLAvgTopK(K' per shard) = fused coarse top-K' + MoL rerank, instead of exact "
@@ -545,12 +541,10 @@ def main() -> None:
 
     lo, hi = shard_bounds(N, world, rank)
     if args.device_table or hi - lo > 4_000_000:
-        X = torch.empty((1, hi - lo, cfg.item_embedding_dim), dtype=torch.float32, device=dev)
-        g = torch.Generator(device=dev).manual_seed(1000 + rank)
-        for s0 in range(0, hi - lo, 8_000_000):
-            n0 = min(8_000_000, hi - lo - s0)
-            X[0, s0 : s0 + n0] = torch.fmod(torch.randn((n0, cfg.item_embedding_dim), generator=g, device=dev), 2.0) * 0.02
-        table_kind = "device truncated normal"
+        # the same counter hash, drawn in place in HBM (rails_hash_item_table: bit-equal to the host generator, so any row of any
+        # rank's shard is reproducible on a CPU by id)
+        X = E.hash_item_table(1, lo, hi - lo, cfg.item_embedding_dim, dev).unsqueeze(0)
+        table_kind = "device counter hash (bit-equal to the host generator)"
     else:
         X = torch.from_numpy(O.hash_item_table(1, lo, hi - lo, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
         table_kind = "host counter hash"

@@ -351,6 +351,13 @@ int rails_rescore_select(const float* exact_scores, int64_t ld, const float* app
                          int32_t k, float margin_eps, float check_eps, float* out_scores, int64_t* out_ids, int32_t* row_ok, float* row_stats,
                          void* stream);
 
+/* ---- synthetic corpora (measurement and test infrastructure; no counterpart in the reference, whose item tables are trained) ----
+ * out[(i - first_item) * dim + c] for items first_item <= i < first_item + n_items: a counter-based hash of (seed, i, c) --
+ *   h = splitmix64((i * dim + c) ^ (seed * 0xD1B54A32D192ED03));  value = float(sum of h's four 16-bit lanes - 131070) * scale
+ * -- so any shard or sub-range of a corpus is reproducible without materialising the table, on the device and (bit for bit) on the
+ * host (oracle/mol_oracle.py hash_item_table, scale = float32(sigma * sqrt(3) / 65536): Irwin-Hall(4), std sigma). */
+int rails_hash_item_table(uint64_t seed, int64_t first_item, int64_t n_items, int32_t dim, float scale, float* out, void* stream);
+
 /* ---- seen-id filter --------------------------------------------------------------------------
  * Replaces the row-wise masking of CandidateIndex.get_top_k_outputs (indexing/candidate_index.py:154-178):
  * keep the first k ids of each row of (rows, k_prime) that do not occur in invalid_ids (rows, width),

@@ -429,6 +429,18 @@ def hash_item_table(seed: int, first_item: int, n_items: int, dim: int, sigma: f
     return centred * scale
 
 
+def hash_item_rows(seed: int, items: np.ndarray, dim: int, sigma: float = 0.02) -> np.ndarray:
+    """Rows `items` (any order, any subset) of the same table: what lets a test re-create on the CPU, by id, the handful of rows of a
+    100 M-item shard it wants to check."""
+    items = np.asarray(items, dtype=np.uint64)
+    i = items[:, None] * np.uint64(dim) + np.arange(dim, dtype=np.uint64)[None, :]
+    with np.errstate(over="ignore"):
+        h = _splitmix64(i ^ (np.uint64(seed) * np.uint64(0xD1B54A32D192ED03) & _M64))
+    s = ((h & np.uint64(0xFFFF)) + ((h >> np.uint64(16)) & np.uint64(0xFFFF))
+         + ((h >> np.uint64(32)) & np.uint64(0xFFFF)) + (h >> np.uint64(48))).astype(np.int64)
+    return (s - 2 * 65535).astype(np.float32) * np.float32(sigma * math.sqrt(3.0) / 65536.0)
+
+
 def synthetic_weights(cfg: MoLConfig, seed: int = 0, uid_rows: Optional[int] = None) -> Dict[str, torch.Tensor]:
     """Random-init MoL weights with the reference's initialisers (modeling/similarity_utils.py:34-38,
     rails/similarities/layers.py:29-34, torch.nn.Embedding default)."""

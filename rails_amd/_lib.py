@@ -175,6 +175,7 @@ PROTOTYPES = {
     "rails_rescore_select": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                        C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rails_abi_version": (C.c_int, []),
+    "rails_hash_item_table": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]),
     "rails_mol_gate_combine": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                          C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rails_topk_filter_fusable": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32]),

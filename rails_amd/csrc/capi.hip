@@ -600,6 +600,14 @@ int rails_merge_candidates_filtered(const int64_t* gathered, int32_t n_ranks, in
 
 int rails_abi_version(void) { return RAILS_ABI_VERSION; }
 
+int rails_hash_item_table(uint64_t seed, int64_t first_item, int64_t n_items, int32_t dim, float scale, float* out, void* stream) {
+  g_err[0] = '\0';
+  if (first_item < 0 || n_items < 0 || dim <= 0) { set_error("hash_item_table: bad size"); return RAILS_EINVAL; }
+  if (n_items == 0) return RAILS_OK;
+  if (!out) { set_error("hash_item_table: NULL pointer"); return RAILS_EINVAL; }
+  return fail(hash_item_table(seed, first_item, n_items, dim, scale, out, (hipStream_t)stream), "hash_item_table");
+}
+
 int rails_range_flag_i32(const int32_t* values, int32_t n, int32_t lo, int32_t hi, int32_t* flag, void* stream) {
   g_err[0] = '\0';
   if (n < 0 || (n > 0 && (!values || !flag))) { set_error("range_flag: bad argument"); return RAILS_EINVAL; }

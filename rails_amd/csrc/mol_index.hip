@@ -452,4 +452,33 @@ int index_gather(const Shape& s, const float* ipack, int64_t n, const int64_t* i
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
+// ---- synthetic item table on the device (measurement / test infrastructure) ------------------------------------------------------
+// The counter-hash generator of the synthetic corpora ("generated by a counter-based hash of the item id so any
+// shard / sub-range is reproducible on CPU without materialising the table"), bit-equal to oracle/mol_oracle.py hash_item_table:
+//   h = splitmix64((item * dim + col) ^ (seed * 0xD1B54A32D192ED03));  value = float(sum of h's four 16-bit lanes - 2 * 65535) * scale
+// Integer arithmetic + one exact int -> float conversion + one fp32 multiply: the same bits on every platform.  A 125 M-item shard
+// (32 GB) is drawn in place in HBM instead of being hashed on the host and copied.
+__global__ void hash_item_table_kernel(unsigned long long seed_mix, int64_t first_item, int64_t n_items, int dim, float scale, float* __restrict__ out) {
+  const int64_t total = n_items * dim;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    unsigned long long x = ((unsigned long long)first_item * (unsigned long long)dim + (unsigned long long)i) ^ seed_mix;
+    x += 0x9E3779B97F4A7C15ull;
+    unsigned long long z = x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    const long long s = (long long)((z & 0xFFFFull) + ((z >> 16) & 0xFFFFull) + ((z >> 32) & 0xFFFFull) + (z >> 48)) - 2 * 65535;
+    out[i] = (float)s * scale;
+  }
+}
+
+int hash_item_table(unsigned long long seed, int64_t first_item, int64_t n_items, int dim, float scale, float* out, hipStream_t stream) {
+  const int64_t total = n_items * dim;
+  if (total <= 0) return kOk;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(hash_item_table_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, seed * 0xD1B54A32D192ED03ull, first_item, n_items, dim, scale, out);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 }  // namespace mol

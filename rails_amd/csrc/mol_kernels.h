@@ -147,6 +147,7 @@ int component_score(const Shape& s, const float* eq, int B, const void* table, i
 int sort_rows_i64(const int64_t* in, int rows, int n, int64_t* out, hipStream_t stream);
 int mask_sorted_duplicates(const int64_t* idx, float* scores, int64_t ld, int rows, int n, float fill, hipStream_t stream);
 
+int hash_item_table(unsigned long long seed, int64_t first_item, int64_t n_items, int dim, float scale, float* out, hipStream_t stream);
 int mips_pack_items(const float* items, int64_t n, int D, float* out, hipStream_t stream);
 int mips_score(const float* q, int B, int D, const float* ifrag, int64_t n, float* qfrag_ws, float* logits, int64_t ld,
                int n_cu, hipStream_t stream);

@@ -769,6 +769,21 @@ def topk_filtered(scores: torch.Tensor, k_prime: int, ids: Optional[torch.Tensor
     return out_i, out_s
 
 
+def hash_item_table(seed: int, first_item: int, n_items: int, dim: int, device, sigma: float = 0.02, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """(n_items, dim) fp32 rows of the synthetic counter-hash item table, drawn on the device: the same bits as
+    oracle.mol_oracle.hash_item_table(seed, first_item, n_items, dim, sigma) (include/rails_amd.h rails_hash_item_table)."""
+    import math
+
+    import numpy as np
+
+    if out is None:
+        out = torch.empty((n_items, dim), dtype=torch.float32, device=device)
+    scale = float(np.float32(sigma * math.sqrt(3.0) / 65536.0))
+    with _on_device(out.device):
+        _lib.check(_lib.load().rails_hash_item_table(seed, first_item, n_items, dim, C.c_float(scale), _ptr(out), _stream()), "rails_hash_item_table")
+    return out
+
+
 def range_flag(values: torch.Tensor, lo: int, hi: int, flag: torch.Tensor) -> None:
     """flag |= any(values < lo or values > hi), on the device (rails_range_flag_i32); `flag` is an int32 device scalar the caller zeroed."""
     lib = _lib.load()

@@ -396,7 +396,11 @@ class MoLSimilarity(SimilarityModule):
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
+        # drop the engine outright: load_state_dict copies in place, and under torch.inference_mode() an in-place copy does NOT bump
+        # the parameters' version counters -- the (data_ptr, version) key above would keep serving the old weights
         self._param_list = None
+        self._engine = None
+        self._engine_key = None
         return super().load_state_dict(*args, **kwargs)
 
     # ---- reference API --------------------------------------------------------------------------

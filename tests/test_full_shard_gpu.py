@@ -35,12 +35,14 @@ def _need_free(dev, gb: float) -> None:
 
 
 def _device_table(n: int, dim: int, dev, seed: int) -> torch.Tensor:
-    X = torch.empty((1, n, dim), dtype=torch.float32, device=dev)
-    g = torch.Generator(device=dev).manual_seed(seed)
-    for s in range(0, n, 8_000_000):
-        m = min(8_000_000, n - s)
-        X[0, s : s + m] = torch.fmod(torch.randn((m, dim), generator=g, device=dev), 2.0) * 0.02
-    return X
+    """The counter-hash table of SURVEY.md section 7, drawn on the device (rails_hash_item_table): bit-equal to
+    oracle.hash_item_table, so the rows a test checks against the oracle are re-created ON THE CPU BY ID (_oracle_rows) instead
+    of being copied back from the device."""
+    return E.hash_item_table(seed, 0, n, dim, dev).unsqueeze(0)
+
+
+def _oracle_rows(seed: int, cols: torch.Tensor, dim: int) -> torch.Tensor:
+    return torch.from_numpy(O.hash_item_rows(seed, cols.numpy(), dim)).unsqueeze(0)
 
 
 def _sample_columns(n: int, seed: int) -> torch.Tensor:
@@ -68,7 +70,8 @@ def test_config4_shard_exact_topk_properties(dev, precision):
     assert bool((s[:, :-1] >= s[:, 1:]).all())
     assert int(i.min()) >= 1 and int(i.max()) <= N
     cols = _sample_columns(N, seed=44)
-    ref = O.mol_logits(cfg, w, q, X[:, cols.to(dev)].cpu())
+    assert torch.equal(X[:, cols.to(dev)].cpu(), _oracle_rows(4, cols, cfg.item_embedding_dim))     # the device table IS the host generator's
+    ref = O.mol_logits(cfg, w, q, _oracle_rows(4, cols, cfg.item_embedding_dim))
     d = float((logits[:, cols.to(dev)].cpu() - ref).abs().max())
     assert d <= LOGIT_TOL, d
     assert torch.equal(torch.gather(logits, 1, i - 1), s)
@@ -146,7 +149,7 @@ def test_config5_shard_two_pass_properties(dev):
         assert torch.equal(cs, fs) and torch.equal(cp, fp)
         # exact brute force over the whole shard, eight queries (4 GB of logits) at a time; pass 2 == exact MoL top-k of the candidates
         cols = _sample_columns(N, seed=55).to(dev)
-        ref = O.mol_logits(cfg, w, q, X[:, cols].cpu())
+        ref = O.mol_logits(cfg, w, q, _oracle_rows(5, cols.cpu(), cfg.item_embedding_dim))   # rows re-created on the CPU by id
         hits10 = hitsk = 0
         for b0 in range(0, B, 8):
             logits = at.all_logits(qd[b0 : b0 + 8])

@@ -682,6 +682,16 @@ def test_small_unit_kernel_returns_the_bits_of_the_32x32_kernels(dev, monkeypatc
     assert float((outs["7"][:, cols.to(dev)].cpu() - ref).abs().max()) <= LOGIT_TOL
 
 
+@pytest.mark.parametrize("seed,first,n,dim", [(1, 0, 1000, 64), (7, 123_456_789, 4097, 50), (3, 999_999_000, 33, 256)])
+def test_device_item_table_generator_equals_the_oracle_generator(dev, seed, first, n, dim):
+    """rails_hash_item_table draws the synthetic corpora in HBM with the bits of oracle.hash_item_table (integer hash, one exact
+    int -> float conversion, one fp32 multiply): any row of any shard can be re-created on a CPU by id."""
+    got = E.hash_item_table(seed, first, n, dim, dev).cpu()
+    assert torch.equal(got, torch.from_numpy(O.hash_item_table(seed, first, n, dim)))
+    rows = torch.tensor([0, n // 2, n - 1])
+    assert torch.equal(got[rows], torch.from_numpy(O.hash_item_rows(seed, (rows + first).numpy(), dim)))
+
+
 def test_seen_id_filters_with_zero_width_history(dev):
     """A workload without history (BASELINE configs 4 and 5: seen-id width 0) hands the filters a (rows, 0) tensor, whose data pointer
     is null: every filtering entry point must treat it as "nothing to remove" -- the first k of the k' winners -- not as a NULL argument
@@ -781,6 +791,15 @@ def test_index_follows_parameter_updates(dev):
         fourth = tk.all_logits(q)
     assert float((fourth.cpu() - O.mol_logits(fx.cfg, w2, fx.t("q"), fx.t("X"))).abs().max()) <= LOGIT_TOL
     assert float((fourth - third).abs().max()) > 1e-4
+    # load_state_dict INSIDE torch.inference_mode(): the in-place copy bumps no version counter there (bench.py's recall leg reloads
+    # planted-structure weights that way; the old engine kept scoring with the previous weights before round 4)
+    w5 = {k: v.clone() for k, v in w2.items()}
+    w5["_gating_fn._qi_partial_module.3.weight"] *= 0.25
+    with torch.inference_mode():
+        mol.load_state_dict({k: v.to(dev) for k, v in w5.items()})
+        fifth = tk.all_logits(q)
+    assert float((fifth.cpu() - O.mol_logits(fx.cfg, w5, fx.t("q"), fx.t("X"))).abs().max()) <= LOGIT_TOL
+    assert float((fifth - fourth).abs().max()) > 1e-4
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
