@@ -975,6 +975,9 @@ def main() -> None:
                 "value": B * args.steps / exact_elapsed, "unit": "queries/s", "ms_per_step": exact_elapsed / args.steps * 1e3,
                 "output_identical_to_fp32_path": identical, "rescore_calls": stats["calls"], "dense_fp32_fallbacks": stats["fallbacks"],
                 "shadow_audit": {"audited_calls": stats["audited"], "mismatches": stats["mismatches"]}, "eps": stats.get("eps"),
+                "eps_rigorous": stats.get("eps_rigorous"), "eps_rigorous_usable": stats.get("eps_rigorous_usable"),
+                "guarantee": "conditional on the monitored empirical bound eps (the a-priori bound eps_rigorous is not usable: rails_amd/topk_modules.py rigorous_eps)"
+                             if not stats.get("eps_rigorous_usable") else "unconditional: eps_rigorous <= 4 x the default eps",
             }
 
     if world > 1:

@@ -365,9 +365,58 @@ class MoLBruteForceTopK(MoLTopKModule):
             self._note_verdict(i >= new_redone, k, kc)
 
     def stats(self) -> Dict[str, float]:
-        """rescore_stats brought up to date with the device-side verdicts and the audit counter (synchronises)."""
+        """rescore_stats brought up to date with the device-side verdicts and the audit counter (synchronises), plus the a-priori
+        bound of rigorous_eps() next to the empirical eps the verdicts use."""
         self._absorb_state(wait=True)
-        return self.audit_summary()
+        out = self.audit_summary()
+        eng = self._bind()
+        if eng.exact is not None:
+            out.update(self.rigorous_eps())
+        return out
+
+    def rigorous_eps(self) -> Dict[str, float]:
+        """An A-PRIORI bound on |first pass - fp32 logit| that holds for EVERY (query, item) pair, from the weights alone
+        (dot_product_l2_norm = True: |cl| <= 1/tau).  Per product of two rounded operands the relative error is rho = 2u + u^2, with
+        u = 2^-10 for the one-product pass (operands truncated to f16) and ~2^-21 for f16x3 (hi + lo halves, lo*lo dropped: rho taken
+        as 2^-20).  Propagated with row-L1 norms through the path (rails/similarities/mol/similarity_fn.py:389-413):
+            |d cl|  <= rho / tau
+            |d pre| <= A1 (2 rho + rho^2) / tau                      A1 = max_h ||W1[h, :]||_1   (cl is rounded again as GEMM2's operand)
+            |d gqi| <= A2 (1.1 |d pre| + rho P)                      A2 = max_l ||W2[l, :]||_1,  P = max_h (|b1[h]| + ||W1[h, :]||_1 / tau) >= |hid|,
+                                                                     |silu'| <= 1.1
+            |d w|   <= 1.1 |d gqi|                                   (w = g sigmoid(g); gq, gi are the same fp32 values in both passes)
+            |d s|   <= |d cl| + min(2, 2 |d w|) / tau                (||softmax(w + d) - softmax(w)||_1 <= 2 ||d||_inf, and <= 2 trivially)
+        The verified modes could drop their monitored, empirical eps for this number only where it is not far larger -- it is: the
+        bound adds absolute values where the real errors cancel (random-init amzn-books: 40.0 for the one-product pass, i.e. the
+        trivial |s| <= 1/tau bound, and ~0.2 for f16x3, against observed maxima of 5e-2 and 3e-5).  It is reported so that the
+        guarantee's status is explicit: `eps_rigorous_usable` is False and the modes stay "conditional on the monitored bound"."""
+        eng = self._bind()
+        cached = getattr(self, "_rig_cache", None)
+        if cached is not None and cached[0] is eng:
+            return cached[1]
+        spec = eng.spec
+        sd = self._mol_module.state_dict()
+        single = eng.dense_precision == "f16x1"
+        rho = 2.0 ** -9 + 2.0 ** -20 if single else 2.0 ** -20
+        inv_tau = 1.0 / float(spec.temperature)
+        out: Dict[str, float] = {}
+        w1, b1 = sd.get("_gating_fn._qi_partial_module.1.weight"), sd.get("_gating_fn._qi_partial_module.1.bias")
+        w2 = sd.get("_gating_fn._qi_partial_module.3.weight")
+        if w1 is None or w2 is None or not spec.dot_product_l2_norm:
+            out = {"eps_rigorous": float("inf"), "eps_rigorous_usable": False}
+        else:
+            r1 = w1.float().abs().sum(1)
+            a1, a2 = float(r1.max()), float(w2.float().abs().sum(1).max())
+            p = float((b1.float().abs() + r1 * inv_tau).max())
+            d_cl = rho * inv_tau
+            d_pre = a1 * (2.0 * rho + rho * rho) * inv_tau
+            d_gqi = a2 * (1.1 * d_pre + rho * p)
+            d_w = 1.1 * d_gqi
+            bound = d_cl + min(2.0, 2.0 * d_w) * inv_tau
+            default = (self.RESCORE_EPS_PER_INV_TEMPERATURE_F16X1 if single else self.RESCORE_EPS_PER_INV_TEMPERATURE) * inv_tau
+            out = {"eps_rigorous": bound, "eps_default": default, "eps_rigorous_usable": bool(bound <= 4.0 * default),
+                   "eps_rigorous_terms": {"rho": rho, "A1": a1, "A2": a2, "P": p, "d_cl": d_cl, "d_pre": d_pre, "d_gqi": d_gqi, "d_w": d_w}}
+        self._rig_cache = (eng, out)
+        return out
 
     # Shadow audit: every AUDIT_EVERY-th verified call is ALSO run on the dense fp32 path and compared bit for bit; the counts are in
     # rescore_stats["audited" / "mismatches"] (bench.py reports them).  0 = off.  RAILS_AUDIT_EVERY overrides the default.
