@@ -24,6 +24,10 @@
 #include "mol_kernels.h"
 #include "mol_layout.h"
 
+#ifndef RAILS_BATCHED_PROLOGUE_BYTES
+#define RAILS_BATCHED_PROLOGUE_BYTES (1300 * 1024)   // query-side weights per query beyond which the batched (MFMA) kernels take over
+#endif
+
 namespace mol {
 
 constexpr int kQueryThreads = 1024;  // 16 waves: the prologue is a chain of small dense layers, latency-bound
@@ -98,6 +102,36 @@ __device__ __forceinline__ void wave_dense_t(const float* __restrict__ W, const 
   }
 }
 
+// wave_dense for ONE pass of columns (ncols <= 16 NC) whose input vector still has to come from global memory: the weight loads of
+// the wave's columns are issued FIRST, the input row is copied to LDS under them, then the barrier -- one L2 round trip instead of
+// two in a row.  Same per-column arithmetic as wave_dense_t (k ascending per lane, the same shuffle tree): same bits.
+template <int KPL, int NC>
+__device__ __forceinline__ void wave_dense_prefetched(const float* __restrict__ W, const float* __restrict__ bias, int ncols, int K,
+                                                      const float* __restrict__ src, float* __restrict__ in_s, float* __restrict__ out_s) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = wave * NC;
+  float wv[NC][KPL];
+#pragma unroll
+  for (int j = 0; j < NC; ++j)
+#pragma unroll
+    for (int i = 0; i < KPL; ++i)
+      wv[j][i] = (c0 + j < ncols && lane + 64 * i < K) ? W[(int64_t)(c0 + j) * K + lane + 64 * i] : 0.0f;
+  for (int i = threadIdx.x; i < K; i += kQueryThreads) in_s[i] = src[i];
+  __syncthreads();
+  float xv[KPL];
+#pragma unroll
+  for (int i = 0; i < KPL; ++i) xv[i] = (lane + 64 * i < K) ? in_s[lane + 64 * i] : 0.0f;
+#pragma unroll
+  for (int j = 0; j < NC; ++j) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int i = 0; i < KPL; ++i) acc = __builtin_fmaf(wv[j][i], xv[i], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0 && c0 + j < ncols) out_s[c0 + j] = acc + (bias ? bias[c0 + j] : 0.0f);
+  }
+}
+
 __device__ __forceinline__ void wave_dense(const float* __restrict__ W, const float* __restrict__ bias, int ncols,
                                            int K, const float* __restrict__ in_s, float* __restrict__ out_s,
                                            bool silu) {
@@ -123,6 +157,41 @@ __device__ __forceinline__ void wave_dense(const float* __restrict__ W, const fl
       }
     }
   }
+}
+
+// One pre-activation column of the GLU layer, h[c] = b[c] + sum_k q[k] W[k][c]: a thread owns the column, up to 64 loads in flight
+// (one L2 round trip for D <= 64), FMAs in k order.  Shared by the per-query kernel and the split kernels: same bits.
+__device__ __forceinline__ float glu_column(const QueryArgs& a, const float* qs, int c) {
+  const int D = a.D, QH = a.QH;
+  float acc = 0.0f;
+  int k = 0;
+  for (; k + 64 <= D; k += 64) {
+    float wv[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) wv[i] = a.w.q_glu_w[(int64_t)(k + i) * 2 * QH + c];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc = __builtin_fmaf(qs[k + i], wv[i], acc);
+  }
+  for (; k + 32 <= D; k += 32) {
+    float wv[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) wv[i] = a.w.q_glu_w[(int64_t)(k + i) * 2 * QH + c];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) acc = __builtin_fmaf(qs[k + i], wv[i], acc);
+  }
+  for (; k + 16 <= D; k += 16) {
+    float wv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wv[i] = a.w.q_glu_w[(int64_t)(k + i) * 2 * QH + c];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc = __builtin_fmaf(qs[k + i], wv[i], acc);
+  }
+  for (; k < D; ++k) acc = __builtin_fmaf(qs[k], a.w.q_glu_w[(int64_t)k * 2 * QH + c], acc);
+  return acc + a.w.q_glu_b[c];
+}
+__device__ __forceinline__ float glu_act(const QueryArgs& a, float l, float r) {
+  const float act = a.glu == RAILS_GEGLU ? 0.5f * l * (1.0f + erff(l * 0.70710678118654752440f)) : l / (1.0f + expf(-l));
+  return act * r;
 }
 
 // grid (padded queries, 2): blockIdx.y = 0 computes the query's sub-embeddings (GLU -> projection -> l2norm -> Eq fragments),
@@ -178,39 +247,10 @@ __global__ __launch_bounds__(kQueryThreads) void query_prologue_kernel(QueryArgs
   }
 
   // GLU: h = q W + b (D x 2QH, row-major so lanes stride columns); act(lhs) * rhs.  QH = 0: the projection is a plain Linear
-  for (int c = threadIdx.x; c < 2 * QH; c += kQueryThreads) {
-    float acc = 0.0f;
-    int k = 0;
-    for (; k + 64 <= D; k += 64) {   // 64 loads in flight (one L2 round trip for D = 64), then 64 FMAs in k order
-      float wv[64];
-#pragma unroll
-      for (int i = 0; i < 64; ++i) wv[i] = a.w.q_glu_w[(int64_t)(k + i) * 2 * QH + c];
-#pragma unroll
-      for (int i = 0; i < 64; ++i) acc = __builtin_fmaf(qs[k + i], wv[i], acc);
-    }
-    for (; k + 32 <= D; k += 32) {   // 32 loads in flight, then 32 FMAs in k order
-      float wv[32];
-#pragma unroll
-      for (int i = 0; i < 32; ++i) wv[i] = a.w.q_glu_w[(int64_t)(k + i) * 2 * QH + c];
-#pragma unroll
-      for (int i = 0; i < 32; ++i) acc = __builtin_fmaf(qs[k + i], wv[i], acc);
-    }
-    for (; k + 16 <= D; k += 16) {
-      float wv[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) wv[i] = a.w.q_glu_w[(int64_t)(k + i) * 2 * QH + c];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc = __builtin_fmaf(qs[k + i], wv[i], acc);
-    }
-    for (; k < D; ++k) acc = __builtin_fmaf(qs[k], a.w.q_glu_w[(int64_t)k * 2 * QH + c], acc);
-    glu[c] = acc + a.w.q_glu_b[c];
-  }
+  for (int c = threadIdx.x; c < 2 * QH; c += kQueryThreads) glu[c] = glu_column(a, qs, c);
   __syncthreads();
   for (int c = threadIdx.x; c < QH; c += kQueryThreads) {
-    const float l = glu[c], r = glu[QH + c];
-    const float act = a.glu == RAILS_GEGLU ? 0.5f * l * (1.0f + erff(l * 0.70710678118654752440f))
-                                           : l / (1.0f + expf(-l));
-    glu[c] = act * r;  // lhs slot is only read by its own thread
+    glu[c] = glu_act(a, glu[c], glu[QH + c]);  // lhs slot is only read by its own thread
   }
   __syncthreads();
 
@@ -242,6 +282,118 @@ __global__ __launch_bounds__(kQueryThreads) void query_prologue_kernel(QueryArgs
     // EqFrag[g][sc][lane][j] = Eq[g*QT + row/PQ][row%PQ][kdim_of(4sc + j, hi)], lane = hi*32 + row
     const int hi = k / (d / 2), s = k - hi * (d / 2);
     eq_frag_store(eqf, s, hi, qj * PQ + p, v / a.temperature, a.split);  // fragment copy carries 1/tau
+    if (a.eqfrag2) eq_frag_store(a.eqfrag2 + (int64_t)g * 32 * d, s, hi, qj * PQ + p, v / a.temperature, !a.split);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Split prologue (round 4): the per-query kernel's arithmetic -- the same bits -- spread over more workgroups in TWO short launches.
+// The per-query kernel streams all of a query's weights (1.1 MB for ML-1M) through ONE CU at the ~150 GB/s a CU draws from L2: 22 us
+// for 32 queries, a third of an ML-1M step.  Here
+//   launch 1   workgroup = (128 GLU outputs of one query): 256 threads, a thread per pre-activation column (lhs and gate half), then
+//              act(lhs) * rhs -> a scratch row in the query pack;
+//   launch 2   workgroup = (one sub-embedding group p of one query): its d projection columns over the GLU row (or the uid
+//              embedding), its l2 norm, its share of the Eq fragments; one more workgroup per query runs the query-only gate chain.
+// A workgroup touches 25-260 KB of weights instead of 1-3 MB; the launch boundary replaces the per-query kernel's barrier between
+// the two layers.
+// ---------------------------------------------------------------------------------------------
+constexpr int kGluSlice = 128, kGluThreads = 256;
+__global__ __launch_bounds__(kGluThreads) void query_glu_slice_kernel(QueryArgs a, float* __restrict__ glu_out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* qs = smem;            // [D]
+  float* pre = smem + a.D;     // [256]: lhs columns, then their gate columns
+  const int b = blockIdx.y, c0 = blockIdx.x * kGluSlice, QH = a.QH;
+  for (int i = threadIdx.x; i < a.D; i += kGluThreads) qs[i] = a.q[(int64_t)b * a.D + i];
+  __syncthreads();
+  const int half = threadIdx.x >> 7, cc = c0 + (threadIdx.x & (kGluSlice - 1));
+  if (cc < QH) pre[threadIdx.x] = glu_column(a, qs, half * QH + cc);
+  __syncthreads();
+  if (threadIdx.x < kGluSlice && cc < QH) glu_out[(int64_t)b * QH + cc] = glu_act(a, pre[threadIdx.x], pre[kGluSlice + threadIdx.x]);
+}
+
+// grid (P_Q + 1, padded queries): x < P_Q: sub-embedding group x; x == P_Q: the query-only gate row
+__global__ __launch_bounds__(kQueryThreads) void query_group_kernel(QueryArgs a, const float* __restrict__ glu_in) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int D = a.D, d = a.d, PQ = a.PQ, L = a.PQ * a.PX, QH = a.QH;
+  const int QT = 32 / PQ;
+  const int K = QH > 0 ? QH : D;
+  float* in_s = smem;           // [max(K, D)]: the GLU row (projection groups) or the raw query (gate chain, plain-Linear projection)
+  float* eqs = in_s + (K > D ? K : D);   // [d]
+  float* hq = eqs + d;          // [Hq]
+  float* gqs = hq + a.Hq;       // [L]
+  __shared__ float inv;
+  const int b = blockIdx.y, p = blockIdx.x;
+  const int g = b / QT, qj = b % QT;
+  float* eqf = a.eqfrag + (int64_t)g * 32 * d;
+  if (p == PQ) {   // gate chain, as in query_prologue_kernel
+    if (b >= a.B) return;
+    for (int i = threadIdx.x; i < D; i += kQueryThreads) in_s[i] = a.q[(int64_t)b * D + i];
+    __syncthreads();
+    if (a.has_gate) {
+      wave_dense(a.w.gq_w1, a.w.gq_b1, a.Hq, D, in_s, hq, true);
+      __syncthreads();
+      wave_dense(a.w.gq_w2, nullptr, L, a.Hq, hq, gqs, false);
+    } else {
+      for (int i = threadIdx.x; i < L; i += kQueryThreads) gqs[i] = 0.0f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < L; i += kQueryThreads) {
+      if (a.gq_out) a.gq_out[(int64_t)b * L + i] = gqs[i];
+      const int hi = i / (L / 2), e = i - hi * (L / 2);
+      a.gqfrag[(int64_t)b * L + i] = -kLog2e * gqs[logit_of(e, hi, PQ, a.PX)];
+      if (a.gqfrag2) a.gqfrag2[(int64_t)b * L + i] = -kLog2e * gqs[logit_of(e, hi, PQ, a.PX)];
+    }
+    return;
+  }
+  if (b >= a.B) {  // padding row of the last query group: zero operand rows
+    for (int k = threadIdx.x; k < d; k += kQueryThreads) {
+      const int hi = k / (d / 2), s = k - hi * (d / 2);
+      eq_frag_store(eqf, s, hi, qj * PQ + p, 0.0f, a.split);
+      if (a.eqfrag2) eq_frag_store(a.eqfrag2 + (int64_t)g * 32 * d, s, hi, qj * PQ + p, 0.0f, !a.split);
+    }
+    return;
+  }
+  const int proj_groups = PQ - a.n_uid;
+  if (p < proj_groups) {
+    const float* src = QH > 0 ? glu_in + (int64_t)b * QH : a.q + (int64_t)b * D;
+    const float* Wp = a.w.q_proj_w + (int64_t)p * d * K;
+    const float* bp = a.w.q_proj_b + p * d;
+    const int kpl = (K + 63) / 64;
+    if (d <= 64 && kpl <= 8) {          // the wave_dense dispatch of this size (four columns per wave), weights requested ahead
+      if (kpl <= 1) wave_dense_prefetched<1, 4>(Wp, bp, d, K, src, in_s, eqs);
+      else if (kpl <= 2) wave_dense_prefetched<2, 4>(Wp, bp, d, K, src, in_s, eqs);
+      else if (kpl <= 4) wave_dense_prefetched<4, 4>(Wp, bp, d, K, src, in_s, eqs);
+      else wave_dense_prefetched<8, 4>(Wp, bp, d, K, src, in_s, eqs);
+    } else if (d <= 128 && kpl <= 8) {   // eight columns per wave
+      if (kpl <= 1) wave_dense_prefetched<1, 8>(Wp, bp, d, K, src, in_s, eqs);
+      else if (kpl <= 2) wave_dense_prefetched<2, 8>(Wp, bp, d, K, src, in_s, eqs);
+      else if (kpl <= 4) wave_dense_prefetched<4, 8>(Wp, bp, d, K, src, in_s, eqs);
+      else wave_dense_prefetched<8, 8>(Wp, bp, d, K, src, in_s, eqs);
+    } else {
+      for (int i = threadIdx.x; i < K; i += kQueryThreads) in_s[i] = src[i];
+      __syncthreads();
+      wave_dense(Wp, bp, d, K, in_s, eqs, false);
+    }
+  } else {
+    const int t = p - proj_groups;
+    const int64_t hs = a.w.uid_hash_size[t];
+    int64_t row = a.user_ids[b] % hs;
+    if (row < 0) row += hs;  // python % is non-negative
+    row += 1;
+    for (int k = threadIdx.x; k < d; k += kQueryThreads) eqs[k] = a.w.uid_table[t][row * d + k];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float ss = 0.0f;
+    for (int k = 0; k < d; ++k) ss = __builtin_fmaf(eqs[k], eqs[k], ss);
+    inv = a.l2norm ? fmaxf(sqrtf(ss), a.eps) : 1.0f;
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < d; k += kQueryThreads) {
+    const float v = eqs[k] / inv;
+    if (a.eq_out) a.eq_out[((int64_t)b * PQ + p) * d + k] = v;
+    const int hi = k / (d / 2), s = k - hi * (d / 2);
+    eq_frag_store(eqf, s, hi, qj * PQ + p, v / a.temperature, a.split);
     if (a.eqfrag2) eq_frag_store(a.eqfrag2 + (int64_t)g * 32 * d, s, hi, qj * PQ + p, v / a.temperature, !a.split);
   }
 }
@@ -525,14 +677,15 @@ int query_prologue(const Shape& s, const Weights& w, const float* q, const int64
   a.gqfrag2 = qpack_other ? qpack_other + (int64_t)n_groups * 32 * a.d : nullptr;
   a.eq_out = eq_out; a.gq_out = gq_out;
   const int L = a.PQ * a.PX;
-  // RAILS_PROLOGUE: 0 / unset = choose, 1 = per-query kernel, 2 = batched kernels (measurement override)
-  static const int forced = [] { const char* e = getenv("RAILS_PROLOGUE"); return e ? atoi(e) : 0; }();
+  // RAILS_PROLOGUE: 0 / unset = choose, 1 = per-query kernel, 2 = batched (MFMA) kernels, 3 = split per-query kernels (measurement override)
+  const char* forced_env = getenv("RAILS_PROLOGUE");   // read per call: tests and A/B runs switch it in-process
+  const int forced = forced_env ? atoi(forced_env) : 0;
   const bool batched_ok = a.QH > 0 && a.has_gate && a.QH % 32 == 0 && a.Hq % 32 == 0 && a.d % 32 == 0 && L % 32 == 0 && a.d <= 256;
   // The per-query kernel streams every weight matrix through one CU per query (~150 GB/s of L2 each); the batched
   // kernels read them once but pay three dependent launches (~8 us each).  Crossover ~1.3 MB of weights per query.
   const size_t weight_bytes = sizeof(float) * ((size_t)a.D * 2 * a.QH + (size_t)(a.PQ - a.n_uid) * a.d * a.QH + (size_t)a.Hq * a.D + (size_t)L * a.Hq);
-  const bool use_batched = forced == 2 || (forced != 1 && weight_bytes > (size_t)1300 * 1024);
-  if (batched_ok && use_batched) {
+  const bool use_batched = forced == 2 || (forced == 0 && weight_bytes > (size_t)RAILS_BATCHED_PROLOGUE_BYTES);
+  if (batched_ok && use_batched && !(forced == 0 && a.QH > 0 && B <= 64)) {
     // scratch rows behind the fragment pack (rails_mol_query_pack_floats counts them)
     const int64_t bt = (int64_t)(B + 31) / 32 * 32;
     float* glu = a.gqfrag + (int64_t)B * L;
@@ -545,6 +698,20 @@ int query_prologue(const Shape& s, const Weights& w, const float* q, const int64
                        (const float*)glu, (const float*)hq, eq_raw, gq_raw);
     hipLaunchKernelGGL(query_p3_kernel, dim3(a.PQ - a.n_uid + 1, tiles), dim3(kP3Threads), 32 * a.d * sizeof(float), stream, a, (const float*)eq_raw,
                        (const float*)gq_raw);
+    return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+  }
+  // Measured (profiles/r04_prologue_kernel_times.txt, B = 32): ML-1M per-query 21.7 / batched 18.4 / split 15.0 us; ML-20M 39.6 / 23.7 /
+  // 21.6 (B <= 8: 19.6 batched, 14.5 split); amzn-books 14.5 / 17.9 / 15.8.  Beyond ~64 queries the split kernels' 9 workgroups of 1 024
+  // threads per query no longer fit one round (B = 128: 30-45 us).
+  const bool use_split = forced == 3 || (forced == 0 && a.QH > 0 && B <= 64 && weight_bytes > (size_t)1000 * 1024);
+  if (use_split) {
+    // split prologue: two short launches, same bits as the per-query kernel (RAILS_PROLOGUE=1 keeps that one)
+    float* glu = a.gqfrag + (int64_t)B * L;   // scratch rows behind the fragment pack (rails_mol_query_pack_floats counts them)
+    if (a.QH > 0)
+      hipLaunchKernelGGL(query_glu_slice_kernel, dim3((a.QH + kGluSlice - 1) / kGluSlice, B), dim3(kGluThreads), sizeof(float) * (size_t)(a.D + kGluThreads), stream, a, glu);
+    const int K = a.QH > 0 ? a.QH : a.D;
+    const size_t lds2 = sizeof(float) * (size_t)((K > a.D ? K : a.D) + a.d + a.Hq + L);
+    hipLaunchKernelGGL(query_group_kernel, dim3(a.PQ + 1, n_groups * QT), dim3(kQueryThreads), lds2, stream, a, (const float*)glu);
     return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
   }
   const size_t lds = sizeof(float) * (size_t)(a.D + 2 * a.QH + a.PQ * a.d + a.Hq + a.PQ * a.PX + a.PQ);

@@ -647,7 +647,10 @@ class MoLAvgTopK(MoLTopKModule):
                     coarse = eng.coarse_scores(eq, table, average_queries, out=self._buf("coarse_all", eq.shape[0] * n, torch.float32).view(eq.shape[0], n), run_if=flag)
                     E.topk(coarse, self._avg_top_k, out=(sc, idx), run_if=flag)
                     return (sc, idx) if with_scores else idx
-                check = lambda: int(counts.min()) >= k_lo and int(counts.max()) <= k_hi   # noqa: E731
+                # one flag kernel + ONE 4-byte read (was a min and a max reduction, two reads)
+                bad = torch.zeros(1, dtype=torch.int32, device=counts.device)
+                E.range_flag(counts, k_lo, k_hi, bad)
+                check = lambda: int(bad.item()) == 0   # noqa: E731
                 if pending is not None:
                     pending.append(check)
                     return (sc, idx) if with_scores else idx
@@ -754,7 +757,9 @@ class _ComponentCandidates:
                     scores = eng.component_scores(eq, table, out=self._buf("component_all", rows * n, torch.float32).view(rows, n), run_if=flag)
                     E.topk(scores, k_per_group, out=(sc_c, pos), run_if=flag)
                     return pos.view(eq.shape[0], -1)
-                check = lambda: int(counts.min()) >= k_per_group and int(counts.max()) <= k_hi   # noqa: E731
+                bad = torch.zeros(1, dtype=torch.int32, device=counts.device)
+                E.range_flag(counts, k_per_group, k_hi, bad)
+                check = lambda: int(bad.item()) == 0   # noqa: E731
                 if pending is not None:
                     pending.append(check)
                     return pos.view(eq.shape[0], -1)

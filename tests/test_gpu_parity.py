@@ -698,6 +698,32 @@ def test_device_item_table_generator_equals_the_oracle_generator(dev, seed, firs
     assert torch.equal(got[rows], torch.from_numpy(O.hash_item_rows(seed, (rows + first).numpy(), dim)))
 
 
+@pytest.mark.parametrize("B", [1, 5, 32, 70])
+@pytest.mark.parametrize("cfg_name", ["ml-1m", "ml-20m", "amzn-books"])
+def test_split_prologue_returns_the_bits_of_the_per_query_kernel(dev, monkeypatch, cfg_name, B):
+    """The split prologue (two short launches: GLU slices, then one workgroup per sub-embedding group + one for the gate chain;
+    mol_query.hip) computes every column exactly as the per-query kernel does: fragments, plain Eq and gq are the same bits, padding
+    rows of the last query group included (B = 5, 70: partial groups)."""
+    cfg = O.CONFIGS[cfg_name]
+    mol = build_module(cfg, O.synthetic_weights(cfg, seed=13), dev, "fp32")
+    q = O.synthetic_queries(cfg, B, seed=40 + B).to(dev)
+    uid = (torch.arange(B, dtype=torch.int64, device=dev) * 977) if cfg.uid_embedding_hash_sizes else None
+    n_frag = ((B + 3) // 4) * 32 * cfg.dot_product_dimension + B * cfg.query_dot_product_groups * cfg.item_dot_product_groups
+    outs = {}
+    with torch.inference_mode():
+        eng = mol.engine()
+        for mode in ("1", "3", "2"):
+            monkeypatch.setenv("RAILS_PROLOGUE", mode)
+            qpack, eq, gq = eng.query_pack(q, uid, want_plain=True)
+            outs[mode] = (qpack[:n_frag].clone(), eq.clone(), gq.clone())
+        torch.cuda.synchronize()
+    for a, b in zip(outs["1"], outs["3"]):
+        assert torch.equal(a, b)
+    eq_ref = O.query_component_embeddings(cfg, O.synthetic_weights(cfg, seed=13), q.cpu(), None if uid is None else uid.cpu())
+    assert float((outs["3"][1].cpu() - eq_ref).abs().max()) <= STAGE_TOL
+    assert float((outs["2"][1] - outs["3"][1]).abs().max()) <= STAGE_TOL      # the batched MFMA kernels sum in another order
+
+
 def test_seen_id_filters_with_zero_width_history(dev):
     """A workload without history (BASELINE configs 4 and 5: seen-id width 0) hands the filters a (rows, 0) tensor, whose data pointer
     is null: every filtering entry point must treat it as "nothing to remove" -- the first k of the k' winners -- not as a NULL argument
