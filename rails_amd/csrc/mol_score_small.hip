@@ -39,6 +39,9 @@
 #ifndef RAILS_SMALL_WGCU
 #define RAILS_SMALL_WGCU 2    // workgroups per CU: NW * WGCU / 4 waves per SIMD
 #endif
+#ifndef RAILS_SMALL_ASM
+#define RAILS_SMALL_ASM 1     // 1: the unit's operand loads are pinned inline-asm requests with hand-counted vmcnt waits
+#endif
 #ifndef RAILS_SMALL_HD
 #define RAILS_SMALL_HD 0      // GEMM1 load rounds in flight; 0: what fits ~40 registers (8x8x32: 1, P_X = 4: 2)
 #endif
@@ -71,6 +74,22 @@ __device__ __forceinline__ float4 ld16(const float4* __restrict__ p) {
   return make_float4(v[0], v[1], v[2], v[3]);
 }
 __device__ __forceinline__ float4 ld_pair(const float4* __restrict__ p) { return swap_pair(ld16(p)); }
+
+// Loads the compiler cannot move (RAILS_SMALL_ASM): left to itself it sinks a unit's operand loads towards their uses -- and, vmcnt
+// being in order, puts late requests in front of waits for early ones -- so a unit pays two or three memory round trips where one
+// would do.  These are issued exactly where written; vm_wait<N>() waits until at most N requests are outstanding and ties the
+// registers it covers (a use cannot be scheduled above it).  The compiler's own loads (query fragments, gate weights via LDS) only
+// ever make either side wait LONGER than needed (vmcnt counts every request of the wave), never too little.
+__device__ __forceinline__ void ld16_pinned(f32x4& v, const float4* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
+}
+template <int N, int CNT>
+__device__ __forceinline__ void vm_wait(f32x4 (&v)[CNT]) {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#pragma unroll
+  for (int i = 0; i < CNT; ++i) asm volatile("" : "+v"(v[i]));
+}
+__device__ __forceinline__ float4 swap_pair4(const f32x4 v) { return swap_pair(make_float4(v[0], v[1], v[2], v[3])); }
 
 __device__ __forceinline__ f32x2 pk_fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f32x2 pk_sig(f32x2 t) {  // 1 / (1 + 2^t), the ops of pk_sigmoid_arg (mol_score_fp32_unit.h)
@@ -269,6 +288,60 @@ __global__ __launch_bounds__(NW * 64, NW * RAILS_SMALL_WGCU / 4) void mol_score_
 
     // GEMM1.  Rounds of two packed chunks (four K-steps) per item group; the loads of round r + HD are issued when round r's
     // registers have been consumed (HD rounds in flight), the item gate rows of the unit behind the last round's.
+#if RAILS_SMALL_ASM
+    // every round (up to ~80 registers of them) requested up front, the item gate rows into the first registers a round frees
+    constexpr int R = G::KC / 2, NL = PX + 1, HD = (80 / (4 * NL) < R ? 80 / (4 * NL) : R), NG = PX / 2;
+    f32x4 ring[HD][NL], gir[NG];
+    float4 gi[NG];
+#pragma unroll
+    for (int r = 0; r < HD; ++r) {
+      ld16_pinned(ring[r][0], eq + 2 * r * 64);
+#pragma unroll
+      for (int m = 0; m < PX; ++m) ld16_pinned(ring[r][1 + m], tEx + (m * G::KC + 2 * r) * 64);
+    }
+    f32x4 D1[PX];
+#pragma unroll
+    for (int m = 0; m < PX; ++m) D1[m] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      constexpr int dummy = 0; (void)dummy;
+      // requests issued after round r's: rounds r + 1 .. min(r + HD - 1, R - 1), and the gate rows once round R - HD has been consumed
+      const int last = r + HD - 1 < R - 1 ? r + HD - 1 : R - 1;
+      const int newer = (last - r) * NL + (r > R - HD ? NG : 0);
+      switch (newer) {   // vmcnt takes an immediate: `newer` is a compile-time value of the unrolled loop
+#define RAILS_VMW(n) case n: vm_wait<n, NL>(ring[r % HD]); break;
+        RAILS_VMW(0) RAILS_VMW(2) RAILS_VMW(4) RAILS_VMW(5) RAILS_VMW(7) RAILS_VMW(9) RAILS_VMW(10) RAILS_VMW(12) RAILS_VMW(13) RAILS_VMW(15) RAILS_VMW(17) RAILS_VMW(18) RAILS_VMW(20)
+        RAILS_VMW(22) RAILS_VMW(27)
+#undef RAILS_VMW
+        default: vm_wait<0, NL>(ring[r % HD]); break;
+      }
+      const float4 a = swap_pair4(ring[r % HD][0]);
+      float4 b[PX];
+#pragma unroll
+      for (int m = 0; m < PX; ++m) b[m] = swap_pair4(ring[r % HD][1 + m]);
+      if (r + HD < R) {
+        ld16_pinned(ring[r % HD][0], eq + 2 * (r + HD) * 64);
+#pragma unroll
+        for (int m = 0; m < PX; ++m) ld16_pinned(ring[r % HD][1 + m], tEx + (m * G::KC + 2 * (r + HD)) * 64);
+      } else if (r == R - HD) {
+#pragma unroll
+        for (int mm = 0; mm < NG; ++mm) ld16_pinned(gir[mm], tGi + 2 * mm * 64);
+      }
+#pragma unroll
+      for (int m = 0; m < PX; ++m) D1[m] = mfma16(a.x, b[m].x, D1[m]);
+#pragma unroll
+      for (int m = 0; m < PX; ++m) D1[m] = mfma16(a.z, b[m].z, D1[m]);
+#pragma unroll
+      for (int m = 0; m < PX; ++m) D1[m] = mfma16(a.y, b[m].y, D1[m]);
+#pragma unroll
+      for (int m = 0; m < PX; ++m) D1[m] = mfma16(a.w, b[m].w, D1[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < PX; ++m) asm volatile("" : "+v"(D1[m]));   // the gate rows' wait stays behind GEMM1's last MFMAs (asm statements keep their order)
+    vm_wait<0, NG>(gir);
+#pragma unroll
+    for (int mm = 0; mm < NG; ++mm) gi[mm] = make_float4(gir[mm][0], gir[mm][1], gir[mm][2], gir[mm][3]);
+#else
     constexpr int R = G::KC / 2, kHdFit = 40 / (4 * (PX + 1)) > 0 ? 40 / (4 * (PX + 1)) : 1;   // rounds in flight that fit ~40 registers
     constexpr int kHdWant = RAILS_SMALL_HD > 0 ? RAILS_SMALL_HD : kHdFit, HD = kHdWant < R ? kHdWant : R;
     float4 ra[HD], rb[HD][PX], gi[PX / 2];
@@ -305,6 +378,7 @@ __global__ __launch_bounds__(NW * 64, NW * RAILS_SMALL_WGCU / 4) void mol_score_
 #pragma unroll
       for (int m = 0; m < PX; ++m) D1[m] = mfma16(a.w, b[m].w, D1[m]);
     }
+#endif
     if (!staged) {   // wave-uniform; every wave of the workgroup passes exactly one of the two barriers
       __syncthreads();   // drains this wave's DMA pieces (vmcnt(0)) and meets the others
       staged = true;
