@@ -584,6 +584,7 @@ def main() -> None:
                            "against": "exact brute-force MoL top-k over the whole corpus (every item of every shard scored by the fp32 kernels, same all-gather + merge)",
                            "weights": "planted structure (gate output layers x 0.25); the timed region below uses the plain random init, where pass 1 is uncorrelated with MoL"}
             del mod_p, local_p
+            gc.collect()              # the collector is off (see above): the module's reference cycles would keep its 160 GB index alive
             torch.cuda.empty_cache()
             mol.load_state_dict({kk: vv.to(dev) for kk, vv in weights.items()}, strict=True)
 
