@@ -54,6 +54,26 @@ def test_committed_round3_bench_line_carries_the_full_shard_legs():
     assert legs[2]["dense_fp32_fallbacks"] == 0 and 0 < legs[3]["hbm_frac_lower_bound"] < 1 and 0 < legs[0]["mfma_frac_lower_bound"] < 1
 
 
+def test_committed_round4_bench_line_carries_the_quality_half():
+    """profiles/r04_bench.json (the default `python bench.py` run at the end of round 4): BASELINE.json's metric is "queries/sec + HR@10/50
+    parity" -- the line carries both halves, the reference's own CSV row, and recall@k vs exact for the config-5 shard."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    check_line(d, expect_cpu_baseline=True)
+    hp = d["hr_parity"]
+    assert hp["parity"] is True and hp["identical_rows"] + hp["rows_differing_only_inside_oracle_ties"] == hp["rows"] == 32
+    for key in ("hr@1", "hr@5", "hr@10", "hr@50", "hr@100", "ndcg@10", "mrr"):
+        assert hp[key]["rows_differing"] == 0 and hp[key]["hip"] == hp[key]["oracle"]
+    csv = d["reference_csv"]
+    assert csv["header"] == "HR@1,HR@5,HR@10,HR@50,HR@100,BatchTimeMsAvg,BatchTimeMsDev" and csv["row"].split(",")[:5] == csv["oracle_row"].split(",")
+    two_pass = d["full_shards"][3]
+    assert "N=125000000" in two_pass["workload"] and 0.3 < two_pass["recall"]["recall@10"] <= 1.0 and 0.2 < two_pass["recall"]["recall@120"] <= 1.0
+    for mode in ("f16-exact", "f16x3-exact"):
+        e = d["exact_fast_path"][mode]
+        assert e["output_identical_to_fp32_path"] is True and e["eps_rigorous"] > e["eps"] and e["eps_rigorous_usable"] is False
+    tp = json.load(open(os.path.join(ROOT, "profiles", "r04_two_pass_125m.json")))
+    assert tp["roofline"]["bound"] == "hbm" and 0 < tp["roofline"]["frac"] < 1 and 0.3 < tp["recall"]["recall@10"] <= 1.0
+
+
 @pytest.mark.gpu
 def test_live_bench_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-fast-path", "--no-matrix",
