@@ -501,14 +501,16 @@ def main() -> None:
 
         import datetime
 
-        # a hung collective must end the run with rc != 0, not with a number: 60 s per collective, asynchronous errors tear the process down
+        # a hung collective must end the run with rc != 0, not with a number: asynchronous errors tear the process down after
+        # RAILS_BENCH_COLLECTIVE_TIMEOUT_S (default 120 s: the first collective includes RCCL's communicator set-up over xGMI)
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        coll_timeout = datetime.timedelta(seconds=int(os.environ.get("RAILS_BENCH_COLLECTIVE_TIMEOUT_S", "120")))
         if test_backend:
-            dist.init_process_group(test_backend, timeout=datetime.timedelta(seconds=60))
+            dist.init_process_group(test_backend, timeout=coll_timeout)
         else:
             if torch.cuda.device_count() < world:
                 raise SystemExit(f"--gpus {world} needs {world} visible devices, found {torch.cuda.device_count()} (one rank per GPU over RCCL)")
-            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=60))
+            dist.init_process_group("nccl", device_id=dev, timeout=coll_timeout)
             if dist.get_backend() != "nccl":
                 raise SystemExit(f"backend is {dist.get_backend()}, expected nccl (= RCCL on ROCm)")
 
