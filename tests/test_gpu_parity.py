@@ -1473,6 +1473,34 @@ def test_gating_combination_none_at_256_logits(dev, precision):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg_name", ["ml-1m", "amzn-books"])
+def test_gating_combination_none_on_every_fp32_shell(dev, monkeypatch, cfg_name):
+    """gating_combination_type "none" (similarity_fn.py:187-197; with and without the query-only / item-only gate parts) through the
+    small-unit shell, the independent-wave 32x32x2 shell and the dispatcher's choice: same bits, within 1e-4 of the oracle."""
+    import dataclasses
+
+    for has_q, has_i in ((True, True), (False, False)):
+        cfg = dataclasses.replace(O.CONFIGS[cfg_name], gating_combination_type="none", gating_query_fn=has_q, gating_item_fn=has_i)
+        w = O.synthetic_weights(cfg, seed=17)
+        N, B = 1234, 7
+        X = torch.from_numpy(O.hash_item_table(19, 0, N, cfg.item_embedding_dim))
+        q = O.synthetic_queries(cfg, B, seed=33)
+        uid = torch.arange(B, dtype=torch.int64) * 11 if cfg.uid_embedding_hash_sizes else None
+        ref = O.mol_logits(cfg, w, q, X.unsqueeze(0), uid)
+        mol = _module_for(cfg, w, dev, "fp32")
+        outs = {}
+        with torch.inference_mode():
+            eng = mol.engine()
+            index = eng.build_index(X.to(dev))
+            qpack, _, _ = eng.query_pack(q.to(dev), None if uid is None else uid.to(dev))
+            for variant in ("7", "1", "0"):
+                monkeypatch.setenv("RAILS_SCORE_VARIANT", variant)
+                outs[variant] = eng.score_dense(qpack, B, index).clone()
+        assert torch.equal(outs["7"], outs["1"]) and torch.equal(outs["7"], outs["0"])
+        assert float((outs["7"].cpu() - ref).abs().max()) <= LOGIT_TOL
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("rows,n,kp,width,k", [(4, 5000, 200, 61, 120), (32, 200_000, 200, 61, 120), (3, 30_000, 512, 211, 300), (2, 3883, 200, 211, 120),
                                                (5, 27_278, 25, 30, 20), (2, 1500, 10, 1, 10), (3, 100_003, 331, 256, 331)])
 def test_fused_topk_filter_equals_the_two_kernels(dev, rows, n, kp, width, k):
