@@ -21,11 +21,27 @@ namespace mol {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Gate pack -> LDS.  By LDS-DMA (1 KiB per wave-instruction, no registers, NOT waited for here): every shell passes a __syncthreads()
+// -- which drains the wave's DMA pieces (vmcnt(0)) -- before its first weight read, and the staged shells issue their first tile's DMA
+// right behind this, so the two round trips run side by side instead of one after the other (a copy through registers waits for its
+// loads before it can store; small corpora are one round of tiles: every microsecond of prologue is on the critical path).
+#ifndef RAILS_STAGE_DMA
+#define RAILS_STAGE_DMA 1
+#endif
 template <class G, int NW>
 __device__ __forceinline__ void stage_weights(const ScoreArgs& p, float* smem) {
+#if RAILS_STAGE_DMA
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int kPieces = G::kWpackFloats / 256;
+  for (int piece = wave; piece < kPieces; piece += NW)
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.wpack + piece * 256 + lane * 4),
+                                     (__attribute__((address_space(3))) void*)(smem + piece * 256), 16, 0, 0);
+  for (int i = kPieces * 256 + threadIdx.x; i < G::kWpackFloats; i += NW * 64) smem[i] = p.wpack[i];
+#else
   const float4* src = reinterpret_cast<const float4*>(p.wpack);
   float4* dst = reinterpret_cast<float4*>(smem);
   for (int i = threadIdx.x; i < G::kWpackFloats / 4; i += NW * 64) dst[i] = src[i];
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
