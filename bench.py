@@ -776,33 +776,43 @@ def main() -> None:
                    + torch.arange(fin_i.numel(), device=dev, dtype=torch.int64).view_as(fin_i) * 0x165667B19E3779F9)
             digest = gather_i64(mix.sum().reshape(1))
             all_identical = bool((digest == digest[0]).all())
-            # (2) merged == unsharded: the item rows of every rank's local top-k' are all-gathered, ONE device scores their union (a
-            #     superset of every query's candidates: anything that beats a query's k'-th overall is in its shard's local top-k') as a
-            #     corpus of its own and selects.  Ids sorted ascending = global position order, so ties break as in the whole corpus;
-            #     the scoring kernels return the same bits whatever the corpus size (small-unit and 32x32x2 shells alike).
+            # ALL collectives of the check first (every rank runs them unconditionally); the local recompute, which can only fail
+            # locally, afterwards -- an exception there must not leave the ranks at different collectives
             rows = X[0].index_select(0, (li_.reshape(-1) - (lo + 1)).clamp(min=0))
             g_rows = all_gather_rows(rows.reshape(1, -1)).view(-1, X.shape[2])
             g_ids = gather_i64(li_.reshape(-1)).reshape(-1)
-            u_ids = torch.unique(g_ids, sorted=True)
-            order = torch.argsort(g_ids, stable=True)
-            keep = torch.ones_like(order, dtype=torch.bool)
-            keep[1:] = g_ids[order][1:] != g_ids[order][:-1]
-            u_rows = g_rows[order][keep]
-            assert u_rows.shape[0] == u_ids.numel()
-            union = rails_amd.MoLBruteForceTopK(mol, u_rows.unsqueeze(0).contiguous(), u_ids.unsqueeze(0))
-            us_, ui_ = union(q, k=kp, **kw)
-            merged_equals_unsharded = bool(torch.equal(us_, ms_) and torch.equal(ui_, mi_))
             # (3) per shard: nothing outside the merged list beats its k'-th score
             kth = ms_[:, -1:]
             above_local = (logits > kth).sum(1)
             mine_in_merged = ((mi_ > lo) & (mi_ <= hi) & (ms_ > kth)).sum(1)
             ok_local = torch.tensor([int(bool((above_local == mine_in_merged).all()))], dtype=torch.int64, device=dev)
             nothing_outside = bool((gather_i64(ok_local) == 1).all())
+            # (2) merged == unsharded: ONE device scores the union of every rank's local top-k' rows (a superset of every query's
+            #     candidates: anything that beats a query's k'-th overall is in its shard's local top-k') as a corpus of its own and
+            #     selects.  Ids sorted ascending = global position order, so ties break as in the whole corpus; the scoring kernels
+            #     return the same bits whatever the corpus size (small-unit and 32x32x2 shells alike).
+            merged_equals_unsharded, union_items, check_error = None, None, None
+            try:
+                u_ids = torch.unique(g_ids, sorted=True)
+                order = torch.argsort(g_ids, stable=True)
+                keep = torch.ones_like(order, dtype=torch.bool)
+                keep[1:] = g_ids[order][1:] != g_ids[order][:-1]
+                u_rows = g_rows[order][keep]
+                assert u_rows.shape[0] == u_ids.numel()
+                union = rails_amd.MoLBruteForceTopK(mol, u_rows.unsqueeze(0).contiguous(), u_ids.unsqueeze(0))
+                us_, ui_ = union(q, k=kp, **kw)
+                merged_equals_unsharded = bool(torch.equal(us_, ms_) and torch.equal(ui_, mi_))
+                union_items = int(u_ids.numel())
+                del union
+            except Exception as e:   # noqa: BLE001 -- a failure OF the check (not a failed check) is reported, it does not void the timing
+                check_error = f"{type(e).__name__}: {e}"[:300]
             sharded_check = {"all_ranks_identical": all_identical, "merged_equals_unsharded": merged_equals_unsharded,
-                             "nothing_outside_beats_kth": nothing_outside, "union_items": int(u_ids.numel()),
+                             "nothing_outside_beats_kth": nothing_outside, "union_items": union_items,
                              "how": "digest of (ids, score bits) all-gathered; union of every rank's local top-k' rows re-scored and re-selected on one device; "
                                     "per-shard count of logits above the merged k'-th"}
-            if not (all_identical and merged_equals_unsharded and nothing_outside):
+            if check_error:
+                sharded_check["error"] = check_error
+            if not all_identical or merged_equals_unsharded is False or not nothing_outside:
                 raise SystemExit(f"sharded result failed its in-run check: {sharded_check}")
             sharded_info = {
                 "check": sharded_check,
