@@ -518,9 +518,9 @@ struct F16Unit {
   template <class G, int NW>
   static __device__ __forceinline__ void stage(const ScoreArgs& p, float* smem) { SplitPack<G>::template stage<NW>(p, smem); }
 
-  template <class G, int PX, int DD, bool BULK = false, bool PIPE = false>
+  template <class G, int PX, int DD, bool BULK = false, int PIPE = 0>   // PIPE > 1 (the fp32 unit's register ring) means "none" here
   static __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float* __restrict__ eq, const float4* tEx, int lane) {
-    gemm1_presplit<G, PX, DD, BULK, PIPE>(D1, reinterpret_cast<const h8*>(eq), reinterpret_cast<const h8*>(tEx), lane);
+    gemm1_presplit<G, PX, DD, BULK, (PIPE == 1)>(D1, reinterpret_cast<const h8*>(eq), reinterpret_cast<const h8*>(tEx), lane);
   }
 
   template <class G, int PX, bool SEL = false, class SelT = SelNone>

@@ -50,13 +50,49 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 
 // GEMM1: D1[m][(qj,p), x] = sum_d Eq[qj,p,d] * Ex[x,m,d].  `eq` is the query group's A operand in fragment
 // order ([sc][lane] float4), `tEx` the tile's B operand ([m][sc][lane] float4) -- in HBM or in LDS.
-template <class G, int PX, int DD, bool BULK = false, bool PIPE = false>
+// PIPE: 0 = each K-chunk loaded where it is used; 1 = one chunk requested ahead; n > 1 = a register ring of n chunks in flight.
+template <class G, int PX, int DD, bool BULK = false, int PIPE = 0>
 __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float4* __restrict__ eq, const float4* tEx, int lane) {
 #pragma unroll
   for (int m = 0; m < PX; ++m)
 #pragma unroll
     for (int r = 0; r < 16; ++r) D1[m][r] = 0.0f;
-  if constexpr (PIPE) {
+  if constexpr ((PIPE > 1) && (DD / 8) > PIPE) {
+    // deep K (8x4x128: 16 chunks of 16 MFMAs): a chunk's A operand comes from the query pack in L1 / L2 (500-900 cycles under load)
+    // against 1 024 cycles of MFMAs per chunk, and one chunk ahead leaves part of the round trip exposed; PIPE chunks are kept in
+    // flight in a register ring.  Same chain order, same bits.
+    constexpr int PD = PIPE, NC = DD / 8;
+    float4 ra[PD], rb[PD][PX];
+#pragma unroll
+    for (int c = 0; c < PD; ++c) {
+      ra[c] = eq[c * 64 + lane];
+#pragma unroll
+      for (int m = 0; m < PX; ++m) rb[c][m] = tEx[(m * NC + c) * 64 + lane];
+    }
+#pragma unroll
+    for (int sc = 0; sc < NC; ++sc) {
+      const float4 a = ra[sc % PD];
+      float4 b[PX];
+#pragma unroll
+      for (int m = 0; m < PX; ++m) b[m] = rb[sc % PD][m];
+      if (sc + PD < NC) {
+        ra[sc % PD] = eq[(sc + PD) * 64 + lane];
+#pragma unroll
+        for (int m = 0; m < PX; ++m) rb[sc % PD][m] = tEx[(m * NC + sc + PD) * 64 + lane];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < PX; ++m) {
+        D1[m] = mfma32(a.x, b[m].x, D1[m]);
+        D1[m] = mfma32(a.y, b[m].y, D1[m]);
+        D1[m] = mfma32(a.z, b[m].z, D1[m]);
+        D1[m] = mfma32(a.w, b[m].w, D1[m]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
+  if constexpr (PIPE != 0) {
     // Operands straight from memory (independent-wave shell): K-chunk sc + 1 is requested BEFORE chunk sc's MFMAs, so a chunk's
     // memory latency runs under 2 048 cycles of this wave's matrix work (and its partner's) instead of in front of them.  Costs PX
     // more float4 of registers, in the one phase of the unit that has them to spare (no D2 / D3 yet).
@@ -247,7 +283,7 @@ struct Fp32Unit {
   static constexpr int kLdsWeightFloats = G::kWpackFloats;
   template <class G, int NW>
   static __device__ __forceinline__ void stage(const ScoreArgs& p, float* smem) { stage_weights<G, NW>(p, smem); }
-  template <class G, int PX, int DD, bool BULK = false, bool PIPE = false>
+  template <class G, int PX, int DD, bool BULK = false, int PIPE = 0>
   static __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float* __restrict__ eq, const float4* tEx, int lane) {
     mol::gemm1<G, PX, DD, BULK, PIPE>(D1, reinterpret_cast<const float4*>(eq), tEx, lane);
   }

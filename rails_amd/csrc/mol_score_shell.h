@@ -99,7 +99,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(Score
 #ifndef RAILS_DIRECT_PIPE
 #define RAILS_DIRECT_PIPE 1
 #endif
-    U::template gemm1<G, PX, DD, (NW == 4), (NW == 8 && RAILS_DIRECT_PIPE != 0)>(D1, eq, tEx, lane);   // one wave per SIMD: the whole tile requested up front; two: one K-chunk ahead
+    U::template gemm1<G, PX, DD, (NW == 4), ((NW == 8 && RAILS_DIRECT_PIPE != 0) ? 1 : 0)>(D1, eq, tEx, lane);   // one wave per SIMD: the whole tile requested up front; two: one K-chunk ahead
     // (Measured three times and not kept: an L2 touch of this wave's next tile from here -- untracked asm loads in rounds 1 and 3,
     // ordinary loads consumed at the end of the unit in round 3: B = 1 ... 8 all 2-5 % slower.  What does help these shells is the
     // K-chunk lookahead inside GEMM1, above.  An early touch of THIS tile's gate rows, read at the head of the epilogue, changed nothing
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(Score
 #ifndef RAILS_STAGED_PIPE
 #define RAILS_STAGED_PIPE 0   // GEMM1 one K-chunk ahead with the tile in LDS: measured no difference (6.34 ms either way)
 #endif
-      U::template gemm1<G, PX, DD, false, (RAILS_STAGED_PIPE != 0)>(D1, eq, tEx, lane);
+      U::template gemm1<G, PX, DD, false, RAILS_STAGED_PIPE>(D1, eq, tEx, lane);
       U::template queries<G, PX, SEL>(D1, p, sel, g, -1, tile * kTileItems, smem, tGi, lane, hi, x);
     }
   }
@@ -233,9 +233,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged1_kernel(Scor
       const int g = off + stride * gi_idx;
       f32x16 D1[PX];
 #ifndef RAILS_STAGED1_PIPE
-#define RAILS_STAGED1_PIPE 0   // likewise: ML-20M 0.211 ms, ML-1M 0.032 ms either way
+#define RAILS_STAGED1_PIPE 3   // a ring of three K-chunks: ML-20M 64 x 221 184 2.820 -> 2.765 ms, B = 32 0.200 -> 0.194 ms (one ahead: 2.780); ML-1M 0.030 ms either way
 #endif
-      if (has) U::template gemm1<G, PX, DD, false, (RAILS_STAGED1_PIPE != 0)>(D1, p.eqfrag + (int64_t)g * G::kEqGroupFloats, tEx, lane);
+      // the ring costs PIPE * (PX + 1) float4 registers: built where that is <= 16 and K is deeper than the ring (4 x 128 shapes); elsewhere none (8 x 32 would spill)
+      constexpr int kPipe = (RAILS_STAGED1_PIPE > 1 && (RAILS_STAGED1_PIPE * (PX + 1) > 16 || DD / 8 <= RAILS_STAGED1_PIPE)) ? 0 : RAILS_STAGED1_PIPE;
+      if (has) U::template gemm1<G, PX, DD, false, kPipe>(D1, p.eqfrag + (int64_t)g * G::kEqGroupFloats, tEx, lane);
       if (it == n_it - 1) {
         __syncthreads();   // every wave is past its last GEMM1 of this tile: the Ex buffer is free
         if (i + 1 < mine) {
