@@ -31,9 +31,10 @@ extern "C" {
 
 /* Version of this interface: bumped whenever a struct gains a field or an entry point changes meaning (round 2 -> 3: 3, the
  * structs of round 2 carried no version; 5: the launch predicate became the explicit `run_if` argument of the entry points that
- * honour it and the per-thread rails_set_run_predicate is gone -- the library keeps no state between calls but the last error).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
+ * honour it and the per-thread rails_set_run_predicate is gone -- the library keeps no state between calls but the last error;
+ * 6: rails_mol_coarse_topk gained its out_of_range output, rails_topk_candidates is new, rails_mol_score_indexed takes any n_cand).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
  * against an older header pass shorter structs, and the library would read the new fields from whatever follows them. */
-#define RAILS_ABI_VERSION 5
+#define RAILS_ABI_VERSION 6
 int rails_abi_version(void);
 
 #define RAILS_OK 0
@@ -188,7 +189,7 @@ int rails_mol_score_candidates(const rails_mol_shape* shape, const float* gate_p
 /* Per-row candidates scored IN PLACE: logits[b][j] = MoL(query b, item positions[b][j]) with the item operands read straight from the
  * shared index -- rails_mol_index_gather + rails_mol_score_candidates without the gathered copy and its launch (same arithmetic per
  * pair, same bits).  Exact-fp32 shapes on the independent-wave shell (rails_mol_score_indexed_supported != 0); the 256-logit shape
- * and the f16 precisions gather.  positions must lie in [0, n_items) (they are clamped, not masked); n_cand a multiple of 32. */
+ * and the f16 precisions gather.  positions must lie in [0, n_items) (they are clamped, not masked); any n_cand >= 1. */
 int rails_mol_score_indexed_supported(const rails_mol_shape* shape, int32_t batch, int64_t n_cand);
 int rails_mol_score_indexed(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack, int32_t batch, const float* index,
                             int64_t n_items, const int64_t* positions, int64_t n_cand, float* logits, int64_t ld, void* stream);
@@ -222,17 +223,21 @@ int rails_mol_coarse_score(const rails_mol_shape* shape, const float* eq, int32_
                            const void* table, int64_t n_items, float* scores, int64_t ld, const int32_t* run_if, void* stream);
 
 /* Fused coarse scoring + exact top-K' (the same scores as rails_mol_coarse_score followed by rails_topk, without
- * materialising the (batch, n_items) matrix): a strided sample of the table fixes a per-query threshold, one streaming
- * pass collects the items at or above it, and the K' best of those are selected with the position tie rule.
- * out_scores / out_positions: (batch, k_prime), descending.  out_counts[b] = candidates query b collected; the result
- * for query b is exact iff k_prime <= out_counts[b] <= the internal capacity (min(24576, max(4096, 8 k_prime)), rounded up
- * to a multiple of 64; capacity + 1 is reported when one of the 16 internal sub-lists overflowed) -- otherwise (heavy
- * ties at the threshold) the caller falls back to rails_mol_coarse_score + rails_topk.
- * k_prime <= 4096.  rails_mol_coarse_topk_workspace_bytes returns 0 when the sizes are unsupported. */
+ * materialising the (batch, n_items) matrix): per-group maxima of a strided sample of the table fix a per-query threshold,
+ * one streaming pass collects the items at or above it, and the K' best of those are selected with the position tie rule.
+ * Four launches.  out_scores / out_positions: (batch, k_prime), descending.  out_counts[b] = candidates query b collected;
+ * the result for query b is exact iff k_prime <= out_counts[b] <= the internal capacity (min(24576, max(4096, 8 k_prime)),
+ * rounded up to a multiple of 64; capacity + 1 is reported when one of the 16 internal sub-lists overflowed) -- otherwise
+ * (heavy ties at the threshold) the caller falls back to rails_mol_coarse_score + rails_topk; slots of an under-filled row
+ * name position 0 with score -inf.  out_of_range (may be NULL): one int32 the call sets to 1 if some query's count is
+ * outside that range and to 0 otherwise -- what rails_range_flag computes from out_counts, inside the call's own launches
+ * (usable as the run_if predicate of the fallback).
+ * k_prime <= 4096, batch <= 128 (slice larger batches).  rails_mol_coarse_topk_workspace_bytes returns 0 when the sizes are
+ * unsupported. */
 size_t rails_mol_coarse_topk_workspace_bytes(const rails_mol_shape* shape, int32_t batch, int64_t n_items, int32_t k_prime);
 int rails_mol_coarse_topk(const rails_mol_shape* shape, const float* eq, int32_t batch, int32_t average_queries,
                           const void* table, int64_t n_items, int32_t k_prime, void* workspace, size_t workspace_bytes,
-                          float* out_scores, int64_t* out_positions, int32_t* out_counts, void* stream);
+                          float* out_scores, int64_t* out_positions, int32_t* out_counts, int32_t* out_of_range, void* stream);
 
 /* ---- per-component candidate generation (MoLNaiveTopK / MoLCombTopK) ------------------------------
  * Replaces the bf16 component table (rails/indexing/mol_top_k.py:61-73, :172-174) and the per-query-group bf16 `mm`
@@ -268,6 +273,13 @@ size_t rails_topk_workspace_bytes(int32_t rows, int64_t n, int32_t k);
 int rails_topk(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t k, int32_t sorted,
                const int64_t* ids, int64_t ids_row_stride, float* out_scores, int64_t* out_ids,
                void* workspace, size_t workspace_bytes, const int32_t* run_if, void* stream);
+
+/* The final_topk of a candidate rerank (rails/indexing/mol_top_k.py:371-382: torch.topk over the candidates' scores,
+ * torch.gather of their corpus positions, item_ids lookup) in one launch: row b holds n_cand <= 16384 scores, candidate j of row b
+ * is corpus position positions[b * n_cand + j]; out_ids[b][j'] = ids[position] (ids: one shared id row, or NULL for the position
+ * itself).  Same order and tie rule (candidate column ascending) as rails_topk on the same rows. */
+int rails_topk_candidates(const float* scores, int64_t ld, int32_t rows, int32_t n_cand, int32_t k, const int64_t* positions,
+                          const int64_t* ids, float* out_scores, int64_t* out_ids, void* stream);
 
 /* CandidateIndex.get_top_k_outputs' selection in ONE chain (reference indexing/candidate_index.py:149-175 after
  * rails/indexing/mol_top_k.py:123-130): exact top-k' of every row with the id map, then the seen-id filter of

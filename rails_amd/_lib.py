@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RAILS_AMD_LIBRARY: load another build of the same library (e.g. the phase-stamp debug build of tools/query_phases.sh)
 LIB_PATH = os.environ.get("RAILS_AMD_LIBRARY") or os.path.join(_HERE, "librails_amd.so")
 
-RAILS_ABI_VERSION = 5   # include/rails_amd.h
+RAILS_ABI_VERSION = 6   # include/rails_amd.h
 RAILS_OK = 0
 RAILS_EINVAL = -22
 RAILS_ENOTSUP = -95
@@ -129,7 +129,7 @@ PROTOTYPES = {
     "rails_mol_coarse_build": (C.c_int, [_SHAPE_P, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "rails_mol_coarse_topk_workspace_bytes": (C.c_size_t, [_SHAPE_P, C.c_int32, C.c_int64, C.c_int32]),
     "rails_mol_coarse_topk": (C.c_int, [_SHAPE_P, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
-                                        C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                        C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rails_mol_coarse_score": (
         C.c_int,
         [_SHAPE_P, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
@@ -167,6 +167,7 @@ PROTOTYPES = {
         [C.c_void_p, C.c_int64, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
          C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p],
     ),
+    "rails_topk_candidates": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rails_pack_candidates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "rails_merge_candidates": (
         C.c_int,

@@ -334,7 +334,7 @@ int rails_mol_score_dense(const rails_mol_shape* s, const float* gate_pack, cons
 }
 
 int rails_mol_score_indexed_supported(const rails_mol_shape* s, int32_t batch, int64_t n_cand) {
-  if (!s || !shape_supported(s) || is_split(*s) || batch <= 0 || n_cand <= 0 || n_cand % 32 != 0) return 0;
+  if (!s || !shape_supported(s) || is_split(*s) || batch <= 0 || n_cand <= 0) return 0;
   const int cu = compute_units();
   if (cu <= 0) return 0;
   ScoreArgs a;
@@ -353,7 +353,6 @@ int rails_mol_score_indexed(const rails_mol_shape* s, const float* gate_pack, co
   if (batch < 0 || n_items <= 0 || n_cand < 0) { set_error("score_indexed: bad size"); return RAILS_EINVAL; }
   if (batch == 0 || n_cand == 0) return RAILS_OK;
   if (!gate_pack || !query_pack || !index || !positions || !logits) { set_error("score_indexed: NULL pointer"); return RAILS_EINVAL; }
-  if (n_cand % 32 != 0) { set_error("score_indexed: n_cand must be a multiple of 32"); return RAILS_EINVAL; }
   if (ld < n_cand) { set_error("score_indexed: ld < n_cand"); return RAILS_EINVAL; }
   if (is_split(*s)) { set_error("score_indexed: exact-fp32 precision only"); return RAILS_ENOTSUP; }
   const int cu = compute_units();
@@ -433,7 +432,7 @@ size_t rails_mol_coarse_topk_workspace_bytes(const rails_mol_shape* s, int32_t b
 
 int rails_mol_coarse_topk(const rails_mol_shape* s, const float* eq, int32_t batch, int32_t average_queries, const void* table,
                           int64_t n_items, int32_t k_prime, void* workspace, size_t workspace_bytes, float* out_scores,
-                          int64_t* out_positions, int32_t* out_counts, void* stream) {
+                          int64_t* out_positions, int32_t* out_counts, int32_t* out_of_range, void* stream) {
   g_err[0] = '\0';
   if (!shape_ok(s)) return RAILS_EINVAL;
   if (batch < 0 || n_items < 0 || k_prime < 0) { set_error("coarse_topk: negative size"); return RAILS_EINVAL; }
@@ -443,7 +442,7 @@ int rails_mol_coarse_topk(const rails_mol_shape* s, const float* eq, int32_t bat
   const int cu = compute_units();
   if (cu <= 0) { set_error("coarse_topk: no HIP device"); return RAILS_ELAUNCH; }
   const int r = coarse_topk(*s, eq, batch, average_queries ? 1 : 0, table, n_items, k_prime, workspace, workspace_bytes,
-                            out_scores, out_positions, out_counts, cu, (hipStream_t)stream);
+                            out_scores, out_positions, out_counts, out_of_range, cu, (hipStream_t)stream);
   return r == kOk ? r : fail(r, "coarse_topk");
 }
 
@@ -547,6 +546,22 @@ int rails_topk(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t
   const int r = topk(scores, ld, rows, n, k, ids, ids_row_stride, out_scores, out_ids, workspace, workspace_bytes, cu,
                      (hipStream_t)stream, nullptr, 0, 0, nullptr, run_if);
   return r == kOk ? r : fail(r, "topk");
+}
+
+int rails_topk_candidates(const float* scores, int64_t ld, int32_t rows, int32_t n_cand, int32_t k, const int64_t* positions,
+                          const int64_t* ids, float* out_scores, int64_t* out_ids, void* stream) {
+  g_err[0] = '\0';
+  if (rows < 0 || n_cand < 0 || k < 0) { set_error("topk_candidates: negative size"); return RAILS_EINVAL; }
+  if (k > n_cand) { set_error("topk_candidates: selected index k out of range (k = %d > n = %d)", k, n_cand); return RAILS_EINVAL; }
+  if (rows == 0 || k == 0) return RAILS_OK;
+  if (!scores || !positions || !out_scores || !out_ids) { set_error("topk_candidates: NULL pointer"); return RAILS_EINVAL; }
+  if (ld < n_cand) { set_error("topk_candidates: ld < n_cand"); return RAILS_EINVAL; }
+  if (n_cand > 16384) { set_error("topk_candidates: n_cand = %d exceeds 16384", n_cand); return RAILS_ENOTSUP; }
+  const int cu = compute_units();
+  if (cu <= 0) { set_error("topk_candidates: no HIP device"); return RAILS_ELAUNCH; }
+  const int r = topk(scores, ld, rows, n_cand, k, ids, 0, out_scores, out_ids, nullptr, 0, cu, (hipStream_t)stream, nullptr, 0, 0, nullptr,
+                     nullptr, positions, n_cand);
+  return r == kOk ? r : fail(r, "topk_candidates");
 }
 
 int rails_topk_filter_fusable(int64_t n, int32_t k_prime, int32_t width, int32_t k) { return topk_can_fuse_filter(n, k_prime, width, k) ? 1 : 0; }

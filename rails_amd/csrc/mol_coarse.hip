@@ -52,7 +52,8 @@ __global__ void coarse_build_kernel(const float* __restrict__ ipack, int64_t n, 
 //
 // Three modes share the arithmetic (so their scores are bit-identical):
 //   kScanAll     scores[b][x] for every item                         (the materialising path)
-//   kScanSample  scores of every `stride`-th tile, compacted          (threshold estimation of the fused top-K')
+//   kScanSample  every `stride`-th tile; each wave keeps the running MAXIMUM of its scores per (query, tile column) and writes
+//                one 32 x 32 block of maxima at the end               (threshold estimation of the fused top-K', see below)
 //   kScanSelect  keys (score, position) of the items whose score is >= thr[b] appended to per-query candidate lists
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float cf32x16 __attribute__((ext_vector_type(16)));
@@ -62,6 +63,13 @@ enum { kScanAll = 0, kScanSample = 1, kScanSelect = 2 };
 // sub-list from the tile index keeps the split even for any item order.
 constexpr int kSubLists = 16;
 constexpr int kScanThreads = 256;
+constexpr int kSampleMaxQT = 4;       // query tiles (of 32) a sample launch keeps running maxima for: B <= 128
+constexpr int kSampleGrid = 256;      // workgroups of a sample launch: 1 024 waves -> 32 768 maxima per query, one row_select launch
+#ifndef RAILS_SCAN_NT
+#define RAILS_SCAN_NT 1   // the select scan of a single query tile (B <= 32) reads the table with non-temporal loads -- each byte is used once:
+                          // 125 M x 32 bf16, B = 32: 1 388 -> 1 315 us (5.8 -> 6.1 TB/s); with four query tiles (B = 128) the scan is no longer
+                          // bound by the reads and the hint costs 1.5 %, so those launches keep the default policy
+#endif
 #ifndef RAILS_SCAN_WAVES
 #define RAILS_SCAN_WAVES 3   // waves per SIMD the select scan is compiled for (168 VGPRs; 3 over 2: 3.07 -> 2.87 ms per config-5 step at B = 128,
                            // nothing at B = 32); the store modes hold sixteen addresses per tile and keep 2
@@ -72,11 +80,14 @@ constexpr int kScanThreads = 256;
 
 struct CoarseScanArgs {
   const float* eq; int B, PQ, d, avg;
-  const unsigned short* qfrag;          // the queries' A fragments made once by coarse_query_kernel (else every workgroup makes them from eq)
+  const unsigned short* qfrag;          // the queries' A fragments, made once by workgroup 0 of the sample scan (NULL: every workgroup makes them from eq)
   const unsigned short* table; int64_t n;
-  float* scores; int64_t ld;            // kScanAll / kScanSample
-  unsigned short* scores16;             // kScanSample: the sample as bf16 bit patterns instead (the scores ARE bf16 values)
-  int stride;                           // kScanSample: tiles t with t % stride == 0, column (t / stride) * 32 + x
+  float* scores; int64_t ld;            // kScanAll: scores[b * ld + item]
+  unsigned short* scores16;             // kScanSample: scores16[b * ld + wave * 32 + x] = the wave's running maximum in column x, as bf16 bits
+  int stride;                           // kScanSample: the tiles t with t % stride == 0
+  unsigned short* qfrag_out;            // kScanSample: workgroup 0 leaves the queries' A fragments here for the select scan ...
+  unsigned int* zero_words; int n_zero; // ... and zeroes these words (the candidate counters)
+  int32_t* zero_flag;                   // ... and the caller's out-of-range flag, which the key selection may raise
   const float* thr; int64_t thr_stride; // kScanSelect: thr[b * thr_stride], a bf16 value
   unsigned long long* keys; int cap;    // kScanSelect: keys[b * cap + sub * (cap / kSubLists) + slot]
   unsigned int* counts;                 // kScanSelect: counts[b * kSubLists + sub], candidates seen (may exceed the sub-list)
@@ -161,12 +172,7 @@ __device__ __forceinline__ void coarse_query_element(const float* __restrict__ e
   const int qt = b >> 5, row = b & 31, c = dd >> 4, h = (dd >> 3) & 1, j = dd & 7;
   frag[(((size_t)qt * DC + c) * 64 + h * 32 + row) * 8 + j] = (unsigned short)(__float_as_uint(v) >> 16);
 }
-__global__ void coarse_query_kernel(const float* __restrict__ eq, int B, int PQ, int d, int avg, unsigned short* __restrict__ frag) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < (B + 31) / 32 * 32 * d) coarse_query_element(eq, B, PQ, d, avg, i, frag);
-}
-
-template <int DC, int MODE>   // DC = d / 16 K chunks
+template <int DC, int MODE, bool NT = false>   // DC = d / 16 K chunks; NT: non-temporal table loads
 __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MODE == kScanSelect ? RAILS_SCAN_WAVES : 2, MODE == kScanSelect ? RAILS_SCAN_WAVES : 2))) void coarse_scan_kernel(CoarseScanArgs a) {
   MOL_RUN_IF(a.run_if);
   extern __shared__ __attribute__((aligned(16))) unsigned short qfrag[];   // [n_qt][DC][64 lanes][8] bf16, then thr
@@ -191,6 +197,14 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
       ntlo_s[i] = -coarse_unorderable(coarse_orderable(thr) - 0x10000u);
     }
   __syncthreads();
+  if constexpr (MODE == kScanSample) {
+    if (blockIdx.x == 0) {
+      if (a.qfrag_out)
+        for (int i = threadIdx.x; i < n_qt * DC * 64; i += kScanThreads) reinterpret_cast<bf16x8*>(a.qfrag_out)[i] = reinterpret_cast<const bf16x8*>(qfrag)[i];
+      for (int i = threadIdx.x; i < a.n_zero; i += kScanThreads) a.zero_words[i] = 0u;
+      if (a.zero_flag && threadIdx.x == 0) *a.zero_flag = 0;
+    }
+  }
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int x = lane & 31, h = lane >> 5;
@@ -202,7 +216,7 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
   // One trip = TU item tiles of a wave, held as B fragments in registers.  The trips are DOUBLE-BUFFERED: the 16-byte loads of
   // the next trip are issued before the current one is scored, so a wave always has a trip of table bytes in flight (with one
   // trip per wave and two waves per SIMD only 4 MB of the chip's reads were outstanding: 4.6 TB/s by Little's law).
-  constexpr int TU = RAILS_SCAN_TU > 0 ? RAILS_SCAN_TU : (MODE != kScanSelect ? (DC <= 4 ? 2 : 1) : (DC <= 2 ? 4 : (DC <= 4 ? 2 : 1)));   // the score stores of the other modes hold 16 addresses per tile
+  constexpr int TU = (MODE == kScanSelect && RAILS_SCAN_TU > 0) ? RAILS_SCAN_TU : (MODE == kScanAll ? (DC <= 4 ? 2 : 1) : (DC <= 2 ? 4 : (DC <= 4 ? 2 : 1)));   // the score stores of kScanAll hold 16 addresses per tile
   struct Trip {
     bf16x8 Bv[TU][DC];
     int64_t item[TU];
@@ -217,7 +231,10 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
       T.item[u] = item;
       const unsigned short* rowp = a.table + item * d + 8 * h;
 #pragma unroll
-      for (int c = 0; c < DC; ++c) T.Bv[u][c] = *reinterpret_cast<const bf16x8*>(rowp + 16 * c);
+      for (int c = 0; c < DC; ++c) {
+        if constexpr (NT) T.Bv[u][c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(rowp + 16 * c));
+        else T.Bv[u][c] = *reinterpret_cast<const bf16x8*>(rowp + 16 * c);
+      }
     }
   };
   auto load_query_tile = [&](int qt, bf16x8 (&A)[DC], cf32x16& ntlo) {
@@ -286,7 +303,40 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
   bf16x8 A[DC];
   cf32x16 ntlo = {0};
   load_query_tile(0, A, ntlo);
+  // Sample mode: mx[qt][r] = the largest score this wave has seen for (query qt * 32 + acc_row(r, h), column x).  The r-th largest
+  // of these maxima over disjoint groups of items is at most the r-th largest sample score, so it bounds the K'-th score of the
+  // corpus from below just as the sample's own r-th largest does (coarse_topk below) -- and the two coincide unless two of the
+  // sample's top r fell into one group (r^2 / 2 groups expected: 0.02 for r = 40 and 32 768 groups).  It replaces B * n / stride
+  // two-byte stores and their read-back by the selection (64 + 64 MB per batch of 32 on a 125 M-item shard: 40 + 48 us) with a
+  // 2 MB block of maxima.
+  cf32x16 mx[MODE == kScanSample ? kSampleMaxQT : 1];
+  if constexpr (MODE == kScanSample) {
+#pragma unroll
+    for (int qt = 0; qt < kSampleMaxQT; ++qt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx[qt][r] = -INFINITY;
+  }
   auto score_trip = [&](int64_t w0, const Trip& T) {
+    if constexpr (MODE == kScanSample) {
+#pragma unroll
+      for (int qt = 0; qt < kSampleMaxQT; ++qt) {
+        if (qt < n_qt) {
+          if (n_qt > 1) load_query_tile(qt, A, ntlo);
+#pragma unroll
+          for (int u = 0; u < TU; ++u) {
+            cf32x16 acc = {0};
+#pragma unroll
+            for (int c = 0; c < DC; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c], T.Bv[u][c], acc, 0, 0, 0);
+            if (w0 + u < n_work) {                                   // a trip past the end holds the last row again: not a sample
+              const float pen = T.in[u] ? 0.0f : -INFINITY;          // nor are the columns past the end of a ragged last tile
+#pragma unroll
+              for (int r = 0; r < 16; ++r) mx[qt][r] = fmaxf(mx[qt][r], acc[r] + pen);
+            }
+          }
+        }
+      }
+      return;
+    }
     for (int qt = 0; qt < n_qt; ++qt) {
       if (n_qt > 1) load_query_tile(qt, A, ntlo);
       unsigned int fired = 0u;
@@ -300,15 +350,11 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
         } else {
           const int64_t w = w0 + u;
           if (w < n_work) {
-            const int64_t colx = MODE == kScanSample ? w * 32 + x : T.item[u];
+            const int64_t colx = T.item[u];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int q = qt * 32 + acc_row(r, h);
-              if (q < B && (T.in[u] || MODE == kScanSample)) {
-                const float sc = T.in[u] ? bf16_rn(acc[r]) : -INFINITY;
-                if (MODE == kScanSample && a.scores16) a.scores16[(int64_t)q * a.ld + colx] = (unsigned short)(__float_as_uint(sc) >> 16);
-                else a.scores[(int64_t)q * a.ld + colx] = sc;
-              }
+              if (q < B && T.in[u]) a.scores[(int64_t)q * a.ld + colx] = bf16_rn(acc[r]);
             }
           }
         }
@@ -318,9 +364,10 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
     }
   };
   int64_t w0 = gw * TU;
-  if (w0 >= n_work) return;
+  if (MODE != kScanSample && w0 >= n_work) return;
   const int64_t hop = n_waves * TU;
   Trip T, N;
+  if (w0 < n_work) {
   load_trip(w0, T);
   for (;;) {
     const int64_t w1 = w0 + hop;
@@ -336,7 +383,17 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
     T = N;
     w0 = w1;
   }
+  }
   if constexpr (MODE == kScanSelect) stage_flush_mixed(stage_s[wave], &stage_n[wave], lane, a.keys, a.counts, a.cap, 1u);
+  if constexpr (MODE == kScanSample) {   // a wave that saw no tile writes -inf: the row of maxima has no holes
+#pragma unroll
+    for (int qt = 0; qt < kSampleMaxQT; ++qt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = qt * 32 + acc_row(r, h);
+        if (q < B) a.scores16[(int64_t)q * a.ld + gw * 32 + x] = (unsigned short)(__float_as_uint(bf16_rn(mx[qt][r])) >> 16);
+      }
+  }
 }
 
 template <int MODE>
@@ -352,13 +409,24 @@ static int launch_coarse_scan(const CoarseScanArgs& a, hipStream_t stream) {
   int64_t grid = (n_work + 4 * tu - 1) / (4 * tu);
   static const int64_t grid_cap = [] { const char* e = getenv("RAILS_SCAN_GRID"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : (int64_t)2048; }();
   if (grid > grid_cap) grid = grid_cap;     // 2048: 8 workgroups of 4 waves per CU
-  if (grid < 1) return kOk;
-  switch (dc) {
-    case 2: hipLaunchKernelGGL((coarse_scan_kernel<2, MODE>), dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a); break;
-    case 4: hipLaunchKernelGGL((coarse_scan_kernel<4, MODE>), dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a); break;
-    case 8: hipLaunchKernelGGL((coarse_scan_kernel<8, MODE>), dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a); break;
-    default: set_error("coarse scan: d = %d (supported: 32, 64, 128)", a.d); return kErrUnsupported;
+  if constexpr (MODE == kScanSample) {
+    if (n_qt > kSampleMaxQT) { set_error("coarse sample scan: batch %d exceeds %d queries", a.B, 32 * kSampleMaxQT); return kErrUnsupported; }
+    grid = a.ld / (32 * (kScanThreads / 64));   // the plan's: every wave writes its 32 columns of the (B, ld) block of maxima
   }
+  if (grid < 1) return kOk;
+  auto go = [&](auto nt) {
+    constexpr bool NT = decltype(nt)::value;
+    switch (dc) {
+      case 2: hipLaunchKernelGGL((coarse_scan_kernel<2, MODE, NT>), dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a); return true;
+      case 4: hipLaunchKernelGGL((coarse_scan_kernel<4, MODE, NT>), dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a); return true;
+      case 8: hipLaunchKernelGGL((coarse_scan_kernel<8, MODE, NT>), dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a); return true;
+      default: return false;
+    }
+  };
+  bool known;
+  if constexpr (MODE == kScanSelect && RAILS_SCAN_NT != 0) known = n_qt == 1 ? go(std::true_type{}) : go(std::false_type{});
+  else known = go(std::false_type{});
+  if (!known) { set_error("coarse scan: d = %d (supported: 32, 64, 128)", a.d); return kErrUnsupported; }
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
@@ -414,8 +482,10 @@ static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 #ifndef RAILS_SAMPLE16
 #define RAILS_SAMPLE16 1   // 0: fp32 threshold samples (measurement)
 #endif
-static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p) {
+// group_max: the sample is the coarse scan's block of per-wave running maxima (kScanSample above) instead of every sampled score
+static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p, bool group_max = false) {
   if (k_prime < 1 || k_prime > 4096 || n < k_prime) return false;
+  if (group_max && B > 32 * kSampleMaxQT) return false;
   const int64_t n_tiles = (n + 31) >> 5;
   // sample every stride-th tile: m = ~8 expected hits above the true K'-th score for large K', never denser than 1/64 of
   // the table (small K' just get fewer expected hits, and r below keeps the miss probability ~1e-9).  m = 16 (stride K'/16)
@@ -440,6 +510,20 @@ static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p) {
   p->stride = stride; p->r = r;
   p->n_sample = ((n_tiles + stride - 1) / stride) * 32;
   if (p->n_sample < r) return false;
+  if (group_max) {
+    // one column block of 32 maxima per wave: up to kSampleGrid workgroups (fewer for small samples: a wave takes whole trips
+    // of up to four tiles), at least 16 so that the row has the 2 048 entries the register-resident selection wants; the waves beyond the
+    // sample write -inf.  The threshold needs r real maxima; 4r keeps two of the top r from sharing a group too often.
+    const int64_t n_work = (n_tiles + stride - 1) / stride;
+    const int waves_per_wg = kScanThreads / 64;
+    int64_t grid = (n_work + 2 * waves_per_wg - 1) / (2 * waves_per_wg);
+    if (grid > kSampleGrid) grid = kSampleGrid;
+    const int64_t trips = (n_work + 3) / 4;   // a wave's trip is up to four tiles (d = 32)
+    const int64_t groups = (trips < grid * waves_per_wg ? trips : grid * waves_per_wg) * 32;
+    if (groups < 4 * (int64_t)r) return false;
+    if (grid < 16) grid = 16;
+    p->n_sample = grid * waves_per_wg * 32;
+  }
   int cap = 8 * k_prime;
   if (cap < 4096) cap = 4096;
   if (cap > 24 * 1024) cap = 24 * 1024;
@@ -449,7 +533,8 @@ static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p) {
   p->off_keys = o; o += align256(sizeof(unsigned long long) * (size_t)B * cap);
   // the sample holds bf16 values: kept as 16-bit patterns where the selection of its r-th largest reads them (B * n_sample
   // elements written by the sample scan and read back once: 0.5 GB per batch of 128 on a 125 M-item shard as fp32)
-  p->sample16 = RAILS_SAMPLE16 && topk_bf16_source_ok(B, p->n_sample, r);
+  p->sample16 = (RAILS_SAMPLE16 || group_max) && topk_bf16_source_ok(B, p->n_sample, r);
+  if (group_max && !p->sample16) return false;
   p->off_sample = o; o += align256((p->sample16 ? sizeof(unsigned short) : sizeof(float)) * (size_t)B * p->n_sample);
   p->off_top_s = o; o += align256(sizeof(float) * (size_t)B * r);
   p->off_top_i = o; o += align256(sizeof(int64_t) * (size_t)B * r);
@@ -462,7 +547,7 @@ static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p) {
 
 size_t coarse_topk_workspace_bytes(const Shape& s, int B, int64_t n, int k_prime) {
   CoarseTopkPlan p;
-  return coarse_topk_plan(B, n, k_prime, &p) ? p.total : 0;
+  return coarse_topk_plan(B, n, k_prime, &p, true) ? p.total : 0;
 }
 
 // flag |= any(v[i] < lo || v[i] > hi): the validity check of a fused scan's candidate counts, on the device
@@ -477,42 +562,37 @@ int range_flag(const int32_t* v, int n, int lo, int hi, int32_t* flag, hipStream
 }
 
 int coarse_topk(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, int k_prime, void* ws,
-                size_t ws_bytes, float* out_scores, int64_t* out_pos, int32_t* out_counts, int n_cu, hipStream_t stream) {
+                size_t ws_bytes, float* out_scores, int64_t* out_pos, int32_t* out_counts, int32_t* out_flag, int n_cu, hipStream_t stream) {
   CoarseTopkPlan p;
-  if (!coarse_topk_plan(B, n, k_prime, &p)) { set_error("coarse_topk: unsupported size (K' = %d, n = %lld)", k_prime, (long long)n); return kErrUnsupported; }
+  if (!coarse_topk_plan(B, n, k_prime, &p, true)) { set_error("coarse_topk: unsupported size (B = %d, K' = %d, n = %lld)", B, k_prime, (long long)n); return kErrUnsupported; }
   if (n >= (1ll << 32)) { set_error("coarse_topk: n does not fit 32-bit positions; shard the corpus"); return kErrUnsupported; }
   if (ws_bytes < p.total) { set_error("coarse_topk: workspace too small"); return kErrNoMem; }
   char* base = static_cast<char*>(ws);
   unsigned int* counts = reinterpret_cast<unsigned int*>(base);
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(base + p.off_keys);
-  float* sample = reinterpret_cast<float*>(base + p.off_sample);
+  unsigned short* sample = reinterpret_cast<unsigned short*>(base + p.off_sample);
   float* top_s = reinterpret_cast<float*>(base + p.off_top_s);
   int64_t* top_i = reinterpret_cast<int64_t*>(base + p.off_top_i);
-  if (hipMemsetAsync(base, 0, p.off_sample, stream) != hipSuccess) return kErrLaunch;   // counts + candidate keys
+  unsigned short* frag = reinterpret_cast<unsigned short*>(base + p.off_qfrag);
 
+  // Four launches: sample scan (which also makes the queries' A fragments for the select scan and zeroes the candidate counters),
+  // the r-th largest of each row of maxima, select scan, key selection (which also reports the counts and raises out_flag).  The candidate lists are
+  // not zeroed: the key selection reads the filled slots only.
   CoarseScanArgs a{};
   a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.d = s.dot_product_dimension; a.avg = avg;
   a.table = static_cast<const unsigned short*>(table); a.n = n;
-  {   // the queries' A fragments, once for both scans
-    unsigned short* frag = reinterpret_cast<unsigned short*>(base + p.off_qfrag);
-    const int elems = (B + 31) / 32 * 32 * a.d;
-    hipLaunchKernelGGL(coarse_query_kernel, dim3((elems + 255) / 256), dim3(256), 0, stream, eq, B, a.PQ, a.d, avg, frag);
-    a.qfrag = frag;
-  }
-  a.scores = p.sample16 ? nullptr : sample; a.scores16 = p.sample16 ? reinterpret_cast<unsigned short*>(sample) : nullptr;
-  a.ld = p.n_sample; a.stride = p.stride;
+  a.qfrag_out = frag; a.zero_words = counts; a.n_zero = B * kSubLists; a.zero_flag = out_flag;
+  a.scores16 = sample; a.ld = p.n_sample; a.stride = p.stride;
   int rc = launch_coarse_scan<kScanSample>(a, stream);
   if (rc != kOk) return rc;
-  rc = topk(a.scores, p.n_sample, B, p.n_sample, p.r, nullptr, 0, top_s, top_i, base + p.off_ws, p.topk_ws, n_cu, stream, nullptr, 0, 0, a.scores16);
+  rc = topk(nullptr, p.n_sample, B, p.n_sample, p.r, nullptr, 0, top_s, top_i, base + p.off_ws, p.topk_ws, n_cu, stream, nullptr, 0, 0, sample);
   if (rc != kOk) return rc;
-  a.scores = nullptr; a.stride = 1;
+  a.qfrag = frag; a.qfrag_out = nullptr; a.zero_words = nullptr; a.n_zero = 0; a.zero_flag = nullptr;
+  a.scores16 = nullptr; a.ld = 0; a.stride = 1;
   a.thr = top_s + (p.r - 1); a.thr_stride = p.r; a.keys = keys; a.cap = p.cap; a.counts = counts;
   rc = launch_coarse_scan<kScanSelect>(a, stream);
   if (rc != kOk) return rc;
-  rc = select_keys(keys, B, p.cap, k_prime, out_scores, out_pos, stream);
-  if (rc != kOk) return rc;
-  hipLaunchKernelGGL(coarse_counts_kernel, dim3((B + 63) / 64), dim3(64), 0, stream, counts, B, p.cap, out_counts);
-  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+  return select_sublists(keys, counts, B, p.cap, kSubLists, k_prime, out_scores, out_pos, out_counts, out_flag, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -111,7 +111,7 @@ int query_prologue(const Shape& s, const Weights& w, const float* q, const int64
 int coarse_build(const Shape& s, const float* ipack, int64_t n, void* table, hipStream_t stream);
 size_t coarse_topk_workspace_bytes(const Shape& s, int B, int64_t n, int k_prime);
 int coarse_topk(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, int k_prime, void* ws,
-                size_t ws_bytes, float* out_scores, int64_t* out_pos, int32_t* out_counts, int n_cu, hipStream_t stream);
+                size_t ws_bytes, float* out_scores, int64_t* out_pos, int32_t* out_counts, int32_t* out_flag, int n_cu, hipStream_t stream);
 size_t component_topk_workspace_bytes(const Shape& s, int B, int64_t n, int k_group);
 int component_topk(const Shape& s, const float* eq, int B, const void* table, int64_t n, int k_group, void* ws, size_t ws_bytes,
                    float* out_scores, int64_t* out_pos, int32_t* out_counts, int n_cu, hipStream_t stream);
@@ -138,6 +138,8 @@ int hstu_encode_fused(const float* emb, const int64_t* ids, const int64_t* lengt
                       float eps, float* out, hipStream_t stream);
 int select_keys(const unsigned long long* keys, int rows, int keys_per_row, int k, float* out_scores, int64_t* out_pos,
                 hipStream_t stream);
+int select_sublists(const unsigned long long* keys, const unsigned int* counts, int rows, int cap, int n_sub, int k, float* out_scores,
+                    int64_t* out_pos, int32_t* out_counts, int32_t* out_flag, hipStream_t stream);
 int coarse_score(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, float* scores, int64_t ld,
                  hipStream_t stream, const int32_t* run_if = nullptr);
 
@@ -160,7 +162,7 @@ bool topk_can_fuse_filter(int64_t n, int k, int width, int k_out);
 int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int64_t* ids, int64_t ids_row_stride,
          float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, int n_cu, hipStream_t stream,
          const int64_t* f_invalid = nullptr, int f_width = 0, int f_k = 0, const unsigned short* scores16 = nullptr,
-         const int32_t* run_if = nullptr);
+         const int32_t* run_if = nullptr, const int64_t* ids_index = nullptr, int64_t ids_index_ld = 0);   // ids_index: see map_id (topk.hip)
 // scores16 != NULL: the rows are bf16 bit patterns (ld, n in elements); only where topk_bf16_source_ok says so
 bool topk_bf16_source_ok(int rows, int64_t n, int k);
 int select_lists(unsigned long long* lists, unsigned int* thr, int rows, int cap, int k, const int64_t* ids,

@@ -89,7 +89,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(Score
     const int64_t tile_addr = p.per_row ? (int64_t)row * p.n_tiles + tile : tile;
     const float4* tEx = reinterpret_cast<const float4*>(p.ipack + tile_addr * (int64_t)G::kTileFloats);
     if constexpr (INDEXED) {
-      int64_t src = p.cand_pos[(int64_t)row * p.n_items + tile * kTileItems + x];
+      int col = (int)tile * kTileItems + x;                        // ragged last tile: the row's last candidate again, those columns are not stored
+      col = col < (int)p.n_items ? col : (int)p.n_items - 1;
+      int64_t src = p.cand_pos[(int64_t)row * p.n_items + col];
       src = src < 0 ? 0 : (src >= p.index_items ? p.index_items - 1 : src);   // callers pass positions of the index; clamped for memory safety only
       tEx = reinterpret_cast<const float4*>(p.ipack) + (src >> 5) * (int64_t)(G::kTileFloats / 4) + (lane & 32) + (src & 31) - lane;
     }

@@ -52,6 +52,17 @@ __device__ __forceinline__ unsigned int orderable(float f) {
 __device__ __forceinline__ float unorderable(unsigned int k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
+// The id written for column `pos` of row `row`: ids[ids_row_stride * row + pos], the position itself without an id table, or --
+// with ids_index (the rows are candidate lists, ids_index[row][pos] the candidate's position in the corpus) -- ids[ids_index[row][pos]]
+// resp. that corpus position (torch.gather + the id lookup of rails/indexing/mol_top_k.py:379-382 inside the selection's launch).
+__device__ __forceinline__ int64_t map_id(const int64_t* __restrict__ ids, int64_t ids_row_stride, const int64_t* __restrict__ ids_index,
+                                          int64_t ids_index_ld, int row, unsigned int pos) {
+  if (ids_index) {
+    const int64_t at = ids_index[(int64_t)row * ids_index_ld + pos];
+    return ids ? ids[ids_row_stride * row + at] : at;
+  }
+  return ids ? ids[ids_row_stride * row + pos] : (int64_t)pos;
+}
 __device__ __forceinline__ unsigned long long make_key(float score, unsigned int pos) {
   return ((unsigned long long)orderable(score) << 32) | (unsigned int)(~pos);
 }
@@ -183,7 +194,8 @@ __global__ __launch_bounds__(kSortThreads) void sort_emit_kernel(const float* __
                                                                 float* __restrict__ out_scores,
                                                                 int64_t* __restrict__ out_ids,
                                                                 unsigned long long* __restrict__ keys_out, int64_t keys_ld, const int32_t* __restrict__ run_if,
-                                                                const SelectState* __restrict__ count_from = nullptr) {
+                                                                const SelectState* __restrict__ count_from = nullptr,
+                                                                const int64_t* __restrict__ ids_index = nullptr, int64_t ids_index_ld = 0) {
   MOL_RUN_IF(run_if);
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
   const int row = blockIdx.x;
@@ -205,7 +217,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_emit_kernel(const float* __
     if (owner && kv != 0ull && rank < (unsigned int)k) {
       const unsigned int pos = ~(unsigned int)(kv & 0xFFFFFFFFull);
       out_scores[(int64_t)row * k + rank] = unorderable((unsigned int)(kv >> 32));
-      out_ids[(int64_t)row * k + rank] = ids ? ids[ids_row_stride * row + pos] : (int64_t)pos;
+      out_ids[(int64_t)row * k + rank] = map_id(ids, ids_row_stride, ids_index, ids_index_ld, row, pos);
     }
     return;
   }
@@ -237,7 +249,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_emit_kernel(const float* __
     if (out_scores) {
       const unsigned int pos = ~(unsigned int)(kv & 0xFFFFFFFFull);
       out_scores[(int64_t)row * k + j] = unorderable((unsigned int)(kv >> 32));
-      out_ids[(int64_t)row * k + j] = ids ? ids[ids_row_stride * row + pos] : (int64_t)pos;
+      out_ids[(int64_t)row * k + j] = map_id(ids, ids_row_stride, ids_index, ids_index_ld, row, pos);
     } else {
       keys_out[row * keys_ld + (int64_t)blockIdx.y * k + j] = kv;
     }
@@ -525,6 +537,7 @@ struct RowSelectArgs {
   unsigned int* keys_thr;
   int k; int lds_keys;
   const int64_t* ids; int64_t ids_row_stride;                    // final output (out_scores != NULL)
+  const int64_t* ids_index; int64_t ids_index_ld;                // map_id
   float* out_scores; int64_t* out_ids;
   unsigned long long* keys_out;                                  // else: keys_out[(row*gridDim.y + c)*k + j]
   const int32_t* run_if;                                         // launch predicate (mol_kernels.h)
@@ -533,7 +546,7 @@ struct RowSelectArgs {
   const int64_t* f_invalid; int f_width; int f_k;
 };
 
-template <int VPT, bool KEYS>
+template <int VPT, bool KEYS, bool IDX = false>   // IDX: ids through ids_index (map_id); built for VPT = 4 only (candidate rows of <= 4 096)
 __global__ __launch_bounds__(kRowThreads) void row_select_kernel(const RowSelectArgs a) {
   static_assert(VPT % 4 == 0, "float4 loads");
   MOL_RUN_IF(a.run_if);
@@ -627,7 +640,9 @@ __global__ __launch_bounds__(kRowThreads) void row_select_kernel(const RowSelect
     if (a.out_scores) {
       const unsigned int pos = ~(unsigned int)(kv & 0xFFFFFFFFull);
       const float sc = unorderable((unsigned int)(kv >> 32));
-      const int64_t id = a.ids ? a.ids[a.ids_row_stride * row + pos] : (int64_t)pos;
+      int64_t id;
+      if constexpr (IDX) id = map_id(a.ids, a.ids_row_stride, a.ids_index, a.ids_index_ld, row, pos);
+      else id = a.ids ? a.ids[a.ids_row_stride * row + pos] : (int64_t)pos;
       if (fuse) { f_sc[j] = sc; f_id[j] = id; }
       else { a.out_scores[(int64_t)row * k + j] = sc; a.out_ids[(int64_t)row * k + j] = id; }
     } else {
@@ -780,9 +795,9 @@ __global__ __launch_bounds__(kRowThreads) void row_select_kernel(const RowSelect
   finish();
 }
 
-template <int VPT, bool KEYS>
+template <int VPT, bool KEYS, bool IDX = false>
 static int launch_row_select_t(const RowSelectArgs& a, int rows, int chunks, hipStream_t stream) {
-  hipLaunchKernelGGL((row_select_kernel<VPT, KEYS>), dim3(rows, chunks), dim3(kRowThreads),
+  hipLaunchKernelGGL((row_select_kernel<VPT, KEYS, IDX>), dim3(rows, chunks), dim3(kRowThreads),
                      (a.lds_keys + 2 * kRowThreads) * sizeof(unsigned long long), stream, a);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
@@ -866,7 +881,8 @@ bool topk_bf16_source_ok(int rows, int64_t n, int k) {
 
 int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int64_t* ids, int64_t ids_row_stride,
          float* out_scores, int64_t* out_ids, void* ws, size_t ws_bytes, int n_cu, hipStream_t stream,
-         const int64_t* f_invalid, int f_width, int f_k, const unsigned short* scores16, const int32_t* run_if) {
+         const int64_t* f_invalid, int f_width, int f_k, const unsigned short* scores16, const int32_t* run_if,
+         const int64_t* ids_index, int64_t ids_index_ld) {
   if (rows <= 0 || k <= 0) return kOk;
   if (scores16 && !topk_bf16_source_ok(rows, n, k)) { set_error("topk: no bf16-source path at n = %lld, k = %d", (long long)n, k); return kErrUnsupported; }
   if (f_invalid && !topk_can_fuse_filter(n, k, f_width, f_k)) { set_error("topk: the seen-id filter cannot be fused at n = %lld, k = %d, width = %d", (long long)n, k, f_width); return kErrUnsupported; }
@@ -874,7 +890,20 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
   if (n >= (1ll << 32)) { set_error("n = %lld does not fit 32-bit positions; shard the corpus", (long long)n); return kErrUnsupported; }
   if (ensure_sort_lds() != kOk) return kErrLaunch;
   const int32_t* pred = run_if;   // the caller's launch predicate (NULL for the internal selections of the fused scans)
-  if (n > 1024 && k <= kRowMaxK) {
+  // 512 < n <= 1024 (the K' = 1 000 candidates of a two-pass rerank, k = 120): the register-resident selection's fast path instead of a
+  // full sort of 1 024 keys (13.6 -> 7 us per 32 rows)
+  if (ids_index && n > kSortCap) { set_error("topk: ids_index needs n <= %d", kSortCap); return kErrUnsupported; }
+  if (ids_index && n > 512 && n <= 4 * kRowThreads && k <= kRowMaxK && !scores16 && !f_invalid) {
+    RowSelectArgs a{};
+    a.run_if = pred;
+    a.scores = scores; a.ld = ld; a.n = n; a.k = k; a.chunk = n; a.ids = ids; a.ids_row_stride = ids_row_stride; a.out_scores = out_scores; a.out_ids = out_ids;
+    a.ids_index = ids_index; a.ids_index_ld = ids_index_ld;
+    int lds_keys = 2;                                   // as launch_row_select sets it
+    while (lds_keys < a.k) lds_keys <<= 1;
+    a.lds_keys = a.k <= kRowFastK ? kRowCandCap : lds_keys;
+    return launch_row_select_t<4, false, true>(a, rows, 1, stream);
+  }
+  if ((n > 1024 || (n > 512 && k <= kRowFastK && !scores16 && !f_invalid)) && k <= kRowMaxK && !ids_index) {
     RowSelectArgs a{};
     a.run_if = pred;
     a.scores = scores; a.scores16 = scores16; a.ld = ld; a.n = n; a.k = k;
@@ -902,7 +931,7 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
     const int npad = next_pow2((int)n < 2 ? 2 : (int)n);
     hipLaunchKernelGGL(sort_emit_kernel, dim3(rows), dim3(kSortThreads), (npad <= kSortThreads ? 3 * npad : npad) * sizeof(unsigned long long), stream,
                        scores, ld, n, n, (const unsigned long long*)nullptr, (int64_t)0, 0, k, npad, ids, ids_row_stride,
-                       out_scores, out_ids, (unsigned long long*)nullptr, (int64_t)0, pred);
+                       out_scores, out_ids, (unsigned long long*)nullptr, (int64_t)0, pred, (const SelectState*)nullptr, ids_index, ids_index_ld);
     return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
   }
   if (ws_bytes < topk_workspace_bytes(rows, n, k)) { set_error("top-k workspace too small"); return kErrNoMem; }
@@ -934,7 +963,7 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
                      (int64_t)npad, k, chunk, pred);
   hipLaunchKernelGGL(sort_emit_kernel, dim3(rows), dim3(kSortThreads), (npad <= kSortThreads ? 3 * npad : npad) * sizeof(unsigned long long), stream, scores, ld, n, n,
                      cand, (int64_t)npad, npad, k, npad, ids, ids_row_stride, out_scores, out_ids, (unsigned long long*)nullptr,
-                     (int64_t)0, pred, (const SelectState*)st);
+                     (int64_t)0, pred, (const SelectState*)st, ids_index, ids_index_ld);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
@@ -951,6 +980,170 @@ int select_keys(const unsigned long long* keys, int rows, int keys_per_row, int 
   b.keys_in = keys; b.keys_per_row = keys_per_row; b.k = k;
   b.out_scores = out_scores; b.out_ids = out_pos;
   return launch_row_select<true>(b, rows, 1, keys_per_row, stream);
+}
+
+// ---- selection over a row's candidate SUB-LISTS (the fused coarse top-K' of mol_coarse.hip) -------------------------------------
+// The select scan leaves, per row, n_sub sub-lists of cap / n_sub slots with their fill counts.  One workgroup per row:
+//   * reads the counts, writes the row's candidate count (cap + 1 when a sub-list overflowed) and raises *out_flag when the row is
+//     not exact (overflow, or fewer than k candidates) -- the counts kernel and the range check of the caller, in this launch;
+//   * loads the FILLED slots only (the lists need no zeroing between calls) into registers as 64-bit keys;
+//   * finds the k-th largest key by MSD radix selection, eight bits per pass: a 256-bin LDS histogram of the keys that match the
+//     resolved prefix (a wave adds its most common digit with one atomic), one wave turns it into the digit.  Bytes in which all
+//     keys agree -- bits of OR ^ AND over the row -- take no pass (bf16 scores: the two low bytes of the score word; the top byte
+//     of the positions), and the passes stop as soon as every key that still matches is wanted: 3-5 passes of two barriers for a
+//     row of ~4 000 candidates, where the two-bits-per-step bisection of row_select_kernel took 17 (+ 16 on the positions when
+//     the k-th score is tied, which bf16 scores almost always are);
+//   * compacts the k winners into LDS, sorts them (block_sort_desc / block_sort_desc_multi) and writes (score, position).
+// K' = 1 000 of ~4 100 candidates per row, 32 rows: 56.7 us (row_select_kernel<8, true>) + 5.1 (counts) + 5.1 (memset of the
+// lists) -> see profiles/README.md.
+struct SubSelArgs {
+  const unsigned long long* keys; const unsigned int* counts; int cap, n_sub, k, npad;
+  float* out_scores; int64_t* out_pos; int32_t* out_counts; int32_t* out_flag;
+};
+
+template <int VPT>
+__global__ __launch_bounds__(kRowThreads) void sublist_select_kernel(const SubSelArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];   // npad sort slots (+ 2 npad exchange slots when npad <= 1024)
+  __shared__ unsigned int cnt_s[64];
+  __shared__ __attribute__((aligned(16))) unsigned int hist[2][256];
+  __shared__ unsigned long long red[2];      // OR, AND over the row's keys
+  __shared__ unsigned int pick[3];           // digit, keys still wanted among the matching ones, matching keys
+  __shared__ unsigned int cursor;
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int k = a.k, subcap = a.cap / a.n_sub, npad = a.npad;
+  if (tid < a.n_sub) cnt_s[tid] = a.counts[(int64_t)row * a.n_sub + tid];
+  if (tid < 512) (&hist[0][0])[tid] = 0u;
+  if (tid == 0) { cursor = 0u; red[0] = 0ull; red[1] = ~0ull; }
+  for (int i = tid; i < npad; i += kRowThreads) skeys[i] = 0ull;
+  __syncthreads();
+  unsigned int total = 0u, held = 0u;
+  bool over = false;
+  for (int sub = 0; sub < a.n_sub; ++sub) {
+    const unsigned int c = cnt_s[sub];
+    total += c;
+    held += c < (unsigned int)subcap ? c : (unsigned int)subcap;
+    over |= c > (unsigned int)subcap;
+  }
+  if (tid == 0) {
+    a.out_counts[row] = over ? a.cap + 1 : (int32_t)total;
+    if ((over || total < (unsigned int)k) && a.out_flag) *a.out_flag = 1;   // every writer stores the same value
+  }
+  const unsigned int want = held < (unsigned int)k ? held : (unsigned int)k;   // < k only on rows the caller redoes
+  unsigned long long key[VPT];
+  unsigned long long vor = 0ull, vand = ~0ull;
+  const unsigned long long* src = a.keys + (int64_t)row * a.cap;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const int i = j * kRowThreads + tid;
+    const int sub = i / subcap;
+    const bool filled = i < a.cap && (unsigned int)(i - sub * subcap) < cnt_s[sub < a.n_sub ? sub : 0];
+    key[j] = filled ? src[i] : 0ull;
+    if (key[j]) { vor |= key[j]; vand &= key[j]; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { vor |= __shfl_xor(vor, o, 64); vand &= __shfl_xor(vand, o, 64); }
+  if (lane == 0) { atomicOr(&red[0], vor); atomicAnd(&red[1], vand); }
+  __syncthreads();
+  vor = red[0];
+  const unsigned long long varying = want ? vor ^ red[1] : 0ull;
+  unsigned long long prefix = 0ull, fixed = 0ull;
+  unsigned int need = want;
+  int pass = 0;
+  for (int byte = 7; byte >= 0 && want; --byte) {
+    const int shift = 8 * byte;
+    const unsigned long long bmask = 0xFFull << shift;
+    if ((varying & bmask) == 0ull) { prefix |= vor & bmask; fixed |= bmask; continue; }   // all keys agree on this byte
+    unsigned int* h = hist[pass & 1];
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const bool act = key[j] != 0ull && (key[j] & fixed) == prefix;
+      const unsigned int digit = (unsigned int)(key[j] >> shift) & 255u;
+      const unsigned long long m = __ballot(act);
+      if (m) {   // wave-uniform
+        const int leader = __ffsll((long long)m) - 1;
+        const unsigned int d0 = (unsigned int)__shfl((int)digit, leader, 64);
+        const unsigned long long same = __ballot(act && digit == d0);
+        if (lane == leader) atomicAdd(&h[d0], (unsigned int)__popcll(same));
+        if (act && digit != d0) atomicAdd(&h[digit], 1u);
+      }
+    }
+    if (tid >= 256 && tid < 512) hist[(pass + 1) & 1][tid - 256] = 0u;   // the next pass' bins (last read before the previous barrier)
+    __syncthreads();
+    if (tid < 64) {
+      const uint4 c4 = reinterpret_cast<const uint4*>(h)[lane];      // bins 4 lane .. 4 lane + 3
+      const unsigned int mine = c4.x + c4.y + c4.z + c4.w;
+      unsigned int incl = mine;                                       // keys in the bins of lanes >= lane
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_down(incl, o, 64); if (lane + o < 64) incl += t; }
+      unsigned int cum = incl - mine;                                 // keys in higher bins
+      const unsigned int c[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+      for (int b = 3; b >= 0; --b) {
+        if (cum < need && need <= cum + c[b]) { pick[0] = 4u * lane + b; pick[1] = need - cum; pick[2] = c[b]; }
+        cum += c[b];
+      }
+    }
+    __syncthreads();
+    prefix |= (unsigned long long)pick[0] << shift;
+    fixed |= bmask;
+    need = pick[1];
+    ++pass;
+    if (pick[2] == need) break;      // every key that still matches the prefix is wanted
+  }
+  // exactly `want` keys satisfy (key & fixed) >= prefix
+  {
+    unsigned int c = 0u;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) c += (want && key[j] != 0ull && (key[j] & fixed) >= prefix) ? 1u : 0u;
+    unsigned int incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int x = __shfl_up(incl, o, 64); if (lane >= o) incl += x; }
+    unsigned int base = 0u;
+    if (lane == 63 && incl) base = atomicAdd(&cursor, incl);
+    base = (unsigned int)__shfl((int)base, 63, 64);
+    unsigned int at = base + incl - c;
+    if (c) {
+#pragma unroll
+      for (int j = 0; j < VPT; ++j)
+        if (key[j] != 0ull && (key[j] & fixed) >= prefix) { if (at < (unsigned int)npad) skeys[at] = key[j]; ++at; }
+    }
+  }
+  __syncthreads();
+  auto emit = [&](unsigned long long kv, int j) {
+    a.out_scores[(int64_t)row * k + j] = kv ? unorderable((unsigned int)(kv >> 32)) : -INFINITY;
+    a.out_pos[(int64_t)row * k + j] = kv ? (int64_t)(~(unsigned int)(kv & 0xFFFFFFFFull)) : 0;   // an unfilled slot names item 0 (such a row is redone by the caller)
+  };
+  if (npad <= kRowThreads) {
+    unsigned long long kv = tid < npad ? skeys[tid] : 0ull;
+    kv = block_sort_desc(kv, npad, skeys + npad);
+    if (tid < k) emit(kv, tid);
+  } else {
+    if (npad == 2 * kRowThreads) block_sort_desc_multi<2>(skeys);
+    else block_sort_desc_multi<4>(skeys);
+    for (int j = tid; j < k; j += kRowThreads) emit(skeys[j], j);
+  }
+}
+
+// keys[row][sub][slot], counts[row][sub]: the k largest keys of every row as (score, position), descending; out_counts[row] = its
+// candidates (cap + 1: a sub-list overflowed); *out_flag (optional, zeroed by the caller) = 1 if some row has not k <= count <= cap.
+int select_sublists(const unsigned long long* keys, const unsigned int* counts, int rows, int cap, int n_sub, int k, float* out_scores,
+                    int64_t* out_pos, int32_t* out_counts, int32_t* out_flag, hipStream_t stream) {
+  static_assert(kSortThreads == kRowThreads, "block_sort_desc_multi sorts KPT * kSortThreads keys with the workgroup of this kernel");
+  if (rows <= 0 || k <= 0) return kOk;
+  if (k > kRowMaxK || cap > 24 * kRowThreads || k > cap || n_sub < 1 || n_sub > 64 || cap % n_sub) {
+    set_error("select_sublists: k = %d of %d slots in %d sub-lists is out of range", k, cap, n_sub);
+    return kErrUnsupported;
+  }
+  SubSelArgs a{};
+  a.keys = keys; a.counts = counts; a.cap = cap; a.n_sub = n_sub; a.k = k;
+  a.npad = next_pow2(k < 64 ? 64 : k);
+  a.out_scores = out_scores; a.out_pos = out_pos; a.out_counts = out_counts; a.out_flag = out_flag;
+  const size_t lds = (size_t)(a.npad <= kRowThreads ? 3 * a.npad : a.npad) * sizeof(unsigned long long);
+  if (cap <= 4 * kRowThreads) hipLaunchKernelGGL((sublist_select_kernel<4>), dim3(rows), dim3(kRowThreads), lds, stream, a);
+  else if (cap <= 8 * kRowThreads) hipLaunchKernelGGL((sublist_select_kernel<8>), dim3(rows), dim3(kRowThreads), lds, stream, a);
+  else if (cap <= 16 * kRowThreads) hipLaunchKernelGGL((sublist_select_kernel<16>), dim3(rows), dim3(kRowThreads), lds, stream, a);
+  else hipLaunchKernelGGL((sublist_select_kernel<24>), dim3(rows), dim3(kRowThreads), lds, stream, a);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
 // Final selection of the fused score + select path (mol_select.h): sparse rows of `cap` slots, empty ones 0.

@@ -384,7 +384,7 @@ class MolEngine:
         return bool(self.lib.rails_mol_score_indexed_supported(C.byref(self.shape), int(batch), int(n_cand)))
 
     def score_indexed(self, qpack: torch.Tensor, batch: int, index: MolIndex, positions: torch.Tensor) -> torch.Tensor:
-        """(B, n_cand) logits of per-row candidates given as positions of `index` (a multiple of 32 per row, all inside the index):
+        """(B, n_cand) logits of per-row candidates given as positions of `index` (all inside the index):
         gather_index + score_candidates without the gathered copy (include/rails_amd.h rails_mol_score_indexed)."""
         positions = positions.to(device=index.buf.device, dtype=torch.int64).contiguous()
         n_cand = positions.shape[1]
@@ -507,10 +507,11 @@ class MolEngine:
             )
         return out
 
-    def coarse_topk(self, eq: torch.Tensor, table: torch.Tensor, average_queries: bool, k_prime: int):
+    def coarse_topk(self, eq: torch.Tensor, table: torch.Tensor, average_queries: bool, k_prime: int, with_flag: bool = False):
         """Fused coarse scoring + exact top-K' (no (B, N) score matrix).  -> (scores (B, K'), positions (B, K'), counts (B,)
         int32) or None when the sizes are unsupported.  The result is exact iff K' <= counts[b] <= capacity for every b
-        (see include/rails_amd.h); the caller checks and falls back to coarse_scores + topk otherwise."""
+        (see include/rails_amd.h); the caller checks and falls back to coarse_scores + topk otherwise.  with_flag: a fourth
+        element, a device int32 that is 1 iff some count is out of range (written by the call's own launches)."""
         B, n = eq.shape[0], table.shape[0]
         ws_bytes = self.lib.rails_mol_coarse_topk_workspace_bytes(C.byref(self.shape), B, n, k_prime)
         if ws_bytes == 0:
@@ -520,14 +521,15 @@ class MolEngine:
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         out_s = torch.empty((B, k_prime), dtype=torch.float32, device=dev)
         out_p = torch.empty((B, k_prime), dtype=torch.int64, device=dev)
-        counts = torch.empty((B,), dtype=torch.int32, device=dev)
+        counts = torch.empty((B + 1,), dtype=torch.int32, device=dev)   # [B]: the out-of-range flag
+        flag = counts[B:]
         with _on_device(dev):
             _lib.check(
                 self.lib.rails_mol_coarse_topk(C.byref(self.shape), _ptr(eq), B, 1 if average_queries else 0, _ptr(table), n, k_prime,
-                                               _ptr(ws), ws_bytes, _ptr(out_s), _ptr(out_p), _ptr(counts), _stream()),
+                                               _ptr(ws), ws_bytes, _ptr(out_s), _ptr(out_p), _ptr(counts), _ptr(flag) if with_flag else None, _stream()),
                 "rails_mol_coarse_topk",
             )
-        return out_s, out_p, counts
+        return (out_s, out_p, counts[:B], flag) if with_flag else (out_s, out_p, counts[:B])
 
     @staticmethod
     def coarse_topk_capacity(k_prime: int) -> int:
@@ -728,6 +730,30 @@ def gate_combine(logits: torch.Tensor, pair_part: Optional[torch.Tensor], query_
                                               1 if item_part_per_row else 0, _lib.RAILS_COMBINE_GLU_SILU if glu_silu else _lib.RAILS_COMBINE_NONE,
                                               1 if renormalise else 0, float(eps), _ptr(out), _ptr(probs), _stream()), "rails_mol_gate_combine")
     return out, probs
+
+
+def topk_candidates(scores: torch.Tensor, k: int, positions: torch.Tensor, ids: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The final_topk of a candidate rerank in one launch (include/rails_amd.h rails_topk_candidates; reference
+    rails/indexing/mol_top_k.py:371-382): top-k of every row of `scores` (rows, n_cand); the id of candidate j of row b is
+    ids[positions[b, j]] (ids: the module's flat id row), or positions[b, j] itself without ids."""
+    lib = _lib.load()
+    _require_device(scores, "scores")
+    if scores.dtype != torch.float32 or scores.stride(1) != 1:
+        scores = _f32c(scores)
+    rows, n = scores.shape
+    if k > n:
+        raise RuntimeError(f"selected index k out of range (k={k}, n={n})")
+    positions = positions.to(device=scores.device, dtype=torch.int64).contiguous()
+    if positions.shape != (rows, n):
+        raise ValueError("positions must be (rows, n_cand) like scores")
+    if ids is not None:
+        ids = ids.to(device=scores.device, dtype=torch.int64).reshape(-1).contiguous()
+    out_s = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
+    out_i = torch.empty((rows, k), dtype=torch.int64, device=scores.device)
+    with _on_device(scores.device):
+        _lib.check(lib.rails_topk_candidates(_ptr(scores), scores.stride(0), rows, n, k, _ptr(positions), _ptr(ids), _ptr(out_s), _ptr(out_i), _stream()),
+                   "rails_topk_candidates")
+    return out_s, out_i
 
 
 def topk_filter_fusable(n: int, k_prime: int, width: int, k: int) -> bool:

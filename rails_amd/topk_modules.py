@@ -93,12 +93,8 @@ class MoLTopKModule(TopKModule):
         candidates in place (rails_mol_score_indexed: no gathered copy, one launch; the same bits as gather + score_candidates);
         the f16 builds, which have no indexed instantiation, gather a per-row index of the candidates first."""
         K = positions.shape[1]
-        Kp = (K + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS
-        if eng.score_indexed_supported(batch, Kp):
-            pos = positions.to(torch.int64)
-            if Kp != K:
-                pos = torch.nn.functional.pad(pos, (0, Kp - K), value=0)    # position 0 always exists; its columns are cut off below
-            return eng.score_indexed(qpack, batch, self._index, pos)[:, :K]
+        if eng.score_indexed_supported(batch, K):
+            return eng.score_indexed(qpack, batch, self._index, positions)   # any K: the kernel masks the ragged last tile
         cand, kp = eng.gather_index(self._index, positions)
         return eng.score_candidates(qpack, batch, cand, kp)[:, :K]
 
@@ -633,24 +629,18 @@ class MoLAvgTopK(MoLTopKModule):
         # Same scores and the same exact top-K' as the materialising path below -- when every query's candidate count
         # landed inside [K', capacity]; the check costs one 128-byte device-to-host copy.
         if n >= self.fused_coarse_min_items and self._avg_top_k <= 4096 and not getattr(self, "_no_fused", False):
-            fused = eng.coarse_topk(eq, table, average_queries, self._avg_top_k)
+            fused = eng.coarse_topk(eq, table, average_queries, self._avg_top_k, with_flag=True)
             if fused is not None:
-                sc, idx, counts = fused
-                k_lo, k_hi = self._avg_top_k, eng.coarse_topk_capacity(self._avg_top_k)
+                # bad: 1 iff some row's candidate count is outside [K', capacity] -- raised by the call's key-selection launch
+                sc, idx, counts, bad = fused
                 if eq.shape[0] * n * 4 <= self.DEVICE_REDO_BYTES:
-                    # the check and the redo ON THE DEVICE: a flag kernel looks at the counts, the materialising scan and its top-K'
-                    # are enqueued under that flag as their launch predicate and overwrite (sc, idx) -- no-ops unless a count was
-                    # out of range; nothing for the host to wait for (the (B, N) score buffer is recycled across calls)
-                    flag = self._buf("redo_flag", 1, torch.int32)
-                    flag.zero_()
-                    E.range_flag(counts, k_lo, k_hi, flag)
-                    coarse = eng.coarse_scores(eq, table, average_queries, out=self._buf("coarse_all", eq.shape[0] * n, torch.float32).view(eq.shape[0], n), run_if=flag)
-                    E.topk(coarse, self._avg_top_k, out=(sc, idx), run_if=flag)
+                    # the redo ON THE DEVICE: the materialising scan and its top-K' are enqueued under that flag as their launch
+                    # predicate and overwrite (sc, idx) -- no-ops unless a count was out of range; nothing for the host to wait
+                    # for (the (B, N) score buffer is recycled across calls)
+                    coarse = eng.coarse_scores(eq, table, average_queries, out=self._buf("coarse_all", eq.shape[0] * n, torch.float32).view(eq.shape[0], n), run_if=bad)
+                    E.topk(coarse, self._avg_top_k, out=(sc, idx), run_if=bad)
                     return (sc, idx) if with_scores else idx
-                # one flag kernel + ONE 4-byte read (was a min and a max reduction, two reads)
-                bad = torch.zeros(1, dtype=torch.int32, device=counts.device)
-                E.range_flag(counts, k_lo, k_hi, bad)
-                check = lambda: int(bad.item()) == 0   # noqa: E731
+                check = lambda: int(bad.item()) == 0   # noqa: E731  (ONE 4-byte read, after everything else is enqueued)
                 if pending is not None:
                     pending.append(check)
                     return (sc, idx) if with_scores else idx
@@ -664,7 +654,7 @@ class MoLAvgTopK(MoLTopKModule):
         """Full MoL on per-row candidates (positions, (B, K')) -> exact top-min(k, K') among them."""
         eng = self._bind()
         scores = self._score_at(eng, qpack, batch, cand_idx)
-        return E.topk(scores, min(k, cand_idx.shape[1]), ids=self._ids_flat[cand_idx])
+        return E.topk_candidates(scores, min(k, cand_idx.shape[1]), cand_idx, self._ids_flat)
 
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
         if k > self._avg_top_k:  # the reference raises after doing the work (mol_top_k.py:383-386)
@@ -680,7 +670,7 @@ class MoLAvgTopK(MoLTopKModule):
             with torch.profiler.record_function("filtered_scoring"):
                 cand_scores = self._score_at(eng, qpack, query_embeddings.size(0), idx)
             with torch.profiler.record_function("final_topk"):
-                scores, ids = E.topk(cand_scores, min(k, idx.shape[1]), ids=self._ids_flat[idx])
+                scores, ids = E.topk_candidates(cand_scores, min(k, idx.shape[1]), idx, self._ids_flat)   # top-k + gather + id lookup, one launch
             # everything is enqueued; only now look at the fused scan's candidate counts (rarely out of range: heavy ties)
             if all(chk() for chk in pending):
                 break
@@ -781,7 +771,7 @@ class _ComponentCandidates:
         if big:   # full ranking of more than 16 384 candidates: stable descending sort = (score desc, column asc), rails_topk's tie rule
             vals, order = torch.sort(scores, dim=1, descending=True, stable=True)
             return vals, torch.gather(self._ids_flat[sorted_idx], 1, order)
-        return E.topk(scores, k, ids=self._ids_flat[sorted_idx], sorted=sorted)
+        return E.topk_candidates(scores, k, sorted_idx, self._ids_flat)
 
 
 class MoLNaiveTopK(MoLTopKModule, _ComponentCandidates):

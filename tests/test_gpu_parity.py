@@ -464,6 +464,70 @@ def test_fused_coarse_topk_falls_back_on_heavy_ties(dev):
         assert torch.equal(s1, s2) and torch.equal(i1, i2)
 
 
+def test_fused_coarse_topk_raises_its_flag_exactly_when_a_count_is_out_of_range(dev):
+    """ABI 6: rails_mol_coarse_topk reports `out_of_range` from inside its key-selection launch -- 0 on an ordinary corpus (and
+    the counts in range), 1 on the heavy-ties corpus (a sub-list overflowed), 1 when fewer than K' candidates reach the threshold
+    (a corpus whose best K' scores are -inf cannot happen; an under-filled row is produced with a table of NaN rows instead, whose
+    scores never compare >= a threshold): such a row names position 0 with score -inf in its unfilled slots."""
+    cfg = O.CONFIGS["amzn-books"]
+    mol = build_module(cfg, O.synthetic_weights(cfg, seed=2), dev)
+    n = 300_000
+    q = O.synthetic_queries(cfg, 8, seed=4).to(dev)
+    ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    with torch.inference_mode():
+        X = torch.from_numpy(O.hash_item_table(6, 0, n, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+        at = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=200)
+        eng = at._bind()
+        _, eq, _ = eng.query_pack(q, None, want_plain=True)
+        cap = eng.coarse_topk_capacity(200)
+        for _ in range(2):    # the flag is reset by every call
+            _, _, counts, flag = eng.coarse_topk(eq, at._table(), False, 200, with_flag=True)
+            assert int(flag.item()) == 0 and int(counts.min()) >= 200 and int(counts.max()) <= cap
+            tied = at._table()[torch.arange(n, device=dev) % 40].contiguous()
+            _, _, counts, flag = eng.coarse_topk(eq, tied, False, 200, with_flag=True)
+            assert int(flag.item()) == 1 and int(counts.max()) > cap
+        nan_table = at._table().clone()
+        nan_table[1000:] = float("nan")       # 1 000 real items: the sample sees a few of them, the scan collects fewer than K' = 2 000
+        fs, fp, counts, flag = eng.coarse_topk(eq, nan_table, False, 2000, with_flag=True)
+        assert int(flag.item()) == 1 and int(counts.min()) < 2000
+        for b in range(eq.shape[0]):
+            c = int(counts[b])
+            if c < 2000:
+                assert bool((fp[b, c:] == 0).all()) and bool(torch.isinf(fs[b, c:]).all()) and bool((fs[b, c:] < 0).all())
+                assert bool((fp[b, :c] < 1000).all())
+
+
+@pytest.mark.parametrize("rows,n,k", [(32, 1000, 120), (5, 100, 10), (7, 600, 512), (3, 1024, 300), (4, 3000, 200), (2, 4096, 2000), (3, 9000, 100), (1, 513, 513)])
+def test_topk_candidates_equals_topk_over_gathered_ids(dev, rows, n, k):
+    """rails_topk_candidates (ABI 6; reference mol_top_k.py:371-382 in one launch): top-k of candidate rows with the ids looked
+    up THROUGH the candidates' corpus positions == rails_topk with ids = item_ids[positions] (the gathered copy the module made
+    before); scores with ties (few distinct values), so the column tie rule shows."""
+    g = torch.Generator().manual_seed(rows * 7919 + n)
+    corpus = 50_000
+    scores = (torch.randint(0, 37, (rows, n), generator=g).float() / 8.0).to(dev)
+    pos = torch.randint(0, corpus, (rows, n), generator=g).to(dev)
+    item_ids = (torch.arange(corpus, dtype=torch.int64, device=dev) * 3 + 11)
+    ws, wi = E.topk(scores, k, ids=item_ids[pos])
+    gs, gi = E.topk_candidates(scores, k, pos, item_ids)
+    assert torch.equal(gs, ws) and torch.equal(gi, wi)
+    gs, gp = E.topk_candidates(scores, k, pos)               # no id table: the corpus positions themselves
+    assert torch.equal(gs, ws) and torch.equal(gp, torch.gather(pos, 1, E.topk(scores, k)[1]))
+
+
+@pytest.mark.parametrize("n,k", [(513, 1), (600, 120), (1000, 120), (1024, 512), (777, 512), (1000, 513)])
+def test_topk_between_512_and_1024_columns(dev, n, k):
+    """Rows of 513 .. 1 024 scores with k <= 512 take the register-resident selection (they were fully sorted before): the same
+    (scores, positions) as a stable descending sort, ties and -inf included."""
+    g = torch.Generator().manual_seed(n * 31 + k)
+    scores = (torch.randint(0, 50, (6, n), generator=g).float() / 4.0)
+    scores[0, : n // 2] = float("-inf")
+    scores[1] = 1.5
+    scores = scores.to(dev)
+    vals, order = torch.sort(scores, dim=1, descending=True, stable=True)
+    gs, gp = E.topk(scores, k)
+    assert torch.equal(gs, vals[:, :k]) and torch.equal(gp, order[:, :k])
+
+
 @pytest.mark.parametrize("cfg_name,n,k_g", [("amzn-books", 300_001, 5), ("amzn-books", 300_001, 100), ("ml-1m", 280_000, 50)])
 def test_fused_component_topk_equals_the_materialised_path(dev, cfg_name, n, k_g):
     """Candidate generation of MoLNaiveTopK / MoLCombTopK at scale: same MFMA arithmetic as rails_mol_component_score, so the
@@ -1690,7 +1754,8 @@ def test_filtered_merge_equals_merge_then_filter(dev, R, rows, k, width, k_out):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg_name,N,B,n_cand", [("amzn-books", 50_003, 5, 64), ("amzn-books", 200_000, 33, 352), ("ml-20m", 27_278, 32, 288), ("ml-1m", 3_883, 7, 32)])
+@pytest.mark.parametrize("cfg_name,N,B,n_cand", [("amzn-books", 50_003, 5, 64), ("amzn-books", 200_000, 33, 352), ("ml-20m", 27_278, 32, 288), ("ml-1m", 3_883, 7, 32),
+                                                 ("amzn-books", 50_003, 32, 1000), ("amzn-books", 50_003, 3, 5), ("ml-20m", 27_278, 9, 77)])   # ragged last tile of candidates
 def test_indexed_candidate_scoring_equals_gather_then_score(dev, cfg_name, N, B, n_cand):
     """rails_mol_score_indexed (per-row candidates read in place from the shared index) against rails_mol_index_gather +
     rails_mol_score_candidates: the same arithmetic per (query, item) pair, hence the same bits -- duplicates, the first and the
@@ -1703,10 +1768,10 @@ def test_indexed_candidate_scoring_equals_gather_then_score(dev, cfg_name, N, B,
         g = torch.Generator().manual_seed(N + B)
         pos = torch.randint(0, N, (B, n_cand), generator=g).to(dev)
         pos[:, 0], pos[:, 1], pos[:, 2] = 0, N - 1, pos[:, 3]
-        cand, _ = eng.gather_index(tk._index, pos)
-        want = eng.score_candidates(qpack, B, cand, n_cand)
+        cand, kp = eng.gather_index(tk._index, pos)
+        want = eng.score_candidates(qpack, B, cand, kp)[:, :n_cand]
         got = eng.score_indexed(qpack, B, tk._index, pos)
-        assert torch.equal(got, want)
+        assert got.shape == (B, n_cand) and torch.equal(got, want)
         dense = eng.score_dense(qpack, B, tk._index)
         assert torch.equal(got, torch.gather(dense, 1, pos))      # and both are the dense kernel's values at those positions
 
