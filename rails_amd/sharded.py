@@ -84,8 +84,10 @@ class ShardedTopK(TopKModule):
             self._local_module = self._make_local_module(mol_module, item_embeddings_shard, item_ids_shard)
             self._n_local = self._local_module.num_items
             local_topk = lambda q, k, **kw: self._local_module(q, k=k, **kw)  # noqa: E731
+            self._local_topk_is_module = True
         else:
             self._n_local = int(item_ids_shard.numel())
+            self._local_topk_is_module = False
         self._local_topk = local_topk
         self._merge = merge if merge is not None else _hip_merge
         self._xstream = None     # exchange stream (all-gather + merge), created on first GPU use
@@ -102,21 +104,28 @@ class ShardedTopK(TopKModule):
         if k > self._n_total:
             raise RuntimeError(f"selected index k out of range (k={k}, n={self._n_total})")
         k_local = min(k, self._n_local)
-        if k_local > 0:
+        local = getattr(self, "_local_module", None)
+        spec = None   # a local module with its own submit / result (MoLAvgTopK): its speculative output travels on, verified in result()
+        if k_local > 0 and local is not None and hasattr(local, "submit") and self._local_topk_is_module:
+            spec = local.submit(query_embeddings, k_local, **kwargs)
+            s, ids = spec[1], spec[2]
+            if spec[0] == "final":
+                spec = None
+        elif k_local > 0:
             s, ids = self._local_topk(query_embeddings, k_local, **kwargs)
         else:  # an empty shard still takes part in the collective
             B = query_embeddings.size(0)
             s = torch.empty((B, 0), dtype=torch.float32, device=query_embeddings.device)
             ids = torch.empty((B, 0), dtype=torch.int64, device=query_embeddings.device)
         if self._world == 1:
-            return ("done", s, ids)
+            return ("done", s, ids, spec)
         on_gpu = s.is_cuda and self._merge is _hip_merge
         msg = E.pack_candidates(s, ids, k) if on_gpu else pack_candidates(s.float(), ids, k)
         ready = None
         if msg.is_cuda:
             ready = torch.cuda.Event()
             ready.record()
-        return ("pending", msg, ready, k, on_gpu, s.dtype)
+        return ("pending", msg, ready, k, on_gpu, s.dtype, spec)
 
     def forward_filtered(self, query_embeddings: torch.Tensor, k_prime: int, invalid_ids: torch.Tensor, k: int, **kwargs):
         """CandidateIndex.get_top_k_outputs' body for the sharded modules: the seen-id filter runs inside the merge launch
@@ -134,10 +143,20 @@ class ShardedTopK(TopKModule):
         module's exchange stream, behind the handle's event; the current stream waits for the merge only.
         seen = (invalid_ids, k): the seen-id filter inside the merge launch -> (ids (B, k), scores (B, k)) instead (GPU merge only)."""
         if handle[0] == "done":
+            s, ids = handle[1], handle[2]
+            if handle[3] is not None:
+                s, ids = self._local_module.result(handle[3])     # the verified output (the same tensors unless the call was redone)
             if seen is not None:
-                return E.filter_seen_ids(handle[2], handle[1], seen[0], seen[1])
-            return handle[1], handle[2]
-        _, msg, ready, k, on_gpu, dtype = handle
+                return E.filter_seen_ids(ids, s, seen[0], seen[1])
+            return s, ids
+        _, msg, ready, k, on_gpu, dtype, spec = handle
+        if spec is not None:
+            s, ids = self._local_module.result(spec)
+            if s is not spec[1]:                                   # redone on the materialising path: pack again
+                msg = E.pack_candidates(s, ids, k) if on_gpu else pack_candidates(s.float(), ids, k)
+                if msg.is_cuda:
+                    ready = torch.cuda.Event()
+                    ready.record()
         if seen is not None and not (msg.is_cuda and on_gpu):
             raise RuntimeError("result(seen=...) needs the HIP merge")
         if not msg.is_cuda:

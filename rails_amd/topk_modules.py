@@ -596,6 +596,7 @@ class MoLAvgTopK(MoLTopKModule):
         self.fused_coarse_min_items: int = 262144    # below this the (B, N) scores are small and one launch chain shorter
         self._coarse_engine = None
         self._coarse_table = None
+        self._verdict_pool: list = []
 
     def _table(self) -> torch.Tensor:
         eng = self._bind()
@@ -614,9 +615,9 @@ class MoLAvgTopK(MoLTopKModule):
         """(B, P_Q, d) query components -> (B, avg_top_k) positions of the coarse top-K', best first
         (with_scores: -> (scores, positions), the bf16 coarse scores as fp32).
         The fused scan's result is exact iff every row collected between K' and `capacity` candidates.  With `pending` (a
-        list) the check is DEFERRED: the positions are returned at once, a closure that reads the counts is appended, and the
-        caller verifies after it has enqueued everything that depends on the positions (speculate, then verify: the GPU
-        never waits for the host in mid-pipeline).  Without it the check is made here (one 128-byte D2H copy)."""
+        list) the check is DEFERRED: the positions are returned at once, the scan's device verdict word (1 = out of range) is
+        appended, and the caller reads it after it has enqueued everything that depends on the positions (speculate, then
+        verify: the GPU never waits for the host in mid-pipeline).  Without it the check is made here (one 4-byte D2H copy)."""
         eng = self._bind()
         table = self._table()
         n = table.shape[0]
@@ -640,11 +641,10 @@ class MoLAvgTopK(MoLTopKModule):
                     coarse = eng.coarse_scores(eq, table, average_queries, out=self._buf("coarse_all", eq.shape[0] * n, torch.float32).view(eq.shape[0], n), run_if=bad)
                     E.topk(coarse, self._avg_top_k, out=(sc, idx), run_if=bad)
                     return (sc, idx) if with_scores else idx
-                check = lambda: int(bad.item()) == 0   # noqa: E731  (ONE 4-byte read, after everything else is enqueued)
-                if pending is not None:
-                    pending.append(check)
+                if pending is not None:      # the caller reads the verdict word after it has enqueued everything that follows
+                    pending.append(bad)
                     return (sc, idx) if with_scores else idx
-                if check():
+                if int(bad.item()) == 0:
                     return (sc, idx) if with_scores else idx
         coarse = eng.coarse_scores(eq, table, average_queries)
         sc, idx = E.topk(coarse, self._avg_top_k)
@@ -656,27 +656,59 @@ class MoLAvgTopK(MoLTopKModule):
         scores = self._score_at(eng, qpack, batch, cand_idx)
         return E.topk_candidates(scores, min(k, cand_idx.shape[1]), cand_idx, self._ids_flat)
 
-    def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+    def _enqueue(self, query_embeddings: torch.Tensor, k: int, pending: list, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        """One pass of forward's launches; the device verdicts of the fused scan (int32 words, 1 = redo) are appended to `pending`."""
+        # the reference's four profiler spans (mol_top_k.py:350-382), around the launches that do the same work here
+        with torch.profiler.record_function("avg_top_k_scoring"):
+            qpack, idx = self._coarse_topk(query_embeddings, average_queries=False, pending=pending, **kwargs)
+        eng = self._bind()
+        with torch.profiler.record_function("avg_topk_selection"):
+            pass    # the reference gathers the candidates' embeddings here; they are read in place by the scoring launch below
+        with torch.profiler.record_function("filtered_scoring"):
+            cand_scores = self._score_at(eng, qpack, query_embeddings.size(0), idx)
+        with torch.profiler.record_function("final_topk"):
+            scores, ids = E.topk_candidates(cand_scores, min(k, idx.shape[1]), idx, self._ids_flat)   # top-k + gather + id lookup, one launch
+        return scores.to(query_embeddings.dtype), ids
+
+    # ---- two-stage form of forward ---------------------------------------------------------------------------------------------
+    # The fused coarse scan is exact unless a candidate count left its range (heavy ties at the threshold), which only the device
+    # knows when the launches are enqueued.  forward() = result(submit()): submit enqueues the whole call on that assumption and
+    # copies the scan's verdict word to pinned host memory behind it; result waits for THAT copy (not for the stream), and redoes
+    # the call on the materialising path in the rare other case.  A caller with the next batch at hand calls submit(batch i + 1)
+    # before result(batch i): the host's look at the verdict then costs the GPU nothing (bench.py --two-pass reports both rates).
+    def submit(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs):
         if k > self._avg_top_k:  # the reference raises after doing the work (mol_top_k.py:383-386)
             raise ValueError(f"avg_top_k ({self._avg_top_k}) must be larger than k ({k})")
-        # the reference's four profiler spans (mol_top_k.py:350-382), around the launches that do the same work here
-        for attempt in range(2):
-            pending: list = []
-            with torch.profiler.record_function("avg_top_k_scoring"):
-                qpack, idx = self._coarse_topk(query_embeddings, average_queries=False, pending=pending, **kwargs)
-            eng = self._bind()
-            with torch.profiler.record_function("avg_topk_selection"):
-                pass    # the reference gathers the candidates' embeddings here; they are read in place by the scoring launch below
-            with torch.profiler.record_function("filtered_scoring"):
-                cand_scores = self._score_at(eng, qpack, query_embeddings.size(0), idx)
-            with torch.profiler.record_function("final_topk"):
-                scores, ids = E.topk_candidates(cand_scores, min(k, idx.shape[1]), idx, self._ids_flat)   # top-k + gather + id lookup, one launch
-            # everything is enqueued; only now look at the fused scan's candidate counts (rarely out of range: heavy ties)
-            if all(chk() for chk in pending):
-                break
-            self._no_fused = True      # redo this call on the materialising path
-        self._no_fused = False
-        return scores.to(query_embeddings.dtype), ids
+        pending: list = []
+        scores, ids = self._enqueue(query_embeddings, k, pending, **kwargs)
+        if not pending:
+            return ("final", scores, ids)
+        pool = self._verdict_pool      # pinned words go back to the pool in result(): no host allocation per call
+        host = pool.pop() if pool and pool[-1].numel() == len(pending) else torch.empty(len(pending), dtype=torch.int32, pin_memory=True)
+        for j, bad in enumerate(pending):
+            host[j : j + 1].copy_(bad, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return ("speculative", scores, ids, host, done, query_embeddings, k, kwargs)
+
+    def result(self, handle) -> Tuple[torch.Tensor, torch.Tensor]:
+        if handle[0] == "final":
+            return handle[1], handle[2]
+        _, scores, ids, host, done, query_embeddings, k, kwargs = handle
+        done.synchronize()
+        redo = int(host.max()) != 0
+        if len(self._verdict_pool) < 8:
+            self._verdict_pool.append(host)
+        if not redo:
+            return scores, ids
+        self._no_fused = True      # redo this call on the materialising path
+        try:
+            return self._enqueue(query_embeddings, k, [], **kwargs)
+        finally:
+            self._no_fused = False
+
+    def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self.result(self.submit(query_embeddings, k, sorted, **kwargs))
 
     def coarse_candidates(self, query_embeddings: torch.Tensor, **kwargs):
         """Pass 1 on this module's items: -> (coarse scores (B, K'), positions (B, K')), best first (ties by position)."""

@@ -464,6 +464,35 @@ def test_fused_coarse_topk_falls_back_on_heavy_ties(dev):
         assert torch.equal(s1, s2) and torch.equal(i1, i2)
 
 
+def test_avg_topk_submit_then_result_equals_forward(dev):
+    """MoLAvgTopK.submit / result (forward in two stages: everything enqueued on the assumption that the fused scan was exact, the
+    verdict word read afterwards): two batches submitted before either result is taken give forward's outputs; on the heavy-ties
+    corpus the verdict says redo and result() returns the materialising path's answer; the same through ShardedMoLAvgTopK."""
+    from rails_amd.sharded import ShardedMoLAvgTopK
+    cfg = O.CONFIGS["amzn-books"]
+    mol = build_module(cfg, O.synthetic_weights(cfg, seed=2), dev)
+    n = 300_000
+    ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    qa, qb = O.synthetic_queries(cfg, 8, seed=4).to(dev), O.synthetic_queries(cfg, 8, seed=5).to(dev)
+    base = torch.from_numpy(O.hash_item_table(6, 0, n, cfg.item_embedding_dim))
+    with torch.inference_mode():
+        for tied in (False, True):
+            X = (base[torch.arange(n) % 40] if tied else base).unsqueeze(0).to(dev)
+            for make in (lambda: rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=200), lambda: ShardedMoLAvgTopK(mol, X, ids, n, avg_top_k=200)):
+                at = make()
+                local = getattr(at, "_local_module", at)
+                local.DEVICE_REDO_BYTES = 0                      # as on a full shard: no room for the (B, N) redo buffer, the host reads the verdict
+                ha, hb = at.submit(qa, 50), at.submit(qb, 50)
+                spec = ha if at is local else ha[3]
+                assert spec is not None and spec[0] == "speculative"
+                ra, rb = at.result(ha), at.result(hb)
+                local.fused_coarse_min_items = 1 << 62          # the materialising path
+                wa, wb = at(qa, k=50), at(qb, k=50)
+                assert torch.equal(ra[0], wa[0]) and torch.equal(ra[1], wa[1]) and torch.equal(rb[0], wb[0]) and torch.equal(rb[1], wb[1])
+                if tied:
+                    assert ra[0] is not spec[1]                  # redone, not the speculative tensors
+
+
 def test_fused_coarse_topk_raises_its_flag_exactly_when_a_count_is_out_of_range(dev):
     """ABI 6: rails_mol_coarse_topk reports `out_of_range` from inside its key-selection launch -- 0 on an ordinary corpus (and
     the counts in range), 1 on the heavy-ties corpus (a sub-list overflowed), 1 when fewer than K' candidates reach the threshold
