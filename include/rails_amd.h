@@ -230,7 +230,7 @@ int rails_mol_coarse_score(const rails_mol_shape* shape, const float* eq, int32_
  * rounded up to a multiple of 64; capacity + 1 is reported when one of the 16 internal sub-lists overflowed) -- otherwise
  * (heavy ties at the threshold) the caller falls back to rails_mol_coarse_score + rails_topk; slots of an under-filled row
  * name position 0 with score -inf.  out_of_range (may be NULL): one int32 the call sets to 1 if some query's count is
- * outside that range and to 0 otherwise -- what rails_range_flag computes from out_counts, inside the call's own launches
+ * outside that range and to 0 otherwise -- what rails_range_flag_i32 computes from out_counts, inside the call's own launches
  * (usable as the run_if predicate of the fallback).
  * k_prime <= 4096, batch <= 128 (slice larger batches).  rails_mol_coarse_topk_workspace_bytes returns 0 when the sizes are
  * unsupported. */
