@@ -582,6 +582,11 @@ class MoLBruteForceTopK(MoLTopKModule):
                 self._index32 = eng.exact.build_index(self._item_embeddings[0])
         return eng
 
+def _verdicts_clear(pending: list) -> bool:
+    """pending: device int32 verdict words of fused scans (1 = a candidate count left its range).  One host read each (normally one)."""
+    return all(int(bad.item()) == 0 for bad in pending)
+
+
 class MoLAvgTopK(MoLTopKModule):
     DEVICE_REDO_BYTES = 1 << 30   # materialised score matrices up to this size are kept as the device-side redo buffer of a fused scan;
                                   # beyond it (a 125 M-item shard: 16 GB) the counts are read on the host after the call is enqueued
@@ -781,11 +786,10 @@ class _ComponentCandidates:
                     return pos.view(eq.shape[0], -1)
                 bad = torch.zeros(1, dtype=torch.int32, device=counts.device)
                 E.range_flag(counts, k_per_group, k_hi, bad)
-                check = lambda: int(bad.item()) == 0   # noqa: E731
-                if pending is not None:
-                    pending.append(check)
+                if pending is not None:      # a device verdict word (1 = redo), read by the caller once everything is enqueued
+                    pending.append(bad)
                     return pos.view(eq.shape[0], -1)
-                if check():
+                if int(bad.item()) == 0:
                     return pos.view(eq.shape[0], -1)
         scores = eng.component_scores(eq, table)
         _, pos = E.topk(scores, k_per_group)
@@ -825,7 +829,7 @@ class MoLNaiveTopK(MoLTopKModule, _ComponentCandidates):
             pending: list = []
             all_indices = self._component_topk(eq, self._k_per_group, pending)
             scores, ids = self._rerank_union(qpack, query_embeddings.size(0), all_indices, sorted)
-            if all(chk() for chk in pending):
+            if _verdicts_clear(pending):
                 break
             self._no_fused = True
         self._no_fused = False
@@ -849,7 +853,7 @@ class MoLCombTopK(MoLAvgTopK, _ComponentCandidates):
             comp = self._component_topk(eq, self._k_per_group, pending)
             avg_idx = self._coarse_topk_from_eq(eq, average_queries=True, pending=pending)
             scores, ids = self._rerank_union(qpack, query_embeddings.size(0), torch.cat([comp, avg_idx], dim=1), sorted)
-            if all(chk() for chk in pending):
+            if _verdicts_clear(pending):
                 break
             self._no_fused = True
         self._no_fused = False

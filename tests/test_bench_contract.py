@@ -70,8 +70,10 @@ def test_committed_round4_bench_line_carries_the_quality_half():
     for mode in ("f16-exact", "f16x3-exact"):
         e = d["exact_fast_path"][mode]
         assert e["output_identical_to_fp32_path"] is True and e["eps_rigorous"] > e["eps"] and e["eps_rigorous_usable"] is False
+    assert two_pass["pipelined"]["output_equal_to_unpipelined"] is True and two_pass["pipelined"]["ms_per_step"] <= two_pass["ms_per_step"] * 1.02
     tp = json.load(open(os.path.join(ROOT, "profiles", "r04_two_pass_125m.json")))
     assert tp["roofline"]["bound"] == "hbm" and 0 < tp["roofline"]["frac"] < 1 and 0.3 < tp["recall"]["recall@10"] <= 1.0
+    assert tp["pipelined"]["output_equal_to_unpipelined"] is True and tp["ms_per_step"] < 1.65     # config-5 shard: 1.73 ms before the round-4 rebuild
 
 
 @pytest.mark.gpu

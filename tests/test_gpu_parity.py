@@ -493,6 +493,27 @@ def test_avg_topk_submit_then_result_equals_forward(dev):
                     assert ra[0] is not spec[1]                  # redone, not the speculative tensors
 
 
+@pytest.mark.parametrize("tied", [False, True])
+def test_candidate_unions_with_the_verdict_read_on_the_host(dev, tied, monkeypatch):
+    """MoLNaiveTopK / MoLCombTopK where the (rows, N) redo buffer "does not fit" (DEVICE_REDO_BYTES = 0, as on a full shard): the
+    fused scans' verdict words are collected while the call is enqueued and read once at its end; on the heavy-ties corpus they say
+    redo and the materialising path answers.  Same outputs as with the fused scans switched off."""
+    monkeypatch.setattr(rails_amd.MoLAvgTopK, "DEVICE_REDO_BYTES", 0)
+    cfg = O.CONFIGS["amzn-books"]
+    mol = build_module(cfg, O.synthetic_weights(cfg, seed=2), dev)
+    n = 300_000
+    base = torch.from_numpy(O.hash_item_table(6, 0, n, cfg.item_embedding_dim))
+    X = (base[torch.arange(n) % 40] if tied else base).unsqueeze(0).to(dev)
+    ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    q = O.synthetic_queries(cfg, 4, seed=4).to(dev)
+    with torch.inference_mode():
+        for mod in (rails_amd.MoLNaiveTopK(mol, X, ids, k_per_group=5), rails_amd.MoLCombTopK(mol, X, ids, avg_top_k=200, k_per_group=5)):
+            s1, i1 = mod(q, k=50)
+            mod.fused_component_min_items = mod.fused_coarse_min_items = 1 << 62
+            s2, i2 = mod(q, k=50)
+            assert torch.equal(s1, s2) and torch.equal(i1, i2)
+
+
 def test_fused_coarse_topk_raises_its_flag_exactly_when_a_count_is_out_of_range(dev):
     """ABI 6: rails_mol_coarse_topk reports `out_of_range` from inside its key-selection launch -- 0 on an ordinary corpus (and
     the counts in range), 1 on the heavy-ties corpus (a sub-list overflowed), 1 when fewer than K' candidates reach the threshold

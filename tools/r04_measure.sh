@@ -10,6 +10,9 @@ PMC_EXTRA="--workload amzn-books --batch 32" bash tools/pmc.sh $O/pmc 0 > $O/pmc
 # config 5: one full 8-way shard, two-pass, with the recall phase; plain and under the profiler
 python bench.py --workload synthetic-8x8x32 --two-pass 1000 --no-cpu-baseline --no-matrix --no-other-workloads --no-fast-path --steps 10 --warmup 2 > $O/two_pass_125m.json 2> $O/two_pass_125m.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c5 -o r04c5 -- python bench.py --workload synthetic-8x8x32 --two-pass 1000 --no-recall --no-cpu-baseline --no-matrix --no-other-workloads --no-fast-path --steps 10 --warmup 2 > $O/two_pass_125m_prof.json 2>> $O/two_pass_125m.err
+# the coarse pass of config 5 on its own (no MoL index): ms per call, per-kernel split, fused == materialised check
+bash tools/r04_c5_ab.sh final > $O/c5_coarse_pass.txt 2>&1; cp gpurun_out/c5ab_final/kernel_split.txt $O/c5_coarse_pass_kernel_split.txt 2>/dev/null
+python bench.py --workload synthetic-8x8x32 --two-pass 1000 --batch 128 --no-recall --no-cpu-baseline --no-matrix --no-other-workloads --no-fast-path --steps 10 --warmup 2 > $O/two_pass_125m_b128.json 2>> $O/two_pass_125m.err
 # config 4: one full 8-way shard, exact
 python bench.py --workload synthetic-16x16x64 --no-cpu-baseline --no-matrix --no-hr-parity --steps 5 --warmup 1 > $O/bench_c4_shard.json 2> $O/bench_c4.err
 python bench.py --batch 128 --no-cpu-baseline --no-matrix --no-other-workloads --steps 10 --warmup 2 > $O/bench_b128.json 2> $O/bench_b128.err
