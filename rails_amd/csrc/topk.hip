@@ -528,6 +528,112 @@ __device__ __forceinline__ void filter_from_lds(const int64_t* id_s, const float
   }
 }
 
+// ---- MSD radix selection of the want-th largest 64-bit key of a workgroup's register-resident keys ---------------------------------
+// key_of(j), j < VPT: the thread's keys, 0 = no key (real keys are never 0 and all distinct).  Eight bits per pass: a 256-bin LDS
+// histogram of the keys that match the resolved prefix (a wave adds its most common digit with one atomic), one wave turns it into
+// the digit.  Bytes in which all keys agree -- bits of OR ^ AND over the keys -- take no pass (bf16 scores: the two low bytes of the
+// score word; the top byte of the positions), and the passes stop as soon as every key that still matches is wanted.  On return
+// exactly min(want, #keys) keys satisfy (key & fixed) >= prefix.  Two barriers per pass (the two-bits-per-step bisection this
+// replaced took 17 steps on the scores + 16 on the positions whenever the k-th score was tied).
+// `sh` must be initialised (radix_init by every thread, then a barrier) before the call; all threads of the workgroup call.
+struct RadixShared {
+  __attribute__((aligned(16))) unsigned int hist[2][256];
+  unsigned long long red[2];      // OR, AND over the keys
+  unsigned int pick[3];           // digit, keys still wanted among the matching ones, matching keys
+  unsigned int count;             // keys
+};
+template <int NT>
+__device__ __forceinline__ void radix_init(RadixShared& sh) {
+  for (int i = threadIdx.x; i < 512; i += NT) (&sh.hist[0][0])[i] = 0u;
+  if (threadIdx.x == 0) { sh.red[0] = 0ull; sh.red[1] = ~0ull; sh.count = 0u; }
+}
+// Keys come as two 32-bit words: hi_of(j) (the score word, 0 = no key: orderable() never returns 0) and lo_of(j, z) (the position word;
+// z is an opaque zero the callers add into what they compute, so that the compiler does not hoist VPT position words out of the pass
+// loop -- with 48 scores per thread that cost 436-968 B of scratch per lane).  Selected afterwards: radix_selected(hi, lo, sel).
+struct RadixSel { unsigned int ph, fh, pl, fl; };   // prefix / fixed mask of the score word and of the position word
+__device__ __forceinline__ bool radix_selected(unsigned int hi, unsigned int lo, const RadixSel& r) {
+  const unsigned int mh = hi & r.fh;
+  return hi != 0u && (mh > r.ph || (mh == r.ph && (lo & r.fl) >= r.pl));
+}
+template <int VPT, class KH, class KL>
+__device__ __forceinline__ void radix_select(KH hi_of, KL lo_of, unsigned int want, RadixShared& sh, RadixSel& sel) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  unsigned int oh = 0u, ah = ~0u, ol = 0u, al = ~0u, mine = 0u;
+#pragma unroll
+  for (int j = 0; j < VPT; ++j) {
+    const unsigned int h = hi_of(j), l = lo_of(j, 0u);
+    if (h) { oh |= h; ah &= h; ol |= l; al &= l; ++mine; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    oh |= __shfl_xor(oh, o, 64); ah &= __shfl_xor(ah, o, 64); ol |= __shfl_xor(ol, o, 64); al &= __shfl_xor(al, o, 64);
+    mine += __shfl_xor(mine, o, 64);
+  }
+  if (lane == 0) {
+    atomicOr(&sh.red[0], ((unsigned long long)oh << 32) | ol);
+    atomicAnd(&sh.red[1], ((unsigned long long)ah << 32) | al);
+    atomicAdd(&sh.count, mine);
+  }
+  __syncthreads();
+  const unsigned long long vor = sh.red[0];
+  if (want > sh.count) want = sh.count;
+  const unsigned long long varying = vor ^ sh.red[1];
+  sel = RadixSel{0u, 0u, 0u, 0u};
+  if (!want) { sel = RadixSel{~0u, ~0u, ~0u, ~0u}; return; }   // nothing is selected
+  unsigned int need = want;
+  int pass = 0;
+#pragma unroll 1
+  for (int byte = 7; byte >= 0; --byte) {   // rolled: one copy of the pass in the callers' code
+    const int shift = 8 * (byte & 3);
+    const bool score_word = byte >= 4;
+    const unsigned int bmask = 0xFFu << shift;
+    const unsigned int vary_w = score_word ? (unsigned int)(varying >> 32) : (unsigned int)varying;
+    const unsigned int or_w = score_word ? (unsigned int)(vor >> 32) : (unsigned int)vor;
+    if ((vary_w & bmask) == 0u) {   // all keys agree on this byte
+      if (score_word) { sel.ph |= or_w & bmask; sel.fh |= bmask; } else { sel.pl |= or_w & bmask; sel.fl |= bmask; }
+      continue;
+    }
+    unsigned int* h = sh.hist[pass & 1];
+    unsigned int z = 0u;
+    asm volatile("" : "+v"(z));
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const unsigned int kh = hi_of(j), kl = lo_of(j, z);
+      const bool act = kh != 0u && (kh & sel.fh) == sel.ph && (kl & sel.fl) == sel.pl;
+      const unsigned int digit = ((score_word ? kh : kl) >> shift) & 255u;
+      const unsigned long long m = __ballot(act);
+      if (m) {   // wave-uniform
+        const int leader = __ffsll((long long)m) - 1;
+        const unsigned int d0 = (unsigned int)__shfl((int)digit, leader, 64);
+        const unsigned long long same = __ballot(act && digit == d0);
+        if (lane == leader) atomicAdd(&h[d0], (unsigned int)__popcll(same));
+        if (act && digit != d0) atomicAdd(&h[digit], 1u);
+      }
+    }
+    if (tid >= 256 && tid < 512) sh.hist[(pass + 1) & 1][tid - 256] = 0u;   // the next pass' bins (last read before the previous barrier)
+    __syncthreads();
+    if (tid < 64) {
+      const uint4 c4 = reinterpret_cast<const uint4*>(h)[lane];      // bins 4 lane .. 4 lane + 3
+      const unsigned int sum4 = c4.x + c4.y + c4.z + c4.w;
+      unsigned int incl = sum4;                                       // keys in the bins of lanes >= lane
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_down(incl, o, 64); if (lane + o < 64) incl += t; }
+      unsigned int cum = incl - sum4;                                 // keys in higher bins
+      const unsigned int c[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+      for (int b = 3; b >= 0; --b) {
+        if (cum < need && need <= cum + c[b]) { sh.pick[0] = 4u * lane + b; sh.pick[1] = need - cum; sh.pick[2] = c[b]; }
+        cum += c[b];
+      }
+    }
+    __syncthreads();
+    if (score_word) { sel.ph |= sh.pick[0] << shift; sel.fh |= bmask; } else { sel.pl |= sh.pick[0] << shift; sel.fl |= bmask; }
+    need = sh.pick[1];
+    ++pass;
+    if (sh.pick[2] == need) break;      // every key that still matches the prefix is wanted
+  }
+}
+
 struct RowSelectArgs {
   const float* scores; int64_t ld; int64_t n; int64_t chunk;     // SCORES source: row r, chunk c = [c*chunk, min(n, (c+1)*chunk))
   const unsigned short* scores16;                                // SCORES source held as bf16 bit patterns (then `scores` is unused)
@@ -553,6 +659,7 @@ __global__ __launch_bounds__(kRowThreads) void row_select_kernel(const RowSelect
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // lds_keys candidates + 2048 exchange
   __shared__ unsigned int ctr[3][16];
   __shared__ unsigned int cursor;
+  __shared__ RadixShared rsh;
   __shared__ int64_t f_id[kFuseMaxK], f_inv[kFuseMaxW];
   __shared__ float f_sc[kFuseMaxK];
   __shared__ int f_scratch[kRowThreads / 64 + 2];
@@ -631,6 +738,7 @@ __global__ __launch_bounds__(kRowThreads) void row_select_kernel(const RowSelect
   for (int j = 0; j < VPT; ++j) tmax = v[j] > tmax ? v[j] : tmax;
   if (tid < 48) (&ctr[0][0])[tid] = 0u;
   if (tid == 0) cursor = 0u;
+  radix_init<kRowThreads>(rsh);
   for (int i = tid; i < lds_keys; i += kRowThreads) keys[i] = 0ull;
   __syncthreads();
   RAILS_PHASE(1);
@@ -746,49 +854,16 @@ __global__ __launch_bounds__(kRowThreads) void row_select_kernel(const RowSelect
     for (int i = tid; i < lds_keys; i += kRowThreads) keys[i] = 0ull;
   }
 
-  // block-wide counts of three per-element predicates; one barrier
-  auto count3 = [&](auto p1, auto p2, auto p3, unsigned int& n1, unsigned int& n2, unsigned int& n3) {
-    unsigned int a1 = 0, a2 = 0, a3 = 0;
-#pragma unroll
-    for (int j = 0; j < VPT; ++j) { a1 += p1(j) ? 1u : 0u; a2 += p2(j) ? 1u : 0u; a3 += p3(j) ? 1u : 0u; }
-    unsigned long long pk = (unsigned long long)a1 | ((unsigned long long)a2 << 21) | ((unsigned long long)a3 << 42);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) pk += __shfl_xor(pk, o, 64);
-    const int buf = it % 3;
-    if (lane == 0) {
-      atomicAdd(&ctr[buf][0], (unsigned int)(pk & 0x1FFFFFu));
-      atomicAdd(&ctr[buf][1], (unsigned int)((pk >> 21) & 0x1FFFFFu));
-      atomicAdd(&ctr[buf][2], (unsigned int)(pk >> 42));
-    }
-    if (tid < 16) ctr[(it + 1) % 3][tid] = 0u;
-    __syncthreads();
-    n1 = ctr[buf][0]; n2 = ctr[buf][1]; n3 = ctr[buf][2];
-    ++it;
+  // the k-th largest 64-bit key (score, then lowest position first) by MSD radix selection over the registers (radix_select above;
+  // the two-bits-per-step bisection it replaced: n = 3 200, k = 3 200 66.7 -> see profiles/README.md)
+  auto hi_of = [&](int j) -> unsigned int { return v[j]; };               // elements past the end and empty key slots were loaded as 0
+  auto lo_of = [&](int j, unsigned int z) -> unsigned int {
+    if constexpr (KEYS) return lo[j];
+    else return ~(begin + (unsigned int)local_index(j) + z);
   };
-  // the k-th largest score T = the largest T with count(v >= T) >= k  (padding elements hold v = 0 and k <= cnt)
-  unsigned int T = 0u;
-  for (int bit = 30; bit >= 0; bit -= 2) {
-    const unsigned int c1 = T | (1u << bit), c2 = T | (2u << bit), c3 = T | (3u << bit);
-    unsigned int n1, n2, n3;
-    count3([&](int j) { return v[j] >= c1; }, [&](int j) { return v[j] >= c2; }, [&](int j) { return v[j] >= c3; }, n1, n2, n3);
-    T = n3 >= (unsigned int)k ? c3 : n2 >= (unsigned int)k ? c2 : n1 >= (unsigned int)k ? c1 : T;
-  }
-  unsigned int n_gt, n_eq, unused;
-  count3([&](int j) { return v[j] > T; }, [&](int j) { return v[j] == T && local_index(j) < cnt; }, [&](int) { return false; }, n_gt, n_eq, unused);
-  const unsigned int need_eq = (unsigned int)k - n_gt;   // >= 1
-  unsigned int P = 0u;                                   // threshold on the low key word among the elements tied at T
-  if (n_eq != need_eq) {
-    // lowest positions first = largest low words first: the need_eq-th largest low word among the tied elements
-    for (int bit = 30; bit >= 0; bit -= 2) {
-      const unsigned int c1 = P | (1u << bit), c2 = P | (2u << bit), c3 = P | (3u << bit);
-      unsigned int n1, n2, n3;
-      count3([&](int j) { return v[j] == T && local_index(j) < cnt && low_of(j) >= c1; },
-             [&](int j) { return v[j] == T && local_index(j) < cnt && low_of(j) >= c2; },
-             [&](int j) { return v[j] == T && local_index(j) < cnt && low_of(j) >= c3; }, n1, n2, n3);
-      P = n3 >= need_eq ? c3 : n2 >= need_eq ? c2 : n1 >= need_eq ? c1 : P;
-    }
-  }
-  compact([&](int j) { return v[j] > T || (v[j] == T && low_of(j) >= P); });
+  RadixSel sel;
+  radix_select<VPT>(hi_of, lo_of, (unsigned int)k, rsh, sel);
+  compact([&](int j) { return radix_selected(v[j], low_of(j), sel); });
   int npad = 2;
   while (npad < k) npad <<= 1;
   emit_sorted(npad);
@@ -893,7 +968,11 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
   // 512 < n <= 1024 (the K' = 1 000 candidates of a two-pass rerank, k = 120): the register-resident selection's fast path instead of a
   // full sort of 1 024 keys (13.6 -> 7 us per 32 rows)
   if (ids_index && n > kSortCap) { set_error("topk: ids_index needs n <= %d", kSortCap); return kErrUnsupported; }
-  if (ids_index && n > 512 && n <= 4 * kRowThreads && k <= kRowMaxK && !scores16 && !f_invalid) {
+  // k > 512 of a short row: when the k winners fill the same power of two of sort slots as the whole row would (k = 3 200 of 3 200,
+  // 2 561 of 4 096), selecting first buys nothing -- the row is sorted whole (n = 3 200 = k: 52 -> 41 us per 32 rows; k = 1 000 of
+  // 3 200 stays on the selection: 28 vs 41 us; tools/r04_topk_bigk_ab.sh)
+  const bool sort_whole = k > kRowFastK && n <= kSortCap && next_pow2((int)n) <= next_pow2(k) && !scores16 && !f_invalid;
+  if (!sort_whole && ids_index && n > 512 && n <= 4 * kRowThreads && k <= kRowMaxK && !scores16 && !f_invalid) {
     RowSelectArgs a{};
     a.run_if = pred;
     a.scores = scores; a.ld = ld; a.n = n; a.k = k; a.chunk = n; a.ids = ids; a.ids_row_stride = ids_row_stride; a.out_scores = out_scores; a.out_ids = out_ids;
@@ -903,7 +982,7 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
     a.lds_keys = a.k <= kRowFastK ? kRowCandCap : lds_keys;
     return launch_row_select_t<4, false, true>(a, rows, 1, stream);
   }
-  if ((n > 1024 || (n > 512 && k <= kRowFastK && !scores16 && !f_invalid)) && k <= kRowMaxK && !ids_index) {
+  if (!sort_whole && (n > 1024 || (n > 512 && k <= kRowFastK && !scores16 && !f_invalid)) && k <= kRowMaxK && !ids_index) {
     RowSelectArgs a{};
     a.run_if = pred;
     a.scores = scores; a.scores16 = scores16; a.ld = ld; a.n = n; a.k = k;
@@ -1005,15 +1084,13 @@ template <int VPT>
 __global__ __launch_bounds__(kRowThreads) void sublist_select_kernel(const SubSelArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long skeys[];   // npad sort slots (+ 2 npad exchange slots when npad <= 1024)
   __shared__ unsigned int cnt_s[64];
-  __shared__ __attribute__((aligned(16))) unsigned int hist[2][256];
-  __shared__ unsigned long long red[2];      // OR, AND over the row's keys
-  __shared__ unsigned int pick[3];           // digit, keys still wanted among the matching ones, matching keys
+  __shared__ RadixShared rsh;
   __shared__ unsigned int cursor;
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int k = a.k, subcap = a.cap / a.n_sub, npad = a.npad;
   if (tid < a.n_sub) cnt_s[tid] = a.counts[(int64_t)row * a.n_sub + tid];
-  if (tid < 512) (&hist[0][0])[tid] = 0u;
-  if (tid == 0) { cursor = 0u; red[0] = 0ull; red[1] = ~0ull; }
+  radix_init<kRowThreads>(rsh);
+  if (tid == 0) cursor = 0u;
   for (int i = tid; i < npad; i += kRowThreads) skeys[i] = 0ull;
   __syncthreads();
   unsigned int total = 0u, held = 0u;
@@ -1029,72 +1106,24 @@ __global__ __launch_bounds__(kRowThreads) void sublist_select_kernel(const SubSe
     if ((over || total < (unsigned int)k) && a.out_flag) *a.out_flag = 1;   // every writer stores the same value
   }
   const unsigned int want = held < (unsigned int)k ? held : (unsigned int)k;   // < k only on rows the caller redoes
-  unsigned long long key[VPT];
-  unsigned long long vor = 0ull, vand = ~0ull;
+  unsigned int khi[VPT], klo[VPT];
   const unsigned long long* src = a.keys + (int64_t)row * a.cap;
 #pragma unroll
   for (int j = 0; j < VPT; ++j) {
     const int i = j * kRowThreads + tid;
     const int sub = i / subcap;
     const bool filled = i < a.cap && (unsigned int)(i - sub * subcap) < cnt_s[sub < a.n_sub ? sub : 0];
-    key[j] = filled ? src[i] : 0ull;
-    if (key[j]) { vor |= key[j]; vand &= key[j]; }
+    const unsigned long long kv = filled ? src[i] : 0ull;
+    khi[j] = (unsigned int)(kv >> 32);
+    klo[j] = (unsigned int)kv;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { vor |= __shfl_xor(vor, o, 64); vand &= __shfl_xor(vand, o, 64); }
-  if (lane == 0) { atomicOr(&red[0], vor); atomicAnd(&red[1], vand); }
-  __syncthreads();
-  vor = red[0];
-  const unsigned long long varying = want ? vor ^ red[1] : 0ull;
-  unsigned long long prefix = 0ull, fixed = 0ull;
-  unsigned int need = want;
-  int pass = 0;
-  for (int byte = 7; byte >= 0 && want; --byte) {
-    const int shift = 8 * byte;
-    const unsigned long long bmask = 0xFFull << shift;
-    if ((varying & bmask) == 0ull) { prefix |= vor & bmask; fixed |= bmask; continue; }   // all keys agree on this byte
-    unsigned int* h = hist[pass & 1];
-#pragma unroll
-    for (int j = 0; j < VPT; ++j) {
-      const bool act = key[j] != 0ull && (key[j] & fixed) == prefix;
-      const unsigned int digit = (unsigned int)(key[j] >> shift) & 255u;
-      const unsigned long long m = __ballot(act);
-      if (m) {   // wave-uniform
-        const int leader = __ffsll((long long)m) - 1;
-        const unsigned int d0 = (unsigned int)__shfl((int)digit, leader, 64);
-        const unsigned long long same = __ballot(act && digit == d0);
-        if (lane == leader) atomicAdd(&h[d0], (unsigned int)__popcll(same));
-        if (act && digit != d0) atomicAdd(&h[digit], 1u);
-      }
-    }
-    if (tid >= 256 && tid < 512) hist[(pass + 1) & 1][tid - 256] = 0u;   // the next pass' bins (last read before the previous barrier)
-    __syncthreads();
-    if (tid < 64) {
-      const uint4 c4 = reinterpret_cast<const uint4*>(h)[lane];      // bins 4 lane .. 4 lane + 3
-      const unsigned int mine = c4.x + c4.y + c4.z + c4.w;
-      unsigned int incl = mine;                                       // keys in the bins of lanes >= lane
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_down(incl, o, 64); if (lane + o < 64) incl += t; }
-      unsigned int cum = incl - mine;                                 // keys in higher bins
-      const unsigned int c[4] = {c4.x, c4.y, c4.z, c4.w};
-#pragma unroll
-      for (int b = 3; b >= 0; --b) {
-        if (cum < need && need <= cum + c[b]) { pick[0] = 4u * lane + b; pick[1] = need - cum; pick[2] = c[b]; }
-        cum += c[b];
-      }
-    }
-    __syncthreads();
-    prefix |= (unsigned long long)pick[0] << shift;
-    fixed |= bmask;
-    need = pick[1];
-    ++pass;
-    if (pick[2] == need) break;      // every key that still matches the prefix is wanted
-  }
-  // exactly `want` keys satisfy (key & fixed) >= prefix
+  RadixSel sel;
+  radix_select<VPT>([&](int j) { return khi[j]; }, [&](int j, unsigned int) { return klo[j]; }, want, rsh, sel);
+  // exactly `want` keys are selected
   {
     unsigned int c = 0u;
 #pragma unroll
-    for (int j = 0; j < VPT; ++j) c += (want && key[j] != 0ull && (key[j] & fixed) >= prefix) ? 1u : 0u;
+    for (int j = 0; j < VPT; ++j) c += radix_selected(khi[j], klo[j], sel) ? 1u : 0u;
     unsigned int incl = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const unsigned int x = __shfl_up(incl, o, 64); if (lane >= o) incl += x; }
@@ -1105,7 +1134,7 @@ __global__ __launch_bounds__(kRowThreads) void sublist_select_kernel(const SubSe
     if (c) {
 #pragma unroll
       for (int j = 0; j < VPT; ++j)
-        if (key[j] != 0ull && (key[j] & fixed) >= prefix) { if (at < (unsigned int)npad) skeys[at] = key[j]; ++at; }
+        if (radix_selected(khi[j], klo[j], sel)) { if (at < (unsigned int)npad) skeys[at] = ((unsigned long long)khi[j] << 32) | klo[j]; ++at; }
     }
   }
   __syncthreads();
