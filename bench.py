@@ -1138,7 +1138,7 @@ def main() -> None:
             if args.workload == "synthetic-8x8x32" and hi - lo == 125_000_000 and B in (32, 128):
                 # committed PMC passes of the select scan (the launch that reads the table; the time above also covers the sample
                 # pass and the key selection)
-                tr = committed_traffic(f"synthetic-8x8x32:coarse_scan:N125M:B{B}:r03")
+                tr = committed_traffic(f"synthetic-8x8x32:coarse_scan:N125M:B{B}:r04") or committed_traffic(f"synthetic-8x8x32:coarse_scan:N125M:B{B}:r03")
                 if tr:
                     out["roofline"]["traffic"] = tr
                     out["roofline"]["traffic_source"] = ("profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the select-scan launch on this "
