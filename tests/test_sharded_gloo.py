@@ -193,3 +193,85 @@ def test_message_roundtrip_is_bit_exact():
         assert torch.equal(us[:, r * 9 : r * 9 + 7].view(torch.int32), s[r].view(torch.int32))
         assert torch.equal(ui[:, r * 9 : r * 9 + 7], i[r])
         assert bool(torch.isinf(us[:, r * 9 + 7 : r * 9 + 9]).all()) and bool((ui[:, r * 9 + 7 : r * 9 + 9] == -1).all())
+
+
+class _SpeculatingLocal:
+    """Stand-in for a local module with the two-stage form of forward (MoLAvgTopK.submit / result): submit hands out tensors at once;
+    when `fail` is set they are WRONG (a fused scan whose verdict says redo) and result returns the right ones as new tensors."""
+
+    def __init__(self, cfg, w, X, ids, fail):
+        self.cfg, self.w, self.X, self.ids, self.fail = cfg, w, X, ids, fail
+        self.num_items = int(ids.numel())
+        self.redone = 0
+
+    def _right(self, q, k):
+        s, pos = O.select_topk_deterministic(O.mol_logits(self.cfg, self.w, q, self.X), k)
+        return s, self.ids.reshape(-1)[pos]
+
+    def __call__(self, q, k, **kw):
+        return self._right(q, k)
+
+    def submit(self, q, k, sorted=True, **kw):
+        s, i = self._right(q, k)
+        if self.fail:
+            return ("speculative", torch.zeros_like(s), torch.zeros_like(i), q, k)
+        return ("speculative", s, i, q, k)
+
+    def result(self, handle):
+        if self.fail:
+            self.redone += 1
+            return self._right(handle[3], handle[4])
+        return handle[1], handle[2]
+
+
+def _spec_worker(rank: int, world: int, port: int, n_items: int, k: int, ret):
+    from rails_amd.sharded import ShardedTopK
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(2)
+        cfg = O.CONFIGS["amzn-books"]
+        w = O.synthetic_weights(cfg, seed=0)
+        q = O.synthetic_queries(cfg, 5)
+        lo, hi = shard_bounds(n_items, world, rank)
+        X = torch.from_numpy(O.hash_item_table(1, lo, hi - lo, cfg.item_embedding_dim)).unsqueeze(0)
+        ids = (torch.arange(lo, hi, dtype=torch.int64) * 3 + 1).unsqueeze(0)
+        local = _SpeculatingLocal(cfg, w, X, ids, fail=(rank == 1))
+
+        class Sharded(ShardedTopK):
+            def _make_local_module(self, mol_module, item_embeddings_shard, item_ids_shard):
+                return local
+
+        def merge(scores, all_ids, kk):
+            s, pos = O.select_topk_deterministic(scores, kk)
+            return s, torch.gather(all_ids, 1, pos)
+
+        mod = Sharded(None, X, ids, n_items, merge=merge)
+        h1, h2 = mod.submit(q, k), mod.submit(q, k)      # two batches in flight before either result
+        s, i = mod.result(h1)
+        s2, i2 = mod.result(h2)
+        assert torch.equal(s, s2) and torch.equal(i, i2)
+        assert local.redone == (2 if rank == 1 else 0)
+        ret[rank] = (s.clone(), i.clone())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_topk_carries_a_speculative_local_handle():
+    """ShardedTopK.submit packs what a local module's submit() hands out; result() first asks the local module for the verified
+    output and packs again when it differs (rank 1's speculation fails here).  Merged result == the unsharded oracle on both ranks."""
+    world, n_items, k = 2, 600, 40
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_spec_worker, args=(world, _free_port(), n_items, k, ret), nprocs=world, join=True)
+    cfg = O.CONFIGS["amzn-books"]
+    w = O.synthetic_weights(cfg, seed=0)
+    q = O.synthetic_queries(cfg, 5)
+    X = torch.from_numpy(O.hash_item_table(1, 0, n_items, cfg.item_embedding_dim)).unsqueeze(0)
+    ids = torch.arange(0, n_items, dtype=torch.int64) * 3 + 1
+    rs, rpos = O.select_topk_deterministic(O.mol_logits(cfg, w, q, X), k)
+    for rank in range(world):
+        s, i = ret[rank]
+        assert torch.equal(s, rs) and torch.equal(i, ids[rpos])
