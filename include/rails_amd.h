@@ -32,7 +32,8 @@ extern "C" {
 /* Version of this interface: bumped whenever a struct gains a field or an entry point changes meaning (round 2 -> 3: 3, the
  * structs of round 2 carried no version; 5: the launch predicate became the explicit `run_if` argument of the entry points that
  * honour it and the per-thread rails_set_run_predicate is gone -- the library keeps no state between calls but the last error;
- * 6: rails_mol_coarse_topk gained its out_of_range output, rails_topk_candidates is new, rails_mol_score_indexed takes any n_cand).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
+ * 6: rails_mol_coarse_topk gained its out_of_range output and its optional int8 pre-filter (rails_mol_coarse_prefilter_*),
+ * rails_topk_candidates is new, rails_mol_score_indexed takes any n_cand).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
  * against an older header pass shorter structs, and the library would read the new fields from whatever follows them. */
 #define RAILS_ABI_VERSION 6
 int rails_abi_version(void);
@@ -237,7 +238,16 @@ int rails_mol_coarse_score(const rails_mol_shape* shape, const float* eq, int32_
 size_t rails_mol_coarse_topk_workspace_bytes(const rails_mol_shape* shape, int32_t batch, int64_t n_items, int32_t k_prime);
 int rails_mol_coarse_topk(const rails_mol_shape* shape, const float* eq, int32_t batch, int32_t average_queries,
                           const void* table, int64_t n_items, int32_t k_prime, void* workspace, size_t workspace_bytes,
-                          float* out_scores, int64_t* out_positions, int32_t* out_counts, int32_t* out_of_range, void* stream);
+                          float* out_scores, int64_t* out_positions, int32_t* out_counts, int32_t* out_of_range,
+                          const void* prefilter, void* stream);
+/* Optional int8 pre-filter of rails_mol_coarse_topk's streaming pass (no counterpart in the reference; it changes what the pass
+ * READS, not what it returns): a copy of the coarse table as int8 with one scale (256-byte header + d bytes per item).  With it the
+ * streaming pass reads the int8 copy, one int8 MFMA per 32 items, against a per-query integer bound that no item reaching the
+ * query's threshold can miss (|bf16 dot - scaled int8 dot| <= s |q|_1 / 2 + s_q max|x|_1 / 2 + 3 s s_q d / 4), and scores only the
+ * tiles that pass it from the bf16 table: same candidates, same counts, same output, about half the bytes.  prefilter == NULL: the
+ * pass reads the bf16 table.  d in {32, 64, 128} (rails_mol_coarse_prefilter_bytes returns 0 otherwise). */
+size_t rails_mol_coarse_prefilter_bytes(const rails_mol_shape* shape, int64_t n_items);
+int rails_mol_coarse_prefilter_build(const rails_mol_shape* shape, const void* table, int64_t n_items, void* prefilter, void* stream);
 
 /* ---- per-component candidate generation (MoLNaiveTopK / MoLCombTopK) ------------------------------
  * Replaces the bf16 component table (rails/indexing/mol_top_k.py:61-73, :172-174) and the per-query-group bf16 `mm`

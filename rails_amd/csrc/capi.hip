@@ -425,6 +425,19 @@ int rails_mol_coarse_build(const rails_mol_shape* s, const float* index, int64_t
   return fail(coarse_build(*s, index, n_items, table, (hipStream_t)stream), "coarse_build");
 }
 
+size_t rails_mol_coarse_prefilter_bytes(const rails_mol_shape* s, int64_t n_items) {
+  if (!shape_ok(s)) return 0;
+  return coarse_prefilter_bytes(*s, n_items);
+}
+
+int rails_mol_coarse_prefilter_build(const rails_mol_shape* s, const void* table, int64_t n_items, void* prefilter, void* stream) {
+  g_err[0] = '\0';
+  if (!shape_ok(s)) return RAILS_EINVAL;
+  if (n_items <= 0) { set_error("coarse_prefilter_build: n_items must be positive"); return RAILS_EINVAL; }
+  if (!table || !prefilter) { set_error("coarse_prefilter_build: NULL pointer"); return RAILS_EINVAL; }
+  return fail(coarse_prefilter_build(*s, table, n_items, prefilter, (hipStream_t)stream), "coarse_prefilter_build");
+}
+
 size_t rails_mol_coarse_topk_workspace_bytes(const rails_mol_shape* s, int32_t batch, int64_t n_items, int32_t k_prime) {
   if (!shape_ok(s) || batch <= 0) return 0;
   return coarse_topk_workspace_bytes(*s, batch, n_items, k_prime);
@@ -432,7 +445,7 @@ size_t rails_mol_coarse_topk_workspace_bytes(const rails_mol_shape* s, int32_t b
 
 int rails_mol_coarse_topk(const rails_mol_shape* s, const float* eq, int32_t batch, int32_t average_queries, const void* table,
                           int64_t n_items, int32_t k_prime, void* workspace, size_t workspace_bytes, float* out_scores,
-                          int64_t* out_positions, int32_t* out_counts, int32_t* out_of_range, void* stream) {
+                          int64_t* out_positions, int32_t* out_counts, int32_t* out_of_range, const void* prefilter, void* stream) {
   g_err[0] = '\0';
   if (!shape_ok(s)) return RAILS_EINVAL;
   if (batch < 0 || n_items < 0 || k_prime < 0) { set_error("coarse_topk: negative size"); return RAILS_EINVAL; }
@@ -442,7 +455,7 @@ int rails_mol_coarse_topk(const rails_mol_shape* s, const float* eq, int32_t bat
   const int cu = compute_units();
   if (cu <= 0) { set_error("coarse_topk: no HIP device"); return RAILS_ELAUNCH; }
   const int r = coarse_topk(*s, eq, batch, average_queries ? 1 : 0, table, n_items, k_prime, workspace, workspace_bytes,
-                            out_scores, out_positions, out_counts, out_of_range, cu, (hipStream_t)stream);
+                            out_scores, out_positions, out_counts, out_of_range, prefilter, cu, (hipStream_t)stream);
   return r == kOk ? r : fail(r, "coarse_topk");
 }
 

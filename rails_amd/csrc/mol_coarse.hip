@@ -88,6 +88,7 @@ struct CoarseScanArgs {
   unsigned short* qfrag_out;            // kScanSample: workgroup 0 leaves the queries' A fragments here for the select scan ...
   unsigned int* zero_words; int n_zero; // ... and zeroes these words (the candidate counters)
   int32_t* zero_flag;                   // ... and the caller's out-of-range flag, which the key selection may raise
+  signed char* q8_out; float* qmeta_out; // ... and, for the int8 pre-filter, the queries' int8 fragments and (s_q, |q|_1) per query
   const float* thr; int64_t thr_stride; // kScanSelect: thr[b * thr_stride], a bf16 value
   unsigned long long* keys; int cap;    // kScanSelect: keys[b * cap + sub * (cap / kSubLists) + slot]
   unsigned int* counts;                 // kScanSelect: counts[b * kSubLists + sub], candidates seen (may exceed the sub-list)
@@ -172,6 +173,8 @@ __device__ __forceinline__ void coarse_query_element(const float* __restrict__ e
   const int qt = b >> 5, row = b & 31, c = dd >> 4, h = (dd >> 3) & 1, j = dd & 7;
   frag[(((size_t)qt * DC + c) * 64 + h * 32 + row) * 8 + j] = (unsigned short)(__float_as_uint(v) >> 16);
 }
+__device__ __forceinline__ void quantise_query(const unsigned short* qfrag, int DC, int d, int q, signed char* q8, float* qmeta);   // int8 pre-filter, below
+
 template <int DC, int MODE, bool NT = false>   // DC = d / 16 K chunks; NT: non-temporal table loads
 __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MODE == kScanSelect ? RAILS_SCAN_WAVES : 2, MODE == kScanSelect ? RAILS_SCAN_WAVES : 2))) void coarse_scan_kernel(CoarseScanArgs a) {
   MOL_RUN_IF(a.run_if);
@@ -203,6 +206,8 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
         for (int i = threadIdx.x; i < n_qt * DC * 64; i += kScanThreads) reinterpret_cast<bf16x8*>(a.qfrag_out)[i] = reinterpret_cast<const bf16x8*>(qfrag)[i];
       for (int i = threadIdx.x; i < a.n_zero; i += kScanThreads) a.zero_words[i] = 0u;
       if (a.zero_flag && threadIdx.x == 0) *a.zero_flag = 0;
+      if (a.q8_out)
+        for (int q = threadIdx.x; q < n_qt * 32; q += kScanThreads) quantise_query(qfrag, DC, d, q, a.q8_out, a.qmeta_out);
     }
   }
 
@@ -475,7 +480,7 @@ __global__ void coarse_counts_kernel(const unsigned int* __restrict__ counts, in
   out[b] = over ? cap + 1 : (int32_t)total;
 }
 
-struct CoarseTopkPlan { int stride, r, cap; bool sample16; int64_t n_sample; size_t off_keys, off_sample, off_top_s, off_top_i, off_ws, off_qfrag, total, topk_ws; };
+struct CoarseTopkPlan { int stride, r, cap; bool sample16; int64_t n_sample; size_t off_keys, off_sample, off_top_s, off_top_i, off_ws, off_qfrag, off_q8, off_qmeta, total, topk_ws; };
 
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 
@@ -541,8 +546,260 @@ static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p, b
   p->topk_ws = topk_workspace_bytes(B, p->n_sample, r);
   p->off_ws = o; o += align256(p->topk_ws);
   p->off_qfrag = o; o += align256(sizeof(unsigned short) * (size_t)((B + 31) / 32) * 32 * 128);   // coarse_topk's query fragments (d <= 128)
+  p->off_q8 = o; o += align256((size_t)((B + 31) / 32) * 32 * 128);                                // the same as int8 (pre-filter)
+  p->off_qmeta = o; o += align256(sizeof(float) * 2 * (size_t)((B + 31) / 32) * 32);
   p->total = o;
   return true;
+}
+
+// ---- int8 pre-filter of the select scan -------------------------------------------------------------------------------------------
+// The select scan is bound by reading the table: 2d bytes per item.  A second copy of the table as int8 with ONE scale for the whole
+// table (d bytes per item) is enough to decide which tiles can hold a candidate at all:
+//   x_k = s (i_k + e_k), q_k = s_q (j_k + f_k), |e_k|, |f_k| <= 1/2   =>
+//   | sum_k q_k x_k  -  s s_q sum_k j_k i_k |  <=  eps_b = s |q_b|_1 / 2 + s_q,b max_x |x|_1 / 2 + 3 s s_q,b d / 4
+// so an item whose bf16 score reaches query b's threshold has the INTEGER dot product I >= (thr_lo,b - eps_b) / (s s_q,b), thr_lo the
+// bf16 value below the threshold (the margin the bf16 pre-test keeps for the rounding of the sum).  The scan streams the int8 table,
+// one v_mfma_i32_32x32x32_i8 per tile and query tile with the accumulator started at minus that integer bound -- the same sign-bit
+// pre-test as the bf16 scan -- and only the tiles that fire (a few per cent) are read from the bf16 table and scored as before, with
+// the materialising path's bits: candidates, counts and keys are exactly those of the scan without the pre-filter.  HBM bytes per
+// batch: N d (+ 2d per item of a fired tile) instead of 2 N d.
+// The buffer: 256 bytes of header [scale, 127 / max|x|, max_x |x|_1] then N * d int8, item-major like the table.
+constexpr size_t kPrefilterHeader = 256;
+struct PrefilterHeader { float scale, inv_scale, x1max; unsigned int maxabs_bits, x1max_bits; };
+
+__global__ void prefilter_stats_kernel(const unsigned short* __restrict__ table, int64_t n, int d, PrefilterHeader* hdr) {
+  const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float mx = 0.0f, l1 = 0.0f;
+  if (item < n) {
+    const unsigned short* row = table + item * d;
+    for (int k = 0; k < d; k += 8) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(row + k);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float a = fabsf((float)v[j]); mx = fmaxf(mx, a); l1 += a; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); l1 = fmaxf(l1, __shfl_xor(l1, o, 64)); }
+  if ((threadIdx.x & 63) == 0) {   // non-negative floats order like their bit patterns.  fmaxf drops NaN: an item with a NaN sum never passes the
+    atomicMax(&hdr->maxabs_bits, __float_as_uint(mx));   // exact test, so it need not enter the bound; inf stays inf
+    atomicMax(&hdr->x1max_bits, __float_as_uint(l1));
+  }
+}
+__global__ void prefilter_finish_kernel(PrefilterHeader* hdr) {
+  const float mx = __uint_as_float(hdr->maxabs_bits);
+  hdr->scale = mx > 0.0f ? mx / 127.0f : 1.0f;              // inf stays inf: every tile then fires (the bound below becomes -inf)
+  hdr->inv_scale = mx > 0.0f ? 127.0f / mx : 1.0f;
+  hdr->x1max = __uint_as_float(hdr->x1max_bits);
+}
+__device__ __forceinline__ int quant8(float v, float inv_scale) {
+  const float t = rintf(v * inv_scale);
+  return t >= -127.0f && t <= 127.0f ? (int)t : 0;           // NaN (and inf / inf): 0 -- such an item never passes the exact test either
+}
+__global__ void prefilter_quant_kernel(const unsigned short* __restrict__ table, int64_t n_elems, const PrefilterHeader* __restrict__ hdr,
+                                       signed char* __restrict__ out) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+  if (i >= n_elems) return;
+  const float inv = hdr->inv_scale;
+  const bf16x8 a = *reinterpret_cast<const bf16x8*>(table + i), b = *reinterpret_cast<const bf16x8*>(table + i + 8);
+  unsigned int w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    w[j >> 2] |= ((unsigned int)quant8((float)a[j], inv) & 255u) << (8 * (j & 3));
+    w[2 + (j >> 2)] |= ((unsigned int)quant8((float)b[j], inv) & 255u) << (8 * (j & 3));
+  }
+  *reinterpret_cast<uint4*>(out + i) = uint4{w[0], w[1], w[2], w[3]};
+}
+
+size_t coarse_prefilter_bytes(const Shape& s, int64_t n) {
+  const int d = s.dot_product_dimension;
+  return d % 32 == 0 && d <= 128 && n > 0 ? kPrefilterHeader + (size_t)n * d : 0;
+}
+int coarse_prefilter_build(const Shape& s, const void* table, int64_t n, void* prefilter, hipStream_t stream) {
+  const int d = s.dot_product_dimension;
+  if (coarse_prefilter_bytes(s, n) == 0) { set_error("coarse pre-filter: d = %d (supported: 32, 64, 128)", d); return kErrUnsupported; }
+  PrefilterHeader* hdr = static_cast<PrefilterHeader*>(prefilter);
+  if (hipMemsetAsync(hdr, 0, kPrefilterHeader, stream) != hipSuccess) return kErrLaunch;
+  hipLaunchKernelGGL(prefilter_stats_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, static_cast<const unsigned short*>(table), n, d, hdr);
+  hipLaunchKernelGGL(prefilter_finish_kernel, dim3(1), dim3(1), 0, stream, hdr);
+  const int64_t n_elems = n * d;
+  hipLaunchKernelGGL(prefilter_quant_kernel, dim3((unsigned)((n_elems / 16 + 255) / 256)), dim3(256), 0, stream, static_cast<const unsigned short*>(table), n_elems,
+                     hdr, static_cast<signed char*>(prefilter) + kPrefilterHeader);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+typedef int ci32x4 __attribute__((ext_vector_type(4)));
+typedef int ci32x16 __attribute__((ext_vector_type(16)));
+
+// The queries for the int8 scan, from their bf16 A fragments in LDS (fragment order [qt][c][h * 32 + row][8]): one thread per query
+// writes its int8 fragment bytes [qt][c8][h * 32 + row][16] (k = 32 c8 + 16 h + j) and (s_q, |q|_1).
+__device__ __forceinline__ void quantise_query(const unsigned short* qfrag, int DC, int d, int q, signed char* q8, float* qmeta) {
+  const int qt = q >> 5, row = q & 31;
+  auto at = [&](int dd) { return bf16_to_f32(qfrag[(((size_t)qt * DC + (dd >> 4)) * 64 + ((dd >> 3) & 1) * 32 + row) * 8 + (dd & 7)]); };
+  float mx = 0.0f, l1 = 0.0f;
+  for (int dd = 0; dd < d; ++dd) { const float a = fabsf(at(dd)); mx = fmaxf(mx, a); l1 += a; }
+  const float inv = mx > 0.0f ? 127.0f / mx : 1.0f;
+  for (int dd = 0; dd < d; ++dd)
+    q8[(((size_t)qt * (d / 32) + (dd >> 5)) * 64 + ((dd >> 4) & 1) * 32 + row) * 16 + (dd & 15)] = (signed char)quant8(at(dd), inv);
+  qmeta[2 * q] = mx > 0.0f ? mx / 127.0f : 1.0f;
+  qmeta[2 * q + 1] = l1;
+}
+
+struct CoarseI8Args {
+  const unsigned short* qfrag; const signed char* q8; const float* qmeta;   // made by the sample scan's workgroup 0
+  const unsigned short* table; const signed char* table8; const PrefilterHeader* hdr; int64_t n; int B, d;
+  const float* thr; int64_t thr_stride;
+  unsigned long long* keys; int cap; unsigned int* counts;
+};
+
+template <int DC8, bool NT>   // DC8 = d / 32 K chunks of the int8 MFMA; NT: non-temporal table loads
+__global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(RAILS_SCAN_WAVES, RAILS_SCAN_WAVES))) void coarse_scan_i8_kernel(CoarseI8Args a) {
+  constexpr int DC = 2 * DC8;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // bf16 fragments, int8 fragments, thr, thr_lo, integer starts
+  const int d = a.d, B = a.B;
+  const int n_qt = (B + 31) / 32;
+  unsigned short* qfrag = lds;                                                             // [n_qt][DC][64][8]
+  signed char* q8 = reinterpret_cast<signed char*>(qfrag + (size_t)n_qt * DC * 64 * 8);   // [n_qt][DC8][64][16]
+  float* thr_s = reinterpret_cast<float*>(q8 + (size_t)n_qt * DC8 * 64 * 16);             // [n_qt * 32]
+  float* tlo_s = thr_s + n_qt * 32;                                                        // the bf16 value below thr
+  int* nb_s = reinterpret_cast<int*>(tlo_s + n_qt * 32);                                   // minus the integer bound
+  __shared__ StageEntry stage_s[kScanThreads / 64][kStage];
+  __shared__ unsigned int stage_n[kScanThreads / 64];
+  __shared__ float acc_s[(kScanThreads / 64) * 16 * 64];
+  if (threadIdx.x < kScanThreads / 64) stage_n[threadIdx.x] = 0u;
+  for (int i = threadIdx.x; i < n_qt * DC * 64; i += kScanThreads) reinterpret_cast<bf16x8*>(qfrag)[i] = reinterpret_cast<const bf16x8*>(a.qfrag)[i];
+  for (int i = threadIdx.x; i < n_qt * DC8 * 64; i += kScanThreads) reinterpret_cast<ci32x4*>(q8)[i] = reinterpret_cast<const ci32x4*>(a.q8)[i];
+  for (int i = threadIdx.x; i < n_qt * 32; i += kScanThreads) {
+    const float thr = i < B ? a.thr[(int64_t)i * a.thr_stride] : INFINITY;
+    const float tlo = coarse_unorderable(coarse_orderable(thr) - 0x10000u);
+    const float s = a.hdr->scale, sq = a.qmeta[2 * i], l1 = a.qmeta[2 * i + 1];
+    const float eps = 1.002f * (0.5f * s * l1 + 0.5f * sq * a.hdr->x1max + 0.75f * s * sq * (float)d);
+    float bound = floorf((tlo - eps) / (s * sq)) - 2.0f;          // integer dot products below it cannot reach thr
+    if (!(bound > -1073741824.0f)) bound = -1073741824.0f;        // -inf / NaN (a table with inf or NaN sums): every tile fires
+    if (bound > 1073741824.0f) bound = 1073741824.0f;             // rows past B (thr = inf): never
+    thr_s[i] = thr;
+    tlo_s[i] = tlo;
+    nb_s[i] = -(int)bound;
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int x = lane & 31, h = lane >> 5;
+  const int64_t n_tiles = (a.n + 31) >> 5;
+  const int64_t gw = (int64_t)blockIdx.x * (kScanThreads / 64) + wave, n_waves = (int64_t)gridDim.x * (kScanThreads / 64);
+  constexpr int TU = DC8 == 1 ? 8 : (DC8 == 2 ? 4 : 2);   // item tiles per trip: 8 KiB of table per wave in flight
+  struct Trip { ci32x4 Bq[TU][DC8]; };
+  auto load_trip = [&](int64_t w0, Trip& T) {
+#pragma unroll
+    for (int u = 0; u < TU; ++u) {
+      int64_t item = (w0 + u) * 32 + x;
+      if (item >= a.n) item = a.n - 1;
+      const signed char* rowp = a.table8 + item * d + 16 * h;
+#pragma unroll
+      for (int c = 0; c < DC8; ++c) {
+        if constexpr (NT) T.Bq[u][c] = __builtin_nontemporal_load(reinterpret_cast<const ci32x4*>(rowp + 32 * c));
+        else T.Bq[u][c] = *reinterpret_cast<const ci32x4*>(rowp + 32 * c);
+      }
+    }
+  };
+  // a fired tile: its rows of the bf16 table, scored from zero like the materialising path, the scores at or above the threshold appended
+  auto exact_tile = [&](int qt, int64_t tile) {
+    int64_t item = tile * 32 + x;
+    const bool in = item < a.n;
+    if (!in) item = a.n - 1;
+    const unsigned short* rowp = a.table + item * d + 8 * h;
+    cf32x16 acc = {0};
+#pragma unroll
+    for (int c = 0; c < DC; ++c)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(qfrag + (((size_t)qt * DC + c) * 64 + lane) * 8),
+                                                    *reinterpret_cast<const bf16x8*>(rowp + 16 * c), acc, 0, 0, 0);
+    unsigned int mask = 0u;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mask |= acc[r] >= tlo_s[qt * 32 + acc_row(r, h)] ? 1u << r : 0u;
+    if (!in) mask = 0u;
+    if (__any(mask != 0u)) {
+      float* mine = acc_s + (wave * 16) * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mine[r * 64] = acc[r];
+      while (__any(mask != 0u)) {
+        if (mask != 0u) {
+          const int r = __ffs(mask) - 1;
+          mask &= mask - 1u;
+          const int q = qt * 32 + acc_row(r, h);
+          const float sc = bf16_rn(mine[r * 64]);
+          if (q < B && sc >= thr_s[q])
+            stage_push(stage_s[wave], &stage_n[wave], a.keys, a.counts, a.cap, (int)(tile % kSubLists), (unsigned int)q,
+                       ((unsigned long long)coarse_orderable(sc) << 32) | (unsigned int)(~(unsigned int)item));
+        }
+      }
+    }
+    stage_flush_mixed(stage_s[wave], &stage_n[wave], lane, a.keys, a.counts, a.cap, 64u);
+  };
+  ci32x4 A8[DC8];
+  ci32x16 nb;
+  auto load_query_tile = [&](int qt) {
+#pragma unroll
+    for (int c = 0; c < DC8; ++c) A8[c] = *reinterpret_cast<const ci32x4*>(q8 + (((size_t)qt * DC8 + c) * 64 + lane) * 16);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nb[r] = nb_s[qt * 32 + acc_row(r, h)];
+  };
+  load_query_tile(0);
+  int64_t w0 = gw * TU;
+  if (w0 < n_tiles) {
+    const int64_t hop = n_waves * TU;
+    Trip T, N;
+    load_trip(w0, T);
+    for (;;) {
+      const int64_t w1 = w0 + hop;
+      load_trip(w1 < n_tiles ? w1 : w0, N);       // past the end: this trip again, harmless
+#pragma unroll
+      for (int u = 0; u < TU; ++u)
+#pragma unroll
+        for (int c = 0; c < DC8; ++c) asm volatile("" : "+v"(T.Bq[u][c]));   // the wait for T belongs here, with N in flight (see coarse_scan_kernel)
+      for (int qt = 0; qt < n_qt; ++qt) {
+        if (n_qt > 1) load_query_tile(qt);
+        unsigned int fired = 0u;
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+          ci32x16 acc = nb;
+#pragma unroll
+          for (int c = 0; c < DC8; ++c) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A8[c], T.Bq[u][c], acc, 0, 0, 0);
+          if (__any(any_sign_clear(__builtin_bit_cast(cf32x16, acc)))) fired |= 1u << u;
+        }
+        while (fired) {   // wave-uniform; rare
+          const int u = __ffs(fired) - 1;
+          fired &= fired - 1u;
+          if (w0 + u < n_tiles) exact_tile(qt, w0 + u);
+        }
+      }
+      if (w1 >= n_tiles) break;
+      T = N;
+      w0 = w1;
+    }
+  }
+  stage_flush_mixed(stage_s[wave], &stage_n[wave], lane, a.keys, a.counts, a.cap, 1u);
+}
+
+static int launch_coarse_scan_i8(const CoarseI8Args& a, hipStream_t stream) {
+  const int n_qt = (a.B + 31) / 32, dc8 = a.d / 32;
+  const size_t lds = (size_t)n_qt * (2 * dc8 * 1024 + dc8 * 1024 + 3 * 32 * 4);
+  if (lds > 48 * 1024) { set_error("coarse int8 scan: batch %d x d %d does not fit LDS", a.B, a.d); return kErrUnsupported; }
+  const int64_t n_tiles = (a.n + 31) >> 5;
+  const int tu = dc8 == 1 ? 8 : (dc8 == 2 ? 4 : 2);
+  int64_t grid = (n_tiles + 4 * tu - 1) / (4 * tu);
+  if (grid > 2048) grid = 2048;
+  if (grid < 1) return kOk;
+  auto go = [&](auto nt) {
+    constexpr bool NT = decltype(nt)::value;
+    switch (dc8) {
+      case 1: hipLaunchKernelGGL((coarse_scan_i8_kernel<1, NT>), dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a); return true;
+      case 2: hipLaunchKernelGGL((coarse_scan_i8_kernel<2, NT>), dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a); return true;
+      case 4: hipLaunchKernelGGL((coarse_scan_i8_kernel<4, NT>), dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a); return true;
+      default: return false;
+    }
+  };
+  const bool known = (RAILS_SCAN_NT != 0 && n_qt == 1) ? go(std::true_type{}) : go(std::false_type{});
+  if (!known) { set_error("coarse int8 scan: d = %d (supported: 32, 64, 128)", a.d); return kErrUnsupported; }
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
 size_t coarse_topk_workspace_bytes(const Shape& s, int B, int64_t n, int k_prime) {
@@ -562,7 +819,8 @@ int range_flag(const int32_t* v, int n, int lo, int hi, int32_t* flag, hipStream
 }
 
 int coarse_topk(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, int k_prime, void* ws,
-                size_t ws_bytes, float* out_scores, int64_t* out_pos, int32_t* out_counts, int32_t* out_flag, int n_cu, hipStream_t stream) {
+                size_t ws_bytes, float* out_scores, int64_t* out_pos, int32_t* out_counts, int32_t* out_flag, const void* prefilter, int n_cu,
+                hipStream_t stream) {
   CoarseTopkPlan p;
   if (!coarse_topk_plan(B, n, k_prime, &p, true)) { set_error("coarse_topk: unsupported size (B = %d, K' = %d, n = %lld)", B, k_prime, (long long)n); return kErrUnsupported; }
   if (n >= (1ll << 32)) { set_error("coarse_topk: n does not fit 32-bit positions; shard the corpus"); return kErrUnsupported; }
@@ -582,15 +840,27 @@ int coarse_topk(const Shape& s, const float* eq, int B, int avg, const void* tab
   a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.d = s.dot_product_dimension; a.avg = avg;
   a.table = static_cast<const unsigned short*>(table); a.n = n;
   a.qfrag_out = frag; a.zero_words = counts; a.n_zero = B * kSubLists; a.zero_flag = out_flag;
+  signed char* q8 = reinterpret_cast<signed char*>(base + p.off_q8);
+  float* qmeta = reinterpret_cast<float*>(base + p.off_qmeta);
+  if (prefilter) { a.q8_out = q8; a.qmeta_out = qmeta; }
   a.scores16 = sample; a.ld = p.n_sample; a.stride = p.stride;
   int rc = launch_coarse_scan<kScanSample>(a, stream);
   if (rc != kOk) return rc;
   rc = topk(nullptr, p.n_sample, B, p.n_sample, p.r, nullptr, 0, top_s, top_i, base + p.off_ws, p.topk_ws, n_cu, stream, nullptr, 0, 0, sample);
   if (rc != kOk) return rc;
-  a.qfrag = frag; a.qfrag_out = nullptr; a.zero_words = nullptr; a.n_zero = 0; a.zero_flag = nullptr;
-  a.scores16 = nullptr; a.ld = 0; a.stride = 1;
-  a.thr = top_s + (p.r - 1); a.thr_stride = p.r; a.keys = keys; a.cap = p.cap; a.counts = counts;
-  rc = launch_coarse_scan<kScanSelect>(a, stream);
+  if (prefilter) {   // the select scan over the int8 copy of the table; fired tiles are scored from the bf16 table
+    CoarseI8Args i8{};
+    i8.qfrag = frag; i8.q8 = q8; i8.qmeta = qmeta;
+    i8.table = static_cast<const unsigned short*>(table); i8.hdr = static_cast<const PrefilterHeader*>(prefilter);
+    i8.table8 = static_cast<const signed char*>(prefilter) + kPrefilterHeader; i8.n = n; i8.B = B; i8.d = a.d;
+    i8.thr = top_s + (p.r - 1); i8.thr_stride = p.r; i8.keys = keys; i8.cap = p.cap; i8.counts = counts;
+    rc = launch_coarse_scan_i8(i8, stream);
+  } else {
+    a.qfrag = frag; a.qfrag_out = nullptr; a.zero_words = nullptr; a.n_zero = 0; a.zero_flag = nullptr; a.q8_out = nullptr; a.qmeta_out = nullptr;
+    a.scores16 = nullptr; a.ld = 0; a.stride = 1;
+    a.thr = top_s + (p.r - 1); a.thr_stride = p.r; a.keys = keys; a.cap = p.cap; a.counts = counts;
+    rc = launch_coarse_scan<kScanSelect>(a, stream);
+  }
   if (rc != kOk) return rc;
   return select_sublists(keys, counts, B, p.cap, kSubLists, k_prime, out_scores, out_pos, out_counts, out_flag, stream);
 }

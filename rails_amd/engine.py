@@ -507,11 +507,25 @@ class MolEngine:
             )
         return out
 
-    def coarse_topk(self, eq: torch.Tensor, table: torch.Tensor, average_queries: bool, k_prime: int, with_flag: bool = False):
+    def build_coarse_prefilter(self, table: torch.Tensor) -> Optional[torch.Tensor]:
+        """The int8 copy of a coarse table that lets coarse_topk's streaming pass read d instead of 2d bytes per item
+        (include/rails_amd.h rails_mol_coarse_prefilter_build); None for shapes without one."""
+        n = table.shape[0]
+        nbytes = self.lib.rails_mol_coarse_prefilter_bytes(C.byref(self.shape), n)
+        if nbytes == 0:
+            return None
+        pre = torch.empty(nbytes, dtype=torch.uint8, device=table.device)
+        with _on_device(table.device):
+            _lib.check(self.lib.rails_mol_coarse_prefilter_build(C.byref(self.shape), _ptr(table), n, _ptr(pre), _stream()), "rails_mol_coarse_prefilter_build")
+        return pre
+
+    def coarse_topk(self, eq: torch.Tensor, table: torch.Tensor, average_queries: bool, k_prime: int, with_flag: bool = False,
+                    prefilter: Optional[torch.Tensor] = None):
         """Fused coarse scoring + exact top-K' (no (B, N) score matrix).  -> (scores (B, K'), positions (B, K'), counts (B,)
         int32) or None when the sizes are unsupported.  The result is exact iff K' <= counts[b] <= capacity for every b
         (see include/rails_amd.h); the caller checks and falls back to coarse_scores + topk otherwise.  with_flag: a fourth
-        element, a device int32 that is 1 iff some count is out of range (written by the call's own launches)."""
+        element, a device int32 that is 1 iff some count is out of range (written by the call's own launches).
+        prefilter: build_coarse_prefilter(table) -- same outputs, the streaming pass reads the int8 copy."""
         B, n = eq.shape[0], table.shape[0]
         ws_bytes = self.lib.rails_mol_coarse_topk_workspace_bytes(C.byref(self.shape), B, n, k_prime)
         if ws_bytes == 0:
@@ -526,7 +540,7 @@ class MolEngine:
         with _on_device(dev):
             _lib.check(
                 self.lib.rails_mol_coarse_topk(C.byref(self.shape), _ptr(eq), B, 1 if average_queries else 0, _ptr(table), n, k_prime,
-                                               _ptr(ws), ws_bytes, _ptr(out_s), _ptr(out_p), _ptr(counts), _ptr(flag) if with_flag else None, _stream()),
+                                               _ptr(ws), ws_bytes, _ptr(out_s), _ptr(out_p), _ptr(counts), _ptr(flag) if with_flag else None, _ptr(prefilter), _stream()),
                 "rails_mol_coarse_topk",
             )
         return (out_s, out_p, counts[:B], flag) if with_flag else (out_s, out_p, counts[:B])

@@ -601,14 +601,22 @@ class MoLAvgTopK(MoLTopKModule):
         self.fused_coarse_min_items: int = 262144    # below this the (B, N) scores are small and one launch chain shorter
         self._coarse_engine = None
         self._coarse_table = None
+        self._coarse_prefilter = None
         self._verdict_pool: list = []
+
+    PREFILTER_MIN_ITEMS = 4_000_000   # the int8 copy of the coarse table pays where the streaming pass is bound by HBM reads
 
     def _table(self) -> torch.Tensor:
         eng = self._bind()
         if self._coarse_engine is not eng:
             self._coarse_engine = eng
             self._coarse_table = eng.build_coarse_table(self._index, self._item_embeddings[0])
+            self._coarse_prefilter = eng.build_coarse_prefilter(self._coarse_table) if self._coarse_table.shape[0] >= self.PREFILTER_MIN_ITEMS else None
         return self._coarse_table
+
+    def _prefilter(self) -> Optional[torch.Tensor]:
+        self._table()
+        return self._coarse_prefilter
 
     def _coarse_topk(self, query_embeddings: torch.Tensor, average_queries: bool, pending: Optional[list] = None, **kwargs):
         eng = self._bind()
@@ -635,7 +643,7 @@ class MoLAvgTopK(MoLTopKModule):
         # Same scores and the same exact top-K' as the materialising path below -- when every query's candidate count
         # landed inside [K', capacity]; the check costs one 128-byte device-to-host copy.
         if n >= self.fused_coarse_min_items and self._avg_top_k <= 4096 and not getattr(self, "_no_fused", False):
-            fused = eng.coarse_topk(eq, table, average_queries, self._avg_top_k, with_flag=True)
+            fused = eng.coarse_topk(eq, table, average_queries, self._avg_top_k, with_flag=True, prefilter=self._prefilter())
             if fused is not None:
                 # bad: 1 iff some row's candidate count is outside [K', capacity] -- raised by the call's key-selection launch
                 sc, idx, counts, bad = fused

@@ -407,6 +407,9 @@ def test_fused_coarse_topk_equals_the_materialised_path(dev, cfg_name, n, avg_k)
             fs, fp, counts = eng.coarse_topk(eq, at._table(), average, avg_k)
             assert int(counts.min()) >= avg_k and int(counts.max()) <= eng.coarse_topk_capacity(avg_k), counts
             assert torch.equal(fs, rs) and torch.equal(fp, rp)
+            # the int8 pre-filter changes what the streaming pass reads, not what it finds: same candidates, counts, output
+            ps, pp, pc = eng.coarse_topk(eq, at._table(), average, avg_k, prefilter=eng.build_coarse_prefilter(at._table()))
+            assert torch.equal(ps, rs) and torch.equal(pp, rp) and torch.equal(pc, counts)
         # the module takes the fused path at this size and returns what the materialising path returns
         s1, i1 = at(q, k=50, **kw)
         at.fused_coarse_min_items = 1 << 62
@@ -440,6 +443,8 @@ def test_fused_coarse_topk_over_several_trips_per_wave(dev, cfg_name, n, B, avg_
         fs, fp, counts = eng.coarse_topk(eq, at._table(), True, avg_k)
         assert int(counts.min()) >= avg_k and int(counts.max()) <= eng.coarse_topk_capacity(avg_k), counts
         assert torch.equal(fs, rs) and torch.equal(fp, rp)
+        ps, pp, pc = eng.coarse_topk(eq, at._table(), True, avg_k, prefilter=eng.build_coarse_prefilter(at._table()))
+        assert torch.equal(ps, rs) and torch.equal(pp, rp) and torch.equal(pc, counts)
 
 
 def test_fused_coarse_topk_falls_back_on_heavy_ties(dev):
@@ -512,6 +517,78 @@ def test_candidate_unions_with_the_verdict_read_on_the_host(dev, tied, monkeypat
             mod.fused_component_min_items = mod.fused_coarse_min_items = 1 << 62
             s2, i2 = mod(q, k=50)
             assert torch.equal(s1, s2) and torch.equal(i1, i2)
+
+
+@pytest.mark.parametrize("case", ["outlier", "inf", "nan_rows", "zeros", "ties", "tiny_queries", "negative"])
+def test_int8_prefilter_never_loses_a_candidate(dev, case, monkeypatch):
+    """The int8 pre-filter of the fused coarse top-K' decides which tiles are scored at all, from a rigorous bound on |bf16 dot -
+    scaled int8 dot|.  Tables and queries that stress the bound: one item 1 000 x larger than the rest (the single scale crushes every
+    other item to zero: the bound must then let every tile through), an inf entry, NaN rows, an all-zero table, a table of 40 distinct
+    rows, queries 1e-6 x smaller than the items, all-negative scores.  Always: same (scores, positions, counts) as without it."""
+    cfg = O.CONFIGS["amzn-books"]
+    mol = build_module(cfg, O.synthetic_weights(cfg, seed=2), dev)
+    n, K = 300_000, 300
+    ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    q = O.synthetic_queries(cfg, 9, seed=4).to(dev)
+    with torch.inference_mode():
+        X = torch.from_numpy(O.hash_item_table(6, 0, n, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+        at = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=K)
+        eng = at._bind()
+        _, eq, _ = eng.query_pack(q, None, want_plain=True)
+        table = at._table().clone()
+        if case == "outlier":
+            table[12345] = table[12345] * 1000.0
+        elif case == "inf":
+            table[777, 3] = float("inf")
+        elif case == "nan_rows":
+            table[5000:9000] = float("nan")
+        elif case == "zeros":
+            table.zero_()
+        elif case == "ties":
+            table = table[torch.arange(n, device=dev) % 40].contiguous()
+        elif case == "tiny_queries":
+            eq = eq * 1e-6
+        elif case == "negative":
+            table = -table.abs()
+            eq = eq.abs()
+        pre = eng.build_coarse_prefilter(table)
+        for average in (False, True):
+            fs, fp, counts = eng.coarse_topk(eq, table, average, K)
+            ps, pp, pc = eng.coarse_topk(eq, table, average, K, prefilter=pre)
+            assert torch.equal(pc, counts)                # the same candidates reached the lists
+            exact = (counts >= K) & (counts <= eng.coarse_topk_capacity(K))      # rows whose lists hold every candidate: defined output
+            if case in ("zeros", "ties"):
+                assert not bool(exact.any())              # every score tied thousands of times: all rows overflow, the caller redoes them
+            else:
+                assert bool(exact.all()) or case == "inf", (case, counts)
+            rs, rp = E.topk(eng.coarse_scores(eq, table, average), K)
+            for b in torch.nonzero(exact).flatten().tolist():
+                assert torch.equal(ps[b], rs[b]) and torch.equal(pp[b], rp[b]) and torch.equal(fs[b], rs[b]) and torch.equal(fp[b], rp[b])
+
+
+def test_avg_topk_module_with_the_int8_prefilter(dev, monkeypatch):
+    """MoLAvgTopK builds the pre-filter for large tables on its own (PREFILTER_MIN_ITEMS); lowered here: forward with it == forward
+    without it == the materialising path, d = 32 / 64 / 128 shapes."""
+    for cfg_name, n in (("amzn-books", 300_001), ("ml-1m", 280_000), ("ml-20m", 270_000)):
+        cfg = O.CONFIGS[cfg_name]
+        mol = build_module(cfg, O.synthetic_weights(cfg, seed=2), dev)
+        X = torch.from_numpy(O.hash_item_table(5, 0, n, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+        ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+        B = 70
+        q = O.synthetic_queries(cfg, B, seed=4).to(dev)
+        kw = {"user_ids": torch.arange(B, dtype=torch.int64, device=dev) * 7 + 1} if len(cfg.uid_embedding_hash_sizes) > 0 else {}
+        with torch.inference_mode():
+            monkeypatch.setattr(rails_amd.MoLAvgTopK, "PREFILTER_MIN_ITEMS", 1)
+            a = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=500)
+            s1, i1 = a(q, k=50, **kw)
+            assert a._prefilter() is not None
+            monkeypatch.setattr(rails_amd.MoLAvgTopK, "PREFILTER_MIN_ITEMS", 1 << 62)
+            b = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=500)
+            s2, i2 = b(q, k=50, **kw)
+            assert b._prefilter() is None
+            b.fused_coarse_min_items = 1 << 62
+            s3, i3 = b(q, k=50, **kw)
+            assert torch.equal(s1, s2) and torch.equal(i1, i2) and torch.equal(s1, s3) and torch.equal(i1, i3)
 
 
 def test_fused_coarse_topk_raises_its_flag_exactly_when_a_count_is_out_of_range(dev):

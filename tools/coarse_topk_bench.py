@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--avg-top-k", type=int, default=1000)
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--check", type=int, default=0, help="compare with coarse_scores + topk on a table of this many items first")
+    ap.add_argument("--prefilter", default="both", choices=["off", "on", "both"], help="the int8 pre-filter of the streaming pass (rails_mol_coarse_prefilter_build)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     cfg = O.CONFIGS["synthetic-8x8x32"]
@@ -54,6 +55,7 @@ def main():
 
         if args.check:
             t = table_of(args.check)
+            pre = eng.build_coarse_prefilter(t)
             for B in (1, 32, 77):
                 eq = queries(B)
                 sc, pos, counts = eng.coarse_topk(eq, t, False, args.avg_top_k)
@@ -62,23 +64,28 @@ def main():
                 ok = bool(((counts >= args.avg_top_k) & (counts <= cap)).all())
                 print(f"check N={args.check} B={B}: counts {int(counts.min())}..{int(counts.max())} (cap {cap}) in range {ok}; "
                       f"scores equal {torch.equal(sc, ref_s)}, positions equal {torch.equal(pos, ref_p)}")
-            del t
+                s8, p8, c8 = eng.coarse_topk(eq, t, False, args.avg_top_k, prefilter=pre)
+                print(f"      with the int8 pre-filter: scores equal {torch.equal(s8, ref_s)}, positions equal {torch.equal(p8, ref_p)}, counts equal {torch.equal(c8, counts)}")
+            del t, pre
         table = table_of(args.items)
+        pre_all = eng.build_coarse_prefilter(table) if args.prefilter != "off" else None
         for B in [int(b) for b in args.batch.split(",")]:
             eq = queries(B)
-            for _ in range(3):
-                out = eng.coarse_topk(eq, table, False, args.avg_top_k)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(args.reps):
-                out = eng.coarse_topk(eq, table, False, args.avg_top_k)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / args.reps
-            counts = out[2]
-            print(f"N={args.items} B={B} K'={args.avg_top_k}: {ms:.4f} ms per call = {table.numel() * 2 / ms / 1e9:.2f} TB/s of table read; "
-                  f"candidates per query {int(counts.min())}..{int(counts.max())} mean {float(counts.float().mean()):.0f} of {eng.coarse_topk_capacity(args.avg_top_k)} slots")
+            for mode in (["off", "on"] if args.prefilter == "both" else [args.prefilter]):
+                pre = pre_all if mode == "on" else None
+                for _ in range(3):
+                    out = eng.coarse_topk(eq, table, False, args.avg_top_k, prefilter=pre)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.reps):
+                    out = eng.coarse_topk(eq, table, False, args.avg_top_k, prefilter=pre)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / args.reps
+                counts = out[2]
+                print(f"N={args.items} B={B} K'={args.avg_top_k} pre-filter {mode}: {ms:.4f} ms per call = {table.numel() * 2 / ms / 1e9:.2f} TB/s of bf16-table bytes; "
+                      f"candidates per query {int(counts.min())}..{int(counts.max())} mean {float(counts.float().mean()):.0f} of {eng.coarse_topk_capacity(args.avg_top_k)} slots")
 
 
 if __name__ == "__main__":
