@@ -457,11 +457,12 @@ def full_shard_legs(B: int, k: int, dev) -> list:
                     pipelined(10)
                     torch.cuda.synchronize()
                     dtp = (time.perf_counter() - t0) / 10
-                    leg["pipelined"] = {"ms_per_step": dtp * 1e3, "queries_per_s": B / dtp, "hbm_frac_lower_bound": int(mod._table().numel() * mod._table().element_size()) / dtp / 8.0e12,
+                    leg["pipelined"] = {"ms_per_step": dtp * 1e3, "queries_per_s": B / dtp, "hbm_frac_lower_bound": int(mod._prefilter().numel() if mod._prefilter() is not None else mod._table().numel() * mod._table().element_size()) / dtp / 8.0e12,
                                         "output_equal_to_unpipelined": bool(torch.equal(p_out[0], r_scores) and torch.equal(p_out[1], r_ids))}
                     leg["coarse_table_bytes"] = int(mod._table().numel() * mod._table().element_size())
+                    leg["int8_prefilter_bytes"] = int(mod._prefilter().numel()) if mod._prefilter() is not None else 0
                     # the whole step (prologue, sample + threshold, select scan, key selection, in-place rerank, final top-k) against ONE read of the table
-                    leg["hbm_frac_lower_bound"] = leg["coarse_table_bytes"] / dt / 8.0e12
+                    leg["hbm_frac_lower_bound"] = (leg["int8_prefilter_bytes"] or leg["coarse_table_bytes"]) / dt / 8.0e12   # the bytes the streaming pass reads once
                     # north_star: "recall@k vs exact reported".  On the planted-structure weights (the plain random init has nothing
                     # for a two-pass search to find): the module is rebuilt on the same table -- one 160 GB index at a time
                     del mod, cand
@@ -883,14 +884,26 @@ def main() -> None:
             _, eq_plain, _ = eng.query_pack(q, kw.get("user_ids"), want_plain=True)
             kp_local = min(args.two_pass, hi - lo)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            eng.coarse_topk(eq_plain, table, False, kp_local)
+            pre = local._prefilter()          # the int8 copy the streaming pass reads instead of the bf16 table (large tables)
+            eng.coarse_topk(eq_plain, table, False, kp_local, prefilter=pre)
             e0.record()
             for _ in range(args.steps):
-                eng.coarse_topk(eq_plain, table, False, kp_local)
+                eng.coarse_topk(eq_plain, table, False, kp_local, prefilter=pre)
             e1.record()
             torch.cuda.synchronize()
             score_ms = e0.elapsed_time(e1) / args.steps
-            coarse_table_bytes = table.numel() * table.element_size()
+            bf16_table_bytes = table.numel() * table.element_size()
+            # algorithmic bytes of the pass = what its streaming launch has to read once: the int8 copy (d bytes per item) when
+            # there is one, else the bf16 table (2d)
+            coarse_table_bytes = (pre.numel() - 256) if pre is not None else bf16_table_bytes
+            score_ms_bf16 = None
+            if pre is not None:
+                e0.record()
+                for _ in range(args.steps):
+                    eng.coarse_topk(eq_plain, table, False, kp_local)
+                e1.record()
+                torch.cuda.synchronize()
+                score_ms_bf16 = e0.elapsed_time(e1) / args.steps
         else:
             score_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
 
@@ -1131,14 +1144,19 @@ def main() -> None:
             out["pipelined"] = two_pass_pipelined
             out["scaling"] = "weak" if args.workload.startswith("synthetic") and not args.items else "strong"
             out["roofline"] = {
-                "kernel": "coarse_scan_kernel (fused coarse top-K': sample pass + select pass + key selection)",
+                "kernel": ("coarse_scan_i8_kernel (fused coarse top-K': sample pass + select pass over the int8 copy of the table, fired tiles from the bf16 table + key selection)"
+                           if score_ms_bf16 is not None else "coarse_scan_kernel (fused coarse top-K': sample pass + select pass + key selection)"),
                 "bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
                 "traffic": None, "kernel_ms": score_ms, "hbm_bytes_alg_per_launch": coarse_table_bytes,
             }
+            if score_ms_bf16 is not None:
+                out["roofline"]["without_int8_prefilter"] = {"kernel_ms": score_ms_bf16, "hbm_bytes_alg_per_launch": bf16_table_bytes,
+                                                             "achieved": bf16_table_bytes / (score_ms_bf16 * 1e-3) / 1e9, "frac": bf16_table_bytes / (score_ms_bf16 * 1e-3) / 1e9 / PEAK_HBM_GBPS}
             if args.workload == "synthetic-8x8x32" and hi - lo == 125_000_000 and B in (32, 128):
                 # committed PMC passes of the select scan (the launch that reads the table; the time above also covers the sample
                 # pass and the key selection)
-                tr = committed_traffic(f"synthetic-8x8x32:coarse_scan:N125M:B{B}:r04") or committed_traffic(f"synthetic-8x8x32:coarse_scan:N125M:B{B}:r03")
+                tr = (committed_traffic(f"synthetic-8x8x32:coarse_scan_i8:N125M:B{B}:r04") if score_ms_bf16 is not None else None) or \
+                    (None if score_ms_bf16 is not None else (committed_traffic(f"synthetic-8x8x32:coarse_scan:N125M:B{B}:r04") or committed_traffic(f"synthetic-8x8x32:coarse_scan:N125M:B{B}:r03")))
                 if tr:
                     out["roofline"]["traffic"] = tr
                     out["roofline"]["traffic_source"] = ("profiles/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the select-scan launch on this "

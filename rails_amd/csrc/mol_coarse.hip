@@ -627,6 +627,12 @@ int coarse_prefilter_build(const Shape& s, const void* table, int64_t n, void* p
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
+#ifndef RAILS_SCAN8_WAVES
+#define RAILS_SCAN8_WAVES 3
+#endif
+#ifndef RAILS_SCAN8_TU
+#define RAILS_SCAN8_TU 8      // KiB of int8 table per wave and trip (tiles of d = 32)
+#endif
 typedef int ci32x4 __attribute__((ext_vector_type(4)));
 typedef int ci32x16 __attribute__((ext_vector_type(16)));
 
@@ -652,7 +658,7 @@ struct CoarseI8Args {
 };
 
 template <int DC8, bool NT>   // DC8 = d / 32 K chunks of the int8 MFMA; NT: non-temporal table loads
-__global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(RAILS_SCAN_WAVES, RAILS_SCAN_WAVES))) void coarse_scan_i8_kernel(CoarseI8Args a) {
+__global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(RAILS_SCAN8_WAVES, RAILS_SCAN8_WAVES))) void coarse_scan_i8_kernel(CoarseI8Args a) {
   constexpr int DC = 2 * DC8;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds[];   // bf16 fragments, int8 fragments, thr, thr_lo, integer starts
   const int d = a.d, B = a.B;
@@ -686,7 +692,7 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(RA
   const int x = lane & 31, h = lane >> 5;
   const int64_t n_tiles = (a.n + 31) >> 5;
   const int64_t gw = (int64_t)blockIdx.x * (kScanThreads / 64) + wave, n_waves = (int64_t)gridDim.x * (kScanThreads / 64);
-  constexpr int TU = DC8 == 1 ? 8 : (DC8 == 2 ? 4 : 2);   // item tiles per trip: 8 KiB of table per wave in flight
+  constexpr int TU = RAILS_SCAN8_TU / DC8;   // item tiles per trip: 8 KiB of table per wave in flight
   struct Trip { ci32x4 Bq[TU][DC8]; };
   auto load_trip = [&](int64_t w0, Trip& T) {
 #pragma unroll
@@ -784,9 +790,10 @@ static int launch_coarse_scan_i8(const CoarseI8Args& a, hipStream_t stream) {
   const size_t lds = (size_t)n_qt * (2 * dc8 * 1024 + dc8 * 1024 + 3 * 32 * 4);
   if (lds > 48 * 1024) { set_error("coarse int8 scan: batch %d x d %d does not fit LDS", a.B, a.d); return kErrUnsupported; }
   const int64_t n_tiles = (a.n + 31) >> 5;
-  const int tu = dc8 == 1 ? 8 : (dc8 == 2 ? 4 : 2);
+  const int tu = RAILS_SCAN8_TU / dc8;
   int64_t grid = (n_tiles + 4 * tu - 1) / (4 * tu);
-  if (grid > 2048) grid = 2048;
+  static const int64_t grid_cap = [] { const char* e = getenv("RAILS_SCAN8_GRID"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : (int64_t)2048; }();
+  if (grid > grid_cap) grid = grid_cap;
   if (grid < 1) return kOk;
   auto go = [&](auto nt) {
     constexpr bool NT = decltype(nt)::value;
