@@ -708,20 +708,29 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(RA
     }
   };
   // a fired tile: its rows of the bf16 table, scored from zero like the materialising path, the scores at or above the threshold appended
-  auto exact_tile = [&](int qt, int64_t tile) {
+  // Only the COLUMNS whose pre-test fired are read (`need`: this lane's item, in either half of its rows): the bound holds item by
+  // item, so the other columns of the tile cannot hold a candidate of this query tile -- 64 B of bf16 table per suspect instead of
+  // the tile's 2 KiB (the fired tiles' rows were 0.65 GB of the launch's 4.65 GB).
+  auto exact_tile = [&](int qt, int64_t tile, bool need) {
     int64_t item = tile * 32 + x;
     const bool in = item < a.n;
     if (!in) item = a.n - 1;
     const unsigned short* rowp = a.table + item * d + 8 * h;
+    bf16x8 Bu[DC];
+#pragma unroll
+    for (int c = 0; c < DC; ++c) Bu[c] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (need) {
+#pragma unroll
+      for (int c = 0; c < DC; ++c) Bu[c] = *reinterpret_cast<const bf16x8*>(rowp + 16 * c);
+    }
     cf32x16 acc = {0};
 #pragma unroll
     for (int c = 0; c < DC; ++c)
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(qfrag + (((size_t)qt * DC + c) * 64 + lane) * 8),
-                                                    *reinterpret_cast<const bf16x8*>(rowp + 16 * c), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(qfrag + (((size_t)qt * DC + c) * 64 + lane) * 8), Bu[c], acc, 0, 0, 0);
     unsigned int mask = 0u;
 #pragma unroll
     for (int r = 0; r < 16; ++r) mask |= acc[r] >= tlo_s[qt * 32 + acc_row(r, h)] ? 1u << r : 0u;
-    if (!in) mask = 0u;
+    if (!in || !need) mask = 0u;
     if (__any(mask != 0u)) {
       float* mine = acc_s + (wave * 16) * 64 + lane;
 #pragma unroll
@@ -763,18 +772,23 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(RA
         for (int c = 0; c < DC8; ++c) asm volatile("" : "+v"(T.Bq[u][c]));   // the wait for T belongs here, with N in flight (see coarse_scan_kernel)
       for (int qt = 0; qt < n_qt; ++qt) {
         if (n_qt > 1) load_query_tile(qt);
-        unsigned int fired = 0u;
+        unsigned int fired = 0u, mine = 0u;   // tiles of the trip with a suspect (wave-uniform); this lane's own suspects
 #pragma unroll
         for (int u = 0; u < TU; ++u) {
           ci32x16 acc = nb;
 #pragma unroll
           for (int c = 0; c < DC8; ++c) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(A8[c], T.Bq[u][c], acc, 0, 0, 0);
-          if (__any(any_sign_clear(__builtin_bit_cast(cf32x16, acc)))) fired |= 1u << u;
+          const bool hit = any_sign_clear(__builtin_bit_cast(cf32x16, acc));
+          if (__any(hit)) fired |= 1u << u;
+          mine |= hit ? 1u << u : 0u;
         }
-        while (fired) {   // wave-uniform; rare
-          const int u = __ffs(fired) - 1;
-          fired &= fired - 1u;
-          if (w0 + u < n_tiles) exact_tile(qt, w0 + u);
+        if (fired) {   // wave-uniform; rare
+          mine |= (unsigned int)__shfl_xor((int)mine, 32, 64);   // the other half of the column's rows
+          while (fired) {
+            const int u = __ffs(fired) - 1;
+            fired &= fired - 1u;
+            if (w0 + u < n_tiles) exact_tile(qt, w0 + u, ((mine >> u) & 1u) != 0u);
+          }
         }
       }
       if (w1 >= n_tiles) break;
