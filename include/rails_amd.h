@@ -245,7 +245,10 @@ int rails_mol_coarse_topk(const rails_mol_shape* shape, const float* eq, int32_t
  * streaming pass reads the int8 copy, one int8 MFMA per 32 items, against a per-query integer bound that no item reaching the
  * query's threshold can miss (|bf16 dot - scaled int8 dot| <= s |q|_1 / 2 + s_q max|x|_1 / 2 + 3 s s_q d / 4), and scores only the
  * tiles that pass it from the bf16 table: same candidates, same counts, same output, about half the bytes.  prefilter == NULL: the
- * pass reads the bf16 table.  d in {32, 64, 128} (rails_mol_coarse_prefilter_bytes returns 0 otherwise). */
+ * pass reads the bf16 table.  d in {32, 64, 128} (rails_mol_coarse_prefilter_bytes returns 0 otherwise).
+ * The header keeps two running uint64 statistics the calls add to: bytes 32..39 = (32-item tile, 32-query tile) blocks that passed the
+ * integer bound, bytes 40..47 = blocks tested.  A table whose single scale is set by a few outliers makes most blocks pass (the
+ * output stays exact, the pass then reads both copies): a caller that reads a ratio near 1 should pass NULL from then on. */
 size_t rails_mol_coarse_prefilter_bytes(const rails_mol_shape* shape, int64_t n_items);
 int rails_mol_coarse_prefilter_build(const rails_mol_shape* shape, const void* table, int64_t n_items, void* prefilter, void* stream);
 

@@ -563,9 +563,13 @@ static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p, b
 // pre-test as the bf16 scan -- and only the tiles that fire (a few per cent) are read from the bf16 table and scored as before, with
 // the materialising path's bits: candidates, counts and keys are exactly those of the scan without the pre-filter.  HBM bytes per
 // batch: N d (+ 2d per item of a fired tile) instead of 2 N d.
-// The buffer: 256 bytes of header [scale, 127 / max|x|, max_x |x|_1] then N * d int8, item-major like the table.
+// The buffer: 256 bytes of header [scale, 127 / max|x|, max_x |x|_1, ..., fired, scanned] then N * d int8, item-major like the table.
 constexpr size_t kPrefilterHeader = 256;
-struct PrefilterHeader { float scale, inv_scale, x1max; unsigned int maxabs_bits, x1max_bits; };
+struct PrefilterHeader {
+  float scale, inv_scale, x1max; unsigned int maxabs_bits, x1max_bits; unsigned int pad[3];
+  unsigned long long fired, scanned;   // byte 32 / 40: (tile, query tile) blocks that fired / were tested, summed over the select scans so far --
+};                                     // a caller that sees most of them fire (a table whose scale is set by a few outliers) drops the pre-filter
+static_assert(sizeof(PrefilterHeader) <= 256 && offsetof(PrefilterHeader, fired) == 32, "header layout (include/rails_amd.h)");
 
 __global__ void prefilter_stats_kernel(const unsigned short* __restrict__ table, int64_t n, int d, PrefilterHeader* hdr) {
   const int64_t item = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -652,7 +656,7 @@ __device__ __forceinline__ void quantise_query(const unsigned short* qfrag, int 
 
 struct CoarseI8Args {
   const unsigned short* qfrag; const signed char* q8; const float* qmeta;   // made by the sample scan's workgroup 0
-  const unsigned short* table; const signed char* table8; const PrefilterHeader* hdr; int64_t n; int B, d;
+  const unsigned short* table; const signed char* table8; PrefilterHeader* hdr; int64_t n; int B, d;
   const float* thr; int64_t thr_stride;
   unsigned long long* keys; int cap; unsigned int* counts;
 };
@@ -758,6 +762,7 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(RA
     for (int r = 0; r < 16; ++r) nb[r] = nb_s[qt * 32 + acc_row(r, h)];
   };
   load_query_tile(0);
+  unsigned int n_fired = 0u;
   int64_t w0 = gw * TU;
   if (w0 < n_tiles) {
     const int64_t hop = n_waves * TU;
@@ -784,6 +789,7 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(RA
         }
         if (fired) {   // wave-uniform; rare
           mine |= (unsigned int)__shfl_xor((int)mine, 32, 64);   // the other half of the column's rows
+          n_fired += (unsigned int)__popc(fired);
           while (fired) {
             const int u = __ffs(fired) - 1;
             fired &= fired - 1u;
@@ -797,6 +803,8 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(RA
     }
   }
   stage_flush_mixed(stage_s[wave], &stage_n[wave], lane, a.keys, a.counts, a.cap, 1u);
+  if (lane == 0 && n_fired) atomicAdd(&a.hdr->fired, (unsigned long long)n_fired);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.hdr->scanned, (unsigned long long)(n_tiles * n_qt));
 }
 
 static int launch_coarse_scan_i8(const CoarseI8Args& a, hipStream_t stream) {
@@ -872,7 +880,7 @@ int coarse_topk(const Shape& s, const float* eq, int B, int avg, const void* tab
   if (prefilter) {   // the select scan over the int8 copy of the table; fired tiles are scored from the bf16 table
     CoarseI8Args i8{};
     i8.qfrag = frag; i8.q8 = q8; i8.qmeta = qmeta;
-    i8.table = static_cast<const unsigned short*>(table); i8.hdr = static_cast<const PrefilterHeader*>(prefilter);
+    i8.table = static_cast<const unsigned short*>(table); i8.hdr = static_cast<PrefilterHeader*>(const_cast<void*>(prefilter));   // the header's two statistics words are updated
     i8.table8 = static_cast<const signed char*>(prefilter) + kPrefilterHeader; i8.n = n; i8.B = B; i8.d = a.d;
     i8.thr = top_s + (p.r - 1); i8.thr_stride = p.r; i8.keys = keys; i8.cap = p.cap; i8.counts = counts;
     rc = launch_coarse_scan_i8(i8, stream);

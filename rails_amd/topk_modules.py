@@ -614,9 +614,29 @@ class MoLAvgTopK(MoLTopKModule):
             self._coarse_prefilter = eng.build_coarse_prefilter(self._coarse_table) if self._coarse_table.shape[0] >= self.PREFILTER_MIN_ITEMS else None
         return self._coarse_table
 
+    PREFILTER_MAX_FIRED = 0.35        # fraction of (tile, query tile) blocks passing the integer bound beyond which the copy is dropped
+    PREFILTER_CHECK_CALLS = (2, 64)   # the header's statistics are read (16 bytes, one sync) after this many calls, then every so many
+
     def _prefilter(self) -> Optional[torch.Tensor]:
         self._table()
-        return self._coarse_prefilter
+        pre = self._coarse_prefilter
+        if pre is not None:
+            # a table whose one scale is set by a few outliers makes most tiles pass the bound: still exact, but the pass then reads
+            # both copies.  The select scans keep (fired, tested) counts in the header; looked at now and then
+            self._prefilter_calls = getattr(self, "_prefilter_calls", 0) + 1
+            first, every = self.PREFILTER_CHECK_CALLS
+            if self._prefilter_calls == first + 1 or self._prefilter_calls % every == 0:
+                fired, tested = (int(v) for v in pre[32:48].view(torch.int64).cpu())
+                if tested > 0 and fired > self.PREFILTER_MAX_FIRED * tested:
+                    self._coarse_prefilter = pre = None
+        return pre
+
+    def prefilter_stats(self) -> Optional[dict]:
+        """(tile, query tile) blocks of the int8 select scans so far: how many passed the integer bound, how many were tested."""
+        if self._coarse_prefilter is None:
+            return None
+        fired, tested = (int(v) for v in self._coarse_prefilter[32:48].view(torch.int64).cpu())
+        return {"fired": fired, "tested": tested, "fraction": fired / tested if tested else 0.0}
 
     def _coarse_topk(self, query_embeddings: torch.Tensor, average_queries: bool, pending: Optional[list] = None, **kwargs):
         eng = self._bind()

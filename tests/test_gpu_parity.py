@@ -591,6 +591,38 @@ def test_avg_topk_module_with_the_int8_prefilter(dev, monkeypatch):
             assert torch.equal(s1, s2) and torch.equal(i1, i2) and torch.equal(s1, s3) and torch.equal(i1, i3)
 
 
+def test_avg_topk_drops_a_prefilter_that_filters_nothing(dev, monkeypatch):
+    """The select scans count, in the pre-filter's header, the (tile, query tile) blocks that passed the integer bound.  On an
+    ordinary table few do and the module keeps the int8 copy; with one item 1 000 x larger than the rest the single scale crushes
+    the others, every block passes, and the module drops the copy after its second call -- outputs unchanged throughout."""
+    monkeypatch.setattr(rails_amd.MoLAvgTopK, "PREFILTER_MIN_ITEMS", 1)
+    cfg = O.CONFIGS["amzn-books"]
+    mol = build_module(cfg, O.synthetic_weights(cfg, seed=2), dev)
+    n = 300_000
+    X = torch.from_numpy(O.hash_item_table(5, 0, n, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    q = O.synthetic_queries(cfg, 4, seed=4).to(dev)     # few queries, small K': ~4 K' B = 800 candidates over 9 375 tiles
+    with torch.inference_mode():
+        a = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=20)
+        outs = [a(q, k=20) for _ in range(4)]
+        st = a.prefilter_stats()
+        assert st is not None and st["tested"] > 0 and st["fraction"] < 0.35, st
+        b = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=20)
+        eng = b._bind()
+        b._table()[4321] *= 1000.0                                   # an outlier row sets the scale of the whole int8 copy
+        b._coarse_prefilter = eng.build_coarse_prefilter(b._table())
+        outs_b = [b(q, k=20) for _ in range(4)]
+        assert b._coarse_prefilter is None                           # dropped after the statistics were read
+        b2 = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=20)
+        b2._table()[4321] *= 1000.0
+        b2._coarse_prefilter = None
+        want = b2(q, k=20)
+        for o in outs_b:
+            assert torch.equal(o[0], want[0]) and torch.equal(o[1], want[1])
+        for o in outs[1:]:
+            assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+
+
 def test_fused_coarse_topk_raises_its_flag_exactly_when_a_count_is_out_of_range(dev):
     """ABI 6: rails_mol_coarse_topk reports `out_of_range` from inside its key-selection launch -- 0 on an ordinary corpus (and
     the counts in range), 1 on the heavy-ties corpus (a sub-list overflowed), 1 when fewer than K' candidates reach the threshold
