@@ -913,8 +913,11 @@ static bool two_level_plan_at(int64_t n, int k, int64_t max_chunk, int* chunks, 
   if (n - (int64_t)(*chunks - 1) * len < k) return false;
   return true;
 }
-static bool two_level_plan(int64_t n, int k, int* chunks, int64_t* chunk, int rows = 1 << 30) {
-  if (k > kRowFastK) return false;
+// max_k: kRowFastK for ordinary calls -- beyond it the multi-launch radix path is faster (32 x 695 762, k = 1 000: 111 vs 186 us) --
+// and kRowMaxK for calls under a launch predicate: those are the fallbacks behind a device-side verdict, no-ops in the common case,
+// where what counts is how many launches they are (2 instead of 10: ~40 us of every MoLAvgTopK call with K' >= 1 000 at amzn-books size)
+static bool two_level_plan(int64_t n, int k, int* chunks, int64_t* chunk, int rows = 1 << 30, int max_k = 512) {
+  if (k > max_k) return false;
   // first-level chunk size: RAILS_ROW_CHUNK (measurement override), else the largest a workgroup holds in registers -- half of that
   // for up to eight rows, where 49 152-element chunks leave most of the chip idle (695 762 elements: 1 row 29 -> 27 us, 4 rows
   // 37 -> 31, 8 rows 37 -> 32; from 32 rows on smaller chunks only add second-level work: 63 -> 75 us).  A plan that does not work
@@ -992,7 +995,7 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
       return launch_row_select<false>(a, rows, 1, (int)n, stream);
     }
     int chunks; int64_t chunk;
-    if (two_level_plan(n, k, &chunks, &chunk, rows)) {   // two launches: per-chunk winners, then the winners' winners
+    if (two_level_plan(n, k, &chunks, &chunk, rows, pred ? kRowMaxK : kRowFastK)) {   // two launches: per-chunk winners, then the winners' winners
       if (ws_bytes < topk_workspace_bytes(rows, n, k)) { set_error("top-k workspace too small"); return kErrNoMem; }
       unsigned long long* lvl1 = static_cast<unsigned long long*>(ws);
       a.chunk = chunk; a.keys_out = lvl1;

@@ -673,6 +673,24 @@ def test_topk_candidates_equals_topk_over_gathered_ids(dev, rows, n, k):
     assert torch.equal(gs, ws) and torch.equal(gp, torch.gather(pos, 1, E.topk(scores, k)[1]))
 
 
+@pytest.mark.parametrize("n,k", [(300_000, 1000), (695_762, 1600), (120_000, 4096), (60_000, 600)])
+def test_predicated_topk_takes_the_two_launch_route_and_equals_the_plain_call(dev, n, k):
+    """rails_topk under a launch predicate (the fallback behind a device-side verdict) selects k > 512 of a long row in two launches
+    (per-chunk winners through the radix core, then the winners' winners) where the plain call takes the multi-launch radix path:
+    predicate 1 -> the plain call's output, ties by position included; predicate 0 -> the outputs are left alone."""
+    g = torch.Generator().manual_seed(n + k)
+    scores = (torch.randint(0, 3000, (5, n), generator=g).float() / 64.0).to(dev)      # many exact ties around the k-th place
+    want_s, want_i = E.topk(scores, k)
+    out_s = torch.full((5, k), -7.0, dtype=torch.float32, device=dev)
+    out_i = torch.full((5, k), -7, dtype=torch.int64, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    E.topk(scores, k, out=(out_s, out_i), run_if=flag)
+    assert bool((out_s == -7.0).all()) and bool((out_i == -7).all())
+    flag.fill_(1)
+    E.topk(scores, k, out=(out_s, out_i), run_if=flag)
+    assert torch.equal(out_s, want_s) and torch.equal(out_i, want_i)
+
+
 @pytest.mark.parametrize("n,k", [(513, 1), (600, 120), (1000, 120), (1024, 512), (777, 512), (1000, 513)])
 def test_topk_between_512_and_1024_columns(dev, n, k):
     """Rows of 513 .. 1 024 scores with k <= 512 take the register-resident selection (they were fully sorted before): the same
