@@ -23,6 +23,8 @@ from __future__ import annotations
 
 from typing import Callable, Optional, Tuple
 
+import contextlib
+
 import torch
 import torch.distributed as dist
 
@@ -93,7 +95,12 @@ class ShardedTopK(TopKModule):
         self._xstream = None     # exchange stream (all-gather + merge), created on first GPU use
 
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
-        return self.result(self.submit(query_embeddings, k, sorted, **kwargs))
+        with self._inline():     # a plain call has no neighbouring batch to overlap with (MoLAvgTopK.submit)
+            return self.result(self.submit(query_embeddings, k, sorted, **kwargs))
+
+    def _inline(self):
+        local = getattr(self, "_local_module", None)
+        return local.inline_calls() if hasattr(local, "inline_calls") else contextlib.nullcontext()
 
     # ---- two-stage form of forward: submit() enqueues this rank's part, result() the exchange ------------------------------
     # A caller that has the next batch at hand calls submit(batch i+1) BEFORE result(batch i): the all-gather and the merge of
@@ -111,6 +118,10 @@ class ShardedTopK(TopKModule):
             s, ids = spec[1], spec[2]
             if spec[0] == "final":
                 spec = None
+            elif self._world > 1 and s.is_cuda and isinstance(spec[-1], torch.cuda.Stream):
+                # the local call ran on a stream of its own and the pack below reads its output here: join it now (with one shard
+                # nothing reads it before result(), and batches overlap)
+                torch.cuda.current_stream(s.device).wait_event(spec[4])
         elif k_local > 0:
             s, ids = self._local_topk(query_embeddings, k_local, **kwargs)
         else:  # an empty shard still takes part in the collective
@@ -136,7 +147,8 @@ class ShardedTopK(TopKModule):
             return local.forward_filtered(query_embeddings, k_prime, invalid_ids, k, **kwargs) if hasattr(local, "forward_filtered") else None
         if not (query_embeddings.is_cuda and self._merge is _hip_merge and E.merge_filter_fusable(k_prime, invalid_ids.shape[1], k)) or k_prime > self._n_total:
             return None
-        return self.result(self.submit(query_embeddings, k_prime, **kwargs), seen=(invalid_ids, k))
+        with self._inline():
+            return self.result(self.submit(query_embeddings, k_prime, **kwargs), seen=(invalid_ids, k))
 
     def result(self, handle, seen=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """All-gather of the per-shard candidates + merge -> (scores, ids), identical on every rank.  On the GPU both run on this

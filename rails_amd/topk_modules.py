@@ -18,6 +18,8 @@ from typing import Dict, Optional, Tuple
 
 import math
 
+import contextlib
+
 import torch
 
 from . import engine as E
@@ -603,7 +605,10 @@ class MoLAvgTopK(MoLTopKModule):
         self._coarse_table = None
         self._coarse_prefilter = None
         self._verdict_pool: list = []
+        self._side_streams = None
+        self._side_turn = 0
 
+    OVERLAP_BATCHES = True            # submit(): speculative calls alternate between two streams of the module (see submit)
     PREFILTER_MIN_ITEMS = 4_000_000   # the int8 copy of the coarse table pays where the streaming pass is bound by HBM reads
 
     def _table(self) -> torch.Tensor:
@@ -712,26 +717,50 @@ class MoLAvgTopK(MoLTopKModule):
     def submit(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs):
         if k > self._avg_top_k:  # the reference raises after doing the work (mol_top_k.py:383-386)
             raise ValueError(f"avg_top_k ({self._avg_top_k}) must be larger than k ({k})")
+        # Calls that will be speculative (the (B, N) redo buffer does not fit: large shards) alternate between two streams of the
+        # module's own: the latency-bound launches of one batch (prologue, sample, threshold, key selection, rerank: ~0.15 ms of
+        # a 0.85 ms call on a 125 M-item shard) then run under the table scan of the neighbouring batch.  The caller's stream joins
+        # a call's stream in result().  Calls that share the module's redo buffers (small corpora) stay on the caller's stream.
+        side = None
+        if self.OVERLAP_BATCHES and query_embeddings.is_cuda and query_embeddings.size(0) * self.num_items * 4 > self.DEVICE_REDO_BYTES:
+            if self._side_streams is None:
+                self._side_streams = [torch.cuda.Stream(query_embeddings.device), torch.cuda.Stream(query_embeddings.device)]
+            side = self._side_streams[self._side_turn]
+            self._side_turn ^= 1
+            side.wait_stream(torch.cuda.current_stream(query_embeddings.device))     # the inputs are ready where the caller stands
+            query_embeddings.record_stream(side)
         pending: list = []
-        scores, ids = self._enqueue(query_embeddings, k, pending, **kwargs)
-        if not pending:
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            scores, ids = self._enqueue(query_embeddings, k, pending, **kwargs)
+            if not pending:
+                host = None
+            else:
+                pool = self._verdict_pool      # pinned words go back to the pool in result(): no host allocation per call
+                host = pool.pop() if pool and pool[-1].numel() == len(pending) else torch.empty(len(pending), dtype=torch.int32, pin_memory=True)
+                for j, bad in enumerate(pending):
+                    host[j : j + 1].copy_(bad, non_blocking=True)
+            done = torch.cuda.Event() if (pending or side is not None) else None
+            if done is not None:
+                done.record()
+        if not pending and side is None:
             return ("final", scores, ids)
-        pool = self._verdict_pool      # pinned words go back to the pool in result(): no host allocation per call
-        host = pool.pop() if pool and pool[-1].numel() == len(pending) else torch.empty(len(pending), dtype=torch.int32, pin_memory=True)
-        for j, bad in enumerate(pending):
-            host[j : j + 1].copy_(bad, non_blocking=True)
-        done = torch.cuda.Event()
-        done.record()
-        return ("speculative", scores, ids, host, done, query_embeddings, k, kwargs)
+        return ("speculative", scores, ids, host, done, query_embeddings, k, kwargs, side)
 
     def result(self, handle) -> Tuple[torch.Tensor, torch.Tensor]:
         if handle[0] == "final":
             return handle[1], handle[2]
-        _, scores, ids, host, done, query_embeddings, k, kwargs = handle
-        done.synchronize()
-        redo = int(host.max()) != 0
-        if len(self._verdict_pool) < 8:
-            self._verdict_pool.append(host)
+        _, scores, ids, host, done, query_embeddings, k, kwargs, side = handle
+        if side is not None:           # the caller's stream takes over the outputs
+            cur = torch.cuda.current_stream(scores.device)
+            cur.wait_event(done)
+            scores.record_stream(cur)
+            ids.record_stream(cur)
+        redo = False
+        if host is not None:
+            done.synchronize()
+            redo = int(host.max()) != 0
+            if len(self._verdict_pool) < 8:
+                self._verdict_pool.append(host)
         if not redo:
             return scores, ids
         self._no_fused = True      # redo this call on the materialising path
@@ -741,7 +770,18 @@ class MoLAvgTopK(MoLTopKModule):
             self._no_fused = False
 
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
-        return self.result(self.submit(query_embeddings, k, sorted, **kwargs))
+        with self.inline_calls():      # nothing to overlap with: stay on the caller's stream (the hand-over between streams costs ~50 us)
+            return self.result(self.submit(query_embeddings, k, sorted, **kwargs))
+
+    @contextlib.contextmanager
+    def inline_calls(self):
+        """submit() inside this block stays on the caller's stream (what a plain forward wants)."""
+        saved = self.OVERLAP_BATCHES
+        self.OVERLAP_BATCHES = False
+        try:
+            yield
+        finally:
+            self.OVERLAP_BATCHES = saved
 
     def coarse_candidates(self, query_embeddings: torch.Tensor, **kwargs):
         """Pass 1 on this module's items: -> (coarse scores (B, K'), positions (B, K')), best first (ties by position)."""
