@@ -729,6 +729,9 @@ class MoLAvgTopK(MoLTopKModule):
             self._side_turn ^= 1
             side.wait_stream(torch.cuda.current_stream(query_embeddings.device))     # the inputs are ready where the caller stands
             query_embeddings.record_stream(side)
+            for v in kwargs.values():          # user_ids and the like: read on the call's stream after the caller may have let go of them
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(side)
         pending: list = []
         with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
             scores, ids = self._enqueue(query_embeddings, k, pending, **kwargs)
