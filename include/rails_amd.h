@@ -239,7 +239,7 @@ size_t rails_mol_coarse_topk_workspace_bytes(const rails_mol_shape* shape, int32
 int rails_mol_coarse_topk(const rails_mol_shape* shape, const float* eq, int32_t batch, int32_t average_queries,
                           const void* table, int64_t n_items, int32_t k_prime, void* workspace, size_t workspace_bytes,
                           float* out_scores, int64_t* out_positions, int32_t* out_counts, int32_t* out_of_range,
-                          const void* prefilter, void* stream);
+                          void* prefilter, void* stream);
 /* Optional int8 pre-filter of rails_mol_coarse_topk's streaming pass (no counterpart in the reference; it changes what the pass
  * READS, not what it returns): a copy of the coarse table as int8 with one scale (256-byte header + d bytes per item).  With it the
  * streaming pass reads the int8 copy, one int8 MFMA per 32 items, against a per-query integer bound that no item reaching the

@@ -445,7 +445,7 @@ size_t rails_mol_coarse_topk_workspace_bytes(const rails_mol_shape* s, int32_t b
 
 int rails_mol_coarse_topk(const rails_mol_shape* s, const float* eq, int32_t batch, int32_t average_queries, const void* table,
                           int64_t n_items, int32_t k_prime, void* workspace, size_t workspace_bytes, float* out_scores,
-                          int64_t* out_positions, int32_t* out_counts, int32_t* out_of_range, const void* prefilter, void* stream) {
+                          int64_t* out_positions, int32_t* out_counts, int32_t* out_of_range, void* prefilter, void* stream) {
   g_err[0] = '\0';
   if (!shape_ok(s)) return RAILS_EINVAL;
   if (batch < 0 || n_items < 0 || k_prime < 0) { set_error("coarse_topk: negative size"); return RAILS_EINVAL; }

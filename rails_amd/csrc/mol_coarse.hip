@@ -848,7 +848,7 @@ int range_flag(const int32_t* v, int n, int lo, int hi, int32_t* flag, hipStream
 }
 
 int coarse_topk(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, int k_prime, void* ws,
-                size_t ws_bytes, float* out_scores, int64_t* out_pos, int32_t* out_counts, int32_t* out_flag, const void* prefilter, int n_cu,
+                size_t ws_bytes, float* out_scores, int64_t* out_pos, int32_t* out_counts, int32_t* out_flag, void* prefilter, int n_cu,
                 hipStream_t stream) {
   CoarseTopkPlan p;
   if (!coarse_topk_plan(B, n, k_prime, &p, true)) { set_error("coarse_topk: unsupported size (B = %d, K' = %d, n = %lld)", B, k_prime, (long long)n); return kErrUnsupported; }
@@ -880,7 +880,7 @@ int coarse_topk(const Shape& s, const float* eq, int B, int avg, const void* tab
   if (prefilter) {   // the select scan over the int8 copy of the table; fired tiles are scored from the bf16 table
     CoarseI8Args i8{};
     i8.qfrag = frag; i8.q8 = q8; i8.qmeta = qmeta;
-    i8.table = static_cast<const unsigned short*>(table); i8.hdr = static_cast<PrefilterHeader*>(const_cast<void*>(prefilter));   // the header's two statistics words are updated
+    i8.table = static_cast<const unsigned short*>(table); i8.hdr = static_cast<PrefilterHeader*>(prefilter);   // the header's two statistics words are updated
     i8.table8 = static_cast<const signed char*>(prefilter) + kPrefilterHeader; i8.n = n; i8.B = B; i8.d = a.d;
     i8.thr = top_s + (p.r - 1); i8.thr_stride = p.r; i8.keys = keys; i8.cap = p.cap; i8.counts = counts;
     rc = launch_coarse_scan_i8(i8, stream);
