@@ -776,6 +776,18 @@ class MoLAvgTopK(MoLTopKModule):
         with self.inline_calls():      # nothing to overlap with: stay on the caller's stream (the hand-over between streams costs ~50 us)
             return self.result(self.submit(query_embeddings, k, sorted, **kwargs))
 
+    def forward_filtered(self, query_embeddings: torch.Tensor, k_prime: int, invalid_ids: torch.Tensor, k: int, **kwargs):
+        """CandidateIndex.get_top_k_outputs' body: forward(k_prime) + the seen-id filter, with the filter enqueued BEFORE the host looks
+        at the scan's verdict word (it then runs while the host is on its way back) -> (top_k_ids, top_k_scores); None where this
+        does not apply (subclasses with their own forward, k_prime beyond K': the caller composes the two calls)."""
+        if type(self).forward is not MoLAvgTopK.forward or k_prime > self._avg_top_k or k_prime < k:
+            return None
+        with self.inline_calls():
+            h = self.submit(query_embeddings, k_prime, **kwargs)
+        out = E.filter_seen_ids(h[2], h[1], invalid_ids, k)
+        scores, ids = self.result(h)
+        return out if scores is h[1] else E.filter_seen_ids(ids, scores, invalid_ids, k)
+
     @contextlib.contextmanager
     def inline_calls(self):
         """submit() inside this block stays on the caller's stream (what a plain forward wants)."""

@@ -591,6 +591,32 @@ def test_avg_topk_module_with_the_int8_prefilter(dev, monkeypatch):
             assert torch.equal(s1, s2) and torch.equal(i1, i2) and torch.equal(s1, s3) and torch.equal(i1, i3)
 
 
+@pytest.mark.parametrize("tied", [False, True])
+def test_avg_topk_with_the_filter_enqueued_before_the_verdict_is_read(dev, tied, monkeypatch):
+    """CandidateIndex.get_top_k_outputs through MoLAvgTopK.forward_filtered (the seen-id filter enqueued on the speculative output,
+    redone if the scan's verdict says so) == forward + filter_seen_ids, on an ordinary corpus and on the heavy-ties one."""
+    monkeypatch.setattr(rails_amd.MoLAvgTopK, "DEVICE_REDO_BYTES", 0)
+    cfg = O.CONFIGS["amzn-books"]
+    mol = build_module(cfg, O.synthetic_weights(cfg, seed=2), dev)
+    n = 300_000
+    base = torch.from_numpy(O.hash_item_table(6, 0, n, cfg.item_embedding_dim))
+    X = (base[torch.arange(n) % 40] if tied else base).unsqueeze(0).to(dev)
+    ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    q = O.synthetic_queries(cfg, 8, seed=4).to(dev)
+    with torch.inference_mode():
+        at = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=200)
+        cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)
+        s0, i0 = at(q, k=60)
+        inv = torch.zeros((8, 21), dtype=torch.int64, device=dev)
+        inv[:, :10] = i0[:, 5:15]
+        got_i, got_s, _ = cand.get_top_k_outputs(q, 40, {}, at, inv)
+        want_i, want_s = E.filter_seen_ids(*reversed(at(q, k=61)), inv, 40)
+        assert torch.equal(got_i, want_i) and torch.equal(got_s, want_s)
+        assert at.forward_filtered(q, 61, inv, 40) is not None
+        comb = rails_amd.MoLCombTopK(mol, X, ids, avg_top_k=200, k_per_group=5)
+        assert comb.forward_filtered(q, 61, inv, 40) is None       # its forward is its own
+
+
 def test_avg_topk_drops_a_prefilter_that_filters_nothing(dev, monkeypatch):
     """The select scans count, in the pre-filter's header, the (tile, query tile) blocks that passed the integer bound.  On an
     ordinary table few do and the module keeps the int8 copy; with one item 1 000 x larger than the rest the single scale crushes
