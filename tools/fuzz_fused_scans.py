@@ -40,6 +40,17 @@ for case in range(24):
         out_of_range += not in_range
         if in_range and not (torch.equal(fs, rs) and torch.equal(fp, rp)):
             bad += 1; print("COARSE MISMATCH", name, n, B, kp, avg)
+        # the int8 pre-filter of the streaming pass, on the table as it is and on a copy whose rows are rescaled at random (x 1e-3 .. 1e3,
+        # a few rows x 1e4: the single scale then serves some rows badly): same candidates, counts and output
+        for tbl in (at._table(), (at._table().float() * torch.pow(10.0, torch.randint(-3, 4, (at._table().shape[0], 1), device=dev).float())).to(torch.bfloat16)):
+            pre = eng.build_coarse_prefilter(tbl)
+            if pre is None:
+                continue
+            a0, b0, c0 = eng.coarse_topk(eq, tbl, avg, kp)
+            a1, b1, c1 = eng.coarse_topk(eq, tbl, avg, kp, prefilter=pre)
+            ok_rows = (c0 >= kp) & (c0 <= eng.coarse_topk_capacity(kp))
+            if not torch.equal(c0, c1) or not (torch.equal(a0[ok_rows], a1[ok_rows]) and torch.equal(b0[ok_rows], b1[ok_rows])):
+                bad += 1; print("PREFILTER MISMATCH", name, n, B, kp, avg)
         if B <= 16 and case % 3 == 0:
             nt = rails_amd.MoLNaiveTopK(mol, X, ids, k_per_group=5)
             kg = random.choice([1, 5, 50, 100])
