@@ -45,6 +45,7 @@ class MoLTopKModule(TopKModule):
         self._item_ids: torch.Tensor = item_ids
         self._ids_flat: torch.Tensor = item_ids.reshape(-1).to(device=item_embeddings.device, dtype=torch.int64).contiguous()
         self._engine: Optional[E.MolEngine] = None
+        self._call_eng: Optional[E.MolEngine] = None
         self._index: Optional[E.MolIndex] = None
         self._scratch: Dict[tuple, torch.Tensor] = {}   # internal buffers recycled across calls (never returned)
         self._bind()
@@ -68,11 +69,25 @@ class MoLTopKModule(TopKModule):
         return self._item_embeddings.shape[1]
 
     def _bind(self) -> E.MolEngine:
+        if self._call_eng is not None:   # inside one_bind(): the parameters were checked when the call began
+            return self._call_eng
         eng = self._mol_module.engine()
         if eng is not self._engine:  # first use, or the module's parameters changed
             self._engine = eng
             self._index = eng.build_index(self._item_embeddings[0])
         return eng
+
+    @contextlib.contextmanager
+    def one_bind(self):
+        """One look at the module's parameters for a whole call: `engine()` compares 2 x 48 (pointer, version) pairs, ~10 us, and a
+        two-pass call asks for the engine six times -- host time that sits between the batches of a plain loop."""
+        outer = self._call_eng
+        if outer is None:
+            self._call_eng = self._bind()
+        try:
+            yield
+        finally:
+            self._call_eng = outer
 
     def all_logits(self, query_embeddings: torch.Tensor, **kwargs) -> torch.Tensor:
         """(B, N) fp32 MoL logits against the whole corpus."""
@@ -696,15 +711,17 @@ class MoLAvgTopK(MoLTopKModule):
 
     def _enqueue(self, query_embeddings: torch.Tensor, k: int, pending: list, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
         """One pass of forward's launches; the device verdicts of the fused scan (int32 words, 1 = redo) are appended to `pending`."""
-        # the reference's four profiler spans (mol_top_k.py:350-382), around the launches that do the same work here
-        with torch.profiler.record_function("avg_top_k_scoring"):
+        # the reference's four profiler spans (mol_top_k.py:350-382), around the launches that do the same work here (entered only
+        # under a profiler: a span costs ~9 us of host time, four of them more than the GPU needs for the launches they bracket)
+        span = torch.profiler.record_function if torch.autograd._profiler_enabled() else (lambda name: contextlib.nullcontext())
+        with span("avg_top_k_scoring"):
             qpack, idx = self._coarse_topk(query_embeddings, average_queries=False, pending=pending, **kwargs)
         eng = self._bind()
-        with torch.profiler.record_function("avg_topk_selection"):
+        with span("avg_topk_selection"):
             pass    # the reference gathers the candidates' embeddings here; they are read in place by the scoring launch below
-        with torch.profiler.record_function("filtered_scoring"):
+        with span("filtered_scoring"):
             cand_scores = self._score_at(eng, qpack, query_embeddings.size(0), idx)
-        with torch.profiler.record_function("final_topk"):
+        with span("final_topk"):
             scores, ids = E.topk_candidates(cand_scores, min(k, idx.shape[1]), idx, self._ids_flat)   # top-k + gather + id lookup, one launch
         return scores.to(query_embeddings.dtype), ids
 
@@ -733,7 +750,7 @@ class MoLAvgTopK(MoLTopKModule):
                 if torch.is_tensor(v) and v.is_cuda:
                     v.record_stream(side)
         pending: list = []
-        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+        with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()), self.one_bind():
             scores, ids = self._enqueue(query_embeddings, k, pending, **kwargs)
             if not pending:
                 host = None
