@@ -1021,6 +1021,11 @@ class CandidateIndex(object):
         truncate_k_prime_to: Optional[int] = None,
     ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
         """-> (top_k_ids (B, k), top_k_scores (B, k), None).  Note: ids first, as in the reference."""
+        bind = getattr(getattr(top_k_module, "_local_module", top_k_module), "one_bind", None)
+        with bind() if bind is not None else contextlib.nullcontext():     # one look at the model's parameters per call (MoLTopKModule.one_bind)
+            return self._get_top_k_outputs(query_embeddings, k, aux_payloads, top_k_module, invalid_ids, r, return_embeddings, truncate_k_prime_to)
+
+    def _get_top_k_outputs(self, query_embeddings, k, aux_payloads, top_k_module, invalid_ids, r, return_embeddings, truncate_k_prime_to):
         if return_embeddings:
             # the reference's own branch is broken (undefined `top_k_indices`, candidate_index.py:182)
             raise NotImplementedError("return_embeddings=True is not supported")
