@@ -617,6 +617,35 @@ def test_avg_topk_with_the_filter_enqueued_before_the_verdict_is_read(dev, tied,
         assert comb.forward_filtered(q, 61, inv, 40) is None       # its forward is its own
 
 
+def test_avg_topk_many_batches_in_flight_on_alternating_streams(dev, monkeypatch):
+    """Forty different batches through submit / result with two or three of them in flight (speculative calls alternate between
+    two streams of the module; their workspaces, outputs and verdict words are recycled by the caching allocators): every result
+    equals the plain forward of its own batch -- also when the results are taken out of submission order."""
+    monkeypatch.setattr(rails_amd.MoLAvgTopK, "DEVICE_REDO_BYTES", 0)
+    monkeypatch.setattr(rails_amd.MoLAvgTopK, "PREFILTER_MIN_ITEMS", 1)
+    cfg = O.CONFIGS["amzn-books"]
+    mol = build_module(cfg, O.synthetic_weights(cfg, seed=2), dev)
+    n = 400_000
+    X = torch.from_numpy(O.hash_item_table(5, 0, n, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    with torch.inference_mode():
+        at = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=60)
+        batches = [O.synthetic_queries(cfg, 3 + (i % 5), seed=100 + i).to(dev) for i in range(40)]
+        want = [at(q, k=20) for q in batches]
+        handles, got = [], {}
+        for i, q in enumerate(batches):
+            handles.append((i, at.submit(q.clone(), 20)))       # the clone is dropped right away: the call's stream must keep it alive
+            if len(handles) == 3:
+                j, h = handles.pop(1 if i % 2 else 0)            # not always the oldest
+                got[j] = at.result(h)
+            junk = torch.randn(1 << 20, device=dev)              # allocator churn on the caller's stream
+            del junk
+        for j, h in handles:
+            got[j] = at.result(h)
+        for i in range(40):
+            assert torch.equal(got[i][0], want[i][0]) and torch.equal(got[i][1], want[i][1]), i
+
+
 def test_avg_topk_drops_a_prefilter_that_filters_nothing(dev, monkeypatch):
     """The select scans count, in the pre-filter's header, the (tile, query tile) blocks that passed the integer bound.  On an
     ordinary table few do and the module keeps the int8 copy; with one item 1 000 x larger than the rest the single scale crushes
