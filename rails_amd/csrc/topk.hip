@@ -1095,6 +1095,17 @@ __global__ __launch_bounds__(kRowThreads) void sublist_select_kernel(const SubSe
   radix_init<kRowThreads>(rsh);
   if (tid == 0) cursor = 0u;
   for (int i = tid; i < npad; i += kRowThreads) skeys[i] = 0ull;
+  // every slot is requested now, next to the counts (one round trip to memory instead of two); the slots beyond a sub-list's count
+  // hold leftovers of earlier calls and are masked below
+  unsigned long long raw[VPT];
+  {
+    const unsigned long long* src0 = a.keys + (int64_t)row * a.cap;
+#pragma unroll
+    for (int j = 0; j < VPT; ++j) {
+      const int i = j * kRowThreads + tid;
+      raw[j] = i < a.cap ? src0[i] : 0ull;
+    }
+  }
   __syncthreads();
   unsigned int total = 0u, held = 0u;
   bool over = false;
@@ -1110,13 +1121,12 @@ __global__ __launch_bounds__(kRowThreads) void sublist_select_kernel(const SubSe
   }
   const unsigned int want = held < (unsigned int)k ? held : (unsigned int)k;   // < k only on rows the caller redoes
   unsigned int khi[VPT], klo[VPT];
-  const unsigned long long* src = a.keys + (int64_t)row * a.cap;
 #pragma unroll
   for (int j = 0; j < VPT; ++j) {
     const int i = j * kRowThreads + tid;
     const int sub = i / subcap;
     const bool filled = i < a.cap && (unsigned int)(i - sub * subcap) < cnt_s[sub < a.n_sub ? sub : 0];
-    const unsigned long long kv = filled ? src[i] : 0ull;
+    const unsigned long long kv = filled ? raw[j] : 0ull;
     khi[j] = (unsigned int)(kv >> 32);
     klo[j] = (unsigned int)kv;
   }
