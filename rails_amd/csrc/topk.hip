@@ -855,7 +855,7 @@ __global__ __launch_bounds__(kRowThreads) void row_select_kernel(const RowSelect
   }
 
   // the k-th largest 64-bit key (score, then lowest position first) by MSD radix selection over the registers (radix_select above;
-  // the two-bits-per-step bisection it replaced: n = 3 200, k = 3 200 66.7 -> see profiles/README.md)
+  // the two-bits-per-step bisection it replaced: 32 rows, k = 1 000 of 3 200 40 -> 28 us, 2 000 of 16 000 66 -> 49 us; docs/HISTORY.md R4.5)
   auto hi_of = [&](int j) -> unsigned int { return v[j]; };               // elements past the end and empty key slots were loaded as 0
   auto lo_of = [&](int j, unsigned int z) -> unsigned int {
     if constexpr (KEYS) return lo[j];
@@ -1077,7 +1077,7 @@ int select_keys(const unsigned long long* keys, int rows, int keys_per_row, int 
 //     the k-th score is tied, which bf16 scores almost always are);
 //   * compacts the k winners into LDS, sorts them (block_sort_desc / block_sort_desc_multi) and writes (score, position).
 // K' = 1 000 of ~4 100 candidates per row, 32 rows: 56.7 us (row_select_kernel<8, true>) + 5.1 (counts) + 5.1 (memset of the
-// lists) -> see profiles/README.md.
+// lists) -> 24.6 us (docs/HISTORY.md R4.5).
 struct SubSelArgs {
   const unsigned long long* keys; const unsigned int* counts; int cap, n_sub, k, npad;
   float* out_scores; int64_t* out_pos; int32_t* out_counts; int32_t* out_flag;
