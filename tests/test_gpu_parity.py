@@ -728,6 +728,19 @@ def test_topk_candidates_equals_topk_over_gathered_ids(dev, rows, n, k):
     assert torch.equal(gs, ws) and torch.equal(gp, torch.gather(pos, 1, E.topk(scores, k)[1]))
 
 
+def test_topk_candidates_equals_the_oracle_selection_rule(dev):
+    """rails_topk_candidates against the oracle's deterministic rule (score desc, column asc: what the reference's torch.topk +
+    torch.gather + item_ids lookup returns modulo its tie order, mol_top_k.py:371-382) on rows with many exact ties."""
+    g = torch.Generator().manual_seed(7)
+    rows, n, k, corpus = 6, 1000, 120, 30_000
+    scores = (torch.randint(0, 25, (rows, n), generator=g).float() / 4.0)
+    pos = torch.stack([torch.randperm(corpus, generator=g)[:n] for _ in range(rows)])
+    item_ids = torch.arange(corpus, dtype=torch.int64) * 5 + 3
+    ws, wcol = O.select_topk_deterministic(scores, k)
+    gs, gi = E.topk_candidates(scores.to(dev), k, pos.to(dev), item_ids.to(dev))
+    assert torch.equal(gs.cpu(), ws) and torch.equal(gi.cpu(), item_ids[torch.gather(pos, 1, wcol)])
+
+
 @pytest.mark.parametrize("n,k", [(300_000, 1000), (695_762, 1600), (120_000, 4096), (60_000, 600)])
 def test_predicated_topk_takes_the_two_launch_route_and_equals_the_plain_call(dev, n, k):
     """rails_topk under a launch predicate (the fallback behind a device-side verdict) selects k > 512 of a long row in two launches
