@@ -498,3 +498,26 @@ def synthetic_queries(cfg: MoLConfig, batch: int, seed: int = 2) -> torch.Tensor
     (modeling/sequential/output_postprocessors.py:76-85)."""
     g = torch.Generator().manual_seed(seed)
     return F.layer_norm(torch.randn((batch, cfg.query_embedding_dim), generator=g), (cfg.query_embedding_dim,))
+
+
+def int8_prefilter_bound(q_bf16: torch.Tensor, table_bf16: torch.Tensor):
+    """CPU restatement of the int8 pre-filter of rails_amd's fused coarse top-K' (rails_amd/csrc/mol_coarse.hip: prefilter_*_kernel,
+    quantise_query, the preamble of coarse_scan_i8_kernel) -- no counterpart in the reference; test infrastructure for the claim
+    that the integer test cannot lose an item the bf16 scan keeps.  q (B, d), table (N, d): bf16 values.
+    -> (I (B, N) int64 integer dot products, eps (B,), s (scalar), s_q (B,)) with  |q . x - s s_q I| <= eps  for every pair."""
+    q = q_bf16.float()
+    x = table_bf16.float()
+    d = x.shape[1]
+    f32 = torch.float32
+    mx = x.abs().max()
+    inv = (torch.tensor(127.0, dtype=f32) / mx) if mx > 0 else torch.tensor(1.0)
+    s = (mx / 127.0) if mx > 0 else torch.tensor(1.0)
+    xi = torch.clamp(torch.round(x * inv), -127, 127).to(torch.int64)            # rintf = round half to even, as torch.round
+    x1max = x.abs().sum(1).max()
+    qmx = q.abs().amax(1)
+    qinv = torch.where(qmx > 0, 127.0 / qmx, torch.ones_like(qmx))
+    s_q = torch.where(qmx > 0, qmx / 127.0, torch.ones_like(qmx))
+    qi = torch.clamp(torch.round(q * qinv[:, None]), -127, 127).to(torch.int64)
+    l1 = q.abs().sum(1)
+    eps = 1.002 * (0.5 * s * l1 + 0.5 * s_q * x1max + 0.75 * s * s_q * d)
+    return qi @ xi.T, eps, s, s_q
