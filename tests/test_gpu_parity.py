@@ -566,6 +566,29 @@ def test_int8_prefilter_never_loses_a_candidate(dev, case, monkeypatch):
                 assert torch.equal(ps[b], rs[b]) and torch.equal(pp[b], rp[b]) and torch.equal(fs[b], rs[b]) and torch.equal(fp[b], rp[b])
 
 
+def test_int8_prefilter_build_equals_the_cpu_restatement(dev):
+    """rails_mol_coarse_prefilter_build against oracle.int8_prefilter_bound's quantisation: the same scale, the same max |x|_1 and
+    the same int8 value for every entry of the table (the bound tested on the CPU is the bound of what the kernel built)."""
+    cfg = O.CONFIGS["amzn-books"]
+    mol = build_module(cfg, O.synthetic_weights(cfg, seed=2), dev)
+    n = 100_003
+    X = torch.from_numpy(O.hash_item_table(5, 0, n, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    with torch.inference_mode():
+        at = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=100)
+        eng = at._bind()
+        table = at._table()
+        pre = eng.build_coarse_prefilter(table).cpu()
+        hdr = pre[:12].view(torch.float32)
+        x = table.cpu().float()
+        mx = x.abs().max()
+        assert float(hdr[0]) == float(mx / 127.0) and float(hdr[1]) == float(torch.tensor(127.0) / mx)
+        assert abs(float(hdr[2]) - float(x.abs().sum(1).max())) <= 1e-5 * float(hdr[2])      # summation order
+        want = torch.clamp(torch.round(x * hdr[1]), -127, 127).to(torch.int8)
+        got = pre[256:].view(torch.int8).view(n, -1)
+        assert torch.equal(got, want)
+
+
 def test_avg_topk_module_with_the_int8_prefilter(dev, monkeypatch):
     """MoLAvgTopK builds the pre-filter for large tables on its own (PREFILTER_MIN_ITEMS); lowered here: forward with it == forward
     without it == the materialising path, d = 32 / 64 / 128 shapes."""
