@@ -167,8 +167,18 @@ __device__ __forceinline__ void coarse_query_element(const float* __restrict__ e
   const int DC = d / 16;
   const int b = i / d, dd = i - b * d;
   float acc = 0.0f;
-  if (b < B)
-    for (int p = 0; p < PQ; ++p) acc += eq[((int64_t)b * PQ + p) * d + dd];
+  if (b < B) {
+    // eight loads in flight, then their sum in the same order (one load per add waits a round trip per query group: P_Q round
+    // trips at the head of every workgroup of the sample scan -- 26.9 -> 19.7 us for that launch)
+    for (int p0 = 0; p0 < PQ; p0 += 8) {
+      float v8[8];
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) v8[jj] = p0 + jj < PQ ? eq[((int64_t)b * PQ + p0 + jj) * d + dd] : 0.0f;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj)
+        if (p0 + jj < PQ) acc += v8[jj];
+    }
+  }
   const float v = b < B ? bf16_rn(avg ? acc / (float)PQ : acc) : 0.0f;
   const int qt = b >> 5, row = b & 31, c = dd >> 4, h = (dd >> 3) & 1, j = dd & 7;
   frag[(((size_t)qt * DC + c) * 64 + h * 32 + row) * 8 + j] = (unsigned short)(__float_as_uint(v) >> 16);
