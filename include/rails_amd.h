@@ -33,9 +33,9 @@ extern "C" {
  * structs of round 2 carried no version; 5: the launch predicate became the explicit `run_if` argument of the entry points that
  * honour it and the per-thread rails_set_run_predicate is gone -- the library keeps no state between calls but the last error;
  * 6: rails_mol_coarse_topk gained its out_of_range output and its optional int8 pre-filter (rails_mol_coarse_prefilter_*),
- * rails_topk_candidates is new, rails_mol_score_indexed takes any n_cand).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
+ * rails_topk_candidates is new, rails_mol_score_indexed takes any n_cand; 7: rails_rescore_verdict gained its guard arguments and state[7], the rails_*_probe_* entry points are new).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
  * against an older header pass shorter structs, and the library would read the new fields from whatever follows them. */
-#define RAILS_ABI_VERSION 6
+#define RAILS_ABI_VERSION 7
 int rails_abi_version(void);
 
 #define RAILS_OK 0
@@ -368,13 +368,31 @@ int rails_range_flag_i32(const int32_t* values, int32_t n, int32_t lo, int32_t h
  * caller's calibration state (8 floats in device memory, zero-initialised once):
  *   state[0]  largest |first pass - fp32| ever observed (updated here; never decreases)
  *   state[1]  REDO flag, an int32 (written here): 1 iff some row's margin <= eps or a NaN was seen, eps = max(default_eps, safety * state[0])
- *   state[2]  eps   state[3] / state[4]  this call's largest error / smallest margin   state[5] / state[6]  calls / redone calls so far */
-int rails_rescore_verdict(const float* row_stats, int32_t rows, float default_eps, float safety, float* state, void* stream);
+ *   state[2]  eps   state[3] / state[4]  this call's largest error / smallest margin   state[5] / state[6]  calls / redone calls so far
+ *   state[7]  largest |guard value| ever observed
+ * guard_values (optional, may be NULL): guard_count floats whose magnitudes must not exceed guard_limit for the caller's bound on
+ * |first pass - fp32| to hold -- the proved exact top-k passes the batch's prescaled query-gate rows gq' (the one data-dependent magnitude of
+ * its a-priori bound, rails_amd/f16x3_bound.py); a larger value or a NaN raises REDO like a failed margin.
+ * No counterpart in the reference (rails/indexing/mol_top_k.py:99-130 scores every item in one precision). */
+int rails_rescore_verdict(const float* row_stats, int32_t rows, float default_eps, float safety, const float* guard_values, int64_t guard_count,
+                          float guard_limit, float* state, void* stream);
 
 int rails_rescore_select(const float* exact_scores, int64_t ld, const float* approx_scores, const float* approx_dense, int64_t ld_dense,
                          const int64_t* positions, const int64_t* ids, int64_t n_items, int32_t rows, int32_t n_ranked, int32_t n_cand,
                          int32_t k, float margin_eps, float check_eps, float* out_scores, int64_t* out_ids, int32_t* row_ok, float* row_stats,
                          void* stream);
+
+/* ---- arithmetic-model probes (test infrastructure of the proved exact top-k; no counterpart in the reference) -------------------------
+ * The a-priori bound on |first pass - fp32 logit| (rails_amd/f16x3_bound.py) models the two matrix instructions and the two
+ * transcendentals the scoring kernels are made of; these entry points run ONE such instruction per element on caller-supplied operands so
+ * that tests can measure the model on the part (tests/test_gpu_parity.py::test_f16_mfma_accumulation_model and neighbours).
+ *   rails_mfma_probe_f16: n independent D = C + A B with v_mfma_f32_32x32x16_f16; A (32 x 16) and B (16 x 32) row-major f16 bit patterns,
+ *                         C and D (32 x 32) row-major fp32, n of each back to back.
+ *   rails_mfma_probe_f32: the same with v_mfma_f32_32x32x2_f32; A (32 x 2), B (2 x 32) fp32.
+ *   rails_scalar_probe_f32: out[0..n) = v_exp_f32(x), out[n..2n) = v_rcp_f32(x), out[2n..3n) = x / (1 + 2^x) as the kernels compute it. */
+int rails_mfma_probe_f16(const uint16_t* a, const uint16_t* b, const float* c, float* d, int64_t n, void* stream);
+int rails_mfma_probe_f32(const float* a, const float* b, const float* c, float* d, int64_t n, void* stream);
+int rails_scalar_probe_f32(const float* x, int64_t n, float* out, void* stream);
 
 /* ---- synthetic corpora (measurement and test infrastructure; no counterpart in the reference, whose item tables are trained) ----
  * out[(i - first_item) * dim + c] for items first_item <= i < first_item + n_items: a counter-based hash of (seed, i, c) --

@@ -1,0 +1,415 @@
+"""TEST INFRASTRUCTURE (oracle): restatement of the a-priori bound of the proved exact top-k, and CPU emulations of the two arithmetics
+it compares.  Only tests/, __graft_entry__.smoke() and bench.py's checking legs may import this file; the product computes its bound in
+rails_amd/f16x3_bound.py and never looks here.
+
+What is restated
+  * first_pass_bound(): the bound eps >= |f16x3 first pass - fp32 kernel| for every (query, item) pair, from the pair-gate weights --
+    written from the derivation in rails_amd/f16x3_bound.py's docstring with plain loops over rows (the product uses matrix
+    expressions), so that a slip in either shows as a disagreement (tests/test_f16x3_bound_cpu.py compares them term by term).
+  * three evaluations of one (query, item) pair's logit from the SAME fp32 operands
+        exact64()      float64, the real-valued function (reference: rails/similarities/mol/similarity_fn.py:389-413, :148-201, :31-46)
+        emulate_fp32() the fp32 kernels' arithmetic: fma chains in the layout's order (csrc/mol_layout.h logit_of / hidden_of /
+                       kdim_of), phi(t) = t * rcp(1 + exp2(t)) in fp32, shifted softmax, packed partial sums (csrc/mol_score_fp32_unit.h)
+        emulate_f16x3() the split-f16 kernels' arithmetic: RTZ / RNE operand splits, three products per block, one fp32 rounding per
+                       MFMA made ADVERSARIAL (each instruction's result is pushed one more ulp away from the exact sum, so the emulated
+                       instruction errs by up to 3 u |D|: the test then uses kappa = 3), un-shifted softmax (csrc/mol_score_f16_unit.h)
+    The property test asserts |emulate_* - exact64| <= the two halves of the bound, stage by stage (cl, t, q) and for the logit.
+The transcendentals are numpy's float32 exp2 and 1/x perturbed by one ulp at random: the hardware's are specified to 1 ulp, not bit-exact.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import numpy as np
+
+U = 2.0 ** -24
+KAPPA = 4.0
+OMEGA = 2.0 ** -100
+LOG2E_F32 = np.float32(1.4426950408889634)
+LIP = 1.1
+GATE_GUARD = 256.0
+F16_LIMIT = 60000.0
+
+
+def gamma(n: float, unit: float = U) -> float:
+    return n * unit / (1.0 - n * unit)
+
+
+# ---- layout (csrc/mol_layout.h) ---------------------------------------------------------------------------------------------------
+def acc_row(reg: int, hi: int) -> int:
+    return (reg & 3) + 8 * (reg >> 2) + 4 * hi
+
+
+def logit_of(e: int, hi: int, p_q: int, p_x: int) -> int:
+    rpq = p_q // 2
+    return acc_row(e % rpq, hi) * p_x + e // rpq
+
+
+def hidden_of(f: int, hi: int) -> int:
+    return 32 * (f // 16) + acc_row(f % 16, hi)
+
+
+def kdim_of(s: int, hi: int, d: int) -> int:
+    return hi * (d // 2) + s
+
+
+def gemm2_order(p_q: int, p_x: int):
+    return [logit_of(e, hi, p_q, p_x) for e in range(p_q * p_x // 2) for hi in (0, 1)]
+
+
+def gemm3_order(hidden: int):
+    return [hidden_of(f, hi) for f in range(hidden // 2) for hi in (0, 1)]
+
+
+def gemm1_order(d: int):
+    return [kdim_of(s, hi, d) for s in range(d // 2) for hi in (0, 1)]
+
+
+# ---- the bound, restated ----------------------------------------------------------------------------------------------------------
+def _split_constants(kernel: bool):
+    """(R, A, LAM, A2): |x - hi - lo| <= R|x| + A, |lo| <= LAM|x| + A2.  hi = RTZ_f16(x); lo = RTZ_f16(x - hi) in the kernel, RNE in the packs."""
+    return (2.0 ** -20, 2.0 ** -24, 2.0 ** -10, 2.0 ** -24) if kernel else (2.0 ** -21, 2.0 ** -25, 2.0 ** -10 * (1 + 2.0 ** -11), 2.0 ** -24)
+
+
+def first_pass_bound(w1, b1, w2, b2, temperature: float, dot_dim: int, p_q: int, p_x: int, kappa: float = KAPPA,
+                     gate_guard: float = GATE_GUARD) -> Dict[str, float]:
+    w1 = np.abs((np.float32(-LOG2E_F32) * np.asarray(w1, np.float32)).astype(np.float64))
+    b1 = np.abs((np.float32(-LOG2E_F32) * np.asarray(b1, np.float32)).astype(np.float64))
+    b2 = np.abs((np.float32(-LOG2E_F32) * np.asarray(b2, np.float32)).astype(np.float64))
+    w2 = np.abs(np.asarray(w2, np.float32).astype(np.float64))
+    H, L = w1.shape
+    d = int(dot_dim)
+    out = {"eps": math.inf}
+    if L != p_q * p_x or w2.shape != (L, H) or L % 32 or H % 32 or d % 16 or p_q % 2:
+        return out
+    if not (np.isfinite(w1).all() and np.isfinite(w2).all() and np.isfinite(b1).all() and np.isfinite(b2).all()):
+        return out
+    inv_tau = 1.0 / float(np.float32(temperature))
+    slack = 1.0 + (d + 8) * U
+    c0 = inv_tau * slack * slack
+    n_eq, n_ex = math.sqrt(d) * inv_tau * slack, math.sqrt(d) * slack
+    th = gamma(7)
+    ku = max(kappa, 1.0) * U
+    o2, o3 = gemm2_order(p_q, p_x), gemm3_order(H)
+
+    def block(sa, sb):
+        ra, aa, la, aa2 = sa
+        rb, ab, lb, ab2 = sb
+        return (ra + rb + ra * rb + la * lb,            # relative loss
+                aa * (1 + rb) + lb * aa2,               # x |b|_1
+                ab * (1 + ra) + la * ab2,               # x |a|_1
+                aa * ab + aa2 * ab2,                    # per product
+                la + lb, ab2, aa2)                      # relative mass of the two small products; absolute parts x |a|_1, x |b|_1
+
+    def chain32(terms, c0_):
+        """fma chain: term j (0-based) of n is rounded n - j times; the two terms of one instruction are charged worst case"""
+        n = len(terms)
+        e = gamma(n) * c0_
+        for j in range(0, n, 2):
+            big, small = max(terms[j], terms[j + 1]), min(terms[j], terms[j + 1])
+            e += gamma(n - j) * big + gamma(n - j - 1) * small
+        return e
+
+    def chain16(terms, c0_, small_mass):
+        """MFMA chain: the hi*hi mass of K-step s is rounded by the instructions 3s+3 .. M and possibly one final add"""
+        nk = len(terms) // 16
+        m = 3 * nk
+        e = gamma(m + 1, ku) * (c0_ + small_mass)
+        for s_ in range(nk):
+            e += gamma(m - 3 * s_, ku) * sum(terms[16 * s_ : 16 * s_ + 16])
+        return e
+
+    def tail(dq, q_star, dcl, x1):
+        t2 = [gate_guard + q_star[l] + dq[l] for l in range(L)]
+        dt2 = [dq[l] + U * t2[l] * (1 + U) for l in range(L)]
+        du = max(LIP * dt2[l] + th * (t2[l] + dt2[l]) + OMEGA for l in range(L))
+        umax = max((t2[l] + dt2[l]) * (1 + th) for l in range(L))
+        nu = gamma(2) + gamma(L // 2 + 8) + math.log(2.0) * U * 2.0 * umax * (1 + U) + OMEGA
+        dw = math.log(2.0) * du + nu
+        return dcl + dw * x1 + (math.expm1(2.0 * nu) * (1 + gamma(4)) + gamma(4)) * x1, dw, max(t2)
+
+    a1 = w1.sum(1)
+    a2 = w2.sum(1)
+    t_star = [b1[h] + a1[h] * c0 for h in range(H)]
+    q_star = [b2[l] + sum(w2[l, h] * t_star[h] for h in range(H)) for l in range(L)]
+
+    # f16x3
+    pk, kn = _split_constants(False), _split_constants(True)
+    rho, ba, bb, abs2, small, x_a, x_b = block(pk, pk)
+    g1 = c0 * (1 + small) + n_eq * x_a + n_ex * x_b
+    dcl16 = rho * c0 + bb * n_eq + ba * n_ex + d * abs2 + gamma(3 * d / 16 + 1, ku) * g1
+    x1 = c0 + dcl16
+    rho, ba, bb, abs2, small, x_a, x_b = block(pk, kn)
+    dt16, t16, dh16, y16 = [], [], [], []
+    for h in range(H):
+        s2 = a1[h] * x1
+        sm = s2 * small + a1[h] * x_a + L * x1 * x_b
+        e = a1[h] * dcl16 + rho * s2 + bb * a1[h] + ba * L * x1 + L * abs2 + chain16([w1[h, l] * x1 for l in o2], b1[h], sm)
+        dt16.append(e)
+        t16.append(t_star[h] + e)
+        dh16.append(LIP * e + th * t16[-1] + OMEGA)
+        y16.append(t16[-1] * (1 + th))
+    ysum = sum(y16)
+    dq16 = []
+    for l in range(L):
+        s3 = sum(w2[l, h] * y16[h] for h in range(H))
+        sm = s3 * small + a2[l] * x_a + ysum * x_b
+        dq16.append(sum(w2[l, h] * dh16[h] for h in range(H)) + rho * s3 + bb * a2[l] + ba * ysum + H * abs2
+                    + chain16([w2[l, h] * y16[h] for h in o3], b2[l], sm))
+    in_range = max(x1, max(y16), w1.max(), w2.max()) < F16_LIMIT
+    eps16, dw16, t2max = tail(dq16, q_star, dcl16, x1)
+
+    # fp32
+    dcl32 = gamma(d) * c0
+    x1f = c0 + dcl32
+    dt32, dh32, y32 = [], [], []
+    for h in range(H):
+        e = a1[h] * dcl32 + chain32([w1[h, l] * x1f for l in o2], b1[h])
+        dt32.append(e)
+        t32 = t_star[h] + e
+        dh32.append(LIP * e + th * t32 + OMEGA)
+        y32.append(t32 * (1 + th))
+    dq32 = [sum(w2[l, h] * dh32[h] for h in range(H)) + chain32([w2[l, h] * y32[h] for h in o3], b2[l]) for l in range(L)]
+    eps32, dw32, _ = tail(dq32, q_star, dcl32, x1f)
+
+    out.update({"eps": eps16 + eps32 if in_range else math.inf, "eps16": eps16, "eps32": eps32, "d_cl16": dcl16, "d_cl32": dcl32,
+                "d_t16": max(dt16), "d_t32": max(dt32), "d_q16": max(dq16), "d_q32": max(dq32), "d_w16": dw16, "d_w32": dw32,
+                "t2_max": t2max, "in_f16_range": bool(in_range),
+                "per_h": {"d_t16": np.array(dt16), "d_t32": np.array(dt32)}, "per_l": {"d_q16": np.array(dq16), "d_q32": np.array(dq32)}})
+    return out
+
+
+# ---- the three evaluations --------------------------------------------------------------------------------------------------------
+def prescale(w1, b1, w2, b2):
+    """the gate pack's fp32 values (csrc/mol_index.hip pack_gate_kernel): W1' = -log2e W1, b1' = -log2e b1, W2, b2' = -log2e b2"""
+    k = np.float32(-LOG2E_F32)
+    return (k * np.asarray(w1, np.float32), k * np.asarray(b1, np.float32), np.asarray(w2, np.float32), k * np.asarray(b2, np.float32))
+
+
+def _phi64(t):
+    return t / (1.0 + np.exp2(t))
+
+
+def exact64(eqp, ex, gqp, gi, w1p, b1p, w2, b2p):
+    """eqp (P, L, d) fp32: the query row Eq'[p] of every logit; ex (P, L, d): the item row Ex[m]; gqp, gi (P, L).  -> dict of float64 stages"""
+    eqp, ex, gqp, gi = (np.asarray(v, np.float64) for v in (eqp, ex, gqp, gi))
+    w1p, b1p, w2, b2p = (np.asarray(v, np.float64) for v in (w1p, b1p, w2, b2p))
+    cl = (eqp * ex).sum(2)
+    t = cl @ w1p.T + b1p
+    hid = _phi64(t)
+    q = hid @ w2.T + b2p
+    t2 = gqp * gi + q
+    u = _phi64(t2)
+    w = -u * math.log(2.0)
+    w = w - w.max(1, keepdims=True)
+    pi = np.exp(w)
+    pi /= pi.sum(1, keepdims=True)
+    return {"cl": cl, "t": t, "q": q, "s": (pi * cl).sum(1)}
+
+
+def _f32(x):
+    return np.asarray(x, np.float64).astype(np.float32)
+
+
+def _fma32(a, b, c):
+    """round-to-nearest fp32 fma on float32 arrays (product exact in float64; the float64 addition's own rounding is 2^-29 of an fp32 ulp)"""
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+
+def _ulp_jitter(x, rng):
+    """x (float32) moved by -1, 0 or +1 ulp at random: a transcendental specified to 1 ulp"""
+    step = rng.integers(-1, 2, size=x.shape)
+    up = np.nextafter(x, np.float32(np.inf))
+    dn = np.nextafter(x, np.float32(-np.inf))
+    return np.where(step > 0, up, np.where(step < 0, dn, x)).astype(np.float32)
+
+
+def _phi32(t, rng):
+    with np.errstate(over="ignore", under="ignore"):
+        e = _ulp_jitter(np.exp2(t.astype(np.float32)), rng) + np.float32(1.0)
+        r = _ulp_jitter((np.float32(1.0) / e).astype(np.float32), rng)
+    return (t * r).astype(np.float32)
+
+
+def emulate_fp32(eqp, ex, gqp, gi, w1p, b1p, w2, b2p, p_q: int, p_x: int, seed: int = 0):
+    rng = np.random.default_rng(seed)
+    eqp, ex, gqp, gi = (np.asarray(v, np.float32) for v in (eqp, ex, gqp, gi))
+    P, L, d = eqp.shape
+    H = w1p.shape[0]
+    cl = np.zeros((P, L), np.float32)
+    for k in gemm1_order(d):
+        cl = _fma32(eqp[:, :, k], ex[:, :, k], cl)
+    t = np.broadcast_to(b1p.astype(np.float32), (P, H)).copy()
+    for l in gemm2_order(p_q, p_x):
+        t = _fma32(w1p[None, :, l], cl[:, l : l + 1], t)
+    hid = _phi32(t, rng)
+    q = np.broadcast_to(b2p.astype(np.float32), (P, L)).copy()
+    for h in gemm3_order(H):
+        q = _fma32(w2[None, :, h], hid[:, h : h + 1], q)
+    t2 = _fma32(gqp, gi, q)
+    u = _phi32(t2, rng)
+    mn = u.min(1, keepdims=True)
+    with np.errstate(under="ignore"):
+        exw = _ulp_jitter(np.exp2((mn - u).astype(np.float32)), rng)
+    # per lane half: two interleaved partial sums (packed registers), joined, then the halves joined (mol_score_fp32_unit.h)
+    E = L // 2
+    den_h, num_h = [], []
+    for hi in (0, 1):
+        cols = [logit_of(e, hi, p_q, p_x) for e in range(E)]
+        dx = np.zeros(P, np.float32); dy = np.zeros(P, np.float32); nx = np.zeros(P, np.float32); ny = np.zeros(P, np.float32)
+        for e in range(0, E, 2):
+            dx = (dx + exw[:, cols[e]]).astype(np.float32); dy = (dy + exw[:, cols[e + 1]]).astype(np.float32)
+            nx = _fma32(exw[:, cols[e]], cl[:, cols[e]], nx); ny = _fma32(exw[:, cols[e + 1]], cl[:, cols[e + 1]], ny)
+        den_h.append((dx + dy).astype(np.float32)); num_h.append((nx + ny).astype(np.float32))
+    den, num = (den_h[0] + den_h[1]).astype(np.float32), (num_h[0] + num_h[1]).astype(np.float32)
+    rden = _ulp_jitter((np.float32(1.0) / den).astype(np.float32), rng)
+    s = ((num * rden).astype(np.float32) / np.maximum((den * rden).astype(np.float32), np.float32(1e-6))).astype(np.float32)
+    return {"cl": cl.astype(np.float64), "t": t.astype(np.float64), "q": q.astype(np.float64), "s": s.astype(np.float64)}
+
+
+def rtz_f16(x):
+    """float32 -> float16, rounded toward zero (v_cvt_pkrtz_f16_f32); f16 subnormals kept"""
+    x = np.asarray(x, np.float32)
+    with np.errstate(over="ignore"):
+        h = x.astype(np.float16)
+    too_big = np.abs(h.astype(np.float32)) > np.abs(x)
+    h = np.where(too_big, np.nextafter(h, np.float16(0)), h).astype(np.float16)
+    return h
+
+
+def split_f16(x, kernel: bool):
+    """-> (hi, lo) as float64 arrays of f16 values: hi = RTZ(x); lo = RTZ (kernel) or RNE (packs) of the exact fp32 remainder"""
+    x = np.asarray(x, np.float32)
+    hi = rtz_f16(x)
+    r = (x - hi.astype(np.float32)).astype(np.float32)
+    lo = rtz_f16(r) if kernel else r.astype(np.float16)
+    return hi.astype(np.float64), lo.astype(np.float64)
+
+
+def _mfma16(acc, a_list, b_list, rng):
+    """one f16 MFMA: acc + sum of <= 16 exact products, rounded to fp32 and pushed one ulp further from the exact sum (adversarial model)"""
+    exact = acc.astype(np.float64) + sum(a * b for a, b in zip(a_list, b_list))
+    r = exact.astype(np.float32)
+    away = np.where(r.astype(np.float64) >= exact, np.nextafter(r, np.float32(np.inf)), np.nextafter(r, np.float32(-np.inf)))
+    return np.where(rng.random(r.shape) < 0.75, away, r).astype(np.float32)
+
+
+def emulate_f16x3(eqp, ex, gqp, gi, w1p, b1p, w2, b2p, p_q: int, p_x: int, seed: int = 0):
+    rng = np.random.default_rng(seed + 1)
+    eqp, ex, gqp, gi = (np.asarray(v, np.float32) for v in (eqp, ex, gqp, gi))
+    P, L, d = eqp.shape
+    H = w1p.shape[0]
+    qh, ql = split_f16(eqp, kernel=False)
+    xh, xl = split_f16(ex, kernel=False)
+    w1h, w1l = split_f16(w1p, kernel=False)
+    w2h, w2l = split_f16(w2, kernel=False)
+    # GEMM1: K-step ks covers the 8 K-values s = 8 ks .. 8 ks + 7 of both lane halves
+    cl = np.zeros((P, L), np.float32)
+    for ks in range(d // 16):
+        cols = [kdim_of(8 * ks + j, hi, d) for hi in (0, 1) for j in range(8)]
+        for (a, b) in ((ql, xh), (qh, xl), (qh, xh)):
+            cl = _mfma16(cl, [a[:, :, k] for k in cols], [b[:, :, k] for k in cols], rng)
+    # GEMM2: cl is split in the kernel
+    ch, clo = split_f16(cl, kernel=True)
+    t = np.broadcast_to(b1p.astype(np.float32), (P, H)).copy()
+    for ks in range(L // 16):
+        cols = [logit_of(8 * ks + j, hi, p_q, p_x) for hi in (0, 1) for j in range(8)]
+        for (a, b) in ((w1l, ch), (w1h, clo), (w1h, ch)):
+            t = _mfma16(t, [a[None, :, l] for l in cols], [b[:, l : l + 1] for l in cols], rng)
+    hid = _phi32(t, rng)
+    hh, hl = split_f16(hid, kernel=True)
+    q = np.broadcast_to(b2p.astype(np.float32), (P, L)).copy()
+    for ks in range(H // 16):
+        cols = [hidden_of(8 * ks + j, hi) for hi in (0, 1) for j in range(8)]
+        for (a, b) in ((w2l, hh), (w2h, hl), (w2h, hh)):
+            q = _mfma16(q, [a[None, :, h] for h in cols], [b[:, h : h + 1] for h in cols], rng)
+    t2 = _fma32(gqp, gi, q)
+    u = _phi32(t2, rng)
+    with np.errstate(over="ignore"):
+        exw = _ulp_jitter(np.exp2((-u).astype(np.float32)), rng)
+    E = L // 2
+    den_h, num_h = [], []
+    for hi in (0, 1):
+        cols = [logit_of(e, hi, p_q, p_x) for e in range(E)]
+        dn = np.zeros(P, np.float32); nm = np.zeros(P, np.float32)
+        for e in range(E):
+            dn = (dn + exw[:, cols[e]]).astype(np.float32)
+            nm = _fma32(exw[:, cols[e]], cl[:, cols[e]], nm)
+        den_h.append(dn); num_h.append(nm)
+    with np.errstate(over="ignore", invalid="ignore"):
+        den, num = (den_h[0] + den_h[1]).astype(np.float32), (num_h[0] + num_h[1]).astype(np.float32)
+    redo = ~(den < np.float32(1.0e30))
+    if redo.any():   # an exp got large: the stable form from the u values (mol_score_f16_unit.h epi_final)
+        mn = u.min(1, keepdims=True)
+        with np.errstate(under="ignore"):
+            ex2 = _ulp_jitter(np.exp2((mn - u).astype(np.float32)), rng)
+        den_h, num_h = [], []
+        for hi in (0, 1):
+            cols = [logit_of(e, hi, p_q, p_x) for e in range(E)]
+            dn = np.zeros(P, np.float32); nm = np.zeros(P, np.float32)
+            for e in range(E):
+                dn = (dn + ex2[:, cols[e]]).astype(np.float32)
+                nm = _fma32(ex2[:, cols[e]], cl[:, cols[e]], nm)
+            den_h.append(dn); num_h.append(nm)
+        den = np.where(redo, (den_h[0] + den_h[1]).astype(np.float32), den)
+        num = np.where(redo, (num_h[0] + num_h[1]).astype(np.float32), num)
+    rden = _ulp_jitter((np.float32(1.0) / den).astype(np.float32), rng)
+    s = ((num * rden).astype(np.float32) / np.maximum((den * rden).astype(np.float32), np.float32(1e-6))).astype(np.float32)
+    return {"cl": cl.astype(np.float64), "t": t.astype(np.float64), "q": q.astype(np.float64), "s": s.astype(np.float64)}
+
+
+# ---- stress families shared by the CPU property test and the GPU test -------------------------------------------------------------
+def stress_weights(w: dict, kind: str, seed: int):
+    """-> (weights with the pair gate stressed, scale of the item table).  Keys are the reference's state_dict names."""
+    import torch
+
+    g = torch.Generator().manual_seed(1000 + seed)
+    p = "_gating_fn._qi_partial_module."
+    w = dict(w)
+    if kind == "gaussian":
+        return w, 1.0
+    if kind == "outlier":           # a few huge entries in both matrices and the biases
+        for key in (p + "1.weight", p + "3.weight"):
+            m = w[key].clone()
+            idx = torch.randint(0, m.numel(), (6,), generator=g)
+            m.view(-1)[idx] *= 40.0
+            w[key] = m
+        w[p + "1.bias"] = torch.randn(w[p + "1.bias"].shape, generator=g) * 0.5
+        w[p + "3.bias"] = torch.randn(w[p + "3.bias"].shape, generator=g) * 0.5
+        return w, 1.0
+    if kind == "hot gate":          # large gate logits: the softmax is nearly one-hot
+        w[p + "3.weight"] = w[p + "3.weight"] * 4.0
+        w[p + "3.bias"] = torch.randn(w[p + "3.bias"].shape, generator=g) * 2.0
+        return w, 1.0
+    if kind == "near overflow":     # gate logits of a few tens to a hundred: 2^(-u) nears the fp32 range, the stable form takes over
+        w[p + "3.weight"] = w[p + "3.weight"] * 8.0
+        w[p + "3.bias"] = torch.full(w[p + "3.bias"].shape, 30.0)
+        return w, 1.0
+    if kind == "tiny components":   # item rows of tiny norm: f16 subnormal lo halves everywhere downstream
+        return w, 1.0e-3
+    raise ValueError(kind)
+
+
+def pair_operands(cfg, w: dict, q, items, user_ids=None):
+    """fp32 operands of every (query, item) pair as the kernels see them, from the oracle's stage functions:
+    eqp (P, L, d) = Eq[b, p] / tau, ex (P, L, d) = Ex[x, m], gqp (P, L) = -log2e gq[b], gi (P, L), P = B * X pairs, l = p * P_X + m."""
+    import torch
+
+    from oracle import mol_oracle as O
+
+    eq = O.query_component_embeddings(cfg, w, q, user_ids)            # (B, P_Q, d), l2-normalised
+    exm = O.item_component_embeddings(cfg, w, items)                   # (X, P_X, d)
+    gq = O.query_gate(cfg, w, q)                                       # (B, L)
+    gi = O.item_gate(cfg, w, items)                                    # (X, L)
+    B, PQ, d = eq.shape
+    X, PX, _ = exm.shape
+    L = PQ * PX
+    eqs = (eq / torch.tensor(cfg.temperature, dtype=torch.float32)).numpy()
+    eqp = np.repeat(eqs[:, None, :, None, :], PX, axis=3).reshape(B, 1, L, d)
+    exl = np.tile(exm.numpy()[None, :, None, :, :], (1, 1, PQ, 1, 1)).reshape(1, X, L, d)
+    eqp = np.broadcast_to(eqp, (B, X, L, d)).reshape(B * X, L, d)
+    exl = np.broadcast_to(exl, (B, X, L, d)).reshape(B * X, L, d)
+    gqp = np.broadcast_to((np.float32(-LOG2E_F32) * gq.numpy())[:, None, :], (B, X, L)).reshape(B * X, L)
+    gil = np.broadcast_to(gi.numpy()[None, :, :], (B, X, L)).reshape(B * X, L)
+    return np.ascontiguousarray(eqp), np.ascontiguousarray(exl), np.ascontiguousarray(gqp), np.ascontiguousarray(gil)

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RAILS_AMD_LIBRARY: load another build of the same library (e.g. the phase-stamp debug build of tools/query_phases.sh)
 LIB_PATH = os.environ.get("RAILS_AMD_LIBRARY") or os.path.join(_HERE, "librails_amd.so")
 
-RAILS_ABI_VERSION = 6   # include/rails_amd.h
+RAILS_ABI_VERSION = 7   # include/rails_amd.h
 RAILS_OK = 0
 RAILS_EINVAL = -22
 RAILS_ENOTSUP = -95
@@ -194,7 +194,10 @@ PROTOTYPES = {
     "rails_mol_score_indexed_supported": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64]),
     "rails_mol_score_indexed": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "rails_range_flag_i32": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
-    "rails_rescore_verdict": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p]),
+    "rails_rescore_verdict": (C.c_int, [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_void_p]),
+    "rails_mfma_probe_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "rails_mfma_probe_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "rails_scalar_probe_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "rails_filter_seen_ids": (
         C.c_int,
         [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,

@@ -642,11 +642,33 @@ int rails_range_flag_i32(const int32_t* values, int32_t n, int32_t lo, int32_t h
   return fail(range_flag(values, n, lo, hi, flag, (hipStream_t)stream), "range_flag");
 }
 
-int rails_rescore_verdict(const float* row_stats, int32_t rows, float default_eps, float safety, float* state, void* stream) {
+int rails_rescore_verdict(const float* row_stats, int32_t rows, float default_eps, float safety, const float* guard_values, int64_t guard_count,
+                          float guard_limit, float* state, void* stream) {
   g_err[0] = '\0';
-  if (rows <= 0 || !row_stats || !state || !(default_eps >= 0.0f) || !(safety >= 0.0f)) { set_error("rescore_verdict: bad argument"); return RAILS_EINVAL; }
-  const int r = rescore_verdict(row_stats, rows, default_eps, safety, state, (hipStream_t)stream);
+  if (rows <= 0 || !row_stats || !state || !(default_eps >= 0.0f) || !(safety >= 0.0f) || guard_count < 0 || (guard_values && !(guard_limit >= 0.0f))) {
+    set_error("rescore_verdict: bad argument");
+    return RAILS_EINVAL;
+  }
+  const int r = rescore_verdict(row_stats, rows, default_eps, safety, guard_values, guard_count, guard_limit, state, (hipStream_t)stream);
   return r == kOk ? r : fail(r, "rescore_verdict");
+}
+
+int rails_mfma_probe_f16(const uint16_t* a, const uint16_t* b, const float* c, float* d, int64_t n, void* stream) {
+  g_err[0] = '\0';
+  if (n < 0 || (n > 0 && (!a || !b || !c || !d))) { set_error("mfma_probe_f16: bad argument"); return RAILS_EINVAL; }
+  return fail(mfma_probe_f16(a, b, c, d, n, (hipStream_t)stream), "mfma_probe_f16");
+}
+
+int rails_mfma_probe_f32(const float* a, const float* b, const float* c, float* d, int64_t n, void* stream) {
+  g_err[0] = '\0';
+  if (n < 0 || (n > 0 && (!a || !b || !c || !d))) { set_error("mfma_probe_f32: bad argument"); return RAILS_EINVAL; }
+  return fail(mfma_probe_f32(a, b, c, d, n, (hipStream_t)stream), "mfma_probe_f32");
+}
+
+int rails_scalar_probe_f32(const float* x, int64_t n, float* out, void* stream) {
+  g_err[0] = '\0';
+  if (n < 0 || (n > 0 && (!x || !out))) { set_error("scalar_probe_f32: bad argument"); return RAILS_EINVAL; }
+  return fail(scalar_probe(x, n, out, (hipStream_t)stream), "scalar_probe_f32");
 }
 
 int rails_rescore_select(const float* exact_scores, int64_t ld, const float* approx_scores, const float* approx_dense, int64_t ld_dense,

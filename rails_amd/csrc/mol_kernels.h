@@ -173,7 +173,12 @@ int select_lists(unsigned long long* lists, unsigned int* thr, int rows, int cap
                  const int64_t* f_invalid = nullptr, int f_width = 0, int f_k = 0);
 int pack_candidates(const float* scores, const int64_t* ids, int rows, int k_local, int k, int64_t* msg, hipStream_t stream);
 int range_flag(const int32_t* v, int n, int lo, int hi, int32_t* flag, hipStream_t stream);
-int rescore_verdict(const float* row_stats, int rows, float default_eps, float safety, float* state, hipStream_t stream);
+int rescore_verdict(const float* row_stats, int rows, float default_eps, float safety, const float* guard, int64_t guard_count, float guard_limit,
+                    float* state, hipStream_t stream);
+// arithmetic-model probes (arith_model.hip)
+int mfma_probe_f16(const unsigned short* a, const unsigned short* b, const float* c, float* d, int64_t n, hipStream_t stream);
+int mfma_probe_f32(const float* a, const float* b, const float* c, float* d, int64_t n, hipStream_t stream);
+int scalar_probe(const float* x, int64_t n, float* out, hipStream_t stream);
 int rescore_select(const float* exact, int64_t ld, const float* approx, const float* approx_dense, int64_t ld_dense, const int64_t* positions,
                    const int64_t* ids, int rows, int n_ranked, int kc, int k, float margin_eps, float check_eps, float* out_scores,
                    int64_t* out_ids, int* ok, float* stats, hipStream_t stream);

@@ -1501,11 +1501,15 @@ __global__ __launch_bounds__(kSortThreads) void rescore_select_kernel(const floa
 // Verdict of a speculative call on the device (the host used to read the per-row stats and decide: ~100 us of GPU idle per call).
 // state[0] largest |first pass - fp32| ever seen (in/out)   state[1] REDO flag as int32 (out; the fallback's launch predicate)
 // state[2] eps used   state[3] this call's largest error   state[4] this call's smallest margin   state[5] calls   state[6] redone calls
+// state[7] largest |guard value| ever seen
+// guard (optional): `guard_count` floats whose magnitudes must stay <= guard_limit for the caller's bound on |first pass - fp32| to
+// hold (the proved mode passes the batch's gq' rows: rails_amd/f16x3_bound.py); a larger one, or a NaN, raises REDO like a failed margin.
 __global__ __launch_bounds__(256) void rescore_verdict_kernel(const float* __restrict__ row_stats, int rows, float default_eps, float safety,
+                                                              const float* __restrict__ guard, int64_t guard_count, float guard_limit,
                                                               float* __restrict__ state) {
-  __shared__ float s_err[256], s_gap[256];
+  __shared__ float s_err[256], s_gap[256], s_grd[256];
   __shared__ int s_bad[256];
-  float err = 0.0f, gap = INFINITY;
+  float err = 0.0f, gap = INFINITY, grd = 0.0f;
   int bad = 0;
   for (int r = threadIdx.x; r < rows; r += 256) {
     const float e = row_stats[2 * r], g = row_stats[2 * r + 1];
@@ -1513,12 +1517,18 @@ __global__ __launch_bounds__(256) void rescore_verdict_kernel(const float* __res
     err = fmaxf(err, e);
     gap = fminf(gap, g);
   }
-  s_err[threadIdx.x] = err; s_gap[threadIdx.x] = gap; s_bad[threadIdx.x] = bad;
+  for (int64_t i = threadIdx.x; i < guard_count; i += 256) {
+    const float v = fabsf(guard[i]);
+    if (!(v <= guard_limit)) bad = 1;           // too large, or NaN
+    grd = fmaxf(grd, v == v ? v : INFINITY);
+  }
+  s_err[threadIdx.x] = err; s_gap[threadIdx.x] = gap; s_bad[threadIdx.x] = bad; s_grd[threadIdx.x] = grd;
   __syncthreads();
   for (int w = 128; w > 0; w >>= 1) {
     if ((int)threadIdx.x < w) {
       s_err[threadIdx.x] = fmaxf(s_err[threadIdx.x], s_err[threadIdx.x + w]);
       s_gap[threadIdx.x] = fminf(s_gap[threadIdx.x], s_gap[threadIdx.x + w]);
+      s_grd[threadIdx.x] = fmaxf(s_grd[threadIdx.x], s_grd[threadIdx.x + w]);
       s_bad[threadIdx.x] |= s_bad[threadIdx.x + w];
     }
     __syncthreads();
@@ -1536,11 +1546,14 @@ __global__ __launch_bounds__(256) void rescore_verdict_kernel(const float* __res
     state[4] = gap;
     state[5] += 1.0f;
     if (redo) state[6] += 1.0f;
+    state[7] = fmaxf(state[7], s_grd[0]);
   }
 }
 
-int rescore_verdict(const float* row_stats, int rows, float default_eps, float safety, float* state, hipStream_t stream) {
-  hipLaunchKernelGGL(rescore_verdict_kernel, dim3(1), dim3(256), 0, stream, row_stats, rows, default_eps, safety, state);
+int rescore_verdict(const float* row_stats, int rows, float default_eps, float safety, const float* guard, int64_t guard_count, float guard_limit,
+                    float* state, hipStream_t stream) {
+  hipLaunchKernelGGL(rescore_verdict_kernel, dim3(1), dim3(256), 0, stream, row_stats, rows, default_eps, safety, guard, guard ? guard_count : 0,
+                     guard_limit, state);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

@@ -841,11 +841,53 @@ def range_flag(values: torch.Tensor, lo: int, hi: int, flag: torch.Tensor) -> No
         _lib.check(lib.rails_range_flag_i32(_ptr(values), values.numel(), int(lo), int(hi), _ptr(flag), _stream()), "rails_range_flag_i32")
 
 
-def rescore_verdict(stats: torch.Tensor, state: torch.Tensor, default_eps: float, safety: float) -> None:
-    """Device-side verdict of a speculative call (rails_rescore_verdict): updates `state` (8 fp32 on the device) in stream order."""
+def rescore_verdict(stats: torch.Tensor, state: torch.Tensor, default_eps: float, safety: float,
+                    guard: Optional[torch.Tensor] = None, guard_limit: float = 0.0) -> None:
+    """Device-side verdict of a speculative call (rails_rescore_verdict): updates `state` (8 fp32 on the device) in stream order.
+    guard: fp32 values (contiguous) whose magnitudes must stay <= guard_limit, else the call is flagged for the redo."""
     lib = _lib.load()
     with _on_device(stats.device):
-        _lib.check(lib.rails_rescore_verdict(_ptr(stats), stats.shape[0], float(default_eps), float(safety), _ptr(state), _stream()), "rails_rescore_verdict")
+        _lib.check(lib.rails_rescore_verdict(_ptr(stats), stats.shape[0], float(default_eps), float(safety), _ptr(guard),
+                                             0 if guard is None else guard.numel(), float(guard_limit), _ptr(state), _stream()), "rails_rescore_verdict")
+
+
+def mfma_probe_f16(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+    """n x (32 x 16) f16, n x (16 x 32) f16, n x (32 x 32) fp32 -> n x (32 x 32) fp32: one v_mfma_f32_32x32x16_f16 each (rails_mfma_probe_f16)."""
+    lib = _lib.load()
+    _require_device(a, "a")
+    a, b, c = a.to(torch.float16).contiguous(), b.to(torch.float16).contiguous(), _f32c(c)
+    n = a.shape[0]
+    if tuple(a.shape) != (n, 32, 16) or tuple(b.shape) != (n, 16, 32) or tuple(c.shape) != (n, 32, 32):
+        raise ValueError("mfma_probe_f16: a (n, 32, 16), b (n, 16, 32), c (n, 32, 32)")
+    d = torch.empty_like(c)
+    with _on_device(a.device):
+        _lib.check(lib.rails_mfma_probe_f16(_ptr(a), _ptr(b), _ptr(c), _ptr(d), n, _stream()), "rails_mfma_probe_f16")
+    return d
+
+
+def mfma_probe_f32(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
+    """n x (32 x 2), n x (2 x 32), n x (32 x 32) fp32 -> n x (32 x 32): one v_mfma_f32_32x32x2_f32 each (rails_mfma_probe_f32)."""
+    lib = _lib.load()
+    _require_device(a, "a")
+    a, b, c = _f32c(a), _f32c(b), _f32c(c)
+    n = a.shape[0]
+    if tuple(a.shape) != (n, 32, 2) or tuple(b.shape) != (n, 2, 32) or tuple(c.shape) != (n, 32, 32):
+        raise ValueError("mfma_probe_f32: a (n, 32, 2), b (n, 2, 32), c (n, 32, 32)")
+    d = torch.empty_like(c)
+    with _on_device(a.device):
+        _lib.check(lib.rails_mfma_probe_f32(_ptr(a), _ptr(b), _ptr(c), _ptr(d), n, _stream()), "rails_mfma_probe_f32")
+    return d
+
+
+def scalar_probe(x: torch.Tensor) -> torch.Tensor:
+    """(n,) fp32 -> (3, n): v_exp_f32(x), v_rcp_f32(x), x / (1 + 2^x) as the scoring kernels compute it (rails_scalar_probe_f32)."""
+    lib = _lib.load()
+    _require_device(x, "x")
+    x = _f32c(x).reshape(-1)
+    out = torch.empty((3, x.numel()), dtype=torch.float32, device=x.device)
+    with _on_device(x.device):
+        _lib.check(lib.rails_scalar_probe_f32(_ptr(x), x.numel(), _ptr(out), _stream()), "rails_scalar_probe_f32")
+    return out
 
 
 def rescore_select(exact: torch.Tensor, approx: torch.Tensor, positions: torch.Tensor, ids: Optional[torch.Tensor], n_items: int, k: int,

@@ -324,6 +324,7 @@ class MoLSimilarity(SimilarityModule):
         self._engine: Optional[MolEngine] = None
         self._engine_key = None
         self._param_list = None
+        self._extra_engines: Dict[str, tuple] = {}
         # None -> RAILS_PRECISION or "fp32" (exact fp32 MFMA, the parity path); "f16x3" -> opt-in split-f16 gate MLP
         self.precision: Optional[str] = None
 
@@ -371,8 +372,10 @@ class MoLSimilarity(SimilarityModule):
             gating_item_fn=has_i,
         )
 
-    def engine(self) -> MolEngine:
-        """HIP engine bound to the CURRENT parameter values (rebuilt when any parameter changed)."""
+    def engine(self, precision: Optional[str] = None) -> MolEngine:
+        """HIP engine bound to the CURRENT parameter values (rebuilt when any parameter changed).  `precision` asks for an engine of
+        another precision than the module's own (the proved exact top-k keeps a split-f16 engine next to the fp32 one); each
+        precision has its own cached engine."""
         _eval_only(self)
         if not self._apply_query_embeddings_fn or not self._apply_item_embeddings_fn:
             raise NotImplementedError("apply_query_embeddings_fn / apply_item_embeddings_fn = False is not supported")
@@ -382,6 +385,15 @@ class MoLSimilarity(SimilarityModule):
         plist = self._param_list
         if plist is None:
             plist = self._param_list = [v for _, v in self.state_dict(keep_vars=True).items()]
+        if precision is not None and precision != self.precision:
+            key = (precision,) + tuple((v.data_ptr(), _version(v)) for v in plist)
+            hit = self._extra_engines.get(precision)
+            if hit is None or hit[0] != key:
+                params = dict(self.state_dict(keep_vars=True))
+                self._param_list = list(params.values())
+                key = (precision,) + tuple((v.data_ptr(), _version(v)) for v in self._param_list)
+                hit = self._extra_engines[precision] = (key, MolEngine(self.shape_spec(), params, precision=precision))
+            return hit[1]
         key = (self.precision,) + tuple((v.data_ptr(), _version(v)) for v in plist)
         if self._engine is None or key != self._engine_key:
             params = dict(self.state_dict(keep_vars=True))
@@ -401,6 +413,7 @@ class MoLSimilarity(SimilarityModule):
         self._param_list = None
         self._engine = None
         self._engine_key = None
+        self._extra_engines = {}
         return super().load_state_dict(*args, **kwargs)
 
     # ---- reference API --------------------------------------------------------------------------

@@ -71,11 +71,14 @@ class MoLTopKModule(TopKModule):
     def _bind(self) -> E.MolEngine:
         if self._call_eng is not None:   # inside one_bind(): the parameters were checked when the call began
             return self._call_eng
-        eng = self._mol_module.engine()
+        eng = self._engine_for_bind()
         if eng is not self._engine:  # first use, or the module's parameters changed
             self._engine = eng
             self._index = eng.build_index(self._item_embeddings[0])
         return eng
+
+    def _engine_for_bind(self) -> E.MolEngine:
+        return self._mol_module.engine()
 
     @contextlib.contextmanager
     def one_bind(self):
@@ -117,7 +120,10 @@ class MoLTopKModule(TopKModule):
 
 
 class MoLBruteForceTopK(MoLTopKModule):
-    def __init__(self, mol_module: MoLSimilarity, item_embeddings: torch.Tensor, item_ids: torch.Tensor) -> None:
+    def __init__(self, mol_module: MoLSimilarity, item_embeddings: torch.Tensor, item_ids: torch.Tensor, exact_mode: Optional[str] = None) -> None:
+        """exact_mode (not in the reference's signature, rails/indexing/mol_top_k.py:84-97): "proved" | "dense", default EXACT_MODE."""
+        if exact_mode not in (None, "proved", "dense"):
+            raise ValueError(f"exact_mode must be 'proved' or 'dense', got {exact_mode!r}")
         self._index32: Optional[E.MolIndex] = None          # precision "f16x3-exact": dense fp32 index (candidate gather, fallback)
         self._index32_engine = None
         self.keep_dense_fp32_index: Optional[bool] = self.KEEP_DENSE_FP32_INDEX
@@ -134,11 +140,76 @@ class MoLBruteForceTopK(MoLTopKModule):
         self._debug_first_pass_bias = None
         self._verdict_state: Optional[torch.Tensor] = None
         self._state_pending = None
-        self._pad_scale = 1           # candidate margin multiplier, doubled (up to 4) when a verification fails
+        self._pad_scale = 1           # candidate margin multiplier, doubled when a verification fails
         self._pause_left = 0
+        self.exact_mode: str = exact_mode or self.EXACT_MODE
+        self._proved_choice = None    # (fp32 engine the choice was made for, precision to bind or None)
+        self._gate_guard_limit: Optional[float] = None
         self._ok_event = None
         self._probe_n = -1
         super().__init__(mol_module=mol_module, item_embeddings=item_embeddings, item_ids=item_ids)
+
+    # ---- which arithmetic an exact top-k runs in -----------------------------------------------------------------------------------
+    # A module whose MoL precision is the default (fp32) returns the fp32 kernels' bits.  "proved" (the default): the split-f16 kernels
+    # pick the candidates, the fp32 kernels re-score them, and the a-priori bound of rails_amd/f16x3_bound.py on |first pass - fp32|
+    # proves per call, on the device, that nothing outside the candidates can belong to the result -- the dense fp32 path's output bit for
+    # bit at ~2.3 x its speed; a call that cannot be proved (crowded scores, a guard of the bound violated) is redone on the dense fp32
+    # kernels behind the verdict.  "dense": the fp32 kernels over the whole corpus, always.  RAILS_EXACT_MODE overrides the default.
+    # The proved mode needs both index formats resident (2 x the fp32 index bytes); corpora where that does not fit, corpora below
+    # SPECULATE_MIN_ITEMS and modules whose bound is infinite (see the guards in f16x3_bound.py) run "dense".
+    EXACT_MODE = __import__("os").environ.get("RAILS_EXACT_MODE", "proved")
+
+    def _engine_for_bind(self) -> E.MolEngine:
+        mol = self._mol_module
+        base = mol.engine()
+        if self.exact_mode != "proved" or base.precision != "fp32" or base.exact is not None:
+            return base
+        if self._proved_choice is None or self._proved_choice[0] is not base:
+            self._proved_choice = (base, "f16x3-exact" if self._proved_applies(base) else None)
+        want = self._proved_choice[1]
+        return mol.engine(want) if want else base
+
+    def _proved_applies(self, base: E.MolEngine) -> bool:
+        spec, N = base.spec, self._item_embeddings.shape[1]
+        if N < self.SPECULATE_MIN_ITEMS or N > 0xFFFFFFFF or not self._item_embeddings.is_cuda:
+            return False
+        if not math.isfinite(self._bound_from_weights(spec).get("eps", math.inf)):
+            return False
+        if not base.lib.rails_mol_shape_supported(E.C.byref(spec.to_c("f16x3"))):
+            return False
+        if self.keep_dense_fp32_index is False:
+            return False
+        need = base.lib.rails_mol_index_floats(E.C.byref(base.shape), N) * 4
+        free, _ = torch.cuda.mem_get_info(self._item_embeddings.device)
+        held = self._index.buf.numel() * 4 if self._index is not None else 0     # a rebind: the old index is dropped first
+        return free + held > 2 * need + min(32 * N * 4, self.MAX_LOGIT_BYTES) + (1 << 30)
+
+    def _bound_from_weights(self, spec) -> Dict[str, float]:
+        """rails_amd/f16x3_bound.py for this module's pair-gate weights; {"eps": inf} where a guard of the bound fails."""
+        from . import f16x3_bound as FB
+
+        if (not spec.dot_product_l2_norm or spec.gating_combination_type != "glu_silu" or spec.gating_qi_hidden_dim <= 0
+                or not (spec.gating_query_fn and spec.gating_item_fn)):
+            return {"eps": math.inf}
+        g = self._mol_module._gating_fn._qi_partial_module
+        lin = [m for m in g.modules() if isinstance(m, torch.nn.Linear)]
+        if len(lin) != 2:
+            return {"eps": math.inf}
+        zeros = lambda n: torch.zeros(n)
+        b1 = lin[0].bias if lin[0].bias is not None else zeros(lin[0].out_features)
+        b2 = lin[1].bias if lin[1].bias is not None else zeros(lin[1].out_features)
+        return FB.first_pass_bound(lin[0].weight, b1, lin[1].weight, b2, spec.temperature, spec.dot_product_dimension,
+                                   spec.query_dot_product_groups, spec.item_dot_product_groups)
+
+    def all_logits(self, query_embeddings: torch.Tensor, **kwargs) -> torch.Tensor:
+        """(B, N) fp32 MoL logits against the whole corpus -- of the module's OWN precision (the proved mode's internal split-f16
+        engine is not the module's precision: its fp32 companion answers)."""
+        eng = self._bind()
+        if eng.exact is not None and self._mol_module.engine() is not eng:
+            ex = eng.exact
+            qpack, _, _ = ex.query_pack(query_embeddings, kwargs.get("user_ids"))
+            return ex.score_dense(qpack, query_embeddings.size(0), self._dense_fp32_index())
+        return super().all_logits(query_embeddings, **kwargs)
 
     # Selection fused into the scoring kernels (rails_mol_score_topk): one scoring launch that appends the survivors of a running
     # per-query bound, one selection launch over the survivor lists -- no pass over (B, N) logits.  Same result bit for bit.
@@ -253,12 +324,25 @@ class MoLBruteForceTopK(MoLTopKModule):
         if k > N:
             raise RuntimeError(f"selected index k out of range (k={k}, n={N})")
         single = eng.dense_precision == "f16x1"
-        pad = (max(128, k // 2) if single else max(64, k // 4)) * self._pad_scale
-        kc = (k + pad + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS
-        if k <= 384:
-            kc = min(kc, 512)       # rails_topk's two-launch path ends at k = 512; beyond it a selection costs five reads of the logits
+        # The bound on |first pass - fp32|: A PRIORI for the f16x3 first pass (rails_amd/f16x3_bound.py: the call is then PROVED to
+        # return the dense fp32 result whenever its verdict clears); monitored and empirical for the one-product first pass, whose a-priori
+        # bound is vacuous.  A module whose a-priori bound is infinite (a guard fails) does not speculate.
+        eps_proved = None if single else self._proved_eps()
+        if eps_proved is not None and not math.isfinite(eps_proved):
+            self.rescore_stats["unprovable_calls"] = self.rescore_stats.get("unprovable_calls", 0) + 1
+            return self._forward_fp32_dense(query_embeddings, k, **kwargs)
+        if eps_proved is not None:
+            # candidates: every item within eps of the k-th score must be among them.  On the BASELINE shapes that is 1.3-2.2 k (k = 200:
+            # 260-430 items, k = 2 561: 3 200-4 900; tools/proved_candidate_census.py); a failed verdict doubles the margin
+            pad = max(312, k) * self._pad_scale
+            kc = min((k + pad + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS, 16384)
+        else:
+            pad = (max(128, k // 2) if single else max(64, k // 4)) * self._pad_scale
+            kc = (k + pad + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS
+            if k <= 384:
+                kc = min(kc, 512)       # rails_topk's two-launch path ends at k = 512; beyond it a selection costs five reads of the logits
         oversize = B * N * 4 > self.MAX_LOGIT_BYTES      # the 4 GiB logit policy comes first: no route below may materialise (B, N)
-        if kc >= N or k == 0 or kc > 16384 or N > 0xFFFFFFFF or N < self.SPECULATE_MIN_ITEMS or self._speculation_paused():
+        if kc >= N or k == 0 or kc > 16384 or k + E.TILE_ITEMS > kc or N > 0xFFFFFFFF or N < self.SPECULATE_MIN_ITEMS or self._speculation_paused():
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
         if oversize:                              # the speculative pass wants the whole (B, N) s16 matrix
             rows = self.MAX_LOGIT_BYTES // (N * 4)
@@ -281,13 +365,20 @@ class MoLBruteForceTopK(MoLTopKModule):
             c16, pos, status = eng.score_topk(qpack16, B, self._index, kc, logits_out=s16)
             E.topk(s16, kc, workspace=ws, out=(c16, pos), run_if=status)
         else:
+            hook = self._first_pass_hook        # measurement only (bench.py: events around the dominant launch, on its stream)
+            if hook is not None:
+                hook(0)
             eng.score_dense(qpack16, B, self._index, out=s16)
+            if hook is not None:
+                hook(1)
             if self._debug_first_pass_bias is not None:   # tests only: (positions, delta) -- the first pass is made to under-score these items
                 s16[:, self._debug_first_pass_bias[0]] -= self._debug_first_pass_bias[1]
             c16, pos = E.topk(s16, kc, workspace=ws)
-        # two more tiles per query of probes (random + highest-norm items), re-scored too, so that the bound |s16 - s32| <= eps is
-        # watched outside the candidates as well
-        pos = torch.cat([pos, *self._probes(B, N)], dim=1)
+        # two more tiles per query of probes (random + highest-norm items), re-scored too, so that the MONITORED bound |s16 - s32| <= eps is
+        # watched outside the candidates as well (the a-priori bound needs no watching: the candidates' own errors are still compared
+        # with it, and one above it is reported as a violation of the arithmetic model)
+        if eps_proved is None:
+            pos = torch.cat([pos, *self._probes(B, N)], dim=1)
         if self._index32 is not None and B * pos.shape[1] <= self.INDEXED_MAX_CANDIDATES and ex.score_indexed_supported(B, pos.shape[1]):
             # read the candidates in place from the fp32 index: one launch less and no gathered copy.  A candidate's 1 280 bytes are 80
             # pieces of 16 bytes in the tile-packed index, each in its own cache line, whoever fetches them -- the gather kernel paid
@@ -304,18 +395,28 @@ class MoLBruteForceTopK(MoLTopKModule):
             e32 = ex.score_candidates(qpack32, B, cand, pos.shape[1])
         scores, ids, _, stats = E.rescore_select(e32, c16, pos, self._ids_flat, N, k, approx_dense=s16)
         self.rescore_stats["calls"] += 1
+        self.rescore_stats["kc"] = kc
         # The bound eps on |s16 - s32|: never below the calibrated default, and SAFETY x the largest error this module has seen on its
         # candidates and probes (this call included) -- a model whose weights make the first pass coarser widens its own margin
         # instead of failing the monitor forever.  The row passes when its k-th exact score clears the best non-candidate by eps.
         default = (self.RESCORE_EPS_PER_INV_TEMPERATURE_F16X1 if single else self.RESCORE_EPS_PER_INV_TEMPERATURE) / eng.spec.temperature
         safety = self.SAFETY_F16X1 if single else self.SAFETY_F16X3
+        guard, guard_limit = None, 0.0
+        if eps_proved is not None:
+            # eps = the a-priori bound (safety 1: an observed error above it -- a violation of the model -- still widens the margin); the
+            # one data-dependent hypothesis of the bound, max |gq'| max |gi| <= gate_guard, is checked by the verdict kernel on the
+            # batch's gq' rows (behind the Eq fragments in the fp32 query pack)
+            default, safety = eps_proved, 1.0
+            sp = eng.spec
+            off = (B + 32 // sp.query_dot_product_groups - 1) // (32 // sp.query_dot_product_groups) * 32 * sp.dot_product_dimension
+            guard, guard_limit = qpack32[off : off + B * sp.num_logits], self._gate_guard_limit
         if self._index32 is not None and self._index32_engine is ex and self.DEVICE_VERDICT:
             # Verdict and fallback ON THE DEVICE: rails_rescore_verdict folds the row stats into the calibration state and writes the
             # REDO flag; the dense fp32 pass and its top-k are enqueued behind it under that flag as their launch predicate (no-ops
             # unless the verification failed) and overwrite (scores, ids).  The host never waits; it looks at a snapshot of the
             # state when the NEXT call starts (statistics, candidate margin, pause logic).
             state = self._state()
-            E.rescore_verdict(stats, state, default, safety)
+            E.rescore_verdict(stats, state, default, safety, guard, guard_limit)
             redo = state.view(torch.int32)[1:2]
             l32 = ex.score_dense(qpack32, B, self._index32, out=self._buf("logits", B * N, torch.float32).view(B, N), run_if=redo)
             E.topk(l32, k, ids=self._ids_flat, workspace=ws, out=(scores, ids), run_if=redo)
@@ -328,6 +429,12 @@ class MoLBruteForceTopK(MoLTopKModule):
                 self._err_seen = max(err, self._err_seen)   # never forgotten: a rare outlier keeps the margin wide until the engine changes
             eps = max(default, safety * self._err_seen)
             good = err == err and err != float("inf") and gap > eps
+            if guard is not None and good:      # the bound's data-dependent guard, on the host in this (index-less) variant
+                gmax = float(guard.abs().max())
+                self.rescore_stats["guard_max"] = max(self.rescore_stats.get("guard_max", 0.0), gmax)
+                good = gmax <= guard_limit
+            if eps_proved is not None:
+                self._count_proved(1 if good else 0)
             self.rescore_stats["eps"] = eps
             self._note_verdict(good, k, kc)
             if not good:
@@ -343,7 +450,10 @@ class MoLBruteForceTopK(MoLTopKModule):
         self._recent.append(good)
         if not good:
             self.rescore_stats["fallbacks"] += 1
-            if self._pad_scale < 4 and not (k <= 384 and kc >= 512):
+            if self._proved_eps_cache is not None and self._proved_eps_cache[1] is not None:
+                if kc < 16384:
+                    self._pad_scale *= 2      # proved mode: the candidates must cover everything within eps of the k-th score
+            elif self._pad_scale < 4 and not (k <= 384 and kc >= 512):
                 self._pad_scale *= 2          # crowded scores or a coarse first pass: more candidates from the next call on
 
     def _state(self) -> torch.Tensor:
@@ -372,10 +482,65 @@ class MoLBruteForceTopK(MoLTopKModule):
         self._state_seen = (calls, redone)
         self._err_seen = max(self._err_seen, float(h[0]))
         self.rescore_stats["eps"] = float(h[2])
+        self.rescore_stats["guard_max"] = max(self.rescore_stats.get("guard_max", 0.0), float(h[7]))
         k, kc = self._state_pending
         self._state_pending = None
         for i in range(new_calls):
             self._note_verdict(i >= new_redone, k, kc)
+        if self._proved_eps_cache is not None and self._proved_eps_cache[1] is not None:
+            self._count_proved(new_calls - new_redone)
+
+    _first_pass_hook = None
+    _proved_eps_cache = None      # (engine, eps as the float32 handed to the verdict or None: monitored mode)
+
+    def _proved_eps(self) -> Optional[float]:
+        """The a-priori bound for the bound engine, rounded UP to a float32 (the verdict compares in fp32: gap = fl(e_k - m) > eps, one
+        rounding of relative 2^-24 on a gap of at most 2 / tau -- covered by the 2^-16 relative slack added here), or inf when a
+        guard fails.  Computed once per engine; also fixes the device-side guard limit GATE_GUARD / max |gi| from the item index."""
+        eng = self._engine
+        if self._proved_eps_cache is not None and self._proved_eps_cache[0] is eng:
+            return self._proved_eps_cache[1]
+        from . import f16x3_bound as FB
+
+        eps = float(self._bound_from_weights(eng.spec).get("eps", math.inf))
+        if math.isfinite(eps):
+            eps32 = torch.tensor(eps * (1.0 + 2.0 ** -16), dtype=torch.float32)
+            eps = float(torch.nextafter(eps32, torch.tensor(float("inf"))))
+            gi_max = self._gi_abs_max()
+            self._gate_guard_limit = min(FB.GATE_GUARD / gi_max, 3.0e38) if gi_max > 0.0 else 3.0e38
+            if not math.isfinite(gi_max):
+                eps = math.inf
+        self._proved_eps_cache = (eng, eps)
+        self.rescore_stats["proved_calls"] = 0
+        self.rescore_stats["bound_violations"] = 0
+        return eps
+
+    def _gi_abs_max(self) -> float:
+        """max |gi| over the corpus, from the item-gate rows of the tile-packed index (fp32 in both formats; padding rows are zero).
+        Once per index: metadata of the bound, not part of the scoring path."""
+        idx = self._index
+        tiles = (idx.n_items + E.TILE_ITEMS - 1) // E.TILE_ITEMS
+        if tiles == 0:
+            return 0.0
+        tf = idx.buf.numel() // tiles
+        gi_f = E.TILE_ITEMS * self._engine.spec.num_logits
+        view = idx.buf.view(tiles, tf)[:, tf - gi_f :]
+        best = 0.0
+        for t0 in range(0, tiles, 1 << 16):
+            lo, hi = torch.aminmax(view[t0 : t0 + (1 << 16)])
+            lo, hi = float(lo), float(hi)
+            if lo != lo or hi != hi:
+                return math.inf
+            best = max(best, -lo, hi)
+        return best
+
+    def _count_proved(self, n_clear: int) -> None:
+        """Calls whose verdict cleared count as PROVED while no observed |first pass - fp32| has exceeded the a-priori bound."""
+        eps = self._proved_eps_cache[1]
+        if self._err_seen > eps:
+            self.rescore_stats["bound_violations"] = self.rescore_stats.get("bound_violations", 0) + 1
+            return
+        self.rescore_stats["proved_calls"] = self.rescore_stats.get("proved_calls", 0) + max(0, n_clear)
 
     def stats(self) -> Dict[str, float]:
         """rescore_stats brought up to date with the device-side verdicts and the audit counter (synchronises), plus the a-priori
@@ -388,46 +553,30 @@ class MoLBruteForceTopK(MoLTopKModule):
         return out
 
     def rigorous_eps(self) -> Dict[str, float]:
-        """An A-PRIORI bound on |first pass - fp32 logit| that holds for EVERY (query, item) pair, from the weights alone
-        (dot_product_l2_norm = True: |cl| <= 1/tau).  Per product of two rounded operands the relative error is rho = 2u + u^2, with
-        u = 2^-10 for the one-product pass (operands truncated to f16) and ~2^-21 for f16x3 (hi + lo halves, lo*lo dropped: rho taken
-        as 2^-20).  Propagated with row-L1 norms through the path (rails/similarities/mol/similarity_fn.py:389-413):
-            |d cl|  <= rho / tau
-            |d pre| <= A1 (2 rho + rho^2) / tau                      A1 = max_h ||W1[h, :]||_1   (cl is rounded again as GEMM2's operand)
-            |d gqi| <= A2 (1.1 |d pre| + rho P)                      A2 = max_l ||W2[l, :]||_1,  P = max_h (|b1[h]| + ||W1[h, :]||_1 / tau) >= |hid|,
-                                                                     |silu'| <= 1.1
-            |d w|   <= 1.1 |d gqi|                                   (w = g sigmoid(g); gq, gi are the same fp32 values in both passes)
-            |d s|   <= |d cl| + min(2, 2 |d w|) / tau                (||softmax(w + d) - softmax(w)||_1 <= 2 ||d||_inf, and <= 2 trivially)
-        The verified modes could drop their monitored, empirical eps for this number only where it is not far larger -- it is: the
-        bound adds absolute values where the real errors cancel (random-init amzn-books: 40.0 for the one-product pass, i.e. the
-        trivial |s| <= 1/tau bound, and ~0.2 for f16x3, against observed maxima of 5e-2 and 3e-5).  It is reported so that the
-        guarantee's status is explicit: `eps_rigorous_usable` is False and the modes stay "conditional on the monitored bound"."""
+        """The A-PRIORI bound on |first pass - fp32 logit| that holds for EVERY (query, item) pair, from the pair-gate weights alone
+        (rails_amd/f16x3_bound.py, which states the arithmetic model and the propagation; oracle/f16x3_bound.py restates it and
+        tests/test_f16x3_bound_cpu.py checks it against float64 evaluations of both arithmetics).
+          eps_rigorous          the bound for this module's first pass: finite for the f16x3 pass of a glu_silu module with a hidden pair-gate
+                                layer and l2-normalised components (random-init amzn-books: ~0.7 on logits in [-20, 20], against an observed
+                                maximum of 3e-5 -- the bound adds absolute values where the real roundings cancel); infinite otherwise,
+                                and for the one-product pass "f16-exact", whose operands carry 11 bits (its bound is the trivial 2 / tau).
+          eps_rigorous_usable   True iff the verified top-k of this module RUNS on that bound: the verdicts then compare e_k - m with
+                                eps_rigorous itself and a cleared call is proved, not merely monitored.
+          eps_default           the calibrated empirical eps of the monitored modes, for comparison."""
         eng = self._bind()
         cached = getattr(self, "_rig_cache", None)
         if cached is not None and cached[0] is eng:
             return cached[1]
-        spec = eng.spec
-        sd = self._mol_module.state_dict()
         single = eng.dense_precision == "f16x1"
-        rho = 2.0 ** -9 + 2.0 ** -20 if single else 2.0 ** -20
-        inv_tau = 1.0 / float(spec.temperature)
-        out: Dict[str, float] = {}
-        w1, b1 = sd.get("_gating_fn._qi_partial_module.1.weight"), sd.get("_gating_fn._qi_partial_module.1.bias")
-        w2 = sd.get("_gating_fn._qi_partial_module.3.weight")
-        if w1 is None or w2 is None or not spec.dot_product_l2_norm:
-            out = {"eps_rigorous": float("inf"), "eps_rigorous_usable": False}
+        inv_tau = 1.0 / float(eng.spec.temperature)
+        default = (self.RESCORE_EPS_PER_INV_TEMPERATURE_F16X1 if single else self.RESCORE_EPS_PER_INV_TEMPERATURE) * inv_tau
+        if single:
+            out = {"eps_rigorous": 2.0 * inv_tau, "eps_default": default, "eps_rigorous_usable": False}
         else:
-            r1 = w1.float().abs().sum(1)
-            a1, a2 = float(r1.max()), float(w2.float().abs().sum(1).max())
-            p = float((b1.float().abs() + r1 * inv_tau).max())
-            d_cl = rho * inv_tau
-            d_pre = a1 * (2.0 * rho + rho * rho) * inv_tau
-            d_gqi = a2 * (1.1 * d_pre + rho * p)
-            d_w = 1.1 * d_gqi
-            bound = d_cl + min(2.0, 2.0 * d_w) * inv_tau
-            default = (self.RESCORE_EPS_PER_INV_TEMPERATURE_F16X1 if single else self.RESCORE_EPS_PER_INV_TEMPERATURE) * inv_tau
-            out = {"eps_rigorous": bound, "eps_default": default, "eps_rigorous_usable": bool(bound <= 4.0 * default),
-                   "eps_rigorous_terms": {"rho": rho, "A1": a1, "A2": a2, "P": p, "d_cl": d_cl, "d_pre": d_pre, "d_gqi": d_gqi, "d_w": d_w}}
+            terms = self._bound_from_weights(eng.spec)
+            bound = float(terms.get("eps", math.inf))
+            out = {"eps_rigorous": bound, "eps_default": default, "eps_rigorous_usable": bool(math.isfinite(bound) and eng.exact is not None),
+                   "eps_rigorous_terms": {k: v for k, v in terms.items() if k != "eps"}}
         self._rig_cache = (eng, out)
         return out
 

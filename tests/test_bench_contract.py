@@ -69,7 +69,7 @@ def test_committed_round4_bench_line_carries_the_quality_half():
     assert "N=125000000" in two_pass["workload"] and 0.3 < two_pass["recall"]["recall@10"] <= 1.0 and 0.2 < two_pass["recall"]["recall@120"] <= 1.0
     for mode in ("f16-exact", "f16x3-exact"):
         e = d["exact_fast_path"][mode]
-        assert e["output_identical_to_fp32_path"] is True and e["eps_rigorous"] > e["eps"] and e["eps_rigorous_usable"] is False
+        assert e["output_identical_to_fp32_path"] is True and e["eps_rigorous"] > e["eps"]     # (round 4 ran the verdicts on the monitored eps; round 5 runs them on the a-priori one)
     assert two_pass["pipelined"]["output_equal_to_unpipelined"] is True and two_pass["pipelined"]["ms_per_step"] <= two_pass["ms_per_step"] * 1.02
     tp = json.load(open(os.path.join(ROOT, "profiles", "r04_two_pass_125m.json")))
     assert tp["roofline"]["bound"] == "hbm" and 0 < tp["roofline"]["frac"] < 1 and 0.3 < tp["recall"]["recall@10"] <= 1.0
@@ -86,6 +86,13 @@ def test_live_bench_line():
     d = json.loads(lines[0])
     check_line(d, expect_cpu_baseline=False)
     assert d["steps"] == 3 and d["warmup"] == 1 and d["n_gpus"] == 1
+    # round 5: `value` is the PROVED exact path (the module's default) -- every timed call proved on the device with the a-priori bound, output identical
+    # to the dense fp32 kernels', which are timed beside it; the roofline is the split-f16 first pass against a third of the f16 MFMA peak
+    pr = d["proved"]
+    assert pr["is_headline"] is True and pr["output_identical_to_fp32_path"] is True and pr["proved_calls"] == pr["timed_calls"] == 3
+    assert pr["dense_fp32_fallbacks"] == 0 and pr["bound_violations"] == 0 and 0 < pr["eps_a_priori"] < 2.0
+    assert d["value"] == pr["value"] and d["fp32_dense"]["value"] < d["value"] and d["config"]["prefilter"] == "f16x3, a-priori eps"
+    assert abs(d["roofline"]["peak"] - 2500 / 3) < 1e-6 and "F16Unit" in d["roofline"]["kernel"] and d["fp32_dense"]["roofline"]["peak"] < 200
     # the quality half of BASELINE.json's metric ("+ HR@10/50 parity") rides on the line: HIP path vs the CPU oracle chain, row by row
     hp = d["hr_parity"]
     assert hp["parity"] is True and hp["identical_rows"] + hp["rows_differing_only_inside_oracle_ties"] == hp["rows"] == d["config"]["global_batch"]

@@ -1,0 +1,123 @@
+"""CPU property tests of the a-priori bound of the proved exact top-k (rails_amd/f16x3_bound.py):
+  * the product's bound == the oracle's independent restatement, term by term, on every BASELINE shape and every stress family;
+  * |emulated fp32 kernel - float64| <= eps32 and |emulated f16x3 kernel (adversarial MFMA rounding) - float64| <= eps16, for the logit
+    AND for every intermediate stage (cl, t, q) against the stage bounds the derivation goes through;
+  * the building blocks: the operand-split constants, phi's Lipschitz constant, the softmax-mixture Lipschitz bound.
+The same families run on the GPU against the real kernels (tests/test_proved_gpu.py)."""
+import dataclasses
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import f16x3_bound as OB
+from oracle import mol_oracle as O
+from rails_amd import f16x3_bound as FB
+
+SHAPES = ["amzn-books", "ml-1m", "ml-20m", "synthetic-16x16x64", "synthetic-8x8x32"]
+STRESS = ["gaussian", "outlier", "hot gate", "near overflow", "tiny components"]
+EMU_KAPPA = 3.0     # the emulated MFMA errs by up to 1.5 ulp of its result = 3 u |D|
+
+
+def _case(workload: str, kind: str, seed: int):
+    cfg = O.CONFIGS[workload]
+    if cfg.uid_embedding_hash_sizes:
+        cfg = dataclasses.replace(cfg, uid_embedding_hash_sizes=(63,))
+    w = O.synthetic_weights(cfg, seed=seed, uid_rows=64 if cfg.uid_embedding_hash_sizes else None)
+    w, item_scale = OB.stress_weights(w, kind, seed)
+    p = "_gating_fn._qi_partial_module."
+    args = (w[p + "1.weight"], w[p + "1.bias"], w[p + "3.weight"], w[p + "3.bias"], cfg.temperature, cfg.dot_product_dimension,
+            cfg.query_dot_product_groups, cfg.item_dot_product_groups)
+    return cfg, w, item_scale, args
+
+
+@pytest.mark.parametrize("kind", STRESS)
+@pytest.mark.parametrize("workload", SHAPES)
+def test_product_bound_equals_the_restatement(workload, kind):
+    _, _, _, args = _case(workload, kind, seed=3)
+    a = FB.first_pass_bound(*args)
+    b = OB.first_pass_bound(*(np.asarray(t) if torch.is_tensor(t) else t for t in args))
+    if math.isinf(a["eps"]):
+        assert math.isinf(b["eps"])
+    for key in ("eps", "eps16", "eps32", "d_cl16", "d_cl32", "d_t16", "d_t32", "d_q16", "d_q32", "d_w16", "d_w32"):
+        if key in a and math.isfinite(a[key]):
+            assert a[key] == pytest.approx(b[key], rel=1e-9), key
+    assert a["in_f16_range"] == b["in_f16_range"]
+
+
+@pytest.mark.parametrize("kind", STRESS)
+@pytest.mark.parametrize("workload", SHAPES)
+def test_emulated_arithmetics_stay_inside_the_bound(workload, kind):
+    cfg, w, item_scale, args = _case(workload, kind, seed=4)
+    big = cfg.num_logits > 64
+    B, X = (2, 6) if big else (4, 24)
+    q = O.synthetic_queries(cfg, B, seed=7)
+    items = torch.from_numpy(O.hash_item_table(9, 0, X, cfg.item_embedding_dim)) * item_scale
+    uid = torch.arange(1, B + 1) if cfg.uid_embedding_hash_sizes else None
+    eqp, ex, gqp, gi = OB.pair_operands(cfg, w, q, items, uid)
+    w1p, b1p, w2, b2p = OB.prescale(*(np.asarray(t) for t in args[:4]))
+    bound = OB.first_pass_bound(*(np.asarray(t) if torch.is_tensor(t) else t for t in args), kappa=EMU_KAPPA)
+    assert float(np.abs(gqp * gi).max()) <= OB.GATE_GUARD          # the data-dependent guard holds for these inputs
+    ref = OB.exact64(eqp, ex, gqp, gi, w1p, b1p, w2, b2p)
+    e32 = OB.emulate_fp32(eqp, ex, gqp, gi, w1p, b1p, w2, b2p, cfg.query_dot_product_groups, cfg.item_dot_product_groups, seed=1)
+    e16 = OB.emulate_f16x3(eqp, ex, gqp, gi, w1p, b1p, w2, b2p, cfg.query_dot_product_groups, cfg.item_dot_product_groups, seed=1)
+    if not bound["in_f16_range"]:
+        pytest.skip("operands leave the f16 range: the bound is infinite and the product does not speculate")
+    rows = []
+    for name, emu, tag in (("fp32", e32, "32"), ("f16x3", e16, "16")):
+        d_cl = float(np.abs(emu["cl"] - ref["cl"]).max())
+        d_t = np.abs(emu["t"] - ref["t"]).max(0)
+        d_q = np.abs(emu["q"] - ref["q"]).max(0)
+        d_s = float(np.abs(emu["s"] - ref["s"]).max())
+        rows.append((name, d_cl / bound["d_cl" + tag], float((d_t / bound["per_h"]["d_t" + tag]).max()), float((d_q / bound["per_l"]["d_q" + tag]).max()), d_s / bound["eps" + tag]))
+        assert np.isfinite(emu["s"]).all()
+        assert d_cl <= bound["d_cl" + tag]
+        assert (d_t <= bound["per_h"]["d_t" + tag]).all()
+        assert (d_q <= bound["per_l"]["d_q" + tag]).all()
+        assert d_s <= bound["eps" + tag]
+    assert float(np.abs(e16["s"] - e32["s"]).max()) <= bound["eps"]
+    print(workload, kind, "observed / bound (cl, t, q, s):", [(n, f"{a:.2e}", f"{b:.2e}", f"{c:.2e}", f"{d:.2e}") for n, a, b, c, d in rows], "eps", round(bound["eps"], 4))
+
+
+def test_operand_split_constants():
+    """|x - hi - lo| <= R |x| + A and |lo| <= LAM |x| + A' for both split flavours, over normal, tiny (f16-subnormal) and large values"""
+    g = np.random.default_rng(0)
+    x = np.concatenate([g.standard_normal(200_000) * s for s in (1e-7, 1e-5, 1e-3, 1.0, 50.0, 6.0e4)]).astype(np.float32)
+    x = x[np.abs(x) < 65000]
+    for kernel in (True, False):
+        hi, lo = OB.split_f16(x, kernel)
+        r, a, lam, a2 = OB._split_constants(kernel)
+        x64 = x.astype(np.float64)
+        assert (np.abs(x64 - hi - lo) <= r * np.abs(x64) + a).all()
+        assert (np.abs(lo) <= lam * np.abs(x64) + a2).all()
+        assert (np.abs(hi) <= np.abs(x64)).all()
+
+
+def test_phi_lipschitz_and_magnitude():
+    t = np.linspace(-200.0, 200.0, 2_000_001)
+    phi = OB._phi64(t)
+    assert np.abs(np.diff(phi) / np.diff(t)).max() <= OB.LIP
+    assert (np.abs(phi) <= np.abs(t) + 1e-300).all()
+
+
+def test_mixture_lipschitz_bound():
+    """|f(w + delta, c) - f(w, c)| <= max |delta| (max c - min c) / 2 for f = sum softmax(w) c: random and adversarial (two-cluster) cases"""
+    g = np.random.default_rng(1)
+    worst = 0.0
+    for trial in range(4000):
+        L = int(g.integers(2, 65))
+        w = g.standard_normal(L) * g.choice([0.1, 1.0, 10.0])
+        c = g.standard_normal(L) * 20.0
+        a = 10.0 ** g.uniform(-6, 0.5)
+        delta = g.choice([-a, a], L) if trial % 2 else g.uniform(-a, a, L)
+        if trial % 4 == 3:       # extremal: delta follows the sign of c - median, weights split evenly between two atoms
+            c = np.where(np.arange(L) % 2 == 0, -20.0, 20.0)
+            w = np.zeros(L)
+            delta = np.where(c > 0, a, -a)
+        sm = lambda v: np.exp(v - v.max()) / np.exp(v - v.max()).sum()
+        lhs = abs((sm(w + delta) * c).sum() - (sm(w) * c).sum())
+        rhs = a * (c.max() - c.min()) / 2
+        worst = max(worst, lhs / rhs)
+        assert lhs <= rhs * (1 + 1e-9)
+    assert worst > 0.5      # the bound is approached: it is not vacuous

@@ -1,0 +1,266 @@
+"""The PROVED exact top-k on the GPU: the arithmetic model behind the a-priori bound of rails_amd/f16x3_bound.py measured on the part
+(hypotheses H1-H3), |first pass - fp32| against the bound on stressed models, and the module -- first pass on the split-f16 kernels,
+fp32 re-scoring, device verdict with the a-priori eps -- against the dense fp32 path, bit for bit, on every BASELINE shape.
+Reference call site replaced: rails/indexing/mol_top_k.py:99-130 (MoLBruteForceTopK.forward)."""
+import dataclasses
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import rails_amd
+from oracle import f16x3_bound as OB
+from oracle import mol_oracle as O
+from rails_amd import engine as E
+from rails_amd import f16x3_bound as FB
+from tests._fixtures import Fixture, full_size_inputs
+from tests.test_gpu_parity import build_module
+
+pytestmark = pytest.mark.gpu
+U = 2.0 ** -24
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+# ---- H2: one v_mfma_f32_32x32x16_f16 ---------------------------------------------------------------------------------------------
+def _f16_families(g):
+    """(name, a (n, 32, 16) f16, b (n, 16, 32) f16, c (n, 32, 32) fp32): operand sets that stress the accumulation inside the instruction"""
+    n = 64
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    fam = []
+    a, b = rnd(n, 32, 16), rnd(n, 16, 32)
+    fam.append(("gaussian, C ~ 1", a, b, rnd(n, 32, 32)))
+    fam.append(("gaussian, C ~ 100", a, b, 100 * rnd(n, 32, 32)))
+    fam.append(("gaussian, C ~ 1e-3", a, b, 1e-3 * rnd(n, 32, 32)))
+    fam.append(("same sign, C = 0", a.abs(), b.abs(), torch.zeros(n, 32, 32)))
+    ea = torch.randint(-12, 5, (n, 32, 16), generator=g).float()
+    eb = torch.randint(-12, 5, (n, 16, 32), generator=g).float()
+    fam.append(("mixed exponents 2^-12 .. 2^4", (1 + torch.rand(n, 32, 16, generator=g)) * 2 ** ea, (1 + torch.rand(n, 16, 32, generator=g)) * 2 ** eb * torch.sign(rnd(n, 16, 32)), rnd(n, 32, 32)))
+    fam.append(("large C, small products", 2.0 ** -5 * a, 2.0 ** -5 * b, 1024 * (1 + torch.rand(n, 32, 32, generator=g))))
+    fam.append(("lo x hi block: |a| ~ 2^-10", 2.0 ** -10 * a, b, 20 * rnd(n, 32, 32)))
+    sub = torch.randint(1, 1024, (n, 32, 16), generator=g).float() * 2.0 ** -24        # f16 subnormals
+    fam.append(("f16 subnormal operands", sub, 16 * b, torch.zeros(n, 32, 32)))
+    half = rnd(n, 32, 8)
+    fam.append(("cancelling pairs", torch.cat([half, -half], 2), torch.cat([b[:, :8], b[:, :8]], 1), rnd(n, 32, 32)))
+    return [(name, x.half(), y.half(), z.float()) for name, x, y, z in fam]
+
+
+def test_f16_mfma_accumulation_model(dev):
+    """H2: D = C + sum_16 a_i b_i + e with |e| <= KAPPA u (|C| + sum |a_i b_i|).  The largest ratio e / (u (...)) over operand
+    families that stress alignment, cancellation and subnormals must stay below KAPPA / 2; f16 subnormal operands must be kept."""
+    g = torch.Generator().manual_seed(0)
+    worst = 0.0
+    for name, a, b, c in _f16_families(g):
+        d = E.mfma_probe_f16(a.to(dev), b.to(dev), c.to(dev)).cpu().double()
+        a64, b64, c64 = a.double(), b.double(), c.double()
+        exact = c64 + a64 @ b64                                  # products of f16 are exact in float64, the sum is good to 2^-53
+        mag = c64.abs() + a64.abs() @ b64.abs()
+        ratio = float(((d - exact).abs() / (U * mag).clamp_min(1e-300)).max())
+        one_rounding = float(((d - exact).abs() / (U * exact.abs()).clamp_min(1e-300)).max())
+        print(f"f16 MFMA  {name:34s} max |e| / (u mag) = {ratio:.3f}   max |e| / (u |D|) = {one_rounding:.3f}")
+        worst = max(worst, ratio)
+        if "subnormal" in name:
+            assert float(d.abs().max()) > 0 and ratio <= 1.0, "f16 subnormal operands are flushed"
+    print("f16 MFMA worst ratio", worst, "KAPPA", FB.KAPPA)
+    assert worst <= FB.KAPPA / 2
+
+
+def test_fp32_mfma_is_a_chain_of_fmas(dev):
+    """H1 for one instruction: v_mfma_f32_32x32x2_f32 returns C + a0 b0 + a1 b1 within the error of two round-to-nearest fmas, in either order."""
+    g = torch.Generator().manual_seed(1)
+    n = 64
+    worst = 0.0
+    for scale_c in (1.0, 1e3, 1e-3, 0.0):
+        a, b, c = torch.randn(n, 32, 2, generator=g), torch.randn(n, 2, 32, generator=g), scale_c * torch.randn(n, 32, 32, generator=g)
+        d = E.mfma_probe_f32(a.to(dev), b.to(dev), c.to(dev)).cpu().double()
+        a64, b64, c64 = a.double(), b.double(), c.double()
+        p0, p1 = a64[:, :, 0:1] * b64[:, 0:1, :], a64[:, :, 1:2] * b64[:, 1:2, :]
+        exact = c64 + p0 + p1
+        # a term is rounded by its own fma and by every later one: the first product twice, the second once, C twice
+        bound = 2 * U * (c64.abs() + torch.maximum(p0.abs(), p1.abs())) + U * torch.minimum(p0.abs(), p1.abs())
+        r = float(((d - exact).abs() / bound.clamp_min(1e-300)).max())
+        worst = max(worst, r)
+        # which order?  (informational: the bound charges the larger product the larger factor)
+        f01 = ((c64 + p0).float().double() + p1).float().double()
+        f10 = ((c64 + p1).float().double() + p0).float().double()
+        print(f"fp32 MFMA  C ~ {scale_c:g}: max |e| / bound = {r:.3f};  bits equal to k = 0 then 1: {float((d == f01).double().mean()):.4f}, 1 then 0: {float((d == f10).double().mean()):.4f}")
+    assert worst <= 1.0 + 1e-6
+
+
+def test_scalar_transcendentals_are_one_ulp(dev):
+    """H3: v_exp_f32 and v_rcp_f32 within 1 ulp (relative 2 u), and phi(t) = t / (1 + 2^t) as the kernels compute it within gamma(7) |phi|."""
+    g = torch.Generator().manual_seed(2)
+    x = torch.cat([torch.randn(1 << 16, generator=g) * s for s in (0.1, 1.0, 8.0, 40.0)] + [torch.linspace(-126, 126, 1 << 14)])
+    out = E.scalar_probe(x.to(dev)).cpu().double()
+    x64 = x.double()
+    e_exp = float(((out[0] - torch.exp2(x64)).abs() / torch.exp2(x64)).max())
+    nz = x64.abs() > 1e-30
+    e_rcp = float(((out[1][nz] - 1 / x64[nz]).abs() * x64[nz].abs()).max())
+    phi = x64 / (1 + torch.exp2(x64))
+    sel = phi.abs() > 1e-30
+    e_phi = float(((out[2][sel] - phi[sel]).abs() / phi[sel].abs()).max())
+    print(f"v_exp_f32 max rel err = {e_exp / U:.3f} u   v_rcp_f32 = {e_rcp / U:.3f} u   phi = {e_phi / U:.3f} u  (model: 2, 2, 7)")
+    assert e_exp <= 2 * U * 1.001 and e_rcp <= 2 * U * 1.001 and e_phi <= FB.gamma(7)
+
+
+# ---- |first pass - fp32| against the bound, on the kernels -----------------------------------------------------------------------
+STRESS = ["gaussian", "outlier", "hot gate", "near overflow", "tiny components"]
+
+
+def _stressed(cfg, kind: str, seed: int):
+    """weights, items: the families of the CPU property test (oracle/f16x3_bound.py stress_case) at kernel scale"""
+    w = O.synthetic_weights(cfg, seed=seed, uid_rows=64 if cfg.uid_embedding_hash_sizes else None)
+    w, scale_items = OB.stress_weights(w, kind, seed)
+    return w, scale_items
+
+
+@pytest.mark.parametrize("kind", STRESS)
+@pytest.mark.parametrize("workload", ["amzn-books", "ml-1m", "ml-20m", "synthetic-16x16x64"])
+def test_first_pass_error_stays_below_the_a_priori_bound(dev, workload, kind):
+    """max |f16x3 logit - fp32 logit| over B x N pairs <= eps (and the oracle's restatement of the bound equals the product's)."""
+    cfg = O.CONFIGS[workload]
+    if cfg.uid_embedding_hash_sizes:
+        cfg = dataclasses.replace(cfg, uid_embedding_hash_sizes=(63,))
+    w, item_scale = _stressed(cfg, kind, seed=5)
+    N, B = 40_000, 16
+    X = torch.from_numpy(O.hash_item_table(21, 0, N, cfg.item_embedding_dim)) * item_scale
+    q = O.synthetic_queries(cfg, B, seed=41)
+    kw = {"user_ids": torch.arange(B, dtype=torch.int64, device=dev)} if cfg.uid_embedding_hash_sizes else {}
+    p = "_gating_fn._qi_partial_module."
+    args = (w[p + "1.weight"], w[p + "1.bias"], w[p + "3.weight"], w[p + "3.bias"], cfg.temperature, cfg.dot_product_dimension,
+            cfg.query_dot_product_groups, cfg.item_dot_product_groups)
+    bound = FB.first_pass_bound(*args)
+    restated = OB.first_pass_bound(*(np.asarray(t) if torch.is_tensor(t) else t for t in args))
+    assert bound["eps"] == pytest.approx(restated["eps"], rel=1e-9) or (math.isinf(bound["eps"]) and math.isinf(restated["eps"]))
+    with torch.inference_mode():
+        try:
+            m16 = build_module(cfg, w, dev, "f16x3")
+            s16 = rails_amd.MoLBruteForceTopK(m16, X.unsqueeze(0).to(dev), torch.arange(N, device=dev).unsqueeze(0)).all_logits(q.to(dev), **kw)
+        except NotImplementedError:
+            assert math.isinf(bound["eps"]) or not bound["in_f16_range"] or kind == "near overflow"
+            return
+        m32 = build_module(cfg, w, dev, "fp32")
+        tk32 = rails_amd.MoLBruteForceTopK(m32, X.unsqueeze(0).to(dev), torch.arange(N, device=dev).unsqueeze(0))
+        tk32.exact_mode = "dense"
+        s32 = tk32.all_logits(q.to(dev), **kw)
+    err = float((s16 - s32).abs().max())
+    print(f"{workload:20s} {kind:16s} max |s16 - s32| = {err:.3e}   eps = {bound['eps']:.4f}   ratio = {err / bound['eps']:.2e}  gate |t2| <= {bound.get('t2_max', 0):.0f}")
+    assert torch.isfinite(s16).all() and torch.isfinite(s32).all()
+    assert err <= bound["eps"]
+
+
+# ---- the module -------------------------------------------------------------------------------------------------------------------
+def _dense(m32, X, ids):
+    tk = rails_amd.MoLBruteForceTopK(m32, X, ids)
+    tk.exact_mode = "dense"
+    return tk
+
+
+@pytest.mark.parametrize("workload,N,B,k", [("amzn-books", 695762, 32, 200), ("amzn-books", 695762, 32, 2561), ("amzn-books", 100_003, 5, 120),
+                                            ("ml-20m", 27278, 32, 200), ("ml-1m", 3883, 32, 200), ("synthetic-16x16x64", 400_000, 32, 200)])
+def test_proved_mode_is_the_default_and_equals_dense_fp32(dev, workload, N, B, k):
+    """A module of the DEFAULT precision: MoLBruteForceTopK runs the proved mode (split-f16 first pass, a-priori eps) and returns the
+    dense fp32 kernels' output bit for bit -- scores, ids, tie order -- with every call proved and no fallback; via forward and via
+    CandidateIndex.get_top_k_outputs with the seen-id filter.  C1 / C2 are below SPECULATE_MIN_ITEMS by default (they run dense there):
+    here the threshold is lifted so that the proved route itself is exercised at their full N."""
+    cfg = O.CONFIGS[workload]
+    w = O.synthetic_weights(cfg, seed=0)
+    X = torch.from_numpy(O.hash_item_table(1, 0, N, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = (torch.arange(N, dtype=torch.int64, device=dev) * 3 + 7).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B, seed=2).to(dev)
+    kw = {"user_ids": torch.arange(1, B + 1, dtype=torch.int64, device=dev)} if cfg.uid_embedding_hash_sizes else {}
+    k = min(k, N)
+    with torch.inference_mode():
+        m = build_module(cfg, w, dev, None)
+        r_s, r_i = _dense(m, X, ids)(q, k=k, **kw)
+        old = rails_amd.MoLBruteForceTopK.SPECULATE_MIN_ITEMS
+        try:
+            rails_amd.MoLBruteForceTopK.SPECULATE_MIN_ITEMS = 0
+            tk = rails_amd.MoLBruteForceTopK(m, X, ids)
+            assert tk.exact_mode == "proved" and tk._bind().exact is not None, "the proved mode is not the default exact path"
+            for _ in range(3):
+                s, i = tk(q, k=k, **kw)
+                assert torch.equal(s, r_s) and torch.equal(i, r_i)
+            st = tk.stats()
+            print(workload, N, B, k, {key: st[key] for key in ("calls", "fallbacks", "proved_calls", "bound_violations", "eps", "eps_rigorous", "guard_max")}, "kc pad", tk._pad_scale)
+            assert st["eps_rigorous_usable"] is True and st["eps"] == pytest.approx(st["eps_rigorous"], rel=1e-4)
+            assert st["calls"] == 3 and st["proved_calls"] == 3 and st["fallbacks"] == 0 and st["bound_violations"] == 0
+            inv = ids[0, torch.randint(0, N, (B, 61), device=dev)]
+            kk = min(k, 120)
+            ci = rails_amd.CandidateIndex(ids, X)
+            a = ci.get_top_k_outputs(q, k=kk, aux_payloads=kw, top_k_module=tk, invalid_ids=inv, truncate_k_prime_to=200)
+            b = ci.get_top_k_outputs(q, k=kk, aux_payloads=kw, top_k_module=_dense(m, X, ids), invalid_ids=inv, truncate_k_prime_to=200)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+            # the module's own logits stay the fp32 kernels' (the split-f16 engine is internal)
+            assert torch.equal(tk.all_logits(q[:2], **{key: v[:2] for key, v in kw.items()}), _dense(m, X, ids).all_logits(q[:2], **{key: v[:2] for key, v in kw.items()}))
+        finally:
+            rails_amd.MoLBruteForceTopK.SPECULATE_MIN_ITEMS = old
+
+
+def test_proved_mode_unprovable_calls_fall_back(dev):
+    """What cannot be proved is redone on the dense fp32 kernels, and says so:
+      (a) stressed gate weights (x 6): the a-priori bound is several logit units, the candidates cannot cover everything within it
+          -> verdicts fail, the device-side fallback returns the dense result, the margin grows;
+      (b) a violated guard: query-gate rows beyond gate_guard / max |gi| -> REDO, never proved;
+      (c) an observed |first pass - fp32| above the bound (planted on a candidate through the test hook) is a violation of the
+          arithmetic model: counted, the call is not proved, the result is still the dense one (the hook's victim is re-scored);
+      (d) a module outside the bound's guards (gating_combination "none") does not speculate at all."""
+    cfg = O.CONFIGS["amzn-books"]
+    N, B, k = 150_000, 8, 100
+    X = torch.from_numpy(O.hash_item_table(31, 0, N, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = torch.arange(1, N + 1, dtype=torch.int64, device=dev).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B, seed=43).to(dev)
+    p = "_gating_fn._qi_partial_module."
+    with torch.inference_mode():
+        # (a)
+        w = O.synthetic_weights(cfg, seed=9)
+        w[p + "1.weight"] = w[p + "1.weight"] * 6.0
+        w[p + "3.weight"] = w[p + "3.weight"] * 6.0
+        m = build_module(cfg, w, dev, None)
+        r_s, r_i = _dense(m, X, ids)(q, k=k)
+        tk = rails_amd.MoLBruteForceTopK(m, X, ids)
+        assert tk._bind().exact is not None and tk.stats()["eps_rigorous"] > 5.0
+        for _ in range(3):
+            s, i = tk(q, k=k)
+            assert torch.equal(s, r_s) and torch.equal(i, r_i)
+        st = tk.stats()
+        print("stressed gate:", {key: st[key] for key in ("calls", "fallbacks", "proved_calls", "eps_rigorous")}, "pad", tk._pad_scale)
+        assert st["fallbacks"] >= 1 and st["proved_calls"] == st["calls"] - st["fallbacks"] and tk._pad_scale > 1
+        # (b)
+        w = O.synthetic_weights(cfg, seed=9)
+        m = build_module(cfg, w, dev, None)
+        r_s, r_i = _dense(m, X, ids)(q, k=k)
+        tk = rails_amd.MoLBruteForceTopK(m, X, ids)
+        s, i = tk(q, k=k)
+        assert torch.equal(s, r_s) and torch.equal(i, r_i) and tk.stats()["proved_calls"] == 1
+        tk._gate_guard_limit = 0.5 * tk.stats()["guard_max"]
+        s, i = tk(q, k=k)
+        st = tk.stats()
+        assert torch.equal(s, r_s) and torch.equal(i, r_i) and st["proved_calls"] == 1 and st["fallbacks"] == 1, st
+        # (c)
+        tk = rails_amd.MoLBruteForceTopK(m, X, ids)
+        victim = (r_i[0, 50:51] - 1)
+        tk._debug_first_pass_bias = (victim, 3.0)       # stays a candidate (k = 100 of 412), its first-pass logit is 3.0 off
+        s, i = tk(q, k=k)
+        s, i = tk(q, k=k)
+        st = tk.stats()
+        print("planted:", {key: st[key] for key in ("calls", "fallbacks", "proved_calls", "bound_violations", "eps")})
+        assert torch.equal(s, r_s) and torch.equal(i, r_i) and st["bound_violations"] >= 1 and st["proved_calls"] == 0
+        # (d)
+        cfg_n = dataclasses.replace(cfg, gating_combination_type="none")
+        wn = O.synthetic_weights(cfg_n, seed=9)
+        mol, _ = rails_amd.create_mol_interaction_module(
+            cfg.query_embedding_dim, cfg.item_embedding_dim, cfg.dot_product_dimension, cfg.query_dot_product_groups, cfg.item_dot_product_groups,
+            cfg.temperature, 0.0, cfg.query_hidden_dim, 0.1, cfg.item_hidden_dim, cfg.gating_query_hidden_dim, cfg.gating_qi_hidden_dim,
+            cfg.gating_item_hidden_dim, cfg.softmax_dropout_rate, False, query_nonlinearity=cfg.query_nonlinearity, gating_combination_type="none")
+        mol.load_state_dict(wn, strict=True)
+        mol = mol.to(dev).eval()
+        tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
+        assert tk._bind().exact is None        # dense fp32: nothing to prove
+        ref = O.brute_force_topk(cfg_n, wn, q.cpu(), X.cpu(), ids.cpu(), k)
+        s, i = tk(q, k=k)
+        assert float((s.cpu() - ref[0]).abs().max()) <= 1e-4
