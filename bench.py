@@ -495,10 +495,10 @@ def full_shard_legs(B: int, k: int, dev) -> list:
                     pipelined(10)
                     torch.cuda.synchronize()
                     dtp = (time.perf_counter() - t0) / 10
-                    leg["pipelined"] = {"ms_per_step": dtp * 1e3, "queries_per_s": B / dtp, "hbm_frac_lower_bound": int(mod._prefilter().numel() if mod._prefilter() is not None else mod._table().numel() * mod._table().element_size()) / dtp / 8.0e12,
+                    leg["pipelined"] = {"ms_per_step": dtp * 1e3, "queries_per_s": B / dtp, "hbm_frac_lower_bound": int(mod._prefilter(count=False).numel() if mod._prefilter(count=False) is not None else mod._table().numel() * mod._table().element_size()) / dtp / 8.0e12,
                                         "output_equal_to_unpipelined": bool(torch.equal(p_out[0], r_scores) and torch.equal(p_out[1], r_ids))}
                     leg["coarse_table_bytes"] = int(mod._table().numel() * mod._table().element_size())
-                    leg["int8_prefilter_bytes"] = int(mod._prefilter().numel()) if mod._prefilter() is not None else 0
+                    leg["int8_prefilter_bytes"] = int(mod._prefilter(count=False).numel()) if mod._prefilter(count=False) is not None else 0
                     # the whole step (prologue, sample + threshold, select scan, key selection, in-place rerank, final top-k) against ONE read of the table
                     leg["hbm_frac_lower_bound"] = (leg["int8_prefilter_bytes"] or leg["coarse_table_bytes"]) / dt / 8.0e12   # the bytes the streaming pass reads once
                     # north_star: "recall@k vs exact reported".  On the planted-structure weights (the plain random init has nothing
@@ -939,7 +939,7 @@ def main() -> None:
             _, eq_plain, _ = eng.query_pack(q, kw.get("user_ids"), want_plain=True)
             kp_local = min(args.two_pass, hi - lo)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            pre = local._prefilter()          # the int8 copy the streaming pass reads instead of the bf16 table (large tables)
+            pre = local._prefilter(count=False)          # the int8 copy the streaming pass reads instead of the bf16 table (large tables)
             eng.coarse_topk(eq_plain, table, False, kp_local, prefilter=pre)
             e0.record()
             for _ in range(args.steps):

@@ -817,9 +817,18 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(RA
   if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.hdr->scanned, (unsigned long long)(n_tiles * n_qt));
 }
 
+// dynamic LDS of the int8 select scan: the queries' bf16 fragments, their int8 fragments and three bound rows per query tile
+static size_t coarse_scan_i8_lds(int B, int d) {
+  const int n_qt = (B + 31) / 32, dc8 = d / 32;
+  return (size_t)n_qt * (2 * dc8 * 1024 + dc8 * 1024 + 3 * 32 * 4);
+}
+// d = 128 with 97..128 queries needs 50 688 B, over the 48 KiB a launch gets without opting in: coarse_topk() then runs the bf16 select
+// scan, whose output is the same bit for bit (the pre-filter only decides WHICH tiles are scored from the bf16 table)
+static bool coarse_scan_i8_fits(int B, int d) { return (d == 32 || d == 64 || d == 128) && coarse_scan_i8_lds(B, d) <= 48 * 1024; }
+
 static int launch_coarse_scan_i8(const CoarseI8Args& a, hipStream_t stream) {
   const int n_qt = (a.B + 31) / 32, dc8 = a.d / 32;
-  const size_t lds = (size_t)n_qt * (2 * dc8 * 1024 + dc8 * 1024 + 3 * 32 * 4);
+  const size_t lds = coarse_scan_i8_lds(a.B, a.d);
   if (lds > 48 * 1024) { set_error("coarse int8 scan: batch %d x d %d does not fit LDS", a.B, a.d); return kErrUnsupported; }
   const int64_t n_tiles = (a.n + 31) >> 5;
   const int tu = RAILS_SCAN8_TU / dc8;
@@ -864,6 +873,7 @@ int coarse_topk(const Shape& s, const float* eq, int B, int avg, const void* tab
   if (!coarse_topk_plan(B, n, k_prime, &p, true)) { set_error("coarse_topk: unsupported size (B = %d, K' = %d, n = %lld)", B, k_prime, (long long)n); return kErrUnsupported; }
   if (n >= (1ll << 32)) { set_error("coarse_topk: n does not fit 32-bit positions; shard the corpus"); return kErrUnsupported; }
   if (ws_bytes < p.total) { set_error("coarse_topk: workspace too small"); return kErrNoMem; }
+  if (prefilter && !coarse_scan_i8_fits(B, s.dot_product_dimension)) prefilter = nullptr;   // decided BEFORE anything is enqueued: the bf16 select scan, same output
   char* base = static_cast<char*>(ws);
   unsigned int* counts = reinterpret_cast<unsigned int*>(base);
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(base + p.off_keys);

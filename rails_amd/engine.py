@@ -542,6 +542,15 @@ class MolEngine:
             return None
         eq = _f32c(eq)
         dev = table.device
+        if prefilter is not None:
+            # the C side indexes the int8 copy by this call's n and d, and the exactness argument assumes copy and scale belong to THIS
+            # table: a buffer of another size or device (a stale copy of a rebuilt table) is refused
+            want = memo.get(("prefilter", n))
+            if want is None:
+                want = memo[("prefilter", n)] = self.lib.rails_mol_coarse_prefilter_bytes(C.byref(self.shape), n)
+            if prefilter.device != dev or prefilter.dtype != torch.uint8 or prefilter.numel() != want or not prefilter.is_contiguous():
+                raise ValueError(f"coarse_topk: the int8 pre-filter does not belong to this table ({prefilter.numel()} bytes on {prefilter.device}, "
+                                 f"expected {want} on {dev}): rebuild it with build_coarse_prefilter(table)")
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         out_s = torch.empty((B, k_prime), dtype=torch.float32, device=dev)
         out_p = torch.empty((B, k_prime), dtype=torch.int64, device=dev)

@@ -308,7 +308,23 @@ class HSTU(torch.nn.Module):
             if bool(((lengths < min_len) | (lengths > N)).any()):
                 raise ValueError(f"past_lengths must lie in [{min_len}, {N}] (got min {int(lengths.min())}, max {int(lengths.max())})")
             return lengths.to(device=dev).contiguous()
-        return lengths.to(device=dev).clamp(min=min_len, max=N).contiguous()
+        lengths = lengths.to(device=dev)
+        # sync-free, but not silent: out-of-range lengths are counted in a sticky device counter (HSTU.length_violations() reads it at a
+        # moment of the caller's choosing -- end of an eval pass, a stats call), then clamped
+        bad = ((lengths < min_len) | (lengths > N)).sum()
+        ctr = HSTU._violations.get(dev)
+        if ctr is None:
+            ctr = HSTU._violations[dev] = torch.zeros((), dtype=torch.int64, device=dev)
+        ctr += bad
+        return lengths.clamp(min=min_len, max=N).contiguous()
+
+    _violations: dict = {}
+
+    @staticmethod
+    def length_violations() -> int:
+        """Out-of-range past_lengths seen (and clamped) on the sync-free device path since the process started: an upstream data bug when
+        non-zero.  One synchronising read per device."""
+        return sum(int(v.item()) for v in HSTU._violations.values())
 
     def _normalize(self, x2d: torch.Tensor, rows: Optional[torch.Tensor]) -> torch.Tensor:
         lib = _lib.load()

@@ -786,18 +786,31 @@ class MoLAvgTopK(MoLTopKModule):
     PREFILTER_MAX_FIRED = 0.35        # fraction of (tile, query tile) blocks passing the integer bound beyond which the copy is dropped
     PREFILTER_CHECK_CALLS = (2, 64)   # the header's statistics are read (16 bytes, one sync) after this many calls, then every so many
 
-    def _prefilter(self) -> Optional[torch.Tensor]:
+    def _prefilter(self, count: bool = True) -> Optional[torch.Tensor]:
+        """The int8 copy of the coarse table (None: not built, or dropped).  count = False: a look that is not a scan (statistics, bench
+        probes) and must not advance the check schedule."""
         self._table()
         pre = self._coarse_prefilter
-        if pre is not None:
+        if pre is not None and count:
             # a table whose one scale is set by a few outliers makes most tiles pass the bound: still exact, but the pass then reads
-            # both copies.  The select scans keep (fired, tested) counts in the header; looked at now and then
+            # both copies.  The select scans keep (fired, tested) counts in the header; looked at now and then -- WITHOUT a host wait:
+            # the 16 bytes are copied to pinned memory behind the launches already enqueued and read by a later call, once the copy
+            # has landed (a blocking read here stalled the submit / result pipeline on call 3 and on every 64th call)
             self._prefilter_calls = getattr(self, "_prefilter_calls", 0) + 1
+            pend = getattr(self, "_prefilter_pending", None)
             first, every = self.PREFILTER_CHECK_CALLS
-            if self._prefilter_calls == first + 1 or self._prefilter_calls % every == 0:
-                fired, tested = (int(v) for v in pre[32:48].view(torch.int64).cpu())
-                if tested > 0 and fired > self.PREFILTER_MAX_FIRED * tested:
-                    self._coarse_prefilter = pre = None
+            if pend is not None:
+                if pend[1].query():
+                    fired, tested = (int(v) for v in pend[0])
+                    self._prefilter_pending = None
+                    if tested > 0 and fired > self.PREFILTER_MAX_FIRED * tested:
+                        self._coarse_prefilter = pre = None
+            elif self._prefilter_calls == first + 1 or self._prefilter_calls % every == 0:
+                host = torch.empty(2, dtype=torch.int64).pin_memory()
+                host.copy_(pre[32:48].view(torch.int64), non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._prefilter_pending = (host, ev)
         return pre
 
     def prefilter_stats(self) -> Optional[dict]:
@@ -880,6 +893,9 @@ class MoLAvgTopK(MoLTopKModule):
     # copies the scan's verdict word to pinned host memory behind it; result waits for THAT copy (not for the stream), and redoes
     # the call on the materialising path in the rare other case.  A caller with the next batch at hand calls submit(batch i + 1)
     # before result(batch i): the host's look at the verdict then costs the GPU nothing (bench.py --two-pass reports both rates).
+    # The handle submit() returns is OPAQUE: the tensors inside it may still be in flight on a stream of the module's own and are
+    # joined to the caller's stream only by result() -- read them through result(), never through the handle, and do not drop a handle
+    # without calling result() (ShardedTopK.submit, which needs the scores earlier, waits on the handle's event explicitly).
     def submit(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs):
         if k > self._avg_top_k:  # the reference raises after doing the work (mol_top_k.py:383-386)
             raise ValueError(f"avg_top_k ({self._avg_top_k}) must be larger than k ({k})")

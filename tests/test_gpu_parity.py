@@ -592,12 +592,13 @@ def test_int8_prefilter_build_equals_the_cpu_restatement(dev):
 def test_avg_topk_module_with_the_int8_prefilter(dev, monkeypatch):
     """MoLAvgTopK builds the pre-filter for large tables on its own (PREFILTER_MIN_ITEMS); lowered here: forward with it == forward
     without it == the materialising path, d = 32 / 64 / 128 shapes."""
-    for cfg_name, n in (("amzn-books", 300_001), ("ml-1m", 280_000), ("ml-20m", 270_000)):
+    # (the last case, d = 128 with B = 128: the int8 scan's LDS image would be 50 688 B, over what a launch gets -- the call must take the
+    #  bf16 select scan instead, before anything is enqueued, with the same output; it used to fail after the sample launch)
+    for cfg_name, n, B in (("amzn-books", 300_001, 70), ("ml-1m", 280_000, 70), ("ml-20m", 270_000, 70), ("ml-20m", 270_000, 128)):
         cfg = O.CONFIGS[cfg_name]
         mol = build_module(cfg, O.synthetic_weights(cfg, seed=2), dev)
         X = torch.from_numpy(O.hash_item_table(5, 0, n, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
         ids = torch.arange(1, n + 1, dtype=torch.int64, device=dev).unsqueeze(0)
-        B = 70
         q = O.synthetic_queries(cfg, B, seed=4).to(dev)
         kw = {"user_ids": torch.arange(B, dtype=torch.int64, device=dev) * 7 + 1} if len(cfg.uid_embedding_hash_sizes) > 0 else {}
         with torch.inference_mode():

@@ -181,7 +181,9 @@ def test_encode_rejects_out_of_range_lengths():
                     m.encode(bad.cpu(), ids, emb, {})          # lengths from the host (the data loader's case): checked there
                 # device-resident lengths are clamped on the device (no blocking read in the hot path) unless strict mode is on
                 clamped = bad.clamp(min=1, max=ids.shape[1])
+                before = type(m).length_violations()
                 assert torch.equal(m.encode(bad, ids, emb, {}), m.encode(clamped, ids, emb, {}))
+                assert type(m).length_violations() == before + 1        # ... and counted: the clamp is not silent
                 type(m).STRICT_DEVICE_LENGTHS = True
                 try:
                     with pytest.raises(ValueError, match="past_lengths"):
