@@ -332,9 +332,10 @@ class MoLBruteForceTopK(MoLTopKModule):
             self.rescore_stats["unprovable_calls"] = self.rescore_stats.get("unprovable_calls", 0) + 1
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
         if eps_proved is not None:
-            # candidates: every item within eps of the k-th score must be among them.  On the BASELINE shapes that is 1.3-2.2 k (k = 200:
-            # 260-430 items, k = 2 561: 3 200-4 900; tools/proved_candidate_census.py); a failed verdict doubles the margin
-            pad = max(312, k) * self._pad_scale
+            # candidates: every item within eps of the k-th score must be among them.  amzn-books, eps = 0.9-1.0: 470-680 items at k = 200,
+            # 6 000-7 500 at k = 2 561 (128 queries; profiles/r05_proved_candidate_census.json); rails_topk costs the same 80-90 us from
+            # 544 to 1 536 candidates per row of 700 k scores, so the margin starts generous.  A failed verdict doubles it
+            pad = max(824, 3 * k) * self._pad_scale
             kc = min((k + pad + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS, 16384)
         else:
             pad = (max(128, k // 2) if single else max(64, k // 4)) * self._pad_scale
@@ -450,7 +451,7 @@ class MoLBruteForceTopK(MoLTopKModule):
         self._recent.append(good)
         if not good:
             self.rescore_stats["fallbacks"] += 1
-            if self._proved_eps_cache is not None and self._proved_eps_cache[1] is not None:
+            if self._in_proved_mode():
                 if kc < 16384:
                     self._pad_scale *= 2      # proved mode: the candidates must cover everything within eps of the k-th score
             elif self._pad_scale < 4 and not (k <= 384 and kc >= 512):
@@ -487,11 +488,15 @@ class MoLBruteForceTopK(MoLTopKModule):
         self._state_pending = None
         for i in range(new_calls):
             self._note_verdict(i >= new_redone, k, kc)
-        if self._proved_eps_cache is not None and self._proved_eps_cache[1] is not None:
+        if self._in_proved_mode():
             self._count_proved(new_calls - new_redone)
 
     _first_pass_hook = None
     _proved_eps_cache = None      # (engine, eps as the float32 handed to the verdict or None: monitored mode)
+
+    def _in_proved_mode(self) -> bool:
+        c = self._proved_eps_cache
+        return c is not None and c[0] is self._engine and c[1] is not None and self._engine.dense_precision != "f16x1"
 
     def _proved_eps(self) -> Optional[float]:
         """The a-priori bound for the bound engine, rounded UP to a float32 (the verdict compares in fp32: gap = fl(e_k - m) > eps, one
