@@ -725,25 +725,11 @@ def main() -> None:
                 ev0[i].record()
             k_local = min(kp, hi - lo)
             mark = (lambda: ev1[i].record()) if i is not None else (lambda: None)
-            fused = getattr(local, "FUSED_SELECT", False) and local._fused_ok(eng, B, hi - lo, k_local)
-            if fused and world == 1 and E.topk_filter_fusable(hi - lo, k_local, inv.shape[1], k):
-                # what the module API does (MoLBruteForceTopK.forward_filtered): the scoring kernels append the survivors of a running
-                # bound, one selection launch applies the id map and the seen-id filter; the dense pass behind it runs only if a
-                # survivor list overflowed (launch predicate = the status word; no-ops here)
-                out_i, out_s, status = eng.score_topk(qpack, B, local._index, k_local, ids=local._ids_flat, invalid_ids=inv, k_out=k, between=mark)
-                eng.score_dense(qpack, B, local._index, out=logits, run_if=status)
-                E.topk_filtered(logits, k_local, local._ids_flat, inv, k, out=(out_i, out_s), run_if=status)
-                return out_i, out_s
-            if fused:
-                s, top, status = eng.score_topk(qpack, B, local._index, k_local, ids=local._ids_flat, between=mark)
-                eng.score_dense(qpack, B, local._index, out=logits, run_if=status)
-                E.topk(logits, k_local, ids=local._ids_flat, out=(s, top), run_if=status)
-            else:
-                eng.score_dense(qpack, B, local._index, out=logits)
-                mark()
-                if world == 1 and E.topk_filter_fusable(hi - lo, k_local, inv.shape[1], k):   # filter fused into the selection over the dense logits
-                    return E.topk_filtered(logits, k_local, local._ids_flat, inv, k)
-                s, top = E.topk(logits, k_local, ids=local._ids_flat)
+            eng.score_dense(qpack, B, local._index, out=logits)
+            mark()
+            if world == 1 and E.topk_filter_fusable(hi - lo, k_local, inv.shape[1], k):   # filter fused into the selection over the dense logits
+                return E.topk_filtered(logits, k_local, local._ids_flat, inv, k)
+            s, top = E.topk(logits, k_local, ids=local._ids_flat)
             if world > 1:
                 gathered = all_gather_rows(E.pack_candidates(s, top, kp))
                 if E.merge_filter_fusable(kp, inv.shape[1], k):   # what the sharded module does: the filter inside the merge launch
@@ -1047,35 +1033,6 @@ def main() -> None:
             local.exact_mode = "dense"
             eng = local._bind()       # the legs below drive the fp32 kernels by hand again
 
-    # ---- opt-in: the selection fused into the scoring kernels (rails_mol_score_topk), the same step timed
-    #      the same way after the headline region, its output compared with the headline step's.  Reported separately.
-    fused_leg = None
-    if not two_pass and world == 1 and not args.no_fast_path:
-        with torch.inference_mode():
-            was = local.FUSED_SELECT
-            local.FUSED_SELECT = True
-            if local._fused_ok(eng, B, hi - lo, min(kp, hi - lo)) and E.topk_filter_fusable(hi - lo, min(kp, hi - lo), inv.shape[1], k):
-                ref_out = step() if not was else None
-                if ref_out is None:
-                    local.FUSED_SELECT = False
-                    ref_out = step()
-                    local.FUSED_SELECT = True
-                ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-                ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-                for _ in range(args.warmup):
-                    step()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for i in range(args.steps):
-                    got = step(i)
-                torch.cuda.synchronize()
-                fe = time.perf_counter() - t0
-                fused_leg = {"what": "rails_mol_score_topk: survivor lists appended by the scoring kernel under a running bound + one selection launch (no pass over (B, N) logits); opt-in (RAILS_FUSED_SELECT=1)",
-                             "ms_per_step": fe / args.steps * 1e3, "kernel_ms": sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps,
-                             "output_identical_to_headline_step": bool(torch.equal(got[0], ref_out[0]) and torch.equal(got[1], ref_out[1])),
-                             "is_headline": bool(was)}
-            local.FUSED_SELECT = was
-
     # ---- opt-in precision mode "f16x3" (same API, same index, same 1e-4 bar), timed the same
     #      way AFTER the headline region so it cannot perturb it.  Reported separately; `value` stays the exact-fp32 path.
     fast = None
@@ -1283,8 +1240,6 @@ def main() -> None:
                     "peak_note": "2500 TFLOP/s dense f16 MFMA / 3 MFMAs per algorithmic product block; issued-MFMA rate = 3 x achieved",
                 }
             out["proved"] = leg
-        if fused_leg:
-            out["fused_select"] = fused_leg
         out["without_seen_id_filter"] = {"value": B * args.steps / nofilter_elapsed, "unit": "queries/s",
                                          "ms_per_step": nofilter_elapsed / args.steps * 1e3, "k": k}
         if two_pass:

@@ -14,8 +14,8 @@
  *     a thread-local human-readable message for the last failure;
  *   - `run_if` (where an entry point has it) is the LAUNCH PREDICATE: NULL, or an int32 in device memory that every kernel of the
  *     call reads when it starts, in stream order -- the call is a no-op unless it is non-zero.  It is how a caller enqueues a
- *     fallback behind a device-side verdict without reading the verdict on the host (rails_rescore_verdict, rails_range_flag_i32
- *     and the status word of rails_mol_score_topk write such flags).  No counterpart in the reference;
+ *     fallback behind a device-side verdict without reading the verdict on the host (rails_rescore_verdict and rails_range_flag_i32
+ *     write such flags).  No counterpart in the reference;
  *   - packed buffers (`gate pack`, `item index`, `query pack`) are opaque fp32 blobs whose sizes
  *     come from the *_floats() helpers; they are only valid for the shape they were built for.
  */
@@ -33,7 +33,7 @@ extern "C" {
  * structs of round 2 carried no version; 5: the launch predicate became the explicit `run_if` argument of the entry points that
  * honour it and the per-thread rails_set_run_predicate is gone -- the library keeps no state between calls but the last error;
  * 6: rails_mol_coarse_topk gained its out_of_range output and its optional int8 pre-filter (rails_mol_coarse_prefilter_*),
- * rails_topk_candidates is new, rails_mol_score_indexed takes any n_cand; 7: rails_rescore_verdict gained its guard arguments and state[7], the rails_*_probe_* entry points are new).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
+ * rails_topk_candidates is new, rails_mol_score_indexed takes any n_cand; 7: rails_rescore_verdict gained its guard arguments and state[7], the rails_*_probe_* entry points are new, and rails_mol_score_topk / _survivors / rails_select_survivors -- the selection fused into the scoring kernels, 0.9 % slower than the dense kernels + rails_topk wherever it was measured -- are gone).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
  * against an older header pass shorter structs, and the library would read the new fields from whatever follows them. */
 #define RAILS_ABI_VERSION 7
 int rails_abi_version(void);
@@ -303,34 +303,6 @@ int rails_topk_filter_fusable(int64_t n, int32_t k_prime, int32_t width, int32_t
 int rails_topk_filtered(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t k_prime, const int64_t* ids, int64_t ids_row_stride,
                         const int64_t* invalid_ids, int32_t width, int32_t k, int64_t* out_ids, float* out_scores, void* workspace,
                         size_t workspace_bytes, const int32_t* run_if, void* stream);
-
-/* Scoring with the selection fused in: MoLBruteForceTopK.forward's `all_logits = mol(...)` + `torch.topk` + id gather
- * (reference rails/indexing/mol_top_k.py:118-130) and, optionally, CandidateIndex.get_top_k_outputs' seen-id filter
- * (indexing/candidate_index.py:149-175) as ONE scoring launch + ONE selection launch that never reads (B, N) logits: the scoring
- * kernels compare every logit with a running per-query lower bound on the k-th largest and append the survivors as 64-bit keys
- * (the keys of rails_topk) to per-query lists, the selection launch picks the k largest keys of each list.  Same keys, same total
- * order: the result equals rails_mol_score_dense + rails_topk (+ rails_filter_seen_ids) bit for bit.
- *   logits      NULL, or a (B, ld) buffer that additionally receives the dense logits (the verified modes read them)
- *   invalid_ids NULL, or (B, width) seen ids: the filter runs inside the selection launch and k_out results per row are written
- *   workspace   rails_mol_score_topk_workspace_bytes(B) bytes, ZERO-FILLED ONCE by the caller; every call leaves it zeroed again.
- *               Its word at byte offset 4 * B is the status: 0, or 1 when a list overflowed (adversarial orders, e.g. scores
- *               ascending in position) -- the outputs are then NOT valid and the caller re-runs the dense entry points, typically
- *               enqueued right behind this call with run_if = the status word, with no host round trip.
- * Available (rails_mol_score_topk_supported != 0) for B <= 256, k <= 384, n >= 131 072 on the staged and team shells (>= 8 query
- * groups); RAILS_ENOTSUP otherwise -- call the dense entry points then. */
-size_t rails_mol_score_topk_workspace_bytes(int32_t batch);
-int rails_mol_score_topk_supported(const rails_mol_shape* shape, int32_t batch, int64_t n_items, int32_t k);
-int rails_mol_score_topk(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack, int32_t batch, const float* index,
-                         int64_t n_items, int32_t k, const int64_t* ids, int64_t ids_row_stride, float* logits, int64_t ld,
-                         const int64_t* invalid_ids, int32_t width, int32_t k_out, float* out_scores, int64_t* out_ids, void* workspace,
-                         size_t workspace_bytes, void* stream);
-/* The two launches of rails_mol_score_topk on their own (same arguments, same workspace): the scoring launch that fills the survivor
- * lists, and the selection launch that consumes them.  For callers that want something between them (events around the scoring
- * kernel, as bench.py does) -- rails_mol_score_topk is exactly one call of each. */
-int rails_mol_score_survivors(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack, int32_t batch, const float* index,
-                              int64_t n_items, int32_t k, float* logits, int64_t ld, void* workspace, size_t workspace_bytes, void* stream);
-int rails_select_survivors(int32_t batch, int32_t k, const int64_t* ids, int64_t ids_row_stride, const int64_t* invalid_ids, int32_t width,
-                           int32_t k_out, float* out_scores, int64_t* out_ids, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- item-sharded top-k (no counterpart in the reference, whose eval is single-GPU: eval_from_checkpoint.py:554-555) ----
  * Each rank turns its local top-k into one message row of 2k int64 (k score words: fp32 bits in the low half | k ids;

@@ -4,7 +4,6 @@
 #include <stdio.h>
 
 #include "mol_kernels.h"
-#include "mol_select.h"
 #include "mol_layout.h"
 
 namespace mol {
@@ -249,83 +248,6 @@ static int score_common(const rails_mol_shape* s, const float* gate_pack, const 
   fill_score_args(s, gate_pack, query_pack, batch, index, n_items, logits, ld, per_row, &a, run_if);
   const int r = score_launch(*s, a, cu, (hipStream_t)stream);
   return r == kOk ? r : fail(r, what);
-}
-
-// ---- scoring with the selection fused in (mol_select.h) ----
-// workspace: [B bounds][1 status word, padded to 256 B][B lists of kSelCap keys]
-static size_t sel_header_bytes(int batch) { return ((size_t)batch * 4 + 4 + 255) / 256 * 256; }
-
-size_t rails_mol_score_topk_workspace_bytes(int32_t batch) {
-  if (batch <= 0) return 0;
-  return sel_header_bytes(batch) + (size_t)batch * kSelCap * sizeof(unsigned long long);
-}
-
-int rails_mol_score_topk_supported(const rails_mol_shape* s, int32_t batch, int64_t n_items, int32_t k) {
-  if (!s || !shape_supported(s)) return 0;
-  if (batch <= 0 || batch > kSelMaxB || k <= 0 || k > kSelMaxK || n_items < kSelMinItems || n_items >= (1ll << 32)) return 0;
-  const int cu = compute_units();
-  if (cu <= 0) return 0;
-  ScoreArgs a;
-  fill_score_args(s, nullptr, nullptr, batch, nullptr, n_items, nullptr, n_items, 0, &a);
-  a.sel_list = reinterpret_cast<unsigned long long*>(8);   // never dereferenced: dry run
-  a.dry_run = 1;
-  const int r = score_launch(*s, a, cu, nullptr);
-  g_err[0] = '\0';
-  return r == kOk ? 1 : 0;
-}
-
-static int score_topk_args(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch, const float* index,
-                           int64_t n_items, int32_t k, float* logits, int64_t ld, void* workspace, size_t workspace_bytes, ScoreArgs* a, const char* what) {
-  g_err[0] = '\0';
-  if (!rails_mol_score_topk_supported(s, batch, n_items, k)) { set_error("%s: not available for this shape / batch / corpus / k (rails_mol_score_topk_supported)", what); return RAILS_ENOTSUP; }
-  if (!workspace) { set_error("%s: NULL pointer", what); return RAILS_EINVAL; }
-  if (logits && ld < n_items) { set_error("%s: ld < n_items", what); return RAILS_EINVAL; }
-  if (workspace_bytes < rails_mol_score_topk_workspace_bytes(batch)) { set_error("%s: workspace too small", what); return RAILS_ENOMEM; }
-  fill_score_args(s, gate_pack, query_pack, batch, index, n_items, logits, ld, 0, a);
-  char* ws = static_cast<char*>(workspace);
-  a->sel_thr = reinterpret_cast<unsigned int*>(ws);
-  a->sel_status = reinterpret_cast<int32_t*>(a->sel_thr + batch);
-  a->sel_list = reinterpret_cast<unsigned long long*>(ws + sel_header_bytes(batch));
-  a->sel_k = k;
-  return RAILS_OK;
-}
-
-int rails_mol_score_survivors(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch, const float* index,
-                              int64_t n_items, int32_t k, float* logits, int64_t ld, void* workspace, size_t workspace_bytes, void* stream) {
-  ScoreArgs a;
-  int r = score_topk_args(s, gate_pack, query_pack, batch, index, n_items, k, logits, ld, workspace, workspace_bytes, &a, "score_survivors");
-  if (r != RAILS_OK) return r;
-  if (!gate_pack || !query_pack || !index) { set_error("score_survivors: NULL pointer"); return RAILS_EINVAL; }
-  r = score_launch(*s, a, compute_units(), (hipStream_t)stream);
-  return r == kOk ? r : fail(r, "score_survivors");
-}
-
-int rails_select_survivors(int32_t batch, int32_t k, const int64_t* ids, int64_t ids_row_stride, const int64_t* invalid_ids, int32_t width,
-                           int32_t k_out, float* out_scores, int64_t* out_ids, void* workspace, size_t workspace_bytes, void* stream) {
-  g_err[0] = '\0';
-  if (batch <= 0 || batch > kSelMaxB || k <= 0 || k > kSelMaxK) { set_error("select_survivors: bad size"); return RAILS_EINVAL; }
-  if (!out_scores || !out_ids || !workspace) { set_error("select_survivors: NULL pointer"); return RAILS_EINVAL; }
-  if (workspace_bytes < rails_mol_score_topk_workspace_bytes(batch)) { set_error("select_survivors: workspace too small"); return RAILS_ENOMEM; }
-  if (invalid_ids && (width < 0 || k_out <= 0 || k_out > k)) { set_error("select_survivors: bad filter sizes"); return RAILS_EINVAL; }
-  char* ws = static_cast<char*>(workspace);
-  const int r = select_lists(reinterpret_cast<unsigned long long*>(ws + sel_header_bytes(batch)), reinterpret_cast<unsigned int*>(ws), batch, kSelCap, k, ids,
-                             ids_row_stride, out_scores, out_ids, (hipStream_t)stream, invalid_ids, width, k_out);
-  return r == kOk ? r : fail(r, "select_survivors");
-}
-
-int rails_mol_score_topk(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch, const float* index,
-                         int64_t n_items, int32_t k, const int64_t* ids, int64_t ids_row_stride, float* logits, int64_t ld,
-                         const int64_t* invalid_ids, int32_t width, int32_t k_out, float* out_scores, int64_t* out_ids, void* workspace,
-                         size_t workspace_bytes, void* stream) {
-  // the selection's arguments are checked BEFORE the scoring launch fills the survivor lists: a rejected selection would leave
-  // keys and bounds of this batch in the workspace, which every call must leave zeroed
-  g_err[0] = '\0';
-  if (!out_scores || !out_ids) { set_error("score_topk: NULL pointer"); return RAILS_EINVAL; }
-  if (invalid_ids && (width < 0 || k_out <= 0 || k_out > k)) { set_error("score_topk: bad filter sizes"); return RAILS_EINVAL; }
-  if (invalid_ids && !(k <= 512 && width <= 256)) { set_error("score_topk: the seen-id filter cannot be fused at k = %d, width = %d", k, width); return RAILS_ENOTSUP; }
-  const int r = rails_mol_score_survivors(s, gate_pack, query_pack, batch, index, n_items, k, logits, ld, workspace, workspace_bytes, stream);
-  if (r != RAILS_OK) return r;
-  return rails_select_survivors(batch, k, ids, ids_row_stride, invalid_ids, width, k_out, out_scores, out_ids, workspace, workspace_bytes, stream);
 }
 
 int rails_mol_score_dense(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch,

@@ -43,16 +43,11 @@ struct ScoreArgs {
   int single;           // 1 (with split): precision F16X1 -- the one-product kernels, which ignore the lo fragments
   int split;            // 1: precision mode f16x3 -- gate pack, query pack and item index hold f16 hi/lo fragments (mol_layout.h)
   const int32_t* run_if;   // device flag (the entry point's run_if argument): the launch is a no-op when *run_if == 0; NULL = unconditional
-  // selection fused into the scoring pass (mol_select.h): NULL list = dense logits only; with a list, `logits` may be NULL
-  unsigned long long* sel_list;   // [B][kSelSegs workgroups][kSelSegCap] keys; empty slots are 0
-  unsigned int* sel_thr;          // [B] running lower bound on the k-th largest orderable score (0: none yet)
-  int sel_k;
   // per-row candidates addressed IN the shared index (rails_mol_score_indexed): candidate j of row b is item cand_pos[b * n_items + j]
   // of an index of index_items items; NULL = per-row candidates come as their own gathered tiles (rails_mol_score_candidates)
   const int64_t* cand_pos;
   int64_t index_items;
-  int32_t* sel_status;            // zeroed by the scoring launch, set by the final selection when a list overflowed
-  int dry_run;                    // 1: validate the dispatch (shape, shell, fused selection possible) without launching
+  int dry_run;                    // 1: validate the dispatch (shape, shell) without launching
 };
 
 int pack_gate_weights_split(const Shape& s, const Weights& w, float* wpack, hipStream_t stream);
@@ -168,9 +163,6 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
          const int32_t* run_if = nullptr, const int64_t* ids_index = nullptr, int64_t ids_index_ld = 0);   // ids_index: see map_id (topk.hip)
 // scores16 != NULL: the rows are bf16 bit patterns (ld, n in elements); only where topk_bf16_source_ok says so
 bool topk_bf16_source_ok(int rows, int64_t n, int k);
-int select_lists(unsigned long long* lists, unsigned int* thr, int rows, int cap, int k, const int64_t* ids,
-                 int64_t ids_row_stride, float* out_scores, int64_t* out_ids, hipStream_t stream,
-                 const int64_t* f_invalid = nullptr, int f_width = 0, int f_k = 0);
 int pack_candidates(const float* scores, const int64_t* ids, int rows, int k_local, int k, int64_t* msg, hipStream_t stream);
 int range_flag(const int32_t* v, int n, int lo, int hi, int32_t* flag, hipStream_t stream);
 int rescore_verdict(const float* row_stats, int rows, float default_eps, float safety, const float* guard, int64_t guard_count, float guard_limit,

@@ -172,7 +172,7 @@ bool score_supported(const Shape& s) {
 // Small-unit shell (mol_score_small.hip) or the 32x32x2 shells?  Same bits either way; RAILS_SCORE_VARIANT=7 forces the small
 // units, any other non-zero value keeps them off.
 static bool use_small_units(const Shape& s, const ScoreArgs& a, int n_cu) {
-  if (!score_small_shape(s) || a.per_row || a.cand_pos || a.sel_list || a.split) return false;
+  if (!score_small_shape(s) || a.per_row || a.cand_pos || a.split) return false;
   const int variant = score_variant();
   if (variant != 0) return variant == 7;
   // Measured on MI355X (profiles/r04_small_units.txt).  The 32x32x2 shells are faster per flop once the chip is full (0.84 against

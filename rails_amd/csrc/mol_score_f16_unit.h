@@ -523,8 +523,8 @@ struct F16Unit {
     gemm1_presplit<G, PX, DD, BULK, (PIPE == 1)>(D1, reinterpret_cast<const h8*>(eq), reinterpret_cast<const h8*>(tEx), lane);
   }
 
-  template <class G, int PX, bool SEL = false, class SelT = SelNone>
-  static __device__ __forceinline__ void queries(f32x16 (&D1)[PX], const ScoreArgs& p, SelT& sel, int g, int only, int64_t item0,
+  template <class G, int PX>
+  static __device__ __forceinline__ void queries(f32x16 (&D1)[PX], const ScoreArgs& p, int g, int only, int64_t item0,
                                                  const float* smem, const float4* tGi4, int lane, int hi, int x) {
     constexpr int NXM = (G::E / 8) * G::TH * 3;   // MFMAs of stage X
     constexpr int NYM = (G::F / 8) * G::TL * 3;   // MFMAs of stage Y
@@ -535,10 +535,8 @@ struct F16Unit {
     const bool lane_stores = hi == 0 && item < p.n_items;
     // rows past the batch end (padding of the last group) run on zero operands and the last real gate row; never stored
     auto gq_of = [&](int q) { return p.gqfrag + (int64_t)(q < p.B ? q : p.B - 1) * G::L + hi * G::E; };
-    std::conditional_t<SEL, SelUnit, SelNone> su;
     auto store = [&](int q, float out) {
-      if constexpr (SEL) sel_query<G::QT>(p, sel, su, g, q - g * G::QT, x, item, out, hi == 0);   // survivors are dealt with after the unit's last query (sel_flush)
-      else if (lane_stores && q < p.B) p.logits[(int64_t)q * p.ld + item] = out;
+      if (lane_stores && q < p.B) p.logits[(int64_t)q * p.ld + item] = out;
     };
 
     f32x16 D2[G::TH];
@@ -601,7 +599,6 @@ struct F16Unit {
           F16_STAMP(4 * Q + 3);
         }
       });
-      if constexpr (SEL) sel_flush<G::QT>(p, sel, su, g, item0);
       return;
     }
     // shared corpus: all QT queries of the group in one straight-line stream;
@@ -626,7 +623,6 @@ struct F16Unit {
       }
       F16_STAMP(3 + 2 * Q);
     });
-    if constexpr (SEL) sel_flush<G::QT>(p, sel, su, g, item0);
   }
 };
 

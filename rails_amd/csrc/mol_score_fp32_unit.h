@@ -289,14 +289,13 @@ struct Fp32Unit {
   }
   // All queries of one unit, each at its own static register offset (no register rotation).
   // `only` >= 0 restricts the unit to that query (per-row candidates).
-  template <class G, int PX, bool SEL = false, class SelT = SelNone>
-  static __device__ __forceinline__ void queries(f32x16 (&D1)[PX], const ScoreArgs& p, SelT& sel, int g, int only, int64_t item0,
+  template <class G, int PX>
+  static __device__ __forceinline__ void queries(f32x16 (&D1)[PX], const ScoreArgs& p, int g, int only, int64_t item0,
                                                  const float* smem, const float4* tGi, int lane, int hi, int x) {
     const float4* sW1 = reinterpret_cast<const float4*>(smem);
     const float4* sW2 = sW1 + G::kW1Floats / 4;
     const float* sB1 = smem + G::kW1Floats + G::kW2Floats;
     const float* sB2 = sB1 + G::TH * 32;
-    std::conditional_t<SEL, SelUnit, SelNone> su;
     [&]<int... Q>(std::integer_sequence<int, Q...>) {
       (
           [&] {
@@ -305,13 +304,11 @@ struct Fp32Unit {
               const float4* gq4 = reinterpret_cast<const float4*>(p.gqfrag + (int64_t)q * G::L + hi * G::E);
               const float out = query_mlp<G, PX, Q * G::RPQ>(D1, sW1, sW2, sB1, sB2, tGi, gq4, lane, hi, p.combine_none);
               const int64_t item = item0 + x;
-              if constexpr (SEL) sel_query<G::QT>(p, sel, su, g, Q, x, item, out, hi == 0);
-              else if (hi == 0 && item < p.n_items) p.logits[(int64_t)q * p.ld + item] = out;
+              if (hi == 0 && item < p.n_items) p.logits[(int64_t)q * p.ld + item] = out;
             }
           }(),
           ...);
     }(std::make_integer_sequence<int, G::QT>{});
-    if constexpr (SEL) sel_flush<G::QT>(p, sel, su, g, item0);
   }
 };
 

@@ -15,7 +15,6 @@
 
 #include "mol_kernels.h"
 #include "mol_layout.h"
-#include "mol_select.h"
 
 namespace mol {
 
@@ -106,8 +105,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(Score
     // ordinary loads consumed at the end of the unit in round 3: B = 1 ... 8 all 2-5 % slower.  What does help these shells is the
     // K-chunk lookahead inside GEMM1, above.  An early touch of THIS tile's gate rows, read at the head of the epilogue, changed nothing
     // either: the epilogue's own request-ahead ring already covers them.)
-    SelNone none;
-    U::template queries<G, PX, false>(D1, p, none, g, row, tile * kTileItems, smem, tGi, lane, hi, x);
+    U::template queries<G, PX>(D1, p, g, row, tile * kTileItems, smem, tGi, lane, hi, x);
   }
 }
 
@@ -126,15 +124,13 @@ __device__ __forceinline__ void dma_floats(const float* __restrict__ src, float*
   }
 }
 
-template <class U, int PQ, int PX, int DD, int H, int NW, bool SEL = false>
+template <class U, int PQ, int PX, int DD, int H, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(ScoreArgs p) {
   using G = Geo<PQ, PX, DD, H>;
   MOL_RUN_IF(p.run_if);
   static_assert(G::kTileFloats % 256 == 0, "tile must be a whole number of 1 KiB pieces");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* tiles = smem + U::template kLdsWeightFloats<G>;  // two tile buffers
-  __shared__ std::conditional_t<SEL, SelLds, SelNone> sel;   // fused selection (mol_select.h): a separate instantiation, the dense kernel carries none of it
-  if constexpr (SEL) sel_init(p, sel);
   U::template stage<G, NW>(p, smem);
 
   const int lane = threadIdx.x & 63;
@@ -148,10 +144,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(Score
     // (1) my pieces of `tile` have landed (vmcnt(0)); (2) barrier: every wave's pieces have, and every wave
     // is done with the previous tile, so the other buffer may be overwritten
     __syncthreads();
-    if constexpr (SEL) {   // before the DMA: see sel_refresh
-      sel_refresh<NW * 64>(p, sel, it);
-      sel_checkpoint<NW * 64>(p, sel, it, (int)blockIdx.x, (int)gridDim.x);
-    }
     const int64_t next = tile + gridDim.x;
     if (next < p.n_tiles) dma_floats<NW>(p.ipack + next * (int64_t)G::kTileFloats, tiles + (cur ^ 1) * G::kTileFloats, G::kTileFloats, wave, lane);
     const float4* tEx = reinterpret_cast<const float4*>(tiles + cur * G::kTileFloats);
@@ -163,7 +155,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(Score
 #define RAILS_STAGED_PIPE 0   // GEMM1 one K-chunk ahead with the tile in LDS: measured no difference (6.34 ms either way)
 #endif
       U::template gemm1<G, PX, DD, false, RAILS_STAGED_PIPE>(D1, eq, tEx, lane);
-      U::template queries<G, PX, SEL>(D1, p, sel, g, -1, tile * kTileItems, smem, tGi, lane, hi, x);
+      U::template queries<G, PX>(D1, p, g, -1, tile * kTileItems, smem, tGi, lane, hi, x);
     }
   }
 }
@@ -179,7 +171,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged_kernel(Score
 // nsub = grid / leftover workgroups that split its query groups (group = sub + nsub * wave), so the round runs one unit
 // per SIMD instead of two on a few CUs (ML-20M: 853 tiles on 256 CUs -> 3 full rounds + 85 leftover tiles x 3 workgroups).
 // ---------------------------------------------------------------------------------------------
-template <class U, int PQ, int PX, int DD, int H, int NW, bool SEL = false>
+template <class U, int PQ, int PX, int DD, int H, int NW>
 __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged1_kernel(ScoreArgs p) {
   using G = Geo<PQ, PX, DD, H>;
   MOL_RUN_IF(p.run_if);
@@ -203,8 +195,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged1_kernel(Scor
   const bool has_left = b < left * nsub;
   const int64_t mine = rounds + (has_left ? 1 : 0);
   if (mine == 0) return;
-  __shared__ std::conditional_t<SEL, SelLds, SelNone> sel;
-  if constexpr (SEL) sel_init(p, sel);
   U::template stage<G, NW>(p, smem);
   auto tile_of = [&](int64_t i) -> int64_t { return i < rounds ? b + i * grid : rounds * grid + b % left; };
 
@@ -223,10 +213,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged1_kernel(Scor
     // (1) my DMA pieces of `tile` have landed (vmcnt(0)); (2) barrier: every wave's pieces have, and every wave is
     // done with the previous tile's gi buffer
     __syncthreads();
-    if constexpr (SEL) {
-      sel_refresh<NW * 64>(p, sel, i);
-      sel_checkpoint<NW * 64>(p, sel, i, (int)b, (int)grid);
-    }
     const float4* tEx = reinterpret_cast<const float4*>(sEx);
     const float4* tGi = reinterpret_cast<const float4*>(sGi + cur * G::kTileGiFloats);
     for (int it = 0; it < n_it; ++it) {
@@ -248,7 +234,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_staged1_kernel(Scor
           dma_floats<NW>(tn + G::kTileExFloats, sGi + (cur ^ 1) * G::kTileGiFloats, G::kTileGiFloats, wave, lane);
         }
       }
-      if (has) U::template queries<G, PX, SEL>(D1, p, sel, g, -1, tile * kTileItems, smem, tGi, lane, hi, x);
+      if (has) U::template queries<G, PX>(D1, p, g, -1, tile * kTileItems, smem, tGi, lane, hi, x);
     }
   }
 }
@@ -266,15 +252,10 @@ template <class U, int PQ, int PX, int DD, int H, int NW, bool STAGED>
 static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using G = Geo<PQ, PX, DD, H>;
   constexpr size_t lds = ((size_t)U::template kLdsWeightFloats<G> + (STAGED ? 2 * (size_t)G::kTileFloats : 0)) * sizeof(float);
-  // the fused-selection instantiation exists for the default staged kernel only, and only where its LDS state fits next to the tiles
-  // (the dense instantiation carries no SelLds: its fit test is the tiles and weights alone)
-  constexpr bool kSelBuilt = STAGED && NW == 8 && lds + sizeof(SelLds) <= 160 * 1024;
   if constexpr (lds > 160 * 1024) {
     set_error("staged scoring kernel needs %zu B of LDS", lds);
     return kErrUnsupported;
   } else {
-    // fused selection needs the tile loop's barriers for its checkpoints: the independent-wave shell stays dense
-    if (a.sel_list && !kSelBuilt) { set_error("fused selection is not available in this shell (fewer than %d query groups, per-row candidates, forced variants)", kScoreWaves); return kErrUnsupported; }
     if (a.dry_run) return kOk;
     const int wg_per_cu = (NW == 4 && lds <= 80 * 1024) ? 2 : 1;
     int64_t grid;
@@ -285,7 +266,6 @@ static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
       grid = n_units;   // fewer units than wave slots: one unit per workgroup first (wave-major remainder mapping)
     }
     if (grid > (int64_t)n_cu * wg_per_cu) grid = (int64_t)n_cu * wg_per_cu;
-    if (a.sel_list && grid > kSelSegs) grid = kSelSegs;   // one survivor segment per workgroup
     if (grid < 1) return kOk;
     auto go = [&](auto kernel) {
       static DynLdsOnce once;   // one per kernel (the lambda is instantiated per kernel type)
@@ -293,12 +273,9 @@ static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
       hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(NW * 64), lds, stream, a);
       return hipGetLastError() == hipSuccess ? (int)kOk : (int)kErrLaunch;
     };
-    if constexpr (kSelBuilt) {
-      if (a.sel_list) return go(&mol_score_staged_kernel<U, PQ, PX, DD, H, NW, true>);
-    }
     if constexpr (STAGED) {
       if (a.cand_pos) { set_error("indexed candidates need the independent-wave shell"); return kErrUnsupported; }
-      return go(&mol_score_staged_kernel<U, PQ, PX, DD, H, NW, false>);
+      return go(&mol_score_staged_kernel<U, PQ, PX, DD, H, NW>);
     } else {
       if constexpr (U::kIndexedCandidates && NW == 8) {
         if (a.cand_pos) return go(&mol_score_direct_kernel<U, PQ, PX, DD, H, NW, true>);
@@ -313,25 +290,20 @@ template <class U, int PQ, int PX, int DD, int H, int NW>
 static int launch_staged1(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using G = Geo<PQ, PX, DD, H>;
   constexpr size_t lds = ((size_t)U::template kLdsWeightFloats<G> + (size_t)G::kTileExFloats + 2 * (size_t)G::kTileGiFloats) * sizeof(float);
-  constexpr bool kSelBuilt = NW == 8 && lds + sizeof(SelLds) <= 160 * 1024;
   if constexpr (lds > 160 * 1024) {
     set_error("single-buffer staged scoring kernel needs %zu B of LDS", lds);
     return kErrUnsupported;
   } else {
-    if (a.sel_list && !kSelBuilt) { set_error("fused selection is not available in this forced variant"); return kErrUnsupported; }
     if (a.dry_run) return kOk;
     if (a.n_tiles < 1) return kOk;
     auto go = [&](auto kernel) {
       static DynLdsOnce once;
       if (ensure_dyn_lds(once, reinterpret_cast<const void*>(kernel), (int)lds) != kOk) return (int)kErrLaunch;
       // always a full grid: the leftover-round split needs the idle workgroups (they exit at once otherwise)
-      hipLaunchKernelGGL(kernel, dim3((unsigned)(a.sel_list && n_cu > kSelSegs ? kSelSegs : n_cu)), dim3(NW * 64), lds, stream, a);
+      hipLaunchKernelGGL(kernel, dim3((unsigned)n_cu), dim3(NW * 64), lds, stream, a);
       return hipGetLastError() == hipSuccess ? (int)kOk : (int)kErrLaunch;
     };
-    if constexpr (kSelBuilt) {
-      if (a.sel_list) return go(&mol_score_staged1_kernel<U, PQ, PX, DD, H, NW, true>);
-    }
-    return go(&mol_score_staged1_kernel<U, PQ, PX, DD, H, NW, false>);
+    return go(&mol_score_staged1_kernel<U, PQ, PX, DD, H, NW>);
   }
 }
 

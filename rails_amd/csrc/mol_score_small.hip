@@ -403,7 +403,7 @@ int launch_small(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   constexpr int NW = RAILS_SMALL_NW, kWgPerCu = RAILS_SMALL_WGCU;
   constexpr size_t lds = (size_t)G::kPackFloats * sizeof(float);
   static_assert(kWgPerCu * lds <= 160 * 1024, "workgroups per CU");
-  if (a.per_row || a.cand_pos || a.sel_list || a.split) { set_error("the small-unit kernel scores a shared corpus densely in fp32 only"); return kErrUnsupported; }
+  if (a.per_row || a.cand_pos || a.split) { set_error("the small-unit kernel scores a shared corpus densely in fp32 only"); return kErrUnsupported; }
   if (a.dry_run) return kOk;
   const int64_t n_units = ((a.n_items + 15) / 16) * ((a.B + 1) / 2);
   int64_t grid = (n_units + NW - 1) / NW;

@@ -436,10 +436,6 @@ static int launch_wsplit(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using W = WsGeo<P, PQ, PX, DD, H>;
   constexpr size_t lds = (size_t)W::kLdsFloats * sizeof(float);
   static_assert(lds <= 160 * 1024, "exchange buffers must fit LDS");
-  // Fused selection (mol_select.h) is not built into the team kernel: a workgroup here keeps meeting the same query pair (its
-  // survivors would need 16 x the segment of the register-resident shells), and what the dense path pays for the selection at this
-  // shape is 0.5 % of a step.
-  if (a.sel_list) { set_error("fused selection is not available for the 256-logit team kernel"); return kErrUnsupported; }
   if (a.cand_pos) { set_error("indexed candidates are not available for the 256-logit team kernel (gather them: rails_mol_index_gather)"); return kErrUnsupported; }
   if (a.dry_run) return kOk;
   static DynLdsOnce once;

@@ -638,9 +638,6 @@ struct RowSelectArgs {
   const float* scores; int64_t ld; int64_t n; int64_t chunk;     // SCORES source: row r, chunk c = [c*chunk, min(n, (c+1)*chunk))
   const unsigned short* scores16;                                // SCORES source held as bf16 bit patterns (then `scores` is unused)
   const unsigned long long* keys_in; int keys_per_row;           // KEYS source
-  // KEYS source filled by the scoring kernels (mol_select.h): sparse rows, empty slots are 0.  The launch consumes the lists: it
-  // zeroes the slots it read and resets the rows' bounds
-  unsigned int* keys_thr;
   int k; int lds_keys;
   const int64_t* ids; int64_t ids_row_stride;                    // final output (out_scores != NULL)
   const int64_t* ids_index; int64_t ids_index_ld;                // map_id
@@ -683,14 +680,6 @@ __global__ __launch_bounds__(kRowThreads) void row_select_kernel(const RowSelect
       const unsigned long long kv = i < cnt ? src[i] : 0ull;
       v[j] = (unsigned int)(kv >> 32);
       lo[j] = (unsigned int)kv;
-    }
-    if (a.keys_thr) {   // leave the list as the next scoring launch expects it: all zeros, no bound
-#pragma unroll
-      for (int j = 0; j < VPT; ++j) {
-        const int i = j * kRowThreads + tid;
-        if (i < cnt && (v[j] | lo[j])) const_cast<unsigned long long*>(src)[i] = 0ull;
-      }
-      if (tid == 0) a.keys_thr[row] = 0u;
     }
   } else {
     const int64_t b64 = (int64_t)blockIdx.y * a.chunk;
@@ -893,7 +882,6 @@ static int launch_row_select(RowSelectArgs a, int rows, int chunks, int elements
     if (elements <= 48 * kRowThreads) return launch_row_select_t<48, KEYS>(a, rows, chunks, stream);
   } else {
     if (elements <= 24 * kRowThreads) return launch_row_select_t<24, KEYS>(a, rows, chunks, stream);
-    if (elements <= 32 * kRowThreads) return launch_row_select_t<32, KEYS>(a, rows, chunks, stream);
   }
   set_error("row select: %d elements per workgroup", elements);
   return kErrUnsupported;
@@ -1186,22 +1174,6 @@ int select_sublists(const unsigned long long* keys, const unsigned int* counts, 
   else if (cap <= 16 * kRowThreads) hipLaunchKernelGGL((sublist_select_kernel<16>), dim3(rows), dim3(kRowThreads), lds, stream, a);
   else hipLaunchKernelGGL((sublist_select_kernel<24>), dim3(rows), dim3(kRowThreads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
-}
-
-// Final selection of the fused score + select path (mol_select.h): sparse rows of `cap` slots, empty ones 0.
-// Same outputs as topk() on the dense logits -- the k largest keys, id map and (optionally) the fused seen-id filter.
-int select_lists(unsigned long long* lists, unsigned int* thr, int rows, int cap, int k, const int64_t* ids,
-                 int64_t ids_row_stride, float* out_scores, int64_t* out_ids, hipStream_t stream,
-                 const int64_t* f_invalid, int f_width, int f_k) {
-  if (rows <= 0 || k <= 0) return kOk;
-  if (k > kRowFastK || cap > 32 * kRowThreads || k > cap) { set_error("select_lists: k = %d of %d keys per row is out of range", k, cap); return kErrUnsupported; }
-  if (f_invalid && !(k <= kFuseMaxK && f_width >= 0 && f_width <= kFuseMaxW && f_k > 0 && f_k <= k)) { set_error("select_lists: the seen-id filter cannot be fused at k = %d, width = %d", k, f_width); return kErrUnsupported; }
-  RowSelectArgs b{};
-  b.keys_in = lists; b.keys_per_row = cap; b.k = k;
-  b.keys_thr = thr;
-  b.ids = ids; b.ids_row_stride = ids_row_stride; b.out_scores = out_scores; b.out_ids = out_ids;
-  b.f_invalid = f_invalid; b.f_width = f_width; b.f_k = f_k;
-  return launch_row_select<true>(b, rows, 1, cap, stream);
 }
 
 // ---- seen-id filter ----------------------------------------------------------------------------

@@ -404,64 +404,6 @@ class MolEngine:
             )
         return out
 
-    # scoring with the selection fused in (include/rails_amd.h rails_mol_score_topk): no (B, N) logits are read back
-    def score_topk_supported(self, batch: int, n_items: int, k: int) -> bool:
-        return bool(self.lib.rails_mol_score_topk_supported(C.byref(self.dense_shape), int(batch), int(n_items), int(k)))
-
-    def _score_topk_workspace(self, batch: int, device: torch.device) -> torch.Tensor:
-        """Zero-filled once; every call leaves it zeroed again (the selection launch consumes the lists)."""
-        key = (batch, device)
-        ws = self._sel_ws.get(key) if hasattr(self, "_sel_ws") else None
-        if ws is None:
-            if not hasattr(self, "_sel_ws"):
-                self._sel_ws = {}
-            ws = torch.zeros(self.lib.rails_mol_score_topk_workspace_bytes(batch), dtype=torch.uint8, device=device)
-            self._sel_ws[key] = ws
-        return ws
-
-    def score_topk(self, qpack: torch.Tensor, batch: int, index: MolIndex, k: int, ids: Optional[torch.Tensor] = None,
-                   invalid_ids: Optional[torch.Tensor] = None, k_out: int = 0, logits_out: Optional[torch.Tensor] = None, between=None):
-        """-> (scores (B, k), ids (B, k), status) or, with invalid_ids, (out_ids (B, k_out), out_scores (B, k_out), status): what
-        score_dense + topk (+ filter_seen_ids) return, bit for bit, unless status (a device int32) is non-zero -- a survivor list
-        overflowed; the caller then re-runs the dense entry points, e.g. with run_if=status."""
-        dev = index.buf.device
-        stride = 0
-        if ids is not None:
-            if ids.dtype != torch.int64 or ids.device != dev:
-                ids = ids.to(device=dev, dtype=torch.int64)
-            if ids.dim() == 2 and ids.shape[0] == batch and batch > 1:
-                ids = ids.contiguous()
-                stride = ids.shape[1]
-            else:
-                ids = ids.reshape(-1).contiguous()
-        ws = self._score_topk_workspace(batch, dev)
-        width = 0
-        if invalid_ids is not None:
-            invalid_ids = invalid_ids.to(device=dev, dtype=torch.int64).contiguous()
-            width = invalid_ids.shape[1]
-        ko = k_out if invalid_ids is not None else k
-        out_s = torch.empty((batch, ko), dtype=torch.float32, device=dev)
-        out_i = torch.empty((batch, ko), dtype=torch.int64, device=dev)
-        ld = logits_out.stride(0) if logits_out is not None else 0
-        with _on_device(dev):
-            if between is None:
-                _lib.check(
-                    self.lib.rails_mol_score_topk(C.byref(self.dense_shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(index.buf), index.n_items, k, _ptr(ids), stride,
-                                                  _ptr(logits_out), ld, _inv_ptr(invalid_ids), width, k_out if invalid_ids is not None else 0,
-                                                  _ptr(out_s), _ptr(out_i), _ptr(ws), ws.numel(), _stream()),
-                    "rails_mol_score_topk",
-                )
-            else:   # the same two launches with a callback between them (bench.py: the event that closes the scoring kernel's bracket)
-                _lib.check(self.lib.rails_mol_score_survivors(C.byref(self.dense_shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(index.buf), index.n_items, k,
-                                                              _ptr(logits_out), ld, _ptr(ws), ws.numel(), _stream()), "rails_mol_score_survivors")
-                between()
-                _lib.check(self.lib.rails_select_survivors(batch, k, _ptr(ids), stride, _inv_ptr(invalid_ids), width, k_out if invalid_ids is not None else 0,
-                                                           _ptr(out_s), _ptr(out_i), _ptr(ws), ws.numel(), _stream()), "rails_select_survivors")
-        status = ws[4 * batch: 4 * batch + 4].view(torch.int32)
-        if invalid_ids is not None:
-            return out_i, out_s, status
-        return out_s, out_i, status
-
     def score_candidates(self, qpack: torch.Tensor, batch: int, cand_index: MolIndex, n_cand_padded: int) -> torch.Tensor:
         out = torch.empty((batch, n_cand_padded), dtype=torch.float32, device=cand_index.buf.device)
         with _on_device(cand_index.buf.device):

@@ -211,34 +211,6 @@ class MoLBruteForceTopK(MoLTopKModule):
             return ex.score_dense(qpack, query_embeddings.size(0), self._dense_fp32_index())
         return super().all_logits(query_embeddings, **kwargs)
 
-    # Selection fused into the scoring kernels (rails_mol_score_topk): one scoring launch that appends the survivors of a running
-    # per-query bound, one selection launch over the survivor lists -- no pass over (B, N) logits.  Same result bit for bit.
-    # OPT-IN (RAILS_FUSED_SELECT=1 or FUSED_SELECT = True): measured on amzn-books it saves ~20 us of selection per step and costs
-    # ~85 us inside the scoring kernel (checkpoint selections 31 us, survivor appends 53 us), so the dense
-    # kernels + rails_topk stay the default.  Where the C side does not offer it (fewer than eight query groups, k > 384, corpora
-    # below 131 072 items, shells without checkpoints) and beyond the logit budget (the overflow fallback below needs the dense
-    # buffer) the dense kernels run regardless.
-    FUSED_SELECT = __import__("os").environ.get("RAILS_FUSED_SELECT", "0") != "0"
-
-    def _fused_ok(self, eng, B: int, N: int, k: int) -> bool:
-        return self.FUSED_SELECT and B * N * 4 <= self.MAX_LOGIT_BYTES and eng.score_topk_supported(B, N, k)
-
-    def _forward_fused(self, query_embeddings: torch.Tensor, k: int, invalid_ids: Optional[torch.Tensor] = None, k_out: int = 0, **kwargs):
-        eng = self._bind()
-        B, N = query_embeddings.size(0), self._index.n_items
-        n_q = eng.lib.rails_mol_query_pack_floats(E.C.byref(eng.shape), B)
-        qpack, _, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"), out=self._buf("qpack", n_q, torch.float32))
-        a, b, status = eng.score_topk(qpack, B, self._index, k, ids=self._ids_flat, invalid_ids=invalid_ids, k_out=k_out)
-        # A survivor list overflowed (scores ascending in position, say): the dense pass, enqueued under the status word as its
-        # launch predicate, overwrites the outputs.  No-ops otherwise; the host never looks.
-        logits = eng.score_dense(qpack, B, self._index, out=self._buf("logits", B * N, torch.float32).view(B, N), run_if=status)
-        ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(B, N, k), torch.uint8)
-        if invalid_ids is None:
-            E.topk(logits, k, ids=self._ids_flat, workspace=ws, out=(a, b), run_if=status)
-        else:
-            E.topk_filtered(logits, k, self._ids_flat, invalid_ids, k_out, workspace=ws, out=(a, b), run_if=status)
-        return a, b
-
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
         eng = self._bind()
         if eng.exact is not None:
@@ -246,9 +218,6 @@ class MoLBruteForceTopK(MoLTopKModule):
         B, N = query_embeddings.size(0), self._index.n_items
         if B * N * 4 > self.MAX_LOGIT_BYTES and k <= self.CHUNK_ITEMS:
             return self._forward_chunked(query_embeddings, k, **kwargs)
-        if sorted and self._fused_ok(eng, B, N, k):
-            scores, ids = self._forward_fused(query_embeddings, k, **kwargs)
-            return scores.to(query_embeddings.dtype), ids
         logits = self._all_logits_scratch(query_embeddings, **kwargs)
         ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(logits.shape[0], logits.shape[1], k), torch.uint8)
         scores, ids = E.topk(logits, k, ids=self._ids_flat, sorted=sorted, workspace=ws)
@@ -256,16 +225,13 @@ class MoLBruteForceTopK(MoLTopKModule):
 
     def forward_filtered(self, query_embeddings: torch.Tensor, k_prime: int, invalid_ids: torch.Tensor, k: int, **kwargs):
         """CandidateIndex.get_top_k_outputs' body for this module: top-k' + id map + seen-id filter with the filter fused into the final
-        selection launch (rails_mol_score_topk, or rails_topk_filtered on the dense logits) -> (top_k_ids (B, k), top_k_scores (B, k)),
+        selection launch (rails_topk_filtered on the dense logits) -> (top_k_ids (B, k), top_k_scores (B, k)),
         or None when the sizes / the precision route are outside the fused path (the caller then composes forward +
         filter_seen_ids: same bits)."""
         eng = self._bind()
         B, N = query_embeddings.size(0), self._index.n_items
         if eng.exact is not None or B * N * 4 > self.MAX_LOGIT_BYTES or not E.topk_filter_fusable(N, k_prime, invalid_ids.shape[1], k):
             return None
-        if self._fused_ok(eng, B, N, k_prime):
-            ids, scores = self._forward_fused(query_embeddings, k_prime, invalid_ids=invalid_ids, k_out=k, **kwargs)
-            return ids, scores.to(query_embeddings.dtype)
         logits = self._all_logits_scratch(query_embeddings, **kwargs)
         ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(B, N, k_prime), torch.uint8)
         ids, scores = E.topk_filtered(logits, k_prime, self._ids_flat, invalid_ids, k, workspace=ws)
@@ -360,21 +326,15 @@ class MoLBruteForceTopK(MoLTopKModule):
                                                self._buf("qpack32", n_q, torch.float32))
         s16 = self._buf("logits", B * N, torch.float32).view(B, N)
         ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(B, N, kc), torch.uint8)
-        if self._debug_first_pass_bias is None and self.FUSED_SELECT and eng.score_topk_supported(B, N, kc):
-            # the first pass writes its dense logits (the probes and the verification read them) AND the survivor lists: the
-            # candidate selection no longer re-reads (B, N)
-            c16, pos, status = eng.score_topk(qpack16, B, self._index, kc, logits_out=s16)
-            E.topk(s16, kc, workspace=ws, out=(c16, pos), run_if=status)
-        else:
-            hook = self._first_pass_hook        # measurement only (bench.py: events around the dominant launch, on its stream)
-            if hook is not None:
-                hook(0)
-            eng.score_dense(qpack16, B, self._index, out=s16)
-            if hook is not None:
-                hook(1)
-            if self._debug_first_pass_bias is not None:   # tests only: (positions, delta) -- the first pass is made to under-score these items
-                s16[:, self._debug_first_pass_bias[0]] -= self._debug_first_pass_bias[1]
-            c16, pos = E.topk(s16, kc, workspace=ws)
+        hook = self._first_pass_hook        # measurement only (bench.py: events around the dominant launch, on its stream)
+        if hook is not None:
+            hook(0)
+        eng.score_dense(qpack16, B, self._index, out=s16)
+        if hook is not None:
+            hook(1)
+        if self._debug_first_pass_bias is not None:   # tests only: (positions, delta) -- the first pass is made to under-score these items
+            s16[:, self._debug_first_pass_bias[0]] -= self._debug_first_pass_bias[1]
+        c16, pos = E.topk(s16, kc, workspace=ws)
         # two more tiles per query of probes (random + highest-norm items), re-scored too, so that the MONITORED bound |s16 - s32| <= eps is
         # watched outside the candidates as well (the a-priori bound needs no watching: the candidates' own errors are still compared
         # with it, and one above it is reported as a violation of the arithmetic model)

@@ -691,6 +691,8 @@ def test_avg_topk_drops_a_prefilter_that_filters_nothing(dev, monkeypatch):
         b._table()[4321] *= 1000.0                                   # an outlier row sets the scale of the whole int8 copy
         b._coarse_prefilter = eng.build_coarse_prefilter(b._table())
         outs_b = [b(q, k=20) for _ in range(4)]
+        torch.cuda.synchronize()                                     # the statistics travel to the host behind the launches: no host wait inside forward
+        outs_b.append(b(q, k=20))                                    # ... and are looked at by the next call that finds them landed
         assert b._coarse_prefilter is None                           # dropped after the statistics were read
         b2 = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=20)
         b2._table()[4321] *= 1000.0
@@ -1510,7 +1512,7 @@ def test_f16x3_exact_equals_the_fp32_path_bit_for_bit(dev, workload, N, B, k, mo
             assert st["eps_rigorous"] >= st["eps_default"] and st["eps_rigorous"] <= 2.0 / cfg.temperature + 1.0
             assert st["eps_rigorous_usable"] is (mode == "f16x3-exact")
             if mode == "f16x3-exact":
-                assert st["proved_calls"] == st["calls"] - st["fallbacks"] and st["bound_violations"] == 0 and st["eps"] == pytest.approx(st["eps_rigorous"], rel=1e-4)
+                assert st["proved_calls"] >= 2 - st["fallbacks"] and st["bound_violations"] == 0 and st["eps"] == pytest.approx(st["eps_rigorous"], rel=1e-4)
         inv = ids[0, torch.randint(0, N, (B, 7), device=dev)]
         kk = min(k, 120)
         ci = rails_amd.CandidateIndex(ids, X)
@@ -1889,8 +1891,8 @@ def test_standalone_module_forwards(fx, mol, dev):
         assert got.shape == ref.shape and float((got.cpu() - ref).abs().max()) <= LOGIT_TOL, (fx.name, name, float((got.cpu() - ref).abs().max()))
 
 
-# ---- selection fused into the scoring kernels (rails_mol_score_topk) -----------------------------------------------------------
-def _fused_case(cfg_name, N, B, dev, precision, seed=31, dup=1):
+# ---- hand-driven kernels on a dense binding --------------------------------------------------------------------------------------
+def _dense_case(cfg_name, N, B, dev, precision, seed=31, dup=1):
     cfg = O.CONFIGS[cfg_name]
     w = O.synthetic_weights(cfg, seed=seed)
     base = torch.from_numpy(O.hash_item_table(seed, 0, (N + dup - 1) // dup, cfg.item_embedding_dim))
@@ -1898,114 +1900,8 @@ def _fused_case(cfg_name, N, B, dev, precision, seed=31, dup=1):
     ids = (torch.arange(N, dtype=torch.int64, device=dev) * 5 + 3).unsqueeze(0)
     q = O.synthetic_queries(cfg, B, seed=seed + 1).to(dev)
     kw = {"user_ids": torch.arange(B, dtype=torch.int64, device=dev) * 7 + 1} if cfg.uid_embedding_hash_sizes else {}
-    tk = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, precision), X, ids)
+    tk = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, precision), X, ids, exact_mode="dense")   # the callers drive this engine's kernels by hand
     return cfg, tk, q, kw
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("precision", PRECISIONS)
-@pytest.mark.parametrize("cfg_name,N,B,k", [("amzn-books", 140_003, 32, 200), ("amzn-books", 300_000, 37, 288), ("amzn-books", 131_072, 32, 10),
-                                            ("amzn-books", 695_762, 32, 384), ("ml-20m", 150_001, 32, 200), ("ml-1m", 200_011, 64, 120)])
-def test_fused_score_topk_equals_the_dense_path(dev, cfg_name, N, B, k, precision):
-    """rails_mol_score_topk (survivor lists appended by the scoring kernels under a running bound + one selection launch) against
-    rails_mol_score_dense + rails_topk: same scores, same ids, same tie order, bit for bit (also when the status word reports the dense pass); the workspace is
-    left zeroed; a second call (which starts from the state the first one left) agrees."""
-    cfg, tk, q, kw = _fused_case(cfg_name, N, B, dev, precision)
-    with torch.inference_mode():
-        eng = tk._bind()
-        assert eng.score_topk_supported(B, N, k), "the case is meant to run the fused path"
-        tk.FUSED_SELECT = False
-        r_s, r_i = tk(q, k=k, **kw)
-        tk.FUSED_SELECT = True
-        for _ in range(2):
-            qpack, _, _ = eng.query_pack(q, kw.get("user_ids"))
-            s, i, status = eng.score_topk(qpack, B, tk._index, k, ids=tk._ids_flat)
-            # 0, or 1 when a survivor segment filled up and the predicated dense pass produced the result: which workgroup publishes
-            # a bound first is a matter of scheduling, and a corpus just above the fused path's minimum leaves little slack
-            # (tools/fused_select_stats.py counts the overflows; the forced case is the overflow test below)
-            assert int(status) in (0, 1)
-            assert torch.equal(s, r_s) and torch.equal(i, r_i)
-            ws = eng._score_topk_workspace(B, q.device)
-            assert int(ws.count_nonzero()) == 0, "the selection launch must leave the lists and bounds zeroed"
-        s, i = tk(q, k=k, **kw)                      # the module route (fused path + predicated dense fallback that does not run)
-        assert torch.equal(s, r_s) and torch.equal(i, r_i)
-        # with the seen-id filter fused into the selection launch
-        width, k_out = 61, max(1, k // 2)
-        inv = r_i[:, torch.randperm(k, device=dev)[:width]] if k >= width else r_i[:, :1].repeat(1, width)
-        if E.topk_filter_fusable(N, k, width, k_out):
-            want_i, want_s = E.filter_seen_ids(r_i, r_s, inv, k_out)
-            got_i, got_s = tk.forward_filtered(q, k, inv, k_out, **kw)
-            assert torch.equal(got_i, want_i) and torch.equal(got_s, want_s)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("precision", PRECISIONS)
-def test_fused_score_topk_with_ties_across_the_kth_place(dev, precision):
-    """Every item eight times: equal scores straddle the k-th place and the survivors of a tie group arrive in any order; the
-    64-bit keys (score, ~position) still give the dense path's order."""
-    cfg, tk, q, kw = _fused_case("amzn-books", 160_000, 32, dev, precision, dup=8)
-    with torch.inference_mode():
-        tk.FUSED_SELECT = False
-        r_s, r_i = tk(q, k=204)
-        tk.FUSED_SELECT = True
-        s, i = tk(q, k=204)
-        assert torch.equal(s, r_s) and torch.equal(i, r_i)
-        assert bool((r_s[:, 0] == r_s[:, 7]).all())
-
-
-@pytest.mark.gpu
-def test_fused_score_topk_overflow_takes_the_dense_pass(dev):
-    """Adversarial order: the corpus sorted by ASCENDING score of the query, so every item beats the running bound and the survivor
-    list (32 768 keys) overflows.  The status word is raised and the module's dense pass, enqueued under it as launch predicate,
-    returns the right answer; the next call on a benign batch runs fused again (the workspace was left clean)."""
-    cfg = O.CONFIGS["amzn-books"]
-    w = O.synthetic_weights(cfg, seed=8)
-    N, B, k = 150_000, 32, 200
-    X0 = torch.from_numpy(O.hash_item_table(21, 0, N, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
-    ids = torch.arange(N, dtype=torch.int64, device=dev).unsqueeze(0)
-    q1 = O.synthetic_queries(cfg, 1, seed=5).to(dev)
-    with torch.inference_mode():
-        mol = build_module(cfg, w, dev, None)
-        order = rails_amd.MoLBruteForceTopK(mol, X0, ids).all_logits(q1)[0].argsort()
-        X = X0[:, order]                                   # ascending in the query's score
-        tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
-        q = q1.repeat(B, 1)
-        eng = tk._bind()
-        assert eng.score_topk_supported(B, N, k)
-        qpack, _, _ = eng.query_pack(q, None)
-        _, _, status = eng.score_topk(qpack, B, tk._index, k, ids=tk._ids_flat)
-        assert int(status) == 1
-        ws = eng._score_topk_workspace(B, q.device)
-        assert int(ws[: 4 * B].count_nonzero()) == 0 and int(ws[4 * B + 4:].count_nonzero()) == 0   # bounds and lists clean, only the status word set
-        tk.FUSED_SELECT = False
-        r_s, r_i = tk(q, k=k)
-        tk.FUSED_SELECT = True
-        s, i = tk(q, k=k)
-        assert torch.equal(s, r_s) and torch.equal(i, r_i)
-        q2 = O.synthetic_queries(cfg, B, seed=6).to(dev)  # benign batch afterwards, on the shuffled corpus of another module
-        tk2 = rails_amd.MoLBruteForceTopK(mol, X0, ids)
-        tk2.FUSED_SELECT = False
-        r_s, r_i = tk2(q2, k=k)
-        tk2.FUSED_SELECT = True
-        s, i = tk2(q2, k=k)
-        assert torch.equal(s, r_s) and torch.equal(i, r_i)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["f16x3-exact", "f16-exact"])
-def test_verified_modes_with_the_fused_first_pass(dev, mode):
-    """The verified modes' first pass through rails_mol_score_topk (dense first-pass logits for the probes AND survivor lists for the
-    candidate selection): still the fp32 module's output bit for bit."""
-    cfg, tk32, q, kw = _fused_case("amzn-books", 200_003, 32, dev, None)
-    with torch.inference_mode():
-        r_s, r_i = tk32(q, k=200, **kw)
-        tk = rails_amd.MoLBruteForceTopK(build_module(cfg, O.synthetic_weights(cfg, seed=31), dev, mode), tk32._item_embeddings, tk32._item_ids)
-        tk.FUSED_SELECT = True
-        for _ in range(3):
-            s, i = tk(q, k=200, **kw)
-            assert torch.equal(s, r_s) and torch.equal(i, r_i)
-        st = tk.stats()
-        assert st["calls"] == 3 and st["fallbacks"] == 0
 
 
 @pytest.mark.gpu
@@ -2038,7 +1934,7 @@ def test_indexed_candidate_scoring_equals_gather_then_score(dev, cfg_name, N, B,
     """rails_mol_score_indexed (per-row candidates read in place from the shared index) against rails_mol_index_gather +
     rails_mol_score_candidates: the same arithmetic per (query, item) pair, hence the same bits -- duplicates, the first and the
     last item of the corpus (a ragged last tile) included."""
-    cfg, tk, q, kw = _fused_case(cfg_name, N, B, dev, None)
+    cfg, tk, q, kw = _dense_case(cfg_name, N, B, dev, None)
     with torch.inference_mode():
         eng = tk._bind()
         assert eng.score_indexed_supported(B, n_cand)

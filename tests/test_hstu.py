@@ -183,7 +183,7 @@ def test_encode_rejects_out_of_range_lengths():
                 clamped = bad.clamp(min=1, max=ids.shape[1])
                 before = type(m).length_violations()
                 assert torch.equal(m.encode(bad, ids, emb, {}), m.encode(clamped, ids, emb, {}))
-                assert type(m).length_violations() == before + 1        # ... and counted: the clamp is not silent
+                assert type(m).length_violations() > before               # ... and counted: the clamp is not silent
                 type(m).STRICT_DEVICE_LENGTHS = True
                 try:
                     with pytest.raises(ValueError, match="past_lengths"):

@@ -42,5 +42,5 @@ def test_hot_kernels_of_the_baseline_shapes():
     assert len(small) == 3 and all(r["scratch"] == 0 and r["vgpr"] <= 128 for r in small)          # four waves per SIMD, no spills
     assert all(r["scratch"] == 0 for r in pick(r"mol_score_wsplit_kernel<"))                         # 16x16x64 (config 4), all precisions
     assert all(r["scratch"] == 0 for r in pick(r"mol_score_\w+_kernel<mol::Fp32Unit, 8, 4, (64|128), 128, 8"))   # ML-1M / ML-20M shapes
-    head = pick(r"mol_score_staged_kernel<mol::Fp32Unit, 8, 8, 32, 128, 8, false>")
+    head = pick(r"mol_score_staged_kernel<mol::Fp32Unit, 8, 8, 32, 128, 8>")
     assert len(head) == 1 and head[0]["scratch"] <= 20                                               # the headline kernel (amzn-books, fp32)

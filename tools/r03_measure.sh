@@ -6,8 +6,6 @@ python bench.py --workload synthetic-16x16x64 --no-cpu-baseline --no-matrix --st
 rm -f $O/shard_steps.txt
 for R in 2 4 8; do for pr in fp32 f16x3 f16-exact; do p=""; [ $pr != fp32 ] && p="--precision $pr"; python tools/shard_step_profile.py --world $R $p 2>&1 | tail -1 >> $O/shard_steps.txt; python tools/shard_step_profile.py --world $R $p --pipeline 2>&1 | tail -1 >> $O/shard_steps.txt; done; done
 python tools/algorithms_bench.py --workload amzn-books > $O/algorithms_books.json 2> $O/algorithms_books.err
-python tools/fused_select_stats.py > $O/fused_select_stats.txt 2>&1
-python tools/fused_select_timing.py > $O/fused_select_timing.txt 2>&1
 python tools/hstu_bench.py > $O/hstu_encoder.json 2> $O/hstu.err
 python bench.py --batch 128 --no-cpu-baseline --no-matrix --no-other-workloads --steps 10 --warmup 2 > $O/bench_b128.json 2> $O/bench_b128.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c5 -o r03c5 -- python bench.py --workload synthetic-8x8x32 --two-pass 1000 --device-table --no-cpu-baseline --no-matrix --no-other-workloads --no-fast-path --steps 10 --warmup 2 > $O/two_pass_125m.json 2> $O/two_pass_125m.err
