@@ -720,7 +720,21 @@ def _verdicts_clear(pending: list) -> bool:
 
 class MoLAvgTopK(MoLTopKModule):
     DEVICE_REDO_BYTES = 1 << 30   # materialised score matrices up to this size are kept as the device-side redo buffer of a fused scan;
-                                  # beyond it (a 125 M-item shard: 16 GB) the counts are read on the host after the call is enqueued
+                                  # beyond it (a 125 M-item shard: 16 GB) the counts are read on the host after the call is enqueued --
+    DEVICE_REDO_FREE_FRACTION = 0.25   # -- unless the buffer fits this fraction of the memory that is free when it is first needed (a full
+                                       # config-5 shard on a 288 GB part: 16 GB of ~68 GB): the redo then stays on the device and no call waits for the host
+
+    def _device_redo_fits(self, nbytes: int) -> bool:
+        """May a (B, N) redo buffer of `nbytes` live on the device?  Decided once per size (the buffer is recycled across calls)."""
+        if nbytes <= self.DEVICE_REDO_BYTES:
+            return True
+        if self.DEVICE_REDO_BYTES <= 0 or self.DEVICE_REDO_FREE_FRACTION <= 0.0:     # tests: "as if it did not fit"
+            return False
+        memo = self.__dict__.setdefault("_redo_fit_memo", {})
+        if nbytes not in memo:
+            free, _ = torch.cuda.mem_get_info(self._item_embeddings.device)
+            memo[nbytes] = nbytes <= self.DEVICE_REDO_FREE_FRACTION * free
+        return memo[nbytes]
 
     """Two-pass approximate top-k (reference rails/indexing/mol_top_k.py:296-429): a bf16 dot product of the
     P_Q-summed query components against the P_X-averaged item components picks `avg_top_k` candidates per query,
@@ -814,7 +828,7 @@ class MoLAvgTopK(MoLTopKModule):
             if fused is not None:
                 # bad: 1 iff some row's candidate count is outside [K', capacity] -- raised by the call's key-selection launch
                 sc, idx, counts, bad = fused
-                if eq.shape[0] * n * 4 <= self.DEVICE_REDO_BYTES:
+                if self._device_redo_fits(eq.shape[0] * n * 4):
                     # the redo ON THE DEVICE: the materialising scan and its top-K' are enqueued under that flag as their launch
                     # predicate and overwrite (sc, idx) -- no-ops unless a count was out of range; nothing for the host to wait
                     # for (the (B, N) score buffer is recycled across calls)
@@ -869,7 +883,7 @@ class MoLAvgTopK(MoLTopKModule):
         # a 0.85 ms call on a 125 M-item shard) then run under the table scan of the neighbouring batch.  The caller's stream joins
         # a call's stream in result().  Calls that share the module's redo buffers (small corpora) stay on the caller's stream.
         side = None
-        if self.OVERLAP_BATCHES and query_embeddings.is_cuda and query_embeddings.size(0) * self.num_items * 4 > self.DEVICE_REDO_BYTES:
+        if self.OVERLAP_BATCHES and query_embeddings.is_cuda and not self._device_redo_fits(query_embeddings.size(0) * self.num_items * 4):
             if self._side_streams is None:
                 self._side_streams = [torch.cuda.Stream(query_embeddings.device), torch.cuda.Stream(query_embeddings.device)]
             side = self._side_streams[self._side_turn]
@@ -907,7 +921,8 @@ class MoLAvgTopK(MoLTopKModule):
             ids.record_stream(cur)
         redo = False
         if host is not None:
-            done.synchronize()
+            while not done.query():      # spin: the word is microseconds away, and a blocking wait parks the thread on an interrupt whose
+                pass                     # wake-up costs 50-100 us of GPU idle per batch (see MoLBruteForceTopK._read_stats)
             redo = int(host.max()) != 0
             if len(self._verdict_pool) < 8:
                 self._verdict_pool.append(host)

@@ -77,8 +77,8 @@ def test_f16_mfma_accumulation_model(dev):
         single = float(((d - exact).abs() / (U * (c64.abs() + psum)).clamp_min(1e-300)).max())
         print(f"f16 MFMA  {name:48s} max |e| / bound = {ratio:.3f}   max |e| / (u (|C| + sum |p|)) = {single:.3f}")
         worst = max(worst, ratio)
-        if "subnormal" in name:
-            assert float(d.abs().max()) > 0 and float(((d - exact).abs() / exact.abs().clamp_min(1e-300)).max()) < 2.0 ** -20, "f16 subnormal operands are flushed"
+        if "subnormal" in name:    # flushed operands would lose whole products: an error of the order of the magnitudes themselves
+            assert float(d.abs().max()) > 0 and float(((d - exact).abs() / (c64.abs() + psum).clamp_min(1e-300)).max()) < 2.0 ** -20, "f16 subnormal operands are flushed"
     print("f16 MFMA worst |e| / bound", worst, "KC", FB.KC, "KP", FB.KP)
     assert worst <= 0.8
 
@@ -108,7 +108,7 @@ def test_fp32_mfma_is_a_chain_of_fmas(dev):
 def test_scalar_transcendentals_are_one_ulp(dev):
     """H3: v_exp_f32 and v_rcp_f32 within 1 ulp (relative 2 u), and phi(t) = t / (1 + 2^t) as the kernels compute it within gamma(7) |phi|."""
     g = torch.Generator().manual_seed(2)
-    x = torch.cat([torch.randn(1 << 16, generator=g) * s for s in (0.1, 1.0, 8.0, 40.0)] + [torch.linspace(-126, 126, 1 << 14)])
+    x = torch.cat([torch.randn(1 << 16, generator=g) * s for s in (0.1, 1.0, 8.0, 40.0)] + [torch.linspace(-126, 126, 1 << 14)]).clamp(-140.0, 126.0)
     out = E.scalar_probe(x.to(dev)).cpu().double()
     x64 = x.double()
     normal = torch.exp2(x64) >= 2.0 ** -125                       # below the normal range v_exp_f32 returns 0 (H4: an absolute 2^-126, carried as OMEGA)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Step time of MoLBruteForceTopK in precisions fp32 / f16x3 / f16x3-exact through get_top_k_outputs on amzn-books (B = 32, k = 120,
+"""Step time of MoLBruteForceTopK in precisions fp32 / proved / f16x3 / f16x3-exact through get_top_k_outputs on amzn-books (B = 32, k = 120,
 k' = 200), for `rocprofv3 --kernel-trace --stats` (per-kernel times of the exact path's extra launches) or on its own (wall time).
   python tools/exact_step_profile.py [--precisions f16x3-exact] [--steps 50]
 """
@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--k", type=int, default=120)
     ap.add_argument("--width", type=int, default=80)
+    ap.add_argument("--k-prime", type=int, default=200, help="truncate_k_prime_to (the harness's timing protocol: 200)")
     args = ap.parse_args()
     cfg_key, N, _ = bench.WORKLOADS["amzn-books"]
     cfg = O.CONFIGS[cfg_key]
@@ -43,14 +44,13 @@ def main():
     cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)
     with torch.inference_mode():
         for pr in args.precisions.split(","):
-            mol.precision = None if pr == "fp32" else pr
-            tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
+            tk = bench.brute_force_module(mol, X, ids, pr)      # "fp32" = dense fp32 kernels, "proved" = the default exact path
             for _ in range(5):
-                cand.get_top_k_outputs(q, args.k, {}, tk, inv)
+                cand.get_top_k_outputs(q, args.k, {}, tk, inv, truncate_k_prime_to=args.k_prime)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                cand.get_top_k_outputs(q, args.k, {}, tk, inv)
+                cand.get_top_k_outputs(q, args.k, {}, tk, inv, truncate_k_prime_to=args.k_prime)
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / args.steps * 1e3
             print(f"{pr:12s} {ms:7.3f} ms per step  {args.batch / ms * 1e3:9.1f} queries/s  {getattr(tk, 'rescore_stats', '')}")
