@@ -1236,6 +1236,7 @@ def main() -> None:
                 "bound_violations": proved["bound_violations"], "output_identical_to_fp32_path": proved["identical"],
                 "eps_a_priori": proved["eps"], "candidates_per_query": proved["kc"], "gate_guard": {"max_abs_gq_seen": proved["guard_max"], "limit": proved["guard_limit"]},
                 "first_pass_kernel_ms": proved["score_ms"], "is_headline": proved["qualifies"],
+                "per_step_ms": [round(v, 3) for v in proved["steps_ms"]],
             }
             if proved["qualifies"]:
                 # `value` = the proved path; the returned scores ARE the fp32 kernels' bits (dtype f32); the dense fp32 measurement of this run moves beside it

@@ -158,6 +158,7 @@ class MoLBruteForceTopK(MoLTopKModule):
     # The proved mode needs both index formats resident (2 x the fp32 index bytes); corpora where that does not fit, corpora below
     # SPECULATE_MIN_ITEMS and modules whose bound is infinite (see the guards in f16x3_bound.py) run "dense".
     EXACT_MODE = __import__("os").environ.get("RAILS_EXACT_MODE", "proved")
+    PROVED_MIN_BATCH = 3          # smaller batches of the default mode run the dense fp32 kernels (see _forward_rescored)
 
     def _engine_for_bind(self) -> E.MolEngine:
         mol = self._mol_module
@@ -296,6 +297,11 @@ class MoLBruteForceTopK(MoLTopKModule):
         eps_proved = None if single else self._proved_eps()
         if eps_proved is not None and not math.isfinite(eps_proved):
             self.rescore_stats["unprovable_calls"] = self.rescore_stats.get("unprovable_calls", 0) + 1
+            return self._forward_fp32_dense(query_embeddings, k, **kwargs)
+        if eps_proved is not None and query_embeddings.size(0) < self.PROVED_MIN_BATCH and self._mol_module.engine() is not eng:
+            # one or two queries: the first pass saves ~0.08 ms per query against the dense fp32 kernels and the verification costs ~0.13 ms
+            # per call (amzn-books: 0.34 against 0.33 ms at B = 1) -- the default mode takes the dense kernels there (an explicit
+            # "f16x3-exact" precision keeps speculating)
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
         if eps_proved is not None:
             # candidates: every item within eps of the k-th score must be among them.  amzn-books, eps = 0.9-1.0: 470-680 items at k = 200,
@@ -490,14 +496,12 @@ class MoLBruteForceTopK(MoLTopKModule):
         tf = idx.buf.numel() // tiles
         gi_f = E.TILE_ITEMS * self._engine.spec.num_logits
         view = idx.buf.view(tiles, tf)[:, tf - gi_f :]
-        best = 0.0
-        for t0 in range(0, tiles, 1 << 16):
-            lo, hi = torch.aminmax(view[t0 : t0 + (1 << 16)])
-            lo, hi = float(lo), float(hi)
-            if lo != lo or hi != hi:
-                return math.inf
-            best = max(best, -lo, hi)
-        return best
+        parts = [torch.stack(torch.aminmax(view[t0 : t0 + (1 << 18)])) for t0 in range(0, tiles, 1 << 18)]    # chunks of 8 M items; no host wait per chunk
+        m = torch.stack(parts)                      # (chunks, 2): per-chunk (min, max); a NaN anywhere propagates
+        lo, hi = float(m[:, 0].min()), float(m[:, 1].max())
+        if lo != lo or hi != hi:
+            return math.inf
+        return max(-lo, hi, 0.0)
 
     def _count_proved(self, n_clear: int) -> None:
         """Calls whose verdict cleared count as PROVED while no observed |first pass - fp32| has exceeded the a-priori bound."""
@@ -672,9 +676,11 @@ class MoLBruteForceTopK(MoLTopKModule):
         B, N = query_embeddings.size(0), self._index.n_items
         have32 = self._index32 is not None and self._index32_engine is ex
         if have32 and B * N * 4 <= self.MAX_LOGIT_BYTES:
-            qpack32, _, _ = ex.query_pack(query_embeddings, kwargs.get("user_ids"))
+            n_q = ex.lib.rails_mol_query_pack_floats(E.C.byref(ex.shape), B)
+            qpack32, _, _ = ex.query_pack(query_embeddings, kwargs.get("user_ids"), out=None if _private else self._buf("qpack32", n_q, torch.float32))
             out = None if _private else self._buf("logits", B * N, torch.float32).view(B, N)
-            scores, ids = E.topk(ex.score_dense(qpack32, B, self._index32, out=out), k, ids=self._ids_flat)
+            ws = None if _private else self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(B, N, k), torch.uint8)
+            scores, ids = E.topk(ex.score_dense(qpack32, B, self._index32, out=out), k, ids=self._ids_flat, workspace=ws)
             return scores.to(query_embeddings.dtype), ids
         if have32:
             return self._forward_chunked(query_embeddings, k, _engine=ex, _index=self._index32, **kwargs)
