@@ -158,6 +158,8 @@ class MoLBruteForceTopK(MoLTopKModule):
     # The proved mode needs both index formats resident (2 x the fp32 index bytes); corpora where that does not fit, corpora below
     # SPECULATE_MIN_ITEMS and modules whose bound is infinite (see the guards in f16x3_bound.py) run "dense".
     EXACT_MODE = __import__("os").environ.get("RAILS_EXACT_MODE", "proved")
+    PROVED_MAX_EPS = 2.0          # a module whose a-priori bound exceeds this many logit units is not worth a second index: the items within eps of the
+                                  # k-th score run into the tens of thousands (16x16x64: eps = 2.9; profiles/r05_proved_candidate_census.json)
     PROVED_MIN_BATCH = 3          # smaller batches of the default mode run the dense fp32 kernels (see _forward_rescored)
 
     def _engine_for_bind(self) -> E.MolEngine:
@@ -174,7 +176,7 @@ class MoLBruteForceTopK(MoLTopKModule):
         spec, N = base.spec, self._item_embeddings.shape[1]
         if N < self.SPECULATE_MIN_ITEMS or N > 0xFFFFFFFF or not self._item_embeddings.is_cuda:
             return False
-        if not math.isfinite(self._bound_from_weights(spec).get("eps", math.inf)):
+        if not self._bound_from_weights(spec).get("eps", math.inf) <= self.PROVED_MAX_EPS:
             return False
         if not base.lib.rails_mol_shape_supported(E.C.byref(spec.to_c("f16x3"))):
             return False
