@@ -333,7 +333,9 @@ def hr_parity_leg(cfg, weights, mol, B: int, k: int, kp: int, dev, n_items: int 
         ri = (rpos - 1) * 3 + 7                                                # the oracle pass numbered the items 1..N
         oracle_s = None
         seen = torch.zeros((B, width), dtype=torch.int64)
-        assert rs.shape[1] == O.k_prime(k, seen, N, kp), "the shared oracle pass must have selected k' candidates"
+        kpr = O.k_prime(k, seen, N, kp)                                        # the harness's k' for this width (160); the shared pass is sorted: its prefix is the top-k'
+        assert rs.shape[1] >= kpr, "the shared oracle pass must have selected at least k' candidates"
+        rs, ri = rs[:, :kpr], ri[:, :kpr]
     else:
         N = n_items
         X = torch.from_numpy(O.hash_item_table(2, 0, N, cfg.item_embedding_dim)).unsqueeze(0)

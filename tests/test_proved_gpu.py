@@ -197,7 +197,13 @@ def test_proved_mode_is_the_default_and_equals_dense_fp32(dev, workload, N, B, k
         try:
             rails_amd.MoLBruteForceTopK.SPECULATE_MIN_ITEMS = 0
             tk = rails_amd.MoLBruteForceTopK(m, X, ids)
-            assert tk.exact_mode == "proved" and tk._bind().exact is not None, "the proved mode is not the default exact path"
+            assert tk.exact_mode == "proved"
+            if cfg.num_logits > 64:     # 16x16x64: the a-priori bound (2.9 logit units) is beyond PROVED_MAX_EPS -> the module does not even build the second index
+                assert tk._bind().exact is None and tk.stats().get("calls", 0) == 0
+                s, i = tk(q, k=k, **kw)
+                assert torch.equal(s, r_s) and torch.equal(i, r_i)
+                return
+            assert tk._bind().exact is not None, "the proved mode is not the default exact path"
             for _ in range(3):
                 s, i = tk(q, k=k, **kw)
                 assert torch.equal(s, r_s) and torch.equal(i, r_i)
@@ -244,7 +250,13 @@ def test_proved_mode_unprovable_calls_fall_back(dev):
         w[p + "3.weight"] = w[p + "3.weight"] * 6.0
         m = build_module(cfg, w, dev, None)
         r_s, r_i = _dense(m, X, ids)(q, k=k)
-        tk = rails_amd.MoLBruteForceTopK(m, X, ids)
+        assert rails_amd.MoLBruteForceTopK(m, X, ids)._bind().exact is None      # eps ~ 33 > PROVED_MAX_EPS: the default does not speculate ...
+        old_max = rails_amd.MoLBruteForceTopK.PROVED_MAX_EPS
+        rails_amd.MoLBruteForceTopK.PROVED_MAX_EPS = math.inf                    # ... unless told to: every verdict then fails and is redone
+        try:
+            tk = rails_amd.MoLBruteForceTopK(m, X, ids)
+        finally:
+            rails_amd.MoLBruteForceTopK.PROVED_MAX_EPS = old_max
         assert tk._bind().exact is not None and tk.stats()["eps_rigorous"] > 5.0
         for _ in range(3):
             s, i = tk(q, k=k)
