@@ -729,8 +729,10 @@ def _verdicts_clear(pending: list) -> bool:
 class MoLAvgTopK(MoLTopKModule):
     DEVICE_REDO_BYTES = 1 << 30   # materialised score matrices up to this size are kept as the device-side redo buffer of a fused scan;
                                   # beyond it (a 125 M-item shard: 16 GB) the counts are read on the host after the call is enqueued --
-    DEVICE_REDO_FREE_FRACTION = 0.25   # -- unless the buffer fits this fraction of the memory that is free when it is first needed (a full
-                                       # config-5 shard on a 288 GB part: 16 GB of ~68 GB): the redo then stays on the device and no call waits for the host
+    DEVICE_REDO_FREE_FRACTION = 0.0    # > 0: larger buffers too, when they fit this fraction of the free memory.  Measured on a full config-5 shard (16 GB
+                                       # buffer, round 5): the dozen predicated no-op launches of the redo (grids sized for 125 M items) cost as much as the
+                                       # host's look at the verdict word (0.884 ms per batch either way) and the stream overlap of submit / result is lost
+                                       # (0.79 -> 0.85 ms pipelined): off
 
     def _device_redo_fits(self, nbytes: int) -> bool:
         """May a (B, N) redo buffer of `nbytes` live on the device?  Decided once per size (the buffer is recycled across calls)."""

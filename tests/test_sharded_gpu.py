@@ -155,6 +155,11 @@ def test_bench_self_spawns_two_ranks():
     chk = sh["check"]
     assert chk["all_ranks_identical"] is True and chk["merged_equals_unsharded"] is True and chk["nothing_outside_beats_kth"] is True
     assert 200 <= chk["union_items"] <= 2 * 32 * 200
+    # the proved exact path (the module's default) ran per shard: identical output on every rank; it is the headline only if every
+    # rank proved every timed call (a shard's k'-th score sits in a denser part of the distribution: fallbacks are legitimate here)
+    pr = d["proved"]
+    assert pr["output_identical_to_fp32_path"] is True and pr["bound_violations"] == 0 and pr["timed_calls"] == 2 * 3
+    assert pr["proved_calls"] + pr["dense_fp32_fallbacks"] >= pr["timed_calls"] - 2 * 3 and pr["is_headline"] == (pr["proved_calls"] == pr["timed_calls"] and pr["dense_fp32_fallbacks"] == 0)
 
 
 def test_bench_two_ranks_on_the_256_logit_shape():
