@@ -983,6 +983,7 @@ def main() -> None:
         if not two_pass and args.precision == "proved":
             local.exact_mode = "proved"
             eng_p = local._bind()
+            mod_stats = topk_mod.stats if hasattr(topk_mod, "stats") else local.stats     # N > 1: the sharded module's global proof keeps the counters
             if eng_p.exact is not None:
                 pe0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
                 pe1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -1004,16 +1005,16 @@ def main() -> None:
                 for _ in range(max(args.warmup, 2)):
                     step_proved()
                 for _ in range(6):
-                    before = local.stats()["fallbacks"]
+                    before = mod_stats()["fallbacks"]
                     step_proved()
                     step_proved()
-                    failed = torch.tensor([local.stats()["fallbacks"] - before], dtype=torch.int64, device="cpu" if (world > 1 and test_backend) else dev)
+                    failed = torch.tensor([mod_stats()["fallbacks"] - before], dtype=torch.int64, device="cpu" if (world > 1 and test_backend) else dev)
                     if world > 1:
                         dist.all_reduce(failed, op=dist.ReduceOp.MAX)
                     if int(failed.item()) == 0:
                         break
-                local.stats()
-                base_stats = dict(local.rescore_stats)
+                mod_stats()
+                base_stats = dict(mod_stats())
                 if world > 1:
                     dist.barrier()
                 torch.cuda.synchronize()
@@ -1032,7 +1033,7 @@ def main() -> None:
                     p_elapsed = float(tpv.item())
                 local._first_pass_hook = None
                 cur["i"] = None
-                st = local.stats()
+                st = mod_stats()
                 p_last_ids, p_last_scores = step_proved()
                 p_identical = p_identical and bool(torch.equal(p_last_ids, ref_ids) and torch.equal(p_last_scores, ref_scores))
                 timed_calls = st["calls"] - base_stats["calls"]
@@ -1045,7 +1046,8 @@ def main() -> None:
                 p_steps_ms = [p_step[i].elapsed_time(p_step[i + 1]) for i in range(args.steps)]
                 proved = {"elapsed": p_elapsed, "score_ms": p_score_ms, "steps_ms": p_steps_ms, "calls": timed_calls, "proved_calls": proved_calls, "fallbacks": fallbacks,
                           "bound_violations": violations, "identical": identical_ranks == world, "eps": st.get("eps_rigorous"), "eps_terms": st.get("eps_rigorous_terms"),
-                          "kc": st.get("kc"), "guard_max": st.get("guard_max"), "guard_limit": local._gate_guard_limit,
+                          "kc": st.get("kc"), "guard_max": st.get("guard_max"), "guard_limit": getattr(topk_mod, "_gp_guard_limit", None) if st.get("global_proof") else local._gate_guard_limit,
+                          "global_proof": bool(st.get("global_proof", False)),
                           "qualifies": bool(identical_ranks == world and proved_calls == timed_calls == args.steps * world and fallbacks == 0 and violations == 0)}
             local.exact_mode = "dense"
             eng = local._bind()       # the legs below drive the fp32 kernels by hand again
@@ -1238,6 +1240,8 @@ def main() -> None:
                 "bound_violations": proved["bound_violations"], "output_identical_to_fp32_path": proved["identical"],
                 "eps_a_priori": proved["eps"], "candidates_per_query": proved["kc"], "gate_guard": {"max_abs_gq_seen": proved["guard_max"], "limit": proved["guard_limit"]},
                 "first_pass_kernel_ms": proved["score_ms"], "is_headline": proved["qualifies"],
+                **({"sharded_global_proof": "one proof for all shards: kc per rank = candidates_per_query; all-gather of the per-shard fp32 top-k' + all-reduce(max) of the "
+                                            "best first-pass score left outside (rails_amd/sharded.py ShardedMoLBruteForceTopK)"} if proved.get("global_proof") else {}),
                 "per_step_ms": [round(v, 3) for v in proved["steps_ms"]],
             }
             if proved["qualifies"]:

@@ -349,6 +349,12 @@ int rails_range_flag_i32(const int32_t* values, int32_t n, int32_t lo, int32_t h
 int rails_rescore_verdict(const float* row_stats, int32_t rows, float default_eps, float safety, const float* guard_values, int64_t guard_count,
                           float guard_limit, float* state, void* stream);
 
+/* row_stats for a GLOBAL verdict of the item-sharded proved top-k (rails_amd/sharded.py; no counterpart in the reference, whose eval is
+ * single-GPU: eval_from_checkpoint.py:554-555): row_stats[row] = [err_max[0], kth_scores[row * ld + col] - m_max[row]], where kth_scores
+ * holds the merged top-k' (col = k' - 1), m_max the all-reduced maximum over ranks of the best first-pass score each rank left outside its
+ * candidates, err_max the all-reduced largest |first pass - fp32| seen on any candidate.  Feed it to rails_rescore_verdict. */
+int rails_margin_stats(const float* kth_scores, int64_t ld, int32_t col, const float* m_max, const float* err_max, int32_t rows, float* row_stats, void* stream);
+
 int rails_rescore_select(const float* exact_scores, int64_t ld, const float* approx_scores, const float* approx_dense, int64_t ld_dense,
                          const int64_t* positions, const int64_t* ids, int64_t n_items, int32_t rows, int32_t n_ranked, int32_t n_cand,
                          int32_t k, float margin_eps, float check_eps, float* out_scores, int64_t* out_ids, int32_t* row_ok, float* row_stats,

@@ -575,6 +575,12 @@ int rails_rescore_verdict(const float* row_stats, int32_t rows, float default_ep
   return r == kOk ? r : fail(r, "rescore_verdict");
 }
 
+int rails_margin_stats(const float* kth_scores, int64_t ld, int32_t col, const float* m_max, const float* err_max, int32_t rows, float* row_stats, void* stream) {
+  g_err[0] = '\0';
+  if (rows < 0 || col < 0 || ld <= col || (rows > 0 && (!kth_scores || !m_max || !err_max || !row_stats))) { set_error("margin_stats: bad argument"); return RAILS_EINVAL; }
+  return fail(margin_stats(kth_scores, ld, col, m_max, err_max, rows, row_stats, (hipStream_t)stream), "margin_stats");
+}
+
 int rails_mfma_probe_f16(const uint16_t* a, const uint16_t* b, const float* c, float* d, int64_t n, void* stream) {
   g_err[0] = '\0';
   if (n < 0 || (n > 0 && (!a || !b || !c || !d))) { set_error("mfma_probe_f16: bad argument"); return RAILS_EINVAL; }

@@ -167,6 +167,7 @@ int pack_candidates(const float* scores, const int64_t* ids, int rows, int k_loc
 int range_flag(const int32_t* v, int n, int lo, int hi, int32_t* flag, hipStream_t stream);
 int rescore_verdict(const float* row_stats, int rows, float default_eps, float safety, const float* guard, int64_t guard_count, float guard_limit,
                     float* state, hipStream_t stream);
+int margin_stats(const float* kth, int64_t ld, int col, const float* m_max, const float* err_max, int rows, float* row_stats, hipStream_t stream);
 // arithmetic-model probes (arith_model.hip)
 int mfma_probe_f16(const unsigned short* a, const unsigned short* b, const float* c, float* d, int64_t n, hipStream_t stream);
 int mfma_probe_f32(const float* a, const float* b, const float* c, float* d, int64_t n, hipStream_t stream);

@@ -1529,6 +1529,22 @@ int rescore_verdict(const float* row_stats, int rows, float default_eps, float s
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
+// row_stats of a GLOBAL verdict (item-sharded proved top-k, rails_amd/sharded.py): row_stats[row] = [err_max[0], kth[row * ld + col] - m_max[row]]
+// -- the largest |first pass - fp32| any rank saw on its candidates, and the margin between the merged k-th fp32 score and the best
+// first-pass score any rank left outside its candidates (both all-reduced by the caller).  -inf margins (m = +inf) and NaNs pass through.
+__global__ void margin_stats_kernel(const float* __restrict__ kth, int64_t ld, int col, const float* __restrict__ m_max, const float* __restrict__ err_max,
+                                    int rows, float* __restrict__ row_stats) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  row_stats[2 * r] = err_max[0];
+  row_stats[2 * r + 1] = kth[(int64_t)r * ld + col] - m_max[r];
+}
+int margin_stats(const float* kth, int64_t ld, int col, const float* m_max, const float* err_max, int rows, float* row_stats, hipStream_t stream) {
+  if (rows <= 0) return kOk;
+  hipLaunchKernelGGL(margin_stats_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, kth, ld, col, m_max, err_max, rows, row_stats);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 int rescore_select(const float* exact, int64_t ld, const float* approx, const float* approx_dense, int64_t ld_dense, const int64_t* positions,
                    const int64_t* ids, int rows, int n_ranked, int kc, int k, float margin_eps, float check_eps, float* out_scores,
                    int64_t* out_ids, int* ok, float* stats, hipStream_t stream) {

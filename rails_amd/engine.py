@@ -802,6 +802,17 @@ def rescore_verdict(stats: torch.Tensor, state: torch.Tensor, default_eps: float
                                              0 if guard is None else guard.numel(), float(guard_limit), _ptr(state), _stream()), "rails_rescore_verdict")
 
 
+def margin_stats(kth_scores: torch.Tensor, col: int, m_max: torch.Tensor, err_max: torch.Tensor) -> torch.Tensor:
+    """(rows, >= col + 1) fp32 merged scores, (rows,) fp32, (1,) fp32 -> (rows, 2) row_stats [err_max, kth_scores[:, col] - m_max] (rails_margin_stats)."""
+    lib = _lib.load()
+    _require_device(kth_scores, "scores")
+    rows = kth_scores.shape[0]
+    stats = torch.empty((rows, 2), dtype=torch.float32, device=kth_scores.device)
+    with _on_device(kth_scores.device):
+        _lib.check(lib.rails_margin_stats(_ptr(kth_scores), kth_scores.stride(0), int(col), _ptr(m_max), _ptr(err_max), rows, _ptr(stats), _stream()), "rails_margin_stats")
+    return stats
+
+
 def mfma_probe_f16(a: torch.Tensor, b: torch.Tensor, c: torch.Tensor) -> torch.Tensor:
     """n x (32 x 16) f16, n x (16 x 32) f16, n x (32 x 32) fp32 -> n x (32 x 32) fp32: one v_mfma_f32_32x32x16_f16 each (rails_mfma_probe_f16)."""
     lib = _lib.load()

@@ -217,10 +217,182 @@ class ShardedTopK(TopKModule):
 
 
 class ShardedMoLBruteForceTopK(ShardedTopK):
-    """Exact: identical to MoLBruteForceTopK over the whole corpus, bit for bit (see the module docstring)."""
+    """Exact: identical to MoLBruteForceTopK over the whole corpus, bit for bit (see the module docstring).
+
+    GLOBAL PROOF (round 5).  The single-device module's default exact path -- split-f16 first pass, fp32 re-scoring of the candidates, proof
+    with the a-priori bound eps on |first pass - fp32| (topk_modules.MoLBruteForceTopK, f16x3_bound.py) -- proved PER SHARD would need
+    every shard to cover what lies within eps of ITS OWN k-th score, which sits in a denser part of the score distribution than the whole
+    corpus' (8 shards of amzn-books: thousands of candidates per shard and query instead of ~85).  So the proof is made once, globally:
+      rank r:  first pass over its shard -> its kc_r best by first-pass score, m_r = the best first-pass score it leaves outside
+               -> fp32 re-scoring of the kc_r -> its best k by (fp32 score, position)
+      all:     ONE all-gather of the (B, 2k) messages (as in the dense path) + ONE all-reduce(MAX) of (m_r per row, largest |fp32 - first pass|
+               seen) -> merge to the global top-k by fp32 score -> verdict per row: e_k - max_r m_r > eps
+    Every item of every shard outside the candidates has a first-pass score <= max_r m_r, hence an fp32 score < e_k: the merged top-k IS the
+    dense one.  Candidates per rank: the ~kc items within eps of the global k-th score spread evenly over the shards, so kc_r = kc / R +
+    4 sqrt(kc / R) + 32 (doubling after a failed verdict).  A failed verdict (crowded scores, a skewed shard, a violated guard) raises REDO
+    on every rank alike -- the verdict's inputs are collective results -- and the dense fp32 kernels redo the shard behind it under that
+    launch predicate; their exchange (a second all-gather + merge) is always enqueued, collectives cannot be predicated, and the output
+    is picked by the flag on the device.  The host never waits.  Used when EVERY rank's local module is bound in proved mode (an
+    all-reduce at the first call); otherwise the per-shard path above."""
+
+    GLOBAL_PROOF = True
 
     def _make_local_module(self, mol_module, item_embeddings_shard, item_ids_shard) -> TopKModule:
         return MoLBruteForceTopK(mol_module, item_embeddings_shard, item_ids_shard)
+
+    # ---- collectives on small tensors (host-staged only on a gloo group: test setups) --------------------------------------------
+    def _all_reduce(self, t: torch.Tensor, op) -> torch.Tensor:
+        if t.is_cuda and dist.get_backend(self._group) == "gloo":
+            h = t.cpu()
+            dist.all_reduce(h, op=op, group=self._group)
+            return h.to(t.device)
+        dist.all_reduce(t, op=op, group=self._group)
+        return t
+
+    def _all_gather_rows(self, msg: torch.Tensor) -> torch.Tensor:
+        if msg.is_cuda and dist.get_backend(self._group) == "gloo":
+            host = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype)
+            dist.all_gather_into_tensor(host, msg.cpu(), group=self._group)
+            return host.to(msg.device)
+        out = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype, device=msg.device)
+        dist.all_gather_into_tensor(out, msg, group=self._group)
+        return out
+
+    def _global_proof(self, query_embeddings: torch.Tensor) -> bool:
+        """Decided collectively, once per binding of the local module (all ranks reach this at the same call)."""
+        local = getattr(self, "_local_module", None)
+        if not (self.GLOBAL_PROOF and self._world > 1 and dist.is_initialized() and isinstance(local, MoLBruteForceTopK) and self._local_topk_is_module
+                and self._merge is _hip_merge and query_embeddings.is_cuda):
+            return False
+        eng = local._bind()
+        if getattr(self, "_gp_engine", None) is not eng:
+            from . import f16x3_bound as FB
+
+            mine = local.shard_can_speculate()
+            flags = torch.tensor([1.0 if mine else 0.0, -(local._gi_abs_max() if mine else 0.0)], dtype=torch.float32, device=query_embeddings.device)
+            flags = self._all_reduce(flags, dist.ReduceOp.MIN)          # min of the flags, max of max |gi| (negated)
+            self._gp_on = bool(flags[0].item() > 0.5)
+            gi_max = -float(flags[1].item())
+            self._gp_guard_limit = min(FB.GATE_GUARD / gi_max, 3.0e38) if gi_max > 0.0 else 3.0e38
+            self._gp_engine = eng
+            self._gp_eps = local._proved_eps() if self._gp_on else None
+            self._gp_state = torch.zeros(8, dtype=torch.float32, device=query_embeddings.device)
+            self._gp_host = torch.zeros(8, dtype=torch.float32).pin_memory()
+            self._gp_event = None
+            self._gp_seen = (0.0, 0.0)
+            self._gp_pad = 1
+            self._gp_stats = {"calls": 0, "fallbacks": 0, "proved_calls": 0, "bound_violations": 0}
+        return self._gp_on
+
+    def _gp_absorb(self, wait: bool = False) -> None:
+        ev = getattr(self, "_gp_event", None)
+        if ev is None:
+            return
+        if wait:
+            ev.synchronize()
+        elif not ev.query():
+            return
+        h = self._gp_host
+        calls, redone = float(h[5]), float(h[6])
+        new_calls, new_redone = int(calls - self._gp_seen[0]), int(redone - self._gp_seen[1])
+        self._gp_seen = (calls, redone)
+        st = self._gp_stats
+        st["calls"] += new_calls
+        st["fallbacks"] += new_redone
+        if float(h[0]) > self._gp_eps:
+            st["bound_violations"] += 1
+        else:
+            st["proved_calls"] += new_calls - new_redone
+        st["guard_max"] = float(h[7])
+        if new_redone > 0 and self._gp_pad < 64:
+            self._gp_pad *= 2
+
+    def stats(self) -> dict:
+        """Counters of the global proof (calls, proved_calls, fallbacks, bound_violations, kc per rank) merged over the local module's (synchronises)."""
+        local = self._local_module
+        out = local.stats()
+        if getattr(self, "_gp_on", False):
+            self._gp_absorb(wait=True)
+            out.update(self._gp_stats)
+            out["global_proof"] = True
+        return out
+
+    def _kc_local(self, k: int) -> int:
+        total = k + max(824, 3 * k) * self._gp_pad
+        per = -(-total // self._world)
+        kc = per + int(4.0 * per ** 0.5) + 32
+        kc = (kc + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS
+        return max(1, min(kc, 16384, self._n_local))
+
+    def submit(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs):
+        if not self._global_proof(query_embeddings) or query_embeddings.size(0) < MoLBruteForceTopK.PROVED_MIN_BATCH:
+            return super().submit(query_embeddings, k, sorted, **kwargs)
+        if k > self._n_total:
+            raise RuntimeError(f"selected index k out of range (k={k}, n={self._n_total})")
+        self._gp_absorb()
+        local = self._local_module
+        with local.one_bind():
+            kc = self._kc_local(k)
+            s, ids, m, err, gq, qpack32 = local.speculate_for_shard(query_embeddings, k, kc, **kwargs)
+        msg = E.pack_candidates(s, ids, k)
+        qpack32 = qpack32.clone()          # the local module recycles its pack with the next submit; the verdict and the redo read it later
+        red = torch.cat([m, err.max().reshape(1)])
+        ready = torch.cuda.Event()
+        ready.record()
+        self._gp_stats["kc"] = kc
+        return ("gproof", msg, red, ready, k, qpack32, gq.numel(), query_embeddings.size(0), query_embeddings.dtype, s.dtype)
+
+    def result(self, handle, seen=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        if handle[0] != "gproof":
+            return super().result(handle, seen)
+        _, msg, red, ready, k, qpack32, n_gq, B, q_dtype, _ = handle
+        local = self._local_module
+        sp = local._engine.spec
+        off = (B + 32 // sp.query_dot_product_groups - 1) // (32 // sp.query_dot_product_groups) * 32 * sp.dot_product_dimension
+        gq = qpack32[off : off + n_gq]
+        cur = torch.cuda.current_stream(msg.device)
+        if self._xstream is None:
+            self._xstream = torch.cuda.Stream(msg.device)
+        side = self._xstream
+        side.wait_event(ready)
+        for t in (msg, red, qpack32):
+            t.record_stream(side)
+        with torch.cuda.stream(side):
+            gathered = self._all_gather_rows(msg)
+            red = self._all_reduce(red, dist.ReduceOp.MAX)
+            ms, mi = E.merge_candidates(gathered, self._world, k, k)
+            stats = E.margin_stats(ms, k - 1, red[:B], red[B:])
+            E.rescore_verdict(stats, self._gp_state, self._gp_eps, 1.0, gq, self._gp_guard_limit)
+            redo = self._gp_state.view(torch.int32)[1:2]
+            # the redo: the dense fp32 kernels over this shard, its exchange, the merge -- launches no-ops unless REDO, collective always
+            k_fb = min(k, self._n_local)
+            s_fb = torch.full((B, k_fb), float("-inf"), dtype=torch.float32, device=msg.device)
+            i_fb = torch.full((B, k_fb), -1, dtype=torch.int64, device=msg.device)
+            local.dense_for_shard(qpack32, B, k, (s_fb, i_fb), redo)
+            gathered2 = self._all_gather_rows(E.pack_candidates(s_fb, i_fb, k))
+            ms2, mi2 = E.merge_candidates(gathered2, self._world, k, k)
+            take = redo.to(torch.bool)
+            ms, mi = torch.where(take, ms2, ms), torch.where(take, mi2, mi)
+            if seen is not None:
+                seen[0].record_stream(side)
+                mi, ms = E.filter_seen_ids(mi, ms, seen[0], seen[1])
+            ms = ms.to(q_dtype)
+            self._gp_host.copy_(self._gp_state, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._gp_event = ev
+        cur.wait_stream(side)
+        ms.record_stream(cur)
+        mi.record_stream(cur)
+        if seen is not None:
+            return mi, ms
+        return ms, mi
+
+    def forward_filtered(self, query_embeddings: torch.Tensor, k_prime: int, invalid_ids: torch.Tensor, k: int, **kwargs):
+        if self._world > 1 and self._global_proof(query_embeddings) and query_embeddings.size(0) >= MoLBruteForceTopK.PROVED_MIN_BATCH and k_prime <= self._n_total:
+            with self._inline():
+                return self.result(self.submit(query_embeddings, k_prime, **kwargs), seen=(invalid_ids, k))
+        return super().forward_filtered(query_embeddings, k_prime, invalid_ids, k, **kwargs)
 
 
 class ShardedMoLAvgTopK(ShardedTopK):

@@ -412,6 +412,64 @@ class MoLBruteForceTopK(MoLTopKModule):
             self._audit(query_embeddings, k, scores, ids, **kwargs)
         return scores.to(query_embeddings.dtype), ids
 
+    # ---- the proved flow split for an item-sharded corpus (rails_amd/sharded.py) --------------------------------------------------
+    def shard_can_speculate(self) -> bool:
+        """True iff this (local) module is bound in proved mode with both index formats resident: what ShardedMoLBruteForceTopK needs from
+        EVERY rank before it runs the global proof."""
+        eng = self._bind()
+        return eng.exact is not None and eng.dense_precision == "f16x3" and self._index32 is not None and self._index32_engine is eng.exact \
+            and math.isfinite(self._proved_eps() or math.inf)
+
+    def speculate_for_shard(self, query_embeddings: torch.Tensor, k: int, kc: int, **kwargs):
+        """Steps 1-4 of the proved flow on THIS shard, without a verdict: first pass over the shard, its kc best by first-pass score
+        re-scored in fp32, the best min(k, kc) of those by (fp32 score, position).
+        -> (scores (B, k_loc), ids (B, k_loc), m (B,), err (B,), gq rows): m = the best first-pass score left OUTSIDE the candidates
+        (-inf when the whole shard is a candidate), err = the largest |fp32 - first pass| over the row's candidates, gq = the batch's
+        prescaled query-gate rows (the guard of the a-priori bound).  The caller proves globally: every item of every shard outside the
+        candidates has s16 <= max over ranks of m, so the merged fp32 top-k is the dense one iff its k-th score exceeds that by eps."""
+        eng = self._bind()
+        ex = eng.exact
+        B, N = query_embeddings.size(0), self._index.n_items
+        dev = query_embeddings.device
+        sp = eng.spec
+        n_q = eng.lib.rails_mol_query_pack_floats(E.C.byref(eng.shape), B)
+        qpack16, qpack32 = eng.query_pack_both(query_embeddings, kwargs.get("user_ids"), self._buf("qpack", n_q, torch.float32),
+                                               self._buf("qpack32", n_q, torch.float32))
+        off = (B + 32 // sp.query_dot_product_groups - 1) // (32 // sp.query_dot_product_groups) * 32 * sp.dot_product_dimension
+        gq = qpack32[off : off + B * sp.num_logits]
+        if N == 0:
+            return (torch.empty((B, 0), dtype=torch.float32, device=dev), torch.empty((B, 0), dtype=torch.int64, device=dev),
+                    torch.full((B,), float("-inf"), dtype=torch.float32, device=dev), torch.zeros((B,), dtype=torch.float32, device=dev), gq, qpack32)
+        kc = min(max(kc, 1), N)
+        s16 = self._buf("logits", B * N, torch.float32).view(B, N)
+        hook = self._first_pass_hook
+        if hook is not None:
+            hook(0)
+        eng.score_dense(qpack16, B, self._index, out=s16)
+        if hook is not None:
+            hook(1)
+        ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(B, N, kc), torch.uint8)
+        c16, pos = E.topk(s16, kc, workspace=ws)
+        e32 = ex.score_indexed(qpack32, B, self._index32, pos)
+        k_loc = min(k, kc)
+        scores, ids, _, stats = E.rescore_select(e32, c16, pos, self._ids_flat, N, k_loc, approx_dense=s16)
+        m = c16[:, kc - 1].contiguous() if kc < N else torch.full((B,), float("-inf"), dtype=torch.float32, device=dev)
+        self.rescore_stats["calls"] += 1
+        self.rescore_stats["kc"] = kc
+        return scores, ids, m, stats[:, 0].contiguous(), gq, qpack32
+
+    def dense_for_shard(self, qpack32: torch.Tensor, batch: int, k: int, out: Tuple[torch.Tensor, torch.Tensor], run_if: torch.Tensor) -> None:
+        """The shard's dense fp32 top-min(k, N) into `out` (scores, ids), under the launch predicate `run_if` (the global verdict's REDO flag)."""
+        ex = self._engine.exact
+        N = self._index.n_items
+        if N == 0:
+            return
+        # buffers of its own: with submit / result pipelining the redo of batch i runs on the exchange stream while batch i + 1's first pass
+        # writes the module's other buffers
+        l32 = ex.score_dense(qpack32, batch, self._index32, out=self._buf("logits_fb", batch * N, torch.float32).view(batch, N), run_if=run_if)
+        ws = self._buf("topk_ws2", E._lib.load().rails_topk_workspace_bytes(batch, N, min(k, N)), torch.uint8)
+        E.topk(l32, min(k, N), ids=self._ids_flat, workspace=ws, out=out, run_if=run_if)
+
     INDEXED_MAX_CANDIDATES = 1 << 30   # rails_mol_score_indexed instead of gather + score_candidates up to this many (B x Kc) candidates (was 1024)
     DEVICE_VERDICT = True     # False: the host reads the verdict (one event spin per call) -- kept for deployments without a resident fp32 index
 

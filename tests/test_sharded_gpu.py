@@ -79,6 +79,21 @@ def _worker(rank: int, world: int, port: int, n_items: int, precision, ret, work
             cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)      # the harness object holds the whole id table; the module is sharded
             c_i, c_s, _ = cand.get_top_k_outputs(q, kk, {}, sh, inv, truncate_k_prime_to=min(k, n_items))
             assert torch.equal(c_i, want_i) and torch.equal(c_s, want_s)
+            if precision in (None, "f16x3-exact"):
+                # the default exact path and its explicit form prove ONCE for all shards (ShardedMoLBruteForceTopK's global proof): every call
+                # above went through it, was proved or redone, and no observed error exceeded the a-priori bound; with an absurd bound every
+                # verdict fails on every rank alike and the dense fp32 redo -- second exchange, output picked by the flag -- returns the same bits
+                st = sh.stats()
+                assert st.get("global_proof") is True and st["calls"] >= 6 and st["proved_calls"] + st["fallbacks"] == st["calls"] and st["bound_violations"] == 0, st
+                assert n_items < 1000 or st["proved_calls"] >= 1, st
+                before = st["fallbacks"]
+                sh._gp_eps = 1.0e9
+                fs, fi = sh(q, k=k)
+                assert torch.equal(fs, full_s) and torch.equal(fi, full_i), "global proof: the redo differs from the single-device result"
+                got = sh.forward_filtered(q, min(k, n_items), inv, kk)
+                assert torch.equal(got[0], want_i) and torch.equal(got[1], want_s)
+                assert sh.stats()["fallbacks"] == before + 2
+                sh._gp_eps = sh._local_module._proved_eps()
             if precision in ("f16x3-exact", "f16-exact"):   # ... and both are the fp32 path's result, bit for bit
                 mol32 = build_module(cfg, O.synthetic_weights(cfg, seed=1), dev)
                 f32_s, f32_i = rails_amd.MoLBruteForceTopK(mol32, X, ids)(q, k=k)

@@ -14,7 +14,8 @@ from oracle import mol_oracle as O
 ap = argparse.ArgumentParser()
 ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--steps", type=int, default=200)
-ap.add_argument("--precision", default=None, help="fp32 (default) | f16x3 | f16x3-exact | f16-exact (the module's verified route)")
+ap.add_argument("--precision", default=None, help="fp32 (default) | f16x3 | f16x3-exact | f16-exact (the module's verified route, proved PER SHARD) | "
+                                                 "proved-global (ShardedMoLBruteForceTopK's flow: one proof for all shards, its collectives replaced by copies)")
 ap.add_argument("--pipeline", action="store_true", help="exchange (copy + merge + filter) of step i on a second stream, behind step i+1's scoring")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
@@ -28,7 +29,7 @@ mol, _ = rails_amd.create_mol_interaction_module(
     query_nonlinearity=cfg.query_nonlinearity, uid_embedding_hash_sizes=list(cfg.uid_embedding_hash_sizes) or None)
 mol.load_state_dict(w, strict=True)
 mol = mol.to(dev).eval()
-if a.precision:
+if a.precision and a.precision != "proved-global":
     mol.precision = a.precision
 lo, hi = shard_bounds(N, a.world, 0)
 X = torch.from_numpy(O.hash_item_table(1, lo, hi - lo, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
@@ -43,7 +44,38 @@ with torch.inference_mode():
     tk.SPECULATE_MIN_ITEMS = 0
     side = torch.cuda.Stream(dev)
 
+    if a.precision == "proved-global":
+        del tk
+        rails_amd.MoLBruteForceTopK.SPECULATE_MIN_ITEMS = 0
+        tk = rails_amd.MoLBruteForceTopK(mol, X, ids, exact_mode="proved")
+        assert tk.shard_can_speculate()
+        eps, state = tk._proved_eps(), torch.zeros(8, dtype=torch.float32, device=dev)
+        total = kp + max(824, 3 * kp)
+        per = -(-total // a.world)
+        kc = min((per + int(4 * per ** 0.5) + 32 + 31) // 32 * 32, hi - lo)
+        print("global proof: eps", eps, "kc per rank", kc)
+
+    def global_step():
+        s, i_, m, err, gq, qp32 = tk.speculate_for_shard(q, kp, kc)
+        msg = E.pack_candidates(s, i_, kp)
+        qp32 = qp32.clone()
+        red = torch.cat([m, err.max().reshape(1)])
+        gathered = msg.repeat(a.world, 1)                                   # stands for the all-gather; the all-reduce is the identity here
+        ms, mi = E.merge_candidates(gathered, a.world, kp, kp)
+        stats = E.margin_stats(ms, kp - 1, red[:B], red[B:])
+        E.rescore_verdict(stats, state, eps, 1.0, gq, tk._gate_guard_limit)
+        redo = state.view(torch.int32)[1:2]
+        s_fb = torch.full((B, kp), float("-inf"), dtype=torch.float32, device=dev)
+        i_fb = torch.full((B, kp), -1, dtype=torch.int64, device=dev)
+        tk.dense_for_shard(qp32, B, kp, (s_fb, i_fb), redo)
+        ms2, mi2 = E.merge_candidates(E.pack_candidates(s_fb, i_fb, kp).repeat(a.world, 1), a.world, kp, kp)
+        take = redo.to(torch.bool)
+        ms, mi = torch.where(take, ms2, ms), torch.where(take, mi2, mi)
+        return E.filter_seen_ids(mi, ms, inv, k)
+
     def local_part():
+        if a.precision == "proved-global":
+            return None
         if a.precision and a.precision.endswith("-exact"):
             s, top = tk(q, k=min(kp, hi - lo))
         else:
@@ -53,6 +85,8 @@ with torch.inference_mode():
         return E.pack_candidates(s, top, kp) if a.world > 1 else (s, top)
 
     def exchange(msg):
+        if a.precision == "proved-global":
+            return global_step()
         if a.world > 1:
             gathered = msg.repeat(a.world, 1)
             if E.merge_filter_fusable(kp, inv.shape[1], k):   # the sharded module's route: the seen-id filter inside the merge launch
@@ -84,4 +118,6 @@ with torch.inference_mode():
     run(a.steps)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
+if a.precision == "proved-global":
+    print("verdict state [seen err, redo, eps, err, gap, calls, redone, guard max]:", state.view(torch.float32).tolist(), "redo flag", int(state.view(torch.int32)[1]))
 print(f"world={a.world} shard={hi - lo} items precision={a.precision or 'fp32'} pipeline={a.pipeline}: {dt * 1e3:.3f} ms/step (no RCCL latency) -> {B / dt:.0f} q/s if all ranks match")
