@@ -92,7 +92,7 @@ def _worker(rank: int, world: int, port: int, n_items: int, precision, ret, work
                 assert torch.equal(fs, full_s) and torch.equal(fi, full_i), "global proof: the redo differs from the single-device result"
                 got = sh.forward_filtered(q, min(k, n_items), inv, kk)
                 assert torch.equal(got[0], want_i) and torch.equal(got[1], want_s)
-                assert sh.stats()["fallbacks"] == before + 2
+                assert sh.stats()["fallbacks"] == before + (2 if n_items >= 1000 else 0)     # (a shard that is all candidates leaves nothing outside: proved whatever the bound)
                 sh._gp_eps = sh._local_module._proved_eps()
             if precision in ("f16x3-exact", "f16-exact"):   # ... and both are the fp32 path's result, bit for bit
                 mol32 = build_module(cfg, O.synthetic_weights(cfg, seed=1), dev)

@@ -37,7 +37,7 @@ ids = torch.arange(lo + 1, hi + 1, dtype=torch.int64, device=dev).unsqueeze(0)
 q = O.synthetic_queries(cfg, B).to(dev)
 inv = torch.zeros((B, width), dtype=torch.int64, device=dev)
 with torch.inference_mode():
-    tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
+    tk = rails_amd.MoLBruteForceTopK(mol, X, ids, exact_mode="dense")     # "fp32" = the dense fp32 kernels (the module's default is the proved mode)
     eng = tk._bind()
     logits = torch.empty((B, hi - lo), dtype=torch.float32, device=dev)
 
