@@ -366,8 +366,12 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
             redo = self._gp_state.view(torch.int32)[1:2]
             # the redo: the dense fp32 kernels over this shard, its exchange, the merge -- launches no-ops unless REDO, collective always
             k_fb = min(k, self._n_local)
-            s_fb = torch.full((B, k_fb), float("-inf"), dtype=torch.float32, device=msg.device)
-            i_fb = torch.full((B, k_fb), -1, dtype=torch.int64, device=msg.device)
+            fb = self.__dict__.setdefault("_gp_fb", {})
+            if (B, k_fb) not in fb:      # written only by a redo; between redos it keeps (-inf, -1) or a stale result: either is harmless, the flag picks
+                fb.clear()
+                fb[(B, k_fb)] = (torch.full((B, k_fb), float("-inf"), dtype=torch.float32, device=msg.device),
+                                 torch.full((B, k_fb), -1, dtype=torch.int64, device=msg.device))
+            s_fb, i_fb = fb[(B, k_fb)]
             local.dense_for_shard(qpack32, B, k, (s_fb, i_fb), redo)
             gathered2 = self._all_gather_rows(E.pack_candidates(s_fb, i_fb, k))
             ms2, mi2 = E.merge_candidates(gathered2, self._world, k, k)

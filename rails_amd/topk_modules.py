@@ -453,10 +453,10 @@ class MoLBruteForceTopK(MoLTopKModule):
         e32 = ex.score_indexed(qpack32, B, self._index32, pos)
         k_loc = min(k, kc)
         scores, ids, _, stats = E.rescore_select(e32, c16, pos, self._ids_flat, N, k_loc, approx_dense=s16)
-        m = c16[:, kc - 1].contiguous() if kc < N else torch.full((B,), float("-inf"), dtype=torch.float32, device=dev)
+        m = c16[:, kc - 1] if kc < N else torch.full((B,), float("-inf"), dtype=torch.float32, device=dev)     # (views: the caller concatenates them into its message)
         self.rescore_stats["calls"] += 1
         self.rescore_stats["kc"] = kc
-        return scores, ids, m, stats[:, 0].contiguous(), gq, qpack32
+        return scores, ids, m, stats[:, 0], gq, qpack32
 
     def dense_for_shard(self, qpack32: torch.Tensor, batch: int, k: int, out: Tuple[torch.Tensor, torch.Tensor], run_if: torch.Tensor) -> None:
         """The shard's dense fp32 top-min(k, N) into `out` (scores, ids), under the launch predicate `run_if` (the global verdict's REDO flag)."""
