@@ -304,7 +304,7 @@ def quick_workload(name: str, B: int, k: int, kp: int, steps: int, dev, items: i
                 "queries_per_s": B / dt, "ms_per_step": dt * 1e3, "prologue_plus_first_pass_ms": score_ms,
                 "rescore_calls": st["calls"], "dense_fp32_fallbacks": st["fallbacks"],
                 **({"proved_calls": st.get("proved_calls", 0), "eps_a_priori": st.get("eps_rigorous"),
-                    "runs_dense_fp32": tk._bind().exact is None} if precision == "proved" else {}), **tr}
+                    "runs_dense_fp32": tk._bind().exact is None, "bound": st.get("bound_kind", "one a-priori eps")} if precision == "proved" else {}), **tr}
     return {"workload": f"{name} {cfg.query_dot_product_groups}x{cfg.item_dot_product_groups}x{cfg.dot_product_dimension}, N={N}", "precision": precision,
             "queries_per_s": B / dt, "ms_per_step": dt * 1e3, "prologue_plus_scoring_ms": score_ms, **graph,
             "scoring_tflops_algorithmic_lower_bound": tf,
@@ -525,6 +525,10 @@ def full_shard_legs(B: int, k: int, dev) -> list:
                     if variant == "proved":
                         leg["proved_calls"], leg["eps_a_priori"], leg["candidates_per_query"] = st.get("proved_calls", 0), st.get("eps_rigorous"), st.get("kc")
                         leg["runs_dense_fp32"] = mod._bind().exact is None
+                        leg["bound"] = st.get("bound_kind", "one a-priori eps")
+                        leg["bound_violations"] = st.get("bound_violations", 0)
+                        if st.get("upper_bound_poly") is not None:
+                            leg["upper_bound_poly"] = st["upper_bound_poly"]
                 legs.append(leg)
                 del mod, cand, X, ids, mol
     gc.collect()

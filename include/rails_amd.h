@@ -33,9 +33,10 @@ extern "C" {
  * structs of round 2 carried no version; 5: the launch predicate became the explicit `run_if` argument of the entry points that
  * honour it and the per-thread rails_set_run_predicate is gone -- the library keeps no state between calls but the last error;
  * 6: rails_mol_coarse_topk gained its out_of_range output and its optional int8 pre-filter (rails_mol_coarse_prefilter_*),
- * rails_topk_candidates is new, rails_mol_score_indexed takes any n_cand; 7: rails_rescore_verdict gained its guard arguments and state[7], the rails_*_probe_* entry points are new, and rails_mol_score_topk / _survivors / rails_select_survivors -- the selection fused into the scoring kernels, 0.9 % slower than the dense kernels + rails_topk wherever it was measured -- are gone).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
+ * rails_topk_candidates is new, rails_mol_score_indexed takes any n_cand; 7: rails_rescore_verdict gained its guard arguments and state[7], the rails_*_probe_* entry points are new, and rails_mol_score_topk / _survivors / rails_select_survivors -- the selection fused into the scoring kernels, 0.9 % slower than the dense kernels + rails_topk wherever it was measured -- are gone;
+ * 8: rails_mol_score_dense_upper[_supported] are new and rails_rescore_select gained one_sided).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
  * against an older header pass shorter structs, and the library would read the new fields from whatever follows them. */
-#define RAILS_ABI_VERSION 7
+#define RAILS_ABI_VERSION 8
 int rails_abi_version(void);
 
 #define RAILS_OK 0
@@ -182,6 +183,16 @@ int rails_mol_query_prologue_both(const rails_mol_shape* shape, const rails_mol_
 int rails_mol_score_dense(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack,
                           int32_t batch, const float* index, int64_t n_items, float* logits, int64_t ld,
                           const int32_t* run_if, void* stream);
+/* The first pass of the proved exact top-k with a PER-PAIR error bound (no counterpart in the reference, which scores every item in one
+ * precision: rails/indexing/mol_top_k.py:99-130): precision F16X3 only; logits[b * ld + x] = s + (ub2 c + ub1) c + ub0 with s the f16x3 logit
+ * rails_mol_score_dense writes and c = max_l |cl_l| over the pair's P_Q * P_X cross logits as the kernel computed them.  With the
+ * coefficients of rails_amd/f16x3_bound.py upper_bound_poly (>= 0, finite) the value is an UPPER BOUND of the pair's fp32-kernel logit: the
+ * bound on |f16x3 - fp32| is quadratic in the magnitude of the cross logits, and the a-priori |cl| <= 1/tau it is otherwise evaluated at is
+ * 2-3 x what the pairs of a corpus reach (config 4: one eps = 3.0 for every pair needs > 60 000 candidates per query at 12.5 M items, the
+ * per-pair bound 730-900).  Built for the 256-logit team kernel (16x16x64); rails_mol_score_dense_upper_supported says whether a shape has it. */
+int rails_mol_score_dense_upper_supported(const rails_mol_shape* shape);
+int rails_mol_score_dense_upper(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack, int32_t batch, const float* index,
+                                int64_t n_items, float ub2, float ub1, float ub0, float* logits, int64_t ld, const int32_t* run_if, void* stream);
 /* Per-row candidates (B' == B branch, similarity_fn.py:397-402): `cand_index` was produced by
  * rails_mol_index_gather with n_rows == batch; logits[b * ld + j] for j < n_cand. */
 int rails_mol_score_candidates(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack,
@@ -330,7 +341,10 @@ int rails_merge_candidates_filtered(const int64_t* gathered, int32_t n_ranks, in
  * |exact - approx| <= check_eps on every candidate and probe  (then no item outside the candidates can belong to the row's
  * top k, given |approx - exact| <= margin_eps everywhere; the probes watch that bound outside the candidates).  n_cand <= 16384.
  * row_stats (rows x 2 floats, optional): [largest |exact - approx| over the row's candidates and probes (inf for a NaN), k-th exact
- * score - min candidate approx], for callers that calibrate the bound from what they observe; row_ok or row_stats may be NULL. */
+ * score - min candidate approx], for callers that calibrate the bound from what they observe; row_ok or row_stats may be NULL.
+ * one_sided != 0: approx_scores are UPPER BOUNDS of the exact scores (rails_mol_score_dense_upper): the monitored error is
+ * max(0, exact - approx) -- zero while the bound holds -- and margin_eps = 0 is the proof (every item outside the candidates has
+ * exact <= approx <= min candidate approx < k-th exact score). */
 /* *flag |= 1 if any of the n int32 values lies outside [lo, hi]: the validity check of the fused scans' candidate counts
  * (rails_mol_coarse_topk / rails_mol_component_topk) on the device, feeding the launch predicate (run_if) of their materialising
  * redo (rails_mol_coarse_score / rails_mol_component_score + rails_topk).  The caller zeroes *flag. */
@@ -357,8 +371,8 @@ int rails_margin_stats(const float* kth_scores, int64_t ld, int32_t col, const f
 
 int rails_rescore_select(const float* exact_scores, int64_t ld, const float* approx_scores, const float* approx_dense, int64_t ld_dense,
                          const int64_t* positions, const int64_t* ids, int64_t n_items, int32_t rows, int32_t n_ranked, int32_t n_cand,
-                         int32_t k, float margin_eps, float check_eps, float* out_scores, int64_t* out_ids, int32_t* row_ok, float* row_stats,
-                         void* stream);
+                         int32_t k, float margin_eps, float check_eps, int32_t one_sided, float* out_scores, int64_t* out_ids, int32_t* row_ok,
+                         float* row_stats, void* stream);
 
 /* ---- arithmetic-model probes (test infrastructure of the proved exact top-k; no counterpart in the reference) -------------------------
  * The a-priori bound on |first pass - fp32 logit| (rails_amd/f16x3_bound.py) models the two matrix instructions and the two

@@ -74,7 +74,9 @@ def _split_constants(kernel: bool):
 
 
 def first_pass_bound(w1, b1, w2, b2, temperature: float, dot_dim: int, p_q: int, p_x: int, kc: float = KC, kp: float = KP,
-                     gate_guard: float = GATE_GUARD) -> Dict[str, float]:
+                     gate_guard: float = GATE_GUARD, cl_max=None) -> Dict[str, float]:
+    """cl_max: state the bound for the pairs with |cl_l| <= cl_max (exact values) for every l; the default is the a-priori 1/tau.  The
+    magnitudes downstream of GEMM1 use it; GEMM1's own error is relative to sum_d |Eq'||Ex| (bounded by the norms, not by cl)."""
     w1 = np.abs((np.float32(-LOG2E_F32) * np.asarray(w1, np.float32)).astype(np.float64))
     b1 = np.abs((np.float32(-LOG2E_F32) * np.asarray(b1, np.float32)).astype(np.float64))
     b2 = np.abs((np.float32(-LOG2E_F32) * np.asarray(b2, np.float32)).astype(np.float64))
@@ -89,6 +91,7 @@ def first_pass_bound(w1, b1, w2, b2, temperature: float, dot_dim: int, p_q: int,
     inv_tau = 1.0 / float(np.float32(temperature))
     slack = 1.0 + (d + 8) * U
     c0 = inv_tau * slack * slack
+    cm = c0 if cl_max is None else min(c0, max(0.0, float(cl_max)))
     n_eq, n_ex = math.sqrt(d) * inv_tau * slack, math.sqrt(d) * slack
     th = gamma(7)
     ku = kc * U
@@ -133,7 +136,7 @@ def first_pass_bound(w1, b1, w2, b2, temperature: float, dot_dim: int, p_q: int,
 
     a1 = w1.sum(1)
     a2 = w2.sum(1)
-    t_star = [b1[h] + a1[h] * c0 for h in range(H)]
+    t_star = [b1[h] + a1[h] * cm for h in range(H)]
     q_star = [b2[l] + sum(w2[l, h] * t_star[h] for h in range(H)) for l in range(L)]
 
     # f16x3
@@ -141,7 +144,7 @@ def first_pass_bound(w1, b1, w2, b2, temperature: float, dot_dim: int, p_q: int,
     rho, ba, bb, abs2, small, x_a, x_b = block(pk, pk)
     g1 = c0 * (1 + small) + n_eq * x_a + n_ex * x_b
     dcl16 = rho * c0 + bb * n_eq + ba * n_ex + d * abs2 + (gamma(3 * d / 16 + 1, ku) + kp * U * (1 + gamma(3 * d / 16 + 1, ku))) * g1
-    x1 = c0 + dcl16
+    x1 = cm + dcl16
     rho, ba, bb, abs2, small, x_a, x_b = block(pk, kn)
     dt16, t16, dh16, y16 = [], [], [], []
     for h in range(H):
@@ -164,7 +167,7 @@ def first_pass_bound(w1, b1, w2, b2, temperature: float, dot_dim: int, p_q: int,
 
     # fp32
     dcl32 = gamma(d) * c0
-    x1f = c0 + dcl32
+    x1f = cm + dcl32
     dt32, dh32, y32 = [], [], []
     for h in range(H):
         e = a1[h] * dcl32 + chain32([w1[h, l] * x1f for l in o2], b1[h])
@@ -183,6 +186,29 @@ def first_pass_bound(w1, b1, w2, b2, temperature: float, dot_dim: int, p_q: int,
 
 
 # ---- the three evaluations --------------------------------------------------------------------------------------------------------
+def upper_poly_shortfall(poly, w1, b1, w2, b2, temperature: float, dot_dim: int, p_q: int, p_x: int, grid: int = 96, **kw) -> float:
+    """What rails_amd/f16x3_bound.upper_bound_poly must deliver, restated: with P(c) = (ub2 c + ub1) c + ub0 evaluated in fp32 and added in
+    fp32 to a logit below 64 in magnitude, P(c) >= eps(c + d_cl16) + the roundings of that evaluation for EVERY computed c = max |cl16| in
+    [0, c_top].  eps and P are non-decreasing, so for ANY grid 0 = g_0 < ... < g_n >= c_top it suffices that
+    P_lo(g_{j-1}) >= eps(g_j + d_cl16) + 2^-18 for j = 1..n (c in (g_{j-1}, g_j] then has P(c) >= P(g_{j-1}) >= eps(g_j + d_cl16) >= eps(c + d_cl16)),
+    P_lo = the float64 value deflated by the fp32 evaluation error (3 u relative).  The condition is only satisfiable on a grid at least as
+    fine as the one the coefficients were fitted on; `grid` is that resolution.  eps is THIS file's first_pass_bound.
+    -> the largest shortfall (<= 0 means the requirement holds)."""
+    ub2, ub1, ub0 = (float(np.float32(v)) for v in poly)
+    assert min(ub2, ub1, ub0) >= 0.0
+    top = first_pass_bound(w1, b1, w2, b2, temperature, dot_dim, p_q, p_x, **kw)
+    inv_tau = 1.0 / float(np.float32(temperature))
+    slack = 1.0 + (int(dot_dim) + 8) * U
+    c_top = (inv_tau * slack * slack + top["d_cl16"]) * (1.0 + 2.0 ** -20)
+    worst = -math.inf
+    for j in range(1, grid + 1):
+        need = first_pass_bound(w1, b1, w2, b2, temperature, dot_dim, p_q, p_x, cl_max=c_top * j / grid + top["d_cl16"], **kw)["eps"] + 2.0 ** -18
+        c = c_top * (j - 1) / grid
+        have = ((ub2 * c + ub1) * c + ub0) * (1.0 - 3.0 * U)
+        worst = max(worst, need - have)
+    return worst
+
+
 def prescale(w1, b1, w2, b2):
     """the gate pack's fp32 values (csrc/mol_index.hip pack_gate_kernel): W1' = -log2e W1, b1' = -log2e b1, W2, b2' = -log2e b2"""
     k = np.float32(-LOG2E_F32)

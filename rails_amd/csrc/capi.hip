@@ -255,6 +255,43 @@ int rails_mol_score_dense(const rails_mol_shape* s, const float* gate_pack, cons
   return score_common(s, gate_pack, query_pack, batch, index, n_items, logits, ld, 0, stream, "score_dense", run_if);
 }
 
+int rails_mol_score_dense_upper_supported(const rails_mol_shape* s) {
+  if (!s || !shape_supported(s) || s->precision != RAILS_PRECISION_F16X3) return 0;
+  const int cu = compute_units();
+  if (cu <= 0) return 0;
+  ScoreArgs a;
+  fill_score_args(s, nullptr, nullptr, 32, nullptr, 32, nullptr, 32, 0, &a);
+  a.upper = 1;
+  a.dry_run = 1;
+  const int r = score_launch(*s, a, cu, nullptr);
+  g_err[0] = '\0';
+  return r == kOk ? 1 : 0;
+}
+
+int rails_mol_score_dense_upper(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch, const float* index,
+                                int64_t n_items, float ub2, float ub1, float ub0, float* logits, int64_t ld, const int32_t* run_if, void* stream) {
+  g_err[0] = '\0';
+  if (!shape_supported(s)) return RAILS_ENOTSUP;
+  if (batch < 0 || n_items < 0) { set_error("score_dense_upper: negative size"); return RAILS_EINVAL; }
+  if (!(ub2 >= 0.0f && ub1 >= 0.0f && ub0 >= 0.0f) || !(ub2 + ub1 + ub0 < INFINITY)) {
+    set_error("score_dense_upper: the bound polynomial needs three finite coefficients >= 0");
+    return RAILS_EINVAL;
+  }
+  if (batch == 0 || n_items == 0) return RAILS_OK;
+  if (!gate_pack || !query_pack || !index || !logits) { set_error("score_dense_upper: NULL pointer"); return RAILS_EINVAL; }
+  if (ld < n_items) { set_error("score_dense_upper: ld (%lld) < n_items (%lld)", (long long)ld, (long long)n_items); return RAILS_EINVAL; }
+  const int cu = compute_units();
+  if (cu <= 0) { set_error("score_dense_upper: no HIP device"); return RAILS_ELAUNCH; }
+  ScoreArgs a;
+  fill_score_args(s, gate_pack, query_pack, batch, index, n_items, logits, ld, 0, &a, run_if);
+  a.upper = 1;
+  a.ub2 = ub2;
+  a.ub1 = ub1;
+  a.ub0 = ub0;
+  const int r = score_launch(*s, a, cu, (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "score_dense_upper");
+}
+
 int rails_mol_score_indexed_supported(const rails_mol_shape* s, int32_t batch, int64_t n_cand) {
   if (!s || !shape_supported(s) || is_split(*s) || batch <= 0 || n_cand <= 0) return 0;
   const int cu = compute_units();
@@ -601,8 +638,8 @@ int rails_scalar_probe_f32(const float* x, int64_t n, float* out, void* stream) 
 
 int rails_rescore_select(const float* exact_scores, int64_t ld, const float* approx_scores, const float* approx_dense, int64_t ld_dense,
                          const int64_t* positions, const int64_t* ids, int64_t n_items, int32_t rows, int32_t n_ranked, int32_t n_cand,
-                         int32_t k, float margin_eps, float check_eps, float* out_scores, int64_t* out_ids, int32_t* row_ok, float* row_stats,
-                         void* stream) {
+                         int32_t k, float margin_eps, float check_eps, int32_t one_sided, float* out_scores, int64_t* out_ids, int32_t* row_ok,
+                         float* row_stats, void* stream) {
   g_err[0] = '\0';
   if (rows < 0 || n_ranked <= 0 || n_cand < n_ranked || k <= 0 || k > n_ranked || ld < n_cand) { set_error("rescore_select: bad size"); return RAILS_EINVAL; }
   if (n_items <= 0 || n_items > 0xFFFFFFFFll) { set_error("rescore_select: positions must fit 32 bits (n_items = %lld)", (long long)n_items); return RAILS_EINVAL; }
@@ -612,7 +649,7 @@ int rails_rescore_select(const float* exact_scores, int64_t ld, const float* app
     return RAILS_EINVAL;
   }
   const int r = rescore_select(exact_scores, ld, approx_scores, approx_dense, ld_dense, positions, ids, rows, n_ranked, n_cand, k, margin_eps,
-                               check_eps, out_scores, out_ids, row_ok, row_stats, (hipStream_t)stream);
+                               check_eps, one_sided != 0, out_scores, out_ids, row_ok, row_stats, (hipStream_t)stream);
   return r == kOk ? r : fail(r, "rescore_select");
 }
 

@@ -48,6 +48,9 @@ struct ScoreArgs {
   const int64_t* cand_pos;
   int64_t index_items;
   int dry_run;                    // 1: validate the dispatch (shape, shell) without launching
+  // rails_mol_score_dense_upper: logits[b][x] = s + (ub2 c + ub1) c + ub0, c = max_l |cl_l| of the pair (mol_score_wsplit.h UPPER)
+  int upper;
+  float ub2, ub1, ub0;
 };
 
 int pack_gate_weights_split(const Shape& s, const Weights& w, float* wpack, hipStream_t stream);
@@ -173,7 +176,7 @@ int mfma_probe_f16(const unsigned short* a, const unsigned short* b, const float
 int mfma_probe_f32(const float* a, const float* b, const float* c, float* d, int64_t n, hipStream_t stream);
 int scalar_probe(const float* x, int64_t n, float* out, hipStream_t stream);
 int rescore_select(const float* exact, int64_t ld, const float* approx, const float* approx_dense, int64_t ld_dense, const int64_t* positions,
-                   const int64_t* ids, int rows, int n_ranked, int kc, int k, float margin_eps, float check_eps, float* out_scores,
+                   const int64_t* ids, int rows, int n_ranked, int kc, int k, float margin_eps, float check_eps, int one_sided, float* out_scores,
                    int64_t* out_ids, int* ok, float* stats, hipStream_t stream);
 int merge_candidates(const int64_t* gathered, int R, int rows, int k, int k_out, float* out_scores, int64_t* out_ids,
                      hipStream_t stream, const int64_t* f_invalid = nullptr, int f_width = 0, int f_k = 0);

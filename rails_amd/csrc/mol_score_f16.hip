@@ -50,6 +50,12 @@ int score_launch_f16(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t s
 #undef MOL_CASE
   if (s.query_dot_product_groups == 16 && s.item_dot_product_groups == 16 && s.dot_product_dimension == 64) {
     // L = 256: tiles (160 KiB) and the gate pack (256 KiB) are beyond LDS staging -- the team kernel (mol_score_wsplit.h)
+#if !RAILS_F16_SINGLE
+    if (a.upper) {
+      if (a.combine_none || a.per_row) { set_error("the upper-bound first pass is built for the glu_silu combiner over a shared corpus"); return kErrUnsupported; }
+      return launch_wsplit<WsF16, 16, 16, 64, 128, true>(a, n_cu, stream);
+    }
+#endif
     return a.combine_none ? launch_wsplit<WsF16T<true>, 16, 16, 64, 128>(a, n_cu, stream) : launch_wsplit<WsF16, 16, 16, 64, 128>(a, n_cu, stream);
   }
   set_error("the f16x3 precision mode is not built for this shape");

@@ -103,7 +103,11 @@ struct WsGeo {
   static constexpr int kLdsFloats = kBiasFloats + kClFloats + kHidFloats + kGqFloats + kGiFloats + kPartFloats;
 };
 
-template <class P, int PQ, int PX, int DD, int H>
+// UPPER (f16x3 policy only; rails_mol_score_dense_upper): the kernel writes s + ub(c) instead of s, c = max_l |cl_l| of the pair and
+// ub(c) = (ub2 c + ub1) c + ub0 the caller's per-pair bound on |s - fp32 logit| (rails_amd/f16x3_bound.py upper_bound_poly): an UPPER BOUND
+// of the pair's fp32 logit.  Each wave folds |cl| over its own logits right after GEMM1 (32 v_max per unit) and leaves the partial in LDS,
+// double-buffered by unit parity because the previous unit's partials are folded after this unit's first barrier.
+template <class P, int PQ, int PX, int DD, int H, bool UPPER = false>
 __global__ __launch_bounds__(256, 1) void mol_score_wsplit_kernel(ScoreArgs p) {
   using W = WsGeo<P, PQ, PX, DD, H>;
   using G = typename W::G;
@@ -119,6 +123,7 @@ __global__ __launch_bounds__(256, 1) void mol_score_wsplit_kernel(ScoreArgs p) {
   float4* sGq = sHid + W::kHidFloats / 4;
   float4* sGi = sGq + W::kGqFloats / 4;     // [wave][EW / 4][lane]: the wave's item-gate fragments of the current unit
   float* sPart = reinterpret_cast<float*>(sGi + W::kGiFloats / 4);
+  [[maybe_unused]] float* sCmax = sPart + W::kPartFloats;   // UPPER: [unit parity][wave][lane]
 
   const int lane = threadIdx.x & 63;
   const int lane16 = lane * 16;
@@ -203,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void mol_score_wsplit_kernel(ScoreArgs p) {
   // the previous unit's output is folded and stored by ONE wave after the next barrier: lane = (query of the group, item)
   bool have_prev = false;
   Unit prev{};
-  auto combine_store = [&](const Unit& un) {
+  auto combine_store = [&](const Unit& un, [[maybe_unused]] int parity) {
     float mn[NWT], dn[NWT], nm[NWT];
 #pragma unroll
     for (int w = 0; w < NWT; ++w) {
@@ -223,7 +228,13 @@ __global__ __launch_bounds__(256, 1) void mol_score_wsplit_kernel(ScoreArgs p) {
     }
     // pi = ex/den, then the eval-time renormalisation pi / clamp(sum pi, 1e-6) (similarity_fn.py:42-46): sum pi = den * (1/den)
     const float rden = __builtin_amdgcn_rcpf(den);
-    const float out = (num * rden) / fmaxf(den * rden, 1e-6f);
+    float out = (num * rden) / fmaxf(den * rden, 1e-6f);
+    if constexpr (UPPER) {
+      float c = sCmax[(parity * NWT) * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < NWT; ++w) c = fmaxf(c, sCmax[(parity * NWT + w) * 64 + lane]);
+      out += __builtin_fmaf(__builtin_fmaf(p.ub2, c, p.ub1), c, p.ub0);
+    }
     const int q = un.g * QT + (lane >> 5);
     const int64_t item = (int64_t)un.tile * kTileItems + (lane & 31);
     if (q < p.B && (un.row < 0 || q == un.row) && item < p.n_items) p.logits[(int64_t)q * p.ld + item] = out;
@@ -235,7 +246,8 @@ __global__ __launch_bounds__(256, 1) void mol_score_wsplit_kernel(ScoreArgs p) {
     cur = decode(u);
     prefetch_first(cur);
   }
-  for (int it = 0; u < n_units; u += stride, ++it) {
+  [[maybe_unused]] int n_done = 0;
+  for (int it = 0; u < n_units; u += stride, ++it, ++n_done) {
     const float* tile_ptr = tile_base(cur);
     const WsBuf tileb(tile_ptr, (unsigned)(G::kTileFloats * sizeof(float)));
     const WsBuf eqb(p.eqfrag + (int64_t)cur.g * G::kEqGroupFloats, (unsigned)(G::kEqGroupFloats * sizeof(float)));
@@ -271,6 +283,19 @@ __global__ __launch_bounds__(256, 1) void mol_score_wsplit_kernel(ScoreArgs p) {
       });
     }
     WS_STAMP(1);
+    if constexpr (UPPER) {   // max |cl| over this wave's logits of (query = lane half, item): accumulator registers [Q RPQ, (Q + 1) RPQ) are query Q
+      float cq[QT];
+#pragma unroll
+      for (int Q = 0; Q < QT; ++Q) {
+        float c = 0.0f;
+#pragma unroll
+        for (int mm = 0; mm < MW; ++mm)
+#pragma unroll
+          for (int r = 0; r < G::RPQ; ++r) c = fmaxf(c, fabsf(D1w[mm][Q * G::RPQ + r]));
+        cq[Q] = fmaxf(c, ws_xor32(c));
+      }
+      sCmax[((it & 1) * NWT + wave) * 64 + lane] = hi ? cq[1] : cq[0];
+    }
     // this wave's cl values of both queries as B-operand chunks -> LDS (all-gather over the team)
     ws_static_for<QT * NC2W>([&](auto ic) {
       constexpr int I = decltype(ic)::value, Q = I / NC2W, c = I % NC2W;
@@ -280,7 +305,7 @@ __global__ __launch_bounds__(256, 1) void mol_score_wsplit_kernel(ScoreArgs p) {
     });
     ws_barrier();   // B1: every wave's cl chunks are in LDS; every wave is done with the previous unit's hid and partials
     WS_STAMP(2);
-    if (have_prev && wave == (it & 3)) combine_store(prev);
+    if (have_prev && wave == (it & 3)) combine_store(prev, (it - 1) & 1);
     // Memory requests that nothing waits for soon go HERE, behind the barrier: vector-memory results return in order, so in
     // phase 1 they sat in front of GEMM1's operand loads and every chunk waited for their HBM misses (GEMM1 at half rate).
     // Phase 2 reads LDS only.
@@ -426,25 +451,25 @@ __global__ __launch_bounds__(256, 1) void mol_score_wsplit_kernel(ScoreArgs p) {
   }
   if (have_prev) {
     __syncthreads();   // also drains the uncounted touch loads before the wave ends
-    if (wave == 0) combine_store(prev);
+    if (wave == 0) combine_store(prev, (n_done - 1) & 1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::"v"(sink));
 }
 
-template <class P, int PQ, int PX, int DD, int H>
+template <class P, int PQ, int PX, int DD, int H, bool UPPER = false>
 static int launch_wsplit(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   using W = WsGeo<P, PQ, PX, DD, H>;
-  constexpr size_t lds = (size_t)W::kLdsFloats * sizeof(float);
+  constexpr size_t lds = ((size_t)W::kLdsFloats + (UPPER ? 2 * W::NWT * 64 : 0)) * sizeof(float);
   static_assert(lds <= 160 * 1024, "exchange buffers must fit LDS");
   if (a.cand_pos) { set_error("indexed candidates are not available for the 256-logit team kernel (gather them: rails_mol_index_gather)"); return kErrUnsupported; }
   if (a.dry_run) return kOk;
   static DynLdsOnce once;
-  if (ensure_dyn_lds(once, reinterpret_cast<const void*>(&mol_score_wsplit_kernel<P, PQ, PX, DD, H>), (int)lds) != kOk) return kErrLaunch;
+  if (ensure_dyn_lds(once, reinterpret_cast<const void*>(&mol_score_wsplit_kernel<P, PQ, PX, DD, H, UPPER>), (int)lds) != kOk) return kErrLaunch;
   const int64_t n_units = a.per_row ? (int64_t)a.B * a.n_tiles : a.n_tiles * a.n_groups;
   if (n_units >= (1LL << 31)) { set_error("scoring launch of %lld units: split the corpus", (long long)n_units); return kErrInvalid; }
   int64_t grid = n_units < n_cu ? n_units : n_cu;
   if (grid < 1) return kOk;
-  hipLaunchKernelGGL((mol_score_wsplit_kernel<P, PQ, PX, DD, H>), dim3((unsigned)grid), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL((mol_score_wsplit_kernel<P, PQ, PX, DD, H, UPPER>), dim3((unsigned)grid), dim3(256), lds, stream, a);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

@@ -1399,6 +1399,8 @@ int merge_candidates(const int64_t* gathered, int R, int rows, int k, int k_out,
 //   ok[row] = (k-th exact score > min approx + margin_eps)  and  (max |exact - approx| <= check_eps)
 // The first clause means no item outside the candidates (approx <= min approx, exact <= approx + eps) can reach the k-th place;
 // the second monitors the error bound eps on the candidates themselves.  NaNs fail both.  (topk_modules._forward_rescored)
+// one_sided: approx is an upper bound of the exact score (rails_mol_score_dense_upper); the monitored quantity is exact - approx (<= 0 when
+// the bound holds; the stat is max(0, .)) and margin_eps = 0 proves the row.
 // Entries [n_ranked, kc) are PROBES: items drawn at random from the whole corpus, re-scored with the candidates.  They only feed
 // the error monitor (their approximate logit is read from the dense matrix at their position); they take no part in the selection.
 __global__ __launch_bounds__(kSortThreads) void rescore_select_kernel(const float* __restrict__ exact, int64_t ld,
@@ -1406,7 +1408,7 @@ __global__ __launch_bounds__(kSortThreads) void rescore_select_kernel(const floa
                                                                       const float* __restrict__ approx_dense, int64_t ld_dense,
                                                                       const int64_t* __restrict__ positions,
                                                                       const int64_t* __restrict__ ids, int n_ranked, int kc, int k, int npad,
-                                                                      float margin_eps, float check_eps, float* __restrict__ out_scores,
+                                                                      float margin_eps, float check_eps, int one_sided, float* __restrict__ out_scores,
                                                                       int64_t* __restrict__ out_ids, int* __restrict__ ok,
                                                                       float* __restrict__ stats) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
@@ -1428,7 +1430,7 @@ __global__ __launch_bounds__(kSortThreads) void rescore_select_kernel(const floa
       } else {
         a = approx_dense[(int64_t)row * ld_dense + pos];
       }
-      const float dd = fabsf(e - a);
+      const float dd = one_sided ? e - a : fabsf(e - a);   // one_sided: `approx` is an UPPER BOUND of the exact score; only exact > approx is an error
       bad |= !(dd <= check_eps);       // catches NaN as well
       err = fmaxf(err, dd == dd ? dd : INFINITY);
     }
@@ -1546,7 +1548,7 @@ int margin_stats(const float* kth, int64_t ld, int col, const float* m_max, cons
 }
 
 int rescore_select(const float* exact, int64_t ld, const float* approx, const float* approx_dense, int64_t ld_dense, const int64_t* positions,
-                   const int64_t* ids, int rows, int n_ranked, int kc, int k, float margin_eps, float check_eps, float* out_scores,
+                   const int64_t* ids, int rows, int n_ranked, int kc, int k, float margin_eps, float check_eps, int one_sided, float* out_scores,
                    int64_t* out_ids, int* ok, float* stats, hipStream_t stream) {
   if (rows <= 0) return kOk;
   if (kc > kSortCap) { set_error("rescore_select: %d candidates exceed the in-LDS sort capacity (%d)", kc, kSortCap); return kErrUnsupported; }
@@ -1555,7 +1557,7 @@ int rescore_select(const float* exact, int64_t ld, const float* approx, const fl
     return kErrLaunch;
   const int npad = next_pow2(kc < 2 ? 2 : kc);
   hipLaunchKernelGGL(rescore_select_kernel, dim3(rows), dim3(kSortThreads), npad * sizeof(unsigned long long), stream, exact, ld, approx,
-                     approx_dense, ld_dense, positions, ids, n_ranked, kc, k, npad, margin_eps, check_eps, out_scores, out_ids, ok, stats);
+                     approx_dense, ld_dense, positions, ids, n_ranked, kc, k, npad, margin_eps, check_eps, one_sided, out_scores, out_ids, ok, stats);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

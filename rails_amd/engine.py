@@ -383,6 +383,27 @@ class MolEngine:
             )
         return out
 
+    def score_dense_upper_supported(self) -> bool:
+        """True iff this engine's dense precision has the upper-bound first pass (include/rails_amd.h rails_mol_score_dense_upper)."""
+        memo = self.__dict__
+        if "_upper_ok" not in memo:
+            memo["_upper_ok"] = bool(self.lib.rails_mol_score_dense_upper_supported(C.byref(self.dense_shape)))
+        return memo["_upper_ok"]
+
+    def score_dense_upper(self, qpack: torch.Tensor, batch: int, index: MolIndex, poly: Tuple[float, float, float], out: Optional[torch.Tensor] = None,
+                          run_if: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """f16x3 logit + (ub2 c + ub1) c + ub0 per pair, c = the pair's largest |cross logit|: an upper bound of the fp32 logit when `poly` is
+        f16x3_bound.upper_bound_poly's (ub2, ub1, ub0)."""
+        if out is None:
+            out = torch.empty((batch, index.n_items), dtype=torch.float32, device=index.buf.device)
+        with _on_device(index.buf.device):
+            _lib.check(
+                self.lib.rails_mol_score_dense_upper(C.byref(self.dense_shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(index.buf), index.n_items,
+                                                     float(poly[0]), float(poly[1]), float(poly[2]), _ptr(out), out.stride(0), _pred(run_if), _stream()),
+                "rails_mol_score_dense_upper",
+            )
+        return out
+
     def score_indexed_supported(self, batch: int, n_cand: int) -> bool:
         key = (int(batch), int(n_cand))
         memo = self.__dict__.setdefault("_indexed_ok", {})     # a dry run of the launch per call otherwise: host time of every rerank
@@ -854,11 +875,11 @@ def scalar_probe(x: torch.Tensor) -> torch.Tensor:
 
 def rescore_select(exact: torch.Tensor, approx: torch.Tensor, positions: torch.Tensor, ids: Optional[torch.Tensor], n_items: int, k: int,
                    margin_eps: float = float("inf"), check_eps: float = float("inf"),
-                   approx_dense: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                   approx_dense: Optional[torch.Tensor] = None, one_sided: bool = False) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """Verified finish of a speculative brute-force top-k (include/rails_amd.h rails_rescore_select): exact (rows, >= n_cand) fp32,
     approx (rows, n_ranked), positions (rows, n_cand >= n_ranked; the tail are probes looked up in approx_dense (rows, n_items))
     -> (scores (rows, k), ids (rows, k), row_ok (rows,) int32 for the given eps, row_stats (rows, 2) fp32 = [max |exact - approx|,
-    k-th exact - min candidate approx])."""
+    k-th exact - min candidate approx]).  one_sided: approx are upper bounds of the exact scores; the error stat is max(0, exact - approx)."""
     lib = _lib.load()
     _require_device(exact, "exact scores")
     rows, n_cand = positions.shape
@@ -869,7 +890,7 @@ def rescore_select(exact: torch.Tensor, approx: torch.Tensor, positions: torch.T
     stats = torch.empty((rows, 2), dtype=torch.float32, device=exact.device)
     with _on_device(exact.device):
         _lib.check(lib.rails_rescore_select(_ptr(exact), exact.stride(0), _ptr(approx), _ptr(approx_dense), 0 if approx_dense is None else approx_dense.stride(0),
-                                            _ptr(positions), _ptr(ids), n_items, rows, approx.shape[1], n_cand, k, margin_eps, check_eps,
+                                            _ptr(positions), _ptr(ids), n_items, rows, approx.shape[1], n_cand, k, margin_eps, check_eps, 1 if one_sided else 0,
                                             _ptr(out_s), _ptr(out_i), _ptr(ok), _ptr(stats), _stream()), "rails_rescore_select")
     return out_s, out_i, ok, stats
 

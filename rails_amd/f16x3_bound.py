@@ -136,10 +136,14 @@ def _chain16(terms: torch.Tensor, c0: torch.Tensor, small_mass: torch.Tensor, kc
 
 
 def first_pass_bound(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, temperature: float, dot_dim: int,
-                     p_q: int, p_x: int, kc: float = KC, kp: float = KP, gate_guard: float = GATE_GUARD) -> Dict[str, float]:
+                     p_q: int, p_x: int, kc: float = KC, kp: float = KP, gate_guard: float = GATE_GUARD,
+                     cl_max: Optional[float] = None) -> Dict[str, float]:
     """eps with |first pass (f16x3) - fp32 kernel| <= eps for every pair, from the pair-gate weights (reference parameter names
     _gating_fn._qi_partial_module.{1,3}.{weight,bias}); infinite when a guard fails.  Also returns the two halves and the
-    intermediate magnitudes (for the report and for the oracle's restatement to be compared term by term)."""
+    intermediate magnitudes (for the report and for the oracle's restatement to be compared term by term).
+    cl_max: the bound holds for the pairs whose cross logits satisfy |cl_l| <= cl_max for every l (exact values; default and cap: the
+    a-priori 1/tau of unit-norm sub-embeddings).  Only the magnitudes DOWNSTREAM of GEMM1 use it -- GEMM1's own error is relative to
+    sum_d |Eq'||Ex|, which the norms bound and cl does not.  The bound is non-decreasing in cl_max (every coefficient is >= 0)."""
     f64 = torch.float64
     k32 = torch.tensor(-LOG2E_F32, dtype=torch.float32)
     w1p = (k32 * w1.detach().float().cpu()).to(f64).abs()          # |W1'| exactly as the pack kernels round it
@@ -157,6 +161,7 @@ def first_pass_bound(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: t
     slack = 1.0 + (d + 8) * U                     # fp32 l2 normalisation: ||Ex_m||_2 <= slack, ||Eq'_p||_2 <= slack / tau
     c0 = inv_tau * slack * slack                  # >= sum_d |Eq'||Ex| >= |cl|
     n1a, n1b = math.sqrt(d) * inv_tau * slack, math.sqrt(d) * slack
+    cm = c0 if cl_max is None else min(c0, max(0.0, float(cl_max)))      # |cl_l| of the pairs the bound is stated for
     a1 = w1p.sum(1)                               # (H,) row L1 norms of W1'
     a2 = w2a.sum(1)                               # (L,)
     th = gamma(7)                                 # phi in floating point: exp2 (2u) + add (u) + rcp (2u) + mul (u)
@@ -178,12 +183,12 @@ def first_pass_bound(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: t
     rho, beta_a, beta_b, abs2, mag, a2b, a2a = _block(_PACK, _PACK)               # GEMM1: Eq' x Ex, both split by the packs
     g1 = c0 * mag + n1a * a2b + n1b * a2a                                         # (the distribution of the mass over k is unknown: flat factor)
     dcl16 = rho * c0 + beta_b * n1a + beta_a * n1b + d * abs2 + (gamma(3 * d / 16 + 1, kc * U) + kp * U * (1 + gamma(3 * d / 16 + 1, kc * U))) * g1
-    x1 = c0 + dcl16
+    x1 = cm + dcl16
     rho, beta_a, beta_b, abs2, mag, a2b, a2a = _block(_PACK, _KERN)               # GEMM2: W1' (pack) x cl (kernel split)
     s2 = a1 * x1
     small2 = s2 * (mag - 1) + a1 * a2b + L * x1 * a2a
     dt16 = a1 * dcl16 + rho * s2 + beta_b * a1 + beta_a * L * x1 + L * abs2 + _chain16(w1o * x1, b1p, small2, kc, kp)
-    t_star = b1p + a1 * c0
+    t_star = b1p + a1 * cm
     t16 = t_star + dt16
     dh16 = LIP * dt16 + th * t16 + OMEGA
     y16 = t16 * (1 + th)
@@ -197,7 +202,7 @@ def first_pass_bound(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: t
 
     # ---- the fp32 kernels ------------------------------------------------------------------------------------------------------
     dcl32 = gamma(d) * c0
-    x1f = c0 + dcl32
+    x1f = cm + dcl32
     dt32 = a1 * dcl32 + _chain32(w1o * x1f, b1p)
     t32 = t_star + dt32
     dh32 = LIP * dt32 + th * t32 + OMEGA
@@ -213,4 +218,63 @@ def first_pass_bound(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: t
         "d_q16": float(dq16.max()), "d_q32": float(dq32.max()), "d_w16": half16["dw"], "d_w32": half32["dw"],
         "t2_max": half16["t2_max"], "in_f16_range": bool(in_range),
     })
+    return out
+
+
+def upper_bound_poly(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, temperature: float, dot_dim: int, p_q: int, p_x: int,
+                     grid: int = 96, **kw) -> Dict[str, object]:
+    """Coefficients (ub2, ub1, ub0), all >= 0 and float32-representable, of a PER-PAIR bound: for every pair whose first pass computed cross
+    logits cl16 with c = max_l |cl16_l|,
+
+        first pass logit + fl32((ub2 c + ub1) c + ub0), added in fp32   >=   the fp32 kernels' logit of the pair
+
+    (the UPPER variant of the first pass writes the left-hand side: csrc/mol_score_wsplit.h, rails_mol_score_dense_upper).  Construction:
+    eps(x) = first_pass_bound(cl_max = x)["eps"] is non-decreasing in x and holds for the pairs with |cl_l| <= x exactly; the pair's exact
+    |cl_l| <= c + d_cl16 (GEMM1's own error, a-priori).  On a grid 0 = g_0 < ... < g_J covering every reachable c, E_j = eps(g_j + d_cl16)
+    bounds the pairs with c <= g_j; a quadratic P with coefficients >= 0 (non-decreasing) that satisfies P(g_{j-1}) >= E_j for j = 1..J
+    therefore satisfies P(c) >= E_j >= |first pass - fp32| for every c in (g_{j-1}, g_j] (and P(0) >= E_1 >= E_0).  P is a least-squares fit
+    through (g_{j-1}, E_j) over the coefficient subsets that come out non-negative, shifted up by its largest shortfall.  The device
+    evaluates P in fp32 (two fmas of non-negative terms: relative 2 u) and adds it to a logit of magnitude < 64 (half an ulp: 2^-18):
+    the coefficients are inflated by 2^-18 relative, ub0 by 2^-17 absolute, and each is rounded UP to a float32.
+    -> {"poly": (ub2, ub1, ub0) or None when the bound is infinite, "c_top", "eps_top" = eps at the a-priori |cl| <= 1/tau, "max_slack"}"""
+    top = first_pass_bound(w1, b1, w2, b2, temperature, dot_dim, p_q, p_x, **kw)
+    out: Dict[str, object] = {"poly": None, "eps_top": top["eps"]}
+    if not math.isfinite(top["eps"]):
+        return out
+    inv_tau = 1.0 / float(torch.tensor(temperature, dtype=torch.float32))
+    slack = 1.0 + (int(dot_dim) + 8) * U
+    dcl = float(top["d_cl16"])
+    c_top = (inv_tau * slack * slack + dcl) * (1.0 + 2.0 ** -20)           # no computed |cl16| exceeds this
+    g = [c_top * j / grid for j in range(grid + 1)]
+    e = [float(first_pass_bound(w1, b1, w2, b2, temperature, dot_dim, p_q, p_x, cl_max=x + dcl, **kw)["eps"]) for x in g]
+    if not all(math.isfinite(v) for v in e):
+        return out
+    xs = torch.tensor(g[:-1], dtype=torch.float64)
+    ys = torch.tensor(e[1:], dtype=torch.float64)
+    cols = torch.stack([xs * xs, xs, torch.ones_like(xs)], 1)
+    best = None
+    for mask in range(1, 8):
+        use = [i for i in range(3) if mask >> i & 1]
+        sol = torch.linalg.lstsq(cols[:, use], ys.unsqueeze(1)).solution.squeeze(1)
+        if bool((sol < 0).any()):
+            continue
+        coef = torch.zeros(3, dtype=torch.float64)
+        coef[use] = sol
+        short = float((ys - cols @ coef).clamp_min(0).max())
+        coef[2] += short
+        cost = float((cols @ coef - ys).mean())            # mean slack of the envelope over the grid
+        if best is None or cost < best[0]:
+            best = (cost, coef)
+    if best is None:
+        return out
+    coef = best[1].clone()
+    coef *= 1.0 + 2.0 ** -18
+    coef[2] += 2.0 ** -17
+    c32 = coef.to(torch.float32)
+    up = torch.nextafter(c32, torch.full_like(c32, float("inf")))
+    c32 = torch.where(c32.to(torch.float64) < coef, up, c32)
+    assert bool((c32.to(torch.float64) >= coef).all()) and bool((c32 >= 0).all())
+    poly = tuple(float(v) for v in c32)
+    out.update({"poly": poly, "c_top": c_top, "d_cl16": dcl, "max_slack": float((cols @ best[1] - ys).max()), "mean_slack": best[0],
+                "grid": grid, "eps_of_c": {f"{g[j]:.3f}": e[j] for j in range(0, grid + 1, max(1, grid // 8))}})
     return out

@@ -176,9 +176,9 @@ class MoLBruteForceTopK(MoLTopKModule):
         spec, N = base.spec, self._item_embeddings.shape[1]
         if N < self.SPECULATE_MIN_ITEMS or N > 0xFFFFFFFF or not self._item_embeddings.is_cuda:
             return False
-        if not self._bound_from_weights(spec).get("eps", math.inf) <= self.PROVED_MAX_EPS:
-            return False
         if not base.lib.rails_mol_shape_supported(E.C.byref(spec.to_c("f16x3"))):
+            return False
+        if self._bound_kind(spec, base.lib) is None:
             return False
         if self.keep_dense_fp32_index is False:
             return False
@@ -203,6 +203,43 @@ class MoLBruteForceTopK(MoLTopKModule):
         b2 = lin[1].bias if lin[1].bias is not None else zeros(lin[1].out_features)
         return FB.first_pass_bound(lin[0].weight, b1, lin[1].weight, b2, spec.temperature, spec.dot_product_dimension,
                                    spec.query_dot_product_groups, spec.item_dot_product_groups)
+
+    def _bound_kind(self, spec, lib) -> Optional[str]:
+        """How the proved flow bounds |first pass - fp32| for this shape and these weights:
+          "eps"    one a-priori eps for every pair (f16x3_bound.first_pass_bound), where it is at most PROVED_MAX_EPS;
+          "upper"  a per-pair bound, quadratic in the pair's largest |cross logit|, added to the first-pass logit by the kernel itself
+                   (f16x3_bound.upper_bound_poly, rails_mol_score_dense_upper): where one eps is too coarse and the shape has the kernel;
+          None     neither (infinite bound, or too coarse without the kernel): the module runs the dense fp32 kernels."""
+        eps = self._bound_from_weights(spec).get("eps", math.inf)
+        if eps <= self.PROVED_MAX_EPS:
+            return "eps"
+        if math.isfinite(eps) and lib.rails_mol_score_dense_upper_supported(E.C.byref(spec.to_c("f16x3"))):
+            return "upper"
+        return None
+
+    def _upper_poly(self) -> Optional[Tuple[float, float, float]]:
+        """(ub2, ub1, ub0) when the bound engine's first pass writes per-pair UPPER BOUNDS of the fp32 logits (_bound_kind "upper"), else None."""
+        eng = self._engine
+        c = self._upper_poly_cache
+        if c is not None and c[0] is eng:
+            return c[1]
+        poly = None
+        if eng.exact is not None and eng.dense_precision == "f16x3" and self._bound_kind(eng.spec, eng.lib) == "upper":
+            from . import f16x3_bound as FB
+
+            lin = [m for m in self._mol_module._gating_fn._qi_partial_module.modules() if isinstance(m, torch.nn.Linear)]
+            sp = eng.spec
+            zeros = lambda n: torch.zeros(n)      # noqa: E731
+            res = FB.upper_bound_poly(lin[0].weight, lin[0].bias if lin[0].bias is not None else zeros(lin[0].out_features), lin[1].weight,
+                                      lin[1].bias if lin[1].bias is not None else zeros(lin[1].out_features), sp.temperature, sp.dot_product_dimension,
+                                      sp.query_dot_product_groups, sp.item_dot_product_groups)
+            poly = res["poly"]
+            self._upper_poly_info = res
+        self._upper_poly_cache = (eng, poly)
+        return poly
+
+    _upper_poly_cache = None
+    _upper_poly_info = None
 
     def all_logits(self, query_embeddings: torch.Tensor, **kwargs) -> torch.Tensor:
         """(B, N) fp32 MoL logits against the whole corpus -- of the module's OWN precision (the proved mode's internal split-f16
@@ -297,6 +334,7 @@ class MoLBruteForceTopK(MoLTopKModule):
         # return the dense fp32 result whenever its verdict clears); monitored and empirical for the one-product first pass, whose a-priori
         # bound is vacuous.  A module whose a-priori bound is infinite (a guard fails) does not speculate.
         eps_proved = None if single else self._proved_eps()
+        upper = None if single else self._upper_poly()          # per-pair upper bounds instead of one eps (then eps_proved == 0)
         if eps_proved is not None and not math.isfinite(eps_proved):
             self.rescore_stats["unprovable_calls"] = self.rescore_stats.get("unprovable_calls", 0) + 1
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
@@ -309,7 +347,8 @@ class MoLBruteForceTopK(MoLTopKModule):
             # candidates: every item within eps of the k-th score must be among them.  amzn-books, eps = 0.9-1.0: 470-680 items at k = 200,
             # 6 000-7 500 at k = 2 561 (128 queries; profiles/r05_proved_candidate_census.json); rails_topk costs the same 80-90 us from
             # 544 to 1 536 candidates per row of 700 k scores, so the margin starts generous.  A failed verdict doubles it
-            pad = max(824, 3 * k) * self._pad_scale
+            # (per-pair upper bounds on a 12.5 M-item shard of 16x16x64: 730-900 items can reach the 200-th score; tools/r05_c4_census.py)
+            pad = (max(1848, 8 * k) if upper is not None else max(824, 3 * k)) * self._pad_scale
             kc = min((k + pad + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS, 16384)
         else:
             pad = (max(128, k // 2) if single else max(64, k // 4)) * self._pad_scale
@@ -337,7 +376,10 @@ class MoLBruteForceTopK(MoLTopKModule):
         hook = self._first_pass_hook        # measurement only (bench.py: events around the dominant launch, on its stream)
         if hook is not None:
             hook(0)
-        eng.score_dense(qpack16, B, self._index, out=s16)
+        if upper is not None:
+            eng.score_dense_upper(qpack16, B, self._index, upper, out=s16)
+        else:
+            eng.score_dense(qpack16, B, self._index, out=s16)
         if hook is not None:
             hook(1)
         if self._debug_first_pass_bias is not None:   # tests only: (positions, delta) -- the first pass is made to under-score these items
@@ -349,6 +391,7 @@ class MoLBruteForceTopK(MoLTopKModule):
         if eps_proved is None:
             pos = torch.cat([pos, *self._probes(B, N)], dim=1)
         if self._index32 is not None and B * pos.shape[1] <= self.INDEXED_MAX_CANDIDATES and ex.score_indexed_supported(B, pos.shape[1]):
+            # (_rescore_candidates below is this branch + the gather fallback, for the sharded flow)
             # read the candidates in place from the fp32 index: one launch less and no gathered copy.  A candidate's 1 280 bytes are 80
             # pieces of 16 bytes in the tile-packed index, each in its own cache line, whoever fetches them -- the gather kernel paid
             # that amplification AND wrote and re-read the copy.  Measured with the GEMM1 lookahead of the independent-wave kernels in
@@ -362,7 +405,7 @@ class MoLBruteForceTopK(MoLTopKModule):
             else:
                 cand = ex.build_index(self._item_embeddings[0].index_select(0, pos.reshape(-1)))
             e32 = ex.score_candidates(qpack32, B, cand, pos.shape[1])
-        scores, ids, _, stats = E.rescore_select(e32, c16, pos, self._ids_flat, N, k, approx_dense=s16)
+        scores, ids, _, stats = E.rescore_select(e32, c16, pos, self._ids_flat, N, k, approx_dense=s16, one_sided=upper is not None)
         self.rescore_stats["calls"] += 1
         self.rescore_stats["kc"] = kc
         # The bound eps on |s16 - s32|: never below the calibrated default, and SAFETY x the largest error this module has seen on its
@@ -418,7 +461,7 @@ class MoLBruteForceTopK(MoLTopKModule):
         EVERY rank before it runs the global proof."""
         eng = self._bind()
         return eng.exact is not None and eng.dense_precision == "f16x3" and self._index32 is not None and self._index32_engine is eng.exact \
-            and math.isfinite(self._proved_eps() or math.inf)
+            and self._proved_eps() is not None and math.isfinite(self._proved_eps())
 
     def speculate_for_shard(self, query_embeddings: torch.Tensor, k: int, kc: int, **kwargs):
         """Steps 1-4 of the proved flow on THIS shard, without a verdict: first pass over the shard, its kc best by first-pass score
@@ -445,14 +488,22 @@ class MoLBruteForceTopK(MoLTopKModule):
         hook = self._first_pass_hook
         if hook is not None:
             hook(0)
-        eng.score_dense(qpack16, B, self._index, out=s16)
+        upper = self._upper_poly()
+        if upper is not None:
+            eng.score_dense_upper(qpack16, B, self._index, upper, out=s16)
+        else:
+            eng.score_dense(qpack16, B, self._index, out=s16)
         if hook is not None:
             hook(1)
         ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(B, N, kc), torch.uint8)
         c16, pos = E.topk(s16, kc, workspace=ws)
-        e32 = ex.score_indexed(qpack32, B, self._index32, pos)
+        if ex.score_indexed_supported(B, pos.shape[1]):
+            e32 = ex.score_indexed(qpack32, B, self._index32, pos)
+        else:                                      # (the 256-logit team kernel takes gathered tiles)
+            cand, _ = ex.gather_index(self._index32, pos)
+            e32 = ex.score_candidates(qpack32, B, cand, pos.shape[1])
         k_loc = min(k, kc)
-        scores, ids, _, stats = E.rescore_select(e32, c16, pos, self._ids_flat, N, k_loc, approx_dense=s16)
+        scores, ids, _, stats = E.rescore_select(e32, c16, pos, self._ids_flat, N, k_loc, approx_dense=s16, one_sided=upper is not None)
         m = c16[:, kc - 1] if kc < N else torch.full((B,), float("-inf"), dtype=torch.float32, device=dev)     # (views: the caller concatenates them into its message)
         self.rescore_stats["calls"] += 1
         self.rescore_stats["kc"] = kc
@@ -535,8 +586,11 @@ class MoLBruteForceTopK(MoLTopKModule):
 
         eps = float(self._bound_from_weights(eng.spec).get("eps", math.inf))
         if math.isfinite(eps):
-            eps32 = torch.tensor(eps * (1.0 + 2.0 ** -16), dtype=torch.float32)
-            eps = float(torch.nextafter(eps32, torch.tensor(float("inf"))))
+            if self._upper_poly() is not None:
+                eps = 0.0          # the first pass writes upper bounds of the fp32 logits: the verdict is e_k > m itself (strict: ties with an outsider are redone)
+            else:
+                eps32 = torch.tensor(eps * (1.0 + 2.0 ** -16), dtype=torch.float32)
+                eps = float(torch.nextafter(eps32, torch.tensor(float("inf"))))
             gi_max = self._gi_abs_max()
             self._gate_guard_limit = min(FB.GATE_GUARD / gi_max, 3.0e38) if gi_max > 0.0 else 3.0e38
             if not math.isfinite(gi_max):
@@ -606,6 +660,11 @@ class MoLBruteForceTopK(MoLTopKModule):
             bound = float(terms.get("eps", math.inf))
             out = {"eps_rigorous": bound, "eps_default": default, "eps_rigorous_usable": bool(math.isfinite(bound) and eng.exact is not None),
                    "eps_rigorous_terms": {k: v for k, v in terms.items() if k != "eps"}}
+            if eng.exact is not None and self._upper_poly() is not None:
+                # one eps for every pair is too coarse for this shape: the first pass adds a per-pair bound (quadratic in the pair's largest
+                # |cross logit|) to its logit and the verdict compares upper bounds with exact scores, eps = 0
+                info = self._upper_poly_info or {}
+                out.update({"bound_kind": "per-pair upper bound", "upper_bound_poly": list(self._upper_poly()), "eps_of_max_abs_cl": info.get("eps_of_c")})
         self._rig_cache = (eng, out)
         return out
 

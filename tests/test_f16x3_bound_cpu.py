@@ -79,6 +79,83 @@ def test_emulated_arithmetics_stay_inside_the_bound(workload, kind):
     print(workload, kind, "observed / bound (cl, t, q, s):", [(n, f"{a:.2e}", f"{b:.2e}", f"{c:.2e}", f"{d:.2e}") for n, a, b, c, d in rows], "eps", round(bound["eps"], 4))
 
 
+@pytest.mark.parametrize("kind", STRESS)
+@pytest.mark.parametrize("workload", SHAPES)
+def test_per_pair_bound_holds_stage_by_stage(workload, kind):
+    """first_pass_bound(cl_max = c) is stated for the pairs whose cross logits satisfy |cl_l| <= c: for single pairs (the smallest, the
+    median and the largest c of the sample, and a few more) every stage error of both emulated arithmetics stays inside the stage bounds
+    evaluated at THAT pair's own c -- the statement the per-pair upper bound of the first pass (upper_bound_poly) rests on."""
+    cfg, w, item_scale, args = _case(workload, kind, seed=6)
+    big = cfg.num_logits > 64
+    B, X = (2, 6) if big else (4, 24)
+    q = O.synthetic_queries(cfg, B, seed=8)
+    items = torch.from_numpy(O.hash_item_table(11, 0, X, cfg.item_embedding_dim)) * item_scale
+    uid = torch.arange(1, B + 1) if cfg.uid_embedding_hash_sizes else None
+    eqp, ex, gqp, gi = OB.pair_operands(cfg, w, q, items, uid)
+    w1p, b1p, w2, b2p = OB.prescale(*(np.asarray(t) for t in args[:4]))
+    np_args = tuple(np.asarray(t) if torch.is_tensor(t) else t for t in args)
+    if not OB.first_pass_bound(*np_args)["in_f16_range"]:
+        pytest.skip("operands leave the f16 range: the bound is infinite and the product does not speculate")
+    ref = OB.exact64(eqp, ex, gqp, gi, w1p, b1p, w2, b2p)
+    e32 = OB.emulate_fp32(eqp, ex, gqp, gi, w1p, b1p, w2, b2p, cfg.query_dot_product_groups, cfg.item_dot_product_groups, seed=2)
+    e16 = OB.emulate_f16x3(eqp, ex, gqp, gi, w1p, b1p, w2, b2p, cfg.query_dot_product_groups, cfg.item_dot_product_groups, seed=2)
+    c_pair = np.abs(ref["cl"]).max(1)
+    order = np.argsort(c_pair)
+    pick = sorted({int(order[0]), int(order[1]), int(order[len(order) // 2]), int(order[-2]), int(order[-1])})
+    worst = 0.0
+    for i in pick:
+        b = OB.first_pass_bound(*np_args, cl_max=float(c_pair[i]))
+        top = OB.first_pass_bound(*np_args)
+        assert b["eps"] <= top["eps"] * (1 + 1e-12)
+        for emu, tag in ((e32, "32"), (e16, "16")):
+            assert abs(emu["cl"][i] - ref["cl"][i]).max() <= b["d_cl" + tag]
+            assert (np.abs(emu["t"][i] - ref["t"][i]) <= b["per_h"]["d_t" + tag]).all()
+            assert (np.abs(emu["q"][i] - ref["q"][i]) <= b["per_l"]["d_q" + tag]).all()
+            assert abs(emu["s"][i] - ref["s"][i]) <= b["eps" + tag]
+            worst = max(worst, float((np.abs(emu["t"][i] - ref["t"][i]) / b["per_h"]["d_t" + tag]).max()))
+        assert abs(e16["s"][i] - e32["s"][i]) <= b["eps"]
+    print(workload, kind, "c of the pairs", [round(float(c_pair[i]), 3) for i in pick], "worst observed / bound of t:", f"{worst:.2e}")
+
+
+@pytest.mark.parametrize("workload,kind", [("ml-1m", "gaussian"), ("ml-1m", "outlier"), ("amzn-books", "hot gate"), ("synthetic-16x16x64", "gaussian")])
+def test_upper_bound_poly_covers_the_restated_bound(workload, kind):
+    """The coefficients the product hands to the UPPER first pass: non-negative float32s whose quadratic, as the device evaluates it, covers the
+    oracle's own eps(c + d_cl16) over the whole range of c (oracle.upper_poly_shortfall restates the requirement); tight (within a few % of
+    eps at the a-priori end, and far below it where the pairs of a corpus sit); and on emulated pairs first pass + P(c16) >= fp32 logit."""
+    cfg, w, item_scale, args = _case(workload, kind, seed=3)
+    np_args = tuple(np.asarray(t) if torch.is_tensor(t) else t for t in args)
+    res = FB.upper_bound_poly(*args)
+    top = OB.first_pass_bound(*np_args)
+    if not math.isfinite(top["eps"]):
+        assert res["poly"] is None
+        return
+    ub2, ub1, ub0 = res["poly"]
+    assert min(ub2, ub1, ub0) >= 0 and all(float(np.float32(v)) == v for v in res["poly"])
+    assert OB.upper_poly_shortfall(res["poly"], *np_args, grid=res["grid"]) <= 0.0
+    assert OB.upper_poly_shortfall(tuple(v * 0.97 for v in res["poly"]), *np_args, grid=res["grid"]) > 0.0       # (the check can fail)
+    c_top = res["c_top"]
+    p_top = (ub2 * c_top + ub1) * c_top + ub0
+    assert top["eps"] <= p_top <= 1.06 * top["eps"] + 1e-4
+    c_typ = 0.375 * c_top
+    assert (ub2 * c_typ + ub1) * c_typ + ub0 <= 0.25 * top["eps"]
+    # emulated pairs
+    big = cfg.num_logits > 64
+    B, X = (2, 6) if big else (4, 24)
+    q = O.synthetic_queries(cfg, B, seed=9)
+    items = torch.from_numpy(O.hash_item_table(13, 0, X, cfg.item_embedding_dim)) * item_scale
+    uid = torch.arange(1, B + 1) if cfg.uid_embedding_hash_sizes else None
+    eqp, ex, gqp, gi = OB.pair_operands(cfg, w, q, items, uid)
+    w1p, b1p, w2, b2p = OB.prescale(*(np.asarray(t) for t in args[:4]))
+    e32 = OB.emulate_fp32(eqp, ex, gqp, gi, w1p, b1p, w2, b2p, cfg.query_dot_product_groups, cfg.item_dot_product_groups, seed=3)
+    e16 = OB.emulate_f16x3(eqp, ex, gqp, gi, w1p, b1p, w2, b2p, cfg.query_dot_product_groups, cfg.item_dot_product_groups, seed=3)
+    c16 = np.abs(e16["cl"]).max(1).astype(np.float32)
+    f = np.float32
+    p32 = (f(ub2) * c16 + f(ub1)).astype(np.float32) * c16 + f(ub0)
+    upper = (e16["s"].astype(np.float32) + p32.astype(np.float32)).astype(np.float32)
+    assert (upper.astype(np.float64) >= e32["s"]).all()
+    assert float((upper - e32["s"]).max()) <= p_top
+
+
 def test_operand_split_constants():
     """|x - hi - lo| <= R |x| + A and |lo| <= LAM |x| + A' for both split flavours, over normal, tiny (f16-subnormal) and large values"""
     g = np.random.default_rng(0)

@@ -96,7 +96,7 @@ def test_config4_shard_verified_mode_equals_fp32(dev):
     ids = torch.arange(1, N + 1, dtype=torch.int64, device=dev).unsqueeze(0)
     q = O.synthetic_queries(cfg, B, seed=4).to(dev)
     with torch.inference_mode():
-        plain = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, "fp32"), X, ids)
+        plain = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, "fp32"), X, ids, exact_mode="dense")
         s, i = plain(q, k=k)
         del plain
         torch.cuda.empty_cache()
@@ -106,8 +106,25 @@ def test_config4_shard_verified_mode_equals_fp32(dev):
             assert torch.equal(fs, s) and torch.equal(fi, i)
         torch.cuda.synchronize()
         st = fast.stats()
-    assert st["calls"] >= 3 and st["fallbacks"] == 0, st
-    del fast, X
+        assert st["calls"] >= 3 and st["fallbacks"] == 0, st
+        del fast
+        torch.cuda.empty_cache()
+        # The DEFAULT exact path on this shape: one a-priori eps (3.0 logit units) proves nothing here, so the first pass writes per-pair
+        # upper bounds of the fp32 logits (rails_mol_score_dense_upper) and the verdict is e_k > best bound outside the candidates --
+        # every call PROVED, no dense fallback, the dense fp32 kernels' bits; also through get_top_k_outputs with the seen-id filter
+        proved = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, None), X, ids)
+        assert proved.exact_mode == "proved" and proved._bind().exact is not None and proved._upper_poly() is not None
+        for _ in range(3):
+            ps, pi = proved(q, k=k)
+            assert torch.equal(ps, s) and torch.equal(pi, i)
+        st = proved.stats()
+        print("config-4 shard, proved mode:", {key: st.get(key) for key in ("calls", "proved_calls", "fallbacks", "bound_violations", "kc", "eps", "bound_kind", "upper_bound_poly")})
+        assert st["calls"] == 3 and st["proved_calls"] == 3 and st["fallbacks"] == 0 and st["bound_violations"] == 0 and st["bound_kind"] == "per-pair upper bound", st
+        inv = i[:, torch.randperm(k, device=dev)[:61]].contiguous()
+        want_i, want_s = E.filter_seen_ids(i, s, inv, 120)
+        got_i, got_s, _ = rails_amd.CandidateIndex(ids=ids, embeddings=X).get_top_k_outputs(q, 120, {}, proved, inv, truncate_k_prime_to=200)
+        assert torch.equal(got_i, want_i) and torch.equal(got_s, want_s)
+    del proved, X
     torch.cuda.empty_cache()
 
 

@@ -169,6 +169,52 @@ def test_first_pass_error_stays_below_the_a_priori_bound(dev, workload, kind):
     assert err <= bound["eps"]
 
 
+@pytest.mark.parametrize("kind", STRESS)
+def test_upper_first_pass_bounds_every_fp32_logit(dev, kind):
+    """rails_mol_score_dense_upper (16x16x64, the team kernel): logit + (ub2 c + ub1) c + ub0 with the product's coefficients is >= the fp32
+    kernels' logit for EVERY pair; the added term is the polynomial of the pair's own largest |cross logit| (checked against the oracle's
+    stage functions on a sample); and it is far below the one a-priori eps where the pairs of a corpus sit."""
+    cfg = O.CONFIGS["synthetic-16x16x64"]
+    w, item_scale = _stressed(cfg, kind, seed=7)
+    N, B = 30_011, 9
+    X = torch.from_numpy(O.hash_item_table(23, 0, N, cfg.item_embedding_dim)) * item_scale
+    q = O.synthetic_queries(cfg, B, seed=45)
+    p = "_gating_fn._qi_partial_module."
+    args = (w[p + "1.weight"], w[p + "1.bias"], w[p + "3.weight"], w[p + "3.bias"], cfg.temperature, cfg.dot_product_dimension,
+            cfg.query_dot_product_groups, cfg.item_dot_product_groups)
+    res = FB.upper_bound_poly(*args)
+    if res["poly"] is None:
+        assert math.isinf(FB.first_pass_bound(*args)["eps"])
+        return
+    ub2, ub1, ub0 = res["poly"]
+    ids = torch.arange(N, device=dev).unsqueeze(0)
+    with torch.inference_mode():
+        tk16 = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, "f16x3"), X.unsqueeze(0).to(dev), ids)
+        eng = tk16._bind()
+        assert eng.score_dense_upper_supported()
+        qpack, _, _ = eng.query_pack(q.to(dev), None)
+        s16 = eng.score_dense(qpack, B, tk16._index)
+        up = eng.score_dense_upper(qpack, B, tk16._index, res["poly"])
+        tk32 = rails_amd.MoLBruteForceTopK(build_module(cfg, w, dev, "fp32"), X.unsqueeze(0).to(dev), ids, exact_mode="dense")
+        s32 = tk32.all_logits(q.to(dev))
+    assert torch.isfinite(up).all() and torch.isfinite(s32).all()
+    assert bool((up >= s32).all()), float((s32 - up).max())
+    add = (up - s16).double().cpu()
+    assert float(add.min()) >= ub0 * (1 - 1e-6) - 2e-6
+    # the added term == P(max |cl|) of the pair: cross logits of a sample from the oracle's stage functions (fp32 torch, ~1e-5 off the kernel's)
+    cols = torch.randint(0, N, (64,), generator=torch.Generator().manual_seed(3))
+    eq = O.query_component_embeddings(cfg, w, q, None)
+    exm = O.item_component_embeddings(cfg, w, X[cols])
+    c = (torch.einsum("bpd,nmd->bnpm", eq, exm) / cfg.temperature).abs().amax((2, 3)).double()
+    want = (ub2 * c + ub1) * c + ub0
+    assert float((add[:, cols] - want).abs().max()) <= 1e-3 * float(want.max()) + 1e-5
+    eps_top = FB.first_pass_bound(*args)["eps"]
+    print(f"16x16x64 {kind:16s} added bound: median {float(add.median()):.4f}  max {float(add.max()):.4f}   one a-priori eps {eps_top:.3f};  min (upper - fp32) = {float((up - s32).min()):.4f}")
+    assert float(add.max()) <= eps_top * 1.06 + 1e-4
+    if kind == "gaussian":
+        assert float(add.median()) <= 0.3 * eps_top
+
+
 # ---- the module -------------------------------------------------------------------------------------------------------------------
 def _dense(m32, X, ids):
     tk = rails_amd.MoLBruteForceTopK(m32, X, ids)
@@ -198,24 +244,23 @@ def test_proved_mode_is_the_default_and_equals_dense_fp32(dev, workload, N, B, k
             rails_amd.MoLBruteForceTopK.SPECULATE_MIN_ITEMS = 0
             tk = rails_amd.MoLBruteForceTopK(m, X, ids)
             assert tk.exact_mode == "proved"
-            if cfg.num_logits > 64:     # 16x16x64: the a-priori bound (2.9 logit units) is beyond PROVED_MAX_EPS -> the module does not even build the second index
-                assert tk._bind().exact is None and tk.stats().get("calls", 0) == 0
-                s, i = tk(q, k=k, **kw)
-                assert torch.equal(s, r_s) and torch.equal(i, r_i)
-                return
             assert tk._bind().exact is not None, "the proved mode is not the default exact path"
+            # 16x16x64: one a-priori eps (3.0 logit units) is beyond PROVED_MAX_EPS -> the first pass writes per-pair upper bounds instead
+            assert (tk._upper_poly() is not None) == (cfg.num_logits > 64)
             for _ in range(3):
                 s, i = tk(q, k=k, **kw)
                 assert torch.equal(s, r_s) and torch.equal(i, r_i)
             st = tk.stats()
             print(workload, N, B, k, {key: st.get(key) for key in ("calls", "fallbacks", "proved_calls", "bound_violations", "eps", "eps_rigorous", "guard_max", "kc")}, "kc pad", tk._pad_scale)
             assert st["eps_rigorous_usable"] is True and st["bound_violations"] == 0
+            assert (st.get("bound_kind") == "per-pair upper bound") == (cfg.num_logits > 64)
             if N > 65536 and cfg.num_logits <= 64:
                 # large corpora of the 8x8x32 shape: a few hundred items lie within eps of the k-th score -> every call is proved
                 assert st["calls"] == 3 and st["proved_calls"] == 3 and st["fallbacks"] == 0 and st["eps"] == pytest.approx(st["eps_rigorous"], rel=1e-4)
             else:
-                # ML-1M / ML-20M (most of the corpus lies within eps of the k-th score) and the 256-logit shape (eps of several logit units):
-                # nothing can be proved -- the calls are redone densely, say so, and stop speculating
+                # ML-1M / ML-20M (most of the corpus lies within eps of the k-th score) and a 400 k-item sub-range of the 256-logit shape (the
+                # k-th score sits where scores are dense: ~10 k items can reach it; the full 12.5 M-item shard, where 730-900 can, is
+                # tests/test_full_shard_gpu.py): what cannot be proved is redone densely, says so, and the margin grows or the module stops speculating
                 assert st["proved_calls"] + st["fallbacks"] + st.get("paused_calls", 0) + st.get("unprovable_calls", 0) + (3 - st["calls"]) >= 3 and st["proved_calls"] <= st["calls"]
             inv = ids[0, torch.randint(0, N, (B, 61), device=dev)]
             kk = min(k, 120)

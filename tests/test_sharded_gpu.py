@@ -79,7 +79,9 @@ def _worker(rank: int, world: int, port: int, n_items: int, precision, ret, work
             cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)      # the harness object holds the whole id table; the module is sharded
             c_i, c_s, _ = cand.get_top_k_outputs(q, kk, {}, sh, inv, truncate_k_prime_to=min(k, n_items))
             assert torch.equal(c_i, want_i) and torch.equal(c_s, want_s)
-            if precision in (None, "f16x3-exact"):
+            provable = bool(sh._global_proof(q))    # (16x16x64: the a-priori eps exceeds PROVED_MAX_EPS, the default binds the dense fp32 kernels)
+            assert provable or workload == "synthetic-16x16x64" or precision not in (None, "f16x3-exact"), "the global proof did not engage"
+            if precision in (None, "f16x3-exact") and provable:
                 # the default exact path and its explicit form prove ONCE for all shards (ShardedMoLBruteForceTopK's global proof): every call
                 # above went through it, was proved or redone, and no observed error exceeded the a-priori bound; with an absurd bound every
                 # verdict fails on every rank alike and the dense fp32 redo -- second exchange, output picked by the flag -- returns the same bits

@@ -25,8 +25,14 @@ def main():
     ap.add_argument("--k", type=int, default=120)
     ap.add_argument("--width", type=int, default=80)
     ap.add_argument("--k-prime", type=int, default=200, help="truncate_k_prime_to (the harness's timing protocol: 200)")
+    ap.add_argument("--workload", default="amzn-books")
+    ap.add_argument("--items", type=int, default=0, help="corpus size (default: the workload's)")
+    ap.add_argument("--min-items", type=int, default=-1, help="override MoLBruteForceTopK.SPECULATE_MIN_ITEMS (where the proved flow starts)")
     args = ap.parse_args()
-    cfg_key, N, _ = bench.WORKLOADS["amzn-books"]
+    cfg_key, N, _ = bench.WORKLOADS[args.workload]
+    N = args.items or N
+    if args.min_items >= 0:
+        rails_amd.MoLBruteForceTopK.SPECULATE_MIN_ITEMS = args.min_items
     cfg = O.CONFIGS[cfg_key]
     dev = torch.device("cuda:0")
     w = O.synthetic_weights(cfg, seed=0)
@@ -42,18 +48,21 @@ def main():
     q = O.synthetic_queries(cfg, args.batch).to(dev)
     inv = ids[0, torch.randint(0, N, (args.batch, args.width), device=dev)]
     cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)
+    kw = {}
+    if cfg.uid_embedding_hash_sizes:
+        kw["user_ids"] = torch.randint(0, cfg.uid_embedding_hash_sizes[0], (args.batch,), dtype=torch.int64).to(dev)
     with torch.inference_mode():
         for pr in args.precisions.split(","):
             tk = bench.brute_force_module(mol, X, ids, pr)      # "fp32" = dense fp32 kernels, "proved" = the default exact path
             for _ in range(5):
-                cand.get_top_k_outputs(q, args.k, {}, tk, inv, truncate_k_prime_to=args.k_prime)
+                cand.get_top_k_outputs(q, args.k, kw, tk, inv, truncate_k_prime_to=args.k_prime)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                cand.get_top_k_outputs(q, args.k, {}, tk, inv, truncate_k_prime_to=args.k_prime)
+                cand.get_top_k_outputs(q, args.k, kw, tk, inv, truncate_k_prime_to=args.k_prime)
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / args.steps * 1e3
-            print(f"{pr:12s} {ms:7.3f} ms per step  {args.batch / ms * 1e3:9.1f} queries/s  {getattr(tk, 'rescore_stats', '')}")
+            print(f"{args.workload} N={N} B={args.batch} {pr:12s} {ms:7.4f} ms per step  {args.batch / ms * 1e3:9.1f} queries/s  {getattr(tk, 'rescore_stats', '')}")
 
 
 if __name__ == "__main__":

@@ -1,12 +1,23 @@
 #!/bin/bash
+# sharded GPU tests at HEAD, per-rank shard steps (global proof), and where the proved flow starts to pay (corpus size sweep)
 cd "$(dirname "$0")/.." || exit 1
-export TMPDIR=/tmp
-O=gpurun_out/s6; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o p -- python bench.py --steps 5 --warmup 1 --no-other-workloads --no-cpu-baseline --no-hr-parity --no-fast-path > $O/bench.json 2> $O/bench.err
-f=$(find $O/prof -name '*kernel_stats.csv' | head -1); python tools/kernel_stats_top.py "$f" 30 | tee $O/top.txt
-rm -rf $O/prof
-python - <<'PY'
-import json
-d=json.load(open("gpurun_out/s6/bench.json"))
-for p in d["matrix"]: print(p["precision"],p["batch"],p["k_prime"],round(p["ms_per_step"],3),p.get("proved_calls"),p.get("dense_fp32_fallbacks"))
-PY
+O=gpurun_out/s16; mkdir -p $O
+python -m pytest tests/test_sharded_gpu.py -x -q -m gpu > $O/sharded_tests.txt 2>&1; echo "sharded tests rc=$?"; tail -3 $O/sharded_tests.txt
+: > $O/shard_steps.txt
+for R in 2 4 8; do
+  for P in fp32 proved-global f16x3-exact; do
+    python tools/shard_step_profile.py --world $R --precision $P 2>&1 | grep -v amdgpu.ids >> $O/shard_steps.txt
+  done
+done
+cat $O/shard_steps.txt
+: > $O/crossover.txt
+for W in ml-1m ml-20m; do
+  python tools/exact_step_profile.py --workload $W --precisions fp32,proved,f16x3 --min-items 0 --steps 200 --width 211 2>&1 | grep -v amdgpu.ids >> $O/crossover.txt
+done
+for N in 16384 32768 65536 131072 262144; do
+  python tools/exact_step_profile.py --items $N --precisions fp32,proved --min-items 0 --steps 100 2>&1 | grep -v amdgpu.ids >> $O/crossover.txt
+done
+for B in 3 4 8 16; do
+  python tools/exact_step_profile.py --batch $B --precisions fp32,proved --steps 100 2>&1 | grep -v amdgpu.ids >> $O/crossover.txt
+done
+cat $O/crossover.txt
