@@ -1050,6 +1050,7 @@ def main() -> None:
                 p_steps_ms = [p_step[i].elapsed_time(p_step[i + 1]) for i in range(args.steps)]
                 proved = {"elapsed": p_elapsed, "score_ms": p_score_ms, "steps_ms": p_steps_ms, "calls": timed_calls, "proved_calls": proved_calls, "fallbacks": fallbacks,
                           "bound_violations": violations, "identical": identical_ranks == world, "eps": st.get("eps_rigorous"), "eps_terms": st.get("eps_rigorous_terms"),
+                          "bound_kind": st.get("bound_kind", "one a-priori eps"), "upper_bound_poly": st.get("upper_bound_poly"),
                           "kc": st.get("kc"), "guard_max": st.get("guard_max"), "guard_limit": getattr(topk_mod, "_gp_guard_limit", None) if st.get("global_proof") else local._gate_guard_limit,
                           "global_proof": bool(st.get("global_proof", False)),
                           "qualifies": bool(identical_ranks == world and proved_calls == timed_calls == args.steps * world and fallbacks == 0 and violations == 0)}
@@ -1236,13 +1237,17 @@ def main() -> None:
             a16 = flops_alg / (proved["score_ms"] * 1e-3) / 1e12
             leg = {
                 "what": "the module's default exact path: split-f16 (f16x3) first pass over the whole corpus -> top-kc candidates per query -> fp32 re-scoring of the "
-                        "candidates in place -> top-k' by (fp32 score, position) -> device-side proof e_k > m + eps with the A-PRIORI bound eps on |first pass - fp32| "
-                        "(rails_amd/f16x3_bound.py); a call that is not proved is redone by the dense fp32 kernels behind the verdict",
+                        "candidates -> top-k' by (fp32 score, position) -> device-side proof " + (
+                            "e_k > m, the first pass having written per-pair UPPER BOUNDS of the fp32 logits (its logit + a bound quadratic in the pair's largest "
+                            "|cross logit|: rails_mol_score_dense_upper, f16x3_bound.upper_bound_poly)" if proved.get("upper_bound_poly") else
+                            "e_k > m + eps with the A-PRIORI bound eps on |first pass - fp32| (rails_amd/f16x3_bound.py)") +
+                        "; a call that is not proved is redone by the dense fp32 kernels behind the verdict",
                 "value": p_val, "unit": "queries/s", "ms_per_step": proved["elapsed"] / args.steps * 1e3,
                 "ms_per_step_stdev": float(torch.tensor(proved["steps_ms"]).std()) if len(proved["steps_ms"]) > 1 else 0.0,
                 "timed_calls": proved["calls"], "proved_calls": proved["proved_calls"], "dense_fp32_fallbacks": proved["fallbacks"],
                 "bound_violations": proved["bound_violations"], "output_identical_to_fp32_path": proved["identical"],
-                "eps_a_priori": proved["eps"], "candidates_per_query": proved["kc"], "gate_guard": {"max_abs_gq_seen": proved["guard_max"], "limit": proved["guard_limit"]},
+                "eps_a_priori": proved["eps"], "bound": proved.get("bound_kind"), **({"upper_bound_poly": proved["upper_bound_poly"]} if proved.get("upper_bound_poly") else {}),
+                "candidates_per_query": proved["kc"], "gate_guard": {"max_abs_gq_seen": proved["guard_max"], "limit": proved["guard_limit"]},
                 "first_pass_kernel_ms": proved["score_ms"], "is_headline": proved["qualifies"],
                 **({"sharded_global_proof": "one proof for all shards: kc per rank = candidates_per_query; all-gather of the per-shard fp32 top-k' + all-reduce(max) of the "
                                             "best first-pass score left outside (rails_amd/sharded.py ShardedMoLBruteForceTopK)"} if proved.get("global_proof") else {}),
@@ -1253,8 +1258,9 @@ def main() -> None:
                 out["fp32_dense"] = {"value": out["value"], "unit": "queries/s", "ms_per_step": out["ms_per_step"], "ms_per_step_stdev": out["ms_per_step_stdev"],
                                      "roofline": out["roofline"], "what": "the dense fp32 kernels over the whole corpus (exact_mode 'dense'), same step, same protocol, timed in this run"}
                 out["value"], out["ms_per_step"], out["ms_per_step_stdev"] = leg["value"], leg["ms_per_step"], leg["ms_per_step_stdev"]
-                out["config"]["exact_path"] = "proved: f16x3 first pass + fp32 re-scoring, a-priori eps (same bits as the dense fp32 kernels)"
-                out["config"]["prefilter"] = "f16x3, a-priori eps"
+                kind = "per-pair a-priori upper bound" if proved.get("upper_bound_poly") else "a-priori eps"
+                out["config"]["exact_path"] = f"proved: f16x3 first pass + fp32 re-scoring, {kind} (same bits as the dense fp32 kernels)"
+                out["config"]["prefilter"] = f"f16x3, {kind}"
                 out["roofline"] = {
                     "kernel": "mol_score_*_kernel<f16x3::F16Unit> (the first pass: the dominant launch of the proved step)", "bound": "mfma", "achieved": a16,
                     "peak": PEAK_F16X3_TFLOPS, "unit": "TFLOP/s", "frac": a16 / PEAK_F16X3_TFLOPS,
