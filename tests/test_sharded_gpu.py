@@ -79,22 +79,27 @@ def _worker(rank: int, world: int, port: int, n_items: int, precision, ret, work
             cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)      # the harness object holds the whole id table; the module is sharded
             c_i, c_s, _ = cand.get_top_k_outputs(q, kk, {}, sh, inv, truncate_k_prime_to=min(k, n_items))
             assert torch.equal(c_i, want_i) and torch.equal(c_s, want_s)
-            provable = bool(sh._global_proof(q))    # (16x16x64: the a-priori eps exceeds PROVED_MAX_EPS, the default binds the dense fp32 kernels)
-            assert provable or workload == "synthetic-16x16x64" or precision not in (None, "f16x3-exact"), "the global proof did not engage"
+            provable = bool(sh._global_proof(q))    # (16x16x64: one a-priori eps exceeds PROVED_MAX_EPS -- the first pass writes per-pair upper bounds there)
+            assert provable or precision not in (None, "f16x3-exact"), "the global proof did not engage"
             if precision in (None, "f16x3-exact") and provable:
                 # the default exact path and its explicit form prove ONCE for all shards (ShardedMoLBruteForceTopK's global proof): every call
                 # above went through it, was proved or redone, and no observed error exceeded the a-priori bound; with an absurd bound every
                 # verdict fails on every rank alike and the dense fp32 redo -- second exchange, output picked by the flag -- returns the same bits
                 st = sh.stats()
                 assert st.get("global_proof") is True and st["calls"] >= 6 and st["proved_calls"] + st["fallbacks"] == st["calls"] and st["bound_violations"] == 0, st
-                assert n_items < 1000 or st["proved_calls"] >= 1, st
+                # (16x16x64 at 20 k items: a fifth of the corpus can reach the k-th score under the per-pair bounds -- calls are redone until the margin has grown)
+                assert n_items < 1000 or st["proved_calls"] >= 1 or workload == "synthetic-16x16x64", st
                 before = st["fallbacks"]
                 sh._gp_eps = 1.0e9
                 fs, fi = sh(q, k=k)
                 assert torch.equal(fs, full_s) and torch.equal(fi, full_i), "global proof: the redo differs from the single-device result"
                 got = sh.forward_filtered(q, min(k, n_items), inv, kk)
                 assert torch.equal(got[0], want_i) and torch.equal(got[1], want_s)
-                assert sh.stats()["fallbacks"] == before + (2 if n_items >= 1000 else 0)     # (a shard that is all candidates leaves nothing outside: proved whatever the bound)
+                after = sh.stats()["fallbacks"]
+                if workload == "synthetic-16x16x64":    # (the margin may have grown to the whole shard by now)
+                    assert before <= after <= before + 2
+                else:
+                    assert after == before + (2 if n_items >= 1000 else 0)     # (a shard that is all candidates leaves nothing outside: proved whatever the bound)
                 sh._gp_eps = sh._local_module._proved_eps()
             if precision in ("f16x3-exact", "f16-exact"):   # ... and both are the fp32 path's result, bit for bit
                 mol32 = build_module(cfg, O.synthetic_weights(cfg, seed=1), dev)
