@@ -76,6 +76,32 @@ def test_committed_round4_bench_line_carries_the_quality_half():
     assert tp["pipelined"]["output_equal_to_unpipelined"] is True and tp["ms_per_step"] < 1.65     # config-5 shard: 1.73 ms before the round-4 rebuild
 
 
+def test_committed_round5_bench_line_is_the_proved_exact_path():
+    """profiles/r05_bench.json (the default `python bench.py` run at the end of round 5): `value` is the proved exact path -- every timed
+    call proved on the device with the a-priori bound, the output bit-identical to the dense fp32 kernels' -- with the dense fp32 number
+    beside it, the roofline of the first-pass kernel against 2 500 / 3 TFLOP/s, HR parity on the whole corpus, and config 4's shard proved
+    through the per-pair upper bounds."""
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench.json")))
+    check_line(d, expect_cpu_baseline=True)
+    p = d["proved"]
+    assert p["is_headline"] is True and p["proved_calls"] == p["timed_calls"] == d["steps"] and p["dense_fp32_fallbacks"] == 0 and p["bound_violations"] == 0
+    assert p["output_identical_to_fp32_path"] is True and abs(p["value"] - d["value"]) < 1e-9 and d["dtype"] == "f32" and d["value"] >= 11000
+    assert d["config"]["exact_path"].startswith("proved") and d["fp32_dense"]["value"] < d["value"] and d["fp32_dense"]["roofline"]["frac"] > 0.8
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and abs(r["peak"] - 2500 / 3) < 1e-6 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["traffic"] is not None
+    assert abs(r["kernel_ms"] - p["first_pass_kernel_ms"]) < 1e-9 and r["kernel_ms"] < d["ms_per_step"]
+    hp = d["hr_parity"]
+    assert hp["parity"] is True and "695762" in hp["what"] and hp["identical_rows"] + hp["rows_differing_only_inside_oracle_ties"] == hp["rows"]
+    assert "all 695762" in d["cpu_baseline"]["sample"]
+    rows = {(m["precision"], m["batch"], m["k_prime"]): m for m in d["matrix"]}
+    assert rows[("proved", 8, 200)]["ms_per_step"] < 0.6 * rows[("fp32", 8, 200)]["ms_per_step"]
+    legs = {l["variant"][:8]: l for l in d["full_shards"]}
+    c4 = legs["proved"]
+    assert "N=12500000" in c4["workload"] and c4["runs_dense_fp32"] is False and c4["bound"] == "per-pair upper bound"
+    assert c4["proved_calls"] == c4["rescore_calls"] > 0 and c4["dense_fp32_fallbacks"] == 0 and c4["bound_violations"] == 0
+    assert c4["ms_per_step"] < 0.45 * legs["fp32"]["ms_per_step"]
+
+
 @pytest.mark.gpu
 def test_live_bench_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-fast-path", "--no-matrix",

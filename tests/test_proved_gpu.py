@@ -274,6 +274,34 @@ def test_proved_mode_is_the_default_and_equals_dense_fp32(dev, workload, N, B, k
             rails_amd.MoLBruteForceTopK.SPECULATE_MIN_ITEMS = old
 
 
+@pytest.mark.parametrize("B", [1, 2])
+def test_small_batches_take_the_dense_kernels_with_the_fused_filter(dev, B):
+    """Batches below PROVED_MIN_BATCH of a default-mode module run the dense fp32 kernels -- through forward and through
+    get_top_k_outputs, where the seen-id filter stays inside the selection launch -- and return what the dense module returns."""
+    cfg = O.CONFIGS["amzn-books"]
+    N, k = 90_001, 120
+    X = torch.from_numpy(O.hash_item_table(5, 0, N, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = (torch.arange(N, dtype=torch.int64, device=dev) * 2 + 3).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B, seed=12).to(dev)
+    with torch.inference_mode():
+        m = build_module(cfg, O.synthetic_weights(cfg, seed=0), dev, None)
+        tk = rails_amd.MoLBruteForceTopK(m, X, ids)
+        assert tk._bind().exact is not None
+        dense = _dense(m, X, ids)
+        s, i = tk(q, k=k)
+        r_s, r_i = dense(q, k=k)
+        assert torch.equal(s, r_s) and torch.equal(i, r_i)
+        inv = ids[0, torch.randint(0, N, (B, 61), device=dev)]
+        inv[:, :7] = r_i[:, :7]                       # some of the best items are "seen"
+        ci = rails_amd.CandidateIndex(ids, X)
+        fused = tk.forward_filtered(q, 200, inv, k)
+        assert fused is not None
+        a = ci.get_top_k_outputs(q, k=k, aux_payloads={}, top_k_module=tk, invalid_ids=inv, truncate_k_prime_to=200)
+        b = ci.get_top_k_outputs(q, k=k, aux_payloads={}, top_k_module=dense, invalid_ids=inv, truncate_k_prime_to=200)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(fused[0], b[0]) and torch.equal(fused[1], b[1])
+        assert tk.stats()["calls"] == 0              # nothing was speculated
+
+
 def test_proved_mode_unprovable_calls_fall_back(dev):
     """What cannot be proved is redone on the dense fp32 kernels, and says so:
       (a) stressed gate weights (x 6): the a-priori bound is several logit units, the candidates cannot cover everything within it
