@@ -1597,6 +1597,39 @@ def test_rescore_select_kernel_against_a_host_restatement(dev):
     assert torch.equal(i2[5].cpu(), (i[5].cpu() - 3) // 7)    # ids = None -> positions
 
 
+def test_rescore_select_one_sided_monitors_upper_bounds(dev):
+    """one_sided = 1 (the first pass wrote UPPER BOUNDS of the exact scores, rails_mol_score_dense_upper): the error stat is max(0, exact - bound),
+    zero while every bound holds however loose it is; margin_eps = 0 is the proof e_k > min candidate bound (strict)."""
+    g = torch.Generator().manual_seed(8)
+    rows, kc, k, N = 5, 160, 50, 3000
+    pos = torch.stack([torch.randperm(N, generator=g)[:kc] for _ in range(rows)])
+    exact = torch.randn(rows, kc, generator=g).mul(2)
+    upper = exact + torch.rand(rows, kc, generator=g) * 0.8 + 0.05              # loose bounds, all valid
+    kth = exact.topk(k).values[:, -1]
+    # rows: 0 proved (a gap of 6 below the k-th exact score, so the smallest bound is far below it); 1 margin fails (no candidate bound below
+    # e_k); 2 a violated bound (exact above its bound by 0.3); 3 the smallest bound == e_k exactly (strict: not proved); 4 a NaN
+    low = exact < kth[:, None]
+    exact = torch.where(low, exact - 6.0, exact)
+    upper = torch.where(low, upper - 6.0, upper)
+    upper[1] = torch.where(low[1], torch.full_like(upper[1], float(kth[1]) + 0.25), upper[1])
+    j2 = int(exact[2].argmax())
+    upper[2, j2] = exact[2, j2] - 0.3
+    upper[3] = torch.where(low[3], torch.full_like(upper[3], float(kth[3])), upper[3])
+    exact[4, 7] = float("nan")
+    s, i, ok, st = E.rescore_select(exact.to(dev), upper.to(dev), pos.to(dev), None, N, k, 0.0, 0.0, one_sided=True)
+    st, ok = st.cpu(), ok.cpu().tolist()
+    assert ok == [1, 0, 0, 0, 0]
+    assert float(st[0, 0]) == 0.0 and float(st[1, 0]) == 0.0 and float(st[3, 0]) == 0.0            # loose but valid bounds: no error
+    assert abs(float(st[2, 0]) - 0.3) <= 1e-6 and float(st[4, 0]) == float("inf")
+    assert float(st[0, 1]) > 0.0 and float(st[1, 1]) < 0.0 and float(st[3, 1]) == 0.0
+    for r in (0, 1, 2, 3):
+        order = sorted(range(kc), key=lambda j: (-float(exact[r, j]), int(pos[r, j])))[:k]
+        assert torch.equal(s[r].cpu(), exact[r, order]) and torch.equal(i[r].cpu(), pos[r, order])
+    # the two-sided form of the same call counts every loose bound as an error
+    _, _, ok2, st2 = E.rescore_select(exact.to(dev), upper.to(dev), pos.to(dev), None, N, k, 0.0, 0.0)
+    assert ok2.cpu().tolist() == [0, 0, 0, 0, 0] and float(st2.cpu()[0, 0]) > 0.05
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_chunked_brute_force_equals_the_one_pass_result(dev, precision):
     """MoLBruteForceTopK never materialises more than MAX_LOGIT_BYTES of logits: above that the corpus is scored in chunks whose
