@@ -189,7 +189,8 @@ int rails_mol_score_dense(const rails_mol_shape* shape, const float* gate_pack, 
  * coefficients of rails_amd/f16x3_bound.py upper_bound_poly (>= 0, finite) the value is an UPPER BOUND of the pair's fp32-kernel logit: the
  * bound on |f16x3 - fp32| is quadratic in the magnitude of the cross logits, and the a-priori |cl| <= 1/tau it is otherwise evaluated at is
  * 2-3 x what the pairs of a corpus reach (config 4: one eps = 3.0 for every pair needs > 60 000 candidates per query at 12.5 M items, the
- * per-pair bound 730-900).  Built for the 256-logit team kernel (16x16x64); rails_mol_score_dense_upper_supported says whether a shape has it. */
+ * per-pair bound 730-900).  Built for the f16x3 kernels of the BASELINE shapes (the 256-logit team kernel and the 8-wave register-resident units);
+ * rails_mol_score_dense_upper_supported says whether a shape has it. */
 int rails_mol_score_dense_upper_supported(const rails_mol_shape* shape);
 int rails_mol_score_dense_upper(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack, int32_t batch, const float* index,
                                 int64_t n_items, float ub2, float ub1, float ub0, float* logits, int64_t ld, const int32_t* run_if, void* stream);

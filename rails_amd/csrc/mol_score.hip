@@ -191,8 +191,8 @@ static bool use_small_units(const Shape& s, const ScoreArgs& a, int n_cu) {
 
 int score_launch(const Shape& s, const ScoreArgs& a, int n_cu, hipStream_t stream) {
   if (!score_supported(s)) return kErrUnsupported;
-  if (a.upper && !(a.split && !a.single && !score_extra_shape(s) && s.query_dot_product_groups == 16 && s.item_dot_product_groups == 16 && s.dot_product_dimension == 64)) {
-    set_error("the upper-bound first pass is built for the f16x3 team kernel (16x16x64) only");
+  if (a.upper && !(a.split && !a.single && !score_extra_shape(s))) {
+    set_error("the upper-bound first pass is built for the f16x3 kernels of the BASELINE shapes");
     return kErrUnsupported;
   }
   if (score_extra_shape(s))

@@ -25,9 +25,21 @@ static int launch_f16(const ScoreArgs& a, int n_cu, hipStream_t stream) {
   constexpr bool tight = (PX + G::TH + G::TL) * 16 > RAILS_F16_TIGHT_LIMIT;
   using U8 = std::conditional_t<tight, F16Unit<false, true>, F16Unit<OVL, false>>;
   using U4 = F16Unit<OVL, false>;
-  if (a.combine_none)   // gating_combination "none": its own instantiation of the unit, direct shell only
+  if (a.combine_none && !a.upper)   // gating_combination "none": its own instantiation of the unit, direct shell only
     return launch_kernel<F16Unit<false, tight, true>, PQ, PX, DD, H, 8, false>(a, n_cu, stream);
   const int variant = choose_variant<PQ, PX, DD, H>(a, n_cu);
+#if !RAILS_F16_SINGLE
+  if (a.upper) {   // rails_mol_score_dense_upper: the 8-wave builds of the unit with the per-pair bound added to the logit
+    using UP = std::conditional_t<tight, F16Unit<false, true, false, true>, F16Unit<true, false, false, true>>;
+    if (a.combine_none || a.per_row) { set_error("the upper-bound first pass is built for the glu_silu combiner over a shared corpus"); return kErrUnsupported; }
+    switch (variant) {
+      case 1: return launch_kernel<UP, PQ, PX, DD, H, 8, false>(a, n_cu, stream);
+      case 2: return launch_kernel<UP, PQ, PX, DD, H, 8, true>(a, n_cu, stream);
+      case 5: return launch_staged1<UP, PQ, PX, DD, H, 8>(a, n_cu, stream);
+      default: set_error("the upper-bound first pass has no 4-wave build (RAILS_SCORE_VARIANT %d)", variant); return kErrUnsupported;
+    }
+  }
+#endif
   if ((variant == 2 || variant == 4 || variant == 5 || variant == 6) && a.per_row) { set_error("staged scoring kernel does not do per-row candidates"); return kErrUnsupported; }
   switch (variant) {
     case 1: return launch_kernel<U8, PQ, PX, DD, H, 8, false>(a, n_cu, stream);

@@ -510,7 +510,9 @@ static __device__ long long g_f16_phase[32];
 // OVERLAP: stage X of query Q+1 carries the epilogue of query Q (needs D2 and D3 of two queries live at once).
 // TIGHT:   the accumulators alone fill the register budget (8x8x32 at two waves per SIMD: 224 of 256): no operand double
 //          buffering in stage Y and no pinned order -- the compiler's own schedule fits without spilling, a pinned one does not.
-template <bool OVERLAP, bool TIGHT, bool NONE = false>
+// UPPER:   the unit writes logit + (ub2 c + ub1) c + ub0, c = max |cl| over the pair's logits as GEMM1 left them: an upper bound of the pair's
+//          fp32 logit under the per-pair form of the a-priori bound (rails_mol_score_dense_upper; mol_score_wsplit.h has the team kernel's).
+template <bool OVERLAP, bool TIGHT, bool NONE = false, bool UPPER = false>
 struct F16Unit {
   static constexpr bool kIndexedCandidates = false;
   template <class G>
@@ -535,7 +537,25 @@ struct F16Unit {
     const bool lane_stores = hi == 0 && item < p.n_items;
     // rows past the batch end (padding of the last group) run on zero operands and the last real gate row; never stored
     auto gq_of = [&](int q) { return p.gqfrag + (int64_t)(q < p.B ? q : p.B - 1) * G::L + hi * G::E; };
-    auto store = [&](int q, float out) {
+    // UPPER: accumulator registers [Q RPQ, (Q + 1) RPQ) of every D1[m] are query Q's logits of item x (rows (r & 3) + 8 (r >> 2) + 4 hi);
+    // the two lane halves hold the two halves of the row set
+    [[maybe_unused]] float cmax[G::QT];
+    if constexpr (UPPER) {
+      static_for<G::QT>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        float c = 0.0f;
+#pragma unroll
+        for (int m = 0; m < PX; ++m)
+#pragma unroll
+          for (int r = 0; r < G::RPQ; ++r) c = fmaxf(c, fabsf(D1[m][Q * G::RPQ + r]));
+        cmax[Q] = fmaxf(c, __shfl_xor(c, 32, 64));
+      });
+    }
+    auto store = [&](auto qc, int q, float out) {
+      if constexpr (UPPER) {
+        const float c = cmax[decltype(qc)::value];
+        out += __builtin_fmaf(__builtin_fmaf(p.ub2, c, p.ub1), c, p.ub0);
+      }
       if (lane_stores && q < p.B) p.logits[(int64_t)q * p.ld + item] = out;
     };
 
@@ -595,7 +615,7 @@ struct F16Unit {
           ep.reset(gq_of(q), tGi, lane);
           stage_y(qc);
           F16_STAMP(4 * Q + 2);
-          store(q, epilogue_alone(qc));
+          store(qc, q, epilogue_alone(qc));
           F16_STAMP(4 * Q + 3);
         }
       });
@@ -617,9 +637,9 @@ struct F16Unit {
         x_begin<G>(xs, w, lane);
         interleave<NXM, G::E>([&](auto ic) { x_mfma<G, PX, (Q + 1) * G::RPQ, decltype(ic)::value>(D1, D2, xs, w, lane); },
                               [&](auto sc) { epi_slice<G, PX, Q * G::RPQ, decltype(sc)::value>(ep, D1, tGi, lane); });
-        store(q, epi_final<G, PX, Q * G::RPQ>(ep, D1));
+        store(qc, q, epi_final<G, PX, Q * G::RPQ>(ep, D1));
       } else {
-        store(q, epilogue_alone(qc));
+        store(qc, q, epilogue_alone(qc));
       }
       F16_STAMP(3 + 2 * Q);
     });

@@ -160,6 +160,8 @@ class MoLBruteForceTopK(MoLTopKModule):
     EXACT_MODE = __import__("os").environ.get("RAILS_EXACT_MODE", "proved")
     PROVED_MAX_EPS = 2.0          # a module whose a-priori bound exceeds this many logit units is not worth a second index: the items within eps of the
                                   # k-th score run into the tens of thousands (16x16x64: eps = 2.9; profiles/r05_proved_candidate_census.json)
+    PROVED_MAX_EPS_PER_PAIR = 8.0 # ... up to this eps (at the a-priori |cl| <= 1/tau) the bound is applied PER PAIR instead: the pairs of a corpus sit at a third of
+                                  # 1/tau and the bound is quadratic in it (_bound_kind "upper": 16x16x64 at random init, 3.0; trained weights of the other shapes)
     PROVED_MIN_BATCH = 3          # smaller batches of the default mode run the dense fp32 kernels (see _forward_rescored)
 
     def _engine_for_bind(self) -> E.MolEngine:
@@ -213,7 +215,7 @@ class MoLBruteForceTopK(MoLTopKModule):
         eps = self._bound_from_weights(spec).get("eps", math.inf)
         if eps <= self.PROVED_MAX_EPS:
             return "eps"
-        if math.isfinite(eps) and lib.rails_mol_score_dense_upper_supported(E.C.byref(spec.to_c("f16x3"))):
+        if eps <= self.PROVED_MAX_EPS_PER_PAIR and lib.rails_mol_score_dense_upper_supported(E.C.byref(spec.to_c("f16x3"))):
             return "upper"
         return None
 
