@@ -319,7 +319,8 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
 
     def _kc_local(self, k: int) -> int:
         upper = self._local_module._upper_poly() is not None       # per-pair upper bounds: more items can reach the k-th score (topk_modules._forward_rescored)
-        total = k + (max(1848, 8 * k) if upper else max(824, 3 * k)) * self._gp_pad
+        floor, per_k = MoLBruteForceTopK.PAD_PER_PAIR if upper else MoLBruteForceTopK.PAD_ONE_EPS
+        total = k + max(floor, per_k * k) * self._gp_pad
         per = -(-total // self._world)
         kc = per + int(4.0 * per ** 0.5) + 32
         kc = (kc + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS

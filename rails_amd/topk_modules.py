@@ -162,6 +162,8 @@ class MoLBruteForceTopK(MoLTopKModule):
                                   # k-th score run into the tens of thousands (16x16x64: eps = 2.9; profiles/r05_proved_candidate_census.json)
     PROVED_MAX_EPS_PER_PAIR = 8.0 # ... up to this eps (at the a-priori |cl| <= 1/tau) the bound is applied PER PAIR instead: the pairs of a corpus sit at a third of
                                   # 1/tau and the bound is quadratic in it (_bound_kind "upper": 16x16x64 at random init, 3.0; trained weights of the other shapes)
+    PAD_ONE_EPS = (824, 3)        # candidates beyond k: max(floor, per_k * k) (doubled after a failed verdict) -- under one eps ...
+    PAD_PER_PAIR = (1848, 8)      # ... and under per-pair upper bounds (sized for a 12.5 M-item shard of 16x16x64: 730-900 items can reach the 200-th score)
     PROVED_MIN_BATCH = 3          # smaller batches of the default mode run the dense fp32 kernels (see _forward_rescored)
 
     def _engine_for_bind(self) -> E.MolEngine:
@@ -363,7 +365,8 @@ class MoLBruteForceTopK(MoLTopKModule):
             # 6 000-7 500 at k = 2 561 (128 queries; profiles/r05_proved_candidate_census.json); rails_topk costs the same 80-90 us from
             # 544 to 1 536 candidates per row of 700 k scores, so the margin starts generous.  A failed verdict doubles it
             # (per-pair upper bounds on a 12.5 M-item shard of 16x16x64: 730-900 items can reach the 200-th score; tools/r05_c4_census.py)
-            pad = (max(1848, 8 * k) if upper is not None else max(824, 3 * k)) * self._pad_scale
+            floor, per_k = self.PAD_PER_PAIR if upper is not None else self.PAD_ONE_EPS
+            pad = max(floor, per_k * k) * self._pad_scale
             kc = min((k + pad + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS, 16384)
         else:
             pad = (max(128, k // 2) if single else max(64, k // 4)) * self._pad_scale

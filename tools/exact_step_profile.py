@@ -28,7 +28,13 @@ def main():
     ap.add_argument("--workload", default="amzn-books")
     ap.add_argument("--items", type=int, default=0, help="corpus size (default: the workload's)")
     ap.add_argument("--min-items", type=int, default=-1, help="override MoLBruteForceTopK.SPECULATE_MIN_ITEMS (where the proved flow starts)")
+    ap.add_argument("--force-per-pair", action="store_true", help="proved rows: per-pair upper bounds even where one eps proves the calls (PROVED_MAX_EPS = 0)")
+    ap.add_argument("--per-pair-pad", type=int, default=0, help="candidate floor beyond k under per-pair bounds (default: the module's 1848)")
     args = ap.parse_args()
+    if args.force_per_pair:
+        rails_amd.MoLBruteForceTopK.PROVED_MAX_EPS = 0.0
+    if args.per_pair_pad:
+        rails_amd.MoLBruteForceTopK.PAD_PER_PAIR = (args.per_pair_pad, 1)
     cfg_key, N, _ = bench.WORKLOADS[args.workload]
     N = args.items or N
     if args.min_items >= 0:
