@@ -184,6 +184,10 @@ class MoLBruteForceTopK(MoLTopKModule):
             return False
         if self._bound_kind(spec, base.lib) is None:
             return False
+        from . import arith_check
+
+        if not arith_check.device_ok(self._item_embeddings.device):     # the bound's hypotheses about the part, re-measured on THIS device (once per process)
+            return False
         if self.keep_dense_fp32_index is False:
             return False
         need = base.lib.rails_mol_index_floats(E.C.byref(base.shape), N) * 4
@@ -678,6 +682,10 @@ class MoLBruteForceTopK(MoLTopKModule):
             bound = float(terms.get("eps", math.inf))
             out = {"eps_rigorous": bound, "eps_default": default, "eps_rigorous_usable": bool(math.isfinite(bound) and eng.exact is not None),
                    "eps_rigorous_terms": {k: v for k, v in terms.items() if k != "eps"}}
+            if eng.exact is not None and self._item_embeddings.is_cuda:
+                from . import arith_check
+
+                out["arithmetic_model_on_device"] = arith_check.report(self._item_embeddings.device)     # H1-H3 re-measured on this device (worst error / bound)
             if eng.exact is not None and self._upper_poly() is not None:
                 # one eps for every pair is too coarse for this shape: the first pass adds a per-pair bound (quadratic in the pair's largest
                 # |cross logit|) to its logit and the verdict compares upper bounds with exact scores, eps = 0

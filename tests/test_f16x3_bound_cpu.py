@@ -156,6 +156,36 @@ def test_upper_bound_poly_covers_the_restated_bound(workload, kind):
     assert float((upper - e32["s"]).max()) <= p_top
 
 
+def test_device_self_check_accepts_the_model_and_rejects_departures_from_it():
+    """rails_amd/arith_check.py (run once per device before the proved mode binds) with emulated probes: arithmetic that follows the model
+    passes; an f16 MFMA that rounds its result to f16, one that flushes f16 subnormal operands, an fp32 MFMA accumulating in bf16-like
+    precision and a 3-ulp exp each fail it."""
+    from rails_amd import arith_check as AC
+
+    def p16(a, b, c): return (c.double() + a.double() @ b.double()).float()
+    def p32(a, b, c): return (c.double() + a.double() @ b.double()).float()
+
+    def ps(x):
+        x64 = x.double()
+        return torch.stack([torch.exp2(x64), 1 / x64, x64 / (1 + torch.exp2(x64))]).float()
+
+    cpu = torch.device("cpu")
+    good = AC.measure(cpu, p16, p32, ps)
+    assert good["ok"] and good["h2_f16_mfma_kc_kp"] < 0.5 and good["h2_f16_subnormals_kept"]
+    assert not AC.measure(cpu, lambda a, b, c: (c + (a.float() @ b.float()).half().float()), p32, ps)["ok"]
+    flush = lambda t: torch.where(t.abs().float() < 2.0 ** -14, torch.zeros_like(t), t)      # noqa: E731
+    r = AC.measure(cpu, lambda a, b, c: p16(flush(a), flush(b), c), p32, ps)
+    assert not r["ok"] and not r["h2_f16_subnormals_kept"]
+    assert not AC.measure(cpu, p16, lambda a, b, c: p32(a, b, c).bfloat16().float(), ps)["ok"]
+
+    def ps_bad(x):
+        out = ps(x)
+        out[0] = out[0] * (1 + 3 * 2.0 ** -23)
+        return out
+
+    assert not AC.measure(cpu, p16, p32, ps_bad)["ok"]
+
+
 def test_operand_split_constants():
     """|x - hi - lo| <= R |x| + A and |lo| <= LAM |x| + A' for both split flavours, over normal, tiny (f16-subnormal) and large values"""
     g = np.random.default_rng(0)

@@ -123,6 +123,31 @@ def test_scalar_transcendentals_are_one_ulp(dev):
     assert e_exp <= 2 * U * 1.001 and e_rcp <= 2 * U * 1.001 and e_phi <= FB.gamma(7)
 
 
+def test_device_self_check_passes_here_and_gates_the_proved_mode(dev):
+    """rails_amd/arith_check.py: the compact re-measurement of H1-H3 that runs once per device before the proved mode binds passes on this
+    part with room to spare, is reported by stats(), and a device that failed it gets the dense kernels."""
+    from rails_amd import arith_check as AC
+
+    rep = AC.report(dev)
+    print("arithmetic self-check:", rep)
+    assert rep["ok"] and rep["h1_fp32_mfma_fma_chain"] <= 1.0 + 1e-6 and rep["h2_f16_mfma_kc_kp"] <= 0.8 and rep["h3_exp_rcp_phi"] <= 0.8 and rep["h2_f16_subnormals_kept"]
+    cfg = O.CONFIGS["amzn-books"]
+    N = 70_000
+    X = torch.from_numpy(O.hash_item_table(3, 0, N, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = torch.arange(N, dtype=torch.int64, device=dev).unsqueeze(0)
+    with torch.inference_mode():
+        m = build_module(cfg, O.synthetic_weights(cfg, seed=0), dev, None)
+        tk = rails_amd.MoLBruteForceTopK(m, X, ids)
+        assert tk._bind().exact is not None and tk.stats()["arithmetic_model_on_device"]["ok"] is True
+        key = str(torch.device(dev))
+        saved = AC._cache[key]
+        try:
+            AC._cache[key] = {"ok": False, "forced": "by the test"}
+            assert rails_amd.MoLBruteForceTopK(m, X, ids)._bind().exact is None
+        finally:
+            AC._cache[key] = saved
+
+
 # ---- |first pass - fp32| against the bound, on the kernels -----------------------------------------------------------------------
 STRESS = ["gaussian", "outlier", "hot gate", "near overflow", "tiny components"]
 
