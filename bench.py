@@ -1048,7 +1048,8 @@ def main() -> None:
                 timed_calls, proved_calls, fallbacks, violations, identical_ranks = (int(v) for v in counts.tolist())
                 p_score_ms = sum(a.elapsed_time(b) for a, b in zip(pe0, pe1)) / args.steps
                 p_steps_ms = [p_step[i].elapsed_time(p_step[i + 1]) for i in range(args.steps)]
-                proved = {"elapsed": p_elapsed, "score_ms": p_score_ms, "steps_ms": p_steps_ms, "calls": timed_calls, "proved_calls": proved_calls, "fallbacks": fallbacks,
+                p_kernel_ms = [a.elapsed_time(b) for a, b in zip(pe0, pe1)]
+                proved = {"elapsed": p_elapsed, "score_ms": p_score_ms, "steps_ms": p_steps_ms, "kernel_ms": p_kernel_ms, "calls": timed_calls, "proved_calls": proved_calls, "fallbacks": fallbacks,
                           "bound_violations": violations, "identical": identical_ranks == world, "eps": st.get("eps_rigorous"), "eps_terms": st.get("eps_rigorous_terms"),
                           "bound_kind": st.get("bound_kind", "one a-priori eps"), "upper_bound_poly": st.get("upper_bound_poly"),
                           "kc": st.get("kc"), "guard_max": st.get("guard_max"), "guard_limit": getattr(topk_mod, "_gp_guard_limit", None) if st.get("global_proof") else local._gate_guard_limit,
@@ -1252,6 +1253,11 @@ def main() -> None:
                 **({"sharded_global_proof": "one proof for all shards: kc per rank = candidates_per_query; all-gather of the per-shard fp32 top-k' + all-reduce(max) of the "
                                             "best first-pass score left outside (rails_amd/sharded.py ShardedMoLBruteForceTopK)"} if proved.get("global_proof") else {}),
                 "per_step_ms": [round(v, 3) for v in proved["steps_ms"]],
+                "per_step_first_pass_kernel_ms": [round(v, 3) for v in proved["kernel_ms"]],
+                # the f16 kernel's time falls for the first ~40 ms of sustained load after an idle gap (clock ramp; the fp32 kernels do not show it):
+                # the second half of the timed steps on its own -- `value` stays the whole timed region
+                "second_half": {"ms_per_step": sum(proved["steps_ms"][args.steps // 2:]) / max(1, args.steps - args.steps // 2),
+                                "first_pass_kernel_ms": sum(proved["kernel_ms"][args.steps // 2:]) / max(1, args.steps - args.steps // 2)},
             }
             if proved["qualifies"]:
                 # `value` = the proved path; the returned scores ARE the fp32 kernels' bits (dtype f32); the dense fp32 measurement of this run moves beside it
