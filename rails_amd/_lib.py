@@ -110,6 +110,9 @@ PROTOTYPES = {
         C.c_int,
         [_SHAPE_P, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
     ),
+    "rails_mol_index_rows_floats": (C.c_size_t, [_SHAPE_P, C.c_int64]),
+    "rails_mol_index_rows_build": (C.c_int, [_SHAPE_P, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "rails_mol_score_indexed_rows": (C.c_int, [_SHAPE_P, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "rails_mol_score_dense_upper_supported": (C.c_int, [_SHAPE_P]),
     "rails_mol_score_dense_upper": (
         C.c_int,

@@ -324,6 +324,41 @@ int rails_mol_score_indexed(const rails_mol_shape* s, const float* gate_pack, co
   return r == kOk ? r : fail(r, "score_indexed");
 }
 
+size_t rails_mol_index_rows_floats(const rails_mol_shape* s, int64_t n_items) {
+  if (!shape_ok(s) || n_items < 0 || is_split(*s)) return 0;
+  return (size_t)n_items * (size_t)(tile_floats(*s) / 32);
+}
+
+int rails_mol_index_rows_build(const rails_mol_shape* s, const float* index, int64_t n_items, float* rows, void* stream) {
+  g_err[0] = '\0';
+  if (!shape_ok(s)) return RAILS_EINVAL;
+  if (is_split(*s)) { set_error("index_rows_build: exact-fp32 index only"); return RAILS_ENOTSUP; }
+  if (n_items < 0) { set_error("index_rows_build: n_items < 0"); return RAILS_EINVAL; }
+  if (n_items == 0) return RAILS_OK;
+  if (!index || !rows) { set_error("index_rows_build: NULL pointer"); return RAILS_EINVAL; }
+  return fail(index_rows_build(*s, index, n_items, rows, (hipStream_t)stream), "index_rows_build");
+}
+
+int rails_mol_score_indexed_rows(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch, const float* index_rows,
+                                 int64_t n_items, const int64_t* positions, int64_t n_cand, float* logits, int64_t ld, void* stream) {
+  g_err[0] = '\0';
+  if (!shape_supported(s)) return RAILS_ENOTSUP;
+  if (batch < 0 || n_items <= 0 || n_cand < 0) { set_error("score_indexed_rows: bad size"); return RAILS_EINVAL; }
+  if (batch == 0 || n_cand == 0) return RAILS_OK;
+  if (!gate_pack || !query_pack || !index_rows || !positions || !logits) { set_error("score_indexed_rows: NULL pointer"); return RAILS_EINVAL; }
+  if (ld < n_cand) { set_error("score_indexed_rows: ld < n_cand"); return RAILS_EINVAL; }
+  if (is_split(*s)) { set_error("score_indexed_rows: exact-fp32 precision only"); return RAILS_ENOTSUP; }
+  const int cu = compute_units();
+  if (cu <= 0) { set_error("score_indexed_rows: no HIP device"); return RAILS_ELAUNCH; }
+  ScoreArgs a;
+  fill_score_args(s, gate_pack, query_pack, batch, index_rows, n_cand, logits, ld, 1, &a);
+  a.cand_pos = positions;
+  a.index_items = n_items;
+  a.irows = index_rows;
+  const int r = score_launch(*s, a, cu, (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "score_indexed_rows");
+}
+
 int rails_mol_score_candidates(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch,
                                const float* cand_index, int64_t n_cand, float* logits, int64_t ld, void* stream) {
   return score_common(s, gate_pack, query_pack, batch, cand_index, n_cand, logits, ld, 1, stream, "score_candidates");

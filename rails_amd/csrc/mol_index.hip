@@ -421,6 +421,26 @@ int index_unpack(const Shape& s, const float* ipack, int64_t n, float* ex, float
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
+// ---- row-major copy of an fp32 index: item i's fragment slot s, lane half h (one float4) at rows[i * RP + 2 s + h], RP = floats per item / 4.
+// A candidate's operands are then RP consecutive float4 (amzn-books: 1 280 B in ten 128-byte lines) instead of RP pieces of 16 B each in a line
+// of its own across the tile (8 x read amplification when candidates are re-scored in place: rails_mol_score_indexed_rows).
+__global__ void index_rows_kernel(const float4* __restrict__ ipack, int64_t n, int rp, int tile_f4, float4* __restrict__ rows) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * rp) return;
+  const int64_t item = i / rp;
+  const int j = (int)(i - item * rp), slot = j >> 1, h = j & 1;
+  rows[i] = ipack[(item >> 5) * tile_f4 + slot * 64 + h * 32 + (item & 31)];
+}
+
+int index_rows_build(const Shape& s, const float* ipack, int64_t n, float* rows, hipStream_t stream) {
+  if (n <= 0) return kOk;
+  const int tile_f4 = (int)(tile_floats(s) / 4), rp = tile_f4 / 32;
+  const int64_t total = n * rp;
+  hipLaunchKernelGGL(index_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, reinterpret_cast<const float4*>(ipack), n, rp, tile_f4,
+                     reinterpret_cast<float4*>(rows));
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 // ---- gather: rows x n_cand candidate positions -> a tile-packed index of their own -----------------
 __global__ void index_gather_kernel(const float4* __restrict__ ipack, int64_t n, const int64_t* __restrict__ idx,
                                     int64_t tiles_per_row, int64_t n_cand, int tile_f4, float4* __restrict__ out) {

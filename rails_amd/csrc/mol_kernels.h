@@ -47,6 +47,7 @@ struct ScoreArgs {
   // of an index of index_items items; NULL = per-row candidates come as their own gathered tiles (rails_mol_score_candidates)
   const int64_t* cand_pos;
   int64_t index_items;
+  const float* irows;             // with cand_pos: the ROW-MAJOR copy of the index (rails_mol_index_rows_build) the candidates are read from instead of ipack
   int dry_run;                    // 1: validate the dispatch (shape, shell) without launching
   // rails_mol_score_dense_upper: logits[b][x] = s + (ub2 c + ub1) c + ub0, c = max_l |cl_l| of the pair (mol_score_wsplit.h UPPER)
   int upper;
@@ -98,6 +99,7 @@ bool score_supported(const Shape& s);
 int pack_gate_weights(const Shape& s, const Weights& w, float* wpack, hipStream_t stream);
 int index_build(const Shape& s, const Weights& w, const float* items, int64_t n, float* ipack, hipStream_t stream);
 int index_unpack(const Shape& s, const float* ipack, int64_t n, float* ex, float* gi, hipStream_t stream);
+int index_rows_build(const Shape& s, const float* ipack, int64_t n, float* rows, hipStream_t stream);
 // fp32 Ex fragments of a freshly built index -> f16 hi/lo fragments, in place (precision f16x3)
 int index_split_inplace(const Shape& s, float* ipack, int64_t n, hipStream_t stream);
 int index_gather(const Shape& s, const float* ipack, int64_t n, const int64_t* idx, int64_t rows, int64_t n_cand,

@@ -51,7 +51,10 @@ __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); 
 // GEMM1: D1[m][(qj,p), x] = sum_d Eq[qj,p,d] * Ex[x,m,d].  `eq` is the query group's A operand in fragment
 // order ([sc][lane] float4), `tEx` the tile's B operand ([m][sc][lane] float4) -- in HBM or in LDS.
 // PIPE: 0 = each K-chunk loaded where it is used; 1 = one chunk requested ahead; n > 1 = a register ring of n chunks in flight.
-template <class G, int PX, int DD, bool BULK = false, int PIPE = 0>
+// SS: float4 stride between consecutive fragment slots of `tEx` as the lane sees them -- 64 in a tile (slot s of lane l at tEx[64 s + l]); 2 in
+// the row-major copy of the index (rails_mol_index_rows_build: item i's slot s, half h at rows[i * RP + 2 s + h]; the rows kernel hands the
+// unit the per-lane pointer row + h - lane, so that tEx[2 s + l] lands there).  Same values, same order, same bits.
+template <class G, int PX, int DD, bool BULK = false, int PIPE = 0, int SS = 64>
 __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float4* __restrict__ eq, const float4* tEx, int lane) {
 #pragma unroll
   for (int m = 0; m < PX; ++m)
@@ -67,7 +70,7 @@ __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float4* __restrict
     for (int c = 0; c < PD; ++c) {
       ra[c] = eq[c * 64 + lane];
 #pragma unroll
-      for (int m = 0; m < PX; ++m) rb[c][m] = tEx[(m * NC + c) * 64 + lane];
+      for (int m = 0; m < PX; ++m) rb[c][m] = tEx[(m * NC + c) * SS + lane];
     }
 #pragma unroll
     for (int sc = 0; sc < NC; ++sc) {
@@ -78,7 +81,7 @@ __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float4* __restrict
       if (sc + PD < NC) {
         ra[sc % PD] = eq[(sc + PD) * 64 + lane];
 #pragma unroll
-        for (int m = 0; m < PX; ++m) rb[sc % PD][m] = tEx[(m * NC + sc + PD) * 64 + lane];
+        for (int m = 0; m < PX; ++m) rb[sc % PD][m] = tEx[(m * NC + sc + PD) * SS + lane];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -98,7 +101,7 @@ __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float4* __restrict
     // more float4 of registers, in the one phase of the unit that has them to spare (no D2 / D3 yet).
     float4 a_n = eq[lane], b_n[PX];
 #pragma unroll
-    for (int m = 0; m < PX; ++m) b_n[m] = tEx[(m * (DD / 8)) * 64 + lane];
+    for (int m = 0; m < PX; ++m) b_n[m] = tEx[(m * (DD / 8)) * SS + lane];
 #pragma unroll
     for (int sc = 0; sc < DD / 8; ++sc) {
       const float4 a = a_n;
@@ -108,7 +111,7 @@ __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float4* __restrict
       if (sc + 1 < DD / 8) {
         a_n = eq[(sc + 1) * 64 + lane];
 #pragma unroll
-        for (int m = 0; m < PX; ++m) b_n[m] = tEx[(m * (DD / 8) + sc + 1) * 64 + lane];
+        for (int m = 0; m < PX; ++m) b_n[m] = tEx[(m * (DD / 8) + sc + 1) * SS + lane];
       }
       __builtin_amdgcn_sched_barrier(0);   // the requests stay above this chunk's MFMAs
 #pragma unroll
@@ -127,7 +130,7 @@ __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float4* __restrict
     const float4 a = eq[sc * 64 + lane];
 #pragma unroll
     for (int m = 0; m < PX; ++m) {
-      const float4 b = tEx[(m * (DD / 8) + sc) * 64 + lane];
+      const float4 b = tEx[(m * (DD / 8) + sc) * SS + lane];
       D1[m] = mfma32(a.x, b.x, D1[m]);
       D1[m] = mfma32(a.y, b.y, D1[m]);
       D1[m] = mfma32(a.z, b.z, D1[m]);
@@ -142,7 +145,7 @@ __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float4* __restrict
 
 // One query of the group: gate MLP (GEMM2 -> silu -> GEMM3), combine, softmax, mixture, on pre-scaled operands
 // (mol_layout.h).  The query's cl values sit in accumulator registers [R0, R0 + RPQ) of every D1 tile.
-template <class G, int PX, int R0>
+template <class G, int PX, int R0, int SS = 64>
 __device__ __forceinline__ float query_mlp(f32x16 (&D1)[PX], const float4* sW1, const float4* sW2, const float* sB1,
                                            const float* sB2, const float4* tGi, const float4* __restrict__ gq4,
                                            int lane, int hi, int combine_none) {
@@ -228,7 +231,7 @@ __device__ __forceinline__ float query_mlp(f32x16 (&D1)[PX], const float4* sW1, 
   if (combine_none) {
 #pragma unroll
     for (int ec = 0; ec < G::E / 4; ++ec) {
-      const float4 gi = tGi[ec * 64 + lane];
+      const float4 gi = tGi[ec * SS + lane];
       const float4 gq = gq4[ec];
       const float giv[4] = {gi.x, gi.y, gi.z, gi.w}, gqv[4] = {gq.x, gq.y, gq.z, gq.w};
 #pragma unroll
@@ -242,7 +245,7 @@ __device__ __forceinline__ float query_mlp(f32x16 (&D1)[PX], const float4* sW1, 
   } else {
 #pragma unroll
     for (int ec = 0; ec < G::E / 4; ++ec) {
-      const float4 gi = tGi[ec * 64 + lane];
+      const float4 gi = tGi[ec * SS + lane];
       const float4 gq = gq4[ec];
       const f32x2 giv[2] = {{gi.x, gi.y}, {gi.z, gi.w}};
       const f32x2 gqv[2] = {{gq.x, gq.y}, {gq.z, gq.w}};
@@ -276,8 +279,9 @@ __device__ __forceinline__ float query_mlp(f32x16 (&D1)[PX], const float4* sW1, 
   return (num * rden) / fmaxf(den * rden, 1e-6f);
 }
 
-// The exact-fp32 unit policy of the kernel shells (mol_score_shell.h).
-struct Fp32Unit {
+// The exact-fp32 unit policy of the kernel shells (mol_score_shell.h).  SS: see gemm1.
+template <int SS>
+struct Fp32UnitImpl {
   static constexpr bool kIndexedCandidates = true;   // the indexed-candidate instantiation of the direct shell is built (mol_score_shell.h)
   template <class G>
   static constexpr int kLdsWeightFloats = G::kWpackFloats;
@@ -285,7 +289,7 @@ struct Fp32Unit {
   static __device__ __forceinline__ void stage(const ScoreArgs& p, float* smem) { stage_weights<G, NW>(p, smem); }
   template <class G, int PX, int DD, bool BULK = false, int PIPE = 0>
   static __device__ __forceinline__ void gemm1(f32x16 (&D1)[PX], const float* __restrict__ eq, const float4* tEx, int lane) {
-    mol::gemm1<G, PX, DD, BULK, PIPE>(D1, reinterpret_cast<const float4*>(eq), tEx, lane);
+    mol::gemm1<G, PX, DD, BULK, PIPE, SS>(D1, reinterpret_cast<const float4*>(eq), tEx, lane);
   }
   // All queries of one unit, each at its own static register offset (no register rotation).
   // `only` >= 0 restricts the unit to that query (per-row candidates).
@@ -302,7 +306,7 @@ struct Fp32Unit {
             const int q = g * G::QT + Q;
             if (q < p.B && (only < 0 || q == only)) {
               const float4* gq4 = reinterpret_cast<const float4*>(p.gqfrag + (int64_t)q * G::L + hi * G::E);
-              const float out = query_mlp<G, PX, Q * G::RPQ>(D1, sW1, sW2, sB1, sB2, tGi, gq4, lane, hi, p.combine_none);
+              const float out = query_mlp<G, PX, Q * G::RPQ, SS>(D1, sW1, sW2, sB1, sB2, tGi, gq4, lane, hi, p.combine_none);
               const int64_t item = item0 + x;
               if (hi == 0 && item < p.n_items) p.logits[(int64_t)q * p.ld + item] = out;
             }
@@ -311,5 +315,7 @@ struct Fp32Unit {
     }(std::make_integer_sequence<int, G::QT>{});
   }
 };
+struct Fp32Unit : Fp32UnitImpl<64> {};       // operands in tile order (the index, gathered candidate tiles, LDS)
+struct Fp32UnitRows : Fp32UnitImpl<2> {};    // candidates read from the row-major copy of the index (mol_score_rows_kernel)
 
 }  // namespace mol

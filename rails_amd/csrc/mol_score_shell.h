@@ -18,6 +18,9 @@
 
 namespace mol {
 
+struct Fp32Unit;       // mol_score_fp32_unit.h: the exact-fp32 unit policy in tile order ...
+struct Fp32UnitRows;   // ... and with the row-major copy's slot stride (mol_score_rows_kernel)
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Gate pack -> LDS.  By LDS-DMA (1 KiB per wave-instruction, no registers, NOT waited for here): every shell passes a __syncthreads()
@@ -106,6 +109,46 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_direct_kernel(Score
     // K-chunk lookahead inside GEMM1, above.  An early touch of THIS tile's gate rows, read at the head of the epilogue, changed nothing
     // either: the epilogue's own request-ahead ring already covers them.)
     U::template queries<G, PX>(D1, p, g, row, tile * kTileItems, smem, tGi, lane, hi, x);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Kernel A' ("rows"): the INDEXED form of kernel A reading each candidate from the ROW-MAJOR copy of the index
+// (rails_mol_index_rows_build): lane (h, x) of a unit reads the float4 of slot s of ITS candidate at rows[i * RP + 2 s + h] -- the
+// candidate's RP float4 are consecutive, so its 128-byte lines are fetched from HBM once and used whole (in the tile-packed index every
+// one of the RP pieces sits in a line of its own: 8 x the bytes).  UR = the unit policy with slot stride 2 (Fp32UnitRows): same values,
+// same order, same bits as kernel A.  Per-row candidates only.
+// ---------------------------------------------------------------------------------------------
+template <class UR, int PQ, int PX, int DD, int H, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_rows_kernel(ScoreArgs p) {
+  using G = Geo<PQ, PX, DD, H>;
+  MOL_RUN_IF(p.run_if);
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  UR::template stage<G, NW>(p, smem);
+  __syncthreads();
+  constexpr int RP = G::kTileFloats / 4 / kTileItems;      // float4 per item
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int hi = lane >> 5, x = lane & 31;
+  const int64_t n_units = (int64_t)p.B * p.n_tiles;
+  const int64_t stride = (int64_t)gridDim.x * NW;
+  const int64_t rounds = n_units / stride;
+  const int64_t bx = (gridDim.x % 8 == 0) ? (int64_t)(blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : (int64_t)blockIdx.x;
+  for (int64_t it = 0; it <= rounds; ++it) {
+    const int64_t u = it < rounds ? it * stride + bx * NW + wave : rounds * stride + (int64_t)wave * gridDim.x + bx;
+    if (u >= n_units) break;
+    const int64_t row64 = u / p.n_tiles;
+    const int tile = (int)(u - row64 * p.n_tiles), row = (int)row64;
+    int col = tile * kTileItems + x;                                   // ragged last tile: the row's last candidate again, those columns are not stored
+    col = col < (int)p.n_items ? col : (int)p.n_items - 1;
+    int64_t src = p.cand_pos[(int64_t)row * p.n_items + col];
+    src = src < 0 ? 0 : (src >= p.index_items ? p.index_items - 1 : src);   // callers pass positions of the index; clamped for memory safety only
+    const float4* tEx = reinterpret_cast<const float4*>(p.irows) + src * RP + hi - lane;
+    const float4* tGi = tEx + 2 * (G::kTileExFloats / 256);            // the Ex slots, two float4 each
+    const float* eq = p.eqfrag + (int64_t)(row / G::QT) * G::kEqGroupFloats;
+    f32x16 D1[PX];
+    UR::template gemm1<G, PX, DD, false, 1>(D1, eq, tEx, lane);
+    UR::template queries<G, PX>(D1, p, row / G::QT, row, (int64_t)tile * kTileItems, smem, tGi, lane, hi, x);
   }
 }
 
@@ -278,6 +321,9 @@ static int launch_kernel(const ScoreArgs& a, int n_cu, hipStream_t stream) {
       return go(&mol_score_staged_kernel<U, PQ, PX, DD, H, NW>);
     } else {
       if constexpr (U::kIndexedCandidates && NW == 8) {
+        if constexpr (std::is_same_v<U, Fp32Unit>) {
+          if (a.cand_pos && a.irows) return go(&mol_score_rows_kernel<Fp32UnitRows, PQ, PX, DD, H, NW>);
+        }
         if (a.cand_pos) return go(&mol_score_direct_kernel<U, PQ, PX, DD, H, NW, true>);
       }
       if (a.cand_pos) { set_error("indexed candidates are built for the exact-fp32 kernels only"); return kErrUnsupported; }

@@ -301,6 +301,29 @@ class MolEngine:
             )
         return ex, gi
 
+    def build_index_rows(self, index: MolIndex) -> torch.Tensor:
+        """Row-major copy of an exact-fp32 index (include/rails_amd.h rails_mol_index_rows_build): what score_indexed_rows reads candidates from."""
+        floats = self.lib.rails_mol_index_rows_floats(C.byref(self.shape), index.n_items)
+        if floats == 0:
+            raise NotImplementedError("the row-major index copy exists for exact-fp32 indexes only")
+        rows = torch.empty(floats, dtype=torch.float32, device=index.buf.device)
+        with _on_device(index.buf.device):
+            _lib.check(self.lib.rails_mol_index_rows_build(C.byref(self.shape), _ptr(index.buf), index.n_items, _ptr(rows), _stream()), "rails_mol_index_rows_build")
+        return rows
+
+    def score_indexed_rows(self, qpack: torch.Tensor, batch: int, rows: torch.Tensor, n_items: int, positions: torch.Tensor) -> torch.Tensor:
+        """score_indexed with the candidates read from the row-major copy: whole cache lines per candidate, same bits."""
+        positions = positions.to(device=rows.device, dtype=torch.int64).contiguous()
+        n_cand = positions.shape[1]
+        out = torch.empty((batch, n_cand), dtype=torch.float32, device=rows.device)
+        with _on_device(rows.device):
+            _lib.check(
+                self.lib.rails_mol_score_indexed_rows(C.byref(self.shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(rows), n_items, _ptr(positions), n_cand,
+                                                      _ptr(out), out.stride(0), _stream()),
+                "rails_mol_score_indexed_rows",
+            )
+        return out
+
     def gather_index(self, index: MolIndex, cand_idx: torch.Tensor) -> Tuple[MolIndex, int]:
         """cand_idx: (rows, K) int64 positions -> per-row tile-packed index, K padded to a multiple of 32."""
         _require_device(cand_idx, "candidate indices")

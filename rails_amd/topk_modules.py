@@ -420,7 +420,7 @@ class MoLBruteForceTopK(MoLTopKModule):
             # (tools/indexed_rescore_probe.py, amzn-books, `f16-exact`): k' = 200  B = 8 / 32 / 128: 0.501 / 1.59 / 5.81 -> 0.494 /
             # 1.59 / 5.76 ms; k' = 2561: 0.631 / 1.93 / 6.88 -> 0.610 / 1.835 / 6.55 ms.  (Before the lookahead the in-place reads cost
             # more than the copy beyond B x Kc = 1024 candidates: B = 32 1.65 -> 1.69 ms; INDEXED_MAX_CANDIDATES keeps the switch.)
-            e32 = ex.score_indexed(qpack32, B, self._index32, pos)
+            e32 = self._rescore(ex, qpack32, B, pos)
         else:
             if self._index32 is not None:
                 cand, _ = ex.gather_index(self._index32, pos)
@@ -519,11 +519,7 @@ class MoLBruteForceTopK(MoLTopKModule):
             hook(1)
         ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(B, N, kc), torch.uint8)
         c16, pos = E.topk(s16, kc, workspace=ws)
-        if ex.score_indexed_supported(B, pos.shape[1]):
-            e32 = ex.score_indexed(qpack32, B, self._index32, pos)
-        else:                                      # (the 256-logit team kernel takes gathered tiles)
-            cand, _ = ex.gather_index(self._index32, pos)
-            e32 = ex.score_candidates(qpack32, B, cand, pos.shape[1])
+        e32 = self._rescore(ex, qpack32, B, pos)
         k_loc = min(k, kc)
         scores, ids, _, stats = E.rescore_select(e32, c16, pos, self._ids_flat, N, k_loc, approx_dense=s16, one_sided=upper is not None)
         m = c16[:, kc - 1] if kc < N else torch.full((B,), float("-inf"), dtype=torch.float32, device=dev)     # (views: the caller concatenates them into its message)
@@ -542,6 +538,19 @@ class MoLBruteForceTopK(MoLTopKModule):
         l32 = ex.score_dense(qpack32, batch, self._index32, out=self._buf("logits_fb", batch * N, torch.float32).view(batch, N), run_if=run_if)
         ws = self._buf("topk_ws2", E._lib.load().rails_topk_workspace_bytes(batch, N, min(k, N)), torch.uint8)
         E.topk(l32, min(k, N), ids=self._ids_flat, workspace=ws, out=out, run_if=run_if)
+
+    ROWS_COPY_MAX_BYTES = 8 << 30      # the row-major copy of the fp32 index is kept for indexes up to this size (0: never)
+    _rows32 = None
+
+    def _rescore(self, ex: E.MolEngine, qpack32: torch.Tensor, B: int, pos: torch.Tensor) -> torch.Tensor:
+        """fp32 logits of per-row candidates `pos` (positions of the resident fp32 index), whichever way is cheapest here -- same bits each way:
+        in place from the row-major copy, in place from the tile-packed index, or gathered tiles (the 256-logit team kernel)."""
+        if ex.score_indexed_supported(B, pos.shape[1]):
+            if self._rows32 is not None:
+                return ex.score_indexed_rows(qpack32, B, self._rows32, self._index32.n_items, pos)
+            return ex.score_indexed(qpack32, B, self._index32, pos)
+        cand, _ = ex.gather_index(self._index32, pos)
+        return ex.score_candidates(qpack32, B, cand, pos.shape[1])
 
     INDEXED_MAX_CANDIDATES = 1 << 30   # rails_mol_score_indexed instead of gather + score_candidates up to this many (B x Kc) candidates (was 1024)
     DEVICE_VERDICT = True     # False: the host reads the verdict (one event spin per call) -- kept for deployments without a resident fp32 index
@@ -862,6 +871,13 @@ class MoLBruteForceTopK(MoLTopKModule):
             self._index32_engine = eng.exact
             if self.keep_dense_fp32_index or free > 2 * need:
                 self._index32 = eng.exact.build_index(self._item_embeddings[0])
+            # ... and, where the candidates are re-scored in place and a third copy is small change (ROWS_COPY_MAX_BYTES), the same index
+            # row-major: a candidate's bytes then come in whole cache lines (score_indexed_rows: 8 x fewer bytes than the tile-packed reads)
+            self._rows32 = None
+            if (self._index32 is not None and self.ROWS_COPY_MAX_BYTES > 0 and need <= self.ROWS_COPY_MAX_BYTES and eng.exact.score_indexed_supported(32, 1024)):
+                free, _ = torch.cuda.mem_get_info(self._item_embeddings.device)
+                if free > 2 * need:
+                    self._rows32 = eng.exact.build_index_rows(self._index32)
         return eng
 
 def _verdicts_clear(pending: list) -> bool:

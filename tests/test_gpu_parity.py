@@ -1981,6 +1981,17 @@ def test_indexed_candidate_scoring_equals_gather_then_score(dev, cfg_name, N, B,
         assert got.shape == (B, n_cand) and torch.equal(got, want)
         dense = eng.score_dense(qpack, B, tk._index)
         assert torch.equal(got, torch.gather(dense, 1, pos))      # and both are the dense kernel's values at those positions
+        # the same candidates read from the ROW-MAJOR copy of the index (rails_mol_index_rows_build / rails_mol_score_indexed_rows): same bits;
+        # the copy holds item i's fragment slot s, lane half h as float4 number 2 s + h of row i
+        rows = eng.build_index_rows(tk._index)
+        tile_f4 = tk._index.buf.numel() // 4 // ((N + 31) // 32)
+        rp = tile_f4 // 32
+        assert rows.numel() == N * rp * 4
+        i = int(pos[0, 3])
+        packed = tk._index.buf.view(-1, 4)
+        for slot, h in ((0, 0), (1, 1), (tile_f4 // 64 - 1, 1)):
+            assert torch.equal(rows.view(-1, 4)[i * rp + 2 * slot + h], packed[(i >> 5) * tile_f4 + slot * 64 + h * 32 + (i & 31)])
+        assert torch.equal(eng.score_indexed_rows(qpack, B, rows, N, pos), got)
 
 
 @pytest.mark.gpu
