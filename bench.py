@@ -1003,10 +1003,10 @@ def main() -> None:
                 p_ids, p_scores = step_proved()
                 p_identical = bool(torch.equal(p_ids, ref_ids) and torch.equal(p_scores, ref_scores))
                 gc.collect()
-                # warm-up: W calls, then -- because a failed verdict doubles the candidate margin for the calls after it, and a shard's
-                # k'-th score sits in a denser part of the score distribution than the whole corpus' -- until two calls in a row were proved
-                # (at most 12 calls; every rank runs the same count: the fallback counter is max-reduced)
-                for _ in range(max(args.warmup, 2)):
+                # settle first: a failed verdict doubles the candidate margin for the calls after it, and a shard's k'-th score sits in a denser
+                # part of the score distribution than the whole corpus' -- calls until two in a row were proved (at most 12; every rank runs the
+                # same count: the fallback counter is max-reduced).  These calls read counters back (host syncs).
+                for _ in range(2):
                     step_proved()
                 for _ in range(6):
                     before = mod_stats()["fallbacks"]
@@ -1019,6 +1019,12 @@ def main() -> None:
                         break
                 mod_stats()
                 base_stats = dict(mod_stats())
+                # ... then the W warm-up steps, with nothing but the barrier + synchronize between them and the timed region: the f16 kernel
+                # loses its clocks within milliseconds of idle and takes ~8 steps to get them back (tools/r05_ramp_probe.py), so counters
+                # are read BEFORE the warm-up (the W calls are subtracted below) and not between warm-up and timing
+                n_warm = max(args.warmup, 0)
+                for _ in range(n_warm):
+                    step_proved()
                 if world > 1:
                     dist.barrier()
                 torch.cuda.synchronize()
@@ -1040,8 +1046,12 @@ def main() -> None:
                 st = mod_stats()
                 p_last_ids, p_last_scores = step_proved()
                 p_identical = p_identical and bool(torch.equal(p_last_ids, ref_ids) and torch.equal(p_last_scores, ref_scores))
-                timed_calls = st["calls"] - base_stats["calls"]
-                counts = torch.tensor([timed_calls, st.get("proved_calls", 0) - base_stats.get("proved_calls", 0), st["fallbacks"] - base_stats["fallbacks"],
+                # warm-up + timed calls since the snapshot; the timed ones are "all proved" only if every call since the snapshot was
+                since_calls = st["calls"] - base_stats["calls"]
+                since_proved = st.get("proved_calls", 0) - base_stats.get("proved_calls", 0)
+                timed_calls = since_calls - n_warm
+                timed_proved = args.steps if (since_proved == since_calls and timed_calls == args.steps) else max(0, min(since_proved - n_warm, timed_calls - (st["fallbacks"] - base_stats["fallbacks"])))
+                counts = torch.tensor([timed_calls, timed_proved, st["fallbacks"] - base_stats["fallbacks"],
                                        st.get("bound_violations", 0), int(p_identical)], dtype=torch.int64, device="cpu" if (world > 1 and test_backend) else dev)
                 if world > 1:          # every rank's shard must have been proved
                     dist.all_reduce(counts, op=dist.ReduceOp.SUM)
