@@ -150,9 +150,20 @@ def measurement_matrix(mol, X, ids, q, kw, inv, cfg, n_items: int, steps: int, d
                 kx = min(kx, n_items)
                 for _ in range(2):
                     cand.get_top_k_outputs(qx, kx, kwx, tk, invx, truncate_k_prime_to=trunc)
+                torch.cuda.synchronize()
+                t_est = time.perf_counter()
+                for _ in range(3):
+                    cand.get_top_k_outputs(qx, kx, kwx, tk, invx, truncate_k_prime_to=trunc)
+                torch.cuda.synchronize()
+                t_est = (time.perf_counter() - t_est) / 3
+                # ~30 ms of the same calls right before each timed region: the f16 kernels lose their clocks within milliseconds of idle and
+                # need ~20 ms of load to get them back (tools/r05_ramp_probe.py); these legs are shorter than that at small batches
+                n_warm = max(2, min(64, int(0.03 / max(t_est, 1e-5)) + 1))
                 dt, per = float("inf"), None
                 for _ in range(2):   # secondary points: the better of two timed regions (one-off stalls of 20-70 ms -- one step of one leg -- were seen in three runs out of three)
                     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+                    for _ in range(n_warm):
+                        cand.get_top_k_outputs(qx, kx, kwx, tk, invx, truncate_k_prime_to=trunc)
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
                     for i in range(steps):
