@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--precision", default=None, help="fp32 | f16x3 (default: RAILS_PRECISION or fp32)")
     ap.add_argument("--check-items", type=int, default=0, help="compare this many sampled columns with the CPU oracle")
+    ap.add_argument("--upper", action="store_true", help="precision f16x3: the UPPER first pass (rails_mol_score_dense_upper, the product's per-pair bound added to the logit)")
     args = ap.parse_args()
     variants = [v for v in args.variants.split(",")]
     cfg_key, N, _ = bench.WORKLOADS[args.workload]
@@ -55,6 +56,14 @@ def main():
         index = eng.build_index(X)
         qpack, _, _ = eng.query_pack(q, uid)
         outs, times = {}, {v: [] for v in variants}
+        score = eng.score_dense
+        if args.upper:
+            from rails_amd import f16x3_bound as FB
+
+            p_ = "_gating_fn._qi_partial_module."
+            poly = FB.upper_bound_poly(w[p_ + "1.weight"], w[p_ + "1.bias"], w[p_ + "3.weight"], w[p_ + "3.bias"], cfg.temperature, cfg.dot_product_dimension,
+                                       cfg.query_dot_product_groups, cfg.item_dot_product_groups)["poly"]
+            score = lambda qp, b, idx, out=None: eng.score_dense_upper(qp, b, idx, poly, out=out)      # noqa: E731
 
         def select(v):
             os.environ["RAILS_SCORE_VARIANT"] = v.rstrip("n")
@@ -62,7 +71,7 @@ def main():
 
         for v in variants:
             select(v)
-            outs[v] = eng.score_dense(qpack, args.batch, index).clone()
+            outs[v] = score(qpack, args.batch, index).clone()
         torch.cuda.synchronize()
         for _ in range(args.rounds):
             for v in variants:
@@ -70,7 +79,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.reps):
-                    eng.score_dense(qpack, args.batch, index, out=outs[v])
+                    score(qpack, args.batch, index, out=outs[v])
                 e1.record()
                 torch.cuda.synchronize()
                 times[v].append(e0.elapsed_time(e1) / args.reps)
