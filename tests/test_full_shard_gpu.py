@@ -175,9 +175,9 @@ def test_config5_shard_two_pass_properties(dev):
             es, ei = E.topk(logits, k, ids=at._ids_flat)
             cand_logits = torch.gather(logits, 1, fp[b0 : b0 + 8])
             ws, wi = E.topk(cand_logits, k, ids=at._ids_flat[fp[b0 : b0 + 8]])
-            assert float((ws - s[b0 : b0 + 8]).abs().max()) <= 2e-5      # candidate kernel vs dense kernel: summation order only
+            assert torch.equal(ws, s[b0 : b0 + 8])                        # the in-place candidate kernel and the dense kernel: one arithmetic, the same bits
             same = wi == i[b0 : b0 + 8]
-            assert float(same.float().mean()) >= 0.99                      # swaps inside groups of logits closer than that
+            assert float(same.float().mean()) >= 0.999                     # (exact ties only: this selection breaks them by slot in the candidate list, the module by corpus position)
             for r in range(8):
                 mine, truth = i[b0 + r].tolist(), ei[r].tolist()
                 hits10 += len(set(mine[:10]) & set(truth[:10]))
