@@ -164,7 +164,7 @@ class MoLBruteForceTopK(MoLTopKModule):
                                   # 1/tau and the bound is quadratic in it (_bound_kind "upper": 16x16x64 at random init, 3.0; trained weights of the other shapes)
     PAD_ONE_EPS = (824, 3)        # candidates beyond k: max(floor, per_k * k) (doubled after a failed verdict) -- under one eps ...
     PAD_PER_PAIR = (1848, 8)      # ... and under per-pair upper bounds (sized for a 12.5 M-item shard of 16x16x64: 730-900 items can reach the 200-th score)
-    PROVED_MIN_BATCH = 3          # smaller batches of the default mode run the dense fp32 kernels (see _forward_rescored)
+    PROVED_MIN_BATCH = 2          # a single query of the default mode runs the dense fp32 kernels (see _forward_rescored)
 
     def _engine_for_bind(self) -> E.MolEngine:
         mol = self._mol_module
@@ -281,8 +281,8 @@ class MoLBruteForceTopK(MoLTopKModule):
         if B * N * 4 > self.MAX_LOGIT_BYTES or not E.topk_filter_fusable(N, k_prime, invalid_ids.shape[1], k):
             return None
         if eng.exact is not None:
-            # the default mode's batches of one or two queries run the dense fp32 kernels (_forward_rescored): keep the filter fused into
-            # their selection launch as the plain fp32 module does (amzn-books B = 1: 0.36 -> 0.32 ms)
+            # the default mode's single-query batches run the dense fp32 kernels (_forward_rescored): keep the filter fused into their
+            # selection launch as the plain fp32 module does (amzn-books B = 1: 0.36 -> 0.32 ms)
             ex = eng.exact
             if not (B < self.PROVED_MIN_BATCH and self._mol_module.engine() is not eng and eng.dense_precision == "f16x3"
                     and self._index32 is not None and self._index32_engine is ex):
@@ -360,8 +360,8 @@ class MoLBruteForceTopK(MoLTopKModule):
             self.rescore_stats["unprovable_calls"] = self.rescore_stats.get("unprovable_calls", 0) + 1
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
         if eps_proved is not None and query_embeddings.size(0) < self.PROVED_MIN_BATCH and self._mol_module.engine() is not eng:
-            # one or two queries: the first pass saves ~0.08 ms per query against the dense fp32 kernels and the verification costs ~0.13 ms
-            # per call (amzn-books: 0.34 against 0.33 ms at B = 1) -- the default mode takes the dense kernels there (an explicit
+            # one query: the first pass saves ~0.1 ms against the dense fp32 kernels and the verification costs as much (amzn-books, B = 1:
+            # 0.327 against 0.324 ms; B = 2: 0.363 against 0.513) -- the default mode takes the dense kernels there (an explicit
             # "f16x3-exact" precision keeps speculating)
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
         if eps_proved is not None:

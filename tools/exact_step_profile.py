@@ -30,8 +30,11 @@ def main():
     ap.add_argument("--min-items", type=int, default=-1, help="override MoLBruteForceTopK.SPECULATE_MIN_ITEMS (where the proved flow starts)")
     ap.add_argument("--force-per-pair", action="store_true", help="proved rows: per-pair upper bounds even where one eps proves the calls (PROVED_MAX_EPS = 0)")
     ap.add_argument("--per-pair-pad", type=int, default=0, help="candidate floor beyond k under per-pair bounds (default: the module's 1848)")
+    ap.add_argument("--min-batch", type=int, default=0, help="override MoLBruteForceTopK.PROVED_MIN_BATCH (smallest batch the default mode speculates on)")
     ap.add_argument("--no-rows-copy", action="store_true", help="re-score the candidates from the tile-packed fp32 index (no row-major copy)")
     args = ap.parse_args()
+    if args.min_batch:
+        rails_amd.MoLBruteForceTopK.PROVED_MIN_BATCH = args.min_batch
     if args.no_rows_copy:
         rails_amd.MoLBruteForceTopK.ROWS_COPY_MAX_BYTES = 0
     if args.force_per_pair:
