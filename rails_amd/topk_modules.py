@@ -734,11 +734,12 @@ class MoLBruteForceTopK(MoLTopKModule):
     SAFETY_F16X3 = 8.0      # eps >= SAFETY x the running maximum of |s16 - s32| over the re-scored candidates and probes
     SAFETY_F16X1 = 3.0
 
-    # Speculation pays on large corpora only: below SPECULATE_MIN_ITEMS the fixed cost of the verification (~0.15 ms) exceeds what
-    # the faster first pass saves (ML-20M, 27 278 items: fp32 step 0.27 ms), so the exact modes run the dense fp32 kernels there.
+    # Speculation pays on large corpora only: below SPECULATE_MIN_ITEMS the fixed cost of the verification (~0.1 ms) exceeds what
+    # the faster first pass saves (ML-20M, 27 278 items: fp32 step 0.26 ms; amzn-books shape at 16 384 items: 0.19 against 0.21 ms of GPU time,
+    # at 32 768: 0.255 against 0.343 ms, at 49 152: 0.332 against 0.497), so the exact modes run the dense fp32 kernels there.
     # It also needs scores that are not crowded around the k-th place: when more than a quarter of the last 16 speculative calls
     # had to be redone, the next 256 calls go straight to the dense fp32 path, then speculation is tried again.
-    SPECULATE_MIN_ITEMS = 1 << 16
+    SPECULATE_MIN_ITEMS = 1 << 15
 
     def _speculation_paused(self) -> bool:
         if self._pause_left == 0 and len(self._recent) >= 16:
