@@ -238,7 +238,9 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
     GLOBAL_PROOF = True
 
     def _make_local_module(self, mol_module, item_embeddings_shard, item_ids_shard) -> TopKModule:
-        return MoLBruteForceTopK(mol_module, item_embeddings_shard, item_ids_shard)
+        # the size-dependent choices of the proved flow (one eps or per-pair bounds, candidate margins) are made for the SHARD size every rank
+        # computes alike -- the last shard may be shorter, and ranks must agree on the form of the bound
+        return MoLBruteForceTopK(mol_module, item_embeddings_shard, item_ids_shard, bound_kind_items=-(-self._n_total // max(self._world, 1)))
 
     # ---- collectives on small tensors (host-staged only on a gloo group: test setups) --------------------------------------------
     def _all_reduce(self, t: torch.Tensor, op) -> torch.Tensor:
@@ -319,7 +321,7 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
 
     def _kc_local(self, k: int) -> int:
         upper = self._local_module._upper_poly() is not None       # per-pair upper bounds: more items can reach the k-th score (topk_modules._forward_rescored)
-        floor, per_k = MoLBruteForceTopK.PAD_PER_PAIR if upper else MoLBruteForceTopK.PAD_ONE_EPS
+        floor, per_k = self._local_module._per_pair_pad() if upper else MoLBruteForceTopK.PAD_ONE_EPS
         total = k + max(floor, per_k * k) * self._gp_pad
         per = -(-total // self._world)
         kc = per + int(4.0 * per ** 0.5) + 32

@@ -120,8 +120,12 @@ class MoLTopKModule(TopKModule):
 
 
 class MoLBruteForceTopK(MoLTopKModule):
-    def __init__(self, mol_module: MoLSimilarity, item_embeddings: torch.Tensor, item_ids: torch.Tensor, exact_mode: Optional[str] = None) -> None:
-        """exact_mode (not in the reference's signature, rails/indexing/mol_top_k.py:84-97): "proved" | "dense", default EXACT_MODE."""
+    def __init__(self, mol_module: MoLSimilarity, item_embeddings: torch.Tensor, item_ids: torch.Tensor, exact_mode: Optional[str] = None,
+                 bound_kind_items: Optional[int] = None) -> None:
+        """exact_mode (not in the reference's signature, rails/indexing/mol_top_k.py:84-97): "proved" | "dense", default EXACT_MODE.
+        bound_kind_items: the corpus size the proved flow's size-dependent choices are made for (the item-sharded wrapper passes the shard size
+        every rank computes alike); default: this module's own corpus."""
+        self.bound_kind_items = bound_kind_items
         if exact_mode not in (None, "proved", "dense"):
             raise ValueError(f"exact_mode must be 'proved' or 'dense', got {exact_mode!r}")
         self._index32: Optional[E.MolIndex] = None          # precision "f16x3-exact": dense fp32 index (candidate gather, fallback)
@@ -164,6 +168,13 @@ class MoLBruteForceTopK(MoLTopKModule):
                                   # 1/tau and the bound is quadratic in it (_bound_kind "upper": 16x16x64 at random init, 3.0; trained weights of the other shapes)
     PAD_ONE_EPS = (824, 3)        # candidates beyond k: max(floor, per_k * k) (doubled after a failed verdict) -- under one eps ...
     PAD_PER_PAIR = (1848, 8)      # ... and under per-pair upper bounds (sized for a 12.5 M-item shard of 16x16x64: 730-900 items can reach the 200-th score)
+    # Corpora up to PER_PAIR_MAX_ITEMS items take the per-pair form whatever their one eps is: their first pass is short, so the UPPER build's extra
+    # work costs microseconds, and the tighter bound proves with half the candidates (kc = 512 at k' = 200: a cheaper selection, half the re-scoring).
+    # amzn-books shape, proved step per-pair / one eps: 20 k items 0.173 / 0.195 ms, 32 k 0.219 / 0.255, 65 k 0.350 / 0.368, 131 k 0.590 / 0.603
+    # (695 k: 2.85 / 2.74 -- one eps wins there); ML-20M (27 278 items), which one eps cannot prove at all: 0.179 ms against 0.239 dense.
+    PER_PAIR_MAX_ITEMS = 196608
+    PAD_PER_PAIR_SMALL = (312, 1)
+    bound_kind_items: Optional[int] = None
     PROVED_MIN_BATCH = 2          # a single query of the default mode runs the dense fp32 kernels (see _forward_rescored)
 
     def _engine_for_bind(self) -> E.MolEngine:
@@ -219,11 +230,20 @@ class MoLBruteForceTopK(MoLTopKModule):
                    (f16x3_bound.upper_bound_poly, rails_mol_score_dense_upper): where one eps is too coarse and the shape has the kernel;
           None     neither (infinite bound, or too coarse without the kernel): the module runs the dense fp32 kernels."""
         eps = self._bound_from_weights(spec).get("eps", math.inf)
+        small = self._policy_items() <= self.PER_PAIR_MAX_ITEMS
+        if (eps > self.PROVED_MAX_EPS or small) and eps <= self.PROVED_MAX_EPS_PER_PAIR and lib.rails_mol_score_dense_upper_supported(E.C.byref(spec.to_c("f16x3"))):
+            return "upper"
         if eps <= self.PROVED_MAX_EPS:
             return "eps"
-        if eps <= self.PROVED_MAX_EPS_PER_PAIR and lib.rails_mol_score_dense_upper_supported(E.C.byref(spec.to_c("f16x3"))):
-            return "upper"
         return None
+
+    def _policy_items(self) -> int:
+        """The corpus size the size-dependent choices of the proved flow are made for: this module's own, or -- set by the item-sharded wrapper,
+        the same on every rank -- the shard size (ranks must agree on the form of the bound)."""
+        return int(self.bound_kind_items or self._item_embeddings.shape[1])
+
+    def _per_pair_pad(self) -> Tuple[int, int]:
+        return self.PAD_PER_PAIR_SMALL if self._policy_items() <= self.PER_PAIR_MAX_ITEMS else self.PAD_PER_PAIR
 
     def _upper_poly(self) -> Optional[Tuple[float, float, float]]:
         """(ub2, ub1, ub0) when the bound engine's first pass writes per-pair UPPER BOUNDS of the fp32 logits (_bound_kind "upper"), else None."""
@@ -369,7 +389,7 @@ class MoLBruteForceTopK(MoLTopKModule):
             # 6 000-7 500 at k = 2 561 (128 queries; profiles/r05_proved_candidate_census.json); rails_topk costs the same 80-90 us from
             # 544 to 1 536 candidates per row of 700 k scores, so the margin starts generous.  A failed verdict doubles it
             # (per-pair upper bounds on a 12.5 M-item shard of 16x16x64: 730-900 items can reach the 200-th score; tools/r05_c4_census.py)
-            floor, per_k = self.PAD_PER_PAIR if upper is not None else self.PAD_ONE_EPS
+            floor, per_k = self._per_pair_pad() if upper is not None else self.PAD_ONE_EPS
             pad = max(floor, per_k * k) * self._pad_scale
             kc = min((k + pad + E.TILE_ITEMS - 1) // E.TILE_ITEMS * E.TILE_ITEMS, 16384)
         else:
@@ -736,10 +756,10 @@ class MoLBruteForceTopK(MoLTopKModule):
 
     # Speculation pays on large corpora only: below SPECULATE_MIN_ITEMS the fixed cost of the verification (~0.1 ms) exceeds what
     # the faster first pass saves (ML-20M, 27 278 items: fp32 step 0.26 ms; amzn-books shape at 16 384 items: 0.19 against 0.21 ms of GPU time,
-    # at 32 768: 0.255 against 0.343 ms, at 49 152: 0.332 against 0.497), so the exact modes run the dense fp32 kernels there.
+    # at 20 000: 0.173 with per-pair bounds, at 32 768: 0.219 against 0.343 ms), so the exact modes run the dense fp32 kernels there.
     # It also needs scores that are not crowded around the k-th place: when more than a quarter of the last 16 speculative calls
     # had to be redone, the next 256 calls go straight to the dense fp32 path, then speculation is tried again.
-    SPECULATE_MIN_ITEMS = 1 << 15
+    SPECULATE_MIN_ITEMS = 1 << 14
 
     def _speculation_paused(self) -> bool:
         if self._pause_left == 0 and len(self._recent) >= 16:
