@@ -537,23 +537,18 @@ struct F16Unit {
     const bool lane_stores = hi == 0 && item < p.n_items;
     // rows past the batch end (padding of the last group) run on zero operands and the last real gate row; never stored
     auto gq_of = [&](int q) { return p.gqfrag + (int64_t)(q < p.B ? q : p.B - 1) * G::L + hi * G::E; };
-    // UPPER: accumulator registers [Q RPQ, (Q + 1) RPQ) of every D1[m] are query Q's logits of item x (rows (r & 3) + 8 (r >> 2) + 4 hi);
-    // the two lane halves hold the two halves of the row set
-    [[maybe_unused]] float cmax[G::QT];
-    if constexpr (UPPER) {
-      static_for<G::QT>([&](auto qc) {
+    // UPPER: accumulator registers [Q RPQ, (Q + 1) RPQ) of every D1[m] are query Q's logits of item x (rows (r & 3) + 8 (r >> 2) + 4 hi); the two
+    // lane halves hold the two halves of the row set.  The maximum is folded where the query's logit is stored (D1 lives that long anyway):
+    // nothing extra stays live across the unit
+    auto store = [&](auto qc, int q, float out) {
+      if constexpr (UPPER) {
         constexpr int Q = decltype(qc)::value;
         float c = 0.0f;
 #pragma unroll
         for (int m = 0; m < PX; ++m)
 #pragma unroll
           for (int r = 0; r < G::RPQ; ++r) c = fmaxf(c, fabsf(D1[m][Q * G::RPQ + r]));
-        cmax[Q] = fmaxf(c, __shfl_xor(c, 32, 64));
-      });
-    }
-    auto store = [&](auto qc, int q, float out) {
-      if constexpr (UPPER) {
-        const float c = cmax[decltype(qc)::value];
+        c = fmaxf(c, __shfl_xor(c, 32, 64));
         out += __builtin_fmaf(__builtin_fmaf(p.ub2, c, p.ub1), c, p.ub0);
       }
       if (lane_stores && q < p.B) p.logits[(int64_t)q * p.ld + item] = out;
