@@ -171,7 +171,7 @@ class MoLBruteForceTopK(MoLTopKModule):
     # Corpora up to PER_PAIR_MAX_ITEMS items take the per-pair form whatever their one eps is: their first pass is short, so the UPPER build's extra
     # work costs microseconds, and the tighter bound proves with half the candidates (kc = 512 at k' = 200: a cheaper selection, half the re-scoring).
     # amzn-books shape, proved step per-pair / one eps: 20 k items 0.173 / 0.195 ms, 32 k 0.219 / 0.255, 65 k 0.350 / 0.368, 131 k 0.590 / 0.603
-    # (695 k: 2.85 / 2.74 -- one eps wins there); ML-20M (27 278 items), which one eps cannot prove at all: 0.179 ms against 0.239 dense.
+    # (695 k: 2.80 / 2.75 -- one eps wins there); ML-20M (27 278 items), which one eps cannot prove at all: 0.179 ms against 0.239 dense.
     PER_PAIR_MAX_ITEMS = 196608
     PAD_PER_PAIR_SMALL = (312, 1)
     bound_kind_items: Optional[int] = None
