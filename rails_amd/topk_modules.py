@@ -167,7 +167,8 @@ class MoLBruteForceTopK(MoLTopKModule):
     PROVED_MAX_EPS_PER_PAIR = 8.0 # ... up to this eps (at the a-priori |cl| <= 1/tau) the bound is applied PER PAIR instead: the pairs of a corpus sit at a third of
                                   # 1/tau and the bound is quadratic in it (_bound_kind "upper": 16x16x64 at random init, 3.0; trained weights of the other shapes)
     PAD_ONE_EPS = (824, 3)        # candidates beyond k: max(floor, per_k * k) (doubled after a failed verdict) -- under one eps ...
-    PAD_PER_PAIR = (1848, 8)      # ... and under per-pair upper bounds (sized for a 12.5 M-item shard of 16x16x64: 730-900 items can reach the 200-th score)
+    PAD_PER_PAIR = (1848, 1)      # ... and under per-pair upper bounds (sized for a 12.5 M-item shard of 16x16x64: 730-900 items can reach the 200-th score;
+                                  # amzn-books at k' = 2 561: 5 152 candidates prove every call where one eps needs 10 272)
     # Corpora up to PER_PAIR_MAX_ITEMS items take the per-pair form whatever their one eps is: their first pass is short, so the UPPER build's extra
     # work costs microseconds, and the tighter bound proves with half the candidates (kc = 512 at k' = 200: a cheaper selection, half the re-scoring).
     # amzn-books shape, proved step per-pair / one eps: 20 k items 0.173 / 0.195 ms, 32 k 0.219 / 0.255, 65 k 0.350 / 0.368, 131 k 0.590 / 0.603
@@ -245,14 +246,24 @@ class MoLBruteForceTopK(MoLTopKModule):
     def _per_pair_pad(self) -> Tuple[int, int]:
         return self.PAD_PER_PAIR_SMALL if self._policy_items() <= self.PER_PAIR_MAX_ITEMS else self.PAD_PER_PAIR
 
-    def _upper_poly(self) -> Optional[Tuple[float, float, float]]:
-        """(ub2, ub1, ub0) when the bound engine's first pass writes per-pair UPPER BOUNDS of the fp32 logits (_bound_kind "upper"), else None."""
+    def _upper_poly(self, k: Optional[int] = None) -> Optional[Tuple[float, float, float]]:
+        """(ub2, ub1, ub0) when the bound engine's first pass writes per-pair UPPER BOUNDS of the fp32 logits (_bound_kind "upper"), else None.
+        With k: also for a CALL of an engine whose form is the one eps, when the call wants PER_PAIR_MIN_K results or more -- the candidates a
+        large k needs under one eps (k' = 2 561 on amzn-books: 10 272) cost more to re-score and sort than the UPPER build adds to the first pass
+        (3.19 -> 2.9 ms per batch); the verdict of such a call runs with eps = 0 on the same state."""
         eng = self._engine
         c = self._upper_poly_cache
-        if c is not None and c[0] is eng:
+        if c is None or c[0] is not eng:
+            c = self._upper_poly_fill(eng)
+        if c[1] is not None or k is None or k < self.PER_PAIR_MIN_K:
             return c[1]
-        poly = None
-        if eng.exact is not None and eng.dense_precision == "f16x3" and self._bound_kind(eng.spec, eng.lib) == "upper":
+        return c[2]
+
+    def _upper_poly_fill(self, eng):
+        """-> (engine, the polynomial if the engine's form is per-pair, the polynomial if the shape has the UPPER build at all)"""
+        poly = any_poly = None
+        kind = self._bound_kind(eng.spec, eng.lib) if (eng.exact is not None and eng.dense_precision == "f16x3") else None
+        if kind is not None and eng.score_dense_upper_supported() and self._bound_from_weights(eng.spec).get("eps", math.inf) <= self.PROVED_MAX_EPS_PER_PAIR:
             from . import f16x3_bound as FB
 
             lin = [m for m in self._mol_module._gating_fn._qi_partial_module.modules() if isinstance(m, torch.nn.Linear)]
@@ -261,11 +272,14 @@ class MoLBruteForceTopK(MoLTopKModule):
             res = FB.upper_bound_poly(lin[0].weight, lin[0].bias if lin[0].bias is not None else zeros(lin[0].out_features), lin[1].weight,
                                       lin[1].bias if lin[1].bias is not None else zeros(lin[1].out_features), sp.temperature, sp.dot_product_dimension,
                                       sp.query_dot_product_groups, sp.item_dot_product_groups)
-            poly = res["poly"]
+            any_poly = res["poly"]
             self._upper_poly_info = res
-        self._upper_poly_cache = (eng, poly)
-        return poly
+            if kind == "upper":
+                poly = any_poly
+        self._upper_poly_cache = (eng, poly, any_poly)
+        return self._upper_poly_cache
 
+    PER_PAIR_MIN_K = 1024         # calls for at least this many results take per-pair bounds whatever the engine's form (see _upper_poly)
     _upper_poly_cache = None
     _upper_poly_info = None
 
@@ -375,7 +389,9 @@ class MoLBruteForceTopK(MoLTopKModule):
         # return the dense fp32 result whenever its verdict clears); monitored and empirical for the one-product first pass, whose a-priori
         # bound is vacuous.  A module whose a-priori bound is infinite (a guard fails) does not speculate.
         eps_proved = None if single else self._proved_eps()
-        upper = None if single else self._upper_poly()          # per-pair upper bounds instead of one eps (then eps_proved == 0)
+        upper = None if single else self._upper_poly(k)         # per-pair upper bounds instead of one eps (then the verdict's eps is 0)
+        if upper is not None and eps_proved is not None and math.isfinite(eps_proved) and self._upper_poly() is None:
+            eps_proved = 0.0          # a large-k call of an engine whose own form is the one eps
         if eps_proved is not None and not math.isfinite(eps_proved):
             self.rescore_stats["unprovable_calls"] = self.rescore_stats.get("unprovable_calls", 0) + 1
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
