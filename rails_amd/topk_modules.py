@@ -114,9 +114,31 @@ class MoLTopKModule(TopKModule):
         the f16 builds, which have no indexed instantiation, gather a per-row index of the candidates first."""
         K = positions.shape[1]
         if eng.score_indexed_supported(batch, K):
+            rows = self._index_rows(eng)
+            if rows is not None:           # the row-major copy: a candidate's bytes in whole cache lines (half the time of the tile-packed reads; same bits)
+                return eng.score_indexed_rows(qpack, batch, rows, self._index.n_items, positions)
             return eng.score_indexed(qpack, batch, self._index, positions)   # any K: the kernel masks the ragged last tile
         cand, kp = eng.gather_index(self._index, positions)
         return eng.score_candidates(qpack, batch, cand, kp)[:, :K]
+
+
+    RERANK_ROWS_COPY_MAX_BYTES = 8 << 30     # fp32 indexes up to this size get a row-major copy for the candidate re-scoring of the rerank paths (0: never)
+    _rows_cache = None
+
+    def _index_rows(self, eng) -> Optional[torch.Tensor]:
+        """The row-major copy of this module's fp32 index (rails_mol_index_rows_build), built at the first rerank; None where it does not apply
+        (f16 index formats, indexes beyond RERANK_ROWS_COPY_MAX_BYTES -- a 125 M-item shard -- or too little free memory)."""
+        c = self._rows_cache
+        if c is not None and c[0] is eng and c[1] is self._index:
+            return c[2]
+        rows = None
+        need = self._index.buf.numel() * 4
+        if getattr(eng, "precision", None) == "fp32" and self._index.buf.is_cuda and 0 < need <= self.RERANK_ROWS_COPY_MAX_BYTES:
+            free, _ = torch.cuda.mem_get_info(self._index.buf.device)
+            if free > 2 * need:
+                rows = eng.build_index_rows(self._index)
+        self._rows_cache = (eng, self._index, rows)
+        return rows
 
 
 class MoLBruteForceTopK(MoLTopKModule):

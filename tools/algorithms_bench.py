@@ -23,7 +23,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--workload", default="amzn-books", choices=sorted(ALGOS))
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--algorithms", default="")
+ap.add_argument("--no-rows-copy", action="store_true", help="rerank from the tile-packed fp32 index (no row-major copy)")
 a = ap.parse_args()
+if a.no_rows_copy:
+    rails_amd.MoLBruteForceTopK.ROWS_COPY_MAX_BYTES = 0
+    rails_amd.MoLBruteForceTopK.RERANK_ROWS_COPY_MAX_BYTES = 0
+    for cls_name in ("MoLAvgTopK", "MoLNaiveTopK", "MoLCombTopK"):
+        getattr(rails_amd, cls_name).RERANK_ROWS_COPY_MAX_BYTES = 0
 dev = torch.device("cuda:0")
 cfg_key, N, width = bench.WORKLOADS[a.workload]
 cfg = O.CONFIGS[cfg_key]
