@@ -34,9 +34,11 @@ extern "C" {
  * honour it and the per-thread rails_set_run_predicate is gone -- the library keeps no state between calls but the last error;
  * 6: rails_mol_coarse_topk gained its out_of_range output and its optional int8 pre-filter (rails_mol_coarse_prefilter_*),
  * rails_topk_candidates is new, rails_mol_score_indexed takes any n_cand; 7: rails_rescore_verdict gained its guard arguments and state[7], the rails_*_probe_* entry points are new, and rails_mol_score_topk / _survivors / rails_select_survivors -- the selection fused into the scoring kernels, 0.9 % slower than the dense kernels + rails_topk wherever it was measured -- are gone;
- * 8: rails_mol_score_dense_upper[_supported] and rails_mol_index_rows_* / rails_mol_score_indexed_rows are new, rails_rescore_select gained one_sided).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
+ * 8: rails_mol_score_dense_upper[_supported] and rails_mol_index_rows_* / rails_mol_score_indexed_rows are new, rails_rescore_select gained one_sided;
+ * 9: rails_candidates_* -- the threshold selection and the fused finish of the proved exact top-k -- and rails_merge_candidates_verdict
+ * are new, rails_mol_score_indexed_rows gained cand_counts).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
  * against an older header pass shorter structs, and the library would read the new fields from whatever follows them. */
-#define RAILS_ABI_VERSION 8
+#define RAILS_ABI_VERSION 9
 int rails_abi_version(void);
 
 #define RAILS_OK 0
@@ -212,8 +214,11 @@ int rails_mol_score_indexed_supported(const rails_mol_shape* shape, int32_t batc
  * use rails_mol_score_indexed). */
 size_t rails_mol_index_rows_floats(const rails_mol_shape* shape, int64_t n_items);
 int rails_mol_index_rows_build(const rails_mol_shape* shape, const float* index, int64_t n_items, float* index_rows, void* stream);
+/* cand_counts (optional, may be NULL): row b has cand_counts[b] <= n_cand candidates (rails_candidates_select's counts): only logits[b][0 .. cand_counts[b])
+ * are written, the tiles past them are skipped. */
 int rails_mol_score_indexed_rows(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack, int32_t batch, const float* index_rows,
-                                 int64_t n_items, const int64_t* positions, int64_t n_cand, float* logits, int64_t ld, void* stream);
+                                 int64_t n_items, const int64_t* positions, int64_t n_cand, float* logits, int64_t ld, const int32_t* cand_counts,
+                                 void* stream);
 int rails_mol_score_indexed(const rails_mol_shape* shape, const float* gate_pack, const float* query_pack, int32_t batch, const float* index,
                             int64_t n_items, const int64_t* positions, int64_t n_cand, float* logits, int64_t ld, void* stream);
 
@@ -342,6 +347,19 @@ int rails_merge_candidates_filtered(const int64_t* gathered, int32_t n_ranks, in
                                     const int64_t* invalid_ids, int32_t width, int32_t k_out, int64_t* out_ids, float* out_scores,
                                     void* stream);
 
+/* rails_merge_candidates[_filtered] over the 2k + 2 wide messages of rails_candidates_finish's sharded form ([k score words | k ids | m | err] per
+ * row and rank) WITH the global verdict of the item-sharded proved top-k in the same launch: row b is proved iff no rank reported a bad row
+ * (err = inf), every guard value is within guard_limit, and  merged k_out-th score - max over ranks of m > eps  (eps as in rails_candidates_finish).
+ * The last workgroup folds the rows into `state` (rails_rescore_verdict's layout) and mirrors it into state_host (optional, pinned host memory;
+ * state_host[5], the call counter, is written last).  call_ws: 8 uint32 in device memory, zeroed once by the caller (left zeroed by every call).
+ * Every rank computes the same verdict from the same gathered bytes, so the ranks agree on a redo without another exchange.
+ * invalid_ids == NULL: (out_scores, out_ids) are (rows, k_out); else the seen-id filter runs inside the launch and they are (rows, f_k).
+ * No counterpart in the reference (single-GPU eval: eval_from_checkpoint.py:554-555). */
+int rails_merge_candidates_verdict(const int64_t* gathered, int32_t n_ranks, int32_t rows, int32_t k, int32_t k_out, float default_eps, float safety,
+                                   const float* guard_values, int32_t guard_per_row, float guard_limit, float* state, float* state_host,
+                                   void* call_ws, const int64_t* invalid_ids, int32_t width, int32_t f_k, int64_t* out_ids, float* out_scores,
+                                   void* stream);
+
 /* Finish of a speculate-then-verify brute-force top-k (precision "f16x3-exact"; no counterpart in the reference, whose
  * MoLBruteForceTopK scores everything in one precision, mol_top_k.py:84-130).  Per row: n_cand entries with their exact fp32
  * logits (row stride ld) and corpus positions (< n_items <= 2^32).  The first n_ranked are the candidates: the top n_ranked items
@@ -384,6 +402,41 @@ int rails_rescore_select(const float* exact_scores, int64_t ld, const float* app
                          const int64_t* positions, const int64_t* ids, int64_t n_items, int32_t rows, int32_t n_ranked, int32_t n_cand,
                          int32_t k, float margin_eps, float check_eps, int32_t one_sided, float* out_scores, int64_t* out_ids, int32_t* row_ok,
                          float* row_stats, void* stream);
+
+/* ---- candidates of the proved exact top-k: threshold selection and fused finish (round 6) -------------------------------------------
+ * No counterpart in the reference (its MoLBruteForceTopK scores every item in one precision and calls torch.topk,
+ * rails/indexing/mol_top_k.py:99-130; the seen-id filter fused below is indexing/candidate_index.py:149-175).  The speculate-then-verify
+ * flow needs, per row, a candidate SET C and a value m such that every item outside C has a first-pass score <= m -- not the exact kc
+ * best.  rails_candidates_select takes a threshold: with b(s) = the bin of score s among 4 096 equal bins of [lo, hi] (scores outside are
+ * clamped; b is monotone), C = {x : b(s_x) >= b_t} for the LOWEST bin b_t that leaves at most `cap` candidates, and m = min over C of s.
+ * One histogram launch + one compaction launch (rows of <= 65 536 scores: one launch), against the ten launches of an exact rails_topk
+ * with k = kc.
+ *   workspace: rails_candidates_workspace_bytes(rows) bytes, ZEROED ONCE by the caller; every select + finish pair leaves it zeroed.  Its
+ *              first `rows` int32 are the rows' candidate counts between the two calls (rails_mol_score_indexed_rows' cand_counts).
+ *   out_positions (rows, cand_ld) int64 / out_approx (rows, cand_ld) float: the candidates (in no particular order) and their first-pass
+ *              scores; cand_ld >= cap; cap <= 16384; n < 2^32.  A NaN score raises the row's flag (the finish then fails the row).
+ * rails_candidates_finish, one workgroup per row: the row's candidates sorted by (exact fp32 score desc, position asc) -- the dense
+ * path's total order -- and the best k written as (out_scores, out_ids = ids[position] or the position when ids is NULL); the row FAILS
+ * unless it has >= k candidates, no NaN, every guard value within guard_limit, and  k-th exact score - m > eps  with eps = max(default_eps,
+ * safety * largest |exact - approx| seen so far (state[0]) or on this row)  -- then no item outside the candidates can belong to the row's
+ * top k given |approx - exact| <= eps everywhere (one_sided != 0: approx are UPPER bounds of the exact scores, the monitored error is
+ * max(0, exact - approx), default_eps = 0 is the proof).  A row whose candidates are all n_items items passes on that alone.
+ * The last workgroup folds the rows into `state` (rails_rescore_verdict's layout; state[1] = the REDO flag, the launch predicate of the
+ * caller's fallback) and mirrors it into state_host (optional; PINNED HOST memory mapped into the device: the words first, state_host[5],
+ * the call counter the host polls, last -- no copy launch).  guard: rows x guard_per_row floats (the batch's prescaled query-gate rows).
+ * invalid_ids != NULL: the seen-id filter of the candidate index over the k winners inside the same launch -> f_out_ids / f_out_scores
+ * (rows, f_k); k <= 512, width <= 256.
+ * msg != NULL (item-sharded form, rails_amd/sharded.py): instead of outputs and verdict, row b of msg (rows, 2k + 2) int64 receives
+ * [k score words | k ids | m | largest error (inf: the row is bad)] -- short rows padded with (-inf, -1) -- for ONE all-gather; the verdict
+ * is rails_merge_candidates_verdict's, after the merge. */
+size_t rails_candidates_workspace_bytes(int32_t rows);
+int rails_candidates_select(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t cap, float lo, float hi, void* workspace,
+                            int64_t* out_positions, float* out_approx, int64_t cand_ld, void* stream);
+int rails_candidates_finish(const float* exact_scores, int64_t ld, const float* approx, const int64_t* positions, int64_t cand_ld, int32_t cap,
+                            void* workspace, const int64_t* ids, int64_t n_items, int32_t rows, int32_t k, float default_eps, float safety,
+                            int32_t one_sided, const float* guard_values, int32_t guard_per_row, float guard_limit, float* out_scores,
+                            int64_t* out_ids, const int64_t* invalid_ids, int32_t width, int32_t f_k, int64_t* f_out_ids, float* f_out_scores,
+                            float* state, float* state_host, int64_t* msg, void* stream);
 
 /* ---- arithmetic-model probes (test infrastructure of the proved exact top-k; no counterpart in the reference) -------------------------
  * The a-priori bound on |first pass - fp32 logit| (rails_amd/f16x3_bound.py) models the two matrix instructions and the two

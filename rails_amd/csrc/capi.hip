@@ -340,7 +340,8 @@ int rails_mol_index_rows_build(const rails_mol_shape* s, const float* index, int
 }
 
 int rails_mol_score_indexed_rows(const rails_mol_shape* s, const float* gate_pack, const float* query_pack, int32_t batch, const float* index_rows,
-                                 int64_t n_items, const int64_t* positions, int64_t n_cand, float* logits, int64_t ld, void* stream) {
+                                 int64_t n_items, const int64_t* positions, int64_t n_cand, float* logits, int64_t ld, const int32_t* cand_counts,
+                                 void* stream) {
   g_err[0] = '\0';
   if (!shape_supported(s)) return RAILS_ENOTSUP;
   if (batch < 0 || n_items <= 0 || n_cand < 0) { set_error("score_indexed_rows: bad size"); return RAILS_EINVAL; }
@@ -355,6 +356,7 @@ int rails_mol_score_indexed_rows(const rails_mol_shape* s, const float* gate_pac
   a.cand_pos = positions;
   a.index_items = n_items;
   a.irows = index_rows;
+  a.cand_count = cand_counts;
   const int r = score_launch(*s, a, cu, (hipStream_t)stream);
   return r == kOk ? r : fail(r, "score_indexed_rows");
 }
@@ -620,6 +622,26 @@ int rails_merge_candidates_filtered(const int64_t* gathered, int32_t n_ranks, in
   return r == kOk ? r : fail(r, "merge_candidates_filtered");
 }
 
+int rails_merge_candidates_verdict(const int64_t* gathered, int32_t n_ranks, int32_t rows, int32_t k, int32_t k_out, float default_eps, float safety,
+                                   const float* guard_values, int32_t guard_per_row, float guard_limit, float* state, float* state_host,
+                                   void* call_ws, const int64_t* invalid_ids, int32_t width, int32_t f_k, int64_t* out_ids, float* out_scores,
+                                   void* stream) {
+  g_err[0] = '\0';
+  if (n_ranks <= 0 || rows < 0 || k <= 0 || k_out <= 0 || (int64_t)k_out > (int64_t)n_ranks * k || width < 0 || !(default_eps >= 0.0f) || !(safety >= 0.0f)) {
+    set_error("merge_candidates_verdict: bad size");
+    return RAILS_EINVAL;
+  }
+  if (rows == 0) return RAILS_OK;
+  if (!gathered || !out_scores || !out_ids || !state || !call_ws || (guard_values && (guard_per_row <= 0 || !(guard_limit >= 0.0f))) ||
+      (invalid_ids && (f_k <= 0 || f_k > k_out))) {
+    set_error("merge_candidates_verdict: bad argument");
+    return RAILS_EINVAL;
+  }
+  MergeVerdict v{default_eps, safety, guard_values, guard_per_row, guard_limit, state, state_host, static_cast<unsigned int*>(call_ws)};
+  const int r = merge_candidates(gathered, n_ranks, rows, k, k_out, out_scores, out_ids, (hipStream_t)stream, invalid_ids, width, f_k, &v);
+  return r == kOk ? r : fail(r, "merge_candidates_verdict");
+}
+
 int rails_abi_version(void) { return RAILS_ABI_VERSION; }
 
 int rails_hash_item_table(uint64_t seed, int64_t first_item, int64_t n_items, int32_t dim, float scale, float* out, void* stream) {
@@ -686,6 +708,39 @@ int rails_rescore_select(const float* exact_scores, int64_t ld, const float* app
   const int r = rescore_select(exact_scores, ld, approx_scores, approx_dense, ld_dense, positions, ids, rows, n_ranked, n_cand, k, margin_eps,
                                check_eps, one_sided != 0, out_scores, out_ids, row_ok, row_stats, (hipStream_t)stream);
   return r == kOk ? r : fail(r, "rescore_select");
+}
+
+size_t rails_candidates_workspace_bytes(int32_t rows) { return candidates_workspace_bytes(rows); }
+
+int rails_candidates_select(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t cap, float lo, float hi, void* workspace,
+                            int64_t* out_positions, float* out_approx, int64_t cand_ld, void* stream) {
+  g_err[0] = '\0';
+  if (rows < 0 || n < 0 || cap <= 0 || ld < n) { set_error("candidates_select: bad size"); return RAILS_EINVAL; }
+  if (rows == 0 || n == 0) return RAILS_OK;
+  if (!scores || !workspace || !out_positions || !out_approx) { set_error("candidates_select: NULL pointer"); return RAILS_EINVAL; }
+  const int cu = compute_units();
+  if (cu <= 0) { set_error("candidates_select: no HIP device"); return RAILS_ELAUNCH; }
+  const int r = candidates_select(scores, ld, rows, n, cap, lo, hi, workspace, out_positions, out_approx, cand_ld, cu, (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "candidates_select");
+}
+
+int rails_candidates_finish(const float* exact_scores, int64_t ld, const float* approx, const int64_t* positions, int64_t cand_ld, int32_t cap,
+                            void* workspace, const int64_t* ids, int64_t n_items, int32_t rows, int32_t k, float default_eps, float safety,
+                            int32_t one_sided, const float* guard_values, int32_t guard_per_row, float guard_limit, float* out_scores,
+                            int64_t* out_ids, const int64_t* invalid_ids, int32_t width, int32_t f_k, int64_t* f_out_ids, float* f_out_scores,
+                            float* state, float* state_host, int64_t* msg, void* stream) {
+  g_err[0] = '\0';
+  if (rows < 0 || cap <= 0 || k <= 0 || ld < cap || cand_ld < cap || n_items <= 0 || n_items > 0xFFFFFFFFll) { set_error("candidates_finish: bad size"); return RAILS_EINVAL; }
+  if (rows == 0) return RAILS_OK;
+  if (!exact_scores || !approx || !positions || !workspace || (!msg && (!out_scores || !out_ids || !state)) || !(default_eps >= 0.0f) || !(safety >= 0.0f) ||
+      (guard_values && (guard_per_row <= 0 || !(guard_limit >= 0.0f))) || (invalid_ids && (msg || !f_out_ids || !f_out_scores))) {
+    set_error("candidates_finish: bad argument");
+    return RAILS_EINVAL;
+  }
+  const int r = candidates_finish(exact_scores, ld, approx, positions, cand_ld, cap, workspace, ids, n_items, rows, k, default_eps, safety, one_sided != 0,
+                                  guard_values, guard_per_row, guard_limit, out_scores, out_ids, invalid_ids, width, f_k, f_out_ids, f_out_scores, state,
+                                  state_host, msg, (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "candidates_finish");
 }
 
 int rails_filter_seen_ids(const int64_t* top_ids, const float* top_scores, int32_t rows, int32_t k_prime,

@@ -48,6 +48,7 @@ struct ScoreArgs {
   const int64_t* cand_pos;
   int64_t index_items;
   const float* irows;             // with cand_pos: the ROW-MAJOR copy of the index (rails_mol_index_rows_build) the candidates are read from instead of ipack
+  const int32_t* cand_count;      // with irows (optional): row b has cand_count[b] <= n_items candidates -- tiles beyond them are skipped (rails_candidates_select's counts)
   int dry_run;                    // 1: validate the dispatch (shape, shell) without launching
   // rails_mol_score_dense_upper: logits[b][x] = s + (ub2 c + ub1) c + ub0, c = max_l |cl_l| of the pair (mol_score_wsplit.h UPPER)
   int upper;
@@ -180,8 +181,18 @@ int scalar_probe(const float* x, int64_t n, float* out, hipStream_t stream);
 int rescore_select(const float* exact, int64_t ld, const float* approx, const float* approx_dense, int64_t ld_dense, const int64_t* positions,
                    const int64_t* ids, int rows, int n_ranked, int kc, int k, float margin_eps, float check_eps, int one_sided, float* out_scores,
                    int64_t* out_ids, int* ok, float* stats, hipStream_t stream);
+size_t candidates_workspace_bytes(int rows);
+int candidates_select(const float* scores, int64_t ld, int rows, int64_t n, int cap, float lo, float hi, void* ws, int64_t* out_pos, float* out_approx,
+                      int64_t cand_ld, int n_cu, hipStream_t stream);
+int candidates_finish(const float* exact, int64_t ld, const float* approx, const int64_t* pos, int64_t cand_ld, int cap, void* ws, const int64_t* ids,
+                      int64_t n_items, int rows, int k, float default_eps, float safety, int one_sided, const float* guard, int guard_per_row,
+                      float guard_limit, float* out_scores, int64_t* out_ids, const int64_t* f_invalid, int f_width, int f_k, int64_t* f_out_ids,
+                      float* f_out_scores, float* state, float* state_host, int64_t* msg, hipStream_t stream);
+struct MergeVerdict {   // rails_merge_candidates_verdict: the global verdict of the item-sharded proved top-k, inside the merge launch
+  float default_eps, safety; const float* guard; int guard_per_row; float guard_limit; float* state; float* state_host; unsigned int* call;
+};
 int merge_candidates(const int64_t* gathered, int R, int rows, int k, int k_out, float* out_scores, int64_t* out_ids,
-                     hipStream_t stream, const int64_t* f_invalid = nullptr, int f_width = 0, int f_k = 0);
+                     hipStream_t stream, const int64_t* f_invalid = nullptr, int f_width = 0, int f_k = 0, const MergeVerdict* verdict = nullptr);
 int filter_seen(const int64_t* top_ids, const float* top_scores, int rows, int k_prime, const int64_t* invalid,
                 int width, int k, int64_t* out_ids, float* out_scores, hipStream_t stream);
 

@@ -139,8 +139,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void mol_score_rows_kernel(ScoreAr
     if (u >= n_units) break;
     const int64_t row64 = u / p.n_tiles;
     const int tile = (int)(u - row64 * p.n_tiles), row = (int)row64;
+    int cnt = (int)p.n_items;
+    if (p.cand_count) {                                                // per-row candidate counts: the tiles past a row's candidates do nothing
+      const int c = __builtin_amdgcn_readfirstlane(p.cand_count[row]);
+      cnt = c < cnt ? c : cnt;
+      if (tile * kTileItems >= cnt) continue;
+    }
     int col = tile * kTileItems + x;                                   // ragged last tile: the row's last candidate again, those columns are not stored
-    col = col < (int)p.n_items ? col : (int)p.n_items - 1;
+    col = col < cnt ? col : cnt - 1;
     int64_t src = p.cand_pos[(int64_t)row * p.n_items + col];
     src = src < 0 ? 0 : (src >= p.index_items ? p.index_items - 1 : src);   // callers pass positions of the index; clamped for memory safety only
     const float4* tEx = reinterpret_cast<const float4*>(p.irows) + src * RP + hi - lane;

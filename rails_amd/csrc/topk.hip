@@ -1262,6 +1262,47 @@ __global__ __launch_bounds__(kFilterThreads) void filter_seen_kernel(const int64
   }
 }
 
+// ---- the call's verdict from its rows' verdicts (rails_candidates_finish, rails_merge_candidates_verdict) ---------------------------
+// One thread per row (its workgroup's thread 0) reports the row; the LAST one to arrive folds the call into `state` (rails_rescore_verdict's
+// layout) and mirrors it into pinned host memory -- the words first, the call counter (which the host polls) last.  `call`: 8 words of the
+// caller's workspace, zero between calls: [0] arrivals [1] a row failed [2] largest error [3] ~orderable(smallest margin) [4] largest guard
+// magnitude [5] a row was bad (NaN, guard).  Rows report through atomics only; the fences order them against the arrival counter.
+__device__ __forceinline__ unsigned int gap_key(float g) { return ~orderable(g); }      // atomicMax over these = the smallest margin
+__device__ __forceinline__ void verdict_commit(unsigned int* call, int rows, int fail, int bad, float err, float gap, float grd, float default_eps,
+                                               float safety, float* st, float* state_host) {
+  if (fail) atomicOr(&call[1], 1u);
+  if (bad) atomicOr(&call[5], 1u);
+  atomicMax(&call[2], __float_as_uint(bad ? 0.0f : err));
+  atomicMax(&call[3], gap_key(gap == gap ? gap : -INFINITY));
+  atomicMax(&call[4], __float_as_uint(grd));
+  __threadfence();
+  const unsigned int t = atomicAdd(&call[0], 1u);
+  if (t != (unsigned int)rows - 1u) return;
+  __threadfence();
+  const unsigned int any_fail = atomicOr(&call[1], 0u), any_bad = atomicOr(&call[5], 0u);
+  const float err_call = __uint_as_float(atomicMax(&call[2], 0u));
+  const float gap_call = unorderable(~atomicMax(&call[3], 0u));
+  const float grd_call = __uint_as_float(atomicMax(&call[4], 0u));
+  float seen = st[0];
+  if (!any_bad) seen = fmaxf(seen, err_call);
+  const int redo = any_fail ? 1 : 0;
+  st[0] = seen;
+  reinterpret_cast<int32_t*>(st)[1] = redo;
+  st[2] = fmaxf(default_eps, safety * seen);
+  st[3] = any_bad ? INFINITY : err_call;
+  st[4] = gap_call;
+  st[5] += 1.0f;
+  if (redo) st[6] += 1.0f;
+  st[7] = fmaxf(st[7], grd_call);
+  if (state_host) {
+    volatile float* sh = state_host;
+    sh[0] = st[0]; reinterpret_cast<volatile int32_t*>(sh)[1] = redo; sh[2] = st[2]; sh[3] = st[3]; sh[4] = st[4]; sh[6] = st[6]; sh[7] = st[7];
+    __threadfence_system();
+    sh[5] = st[5];
+  }
+  call[0] = 0u; call[1] = 0u; call[2] = 0u; call[3] = 0u; call[4] = 0u; call[5] = 0u;
+}
+
 // ---- item-sharded top-k: message pack + merge (rails_amd/sharded.py) -----------------------------------------
 // msg[row] = [k score words (fp32 bits in the low half of an int64) | k ids]; rows shorter than k are padded with
 // (-inf, -1) so every rank contributes the same size to the single all-gather.
@@ -1286,13 +1327,21 @@ __global__ void pack_candidates_kernel(const float* __restrict__ scores, const i
 // legal for the C entry point) is detected and takes the bitonic sort.
 // f_invalid != NULL: the seen-id filter of the candidate index runs inside this launch over the k_out merged winners (staged in LDS,
 // filter_from_lds) and f_k results per row are written -- the sharded counterpart of rails_topk_filtered.
+// v.state != NULL (rails_merge_candidates_verdict): the messages are 2k + 2 wide -- [k score words | k ids | m | err] of rails_candidates_finish's
+// sharded form -- and the row's verdict (merged k_out-th score - max over ranks of m > eps, no bad rank, guard) is folded into the call's.
+struct MergeVerdictArgs {
+  float default_eps, safety; const float* guard; int guard_per_row; float guard_limit;
+  float* state; float* state_host; unsigned int* call;
+};
 __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(const int64_t* __restrict__ gathered, int R, int rows,
                                                                        int k, int k_out, int npad,
                                                                        float* __restrict__ out_scores,
                                                                        int64_t* __restrict__ out_ids,
-                                                                       const int64_t* __restrict__ f_invalid, int f_width, int f_k) {
+                                                                       const int64_t* __restrict__ f_invalid, int f_width, int f_k, int msg_ld,
+                                                                       const MergeVerdictArgs v) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
   __shared__ int unsorted;
+  __shared__ unsigned int s_kth, s_gbad, s_grd;
   __shared__ int64_t f_id[kFuseMaxK], f_inv[kFuseMaxW];
   __shared__ float f_sc[kFuseMaxK];
   __shared__ int f_scratch[kSortThreads / 64 + 2];
@@ -1301,12 +1350,12 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(const in
   const bool fuse = f_invalid != nullptr;
   if (fuse)
     for (int i = threadIdx.x; i < f_width; i += kSortThreads) f_inv[i] = f_invalid[(int64_t)row * f_width + i];   // visible after the barriers below
-  if (threadIdx.x == 0) unsorted = 0;
+  if (threadIdx.x == 0) { unsorted = 0; s_kth = orderable(-INFINITY); s_gbad = 0u; s_grd = 0u; }
   for (int i = threadIdx.x; i < npad; i += kSortThreads) {
     unsigned long long kv = 0ull;
     if (i < count) {
       const int r = i / k, j = i - r * k;
-      const unsigned int bits = (unsigned int)(unsigned long long)gathered[((int64_t)r * rows + row) * 2 * k + j];
+      const unsigned int bits = (unsigned int)(unsigned long long)gathered[((int64_t)r * rows + row) * msg_ld + j];
       kv = ((unsigned long long)orderable(__uint_as_float(bits)) << 32) | (unsigned int)(~(unsigned int)i);
     }
     keys[i] = kv;
@@ -1316,11 +1365,37 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(const in
     const unsigned int pos = ~(unsigned int)(kv & 0xFFFFFFFFull);
     const int r = (int)(pos / (unsigned int)k), jj = (int)(pos - (unsigned int)r * (unsigned int)k);
     const float sc = unorderable((unsigned int)(kv >> 32));
-    const int64_t id = gathered[((int64_t)r * rows + row) * 2 * k + k + jj];
+    const int64_t id = gathered[((int64_t)r * rows + row) * msg_ld + k + jj];
+    if (slot == k_out - 1) s_kth = (unsigned int)(kv >> 32);
     if (fuse) { f_sc[slot] = sc; f_id[slot] = id; }
     else { out_scores[(int64_t)row * k_out + slot] = sc; out_ids[(int64_t)row * k_out + slot] = id; }
   };
   auto finish = [&]() {
+    if (v.state) {
+      if (v.guard)
+        for (int i = threadIdx.x; i < v.guard_per_row; i += kSortThreads) {
+          const float g = fabsf(v.guard[(int64_t)row * v.guard_per_row + i]);
+          if (!(g <= v.guard_limit)) atomicOr(&s_gbad, 1u);
+          atomicMax(&s_grd, __float_as_uint(g == g ? g : INFINITY));
+        }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float m = -INFINITY, err = 0.0f;
+        int bad = s_gbad ? 1 : 0;
+        for (int r = 0; r < R; ++r) {
+          const int64_t* msg = gathered + ((int64_t)r * rows + row) * msg_ld;
+          const float mr = __uint_as_float((unsigned int)(unsigned long long)msg[2 * k]), er = __uint_as_float((unsigned int)(unsigned long long)msg[2 * k + 1]);
+          bad |= !(mr == mr) || !(er < INFINITY);
+          m = fmaxf(m, mr == mr ? mr : INFINITY);
+          err = fmaxf(err, er == er ? er : INFINITY);
+        }
+        const float kth = unorderable(s_kth);              // -inf when fewer than k_out real entries were merged
+        const float gap = kth - m;
+        const float eps = fmaxf(v.default_eps, v.safety * fmaxf(v.state[0], bad ? 0.0f : err));
+        const int fail = bad || !(gap > eps);
+        verdict_commit(v.call, rows, fail, bad, err, gap, __uint_as_float(s_grd), v.default_eps, v.safety, v.state, v.state_host);
+      }
+    }
     if (!fuse) return;
     __syncthreads();
     filter_from_lds<kSortThreads>(f_id, f_sc, k_out, f_inv, f_width, f_k, out_ids + (int64_t)row * f_k, out_scores + (int64_t)row * f_k, f_scratch);
@@ -1374,7 +1449,7 @@ int pack_candidates(const float* scores, const int64_t* ids, int rows, int k_loc
 }
 
 int merge_candidates(const int64_t* gathered, int R, int rows, int k, int k_out, float* out_scores, int64_t* out_ids,
-                     hipStream_t stream, const int64_t* f_invalid, int f_width, int f_k) {
+                     hipStream_t stream, const int64_t* f_invalid, int f_width, int f_k, const MergeVerdict* verdict) {
   if (rows <= 0 || k_out <= 0) return kOk;
   if (f_invalid && !(k_out <= kFuseMaxK && f_width >= 0 && f_width <= kFuseMaxW && f_k > 0 && f_k <= k_out)) {
     set_error("merge_candidates: the seen-id filter cannot be fused at k = %d, width = %d", k_out, f_width);
@@ -1387,8 +1462,15 @@ int merge_candidates(const int64_t* gathered, int R, int rows, int k, int k_out,
   if (ensure_dyn_lds(once, reinterpret_cast<const void*>(&merge_candidates_kernel), kSortCap * (int)sizeof(unsigned long long)) != kOk)
     return kErrLaunch;
   const int npad = next_pow2((int)count < 2 ? 2 : (int)count);
+  MergeVerdictArgs v{};
+  int msg_ld = 2 * k;
+  if (verdict) {
+    v.default_eps = verdict->default_eps; v.safety = verdict->safety; v.guard = verdict->guard; v.guard_per_row = verdict->guard ? verdict->guard_per_row : 0;
+    v.guard_limit = verdict->guard_limit; v.state = verdict->state; v.state_host = verdict->state_host; v.call = verdict->call;
+    msg_ld = 2 * k + 2;
+  }
   hipLaunchKernelGGL(merge_candidates_kernel, dim3(rows), dim3(kSortThreads), npad * sizeof(unsigned long long), stream, gathered, R,
-                     rows, k, k_out, npad, out_scores, out_ids, f_invalid, f_width, f_k);
+                     rows, k, k_out, npad, out_scores, out_ids, f_invalid, f_width, f_k, msg_ld, v);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 
@@ -1620,6 +1702,397 @@ int filter_seen(const int64_t* top_ids, const float* top_scores, int rows, int k
   if (lds > 60000) { set_error("seen-id filter: k' or width too large for LDS"); return kErrUnsupported; }
   hipLaunchKernelGGL(filter_seen_kernel, dim3(rows), dim3(kFilterThreads), lds, stream, top_ids, top_scores, k_prime,
                      invalid, width, k, out_ids, out_scores);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+// ---- candidates of the proved exact top-k: threshold selection + fused verification (round 6) --------------------------------------
+// The proved flow (rails_amd/topk_modules.py) does not need the EXACT kc best first-pass scores of a row: it needs a
+// candidate set C and a value m with "every item outside C has a first-pass score <= m".  Any threshold does: with a monotone bin
+// function b(s), C = {x : b(s_x) >= b_t} and m = min over C of s (an item outside has b(s) < b_t <= b(s_c), hence s < s_c for every
+// candidate c).  So the selection is ONE histogram pass (4 096 linear bins over the a-priori range of the logits, |s| <= 1/tau + the
+// per-pair bound) that finds, per row, the lowest bin b_t with #{b(s) >= b_t} <= cap, and ONE compaction pass -- two launches that read
+// the (B, N) first-pass matrix twice, where the exact radix selection took a memset + 3 histogram + 3 pick + tie + compact + sort
+// launches and five reads (85 us -> ~25 us at 32 x 695 762).  Rows of up to kCandSingleMax scores take both passes in one launch
+// (one workgroup per row, LDS histogram, the second walk hits L2).
+//   rails_candidates_select   -> positions (rows, cap) int64, first-pass scores (rows, cap), counts[row] <= cap (in the workspace)
+//   rails_mol_score_indexed_rows(..., counts)   fp32 logits of the first counts[row] candidates of every row
+//   rails_candidates_finish   one workgroup per row: sort by (fp32 score desc, position asc), top-k (+ the seen-id filter of the candidate
+//                             index), the row's verdict, and -- last workgroup done -- the call's verdict / calibration state, written to the
+//                             device state AND straight into pinned host memory (no copy launch); leaves the workspace zeroed for the next call.
+// Workspace (rails_candidates_workspace_bytes, zeroed ONCE by the caller; every call restores the zeros):
+//   counts[rows] | flags[rows] | call[8] | coarse[rows][64] | fine[rows][4096]
+constexpr int kCandBins = 4096, kCandCoarse = 64, kCandPer = kCandBins / kCandCoarse;
+constexpr int kCandThreads = 512;
+constexpr int kCandSingleMax = 65536;      // rows up to this many scores: one launch, one workgroup per row
+constexpr int kCandStage = 2048;
+
+struct CandWs { unsigned int* counts; unsigned int* flags; unsigned int* call; unsigned int* coarse; unsigned int* fine; };
+static size_t cand_ws_words(int rows) { return (size_t)rows * 2 + 8 + (size_t)rows * kCandCoarse + (size_t)rows * kCandBins; }
+static CandWs cand_ws(void* ws, int rows) {
+  unsigned int* w = static_cast<unsigned int*>(ws);
+  CandWs c;
+  c.counts = w; c.flags = w + rows; c.call = w + 2 * (size_t)rows; c.coarse = c.call + 8; c.fine = c.coarse + (size_t)rows * kCandCoarse;
+  return c;
+}
+size_t candidates_workspace_bytes(int rows) { return cand_ws_words(rows < 1 ? 1 : rows) * sizeof(unsigned int); }
+
+// monotone non-decreasing in s (round-to-nearest subtraction and multiplication by a positive scale, clamp, truncation of a non-negative
+// value); a NaN lands in bin 0 and raises the row's flag
+__device__ __forceinline__ int cand_bin(float s, float lo, float scale) {
+  float x = (s - lo) * scale;
+  x = fminf(fmaxf(x, 0.0f), (float)(kCandBins - 1));
+  return (int)x;
+}
+
+// LDS histogram h[kCandBins] of a workgroup -> coarse sums hc[kCandCoarse] (every thread sums a run of fine bins, runs of one coarse bin sit in
+// neighbouring lanes).  NT * run = kCandBins.
+template <int NT>
+__device__ __forceinline__ void cand_coarse_sums(const unsigned int* h, unsigned int* hc) {
+  constexpr int run = kCandBins / NT;              // 8 (512 threads) or 4 (1024)
+  constexpr int per = kCandPer / run;              // threads per coarse bin: 8 or 16
+  unsigned int s = 0u;
+#pragma unroll
+  for (int j = 0; j < run; ++j) s += h[threadIdx.x * run + j];
+#pragma unroll
+  for (int o = 1; o < per; o <<= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & (per - 1)) == 0) hc[threadIdx.x / per] = s;
+}
+
+// One wave: the threshold bin of a row from its coarse / fine histograms (global or LDS): the LOWEST fine bin b_t whose count of scores in
+// bins >= b_t is <= cap (0 when the whole row fits; kCandBins -- nothing selected -- when the top fine bin alone holds more than cap).
+__device__ __forceinline__ int cand_pick(const unsigned int* coarse, const unsigned int* fine, unsigned int cap, int lane) {
+  const unsigned int cc = coarse[kCandCoarse - 1 - lane];
+  unsigned int incl = cc;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+  const unsigned long long over = __ballot(incl > cap);
+  if (over == 0ull) return 0;
+  const int first = __ffsll((long long)over) - 1;
+  const int cg = kCandCoarse - 1 - first;
+  const unsigned int base = (unsigned int)__shfl((int)(incl - cc), first, 64);     // scores in the coarse bins above cg
+  const unsigned int f = fine[cg * kCandPer + kCandPer - 1 - lane];
+  unsigned int incl2 = f;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned int v = __shfl_up(incl2, o, 64); if (lane >= o) incl2 += v; }
+  const int fit = __popcll(__ballot(base + incl2 <= cap));                          // monotone in the lane: the top `fit` fine bins of cg fit
+  return cg * kCandPer + kCandPer - fit;                                            // fit == 0: the first bin above cg
+}
+
+// the selected scores of [begin, end) of a row -> the row's candidate list: staged in LDS (one LDS atomic per wave that holds one), ONE
+// global atomic per workgroup reserves their range of the list (compact_kernel's scheme); a chunk with more selected scores than the
+// stage holds is walked again and placed directly
+template <int NT>
+__device__ __forceinline__ void cand_append(const float* __restrict__ rowp, int64_t begin, int64_t end, int bt, float lo, float scale,
+                                            unsigned int* count, int64_t* __restrict__ out_pos, float* __restrict__ out_a, unsigned int cap,
+                                            unsigned long long* stage, unsigned int* wg_base, unsigned int* wg_cursor) {
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) *wg_cursor = 0u;
+  __syncthreads();
+  for_each_in_chunk(rowp, begin, end, NT, [&](float sc, int64_t i) {
+    const bool sel = cand_bin(sc, lo, scale) >= bt;
+    const unsigned long long m = __ballot(sel);
+    if (m) {
+      const int leader = __ffsll((long long)m) - 1;
+      unsigned int base = 0;
+      if (lane == leader) base = atomicAdd(wg_cursor, (unsigned int)__popcll(m));
+      base = (unsigned int)__shfl((int)base, leader, 64);
+      if (sel) {
+        const unsigned int slot = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+        if (slot < (unsigned int)kCandStage) stage[slot] = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned int)i;
+      }
+    }
+  });
+  __syncthreads();
+  const unsigned int total = *wg_cursor;
+  if (total == 0u) return;
+  __syncthreads();
+  if (threadIdx.x == 0) { *wg_base = atomicAdd(count, total); *wg_cursor = 0u; }
+  __syncthreads();
+  const unsigned int wbase = *wg_base;
+  if (total <= (unsigned int)kCandStage) {
+    for (unsigned int j = threadIdx.x; j < total; j += NT) {
+      const unsigned long long e = stage[j];
+      if (wbase + j < cap) { out_pos[wbase + j] = (int64_t)(unsigned int)e; out_a[wbase + j] = __uint_as_float((unsigned int)(e >> 32)); }
+    }
+    return;
+  }
+  for_each_in_chunk(rowp, begin, end, NT, [&](float sc, int64_t i) {
+    const bool sel = cand_bin(sc, lo, scale) >= bt;
+    const unsigned long long m = __ballot(sel);
+    if (m) {
+      const int leader = __ffsll((long long)m) - 1;
+      unsigned int base = 0;
+      if (lane == leader) base = atomicAdd(wg_cursor, (unsigned int)__popcll(m));
+      base = (unsigned int)__shfl((int)base, leader, 64);
+      if (sel) {
+        const unsigned int slot = wbase + base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+        if (slot < cap) { out_pos[slot] = i; out_a[slot] = sc; }
+      }
+    }
+  });
+}
+
+__global__ __launch_bounds__(kCandThreads) void cand_hist_kernel(const float* __restrict__ scores, int64_t ld, int64_t n, int64_t chunk, float lo,
+                                                                float scale, unsigned int cap, CandWs w) {
+  __shared__ __attribute__((aligned(16))) unsigned int h[kCandBins];
+  __shared__ unsigned int hc[kCandCoarse];
+  __shared__ int s_cut;
+  const int row = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < kCandBins; i += kCandThreads) h[i] = 0u;
+  __syncthreads();
+  const int64_t begin = (int64_t)blockIdx.x * chunk;
+  const int64_t end = (begin + chunk < n) ? begin + chunk : n;
+  const float* rowp = scores + (int64_t)row * ld;
+  bool nan = false;
+  for_each_in_chunk(rowp, begin, end, kCandThreads, [&](float sc, int64_t) {
+    nan |= !(sc == sc);
+    atomicAdd(&h[cand_bin(sc, lo, scale)], 1u);
+  });
+  if (__ballot(nan) != 0ull && lane == 0) atomicOr(&w.flags[row], 1u);
+  __syncthreads();
+  cand_coarse_sums<kCandThreads>(h, hc);
+  __syncthreads();
+  // Only the bins that can hold the row's threshold are merged: with c the coarse bin in which THIS chunk's count from the top passes cap, the
+  // row's count passes cap in c or above, so its threshold bin lies in a coarse bin >= c -- and every workgroup merges all of its bins >= its c.
+  if (tid < 64) {
+    const unsigned int cc = hc[kCandCoarse - 1 - lane];
+    unsigned int incl = cc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    const unsigned long long over = __ballot(incl > cap);
+    if (lane == 0) s_cut = over ? kCandCoarse - 1 - (__ffsll((long long)over) - 1) : 0;
+  }
+  __syncthreads();
+  const int cut = s_cut;
+  unsigned int* gf = w.fine + (size_t)row * kCandBins;
+  unsigned int* gc = w.coarse + (size_t)row * kCandCoarse;
+  for (int i = cut * kCandPer + tid; i < kCandBins; i += kCandThreads)
+    if (h[i]) atomicAdd(&gf[i], h[i]);
+  if (tid < kCandCoarse && tid >= cut && hc[tid]) atomicAdd(&gc[tid], hc[tid]);
+}
+
+__global__ __launch_bounds__(kCandThreads) void cand_compact_kernel(const float* __restrict__ scores, int64_t ld, int64_t n, int64_t chunk, float lo,
+                                                                   float scale, unsigned int cap, CandWs w, int64_t* __restrict__ out_pos,
+                                                                   float* __restrict__ out_a, int64_t cand_ld) {
+  __shared__ unsigned long long stage[kCandStage];
+  __shared__ unsigned int wg_base, wg_cursor;
+  __shared__ int s_bt;
+  const int row = blockIdx.y, tid = threadIdx.x;
+  if (tid < 64) {
+    const int bt = cand_pick(w.coarse + (size_t)row * kCandCoarse, w.fine + (size_t)row * kCandBins, cap, tid);
+    if (tid == 0) s_bt = bt;
+  }
+  __syncthreads();
+  const int64_t begin = (int64_t)blockIdx.x * chunk;
+  const int64_t end = (begin + chunk < n) ? begin + chunk : n;
+  cand_append<kCandThreads>(scores + (int64_t)row * ld, begin, end, s_bt, lo, scale, &w.counts[row], out_pos + (int64_t)row * cand_ld,
+                            out_a + (int64_t)row * cand_ld, cap, stage, &wg_base, &wg_cursor);
+}
+
+// rows of <= kCandSingleMax scores: histogram, threshold and compaction in one launch (the second walk of the row hits L2)
+__global__ __launch_bounds__(kRowThreads) void cand_single_kernel(const float* __restrict__ scores, int64_t ld, int64_t n, float lo, float scale,
+                                                                 unsigned int cap, CandWs w, int64_t* __restrict__ out_pos, float* __restrict__ out_a,
+                                                                 int64_t cand_ld) {
+  __shared__ __attribute__((aligned(16))) unsigned int h[kCandBins];
+  __shared__ unsigned int hc[kCandCoarse];
+  __shared__ unsigned long long stage[kCandStage];
+  __shared__ unsigned int wg_base, wg_cursor;
+  __shared__ int s_bt;
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < kCandBins; i += kRowThreads) h[i] = 0u;
+  __syncthreads();
+  const float* rowp = scores + (int64_t)row * ld;
+  bool nan = false;
+  for_each_in_chunk(rowp, 0, n, kRowThreads, [&](float sc, int64_t) {
+    nan |= !(sc == sc);
+    atomicAdd(&h[cand_bin(sc, lo, scale)], 1u);
+  });
+  if (__ballot(nan) != 0ull && lane == 0) atomicOr(&w.flags[row], 1u);
+  __syncthreads();
+  cand_coarse_sums<kRowThreads>(h, hc);
+  __syncthreads();
+  if (tid < 64) {
+    const int bt = cand_pick(hc, h, cap, tid);
+    if (tid == 0) s_bt = bt;
+  }
+  __syncthreads();
+  cand_append<kRowThreads>(rowp, 0, n, s_bt, lo, scale, &w.counts[row], out_pos + (int64_t)row * cand_ld, out_a + (int64_t)row * cand_ld, cap, stage,
+                           &wg_base, &wg_cursor);
+}
+
+int candidates_select(const float* scores, int64_t ld, int rows, int64_t n, int cap, float lo, float hi, void* ws, int64_t* out_pos, float* out_approx,
+                      int64_t cand_ld, int n_cu, hipStream_t stream) {
+  if (rows <= 0 || n <= 0) return kOk;
+  if (cap < 1 || cap > kSortCap || cand_ld < cap) { set_error("candidates_select: cap = %d out of range (1 .. %d, row stride %lld)", cap, kSortCap, (long long)cand_ld); return kErrInvalid; }
+  if (n >= (1ll << 32)) { set_error("candidates_select: n = %lld does not fit 32-bit positions", (long long)n); return kErrUnsupported; }
+  if (!(hi > lo)) { set_error("candidates_select: empty score range"); return kErrInvalid; }
+  const float scale = (float)kCandBins / (hi - lo);
+  const CandWs w = cand_ws(ws, rows);
+  static const int single_max = [] { const char* e = getenv("RAILS_CAND_SINGLE_MAX"); const int v = e ? atoi(e) : -1; return v >= 0 ? v : kCandSingleMax; }();
+  if (n <= single_max) {
+    hipLaunchKernelGGL(cand_single_kernel, dim3(rows), dim3(kRowThreads), 0, stream, scores, ld, n, lo, scale, (unsigned int)cap, w, out_pos, out_approx, cand_ld);
+    return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+  }
+  static const int cand_wgs = [] { const char* e = getenv("RAILS_CAND_WGS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 16384 ? v : 0; }();
+  const int target = cand_wgs ? cand_wgs : 4 * (n_cu > 0 ? n_cu : 256);
+  int64_t chunks = (target + rows - 1) / rows;
+  const int64_t max_chunks = (n + 8191) / 8192;
+  if (chunks > max_chunks) chunks = max_chunks;
+  if (chunks < 1) chunks = 1;
+  int64_t chunk = (n + chunks - 1) / chunks;
+  chunk = (chunk + 3) / 4 * 4;
+  chunks = (n + chunk - 1) / chunk;
+  hipLaunchKernelGGL(cand_hist_kernel, dim3((unsigned)chunks, rows), dim3(kCandThreads), 0, stream, scores, ld, n, chunk, lo, scale, (unsigned int)cap, w);
+  hipLaunchKernelGGL(cand_compact_kernel, dim3((unsigned)chunks, rows), dim3(kCandThreads), 0, stream, scores, ld, n, chunk, lo, scale, (unsigned int)cap, w,
+                     out_pos, out_approx, cand_ld);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+// ---- the fused finish -------------------------------------------------------------------------------------------------------------
+struct CandFinishArgs {
+  const float* exact; int64_t ld;            // fp32 logits of the candidates (row stride ld)
+  const float* approx; const int64_t* pos; int64_t cand_ld;   // first-pass scores and corpus positions (row stride cand_ld)
+  CandWs w; int cap, npad, k;
+  const int64_t* ids; int64_t n_items;
+  float default_eps, safety; int one_sided;
+  const float* guard; int guard_per_row; float guard_limit;
+  float* out_scores; int64_t* out_ids;       // (rows, k)
+  const int64_t* f_invalid; int f_width, f_k; int64_t* f_out_ids; float* f_out_scores;   // optional seen-id filter over the k winners
+  float* state; float* state_host;           // verdict state (rails_rescore_verdict's layout); state_host: optional mirror in pinned host memory
+  int64_t* msg;                              // sharded form: (rows, 2k + 2) message [k score words | k ids | m | err], no verdict here
+};
+
+__global__ __launch_bounds__(kSortThreads) void cand_finish_kernel(const CandFinishArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+  __shared__ float red_min[kSortThreads / 64], red_err[kSortThreads / 64], red_grd[kSortThreads / 64];
+  __shared__ int red_bad[kSortThreads / 64];
+  __shared__ int64_t f_id[kFuseMaxK], f_inv[kFuseMaxW];
+  __shared__ float f_sc[kFuseMaxK];
+  __shared__ int f_scratch[kSortThreads / 64 + 2];
+  const int row = blockIdx.x, rows = gridDim.x, tid = threadIdx.x, lane = tid & 63;
+  const int k = a.k, npad = a.npad;
+  const bool fuse = a.f_invalid != nullptr;
+  unsigned int c = a.w.counts[row];
+  if (c > (unsigned int)a.cap) c = (unsigned int)a.cap;
+  const unsigned int flags = a.w.flags[row];
+  const float seen_before = a.state ? a.state[0] : 0.0f;
+  if (fuse)
+    for (int i = tid; i < a.f_width; i += kSortThreads) f_inv[i] = a.f_invalid[(int64_t)row * a.f_width + i];
+  float mn = INFINITY, err = 0.0f, grd = 0.0f;
+  int bad = (flags & 1u) ? 1 : 0;
+  for (int i = tid; i < npad; i += kSortThreads) {
+    unsigned long long kv = 0ull;
+    if (i < (int)c) {
+      const float e = a.exact[(int64_t)row * a.ld + i];
+      const float ap = a.approx[(int64_t)row * a.cand_ld + i];
+      const int64_t p = a.pos[(int64_t)row * a.cand_ld + i];
+      kv = ((unsigned long long)orderable(e) << 32) | (unsigned int)(~(unsigned int)p);
+      mn = fminf(mn, ap);
+      const float dd = a.one_sided ? fmaxf(e - ap, 0.0f) : fabsf(e - ap);
+      bad |= !(dd == dd) || !(e == e) || !(ap == ap);
+      err = fmaxf(err, dd == dd ? dd : INFINITY);
+    }
+    keys[i] = kv;
+  }
+  if (a.guard)
+    for (int i = tid; i < a.guard_per_row; i += kSortThreads) {
+      const float v = fabsf(a.guard[(int64_t)row * a.guard_per_row + i]);
+      if (!(v <= a.guard_limit)) bad = 1;
+      grd = fmaxf(grd, v == v ? v : INFINITY);
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mn = fminf(mn, __shfl_xor(mn, o, 64));
+    err = fmaxf(err, __shfl_xor(err, o, 64));
+    grd = fmaxf(grd, __shfl_xor(grd, o, 64));
+    bad |= __shfl_xor(bad, o, 64);
+  }
+  if (lane == 0) { red_min[tid >> 6] = mn; red_err[tid >> 6] = err; red_grd[tid >> 6] = grd; red_bad[tid >> 6] = bad; }
+  // leave the workspace as the next call expects it (nothing below reads it)
+  {
+    unsigned int* gf = a.w.fine + (size_t)row * kCandBins;
+    for (int i = tid; i < kCandBins; i += kSortThreads) gf[i] = 0u;
+    if (tid < kCandCoarse) a.w.coarse[(size_t)row * kCandCoarse + tid] = 0u;
+    if (tid == 0) { a.w.counts[row] = 0u; a.w.flags[row] = 0u; }
+  }
+  __syncthreads();
+  if (npad <= kSortThreads) {
+    unsigned long long kv = tid < npad ? keys[tid] : 0ull;
+    kv = block_sort_desc(kv, npad, keys + npad);
+    __syncthreads();
+    if (tid < npad) keys[tid] = kv;
+    __syncthreads();
+  } else if (npad == 2 * kSortThreads) block_sort_desc_multi<2>(keys);
+  else if (npad == 4 * kSortThreads) block_sort_desc_multi<4>(keys);
+  else if (npad == 8 * kSortThreads) block_sort_desc_multi<8>(keys);
+  else block_sort_desc_multi<16>(keys);
+  mn = INFINITY; err = 0.0f; grd = 0.0f; bad = 0;
+  for (int wv = 0; wv < kSortThreads / 64; ++wv) { mn = fminf(mn, red_min[wv]); err = fmaxf(err, red_err[wv]); grd = fmaxf(grd, red_grd[wv]); bad |= red_bad[wv]; }
+  const bool whole_row = (int64_t)c >= a.n_items;          // every item of the row is a candidate: nothing is left outside
+  if (whole_row) mn = -INFINITY;
+  else if (c == 0u) mn = INFINITY;                          // no candidate of a non-empty row: nothing is known about it
+  if (a.msg) {
+    // item-sharded form: this rank's part of the global proof travels with its top-k (rails_amd/sharded.py)
+    int64_t* m = a.msg + (int64_t)row * (2 * k + 2);
+    for (int j = tid; j < k; j += kSortThreads) {
+      const unsigned long long kv = j < (int)c ? keys[j] : 0ull;
+      const int64_t p = (int64_t)(~(unsigned int)(kv & 0xFFFFFFFFull));
+      const float sc = kv ? unorderable((unsigned int)(kv >> 32)) : -INFINITY;
+      m[j] = (int64_t)(unsigned long long)__float_as_uint(sc);
+      m[k + j] = kv ? (a.ids ? a.ids[p] : p) : -1;
+    }
+    if (tid == 0) {
+      m[2 * k] = (int64_t)(unsigned long long)__float_as_uint(mn);
+      m[2 * k + 1] = (int64_t)(unsigned long long)__float_as_uint(bad ? INFINITY : err);
+    }
+    return;
+  }
+  for (int j = tid; j < k; j += kSortThreads) {
+    const unsigned long long kv = keys[j];
+    const int64_t p = (int64_t)(~(unsigned int)(kv & 0xFFFFFFFFull));
+    const float sc = unorderable((unsigned int)(kv >> 32));
+    const int64_t id = a.ids ? a.ids[p < a.n_items ? p : 0] : p;
+    a.out_scores[(int64_t)row * k + j] = sc;
+    a.out_ids[(int64_t)row * k + j] = id;
+    if (fuse && j < kFuseMaxK) { f_sc[j] = sc; f_id[j] = id; }
+  }
+  if (tid == 0) {
+    // the row's verdict: its k-th fp32 score must clear the best first-pass score left outside the candidates by eps
+    const float kth = (int)c >= k ? unorderable((unsigned int)(keys[k - 1] >> 32)) : -INFINITY;
+    const float gap = kth - mn;
+    const float eps = fmaxf(a.default_eps, a.safety * fmaxf(seen_before, bad ? 0.0f : err));
+    const int fail = bad || (int)c < k || !(gap > eps);
+    verdict_commit(a.w.call, rows, fail, bad, err, gap, grd, a.default_eps, a.safety, a.state, a.state_host);
+  }
+  if (fuse) {
+    __syncthreads();
+    filter_from_lds<kSortThreads>(f_id, f_sc, k, f_inv, a.f_width, a.f_k, a.f_out_ids + (int64_t)row * a.f_k, a.f_out_scores + (int64_t)row * a.f_k, f_scratch);
+  }
+}
+
+int candidates_finish(const float* exact, int64_t ld, const float* approx, const int64_t* pos, int64_t cand_ld, int cap, void* ws, const int64_t* ids,
+                      int64_t n_items, int rows, int k, float default_eps, float safety, int one_sided, const float* guard, int guard_per_row,
+                      float guard_limit, float* out_scores, int64_t* out_ids, const int64_t* f_invalid, int f_width, int f_k, int64_t* f_out_ids,
+                      float* f_out_scores, float* state, float* state_host, int64_t* msg, hipStream_t stream) {
+  if (rows <= 0) return kOk;
+  if (cap < 1 || cap > kSortCap || k < 1 || (k > cap && !msg)) { set_error("candidates_finish: k = %d of cap = %d out of range", k, cap); return kErrInvalid; }
+  if (f_invalid && !(k <= kFuseMaxK && f_width >= 0 && f_width <= kFuseMaxW && f_k > 0 && f_k <= k)) {
+    set_error("candidates_finish: the seen-id filter cannot be fused at k = %d, width = %d", k, f_width);
+    return kErrUnsupported;
+  }
+  static DynLdsOnce once;
+  if (ensure_dyn_lds(once, reinterpret_cast<const void*>(&cand_finish_kernel), kSortCap * (int)sizeof(unsigned long long)) != kOk) return kErrLaunch;
+  CandFinishArgs a{};
+  a.exact = exact; a.ld = ld; a.approx = approx; a.pos = pos; a.cand_ld = cand_ld; a.w = cand_ws(ws, rows); a.cap = cap; a.k = k;
+  int npad = next_pow2(cap < 64 ? 64 : cap);
+  a.npad = npad;
+  a.ids = ids; a.n_items = n_items; a.default_eps = default_eps; a.safety = safety; a.one_sided = one_sided;
+  a.guard = guard; a.guard_per_row = guard ? guard_per_row : 0; a.guard_limit = guard_limit;
+  a.out_scores = out_scores; a.out_ids = out_ids;
+  a.f_invalid = f_invalid; a.f_width = f_width; a.f_k = f_k; a.f_out_ids = f_out_ids; a.f_out_scores = f_out_scores;
+  a.state = state; a.state_host = state_host; a.msg = msg;
+  const size_t lds = (size_t)(npad <= kSortThreads ? 3 * npad : npad) * sizeof(unsigned long long);
+  hipLaunchKernelGGL(cand_finish_kernel, dim3(rows), dim3(kSortThreads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

@@ -311,15 +311,19 @@ class MolEngine:
             _lib.check(self.lib.rails_mol_index_rows_build(C.byref(self.shape), _ptr(index.buf), index.n_items, _ptr(rows), _stream()), "rails_mol_index_rows_build")
         return rows
 
-    def score_indexed_rows(self, qpack: torch.Tensor, batch: int, rows: torch.Tensor, n_items: int, positions: torch.Tensor) -> torch.Tensor:
-        """score_indexed with the candidates read from the row-major copy: whole cache lines per candidate, same bits."""
-        positions = positions.to(device=rows.device, dtype=torch.int64).contiguous()
+    def score_indexed_rows(self, qpack: torch.Tensor, batch: int, rows: torch.Tensor, n_items: int, positions: torch.Tensor,
+                           counts: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """score_indexed with the candidates read from the row-major copy: whole cache lines per candidate, same bits.
+        counts: per-row candidate counts (int32 on the device; candidates_select's): only the first counts[b] logits of row b are written."""
+        if positions.dtype != torch.int64 or positions.device != rows.device or not positions.is_contiguous():
+            positions = positions.to(device=rows.device, dtype=torch.int64).contiguous()
         n_cand = positions.shape[1]
-        out = torch.empty((batch, n_cand), dtype=torch.float32, device=rows.device)
+        if out is None:
+            out = torch.empty((batch, n_cand), dtype=torch.float32, device=rows.device)
         with _on_device(rows.device):
             _lib.check(
                 self.lib.rails_mol_score_indexed_rows(C.byref(self.shape), _ptr(self.gate_pack), _ptr(qpack), batch, _ptr(rows), n_items, _ptr(positions), n_cand,
-                                                      _ptr(out), out.stride(0), _stream()),
+                                                      _ptr(out), out.stride(0), _ptr(counts), _stream()),
                 "rails_mol_score_indexed_rows",
             )
         return out
@@ -918,6 +922,56 @@ def rescore_select(exact: torch.Tensor, approx: torch.Tensor, positions: torch.T
     return out_s, out_i, ok, stats
 
 
+def candidates_workspace(rows: int, device) -> torch.Tensor:
+    """The zeroed workspace of candidates_select / candidates_finish for up to `rows` rows (include/rails_amd.h: zeroed once, every
+    select + finish pair leaves it zeroed).  Its first `rows` int32 are the per-row candidate counts between the two calls."""
+    n = _lib.load().rails_candidates_workspace_bytes(int(rows))
+    return torch.zeros((n + 3) // 4, dtype=torch.int32, device=device)
+
+
+def candidates_select(scores: torch.Tensor, cap: int, lo: float, hi: float, workspace: torch.Tensor, out_pos: torch.Tensor, out_approx: torch.Tensor) -> None:
+    """Threshold selection of at most `cap` candidates per row of `scores` (rows, n) fp32 (rails_candidates_select): positions into
+    out_pos (rows, >= cap) int64, their scores into out_approx (rows, >= cap) fp32, counts into workspace[:rows]."""
+    lib = _lib.load()
+    _require_device(scores, "scores")
+    rows, n = scores.shape
+    if out_pos.stride(0) != out_approx.stride(0) or out_pos.stride(0) < cap:
+        raise ValueError("candidates_select: out_pos / out_approx must share a row stride >= cap")
+    with _on_device(scores.device):
+        _lib.check(lib.rails_candidates_select(_ptr(scores), scores.stride(0), rows, n, int(cap), float(lo), float(hi), _ptr(workspace), _ptr(out_pos), _ptr(out_approx),
+                                               out_pos.stride(0), _stream()), "rails_candidates_select")
+
+
+def candidates_finish(exact: torch.Tensor, approx: torch.Tensor, positions: torch.Tensor, cap: int, workspace: torch.Tensor, ids: Optional[torch.Tensor], n_items: int,
+                      k: int, default_eps: float, safety: float, one_sided: bool, guard: Optional[torch.Tensor], guard_per_row: int, guard_limit: float,
+                      state: Optional[torch.Tensor], state_host: Optional[torch.Tensor] = None, seen: Optional[Tuple[torch.Tensor, int]] = None,
+                      msg: Optional[torch.Tensor] = None):
+    """rails_candidates_finish: sort the rows' candidates by (fp32 score, position), write the top k, the verdict and (seen = (invalid_ids, k_out)) the
+    seen-id filter's output -> (scores (rows, k), ids (rows, k), f_ids or None, f_scores or None); with `msg` (rows, 2k + 2) int64 the item-sharded
+    message is written instead and nothing is returned."""
+    lib = _lib.load()
+    rows = exact.shape[0]
+    dev = exact.device
+    out_s = out_i = f_i = f_s = inv = None
+    width = f_k = 0
+    if msg is None:
+        out_s = torch.empty((rows, k), dtype=torch.float32, device=dev)
+        out_i = torch.empty((rows, k), dtype=torch.int64, device=dev)
+        if seen is not None:
+            inv, f_k = seen
+            if inv.dtype != torch.int64 or inv.device != dev or not inv.is_contiguous():
+                inv = inv.to(device=dev, dtype=torch.int64).contiguous()
+            width = inv.shape[1]
+            f_i = torch.empty((rows, f_k), dtype=torch.int64, device=dev)
+            f_s = torch.empty((rows, f_k), dtype=torch.float32, device=dev)
+    with _on_device(dev):
+        _lib.check(lib.rails_candidates_finish(_ptr(exact), exact.stride(0), _ptr(approx), _ptr(positions), positions.stride(0), int(cap), _ptr(workspace), _ptr(ids), int(n_items),
+                                               rows, int(k), float(default_eps), float(safety), 1 if one_sided else 0, _ptr(guard), int(guard_per_row), float(guard_limit),
+                                               _ptr(out_s), _ptr(out_i), None if inv is None else _inv_ptr(inv), width, int(f_k), _ptr(f_i), _ptr(f_s), _ptr(state),
+                                               _ptr(state_host), _ptr(msg), _stream()), "rails_candidates_finish")
+    return out_s, out_i, f_i, f_s
+
+
 def pack_candidates(scores: torch.Tensor, ids: torch.Tensor, k: int) -> torch.Tensor:
     """(rows, k_local) fp32 scores + int64 ids -> (rows, 2k) int64 message (score bits | ids), padded with (-inf, -1)."""
     lib = _lib.load()
@@ -961,6 +1015,34 @@ def merge_candidates_filtered(gathered: torch.Tensor, n_ranks: int, k: int, k_pr
         _lib.check(lib.rails_merge_candidates_filtered(_ptr(gathered), n_ranks, rows, k, k_prime, _inv_ptr(invalid_ids), invalid_ids.shape[1], k_out,
                                                        _ptr(out_i), _ptr(out_s), _stream()), "rails_merge_candidates_filtered")
     return out_i, out_s
+
+
+def merge_candidates_verdict(gathered: torch.Tensor, n_ranks: int, k: int, k_out: int, default_eps: float, safety: float, guard: Optional[torch.Tensor],
+                             guard_per_row: int, guard_limit: float, state: torch.Tensor, state_host: Optional[torch.Tensor], call_ws: torch.Tensor,
+                             seen: Optional[Tuple[torch.Tensor, int]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """gathered (n_ranks * rows, 2k + 2) int64 messages of candidates_finish(msg=...) in rank order -> merged exact top-k_out + the global verdict of the
+    item-sharded proved top-k in one launch (include/rails_amd.h rails_merge_candidates_verdict).  -> (scores, ids) (rows, k_out), or with
+    seen = (invalid_ids, k_f) the filtered (ids, scores) (rows, k_f)."""
+    lib = _lib.load()
+    _require_device(gathered, "gathered messages")
+    rows = gathered.shape[0] // n_ranks
+    gathered = gathered.contiguous()
+    dev = gathered.device
+    inv, width, f_k = None, 0, 0
+    cols = k_out
+    if seen is not None:
+        inv, f_k = seen
+        inv = inv.to(device=dev, dtype=torch.int64).contiguous()
+        width, cols = inv.shape[1], f_k
+    out_s = torch.empty((rows, cols), dtype=torch.float32, device=dev)
+    out_i = torch.empty((rows, cols), dtype=torch.int64, device=dev)
+    with _on_device(dev):
+        _lib.check(lib.rails_merge_candidates_verdict(_ptr(gathered), n_ranks, rows, int(k), int(k_out), float(default_eps), float(safety), _ptr(guard), int(guard_per_row),
+                                                      float(guard_limit), _ptr(state), _ptr(state_host), _ptr(call_ws), None if inv is None else _inv_ptr(inv), width, int(f_k),
+                                                      _ptr(out_i), _ptr(out_s), _stream()), "rails_merge_candidates_verdict")
+    if seen is not None:
+        return out_i, out_s
+    return out_s, out_i
 
 
 def filter_seen_ids(top_ids: torch.Tensor, top_scores: torch.Tensor, invalid_ids: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -225,17 +225,20 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
     corpus' (8 shards of amzn-books: thousands of candidates per shard and query instead of ~85).  So the proof is made once, globally:
       rank r:  first pass over its shard -> its kc_r best by first-pass score, m_r = the best first-pass score it leaves outside
                -> fp32 re-scoring of the kc_r -> its best k by (fp32 score, position)
-      all:     ONE all-gather of the (B, 2k) messages (as in the dense path) + ONE all-reduce(MAX) of (m_r per row, largest |fp32 - first pass|
-               seen) -> merge to the global top-k by fp32 score -> verdict per row: e_k - max_r m_r > eps
+      all:     ONE all-gather of (B, 2k + 2) messages -- the rank's top-k, m_r per row and the largest |fp32 - first pass| it saw ride in the
+               same message (round 6; rounds 5 used an all-reduce next to the gather and an always-enqueued second gather for the redo)
+               -> merge to the global top-k by fp32 score + verdict per row, e_k - max_r m_r > eps, in ONE launch
     Every item of every shard outside the candidates has a first-pass score <= max_r m_r, hence an fp32 score < e_k: the merged top-k IS the
     dense one.  Candidates per rank: the ~kc items within eps of the global k-th score spread evenly over the shards, so kc_r = kc / R +
-    4 sqrt(kc / R) + 32 (doubling after a failed verdict).  A failed verdict (crowded scores, a skewed shard, a violated guard) raises REDO
-    on every rank alike -- the verdict's inputs are collective results -- and the dense fp32 kernels redo the shard behind it under that
-    launch predicate; their exchange (a second all-gather + merge) is always enqueued, collectives cannot be predicated, and the output
-    is picked by the flag on the device.  The host never waits.  Used when EVERY rank's local module is bound in proved mode (an
+    4 sqrt(kc / R) + 32 (doubled after a failed verdict, halved again after PAD_DECAY_CALLS proved calls: both decided from the verdicts,
+    which every rank sees alike).  A failed verdict (crowded scores, a skewed shard, a violated guard) is the same on every rank -- its
+    inputs are the gathered bytes -- and is read by the host from the pinned mirror the merge kernel writes; only then do the ranks run
+    the dense fp32 kernels over their shards and a second exchange.  Used when EVERY rank's local module is bound in proved mode (an
     all-reduce at the first call); otherwise the per-shard path above."""
 
     GLOBAL_PROOF = True
+    PAD_DECAY_CALLS = 64          # after this many consecutive proved calls a doubled candidate margin is halved again
+    VERDICT_TIMEOUT_S = 120.0
 
     def _make_local_module(self, mol_module, item_embeddings_shard, item_ids_shard) -> TopKModule:
         # the size-dependent choices of the proved flow (one eps or per-pair bounds, candidate margins) are made for the SHARD size every rank
@@ -252,6 +255,7 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
         return t
 
     def _all_gather_rows(self, msg: torch.Tensor) -> torch.Tensor:
+        self._gp_collectives = getattr(self, "_gp_collectives", 0) + 1
         if msg.is_cuda and dist.get_backend(self._group) == "gloo":
             host = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype)
             dist.all_gather_into_tensor(host, msg.cpu(), group=self._group)
@@ -280,41 +284,18 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
             self._gp_eps = local._proved_eps() if self._gp_on else None
             self._gp_state = torch.zeros(8, dtype=torch.float32, device=query_embeddings.device)
             self._gp_host = torch.zeros(8, dtype=torch.float32).pin_memory()
-            self._gp_event = None
-            self._gp_seen = (0.0, 0.0)
+            self._gp_call = torch.zeros(8, dtype=torch.int32, device=query_embeddings.device)
+            self._gp_issued = 0           # verdicts enqueued so far (the host mirror's call counter reaches it when the last one has landed)
             self._gp_pad = 1
+            self._gp_streak = 0
             self._gp_stats = {"calls": 0, "fallbacks": 0, "proved_calls": 0, "bound_violations": 0}
         return self._gp_on
 
-    def _gp_absorb(self, wait: bool = False) -> None:
-        ev = getattr(self, "_gp_event", None)
-        if ev is None:
-            return
-        if wait:
-            ev.synchronize()
-        elif not ev.query():
-            return
-        h = self._gp_host
-        calls, redone = float(h[5]), float(h[6])
-        new_calls, new_redone = int(calls - self._gp_seen[0]), int(redone - self._gp_seen[1])
-        self._gp_seen = (calls, redone)
-        st = self._gp_stats
-        st["calls"] += new_calls
-        st["fallbacks"] += new_redone
-        if float(h[0]) > self._gp_eps:
-            st["bound_violations"] += 1
-        else:
-            st["proved_calls"] += new_calls - new_redone
-        st["guard_max"] = float(h[7])
-        if new_redone > 0 and self._gp_pad < 64:
-            self._gp_pad *= 2
-
     def stats(self) -> dict:
-        """Counters of the global proof (calls, proved_calls, fallbacks, bound_violations, kc per rank) merged over the local module's (synchronises)."""
+        """Counters of the global proof (calls, proved_calls, fallbacks, bound_violations, kc per rank) merged over the local module's."""
         local = self._local_module
         out = local.stats()
         if getattr(self, "_gp_on", False):
-            self._gp_absorb(wait=True)
             out.update(self._gp_stats)
             out["global_proof"] = True
         return out
@@ -329,72 +310,111 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
         return max(1, min(kc, 16384, self._n_local))
 
     def submit(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs):
-        if not self._global_proof(query_embeddings) or query_embeddings.size(0) < MoLBruteForceTopK.PROVED_MIN_BATCH:
+        B = query_embeddings.size(0)
+        per_shard = -(-self._n_total // max(self._world, 1))
+        # (the 4 GiB logit policy: the first pass wants the whole (B, N_shard) matrix -- beyond it every rank alike takes the per-shard path, which chunks)
+        if (not self._global_proof(query_embeddings) or B < MoLBruteForceTopK.PROVED_MIN_BATCH or B * per_shard * 4 > MoLBruteForceTopK.MAX_LOGIT_BYTES
+                or not MoLBruteForceTopK.FUSED_TAIL):
             return super().submit(query_embeddings, k, sorted, **kwargs)
         if k > self._n_total:
             raise RuntimeError(f"selected index k out of range (k={k}, n={self._n_total})")
-        self._gp_absorb()
         local = self._local_module
         with local.one_bind():
             kc = self._kc_local(k)
-            s, ids, m, err, gq, qpack32 = local.speculate_for_shard(query_embeddings, k, kc, **kwargs)
-        msg = E.pack_candidates(s, ids, k)
-        qpack32 = qpack32.clone()          # the local module recycles its pack with the next submit; the verdict and the redo read it later
-        red = torch.cat([m, err.max().reshape(1)])
+            msg, qpack32 = local.speculate_for_shard(query_embeddings, k, kc, **kwargs)
         ready = torch.cuda.Event()
         ready.record()
         self._gp_stats["kc"] = kc
-        return ("gproof", msg, red, ready, k, qpack32, gq.numel(), query_embeddings.size(0), query_embeddings.dtype, s.dtype)
+        return ("gproof", msg, ready, k, qpack32, query_embeddings, kwargs, sorted)
 
     def result(self, handle, seen=None) -> Tuple[torch.Tensor, torch.Tensor]:
         if handle[0] != "gproof":
             return super().result(handle, seen)
-        _, msg, red, ready, k, qpack32, n_gq, B, q_dtype, _ = handle
+        _, msg, ready, k, qpack32, query_embeddings, kwargs, sorted_ = handle
         local = self._local_module
         sp = local._engine.spec
+        B = query_embeddings.size(0)
         off = (B + 32 // sp.query_dot_product_groups - 1) // (32 // sp.query_dot_product_groups) * 32 * sp.dot_product_dimension
-        gq = qpack32[off : off + n_gq]
+        gq = qpack32[off : off + B * sp.num_logits]
         cur = torch.cuda.current_stream(msg.device)
         if self._xstream is None:
             self._xstream = torch.cuda.Stream(msg.device)
         side = self._xstream
         side.wait_event(ready)
-        for t in (msg, red, qpack32):
+        for t in (msg, qpack32):
             t.record_stream(side)
+        fuse = seen is not None and E.merge_filter_fusable(k, seen[0].shape[1], seen[1])
         with torch.cuda.stream(side):
+            # ONE exchange: the (B, 2k + 2) messages carry every rank's top-k, the best first-pass score it left outside its candidates and the
+            # largest |fp32 - first pass| it saw; merge, verdict and the seen-id filter are one launch behind it
             gathered = self._all_gather_rows(msg)
-            red = self._all_reduce(red, dist.ReduceOp.MAX)
-            ms, mi = E.merge_candidates(gathered, self._world, k, k)
-            stats = E.margin_stats(ms, k - 1, red[:B], red[B:])
-            E.rescore_verdict(stats, self._gp_state, self._gp_eps, 1.0, gq, self._gp_guard_limit)
-            redo = self._gp_state.view(torch.int32)[1:2]
-            # the redo: the dense fp32 kernels over this shard, its exchange, the merge -- launches no-ops unless REDO, collective always
-            k_fb = min(k, self._n_local)
-            fb = self.__dict__.setdefault("_gp_fb", {})
-            if (B, k_fb) not in fb:      # written only by a redo; between redos it keeps (-inf, -1) or a stale result: either is harmless, the flag picks
-                fb.clear()
-                fb[(B, k_fb)] = (torch.full((B, k_fb), float("-inf"), dtype=torch.float32, device=msg.device),
-                                 torch.full((B, k_fb), -1, dtype=torch.int64, device=msg.device))
-            s_fb, i_fb = fb[(B, k_fb)]
-            local.dense_for_shard(qpack32, B, k, (s_fb, i_fb), redo)
-            gathered2 = self._all_gather_rows(E.pack_candidates(s_fb, i_fb, k))
-            ms2, mi2 = E.merge_candidates(gathered2, self._world, k, k)
-            take = redo.to(torch.bool)
-            ms, mi = torch.where(take, ms2, ms), torch.where(take, mi2, mi)
-            if seen is not None:
+            if fuse:
                 seen[0].record_stream(side)
-                mi, ms = E.filter_seen_ids(mi, ms, seen[0], seen[1])
-            ms = ms.to(q_dtype)
-            self._gp_host.copy_(self._gp_state, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            self._gp_event = ev
+            out = E.merge_candidates_verdict(gathered, self._world, k, k, self._gp_eps, 1.0, gq, sp.num_logits, self._gp_guard_limit, self._gp_state,
+                                             self._gp_host, self._gp_call, seen if fuse else None)
+            if seen is not None and not fuse:
+                seen[0].record_stream(side)
+                out = E.filter_seen_ids(out[1], out[0], seen[0], seen[1])
+        self._gp_issued += 1
         cur.wait_stream(side)
-        ms.record_stream(cur)
-        mi.record_stream(cur)
-        if seen is not None:
-            return mi, ms
-        return ms, mi
+        out[0].record_stream(cur)
+        out[1].record_stream(cur)
+        # Every rank computes the verdict from the same gathered bytes, so all of them raise or clear REDO alike; the host reads it from the pinned
+        # mirror the merge kernel writes (with submit / result pipelining batch i + 1 is already enqueued: the device does not idle) and only a
+        # failed verdict -- crowded scores, a skewed shard, a violated guard -- costs more: the dense fp32 kernels over the shards and their
+        # own exchange, issued here, by every rank.
+        redo = self._gp_wait_verdict()
+        st = self._gp_stats
+        st["calls"] += 1
+        if float(self._gp_host[0]) > self._gp_eps:
+            st["bound_violations"] += 1
+        elif not redo:
+            st["proved_calls"] += 1
+        st["guard_max"] = float(self._gp_host[7])
+        if not redo:
+            self._gp_streak += 1
+            if self._gp_pad > 1 and self._gp_streak >= self.PAD_DECAY_CALLS:
+                self._gp_pad //= 2
+                self._gp_streak = 0
+            if seen is not None:
+                return out[0], out[1].to(query_embeddings.dtype)
+            return out[0].to(query_embeddings.dtype), out[1]
+        st["fallbacks"] += 1
+        self._gp_streak = 0
+        if self._gp_pad < 64:
+            self._gp_pad *= 2
+        # the dense fp32 kernels over this shard (the local module's resident fp32 index) and the plain exchange of the per-shard top-k
+        k_local = min(k, self._n_local)
+        if k_local > 0:
+            with local.one_bind():
+                s, ids = local._forward_fp32_dense(query_embeddings, k_local, **kwargs)
+        else:
+            s = torch.empty((B, 0), dtype=torch.float32, device=msg.device)
+            ids = torch.empty((B, 0), dtype=torch.int64, device=msg.device)
+        msg2 = E.pack_candidates(s.float(), ids, k)
+        ready2 = torch.cuda.Event()
+        ready2.record()
+        return super().result(("pending", msg2, ready2, k, True, query_embeddings.dtype, None), seen)
+
+    def _gp_wait_verdict(self) -> bool:
+        """Spin on the pinned mirror's call counter until the verdict enqueued last has landed -> its REDO flag."""
+        import time
+
+        h = self._gp_host
+        want = float(self._gp_issued)
+        t0 = None
+        while float(h[5]) < want:
+            if t0 is None:
+                t0 = time.perf_counter()
+            elif time.perf_counter() - t0 > self.VERDICT_TIMEOUT_S:
+                raise RuntimeError("the item-sharded verdict did not arrive (a kernel or the exchange failed)")
+        return int(h.view(torch.int32)[1]) != 0
+
+    def exchange_info(self) -> dict:
+        info = super().exchange_info()
+        info["collectives_per_proved_step"] = 1
+        info["collectives_issued"] = getattr(self, "_gp_collectives", 0)
+        return info
 
     def forward_filtered(self, query_embeddings: torch.Tensor, k_prime: int, invalid_ids: torch.Tensor, k: int, **kwargs):
         if self._world > 1 and self._global_proof(query_embeddings) and query_embeddings.size(0) >= MoLBruteForceTopK.PROVED_MIN_BATCH and k_prime <= self._n_total:

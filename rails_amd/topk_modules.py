@@ -167,6 +167,7 @@ class MoLBruteForceTopK(MoLTopKModule):
         self._verdict_state: Optional[torch.Tensor] = None
         self._state_pending = None
         self._pad_scale = 1           # candidate margin multiplier, doubled when a verification fails
+        self._state_direct = False    # True: the verdict state reaches the host through the finish kernel's own stores (no copy, no event)
         self._pause_left = 0
         self.exact_mode: str = exact_mode or self.EXACT_MODE
         self._proved_choice = None    # (fp32 engine the choice was made for, precision to bind or None)
@@ -342,7 +343,13 @@ class MoLBruteForceTopK(MoLTopKModule):
             ex = eng.exact
             if not (B < self.PROVED_MIN_BATCH and self._mol_module.engine() is not eng and eng.dense_precision == "f16x3"
                     and self._index32 is not None and self._index32_engine is ex):
-                return None
+                if not (self.FUSED_TAIL and eng.dense_precision == "f16x3" and k <= k_prime <= N):
+                    return None
+                # the proved flow: the filter runs inside its finish launch (and inside the redo's selection)
+                r = self._forward_rescored(query_embeddings, k_prime, _seen=(invalid_ids, k), **kwargs)
+                if r[0] == "filtered":
+                    return r[1], r[2]
+                return E.filter_seen_ids(r[1], r[0], invalid_ids, k)
             n_q = ex.lib.rails_mol_query_pack_floats(E.C.byref(ex.shape), B)
             qpack32, _, _ = ex.query_pack(query_embeddings, kwargs.get("user_ids"), out=self._buf("qpack32", n_q, torch.float32))
             logits = ex.score_dense(qpack32, B, self._index32, out=self._buf("logits", B * N, torch.float32).view(B, N))
@@ -387,7 +394,7 @@ class MoLBruteForceTopK(MoLTopKModule):
     # (tools/single_f16_probe.py) -> default eps = 0.15 on logits in [-20, 20], twice the candidate margin of the f16x3 first pass
     RESCORE_EPS_PER_INV_TEMPERATURE_F16X1 = 7.5e-3
 
-    def _forward_rescored(self, query_embeddings: torch.Tensor, k: int, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+    def _forward_rescored(self, query_embeddings: torch.Tensor, k: int, _seen=None, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
         """The fp32 brute-force result -- same scores, same ids, same tie order -- at the f16x3 kernel's speed.
           1. f16x3 logits s16 over the whole index; the top Kc = k + max(64, k/4) of them (rounded up to whole tiles) are the
              candidates, m = the smallest candidate's s16.  Every other item has s16 <= m.
@@ -447,6 +454,8 @@ class MoLBruteForceTopK(MoLTopKModule):
                     parts.append(self._forward_rescored(query_embeddings[b0 : b0 + rows], k, **kw))
                 return torch.cat([p[0] for p in parts], 0), torch.cat([p[1] for p in parts], 0)
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)   # one row is too long: fp32, in corpus chunks
+        if (eps_proved is not None and self.FUSED_TAIL and self.DEVICE_VERDICT and self._index32 is not None and self._index32_engine is ex):
+            return self._forward_proved(query_embeddings, k, kc, eps_proved, upper, _seen, **kwargs)
         # one prologue writes the query pack in both formats: f16 hi/lo for the first pass, fp32 for the re-scoring
         n_q = eng.lib.rails_mol_query_pack_floats(E.C.byref(eng.shape), B)
         qpack16, qpack32 = eng.query_pack_both(query_embeddings, kwargs.get("user_ids"), self._buf("qpack", n_q, torch.float32),
@@ -515,6 +524,7 @@ class MoLBruteForceTopK(MoLTopKModule):
             self._state_host.copy_(state, non_blocking=True)
             self._state_event.record()
             self._state_pending = (k, kc)
+            self._state_direct = False
         else:
             err, gap = self._read_stats(stats)
             if err == err and err != float("inf"):
@@ -535,6 +545,88 @@ class MoLBruteForceTopK(MoLTopKModule):
             self._audit(query_embeddings, k, scores, ids, **kwargs)
         return scores.to(query_embeddings.dtype), ids
 
+    # ---- the proved flow with the fused tail (round 6) ----------------------------------------------------------------------------
+    # first pass -> rails_candidates_select (threshold selection: one histogram + one compaction launch, one launch for short rows) ->
+    # fp32 re-scoring of the counted candidates -> rails_candidates_finish (sort, top-k, verdict, seen-id filter, calibration state written
+    # to the device AND straight into pinned host memory) -> the dense redo under the verdict's launch predicate: 8-9 launches where the
+    # exact-kc selection + separate verdict / filter / state copy took 19 (amzn-books B = 32: 0.19 -> ~0.1 ms behind the first pass).
+    FUSED_TAIL = __import__("os").environ.get("RAILS_FUSED_TAIL", "1") != "0"
+    _cand = None          # (B, cap) -> (workspace, positions, first-pass scores, fp32 scores)
+    _cand_dirty = False
+
+    def _cand_buffers(self, B: int, cap: int):
+        c = self._cand
+        if c is None or c[0] != (B, cap):
+            dev = self._item_embeddings.device
+            c = self._cand = ((B, cap), E.candidates_workspace(B, dev), torch.zeros((B, cap), dtype=torch.int64, device=dev),
+                              torch.zeros((B, cap), dtype=torch.float32, device=dev), torch.zeros((B, cap), dtype=torch.float32, device=dev))
+            self._cand_dirty = False
+        if self._cand_dirty:       # an exception between select and finish left counts / histograms behind
+            c[1].zero_()
+        return c[1], c[2], c[3], c[4]
+
+    def _score_range(self, upper) -> Tuple[float, float]:
+        """The a-priori range of the first-pass logits (the histogram's bins): a softmax mixture of cross logits in [-1/tau, 1/tau] (l2-normalised
+        components: a guard of the bound) plus, for the UPPER builds, the per-pair bound at the largest |cross logit|.  Scores outside are clamped
+        into the end bins -- any monotone bin function is valid, the range only sets the resolution."""
+        c = 1.02 / float(self._engine.spec.temperature)
+        hi = c + ((upper[0] * c + upper[1]) * c + upper[2] if upper is not None else 0.0)
+        return -c, hi
+
+    def _forward_proved(self, query_embeddings: torch.Tensor, k: int, kc: int, eps_proved: float, upper, seen, **kwargs):
+        eng = self._engine
+        ex = eng.exact
+        B, N = query_embeddings.size(0), self._index.n_items
+        sp = eng.spec
+        n_q = eng.lib.rails_mol_query_pack_floats(E.C.byref(eng.shape), B)
+        qpack16, qpack32 = eng.query_pack_both(query_embeddings, kwargs.get("user_ids"), self._buf("qpack", n_q, torch.float32),
+                                               self._buf("qpack32", n_q, torch.float32))
+        s16 = self._buf("logits", B * N, torch.float32).view(B, N)
+        hook = self._first_pass_hook        # measurement only (bench.py: events around the dominant launch, on its stream)
+        if hook is not None:
+            hook(0)
+        if upper is not None:
+            eng.score_dense_upper(qpack16, B, self._index, upper, out=s16)
+        else:
+            eng.score_dense(qpack16, B, self._index, out=s16)
+        if hook is not None:
+            hook(1)
+        if self._debug_first_pass_bias is not None:   # tests only: (positions, delta) -- the first pass is made to under-score these items
+            s16[:, self._debug_first_pass_bias[0]] -= self._debug_first_pass_bias[1]
+        cap = min(kc, N)
+        ws, pos, a16, e32 = self._cand_buffers(B, cap)
+        self._cand_dirty = True
+        lo, hi = self._score_range(upper)
+        E.candidates_select(s16, cap, lo, hi, ws, pos, a16)
+        if self._rows32 is not None and ex.score_indexed_supported(B, cap):
+            ex.score_indexed_rows(qpack32, B, self._rows32, N, pos, counts=ws, out=e32)
+        else:
+            e32 = self._rescore(ex, qpack32, B, pos)       # every slot (the slots past a row's count hold earlier candidates: valid positions, ignored below)
+        off = (B + 32 // sp.query_dot_product_groups - 1) // (32 // sp.query_dot_product_groups) * 32 * sp.dot_product_dimension
+        guard = qpack32[off : off + B * sp.num_logits]
+        state = self._state()
+        fuse = seen is not None and k <= 512 and seen[0].shape[1] <= 256 and E.topk_filter_fusable(N, k, seen[0].shape[1], seen[1])
+        scores, ids, f_i, f_s = E.candidates_finish(e32, a16, pos, cap, ws, self._ids_flat, N, k, eps_proved, 1.0, upper is not None, guard, sp.num_logits,
+                                                    self._gate_guard_limit, state, self._state_host, seen if fuse else None)
+        self._cand_dirty = False
+        self.rescore_stats["calls"] += 1
+        self.rescore_stats["kc"] = kc
+        # the redo: the dense fp32 kernels behind the verdict, no-ops unless it failed (the host never waits)
+        redo = state.view(torch.int32)[1:2]
+        l32 = ex.score_dense(qpack32, B, self._index32, out=s16, run_if=redo)
+        tws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(B, N, k), torch.uint8)
+        if fuse:
+            E.topk_filtered(l32, k, self._ids_flat, seen[0], seen[1], workspace=tws, out=(f_i, f_s), run_if=redo)
+        else:
+            E.topk(l32, k, ids=self._ids_flat, workspace=tws, out=(scores, ids), run_if=redo)
+        self._state_pending = (k, kc)
+        self._state_direct = True
+        if fuse:
+            return "filtered", f_i, f_s.to(query_embeddings.dtype)
+        if self.audit_every > 0 and self.rescore_stats["calls"] % self.audit_every == 0:
+            self._audit(query_embeddings, k, scores, ids, **kwargs)
+        return scores.to(query_embeddings.dtype), ids
+
     # ---- the proved flow split for an item-sharded corpus (rails_amd/sharded.py) --------------------------------------------------
     def shard_can_speculate(self) -> bool:
         """True iff this (local) module is bound in proved mode with both index formats resident: what ShardedMoLBruteForceTopK needs from
@@ -544,26 +636,30 @@ class MoLBruteForceTopK(MoLTopKModule):
             and self._proved_eps() is not None and math.isfinite(self._proved_eps())
 
     def speculate_for_shard(self, query_embeddings: torch.Tensor, k: int, kc: int, **kwargs):
-        """Steps 1-4 of the proved flow on THIS shard, without a verdict: first pass over the shard, its kc best by first-pass score
-        re-scored in fp32, the best min(k, kc) of those by (fp32 score, position).
-        -> (scores (B, k_loc), ids (B, k_loc), m (B,), err (B,), gq rows): m = the best first-pass score left OUTSIDE the candidates
-        (-inf when the whole shard is a candidate), err = the largest |fp32 - first pass| over the row's candidates, gq = the batch's
-        prescaled query-gate rows (the guard of the a-priori bound).  The caller proves globally: every item of every shard outside the
-        candidates has s16 <= max over ranks of m, so the merged fp32 top-k is the dense one iff its k-th score exceeds that by eps."""
+        """The proved flow on THIS shard without a verdict: first pass over the shard, threshold selection of at most kc candidates by first-pass
+        score, fp32 re-scoring, the best min(k, #candidates) by (fp32 score, position).
+        -> (msg (B, 2k + 2) int64: [k score words | k ids | m | err] per row, the fp32 query pack): m = the smallest first-pass score among the
+        candidates -- every item outside them scores below it (-inf when the whole shard is a candidate, +inf when nothing could be selected) --,
+        err = the largest |fp32 - first pass| over the row's candidates (inf: a NaN).  The caller proves globally, after ONE all-gather of the
+        messages: every item of every shard outside the candidates has s16 <= max over ranks of m, so the merged fp32 top-k is the dense one iff
+        its k-th score exceeds that by eps (rails_merge_candidates_verdict)."""
         eng = self._bind()
         ex = eng.exact
         B, N = query_embeddings.size(0), self._index.n_items
         dev = query_embeddings.device
-        sp = eng.spec
         n_q = eng.lib.rails_mol_query_pack_floats(E.C.byref(eng.shape), B)
-        qpack16, qpack32 = eng.query_pack_both(query_embeddings, kwargs.get("user_ids"), self._buf("qpack", n_q, torch.float32),
-                                               self._buf("qpack32", n_q, torch.float32))
-        off = (B + 32 // sp.query_dot_product_groups - 1) // (32 // sp.query_dot_product_groups) * 32 * sp.dot_product_dimension
-        gq = qpack32[off : off + B * sp.num_logits]
-        if N == 0:
-            return (torch.empty((B, 0), dtype=torch.float32, device=dev), torch.empty((B, 0), dtype=torch.int64, device=dev),
-                    torch.full((B,), float("-inf"), dtype=torch.float32, device=dev), torch.zeros((B,), dtype=torch.float32, device=dev), gq, qpack32)
-        kc = min(max(kc, 1), N)
+        # packs of their own: with submit / result pipelining the verdict of batch i reads its gate rows while batch i + 1's prologue runs
+        qpack16 = self._buf("qpack", n_q, torch.float32)
+        qpack32 = torch.empty(n_q, dtype=torch.float32, device=dev)
+        eng.query_pack_both(query_embeddings, kwargs.get("user_ids"), qpack16, qpack32)
+        msg = torch.empty((B, 2 * k + 2), dtype=torch.int64, device=dev)
+        if N == 0:      # an empty shard still takes part in the exchange: nothing to offer, nothing left outside
+            msg[:, :k] = int(torch.tensor(float("-inf")).view(torch.int32)) & 0xFFFFFFFF
+            msg[:, k : 2 * k] = -1
+            msg[:, 2 * k] = int(torch.tensor(float("-inf")).view(torch.int32)) & 0xFFFFFFFF
+            msg[:, 2 * k + 1] = 0
+            return msg, qpack32
+        cap = min(max(kc, 1), N)
         s16 = self._buf("logits", B * N, torch.float32).view(B, N)
         hook = self._first_pass_hook
         if hook is not None:
@@ -575,27 +671,19 @@ class MoLBruteForceTopK(MoLTopKModule):
             eng.score_dense(qpack16, B, self._index, out=s16)
         if hook is not None:
             hook(1)
-        ws = self._buf("topk_ws", E._lib.load().rails_topk_workspace_bytes(B, N, kc), torch.uint8)
-        c16, pos = E.topk(s16, kc, workspace=ws)
-        e32 = self._rescore(ex, qpack32, B, pos)
-        k_loc = min(k, kc)
-        scores, ids, _, stats = E.rescore_select(e32, c16, pos, self._ids_flat, N, k_loc, approx_dense=s16, one_sided=upper is not None)
-        m = c16[:, kc - 1] if kc < N else torch.full((B,), float("-inf"), dtype=torch.float32, device=dev)     # (views: the caller concatenates them into its message)
+        ws, pos, a16, e32 = self._cand_buffers(B, cap)
+        self._cand_dirty = True
+        lo, hi = self._score_range(upper)
+        E.candidates_select(s16, cap, lo, hi, ws, pos, a16)
+        if self._rows32 is not None and ex.score_indexed_supported(B, cap):
+            ex.score_indexed_rows(qpack32, B, self._rows32, N, pos, counts=ws, out=e32)
+        else:
+            e32 = self._rescore(ex, qpack32, B, pos)
+        E.candidates_finish(e32, a16, pos, cap, ws, self._ids_flat, N, k, 0.0, 1.0, upper is not None, None, 0, 0.0, None, None, msg=msg)
+        self._cand_dirty = False
         self.rescore_stats["calls"] += 1
         self.rescore_stats["kc"] = kc
-        return scores, ids, m, stats[:, 0], gq, qpack32
-
-    def dense_for_shard(self, qpack32: torch.Tensor, batch: int, k: int, out: Tuple[torch.Tensor, torch.Tensor], run_if: torch.Tensor) -> None:
-        """The shard's dense fp32 top-min(k, N) into `out` (scores, ids), under the launch predicate `run_if` (the global verdict's REDO flag)."""
-        ex = self._engine.exact
-        N = self._index.n_items
-        if N == 0:
-            return
-        # buffers of its own: with submit / result pipelining the redo of batch i runs on the exchange stream while batch i + 1's first pass
-        # writes the module's other buffers
-        l32 = ex.score_dense(qpack32, batch, self._index32, out=self._buf("logits_fb", batch * N, torch.float32).view(batch, N), run_if=run_if)
-        ws = self._buf("topk_ws2", E._lib.load().rails_topk_workspace_bytes(batch, N, min(k, N)), torch.uint8)
-        E.topk(l32, min(k, N), ids=self._ids_flat, workspace=ws, out=out, run_if=run_if)
+        return msg, qpack32
 
     ROWS_COPY_MAX_BYTES = 8 << 30      # the row-major copy of the fp32 index is kept for indexes up to this size (0: never)
     _rows32 = None
@@ -638,14 +726,24 @@ class MoLBruteForceTopK(MoLTopKModule):
         unless `wait` (stats()): a snapshot that has not landed yet is picked up by a later call."""
         if self._verdict_state is None or self._state_pending is None:
             return
-        if wait:
-            self._state_event.synchronize()
-        elif not self._state_event.query():
-            return
-        h = self._state_host
+        if self._state_direct:
+            # the finish kernel writes the state into the pinned host words itself, the call counter last: a snapshot is whole when the
+            # counter reads the same before and after it
+            if wait:
+                torch.cuda.current_stream(self._verdict_state.device).synchronize()
+            c0 = float(self._state_host[5])
+            h = self._state_host.tolist()
+            if h[5] != c0 or (h[5] <= self._state_seen[0] and not wait):
+                return
+        else:
+            if wait:
+                self._state_event.synchronize()
+            elif not self._state_event.query():
+                return
+            h = self._state_host
         calls, redone = float(h[5]), float(h[6])
-        new_redone = int(redone - self._state_seen[1])
-        new_calls = int(calls - self._state_seen[0])
+        new_calls = max(0, int(calls - self._state_seen[0]))
+        new_redone = min(new_calls, max(0, int(redone - self._state_seen[1])))
         self._state_seen = (calls, redone)
         self._err_seen = max(self._err_seen, float(h[0]))
         self.rescore_stats["eps"] = float(h[2])

@@ -55,23 +55,24 @@ with torch.inference_mode():
         kc = min((per + int(4 * per ** 0.5) + 32 + 31) // 32 * 32, hi - lo)
         print("global proof: eps", eps, "kc per rank", kc)
 
+    host = torch.zeros(8, dtype=torch.float32).pin_memory()
+    call_ws = torch.zeros(8, dtype=torch.int32, device=dev)
+    issued = [0]
+
     def global_step():
-        s, i_, m, err, gq, qp32 = tk.speculate_for_shard(q, kp, kc)
-        msg = E.pack_candidates(s, i_, kp)
-        qp32 = qp32.clone()
-        red = torch.cat([m, err.max().reshape(1)])
-        gathered = msg.repeat(a.world, 1)                                   # stands for the all-gather; the all-reduce is the identity here
-        ms, mi = E.merge_candidates(gathered, a.world, kp, kp)
-        stats = E.margin_stats(ms, kp - 1, red[:B], red[B:])
-        E.rescore_verdict(stats, state, eps, 1.0, gq, tk._gate_guard_limit)
-        redo = state.view(torch.int32)[1:2]
-        s_fb = torch.full((B, kp), float("-inf"), dtype=torch.float32, device=dev)
-        i_fb = torch.full((B, kp), -1, dtype=torch.int64, device=dev)
-        tk.dense_for_shard(qp32, B, kp, (s_fb, i_fb), redo)
-        ms2, mi2 = E.merge_candidates(E.pack_candidates(s_fb, i_fb, kp).repeat(a.world, 1), a.world, kp, kp)
-        take = redo.to(torch.bool)
-        ms, mi = torch.where(take, ms2, ms), torch.where(take, mi2, mi)
-        return E.filter_seen_ids(mi, ms, inv, k)
+        # round 6: one message (top-k' | ids | m | err), one exchange, merge + verdict + filter in one launch, the verdict read from the pinned mirror
+        msg, qp32 = tk.speculate_for_shard(q, kp, kc)
+        sp = tk._engine.spec
+        off = (B + 32 // sp.query_dot_product_groups - 1) // (32 // sp.query_dot_product_groups) * 32 * sp.dot_product_dimension
+        gq = qp32[off : off + B * sp.num_logits]
+        gathered = msg.repeat(a.world, 1)                                   # stands for the all-gather
+        out = E.merge_candidates_verdict(gathered, a.world, kp, kp, eps, 1.0, gq, sp.num_logits, tk._gate_guard_limit, state, host, call_ws, (inv, k))
+        issued[0] += 1
+        if not a.pipeline:
+            while float(host[5]) < issued[0]:
+                pass
+            assert int(host.view(torch.int32)[1]) == 0, "the emulated global verdict failed"
+        return out
 
     def local_part():
         if a.precision == "proved-global":
