@@ -36,7 +36,8 @@ extern "C" {
  * rails_topk_candidates is new, rails_mol_score_indexed takes any n_cand; 7: rails_rescore_verdict gained its guard arguments and state[7], the rails_*_probe_* entry points are new, and rails_mol_score_topk / _survivors / rails_select_survivors -- the selection fused into the scoring kernels, 0.9 % slower than the dense kernels + rails_topk wherever it was measured -- are gone;
  * 8: rails_mol_score_dense_upper[_supported] and rails_mol_index_rows_* / rails_mol_score_indexed_rows are new, rails_rescore_select gained one_sided;
  * 9: rails_candidates_* -- the threshold selection and the fused finish of the proved exact top-k -- and rails_merge_candidates_verdict
- * are new, rails_mol_score_indexed_rows gained cand_counts).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
+ * are new, rails_mol_score_indexed_rows gained cand_counts, the component table became item-group-major (rails_mol_component_build
+ * gained n_total / first_item, rails_mol_component_topk its out_of_range flag, rails_mol_component_topk_capacity is new)).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
  * against an older header pass shorter structs, and the library would read the new fields from whatever follows them. */
 #define RAILS_ABI_VERSION 9
 int rails_abi_version(void);
@@ -283,18 +284,25 @@ int rails_mol_coarse_prefilter_build(const rails_mol_shape* shape, const void* t
  * Replaces the bf16 component table (rails/indexing/mol_top_k.py:61-73, :172-174) and the per-query-group bf16 `mm`
  * (mol_top_k.py:247-251, :498-502).  scores has batch * P_Q * P_X rows, row (b * P_Q + i) * P_X + m, n_items columns;
  * feed it to rails_topk with k = k_per_group and reshape the (rows, k) positions to (batch, P_Q * P_X * k). */
+/* The table is ITEM-GROUP-major (ABI 9): table[m][x][:] = bf16(Ex[x, m, :]) for the n_total items of the corpus, so that a scan streams one group's
+ * rows back to back.  rails_mol_component_build writes the rows of items [first_item, first_item + n_items) of every group from an index (chunk)
+ * of n_items items -- one call with n_total = n_items, first_item = 0 for a whole index. */
 size_t rails_mol_component_table_bytes(const rails_mol_shape* shape, int64_t n_items);   /* 2 * P_X * d bytes per item */
-int rails_mol_component_build(const rails_mol_shape* shape, const float* index, int64_t n_items, void* table,
+int rails_mol_component_build(const rails_mol_shape* shape, const float* index, int64_t n_items, void* table, int64_t n_total, int64_t first_item,
                               void* stream);
 int rails_mol_component_score(const rails_mol_shape* shape, const float* eq, int32_t batch, const void* table,
                               int64_t n_items, float* scores, int64_t ld, const int32_t* run_if, void* stream);
 /* Fused scoring + exact top-k_group of every (query group, item group) row, without the (rows, n_items) score matrix:
  * same scheme, same outputs contract and same counts check as rails_mol_coarse_topk, over batch * P_Q * P_X rows.
- * out_scores / out_positions: (batch * P_Q * P_X, k_group); out_counts: (batch * P_Q * P_X). */
+ * out_scores / out_positions: (batch * P_Q * P_X, k_group); out_counts: (batch * P_Q * P_X).
+ * batch * P_Q <= 256 query rows per call (a zero workspace size says "unsupported": callers slice the batch or take the materialising path).
+ * out_of_range (optional, an int32 in device memory, zeroed by the call's first launch): raised when some row's candidate count left
+ * [k_group, rails_mol_component_topk_capacity] -- the launch predicate of the caller's redo. */
 size_t rails_mol_component_topk_workspace_bytes(const rails_mol_shape* shape, int32_t batch, int64_t n_items, int32_t k_group);
+int32_t rails_mol_component_topk_capacity(const rails_mol_shape* shape, int32_t batch, int64_t n_items, int32_t k_group);
 int rails_mol_component_topk(const rails_mol_shape* shape, const float* eq, int32_t batch, const void* table, int64_t n_items,
                              int32_t k_group, void* workspace, size_t workspace_bytes, float* out_scores,
-                             int64_t* out_positions, int32_t* out_counts, void* stream);
+                             int64_t* out_positions, int32_t* out_counts, int32_t* out_of_range, void* stream);
 /* torch.sort(indices, dim=1) on (rows, n) int64, n <= 16384 (mol_top_k.py:257, :515); in == out allowed. */
 int rails_sort_rows_i64(const int64_t* in, int32_t rows, int32_t n, int64_t* out, void* stream);
 /* scores[r][j] = fill where sorted_idx[r][j] == sorted_idx[r][j-1] (mol_top_k.py:277-284, :535-542). */
@@ -351,7 +359,7 @@ int rails_merge_candidates_filtered(const int64_t* gathered, int32_t n_ranks, in
  * row and rank) WITH the global verdict of the item-sharded proved top-k in the same launch: row b is proved iff no rank reported a bad row
  * (err = inf), every guard value is within guard_limit, and  merged k_out-th score - max over ranks of m > eps  (eps as in rails_candidates_finish).
  * The last workgroup folds the rows into `state` (rails_rescore_verdict's layout) and mirrors it into state_host (optional, pinned host memory;
- * state_host[5], the call counter, is written last).  call_ws: 8 uint32 in device memory, zeroed once by the caller (left zeroed by every call).
+ * state_host[5], the call counter, is written last).  call_ws: 8 + 4 rows uint32 in device memory (16-byte aligned), zeroed once by the caller (every call leaves its first word, the arrival counter, zero).
  * Every rank computes the same verdict from the same gathered bytes, so the ranks agree on a redo without another exchange.
  * invalid_ids == NULL: (out_scores, out_ids) are (rows, k_out); else the seen-id filter runs inside the launch and they are (rows, f_k).
  * No counterpart in the reference (single-GPU eval: eval_from_checkpoint.py:554-555). */

@@ -152,10 +152,11 @@ PROTOTYPES = {
         [_SHAPE_P, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],
     ),
     "rails_mol_component_table_bytes": (C.c_size_t, [_SHAPE_P, C.c_int64]),
-    "rails_mol_component_build": (C.c_int, [_SHAPE_P, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "rails_mol_component_build": (C.c_int, [_SHAPE_P, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
+    "rails_mol_component_topk_capacity": (C.c_int32, [_SHAPE_P, C.c_int32, C.c_int64, C.c_int32]),
     "rails_mol_component_topk_workspace_bytes": (C.c_size_t, [_SHAPE_P, C.c_int32, C.c_int64, C.c_int32]),
     "rails_mol_component_topk": (C.c_int, [_SHAPE_P, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_size_t,
-                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rails_mol_component_score": (
         C.c_int,
         [_SHAPE_P, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p],

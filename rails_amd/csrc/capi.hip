@@ -472,15 +472,16 @@ size_t rails_mol_component_table_bytes(const rails_mol_shape* s, int64_t n_items
   return (size_t)n_items * (size_t)s->item_dot_product_groups * (size_t)s->dot_product_dimension * 2;
 }
 
-int rails_mol_component_build(const rails_mol_shape* s, const float* index, int64_t n_items, void* table, void* stream) {
+int rails_mol_component_build(const rails_mol_shape* s, const float* index, int64_t n_items, void* table, int64_t n_total, int64_t first_item,
+                              void* stream) {
   g_err[0] = '\0';
   if (!shape_ok(s)) return RAILS_EINVAL;
   if (s->dot_product_dimension % 8 != 0) { set_error("component_build: d must be a multiple of 8"); return RAILS_ENOTSUP; }
-  if (n_items < 0) { set_error("component_build: n_items < 0"); return RAILS_EINVAL; }
+  if (n_items < 0 || first_item < 0 || first_item + n_items > n_total) { set_error("component_build: items [%lld, %lld) outside a table of %lld", (long long)first_item, (long long)(first_item + n_items), (long long)n_total); return RAILS_EINVAL; }
   if (n_items == 0) return RAILS_OK;
   if (!index || !table) { set_error("component_build: NULL pointer"); return RAILS_EINVAL; }
   if (is_split(*s)) { set_error("component_build: needs an fp32-format item index (build one with precision = RAILS_PRECISION_FP32)"); return RAILS_ENOTSUP; }
-  return fail(component_build(*s, index, n_items, table, (hipStream_t)stream), "component_build");
+  return fail(component_build(*s, index, n_items, table, n_total, first_item, (hipStream_t)stream), "component_build");
 }
 
 size_t rails_mol_component_topk_workspace_bytes(const rails_mol_shape* s, int32_t batch, int64_t n_items, int32_t k_group) {
@@ -488,9 +489,14 @@ size_t rails_mol_component_topk_workspace_bytes(const rails_mol_shape* s, int32_
   return component_topk_workspace_bytes(*s, batch, n_items, k_group);
 }
 
+int32_t rails_mol_component_topk_capacity(const rails_mol_shape* s, int32_t batch, int64_t n_items, int32_t k_group) {
+  if (!shape_ok(s) || batch <= 0) return 0;
+  return component_topk_capacity(*s, batch, n_items, k_group);
+}
+
 int rails_mol_component_topk(const rails_mol_shape* s, const float* eq, int32_t batch, const void* table, int64_t n_items,
                              int32_t k_group, void* workspace, size_t workspace_bytes, float* out_scores,
-                             int64_t* out_positions, int32_t* out_counts, void* stream) {
+                             int64_t* out_positions, int32_t* out_counts, int32_t* out_of_range, void* stream) {
   g_err[0] = '\0';
   if (!shape_ok(s)) return RAILS_EINVAL;
   if (batch < 0 || n_items < 0 || k_group < 0) { set_error("component_topk: negative size"); return RAILS_EINVAL; }
@@ -500,7 +506,7 @@ int rails_mol_component_topk(const rails_mol_shape* s, const float* eq, int32_t 
   const int cu = compute_units();
   if (cu <= 0) { set_error("component_topk: no HIP device"); return RAILS_ELAUNCH; }
   const int r = component_topk(*s, eq, batch, table, n_items, k_group, workspace, workspace_bytes, out_scores, out_positions,
-                               out_counts, cu, (hipStream_t)stream);
+                               out_counts, out_of_range, cu, (hipStream_t)stream);
   return r == kOk ? r : fail(r, "component_topk");
 }
 

@@ -80,6 +80,12 @@ constexpr int kSampleGrid = 256;      // workgroups of a sample launch: 1 024 wa
 
 struct CoarseScanArgs {
   const float* eq; int B, PQ, d, avg;
+  // GROUPS (round 6: the per-component scans of MoLNaiveTopK / MoLCombTopK run on this kernel): groups > 1 = one table per item group m
+  // (blockIdx.y), group_stride elements apart, the SAME query rows against each; comp = 1: the query rows are the B * P_Q sub-embeddings
+  // bf16(Eq[b, i, :]) themselves (no sum over the groups).  Row (q, m) of every per-row quantity -- thresholds, sample maxima, scores,
+  // candidate lists -- is q * groups + m.  groups = 1, comp = 0: the coarse pass of MoLAvgTopK.
+  int groups, comp; int64_t group_stride;
+  int no_hits;                          // RAILS_COMP_DEBUG=1 (measurement): the select scan with every threshold at +inf -- its cost without candidates
   const unsigned short* qfrag;          // the queries' A fragments, made once by workgroup 0 of the sample scan (NULL: every workgroup makes them from eq)
   const unsigned short* table; int64_t n;
   float* scores; int64_t ld;            // kScanAll: scores[b * ld + item]
@@ -143,6 +149,28 @@ __device__ __forceinline__ void stage_flush_mixed(volatile StageEntry* st, volat
   if (lane == 0) *cnt = 0u;
 }
 
+// The same staging with the wave's fill count in a scalar register (component scans, round 6: a hit every few blocks): no LDS atomic and no
+// LDS read on the way -- slots from a ballot's prefix count, the entries written and forgotten; the flush reads them back (DS operations of a
+// wave execute in issue order).  `sel` lanes append (key, orow, sub).
+__device__ __forceinline__ void stage_push_reg(volatile StageEntry* st, unsigned int& staged, bool sel, unsigned long long key, unsigned int orow, int sub,
+                                               unsigned long long* keys, unsigned int* counts, int cap, int lane) {
+  const unsigned long long m = __ballot(sel);
+  if (m == 0ull) return;
+  const unsigned int slot = staged + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
+  if (sel) {
+    if (slot < (unsigned int)kStage) { st[slot].key = key; st[slot].orow = orow; st[slot].pad = (unsigned int)sub; }
+    else append_candidate(keys, counts, cap, sub, orow, key);      // list full: straight to global
+  }
+  staged += (unsigned int)__popcll(m);
+}
+__device__ __forceinline__ void stage_flush_reg(volatile StageEntry* st, unsigned int& staged, int lane, unsigned long long* keys, unsigned int* counts, int cap,
+                                                unsigned int at_least) {
+  if (staged < at_least || staged == 0u) return;      // wave-uniform
+  const unsigned int n = staged < (unsigned int)kStage ? staged : (unsigned int)kStage;
+  for (unsigned int e = lane; e < n; e += 64) append_candidate(keys, counts, cap, (int)st[e].pad, st[e].orow, st[e].key);
+  staged = 0u;
+}
+
 // Pre-test of the select scan: the accumulator STARTS at minus the pre-test bound of its (query row, register), so "some score of
 // this lane reaches its bound" is "some accumulator has a clear sign bit" -- an unsigned minimum over the sixteen registers (seven
 // v_min3_u32 and a v_min_u32) and one compare per tile, instead of sixteen compares and sixteen mask ORs.  The bound is one bf16
@@ -183,13 +211,23 @@ __device__ __forceinline__ void coarse_query_element(const float* __restrict__ e
   const int qt = b >> 5, row = b & 31, c = dd >> 4, h = (dd >> 3) & 1, j = dd & 7;
   frag[(((size_t)qt * DC + c) * 64 + h * 32 + row) * 8 + j] = (unsigned short)(__float_as_uint(v) >> 16);
 }
+// component mode: element i = (query row = b * P_Q + group, dimension dd) of bf16(Eq) itself
+__device__ __forceinline__ void component_query_element(const float* __restrict__ eq, int R, int d, int i, unsigned short* frag) {
+  const int DC = d / 16;
+  const int row = i / d, dd = i - row * d;
+  const float v = row < R ? bf16_rn(eq[(int64_t)row * d + dd]) : 0.0f;
+  const int qt = row >> 5, rr = row & 31, c = dd >> 4, h = (dd >> 3) & 1, j = dd & 7;
+  frag[(((size_t)qt * DC + c) * 64 + h * 32 + rr) * 8 + j] = (unsigned short)(__float_as_uint(v) >> 16);
+}
 __device__ __forceinline__ void quantise_query(const unsigned short* qfrag, int DC, int d, int q, signed char* q8, float* qmeta);   // int8 pre-filter, below
 
-template <int DC, int MODE, bool NT = false>   // DC = d / 16 K chunks; NT: non-temporal table loads
-__global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MODE == kScanSelect ? RAILS_SCAN_WAVES : 2, MODE == kScanSelect ? RAILS_SCAN_WAVES : 2))) void coarse_scan_kernel(CoarseScanArgs a) {
+template <int DC, int MODE, bool NT = false, int QTS = kSampleMaxQT, bool COMP = false>   // DC = d / 16 K chunks; NT: non-temporal table loads; QTS: query tiles a sample launch keeps maxima for; COMP: the component scans' select / sample blocks
+__global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu((MODE == kScanSelect && !COMP) ? RAILS_SCAN_WAVES : 2, (MODE == kScanSelect && !COMP) ? RAILS_SCAN_WAVES : 2))) void coarse_scan_kernel(CoarseScanArgs a) {
   MOL_RUN_IF(a.run_if);
   extern __shared__ __attribute__((aligned(16))) unsigned short qfrag[];   // [n_qt][DC][64 lanes][8] bf16, then thr
-  const int d = a.d, B = a.B;
+  const int d = a.d, B = a.comp ? a.B * a.PQ : a.B;      // B: query ROWS from here on
+  const int gm = blockIdx.y, groups = a.groups;          // item group of this workgroup
+  const unsigned short* const table = a.table + (int64_t)gm * a.group_stride;
   const int n_qt = (B + 31) / 32;
   float* thr_s = reinterpret_cast<float*>(qfrag + (size_t)n_qt * DC * 64 * 8);   // [n_qt * 32]
   __shared__ StageEntry stage_s[kScanThreads / 64][kStage];
@@ -199,19 +237,21 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
   if (a.qfrag) {   // 16 bytes per thread and step instead of P_Q dependent loads per element (2 048 workgroups each made them)
     for (int i = threadIdx.x; i < n_qt * DC * 64; i += kScanThreads)
       reinterpret_cast<bf16x8*>(qfrag)[i] = reinterpret_cast<const bf16x8*>(a.qfrag)[i];
+  } else if (a.comp) {
+    for (int i = threadIdx.x; i < n_qt * 32 * d; i += kScanThreads) component_query_element(a.eq, B, d, i, qfrag);
   } else {
     for (int i = threadIdx.x; i < n_qt * 32 * d; i += kScanThreads) coarse_query_element(a.eq, B, a.PQ, d, a.avg, i, qfrag);
   }
   float* ntlo_s = thr_s + n_qt * 32;                                              // [n_qt * 32]: minus the pre-test bound
   if constexpr (MODE == kScanSelect)
     for (int i = threadIdx.x; i < n_qt * 32; i += kScanThreads) {
-      const float thr = i < B ? a.thr[(int64_t)i * a.thr_stride] : INFINITY;
+      const float thr = (i < B && !a.no_hits) ? a.thr[((int64_t)i * groups + gm) * a.thr_stride] : INFINITY;
       thr_s[i] = thr;
       ntlo_s[i] = -coarse_unorderable(coarse_orderable(thr) - 0x10000u);
     }
   __syncthreads();
   if constexpr (MODE == kScanSample) {
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
       if (a.qfrag_out)
         for (int i = threadIdx.x; i < n_qt * DC * 64; i += kScanThreads) reinterpret_cast<bf16x8*>(a.qfrag_out)[i] = reinterpret_cast<const bf16x8*>(qfrag)[i];
       for (int i = threadIdx.x; i < a.n_zero; i += kScanThreads) a.zero_words[i] = 0u;
@@ -231,7 +271,8 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
   // One trip = TU item tiles of a wave, held as B fragments in registers.  The trips are DOUBLE-BUFFERED: the 16-byte loads of
   // the next trip are issued before the current one is scored, so a wave always has a trip of table bytes in flight (with one
   // trip per wave and two waves per SIMD only 4 MB of the chip's reads were outstanding: 4.6 TB/s by Little's law).
-  constexpr int TU = (MODE == kScanSelect && RAILS_SCAN_TU > 0) ? RAILS_SCAN_TU : (MODE == kScanAll ? (DC <= 4 ? 2 : 1) : (DC <= 2 ? 4 : (DC <= 4 ? 2 : 1)));   // the score stores of kScanAll hold 16 addresses per tile
+  constexpr int TU = (MODE == kScanSample && QTS > kSampleMaxQT) ? (DC <= 2 ? 2 : 1)      // eight row tiles of running maxima are 128 registers: shorter trips
+                     : (MODE == kScanSelect && RAILS_SCAN_TU > 0) ? RAILS_SCAN_TU : (MODE == kScanAll ? (DC <= 4 ? 2 : 1) : (DC <= 2 ? 4 : (DC <= 4 ? 2 : 1)));   // the score stores of kScanAll hold 16 addresses per tile
   struct Trip {
     bf16x8 Bv[TU][DC];
     int64_t item[TU];
@@ -244,7 +285,7 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
       T.in[u] = (w0 + u) < n_work && item < a.n;
       if (!T.in[u]) item = a.n - 1;
       T.item[u] = item;
-      const unsigned short* rowp = a.table + item * d + 8 * h;
+      const unsigned short* rowp = table + item * d + 8 * h;
 #pragma unroll
       for (int c = 0; c < DC; ++c) {
         if constexpr (NT) T.Bv[u][c] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(rowp + 16 * c));
@@ -304,7 +345,7 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
             const float thr = thr_s[q];
             const float sc = bf16_rn(mine[r * 64]);   // an un-rounded sum at or above the bound may round up to thr
             if (q < B && sc >= thr)
-              stage_push(stage_s[wave], &stage_n[wave], a.keys, a.counts, a.cap, (int)(t % kSubLists), (unsigned int)q,
+              stage_push(stage_s[wave], &stage_n[wave], a.keys, a.counts, a.cap, (int)(t % kSubLists), (unsigned int)(q * groups + gm),
                          ((unsigned long long)coarse_orderable(sc) << 32) | (unsigned int)(~(unsigned int)item));
           }
         }
@@ -324,19 +365,42 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
   // sample's top r fell into one group (r^2 / 2 groups expected: 0.02 for r = 40 and 32 768 groups).  It replaces B * n / stride
   // two-byte stores and their read-back by the selection (64 + 64 MB per batch of 32 on a 125 M-item shard: 40 + 48 us) with a
   // 2 MB block of maxima.
-  cf32x16 mx[MODE == kScanSample ? kSampleMaxQT : 1];
+  cf32x16 mx[MODE == kScanSample ? QTS : 1];
   if constexpr (MODE == kScanSample) {
 #pragma unroll
-    for (int qt = 0; qt < kSampleMaxQT; ++qt)
+    for (int qt = 0; qt < QTS; ++qt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx[qt][r] = -INFINITY;
   }
+  unsigned int staged = 0u;      // COMP select: entries in this wave's stage (wave-uniform)
   auto score_trip = [&](int64_t w0, const Trip& T) {
     if constexpr (MODE == kScanSample) {
 #pragma unroll
-      for (int qt = 0; qt < kSampleMaxQT; ++qt) {
+      for (int qt = 0; qt < QTS; ++qt) {
         if (qt < n_qt) {
           if (n_qt > 1) load_query_tile(qt, A, ntlo);
+          if constexpr (COMP) {
+            // whole trips inside the corpus (all but a wave's last): the maxima of two tiles per v_max3 -- 8 VALU instructions per block
+            // instead of 32 (an add and a max per score), which is what bounds this launch at 256 query rows
+            bool whole = w0 + TU <= n_work;
+#pragma unroll
+            for (int u = 0; u < TU; ++u) whole = whole && T.in[u];
+            if (__all(whole)) {
+              static_assert(TU == 1 || TU % 2 == 0, "tile pairs");
+#pragma unroll
+              for (int u = 0; u < TU; u += 2) {
+                cf32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+                for (int c = 0; c < DC; ++c) {
+                  acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c], T.Bv[u][c], acc0, 0, 0, 0);
+                  if constexpr (TU > 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c], T.Bv[u + (TU > 1 ? 1 : 0)][c], acc1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx[qt][r] = TU > 1 ? fmaxf(fmaxf(mx[qt][r], acc0[r]), acc1[r]) : fmaxf(mx[qt][r], acc0[r]);
+              }
+              continue;
+            }
+          }
 #pragma unroll
           for (int u = 0; u < TU; ++u) {
             cf32x16 acc = {0};
@@ -347,6 +411,46 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
 #pragma unroll
               for (int r = 0; r < 16; ++r) mx[qt][r] = fmaxf(mx[qt][r], acc[r] + pen);
             }
+          }
+        }
+      }
+      return;
+    }
+    if constexpr (COMP && MODE == kScanSelect) {
+      // Component scans: 256 query rows (eight row tiles walk over every trip) and a candidate in every fifth to fifteenth block.
+      unsigned long long in_m[TU];      // lanes whose item of tile u is inside the corpus (all of them but on a ragged last tile)
+#pragma unroll
+      for (int u = 0; u < TU; ++u) in_m[u] = __ballot(T.in[u]);
+      for (int qt = 0; qt < n_qt; ++qt) {
+        if (n_qt > 1) load_query_tile(qt, A, ntlo);
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+          // pre-test as in the coarse scan (accumulator started at minus the bound, one sign test over the sixteen registers: 9 VALU
+          // instructions per block; sixteen compares into scalar masks measured 2.2 x the whole scan's time) ...
+          cf32x16 pre = ntlo;
+#pragma unroll
+          for (int c = 0; c < DC; ++c) pre = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c], T.Bv[u][c], pre, 0, 0, 0);
+          if (__any(any_sign_clear(pre))) {
+            // ... and a block that fires (one in five to fifteen here, where the coarse scan's fire once in a hundred) is scored again from
+            // zero -- the materialising path's bits -- and walked register by register through the compares' scalar lane masks: no trip
+            // through LDS to index a register, no LDS counter, no second look at the thresholds
+            cf32x16 acc = {0};
+#pragma unroll
+            for (int c = 0; c < DC; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c], T.Bv[u][c], acc, 0, 0, 0);
+            const int64_t t = (w0 + u) * step;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const unsigned long long mk = __builtin_amdgcn_fcmpf(acc[r], -ntlo[r], 3 /* oge */) & in_m[u];
+              if (mk != 0ull) {      // scalar
+                const float sc = bf16_rn(acc[r]);     // an un-rounded sum at or above the bound may round up to the threshold
+                const float thr = coarse_unorderable(coarse_orderable(-ntlo[r]) + 0x10000u);
+                const int q = qt * 32 + acc_row(r, h);
+                const bool keep = T.in[u] && acc[r] >= -ntlo[r] && sc >= thr && q < B;
+                stage_push_reg(stage_s[wave], staged, keep, ((unsigned long long)coarse_orderable(sc) << 32) | (unsigned int)(~(unsigned int)T.item[u]),
+                               (unsigned int)(q * groups + gm), (int)(t % kSubLists), a.keys, a.counts, a.cap, lane);
+              }
+            }
+            stage_flush_reg(stage_s[wave], staged, lane, a.keys, a.counts, a.cap, 64u);
           }
         }
       }
@@ -369,7 +473,7 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int q = qt * 32 + acc_row(r, h);
-              if (q < B && T.in[u]) a.scores[(int64_t)q * a.ld + colx] = bf16_rn(acc[r]);
+              if (q < B && T.in[u]) a.scores[((int64_t)q * groups + gm) * a.ld + colx] = bf16_rn(acc[r]);
             }
           }
         }
@@ -399,42 +503,90 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu(MO
     w0 = w1;
   }
   }
-  if constexpr (MODE == kScanSelect) stage_flush_mixed(stage_s[wave], &stage_n[wave], lane, a.keys, a.counts, a.cap, 1u);
+  if constexpr (MODE == kScanSelect && COMP) stage_flush_reg(stage_s[wave], staged, lane, a.keys, a.counts, a.cap, 1u);
+  else if constexpr (MODE == kScanSelect) stage_flush_mixed(stage_s[wave], &stage_n[wave], lane, a.keys, a.counts, a.cap, 1u);
   if constexpr (MODE == kScanSample) {   // a wave that saw no tile writes -inf: the row of maxima has no holes
 #pragma unroll
-    for (int qt = 0; qt < kSampleMaxQT; ++qt)
+    for (int qt = 0; qt < QTS; ++qt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int q = qt * 32 + acc_row(r, h);
-        if (q < B) a.scores16[(int64_t)q * a.ld + gw * 32 + x] = (unsigned short)(__float_as_uint(bf16_rn(mx[qt][r])) >> 16);
+        if (q < B) a.scores16[((int64_t)q * groups + gm) * a.ld + gw * 32 + x] = (unsigned short)(__float_as_uint(bf16_rn(mx[qt][r])) >> 16);
       }
   }
 }
 
+constexpr int kSampleMaxQTComp = 8;   // ... and of a component sample launch: B * P_Q <= 256 query rows
+
 template <int MODE>
 static int launch_coarse_scan(const CoarseScanArgs& a, hipStream_t stream) {
-  const int n_qt = (a.B + 31) / 32;
+  const int rows = a.comp ? a.B * a.PQ : a.B;
+  const int groups = a.groups > 0 ? a.groups : 1;
+  const int n_qt = (rows + 31) / 32;
   const int dc = a.d / 16;
   const size_t lds = (size_t)n_qt * dc * 64 * 8 * sizeof(unsigned short) + 2 * (size_t)n_qt * 32 * sizeof(float);
-  if (lds > 64 * 1024) { set_error("coarse scan: batch %d x d %d does not fit LDS", a.B, a.d); return kErrUnsupported; }
+  if (lds > 96 * 1024) { set_error("coarse scan: %d query rows x d %d do not fit LDS", rows, a.d); return kErrUnsupported; }
   const int64_t n_tiles = (a.n + 31) >> 5;
   const int64_t step = MODE == kScanSample ? a.stride : 1;
   const int64_t n_work = (n_tiles + step - 1) / step;
   constexpr int tu = MODE != kScanSelect ? 2 : 4;   // tiles per trip at d = 32 (fewer at larger d: then some waves get no trip)
   int64_t grid = (n_work + 4 * tu - 1) / (4 * tu);
   static const int64_t grid_cap = [] { const char* e = getenv("RAILS_SCAN_GRID"); const int64_t v = e ? atoll(e) : 0; return v > 0 ? v : (int64_t)2048; }();
-  if (grid > grid_cap) grid = grid_cap;     // 2048: 8 workgroups of 4 waves per CU
+  const int64_t cap_g = (grid_cap + groups - 1) / groups;   // 2048 workgroups over all groups: 8 workgroups of 4 waves per CU
+  if (grid > cap_g) grid = cap_g;
+  const bool wide = a.comp && n_qt > kSampleMaxQT;
   if constexpr (MODE == kScanSample) {
-    if (n_qt > kSampleMaxQT) { set_error("coarse sample scan: batch %d exceeds %d queries", a.B, 32 * kSampleMaxQT); return kErrUnsupported; }
-    grid = a.ld / (32 * (kScanThreads / 64));   // the plan's: every wave writes its 32 columns of the (B, ld) block of maxima
+    if (n_qt > (a.comp ? kSampleMaxQTComp : kSampleMaxQT)) { set_error("coarse sample scan: %d query rows exceed %d", rows, 32 * (a.comp ? kSampleMaxQTComp : kSampleMaxQT)); return kErrUnsupported; }
+    grid = a.ld / (32 * (kScanThreads / 64));   // the plan's: every wave writes its 32 columns of the row's block of maxima
   }
   if (grid < 1) return kOk;
+  CoarseScanArgs b = a;
+  b.groups = groups;
   auto go = [&](auto nt) {
     constexpr bool NT = decltype(nt)::value;
+    auto fire = [&](auto kernel) {
+      if (lds > 48 * 1024 &&
+          hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)
+        return false;
+      hipLaunchKernelGGL(kernel, dim3((unsigned)grid, (unsigned)groups), dim3(kScanThreads), lds, stream, b);
+      return true;
+    };
+    if constexpr (MODE == kScanSample) {
+      if (a.comp) {      // the component sample: up to eight row tiles of running maxima, two tiles per v_max3
+        if (wide) {
+          switch (dc) {
+            case 2: return fire(&coarse_scan_kernel<2, MODE, NT, kSampleMaxQTComp, true>);
+            case 4: return fire(&coarse_scan_kernel<4, MODE, NT, kSampleMaxQTComp, true>);
+            case 8: return fire(&coarse_scan_kernel<8, MODE, NT, kSampleMaxQTComp, true>);
+            default: return false;
+          }
+        }
+        switch (dc) {
+          case 2: return fire(&coarse_scan_kernel<2, MODE, NT, kSampleMaxQT, true>);
+          case 4: return fire(&coarse_scan_kernel<4, MODE, NT, kSampleMaxQT, true>);
+          case 8: return fire(&coarse_scan_kernel<8, MODE, NT, kSampleMaxQT, true>);
+          default: return false;
+        }
+      }
+    }
+    if constexpr (MODE == kScanSelect) {
+      // RAILS_COMP_SELECT=1 (measurement): the select block that walks a fired block's registers by the compares' scalar masks.  Measured at
+      // amzn-books, B = 32, k_g = 5, stride 4: 198 us (116 without candidates, at two waves per SIMD) against 162 (96) for the coarse scan's
+      // own block at three waves -- the default
+      static const bool comp_block = [] { const char* e = getenv("RAILS_COMP_SELECT"); return e && atoi(e) == 1; }();
+      if (a.comp && comp_block) {
+        switch (dc) {
+          case 2: return fire(&coarse_scan_kernel<2, MODE, NT, kSampleMaxQT, true>);
+          case 4: return fire(&coarse_scan_kernel<4, MODE, NT, kSampleMaxQT, true>);
+          case 8: return fire(&coarse_scan_kernel<8, MODE, NT, kSampleMaxQT, true>);
+          default: return false;
+        }
+      }
+    }
     switch (dc) {
-      case 2: hipLaunchKernelGGL((coarse_scan_kernel<2, MODE, NT>), dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a); return true;
-      case 4: hipLaunchKernelGGL((coarse_scan_kernel<4, MODE, NT>), dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a); return true;
-      case 8: hipLaunchKernelGGL((coarse_scan_kernel<8, MODE, NT>), dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a); return true;
+      case 2: return fire(&coarse_scan_kernel<2, MODE, NT>);
+      case 4: return fire(&coarse_scan_kernel<4, MODE, NT>);
+      case 8: return fire(&coarse_scan_kernel<8, MODE, NT>);
       default: return false;
     }
   };
@@ -458,7 +610,7 @@ int coarse_score(const Shape& s, const float* eq, int B, int avg, const void* ta
                  hipStream_t stream, const int32_t* run_if) {
   if (B <= 0 || n <= 0) return kOk;
   CoarseScanArgs a{};
-  a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.d = s.dot_product_dimension; a.avg = avg;
+  a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.d = s.dot_product_dimension; a.avg = avg; a.groups = 1;
   a.table = static_cast<const unsigned short*>(table); a.n = n; a.scores = scores; a.ld = ld; a.stride = 1;
   a.run_if = run_if;
   return launch_coarse_scan<kScanAll>(a, stream);
@@ -476,20 +628,6 @@ int coarse_score(const Shape& s, const float* eq, int B, int avg, const void* ta
 //   4. row_select over the candidate keys: the K' largest, ties by position -- exactly what top-K' over the materialised
 //      scores returns, PROVIDED K' <= counts[b] <= cap for every query.  counts come back to the caller, who falls back
 //      to the materialising path otherwise (heavy ties at the threshold, adversarial item order).
-// out[b] = candidates of query b, or cap + 1 when one of its sub-lists overflowed (the caller then falls back)
-__global__ void coarse_counts_kernel(const unsigned int* __restrict__ counts, int B, int cap, int32_t* __restrict__ out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  unsigned int total = 0;
-  bool over = false;
-  for (int sub = 0; sub < kSubLists; ++sub) {
-    const unsigned int c = counts[b * kSubLists + sub];
-    total += c;
-    over |= c > (unsigned int)(cap / kSubLists);
-  }
-  out[b] = over ? cap + 1 : (int32_t)total;
-}
-
 struct CoarseTopkPlan { int stride, r, cap; bool sample16; int64_t n_sample; size_t off_keys, off_sample, off_top_s, off_top_i, off_ws, off_qfrag, off_q8, off_qmeta, total, topk_ws; };
 
 static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
@@ -498,9 +636,12 @@ static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 #define RAILS_SAMPLE16 1   // 0: fp32 threshold samples (measurement)
 #endif
 // group_max: the sample is the coarse scan's block of per-wave running maxima (kScanSample above) instead of every sampled score
-static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p, bool group_max = false) {
+// comp_rows > 0: the plan of the component scans (B = all B * P_Q * P_X rows; comp_rows = the B * P_Q query rows of one item group): a denser
+// sample (the threshold's Poisson noise sets how many candidates the select scan appends: ~k + 6 sqrt(k stride) per row, and the appends are
+// what that scan costs at 2 048 rows), a 32-workgroup block of maxima per item group and 2 048-slot lists
+static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p, bool group_max = false, int comp_rows = 0) {
   if (k_prime < 1 || k_prime > 4096 || n < k_prime) return false;
-  if (group_max && B > 32 * kSampleMaxQT) return false;
+  if (group_max && (comp_rows > 0 ? comp_rows > 32 * kSampleMaxQTComp : B > 32 * kSampleMaxQT)) return false;
   const int64_t n_tiles = (n + 31) >> 5;
   // sample every stride-th tile: m = ~8 expected hits above the true K'-th score for large K', never denser than 1/64 of
   // the table (small K' just get fewer expected hits, and r below keeps the miss probability ~1e-9).  m = 16 (stride K'/16)
@@ -510,6 +651,10 @@ static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p, b
   int stride = k_prime / 8;
   if (stride < 64) stride = 64;
   if (stride > 256) stride = 256;
+  if (comp_rows > 0) {
+    static const int forced = [] { const char* e = getenv("RAILS_COMP_STRIDE"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 256 ? v : 0; }();   // measurement override
+    stride = forced ? forced : 4;      // sample + select scan at amzn-books, B = 32, k_g = 5 (round-6 kernels before the COMP select block): 16 -> 42 + 228 us, 4 -> 81 + 162, 1 -> 237 + 136
+  }
   // r = the smallest rank with P(Poisson(m) >= r) <= e^-m (e m / r)^r < 1e-9 (Chernoff), and at least 2m + 4 sqrt(m):
   // the r-th largest sample score is then below the true K'-th score except with negligible probability (and a miss
   // only costs the fallback), while ~r * stride items are expected at or above it
@@ -532,7 +677,7 @@ static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p, b
     const int64_t n_work = (n_tiles + stride - 1) / stride;
     const int waves_per_wg = kScanThreads / 64;
     int64_t grid = (n_work + 2 * waves_per_wg - 1) / (2 * waves_per_wg);
-    if (grid > kSampleGrid) grid = kSampleGrid;
+    if (grid > (comp_rows > 0 ? 32 : kSampleGrid)) grid = comp_rows > 0 ? 32 : kSampleGrid;
     const int64_t trips = (n_work + 3) / 4;   // a wave's trip is up to four tiles (d = 32)
     const int64_t groups = (trips < grid * waves_per_wg ? trips : grid * waves_per_wg) * 32;
     if (groups < 4 * (int64_t)r) return false;
@@ -540,7 +685,7 @@ static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p, b
     p->n_sample = grid * waves_per_wg * 32;
   }
   int cap = 8 * k_prime;
-  if (cap < 4096) cap = 4096;
+  if (cap < (comp_rows > 0 ? 2048 : 4096)) cap = comp_rows > 0 ? 2048 : 4096;
   if (cap > 24 * 1024) cap = 24 * 1024;
   cap = (cap + kSubLists * 4 - 1) / (kSubLists * 4) * (kSubLists * 4);
   p->cap = cap;
@@ -555,7 +700,7 @@ static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p, b
   p->off_top_i = o; o += align256(sizeof(int64_t) * (size_t)B * r);
   p->topk_ws = topk_workspace_bytes(B, p->n_sample, r);
   p->off_ws = o; o += align256(p->topk_ws);
-  p->off_qfrag = o; o += align256(sizeof(unsigned short) * (size_t)((B + 31) / 32) * 32 * 128);   // coarse_topk's query fragments (d <= 128)
+  p->off_qfrag = o; o += align256(sizeof(unsigned short) * (size_t)(((comp_rows > 0 ? comp_rows : B) + 31) / 32) * 32 * 128);   // the query fragments (d <= 128)
   p->off_q8 = o; o += align256((size_t)((B + 31) / 32) * 32 * 128);                                // the same as int8 (pre-filter)
   p->off_qmeta = o; o += align256(sizeof(float) * 2 * (size_t)((B + 31) / 32) * 32);
   p->total = o;
@@ -886,7 +1031,7 @@ int coarse_topk(const Shape& s, const float* eq, int B, int avg, const void* tab
   // the r-th largest of each row of maxima, select scan, key selection (which also reports the counts and raises out_flag).  The candidate lists are
   // not zeroed: the key selection reads the filled slots only.
   CoarseScanArgs a{};
-  a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.d = s.dot_product_dimension; a.avg = avg;
+  a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.d = s.dot_product_dimension; a.avg = avg; a.groups = 1;
   a.table = static_cast<const unsigned short*>(table); a.n = n;
   a.qfrag_out = frag; a.zero_words = counts; a.n_zero = B * kSubLists; a.zero_flag = out_flag;
   signed char* q8 = reinterpret_cast<signed char*>(base + p.off_q8);
@@ -918,11 +1063,16 @@ int coarse_topk(const Shape& s, const float* eq, int B, int avg, const void* tab
 // Per-component candidate generation of MoLNaiveTopK / MoLCombTopK (reference rails/indexing/mol_top_k.py:
 // component table :61-73 and :172-174, scoring :242-255 / :495-506).  For every query group i and item group m the
 // reference scores  bf16(Eq[b,i,:]) . bf16(Ex[x,m,:])  with a bf16 mm and takes the top k_per_group per (b, m) row.
-//   table[x][m][:] = bf16(Ex[x,m,:])                                     2*P_X*d bytes per item, item-major
-//   score[(b*P_Q + i)*P_X + m][x] = bf16( sum_d bf16(Eq[b,i,d]) * table[x][m][d] )   fp32 holding bf16 values
+//   table[m][x][:] = bf16(Ex[x,m,:])                                     2*P_X*d bytes per item, ITEM-GROUP-major (round 6)
+//   score[(b*P_Q + i)*P_X + m][x] = bf16( sum_d bf16(Eq[b,i,d]) * table[m][x][d] )   fp32 holding bf16 values
 // Row order (b, i, m) makes the top-k output reshape to (B, P_Q*P_X*k_g) directly.
+// Round 6: the scans ARE the coarse scan (coarse_scan_kernel with groups = P_X: blockIdx.y picks the item group's table, the B * P_Q
+// sub-embedding rows are the query rows) -- double-buffered trips of tiles, the query tiles walking over a trip in registers, thresholds in
+// the accumulator start -- where rounds 1-5 ran a kernel of their own that re-read a threshold block from LDS for every (item group, query
+// tile) of every tile and took sixteen compares per block (0.40-0.57 ms per batch of 32 at amzn-books: 0.07 of the 356 MB table's HBM
+// time); the table is item-group-major so that a wave streams one group's rows back to back.
 // ---------------------------------------------------------------------------------------------
-__global__ void component_build_kernel(const float* __restrict__ ipack, int64_t n, int PQ, int PX, int d,
+__global__ void component_build_kernel(const float* __restrict__ ipack, int64_t n, int PQ, int PX, int d, int64_t n_total, int64_t first,
                                        unsigned short* __restrict__ table) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int row = PX * d;
@@ -934,197 +1084,79 @@ __global__ void component_build_kernel(const float* __restrict__ ipack, int64_t 
   const int x = (int)(item & 31);
   const float* tEx = ipack + tile * (int64_t)(kTileItems * (PX * d + PQ * PX));
   const int hi = dd / (d / 2), s = dd - hi * (d / 2);
-  table[i] = bf16_bits(tEx[((m * (d / 8) + (s >> 2)) * 64 + hi * 32 + x) * 4 + (s & 3)]);
+  table[((int64_t)m * n_total + first + item) * d + dd] = bf16_bits(tEx[((m * (d / 8) + (s >> 2)) * 64 + hi * 32 + x) * 4 + (s & 3)]);
 }
 
-// The component scan: the coarse scan's structure with P_X B-operands per item (one per item group m) and
-// B * P_Q query rows (A: bf16(Eq[b,i,:]), ceil(B P_Q / 32) row tiles kept in LDS).  Output row (b P_Q + i) P_X + m.
-// In select mode the 16 pre-test bounds of a (row tile, m, lane half) sit contiguously in LDS (4 ds_read_b128).
-struct ComponentScanArgs {
-  const float* eq; int B, PQ, PX, d;
-  const unsigned short* table; int64_t n;
-  float* scores; int64_t ld; int stride;
-  unsigned short* scores16;             // kScanSample: the sample as bf16 bit patterns instead
-  const float* thr; int64_t thr_stride;
-  unsigned long long* keys; int cap;
-  unsigned int* counts;
-  const int32_t* run_if;
-};
-
-template <int DC, int MODE>
-__global__ __launch_bounds__(kScanThreads) void component_scan_kernel(ComponentScanArgs a) {
-  MOL_RUN_IF(a.run_if);
-  extern __shared__ __attribute__((aligned(16))) unsigned short qfrag[];   // [n_qt][DC][64][8] bf16, then bounds
-  const int d = a.d, PX = a.PX;
-  const int R = a.B * a.PQ;                 // query rows
-  const int n_qt = (R + 31) / 32;
-  float* tlo_s = reinterpret_cast<float*>(qfrag + (size_t)n_qt * DC * 64 * 8);   // [n_qt][PX][2][16]
-  __shared__ StageEntry stage_s[kScanThreads / 64][kStage];
-  __shared__ unsigned int stage_n[kScanThreads / 64];
-  if (threadIdx.x < kScanThreads / 64) stage_n[threadIdx.x] = 0u;
-  for (int i = threadIdx.x; i < n_qt * 32 * d; i += kScanThreads) {
-    const int row = i / d, dd = i - row * d;
-    const float v = row < R ? bf16_rn(a.eq[(int64_t)row * d + dd]) : 0.0f;
-    const int qt = row >> 5, rr = row & 31, c = dd >> 4, h = (dd >> 3) & 1, j = dd & 7;
-    qfrag[(((size_t)qt * DC + c) * 64 + h * 32 + rr) * 8 + j] = (unsigned short)(__float_as_uint(v) >> 16);
-  }
-  if constexpr (MODE == kScanSelect) {
-    for (int i = threadIdx.x; i < n_qt * PX * 32; i += kScanThreads) {
-      const int r = i & 15, h = (i >> 4) & 1, m = (i >> 5) % PX, qt = (i >> 5) / PX;
-      const int row = qt * 32 + acc_row(r, h);
-      const float t = row < R ? a.thr[((int64_t)row * PX + m) * a.thr_stride] : INFINITY;
-      tlo_s[i] = coarse_unorderable(coarse_orderable(t) - 0x10000u);   // the bf16 value just below the threshold
-    }
-  }
-  __syncthreads();
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int x = lane & 31, h = lane >> 5;
-  const int64_t n_tiles = (a.n + 31) >> 5;
-  const int64_t step = MODE == kScanSample ? a.stride : 1;
-  const int64_t n_work = (n_tiles + step - 1) / step;
-  const int64_t gw = (int64_t)blockIdx.x * (kScanThreads / 64) + wave, n_waves = (int64_t)gridDim.x * (kScanThreads / 64);
-  for (int64_t w = gw; w < n_work; w += n_waves) {
-    const int64_t t = w * step;
-    int64_t item = t * 32 + x;
-    const bool in = item < a.n;
-    if (!in) item = a.n - 1;
-    for (int m = 0; m < PX; ++m) {
-      const unsigned short* rowp = a.table + (item * PX + m) * d + 8 * h;
-      bf16x8 Bv[DC];
-#pragma unroll
-      for (int c = 0; c < DC; ++c) Bv[c] = *reinterpret_cast<const bf16x8*>(rowp + 16 * c);
-      for (int qt = 0; qt < n_qt; ++qt) {
-        cf32x16 acc = {0};
-#pragma unroll
-        for (int c = 0; c < DC; ++c)
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(qfrag + (((size_t)qt * DC + c) * 64 + lane) * 8),
-                                                        Bv[c], acc, 0, 0, 0);
-        if constexpr (MODE == kScanSelect) {
-          const float4* tl = reinterpret_cast<const float4*>(tlo_s + ((qt * PX + m) * 2 + h) * 16);
-          float tlo[16];
-#pragma unroll
-          for (int v4 = 0; v4 < 4; ++v4) { const float4 f = tl[v4]; tlo[4 * v4] = f.x; tlo[4 * v4 + 1] = f.y; tlo[4 * v4 + 2] = f.z; tlo[4 * v4 + 3] = f.w; }
-          bool hit = false;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) hit |= acc[r] >= tlo[r];
-          if (__any(hit && in)) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const bool maybe = in && acc[r] >= tlo[r];
-              if (__any(maybe)) {
-                const int row = qt * 32 + acc_row(r, h);
-                const float sc = bf16_rn(acc[r]);
-                const float thr = coarse_unorderable(coarse_orderable(tlo[r]) + 0x10000u);
-                if (maybe && row < R && sc >= thr)
-                  stage_push(stage_s[wave], &stage_n[wave], a.keys, a.counts, a.cap, (int)(t % kSubLists), (unsigned int)(row * PX + m),
-                             ((unsigned long long)coarse_orderable(sc) << 32) | (unsigned int)(~(unsigned int)item));
-              }
-            }
-          }
-        } else {
-          const int64_t colx = MODE == kScanSample ? w * 32 + x : item;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = qt * 32 + acc_row(r, h);
-            if (row < R && (in || MODE == kScanSample)) {
-              const float sc = in ? bf16_rn(acc[r]) : -INFINITY;
-              if (MODE == kScanSample && a.scores16) a.scores16[((int64_t)row * PX + m) * a.ld + colx] = (unsigned short)(__float_as_uint(sc) >> 16);
-              else a.scores[((int64_t)row * PX + m) * a.ld + colx] = sc;
-            }
-          }
-        }
-      }
-    }
-    if constexpr (MODE == kScanSelect) stage_flush(stage_s[wave], &stage_n[wave], lane, a.keys, a.counts, a.cap, (int)(t % kSubLists));
-  }
-}
-
-template <int MODE>
-static int launch_component_scan(const ComponentScanArgs& a, hipStream_t stream) {
-  const int n_qt = (a.B * a.PQ + 31) / 32;
-  const int dc = a.d / 16;
-  const size_t lds = (size_t)n_qt * dc * 64 * 8 * sizeof(unsigned short) + (size_t)n_qt * a.PX * 32 * sizeof(float);
-  if (lds > 144 * 1024) { set_error("component scan: batch %d x P_Q %d x d %d does not fit LDS", a.B, a.PQ, a.d); return kErrUnsupported; }
-  const int64_t n_tiles = (a.n + 31) >> 5;
-  const int64_t step = MODE == kScanSample ? a.stride : 1;
-  const int64_t n_work = (n_tiles + step - 1) / step;
-  int64_t grid = (n_work + 3) / 4;
-  if (grid > 2048) grid = 2048;
-  if (grid < 1) return kOk;
-  auto launch = [&](auto kernel) {
-    // query fragments of 8x4x128 at B = 32 are 64 KiB: past the default dynamic-LDS limit
-    if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024) != hipSuccess)
-      return (int)kErrLaunch;
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(kScanThreads), lds, stream, a);
-    return hipGetLastError() == hipSuccess ? (int)kOk : (int)kErrLaunch;
-  };
-  switch (dc) {
-    case 2: return launch(&component_scan_kernel<2, MODE>);
-    case 4: return launch(&component_scan_kernel<4, MODE>);
-    case 8: return launch(&component_scan_kernel<8, MODE>);
-    default: set_error("component scan: d = %d (supported: 32, 64, 128)", a.d); return kErrUnsupported;
-  }
-}
-
-int component_build(const Shape& s, const float* ipack, int64_t n, void* table, hipStream_t stream) {
+int component_build(const Shape& s, const float* ipack, int64_t n, void* table, int64_t n_total, int64_t first, hipStream_t stream) {
   const int64_t total = n * s.item_dot_product_groups * s.dot_product_dimension;
   if (total == 0) return kOk;
   hipLaunchKernelGGL(component_build_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, ipack, n,
-                     s.query_dot_product_groups, s.item_dot_product_groups, s.dot_product_dimension,
+                     s.query_dot_product_groups, s.item_dot_product_groups, s.dot_product_dimension, n_total, first,
                      static_cast<unsigned short*>(table));
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+static void component_args(const Shape& s, const float* eq, int B, const void* table, int64_t n, CoarseScanArgs* a) {
+  *a = CoarseScanArgs{};
+  a->eq = eq; a->B = B; a->PQ = s.query_dot_product_groups; a->d = s.dot_product_dimension; a->avg = 0;
+  a->groups = s.item_dot_product_groups; a->comp = 1; a->group_stride = n * (int64_t)s.dot_product_dimension;
+  a->table = static_cast<const unsigned short*>(table); a->n = n;
 }
 
 int component_score(const Shape& s, const float* eq, int B, const void* table, int64_t n, float* scores, int64_t ld,
                     hipStream_t stream, const int32_t* run_if) {
   if (B <= 0 || n <= 0) return kOk;
-  ComponentScanArgs a{};
-  a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.PX = s.item_dot_product_groups; a.d = s.dot_product_dimension;
-  a.table = static_cast<const unsigned short*>(table); a.n = n; a.scores = scores; a.ld = ld; a.stride = 1;
-  a.run_if = run_if;
-  return launch_component_scan<kScanAll>(a, stream);
+  CoarseScanArgs a;
+  component_args(s, eq, B, table, n, &a);
+  a.scores = scores; a.ld = ld; a.stride = 1; a.run_if = run_if;
+  return launch_coarse_scan<kScanAll>(a, stream);
 }
 
-// Fused per-component top-k_g: the fused coarse top-K' scheme (sample threshold, streaming select, key selection) over
-// the B * P_Q * P_X (query group, item group) rows, instead of a (rows, N) score matrix (5.7 GB at amzn-books, B = 32).
+// Fused per-component top-k_g: the fused coarse top-K' scheme (running-maxima sample, threshold, one select scan into sub-lists, radix key
+// selection: four launches, no memset) over the B * P_Q * P_X (query group, item group) rows, instead of a (rows, N) score matrix (5.7 GB at
+// amzn-books, B = 32).  out_flag (optional): raised when a row's candidate count left [k_group, capacity] (the caller redoes the call on
+// the materialising path); zeroed by the first launch.
 size_t component_topk_workspace_bytes(const Shape& s, int B, int64_t n, int k_group) {
   CoarseTopkPlan p;
-  return coarse_topk_plan(B * s.query_dot_product_groups * s.item_dot_product_groups, n, k_group, &p) ? p.total : 0;
+  return coarse_topk_plan(B * s.query_dot_product_groups * s.item_dot_product_groups, n, k_group, &p, true, B * s.query_dot_product_groups) ? p.total : 0;
 }
 
 int component_topk(const Shape& s, const float* eq, int B, const void* table, int64_t n, int k_group, void* ws, size_t ws_bytes,
-                   float* out_scores, int64_t* out_pos, int32_t* out_counts, int n_cu, hipStream_t stream) {
+                   float* out_scores, int64_t* out_pos, int32_t* out_counts, int32_t* out_flag, int n_cu, hipStream_t stream) {
   const int rows = B * s.query_dot_product_groups * s.item_dot_product_groups;
   CoarseTopkPlan p;
-  if (!coarse_topk_plan(rows, n, k_group, &p)) { set_error("component_topk: unsupported size (k = %d, n = %lld)", k_group, (long long)n); return kErrUnsupported; }
+  if (!coarse_topk_plan(rows, n, k_group, &p, true, B * s.query_dot_product_groups)) { set_error("component_topk: unsupported size (k = %d, n = %lld)", k_group, (long long)n); return kErrUnsupported; }
   if (n >= (1ll << 32)) { set_error("component_topk: n does not fit 32-bit positions; shard the corpus"); return kErrUnsupported; }
   if (ws_bytes < p.total) { set_error("component_topk: workspace too small"); return kErrNoMem; }
   char* base = static_cast<char*>(ws);
   unsigned int* counts = reinterpret_cast<unsigned int*>(base);
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(base + p.off_keys);
-  float* sample = reinterpret_cast<float*>(base + p.off_sample);
+  unsigned short* sample = reinterpret_cast<unsigned short*>(base + p.off_sample);
   float* top_s = reinterpret_cast<float*>(base + p.off_top_s);
   int64_t* top_i = reinterpret_cast<int64_t*>(base + p.off_top_i);
-  if (hipMemsetAsync(base, 0, p.off_sample, stream) != hipSuccess) return kErrLaunch;   // counts + candidate keys
-  ComponentScanArgs a{};
-  a.eq = eq; a.B = B; a.PQ = s.query_dot_product_groups; a.PX = s.item_dot_product_groups; a.d = s.dot_product_dimension;
-  a.table = static_cast<const unsigned short*>(table); a.n = n;
-  a.scores = p.sample16 ? nullptr : sample; a.scores16 = p.sample16 ? reinterpret_cast<unsigned short*>(sample) : nullptr;
-  a.ld = p.n_sample; a.stride = p.stride;
-  int rc = launch_component_scan<kScanSample>(a, stream);
+  unsigned short* frag = reinterpret_cast<unsigned short*>(base + p.off_qfrag);
+  CoarseScanArgs a;
+  component_args(s, eq, B, table, n, &a);
+  a.qfrag_out = frag; a.zero_words = counts; a.n_zero = rows * kSubLists; a.zero_flag = out_flag;
+  a.scores16 = sample; a.ld = p.n_sample; a.stride = p.stride;
+  int rc = launch_coarse_scan<kScanSample>(a, stream);
   if (rc != kOk) return rc;
-  rc = topk(a.scores, p.n_sample, rows, p.n_sample, p.r, nullptr, 0, top_s, top_i, base + p.off_ws, p.topk_ws, n_cu, stream, nullptr, 0, 0, a.scores16);
+  (void)top_i; (void)n_cu;
+  rc = bf16_rows_kth(sample, p.n_sample, rows, (int)p.n_sample, p.r, top_s, stream);      // thr[row] = the r-th largest of the row's maxima
   if (rc != kOk) return rc;
-  a.scores = nullptr; a.stride = 1;
-  a.thr = top_s + (p.r - 1); a.thr_stride = p.r; a.keys = keys; a.cap = p.cap; a.counts = counts;
-  rc = launch_component_scan<kScanSelect>(a, stream);
+  a.qfrag = frag; a.qfrag_out = nullptr; a.zero_words = nullptr; a.n_zero = 0; a.zero_flag = nullptr;
+  a.scores16 = nullptr; a.ld = 0; a.stride = 1;
+  a.thr = top_s; a.thr_stride = 1; a.keys = keys; a.cap = p.cap; a.counts = counts;
+  static const int dbg = [] { const char* e = getenv("RAILS_COMP_DEBUG"); return e ? atoi(e) : 0; }();
+  a.no_hits = dbg & 1;
+  rc = launch_coarse_scan<kScanSelect>(a, stream);
   if (rc != kOk) return rc;
-  rc = select_keys(keys, rows, p.cap, k_group, out_scores, out_pos, stream);
-  if (rc != kOk) return rc;
-  hipLaunchKernelGGL(coarse_counts_kernel, dim3((rows + 63) / 64), dim3(64), 0, stream, counts, rows, p.cap, out_counts);
-  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+  return select_sublists(keys, counts, rows, p.cap, kSubLists, k_group, out_scores, out_pos, out_counts, out_flag, stream);
+}
+
+int component_topk_capacity(const Shape& s, int B, int64_t n, int k_group) {
+  CoarseTopkPlan p;
+  return coarse_topk_plan(B * s.query_dot_product_groups * s.item_dot_product_groups, n, k_group, &p, true, B * s.query_dot_product_groups) ? p.cap : 0;
 }
 
 }  // namespace mol

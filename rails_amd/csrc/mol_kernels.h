@@ -118,7 +118,8 @@ size_t coarse_prefilter_bytes(const Shape& s, int64_t n);
 int coarse_prefilter_build(const Shape& s, const void* table, int64_t n, void* prefilter, hipStream_t stream);
 size_t component_topk_workspace_bytes(const Shape& s, int B, int64_t n, int k_group);
 int component_topk(const Shape& s, const float* eq, int B, const void* table, int64_t n, int k_group, void* ws, size_t ws_bytes,
-                   float* out_scores, int64_t* out_pos, int32_t* out_counts, int n_cu, hipStream_t stream);
+                   float* out_scores, int64_t* out_pos, int32_t* out_counts, int32_t* out_flag, int n_cu, hipStream_t stream);
+int component_topk_capacity(const Shape& s, int B, int64_t n, int k_group);
 // ---- HSTU query encoder, eval path (hstu.hip) ----
 int hstu_preprocess(const float* emb, const int64_t* ids, const int64_t* lengths, const float* pos_emb, int B, int N, int D,
                     float scale, float* out, hipStream_t stream);
@@ -142,12 +143,13 @@ int hstu_encode_fused(const float* emb, const int64_t* ids, const int64_t* lengt
                       float eps, float* out, hipStream_t stream);
 int select_keys(const unsigned long long* keys, int rows, int keys_per_row, int k, float* out_scores, int64_t* out_pos,
                 hipStream_t stream);
+int bf16_rows_kth(const unsigned short* rows16, int64_t ld, int n_rows, int n, int r, float* thr, hipStream_t stream);
 int select_sublists(const unsigned long long* keys, const unsigned int* counts, int rows, int cap, int n_sub, int k, float* out_scores,
                     int64_t* out_pos, int32_t* out_counts, int32_t* out_flag, hipStream_t stream);
 int coarse_score(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, float* scores, int64_t ld,
                  hipStream_t stream, const int32_t* run_if = nullptr);
 
-int component_build(const Shape& s, const float* ipack, int64_t n, void* table, hipStream_t stream);
+int component_build(const Shape& s, const float* ipack, int64_t n, void* table, int64_t n_total, int64_t first, hipStream_t stream);
 int component_score(const Shape& s, const float* eq, int B, const void* table, int64_t n, float* scores, int64_t ld,
                     hipStream_t stream, const int32_t* run_if = nullptr);
 int sort_rows_i64(const int64_t* in, int rows, int n, int64_t* out, hipStream_t stream);

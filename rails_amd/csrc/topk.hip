@@ -1154,6 +1154,145 @@ __global__ __launch_bounds__(kRowThreads) void sublist_select_kernel(const SubSe
   }
 }
 
+// ---- the same for MANY SHORT rows (the component scans of MoLNaiveTopK / MoLCombTopK: 2 048 rows of ~50-500 candidates) ----------------
+// One 256-thread workgroup per row -- eight resident per CU, where the 1 024-thread kernel above runs its 2 048 workgroups four deep and
+// requests all `cap` slots of every row (33 MB) before it knows the counts: 58 us for 2 048 rows, 41 of them with no candidate at all.
+// Here the FILLED slots are loaded into LDS and every key's descending rank is counted against the others (broadcast LDS reads; keys are
+// distinct); keys of rank < k go straight to their output slot.  cap <= kSmallCap, k <= cap.
+constexpr int kSmallThreads = 256, kSmallCap = 2048;
+__global__ __launch_bounds__(kSmallThreads) void sublist_rank_kernel(const SubSelArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned long long skeys[kSmallCap];
+  __shared__ unsigned int cnt_s[64], base_s[65];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const int k = a.k, subcap = a.cap / a.n_sub;
+  if (tid < a.n_sub) cnt_s[tid] = a.counts[(int64_t)row * a.n_sub + tid];
+  __syncthreads();
+  if (tid == 0) {
+    unsigned int total = 0u, held = 0u;
+    bool over = false;
+    for (int sub = 0; sub < a.n_sub; ++sub) {
+      const unsigned int c = cnt_s[sub];
+      base_s[sub] = held;
+      total += c;
+      held += c < (unsigned int)subcap ? c : (unsigned int)subcap;
+      over |= c > (unsigned int)subcap;
+    }
+    base_s[a.n_sub] = held;
+    a.out_counts[row] = over ? a.cap + 1 : (int32_t)total;
+    if ((over || total < (unsigned int)k) && a.out_flag) *a.out_flag = 1;
+  }
+  __syncthreads();
+  const int held = (int)base_s[a.n_sub];
+  const unsigned long long* src = a.keys + (int64_t)row * a.cap;
+  for (int i = tid; i < a.cap; i += kSmallThreads) {      // slot i of the row: sub-list i / subcap, filled iff its index is below the count
+    const int sub = i / subcap, j = i - sub * subcap;
+    if ((unsigned int)j < cnt_s[sub] ) skeys[base_s[sub] + j] = src[i];
+  }
+  __syncthreads();
+  for (int i = tid; i < held; i += kSmallThreads) {
+    const unsigned long long mine = skeys[i];
+    int rank = 0;
+    const ulonglong2* p2 = reinterpret_cast<const ulonglong2*>(skeys);
+    for (int j = 0; j < held / 2; ++j) { const ulonglong2 x = p2[j]; rank += x.x > mine ? 1 : 0; rank += x.y > mine ? 1 : 0; }
+    if (held & 1) rank += skeys[held - 1] > mine ? 1 : 0;
+    if (rank < k) {
+      a.out_scores[(int64_t)row * k + rank] = unorderable((unsigned int)(mine >> 32));
+      a.out_pos[(int64_t)row * k + rank] = (int64_t)(~(unsigned int)(mine & 0xFFFFFFFFull));
+    }
+  }
+  for (int j = held + tid; j < k; j += kSmallThreads) {     // a row with fewer than k candidates (redone by the caller): defined filler
+    a.out_scores[(int64_t)row * k + j] = -INFINITY;
+    a.out_pos[(int64_t)row * k + j] = 0;
+  }
+}
+
+// The r-th largest of every row of bf16 bit patterns (the threshold of a fused scan from its block of running maxima), one WAVE per row:
+// the row's 16-bit orderable keys in registers; a 256-bin LDS histogram of (key - row minimum) >> shift, shift such that the row's RANGE
+// spreads over the bins (the maxima of a row share their high byte: a histogram of the high byte itself sent every lane to one bin, 41 us
+// for 2 048 rows; bisecting the sixteen key bits cost 4 000 VALU instructions per row, 38 us), then -- shift > 0 -- one more histogram
+// inside the bin that holds the r-th largest.  thr[row] = that value as fp32: row_select_kernel's r-th output on the same row.
+constexpr int kKthRegs = 64;      // rows of up to 64 * 2 * 64 = 8 192 values
+__global__ __launch_bounds__(256) void bf16_rows_kth_kernel(const unsigned short* __restrict__ rows16, int64_t ld, int n_rows, int n, int r,
+                                                            float* __restrict__ thr) {
+  __shared__ __attribute__((aligned(16))) unsigned int hist[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * 4 + wave;
+  if (row >= n_rows) return;          // (whole waves: no barrier below)
+  unsigned int* h = hist[wave];
+  const unsigned int* src = reinterpret_cast<const unsigned int*>(rows16 + (int64_t)row * ld);      // (ld and the row starts are even: pairs of values)
+  const int n2 = n / 2, regs = (n2 + 63) / 64;
+  unsigned int kv[kKthRegs];
+  auto key16 = [](unsigned int b) -> unsigned int { return (b & 0x8000u) ? (~b & 0xFFFFu) : (b | 0x8000u); };
+  unsigned int mn = 0xFFFFu, mx = 0u;
+#pragma unroll
+  for (int j = 0; j < kKthRegs; ++j) {
+    kv[j] = 0xFFFFFFFFu;                       // no pair here
+    if (j < regs) {
+      const int i = j * 64 + lane;
+      if (i < n2) {
+        const unsigned int p = src[i], k0 = key16(p & 0xFFFFu), k1 = key16(p >> 16);
+        kv[j] = k0 | (k1 << 16);
+        mn = min(mn, min(k0, k1));
+        mx = max(mx, max(k0, k1));
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mn = min(mn, (unsigned int)__shfl_xor((int)mn, o, 64)); mx = max(mx, (unsigned int)__shfl_xor((int)mx, o, 64)); }
+  const unsigned int range = mx - mn;
+  const int shift = range < 256u ? 0 : 32 - __builtin_clz(range) - 8;      // (range >> shift) <= 255
+  auto pick = [&](unsigned int want, unsigned int& left) -> unsigned int {      // the bin holding the want-th largest counted key; left = its rank inside the bin
+    const uint4 c4 = reinterpret_cast<const uint4*>(h)[lane];
+    const unsigned int sum4 = c4.x + c4.y + c4.z + c4.w;
+    unsigned int incl = sum4;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned int t = __shfl_down(incl, o, 64); if (lane + o < 64) incl += t; }
+    unsigned int cum = incl - sum4;
+    const unsigned int c[4] = {c4.x, c4.y, c4.z, c4.w};
+    unsigned int bin = 0xFFFFFFFFu, lf = 0u;
+#pragma unroll
+    for (int b = 3; b >= 0; --b) {
+      if (cum < want && want <= cum + c[b]) { bin = 4u * lane + b; lf = want - cum; }
+      cum += c[b];
+    }
+    const unsigned long long has = __ballot(bin != 0xFFFFFFFFu);
+    const int src_lane = has ? __ffsll((long long)has) - 1 : 0;
+    left = (unsigned int)__shfl((int)lf, src_lane, 64);
+    return (unsigned int)__shfl((int)bin, src_lane, 64);
+  };
+  for (int i = lane; i < 256; i += 64) h[i] = 0u;
+#pragma unroll
+  for (int j = 0; j < kKthRegs; ++j)
+    if (j < regs && kv[j] != 0xFFFFFFFFu) {
+      atomicAdd(&h[((kv[j] & 0xFFFFu) - mn) >> shift], 1u);
+      atomicAdd(&h[((kv[j] >> 16) - mn) >> shift], 1u);
+    }
+  unsigned int left = 0u;
+  const unsigned int b1 = pick((unsigned int)r, left);
+  unsigned int key = mn + (b1 << shift);
+  if (shift > 0) {
+    const unsigned int low = (1u << shift) - 1u;
+    for (int i = lane; i < 256; i += 64) h[i] = 0u;
+#pragma unroll
+    for (int j = 0; j < kKthRegs; ++j)
+      if (j < regs && kv[j] != 0xFFFFFFFFu) {
+        const unsigned int d0 = (kv[j] & 0xFFFFu) - mn, d1 = (kv[j] >> 16) - mn;
+        if ((d0 >> shift) == b1) atomicAdd(&h[d0 & low], 1u);
+        if ((d1 >> shift) == b1) atomicAdd(&h[d1 & low], 1u);
+      }
+    unsigned int left2 = 0u;
+    key += pick(left, left2);
+  }
+  const unsigned int bits = (key & 0x8000u) ? (key & 0x7FFFu) : (~key & 0xFFFFu);
+  if (lane == 0) thr[row] = __uint_as_float(bits << 16);
+}
+int bf16_rows_kth(const unsigned short* rows16, int64_t ld, int n_rows, int n, int r, float* thr, hipStream_t stream) {
+  if (n_rows <= 0) return kOk;
+  if (r < 1 || r > n || n > kKthRegs * 128 || (n & 1) || (ld & 1)) { set_error("bf16_rows_kth: r = %d of n = %d (even, <= %d), ld = %lld", r, n, kKthRegs * 128, (long long)ld); return kErrInvalid; }
+  hipLaunchKernelGGL(bf16_rows_kth_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, rows16, ld, n_rows, n, r, thr);
+  return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
 // keys[row][sub][slot], counts[row][sub]: the k largest keys of every row as (score, position), descending; out_counts[row] = its
 // candidates (cap + 1: a sub-list overflowed); *out_flag (optional, zeroed by the caller) = 1 if some row has not k <= count <= cap.
 int select_sublists(const unsigned long long* keys, const unsigned int* counts, int rows, int cap, int n_sub, int k, float* out_scores,
@@ -1168,6 +1307,10 @@ int select_sublists(const unsigned long long* keys, const unsigned int* counts, 
   a.keys = keys; a.counts = counts; a.cap = cap; a.n_sub = n_sub; a.k = k;
   a.npad = next_pow2(k < 64 ? 64 : k);
   a.out_scores = out_scores; a.out_pos = out_pos; a.out_counts = out_counts; a.out_flag = out_flag;
+  if (rows >= 512 && cap <= kSmallCap) {      // many short rows (the component scans)
+    hipLaunchKernelGGL(sublist_rank_kernel, dim3(rows), dim3(kSmallThreads), 0, stream, a);
+    return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+  }
   const size_t lds = (size_t)(a.npad <= kRowThreads ? 3 * a.npad : a.npad) * sizeof(unsigned long long);
   if (cap <= 4 * kRowThreads) hipLaunchKernelGGL((sublist_select_kernel<4>), dim3(rows), dim3(kRowThreads), lds, stream, a);
   else if (cap <= 8 * kRowThreads) hipLaunchKernelGGL((sublist_select_kernel<8>), dim3(rows), dim3(kRowThreads), lds, stream, a);
@@ -1263,44 +1406,57 @@ __global__ __launch_bounds__(kFilterThreads) void filter_seen_kernel(const int64
 }
 
 // ---- the call's verdict from its rows' verdicts (rails_candidates_finish, rails_merge_candidates_verdict) ---------------------------
-// One thread per row (its workgroup's thread 0) reports the row; the LAST one to arrive folds the call into `state` (rails_rescore_verdict's
-// layout) and mirrors it into pinned host memory -- the words first, the call counter (which the host polls) last.  `call`: 8 words of the
-// caller's workspace, zero between calls: [0] arrivals [1] a row failed [2] largest error [3] ~orderable(smallest margin) [4] largest guard
-// magnitude [5] a row was bad (NaN, guard).  Rows report through atomics only; the fences order them against the arrival counter.
-__device__ __forceinline__ unsigned int gap_key(float g) { return ~orderable(g); }      // atomicMax over these = the smallest margin
-__device__ __forceinline__ void verdict_commit(unsigned int* call, int rows, int fail, int bad, float err, float gap, float grd, float default_eps,
-                                               float safety, float* st, float* state_host) {
-  if (fail) atomicOr(&call[1], 1u);
-  if (bad) atomicOr(&call[5], 1u);
-  atomicMax(&call[2], __float_as_uint(bad ? 0.0f : err));
-  atomicMax(&call[3], gap_key(gap == gap ? gap : -INFINITY));
-  atomicMax(&call[4], __float_as_uint(grd));
+// Every row's workgroup stores the row's (error, margin, guard magnitude, flags) as ONE 16-byte word of the workspace, fences, and bumps
+// the arrival counter; the LAST workgroup to arrive reduces the rows with its first wave, folds the call into `state`
+// (rails_rescore_verdict's layout) and mirrors it into pinned host memory -- the words first, the call counter (which the host polls)
+// last.  `call`: [0] arrivals (zero between calls), [8 ...) the rows' words.  All threads of the workgroup call (one barrier).
+struct RowVerdict { float err, gap, grd; unsigned int flags; };       // flags: 1 = the row failed, 2 = the row was bad (NaN, guard)
+__device__ __forceinline__ unsigned int gap_key(float g) { return ~orderable(g); }
+__device__ __forceinline__ void verdict_commit(unsigned int* call, int row, int rows, int fail, int bad, float err, float gap, float grd, float default_eps,
+                                               float safety, float* st, float* state_host, int* s_last) {
+  float4* slots = reinterpret_cast<float4*>(call + 8);
+  if (threadIdx.x == 0) {
+    slots[row] = float4{bad ? 0.0f : err, gap == gap ? gap : -INFINITY, grd, __uint_as_float((fail ? 1u : 0u) | (bad ? 2u : 0u))};
+    __threadfence();
+    *s_last = atomicAdd(&call[0], 1u) == (unsigned int)rows - 1u ? 1 : 0;
+  }
+  __syncthreads();
+  if (!*s_last || threadIdx.x >= 64) return;
   __threadfence();
-  const unsigned int t = atomicAdd(&call[0], 1u);
-  if (t != (unsigned int)rows - 1u) return;
-  __threadfence();
-  const unsigned int any_fail = atomicOr(&call[1], 0u), any_bad = atomicOr(&call[5], 0u);
-  const float err_call = __uint_as_float(atomicMax(&call[2], 0u));
-  const float gap_call = unorderable(~atomicMax(&call[3], 0u));
-  const float grd_call = __uint_as_float(atomicMax(&call[4], 0u));
+  float e = 0.0f, g = INFINITY, gd = 0.0f;
+  unsigned int fl = 0u;
+  for (int r = threadIdx.x; r < rows; r += 64) {
+    const volatile float* vp = reinterpret_cast<const volatile float*>(&slots[r]);
+    e = fmaxf(e, vp[0]); g = fminf(g, vp[1]); gd = fmaxf(gd, vp[2]); fl |= __float_as_uint(vp[3]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    e = fmaxf(e, __shfl_xor(e, o, 64)); g = fminf(g, __shfl_xor(g, o, 64)); gd = fmaxf(gd, __shfl_xor(gd, o, 64)); fl |= (unsigned int)__shfl_xor((int)fl, o, 64);
+  }
+  if (threadIdx.x != 0) return;
+  const bool any_bad = (fl & 2u) != 0u;
   float seen = st[0];
-  if (!any_bad) seen = fmaxf(seen, err_call);
-  const int redo = any_fail ? 1 : 0;
+  if (!any_bad) seen = fmaxf(seen, e);
+  const int redo = (fl & 1u) ? 1 : 0;
+  const float calls = st[5] + 1.0f, redone = st[6] + (redo ? 1.0f : 0.0f), grd_all = fmaxf(st[7], gd), eps_used = fmaxf(default_eps, safety * seen);
   st[0] = seen;
   reinterpret_cast<int32_t*>(st)[1] = redo;
-  st[2] = fmaxf(default_eps, safety * seen);
-  st[3] = any_bad ? INFINITY : err_call;
-  st[4] = gap_call;
-  st[5] += 1.0f;
-  if (redo) st[6] += 1.0f;
-  st[7] = fmaxf(st[7], grd_call);
+  st[2] = eps_used;
+  st[3] = any_bad ? INFINITY : e;
+  st[4] = g;
+  st[5] = calls;
+  st[6] = redone;
+  st[7] = grd_all;
+  call[0] = 0u;
   if (state_host) {
-    volatile float* sh = state_host;
-    sh[0] = st[0]; reinterpret_cast<volatile int32_t*>(sh)[1] = redo; sh[2] = st[2]; sh[3] = st[3]; sh[4] = st[4]; sh[6] = st[6]; sh[7] = st[7];
-    __threadfence_system();
-    sh[5] = st[5];
+    // two 16-byte stores into one 32-byte block of pinned host memory, the half with the call counter second: posted writes of one source to
+    // one destination arrive in order, so no system-scope fence (a round trip over the link) stands between them; the host still reads the
+    // counter before and after its snapshot
+    typedef float f32x4v __attribute__((ext_vector_type(4)));
+    f32x4v* sh = reinterpret_cast<f32x4v*>(state_host);
+    __builtin_nontemporal_store(f32x4v{seen, __int_as_float(redo), eps_used, any_bad ? INFINITY : e}, &sh[0]);
+    __builtin_nontemporal_store(f32x4v{g, calls, redone, grd_all}, &sh[1]);
   }
-  call[0] = 0u; call[1] = 0u; call[2] = 0u; call[3] = 0u; call[4] = 0u; call[5] = 0u;
 }
 
 // ---- item-sharded top-k: message pack + merge (rails_amd/sharded.py) -----------------------------------------
@@ -1342,6 +1498,7 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(const in
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
   __shared__ int unsorted;
   __shared__ unsigned int s_kth, s_gbad, s_grd;
+  __shared__ int s_last;
   __shared__ int64_t f_id[kFuseMaxK], f_inv[kFuseMaxW];
   __shared__ float f_sc[kFuseMaxK];
   __shared__ int f_scratch[kSortThreads / 64 + 2];
@@ -1379,22 +1536,20 @@ __global__ __launch_bounds__(kSortThreads) void merge_candidates_kernel(const in
           atomicMax(&s_grd, __float_as_uint(g == g ? g : INFINITY));
         }
       __syncthreads();
-      if (threadIdx.x == 0) {
-        float m = -INFINITY, err = 0.0f;
-        int bad = s_gbad ? 1 : 0;
-        for (int r = 0; r < R; ++r) {
-          const int64_t* msg = gathered + ((int64_t)r * rows + row) * msg_ld;
-          const float mr = __uint_as_float((unsigned int)(unsigned long long)msg[2 * k]), er = __uint_as_float((unsigned int)(unsigned long long)msg[2 * k + 1]);
-          bad |= !(mr == mr) || !(er < INFINITY);
-          m = fmaxf(m, mr == mr ? mr : INFINITY);
-          err = fmaxf(err, er == er ? er : INFINITY);
-        }
-        const float kth = unorderable(s_kth);              // -inf when fewer than k_out real entries were merged
-        const float gap = kth - m;
-        const float eps = fmaxf(v.default_eps, v.safety * fmaxf(v.state[0], bad ? 0.0f : err));
-        const int fail = bad || !(gap > eps);
-        verdict_commit(v.call, rows, fail, bad, err, gap, __uint_as_float(s_grd), v.default_eps, v.safety, v.state, v.state_host);
+      float m = -INFINITY, err = 0.0f;
+      int bad = s_gbad ? 1 : 0;
+      for (int r = 0; r < R; ++r) {       // (every thread: a few broadcast loads)
+        const int64_t* msg = gathered + ((int64_t)r * rows + row) * msg_ld;
+        const float mr = __uint_as_float((unsigned int)(unsigned long long)msg[2 * k]), er = __uint_as_float((unsigned int)(unsigned long long)msg[2 * k + 1]);
+        bad |= !(mr == mr) || !(er < INFINITY);
+        m = fmaxf(m, mr == mr ? mr : INFINITY);
+        err = fmaxf(err, er == er ? er : INFINITY);
       }
+      const float kth = unorderable(s_kth);              // -inf when fewer than k_out real entries were merged
+      const float gap = kth - m;
+      const float eps = fmaxf(v.default_eps, v.safety * fmaxf(v.state[0], bad ? 0.0f : err));
+      const int fail = bad || !(gap > eps);
+      verdict_commit(v.call, row, rows, fail, bad, err, gap, __uint_as_float(s_grd), v.default_eps, v.safety, v.state, v.state_host, &s_last);
     }
     if (!fuse) return;
     __syncthreads();
@@ -1649,6 +1804,18 @@ __global__ __launch_bounds__(kSortThreads) void sort_rows_i64_kernel(const int64
                                                                     int64_t* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
   const int row = blockIdx.x;
+  if (npad >= 2 * kSortThreads && npad <= 16 * kSortThreads) {
+    // the register / shuffle sort (descending) on complemented keys = ascending order of the values: 73 -> ~35 us for 32 rows of 6 400
+    for (int i = threadIdx.x; i < npad; i += kSortThreads)
+      keys[i] = i < n ? ~((unsigned long long)in[(int64_t)row * n + i] ^ 0x8000000000000000ull) : 0ull;      // padding sorts last
+    __syncthreads();
+    if (npad == 2 * kSortThreads) block_sort_desc_multi<2>(keys);
+    else if (npad == 4 * kSortThreads) block_sort_desc_multi<4>(keys);
+    else if (npad == 8 * kSortThreads) block_sort_desc_multi<8>(keys);
+    else block_sort_desc_multi<16>(keys);
+    for (int i = threadIdx.x; i < n; i += kSortThreads) out[(int64_t)row * n + i] = (int64_t)(~keys[i] ^ 0x8000000000000000ull);
+    return;
+  }
   for (int i = threadIdx.x; i < npad; i += kSortThreads)
     keys[i] = i < n ? ((unsigned long long)in[(int64_t)row * n + i] ^ 0x8000000000000000ull) : ~0ull;  // signed order
   __syncthreads();
@@ -1720,18 +1887,20 @@ int filter_seen(const int64_t* top_ids, const float* top_scores, int rows, int k
 //                             index), the row's verdict, and -- last workgroup done -- the call's verdict / calibration state, written to the
 //                             device state AND straight into pinned host memory (no copy launch); leaves the workspace zeroed for the next call.
 // Workspace (rails_candidates_workspace_bytes, zeroed ONCE by the caller; every call restores the zeros):
-//   counts[rows] | flags[rows] | call[8] | coarse[rows][64] | fine[rows][4096]
+//   counts[rows] | flags[rows] | call[8 + 4 rows] (arrival counter, the rows' verdict words) | coarse[rows][64] | fine[rows][4096]
 constexpr int kCandBins = 4096, kCandCoarse = 64, kCandPer = kCandBins / kCandCoarse;
 constexpr int kCandThreads = 512;
 constexpr int kCandSingleMax = 65536;      // rows up to this many scores: one launch, one workgroup per row
 constexpr int kCandStage = 2048;
 
 struct CandWs { unsigned int* counts; unsigned int* flags; unsigned int* call; unsigned int* coarse; unsigned int* fine; };
-static size_t cand_ws_words(int rows) { return (size_t)rows * 2 + 8 + (size_t)rows * kCandCoarse + (size_t)rows * kCandBins; }
+static size_t cand_rows_pad(int rows) { return ((size_t)rows + 3) / 4 * 4; }     // keeps the 16-byte words of the call block aligned
+static size_t cand_ws_words(int rows) { return cand_rows_pad(rows) * 2 + 8 + (size_t)rows * 4 + (size_t)rows * kCandCoarse + (size_t)rows * kCandBins; }
 static CandWs cand_ws(void* ws, int rows) {
   unsigned int* w = static_cast<unsigned int*>(ws);
+  const size_t rp = cand_rows_pad(rows);
   CandWs c;
-  c.counts = w; c.flags = w + rows; c.call = w + 2 * (size_t)rows; c.coarse = c.call + 8; c.fine = c.coarse + (size_t)rows * kCandCoarse;
+  c.counts = w; c.flags = w + rp; c.call = w + 2 * rp; c.coarse = c.call + 8 + 4 * (size_t)rows; c.fine = c.coarse + (size_t)rows * kCandCoarse;
   return c;
 }
 size_t candidates_workspace_bytes(int rows) { return cand_ws_words(rows < 1 ? 1 : rows) * sizeof(unsigned int); }
@@ -1742,6 +1911,38 @@ __device__ __forceinline__ int cand_bin(float s, float lo, float scale) {
   float x = (s - lo) * scale;
   x = fminf(fmaxf(x, 0.0f), (float)(kCandBins - 1));
   return (int)x;
+}
+
+// Walk [begin, end) of a row, four 16-byte loads in flight per thread: f4(x, i) once per aligned group of four scores (positions i .. i + 3),
+// f1(score, i) for the unaligned head and tail.
+template <int NT, class F4, class F1>
+__device__ __forceinline__ void walk_chunk4(const float* __restrict__ rowp, int64_t begin, int64_t end, F4 f4, F1 f1) {
+  int64_t a0 = begin + ((4 - (int64_t)((reinterpret_cast<uintptr_t>(rowp + begin) >> 2) & 3)) & 3);
+  if (a0 > end) a0 = end;
+  const int64_t nvec = (end - a0) >> 2;
+  for (int64_t i = begin + threadIdx.x; i < a0; i += NT) f1(rowp[i], i);
+  const float4* body = reinterpret_cast<const float4*>(rowp + a0);
+  int64_t v = threadIdx.x;
+  for (; v + 3 * NT < nvec; v += 4 * NT) {
+    const float4 x0 = body[v], x1 = body[v + NT], x2 = body[v + 2 * NT], x3 = body[v + 3 * NT];
+    f4(x0, a0 + 4 * v); f4(x1, a0 + 4 * (v + NT)); f4(x2, a0 + 4 * (v + 2 * NT)); f4(x3, a0 + 4 * (v + 3 * NT));
+  }
+  for (; v < nvec; v += NT) f4(body[v], a0 + 4 * v);
+  for (int64_t i = a0 + 4 * nvec + threadIdx.x; i < end; i += NT) f1(rowp[i], i);
+}
+
+// the smallest float whose bin is >= bt (cand_bin is monotone): a score is selected iff it is >= this value -- one compare per score in the
+// compaction walk instead of the bin arithmetic.  bt <= 0: -inf (everything); no such float: NaN (nothing compares >= NaN).
+__device__ __forceinline__ float cand_threshold_value(int bt, float lo, float scale) {
+  if (bt <= 0) return -INFINITY;
+  if (cand_bin(INFINITY, lo, scale) < bt) return __uint_as_float(0x7FC00000u);
+  if (cand_bin(-INFINITY, lo, scale) >= bt) return -INFINITY;
+  unsigned int a = orderable(-INFINITY), b = orderable(INFINITY);       // orderable keys of finite floats lie between: bin(a) < bt <= bin(b)
+  while (b - a > 1u) {
+    const unsigned int mid = a + ((b - a) >> 1);
+    if (cand_bin(unorderable(mid), lo, scale) >= bt) b = mid; else a = mid;
+  }
+  return unorderable(b);
 }
 
 // LDS histogram h[kCandBins] of a workgroup -> coarse sums hc[kCandCoarse] (every thread sums a run of fine bins, runs of one coarse bin sit in
@@ -1780,16 +1981,15 @@ __device__ __forceinline__ int cand_pick(const unsigned int* coarse, const unsig
 
 // the selected scores of [begin, end) of a row -> the row's candidate list: staged in LDS (one LDS atomic per wave that holds one), ONE
 // global atomic per workgroup reserves their range of the list (compact_kernel's scheme); a chunk with more selected scores than the
-// stage holds is walked again and placed directly
+// stage holds is walked again and placed directly.  A score is selected iff it is >= thr (cand_threshold_value of the row's threshold bin).
 template <int NT>
-__device__ __forceinline__ void cand_append(const float* __restrict__ rowp, int64_t begin, int64_t end, int bt, float lo, float scale,
+__device__ __forceinline__ void cand_append(const float* __restrict__ rowp, int64_t begin, int64_t end, float thr,
                                             unsigned int* count, int64_t* __restrict__ out_pos, float* __restrict__ out_a, unsigned int cap,
                                             unsigned long long* stage, unsigned int* wg_base, unsigned int* wg_cursor) {
   const int lane = threadIdx.x & 63;
   if (threadIdx.x == 0) *wg_cursor = 0u;
   __syncthreads();
-  for_each_in_chunk(rowp, begin, end, NT, [&](float sc, int64_t i) {
-    const bool sel = cand_bin(sc, lo, scale) >= bt;
+  auto put = [&](bool sel, float sc, int64_t i, unsigned int base_all, bool direct) {   // wave-uniform call; appends the lanes with sel
     const unsigned long long m = __ballot(sel);
     if (m) {
       const int leader = __ffsll((long long)m) - 1;
@@ -1798,10 +1998,22 @@ __device__ __forceinline__ void cand_append(const float* __restrict__ rowp, int6
       base = (unsigned int)__shfl((int)base, leader, 64);
       if (sel) {
         const unsigned int slot = base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
-        if (slot < (unsigned int)kCandStage) stage[slot] = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned int)i;
+        if (!direct) { if (slot < (unsigned int)kCandStage) stage[slot] = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned int)i; }
+        else if (base_all + slot < cap) { out_pos[base_all + slot] = i; out_a[base_all + slot] = sc; }
       }
     }
-  });
+  };
+  auto walk = [&](unsigned int base_all, bool direct) {
+    walk_chunk4<NT>(rowp, begin, end,
+        [&](const float4 x, int64_t i) {
+          const bool s0 = x.x >= thr, s1 = x.y >= thr, s2 = x.z >= thr, s3 = x.w >= thr;
+          if (__ballot(s0 | s1 | s2 | s3) != 0ull) {       // rare: ~cap of the row's scores are selected
+            put(s0, x.x, i, base_all, direct); put(s1, x.y, i + 1, base_all, direct); put(s2, x.z, i + 2, base_all, direct); put(s3, x.w, i + 3, base_all, direct);
+          }
+        },
+        [&](float sc, int64_t i) { put(sc >= thr, sc, i, base_all, direct); });
+  };
+  walk(0u, false);
   __syncthreads();
   const unsigned int total = *wg_cursor;
   if (total == 0u) return;
@@ -1816,20 +2028,7 @@ __device__ __forceinline__ void cand_append(const float* __restrict__ rowp, int6
     }
     return;
   }
-  for_each_in_chunk(rowp, begin, end, NT, [&](float sc, int64_t i) {
-    const bool sel = cand_bin(sc, lo, scale) >= bt;
-    const unsigned long long m = __ballot(sel);
-    if (m) {
-      const int leader = __ffsll((long long)m) - 1;
-      unsigned int base = 0;
-      if (lane == leader) base = atomicAdd(wg_cursor, (unsigned int)__popcll(m));
-      base = (unsigned int)__shfl((int)base, leader, 64);
-      if (sel) {
-        const unsigned int slot = wbase + base + (unsigned int)__popcll(m & ((1ull << lane) - 1ull));
-        if (slot < cap) { out_pos[slot] = i; out_a[slot] = sc; }
-      }
-    }
-  });
+  walk(wbase, true);
 }
 
 __global__ __launch_bounds__(kCandThreads) void cand_hist_kernel(const float* __restrict__ scores, int64_t ld, int64_t n, int64_t chunk, float lo,
@@ -1844,10 +2043,8 @@ __global__ __launch_bounds__(kCandThreads) void cand_hist_kernel(const float* __
   const int64_t end = (begin + chunk < n) ? begin + chunk : n;
   const float* rowp = scores + (int64_t)row * ld;
   bool nan = false;
-  for_each_in_chunk(rowp, begin, end, kCandThreads, [&](float sc, int64_t) {
-    nan |= !(sc == sc);
-    atomicAdd(&h[cand_bin(sc, lo, scale)], 1u);
-  });
+  auto one = [&](float sc, int64_t) { nan |= !(sc == sc); atomicAdd(&h[cand_bin(sc, lo, scale)], 1u); };
+  walk_chunk4<kCandThreads>(rowp, begin, end, [&](const float4 x, int64_t i) { one(x.x, i); one(x.y, i); one(x.z, i); one(x.w, i); }, one);
   if (__ballot(nan) != 0ull && lane == 0) atomicOr(&w.flags[row], 1u);
   __syncthreads();
   cand_coarse_sums<kCandThreads>(h, hc);
@@ -1876,16 +2073,16 @@ __global__ __launch_bounds__(kCandThreads) void cand_compact_kernel(const float*
                                                                    float* __restrict__ out_a, int64_t cand_ld) {
   __shared__ unsigned long long stage[kCandStage];
   __shared__ unsigned int wg_base, wg_cursor;
-  __shared__ int s_bt;
+  __shared__ float s_thr;
   const int row = blockIdx.y, tid = threadIdx.x;
   if (tid < 64) {
     const int bt = cand_pick(w.coarse + (size_t)row * kCandCoarse, w.fine + (size_t)row * kCandBins, cap, tid);
-    if (tid == 0) s_bt = bt;
+    if (tid == 0) s_thr = cand_threshold_value(bt, lo, scale);
   }
   __syncthreads();
   const int64_t begin = (int64_t)blockIdx.x * chunk;
   const int64_t end = (begin + chunk < n) ? begin + chunk : n;
-  cand_append<kCandThreads>(scores + (int64_t)row * ld, begin, end, s_bt, lo, scale, &w.counts[row], out_pos + (int64_t)row * cand_ld,
+  cand_append<kCandThreads>(scores + (int64_t)row * ld, begin, end, s_thr, &w.counts[row], out_pos + (int64_t)row * cand_ld,
                             out_a + (int64_t)row * cand_ld, cap, stage, &wg_base, &wg_cursor);
 }
 
@@ -1897,27 +2094,30 @@ __global__ __launch_bounds__(kRowThreads) void cand_single_kernel(const float* _
   __shared__ unsigned int hc[kCandCoarse];
   __shared__ unsigned long long stage[kCandStage];
   __shared__ unsigned int wg_base, wg_cursor;
-  __shared__ int s_bt;
+  __shared__ float s_thr;
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   for (int i = tid; i < kCandBins; i += kRowThreads) h[i] = 0u;
   __syncthreads();
   const float* rowp = scores + (int64_t)row * ld;
   bool nan = false;
-  for_each_in_chunk(rowp, 0, n, kRowThreads, [&](float sc, int64_t) {
-    nan |= !(sc == sc);
-    atomicAdd(&h[cand_bin(sc, lo, scale)], 1u);
-  });
+  auto one = [&](float sc, int64_t) { nan |= !(sc == sc); atomicAdd(&h[cand_bin(sc, lo, scale)], 1u); };
+  walk_chunk4<kRowThreads>(rowp, 0, n, [&](const float4 x, int64_t i) { one(x.x, i); one(x.y, i); one(x.z, i); one(x.w, i); }, one);
   if (__ballot(nan) != 0ull && lane == 0) atomicOr(&w.flags[row], 1u);
   __syncthreads();
   cand_coarse_sums<kRowThreads>(h, hc);
   __syncthreads();
   if (tid < 64) {
     const int bt = cand_pick(hc, h, cap, tid);
-    if (tid == 0) s_bt = bt;
+    if (tid == 0) s_thr = cand_threshold_value(bt, lo, scale);
   }
   __syncthreads();
-  cand_append<kRowThreads>(rowp, 0, n, s_bt, lo, scale, &w.counts[row], out_pos + (int64_t)row * cand_ld, out_a + (int64_t)row * cand_ld, cap, stage,
+  cand_append<kRowThreads>(rowp, 0, n, s_thr, &w.counts[row], out_pos + (int64_t)row * cand_ld, out_a + (int64_t)row * cand_ld, cap, stage,
                            &wg_base, &wg_cursor);
+}
+
+static int cand_single_max() {
+  static const int v = [] { const char* e = getenv("RAILS_CAND_SINGLE_MAX"); const int x = e ? atoi(e) : -1; return x >= 0 ? x : kCandSingleMax; }();
+  return v;
 }
 
 int candidates_select(const float* scores, int64_t ld, int rows, int64_t n, int cap, float lo, float hi, void* ws, int64_t* out_pos, float* out_approx,
@@ -1928,13 +2128,12 @@ int candidates_select(const float* scores, int64_t ld, int rows, int64_t n, int 
   if (!(hi > lo)) { set_error("candidates_select: empty score range"); return kErrInvalid; }
   const float scale = (float)kCandBins / (hi - lo);
   const CandWs w = cand_ws(ws, rows);
-  static const int single_max = [] { const char* e = getenv("RAILS_CAND_SINGLE_MAX"); const int v = e ? atoi(e) : -1; return v >= 0 ? v : kCandSingleMax; }();
-  if (n <= single_max) {
+  if (n <= cand_single_max()) {
     hipLaunchKernelGGL(cand_single_kernel, dim3(rows), dim3(kRowThreads), 0, stream, scores, ld, n, lo, scale, (unsigned int)cap, w, out_pos, out_approx, cand_ld);
     return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
   }
   static const int cand_wgs = [] { const char* e = getenv("RAILS_CAND_WGS"); const int v = e ? atoi(e) : 0; return v >= 64 && v <= 16384 ? v : 0; }();
-  const int target = cand_wgs ? cand_wgs : 4 * (n_cu > 0 ? n_cu : 256);
+  const int target = cand_wgs ? cand_wgs : 2 * (n_cu > 0 ? n_cu : 256);      // 128 / 256 / 384 / 512 / 1024 / 2048 workgroups at 32 x 695 762: hist 26.9 / 19.3 / - / 18.2 / 20.9 / 31.5 us
   int64_t chunks = (target + rows - 1) / rows;
   const int64_t max_chunks = (n + 8191) / 8192;
   if (chunks > max_chunks) chunks = max_chunks;
@@ -1959,6 +2158,8 @@ struct CandFinishArgs {
   float* out_scores; int64_t* out_ids;       // (rows, k)
   const int64_t* f_invalid; int f_width, f_k; int64_t* f_out_ids; float* f_out_scores;   // optional seen-id filter over the k winners
   float* state; float* state_host;           // verdict state (rails_rescore_verdict's layout); state_host: optional mirror in pinned host memory
+  int clean_hist;                            // the selection was the two-launch one: its global histograms are zeroed here
+  int debug;                                 // RAILS_FINISH_DEBUG (measurements): 1 = no verdict commit, 2 = no host mirror, 4 = no sort
   int64_t* msg;                              // sharded form: (rows, 2k + 2) message [k score words | k ids | m | err], no verdict here
 };
 
@@ -1969,23 +2170,28 @@ __global__ __launch_bounds__(kSortThreads) void cand_finish_kernel(const CandFin
   __shared__ int64_t f_id[kFuseMaxK], f_inv[kFuseMaxW];
   __shared__ float f_sc[kFuseMaxK];
   __shared__ int f_scratch[kSortThreads / 64 + 2];
+  __shared__ int s_last;
   const int row = blockIdx.x, rows = gridDim.x, tid = threadIdx.x, lane = tid & 63;
   const int k = a.k, npad = a.npad;
   const bool fuse = a.f_invalid != nullptr;
-  unsigned int c = a.w.counts[row];
-  if (c > (unsigned int)a.cap) c = (unsigned int)a.cap;
   const unsigned int flags = a.w.flags[row];
   const float seen_before = a.state ? a.state[0] : 0.0f;
   if (fuse)
     for (int i = tid; i < a.f_width; i += kSortThreads) f_inv[i] = a.f_invalid[(int64_t)row * a.f_width + i];
   float mn = INFINITY, err = 0.0f, grd = 0.0f;
   int bad = (flags & 1u) ? 1 : 0;
+  unsigned int c = a.w.counts[row];
+  if (c > (unsigned int)a.cap) c = (unsigned int)a.cap;
   for (int i = tid; i < npad; i += kSortThreads) {
     unsigned long long kv = 0ull;
+    float e = 0.0f, ap = 0.0f;
+    int64_t p = 0;
+    if (i < a.cap) {      // requested before the row's count is known: one round trip to memory, not two (slots past the count hold stale values, masked below)
+      e = a.exact[(int64_t)row * a.ld + i];
+      ap = a.approx[(int64_t)row * a.cand_ld + i];
+      p = a.pos[(int64_t)row * a.cand_ld + i];
+    }
     if (i < (int)c) {
-      const float e = a.exact[(int64_t)row * a.ld + i];
-      const float ap = a.approx[(int64_t)row * a.cand_ld + i];
-      const int64_t p = a.pos[(int64_t)row * a.cand_ld + i];
       kv = ((unsigned long long)orderable(e) << 32) | (unsigned int)(~(unsigned int)p);
       mn = fminf(mn, ap);
       const float dd = a.one_sided ? fmaxf(e - ap, 0.0f) : fabsf(e - ap);
@@ -2010,13 +2216,16 @@ __global__ __launch_bounds__(kSortThreads) void cand_finish_kernel(const CandFin
   if (lane == 0) { red_min[tid >> 6] = mn; red_err[tid >> 6] = err; red_grd[tid >> 6] = grd; red_bad[tid >> 6] = bad; }
   // leave the workspace as the next call expects it (nothing below reads it)
   {
-    unsigned int* gf = a.w.fine + (size_t)row * kCandBins;
-    for (int i = tid; i < kCandBins; i += kSortThreads) gf[i] = 0u;
-    if (tid < kCandCoarse) a.w.coarse[(size_t)row * kCandCoarse + tid] = 0u;
+    if (a.clean_hist) {
+      unsigned int* gf = a.w.fine + (size_t)row * kCandBins;
+      for (int i = tid; i < kCandBins; i += kSortThreads) gf[i] = 0u;
+      if (tid < kCandCoarse) a.w.coarse[(size_t)row * kCandCoarse + tid] = 0u;
+    }
     if (tid == 0) { a.w.counts[row] = 0u; a.w.flags[row] = 0u; }
   }
   __syncthreads();
-  if (npad <= kSortThreads) {
+  if (a.debug & 4) {
+  } else if (npad <= kSortThreads) {
     unsigned long long kv = tid < npad ? keys[tid] : 0ull;
     kv = block_sort_desc(kv, npad, keys + npad);
     __syncthreads();
@@ -2056,18 +2265,16 @@ __global__ __launch_bounds__(kSortThreads) void cand_finish_kernel(const CandFin
     a.out_ids[(int64_t)row * k + j] = id;
     if (fuse && j < kFuseMaxK) { f_sc[j] = sc; f_id[j] = id; }
   }
-  if (tid == 0) {
-    // the row's verdict: its k-th fp32 score must clear the best first-pass score left outside the candidates by eps
-    const float kth = (int)c >= k ? unorderable((unsigned int)(keys[k - 1] >> 32)) : -INFINITY;
-    const float gap = kth - mn;
-    const float eps = fmaxf(a.default_eps, a.safety * fmaxf(seen_before, bad ? 0.0f : err));
-    const int fail = bad || (int)c < k || !(gap > eps);
-    verdict_commit(a.w.call, rows, fail, bad, err, gap, grd, a.default_eps, a.safety, a.state, a.state_host);
-  }
+  // the row's verdict: its k-th fp32 score must clear the best first-pass score left outside the candidates by eps
+  const float kth = (int)c >= k ? unorderable((unsigned int)(keys[k - 1] >> 32)) : -INFINITY;
+  const float gap = kth - mn;
+  const float eps = fmaxf(a.default_eps, a.safety * fmaxf(seen_before, bad ? 0.0f : err));
+  const int fail = bad || (int)c < k || !(gap > eps);
   if (fuse) {
     __syncthreads();
     filter_from_lds<kSortThreads>(f_id, f_sc, k, f_inv, a.f_width, a.f_k, a.f_out_ids + (int64_t)row * a.f_k, a.f_out_scores + (int64_t)row * a.f_k, f_scratch);
   }
+  if (!(a.debug & 1)) verdict_commit(a.w.call, row, rows, fail, bad, err, gap, grd, a.default_eps, a.safety, a.state, (a.debug & 2) ? nullptr : a.state_host, &s_last);
 }
 
 int candidates_finish(const float* exact, int64_t ld, const float* approx, const int64_t* pos, int64_t cand_ld, int cap, void* ws, const int64_t* ids,
@@ -2091,6 +2298,9 @@ int candidates_finish(const float* exact, int64_t ld, const float* approx, const
   a.out_scores = out_scores; a.out_ids = out_ids;
   a.f_invalid = f_invalid; a.f_width = f_width; a.f_k = f_k; a.f_out_ids = f_out_ids; a.f_out_scores = f_out_scores;
   a.state = state; a.state_host = state_host; a.msg = msg;
+  static const int debug = [] { const char* e = getenv("RAILS_FINISH_DEBUG"); return e ? atoi(e) : 0; }();
+  a.debug = debug;
+  a.clean_hist = n_items > cand_single_max() ? 1 : 0;
   const size_t lds = (size_t)(npad <= kSortThreads ? 3 * npad : npad) * sizeof(unsigned long long);
   hipLaunchKernelGGL(cand_finish_kernel, dim3(rows), dim3(kSortThreads), lds, stream, a);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;

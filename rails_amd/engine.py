@@ -469,9 +469,13 @@ class MolEngine:
         fn = getattr(self.lib, fn_name)
         n, dev = index.n_items, index.buf.device
         table = torch.empty(n * row_elems, dtype=torch.bfloat16, device=dev)
+        grouped = fn_name == "rails_mol_component_build"      # item-group-major table: a chunk of items writes a slice of every group
         with _on_device(dev):
             if self.precision == "fp32":
-                _lib.check(fn(C.byref(self.shape), _ptr(index.buf), n, _ptr(table), _stream()), fn_name)
+                if grouped:
+                    _lib.check(fn(C.byref(self.shape), _ptr(index.buf), n, _ptr(table), n, 0, _stream()), fn_name)
+                else:
+                    _lib.check(fn(C.byref(self.shape), _ptr(index.buf), n, _ptr(table), _stream()), fn_name)
             else:
                 if items is None:
                     raise ValueError(f"{fn_name}: precision='f16x3' needs the raw item embeddings to cut the bf16 table from")
@@ -482,7 +486,10 @@ class MolEngine:
                     m = min(chunk, n - lo)
                     _lib.check(self.lib.rails_mol_index_build(C.byref(self._fp32_shape), C.byref(self.weights), _ptr(items[lo : lo + m]), m, _ptr(tmp), _stream()),
                                "rails_mol_index_build")
-                    _lib.check(fn(C.byref(self._fp32_shape), _ptr(tmp), m, C.c_void_p(table.data_ptr() + 2 * lo * row_elems), _stream()), fn_name)
+                    if grouped:
+                        _lib.check(fn(C.byref(self._fp32_shape), _ptr(tmp), m, _ptr(table), n, lo, _stream()), fn_name)
+                    else:
+                        _lib.check(fn(C.byref(self._fp32_shape), _ptr(tmp), m, C.c_void_p(table.data_ptr() + 2 * lo * row_elems), _stream()), fn_name)
         return table
 
     def build_coarse_table(self, index: MolIndex, items: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -561,14 +568,14 @@ class MolEngine:
 
     # ---- per-component candidates (MoLNaiveTopK / MoLCombTopK) -----------------------------------------
     def build_component_table(self, index: MolIndex, items: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """(N, P_X, d) bf16 component embeddings (reference mol_top_k.py:61-73)."""
+        """(P_X, N, d) bf16 component embeddings (reference mol_top_k.py:61-73), item-group-major: the scans stream one group's rows back to back."""
         px, d = self.spec.item_dot_product_groups, self.spec.dot_product_dimension
-        return self._derived_table("rails_mol_component_build", px * d, index, items).view(index.n_items, px, d)
+        return self._derived_table("rails_mol_component_build", px * d, index, items).view(px, index.n_items, d)
 
     def component_scores(self, eq: torch.Tensor, table: torch.Tensor, out: Optional[torch.Tensor] = None,
                          run_if: Optional[torch.Tensor] = None) -> torch.Tensor:
         """eq (B, P_Q, d) -> (B * P_Q * P_X, N) fp32 holding bf16 values, row (b * P_Q + i) * P_X + m."""
-        B, n = eq.shape[0], table.shape[0]
+        B, n = eq.shape[0], table.shape[1]
         eq = _f32c(eq)
         rows = B * self.spec.query_dot_product_groups * self.spec.item_dot_product_groups
         if out is None:
@@ -580,28 +587,35 @@ class MolEngine:
             )
         return out
 
-    def component_topk(self, eq: torch.Tensor, table: torch.Tensor, k_group: int):
+    def component_topk(self, eq: torch.Tensor, table: torch.Tensor, k_group: int, flag: Optional[torch.Tensor] = None):
         """Fused component scoring + exact top-k_group per (b, i, m) row (no (rows, N) score matrix).
         -> (scores (rows, k_group), positions (rows, k_group), counts (rows,) int32) or None when unsupported; exact iff
-        k_group <= counts <= coarse_topk_capacity(k_group) for every row (the caller checks and falls back)."""
-        B, n = eq.shape[0], table.shape[0]
+        k_group <= counts <= component_topk_capacity for every row -- `flag` (an int32 device scalar, zeroed by the call) is raised otherwise."""
+        B, n = eq.shape[0], table.shape[1]
         ws_bytes = self.lib.rails_mol_component_topk_workspace_bytes(C.byref(self.shape), B, n, k_group)
         if ws_bytes == 0:
             return None
         eq = _f32c(eq)
         dev = table.device
         rows = B * self.spec.query_dot_product_groups * self.spec.item_dot_product_groups
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        memo = self.__dict__.setdefault("_comp_ws", {})          # the workspace is recycled: 30-70 MB of candidate lists per call otherwise
+        ws = memo.get(ws_bytes)
+        if ws is None or ws.device != dev:
+            memo.clear()
+            ws = memo[ws_bytes] = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         out_s = torch.empty((rows, k_group), dtype=torch.float32, device=dev)
         out_p = torch.empty((rows, k_group), dtype=torch.int64, device=dev)
         counts = torch.empty((rows,), dtype=torch.int32, device=dev)
         with _on_device(dev):
             _lib.check(
                 self.lib.rails_mol_component_topk(C.byref(self.shape), _ptr(eq), B, _ptr(table), n, k_group, _ptr(ws), ws_bytes,
-                                                  _ptr(out_s), _ptr(out_p), _ptr(counts), _stream()),
+                                                  _ptr(out_s), _ptr(out_p), _ptr(counts), _ptr(flag), _stream()),
                 "rails_mol_component_topk",
             )
         return out_s, out_p, counts
+
+    def component_topk_capacity(self, batch: int, n: int, k_group: int) -> int:
+        return int(self.lib.rails_mol_component_topk_capacity(C.byref(self.shape), int(batch), int(n), int(k_group)))
 
 
 def sort_rows(idx: torch.Tensor) -> torch.Tensor:

@@ -284,7 +284,7 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
             self._gp_eps = local._proved_eps() if self._gp_on else None
             self._gp_state = torch.zeros(8, dtype=torch.float32, device=query_embeddings.device)
             self._gp_host = torch.zeros(8, dtype=torch.float32).pin_memory()
-            self._gp_call = torch.zeros(8, dtype=torch.int32, device=query_embeddings.device)
+            self._gp_call = torch.zeros(8 + 4 * 256, dtype=torch.int32, device=query_embeddings.device)      # arrival counter + one 16-byte word per row
             self._gp_issued = 0           # verdicts enqueued so far (the host mirror's call counter reaches it when the last one has landed)
             self._gp_pad = 1
             self._gp_streak = 0
@@ -344,6 +344,8 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
         for t in (msg, qpack32):
             t.record_stream(side)
         fuse = seen is not None and E.merge_filter_fusable(k, seen[0].shape[1], seen[1])
+        if self._gp_call.numel() < 8 + 4 * B:
+            self._gp_call = torch.zeros(8 + 4 * B, dtype=torch.int32, device=msg.device)
         with torch.cuda.stream(side):
             # ONE exchange: the (B, 2k + 2) messages carry every rank's top-k, the best first-pass score it left outside its candidates and the
             # largest |fp32 - first pass| it saw; merge, verdict and the seen-id filter are one launch behind it

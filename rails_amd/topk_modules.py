@@ -1333,34 +1333,32 @@ class _ComponentCandidates:
         """-> (B, P_Q * P_X * k_per_group) positions: top k_per_group items of every (query group, item group) pair.
         `pending`: deferred validity check of the fused scan, as in MoLAvgTopK._coarse_topk_from_eq."""
         eng = self._bind()
-        table = self._component_table()
-        n = table.shape[0]
+        table = self._component_table()      # (P_X, N, d), item-group-major
+        n = table.shape[1]
         if k_per_group > n:
             raise RuntimeError(f"selected index k out of range (k={k_per_group}, n={n})")
-        # the component scan keeps the fragments of all B * P_Q query rows in LDS: batches beyond 64 queries go in slices
-        if eq.shape[0] > 64:
-            return torch.cat([self._component_topk(eq[b0 : b0 + 64], k_per_group, pending) for b0 in range(0, eq.shape[0], 64)], dim=0)
+        # the component scans keep the fragments of all B * P_Q query rows in LDS and (the fused form) eight row tiles of running maxima in
+        # registers: batches beyond 256 query rows go in slices
+        max_b = max(1, 256 // eng.spec.query_dot_product_groups)
+        if eq.shape[0] > max_b:
+            return torch.cat([self._component_topk(eq[b0 : b0 + max_b], k_per_group, pending) for b0 in range(0, eq.shape[0], max_b)], dim=0)
         # large corpora: fused scan + threshold select, no (B*P_Q*P_X, N) score matrix (5.7 GB at amzn-books, B = 32);
         # identical to the materialising path below whenever every row's candidate count is inside [k, capacity]
         if n >= getattr(self, "fused_component_min_items", 262144) and not getattr(self, "_no_fused", False):
-            fused = eng.component_topk(eq, table, k_per_group)
+            rows = eq.shape[0] * eng.spec.query_dot_product_groups * eng.spec.item_dot_product_groups
+            on_device = rows * n * 4 <= MoLAvgTopK.DEVICE_REDO_BYTES
+            flag = self._buf("redo_flag_c", 1, torch.int32) if on_device else torch.empty(1, dtype=torch.int32, device=eq.device)   # (zeroed by the call's first launch)
+            fused = eng.component_topk(eq, table, k_per_group, flag)
             if fused is not None:
                 sc_c, pos, counts = fused
-                k_hi = eng.coarse_topk_capacity(k_per_group)
-                rows = counts.numel()
-                if rows * n * 4 <= MoLAvgTopK.DEVICE_REDO_BYTES:     # check + redo on the device, as in MoLAvgTopK._coarse_topk_from_eq
-                    flag = self._buf("redo_flag_c", 1, torch.int32)
-                    flag.zero_()
-                    E.range_flag(counts, k_per_group, k_hi, flag)
+                if on_device:     # redo on the device under the flag, as in MoLAvgTopK._coarse_topk_from_eq
                     scores = eng.component_scores(eq, table, out=self._buf("component_all", rows * n, torch.float32).view(rows, n), run_if=flag)
                     E.topk(scores, k_per_group, out=(sc_c, pos), run_if=flag)
                     return pos.view(eq.shape[0], -1)
-                bad = torch.zeros(1, dtype=torch.int32, device=counts.device)
-                E.range_flag(counts, k_per_group, k_hi, bad)
                 if pending is not None:      # a device verdict word (1 = redo), read by the caller once everything is enqueued
-                    pending.append(bad)
+                    pending.append(flag)
                     return pos.view(eq.shape[0], -1)
-                if int(bad.item()) == 0:
+                if int(flag.item()) == 0:
                     return pos.view(eq.shape[0], -1)
         scores = eng.component_scores(eq, table)
         _, pos = E.topk(scores, k_per_group)

@@ -819,8 +819,10 @@ def test_fused_component_topk_equals_the_materialised_path(dev, cfg_name, n, k_g
         _, eq, _ = eng.query_pack(q, kw.get("user_ids"), want_plain=True)
         table = nt._component_table()
         rs, rp = E.topk(eng.component_scores(eq, table), k_g)
-        fs, fp, counts = eng.component_topk(eq, table, k_g)
-        assert int(counts.min()) >= k_g and int(counts.max()) <= eng.coarse_topk_capacity(k_g), (int(counts.min()), int(counts.max()))
+        flag = torch.ones(1, dtype=torch.int32, device=dev)       # (zeroed by the call, raised when a count leaves its range)
+        fs, fp, counts = eng.component_topk(eq, table, k_g, flag)
+        assert int(counts.min()) >= k_g and int(counts.max()) <= eng.component_topk_capacity(B, n, k_g), (int(counts.min()), int(counts.max()))
+        assert int(flag) == 0
         assert torch.equal(fs, rs) and torch.equal(fp, rp)
         for mod in (nt, rails_amd.MoLCombTopK(mol, X, ids, k_per_group=k_g, avg_top_k=200)):
             s1, i1 = mod(q, k=50, **kw)
@@ -940,8 +942,8 @@ def test_f10_naive_and_comb(dev, cname):
             _, eq, _ = eng.query_pack(q, kw.get("user_ids"), want_plain=True)
             kg = mod._k_per_group
             pos = mod._component_topk(eq, kg).cpu().view(q.shape[0], cfg.query_dot_product_groups, cfg.item_dot_product_groups, kg)
-            table = mod._component_table().cpu()                       # (N, P_X, d) bf16
-            sc = torch.einsum("bid,xmd->bimx", eq.cpu().bfloat16().double(), table.double()).float().bfloat16().float()
+            table = mod._component_table().cpu()                       # (P_X, N, d) bf16 (item-group-major)
+            sc = torch.einsum("bid,mxd->bimx", eq.cpu().bfloat16().double(), table.double()).float().bfloat16().float()
             for b in range(q.shape[0]):
                 for gi_ in range(cfg.query_dot_product_groups):
                     for m in range(cfg.item_dot_product_groups):

@@ -28,7 +28,8 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _worker(rank: int, world: int, port: int, n_items: int, precision, ret, workload: str = "amzn-books"):
+def _worker(rank: int, world: int, port: int, sizes, precision, ret, workload: str = "amzn-books"):
+    """one spawn, every corpus size of `sizes` (an int or a tuple of ints) in turn: the processes' start-up (import, process group) is most of a case's time"""
     import rails_amd
     from oracle import mol_oracle as O
     from rails_amd import engine as E
@@ -46,94 +47,96 @@ def _worker(rank: int, world: int, port: int, n_items: int, precision, ret, work
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        cfg = O.CONFIGS[workload]
-        mol = build_module(cfg, O.synthetic_weights(cfg, seed=1), dev)
-        mol.precision = precision
-        B, k, avg_k = 9, 200, 300
-        q = O.synthetic_queries(cfg, B, seed=5).to(dev)
-        X = torch.from_numpy(O.hash_item_table(7, 0, n_items, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
-        ids = (torch.arange(n_items, dtype=torch.int64, device=dev) * 3 + 1).unsqueeze(0)
-        lo, hi = shard_bounds(n_items, world, rank)
-        with torch.inference_mode():
-            # exact: sharded == single-device brute force, bit for bit, on every rank
-            sh = ShardedMoLBruteForceTopK(mol, X[:, lo:hi], ids[:, lo:hi], n_items)
-            s, i = sh(q, k=k)
-            s2, i2 = sh(q, k=k)   # second call: recycled buffers
-            full_s, full_i = rails_amd.MoLBruteForceTopK(mol, X, ids)(q, k=k)
-            assert torch.equal(s, s2) and torch.equal(i, i2)
-            assert torch.equal(s, full_s) and torch.equal(i, full_i), "sharded exact top-k differs from the single-device result"
-            # pipelined: batch 2 is submitted before batch 1's exchange is taken -- bit-equal to the plain calls
-            q2 = O.synthetic_queries(cfg, B, seed=6).to(dev)
-            h1 = sh.submit(q, k)
-            h2 = sh.submit(q2, k)
-            p1 = sh.result(h1)
-            p2 = sh.result(h2)
-            r2 = sh(q2, k=k)
-            assert torch.equal(p1[0], s) and torch.equal(p1[1], i) and torch.equal(p2[0], r2[0]) and torch.equal(p2[1], r2[1]), "pipelined != unpipelined"
-            # CandidateIndex route: the seen-id filter inside the merge launch == forward + filter_seen_ids
-            kk = min(120, i.shape[1])
-            inv = i[:, torch.randperm(i.shape[1], device=dev)[:61]] if i.shape[1] >= 61 else i[:, :1].repeat(1, 61)
-            want_i, want_s = E.filter_seen_ids(i, s, inv, kk)
-            got = sh.forward_filtered(q, min(k, n_items), inv, kk)
-            assert got is not None and torch.equal(got[0], want_i) and torch.equal(got[1], want_s), "filtered merge != merge + filter"
-            cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)      # the harness object holds the whole id table; the module is sharded
-            c_i, c_s, _ = cand.get_top_k_outputs(q, kk, {}, sh, inv, truncate_k_prime_to=min(k, n_items))
-            assert torch.equal(c_i, want_i) and torch.equal(c_s, want_s)
-            provable = bool(sh._global_proof(q))    # (16x16x64: one a-priori eps exceeds PROVED_MAX_EPS -- the first pass writes per-pair upper bounds there)
-            assert provable or precision not in (None, "f16x3-exact"), "the global proof did not engage"
-            if precision in (None, "f16x3-exact") and provable:
-                # the default exact path and its explicit form prove ONCE for all shards (ShardedMoLBruteForceTopK's global proof): every call
-                # above went through it, was proved or redone, and no observed error exceeded the a-priori bound; with an absurd bound every
-                # verdict fails on every rank alike and the dense fp32 redo -- second exchange, output picked by the flag -- returns the same bits
-                st = sh.stats()
-                assert st.get("global_proof") is True and st["calls"] >= 6 and st["proved_calls"] + st["fallbacks"] == st["calls"] and st["bound_violations"] == 0, st
-                # (16x16x64 at 20 k items: a fifth of the corpus can reach the k-th score under the per-pair bounds -- calls are redone until the margin has grown)
-                assert n_items < 1000 or st["proved_calls"] >= 1 or workload == "synthetic-16x16x64", st
-                before = st["fallbacks"]
-                sh._gp_eps = 1.0e9
-                fs, fi = sh(q, k=k)
-                assert torch.equal(fs, full_s) and torch.equal(fi, full_i), "global proof: the redo differs from the single-device result"
+        for n_items in ((sizes,) if isinstance(sizes, int) else tuple(sizes)):
+            cfg = O.CONFIGS[workload]
+            mol = build_module(cfg, O.synthetic_weights(cfg, seed=1), dev)
+            mol.precision = precision
+            B, k, avg_k = 9, 200, 300
+            q = O.synthetic_queries(cfg, B, seed=5).to(dev)
+            X = torch.from_numpy(O.hash_item_table(7, 0, n_items, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+            ids = (torch.arange(n_items, dtype=torch.int64, device=dev) * 3 + 1).unsqueeze(0)
+            lo, hi = shard_bounds(n_items, world, rank)
+            with torch.inference_mode():
+                # exact: sharded == single-device brute force, bit for bit, on every rank
+                sh = ShardedMoLBruteForceTopK(mol, X[:, lo:hi], ids[:, lo:hi], n_items)
+                s, i = sh(q, k=k)
+                s2, i2 = sh(q, k=k)   # second call: recycled buffers
+                full_s, full_i = rails_amd.MoLBruteForceTopK(mol, X, ids)(q, k=k)
+                assert torch.equal(s, s2) and torch.equal(i, i2)
+                assert torch.equal(s, full_s) and torch.equal(i, full_i), "sharded exact top-k differs from the single-device result"
+                # pipelined: batch 2 is submitted before batch 1's exchange is taken -- bit-equal to the plain calls
+                q2 = O.synthetic_queries(cfg, B, seed=6).to(dev)
+                h1 = sh.submit(q, k)
+                h2 = sh.submit(q2, k)
+                p1 = sh.result(h1)
+                p2 = sh.result(h2)
+                r2 = sh(q2, k=k)
+                assert torch.equal(p1[0], s) and torch.equal(p1[1], i) and torch.equal(p2[0], r2[0]) and torch.equal(p2[1], r2[1]), "pipelined != unpipelined"
+                # CandidateIndex route: the seen-id filter inside the merge launch == forward + filter_seen_ids
+                kk = min(120, i.shape[1])
+                inv = i[:, torch.randperm(i.shape[1], device=dev)[:61]] if i.shape[1] >= 61 else i[:, :1].repeat(1, 61)
+                want_i, want_s = E.filter_seen_ids(i, s, inv, kk)
                 got = sh.forward_filtered(q, min(k, n_items), inv, kk)
-                assert torch.equal(got[0], want_i) and torch.equal(got[1], want_s)
-                after = sh.stats()["fallbacks"]
-                if workload == "synthetic-16x16x64":    # (the margin may have grown to the whole shard by now)
-                    assert before <= after <= before + 2
-                else:
-                    assert after == before + (2 if n_items >= 1000 else 0)     # (a shard that is all candidates leaves nothing outside: proved whatever the bound)
-                sh._gp_eps = sh._local_module._proved_eps()
-            if precision in ("f16x3-exact", "f16-exact"):   # ... and both are the fp32 path's result, bit for bit
-                mol32 = build_module(cfg, O.synthetic_weights(cfg, seed=1), dev)
-                f32_s, f32_i = rails_amd.MoLBruteForceTopK(mol32, X, ids)(q, k=k)
-                assert torch.equal(s, f32_s) and torch.equal(i, f32_i), "f16x3-exact sharded top-k differs from the fp32 path"
-            # two-pass: sharded == merge of the per-shard MoLAvgTopK results (exact MoL scores, shard-major ties)
-            sa = ShardedMoLAvgTopK(mol, X[:, lo:hi], ids[:, lo:hi], n_items, avg_top_k=avg_k)
-            a_s, a_i = sa(q, k=k)
-            parts = []
-            for r in range(world):
-                l2, h2 = shard_bounds(n_items, world, r)
-                parts.append(rails_amd.MoLAvgTopK(mol, X[:, l2:h2], ids[:, l2:h2], avg_top_k=min(avg_k, h2 - l2))(q, k=min(k, h2 - l2)))
-            es, epos = E.topk(torch.cat([p[0] for p in parts], 1), k)
-            assert torch.equal(a_s, es) and torch.equal(a_i, torch.gather(torch.cat([p[1] for p in parts], 1), 1, epos))
-            # global K': coarse candidates exchanged first -> exactly the single-device MoLAvgTopK, bit for bit
-            gk = min(avg_k, n_items)
-            sg = ShardedMoLAvgTopK(mol, X[:, lo:hi], ids[:, lo:hi], n_items, avg_top_k=gk, global_k_prime=True)
-            g_s, g_i = sg(q, k=min(k, gk))
-            o_s, o_i = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=gk)(q, k=min(k, gk))
-            assert torch.equal(g_s, o_s) and torch.equal(g_i, o_i), "global-K' sharded two-pass differs from the single-device algorithm"
-        ret[rank] = (dist.get_backend(), s.cpu(), i.cpu())
+                assert got is not None and torch.equal(got[0], want_i) and torch.equal(got[1], want_s), "filtered merge != merge + filter"
+                cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)      # the harness object holds the whole id table; the module is sharded
+                c_i, c_s, _ = cand.get_top_k_outputs(q, kk, {}, sh, inv, truncate_k_prime_to=min(k, n_items))
+                assert torch.equal(c_i, want_i) and torch.equal(c_s, want_s)
+                provable = bool(sh._global_proof(q))    # (16x16x64: one a-priori eps exceeds PROVED_MAX_EPS -- the first pass writes per-pair upper bounds there)
+                assert provable or precision not in (None, "f16x3-exact"), "the global proof did not engage"
+                if precision in (None, "f16x3-exact") and provable:
+                    # the default exact path and its explicit form prove ONCE for all shards (ShardedMoLBruteForceTopK's global proof): every call
+                    # above went through it, was proved or redone, and no observed error exceeded the a-priori bound; with an absurd bound every
+                    # verdict fails on every rank alike and the dense fp32 redo -- second exchange, output picked by the flag -- returns the same bits
+                    st = sh.stats()
+                    assert st.get("global_proof") is True and st["calls"] >= 6 and st["proved_calls"] + st["fallbacks"] == st["calls"] and st["bound_violations"] == 0, st
+                    # (16x16x64 at 20 k items: a fifth of the corpus can reach the k-th score under the per-pair bounds -- calls are redone until the margin has grown)
+                    assert n_items < 1000 or st["proved_calls"] >= 1 or workload == "synthetic-16x16x64", st
+                    before = st["fallbacks"]
+                    sh._gp_eps = 1.0e9
+                    fs, fi = sh(q, k=k)
+                    assert torch.equal(fs, full_s) and torch.equal(fi, full_i), "global proof: the redo differs from the single-device result"
+                    got = sh.forward_filtered(q, min(k, n_items), inv, kk)
+                    assert torch.equal(got[0], want_i) and torch.equal(got[1], want_s)
+                    after = sh.stats()["fallbacks"]
+                    if workload == "synthetic-16x16x64":    # (the margin may have grown to the whole shard by now)
+                        assert before <= after <= before + 2
+                    else:
+                        assert after == before + (2 if n_items >= 1000 else 0)     # (a shard that is all candidates leaves nothing outside: proved whatever the bound)
+                    sh._gp_eps = sh._local_module._proved_eps()
+                if precision in ("f16x3-exact", "f16-exact"):   # ... and both are the fp32 path's result, bit for bit
+                    mol32 = build_module(cfg, O.synthetic_weights(cfg, seed=1), dev)
+                    f32_s, f32_i = rails_amd.MoLBruteForceTopK(mol32, X, ids)(q, k=k)
+                    assert torch.equal(s, f32_s) and torch.equal(i, f32_i), "f16x3-exact sharded top-k differs from the fp32 path"
+                # two-pass: sharded == merge of the per-shard MoLAvgTopK results (exact MoL scores, shard-major ties)
+                sa = ShardedMoLAvgTopK(mol, X[:, lo:hi], ids[:, lo:hi], n_items, avg_top_k=avg_k)
+                a_s, a_i = sa(q, k=k)
+                parts = []
+                for r in range(world):
+                    l2, h2 = shard_bounds(n_items, world, r)
+                    parts.append(rails_amd.MoLAvgTopK(mol, X[:, l2:h2], ids[:, l2:h2], avg_top_k=min(avg_k, h2 - l2))(q, k=min(k, h2 - l2)))
+                es, epos = E.topk(torch.cat([p[0] for p in parts], 1), k)
+                assert torch.equal(a_s, es) and torch.equal(a_i, torch.gather(torch.cat([p[1] for p in parts], 1), 1, epos))
+                # global K': coarse candidates exchanged first -> exactly the single-device MoLAvgTopK, bit for bit
+                gk = min(avg_k, n_items)
+                sg = ShardedMoLAvgTopK(mol, X[:, lo:hi], ids[:, lo:hi], n_items, avg_top_k=gk, global_k_prime=True)
+                g_s, g_i = sg(q, k=min(k, gk))
+                o_s, o_i = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=gk)(q, k=min(k, gk))
+                assert torch.equal(g_s, o_s) and torch.equal(g_i, o_i), "global-K' sharded two-pass differs from the single-device algorithm"
+            ret[(rank, n_items)] = (dist.get_backend(), s.cpu(), i.cpu())
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("precision", [None, "f16x3", "f16x3-exact", "f16-exact"])
-@pytest.mark.parametrize("n_items", [70_001, 331])   # second case: the last shard is shorter than k
-def test_two_ranks_through_the_hip_modules(n_items, precision):
+def test_two_ranks_through_the_hip_modules(precision):
     world = 2
+    sizes = (70_001, 331)   # second case: the last shard is shorter than k
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(world, _free_port(), n_items, precision, ret), nprocs=world, join=True)
-    assert set(ret.keys()) == {0, 1}
-    assert torch.equal(ret[0][1], ret[1][1]) and torch.equal(ret[0][2], ret[1][2])   # identical on every rank
-    assert ret[0][0] == ("nccl" if torch.cuda.device_count() >= world else "gloo")
+    mp.spawn(_worker, args=(world, _free_port(), sizes, precision, ret), nprocs=world, join=True)
+    assert set(ret.keys()) == {(r, n) for r in range(world) for n in sizes}
+    for n in sizes:
+        assert torch.equal(ret[(0, n)][1], ret[(1, n)][1]) and torch.equal(ret[(0, n)][2], ret[(1, n)][2])   # identical on every rank
+        assert ret[(0, n)][0] == ("nccl" if torch.cuda.device_count() >= world else "gloo")
 
 
 @pytest.mark.parametrize("precision", [None, "f16x3", "f16-exact"])
@@ -143,8 +146,8 @@ def test_two_ranks_16x16x64(precision):
     world = 2
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, _free_port(), 20_003, precision, ret, "synthetic-16x16x64"), nprocs=world, join=True)
-    assert set(ret.keys()) == {0, 1}
-    assert torch.equal(ret[0][1], ret[1][1]) and torch.equal(ret[0][2], ret[1][2])
+    assert set(ret.keys()) == {(0, 20_003), (1, 20_003)}
+    assert torch.equal(ret[(0, 20_003)][1], ret[(1, 20_003)][1]) and torch.equal(ret[(0, 20_003)][2], ret[(1, 20_003)][2])
 
 
 def _bench_two_ranks(*extra):

@@ -56,7 +56,7 @@ with torch.inference_mode():
         print("global proof: eps", eps, "kc per rank", kc)
 
     host = torch.zeros(8, dtype=torch.float32).pin_memory()
-    call_ws = torch.zeros(8, dtype=torch.int32, device=dev)
+    call_ws = torch.zeros(8 + 4 * B, dtype=torch.int32, device=dev)
     issued = [0]
 
     def global_step():
