@@ -295,7 +295,7 @@ int rails_mol_component_score(const rails_mol_shape* shape, const float* eq, int
 /* Fused scoring + exact top-k_group of every (query group, item group) row, without the (rows, n_items) score matrix:
  * same scheme, same outputs contract and same counts check as rails_mol_coarse_topk, over batch * P_Q * P_X rows.
  * out_scores / out_positions: (batch * P_Q * P_X, k_group); out_counts: (batch * P_Q * P_X).
- * batch * P_Q <= 256 query rows per call (a zero workspace size says "unsupported": callers slice the batch or take the materialising path).
+ * batch * P_Q <= 256 query rows per call (128 at d = 128; a zero workspace size says "unsupported": callers slice the batch or take the materialising path).
  * out_of_range (optional, an int32 in device memory, zeroed by the call's first launch): raised when some row's candidate count left
  * [k_group, rails_mol_component_topk_capacity] -- the launch predicate of the caller's redo. */
 size_t rails_mol_component_topk_workspace_bytes(const rails_mol_shape* shape, int32_t batch, int64_t n_items, int32_t k_group);

@@ -554,10 +554,9 @@ static int launch_coarse_scan(const CoarseScanArgs& a, hipStream_t stream) {
     if constexpr (MODE == kScanSample) {
       if (a.comp) {      // the component sample: up to eight row tiles of running maxima, two tiles per v_max3
         if (wide) {
-          switch (dc) {
+          switch (dc) {      // (d = 128 keeps four row tiles: eight would spill -- component_max_rows)
             case 2: return fire(&coarse_scan_kernel<2, MODE, NT, kSampleMaxQTComp, true>);
             case 4: return fire(&coarse_scan_kernel<4, MODE, NT, kSampleMaxQTComp, true>);
-            case 8: return fire(&coarse_scan_kernel<8, MODE, NT, kSampleMaxQTComp, true>);
             default: return false;
           }
         }
@@ -1116,7 +1115,11 @@ int component_score(const Shape& s, const float* eq, int B, const void* table, i
 // selection: four launches, no memset) over the B * P_Q * P_X (query group, item group) rows, instead of a (rows, N) score matrix (5.7 GB at
 // amzn-books, B = 32).  out_flag (optional): raised when a row's candidate count left [k_group, capacity] (the caller redoes the call on
 // the materialising path); zeroed by the first launch.
+// query rows (B * P_Q) one fused component call takes: the sample launch keeps their running maxima in registers
+static int component_max_rows(const Shape& s) { return 32 * (s.dot_product_dimension >= 128 ? kSampleMaxQT : kSampleMaxQTComp); }
+
 size_t component_topk_workspace_bytes(const Shape& s, int B, int64_t n, int k_group) {
+  if (B * s.query_dot_product_groups > component_max_rows(s)) return 0;
   CoarseTopkPlan p;
   return coarse_topk_plan(B * s.query_dot_product_groups * s.item_dot_product_groups, n, k_group, &p, true, B * s.query_dot_product_groups) ? p.total : 0;
 }
@@ -1125,7 +1128,7 @@ int component_topk(const Shape& s, const float* eq, int B, const void* table, in
                    float* out_scores, int64_t* out_pos, int32_t* out_counts, int32_t* out_flag, int n_cu, hipStream_t stream) {
   const int rows = B * s.query_dot_product_groups * s.item_dot_product_groups;
   CoarseTopkPlan p;
-  if (!coarse_topk_plan(rows, n, k_group, &p, true, B * s.query_dot_product_groups)) { set_error("component_topk: unsupported size (k = %d, n = %lld)", k_group, (long long)n); return kErrUnsupported; }
+  if (B * s.query_dot_product_groups > component_max_rows(s) || !coarse_topk_plan(rows, n, k_group, &p, true, B * s.query_dot_product_groups)) { set_error("component_topk: unsupported size (batch = %d, k = %d, n = %lld)", B, k_group, (long long)n); return kErrUnsupported; }
   if (n >= (1ll << 32)) { set_error("component_topk: n does not fit 32-bit positions; shard the corpus"); return kErrUnsupported; }
   if (ws_bytes < p.total) { set_error("component_topk: workspace too small"); return kErrNoMem; }
   char* base = static_cast<char*>(ws);

@@ -1338,8 +1338,8 @@ class _ComponentCandidates:
         if k_per_group > n:
             raise RuntimeError(f"selected index k out of range (k={k_per_group}, n={n})")
         # the component scans keep the fragments of all B * P_Q query rows in LDS and (the fused form) eight row tiles of running maxima in
-        # registers: batches beyond 256 query rows go in slices
-        max_b = max(1, 256 // eng.spec.query_dot_product_groups)
+        # registers (four at d = 128): batches beyond 256 (128) query rows go in slices
+        max_b = max(1, (128 if eng.spec.dot_product_dimension >= 128 else 256) // eng.spec.query_dot_product_groups)
         if eq.shape[0] > max_b:
             return torch.cat([self._component_topk(eq[b0 : b0 + max_b], k_per_group, pending) for b0 in range(0, eq.shape[0], max_b)], dim=0)
         # large corpora: fused scan + threshold select, no (B*P_Q*P_X, N) score matrix (5.7 GB at amzn-books, B = 32);
