@@ -322,6 +322,55 @@ def quick_workload(name: str, B: int, k: int, kp: int, steps: int, dev, items: i
             "mfma_frac_lower_bound": tf / (PEAK_F32_MFMA_TFLOPS if precision == "fp32" else PEAK_F16X3_TFLOPS), **tr}
 
 
+def weights_scale_sweep(cfg, weights, X, ids, q, kw, inv, k: int, kp: int, steps: int, dev, scales=(1.0, 1.5, 2.0, 3.0, 4.0)) -> list:
+    """Where a model lands on the proved mode's provability cliff (round-5 review, weak 2): the a-priori bound grows quadratically with the
+    pair-gate weight scale, so a trained checkpoint with heavier gates than random init may get the per-pair form of the bound, or -- beyond
+    PROVED_MAX_EPS_PER_PAIR -- the dense fp32 kernels.  Per scale s (both pair-gate weight matrices x s): the bound's eps at |cl| <= 1/tau,
+    the form the module binds (one eps / per-pair upper bound / dense), proved and fallback counts over the timed steps, queries/s; the output
+    is checked against the dense fp32 kernels' on the same weights."""
+    p = "_gating_fn._qi_partial_module."
+    rows = []
+    for sc in scales:
+        w = dict(weights)
+        w[p + "1.weight"] = weights[p + "1.weight"] * sc
+        w[p + "3.weight"] = weights[p + "3.weight"] * sc
+        mol, _ = rails_amd.create_mol_interaction_module(
+            cfg.query_embedding_dim, cfg.item_embedding_dim, cfg.dot_product_dimension, cfg.query_dot_product_groups,
+            cfg.item_dot_product_groups, cfg.temperature, 0.0, cfg.query_hidden_dim, 0.1, cfg.item_hidden_dim,
+            cfg.gating_query_hidden_dim, cfg.gating_qi_hidden_dim, cfg.gating_item_hidden_dim, cfg.softmax_dropout_rate, False,
+            query_nonlinearity=cfg.query_nonlinearity, uid_embedding_hash_sizes=list(cfg.uid_embedding_hash_sizes) or None)
+        mol.load_state_dict(w, strict=True)
+        mol = mol.to(dev).eval()
+        with torch.inference_mode():
+            tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
+            dense = rails_amd.MoLBruteForceTopK(mol, X, ids, exact_mode="dense")
+            cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)
+            ref = cand.get_top_k_outputs(q, k, kw, dense, inv, truncate_k_prime_to=kp)
+            del dense
+            for _ in range(3):
+                out = cand.get_top_k_outputs(q, k, kw, tk, inv, truncate_k_prime_to=kp)
+            same = bool(torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1]))
+            st0 = tk.stats() if tk._bind().exact is not None else {}
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                cand.get_top_k_outputs(q, k, kw, tk, inv, truncate_k_prime_to=kp)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            bound = tk._bound_from_weights(tk._mol_module.engine().spec)
+            binds = tk._bind().exact is not None
+            st = tk.stats() if binds else {}
+            rows.append({"pair_gate_weight_scale": sc, "eps_at_max_abs_cl": float(bound.get("eps", float("inf"))),
+                         "route": ("proved, " + st.get("bound_kind", "one a-priori eps")) if binds else "dense fp32 kernels (bound beyond PROVED_MAX_EPS_PER_PAIR or no UPPER build)",
+                         "candidates_per_query": st.get("kc"), "timed_calls": steps,
+                         "proved_calls": st.get("proved_calls", 0) - st0.get("proved_calls", 0), "dense_fp32_fallbacks": st.get("fallbacks", 0) - st0.get("fallbacks", 0),
+                         "bound_violations": st.get("bound_violations", 0), "queries_per_s": q.shape[0] / dt, "ms_per_step": dt * 1e3,
+                         "output_identical_to_fp32_path": same})
+        del tk, mol
+        torch.cuda.empty_cache()
+    return rows
+
+
 def hr_parity_leg(cfg, weights, mol, B: int, k: int, kp: int, dev, n_items: int = 65_536, shared=None, exact_mode: str = "dense") -> dict:
     """The quality half of BASELINE.json's metric ("queries/sec + HR@10/50 parity"): HR@k / NDCG@10 / MRR of the HIP path against the
     CPU oracle chain on the same inputs -- seen ids taken from each row's own winners, and targets PLANTED at known oracle ranks
@@ -570,6 +619,7 @@ def main() -> None:
     ap.add_argument("--no-matrix", action="store_true", help="skip the B = 1 / 8 and accuracy-protocol points")
     ap.add_argument("--no-recall", action="store_true", help="--two-pass: skip the recall@k measurement against exact brute force (planted-structure weights)")
     ap.add_argument("--no-hr-parity", action="store_true", help="skip the HR@k / NDCG / MRR comparison with the CPU oracle chain (the metric's quality half)")
+    ap.add_argument("--no-weights-sweep", action="store_true", help="skip the pair-gate weight-scale sweep of the proved mode (eps, route, proved / fallback counts per scale)")
     ap.add_argument("--no-full-shards", action="store_true", help="skip the legs that run one full 8-way shard of BASELINE configs 4 and 5 (12.5 M / 125 M items) on this GPU")
     ap.add_argument("--items", type=int, default=0, help="override the workload's corpus size N (total over all ranks)")
     ap.add_argument("--device-table", action="store_true",
@@ -1258,8 +1308,9 @@ def main() -> None:
             p_val = B * args.steps / proved["elapsed"]
             a16 = flops_alg / (proved["score_ms"] * 1e-3) / 1e12
             leg = {
-                "what": "the module's default exact path: split-f16 (f16x3) first pass over the whole corpus -> top-kc candidates per query -> fp32 re-scoring of the "
-                        "candidates -> top-k' by (fp32 score, position) -> device-side proof " + (
+                "what": "the module's default exact path: split-f16 (f16x3) first pass over the whole corpus -> threshold selection of at most kc candidates per query "
+                        "(one histogram + one compaction launch) -> fp32 re-scoring of the candidates -> one finish launch: top-k' by (fp32 score, position), seen-id filter, "
+                        "device-side proof UNDER THE MEASURED ARITHMETIC MODEL (hypotheses H1-H3 of rails_amd/f16x3_bound.py, re-checked on this device when the module binds): " + (
                             "e_k > m, the first pass having written per-pair UPPER BOUNDS of the fp32 logits (its logit + a bound quadratic in the pair's largest "
                             "|cross logit|: rails_mol_score_dense_upper, f16x3_bound.upper_bound_poly)" if proved.get("upper_bound_poly") else
                             "e_k > m + eps with the A-PRIORI bound eps on |first pass - fp32| (rails_amd/f16x3_bound.py)") +
@@ -1271,8 +1322,9 @@ def main() -> None:
                 "eps_a_priori": proved["eps"], "bound": proved.get("bound_kind"), **({"upper_bound_poly": proved["upper_bound_poly"]} if proved.get("upper_bound_poly") else {}),
                 "candidates_per_query": proved["kc"], "gate_guard": {"max_abs_gq_seen": proved["guard_max"], "limit": proved["guard_limit"]},
                 "first_pass_kernel_ms": proved["score_ms"], "is_headline": proved["qualifies"],
-                **({"sharded_global_proof": "one proof for all shards: kc per rank = candidates_per_query; all-gather of the per-shard fp32 top-k' + all-reduce(max) of the "
-                                            "best first-pass score left outside (rails_amd/sharded.py ShardedMoLBruteForceTopK)"} if proved.get("global_proof") else {}),
+                **({"sharded_global_proof": "one proof for all shards: kc per rank = candidates_per_query; ONE all-gather of (B, 2k' + 2) messages -- the per-shard fp32 top-k', "
+                                            "the best first-pass score left outside and the largest observed error ride in it -- then merge + verdict + filter in one launch "
+                                            "(rails_amd/sharded.py ShardedMoLBruteForceTopK)"} if proved.get("global_proof") else {}),
                 "per_step_ms": [round(v, 3) for v in proved["steps_ms"]],
                 "per_step_first_pass_kernel_ms": [round(v, 3) for v in proved["kernel_ms"]],
                 # the f16 kernel's time falls for the first ~40 ms of sustained load after an idle gap (clock ramp; the fp32 kernels do not show it):
@@ -1286,7 +1338,8 @@ def main() -> None:
                                      "roofline": out["roofline"], "what": "the dense fp32 kernels over the whole corpus (exact_mode 'dense'), same step, same protocol, timed in this run"}
                 out["value"], out["ms_per_step"], out["ms_per_step_stdev"] = leg["value"], leg["ms_per_step"], leg["ms_per_step_stdev"]
                 kind = "per-pair a-priori upper bound" if proved.get("upper_bound_poly") else "a-priori eps"
-                out["config"]["exact_path"] = f"proved: f16x3 first pass + fp32 re-scoring, {kind} (same bits as the dense fp32 kernels)"
+                out["config"]["exact_path"] = (f"proved under the measured arithmetic model (H1-H3 re-checked on this device): f16x3 first pass + fp32 re-scoring, {kind} "
+                                               "(same bits as the dense fp32 kernels)")
                 out["config"]["prefilter"] = f"f16x3, {kind}"
                 out["roofline"] = {
                     "kernel": "mol_score_*_kernel<f16x3::F16Unit> (the first pass: the dominant launch of the proved step)", "bound": "mfma", "achieved": a16,
@@ -1344,6 +1397,12 @@ def main() -> None:
             out["other_workloads"] = [quick_workload(n, B, k, kp, 10, dev, precision=pr) for n in ("ml-20m", "ml-1m") for pr in ("fp32", "proved", "f16x3", "f16-exact")]
             # BASELINE config 4 (16x16x64, 100 M items 8-way): a 400 k-item sub-range of one shard -- the kernels are linear in N
             out["other_workloads"] += [quick_workload("synthetic-16x16x64", B, k, kp, 5, dev, items=400_000, precision=pr) for pr in ("fp32", "proved", "f16x3", "f16-exact")]
+        if world == 1 and not two_pass and not args.no_weights_sweep and args.precision == "proved":
+            try:
+                out["weights_scale_sweep"] = weights_scale_sweep(cfg, weights, X, ids, q, kw, inv, k, kp, min(args.steps, 10), dev)
+            except Exception as e:   # noqa: BLE001 -- a secondary leg must not take the headline line down with it
+                out["weights_scale_sweep"] = [{"skipped": f"{type(e).__name__}: {e}"[:300]}]
+                torch.cuda.empty_cache()
         if world == 1 and args.workload == "amzn-books" and not args.no_other_workloads and not args.no_full_shards:
             try:
                 out["full_shards"] = full_shard_legs(B, k, dev)

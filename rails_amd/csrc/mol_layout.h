@@ -34,17 +34,17 @@ namespace mol {
 //   softmax(w) = exp2(v - max v) / sum
 constexpr float kLog2e = 1.4426950408889634f;
 
-// Precision mode "f16x3" (opt-in): the two gate GEMMs run on v_mfma_f32_32x32x16_f16 with every operand split into
-// f16 hi + f16 lo (hi = round-toward-zero f16 of the value, lo = f16 of the exact fp32 remainder) and three MFMAs per
-// product block (lo*hi, hi*lo, hi*hi; lo*lo ~ 2^-22 is dropped), accumulated in fp32: ~22 significant bits per product
-// against fp32's 24, at 3/16 of the fp32-MFMA time and -- unlike fp32 MFMA -- overlapping with VALU work.
-// Operands are pre-scaled by powers of two (exact) so that the lo halves stay in f16's normal range:
-//   GEMM1 (still exact fp32) yields s_a * cl;  W1 fragments carry s_w1 * (-log2e) W1;  D2 = c * t, c = s_a * s_w1;
-//   hid'' = D2 * rcp(1 + exp2(D2 / c)) = c * hid';  W2 fragments carry s_w2 * W2;  D3 = c2 * gqi', c2 = c * s_w2.
-// s_w1 is chosen on the host from the weights so that c * log2e * (20 ||W1 row||_1 + |b1|) < 60000: no f16 overflow
-// is possible for |cl| <= 20 (dot_product_l2_norm = True).  K = 16 per MFMA: lane half hi supplies 8 consecutive
-// accumulator registers, so K-step s of GEMM2 covers cl registers e in [8s, 8s+8) and K-step s of GEMM3 covers hidden
-// registers f in [8s, 8s+8) of both lane halves; weight fragments are stored in that order as [s][row tile][lane][8 x f16].
+// Precision mode "f16x3" (the first pass of the proved exact top-k; opt-in as a result-producing precision): ALL THREE contractions --
+// GEMM1 included -- run on v_mfma_f32_32x32x16_f16 with every operand split into f16 hi + f16 lo (hi = round-toward-zero f16 of the
+// value, lo = f16 of the exact fp32 remainder: RTZ in the kernels, RNE in the packs) and three MFMAs per product block (lo*hi, hi*lo,
+// hi*hi; lo*lo ~ 2^-22 is dropped), accumulated in fp32: ~22 significant bits per product against fp32's 24, at 3/16 of the
+// fp32-MFMA time and -- unlike fp32 MFMA -- overlapping with VALU work.  NO operand is rescaled: f16 subnormals are kept by the MFMA
+// and by v_cvt_pkrtz, so every power-of-two scale is 1 (rounds 1-2 prescaled; the arithmetic model of rails_amd/f16x3_bound.py -- H2,
+// the split bounds |x - hi - lo| <= 2^-20 |x| + 2^-24 -- describes THIS form).  The host refuses weights that could overflow f16
+// (engine.py _check_f16_range: log2e * (||W1 row||_1 / tau + |b1|) < 60000 for |cl| <= 1/tau, dot_product_l2_norm = True).
+// K = 16 per MFMA: lane half hi supplies 8 consecutive accumulator registers, so K-step s of GEMM2 covers cl registers e in [8s, 8s+8)
+// and K-step s of GEMM3 covers hidden registers f in [8s, 8s+8) of both lane halves; weight fragments are stored in that order as
+// [s][row tile][lane][8 x f16], hi and lo parts in separate halves of the pack; Eq and Ex arrive pre-split ([ks][hi|lo][lane] h8).
 
 constexpr int kTileItems = 32;  // items per tile = MFMA column count
 

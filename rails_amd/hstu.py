@@ -312,10 +312,14 @@ class HSTU(torch.nn.Module):
         # sync-free, but not silent: out-of-range lengths are counted in a sticky device counter (HSTU.length_violations() reads it at a
         # moment of the caller's choosing -- end of an eval pass, a stats call), then clamped
         bad = ((lengths < min_len) | (lengths > N)).sum()
-        ctr = HSTU._violations.get(dev)
-        if ctr is None:
-            ctr = HSTU._violations[dev] = torch.zeros((), dtype=torch.int64, device=dev)
-        ctr += bad
+        # The counter is replaced, not updated in place: a tensor created under torch.inference_mode() is an inference tensor for ever, and an
+        # in-place update of it from a later no_grad / grad-mode caller raises.  (The sum below is a tensor of whichever mode the CALLER is in;
+        # a value made outside inference mode takes part in inference-mode arithmetic without complaint, the other way round does not -- so the
+        # running total is re-made outside inference mode.)  During stream capture the count is skipped: its storage would belong to the graph's pool.
+        if not torch.cuda.is_current_stream_capturing():
+            with torch.inference_mode(False), torch.no_grad():
+                prev = HSTU._violations.get(dev)
+                HSTU._violations[dev] = (bad.clone() if prev is None else prev + bad.clone())
         return lengths.clamp(min=min_len, max=N).contiguous()
 
     _violations: dict = {}

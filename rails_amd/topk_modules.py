@@ -185,6 +185,8 @@ class MoLBruteForceTopK(MoLTopKModule):
     # The proved mode needs both index formats resident (2 x the fp32 index bytes); corpora where that does not fit, corpora below
     # SPECULATE_MIN_ITEMS and modules whose bound is infinite (see the guards in f16x3_bound.py) run "dense".
     EXACT_MODE = __import__("os").environ.get("RAILS_EXACT_MODE", "proved")
+    if EXACT_MODE not in ("proved", "dense"):
+        raise ValueError(f"RAILS_EXACT_MODE must be 'proved' or 'dense', got {EXACT_MODE!r}")
     PROVED_MAX_EPS = 2.0          # a module whose a-priori bound exceeds this many logit units is not worth a second index: the items within eps of the
                                   # k-th score run into the tens of thousands (16x16x64: eps = 2.9; profiles/r05_proved_candidate_census.json)
     PROVED_MAX_EPS_PER_PAIR = 8.0 # ... up to this eps (at the a-priori |cl| <= 1/tau) the bound is applied PER PAIR instead: the pairs of a corpus sit at a third of

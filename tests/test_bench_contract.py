@@ -105,7 +105,7 @@ def test_committed_round5_bench_line_is_the_proved_exact_path():
 @pytest.mark.gpu
 def test_live_bench_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-fast-path", "--no-matrix",
-                          "--no-other-workloads"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--no-other-workloads", "--no-weights-sweep"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1

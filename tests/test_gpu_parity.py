@@ -134,8 +134,11 @@ def test_f5_harness_metrics(dev):
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
-@pytest.mark.parametrize("name", ["full_c1_ml1m", "full_c2_ml20m"])
+@pytest.mark.parametrize("name", ["full_c1_ml1m", "full_c2_ml20m", "full_c3_books"])
 def test_f7_full_size(name, dev, precision):
+    """MoLBruteForceTopK's default route against the REFERENCE's own output at the corpora's full sizes.  full_c3_books (round 6): all
+    695 762 items of the headline workload -- the default route there is the PROVED flow (split-f16 first pass, fused tail), compared
+    here with what rails.indexing.mol_top_k.MoLBruteForceTopK itself returned (oracle/gen_golden.py), not with another HIP kernel."""
     fx = Fixture(name)
     mol = build_module(fx.cfg, fx.weights, dev, precision)
     X, ids = full_size_inputs(fx)
@@ -150,8 +153,12 @@ def test_f7_full_size(name, dev, precision):
     for tol in (1e-5, 2e-5):
         c = tie_branch_census(i, fx.t("scores"), fx.t("ids"), tol)
         assert c["positions_differing"] <= 0.01 * c["rows"] * c["k"] and c["positions_outside_tie_runs"] == 0, c
-    assert float((logits[0].cpu() - fx.t("logits_first_row")).abs().max()) <= LOGIT_TOL
+    if "logits_first_row" in fx.z:
+        assert float((logits[0].cpu() - fx.t("logits_first_row")).abs().max()) <= LOGIT_TOL
     assert float((logits.double().sum(1).cpu() - fx.t("logits_rowsum_f64")).abs().max()) <= LOGIT_TOL * logits.shape[1] * 0.05
+    if name == "full_c3_books" and precision == "fp32":
+        st = tk.stats()
+        assert tk._bind().exact is not None and st["proved_calls"] == st["calls"] == 1 and st["fallbacks"] == 0, st      # the proved route answered
 
 
 # ---- selection kernels on their own ---------------------------------------------------------------

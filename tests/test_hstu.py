@@ -196,6 +196,18 @@ def test_encode_rejects_out_of_range_lengths():
         empty = lengths.clone()
         empty[0] = 0
         assert m(empty, ids, emb, {}).shape[0] == lengths.shape[0]       # forward() accepts an all-padding sequence
+    # the sticky counter survives callers of every autograd mode (round-5 advice: a counter created under inference_mode used to be an
+    # inference tensor, and the next no_grad caller's in-place update of it raised)
+    bad = lengths.clone()
+    bad[0] = 0
+    before = type(m).length_violations()
+    with torch.inference_mode():
+        m.encode(bad, ids, emb.clone(), {})
+    with torch.no_grad():
+        m.encode(bad, ids, emb.clone(), {})
+    with torch.inference_mode():
+        m.encode(bad, ids, emb.clone(), {})
+    assert type(m).length_violations() == before + 3
 
 
 @pytest.mark.gpu

@@ -96,14 +96,16 @@ def test_f5_harness_metrics():
     assert int((r == 121).sum()) > 0 and int((r <= 10).sum()) > 0
 
 
-@pytest.mark.parametrize("name", ["full_c1_ml1m", "full_c2_ml20m"])
+@pytest.mark.parametrize("name", ["full_c1_ml1m", "full_c2_ml20m", "full_c3_books"])
 def test_f7_full_size(name):
+    """the oracle against the reference's own output at the corpora's full sizes (C3: all 695 762 items of the headline workload, 8 queries)"""
     fx = Fixture(name)
     X, ids = full_size_inputs(fx)
-    s, i, logits = O.brute_force_topk(fx.cfg, fx.weights, fx.t("q"), X, ids, 200, fx.user_ids, chunk=4096)
+    s, i, logits = O.brute_force_topk(fx.cfg, fx.weights, fx.t("q"), X, ids, 200, fx.user_ids, chunk=4096 if X.shape[1] < 100_000 else 65536)
     assert_topk_matches(s, i, fx.t("scores"), fx.t("ids"), atol=3e-6)
-    assert np.allclose(logits.double().sum(1).numpy(), fx.z["logits_rowsum_f64"], rtol=0, atol=2e-2)
-    assert torch.allclose(logits[0], fx.t("logits_first_row"), atol=3e-6, rtol=0)
+    assert np.allclose(logits.double().sum(1).numpy(), fx.z["logits_rowsum_f64"], rtol=0, atol=2e-2 * max(1.0, X.shape[1] / 27278))
+    if "logits_first_row" in fx.z:
+        assert torch.allclose(logits[0], fx.t("logits_first_row"), atol=3e-6, rtol=0)
 
 
 def test_hash_item_table_is_shardable():
