@@ -38,6 +38,15 @@
 #ifndef RAILS_F16_TIGHT_PF
 #define RAILS_F16_TIGHT_PF 2   // epilogue operand ring depth of the TIGHT stream
 #endif
+// Round-6 latency experiments on the TIGHT stream (8x8x32 at two waves per SIMD; A/B builds, tools/r06_f16_pipe_ab.sh; results: DESIGN.md 7.1):
+//   RAILS_F16_TIGHT_YPIPE = 1  stage Y: silu + operand split of K-step s + 1 in the scheduling region of K-step s's MFMAs (both operand slots live)
+//   RAILS_F16_TIGHT_XPIPE = 1  stage X: the cl operand split of K-step s + 1 in the region of K-step s's MFMAs (a second operand slot)
+#ifndef RAILS_F16_TIGHT_YPIPE
+#define RAILS_F16_TIGHT_YPIPE 0
+#endif
+#ifndef RAILS_F16_TIGHT_XPIPE
+#define RAILS_F16_TIGHT_XPIPE 0
+#endif
 
 namespace mol {
 #if RAILS_F16_SINGLE
@@ -414,6 +423,9 @@ template <class G>
 struct XState {
   WSlots<1> ws;
   h8 bh, bl;         // current K-step's cl operand, split right before the K-step's first MFMA
+#if RAILS_F16_TIGHT_XPIPE
+  h8 bh2, bl2;       // the next K-step's, split one region ahead
+#endif
 };
 template <class G, class WP>
 __device__ __forceinline__ void init_d2(f32x16 (&D2)[G::TH], const WP& w, int hi) {
@@ -563,6 +575,21 @@ struct F16Unit {
       init_d2<G>(D2, w, hi);
       x_begin<G>(xs, w, lane);
       if constexpr (TIGHT) {
+#if RAILS_F16_TIGHT_XPIPE
+        cl_split<G, PX, Q * G::RPQ, 0>(D1, w, xs.bh, xs.bl);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<G::E / 8>([&](auto kc) {
+          constexpr int KS = decltype(kc)::value;
+          if constexpr (KS + 1 < G::E / 8) cl_split<G, PX, Q * G::RPQ, KS + 1>(D1, w, xs.bh2, xs.bl2);
+          static_for<3 * G::TH>([&](auto ic) {
+            constexpr int I = 3 * G::TH * KS + decltype(ic)::value;
+            seq_mfma<XSeq<G>, I>(D2, xs.ws, xs.bh, xs.bl, [&](bool hi_part, int f) { return (hi_part ? w.w1hi : w.w1lo)[f * 64 + lane]; });
+          });
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (KS + 1 < G::E / 8) { xs.bh = xs.bh2; xs.bl = xs.bl2; }
+        });
+        return;
+#endif
         static_for<G::E / 8>([&](auto kc) {
           static_for<3 * G::TH>([&](auto ic) { x_mfma<G, PX, Q * G::RPQ, 3 * G::TH * decltype(kc)::value + decltype(ic)::value>(D1, D2, xs, w, lane); });
           __builtin_amdgcn_sched_barrier(0);
@@ -574,6 +601,18 @@ struct F16Unit {
     auto stage_y = [&](auto qc) {         // silu of K-step 0 exposed, then GEMM3 || silu of the following K-steps
       y_begin<G>(ep.D3, ys, w, lane, hi);
       if constexpr (TIGHT) {
+#if RAILS_F16_TIGHT_YPIPE
+        static_for<4>([&](auto sc) { silu_slice<G, decltype(sc)::value>(D2, ys, w); });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NYS>([&](auto kc) {
+          constexpr int KS = decltype(kc)::value;
+          if constexpr (KS + 1 < NYS) static_for<4>([&](auto sc) { silu_slice<G, 4 * (KS + 1) + decltype(sc)::value>(D2, ys, w); });   // into slot (KS + 1) & 1
+          static_for<3 * G::TL>([&](auto ic) { y_mfma<G, 3 * G::TL * KS + decltype(ic)::value>(ep.D3, ys, w, lane); });
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        y_end<G>(ys, ep.D3);
+        return;
+#endif
         static_for<NYS>([&](auto kc) {
           constexpr int KS = decltype(kc)::value;
           static_for<4>([&](auto sc) { silu_slice<G, 4 * KS + decltype(sc)::value>(D2, ys, w); });
