@@ -342,7 +342,7 @@ def weights_scale_sweep(cfg, weights, X, ids, q, kw, inv, k: int, kp: int, steps
         mol.load_state_dict(w, strict=True)
         mol = mol.to(dev).eval()
         with torch.inference_mode():
-            tk = rails_amd.MoLBruteForceTopK(mol, X, ids)
+            tk = rails_amd.MoLBruteForceTopK(mol, X, ids, exact_mode="proved")      # (bench sets the class default to "dense" for its hand-driven legs)
             dense = rails_amd.MoLBruteForceTopK(mol, X, ids, exact_mode="dense")
             cand = rails_amd.CandidateIndex(ids=ids, embeddings=X)
             ref = cand.get_top_k_outputs(q, k, kw, dense, inv, truncate_k_prime_to=kp)
