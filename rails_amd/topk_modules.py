@@ -189,8 +189,10 @@ class MoLBruteForceTopK(MoLTopKModule):
         raise ValueError(f"RAILS_EXACT_MODE must be 'proved' or 'dense', got {EXACT_MODE!r}")
     PROVED_MAX_EPS = 2.0          # a module whose a-priori bound exceeds this many logit units is not worth a second index: the items within eps of the
                                   # k-th score run into the tens of thousands (16x16x64: eps = 2.9; profiles/r05_proved_candidate_census.json)
-    PROVED_MAX_EPS_PER_PAIR = 8.0 # ... up to this eps (at the a-priori |cl| <= 1/tau) the bound is applied PER PAIR instead: the pairs of a corpus sit at a third of
-                                  # 1/tau and the bound is quadratic in it (_bound_kind "upper": 16x16x64 at random init, 3.0; trained weights of the other shapes)
+    PROVED_MAX_EPS_PER_PAIR = 10.0 # ... up to this eps (at the a-priori |cl| <= 1/tau) the bound is applied PER PAIR instead: the pairs of a corpus sit at a third of
+                                  # 1/tau and the bound is quadratic in it (_bound_kind "upper": 16x16x64 at random init, 3.0; trained weights of the other shapes).
+                                  # Round 6 (tools/r06_scale_probe.py, amzn-books, pair-gate weights x s): x 3 (eps 8.6) proves 44 / 45 calls at 3 904 candidates,
+                                  # 2.78 ms per batch against 6.4 dense; x 4 (eps 15.2) proves none even at 16 384 candidates -- hence 10, not 8
     PAD_ONE_EPS = (824, 3)        # candidates beyond k: max(floor, per_k * k) (doubled after a failed verdict) -- under one eps ...
     PAD_PER_PAIR = (1848, 1)      # ... and under per-pair upper bounds (sized for a 12.5 M-item shard of 16x16x64: 730-900 items can reach the 200-th score;
                                   # amzn-books at k' = 2 561: 5 152 candidates prove every call where one eps needs 10 272)

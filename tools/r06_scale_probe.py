@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rails_amd
 from oracle import mol_oracle as O
 sc = float(sys.argv[1]); steps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+if len(sys.argv) > 3:
+    rails_amd.MoLBruteForceTopK.PROVED_MAX_EPS_PER_PAIR = float(sys.argv[3])      # policy probe: the per-pair form up to this eps
 dev = torch.device("cuda:0")
 cfg = O.CONFIGS["amzn-books"]; N, B, k, kp = 695762, 32, 120, 200
 w = O.synthetic_weights(cfg, seed=0)
