@@ -555,19 +555,27 @@ class MoLBruteForceTopK(MoLTopKModule):
     # to the device AND straight into pinned host memory) -> the dense redo under the verdict's launch predicate: 8-9 launches where the
     # exact-kc selection + separate verdict / filter / state copy took 19 (amzn-books B = 32: 0.19 -> ~0.1 ms behind the first pass).
     FUSED_TAIL = __import__("os").environ.get("RAILS_FUSED_TAIL", "1") != "0"
-    _cand = None          # (B, cap) -> (workspace, positions, first-pass scores, fp32 scores)
+    _cand = None          # {(B, cap): [workspace, positions, first-pass scores, fp32 scores]}
     _cand_dirty = False
 
     def _cand_buffers(self, B: int, cap: int):
-        c = self._cand
-        if c is None or c[0] != (B, cap):
+        """(workspace, positions, first-pass scores, fp32 scores) of a (batch, candidate cap): zero-initialised once (the workspace must be; stale
+        positions past a row's count must be valid), kept for the last few shapes (callers that alternate batch sizes do not reallocate)."""
+        pool = self._cand
+        if pool is None:
+            pool = self._cand = {}
+        c = pool.get((B, cap))
+        if c is None:
+            if len(pool) >= 4:
+                pool.pop(next(iter(pool)))
             dev = self._item_embeddings.device
-            c = self._cand = ((B, cap), E.candidates_workspace(B, dev), torch.zeros((B, cap), dtype=torch.int64, device=dev),
-                              torch.zeros((B, cap), dtype=torch.float32, device=dev), torch.zeros((B, cap), dtype=torch.float32, device=dev))
-            self._cand_dirty = False
-        if self._cand_dirty:       # an exception between select and finish left counts / histograms behind
-            c[1].zero_()
-        return c[1], c[2], c[3], c[4]
+            c = pool[(B, cap)] = [E.candidates_workspace(B, dev), torch.zeros((B, cap), dtype=torch.int64, device=dev),
+                                  torch.zeros((B, cap), dtype=torch.float32, device=dev), torch.zeros((B, cap), dtype=torch.float32, device=dev)]
+        elif self._cand_dirty:       # an exception between select and finish left counts / histograms behind
+            for v in pool.values():
+                v[0].zero_()
+        self._cand_dirty = False
+        return c[0], c[1], c[2], c[3]
 
     def _score_range(self, upper) -> Tuple[float, float]:
         """The a-priori range of the first-pass logits (the histogram's bins): a softmax mixture of cross logits in [-1/tau, 1/tau] (l2-normalised
