@@ -1324,8 +1324,7 @@ int select_sublists(const unsigned long long* keys, const unsigned int* counts, 
 //   valid  = not seen, and among the first k such
 //   if fewer than k are valid, back-fill with the first (k - #valid) of the others, in position order
 //   output = the selected positions in ascending position order (exactly k of them)
-constexpr int kFilterThreads = 256;
-
+template <int kFilterThreads>      // 256; 1 024 for long candidate rows (MoLNaiveTopK100's 6 400 per query: 45 -> ~15 us)
 __global__ __launch_bounds__(kFilterThreads) void filter_seen_kernel(const int64_t* __restrict__ top_ids,
                                                                     const float* __restrict__ top_scores, int k_prime,
                                                                     const int64_t* __restrict__ invalid, int width,
@@ -1867,8 +1866,10 @@ int filter_seen(const int64_t* top_ids, const float* top_scores, int rows, int k
   if (k > k_prime) { set_error("seen-id filter: k (%d) > k' (%d)", k, k_prime); return kErrInvalid; }
   const size_t lds = sizeof(int64_t) * (size_t)width + (size_t)k_prime + 16;
   if (lds > 60000) { set_error("seen-id filter: k' or width too large for LDS"); return kErrUnsupported; }
-  hipLaunchKernelGGL(filter_seen_kernel, dim3(rows), dim3(kFilterThreads), lds, stream, top_ids, top_scores, k_prime,
-                     invalid, width, k, out_ids, out_scores);
+  if (k_prime > 1024)
+    hipLaunchKernelGGL(filter_seen_kernel<1024>, dim3(rows), dim3(1024), lds, stream, top_ids, top_scores, k_prime, invalid, width, k, out_ids, out_scores);
+  else
+    hipLaunchKernelGGL(filter_seen_kernel<256>, dim3(rows), dim3(256), lds, stream, top_ids, top_scores, k_prime, invalid, width, k, out_ids, out_scores);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
 }
 

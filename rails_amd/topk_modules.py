@@ -1050,8 +1050,18 @@ class MoLBruteForceTopK(MoLTopKModule):
         return eng
 
 def _verdicts_clear(pending: list) -> bool:
-    """pending: device int32 verdict words of fused scans (1 = a candidate count left its range).  One host read each (normally one)."""
-    return all(int(bad.item()) == 0 for bad in pending)
+    """pending: int32 verdict words of fused scans (1 = a candidate count left its range), read after everything that depends on them is
+    enqueued.  Words in PINNED HOST memory (the component scans write theirs there: the kernels store through the device-visible address)
+    are read after a spin on an event -- no copy launch, no blocking sync (a blocking read parks the thread on an interrupt whose wake-up
+    costs 20-100 us of idle GPU per batch); device words cost one synchronising read each."""
+    if not pending:
+        return True
+    if any(not b.is_cuda for b in pending) and torch.cuda.is_available():
+        ev = torch.cuda.Event()
+        ev.record()
+        while not ev.query():
+            pass
+    return all(int(b.item() if b.is_cuda else b[0]) == 0 for b in pending)
 
 
 class MoLAvgTopK(MoLTopKModule):
@@ -1359,7 +1369,16 @@ class _ComponentCandidates:
         if n >= getattr(self, "fused_component_min_items", 262144) and not getattr(self, "_no_fused", False):
             rows = eq.shape[0] * eng.spec.query_dot_product_groups * eng.spec.item_dot_product_groups
             on_device = rows * n * 4 <= MoLAvgTopK.DEVICE_REDO_BYTES
-            flag = self._buf("redo_flag_c", 1, torch.int32) if on_device else torch.empty(1, dtype=torch.int32, device=eq.device)   # (zeroed by the call's first launch)
+            if on_device:
+                flag = self._buf("redo_flag_c", 1, torch.int32)      # (zeroed by the call's first launch)
+            else:
+                # the verdict word in pinned host memory, written by the kernels themselves: the caller spins on an event and reads it (no 4-byte
+                # copy launch, no blocking .item(): ~30 us of every Naive / Comb call at amzn-books)
+                pool = self.__dict__.setdefault("_flag_pool", [])
+                self.__dict__["_flag_turn"] = (self.__dict__.get("_flag_turn", -1) + 1) % 8
+                while len(pool) < 8:
+                    pool.append(torch.zeros(1, dtype=torch.int32).pin_memory())
+                flag = pool[self.__dict__["_flag_turn"]]
             fused = eng.component_topk(eq, table, k_per_group, flag)
             if fused is not None:
                 sc_c, pos, counts = fused
