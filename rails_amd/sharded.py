@@ -313,7 +313,7 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
         B = query_embeddings.size(0)
         per_shard = -(-self._n_total // max(self._world, 1))
         # (the 4 GiB logit policy: the first pass wants the whole (B, N_shard) matrix -- beyond it every rank alike takes the per-shard path, which chunks)
-        if (not self._global_proof(query_embeddings) or B < MoLBruteForceTopK.PROVED_MIN_BATCH or B * per_shard * 4 > MoLBruteForceTopK.MAX_LOGIT_BYTES
+        if (not self._global_proof(query_embeddings) or not MoLBruteForceTopK.speculation_pays(B, per_shard) or B * per_shard * 4 > MoLBruteForceTopK.MAX_LOGIT_BYTES
                 or not MoLBruteForceTopK.FUSED_TAIL):
             return super().submit(query_embeddings, k, sorted, **kwargs)
         if k > self._n_total:
@@ -419,7 +419,7 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
         return info
 
     def forward_filtered(self, query_embeddings: torch.Tensor, k_prime: int, invalid_ids: torch.Tensor, k: int, **kwargs):
-        if self._world > 1 and self._global_proof(query_embeddings) and query_embeddings.size(0) >= MoLBruteForceTopK.PROVED_MIN_BATCH and k_prime <= self._n_total:
+        if self._world > 1 and self._global_proof(query_embeddings) and MoLBruteForceTopK.speculation_pays(query_embeddings.size(0), -(-self._n_total // self._world)) and k_prime <= self._n_total:
             with self._inline():
                 return self.result(self.submit(query_embeddings, k_prime, **kwargs), seen=(invalid_ids, k))
         return super().forward_filtered(query_embeddings, k_prime, invalid_ids, k, **kwargs)

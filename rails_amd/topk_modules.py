@@ -203,7 +203,15 @@ class MoLBruteForceTopK(MoLTopKModule):
     PER_PAIR_MAX_ITEMS = 196608
     PAD_PER_PAIR_SMALL = (312, 1)
     bound_kind_items: Optional[int] = None
-    PROVED_MIN_BATCH = 2          # a single query of the default mode runs the dense fp32 kernels (see _forward_rescored)
+    # The default mode speculates where the first pass saves more than the verification costs (~70 us of launches): from B x N = 2^18 (query, item)
+    # pairs on.  Same-box steps, proved flow / dense fp32 kernels (tools/r06_probe_p.sh): amzn-books 695 762 items B = 1 0.285 / 0.322 ms, 400 k items
+    # B = 1 0.198 / 0.211, 200 k B = 1 0.131 / 0.125, B = 2 0.145 / 0.184; ML-20M (27 278 items) B = 2 0.100 / 0.057, B = 8 0.113 / 0.094, B = 16 0.113 / 0.146.
+    PROVED_MIN_BATCH = 1
+    PROVED_MIN_PAIRS = 1 << 18
+
+    @classmethod
+    def speculation_pays(cls, batch: int, n_items: int) -> bool:
+        return batch >= cls.PROVED_MIN_BATCH and batch * n_items >= cls.PROVED_MIN_PAIRS
 
     def _engine_for_bind(self) -> E.MolEngine:
         mol = self._mol_module
@@ -342,10 +350,10 @@ class MoLBruteForceTopK(MoLTopKModule):
         if B * N * 4 > self.MAX_LOGIT_BYTES or not E.topk_filter_fusable(N, k_prime, invalid_ids.shape[1], k):
             return None
         if eng.exact is not None:
-            # the default mode's single-query batches run the dense fp32 kernels (_forward_rescored): keep the filter fused into their
-            # selection launch as the plain fp32 module does (amzn-books B = 1: 0.36 -> 0.32 ms)
+            # the default mode's small calls (speculation_pays) run the dense fp32 kernels (_forward_rescored): keep the filter fused into their
+            # selection launch as the plain fp32 module does
             ex = eng.exact
-            if not (B < self.PROVED_MIN_BATCH and self._mol_module.engine() is not eng and eng.dense_precision == "f16x3"
+            if not (not self.speculation_pays(B, N) and self._mol_module.engine() is not eng and eng.dense_precision == "f16x3"
                     and self._index32 is not None and self._index32_engine is ex):
                 if not (self.FUSED_TAIL and eng.dense_precision == "f16x3" and k <= k_prime <= N):
                     return None
@@ -428,10 +436,9 @@ class MoLBruteForceTopK(MoLTopKModule):
         if eps_proved is not None and not math.isfinite(eps_proved):
             self.rescore_stats["unprovable_calls"] = self.rescore_stats.get("unprovable_calls", 0) + 1
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
-        if eps_proved is not None and query_embeddings.size(0) < self.PROVED_MIN_BATCH and self._mol_module.engine() is not eng:
-            # one query: the first pass saves ~0.1 ms against the dense fp32 kernels and the verification costs as much (amzn-books, B = 1:
-            # 0.327 against 0.324 ms; B = 2: 0.363 against 0.513) -- the default mode takes the dense kernels there (an explicit
-            # "f16x3-exact" precision keeps speculating)
+        if eps_proved is not None and not self.speculation_pays(query_embeddings.size(0), self._index.n_items) and self._mol_module.engine() is not eng:
+            # too few (query, item) pairs for the first pass to save what the verification costs (PROVED_MIN_PAIRS) -- the default mode takes
+            # the dense kernels there (an explicit "f16x3-exact" precision keeps speculating)
             return self._forward_fp32_dense(query_embeddings, k, **kwargs)
         if eps_proved is not None:
             # candidates: every item within eps of the k-th score must be among them.  amzn-books, eps = 0.9-1.0: 470-680 items at k = 200,

@@ -310,9 +310,10 @@ def test_proved_mode_is_the_default_and_equals_dense_fp32(dev, workload, N, B, k
     with torch.inference_mode():
         m = build_module(cfg, w, dev, None)
         r_s, r_i = _dense(m, X, ids)(q, k=k, **kw)
-        old = rails_amd.MoLBruteForceTopK.SPECULATE_MIN_ITEMS
+        old = rails_amd.MoLBruteForceTopK.SPECULATE_MIN_ITEMS, rails_amd.MoLBruteForceTopK.PROVED_MIN_PAIRS
         try:
             rails_amd.MoLBruteForceTopK.SPECULATE_MIN_ITEMS = 0
+            rails_amd.MoLBruteForceTopK.PROVED_MIN_PAIRS = 0
             tk = rails_amd.MoLBruteForceTopK(m, X, ids)
             assert tk.exact_mode == "proved"
             assert tk._bind().exact is not None, "the proved mode is not the default exact path"
@@ -351,13 +352,13 @@ def test_proved_mode_is_the_default_and_equals_dense_fp32(dev, workload, N, B, k
             # the module's own logits stay the fp32 kernels' (the split-f16 engine is internal)
             assert torch.equal(tk.all_logits(q[:2], **{key: v[:2] for key, v in kw.items()}), _dense(m, X, ids).all_logits(q[:2], **{key: v[:2] for key, v in kw.items()}))
         finally:
-            rails_amd.MoLBruteForceTopK.SPECULATE_MIN_ITEMS = old
+            rails_amd.MoLBruteForceTopK.SPECULATE_MIN_ITEMS, rails_amd.MoLBruteForceTopK.PROVED_MIN_PAIRS = old
 
 
-@pytest.mark.parametrize("B", [1, 2])
+@pytest.mark.parametrize("B", [1, 2, 3])
 def test_small_batches_take_the_dense_kernels_with_the_fused_filter(dev, B):
-    """Batches below PROVED_MIN_BATCH (a single query) of a default-mode module run the dense fp32 kernels -- through forward and through
-    get_top_k_outputs, where the seen-id filter stays inside the selection launch -- and return what the dense module returns."""
+    """Calls with fewer than PROVED_MIN_PAIRS (query, item) pairs of a default-mode module run the dense fp32 kernels -- through forward and
+    through get_top_k_outputs, where the seen-id filter stays inside the selection launch -- and return what the dense module returns."""
     cfg = O.CONFIGS["amzn-books"]
     N, k = 90_001, 120
     X = torch.from_numpy(O.hash_item_table(5, 0, N, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
@@ -375,13 +376,14 @@ def test_small_batches_take_the_dense_kernels_with_the_fused_filter(dev, B):
         inv[:, :7] = r_i[:, :7]                       # some of the best items are "seen"
         ci = rails_amd.CandidateIndex(ids, X)
         fused = tk.forward_filtered(q, 200, inv, k)
-        dense_route = B < rails_amd.MoLBruteForceTopK.PROVED_MIN_BATCH
-        assert fused is not None      # B = 1: inside the dense selection launch; B >= 2: inside the proved flow's finish launch (round 6)
+        dense_route = not rails_amd.MoLBruteForceTopK.speculation_pays(B, N)
+        assert dense_route == (B < 3)
+        assert fused is not None      # dense route: inside the dense selection launch; otherwise inside the proved flow's finish launch (round 6)
         a = ci.get_top_k_outputs(q, k=k, aux_payloads={}, top_k_module=tk, invalid_ids=inv, truncate_k_prime_to=200)
         b = ci.get_top_k_outputs(q, k=k, aux_payloads={}, top_k_module=dense, invalid_ids=inv, truncate_k_prime_to=200)
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(fused[0], b[0]) and torch.equal(fused[1], b[1])
         st = tk.stats()
-        assert (st["calls"] == 0) == dense_route     # a single query: nothing speculated; two: the proved flow (0.36 against 0.51 ms at full N)
+        assert (st["calls"] == 0) == dense_route     # below the pair count nothing is speculated; from it on the proved flow runs
         assert st["fallbacks"] == 0 or not dense_route
 
 

@@ -37,6 +37,7 @@ def _worker(rank: int, world: int, port: int, sizes, precision, ret, workload: s
     from tests.test_gpu_parity import build_module
 
     rails_amd.MoLBruteForceTopK.SPECULATE_MIN_ITEMS = 0     # the shards are small: keep the verified modes on their speculative route
+    rails_amd.MoLBruteForceTopK.PROVED_MIN_PAIRS = 0        # (and the proved flow, which the default policy starts at 2^18 pairs per call)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     multi = torch.cuda.device_count() >= world

@@ -17,6 +17,13 @@ import rails_amd  # noqa: E402
 from oracle import mol_oracle as O  # noqa: E402  (input generator only)
 
 
+def _stats(tk):
+    """the module's counters brought up to date with the device verdicts (stats() synchronises), without the bound's long breakdown"""
+    st = tk.stats() if hasattr(tk, "stats") else getattr(tk, "rescore_stats", {})
+    keep = ("calls", "proved_calls", "fallbacks", "bound_violations", "kc", "eps", "guard_max", "mismatches")
+    return {k: st[k] for k in keep if k in st}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--precisions", default="fp32,f16x3,f16x3-exact,f16-exact")
@@ -30,11 +37,12 @@ def main():
     ap.add_argument("--min-items", type=int, default=-1, help="override MoLBruteForceTopK.SPECULATE_MIN_ITEMS (where the proved flow starts)")
     ap.add_argument("--force-per-pair", action="store_true", help="proved rows: per-pair upper bounds even where one eps proves the calls (PROVED_MAX_EPS = 0)")
     ap.add_argument("--per-pair-pad", type=int, default=0, help="candidate floor beyond k under per-pair bounds (default: the module's 1848)")
-    ap.add_argument("--min-batch", type=int, default=0, help="override MoLBruteForceTopK.PROVED_MIN_BATCH (smallest batch the default mode speculates on)")
+    ap.add_argument("--min-batch", type=int, default=0, help="speculate from this batch size on whatever the corpus (PROVED_MIN_BATCH = it, PROVED_MIN_PAIRS = 0)")
     ap.add_argument("--no-rows-copy", action="store_true", help="re-score the candidates from the tile-packed fp32 index (no row-major copy)")
     args = ap.parse_args()
     if args.min_batch:
         rails_amd.MoLBruteForceTopK.PROVED_MIN_BATCH = args.min_batch
+        rails_amd.MoLBruteForceTopK.PROVED_MIN_PAIRS = 0
     if args.no_rows_copy:
         rails_amd.MoLBruteForceTopK.ROWS_COPY_MAX_BYTES = 0
     if args.force_per_pair:
@@ -74,7 +82,7 @@ def main():
                 cand.get_top_k_outputs(q, args.k, kw, tk, inv, truncate_k_prime_to=args.k_prime)
             torch.cuda.synchronize()
             ms = (time.perf_counter() - t0) / args.steps * 1e3
-            print(f"{args.workload} N={N} B={args.batch} {pr:12s} {ms:7.4f} ms per step  {args.batch / ms * 1e3:9.1f} queries/s  {getattr(tk, 'rescore_stats', '')}")
+            print(f"{args.workload} N={N} B={args.batch} {pr:12s} {ms:7.4f} ms per step  {args.batch / ms * 1e3:9.1f} queries/s  {_stats(tk)}")
 
 
 if __name__ == "__main__":
