@@ -37,9 +37,10 @@ extern "C" {
  * 8: rails_mol_score_dense_upper[_supported] and rails_mol_index_rows_* / rails_mol_score_indexed_rows are new, rails_rescore_select gained one_sided;
  * 9: rails_candidates_* -- the threshold selection and the fused finish of the proved exact top-k -- and rails_merge_candidates_verdict
  * are new, rails_mol_score_indexed_rows gained cand_counts, the component table became item-group-major (rails_mol_component_build
- * gained n_total / first_item, rails_mol_component_topk its out_of_range flag, rails_mol_component_topk_capacity is new)).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
+ * gained n_total / first_item, rails_mol_component_topk its out_of_range flag, rails_mol_component_topk_capacity is new);
+ * 10: rails_topk_candidates_filtered and rails_rerank_topk_filtered / rails_rerank_workspace_bytes are new).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
  * against an older header pass shorter structs, and the library would read the new fields from whatever follows them. */
-#define RAILS_ABI_VERSION 9
+#define RAILS_ABI_VERSION 10
 int rails_abi_version(void);
 
 #define RAILS_OK 0
@@ -328,6 +329,29 @@ int rails_topk(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t
  * itself).  Same order and tie rule (candidate column ascending) as rails_topk on the same rows. */
 int rails_topk_candidates(const float* scores, int64_t ld, int32_t rows, int32_t n_cand, int32_t k, const int64_t* positions,
                           const int64_t* ids, float* out_scores, int64_t* out_ids, void* stream);
+
+/* The same selection with the seen-id filter of rails_filter_seen_ids applied to the k' winners inside the launch: what
+ * CandidateIndex.get_top_k_outputs keeps of a candidate rerank (indexing/candidate_index.py:149-175 after rails/indexing/mol_top_k.py:260-293 /
+ * :518-551, whose modules return ALL their candidates sorted: the first k unseen ones of that list are the first k unseen ones of its
+ * top k + width, since a masked duplicate never outranks a scored candidate and at most `width` of the scored ones are seen) ->
+ * (out_ids, out_scores) of k per row, the same bits as rails_topk_candidates(k') followed by rails_filter_seen_ids.
+ * Sizes: 1024 < n_cand <= 8192, k <= k' <= 512, k' <= n_cand, width <= 256; RAILS_ENOTSUP otherwise (the caller composes the two calls). */
+int rails_topk_candidates_filtered(const float* scores, int64_t ld, int32_t rows, int32_t n_cand, int32_t k_prime, const int64_t* positions,
+                                   const int64_t* ids, const int64_t* invalid_ids, int32_t width, int32_t k, int64_t* out_ids,
+                                   float* out_scores, void* stream);
+
+/* The same result from candidates in ANY order, duplicates included (the union a Naive / Comb rerank collects, before the integer sort of
+ * rails/indexing/mol_top_k.py:262 / :520 that makes duplicates neighbours): row b holds the scores of its n_cand candidate positions; of every
+ * position the first copy counts, ranked by (score desc, position asc) -- the order of the sorted form -- then the top k' with the seen-id filter as
+ * above.  Two launches (an LDS hash set of the row's positions writes the keys; the selection of rails_topk_candidates_filtered on them), no
+ * sort.  *out_of_range (int32, device-visible, zeroed by the caller; may be pinned host memory) is set to 1 when a row holds fewer than k'
+ * distinct positions: the outputs are then undefined and the caller takes the sorted form (rails_sort_rows_i64 -> score ->
+ * rails_mask_sorted_duplicates -> rails_topk_candidates_filtered), which ranks masked duplicates as the reference does.  positions < 2^32 - 1.
+ * Sizes as rails_topk_candidates_filtered; workspace: rails_rerank_workspace_bytes(rows, n_cand), 256-byte aligned. */
+size_t rails_rerank_workspace_bytes(int32_t rows, int32_t n_cand);
+int rails_rerank_topk_filtered(const float* scores, int64_t ld, int32_t rows, int32_t n_cand, int32_t k_prime, const int64_t* positions,
+                               const int64_t* ids, const int64_t* invalid_ids, int32_t width, int32_t k, void* workspace, size_t workspace_bytes,
+                               int64_t* out_ids, float* out_scores, int32_t* out_of_range, void* stream);
 
 /* CandidateIndex.get_top_k_outputs' selection in ONE chain (reference indexing/candidate_index.py:149-175 after
  * rails/indexing/mol_top_k.py:123-130): exact top-k' of every row with the id map, then the seen-id filter of

@@ -579,6 +579,44 @@ int rails_topk_candidates(const float* scores, int64_t ld, int32_t rows, int32_t
   return r == kOk ? r : fail(r, "topk_candidates");
 }
 
+int rails_topk_candidates_filtered(const float* scores, int64_t ld, int32_t rows, int32_t n_cand, int32_t k_prime, const int64_t* positions,
+                                   const int64_t* ids, const int64_t* invalid_ids, int32_t width, int32_t k, int64_t* out_ids,
+                                   float* out_scores, void* stream) {
+  g_err[0] = '\0';
+  if (rows < 0 || n_cand < 0 || k_prime < 0 || k < 0 || width < 0) { set_error("topk_candidates_filtered: negative size"); return RAILS_EINVAL; }
+  if (k_prime > n_cand || k > k_prime) { set_error("topk_candidates_filtered: need k <= k' <= n_cand (k = %d, k' = %d, n = %d)", k, k_prime, n_cand); return RAILS_EINVAL; }
+  if (rows == 0 || k == 0) return RAILS_OK;
+  if (!scores || !positions || !out_scores || !out_ids || (width > 0 && !invalid_ids)) { set_error("topk_candidates_filtered: NULL pointer"); return RAILS_EINVAL; }
+  if (ld < n_cand) { set_error("topk_candidates_filtered: ld < n_cand"); return RAILS_EINVAL; }
+  if (n_cand <= 1024 || n_cand > 8192 || !topk_can_fuse_filter(n_cand, k_prime, width, k)) {
+    set_error("topk_candidates_filtered: unsupported size (n_cand = %d, k' = %d, width = %d, k = %d)", n_cand, k_prime, width, k);
+    return RAILS_ENOTSUP;
+  }
+  const int cu = compute_units();
+  if (cu <= 0) { set_error("topk_candidates_filtered: no HIP device"); return RAILS_ELAUNCH; }
+  static const int64_t no_seen = 0;     // width 0: the filter still runs (it copies the first k), its list is never read
+  const int r = topk(scores, ld, rows, n_cand, k_prime, ids, 0, out_scores, out_ids, nullptr, 0, cu, (hipStream_t)stream,
+                     width > 0 ? invalid_ids : &no_seen, width, k, nullptr, nullptr, positions, n_cand);
+  return r == kOk ? r : fail(r, "topk_candidates_filtered");
+}
+
+size_t rails_rerank_workspace_bytes(int32_t rows, int32_t n_cand) { return rows > 0 && n_cand > 0 ? rerank_workspace_bytes(rows, n_cand) : 0; }
+
+int rails_rerank_topk_filtered(const float* scores, int64_t ld, int32_t rows, int32_t n_cand, int32_t k_prime, const int64_t* positions,
+                               const int64_t* ids, const int64_t* invalid_ids, int32_t width, int32_t k, void* workspace, size_t workspace_bytes,
+                               int64_t* out_ids, float* out_scores, int32_t* out_of_range, void* stream) {
+  g_err[0] = '\0';
+  if (rows < 0 || n_cand < 0 || k_prime < 0 || k < 0 || width < 0) { set_error("rerank_topk_filtered: negative size"); return RAILS_EINVAL; }
+  if (k_prime > n_cand || k > k_prime) { set_error("rerank_topk_filtered: need k <= k' <= n_cand (k = %d, k' = %d, n = %d)", k, k_prime, n_cand); return RAILS_EINVAL; }
+  if (rows == 0 || k == 0) return RAILS_OK;
+  if (!scores || !positions || !out_scores || !out_ids || !out_of_range || !workspace || (width > 0 && !invalid_ids)) { set_error("rerank_topk_filtered: NULL pointer"); return RAILS_EINVAL; }
+  if (ld < n_cand) { set_error("rerank_topk_filtered: ld < n_cand"); return RAILS_EINVAL; }
+  static const int64_t no_seen = 0;
+  const int r = rerank_topk_filtered(scores, ld, rows, n_cand, k_prime, positions, ids, width > 0 ? invalid_ids : &no_seen, width, k, workspace,
+                                     workspace_bytes, out_ids, out_scores, out_of_range, (hipStream_t)stream);
+  return r == kOk ? r : fail(r, "rerank_topk_filtered");
+}
+
 int rails_topk_filter_fusable(int64_t n, int32_t k_prime, int32_t width, int32_t k) { return topk_can_fuse_filter(n, k_prime, width, k) ? 1 : 0; }
 
 int rails_topk_filtered(const float* scores, int64_t ld, int32_t rows, int64_t n, int32_t k_prime, const int64_t* ids, int64_t ids_row_stride,

@@ -659,6 +659,16 @@ static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p, b
   // only costs the fallback), while ~r * stride items are expected at or above it
   auto r_of = [&](int st) {
     const float m = (float)k_prime / st;
+    if (comp_rows > 0) {
+      // component scans: every candidate beyond the k_g wanted costs the select scan (a fired tile is ~3 x a quiet one, and at k_g = 100 a third
+      // of the (tile, query tile) steps fire), so r is the EXACT smallest rank with P(Poisson(m) >= r) < 1e-9 per row -- the Poisson tail
+      // dominates the binomial one of k_g items landing in every stride-th tile -- instead of the Chernoff rank with its 2m floor
+      // (k_g = 100, stride 4: 59 instead of 72 -> ~ 240 instead of ~ 290 appended per row)
+      double pmf = exp(-(double)m), below = 0.0;      // below = P(X <= r - 1)
+      int r = 0;
+      while (r < 512 && 1.0 - below >= 1e-9) { below += pmf; ++r; pmf *= (double)m / r; }
+      return r < 2 ? 2 : r;
+    }
     int r = (int)(2.0f * m + 4.0f * sqrtf(m)) + 2;
     while (r < 512 && (-m + r * (1.0f + logf(m / r))) > -20.7f) ++r;
     return r > 512 ? 512 : r;

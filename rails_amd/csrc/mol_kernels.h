@@ -154,6 +154,10 @@ int component_score(const Shape& s, const float* eq, int B, const void* table, i
                     hipStream_t stream, const int32_t* run_if = nullptr);
 int sort_rows_i64(const int64_t* in, int rows, int n, int64_t* out, hipStream_t stream);
 int mask_sorted_duplicates(const int64_t* idx, float* scores, int64_t ld, int rows, int n, float fill, hipStream_t stream);
+size_t rerank_workspace_bytes(int rows, int n_cand);
+int rerank_topk_filtered(const float* scores, int64_t ld, int rows, int n_cand, int k_prime, const int64_t* positions, const int64_t* ids,
+                         const int64_t* invalid, int width, int k, void* ws, size_t ws_bytes, int64_t* out_ids, float* out_scores, int32_t* flag,
+                         hipStream_t stream);
 
 int hash_item_table(unsigned long long seed, int64_t first_item, int64_t n_items, int dim, float scale, float* out, hipStream_t stream);
 int mips_pack_items(const float* items, int64_t n, int D, float* out, hipStream_t stream);

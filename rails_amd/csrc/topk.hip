@@ -649,7 +649,7 @@ struct RowSelectArgs {
   const int64_t* f_invalid; int f_width; int f_k;
 };
 
-template <int VPT, bool KEYS, bool IDX = false>   // IDX: ids through ids_index (map_id); built for VPT = 4 only (candidate rows of <= 4 096)
+template <int VPT, bool KEYS, bool IDX = false>   // IDX: ids through ids_index (map_id); built for VPT = 4 / 8 (candidate rows of <= 8 192)
 __global__ __launch_bounds__(kRowThreads) void row_select_kernel(const RowSelectArgs a) {
   static_assert(VPT % 4 == 0, "float4 loads");
   MOL_RUN_IF(a.run_if);
@@ -963,16 +963,21 @@ int topk(const float* scores, int64_t ld, int rows, int64_t n, int k, const int6
   // 2 561 of 4 096), selecting first buys nothing -- the row is sorted whole (n = 3 200 = k: 52 -> 41 us per 32 rows; k = 1 000 of
   // 3 200 stays on the selection: 28 vs 41 us; tools/r04_topk_bigk_ab.sh)
   const bool sort_whole = k > kRowFastK && n <= kSortCap && next_pow2((int)n) <= next_pow2(k) && !scores16 && !f_invalid;
-  if (!sort_whole && ids_index && n > 512 && n <= 4 * kRowThreads && k <= kRowMaxK && !scores16 && !f_invalid) {
+  // candidate rows (ids through ids_index): the register-resident selection up to 8 192 candidates (16 per thread spills), the seen-id filter fused where asked
+  // (round 6: the union of a Naive / Comb rerank, 6 400-7 400 candidates of which get_top_k_outputs wants k + |seen| <= 512)
+  if (!sort_whole && ids_index && n > 512 && n <= 8 * kRowThreads && k <= kRowMaxK && !scores16) {
     RowSelectArgs a{};
     a.run_if = pred;
     a.scores = scores; a.ld = ld; a.n = n; a.k = k; a.chunk = n; a.ids = ids; a.ids_row_stride = ids_row_stride; a.out_scores = out_scores; a.out_ids = out_ids;
     a.ids_index = ids_index; a.ids_index_ld = ids_index_ld;
+    a.f_invalid = f_invalid; a.f_width = f_width; a.f_k = f_k;
     int lds_keys = 2;                                   // as launch_row_select sets it
     while (lds_keys < a.k) lds_keys <<= 1;
     a.lds_keys = a.k <= kRowFastK ? kRowCandCap : lds_keys;
-    return launch_row_select_t<4, false, true>(a, rows, 1, stream);
+    if (n <= 4 * kRowThreads) return launch_row_select_t<4, false, true>(a, rows, 1, stream);
+    return launch_row_select_t<8, false, true>(a, rows, 1, stream);
   }
+  if (ids_index && f_invalid) { set_error("topk: the seen-id filter over candidate rows needs 1024 < n <= %d", 8 * kRowThreads); return kErrUnsupported; }
   if (!sort_whole && (n > 1024 || (n > 512 && k <= kRowFastK && !scores16 && !f_invalid)) && k <= kRowMaxK && !ids_index) {
     RowSelectArgs a{};
     a.run_if = pred;
@@ -1858,6 +1863,71 @@ int mask_sorted_duplicates(const int64_t* idx, float* scores, int64_t ld, int ro
   if (total <= 0) return kOk;
   hipLaunchKernelGGL(mask_sorted_duplicates_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, idx, scores, ld, rows, n, fill);
   return hipGetLastError() == hipSuccess ? kOk : kErrLaunch;
+}
+
+// ---- the tail of a candidate rerank without the integer sort (round 6) ------------------------------------------------------------------
+// get_top_k_outputs over MoLNaiveTopK / MoLCombTopK wants the first k unseen of the candidates ranked by (score desc, position asc) with
+// duplicates dropped.  The module's own forward() sorts the candidate positions (so that duplicates are neighbours and the column order IS the
+// position order: 72 us per 32 rows of 6 400), scores, masks, ranks.  Here the candidates stay in the order the scans left them:
+//   rerank_keys_kernel  one workgroup per row: a 16 384-slot LDS hash set of the row's positions decides which copy of a position is its
+//                       first; that copy's key is (score, ~position) -- the order of the sorted form, whatever the column -- the others' 0
+//                       (an empty key, below everything); rows with fewer than `min_unique` distinct positions raise *flag: an empty key
+//                       could then reach the result, and the caller redoes the call on the sorted form
+//   row_select_kernel<., KEYS>  top-k' of the keys, ids by position, the seen-id filter inside
+// Same (ids, scores) as sort -> score -> mask -> rails_topk_candidates_filtered whenever the flag stays 0.
+constexpr int kRerankHash = 16384;
+constexpr int kRerankMax = 8192;
+
+__global__ __launch_bounds__(1024) void rerank_keys_kernel(const float* __restrict__ scores, int64_t ld, const int64_t* __restrict__ positions, int n,
+                                                          int min_unique, unsigned long long* __restrict__ keys, int32_t* __restrict__ flag) {
+  extern __shared__ unsigned int rr_tab[];      // kRerankHash slots + the row's distinct count
+  const int row = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i <= kRerankHash; i += 1024) rr_tab[i] = i < kRerankHash ? 0xFFFFFFFFu : 0u;
+  __syncthreads();
+  unsigned int uniq = 0u;
+  for (int c = tid; c < n; c += 1024) {
+    const unsigned int p = (unsigned int)positions[(int64_t)row * n + c];
+    unsigned int h = (p * 2654435761u) >> 18;
+    bool first;
+    for (;;) {
+      const unsigned int old = atomicCAS(&rr_tab[h], 0xFFFFFFFFu, p);
+      if (old == 0xFFFFFFFFu) { first = true; break; }
+      if (old == p) { first = false; break; }
+      h = (h + 1u) & (unsigned int)(kRerankHash - 1);
+    }
+    keys[(int64_t)row * n + c] = first ? make_key(scores[(int64_t)row * ld + c], p) : 0ull;
+    uniq += first ? 1u : 0u;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) uniq += (unsigned int)__shfl_xor((int)uniq, o, 64);
+  if ((tid & 63) == 0 && uniq) atomicAdd(&rr_tab[kRerankHash], uniq);
+  __syncthreads();
+  if (tid == 0 && rr_tab[kRerankHash] < (unsigned int)min_unique) *flag = 1;     // every writer stores the same value
+}
+
+size_t rerank_workspace_bytes(int rows, int n_cand) { return sizeof(unsigned long long) * (size_t)rows * (size_t)n_cand; }
+
+int rerank_topk_filtered(const float* scores, int64_t ld, int rows, int n_cand, int k_prime, const int64_t* positions, const int64_t* ids,
+                         const int64_t* invalid, int width, int k, void* ws, size_t ws_bytes, int64_t* out_ids, float* out_scores, int32_t* flag,
+                         hipStream_t stream) {
+  if (rows <= 0 || k <= 0) return kOk;
+  if (n_cand <= 1024 || n_cand > kRerankMax || !topk_can_fuse_filter(n_cand, k_prime, width, k) || k_prime > n_cand) {
+    set_error("rerank_topk_filtered: unsupported size (n_cand = %d, k' = %d, width = %d, k = %d)", n_cand, k_prime, width, k);
+    return kErrUnsupported;
+  }
+  if (ws_bytes < rerank_workspace_bytes(rows, n_cand)) { set_error("rerank_topk_filtered: workspace too small"); return kErrNoMem; }
+  if (ensure_sort_lds() != kOk) return kErrLaunch;
+  static DynLdsOnce once;
+  const int lds = (kRerankHash + 16) * (int)sizeof(unsigned int);
+  if (ensure_dyn_lds(once, reinterpret_cast<const void*>(&rerank_keys_kernel), lds) != kOk) return kErrLaunch;
+  unsigned long long* keys = static_cast<unsigned long long*>(ws);
+  hipLaunchKernelGGL(rerank_keys_kernel, dim3(rows), dim3(1024), lds, stream, scores, ld, positions, n_cand, k_prime, keys, flag);
+  if (hipGetLastError() != hipSuccess) return kErrLaunch;
+  RowSelectArgs b{};
+  b.keys_in = keys; b.keys_per_row = n_cand; b.k = k_prime;
+  b.ids = ids; b.ids_row_stride = 0; b.out_scores = out_scores; b.out_ids = out_ids;
+  b.f_invalid = invalid; b.f_width = width; b.f_k = k;
+  return launch_row_select<true>(b, rows, 1, n_cand, stream);
 }
 
 int filter_seen(const int64_t* top_ids, const float* top_scores, int rows, int k_prime, const int64_t* invalid,

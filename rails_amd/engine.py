@@ -793,6 +793,70 @@ def topk_candidates(scores: torch.Tensor, k: int, positions: torch.Tensor, ids: 
     return out_s, out_i
 
 
+def topk_candidates_filterable(n_cand: int, k_prime: int, width: int, k: int) -> bool:
+    """sizes rails_topk_candidates_filtered takes (include/rails_amd.h)"""
+    return 1024 < n_cand <= 8192 and 0 < k <= k_prime <= min(n_cand, 512) and 0 <= width <= 256
+
+
+def topk_candidates_filtered(scores: torch.Tensor, k_prime: int, positions: torch.Tensor, ids: Optional[torch.Tensor], invalid_ids: torch.Tensor,
+                             k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """topk_candidates(scores, k_prime, positions, ids) followed by filter_seen_ids(..., invalid_ids, k) in one launch (include/rails_amd.h
+    rails_topk_candidates_filtered; reference indexing/candidate_index.py:149-175 over a candidate rerank's output).  -> (out_ids (rows, k),
+    out_scores (rows, k)), ids first like filter_seen_ids."""
+    lib = _lib.load()
+    _require_device(scores, "scores")
+    if scores.dtype != torch.float32 or scores.stride(1) != 1:
+        scores = _f32c(scores)
+    rows, n = scores.shape
+    positions = positions.to(device=scores.device, dtype=torch.int64).contiguous()
+    if positions.shape != (rows, n):
+        raise ValueError("positions must be (rows, n_cand) like scores")
+    if ids is not None:
+        ids = ids.to(device=scores.device, dtype=torch.int64).reshape(-1).contiguous()
+    inv = invalid_ids.to(device=scores.device, dtype=torch.int64).contiguous()
+    if inv.dim() != 2 or inv.shape[0] != rows:
+        raise ValueError("invalid_ids must be (rows, width)")
+    out_i = torch.empty((rows, k), dtype=torch.int64, device=scores.device)
+    out_s = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
+    with _on_device(scores.device):
+        _lib.check(lib.rails_topk_candidates_filtered(_ptr(scores), scores.stride(0), rows, n, k_prime, _ptr(positions), _ptr(ids), _ptr(inv), inv.shape[1], k,
+                                                      _ptr(out_i), _ptr(out_s), _stream()), "rails_topk_candidates_filtered")
+    return out_i, out_s
+
+
+def rerank_topk_filtered(scores: torch.Tensor, k_prime: int, positions: torch.Tensor, ids: Optional[torch.Tensor], invalid_ids: torch.Tensor, k: int,
+                         flag: torch.Tensor, workspace: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The tail of a candidate rerank from UNSORTED candidate positions with duplicates (include/rails_amd.h rails_rerank_topk_filtered): first copy
+    of every position, ranked by (score desc, position asc), top k_prime, seen-id filter -> (out_ids (rows, k), out_scores (rows, k)).  `flag`
+    (int32, zeroed by the caller; device or pinned host memory) is raised when a row has fewer than k_prime distinct positions -- the outputs are
+    then undefined and the caller takes the sorted form."""
+    lib = _lib.load()
+    _require_device(scores, "scores")
+    if scores.dtype != torch.float32 or scores.stride(1) != 1:
+        scores = _f32c(scores)
+    rows, n = scores.shape
+    positions = positions.to(device=scores.device, dtype=torch.int64).contiguous()
+    if positions.shape != (rows, n):
+        raise ValueError("positions must be (rows, n_cand) like scores")
+    if ids is not None:
+        ids = ids.to(device=scores.device, dtype=torch.int64).reshape(-1).contiguous()
+    inv = invalid_ids.to(device=scores.device, dtype=torch.int64).contiguous()
+    if inv.dim() != 2 or inv.shape[0] != rows:
+        raise ValueError("invalid_ids must be (rows, width)")
+    if flag.dtype != torch.int32 or not (flag.is_cuda or flag.is_pinned()):
+        raise ValueError("flag must be an int32 tensor on the device or in pinned host memory")
+    need = int(lib.rails_rerank_workspace_bytes(rows, n))
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=scores.device)
+    out_i = torch.empty((rows, k), dtype=torch.int64, device=scores.device)
+    out_s = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
+    with _on_device(scores.device):
+        _lib.check(lib.rails_rerank_topk_filtered(_ptr(scores), scores.stride(0), rows, n, k_prime, _ptr(positions), _ptr(ids), _ptr(inv), inv.shape[1], k,
+                                                  _ptr(workspace), workspace.numel() * workspace.element_size(), _ptr(out_i), _ptr(out_s), _ptr(flag), _stream()),
+                   "rails_rerank_topk_filtered")
+    return out_i, out_s
+
+
 def topk_filter_fusable(n: int, k_prime: int, width: int, k: int) -> bool:
     return bool(_lib.load().rails_topk_filter_fusable(int(n), int(k_prime), int(width), int(k)))
 

@@ -1402,15 +1402,44 @@ class _ComponentCandidates:
         _, pos = E.topk(scores, k_per_group)
         return pos.view(eq.shape[0], -1)
 
-    def _rerank_union(self, qpack: torch.Tensor, batch: int, all_indices: torch.Tensor, sorted: bool):
+    def _filter_inside(self, n_candidates: int, invalid_ids: torch.Tensor, k: int):
+        """get_top_k_outputs over a module that returns ALL its candidates ranked (masked duplicates last): the first k unseen entries of that
+        list are the first k unseen of its top k + width -- at most `width` scored candidates are seen, and a masked duplicate (-32767.0)
+        outranks a scored one only where fewer than k + width scored ones exist, in both forms alike.  -> (invalid_ids, k) where
+        rails_topk_candidates_filtered takes the sizes, else None (the caller ranks everything and filters after)."""
+        if invalid_ids is None or invalid_ids.dim() != 2 or getattr(self, "NO_FILTER_FUSION", False):
+            return None
+        width = invalid_ids.shape[1]
+        if not E.topk_candidates_filterable(n_candidates, min(k + width, n_candidates), width, k):
+            return None
+        return (invalid_ids, k)
+
+    UNSORTED_RERANK = True     # get_top_k_outputs: rank the candidates where the scans left them (rails_rerank_topk_filtered) instead of sorting their positions first
+
+    def _rerank_union(self, qpack: torch.Tensor, batch: int, all_indices: torch.Tensor, sorted: bool, seen=None, pending: Optional[list] = None):
         """sort -> gather -> full MoL -> mask duplicates with -32767.0 -> top-k over ALL candidates
-        (the reference overwrites k with the candidate count, mol_top_k.py:260 / :518)."""
+        (the reference overwrites k with the candidate count, mol_top_k.py:260 / :518).
+        seen = (invalid_ids, k) (get_top_k_outputs, sizes checked by the caller): instead of the full ranking, the first k unseen entries of it
+        -- the top k + width of the candidates with the seen-id filter inside the selection launch -> (ids, scores).  Where the fused scans'
+        verdict word is pending anyway (pinned host memory, read by the caller once everything is enqueued), the integer sort goes too: the
+        candidates are scored in the order the scans left them and ranked by (score, position) keys, first copy of every position; a row with
+        fewer than k + width distinct positions raises the same word and the call is redone on the sorted form."""
         eng = self._bind()
         big = all_indices.shape[1] > self.UNION_CAP
+        word = next((b for b in (pending or []) if not b.is_cuda), None)
+        if seen is not None and word is not None and self.UNSORTED_RERANK and not getattr(self, "_no_fused", False):
+            invalid_ids, k_out = seen
+            pos = all_indices.to(torch.int64).contiguous()
+            scores = self._score_at(eng, qpack, batch, pos)
+            ws = self._buf("rerank_keys", pos.numel() * 8, torch.uint8)
+            return E.rerank_topk_filtered(scores, min(k_out + invalid_ids.shape[1], pos.shape[1]), pos, self._ids_flat, invalid_ids, k_out, word, ws)
         sorted_idx = torch.sort(all_indices.to(torch.int64), dim=1).values if big else E.sort_rows(all_indices)
         k = sorted_idx.shape[1]
         scores = self._score_at(eng, qpack, batch, sorted_idx)
         E.mask_sorted_duplicates(sorted_idx, scores, -32767.0)
+        if seen is not None:
+            invalid_ids, k_out = seen
+            return E.topk_candidates_filtered(scores, min(k_out + invalid_ids.shape[1], k), sorted_idx, self._ids_flat, invalid_ids, k_out)
         if big:   # full ranking of more than 16 384 candidates: stable descending sort = (score desc, column asc), rails_topk's tie rule
             vals, order = torch.sort(scores, dim=1, descending=True, stable=True)
             return vals, torch.gather(self._ids_flat[sorted_idx], 1, order)
@@ -1430,17 +1459,31 @@ class MoLNaiveTopK(MoLTopKModule, _ComponentCandidates):
         self._check_union_size(mol_module._query_dot_product_groups * mol_module._item_dot_product_groups * k_per_group)
 
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        scores, ids = self._ranked(query_embeddings, sorted, None, kwargs)
+        return scores.to(query_embeddings.dtype), ids
+
+    def forward_filtered(self, query_embeddings: torch.Tensor, k_prime: int, invalid_ids: torch.Tensor, k: int, **kwargs):
+        """CandidateIndex.get_top_k_outputs' body (the module returns all its candidates whatever k_prime is, the filter keeps the first k unseen):
+        -> (top_k_ids, top_k_scores), or None where the filter does not fit the selection launch (_filter_inside)."""
+        mol = self._mol_module
+        seen = self._filter_inside(mol._query_dot_product_groups * mol._item_dot_product_groups * self._k_per_group, invalid_ids, k)
+        if seen is None:
+            return None
+        ids, scores = self._ranked(query_embeddings, True, seen, kwargs)
+        return ids, scores.to(query_embeddings.dtype)
+
+    def _ranked(self, query_embeddings: torch.Tensor, sorted: bool, seen, kwargs):
         eng = self._bind()
         qpack, eq, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"), want_plain=True)
         for attempt in range(2):     # speculate on the fused scans, verify after everything is enqueued
             pending: list = []
             all_indices = self._component_topk(eq, self._k_per_group, pending)
-            scores, ids = self._rerank_union(qpack, query_embeddings.size(0), all_indices, sorted)
+            out = self._rerank_union(qpack, query_embeddings.size(0), all_indices, sorted, seen, pending)
             if _verdicts_clear(pending):
                 break
             self._no_fused = True
         self._no_fused = False
-        return scores.to(query_embeddings.dtype), ids
+        return out
 
 
 class MoLCombTopK(MoLAvgTopK, _ComponentCandidates):
@@ -1453,18 +1496,31 @@ class MoLCombTopK(MoLAvgTopK, _ComponentCandidates):
         self._check_union_size(mol_module._query_dot_product_groups * mol_module._item_dot_product_groups * k_per_group + avg_top_k)
 
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
+        scores, ids = self._ranked(query_embeddings, sorted, None, kwargs)
+        return scores.to(query_embeddings.dtype), ids
+
+    def forward_filtered(self, query_embeddings: torch.Tensor, k_prime: int, invalid_ids: torch.Tensor, k: int, **kwargs):
+        """As MoLNaiveTopK.forward_filtered, over the component candidates + the averaged-query candidates."""
+        mol = self._mol_module
+        seen = self._filter_inside(mol._query_dot_product_groups * mol._item_dot_product_groups * self._k_per_group + self._avg_top_k, invalid_ids, k)
+        if seen is None:
+            return None
+        ids, scores = self._ranked(query_embeddings, True, seen, kwargs)
+        return ids, scores.to(query_embeddings.dtype)
+
+    def _ranked(self, query_embeddings: torch.Tensor, sorted: bool, seen, kwargs):
         eng = self._bind()
         qpack, eq, _ = eng.query_pack(query_embeddings, kwargs.get("user_ids"), want_plain=True)
         for attempt in range(2):
             pending: list = []
             comp = self._component_topk(eq, self._k_per_group, pending)
             avg_idx = self._coarse_topk_from_eq(eq, average_queries=True, pending=pending)
-            scores, ids = self._rerank_union(qpack, query_embeddings.size(0), torch.cat([comp, avg_idx], dim=1), sorted)
+            out = self._rerank_union(qpack, query_embeddings.size(0), torch.cat([comp, avg_idx], dim=1), sorted, seen, pending)
             if _verdicts_clear(pending):
                 break
             self._no_fused = True
         self._no_fused = False
-        return scores.to(query_embeddings.dtype), ids
+        return out
 
 
 class MIPSTopKModule(TopKModule):

@@ -775,6 +775,67 @@ def test_topk_candidates_equals_the_oracle_selection_rule(dev):
     assert torch.equal(gs.cpu(), ws) and torch.equal(gi.cpu(), item_ids[torch.gather(pos, 1, wcol)])
 
 
+@pytest.mark.parametrize("rows,n,kp,width,k", [(32, 6400, 181, 61, 120), (5, 1025, 300, 100, 200), (7, 4096, 512, 256, 256), (3, 7400, 200, 0, 200), (2, 8192, 130, 10, 120),
+                                                 (4, 8000, 1, 0, 1), (6, 3000, 150, 50, 100)])
+def test_topk_candidates_filtered_equals_the_two_calls(dev, rows, n, kp, width, k):
+    """rails_topk_candidates_filtered (ABI 10): the top-k' of candidate rows with the seen-id filter inside the launch == rails_topk_candidates(k')
+    followed by rails_filter_seen_ids -- scores with ties and masked duplicates (-32767.0), seen ids drawn from the winners."""
+    g = torch.Generator().manual_seed(rows * 31 + n + kp)
+    corpus = 80_000
+    scores = (torch.randint(0, 91, (rows, n), generator=g).float() / 8.0)
+    scores[:, ::7] = -32767.0                                  # masked duplicates
+    pos = torch.sort(torch.randint(0, corpus, (rows, n), generator=g), dim=1).values
+    item_ids = torch.arange(corpus, dtype=torch.int64) * 3 + 11
+    scores, pos, item_ids = scores.to(dev), pos.to(dev), item_ids.to(dev)
+    ws, wi = E.topk_candidates(scores, kp, pos, item_ids)
+    inv = torch.cat([wi[:, : width // 2], torch.randint(0, 3 * corpus, (rows, width - width // 2), generator=g).to(dev)], dim=1) if width else torch.zeros((rows, 0), dtype=torch.int64, device=dev)
+    assert E.topk_candidates_filterable(n, kp, width, k)
+    r_i, r_s = E.filter_seen_ids(wi, ws, inv, k)
+    f_i, f_s = E.topk_candidates_filtered(scores, kp, pos, item_ids, inv, k)
+    assert torch.equal(f_i, r_i) and torch.equal(f_s, r_s)
+    assert not E.topk_candidates_filterable(1024, 100, 10, 50) and not E.topk_candidates_filterable(8193, 100, 10, 50) and not E.topk_candidates_filterable(5000, 513, 10, 50) and not E.topk_candidates_filterable(5000, 300, 257, 30)
+    with pytest.raises(RuntimeError):
+        E.topk_candidates_filtered(scores[:, :1000], min(kp, 1000), pos[:, :1000], item_ids, inv, min(k, kp, 1000))
+
+
+@pytest.mark.parametrize("rows,n,kp,width,k,distinct", [(32, 6400, 181, 61, 120, 5000), (5, 1025, 300, 100, 200, 400), (7, 8192, 512, 256, 256, 8192), (3, 7400, 200, 0, 200, 3000),
+                                                          (4, 3000, 150, 50, 100, 149), (2, 2000, 100, 20, 80, 100)])
+def test_rerank_topk_filtered_equals_the_sorted_form(dev, rows, n, kp, width, k, distinct):
+    """rails_rerank_topk_filtered (ABI 10): candidates in any order with duplicates -> the result of the sorted form (rails_sort_rows_i64, scores in
+    that order, rails_mask_sorted_duplicates, rails_topk_candidates_filtered) whenever every row holds at least k' distinct positions; the
+    out-of-range word is raised exactly when one does not.  A position's score is a function of the position (as in a rerank), with ties
+    between positions."""
+    g = torch.Generator().manual_seed(rows * 131 + n + kp)
+    corpus = 3_000_000_000                                        # positions beyond 2^31
+    pool = torch.stack([torch.randperm(200_000, generator=g)[:distinct] for _ in range(rows)]).to(torch.int64) * 14_999 + 7
+    assert int(pool.max()) < corpus
+    pos = torch.gather(pool, 1, torch.randint(0, distinct, (rows, n), generator=g))
+    if distinct >= kp:
+        pos[:, :distinct] = pool[:, torch.randperm(distinct, generator=g)]     # every pool entry at least once
+    score_of = lambda p: ((p * 7 + 3) % 97).float() / 8.0 - 4.0          # many ties between positions
+    item_ids = None
+    pos = pos.to(dev)
+    scores = score_of(pos)
+    inv_src = torch.sort(pos, dim=1).values
+    flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+    # the sorted form
+    sp = E.sort_rows(pos)
+    ss = score_of(sp).contiguous()
+    E.mask_sorted_duplicates(sp, ss, -32767.0)
+    ws, wi = E.topk_candidates(ss, kp, sp, item_ids)
+    inv = torch.cat([wi[:, : width // 2], torch.randint(0, corpus, (rows, width - width // 2), generator=g).to(dev)], dim=1) if width else torch.zeros((rows, 0), dtype=torch.int64, device=dev)
+    want_i, want_s = E.topk_candidates_filtered(ss, kp, sp, item_ids, inv, k)
+    got_i, got_s = E.rerank_topk_filtered(scores, kp, pos, item_ids, inv, k, flag)
+    torch.cuda.synchronize()
+    n_distinct = min(int(torch.unique(pos[r]).numel()) for r in range(rows))
+    assert int(flag[0]) == (1 if n_distinct < kp else 0), (n_distinct, kp)
+    if n_distinct >= kp:
+        assert torch.equal(got_i, want_i) and torch.equal(got_s, want_s)
+        dflag = torch.zeros(1, dtype=torch.int32, device=dev)          # a device word works the same
+        g2_i, g2_s = E.rerank_topk_filtered(scores, kp, pos, item_ids, inv, k, dflag)
+        assert torch.equal(g2_i, want_i) and torch.equal(g2_s, want_s) and int(dflag.item()) == 0
+
+
 @pytest.mark.parametrize("n,k", [(300_000, 1000), (695_762, 1600), (120_000, 4096), (60_000, 600)])
 def test_predicated_topk_takes_the_two_launch_route_and_equals_the_plain_call(dev, n, k):
     """rails_topk under a launch predicate (the fallback behind a device-side verdict) selects k > 512 of a long row in two launches
@@ -972,6 +1033,77 @@ def test_f10_naive_and_comb(dev, cname):
                 assert len(set(i[b, :10].tolist()) & set(ref_i[b, :10].tolist())) >= 9
         with pytest.raises(NotImplementedError):
             rails_amd.get_top_k_module("MoLNaiveFaissTopK5", holder, X, ids)
+
+
+@pytest.mark.parametrize("cfg_name,n,method,B", [("amzn-books", 300_007, "MoLNaiveTopK100", 5), ("amzn-books", 300_007, "MoLCombTopK50_500", 3), ("amzn-books", 40_000, "MoLNaiveTopK25", 4),
+                                                  ("ml-1m", 3883, "MoLCombTopK50_1000", 6), ("amzn-books", 300_007, "MoLNaiveTopK10", 4)])
+def test_naive_and_comb_filter_inside_the_selection_equals_the_full_ranking(dev, monkeypatch, cfg_name, n, method, B):
+    """get_top_k_outputs over MoLNaiveTopK / MoLCombTopK (which return ALL their candidates ranked, reference mol_top_k.py:260-293 / :518-551):
+    round 6 keeps the filter inside the selection launch and selects only the top k + width -- the same (ids, scores) as ranking every
+    candidate and filtering after (indexing/candidate_index.py:149-175), bit for bit, with seen ids taken from the best results; modules whose
+    candidate count or k + width is outside the fused launch (Naive10: 640 candidates) compose the two calls as before."""
+    cfg = O.CONFIGS[cfg_name]
+    w = O.synthetic_weights(cfg, seed=0)
+    mol = build_module(cfg, w, dev)
+    holder = type("M", (), {"_ndp_module": mol})()
+    X = torch.from_numpy(O.hash_item_table(3, 0, n, cfg.item_embedding_dim)).unsqueeze(0).to(dev)
+    ids = (torch.arange(n, dtype=torch.int64, device=dev) * 2 + 9).unsqueeze(0)
+    q = O.synthetic_queries(cfg, B, seed=4).to(dev)
+    kw = {"user_ids": torch.arange(1, B + 1, dtype=torch.int64, device=dev)} if cfg.uid_embedding_hash_sizes else {}
+    k, width = 120, 61
+    # as at bench scale (32 queries x 695 762 items: a 5.7 GB score matrix), the fused scans' redo is the host's: their verdict word sits in pinned memory
+    monkeypatch.setattr(rails_amd.MoLAvgTopK, "DEVICE_REDO_BYTES", 0)
+    unsorted_calls = []
+    real_rerank = E.rerank_topk_filtered
+    monkeypatch.setattr(E, "rerank_topk_filtered", lambda *a, **kw_: (unsorted_calls.append(1), real_rerank(*a, **kw_))[1])
+    with torch.inference_mode():
+        mod = rails_amd.get_top_k_module(method, holder, X, ids)
+        ci = rails_amd.CandidateIndex(ids, X)
+        full_s, full_i = mod(q, k=k, **kw)                      # every candidate, ranked
+        n_cand = full_i.shape[1]
+        inv = torch.cat([full_i[:, :20], full_i[:, 100:110], ids[0, torch.randint(0, n, (B, width - 30), device=dev)]], dim=1)
+        mod.NO_FILTER_FUSION = True
+        assert mod.forward_filtered(q, 181, inv, k, **kw) is None
+        want = ci.get_top_k_outputs(q, k=k, aux_payloads=kw, top_k_module=mod, invalid_ids=inv, truncate_k_prime_to=200)
+        r_i, r_s = E.filter_seen_ids(full_i, full_s, inv, k)
+        assert torch.equal(want[0], r_i) and torch.equal(want[1], r_s)
+        mod.NO_FILTER_FUSION = False
+        fused = mod.forward_filtered(q, 181, inv, k, **kw)
+        assert (fused is not None) == (n_cand > 1024), n_cand
+        got = ci.get_top_k_outputs(q, k=k, aux_payloads=kw, top_k_module=mod, invalid_ids=inv, truncate_k_prime_to=200)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+        assert (len(unsorted_calls) > 0) == (fused is not None and n >= 262144), (len(unsorted_calls), n_cand)
+        if fused is not None:
+            assert torch.equal(fused[0], want[0]) and torch.equal(fused[1], want[1])
+            # the sorted form of the fused tail (the unsorted one runs by default wherever the fused scans ran: n >= 262 144)
+            mod.UNSORTED_RERANK = False
+            n_u = len(unsorted_calls)
+            srt = mod.forward_filtered(q, 181, inv, k, **kw)
+            mod.UNSORTED_RERANK = True
+            assert torch.equal(srt[0], want[0]) and torch.equal(srt[1], want[1]) and len(unsorted_calls) == n_u
+            if n >= 262144:
+                # a union with fewer distinct positions than k + width: the unsorted tail raises the scans' verdict word and the call is redone on
+                # the sorted form, masked duplicates ranked as the reference ranks them
+                calls = []
+                real = type(mod)._component_topk
+
+                def few(self, eq, kg, pending=None):
+                    out = real(self, eq, kg, pending)
+                    calls.append(pending is not None and any(not b.is_cuda for b in pending))
+                    return out[:, :50].repeat(1, out.shape[1] // 50 + 1)[:, : out.shape[1]].contiguous()
+
+                type(mod)._component_topk = few
+                try:
+                    mod.NO_FILTER_FUSION = True
+                    want2 = ci.get_top_k_outputs(q, k=k, aux_payloads=kw, top_k_module=mod, invalid_ids=inv, truncate_k_prime_to=200)
+                    mod.NO_FILTER_FUSION = False
+                    n_before = len(calls)
+                    got2 = ci.get_top_k_outputs(q, k=k, aux_payloads=kw, top_k_module=mod, invalid_ids=inv, truncate_k_prime_to=200)
+                    if "Naive" in method:
+                        assert len(calls) == n_before + 2 and calls[n_before], calls      # speculated once, redone once
+                finally:
+                    type(mod)._component_topk = real
+                assert torch.equal(got2[0], want2[0]) and torch.equal(got2[1], want2[1])
 
 
 def test_sort_rows_and_duplicate_mask(dev):
