@@ -660,11 +660,24 @@ def main() -> None:
     # RAILS_BENCH_TEST_BACKEND=gloo is a TEST hook: several ranks share GPU 0 and the (tiny) all-gather message is
     # staged through the host, so the sharded code path can be exercised on a one-GPU box.  Never set by the driver.
     test_backend = os.environ.get("RAILS_BENCH_TEST_BACKEND")
+    # RAILS_BENCH_TEST_ONE_RANK_EXCHANGE=1 is a TEST hook too: with --gpus 1 the run takes the SHARDED path in a process group of one rank over
+    # backend nccl -- a one-GPU box cannot hold two RCCL ranks, but this way RCCL's all-gather / all-reduce / barrier on device tensors, the
+    # exchange stream and the merge launches all execute once on the part before the driver's multi-GPU run.  Never set by the driver.
+    one_rank_exchange = world == 1 and bool(os.environ.get("RAILS_BENCH_TEST_ONE_RANK_EXCHANGE"))
+    sharded = world > 1 or one_rank_exchange
+    if one_rank_exchange:
+        from rails_amd.sharded import ShardedTopK
+
+        ShardedTopK.EXCHANGE_WITH_ONE_RANK = True
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     if test_backend:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if sharded:
         import torch.distributed as dist
 
         import datetime
@@ -744,7 +757,7 @@ def main() -> None:
                 lg = local_p.all_logits(q[b0 : b0 + 8], **{kk: vv[b0 : b0 + 8] for kk, vv in kw.items()})
                 s_, top_ = E.topk(lg, min(k_r, hi - lo), ids=local_p._ids_flat)
                 del lg
-                if world > 1:
+                if sharded:
                     s_, top_ = E.merge_candidates(all_gather_rows(E.pack_candidates(s_, top_, k_r)), world, k_r, k_r)
                 for r in range(top_.shape[0]):
                     mine, ref = got[b0 + r].tolist(), top_[r].tolist()
@@ -800,10 +813,10 @@ def main() -> None:
             mark = (lambda: ev1[i].record()) if i is not None else (lambda: None)
             eng.score_dense(qpack, B, local._index, out=logits)
             mark()
-            if world == 1 and E.topk_filter_fusable(hi - lo, k_local, inv.shape[1], k):   # filter fused into the selection over the dense logits
+            if not sharded and E.topk_filter_fusable(hi - lo, k_local, inv.shape[1], k):   # filter fused into the selection over the dense logits
                 return E.topk_filtered(logits, k_local, local._ids_flat, inv, k)
             s, top = E.topk(logits, k_local, ids=local._ids_flat)
-            if world > 1:
+            if sharded:
                 gathered = all_gather_rows(E.pack_candidates(s, top, kp))
                 if E.merge_filter_fusable(kp, inv.shape[1], k):   # what the sharded module does: the filter inside the merge launch
                     return E.merge_candidates_filtered(gathered, world, kp, kp, inv, k)
@@ -839,11 +852,11 @@ def main() -> None:
                     out = E.filter_seen_ids(top_, s_, inv, k)
             return out
 
-        pipelined_headline = args.pipeline and (world > 1 or two_pass)
+        pipelined_headline = args.pipeline and (sharded or two_pass)
         gc.collect()
         for _ in range(args.warmup):
             step()
-        if world > 1:
+        if sharded:
             import torch.distributed as dist
 
             dist.barrier()
@@ -857,12 +870,12 @@ def main() -> None:
                 step(i)
         ev_step[args.steps].record()
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
         elapsed = time.perf_counter() - t0
 
         sharded_info = None
-        if world > 1 and not two_pass:
+        if sharded and not two_pass:
             # what carried the exchange, where a step's time goes (events on the launch stream, unpipelined), and the pipelined rate
             pe = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
             for i in range(args.steps):
@@ -955,7 +968,7 @@ def main() -> None:
                 "pipelined": {"ms_per_step": float(tpp.item()) / args.steps * 1e3, "value": B * args.steps / float(tpp.item()), "unit": "queries/s",
                               "output_equal_to_unpipelined": equal, "headline_uses_it": bool(pipelined_headline)},
             }
-        if world > 1 and two_pass:
+        if sharded and two_pass:
             # the approximate mode has no unsharded twin to equal (K' per shard); what the line can carry is that every rank ends with
             # the same (ids, score bits), plus the recall measurement above
             fin_i, fin_s = step()
@@ -975,16 +988,16 @@ def main() -> None:
             ref_out = step()
             p_out = run_pipelined(max(2, args.warmup))
             equal = bool(torch.equal(ref_out[0], p_out[0]) and torch.equal(ref_out[1], p_out[1]))
-            if world > 1:
+            if sharded:
                 dist.barrier()
             torch.cuda.synchronize()
             tp = time.perf_counter()
             run_pipelined(args.steps)
             torch.cuda.synchronize()
-            if world > 1:
+            if sharded:
                 dist.barrier()
             p_elapsed = time.perf_counter() - tp
-            if world > 1:
+            if sharded:
                 tpp = torch.tensor([p_elapsed], dtype=torch.float64, device="cpu" if test_backend else dev)
                 dist.all_reduce(tpp, op=dist.ReduceOp.MAX)
                 p_elapsed = float(tpp.item())
@@ -1029,17 +1042,17 @@ def main() -> None:
 
         for _ in range(args.warmup):
             step_nofilter()
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step_nofilter()
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded:
             dist.barrier()
         nofilter_elapsed = time.perf_counter() - t0
-        if world > 1:
+        if sharded:
             tn = torch.tensor([nofilter_elapsed], dtype=torch.float64, device="cpu" if test_backend else dev)
             dist.all_reduce(tn, op=dist.ReduceOp.MAX)
             nofilter_elapsed = float(tn.item())
@@ -1076,8 +1089,8 @@ def main() -> None:
                     before = mod_stats()["fallbacks"]
                     step_proved()
                     step_proved()
-                    failed = torch.tensor([mod_stats()["fallbacks"] - before], dtype=torch.int64, device="cpu" if (world > 1 and test_backend) else dev)
-                    if world > 1:
+                    failed = torch.tensor([mod_stats()["fallbacks"] - before], dtype=torch.int64, device="cpu" if (sharded and test_backend) else dev)
+                    if sharded:
                         dist.all_reduce(failed, op=dist.ReduceOp.MAX)
                     if int(failed.item()) == 0:
                         break
@@ -1089,7 +1102,7 @@ def main() -> None:
                 n_warm = max(args.warmup, 0)
                 for _ in range(n_warm):
                     step_proved()
-                if world > 1:
+                if sharded:
                     dist.barrier()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
@@ -1098,10 +1111,10 @@ def main() -> None:
                     step_proved(i)
                 p_step[args.steps].record()
                 torch.cuda.synchronize()
-                if world > 1:
+                if sharded:
                     dist.barrier()
                 p_elapsed = time.perf_counter() - t0
-                if world > 1:
+                if sharded:
                     tpv = torch.tensor([p_elapsed], dtype=torch.float64, device="cpu" if test_backend else dev)
                     dist.all_reduce(tpv, op=dist.ReduceOp.MAX)
                     p_elapsed = float(tpv.item())
@@ -1116,8 +1129,8 @@ def main() -> None:
                 timed_calls = since_calls - n_warm
                 timed_proved = args.steps if (since_proved == since_calls and timed_calls == args.steps) else max(0, min(since_proved - n_warm, timed_calls - (st["fallbacks"] - base_stats["fallbacks"])))
                 counts = torch.tensor([timed_calls, timed_proved, st["fallbacks"] - base_stats["fallbacks"],
-                                       st.get("bound_violations", 0), int(p_identical)], dtype=torch.int64, device="cpu" if (world > 1 and test_backend) else dev)
-                if world > 1:          # every rank's shard must have been proved
+                                       st.get("bound_violations", 0), int(p_identical)], dtype=torch.int64, device="cpu" if (sharded and test_backend) else dev)
+                if sharded:          # every rank's shard must have been proved
                     dist.all_reduce(counts, op=dist.ReduceOp.SUM)
                 timed_calls, proved_calls, fallbacks, violations, identical_ranks = (int(v) for v in counts.tolist())
                 p_score_ms = sum(a.elapsed_time(b) for a, b in zip(pe0, pe1)) / args.steps
@@ -1155,19 +1168,19 @@ def main() -> None:
             ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
             for _ in range(args.warmup):
                 step()
-            if world > 1:
+            if sharded:
                 dist.barrier()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(args.steps):
                 step(i)
             torch.cuda.synchronize()
-            if world > 1:
+            if sharded:
                 dist.barrier()
             fast_elapsed = time.perf_counter() - t0
             fast_ms = sum(a.elapsed_time(b) for a, b in zip(ev0, ev1)) / args.steps
             mol.precision = None
-        if world > 1:
+        if sharded:
             tf = torch.tensor([fast_elapsed], dtype=torch.float64, device="cpu" if test_backend else dev)
             dist.all_reduce(tf, op=dist.ReduceOp.MAX)
             fast_elapsed = float(tf.item())
@@ -1208,7 +1221,7 @@ def main() -> None:
                 identical = bool(torch.equal(x_ids, ref_ids) and torch.equal(x_scores, ref_scores))
                 for _ in range(args.warmup):
                     step_exact()
-                if world > 1:
+                if sharded:
                     dist.barrier()
                 torch.cuda.synchronize()
                 dbg = os.environ.get("RAILS_BENCH_DEBUG")
@@ -1221,7 +1234,7 @@ def main() -> None:
                 if dbg:
                     evs[args.steps].record()
                 torch.cuda.synchronize()
-                if world > 1:
+                if sharded:
                     dist.barrier()
                 exact_elapsed = time.perf_counter() - t0
                 if dbg:
@@ -1236,7 +1249,7 @@ def main() -> None:
                 local.audit_every = 0
                 stats["audited"], stats["mismatches"] = audit["audited"], audit["mismatches"]
                 mol.precision = None
-            if world > 1:
+            if sharded:
                 tf = torch.tensor([exact_elapsed], dtype=torch.float64, device="cpu" if test_backend else dev)
                 dist.all_reduce(tf, op=dist.ReduceOp.MAX)
                 exact_elapsed = float(tf.item())
@@ -1252,7 +1265,7 @@ def main() -> None:
                              if not stats.get("eps_rigorous_usable") else "proved per call: the verdicts run on the a-priori bound eps_rigorous (rails_amd/f16x3_bound.py)",
             }
 
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if test_backend else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -1286,7 +1299,7 @@ def main() -> None:
             "config": {
                 "workload": f"{args.workload} HSTU+MoL {cfg.query_dot_product_groups}x{cfg.item_dot_product_groups}x{cfg.dot_product_dimension}, N={N} items, exact brute-force top-k",
                 "global_batch": B, "k": k, "k_prime": kp, "seen_id_width": width, "n_items": N,
-                "parallelism": f"item-shard x{world}" if world > 1 else "single GPU",
+                "parallelism": f"item-shard x{world}" if sharded else "single GPU",
             },
             "roofline": {
                 "kernel": "mol_score_kernel",
@@ -1391,35 +1404,35 @@ def main() -> None:
             out["fast_path"] = fast
         if exact_fast is not None:
             out["exact_fast_path"] = exact_fast
-        if world == 1 and not two_pass and not args.no_matrix:
+        if not sharded and not two_pass and not args.no_matrix:
             # the other points of the reference's protocol on this workload -- small batches (B = 1 is the
             # HBM-bound end: one index pass per query) and the accuracy protocol (k = 2500 -> k' = 2561, no truncation)
             out["matrix"] = measurement_matrix(mol, X, ids, q, kw, inv, cfg, hi - lo, min(args.steps, 10), dev)
-        if world == 1 and args.workload == "amzn-books" and not args.no_other_workloads:
+        if not sharded and args.workload == "amzn-books" and not args.no_other_workloads:
             # the two smaller real-dataset shapes of BASELINE.json (configs 1 and 2): fixed per-batch costs dominate there
             out["other_workloads"] = [quick_workload(n, B, k, kp, 10, dev, precision=pr) for n in ("ml-20m", "ml-1m") for pr in ("fp32", "proved", "f16x3", "f16-exact")]
             # BASELINE config 4 (16x16x64, 100 M items 8-way): a 400 k-item sub-range of one shard -- the kernels are linear in N
             out["other_workloads"] += [quick_workload("synthetic-16x16x64", B, k, kp, 5, dev, items=400_000, precision=pr) for pr in ("fp32", "proved", "f16x3", "f16-exact")]
-        if world == 1 and not two_pass and not args.no_weights_sweep and args.precision == "proved":
+        if not sharded and not two_pass and not args.no_weights_sweep and args.precision == "proved":
             try:
                 out["weights_scale_sweep"] = weights_scale_sweep(cfg, weights, X, ids, q, kw, inv, k, kp, min(args.steps, 10), dev)
             except Exception as e:   # noqa: BLE001 -- a secondary leg must not take the headline line down with it
                 out["weights_scale_sweep"] = [{"skipped": f"{type(e).__name__}: {e}"[:300]}]
                 torch.cuda.empty_cache()
-        if world == 1 and args.workload == "amzn-books" and not args.no_other_workloads and not args.no_full_shards:
+        if not sharded and args.workload == "amzn-books" and not args.no_other_workloads and not args.no_full_shards:
             try:
                 out["full_shards"] = full_shard_legs(B, k, dev)
             except Exception as e:   # noqa: BLE001 -- a secondary leg must not take the headline line down with it (e.g. a smaller device)
                 out["full_shards"] = [{"skipped": f"{type(e).__name__}: {e}"[:300]}]
                 torch.cuda.empty_cache()
         shared = None
-        if world == 1 and not args.no_cpu_baseline and not two_pass:   # the CPU baseline is the exact path
+        if not sharded and not args.no_cpu_baseline and not two_pass:   # the CPU baseline is the exact path
             cb = cpu_baseline(cfg, weights, q_cpu, uid_cpu, N, min(args.cpu_sample_items or N, N), kp)
             oracle_topk = cb.pop("_oracle_topk")
             out["cpu_baseline"] = cb
             if oracle_topk is not None and kp == 200 and k == 120:
                 shared = (q_cpu, uid_cpu, N, oracle_topk)
-        if world == 1 and not two_pass and not args.no_hr_parity:
+        if not sharded and not two_pass and not args.no_hr_parity:
             # the quality half of the metric + the reference's own CSV line (eval_from_checkpoint.py:507-515; BatchTimeMs = this run's step)
             hp = hr_parity_leg(cfg, weights, mol, B, 120, 200, dev, shared=shared,    # the harness's own timing-protocol constants (data/eval.py:128-130)
                                exact_mode="proved" if (proved is not None and proved["qualifies"]) else "dense")
@@ -1431,7 +1444,7 @@ def main() -> None:
                                     "note": "HR columns: hr_parity corpus with planted targets (HIP path; oracle_row = the CPU oracle chain on the same inputs); "
                                             "time columns: the headline step of this run"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -65,6 +65,8 @@ class ShardedTopK(TopKModule):
     every shard, merged.  `local_topk` / `merge` default to the HIP kernels; the CPU tests of the collective logic inject
     oracle-backed callables instead (gloo, world_size 2)."""
 
+    EXCHANGE_WITH_ONE_RANK = False
+
     def _make_local_module(self, mol_module, item_embeddings_shard, item_ids_shard) -> TopKModule:
         raise NotImplementedError
 
@@ -81,6 +83,9 @@ class ShardedTopK(TopKModule):
         super().__init__()
         self._group = group
         self._world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # one shard = the local module's own result, no exchange -- unless EXCHANGE_WITH_ONE_RANK (a test setting: a one-GPU box runs the whole
+        # exchange path -- RCCL all-gather on the exchange stream, merge, global verdict -- in a process group of one rank)
+        self._exchange = self._world > 1 or (self.EXCHANGE_WITH_ONE_RANK and dist.is_initialized())
         self._n_total = n_items_total
         if local_topk is None:
             self._local_module = self._make_local_module(mol_module, item_embeddings_shard, item_ids_shard)
@@ -118,7 +123,7 @@ class ShardedTopK(TopKModule):
             s, ids = spec[1], spec[2]
             if spec[0] == "final":
                 spec = None
-            elif self._world > 1 and s.is_cuda and isinstance(spec[-1], torch.cuda.Stream):
+            elif self._exchange and s.is_cuda and isinstance(spec[-1], torch.cuda.Stream):
                 # the local call ran on a stream of its own and the pack below reads its output here: join it now (with one shard
                 # nothing reads it before result(), and batches overlap)
                 torch.cuda.current_stream(s.device).wait_event(spec[4])
@@ -128,7 +133,7 @@ class ShardedTopK(TopKModule):
             B = query_embeddings.size(0)
             s = torch.empty((B, 0), dtype=torch.float32, device=query_embeddings.device)
             ids = torch.empty((B, 0), dtype=torch.int64, device=query_embeddings.device)
-        if self._world == 1:
+        if not self._exchange:
             return ("done", s, ids, spec)
         on_gpu = s.is_cuda and self._merge is _hip_merge
         msg = E.pack_candidates(s, ids, k) if on_gpu else pack_candidates(s.float(), ids, k)
@@ -142,7 +147,7 @@ class ShardedTopK(TopKModule):
         """CandidateIndex.get_top_k_outputs' body for the sharded modules: the seen-id filter runs inside the merge launch
         (rails_merge_candidates_filtered) -> (top_k_ids (B, k), top_k_scores (B, k)), or None when the sizes are outside the fused path
         or the merge is not the HIP one (the caller then composes forward + filter_seen_ids: same bits)."""
-        if self._world == 1:
+        if not self._exchange:
             local = getattr(self, "_local_module", None)
             return local.forward_filtered(query_embeddings, k_prime, invalid_ids, k, **kwargs) if hasattr(local, "forward_filtered") else None
         if not (query_embeddings.is_cuda and self._merge is _hip_merge and E.merge_filter_fusable(k_prime, invalid_ids.shape[1], k)) or k_prime > self._n_total:
@@ -267,7 +272,7 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
     def _global_proof(self, query_embeddings: torch.Tensor) -> bool:
         """Decided collectively, once per binding of the local module (all ranks reach this at the same call)."""
         local = getattr(self, "_local_module", None)
-        if not (self.GLOBAL_PROOF and self._world > 1 and dist.is_initialized() and isinstance(local, MoLBruteForceTopK) and self._local_topk_is_module
+        if not (self.GLOBAL_PROOF and self._exchange and dist.is_initialized() and isinstance(local, MoLBruteForceTopK) and self._local_topk_is_module
                 and self._merge is _hip_merge and query_embeddings.is_cuda):
             return False
         eng = local._bind()
@@ -419,7 +424,7 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
         return info
 
     def forward_filtered(self, query_embeddings: torch.Tensor, k_prime: int, invalid_ids: torch.Tensor, k: int, **kwargs):
-        if self._world > 1 and self._global_proof(query_embeddings) and MoLBruteForceTopK.speculation_pays(query_embeddings.size(0), -(-self._n_total // self._world)) and k_prime <= self._n_total:
+        if self._exchange and self._global_proof(query_embeddings) and MoLBruteForceTopK.speculation_pays(query_embeddings.size(0), -(-self._n_total // self._world)) and k_prime <= self._n_total:
             with self._inline():
                 return self.result(self.submit(query_embeddings, k_prime, **kwargs), seen=(invalid_ids, k))
         return super().forward_filtered(query_embeddings, k_prime, invalid_ids, k, **kwargs)
@@ -445,7 +450,7 @@ class ShardedMoLAvgTopK(ShardedTopK):
         super().__init__(mol_module, item_embeddings_shard, item_ids_shard, n_items_total, **kwargs)
         rank = dist.get_rank(self._group) if dist.is_initialized() else 0
         self._offset = shard_offset if shard_offset is not None else shard_bounds(n_items_total, self._world, rank)[0]
-        if self._global and self._world > 1 and shard_offset is not None:
+        if self._global and self._exchange and shard_offset is not None:
             # ties are broken by the slot in the rank-major concatenation: that is the global position order only when the shards
             # are disjoint position ranges in rank order
             spans = [None] * self._world
@@ -469,14 +474,14 @@ class ShardedMoLAvgTopK(ShardedTopK):
         return out
 
     def forward_filtered(self, query_embeddings: torch.Tensor, k_prime: int, invalid_ids: torch.Tensor, k: int, **kwargs):
-        if k_prime > self._avg_top_k or (self._global and self._world > 1):
+        if k_prime > self._avg_top_k or (self._global and self._exchange):
             return None   # forward's own checks / the global-K' exchange: the caller composes forward + filter_seen_ids
         return super().forward_filtered(query_embeddings, k_prime, invalid_ids, k, **kwargs)
 
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
         if k > self._avg_top_k:
             raise ValueError(f"avg_top_k ({self._avg_top_k}) must be larger than k ({k})")
-        if not self._global or self._world == 1:
+        if not self._global or not self._exchange:
             return super().forward(query_embeddings, k, sorted, **kwargs)
         K = self._avg_top_k
         if K > self._n_total:

@@ -28,9 +28,12 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _worker(rank: int, world: int, port: int, sizes, precision, ret, workload: str = "amzn-books"):
+def _worker(rank: int, world: int, port: int, sizes, precision, ret, workload: str = "amzn-books", one_rank_exchange: bool = False):
     """one spawn, every corpus size of `sizes` (an int or a tuple of ints) in turn: the processes' start-up (import, process group) is most of a case's time"""
     import rails_amd
+    import rails_amd.sharded
+
+    rails_amd.sharded.ShardedTopK.EXCHANGE_WITH_ONE_RANK = one_rank_exchange
     from oracle import mol_oracle as O
     from rails_amd import engine as E
     from rails_amd.sharded import ShardedMoLAvgTopK, ShardedMoLBruteForceTopK, shard_bounds
@@ -141,6 +144,41 @@ def test_two_ranks_through_the_hip_modules(precision):
     for n in sizes:
         assert torch.equal(ret[(0, n)][1], ret[(1, n)][1]) and torch.equal(ret[(0, n)][2], ret[(1, n)][2])   # identical on every rank
         assert ret[(0, n)][0] == ("nccl" if torch.cuda.device_count() >= world else "gloo")
+
+
+@pytest.mark.parametrize("workload,n", [("amzn-books", 70_001), ("synthetic-16x16x64", 20_003)])
+def test_one_rank_over_rccl_runs_the_exchange_path(workload, n):
+    """A one-GPU box cannot hold two RCCL ranks (one rank per device), so the two-rank cases above exchange over gloo there.  This case runs the
+    SAME checks in a process group of ONE rank over backend nccl with ShardedTopK.EXCHANGE_WITH_ONE_RANK: RCCL's communicator, its all-gather on
+    device tensors on the module's exchange stream, the merge / global-verdict launches behind it, the forced redo's second exchange and the
+    global-K' two-pass exchange all execute on the part -- the stream semantics the multi-GPU run will meet."""
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(1, _free_port(), (n,), None, ret, workload, True), nprocs=1, join=True)
+    assert set(ret.keys()) == {(0, n)} and ret[(0, n)][0] == "nccl"
+
+
+def test_bench_one_rank_exchange_over_rccl():
+    """bench.py's sharded path (RCCL all-gather, all-reduce(MAX) of the timings, barriers, the self-checks) in a process group of one rank over
+    backend nccl: the code the driver's multi-GPU run executes, on this box's one GPU (RAILS_BENCH_TEST_ONE_RANK_EXCHANGE)."""
+    env = dict(os.environ)
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RAILS_BENCH_TEST_BACKEND"):
+        env.pop(v, None)
+    env["RAILS_BENCH_TEST_ONE_RANK_EXCHANGE"] = "1"
+    env["MASTER_PORT"] = str(_free_port())
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                          "--no-other-workloads", "--items", "200000"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    sh = d["sharded"]
+    assert sh["backend"] == "nccl" and sh["rccl_ranks"] == 1 and d["n_gpus"] == 1
+    chk = sh["check"]
+    assert chk["all_ranks_identical"] is True and chk["merged_equals_unsharded"] is True and chk["nothing_outside_beats_kth"] is True
+    assert sh["pipelined"]["output_equal_to_unpipelined"] is True
+    pr = d["proved"]
+    assert pr["output_identical_to_fp32_path"] is True and pr["bound_violations"] == 0 and pr["timed_calls"] == 3
+    assert "sharded_global_proof" in pr          # the ONE-collective proved route ran (its string says what travels)
 
 
 @pytest.mark.parametrize("precision", [None, "f16x3"])

@@ -24,4 +24,6 @@ rm -rf $O/tl_c3 $O/tl_b8 $O/tl_c2 $O/tl_r8
   python tools/exact_step_profile.py --precisions proved,fp32 --steps 400 --workload ml-20m; python tools/exact_step_profile.py --precisions proved,fp32 --steps 400 --workload ml-1m;
   for R in 8 4 2; do python tools/shard_step_profile.py --world $R --precision proved-global; python tools/shard_step_profile.py --world $R --precision proved-global --pipeline; python tools/shard_step_profile.py --world $R; done; } 2>&1 | grep -v amdgpu | cut -c1-220 > $O/step_times.txt
 python tools/algorithms_bench.py --workload amzn-books > $O/algorithms_amzn_books.json 2> /dev/null
+# the sharded path of bench.py in a process group of ONE rank over backend nccl (RCCL's all-gather / all-reduce / barrier on device tensors, exchange stream, merge + global verdict)
+RAILS_BENCH_TEST_ONE_RANK_EXCHANGE=1 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-other-workloads --no-matrix --no-hr-parity --no-weights-sweep > $O/bench_one_rank_rccl.json 2> $O/bench_one_rank_rccl.err; echo "one-rank rccl bench rc=$?"
 ( time timeout 1500 python -m pytest tests -m gpu -q ) > $O/gpu_tests.txt 2>&1; echo "gpu tests rc=$?"; tail -5 $O/gpu_tests.txt
