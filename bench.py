@@ -1123,6 +1123,31 @@ def main() -> None:
                 st = mod_stats()
                 p_last_ids, p_last_scores = step_proved()
                 p_identical = p_identical and bool(torch.equal(p_last_ids, ref_ids) and torch.equal(p_last_scores, ref_scores))
+                # N > 1: the same K steps with batch i + 1 submitted before batch i's result is taken (ShardedTopK.submit / result): the plain call
+                # waits on the host for the global verdict behind its one all-gather; with a batch in flight that wait costs the GPU nothing
+                p_pipe = None
+                if sharded and not two_pass and hasattr(topk_mod, "submit"):
+                    pp_out = run_pipelined(2)
+                    pp_equal = bool(torch.equal(pp_out[0], ref_ids) and torch.equal(pp_out[1], ref_scores))
+                    pp_before = dict(mod_stats())
+                    dist.barrier()
+                    torch.cuda.synchronize()
+                    tpp0 = time.perf_counter()
+                    run_pipelined(args.steps)
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    pp_elapsed = time.perf_counter() - tpp0
+                    tpp_t = torch.tensor([pp_elapsed], dtype=torch.float64, device="cpu" if test_backend else dev)
+                    dist.all_reduce(tpp_t, op=dist.ReduceOp.MAX)
+                    pp_elapsed = float(tpp_t.item())
+                    pp_after = mod_stats()
+                    pp_counts = torch.tensor([pp_after["calls"] - pp_before["calls"], pp_after.get("proved_calls", 0) - pp_before.get("proved_calls", 0),
+                                              pp_after["fallbacks"] - pp_before["fallbacks"], int(pp_equal)], dtype=torch.int64, device="cpu" if test_backend else dev)
+                    dist.all_reduce(pp_counts, op=dist.ReduceOp.SUM)
+                    pc, pv, pf, pe_ = (int(v) for v in pp_counts.tolist())
+                    p_pipe = {"ms_per_step": pp_elapsed / args.steps * 1e3, "queries_per_s": B * args.steps / pp_elapsed, "timed_calls": pc, "proved_calls": pv,
+                              "dense_fp32_fallbacks": pf, "output_equal_to_unpipelined": pe_ == world,
+                              "what": "the same K proved steps with batch i + 1 submitted before batch i's result is taken (depth 1): every result verified before it is returned"}
                 # warm-up + timed calls since the snapshot; the timed ones are "all proved" only if every call since the snapshot was
                 since_calls = st["calls"] - base_stats["calls"]
                 since_proved = st.get("proved_calls", 0) - base_stats.get("proved_calls", 0)
@@ -1140,7 +1165,7 @@ def main() -> None:
                           "bound_violations": violations, "identical": identical_ranks == world, "eps": st.get("eps_rigorous"), "eps_terms": st.get("eps_rigorous_terms"),
                           "bound_kind": st.get("bound_kind", "one a-priori eps"), "upper_bound_poly": st.get("upper_bound_poly"),
                           "kc": st.get("kc"), "guard_max": st.get("guard_max"), "guard_limit": getattr(topk_mod, "_gp_guard_limit", None) if st.get("global_proof") else local._gate_guard_limit,
-                          "global_proof": bool(st.get("global_proof", False)),
+                          "global_proof": bool(st.get("global_proof", False)), "pipelined": p_pipe,
                           "qualifies": bool(identical_ranks == world and proved_calls == timed_calls == args.steps * world and fallbacks == 0 and violations == 0)}
             local.exact_mode = "dense"
             eng = local._bind()       # the legs below drive the fp32 kernels by hand again
@@ -1341,6 +1366,7 @@ def main() -> None:
                 **({"sharded_global_proof": "one proof for all shards: kc per rank = candidates_per_query; ONE all-gather of (B, 2k' + 2) messages -- the per-shard fp32 top-k', "
                                             "the best first-pass score left outside and the largest observed error ride in it -- then merge + verdict + filter in one launch "
                                             "(rails_amd/sharded.py ShardedMoLBruteForceTopK)"} if proved.get("global_proof") else {}),
+                **({"pipelined": proved["pipelined"]} if proved.get("pipelined") else {}),
                 "per_step_ms": [round(v, 3) for v in proved["steps_ms"]],
                 "per_step_first_pass_kernel_ms": [round(v, 3) for v in proved["kernel_ms"]],
                 # the f16 kernel's time falls for the first ~40 ms of sustained load after an idle gap (clock ramp; the fp32 kernels do not show it):
@@ -1353,6 +1379,11 @@ def main() -> None:
                 out["fp32_dense"] = {"value": out["value"], "unit": "queries/s", "ms_per_step": out["ms_per_step"], "ms_per_step_stdev": out["ms_per_step_stdev"],
                                      "roofline": out["roofline"], "what": "the dense fp32 kernels over the whole corpus (exact_mode 'dense'), same step, same protocol, timed in this run"}
                 out["value"], out["ms_per_step"], out["ms_per_step_stdev"] = leg["value"], leg["ms_per_step"], leg["ms_per_step_stdev"]
+                pp = proved.get("pipelined")
+                if args.pipeline and pp and pp["output_equal_to_unpipelined"] and pp["proved_calls"] == pp["timed_calls"] and pp["dense_fp32_fallbacks"] == 0:
+                    # --pipeline: the headline is the rate with one batch in flight (the plain rate stays in `proved`)
+                    out["value"], out["ms_per_step"] = pp["queries_per_s"], pp["ms_per_step"]
+                    out["config"]["pipelined"] = "batch i + 1 submitted before batch i's result is taken (ShardedTopK.submit / result)"
                 kind = "per-pair a-priori upper bound" if proved.get("upper_bound_poly") else "a-priori eps"
                 out["config"]["exact_path"] = (f"proved under the measured arithmetic model (H1-H3 re-checked on this device): f16x3 first pass + fp32 re-scoring, {kind} "
                                                "(same bits as the dense fp32 kernels)")

@@ -179,6 +179,7 @@ def test_bench_one_rank_exchange_over_rccl():
     pr = d["proved"]
     assert pr["output_identical_to_fp32_path"] is True and pr["bound_violations"] == 0 and pr["timed_calls"] == 3
     assert "sharded_global_proof" in pr          # the ONE-collective proved route ran (its string says what travels)
+    assert pr["pipelined"]["output_equal_to_unpipelined"] is True and pr["pipelined"]["timed_calls"] == 3
 
 
 @pytest.mark.parametrize("precision", [None, "f16x3"])
@@ -227,6 +228,8 @@ def test_bench_self_spawns_two_ranks():
     pr = d["proved"]
     assert pr["output_identical_to_fp32_path"] is True and pr["bound_violations"] == 0 and pr["timed_calls"] == 2 * 3
     assert pr["proved_calls"] + pr["dense_fp32_fallbacks"] >= pr["timed_calls"] - 2 * 3 and pr["is_headline"] == (pr["proved_calls"] == pr["timed_calls"] and pr["dense_fp32_fallbacks"] == 0)
+    pp = pr["pipelined"]       # the same steps with a batch in flight: same output, every call accounted for
+    assert pp["output_equal_to_unpipelined"] is True and pp["timed_calls"] == 2 * 3 and pp["proved_calls"] + pp["dense_fp32_fallbacks"] >= pp["timed_calls"] - 2 * 3
 
 
 def test_bench_two_ranks_on_the_256_logit_shape():
