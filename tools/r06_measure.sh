@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 O=gpurun_out/r06_${1:-final}; mkdir -p $O
-python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+( time python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err ) 2> $O/bench_wall.txt; echo "bench rc=$?"; tail -3 $O/bench_wall.txt
 # the headline step alone under rocprofv3 (every launch of the proved step at B = 32)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_headline -o r06 -- python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-matrix --no-other-workloads --no-fast-path --no-hr-parity --no-weights-sweep > $O/bench_headline_under_profiler.json 2> $O/prof_headline.err
 f=$(find $O/prof_headline -name '*kernel_stats.csv' | head -1); cp "$f" $O/kernel_stats_headline.csv; python tools/kernel_stats_top.py "$f" 24 > $O/kernel_stats_headline_top.txt; rm -rf $O/prof_headline
