@@ -47,6 +47,7 @@ def _f16_cases(g: torch.Generator):
     return [(name, x.half(), y.half(), z.float()) for name, x, y, z in out]
 
 
+@FB._few_cpu_threads
 def measure(device: torch.device, probe_f16: Optional[Callable] = None, probe_f32: Optional[Callable] = None,
             probe_scalar: Optional[Callable] = None) -> Dict[str, object]:
     """Worst observed error / model bound per hypothesis (<= 1 means the hypothesis held on every case).  The probes default to the library's."""

@@ -78,6 +78,27 @@ _PACK = (2.0 ** -21, 2.0 ** -25, 2.0 ** -10 * (1 + 2.0 ** -11), 2.0 ** -24)
 _KERN = (2.0 ** -20, 2.0 ** -24, 2.0 ** -10, 2.0 ** -24)
 
 
+def _few_cpu_threads(fn):
+    """The bound is a few hundred float64 operations on weight-sized tensors: with one OpenMP thread per logical CPU (the default in a process
+    launched without OMP_NUM_THREADS, e.g. one rank per GPU under mp.spawn on a 256-thread host) every one of them is a fork / join of the whole
+    pool and several ranks spin against each other -- a module's bind took 10-15 s instead of 0.3 (tests/test_sharded_gpu.py, round 6).  Run it
+    on at most four threads and put the caller's setting back."""
+    import functools
+
+    @functools.wraps(fn)
+    def run(*args, **kwargs):
+        n = torch.get_num_threads()
+        if n <= 4:
+            return fn(*args, **kwargs)
+        torch.set_num_threads(4)
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            torch.set_num_threads(n)
+
+    return run
+
+
 def gamma(n: float, unit: float = U) -> float:
     return n * unit / (1.0 - n * unit)
 
@@ -135,6 +156,7 @@ def _chain16(terms: torch.Tensor, c0: torch.Tensor, small_mass: torch.Tensor, kc
     return gamma(m + 1, unit) * (c0 + small_mass) + step @ g + kp * U * total * (1 + gamma(m + 1, unit))
 
 
+@_few_cpu_threads
 def first_pass_bound(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, temperature: float, dot_dim: int,
                      p_q: int, p_x: int, kc: float = KC, kp: float = KP, gate_guard: float = GATE_GUARD,
                      cl_max: Optional[float] = None) -> Dict[str, float]:
@@ -221,6 +243,7 @@ def first_pass_bound(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: t
     return out
 
 
+@_few_cpu_threads
 def upper_bound_poly(w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, temperature: float, dot_dim: int, p_q: int, p_x: int,
                      grid: int = 96, **kw) -> Dict[str, object]:
     """Coefficients (ub2, ub1, ub0), all >= 0 and float32-representable, of a PER-PAIR bound: for every pair whose first pass computed cross

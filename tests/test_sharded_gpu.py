@@ -34,6 +34,7 @@ def _worker(rank: int, world: int, port: int, sizes, precision, ret, workload: s
     import rails_amd.sharded
 
     rails_amd.sharded.ShardedTopK.EXCHANGE_WITH_ONE_RANK = one_rank_exchange
+    torch.set_num_threads(8)     # (mp.spawn does not set OMP_NUM_THREADS as torchrun does: two ranks with one OpenMP thread per logical CPU each spend their time spinning)
     from oracle import mol_oracle as O
     from rails_amd import engine as E
     from rails_amd.sharded import ShardedMoLAvgTopK, ShardedMoLBruteForceTopK, shard_bounds
