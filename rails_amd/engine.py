@@ -524,11 +524,12 @@ class MolEngine:
         return pre
 
     def coarse_topk(self, eq: torch.Tensor, table: torch.Tensor, average_queries: bool, k_prime: int, with_flag: bool = False,
-                    prefilter: Optional[torch.Tensor] = None):
+                    prefilter: Optional[torch.Tensor] = None, flag: Optional[torch.Tensor] = None):
         """Fused coarse scoring + exact top-K' (no (B, N) score matrix).  -> (scores (B, K'), positions (B, K'), counts (B,)
         int32) or None when the sizes are unsupported.  The result is exact iff K' <= counts[b] <= capacity for every b
         (see include/rails_amd.h); the caller checks and falls back to coarse_scores + topk otherwise.  with_flag: a fourth
-        element, a device int32 that is 1 iff some count is out of range (written by the call's own launches).
+        element, a device int32 that is 1 iff some count is out of range (written by the call's own launches) -- or `flag`, the caller's own
+        int32 word (device or PINNED HOST memory: the kernels store through the device-visible address, no copy is needed to read it).
         prefilter: build_coarse_prefilter(table) -- same outputs, the streaming pass reads the int8 copy."""
         B, n = eq.shape[0], table.shape[0]
         memo = self.__dict__.setdefault("_coarse_ws_bytes", {})
@@ -552,7 +553,12 @@ class MolEngine:
         out_s = torch.empty((B, k_prime), dtype=torch.float32, device=dev)
         out_p = torch.empty((B, k_prime), dtype=torch.int64, device=dev)
         counts = torch.empty((B + 1,), dtype=torch.int32, device=dev)   # [B]: the out-of-range flag
-        flag = counts[B:]
+        if flag is None:
+            flag = counts[B:]
+        elif flag.dtype != torch.int32 or flag.numel() != 1 or not (flag.is_cuda or flag.is_pinned()):
+            raise ValueError("coarse_topk: flag must be one int32 on the device or in pinned host memory")
+        else:
+            with_flag = True
         with _on_device(dev):
             _lib.check(
                 self.lib.rails_mol_coarse_topk(C.byref(self.shape), _ptr(eq), B, 1 if average_queries else 0, _ptr(table), n, k_prime,

@@ -1056,6 +1056,16 @@ class MoLBruteForceTopK(MoLTopKModule):
                     self._rows32 = eng.exact.build_index_rows(self._index32)
         return eng
 
+def _pinned_word(module) -> torch.Tensor:
+    """One int32 in pinned host memory from the module's rotating pool of sixteen (a call takes at most two; at most two batches are in flight);
+    zeroed on the device by the first launch of the call that takes it."""
+    pool = module.__dict__.setdefault("_flag_pool", [])
+    module.__dict__["_flag_turn"] = (module.__dict__.get("_flag_turn", -1) + 1) % 16
+    while len(pool) < 16:
+        pool.append(torch.zeros(1, dtype=torch.int32).pin_memory())
+    return pool[module.__dict__["_flag_turn"]]
+
+
 def _verdicts_clear(pending: list) -> bool:
     """pending: int32 verdict words of fused scans (1 = a candidate count left its range), read after everything that depends on them is
     enqueued.  Words in PINNED HOST memory (the component scans write theirs there: the kernels store through the device-visible address)
@@ -1179,11 +1189,15 @@ class MoLAvgTopK(MoLTopKModule):
         # Same scores and the same exact top-K' as the materialising path below -- when every query's candidate count
         # landed inside [K', capacity]; the check costs one 128-byte device-to-host copy.
         if n >= self.fused_coarse_min_items and self._avg_top_k <= 4096 and not getattr(self, "_no_fused", False):
-            fused = eng.coarse_topk(eq, table, average_queries, self._avg_top_k, with_flag=True, prefilter=self._prefilter())
+            on_device = self._device_redo_fits(eq.shape[0] * n * 4)
+            # a verdict the HOST reads (no device redo, the caller defers the look): the word lives in pinned host memory and the kernels write it
+            # there themselves -- no 4-byte copy behind the call's last launch (round 6, as the component scans)
+            word = _pinned_word(self) if (not on_device and pending is not None) else None
+            fused = eng.coarse_topk(eq, table, average_queries, self._avg_top_k, with_flag=True, prefilter=self._prefilter(), flag=word)
             if fused is not None:
                 # bad: 1 iff some row's candidate count is outside [K', capacity] -- raised by the call's key-selection launch
                 sc, idx, counts, bad = fused
-                if self._device_redo_fits(eq.shape[0] * n * 4):
+                if on_device:
                     # the redo ON THE DEVICE: the materialising scan and its top-K' are enqueued under that flag as their launch
                     # predicate and overwrite (sc, idx) -- no-ops unless a count was out of range; nothing for the host to wait
                     # for (the (B, N) score buffer is recycled across calls)
@@ -1253,6 +1267,8 @@ class MoLAvgTopK(MoLTopKModule):
             scores, ids = self._enqueue(query_embeddings, k, pending, **kwargs)
             if not pending:
                 host = None
+            elif all(not bad.is_cuda for bad in pending):
+                host = list(pending)           # already in pinned host memory (written by the scans themselves): nothing to copy
             else:
                 pool = self._verdict_pool      # pinned words go back to the pool in result(): no host allocation per call
                 host = pool.pop() if pool and pool[-1].numel() == len(pending) else torch.empty(len(pending), dtype=torch.int32, pin_memory=True)
@@ -1278,9 +1294,12 @@ class MoLAvgTopK(MoLTopKModule):
         if host is not None:
             while not done.query():      # spin: the word is microseconds away, and a blocking wait parks the thread on an interrupt whose
                 pass                     # wake-up costs 50-100 us of GPU idle per batch (see MoLBruteForceTopK._read_stats)
-            redo = int(host.max()) != 0
-            if len(self._verdict_pool) < 8:
-                self._verdict_pool.append(host)
+            if isinstance(host, list):
+                redo = any(int(w[0]) != 0 for w in host)
+            else:
+                redo = int(host.max()) != 0
+                if len(self._verdict_pool) < 8:
+                    self._verdict_pool.append(host)
         if not redo:
             return scores, ids
         self._no_fused = True      # redo this call on the materialising path
@@ -1381,11 +1400,7 @@ class _ComponentCandidates:
             else:
                 # the verdict word in pinned host memory, written by the kernels themselves: the caller spins on an event and reads it (no 4-byte
                 # copy launch, no blocking .item(): ~30 us of every Naive / Comb call at amzn-books)
-                pool = self.__dict__.setdefault("_flag_pool", [])
-                self.__dict__["_flag_turn"] = (self.__dict__.get("_flag_turn", -1) + 1) % 8
-                while len(pool) < 8:
-                    pool.append(torch.zeros(1, dtype=torch.int32).pin_memory())
-                flag = pool[self.__dict__["_flag_turn"]]
+                flag = _pinned_word(self)
             fused = eng.component_topk(eq, table, k_per_group, flag)
             if fused is not None:
                 sc_c, pos, counts = fused
