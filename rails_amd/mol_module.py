@@ -372,7 +372,7 @@ class MoLSimilarity(SimilarityModule):
             gating_item_fn=has_i,
         )
 
-    def engine(self, precision: Optional[str] = None) -> MolEngine:
+    def engine(self, precision: Optional[str] = None, _params_as_checked: bool = False) -> MolEngine:
         """HIP engine bound to the CURRENT parameter values (rebuilt when any parameter changed).  `precision` asks for an engine of
         another precision than the module's own (the proved exact top-k keeps a split-f16 engine next to the fp32 one); each
         precision has its own cached engine."""
@@ -386,8 +386,12 @@ class MoLSimilarity(SimilarityModule):
         if plist is None:
             plist = self._param_list = [v for _, v in self.state_dict(keep_vars=True).items()]
         if precision is not None and precision != self.precision:
-            key = (precision,) + tuple((v.data_ptr(), _version(v)) for v in plist)
             hit = self._extra_engines.get(precision)
+            if _params_as_checked and hit is not None and self._engine_key is not None and hit[0][1:] == self._engine_key[1:]:
+                # the caller has just asked for the module's own engine (same thread, nothing in between): the parameters are those of
+                # _engine_key, and this precision's engine was built from the same ones -- no second walk over the 27 tensors
+                return hit[1]
+            key = (precision,) + tuple((v.data_ptr(), _version(v)) for v in plist)
             if hit is None or hit[0] != key:
                 params = dict(self.state_dict(keep_vars=True))
                 self._param_list = list(params.values())

@@ -103,9 +103,21 @@ class ShardedTopK(TopKModule):
         with self._inline():     # a plain call has no neighbouring batch to overlap with (MoLAvgTopK.submit)
             return self.result(self.submit(query_embeddings, k, sorted, **kwargs))
 
+    _plain_call = False
+
+    @contextlib.contextmanager
     def _inline(self):
+        """A plain forward / forward_filtered: there is no neighbouring batch to overlap with, so the local module stays on the caller's stream
+        (MoLAvgTopK.inline_calls) and so does the exchange -- every hand-over between streams is an event the GPU waits 5-12 us for (round 6:
+        two of them per step on an 8-way shard's 0.44 ms)."""
         local = getattr(self, "_local_module", None)
-        return local.inline_calls() if hasattr(local, "inline_calls") else contextlib.nullcontext()
+        saved = self._plain_call
+        self._plain_call = True
+        try:
+            with (local.inline_calls() if hasattr(local, "inline_calls") else contextlib.nullcontext()):
+                yield
+        finally:
+            self._plain_call = saved
 
     # ---- two-stage form of forward: submit() enqueues this rank's part, result() the exchange ------------------------------
     # A caller that has the next batch at hand calls submit(batch i+1) BEFORE result(batch i): the all-gather and the merge of
@@ -183,12 +195,16 @@ class ShardedTopK(TopKModule):
             ms, mi = self._merge(all_s, all_ids, k)
             return ms.to(dtype), mi
         cur = torch.cuda.current_stream(msg.device)
-        if self._xstream is None:
-            self._xstream = torch.cuda.Stream(msg.device)
-        side = self._xstream
-        side.wait_event(ready)
-        msg.record_stream(side)
-        with torch.cuda.stream(side):
+        plain = self._plain_call
+        if plain:
+            side = cur
+        else:
+            if self._xstream is None:
+                self._xstream = torch.cuda.Stream(msg.device)
+            side = self._xstream
+            side.wait_event(ready)
+            msg.record_stream(side)
+        with (contextlib.nullcontext() if plain else torch.cuda.stream(side)):
             # concatenated-along-dim-0 output: the layout both RCCL and gloo accept for all_gather_into_tensor
             if dist.get_backend(self._group) == "gloo":   # test setups only: stage through the host
                 host = torch.empty((self._world * msg.shape[0], msg.shape[1]), dtype=msg.dtype)
@@ -199,17 +215,18 @@ class ShardedTopK(TopKModule):
                 dist.all_gather_into_tensor(gathered, msg, group=self._group)
             if on_gpu and seen is not None:   # one kernel: rank-major candidates -> exact top-k -> seen-id filter
                 mi, ms = E.merge_candidates_filtered(gathered, self._world, k, k, seen[0], seen[1])
-                invalid_keep = seen[0]
-                invalid_keep.record_stream(side)
+                if not plain:
+                    seen[0].record_stream(side)
             elif on_gpu:   # one kernel: rank-major candidates -> exact top-k (scores, ids)
                 ms, mi = E.merge_candidates(gathered, self._world, k, k)
             else:
                 all_s, all_ids = unpack_candidates(gathered.view(self._world, msg.shape[0], msg.shape[1]), k)
                 ms, mi = self._merge(all_s, all_ids, k)
             ms = ms.to(dtype)
-        cur.wait_stream(side)
-        ms.record_stream(cur)
-        mi.record_stream(cur)
+        if not plain:
+            cur.wait_stream(side)
+            ms.record_stream(cur)
+            mi.record_stream(cur)
         if seen is not None:
             return mi, ms
         return ms, mi
@@ -289,6 +306,8 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
             self._gp_eps = local._proved_eps() if self._gp_on else None
             self._gp_state = torch.zeros(8, dtype=torch.float32, device=query_embeddings.device)
             self._gp_host = torch.zeros(8, dtype=torch.float32).pin_memory()
+            self._gp_host_f = self._gp_host.numpy()                         # views of the same pinned words: a poll is a plain memory read,
+            self._gp_host_i = self._gp_host.view(torch.int32).numpy()       # not a tensor index + conversion (2-3 us each, between the batches)
             self._gp_call = torch.zeros(8 + 4 * 256, dtype=torch.int32, device=query_embeddings.device)      # arrival counter + one 16-byte word per row
             self._gp_issued = 0           # verdicts enqueued so far (the host mirror's call counter reaches it when the last one has landed)
             self._gp_pad = 1
@@ -327,8 +346,10 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
         with local.one_bind():
             kc = self._kc_local(k)
             msg, qpack32 = local.speculate_for_shard(query_embeddings, k, kc, **kwargs)
-        ready = torch.cuda.Event()
-        ready.record()
+        ready = None
+        if not self._plain_call:      # (a plain call's exchange follows on this very stream)
+            ready = torch.cuda.Event()
+            ready.record()
         self._gp_stats["kc"] = kc
         return ("gproof", msg, ready, k, qpack32, query_embeddings, kwargs, sorted)
 
@@ -342,30 +363,36 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
         off = (B + 32 // sp.query_dot_product_groups - 1) // (32 // sp.query_dot_product_groups) * 32 * sp.dot_product_dimension
         gq = qpack32[off : off + B * sp.num_logits]
         cur = torch.cuda.current_stream(msg.device)
-        if self._xstream is None:
-            self._xstream = torch.cuda.Stream(msg.device)
-        side = self._xstream
-        side.wait_event(ready)
-        for t in (msg, qpack32):
-            t.record_stream(side)
+        plain = self._plain_call          # a plain call: the exchange stays on the caller's stream (_inline)
+        if plain:
+            side = cur
+        else:
+            if self._xstream is None:
+                self._xstream = torch.cuda.Stream(msg.device)
+            side = self._xstream
+            side.wait_event(ready)
+            for t in (msg, qpack32):
+                t.record_stream(side)
         fuse = seen is not None and E.merge_filter_fusable(k, seen[0].shape[1], seen[1])
         if self._gp_call.numel() < 8 + 4 * B:
             self._gp_call = torch.zeros(8 + 4 * B, dtype=torch.int32, device=msg.device)
-        with torch.cuda.stream(side):
+        with (contextlib.nullcontext() if plain else torch.cuda.stream(side)):
             # ONE exchange: the (B, 2k + 2) messages carry every rank's top-k, the best first-pass score it left outside its candidates and the
             # largest |fp32 - first pass| it saw; merge, verdict and the seen-id filter are one launch behind it
             gathered = self._all_gather_rows(msg)
-            if fuse:
+            if fuse and not plain:
                 seen[0].record_stream(side)
             out = E.merge_candidates_verdict(gathered, self._world, k, k, self._gp_eps, 1.0, gq, sp.num_logits, self._gp_guard_limit, self._gp_state,
                                              self._gp_host, self._gp_call, seen if fuse else None)
             if seen is not None and not fuse:
-                seen[0].record_stream(side)
+                if not plain:
+                    seen[0].record_stream(side)
                 out = E.filter_seen_ids(out[1], out[0], seen[0], seen[1])
         self._gp_issued += 1
-        cur.wait_stream(side)
-        out[0].record_stream(cur)
-        out[1].record_stream(cur)
+        if not plain:
+            cur.wait_stream(side)
+            out[0].record_stream(cur)
+            out[1].record_stream(cur)
         # Every rank computes the verdict from the same gathered bytes, so all of them raise or clear REDO alike; the host reads it from the pinned
         # mirror the merge kernel writes (with submit / result pipelining batch i + 1 is already enqueued: the device does not idle) and only a
         # failed verdict -- crowded scores, a skewed shard, a violated guard -- costs more: the dense fp32 kernels over the shards and their
@@ -373,11 +400,11 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
         redo = self._gp_wait_verdict()
         st = self._gp_stats
         st["calls"] += 1
-        if float(self._gp_host[0]) > self._gp_eps:
+        if float(self._gp_host_f[0]) > self._gp_eps:
             st["bound_violations"] += 1
         elif not redo:
             st["proved_calls"] += 1
-        st["guard_max"] = float(self._gp_host[7])
+        st["guard_max"] = float(self._gp_host_f[7])
         if not redo:
             self._gp_streak += 1
             if self._gp_pad > 1 and self._gp_streak >= self.PAD_DECAY_CALLS:
@@ -407,15 +434,18 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
         """Spin on the pinned mirror's call counter until the verdict enqueued last has landed -> its REDO flag."""
         import time
 
-        h = self._gp_host
+        h = self._gp_host_f
         want = float(self._gp_issued)
         t0 = None
-        while float(h[5]) < want:
-            if t0 is None:
-                t0 = time.perf_counter()
-            elif time.perf_counter() - t0 > self.VERDICT_TIMEOUT_S:
-                raise RuntimeError("the item-sharded verdict did not arrive (a kernel or the exchange failed)")
-        return int(h.view(torch.int32)[1]) != 0
+        n = 0
+        while h[5] < want:
+            n += 1
+            if (n & 1023) == 0:
+                if t0 is None:
+                    t0 = time.perf_counter()
+                elif time.perf_counter() - t0 > self.VERDICT_TIMEOUT_S:
+                    raise RuntimeError("the item-sharded verdict did not arrive (a kernel or the exchange failed)")
+        return int(self._gp_host_i[1]) != 0
 
     def exchange_info(self) -> dict:
         info = super().exchange_info()

@@ -27,6 +27,18 @@ from .mol_module import MoLSimilarity
 
 
 class TopKModule(torch.nn.Module):
+    def __setattr__(self, name, value):
+        """Plain Python state (counters, flags, cached engines, handles: a dozen assignments per call) goes straight to the instance dict:
+        torch.nn.Module.__setattr__ walks its parameter / buffer / module registries for every assignment (1-2.5 us each -- host time that sits
+        between the batches wherever a call ends with the host's look at a verdict).  Tensors, modules and names already registered keep the
+        nn.Module path."""
+        if not isinstance(value, (torch.Tensor, torch.nn.Module)):
+            d = self.__dict__
+            if name not in d.get("_parameters", ()) and name not in d.get("_buffers", ()) and name not in d.get("_modules", ()):
+                d[name] = value
+                return
+        super().__setattr__(name, value)
+
     @abc.abstractmethod
     def forward(self, query_embeddings: torch.Tensor, k: int, sorted: bool = True, **kwargs) -> Tuple[torch.Tensor, torch.Tensor]:
         """-> (top_k_scores (B, k), top_k_ids (B, k))."""
@@ -221,7 +233,7 @@ class MoLBruteForceTopK(MoLTopKModule):
         if self._proved_choice is None or self._proved_choice[0] is not base:
             self._proved_choice = (base, "f16x3-exact" if self._proved_applies(base) else None)
         want = self._proved_choice[1]
-        return mol.engine(want) if want else base
+        return mol.engine(want, _params_as_checked=True) if want else base     # (the second look at the same parameters in the same breath)
 
     def _proved_applies(self, base: E.MolEngine) -> bool:
         spec, N = base.spec, self._item_embeddings.shape[1]
