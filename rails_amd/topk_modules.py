@@ -1090,7 +1090,7 @@ def _verdicts_clear(pending: list) -> bool:
         ev.record()
         while not ev.query():
             pass
-    return all(int(b.item() if b.is_cuda else b[0]) == 0 for b in pending)
+    return all(int(b.item() if b.is_cuda else b.numpy()[0]) == 0 for b in pending)     # (pinned words: a plain memory read through the numpy view)
 
 
 class MoLAvgTopK(MoLTopKModule):
