@@ -64,6 +64,7 @@ enum { kScanAll = 0, kScanSample = 1, kScanSelect = 2 };
 constexpr int kSubLists = 16;
 constexpr int kScanThreads = 256;
 constexpr int kSampleMaxQT = 4;       // query tiles (of 32) a sample launch keeps running maxima for: B <= 128
+constexpr int kSelectMaxRows = 512;   // query rows of a select launch (its workgroup flush keeps a counter per row in LDS)
 constexpr int kSampleGrid = 256;      // workgroups of a sample launch: 1 024 waves -> 32 768 maxima per query, one row_select launch
 #ifndef RAILS_SCAN_NT
 #define RAILS_SCAN_NT 1   // the select scan of a single query tile (B <= 32) reads the table with non-temporal loads -- each byte is used once:
@@ -85,6 +86,7 @@ struct CoarseScanArgs {
   // bf16(Eq[b, i, :]) themselves (no sum over the groups).  Row (q, m) of every per-row quantity -- thresholds, sample maxima, scores,
   // candidate lists -- is q * groups + m.  groups = 1, comp = 0: the coarse pass of MoLAvgTopK.
   int groups, comp; int64_t group_stride;
+  int stage_cap;                        // kScanSelect: entries of the workgroup's LDS list of hits (set by launch_coarse_scan)
   int no_hits;                          // RAILS_COMP_DEBUG=1 (measurement): the select scan with every threshold at +inf -- its cost without candidates
   const unsigned short* qfrag;          // the queries' A fragments, made once by workgroup 0 of the sample scan (NULL: every workgroup makes them from eq)
   const unsigned short* table; int64_t n;
@@ -120,7 +122,7 @@ constexpr int kStage = 128;   // entries per wave (2 KiB)
 __device__ __forceinline__ void append_candidate(unsigned long long* keys, unsigned int* counts, int cap, int sub,
                                                  unsigned int orow, unsigned long long key) {
   const int subcap = cap / kSubLists;
-  const unsigned int slot = atomicAdd(&counts[(int64_t)orow * kSubLists + sub], 1u);
+  const unsigned int slot = counts ? atomicAdd(&counts[(int64_t)orow * kSubLists + sub], 1u) : 0u;   // (counts == NULL: RAILS_COMP_DEBUG=2, a measurement of the path without its atomics)
   if (slot < (unsigned int)subcap) keys[(int64_t)orow * cap + sub * subcap + slot] = key;
 }
 __device__ __forceinline__ void stage_push(volatile StageEntry* st, unsigned int* cnt, unsigned long long* keys,
@@ -230,10 +232,22 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu((M
   const unsigned short* const table = a.table + (int64_t)gm * a.group_stride;
   const int n_qt = (B + 31) / 32;
   float* thr_s = reinterpret_cast<float*>(qfrag + (size_t)n_qt * DC * 64 * 8);   // [n_qt * 32]
-  __shared__ StageEntry stage_s[kScanThreads / 64][kStage];
+  __shared__ StageEntry stage_s[COMP ? kScanThreads / 64 : 1][COMP ? kStage : 1];      // (the per-wave lists of the COMP select block)
   __shared__ unsigned int stage_n[kScanThreads / 64];
   __shared__ float acc_s[MODE == kScanSelect ? (kScanThreads / 64) * 16 * 64 : 1];   // a fired tile's scores, per wave
+  // The select scan's appends (round 6).  A hit used to take its slot from a device-scope atomic on counts[row][tile % 16]: with few query
+  // rows (MoLAvgTopK: 32 rows = 512 counters) the ~500 k appends of K' = 4 000 queue up on the same addresses -- 257 us of a scan that takes 46
+  // without the atomics and 10 without candidates (tools/r06_probe_t.sh).  Now a workgroup keeps ALL its hits in one LDS list (wg_stage, LDS
+  // cursor; a.stage_cap entries behind the thresholds in dynamic LDS: 1 024 where that leaves three workgroups per CU, else 512) and flushes
+  // once, at its end: the entries of a row are counted (LDS), ONE device-scope atomic per (row, workgroup) reserves their slots in sub-list
+  // blockIdx.x % 16, and the keys go out.  Entries beyond the list take their slots one by one as before.
+  const int kWgStage = a.stage_cap;
+  unsigned int* const row_cnt_s = reinterpret_cast<unsigned int*>(thr_s + 2 * n_qt * 32);      // [n_qt * 32]
+  unsigned int* const row_base_s = row_cnt_s + n_qt * 32;                                     // [n_qt * 32]
+  StageEntry* const wg_stage = reinterpret_cast<StageEntry*>(row_base_s + n_qt * 32);        // [a.stage_cap], 16-byte aligned (every part is a multiple of 128 bytes)
+  __shared__ unsigned int wg_n;
   if (threadIdx.x < kScanThreads / 64) stage_n[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) wg_n = 0u;
   if (a.qfrag) {   // 16 bytes per thread and step instead of P_Q dependent loads per element (2 048 workgroups each made them)
     for (int i = threadIdx.x; i < n_qt * DC * 64; i += kScanThreads)
       reinterpret_cast<bf16x8*>(qfrag)[i] = reinterpret_cast<const bf16x8*>(a.qfrag)[i];
@@ -320,7 +334,6 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu((M
       [&]<int... V>(std::integer_sequence<int, V...>) {
         ((u == V ? pick(std::integral_constant<int, V>{}, std::make_integer_sequence<int, DC>{}) : (void)0), ...);
       }(std::make_integer_sequence<int, TU>{});
-      const int64_t t = (w0 + u) * step;
       cf32x16 acc = {0};
 #pragma unroll
       for (int c = 0; c < DC; ++c) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[c], Bu[c], acc, 0, 0, 0);
@@ -344,14 +357,17 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu((M
             const int q = qt * 32 + acc_row(r, h);
             const float thr = thr_s[q];
             const float sc = bf16_rn(mine[r * 64]);   // an un-rounded sum at or above the bound may round up to thr
-            if (q < B && sc >= thr)
-              stage_push(stage_s[wave], &stage_n[wave], a.keys, a.counts, a.cap, (int)(t % kSubLists), (unsigned int)(q * groups + gm),
-                         ((unsigned long long)coarse_orderable(sc) << 32) | (unsigned int)(~(unsigned int)item));
+            if (q < B && sc >= thr) {
+              const unsigned long long key = ((unsigned long long)coarse_orderable(sc) << 32) | (unsigned int)(~(unsigned int)item);
+              const unsigned int i = atomicAdd(&wg_n, 1u);   // LDS
+              if (i < (unsigned int)kWgStage) { wg_stage[i].key = key; wg_stage[i].orow = (unsigned int)q; }
+              else append_candidate(a.keys, a.counts, a.cap, (int)(blockIdx.x % kSubLists), (unsigned int)(q * groups + gm), key);   // list full: one by one
+            }
           }
         }
       }
-      stage_flush_mixed(stage_s[wave], &stage_n[wave], lane, a.keys, a.counts, a.cap, 64u);
     }
+    (void)w0;
   };
   // More than one tile of 32 queries (B > 32): the table is still read ONCE -- the query tiles walk over the trip in registers,
   // their A fragments and accumulator bounds come from LDS once per trip.  (Reading the table once per query tile cost 7.75 ms
@@ -483,7 +499,7 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu((M
     }
   };
   int64_t w0 = gw * TU;
-  if (MODE != kScanSample && w0 >= n_work) return;
+  if (MODE == kScanAll && w0 >= n_work) return;      // (the select scan's waves all meet at the workgroup's flush below)
   const int64_t hop = n_waves * TU;
   Trip T, N;
   if (w0 < n_work) {
@@ -504,7 +520,27 @@ __global__ __launch_bounds__(kScanThreads) __attribute__((amdgpu_waves_per_eu((M
   }
   }
   if constexpr (MODE == kScanSelect && COMP) stage_flush_reg(stage_s[wave], staged, lane, a.keys, a.counts, a.cap, 1u);
-  else if constexpr (MODE == kScanSelect) stage_flush_mixed(stage_s[wave], &stage_n[wave], lane, a.keys, a.counts, a.cap, 1u);
+  else if constexpr (MODE == kScanSelect) {
+    __syncthreads();                                   // every wave is through its tiles: the list is complete
+    const unsigned int n_st = wg_n < (unsigned int)kWgStage ? wg_n : (unsigned int)kWgStage;
+    if (n_st > 0u) {                                   // workgroup-uniform
+      const int rows_wg = n_qt * 32;
+      const int sub = (int)(blockIdx.x % kSubLists), subcap = a.cap / kSubLists;
+      for (int r = threadIdx.x; r < rows_wg; r += kScanThreads) row_cnt_s[r] = 0u;
+      __syncthreads();
+      for (unsigned int e = threadIdx.x; e < n_st; e += kScanThreads) wg_stage[e].pad = atomicAdd(&row_cnt_s[wg_stage[e].orow], 1u);   // the entry's place among its row's
+      __syncthreads();
+      for (int r = threadIdx.x; r < rows_wg; r += kScanThreads) {
+        const unsigned int c = row_cnt_s[r];
+        if (c) row_base_s[r] = a.counts ? atomicAdd(&a.counts[((int64_t)r * groups + gm) * kSubLists + sub], c) : 0u;   // (counts == NULL: RAILS_COMP_DEBUG=2)
+      }
+      __syncthreads();
+      for (unsigned int e = threadIdx.x; e < n_st; e += kScanThreads) {
+        const unsigned int r = wg_stage[e].orow, slot = row_base_s[r] + wg_stage[e].pad;
+        if (slot < (unsigned int)subcap) a.keys[((int64_t)r * groups + gm) * a.cap + (int64_t)sub * subcap + slot] = wg_stage[e].key;
+      }
+    }
+  }
   if constexpr (MODE == kScanSample) {   // a wave that saw no tile writes -inf: the row of maxima has no holes
 #pragma unroll
     for (int qt = 0; qt < QTS; ++qt)
@@ -524,7 +560,15 @@ static int launch_coarse_scan(const CoarseScanArgs& a, hipStream_t stream) {
   const int groups = a.groups > 0 ? a.groups : 1;
   const int n_qt = (rows + 31) / 32;
   const int dc = a.d / 16;
-  const size_t lds = (size_t)n_qt * dc * 64 * 8 * sizeof(unsigned short) + 2 * (size_t)n_qt * 32 * sizeof(float);
+  size_t lds = (size_t)n_qt * dc * 64 * 8 * sizeof(unsigned short) + 2 * (size_t)n_qt * 32 * sizeof(float);
+  int stage_cap = 0;
+  if (MODE == kScanSelect) {
+    // + the flush's two counters per row and the workgroup's list of hits: 1 024 entries where three workgroups still fit a CU's 160 KiB next
+    // to the kernel's 16 KiB of static LDS (the component scans' 256 rows at d = 32: 512 -- a third workgroup per CU is worth more there)
+    lds += 2 * (size_t)n_qt * 32 * sizeof(unsigned int);
+    stage_cap = (lds + 1024 * sizeof(StageEntry) + 17 * 1024) * 3 <= 156 * 1024 ? 1024 : 512;
+    lds += (size_t)stage_cap * sizeof(StageEntry);
+  }
   if (lds > 96 * 1024) { set_error("coarse scan: %d query rows x d %d do not fit LDS", rows, a.d); return kErrUnsupported; }
   const int64_t n_tiles = (a.n + 31) >> 5;
   const int64_t step = MODE == kScanSample ? a.stride : 1;
@@ -535,6 +579,7 @@ static int launch_coarse_scan(const CoarseScanArgs& a, hipStream_t stream) {
   const int64_t cap_g = (grid_cap + groups - 1) / groups;   // 2048 workgroups over all groups: 8 workgroups of 4 waves per CU
   if (grid > cap_g) grid = cap_g;
   const bool wide = a.comp && n_qt > kSampleMaxQT;
+  if (MODE == kScanSelect && n_qt * 32 > kSelectMaxRows) { set_error("coarse select scan: %d query rows exceed %d", rows, kSelectMaxRows); return kErrUnsupported; }
   if constexpr (MODE == kScanSample) {
     if (n_qt > (a.comp ? kSampleMaxQTComp : kSampleMaxQT)) { set_error("coarse sample scan: %d query rows exceed %d", rows, 32 * (a.comp ? kSampleMaxQTComp : kSampleMaxQT)); return kErrUnsupported; }
     grid = a.ld / (32 * (kScanThreads / 64));   // the plan's: every wave writes its 32 columns of the row's block of maxima
@@ -542,6 +587,7 @@ static int launch_coarse_scan(const CoarseScanArgs& a, hipStream_t stream) {
   if (grid < 1) return kOk;
   CoarseScanArgs b = a;
   b.groups = groups;
+  b.stage_cap = stage_cap;
   auto go = [&](auto nt) {
     constexpr bool NT = decltype(nt)::value;
     auto fire = [&](auto kernel) {
@@ -1062,6 +1108,9 @@ int coarse_topk(const Shape& s, const float* eq, int B, int avg, const void* tab
     a.qfrag = frag; a.qfrag_out = nullptr; a.zero_words = nullptr; a.n_zero = 0; a.zero_flag = nullptr; a.q8_out = nullptr; a.qmeta_out = nullptr;
     a.scores16 = nullptr; a.ld = 0; a.stride = 1;
     a.thr = top_s + (p.r - 1); a.thr_stride = p.r; a.keys = keys; a.cap = p.cap; a.counts = counts;
+    static const int dbg = [] { const char* e = getenv("RAILS_COMP_DEBUG"); return e ? atoi(e) : 0; }();
+    a.no_hits = dbg & 1;
+    if (dbg & 2) a.counts = nullptr;      // (measurement: the appends without their global atomics -- wrong results)
     rc = launch_coarse_scan<kScanSelect>(a, stream);
   }
   if (rc != kOk) return rc;
@@ -1162,7 +1211,9 @@ int component_topk(const Shape& s, const float* eq, int B, const void* table, in
   a.thr = top_s; a.thr_stride = 1; a.keys = keys; a.cap = p.cap; a.counts = counts;
   static const int dbg = [] { const char* e = getenv("RAILS_COMP_DEBUG"); return e ? atoi(e) : 0; }();
   a.no_hits = dbg & 1;
+  if (dbg & 2) a.counts = nullptr;
   rc = launch_coarse_scan<kScanSelect>(a, stream);
+  a.counts = counts;
   if (rc != kOk) return rc;
   return select_sublists(keys, counts, rows, p.cap, kSubLists, k_group, out_scores, out_pos, out_counts, out_flag, stream);
 }
