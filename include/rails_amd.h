@@ -38,7 +38,7 @@ extern "C" {
  * 9: rails_candidates_* -- the threshold selection and the fused finish of the proved exact top-k -- and rails_merge_candidates_verdict
  * are new, rails_mol_score_indexed_rows gained cand_counts, the component table became item-group-major (rails_mol_component_build
  * gained n_total / first_item, rails_mol_component_topk its out_of_range flag, rails_mol_component_topk_capacity is new);
- * 10: rails_topk_candidates_filtered and rails_rerank_topk_filtered / rails_rerank_workspace_bytes are new).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
+ * 10: rails_topk_candidates_filtered, rails_rerank_topk_filtered / rails_rerank_workspace_bytes and rails_mol_coarse_topk_capacity are new).  A binding checks rails_abi_version() == RAILS_ABI_VERSION at load time: callers built
  * against an older header pass shorter structs, and the library would read the new fields from whatever follows them. */
 #define RAILS_ABI_VERSION 10
 int rails_abi_version(void);
@@ -256,8 +256,9 @@ int rails_mol_coarse_score(const rails_mol_shape* shape, const float* eq, int32_
  * materialising the (batch, n_items) matrix): per-group maxima of a strided sample of the table fix a per-query threshold,
  * one streaming pass collects the items at or above it, and the K' best of those are selected with the position tie rule.
  * Four launches.  out_scores / out_positions: (batch, k_prime), descending.  out_counts[b] = candidates query b collected;
- * the result for query b is exact iff k_prime <= out_counts[b] <= the internal capacity (min(24576, max(4096, 8 k_prime)),
- * rounded up to a multiple of 64; capacity + 1 is reported when one of the 16 internal sub-lists overflowed) -- otherwise
+ * the result for query b is exact iff k_prime <= out_counts[b] <= rails_mol_coarse_topk_capacity(batch, n_items, k_prime)
+ * (min(24576, max(4096, 8 k_prime)) rounded up to a multiple of 64 for corpora beyond 4 Mi items; 4 k_prime below, where a denser
+ * sample leaves ~1.8 k_prime candidates; capacity + 1 is reported when one of the 16 internal sub-lists overflowed) -- otherwise
  * (heavy ties at the threshold) the caller falls back to rails_mol_coarse_score + rails_topk; slots of an under-filled row
  * name position 0 with score -inf.  out_of_range (may be NULL): one int32 the call sets to 1 if some query's count is
  * outside that range and to 0 otherwise -- what rails_range_flag_i32 computes from out_counts, inside the call's own launches
@@ -265,6 +266,7 @@ int rails_mol_coarse_score(const rails_mol_shape* shape, const float* eq, int32_
  * k_prime <= 4096, batch <= 128 (slice larger batches).  rails_mol_coarse_topk_workspace_bytes returns 0 when the sizes are
  * unsupported. */
 size_t rails_mol_coarse_topk_workspace_bytes(const rails_mol_shape* shape, int32_t batch, int64_t n_items, int32_t k_prime);
+int32_t rails_mol_coarse_topk_capacity(int32_t batch, int64_t n_items, int32_t k_prime);   /* 0: unsupported sizes (ABI 10) */
 int rails_mol_coarse_topk(const rails_mol_shape* shape, const float* eq, int32_t batch, int32_t average_queries,
                           const void* table, int64_t n_items, int32_t k_prime, void* workspace, size_t workspace_bytes,
                           float* out_scores, int64_t* out_positions, int32_t* out_counts, int32_t* out_of_range,

@@ -143,6 +143,7 @@ PROTOTYPES = {
     "rails_mol_coarse_table_bytes": (C.c_size_t, [_SHAPE_P, C.c_int64]),
     "rails_mol_coarse_build": (C.c_int, [_SHAPE_P, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "rails_mol_coarse_topk_workspace_bytes": (C.c_size_t, [_SHAPE_P, C.c_int32, C.c_int64, C.c_int32]),
+    "rails_mol_coarse_topk_capacity": (C.c_int32, [C.c_int32, C.c_int64, C.c_int32]),
     "rails_mol_coarse_topk": (C.c_int, [_SHAPE_P, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
                                         C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rails_mol_coarse_prefilter_bytes": (C.c_size_t, [_SHAPE_P, C.c_int64]),

@@ -439,6 +439,10 @@ size_t rails_mol_coarse_topk_workspace_bytes(const rails_mol_shape* s, int32_t b
   return coarse_topk_workspace_bytes(*s, batch, n_items, k_prime);
 }
 
+int32_t rails_mol_coarse_topk_capacity(int32_t batch, int64_t n_items, int32_t k_prime) {
+  return batch > 0 ? coarse_topk_capacity(batch, n_items, k_prime) : 0;
+}
+
 int rails_mol_coarse_topk(const rails_mol_shape* s, const float* eq, int32_t batch, int32_t average_queries, const void* table,
                           int64_t n_items, int32_t k_prime, void* workspace, size_t workspace_bytes, float* out_scores,
                           int64_t* out_positions, int32_t* out_counts, int32_t* out_of_range, void* prefilter, void* stream) {

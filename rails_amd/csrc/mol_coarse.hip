@@ -700,12 +700,24 @@ static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p, b
     static const int forced = [] { const char* e = getenv("RAILS_COMP_STRIDE"); const int v = e ? atoi(e) : 0; return v >= 1 && v <= 256 ? v : 0; }();   // measurement override
     stride = forced ? forced : 4;      // sample + select scan at amzn-books, B = 32, k_g = 5 (round-6 kernels before the COMP select block): 16 -> 42 + 228 us, 4 -> 81 + 162, 1 -> 237 + 136
   }
+  // Corpora of a few million items (round 6): the sample is cheap there (a 64 k-item sample of a 45 MB table is microseconds), and what the
+  // step pays for is every candidate beyond K' -- appended by the scan, loaded and ranked by the key selection.  m = 64 expected hits and the
+  // exact Poisson rank put ~1.8 K' candidates at or above the threshold where m = 8-16 and the Chernoff rank put 3-4 K'
+  // (amzn-books, K' = 4 000: 16 400 -> 7 400 per query).  Shard-sized corpora keep the sparse sample above.
+  const bool small_corpus = comp_rows == 0 && n <= (4ll << 20);
+  if (small_corpus) {
+    stride = k_prime / 64;
+    const int64_t floor_stride = (n + 65535) / 65536;      // at most ~64 k sampled items per query
+    if (stride < floor_stride) stride = (int)floor_stride;
+    if (stride < 4) stride = 4;
+    if (stride > 256) stride = 256;
+  }
   // r = the smallest rank with P(Poisson(m) >= r) <= e^-m (e m / r)^r < 1e-9 (Chernoff), and at least 2m + 4 sqrt(m):
   // the r-th largest sample score is then below the true K'-th score except with negligible probability (and a miss
   // only costs the fallback), while ~r * stride items are expected at or above it
   auto r_of = [&](int st) {
     const float m = (float)k_prime / st;
-    if (comp_rows > 0) {
+    if (comp_rows > 0 || small_corpus) {
       // component scans: every candidate beyond the k_g wanted costs the select scan (a fired tile is ~3 x a quiet one, and at k_g = 100 a third
       // of the (tile, query tile) steps fire), so r is the EXACT smallest rank with P(Poisson(m) >= r) < 1e-9 per row -- the Poisson tail
       // dominates the binomial one of k_g items landing in every stride-th tile -- instead of the Chernoff rank with its 2m floor
@@ -739,7 +751,7 @@ static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p, b
     if (grid < 16) grid = 16;
     p->n_sample = grid * waves_per_wg * 32;
   }
-  int cap = 8 * k_prime;
+  int cap = (small_corpus ? 4 : 8) * k_prime;      // (~1.8 K' candidates expected under the dense sample, 3-4 K' under the sparse one)
   if (cap < (comp_rows > 0 ? 2048 : 4096)) cap = comp_rows > 0 ? 2048 : 4096;
   if (cap > 24 * 1024) cap = 24 * 1024;
   cap = (cap + kSubLists * 4 - 1) / (kSubLists * 4) * (kSubLists * 4);
@@ -1053,6 +1065,11 @@ static int launch_coarse_scan_i8(const CoarseI8Args& a, hipStream_t stream) {
 size_t coarse_topk_workspace_bytes(const Shape& s, int B, int64_t n, int k_prime) {
   CoarseTopkPlan p;
   return coarse_topk_plan(B, n, k_prime, &p, true) ? p.total : 0;
+}
+
+int coarse_topk_capacity(int B, int64_t n, int k_prime) {
+  CoarseTopkPlan p;
+  return coarse_topk_plan(B, n, k_prime, &p, true) ? p.cap : 0;
 }
 
 // flag |= any(v[i] < lo || v[i] > hi): the validity check of a fused scan's candidate counts, on the device

@@ -111,6 +111,7 @@ int query_prologue(const Shape& s, const Weights& w, const float* q, const int64
 
 int coarse_build(const Shape& s, const float* ipack, int64_t n, void* table, hipStream_t stream);
 size_t coarse_topk_workspace_bytes(const Shape& s, int B, int64_t n, int k_prime);
+int coarse_topk_capacity(int B, int64_t n, int k_prime);
 int coarse_topk(const Shape& s, const float* eq, int B, int avg, const void* table, int64_t n, int k_prime, void* ws,
                 size_t ws_bytes, float* out_scores, int64_t* out_pos, int32_t* out_counts, int32_t* out_flag, void* prefilter, int n_cu,
                 hipStream_t stream);

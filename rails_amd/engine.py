@@ -568,7 +568,11 @@ class MolEngine:
         return (out_s, out_p, counts[:B], flag) if with_flag else (out_s, out_p, counts[:B])
 
     @staticmethod
-    def coarse_topk_capacity(k_prime: int) -> int:
+    def coarse_topk_capacity(k_prime: int, n_items: Optional[int] = None, batch: int = 32) -> int:
+        """candidates per query the fused coarse top-K' can hold (include/rails_amd.h rails_mol_coarse_topk_capacity); without n_items: the
+        figure of shard-sized corpora"""
+        if n_items is not None:
+            return int(_lib.load().rails_mol_coarse_topk_capacity(int(batch), int(n_items), int(k_prime)))
         cap = min(24576, max(4096, 8 * k_prime))
         return (cap + 63) // 64 * 64
 

@@ -413,7 +413,7 @@ def test_fused_coarse_topk_equals_the_materialised_path(dev, cfg_name, n, avg_k)
             coarse = eng.coarse_scores(eq, at._table(), average)
             rs, rp = E.topk(coarse, avg_k)
             fs, fp, counts = eng.coarse_topk(eq, at._table(), average, avg_k)
-            assert int(counts.min()) >= avg_k and int(counts.max()) <= eng.coarse_topk_capacity(avg_k), counts
+            assert int(counts.min()) >= avg_k and int(counts.max()) <= eng.coarse_topk_capacity(avg_k, at._table().shape[0]), counts
             assert torch.equal(fs, rs) and torch.equal(fp, rp)
             # the int8 pre-filter changes what the streaming pass reads, not what it finds: same candidates, counts, output
             ps, pp, pc = eng.coarse_topk(eq, at._table(), average, avg_k, prefilter=eng.build_coarse_prefilter(at._table()))
@@ -449,7 +449,7 @@ def test_fused_coarse_topk_over_several_trips_per_wave(dev, cfg_name, n, B, avg_
         coarse = eng.coarse_scores(eq, at._table(), True)
         rs, rp = E.topk(coarse, avg_k)
         fs, fp, counts = eng.coarse_topk(eq, at._table(), True, avg_k)
-        assert int(counts.min()) >= avg_k and int(counts.max()) <= eng.coarse_topk_capacity(avg_k), counts
+        assert int(counts.min()) >= avg_k and int(counts.max()) <= eng.coarse_topk_capacity(avg_k, at._table().shape[0]), counts
         assert torch.equal(fs, rs) and torch.equal(fp, rp)
         ps, pp, pc = eng.coarse_topk(eq, at._table(), True, avg_k, prefilter=eng.build_coarse_prefilter(at._table()))
         assert torch.equal(ps, rs) and torch.equal(pp, rp) and torch.equal(pc, counts)
@@ -470,7 +470,7 @@ def test_fused_coarse_topk_falls_back_on_heavy_ties(dev):
         eng = at._bind()
         _, eq, _ = eng.query_pack(q, None, want_plain=True)
         _, _, counts = eng.coarse_topk(eq, at._table(), False, 200)
-        assert int(counts.max()) > eng.coarse_topk_capacity(200)
+        assert int(counts.max()) > eng.coarse_topk_capacity(200, at._table().shape[0])
         s1, i1 = at(q, k=50)
         at.fused_coarse_min_items = 1 << 62
         s2, i2 = at(q, k=50)
@@ -564,7 +564,7 @@ def test_int8_prefilter_never_loses_a_candidate(dev, case, monkeypatch):
             fs, fp, counts = eng.coarse_topk(eq, table, average, K)
             ps, pp, pc = eng.coarse_topk(eq, table, average, K, prefilter=pre)
             assert torch.equal(pc, counts)                # the same candidates reached the lists
-            exact = (counts >= K) & (counts <= eng.coarse_topk_capacity(K))      # rows whose lists hold every candidate: defined output
+            exact = (counts >= K) & (counts <= eng.coarse_topk_capacity(K, table.shape[0]))      # rows whose lists hold every candidate: defined output
             if case in ("zeros", "ties"):
                 assert not bool(exact.any())              # every score tied thousands of times: all rows overflow, the caller redoes them
             else:
@@ -727,7 +727,7 @@ def test_fused_coarse_topk_raises_its_flag_exactly_when_a_count_is_out_of_range(
         at = rails_amd.MoLAvgTopK(mol, X, ids, avg_top_k=200)
         eng = at._bind()
         _, eq, _ = eng.query_pack(q, None, want_plain=True)
-        cap = eng.coarse_topk_capacity(200)
+        cap = eng.coarse_topk_capacity(200, n)
         for _ in range(2):    # the flag is reset by every call
             _, _, counts, flag = eng.coarse_topk(eq, at._table(), False, 200, with_flag=True)
             assert int(flag.item()) == 0 and int(counts.min()) >= 200 and int(counts.max()) <= cap
