@@ -1069,16 +1069,20 @@ class MoLBruteForceTopK(MoLTopKModule):
         return eng
 
 def _pinned_word(module) -> torch.Tensor:
-    """One int32 in pinned host memory from the module's rotating pool of sixteen (a call takes at most two; at most two batches are in flight);
-    zeroed on the device by the first launch of the call that takes it."""
-    pool = module.__dict__.setdefault("_flag_pool", [])
-    module.__dict__["_flag_turn"] = (module.__dict__.get("_flag_turn", -1) + 1) % 16
-    while len(pool) < 16:
-        pool.append(torch.zeros(1, dtype=torch.int32).pin_memory())
-    return pool[module.__dict__["_flag_turn"]]
+    """One int32 in pinned host memory, zeroed on the device by the first launch of the call that takes it.  A word goes back to the module's
+    free list only when its verdict has been read (_release_words): a call of many slices, or several batches in flight, never share one."""
+    free = module.__dict__.setdefault("_flag_free", [])
+    return free.pop() if free else torch.zeros(1, dtype=torch.int32).pin_memory()
 
 
-def _verdicts_clear(pending: list) -> bool:
+def _release_words(module, words) -> None:
+    free = module.__dict__.setdefault("_flag_free", [])
+    for w in words:
+        if not w.is_cuda and len(free) < 64:
+            free.append(w)
+
+
+def _verdicts_clear(pending: list, module=None) -> bool:
     """pending: int32 verdict words of fused scans (1 = a candidate count left its range), read after everything that depends on them is
     enqueued.  Words in PINNED HOST memory (the component scans write theirs there: the kernels store through the device-visible address)
     are read after a spin on an event -- no copy launch, no blocking sync (a blocking read parks the thread on an interrupt whose wake-up
@@ -1090,7 +1094,10 @@ def _verdicts_clear(pending: list) -> bool:
         ev.record()
         while not ev.query():
             pass
-    return all(int(b.item() if b.is_cuda else b.numpy()[0]) == 0 for b in pending)     # (pinned words: a plain memory read through the numpy view)
+    clear = all(int(b.item() if b.is_cuda else b.numpy()[0]) == 0 for b in pending)     # (pinned words: a plain memory read through the numpy view)
+    if module is not None:
+        _release_words(module, pending)
+    return clear
 
 
 class MoLAvgTopK(MoLTopKModule):
@@ -1307,7 +1314,8 @@ class MoLAvgTopK(MoLTopKModule):
             while not done.query():      # spin: the word is microseconds away, and a blocking wait parks the thread on an interrupt whose
                 pass                     # wake-up costs 50-100 us of GPU idle per batch (see MoLBruteForceTopK._read_stats)
             if isinstance(host, list):
-                redo = any(int(w[0]) != 0 for w in host)
+                redo = any(int(w.numpy()[0]) != 0 for w in host)
+                _release_words(self, host)
             else:
                 redo = int(host.max()) != 0
                 if len(self._verdict_pool) < 8:
@@ -1506,7 +1514,7 @@ class MoLNaiveTopK(MoLTopKModule, _ComponentCandidates):
             pending: list = []
             all_indices = self._component_topk(eq, self._k_per_group, pending)
             out = self._rerank_union(qpack, query_embeddings.size(0), all_indices, sorted, seen, pending)
-            if _verdicts_clear(pending):
+            if _verdicts_clear(pending, self):
                 break
             self._no_fused = True
         self._no_fused = False
@@ -1543,7 +1551,7 @@ class MoLCombTopK(MoLAvgTopK, _ComponentCandidates):
             comp = self._component_topk(eq, self._k_per_group, pending)
             avg_idx = self._coarse_topk_from_eq(eq, average_queries=True, pending=pending)
             out = self._rerank_union(qpack, query_embeddings.size(0), torch.cat([comp, avg_idx], dim=1), sorted, seen, pending)
-            if _verdicts_clear(pending):
+            if _verdicts_clear(pending, self):
                 break
             self._no_fused = True
         self._no_fused = False
