@@ -104,6 +104,11 @@ class ShardedTopK(TopKModule):
             return self.result(self.submit(query_embeddings, k, sorted, **kwargs))
 
     _plain_call = False
+    EXCHANGE_STREAM = False    # True: submit / result run the exchange (all-gather + merge) on a second stream, concurrently with the next batch's
+                               # scoring.  Measured through the real module in a one-rank nccl group (tools/r06_shard_rccl_probe.py, 8-way shard):
+                               # the two stream hand-overs per step cost more than the overlap gains (0.474 against 0.455 ms for the plain call); with
+                               # everything on the caller's stream, submit / result two batches ahead keeps the device queue full across the host's look
+                               # at the verdict with no hand-over at all.
 
     @contextlib.contextmanager
     def _inline(self):
@@ -195,7 +200,7 @@ class ShardedTopK(TopKModule):
             ms, mi = self._merge(all_s, all_ids, k)
             return ms.to(dtype), mi
         cur = torch.cuda.current_stream(msg.device)
-        plain = self._plain_call
+        plain = self._plain_call or not self.EXCHANGE_STREAM
         if plain:
             side = cur
         else:
@@ -347,7 +352,7 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
             kc = self._kc_local(k)
             msg, qpack32 = local.speculate_for_shard(query_embeddings, k, kc, **kwargs)
         ready = None
-        if not self._plain_call:      # (a plain call's exchange follows on this very stream)
+        if not (self._plain_call or not self.EXCHANGE_STREAM):      # (the exchange follows on this very stream)
             ready = torch.cuda.Event()
             ready.record()
         self._gp_stats["kc"] = kc
@@ -363,7 +368,7 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
         off = (B + 32 // sp.query_dot_product_groups - 1) // (32 // sp.query_dot_product_groups) * 32 * sp.dot_product_dimension
         gq = qpack32[off : off + B * sp.num_logits]
         cur = torch.cuda.current_stream(msg.device)
-        plain = self._plain_call          # a plain call: the exchange stays on the caller's stream (_inline)
+        plain = self._plain_call or not self.EXCHANGE_STREAM          # the exchange stays on the caller's stream (always for a plain call: _inline)
         if plain:
             side = cur
         else:

@@ -16,6 +16,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--world", type=int, default=8)
 ap.add_argument("--steps", type=int, default=200)
 ap.add_argument("--pipeline", action="store_true")
+ap.add_argument("--depth", type=int, default=1, help="batches submitted ahead of the one whose result is taken (--pipeline)")
+ap.add_argument("--exchange-stream", action="store_true", help="ShardedTopK.EXCHANGE_STREAM: the exchange on the module's second stream")
 ap.add_argument("--kc", type=int, default=0, help="candidates per rank (default: the R-way run's; one rank alone proves only with the single-device count, 1024)")
 ap.add_argument("--cprofile", action="store_true", help="cProfile of the timed loop (host side), top functions by own time")
 ap.add_argument("--host-times", action="store_true", help="host time per step inside submit / the all-gather call / the merge call / the wait for the verdict")
@@ -28,6 +30,7 @@ dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 S.ShardedTopK.EXCHANGE_WITH_ONE_RANK = True
+S.ShardedTopK.EXCHANGE_STREAM = a.exchange_stream
 cfg = O.CONFIGS["amzn-books"]
 N, B, k, kp, width = 695762, 32, 120, 200, 61
 mol, _ = rails_amd.create_mol_interaction_module(
@@ -56,11 +59,13 @@ with torch.inference_mode():
             for _ in range(n):
                 cand.get_top_k_outputs(q, k, {}, sh, inv, truncate_k_prime_to=kp)
             return
-        h = sh.submit(q, kp)
+        hs = [sh.submit(q, kp) for _ in range(min(a.depth, n))]
+        sub = len(hs)
         for i in range(n):
-            nxt = sh.submit(q, kp) if i + 1 < n else None
-            sh.result(h, seen=(inv, k))
-            h = nxt
+            if sub < n:
+                hs.append(sh.submit(q, kp))
+                sub += 1
+            sh.result(hs.pop(0), seen=(inv, k))
 
     acc = {}
     if a.host_times:
@@ -92,7 +97,7 @@ with torch.inference_mode():
         ps.sort_stats("tottime").print_stats(28)
         ps.sort_stats("cumulative").print_stats(30)
     st = sh.stats()
-print(f"real module, one-rank nccl group, shard of {a.world}: {hi - lo} items, kc {kc}, pipeline={a.pipeline}: {dt * 1e3:.3f} ms/step  "
+print(f"real module, one-rank nccl group, shard of {a.world}: {hi - lo} items, kc {kc}, pipeline={a.pipeline} depth={a.depth} exchange_stream={a.exchange_stream}: {dt * 1e3:.3f} ms/step  "
       f"calls {st['calls']} proved {st.get('proved_calls')} fallbacks {st['fallbacks']} global_proof {st.get('global_proof')} {sh.exchange_info()}")
 if acc:
     print("host us per step:", {k_: round(v / a.steps * 1e6, 1) for k_, v in acc.items()})
