@@ -1108,8 +1108,16 @@ class MoLAvgTopK(MoLTopKModule):
                                        # host's look at the verdict word (0.884 ms per batch either way) and the stream overlap of submit / result is lost
                                        # (0.79 -> 0.85 ms pipelined): off
 
-    def _device_redo_fits(self, nbytes: int) -> bool:
-        """May a (B, N) redo buffer of `nbytes` live on the device?  Decided once per size (the buffer is recycled across calls)."""
+    REDO_TOPK_TWO_LAUNCHES = 49152 * 24576      # n * K' up to which the predicated redo's top-K' is two launches (rails_topk's two-level plan: chunks of
+                                                # <= 49 152 scores, <= 24 576 winners' keys); beyond it the radix route's nine
+
+    def _device_redo_fits(self, nbytes: int, n_items: Optional[int] = None) -> bool:
+        """May a (B, N) redo buffer of `nbytes` live on the device?  Decided once per size (the buffer is recycled across calls).
+        n_items: the redo also has to be SHORT when it does not run -- every predicated launch of it is a 4.7 us no-op behind each call, and a
+        top-K' beyond the two-level plan is nine of them (amzn-books, K' = 4 000: 47 us of a 0.28 ms call); such calls leave the verdict to
+        the host (its look costs less than that)."""
+        if n_items is not None and n_items * self._avg_top_k > self.REDO_TOPK_TWO_LAUNCHES:
+            return False
         if nbytes <= self.DEVICE_REDO_BYTES:
             return True
         if self.DEVICE_REDO_BYTES <= 0 or self.DEVICE_REDO_FREE_FRACTION <= 0.0:     # tests: "as if it did not fit"
@@ -1208,7 +1216,7 @@ class MoLAvgTopK(MoLTopKModule):
         # Same scores and the same exact top-K' as the materialising path below -- when every query's candidate count
         # landed inside [K', capacity]; the check costs one 128-byte device-to-host copy.
         if n >= self.fused_coarse_min_items and self._avg_top_k <= 4096 and not getattr(self, "_no_fused", False):
-            on_device = self._device_redo_fits(eq.shape[0] * n * 4)
+            on_device = self._device_redo_fits(eq.shape[0] * n * 4, n)
             # a verdict the HOST reads (no device redo, the caller defers the look): the word lives in pinned host memory and the kernels write it
             # there themselves -- no 4-byte copy behind the call's last launch (round 6, as the component scans)
             word = _pinned_word(self) if (not on_device and pending is not None) else None
@@ -1271,7 +1279,7 @@ class MoLAvgTopK(MoLTopKModule):
         # a 0.85 ms call on a 125 M-item shard) then run under the table scan of the neighbouring batch.  The caller's stream joins
         # a call's stream in result().  Calls that share the module's redo buffers (small corpora) stay on the caller's stream.
         side = None
-        if self.OVERLAP_BATCHES and query_embeddings.is_cuda and not self._device_redo_fits(query_embeddings.size(0) * self.num_items * 4):
+        if self.OVERLAP_BATCHES and query_embeddings.is_cuda and not self._device_redo_fits(query_embeddings.size(0) * self.num_items * 4, self.num_items):
             if self._side_streams is None:
                 self._side_streams = [torch.cuda.Stream(query_embeddings.device), torch.cuda.Stream(query_embeddings.device)]
             side = self._side_streams[self._side_turn]
