@@ -73,6 +73,43 @@ def test_size_helpers_and_validation(lib):
         _lib.check(_lib.RAILS_ENOTSUP, "x")
 
 
+def test_round6_size_helpers_and_host_rules(lib):
+    """ABI 10's plan queries answer without a device, and the host-side rules of round 6 are what DESIGN says they are."""
+    import rails_amd
+
+    # rails_mol_coarse_topk_capacity: 4 K' on corpora of up to 4 Mi items (dense sample), min(24 576, max(4 096, 8 K')) beyond; 0 = unsupported sizes
+    cap = lambda n, kp, b=32: int(lib.rails_mol_coarse_topk_capacity(b, n, kp))
+    assert cap(695_762, 4000) == 16000 and cap(695_762, 1000) == 4096 and cap(695_762, 200) == 4096
+    assert cap(125_000_000, 1000) == 8000 and cap(125_000_000, 4000) == 24576 and cap(125_000_000, 200) == 4096
+    assert cap(695_762, 5000) == 0 and cap(100, 200) == 0 and cap(695_762, 200, 0) == 0
+    assert E.MolEngine.coarse_topk_capacity(1000) == 8000 and E.MolEngine.coarse_topk_capacity(1000, 695_762) == 4096
+    # rails_rerank_workspace_bytes: one 64-bit key per candidate
+    assert lib.rails_rerank_workspace_bytes(32, 6400) == 32 * 6400 * 8 and lib.rails_rerank_workspace_bytes(0, 6400) == 0
+    # sizes the filtered candidate selections take (the module composes the two calls elsewhere)
+    assert E.topk_candidates_filterable(6400, 181, 61, 120) and E.topk_candidates_filterable(8192, 512, 256, 512)
+    assert not E.topk_candidates_filterable(640, 181, 61, 120) and not E.topk_candidates_filterable(8193, 181, 61, 120)
+    assert not E.topk_candidates_filterable(6400, 513, 61, 120) and not E.topk_candidates_filterable(6400, 181, 257, 120) and not E.topk_candidates_filterable(6400, 100, 61, 120)
+    # argument validation before any launch
+    assert lib.rails_topk_candidates_filtered(1, 10, 1, 10, 11, 1, None, None, 0, 5, 1, 1, None) == _lib.RAILS_EINVAL          # k' > n_cand
+    assert lib.rails_rerank_topk_filtered(1, 10, 1, 10, 5, 1, None, None, 0, 6, 1, 80, 1, 1, 1, None) == _lib.RAILS_EINVAL      # k > k'
+    # the default exact mode speculates by pair count (DESIGN 7.3)
+    T = rails_amd.MoLBruteForceTopK
+    assert T.speculation_pays(1, 695_762) and T.speculation_pays(32, 86_971) and T.speculation_pays(16, 27_278)
+    assert not T.speculation_pays(8, 27_278) and not T.speculation_pays(1, 200_000) and not T.speculation_pays(32, 3_883)
+    # plain Python state of the top-k modules bypasses nn.Module.__setattr__; tensors and modules do not
+    class M(rails_amd.topk_modules.TopKModule):
+        def forward(self, *a, **k):
+            raise NotImplementedError
+    m = M()
+    m.counter = 3
+    m.lin = torch.nn.Linear(2, 2)
+    m.register_buffer("buf", torch.zeros(2))
+    m.buf = torch.ones(2)
+    m.w = torch.nn.Parameter(torch.zeros(1))
+    assert m.__dict__["counter"] == 3 and "lin" in m._modules and "w" in m._parameters and torch.equal(m._buffers["buf"], torch.ones(2))
+    assert "lin" not in m.__dict__ and "buf" not in m.__dict__ and set(dict(m.named_parameters())) == {"lin.weight", "lin.bias", "w"}
+
+
 def test_module_mirror_state_dict_and_loud_failure_on_cpu():
     fx = Fixture("c1_ml1m")
     cfg = fx.cfg

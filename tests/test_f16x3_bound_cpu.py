@@ -227,3 +227,31 @@ def test_mixture_lipschitz_bound():
         worst = max(worst, lhs / rhs)
         assert lhs <= rhs * (1 + 1e-9)
     assert worst > 0.5      # the bound is approached: it is not vacuous
+
+
+def test_the_bound_runs_on_few_threads_and_restores_the_callers_setting():
+    """first_pass_bound / upper_bound_poly limit OpenMP to four threads while they run (a bind in one-rank-per-GPU processes launched without
+    OMP_NUM_THREADS took 10-15 s on a 256-thread host) and put the caller's thread count back -- also when the body raises."""
+    import torch
+    from rails_amd import f16x3_bound as FB
+
+    seen = []
+
+    @FB._few_cpu_threads
+    def body(fail):
+        seen.append(torch.get_num_threads())
+        if fail:
+            raise RuntimeError("x")
+        return 7
+
+    before = torch.get_num_threads()
+    try:
+        torch.set_num_threads(6)
+        assert body(False) == 7 and seen[-1] == 4 and torch.get_num_threads() == 6
+        with pytest.raises(RuntimeError):
+            body(True)
+        assert torch.get_num_threads() == 6
+        torch.set_num_threads(2)
+        assert body(False) == 7 and seen[-1] == 2 and torch.get_num_threads() == 2
+    finally:
+        torch.set_num_threads(before)
