@@ -203,6 +203,8 @@ class ShardedTopK(TopKModule):
         plain = self._plain_call or not self.EXCHANGE_STREAM
         if plain:
             side = cur
+            if not self._plain_call and ready is not None:
+                cur.wait_event(ready)      # submit() may have run on another stream than the one result() is called on
         else:
             if self._xstream is None:
                 self._xstream = torch.cuda.Stream(msg.device)
@@ -352,7 +354,7 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
             kc = self._kc_local(k)
             msg, qpack32 = local.speculate_for_shard(query_embeddings, k, kc, **kwargs)
         ready = None
-        if not (self._plain_call or not self.EXCHANGE_STREAM):      # (the exchange follows on this very stream)
+        if not self._plain_call:      # (a plain call's exchange follows on this very stream; result() of an explicit submit may be called on another)
             ready = torch.cuda.Event()
             ready.record()
         self._gp_stats["kc"] = kc
@@ -371,6 +373,8 @@ class ShardedMoLBruteForceTopK(ShardedTopK):
         plain = self._plain_call or not self.EXCHANGE_STREAM          # the exchange stays on the caller's stream (always for a plain call: _inline)
         if plain:
             side = cur
+            if not self._plain_call and ready is not None:
+                cur.wait_event(ready)      # submit() may have run on another stream than the one result() is called on
         else:
             if self._xstream is None:
                 self._xstream = torch.cuda.Stream(msg.device)
