@@ -743,7 +743,8 @@ static bool coarse_topk_plan(int B, int64_t n, int k_prime, CoarseTopkPlan* p, b
     // sample write -inf.  The threshold needs r real maxima; 4r keeps two of the top r from sharing a group too often.
     const int64_t n_work = (n_tiles + stride - 1) / stride;
     const int waves_per_wg = kScanThreads / 64;
-    int64_t grid = (n_work + 2 * waves_per_wg - 1) / (2 * waves_per_wg);
+    // (small corpora: a whole trip of four tiles per wave -- half the maxima for the threshold launch to rank: 32 768 -> ~17 000 per query at amzn-books)
+    int64_t grid = (n_work + (small_corpus ? 4 : 2) * waves_per_wg - 1) / ((small_corpus ? 4 : 2) * waves_per_wg);
     if (grid > (comp_rows > 0 ? 32 : kSampleGrid)) grid = comp_rows > 0 ? 32 : kSampleGrid;
     const int64_t trips = (n_work + 3) / 4;   // a wave's trip is up to four tiles (d = 32)
     const int64_t groups = (trips < grid * waves_per_wg ? trips : grid * waves_per_wg) * 32;
